@@ -1,0 +1,246 @@
+/*
+ * tzrec_hip.h -- C ABI of libtzrec_hip.so, the MI355X (gfx950) sharded-embedding hot path
+ * for TorchEasyRec (tzrec).
+ *
+ * This header is the drop-in boundary ("kernel-level seam").  Every entry
+ * point replaces one call the reference makes into an un-vendored native wheel (fbgemm-gpu 1.7.0 /
+ * torchrec 1.7.0, pinned in /root/reference/requirements/runtime.txt) or one pure-PyTorch module of
+ * the reference.  The reference call site that reaches each op is cited next to it
+ * (paths relative to /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every `d_*` pointer is DEVICE memory; `h_*` is host memory read during the call only.
+ *   - `stream` is a hipStream_t passed as void*; every launch is asynchronous on it.
+ *   - no allocation inside: scratch comes from the caller (`ws`, sized by the matching
+ *     `*_workspace` query, 256-byte aligned).
+ *   - return 0 (TZR_OK) or a negative TZR_ERR_* code; never throws, never syncs the device.
+ *   - thread-compatible: one caller thread per device (the reference runs one Python thread per
+ *     rank, tzrec/utils/dist_util.py:57-75).
+ *
+ * Jagged input contract = torchrec KeyedJaggedTensor as tzrec builds it
+ * (tzrec/datasets/data_parser.py:576-585): `values` int64[N] concatenated key-major then
+ * sample-major, `lengths` per (key, sample) key-major, stride = B, `offsets` = [0] + cumsum(lengths)
+ * (int64[F*B+1]), optional per-id float `weights`.
+ */
+#ifndef TZREC_HIP_H_
+#define TZREC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TZR_OK 0
+#define TZR_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, unsupported dim) */
+#define TZR_ERR_LAUNCH (-2)      /* hipLaunch / hipMemsetAsync reported an error */
+#define TZR_ERR_WORKSPACE (-3)   /* workspace too small or misaligned */
+#define TZR_ERR_UNSUPPORTED (-4) /* valid request this build has no kernel for */
+
+#define TZR_MAX_DST 8      /* destination (feature-group) buffers per pooled lookup */
+#define TZR_MAX_FEAT_DST 4 /* feature groups one feature may be copied into */
+
+#define TZR_POOL_SUM 0
+#define TZR_POOL_MEAN 1
+
+#define TZR_OPT_SGD 0
+#define TZR_OPT_ADAGRAD 1         /* elementwise state  [rows, D]  (torchrec.optim Adagrad) */
+#define TZR_OPT_ROWWISE_ADAGRAD 2 /* one scalar per row [rows]     (RowWiseAdagrad)         */
+
+#define TZR_WD_NONE 0
+#define TZR_WD_L2 1
+#define TZR_WD_DECOUPLE 2
+
+#define TZR_BOUNDS_FATAL 0   /* count out-of-range ids, leave them (caller raises)   */
+#define TZR_BOUNDS_WARNING 1 /* count and clamp to row 0 (fbgemm default [upstream]) */
+#define TZR_BOUNDS_IGNORE 2  /* clamp silently                                        */
+
+/* One embedding table shard resident in HBM.  Replaces the fbgemm TBE weight/optimizer-state
+ * buffers (tzrec/optim/optimizer.py:106-255).  `w`/`m` are device addresses of row 0; a row is
+ * `dim` floats, rows are `*_stride` floats apart (stride 2*dim with m = w + dim gives the
+ * interleaved [w|m] 128-byte row used for Adagrad at dim 16). */
+typedef struct TzrTable {
+  uint64_t w;       /* float* device address of weights row 0                                 */
+  uint64_t m;       /* float* device address of optimizer state row 0 (0 for SGD)             */
+  int64_t rows;     /* rows held by this shard                                                */
+  int32_t dim;      /* embedding dim D (multiple of 4, <= 256)                                */
+  int32_t w_stride; /* floats between consecutive weight rows                                 */
+  int32_t m_stride; /* floats between consecutive state rows (rowwise adagrad: 1)             */
+  int32_t first_order; /* smallest TzrFeature.order among the keys reading this table         */
+  int32_t n_feats;  /* number of KJT keys reading this table (their orders are consecutive)   */
+  int32_t reserved;
+} TzrTable; /* 48 bytes */
+
+/* One lookup = (KJT key -> table).  Usually one per key; a key read through two tables (DeepFM:
+ * `cat_0` feeds `cat_0_emb` for the fm/deep groups and `cat_0_emb_wide` for the wide group,
+ * tzrec/modules/embedding.py:744-745,777-786) has one TzrFeature per table.  `dst`/`col` say
+ * where its pooled [B, dim] block lands: feature groups sharing a lookup (DeepFM `fm` and `deep`,
+ * embedding.py:972-976) each get a copy, and the backward sums the groups' gradients. */
+typedef struct TzrFeature {
+  int32_t table;   /* index into the TzrTable array                                           */
+  int32_t key;     /* KJT key index: bag (key, b) is offsets[key*B + b] .. offsets[key*B+b+1]   */
+  int32_t pooling; /* TZR_POOL_SUM / TZR_POOL_MEAN (tzrec/features/feature.py:586-591)         */
+  int32_t n_dst;   /* 1..TZR_MAX_FEAT_DST                                                      */
+  int32_t dst[TZR_MAX_FEAT_DST]; /* destination buffer index                                   */
+  int32_t col[TZR_MAX_FEAT_DST]; /* first float column inside that buffer (multiple of 4)      */
+  int32_t order;   /* rank of this lookup when lookups are sorted by (table, index): the
+                      table-major order the backward plan groups ids in.  A table is read at
+                      most once per key.                                                       */
+  int32_t reserved[3];
+} TzrFeature; /* 64 bytes */
+
+/* One float4 of one destination row: the forward kernel walks slots so that consecutive lanes
+ * write consecutive float4s of a destination row (fuses fbgemm permute_pooled_embs /
+ * KeyedTensor.regroup_as_dict, tzrec/modules/embedding.py:972-976). */
+typedef struct TzrSlot {
+  int32_t feature; /* KJT key index                                                            */
+  int32_t chunk;   /* float4 index inside the embedding row                                    */
+  int32_t dst;     /* destination buffer index                                                 */
+  int32_t col;     /* float column in the destination buffer                                   */
+} TzrSlot; /* 16 bytes */
+
+/* Destination / gradient buffer of one feature group: float [B, stride]. */
+typedef struct TzrDst {
+  uint64_t ptr;   /* float* device address                                                     */
+  int64_t stride; /* floats between consecutive samples (multiple of 4)                        */
+} TzrDst;
+
+/* Fused sparse optimizer applied inside the backward (tzrec/main.py:774-781,
+ * tzrec/optim/optimizer_builder.py:30-97, protos/optimizer.proto:76-139). */
+typedef struct TzrSparseOptim {
+  int32_t kind;              /* TZR_OPT_*                                                       */
+  int32_t weight_decay_mode; /* TZR_WD_* (rowwise adagrad only)                                 */
+  uint64_t d_lr;             /* const float* DEVICE scalar: schedulers mutate it per step
+                                (tzrec/main.py:877-879); graph-replay safe                      */
+  float eps;                 /* fbgemm default 1e-8 [upstream]; not configurable from tzrec     */
+  float weight_decay;
+  float max_gradient;        /* used when gradient_clipping != 0                                */
+  int32_t gradient_clipping;
+} TzrSparseOptim;
+
+/* ---- library identity ------------------------------------------------------------------- */
+const char* tzr_backend(void); /* "hip-gfx950" (the CPU lane emulator used by tests says "emu") */
+int tzr_abi_version(void);
+
+/* ---- index stage (integer, bit-exact) ---------------------------------------------------- */
+
+/* K3: lengths -> offsets (exclusive scan, offsets[n] = total).  Replaces fbgemm
+ * asynchronous_complete_cumsum reached from KeyedJaggedTensor.offsets()
+ * (tzrec/modules/embedding.py:930).  lengths_itemsize is 4 (int32) or 8 (int64). */
+size_t tzr_lengths_to_offsets_workspace(int64_t n);
+int tzr_lengths_to_offsets(const void* d_lengths, int lengths_itemsize, int64_t n,
+                           int64_t* d_offsets, void* ws, size_t ws_bytes, void* stream);
+
+/* K4: bounds check of every id against its table's row count.  Replaces fbgemm
+ * bounds_check_indices (mode from ParameterConstraints.bounds_check_mode,
+ * tzrec/utils/plan_util.py:580,594).  d_oob_count (int64[1]) is incremented per bad id;
+ * WARNING/IGNORE clamp the id to 0 in place. */
+int tzr_bounds_check(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                     int64_t* d_values, const int64_t* d_offsets, int64_t B, int mode,
+                     int64_t* d_oob_count, void* stream);
+
+/* K1: KJT permute.  Replaces fbgemm permute_2D_sparse_data reached from the sharded
+ * input_dist (tzrec/modules/embedding.py:930 -> torchrec KJT.permute [upstream]).
+ * out key t takes input key permute[t] (T output keys, F input keys, repeats allowed).
+ * d_in_offsets is int64[F*B+1]; d_out_offsets (int64[T*B+1]) and d_out_lengths are written;
+ * d_out_values / d_out_weights must hold the permuted total (<= caller's bound n_out_max). */
+size_t tzr_kjt_permute_workspace(int64_t T, int64_t B);
+int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B,
+                    const void* d_in_lengths, int lengths_itemsize, const int64_t* d_in_offsets,
+                    const int64_t* d_in_values, const float* d_in_weights,
+                    void* d_out_lengths, int64_t* d_out_offsets, int64_t* d_out_values,
+                    float* d_out_weights, int64_t n_out_max, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* K2: row-wise bucketize.  Replaces fbgemm block_bucketize_sparse_features (row-wise sharded
+ * tables; RW geometry = contiguous ceil(rows/W) blocks, tzrec/utils/plan_util.py:
+ * 1049-1060 -> torchrec calculate_shard_sizes_and_offsets [upstream]).  For id x of key f:
+ * dst = x / block_size[f] (clamped to W-1), local = x - dst*block_size[f].  Output is
+ * rank-major: new_lengths[(r*F + f)*B + b]; ids keep their relative order inside each
+ * (r, f, b) bag.  d_unbucketize_permute[i] = output position of input id i (nullable). */
+size_t tzr_block_bucketize_workspace(int64_t F, int64_t B, int W);
+int tzr_block_bucketize(const int64_t* d_block_sizes, int F, int64_t B, int W,
+                        const int64_t* d_offsets, const int64_t* d_values, const float* d_weights,
+                        int64_t n_values, void* d_new_lengths, int lengths_itemsize,
+                        int64_t* d_new_offsets, int64_t* d_new_values, float* d_new_weights,
+                        int64_t* d_unbucketize_permute, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pooled embedding lookup ------------------------------------------------------------- */
+
+/* K5 (+K8 fused): pooled gather forward.  Replaces torchrec EmbeddingBagCollection.forward ->
+ * fbgemm split_embedding_codegen_forward_{un,}weighted (self.ebc(kjt),
+ * tzrec/modules/embedding.py:930) and the regroup copy (:972-976):
+ *   dst[g][b, col_f : col_f+D_f] = sum_{i in bag(f,b)} weight_i * W_t[id_i, :]   (mean: / len)
+ * Empty bag -> zeros.  h_dsts: host array of n_dst destination buffers.  d_slots enumerates every
+ * float4 of every destination row exactly once, in destination-then-column order. */
+int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                   const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
+                   const int64_t* d_offsets, const float* d_weights, int64_t B,
+                   const TzrDst* h_dsts, int n_dst, int uniform_bag_len, void* stream);
+
+/* K6: backward index plan = group the N lookups by (table, row), duplicates adjacent, original
+ * order kept inside a row (stable segmented radix sort).  Replaces fbgemm
+ * transpose_embedding_input (linearize + cub radix sort + run-length) reached from the autograd
+ * of self.ebc(kjt).  Depends only on the ids, so it can run ahead of the forward on another
+ * stream.  The plan lives in `ws` and is consumed by tzr_pooled_bwd_apply. */
+size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions, int n_feats, int n_tables,
+                                int64_t B,
+                                int max_dim);
+int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature* d_feats,
+                        int n_feats, int n_keys, int64_t max_rows, int max_dim, const int64_t* d_values,
+                        const int64_t* d_offsets, int64_t n_values, int64_t n_positions,
+                        int64_t B,
+                        int uniform_bag_len, void* ws, size_t ws_bytes, void* stream);
+
+/* K7: fused backward + sparse optimizer.  Replaces fbgemm
+ * split_embedding_backward_codegen_{sgd,adagrad,rowwise_adagrad}_*_exact (optimizer fused into
+ * backward by apply_optimizer_in_backward, tzrec/main.py:774-781): per distinct (table,row)
+ * g = sum over its duplicate lookups (in original lookup order) of weight_i * dL/d(pooled bag),
+ * summed over the feature groups the feature was copied into; then ONE update of the row:
+ *   adagrad          m += g*g;            w -= lr * g / (sqrt(m) + eps)
+ *   rowwise adagrad  m += mean_d(g*g);    w -= lr * g / (sqrt(m) + eps)
+ *   sgd              w -= lr * g
+ * h_grads mirrors the forward's h_dsts (same buffer indices / strides). */
+int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                         int n_tables, int max_dim, const int64_t* d_offsets,
+                         const float* d_weights, int64_t n_values, int64_t n_positions, int64_t B,
+                         int uniform_bag_len, const TzrDst* h_grads, int n_dst,
+                         const TzrSparseOptim* h_optim, void* ws, size_t ws_bytes, void* stream);
+
+/* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
+int tzr_tune(const char* name, int value);
+
+/* ---- feature interaction ----------------------------------------------------------------- */
+
+/* K9: DLRM dot interaction.  Replaces tzrec InteractionArch.forward
+ * (tzrec/modules/interaction.py:80-91: bmm(X, X^T) then strict-upper-triangle gather, row-major
+ * (i<j) order) fused with the concatenations of DLRM.predict (tzrec/models/dlrm.py:123-130).
+ * X[b] = [dense[b] (optional, row 0); sparse[b, 0:F*D] as F rows of D].  n = F + (dense!=0).
+ * out[b, 0 : n(n-1)/2] = X X^T upper triangle (exact fp32, MFMA 16x16x4 f32);
+ * if cat_dense: out[b, P : P+D] = dense[b]; if cat_sparse: the F*D sparse floats follow.
+ * D must be 16 and n <= 32 in this build. */
+int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                            int64_t sparse_stride, int F, int D, int64_t B, float* d_out,
+                            int64_t out_stride, int cat_dense, int cat_sparse, void* stream);
+/* backward: dX = (G + G^T) X with G the upper-triangular gradient; concatenated pass-through
+ * gradients are added.  d_grad_dense may be null when d_dense is null. */
+int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                            int64_t sparse_stride, int F, int D, int64_t B,
+                            const float* d_grad_out, int64_t grad_out_stride, int cat_dense,
+                            int cat_sparse, float* d_grad_dense, int64_t grad_dense_stride,
+                            float* d_grad_sparse, int64_t grad_sparse_stride, void* stream);
+
+/* K10: FM second order.  Replaces tzrec FactorizationMachine.forward
+ * (tzrec/modules/fm.py:27-42): out[b,:] = 0.5*((sum_f x_f)^2 - sum_f x_f^2), x:[B,F,D]. */
+int tzr_fm_fwd(const float* d_x, int64_t x_stride, int F, int D, int64_t B, float* d_out,
+               int64_t out_stride, void* stream);
+int tzr_fm_bwd(const float* d_x, int64_t x_stride, int F, int D, int64_t B,
+               const float* d_grad_out, int64_t grad_out_stride, float* d_grad_x,
+               int64_t grad_x_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TZREC_HIP_H_ */

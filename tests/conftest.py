@@ -1,0 +1,46 @@
+"""pytest wiring.
+
+* ``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI symbol checks, and the kernel
+  *logic* run through the CPU lane emulator build of the unchanged .hip sources (tests/emu).
+* ``-m gpu``: the parity tests proper -- same test bodies, real gfx950 library, HIP tensors.
+
+The ``dev`` fixture selects the library: param "emu" -> tests/emu/_build/libtzrec_emu.so + cpu
+tensors; param "hip" (marked gpu) -> torcheasyrec_amd/libtzrec_hip.so + cuda tensors.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session")
+def emu_path():
+    from emu.build_emu import build
+
+    return build()
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    from torcheasyrec_amd import _lib
+
+    if request.param == "emu":
+        _lib.use_library(request.getfixturevalue("emu_path"))
+        assert _lib.backend() == "emu"
+        return torch.device("cpu")
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test selected but no HIP device is visible")
+    _lib.use_library(_lib.LIB_PATH)
+    assert _lib.backend().startswith("hip"), "GPU tests must run on the native gfx950 library"
+    return torch.device("cuda", 0)

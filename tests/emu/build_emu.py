@@ -1,0 +1,58 @@
+"""Build tests/emu/_build/libtzrec_emu.so: the UNCHANGED torcheasyrec_amd/csrc/*.hip kernels compiled
+for the host CPU against the lane emulator (tests/emu/hip/hip_runtime.h).  Test infrastructure
+only -- lets the kernel logic be checked against the oracle in a container with no GPU."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "torcheasyrec_amd", "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+OUT = os.path.join(OUT_DIR, "libtzrec_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _sources():
+    srcs = sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f != "abi.hip"
+    )
+    return srcs + [os.path.join(HERE, "abi_emu.cpp")]
+
+
+def _digest():
+    h = hashlib.sha256()
+    deps = _sources() + [
+        os.path.join(CSRC, "tzr_common.h"),
+        os.path.join(ROOT, "include", "tzrec_hip.h"),
+        os.path.join(HERE, "hip", "hip_runtime.h"),
+    ]
+    for p in deps:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    stamp = os.path.join(OUT_DIR, "stamp")
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    cc = CLANG if os.path.exists(CLANG) else "clang++"
+    objs = []
+    for src in _sources():
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+        cmd = [cc, "-x", "c++", "-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unused-value",
+               "-I", HERE, "-I", CSRC, "-c", src, "-o", obj]
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([cc, "-shared", "-pthread", "-o", OUT] + objs)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

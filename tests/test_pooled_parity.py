@@ -1,0 +1,284 @@
+"""Parity of the pooled lookup forward (K5+K8) and fused backward (K6+K7) against the oracle.
+
+Tolerances (north_star): index stage bit-exact; fp32 pooled embeddings within 1e-5 relative.
+L=1 sum pooling is a copy and must be bit-exact.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
+
+RTOL = 1e-5
+
+
+def _make_tables(spec, seed=0):
+    """spec: list of (name, rows, dim, pooling, [features])"""
+    cfgs, inits = [], {}
+    g = torch.Generator().manual_seed(seed)
+    for name, rows, dim, pooling, feats in spec:
+        w = (torch.rand(rows, dim, generator=g) - 0.5) * 0.2
+        inits[name] = w
+        cfgs.append(EmbeddingBagConfig(name, dim, rows, list(feats), pooling,
+                                       init_fn=lambda t, w=w: t.copy_(w)))
+    return cfgs, inits
+
+
+def _make_kjt(keys, rows_per_key, B, rng, mode="uniform1", weighted=False):
+    vals, lens = [], []
+    for k, rows in zip(keys, rows_per_key):
+        if mode == "uniform1":
+            L = np.ones(B, dtype=np.int32)
+        elif mode == "jagged":
+            L = rng.poisson(2.0, size=B).astype(np.int32)
+            L[rng.integers(0, B, size=max(B // 8, 1))] = 0
+        elif mode == "long":
+            L = rng.integers(0, 70, size=B).astype(np.int32)
+        else:
+            raise ValueError(mode)
+        lens.append(L)
+        vals.append(rng.integers(0, rows, size=int(L.sum())).astype(np.int64))
+    values = torch.from_numpy(np.concatenate(vals))
+    lengths = torch.from_numpy(np.concatenate(lens))
+    weights = None
+    if weighted:
+        weights = torch.from_numpy(rng.uniform(0.5, 1.5, size=values.numel()).astype(np.float32))
+    return KeyedJaggedTensor(keys, values, lengths, weights)
+
+
+def _oracle_blocks(ebc_spec, inits, kjt_cpu, lookups, req_grad=False):
+    B = kjt_cpu.stride()
+    keys = kjt_cpu.keys()
+    tabs = {n: inits[n].clone().requires_grad_(req_grad) for n in inits}
+    name_of = {}
+    pool_of = {}
+    for name, rows, dim, pooling, feats in ebc_spec:
+        for f in feats:
+            name_of.setdefault(f, []).append(name)
+            pool_of[name] = pooling
+    blocks = {}
+    # one block per (table, feature) in table-then-feature order
+    v, l, w = _reorder_kjt(kjt_cpu, [f for (f, t) in lookups])
+    all_blocks = orc.pooled_lookup(
+        [tabs[t] for (f, t) in lookups], [pool_of[t] for (f, t) in lookups], v, l, B, w
+    )
+    for (f, t), blk in zip(lookups, all_blocks):
+        key = f if len(name_of[f]) == 1 else f"{f}@{t}"
+        blocks[key] = blk
+    return blocks, tabs
+
+
+def _reorder_kjt(kjt, feat_list):
+    """values/lengths(/weights) of the listed keys concatenated key-major (CPU)."""
+    B = kjt.stride()
+    off = orc.lengths_to_offsets(kjt.lengths().numpy())
+    keys = kjt.keys()
+    vs, ls, ws = [], [], []
+    for f in feat_list:
+        i = keys.index(f)
+        s, e = off[i * B], off[(i + 1) * B]
+        vs.append(kjt.values()[s:e])
+        ls.append(kjt.lengths()[i * B:(i + 1) * B])
+        if kjt.weights_or_none() is not None:
+            ws.append(kjt.weights_or_none()[s:e])
+    return torch.cat(vs), torch.cat(ls), (torch.cat(ws) if ws else None)
+
+
+def _lookup_list(spec):
+    return [(f, name) for name, rows, dim, pooling, feats in spec for f in feats]
+
+
+SPEC_CRITEO_SMALL = [
+    ("t_big", 5000, 16, "sum", ["c0"]),
+    ("t_mid", 300, 16, "sum", ["c1"]),
+    ("t_tiny", 3, 16, "sum", ["c2"]),
+    ("t_four", 4, 16, "sum", ["c3"]),
+]
+
+
+@pytest.mark.parametrize("B", [1, 7, 64, 300])
+def test_forward_uniform1_bitexact(dev, B):
+    rng = np.random.default_rng(B)
+    cfgs, inits = _make_tables(SPEC_CRITEO_SMALL)
+    ebc = EmbeddingBagCollection(cfgs, device=dev)
+    keys = ["c0", "c1", "c2", "c3"]
+    kjt = _make_kjt(keys, [5000, 300, 3, 4], B, rng)
+    assert kjt.uniform_length() == 1
+    out = ebc(kjt.to(dev))
+    blocks, _ = _oracle_blocks(SPEC_CRITEO_SMALL, inits, kjt, _lookup_list(SPEC_CRITEO_SMALL))
+    ref = torch.cat([blocks[k] for k in out.keys()], dim=1)
+    assert out.values().shape == (B, 64)
+    assert torch.equal(out.values().cpu(), ref)  # a copy: bit-exact
+
+
+SPEC_MIXED = [
+    ("u_emb", 1000, 16, "sum", ["user", "user_hist"]),  # shared table, two keys
+    ("i_emb", 57, 8, "mean", ["item"]),
+    ("w_emb", 1000, 4, "sum", ["wide_user"]),
+    ("big_d", 40, 32, "sum", ["ctx"]),
+]
+
+
+@pytest.mark.parametrize("mode,weighted", [("jagged", False), ("jagged", True), ("long", False)])
+def test_forward_jagged(dev, mode, weighted):
+    rng = np.random.default_rng(11)
+    B = 37
+    cfgs, inits = _make_tables(SPEC_MIXED)
+    ebc = EmbeddingBagCollection(cfgs, device=dev)
+    keys = ["ctx", "item", "unused_key", "user", "user_hist", "wide_user"]
+    rows = [40, 57, 10, 1000, 1000, 1000]
+    kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted)
+    out = ebc(kjt.to(dev))
+    blocks, _ = _oracle_blocks(SPEC_MIXED, inits, kjt, _lookup_list(SPEC_MIXED))
+    assert out.keys() == ["user", "user_hist", "item", "wide_user", "ctx"]
+    ref = torch.cat([blocks[k] for k in out.keys()], dim=1)
+    torch.testing.assert_close(out.values().cpu(), ref, rtol=RTOL, atol=1e-6)
+
+
+def test_forward_grouped_deepfm_layout(dev):
+    """DeepFM: key read through two tables (wide dim 4 + deep dim 16), deep block copied into the
+    `fm` and `deep` groups (/root/reference/tzrec/modules/embedding.py:744-786,972-976)."""
+    rng = np.random.default_rng(5)
+    B = 50
+    spec = [
+        ("a_emb", 100, 16, "sum", ["a"]),
+        ("b_emb", 7, 16, "sum", ["b"]),
+        ("a_emb_wide", 100, 4, "sum", ["a"]),
+        ("b_emb_wide", 7, 4, "sum", ["b"]),
+    ]
+    cfgs, inits = _make_tables(spec)
+    groups = {
+        "wide": ["a@a_emb_wide", "b@b_emb_wide"],
+        "fm": ["a@a_emb", "b@b_emb"],
+        "deep": ["b@b_emb", "a@a_emb"],
+    }
+    ebc = EmbeddingBagCollection(cfgs, device=dev, groups=groups)
+    kjt = _make_kjt(["a", "b"], [100, 7], B, rng)
+    out = ebc.forward_grouped(kjt.to(dev))
+    blocks, _ = _oracle_blocks(spec, inits, kjt, _lookup_list(spec))
+    ref = orc.regroup(blocks, groups)
+    for g in groups:
+        assert torch.equal(out[g].cpu(), ref[g]), g
+
+
+def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups=None, steps=2, seed=3,
+                       rtol=2e-5):
+    rng = np.random.default_rng(seed)
+    cfgs, inits = _make_tables(spec)
+    ebc = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt_cfg, groups=groups)
+    lookups = _lookup_list(spec)
+    # oracle state
+    w_ref = {n: inits[n].numpy().copy() for n in inits}
+    if opt_cfg.kind == "adagrad":
+        m_ref = {n: np.full_like(w_ref[n], opt_cfg.initial_accumulator_value) for n in w_ref}
+    elif opt_cfg.kind == "rowwise_adagrad":
+        m_ref = {n: np.zeros(w_ref[n].shape[0], np.float32) for n in w_ref}
+    else:
+        m_ref = {n: None for n in w_ref}
+    oopt = orc.SparseOptim(kind=opt_cfg.kind, lr=opt_cfg.lr, eps=opt_cfg.eps,
+                           weight_decay=opt_cfg.weight_decay, weight_decay_mode=opt_cfg.weight_decay_mode,
+                           gradient_clipping=opt_cfg.gradient_clipping, max_gradient=opt_cfg.max_gradient)
+    pool_of = {name: pooling for name, _, _, pooling, _ in spec}
+    for step in range(steps):
+        kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted)
+        kd = kjt.to(dev)
+        if groups is None:
+            out = ebc(kd).values()
+            outs = {"__all__": out}
+            layout = {"__all__": [f if sum(1 for (ff, _) in lookups if ff == f) == 1 else f"{f}@{t}" for f, t in lookups]}
+        else:
+            outs = ebc.forward_grouped(kd)
+            layout = groups
+        gens = {g: torch.from_numpy(rng.standard_normal(tuple(outs[g].shape)).astype(np.float32)) for g in outs}
+        loss = sum((outs[g] * gens[g].to(dev)).sum() for g in outs)
+        loss.backward()
+        # oracle: per lookup block gradient = sum over groups containing it
+        name_count = {}
+        for f, t in lookups:
+            name_count[f] = name_count.get(f, 0) + 1
+        off = orc.lengths_to_offsets(kjt.lengths().numpy())
+        for f, t in lookups:
+            ok = f if name_count[f] == 1 else f"{f}@{t}"
+            D = w_ref[t].shape[1]
+            gblk = np.zeros((B, D), np.float32)
+            for g, oks in layout.items():
+                col = 0
+                for k2 in oks:
+                    d2 = [w_ref[tt].shape[1] for (ff, tt) in lookups if (ff if name_count[ff] == 1 else f"{ff}@{tt}") == k2][0]
+                    if k2 == ok:
+                        gblk = gblk + gens[g].numpy()[:, col:col + D]
+                    col += d2
+            ki = keys.index(f)
+            s, e = off[ki * B], off[(ki + 1) * B]
+            L = kjt.lengths().numpy()[ki * B:(ki + 1) * B]
+            psw = kjt.weights_or_none().numpy()[s:e] if weighted else None
+            lg = orc.lookup_grads([gblk], L, B, [pool_of[t]], psw)
+            # features sharing a table must be applied together: collect
+            w_ref.setdefault("__pending__", {}).setdefault(t, []).append((kjt.values().numpy()[s:e], lg))
+        pend = w_ref.pop("__pending__")
+        for t, items in pend.items():
+            ids = np.concatenate([i for i, _ in items])
+            gr = np.concatenate([g for _, g in items], axis=0)
+            orc.sparse_update(w_ref[t], m_ref[t], ids, gr, oopt)
+    for n in inits:
+        got = ebc.table_weights()[n].detach().cpu().numpy()
+        np.testing.assert_allclose(got, w_ref[n], rtol=rtol, atol=1e-7, err_msg=f"weights of {n}")
+        if m_ref[n] is not None:
+            gotm = ebc.table_states()[n].detach().cpu().numpy()
+            np.testing.assert_allclose(gotm, m_ref[n], rtol=rtol, atol=1e-7, err_msg=f"state of {n}")
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "rowwise_adagrad", "sgd"])
+def test_backward_uniform1(dev, kind):
+    opt = SparseOptimizerConfig(kind=kind, lr=0.05)
+    _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 200,
+                       "uniform1", False, opt)
+
+
+def test_backward_long_runs(dev):
+    """3- and 4-row tables with thousands of lookups: the long-run piece path.
+
+    ~1,700 random-sign gradients are summed per row; the kernel reduces them with a fixed tree, the
+    oracle sequentially, so the comparison carries fp32 order-of-summation noise (cancellation
+    amplifies it on g, and m = g*g doubles it): tolerance 5e-4 here, 2e-5 everywhere else.
+    """
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.05)
+    _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 5000,
+                       "uniform1", False, opt, steps=1, rtol=5e-4)
+
+
+@pytest.mark.parametrize("kind,weighted", [("adagrad", False), ("rowwise_adagrad", True)])
+def test_backward_jagged_shared_table(dev, kind, weighted):
+    opt = SparseOptimizerConfig(kind=kind, lr=0.02, gradient_clipping=True, max_gradient=0.7)
+    keys = ["ctx", "item", "unused_key", "user", "user_hist", "wide_user"]
+    rows = [40, 57, 10, 1000, 1000, 1000]
+    _run_backward_case(dev, SPEC_MIXED, keys, rows, 45, "jagged", weighted, opt)
+
+
+def test_backward_grouped_sums_group_grads(dev):
+    spec = [
+        ("a_emb", 100, 16, "sum", ["a"]),
+        ("b_emb", 7, 16, "sum", ["b"]),
+        ("a_emb_wide", 100, 4, "sum", ["a"]),
+        ("b_emb_wide", 7, 4, "sum", ["b"]),
+    ]
+    groups = {
+        "wide": ["a@a_emb_wide", "b@b_emb_wide"],
+        "fm": ["a@a_emb", "b@b_emb"],
+        "deep": ["b@b_emb", "a@a_emb"],
+    }
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.01)
+    _run_backward_case(dev, spec, ["a", "b"], [100, 7], 64, "uniform1", False, opt, groups=groups)
+
+
+def test_rowwise_weight_decay_modes(dev):
+    for mode in ("l2", "decouple"):
+        opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.03, weight_decay=0.01, weight_decay_mode=mode)
+        _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 100,
+                           "uniform1", False, opt, steps=2)

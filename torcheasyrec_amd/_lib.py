@@ -1,0 +1,172 @@
+"""ctypes binding of the C-ABI library ``libtzrec_hip.so`` (``include/tzrec_hip.h``).
+
+The product path has exactly one compute backend: the hipcc-built gfx950 library that sits next to
+this file.  If it is missing, ``lib()`` raises -- there is no CPU fallback.  (Tests may point the
+loader at the CPU lane-emulator build of the same kernels with ``use_library``; that build reports
+``tzr_backend() == "emu"`` and accepts CPU tensors only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtzrec_hip.so")
+
+TZR_OK = 0
+TZR_MAX_DST = 8
+TZR_MAX_FEAT_DST = 4
+POOL_SUM, POOL_MEAN = 0, 1
+OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
+WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
+BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
+
+_ERR = {-1: "TZR_ERR_INVALID", -2: "TZR_ERR_LAUNCH", -3: "TZR_ERR_WORKSPACE", -4: "TZR_ERR_UNSUPPORTED"}
+
+# numpy mirrors of the header structs (host-side construction, then uploaded as bytes)
+TABLE_DT = np.dtype(
+    [("w", "<u8"), ("m", "<u8"), ("rows", "<i8"), ("dim", "<i4"), ("w_stride", "<i4"),
+     ("m_stride", "<i4"), ("first_order", "<i4"), ("n_feats", "<i4"), ("reserved", "<i4")]
+)
+FEATURE_DT = np.dtype(
+    [("table", "<i4"), ("key", "<i4"), ("pooling", "<i4"), ("n_dst", "<i4"),
+     ("dst", "<i4", (TZR_MAX_FEAT_DST,)), ("col", "<i4", (TZR_MAX_FEAT_DST,)), ("order", "<i4"),
+     ("reserved", "<i4", (3,))]
+)
+SLOT_DT = np.dtype([("feature", "<i4"), ("chunk", "<i4"), ("dst", "<i4"), ("col", "<i4")])
+assert TABLE_DT.itemsize == 48 and FEATURE_DT.itemsize == 64 and SLOT_DT.itemsize == 16
+
+
+class TzrDst(C.Structure):
+    _fields_ = [("ptr", C.c_uint64), ("stride", C.c_int64)]
+
+
+class TzrSparseOptim(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("weight_decay_mode", C.c_int32),
+        ("d_lr", C.c_uint64),
+        ("eps", C.c_float),
+        ("weight_decay", C.c_float),
+        ("max_gradient", C.c_float),
+        ("gradient_clipping", C.c_int32),
+    ]
+
+
+class TzrError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+_backend: Optional[str] = None
+
+_vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+
+_SIGNATURES = {
+    "tzr_backend": (C.c_char_p, []),
+    "tzr_abi_version": (_i32, []),
+    "tzr_tune": (_i32, [C.c_char_p, _i32]),
+    "tzr_lengths_to_offsets_workspace": (_sz, [_i64]),
+    "tzr_lengths_to_offsets": (_i32, [_vp, _i32, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_bounds_check": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "tzr_kjt_permute_workspace": (_sz, [_i64, _i64]),
+    "tzr_kjt_permute": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i64, _vp, _sz, _vp]),
+    "tzr_block_bucketize_workspace": (_sz, [_i64, _i64, _i32]),
+    "tzr_block_bucketize": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp,
+                                   _vp, _vp, _vp, _sz, _vp]),
+    "tzr_pooled_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
+                              _i32, _i32, _vp]),
+    "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
+    "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
+                                   _i32, _vp, _sz, _vp]),
+    "tzr_pooled_bwd_apply": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32,
+                                    C.POINTER(TzrDst), _i32, C.POINTER(TzrSparseOptim), _vp, _sz,
+                                    _vp]),
+    "tzr_dot_interaction_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,
+                                       _i32, _vp]),
+    "tzr_dot_interaction_bwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,
+                                       _i32, _vp, _i64, _vp, _i64, _vp]),
+    "tzr_fm_fwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
+    "tzr_fm_bwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _bind(path: str) -> C.CDLL:
+    handle = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError -> a symbol the header declares is missing
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def use_library(path: str) -> None:
+    """Load an explicit library file (tests: the lane-emulator build)."""
+    global _lib, _backend
+    _lib = _bind(path)
+    _backend = _lib.tzr_backend().decode()
+
+
+def lib() -> C.CDLL:
+    global _lib, _backend
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TzrError(
+                f"{LIB_PATH} is missing: build the gfx950 kernels first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback."
+            )
+        use_library(LIB_PATH)
+    return _lib
+
+
+def backend() -> str:
+    lib()
+    return _backend  # type: ignore[return-value]
+
+
+def check(rc: int, what: str) -> None:
+    if rc != TZR_OK:
+        raise TzrError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def check_device(t: torch.Tensor) -> None:
+    """The HIP library takes device pointers only; the emulator host pointers only."""
+    if backend() == "emu":
+        if t.device.type != "cpu":
+            raise TzrError("emulator library loaded but tensor is on " + str(t.device))
+    elif t.device.type != "cuda":
+        raise TzrError(
+            f"tensor on {t.device}: the gfx950 library needs HIP device memory (no CPU path)"
+        )
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    check_device(t)
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> Optional[int]:
+    if device.type != "cuda":
+        return None
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def upload_struct(arr: np.ndarray, device: torch.device) -> torch.Tensor:
+    """Structured numpy array -> uint8 device tensor holding the same bytes."""
+    raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device)
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """256-byte aligned scratch from the torch caching allocator."""
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:]

@@ -1,0 +1,5 @@
+// Library identity of libtzrec_hip.so (include/tzrec_hip.h).
+#include "tzr_common.h"
+
+extern "C" const char* tzr_backend(void) { return "hip-gfx950"; }
+extern "C" int tzr_abi_version(void) { return 1; }

@@ -1,0 +1,326 @@
+// K1-K4: integer index stage of the sharded embedding path (bit-exact vs the oracle).
+//
+//   K3 tzr_lengths_to_offsets  <- fbgemm asynchronous_complete_cumsum (KJT.offsets())
+//   K4 tzr_bounds_check        <- fbgemm bounds_check_indices
+//   K1 tzr_kjt_permute         <- fbgemm permute_2D_sparse_data (sharded input_dist)
+//   K2 tzr_block_bucketize     <- fbgemm block_bucketize_sparse_features (row-wise tables)
+// all reached from self.ebc(kjt), /root/reference/tzrec/modules/embedding.py:930, through
+// torchrec's sharded EmbeddingBagCollection [upstream 1.7.0].  Pure HBM-streaming integer work:
+// coalesced 8-byte loads, LDS only for the workgroup scans.
+#include "tzr_common.h"
+
+#define IDX_THREADS 256
+#define IDX_ITEMS 8
+#define IDX_TILE (IDX_THREADS * IDX_ITEMS)
+
+__device__ __forceinline__ int64_t idx_load_len(const void* p, int itemsize, int64_t i) {
+  return itemsize == 4 ? (int64_t) reinterpret_cast<const int32_t*>(p)[i]
+                       : reinterpret_cast<const int64_t*>(p)[i];
+}
+__device__ __forceinline__ void idx_store_len(void* p, int itemsize, int64_t i, int64_t v) {
+  if (itemsize == 4) reinterpret_cast<int32_t*>(p)[i] = (int32_t)v;
+  else reinterpret_cast<int64_t*>(p)[i] = v;
+}
+
+// Inclusive scan of one value per thread across the workgroup (wave shuffles + LDS).
+__device__ __forceinline__ int64_t idx_block_inclusive(int64_t v, int64_t* wave_tot /*[4] LDS*/) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  for (int d = 1; d < TZR_WAVE; d <<= 1) {
+    const int64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  if (lane == TZR_WAVE - 1) wave_tot[wv] = v;
+  __syncthreads();
+  int64_t pre = 0;
+  for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+  __syncthreads();
+  return v + pre;
+}
+
+// pass 1: per-tile sums
+__global__ __launch_bounds__(IDX_THREADS) void tzr_scan_tile_sums_kernel(
+    const void* __restrict__ in, int itemsize, int64_t n, int64_t* __restrict__ tile_sums) {
+  __shared__ int64_t wt[IDX_THREADS / TZR_WAVE];
+  const int64_t base = (int64_t)blockIdx.x * IDX_TILE;
+  int64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < IDX_ITEMS; ++j) {
+    const int64_t i = base + (int64_t)j * IDX_THREADS + threadIdx.x;
+    if (i < n) s += idx_load_len(in, itemsize, i);
+  }
+  const int64_t inc = idx_block_inclusive(s, wt);
+  if (threadIdx.x == IDX_THREADS - 1) tile_sums[blockIdx.x] = inc;
+}
+
+// pass 2: one workgroup turns tile sums into exclusive tile prefixes (loop with carry)
+__global__ __launch_bounds__(IDX_THREADS) void tzr_scan_tile_prefix_kernel(
+    int64_t* __restrict__ tile_sums, int64_t n_tiles, int64_t* __restrict__ total_out) {
+  __shared__ int64_t wt[IDX_THREADS / TZR_WAVE];
+  __shared__ int64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t b = 0; b < n_tiles; b += IDX_THREADS) {
+    const int64_t i = b + threadIdx.x;
+    const int64_t v = i < n_tiles ? tile_sums[i] : 0;
+    const int64_t inc = idx_block_inclusive(v, wt);
+    const int64_t carry = carry_s;
+    if (i < n_tiles) tile_sums[i] = carry + inc - v;
+    __syncthreads();
+    if (threadIdx.x == IDX_THREADS - 1) carry_s = carry + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+// pass 3: exclusive scan inside each tile + tile prefix; thread t owns IDX_ITEMS consecutive items
+__global__ __launch_bounds__(IDX_THREADS) void tzr_scan_final_kernel(
+    const void* __restrict__ in, int itemsize, int64_t n, const int64_t* __restrict__ tile_prefix,
+    int64_t* __restrict__ out /*[n+1]*/) {
+  __shared__ int64_t wt[IDX_THREADS / TZR_WAVE];
+  const int64_t base = (int64_t)blockIdx.x * IDX_TILE + (int64_t)threadIdx.x * IDX_ITEMS;
+  int64_t v[IDX_ITEMS];
+  int64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < IDX_ITEMS; ++j) {
+    v[j] = (base + j < n) ? idx_load_len(in, itemsize, base + j) : 0;
+    s += v[j];
+  }
+  const int64_t inc = idx_block_inclusive(s, wt);
+  int64_t run = tile_prefix[blockIdx.x] + inc - s;
+#pragma unroll
+  for (int j = 0; j < IDX_ITEMS; ++j) {
+    if (base + j < n) out[base + j] = run;
+    run += v[j];
+    if (base + j == n - 1) out[n] = run;
+  }
+  if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+static int idx_scan(const void* in, int itemsize, int64_t n, int64_t* out, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+  const int64_t tiles = n > 0 ? (n + IDX_TILE - 1) / IDX_TILE : 1;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < (size_t)tiles * 8)
+    return TZR_ERR_WORKSPACE;
+  int64_t* tile_sums = static_cast<int64_t*>(ws);
+  hipLaunchKernelGGL(tzr_scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, s, in,
+                     itemsize, n, tile_sums);
+  hipLaunchKernelGGL(tzr_scan_tile_prefix_kernel, dim3(1), dim3(IDX_THREADS), 0, s, tile_sums,
+                     tiles, (int64_t*)nullptr);
+  hipLaunchKernelGGL(tzr_scan_final_kernel, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, s, in,
+                     itemsize, n, tile_sums, out);
+  return TZR_OK;
+}
+
+extern "C" size_t tzr_lengths_to_offsets_workspace(int64_t n) {
+  const int64_t tiles = n > 0 ? (n + IDX_TILE - 1) / IDX_TILE : 1;
+  return tzr_align_up((size_t)tiles * 8) + 256;
+}
+
+extern "C" int tzr_lengths_to_offsets(const void* d_lengths, int lengths_itemsize, int64_t n,
+                                      int64_t* d_offsets, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  if (!d_offsets || n < 0 || (lengths_itemsize != 4 && lengths_itemsize != 8)) return TZR_ERR_INVALID;
+  if (n > 0 && !d_lengths) return TZR_ERR_INVALID;
+  const int rc = idx_scan(d_lengths, lengths_itemsize, n, d_offsets, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream));
+  if (rc != TZR_OK) return rc;
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- K4 -------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(IDX_THREADS) void tzr_bounds_check_kernel(
+    const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats, int F,
+    int64_t* __restrict__ values, const int64_t* __restrict__ offsets, int64_t B, int mode,
+    unsigned long long* __restrict__ oob) {
+  // one (key, sample-tile) per workgroup: blockIdx.y = key, blockIdx.x tiles the key's ids
+  const int f = blockIdx.y;
+  if (feats[f].table < 0) return;  // key not owned by this module
+  const int64_t rows = tables[feats[f].table].rows;
+  const int64_t key = feats[f].key;
+  const int64_t s = offsets[key * B], e = offsets[(key + 1) * B];
+  unsigned bad = 0;
+  for (int64_t i = s + (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x; i < e;
+       i += (int64_t)gridDim.x * IDX_THREADS) {
+    const int64_t id = values[i];
+    if ((uint64_t)id >= (uint64_t)rows) {
+      ++bad;
+      if (mode != TZR_BOUNDS_FATAL) values[i] = 0;
+    }
+  }
+  if (bad && mode != TZR_BOUNDS_IGNORE) atomicAdd(oob, (unsigned long long)bad);
+}
+
+extern "C" int tzr_bounds_check(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                                int64_t* d_values, const int64_t* d_offsets, int64_t B, int mode,
+                                int64_t* d_oob_count, void* stream) {
+  if (!d_tables || !d_feats || n_feats <= 0 || !d_offsets || B < 0 || !d_oob_count || mode < 0 ||
+      mode > 2)
+    return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  if (!d_values) return TZR_ERR_INVALID;
+  const unsigned gx = (unsigned)std::min<int64_t>(256, (B + IDX_THREADS - 1) / IDX_THREADS);
+  hipLaunchKernelGGL(tzr_bounds_check_kernel, dim3(gx, (unsigned)n_feats), dim3(IDX_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_tables, d_feats, n_feats, d_values,
+                     d_offsets, B, mode, reinterpret_cast<unsigned long long*>(d_oob_count));
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- K1 -------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(IDX_THREADS) void tzr_permute_lengths_kernel(
+    const int32_t* __restrict__ permute, int64_t B, const void* __restrict__ in_lengths,
+    int itemsize, void* __restrict__ out_lengths) {
+  const int t = blockIdx.y;
+  const int64_t p = permute[t];
+  for (int64_t b = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x; b < B;
+       b += (int64_t)gridDim.x * IDX_THREADS)
+    idx_store_len(out_lengths, itemsize, (int64_t)t * B + b,
+                  idx_load_len(in_lengths, itemsize, p * B + b));
+}
+
+// Key t's values are one contiguous segment in both layouts: a segmented memcpy.
+__global__ __launch_bounds__(IDX_THREADS) void tzr_permute_values_kernel(
+    const int32_t* __restrict__ permute, int64_t B, const int64_t* __restrict__ in_offsets,
+    const int64_t* __restrict__ out_offsets, const int64_t* __restrict__ in_values,
+    const float* __restrict__ in_weights, int64_t* __restrict__ out_values,
+    float* __restrict__ out_weights, int64_t n_out_max) {
+  const int t = blockIdx.y;
+  const int64_t p = permute[t];
+  const int64_t src = in_offsets[p * B];
+  const int64_t dst = out_offsets[(int64_t)t * B];
+  int64_t n = out_offsets[(int64_t)(t + 1) * B] - dst;
+  if (dst + n > n_out_max) n = n_out_max > dst ? n_out_max - dst : 0;
+  for (int64_t i = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * IDX_THREADS) {
+    out_values[dst + i] = in_values[src + i];
+    if (in_weights) out_weights[dst + i] = in_weights[src + i];
+  }
+}
+
+extern "C" size_t tzr_kjt_permute_workspace(int64_t T, int64_t B) {
+  return tzr_lengths_to_offsets_workspace(T * B);
+}
+
+extern "C" int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B,
+                               const void* d_in_lengths, int lengths_itemsize,
+                               const int64_t* d_in_offsets, const int64_t* d_in_values,
+                               const float* d_in_weights, void* d_out_lengths,
+                               int64_t* d_out_offsets, int64_t* d_out_values,
+                               float* d_out_weights, int64_t n_out_max, void* ws, size_t ws_bytes,
+                               void* stream) {
+  if (!d_permute || T <= 0 || F <= 0 || B < 0 || !d_in_offsets || !d_out_offsets ||
+      (lengths_itemsize != 4 && lengths_itemsize != 8) || n_out_max < 0)
+    return TZR_ERR_INVALID;
+  if (d_in_weights && !d_out_weights) return TZR_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) {
+    if (hipMemsetAsync(d_out_offsets, 0, 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    return TZR_OK;
+  }
+  if (!d_in_lengths || !d_out_lengths) return TZR_ERR_INVALID;
+  const unsigned gx = (unsigned)std::min<int64_t>(64, (B + IDX_THREADS - 1) / IDX_THREADS);
+  hipLaunchKernelGGL(tzr_permute_lengths_kernel, dim3(gx, (unsigned)T), dim3(IDX_THREADS), 0, s,
+                     d_permute, B, d_in_lengths, lengths_itemsize, d_out_lengths);
+  const int rc = idx_scan(d_out_lengths, lengths_itemsize, (int64_t)T * B, d_out_offsets, ws,
+                          ws_bytes, s);
+  if (rc != TZR_OK) return rc;
+  if (n_out_max > 0) {
+    if (!d_in_values || !d_out_values) return TZR_ERR_INVALID;
+    hipLaunchKernelGGL(tzr_permute_values_kernel, dim3(128, (unsigned)T), dim3(IDX_THREADS), 0, s,
+                       d_permute, B, d_in_offsets, d_out_offsets, d_in_values, d_in_weights,
+                       d_out_values, d_out_weights, n_out_max);
+  }
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- K2 -------------------------------------------------------------------------------------
+// One thread per bag (a bag is owned by one thread, so its W counters / cursors are private plain
+// read-modify-writes: deterministic, ids keep their order inside every (rank, key, sample) bag).
+
+__global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_count_kernel(
+    const int64_t* __restrict__ block_sizes, int F, int64_t B, int W,
+    const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
+    void* __restrict__ new_lengths, int itemsize) {
+  const int64_t bag = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x;
+  if (bag >= (int64_t)F * B) return;
+  const int64_t bs = block_sizes[bag / B];
+  const int64_t FB = (int64_t)F * B;
+  for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
+    int64_t r = values[i] / bs;
+    r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+    const int64_t o = r * FB + bag;
+    idx_store_len(new_lengths, itemsize, o, idx_load_len(new_lengths, itemsize, o) + 1);
+  }
+}
+
+__global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_scatter_kernel(
+    const int64_t* __restrict__ block_sizes, int F, int64_t B, int W,
+    const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
+    const float* __restrict__ weights, int64_t* __restrict__ cursor /*[W*F*B] = new_offsets copy*/,
+    int64_t* __restrict__ new_values, float* __restrict__ new_weights,
+    int64_t* __restrict__ unbucketize) {
+  const int64_t bag = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x;
+  if (bag >= (int64_t)F * B) return;
+  const int64_t bs = block_sizes[bag / B];
+  const int64_t FB = (int64_t)F * B;
+  for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
+    const int64_t id = values[i];
+    int64_t r = id / bs;
+    r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+    const int64_t o = r * FB + bag;
+    const int64_t pos = cursor[o];
+    cursor[o] = pos + 1;
+    new_values[pos] = id - r * bs;
+    if (weights) new_weights[pos] = weights[i];
+    if (unbucketize) unbucketize[i] = pos;
+  }
+}
+
+extern "C" size_t tzr_block_bucketize_workspace(int64_t F, int64_t B, int W) {
+  const int64_t n = (int64_t)W * F * B;
+  return tzr_lengths_to_offsets_workspace(n) + tzr_align_up((size_t)n * 8) + 256;
+}
+
+extern "C" int tzr_block_bucketize(const int64_t* d_block_sizes, int F, int64_t B, int W,
+                                   const int64_t* d_offsets, const int64_t* d_values,
+                                   const float* d_weights, int64_t n_values, void* d_new_lengths,
+                                   int lengths_itemsize, int64_t* d_new_offsets,
+                                   int64_t* d_new_values, float* d_new_weights,
+                                   int64_t* d_unbucketize_permute, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!d_block_sizes || F <= 0 || B < 0 || W <= 0 || !d_offsets || n_values < 0 ||
+      !d_new_offsets || (lengths_itemsize != 4 && lengths_itemsize != 8))
+    return TZR_ERR_INVALID;
+  if (d_weights && !d_new_weights) return TZR_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)W * F * B;
+  if (n == 0) {
+    if (hipMemsetAsync(d_new_offsets, 0, 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    return TZR_OK;
+  }
+  if (!d_new_lengths || (n_values > 0 && (!d_values || !d_new_values))) return TZR_ERR_INVALID;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) ||
+      ws_bytes < tzr_block_bucketize_workspace(F, B, W) - 256)
+    return TZR_ERR_WORKSPACE;
+  const size_t scan_ws = tzr_lengths_to_offsets_workspace(n) - 256;
+  int64_t* cursor = reinterpret_cast<int64_t*>(static_cast<char*>(ws) + tzr_align_up(scan_ws));
+  if (hipMemsetAsync(d_new_lengths, 0, (size_t)n * lengths_itemsize, s) != hipSuccess)
+    return TZR_ERR_LAUNCH;
+  const unsigned gb = (unsigned)(((int64_t)F * B + IDX_THREADS - 1) / IDX_THREADS);
+  hipLaunchKernelGGL(tzr_bucketize_count_kernel, dim3(gb), dim3(IDX_THREADS), 0, s, d_block_sizes,
+                     F, B, W, d_offsets, d_values, d_new_lengths, lengths_itemsize);
+  const int rc = idx_scan(d_new_lengths, lengths_itemsize, n, d_new_offsets, ws, scan_ws, s);
+  if (rc != TZR_OK) return rc;
+  if (hipMemcpyAsync(cursor, d_new_offsets, (size_t)n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return TZR_ERR_LAUNCH;
+  hipLaunchKernelGGL(tzr_bucketize_scatter_kernel, dim3(gb), dim3(IDX_THREADS), 0, s,
+                     d_block_sizes, F, B, W, d_offsets, d_values, d_weights, cursor, d_new_values,
+                     d_new_weights, d_unbucketize_permute);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

@@ -1,0 +1,294 @@
+// K9 / K10: DLRM dot interaction and FM second-order term for gfx950.
+//
+// K9 replaces InteractionArch.forward (/root/reference/tzrec/modules/interaction.py:80-91:
+// torch.bmm(X, X^T) + strict-upper-triangle gather) fused with the concatenations of
+// DLRM.predict (/root/reference/tzrec/models/dlrm.py:123-130).  K10 replaces
+// FactorizationMachine.forward (/root/reference/tzrec/modules/fm.py:27-42).
+//
+// Both ops are HBM-bound (K9: 1728 B in + up to 3132 B out per sample for 23 kflop).  MFMA is used
+// only for the dense pairwise contraction: one wave per sample, n <= 32 rows padded to two 16-row
+// blocks, K = D = 16, exact fp32 v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain, no TF32 on
+// gfx950).  Fragment maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&15][k=l>>4],
+// B[k=l>>4][j=l&15]; accumulator reg r of lane l is D[row=(l>>4)*4+r][col=l&15].
+#include "tzr_common.h"
+
+#define IA_THREADS 256
+#define IA_WAVES (IA_THREADS / TZR_WAVE)
+#define IA_MAXN 32
+#define IA_D 16
+#define IA_MAXP (IA_MAXN * (IA_MAXN - 1) / 2)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((packed, aligned(4))) tzr_f4u {
+  float x, y, z, w;
+};
+__device__ __forceinline__ void tzr_st4_a4(float* p, float4 v) {  // 4-byte aligned 16-byte store
+  tzr_f4u u;
+  u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+  *reinterpret_cast<tzr_f4u*>(p) = u;
+}
+__device__ __forceinline__ float4 tzr_ld4_a4(const float* p) {
+  const tzr_f4u u = *reinterpret_cast<const tzr_f4u*>(p);
+  return make_float4(u.x, u.y, u.z, u.w);
+}
+
+// row i of X[b]: the dense row (if any) is row 0, sparse rows follow.
+__device__ __forceinline__ const float* ia_row(const float* dense, int64_t dense_stride,
+                                               const float* sparse, int64_t sparse_stride,
+                                               int64_t b, int i, int hd) {
+  return (hd && i == 0) ? dense + b * dense_stride
+                        : sparse + b * sparse_stride + (int64_t)(i - hd) * IA_D;
+}
+
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int64_t B, float* __restrict__ out, int64_t out_stride,
+    int cat_dense, int cat_sparse) {
+  __shared__ float tri[IA_WAVES][IA_MAXP + 16];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+  const int P = n * (n - 1) / 2;
+  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += (int64_t)gridDim.x * IA_WAVES) {
+    const int64_t b = b0 + wv;
+    const bool on = b < B;
+    float4 a0 = tzr_zero4(), a1 = tzr_zero4();
+    if (on) {
+      if (r < n) a0 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, r, hd) + 4 * q);
+      if (16 + r < n)
+        a1 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, 16 + r, hd) + 4 * q);
+    }
+    f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c11 = c00;
+    const float x0[4] = {a0.x, a0.y, a0.z, a0.w};
+    const float x1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x0[e], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x1[e], c01, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], x1[e], c11, 0, 0, 0);
+    }
+    // strict upper triangle, row-major (i<j): idx(i,j) = i*(2n-i-1)/2 + j-i-1, staged in LDS so
+    // the global write is one contiguous run per sample
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i0 = 4 * q + reg, i1 = 16 + i0;
+      const int j0 = r, j1 = 16 + r;
+      if (i0 < j0 && j0 < n) tri[wv][i0 * (2 * n - i0 - 1) / 2 + j0 - i0 - 1] = c00[reg];
+      if (j1 < n) tri[wv][i0 * (2 * n - i0 - 1) / 2 + j1 - i0 - 1] = c01[reg];
+      if (i1 < j1 && j1 < n) tri[wv][i1 * (2 * n - i1 - 1) / 2 + j1 - i1 - 1] = c11[reg];
+    }
+    __syncthreads();
+    if (on) {
+      float* o = out + b * out_stride;
+      for (int idx = lane; idx < P; idx += TZR_WAVE) o[idx] = tri[wv][idx];
+      int col = P;
+      if (cat_dense && hd) {
+        if (r == 0) tzr_st4_a4(o + col + 4 * q, a0);
+        col += IA_D;
+      }
+      if (cat_sparse) {
+        if (r >= hd && r < n) tzr_st4_a4(o + col + (r - hd) * IA_D + 4 * q, a0);
+        if (16 + r < n) tzr_st4_a4(o + col + (16 + r - hd) * IA_D + 4 * q, a1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int64_t B, const float* __restrict__ gout,
+    int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
+    int64_t gdense_stride, float* __restrict__ gsparse, int64_t gsparse_stride) {
+  // S = G + G^T per wave, 32 x 33 floats (odd row stride: conflict-free column reads)
+  __shared__ float S[IA_WAVES][IA_MAXN * (IA_MAXN + 1)];
+  __shared__ unsigned short ij[IA_MAXP];  // idx -> (i << 8) | j
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+  const int P = n * (n - 1) / 2;
+  for (int idx = threadIdx.x; idx < P; idx += IA_THREADS) {
+    int i = 0, rem = idx;
+    while (rem >= n - 1 - i) {
+      rem -= n - 1 - i;
+      ++i;
+    }
+    ij[idx] = (unsigned short)((i << 8) | (i + 1 + rem));
+  }
+  for (int k = threadIdx.x; k < IA_WAVES * IA_MAXN * (IA_MAXN + 1); k += IA_THREADS)
+    (&S[0][0])[k] = 0.f;
+  __syncthreads();
+  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += (int64_t)gridDim.x * IA_WAVES) {
+    const int64_t b = b0 + wv;
+    const bool on = b < B;
+    if (on) {
+      const float* g = gout + b * gout_stride;
+      for (int idx = lane; idx < P; idx += TZR_WAVE) {
+        const float v = g[idx];
+        const int i = ij[idx] >> 8, j = ij[idx] & 255;
+        S[wv][i * (IA_MAXN + 1) + j] = v;
+        S[wv][j * (IA_MAXN + 1) + i] = v;
+      }
+    }
+    __syncthreads();
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+    for (int ks = 0; ks < IA_MAXN / 4; ++ks) {
+      const int k = 4 * ks + q;  // contraction index = row of X
+      float xb = 0.f;
+      if (on && k < n) xb = ia_row(dense, dense_stride, sparse, sparse_stride, b, k, hd)[r];
+      const float s0 = S[wv][r * (IA_MAXN + 1) + k];
+      const float s1 = S[wv][(16 + r) * (IA_MAXN + 1) + k];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(s0, xb, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(s1, xb, d1, 0, 0, 0);
+    }
+    if (on) {
+      const float* g = gout + b * gout_stride;
+      const int pd = P;                                // pass-through dense columns
+      const int ps = P + ((cat_dense && hd) ? IA_D : 0);  // pass-through sparse columns
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int i = 16 * blk + 4 * q + reg;
+          if (i >= n) continue;
+          float v = blk ? d1[reg] : d0[reg];
+          if (hd && i == 0) {
+            if (cat_dense) v += g[pd + r];
+            gdense[b * gdense_stride + r] = v;
+          } else {
+            if (cat_sparse) v += g[ps + (i - hd) * IA_D + r];
+            gsparse[b * gsparse_stride + (int64_t)(i - hd) * IA_D + r] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static unsigned ia_grid(int64_t B) {
+  const int64_t wg = (B + IA_WAVES - 1) / IA_WAVES;
+  return (unsigned)(wg < 1 ? 1 : (wg > 4096 ? 4096 : wg));
+}
+
+extern "C" int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_stride,
+                                       const float* d_sparse, int64_t sparse_stride, int F, int D,
+                                       int64_t B, float* d_out, int64_t out_stride, int cat_dense,
+                                       int cat_sparse, void* stream) {
+  const int hd = d_dense ? 1 : 0;
+  const int n = F + hd;
+  if (!d_sparse || !d_out || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (D != IA_D || n > IA_MAXN || n < 2) return TZR_ERR_UNSUPPORTED;
+  if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
+      (reinterpret_cast<uintptr_t>(d_sparse) & 15) || (reinterpret_cast<uintptr_t>(d_dense) & 15))
+    return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  hipLaunchKernelGGL(tzr_dot_interaction_fwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
+                     sparse_stride, n, hd, B, d_out, out_stride, cat_dense, cat_sparse);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_stride,
+                                       const float* d_sparse, int64_t sparse_stride, int F, int D,
+                                       int64_t B, const float* d_grad_out, int64_t grad_out_stride,
+                                       int cat_dense, int cat_sparse, float* d_grad_dense,
+                                       int64_t grad_dense_stride, float* d_grad_sparse,
+                                       int64_t grad_sparse_stride, void* stream) {
+  const int hd = d_dense ? 1 : 0;
+  const int n = F + hd;
+  if (!d_sparse || !d_grad_out || !d_grad_sparse || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (hd && !d_grad_dense) return TZR_ERR_INVALID;
+  if (D != IA_D || n > IA_MAXN || n < 2) return TZR_ERR_UNSUPPORTED;
+  if (B == 0) return TZR_OK;
+  hipLaunchKernelGGL(tzr_dot_interaction_bwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
+                     sparse_stride, n, hd, B, d_grad_out, grad_out_stride, cat_dense, cat_sparse,
+                     d_grad_dense, grad_dense_stride, d_grad_sparse, grad_sparse_stride);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- K10: FM ---------------------------------------------------------------------------------
+// thread = (sample, float4 chunk of D); F sequential float4 loads per thread, D/4 consecutive lanes
+// read one contiguous embedding row.
+
+template <bool BWD>
+__global__ __launch_bounds__(IA_THREADS) void tzr_fm_kernel(
+    const float* __restrict__ x, int64_t x_stride, int F, int D, int64_t B,
+    const float* __restrict__ gout, int64_t gout_stride, float* __restrict__ out,
+    int64_t out_stride) {
+  const int lg = D >> 2;
+  const int64_t total = B * lg;
+  for (int64_t k = (int64_t)blockIdx.x * IA_THREADS + threadIdx.x; k < total;
+       k += (int64_t)gridDim.x * IA_THREADS) {
+    const int64_t b = k / lg;
+    const int c = (int)(k - b * lg);
+    const float* xp = x + b * x_stride + 4 * c;
+    float4 s = tzr_zero4(), ss = tzr_zero4();
+    for (int f = 0; f < F; ++f) {
+      const float4 v = tzr_ld4(xp + (int64_t)f * D);
+      s = tzr_add4(s, v);
+      ss.x = fmaf(v.x, v.x, ss.x); ss.y = fmaf(v.y, v.y, ss.y);
+      ss.z = fmaf(v.z, v.z, ss.z); ss.w = fmaf(v.w, v.w, ss.w);
+    }
+    if (!BWD) {
+      float4 o;
+      o.x = 0.5f * (s.x * s.x - ss.x); o.y = 0.5f * (s.y * s.y - ss.y);
+      o.z = 0.5f * (s.z * s.z - ss.z); o.w = 0.5f * (s.w * s.w - ss.w);
+      tzr_st4(out + b * out_stride + 4 * c, o);
+    } else {
+      const float4 g = tzr_ld4(gout + b * gout_stride + 4 * c);
+      float* op = out + b * out_stride + 4 * c;
+      for (int f = 0; f < F; ++f) {
+        const float4 v = tzr_ld4(xp + (int64_t)f * D);
+        float4 o;
+        o.x = g.x * (s.x - v.x); o.y = g.y * (s.y - v.y);
+        o.z = g.z * (s.z - v.z); o.w = g.w * (s.w - v.w);
+        tzr_st4(op + (int64_t)f * D, o);
+      }
+    }
+  }
+}
+
+static int fm_check(const float* x, int64_t xs, int F, int D, int64_t B) {
+  if (!x || F <= 0 || D <= 0 || B < 0) return TZR_ERR_INVALID;
+  if ((D & 3) || (xs & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return TZR_ERR_UNSUPPORTED;
+  return TZR_OK;
+}
+
+extern "C" int tzr_fm_fwd(const float* d_x, int64_t x_stride, int F, int D, int64_t B,
+                          float* d_out, int64_t out_stride, void* stream) {
+  int rc = fm_check(d_x, x_stride, F, D, B);
+  if (rc != TZR_OK) return rc;
+  if (!d_out || (out_stride & 3) || (reinterpret_cast<uintptr_t>(d_out) & 15)) return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  const int64_t total = B * (D >> 2);
+  const unsigned grid = (unsigned)std::min<int64_t>(8192, (total + IA_THREADS - 1) / IA_THREADS);
+  hipLaunchKernelGGL((tzr_fm_kernel<false>), dim3(grid), dim3(IA_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_x, x_stride, F, D, B,
+                     (const float*)nullptr, (int64_t)0, d_out, out_stride);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+extern "C" int tzr_fm_bwd(const float* d_x, int64_t x_stride, int F, int D, int64_t B,
+                          const float* d_grad_out, int64_t grad_out_stride, float* d_grad_x,
+                          int64_t grad_x_stride, void* stream) {
+  int rc = fm_check(d_x, x_stride, F, D, B);
+  if (rc != TZR_OK) return rc;
+  if (!d_grad_out || !d_grad_x || (grad_out_stride & 3) || (grad_x_stride & 3) ||
+      (reinterpret_cast<uintptr_t>(d_grad_out) & 15) || (reinterpret_cast<uintptr_t>(d_grad_x) & 15))
+    return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  const int64_t total = B * (D >> 2);
+  const unsigned grid = (unsigned)std::min<int64_t>(8192, (total + IA_THREADS - 1) / IA_THREADS);
+  hipLaunchKernelGGL((tzr_fm_kernel<true>), dim3(grid), dim3(IA_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_x, x_stride, F, D, B, d_grad_out,
+                     grad_out_stride, d_grad_x, grad_x_stride);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

@@ -1,0 +1,197 @@
+// K5 (+K8 fused): pooled embedding gather forward for gfx950.
+//
+// Replaces torchrec EmbeddingBagCollection.forward -> fbgemm
+// split_embedding_codegen_forward_{un,}weighted_kernel (self.ebc(kjt),
+// /root/reference/tzrec/modules/embedding.py:930) fused with the feature-group regroup copy
+// (KeyedTensor.regroup_as_dict, embedding.py:972-976).
+//
+// Mapping (HBM-bound, no reuse => no MFMA, no LDS tile of rows):
+//   * a workgroup owns `tile_b` consecutive samples x up to FWD_MAX_SLOTS float4 "slots" of their
+//     destination rows; thread k of the tile handles (sample k / ns, slot k % ns), so consecutive
+//     lanes write consecutive float4s of one destination row (full 128-B lines, 1 KiB per wave
+//     store) and the D/4 lanes of a feature read one embedding row as contiguous 16-B pieces;
+//   * the per-slot metadata (row base + chunk, destination base) is resolved once per workgroup
+//     into LDS, so the id -> row dependent chain is two loads (id, row);
+//   * every thread keeps FWD_UNROLL independent gathers in flight (random 64-B row reads are
+//     latency-bound: ~1 us under load x 8 TB/s needs ~16 rows in flight per wave);
+//   * ids of a tile are `tile_b` consecutive int64 per feature (key-major KJT), re-used from L1 by
+//     the lanes of the tile.
+#include "tzr_common.h"
+
+#define FWD_THREADS 256
+#define FWD_UNROLL 4
+#define FWD_MAX_SLOTS 512
+
+struct FwdDsts {
+  TzrDst d[TZR_MAX_DST];
+};
+
+struct FwdRSlot {  // resolved slot, 40 bytes
+  const float* w;  // table row 0 + chunk*4
+  float* dst;      // destination buffer + col
+  int64_t rows;    // ids outside [0, rows) read row 0 (memory safety; K4 counts / reports them)
+  int32_t dst_stride;
+  int32_t w_stride;
+  int32_t feat;  // KJT key index
+  int32_t pooling;
+};
+
+int g_tzr_fwd_tile_b = 0;  // 0 = auto; set through tzr_tune("fwd_tile_b", v)
+
+template <bool UNIFORM1, bool WEIGHTED>
+__global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
+    const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
+    const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int tile_b,
+    FwdDsts dsts) {
+  __shared__ FwdRSlot rs[FWD_MAX_SLOTS];
+  const int s0 = blockIdx.y * FWD_MAX_SLOTS;
+  const int ns = min(FWD_MAX_SLOTS, n_slots - s0);
+  for (int s = threadIdx.x; s < ns; s += FWD_THREADS) {
+    TzrSlot sl = slots[s0 + s];
+    TzrFeature ft = feats[sl.feature];
+    TzrTable tb = tables[ft.table];
+    FwdRSlot r;
+    r.w = reinterpret_cast<const float*>(tb.w) + sl.chunk * 4;
+    r.dst = reinterpret_cast<float*>(dsts.d[sl.dst].ptr) + sl.col;
+    r.dst_stride = (int32_t)dsts.d[sl.dst].stride;
+    r.w_stride = tb.w_stride;
+    r.rows = tb.rows;
+    r.feat = ft.key;
+    r.pooling = ft.pooling;
+    rs[s] = r;
+  }
+  __syncthreads();
+
+  const int64_t b0 = (int64_t)blockIdx.x * tile_b;
+  const int nb = (int)min((int64_t)tile_b, B - b0);
+  const int total = nb * ns;
+
+  for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * FWD_UNROLL) {
+    const float* wp[FWD_UNROLL];
+    float* dp[FWD_UNROLL];
+    int64_t st[FWD_UNROLL], en[FWD_UNROLL];
+    int32_t wstride[FWD_UNROLL];
+    int64_t rows[FWD_UNROLL];
+    int32_t pool[FWD_UNROLL];
+    float4 acc[FWD_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FWD_UNROLL; ++u) {
+      const int k = k0 + u * FWD_THREADS;
+      const bool ok = k < total;
+      const int bl = ok ? k / ns : 0;
+      const int s = ok ? k - bl * ns : 0;
+      const FwdRSlot r = rs[s];
+      const int64_t b = b0 + bl;
+      const int64_t bag = (int64_t)r.feat * B + b;
+      wp[u] = r.w;
+      wstride[u] = r.w_stride;
+      rows[u] = r.rows;
+      pool[u] = r.pooling;
+      dp[u] = r.dst + b * (int64_t)r.dst_stride;
+      if (UNIFORM1) {
+        st[u] = bag;
+        en[u] = ok ? bag + 1 : bag;
+      } else {
+        st[u] = ok ? offsets[bag] : 0;
+        en[u] = ok ? offsets[bag + 1] : 0;
+      }
+      acc[u] = tzr_zero4();
+    }
+    if (UNIFORM1) {
+      // one id per bag: FWD_UNROLL independent id loads, then FWD_UNROLL independent row loads
+      int64_t id[FWD_UNROLL];
+      float sc[FWD_UNROLL];
+#pragma unroll
+      for (int u = 0; u < FWD_UNROLL; ++u) {
+        id[u] = (st[u] < en[u]) ? values[st[u]] : 0;
+        if ((uint64_t)id[u] >= (uint64_t)rows[u]) id[u] = 0;
+        sc[u] = (WEIGHTED && st[u] < en[u]) ? weights[st[u]] : 1.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < FWD_UNROLL; ++u) {
+        if (st[u] < en[u]) {
+          float4 v = tzr_ld4(wp[u] + id[u] * (int64_t)wstride[u]);
+          if (WEIGHTED) {
+            v.x *= sc[u]; v.y *= sc[u]; v.z *= sc[u]; v.w *= sc[u];
+          }
+          acc[u] = v;
+        }
+      }
+    } else {
+      int64_t maxlen = 0;
+#pragma unroll
+      for (int u = 0; u < FWD_UNROLL; ++u) maxlen = max(maxlen, en[u] - st[u]);
+      for (int64_t j = 0; j < maxlen; ++j) {
+        int64_t id[FWD_UNROLL];
+        float sc[FWD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u) {
+          const bool on = st[u] + j < en[u];
+          id[u] = on ? values[st[u] + j] : 0;
+          if ((uint64_t)id[u] >= (uint64_t)rows[u]) id[u] = 0;
+          sc[u] = (WEIGHTED && on) ? weights[st[u] + j] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u) {
+          if (st[u] + j < en[u]) {
+            const float4 v = tzr_ld4(wp[u] + id[u] * (int64_t)wstride[u]);
+            // accumulation order = bag order, one fmaf per element (matches the oracle's
+            // sequential fp32 sum up to fma contraction of the per-sample weight)
+            acc[u] = WEIGHTED ? tzr_fma4(sc[u], v, acc[u]) : tzr_add4(acc[u], v);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FWD_UNROLL; ++u) {
+        const int64_t len = en[u] - st[u];
+        if (pool[u] == TZR_POOL_MEAN && len > 1) {
+          const float inv = 1.0f / (float)len;
+          acc[u].x *= inv; acc[u].y *= inv; acc[u].z *= inv; acc[u].w *= inv;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FWD_UNROLL; ++u) {
+      if (k0 + u * FWD_THREADS < total) tzr_st4(dp[u], acc[u]);
+    }
+  }
+}
+
+extern "C" int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                              const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
+                              const int64_t* d_offsets, const float* d_weights, int64_t B,
+                              const TzrDst* h_dsts, int n_dst, int uniform_bag_len, void* stream) {
+  if (!d_tables || !d_feats || !d_slots || !h_dsts || n_feats <= 0 || n_slots <= 0 || B < 0 ||
+      n_dst <= 0 || n_dst > TZR_MAX_DST)
+    return TZR_ERR_INVALID;
+  if (uniform_bag_len != 1 && !d_offsets) return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  if (!d_values) return TZR_ERR_INVALID;
+  FwdDsts dsts;
+  for (int i = 0; i < TZR_MAX_DST; ++i) {
+    dsts.d[i].ptr = 0;
+    dsts.d[i].stride = 0;
+  }
+  for (int i = 0; i < n_dst; ++i) {
+    if (!h_dsts[i].ptr || (h_dsts[i].stride & 3) || (h_dsts[i].ptr & 15)) return TZR_ERR_INVALID;
+    if (h_dsts[i].stride > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;
+    dsts.d[i] = h_dsts[i];
+  }
+  int tile_b = g_tzr_fwd_tile_b;
+  if (tile_b <= 0) tile_b = B <= 16384 ? 8 : (B <= 32768 ? 16 : 32);
+  dim3 grid((unsigned)((B + tile_b - 1) / tile_b), (unsigned)((n_slots + FWD_MAX_SLOTS - 1) / FWD_MAX_SLOTS));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool u1 = uniform_bag_len == 1;
+  const bool wt = d_weights != nullptr;
+#define TZR_FWD_LAUNCH(U, W)                                                                     \
+  hipLaunchKernelGGL((tzr_pooled_fwd_kernel<U, W>), grid, dim3(FWD_THREADS), 0, s, d_tables,     \
+                     d_feats, d_slots, n_slots, d_values, d_offsets, d_weights, B, tile_b, dsts)
+  if (u1 && wt) TZR_FWD_LAUNCH(true, true);
+  else if (u1) TZR_FWD_LAUNCH(true, false);
+  else if (wt) TZR_FWD_LAUNCH(false, true);
+  else TZR_FWD_LAUNCH(false, false);
+#undef TZR_FWD_LAUNCH
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

@@ -1,0 +1,15 @@
+// Experiment knobs (include/tzrec_hip.h: tzr_tune).  Defaults are chosen inside each launcher.
+#include <string.h>
+
+#include "tzr_common.h"
+
+extern int g_tzr_fwd_tile_b;
+
+extern "C" int tzr_tune(const char* name, int value) {
+  if (!name) return TZR_ERR_INVALID;
+  if (!strcmp(name, "fwd_tile_b")) {
+    g_tzr_fwd_tile_b = value;
+    return TZR_OK;
+  }
+  return TZR_ERR_INVALID;
+}

@@ -1,0 +1,451 @@
+"""EmbeddingBagCollection on the gfx950 kernels: pooled lookup + in-backward fused sparse optimizer.
+
+Host-side mirror of what sits under ``EmbeddingGroupImpl.forward`` in the reference
+(/root/reference/tzrec/modules/embedding.py:855 builds ``EmbeddingBagCollection(list[EmbeddingBag
+Config], device)``, :930 calls ``self.ebc(kjt)`` -> ``KeyedTensor``, :972-976 regroups it per feature
+group).  Names and argument meanings follow torchrec 1.7.0 (EmbeddingBagConfig.name /
+embedding_dim / num_embeddings / feature_names / pooling; ``forward(KeyedJaggedTensor) ->
+KeyedTensor`` with keys in table-then-feature order).  Differences by design:
+
+* the optimizer is part of the module (the reference fuses it with
+  ``apply_optimizer_in_backward``, /root/reference/tzrec/main.py:774-781): ``loss.backward()``
+  updates the rows it touched and leaves no ``.grad`` on the tables;
+* ``forward_grouped`` writes the pooled blocks straight into feature-group layout, so the
+  regroup copy of embedding.py:972-976 disappears;
+* for Adagrad at D=16 a table row is stored as one 128-byte line ``[w(16) | m(16)]``
+  (``row_layout="interleaved"``): the backward read-modify-write of a row touches one HBM line.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .sparse import KeyedJaggedTensor, KeyedTensor
+
+
+@dataclass
+class EmbeddingBagConfig:
+    """torchrec.modules.embedding_configs.EmbeddingBagConfig fields tzrec fills
+    (/root/reference/tzrec/features/feature.py:611-636)."""
+
+    name: str
+    embedding_dim: int
+    num_embeddings: int
+    feature_names: List[str] = field(default_factory=list)
+    pooling: str = "sum"  # PoolingType.SUM / MEAN
+    init_fn: Optional[Callable[[torch.Tensor], None]] = None
+
+
+@dataclass
+class SparseOptimizerConfig:
+    """Fused sparse optimizer (/root/reference/tzrec/optim/optimizer_builder.py:30-97,
+    protos/optimizer.proto:76-139): ``adagrad_optimizer`` -> kind "adagrad",
+    ``rowwise_adagrad_optimizer`` -> "rowwise_adagrad", ``sgd_optimizer`` -> "sgd"."""
+
+    kind: str = "adagrad"
+    lr: float = 0.002
+    eps: float = 1e-8  # fbgemm default [upstream]; tzrec protos do not expose it
+    weight_decay: float = 0.0
+    weight_decay_mode: str = "none"  # NONE | L2 | DECOUPLE (rowwise adagrad)
+    gradient_clipping: bool = False
+    max_gradient: float = 1.0
+    initial_accumulator_value: float = 0.0
+
+
+_OPT_KIND = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "rowwise_adagrad": _lib.OPT_ROWWISE_ADAGRAD}
+_WD_MODE = {"none": _lib.WD_NONE, "l2": _lib.WD_L2, "decouple": _lib.WD_DECOUPLE}
+
+
+class FusedSparseOptimizer:
+    """KeyedOptimizer-like handle of the in-backward optimizer (``model.fused_optimizer`` in the
+    reference, /root/reference/tzrec/main.py:849,877-879): schedulers mutate
+    ``param_groups[i]["lr"]``; the value is mirrored into a device scalar the kernels read, so a
+    captured hipGraph sees new learning rates without re-capture."""
+
+    def __init__(self, cfg: SparseOptimizerConfig, ebc: "EmbeddingBagCollection") -> None:
+        self.cfg = cfg
+        self._ebc = ebc
+        self.param_groups = [{"lr": float(cfg.lr), "params": list(ebc.table_weights().values())}]
+        self._lr_dev: Optional[torch.Tensor] = None
+        self._lr_host: Optional[float] = None
+
+    @property
+    def params(self) -> Dict[str, torch.Tensor]:
+        return self._ebc.table_weights()
+
+    def lr_device(self, device: torch.device) -> torch.Tensor:
+        lr = float(self.param_groups[0]["lr"])
+        if self._lr_dev is None or self._lr_dev.device != device:
+            self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=device)
+            self._lr_host = lr
+        elif lr != self._lr_host:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+        return self._lr_dev
+
+    def zero_grad(self, set_to_none: bool = True) -> None:  # tables never hold .grad
+        pass
+
+    def step(self, closure=None) -> None:  # the update already happened inside backward
+        pass
+
+    def state_dict(self) -> Dict[str, object]:
+        return {
+            "state": {n: {"momentum1": s} for n, s in self._ebc.table_states().items()},
+            "param_groups": [{"lr": self.param_groups[0]["lr"]}],
+        }
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        for n, st in sd.get("state", {}).items():
+            dst = self._ebc.table_states().get(n)
+            if dst is not None:
+                dst.copy_(st["momentum1"])
+        if sd.get("param_groups"):
+            self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
+
+
+class _Table(nn.Module):
+    def __init__(self, weight: torch.Tensor) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=False)
+
+
+@dataclass
+class _Lookup:
+    key: str  # KJT key
+    table: int
+    out_key: str  # name of the pooled block (feature, or feature@table when ambiguous)
+
+
+class _Meta:
+    """Device-side descriptors for one KJT key list (see include/tzrec_hip.h)."""
+
+    def __init__(self) -> None:
+        self.tables_np = self.feats_np = self.slots_np = None
+        self.d_tables = self.d_feats = self.d_slots = None
+        self.n_keys = 0
+
+
+class _PooledLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ebc, kjt, dst_names, hook):  # hook: zero-size tensor that requires grad
+        outs = ebc._launch_forward(kjt, dst_names)
+        ctx.ebc, ctx.kjt, ctx.dst_names = ebc, kjt, dst_names
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.ebc._launch_backward(ctx.kjt, ctx.dst_names, grads)
+        return None, None, None, None
+
+
+class EmbeddingBagCollection(nn.Module):
+    """Pooled embedding lookup for a set of tables.
+
+    Args:
+        tables: table configs; ``feature_names`` are the KJT keys each table serves.
+        device: where the table storage lives (a HIP device in production).
+        optimizer: fused sparse optimizer; ``None`` makes the tables frozen (forward only).
+        groups: optional ``{group_name: [out_key, ...]}`` feature-group layout for
+            ``forward_grouped`` (out_key = feature name, or ``feature@table`` when the feature is
+            served by several tables).
+        row_layout: "interleaved" stores Adagrad state next to the weights in one row
+            (``[w | m]``), "split" keeps two arrays.
+    """
+
+    def __init__(
+        self,
+        tables: Sequence[EmbeddingBagConfig],
+        device: Optional[torch.device] = None,
+        optimizer: Optional[SparseOptimizerConfig] = None,
+        groups: Optional[Dict[str, List[str]]] = None,
+        row_layout: str = "interleaved",
+    ) -> None:
+        super().__init__()
+        device = torch.device(device) if device is not None else torch.device("cpu")
+        self._device = device
+        self._configs = list(tables)
+        self._opt_cfg = optimizer
+        self._row_layout = row_layout
+        self.embedding_bags = nn.ModuleDict()
+        self._storage: List[torch.Tensor] = []
+        self._states: Dict[str, torch.Tensor] = {}
+        self._lookups: List[_Lookup] = []
+        names = set()
+        feat_tables: Dict[str, List[int]] = {}
+        for t, cfg in enumerate(self._configs):
+            if cfg.name in names:
+                raise ValueError(f"duplicate table name {cfg.name}")
+            names.add(cfg.name)
+            if cfg.embedding_dim % 4 or cfg.embedding_dim > 256:
+                raise ValueError(f"{cfg.name}: embedding_dim must be a multiple of 4, <= 256")
+            for f in cfg.feature_names:
+                feat_tables.setdefault(f, []).append(t)
+        # torchrec order: table-then-feature; a feature on >1 tables is exposed as feature@table
+        # (/root/reference/tzrec/modules/embedding.py:753-758,826-827)
+        for t, cfg in enumerate(self._configs):
+            for f in cfg.feature_names:
+                out_key = f if len(feat_tables[f]) == 1 else f"{f}@{cfg.name}"
+                self._lookups.append(_Lookup(f, t, out_key))
+        self._out_dim = {lk.out_key: self._configs[lk.table].embedding_dim for lk in self._lookups}
+        self._allocate()
+        self._groups = groups
+        self._dst_layouts: Dict[Tuple[str, ...], List[Tuple[str, List[str]]]] = {}
+        self._meta_cache: Dict[Tuple, _Meta] = {}
+        self.fused_optimizer = FusedSparseOptimizer(optimizer, self) if optimizer is not None else None
+        self._hook = torch.zeros(0, requires_grad=True, device=device)
+
+    # -- storage ---------------------------------------------------------------------------
+    def _allocate(self) -> None:
+        kind = self._opt_cfg.kind if self._opt_cfg is not None else None
+        init_m = self._opt_cfg.initial_accumulator_value if self._opt_cfg is not None else 0.0
+        for cfg in self._configs:
+            rows, D = cfg.num_embeddings, cfg.embedding_dim
+            if kind == "adagrad" and self._row_layout == "interleaved":
+                store = torch.empty(rows, 2 * D, dtype=torch.float32, device=self._device)
+                weight, state = store[:, :D], store[:, D:]
+                state.fill_(init_m)
+            else:
+                store = torch.empty(rows, D, dtype=torch.float32, device=self._device)
+                weight = store
+                if kind == "adagrad":
+                    state = torch.full((rows, D), init_m, dtype=torch.float32, device=self._device)
+                elif kind == "rowwise_adagrad":
+                    state = torch.zeros(rows, dtype=torch.float32, device=self._device)
+                else:
+                    state = None
+            if cfg.init_fn is not None:
+                cfg.init_fn(weight)
+            else:  # EmbeddingBagConfig default [upstream]: uniform(-sqrt(1/rows), sqrt(1/rows))
+                a = math.sqrt(1.0 / max(rows, 1))
+                weight.uniform_(-a, a)
+            self._storage.append(store)
+            self.embedding_bags[cfg.name] = _Table(weight)
+            if state is not None:
+                self._states[cfg.name] = state
+
+    def table_weights(self) -> Dict[str, torch.Tensor]:
+        return {n: m.weight for n, m in self.embedding_bags.items()}
+
+    def table_states(self) -> Dict[str, torch.Tensor]:
+        return self._states
+
+    def embedding_bag_configs(self) -> List[EmbeddingBagConfig]:
+        return self._configs
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    # -- descriptors -------------------------------------------------------------------------
+    def _default_layout(self) -> List[Tuple[str, List[str]]]:
+        return [("__all__", [lk.out_key for lk in self._lookups])]
+
+    def _meta(self, kjt_keys: Sequence[str], layout: List[Tuple[str, List[str]]]) -> _Meta:
+        ck = (tuple(kjt_keys), tuple((n, tuple(ks)) for n, ks in layout),
+              tuple(m.weight.data_ptr() for m in self.embedding_bags.values()))
+        meta = self._meta_cache.get(ck)
+        if meta is not None:
+            return meta
+        if len(layout) > _lib.TZR_MAX_DST:
+            raise ValueError(f"at most {_lib.TZR_MAX_DST} feature groups per lookup")
+        key_index = {k: i for i, k in enumerate(kjt_keys)}
+        T, Fn = len(self._configs), len(self._lookups)
+        feats = np.zeros(Fn, dtype=_lib.FEATURE_DT)
+        feats["dst"] = -1
+        by_out = {lk.out_key: i for i, lk in enumerate(self._lookups)}
+        for i, lk in enumerate(self._lookups):
+            if lk.key not in key_index:
+                raise KeyError(f"KeyedJaggedTensor has no key {lk.key!r} needed by table "
+                               f"{self._configs[lk.table].name!r}")
+            feats[i]["table"] = lk.table
+            feats[i]["key"] = key_index[lk.key]
+            feats[i]["pooling"] = _lib.POOL_MEAN if self._configs[lk.table].pooling.lower() == "mean" else _lib.POOL_SUM
+        # lookups are already in (table, index) order
+        feats["order"] = np.arange(Fn, dtype=np.int32)
+        slots = []
+        for d, (_, out_keys) in enumerate(layout):
+            col = 0
+            for ok in out_keys:
+                i = by_out[ok]
+                n = int(feats[i]["n_dst"])
+                if n >= _lib.TZR_MAX_FEAT_DST:
+                    raise ValueError(f"{ok}: a lookup can be copied into at most {_lib.TZR_MAX_FEAT_DST} groups")
+                feats[i]["dst"][n] = d
+                feats[i]["col"][n] = col
+                feats[i]["n_dst"] = n + 1
+                D = self._configs[self._lookups[i].table].embedding_dim
+                for c in range(D // 4):
+                    slots.append((i, c, d, col + 4 * c))
+                col += D
+        tables = np.zeros(T, dtype=_lib.TABLE_DT)
+        kind = self._opt_cfg.kind if self._opt_cfg is not None else None
+        for t, cfg in enumerate(self._configs):
+            w = self.embedding_bags[cfg.name].weight
+            st = self._states.get(cfg.name)
+            tables[t]["w"] = w.data_ptr()
+            tables[t]["m"] = st.data_ptr() if st is not None else 0
+            tables[t]["rows"] = cfg.num_embeddings
+            tables[t]["dim"] = cfg.embedding_dim
+            tables[t]["w_stride"] = w.stride(0)
+            tables[t]["m_stride"] = (1 if kind == "rowwise_adagrad" else (st.stride(0) if st is not None else 0))
+            mine = [i for i, lk in enumerate(self._lookups) if lk.table == t]
+            tables[t]["first_order"] = mine[0] if mine else 0
+            tables[t]["n_feats"] = len(mine)
+        meta = _Meta()
+        meta.tables_np, meta.feats_np = tables, feats
+        meta.slots_np = np.array(slots, dtype=_lib.SLOT_DT)
+        meta.d_tables = _lib.upload_struct(tables, self._device)
+        meta.d_feats = _lib.upload_struct(feats, self._device)
+        meta.d_slots = _lib.upload_struct(meta.slots_np, self._device)
+        meta.n_keys = len(kjt_keys)
+        self._meta_cache[ck] = meta
+        return meta
+
+    def _layout_for(self, dst_names: Tuple[str, ...]) -> List[Tuple[str, List[str]]]:
+        if dst_names == ("__all__",):
+            return self._default_layout()
+        assert self._groups is not None
+        return [(g, self._groups[g]) for g in dst_names]
+
+    # -- launches ----------------------------------------------------------------------------
+    def _kjt_args(self, kjt: KeyedJaggedTensor):
+        uniform = kjt.uniform_length() == 1
+        offsets = None if uniform else kjt.offsets()
+        return uniform, offsets
+
+    def _launch_forward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
+        layout = self._layout_for(dst_names)
+        meta = self._meta(kjt.keys(), layout)
+        B = kjt.stride()
+        uniform, offsets = self._kjt_args(kjt)
+        widths = [sum(self._out_dim[k] for k in ks) for _, ks in layout]
+        outs = [torch.empty(B, w, dtype=torch.float32, device=self._device) for w in widths]
+        dsts = (_lib.TzrDst * len(outs))()
+        for i, o in enumerate(outs):
+            dsts[i].ptr = _lib.ptr(o)
+            dsts[i].stride = o.stride(0)
+        rc = _lib.lib().tzr_pooled_fwd(
+            _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
+            _lib.ptr(meta.d_slots), len(meta.slots_np), _lib.ptr(kjt.values()), _lib.ptr(offsets),
+            _lib.ptr(kjt.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
+            _lib.stream_ptr(self._device),
+        )
+        _lib.check(rc, "tzr_pooled_fwd")
+        return outs
+
+    def _bwd_dims(self) -> Tuple[int, int]:
+        return (max(c.num_embeddings for c in self._configs), max(c.embedding_dim for c in self._configs))
+
+    def _n_positions(self, kjt: KeyedJaggedTensor) -> int:
+        """Capacity of the backward plan's table-major position space: every lookup (key -> table)
+        contributes its key's ids, so a key read through k tables counts k times."""
+        if kjt.uniform_length() is not None:
+            return len(self._lookups) * kjt.stride() * kjt.uniform_length()
+        mult: Dict[str, int] = {}
+        for lk in self._lookups:
+            mult[lk.key] = mult.get(lk.key, 0) + 1
+        return kjt.values().numel() * max(mult.values())
+
+    def plan_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> torch.Tensor:
+        """K6: build the backward index plan for this batch (depends on ids only, so callers may run
+        it early on a side stream).  Returns the workspace holding the plan."""
+        layout = self._layout_for(dst_names)
+        meta = self._meta(kjt.keys(), layout)
+        L = _lib.lib()
+        B, N = kjt.stride(), kjt.values().numel()
+        uniform, offsets = self._kjt_args(kjt)
+        max_rows, max_dim = self._bwd_dims()
+        NP = self._n_positions(kjt)
+        nbytes = L.tzr_pooled_bwd_workspace(N, NP, len(self._lookups), len(self._configs), B, max_dim)
+        ws = _lib.workspace(nbytes, self._device)
+        rc = L.tzr_pooled_bwd_plan(
+            _lib.ptr(meta.d_tables), len(self._configs), _lib.ptr(meta.d_feats), len(self._lookups),
+            meta.n_keys, max_rows, max_dim, _lib.ptr(kjt.values()), _lib.ptr(offsets), N, NP, B,
+            1 if uniform else 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
+        )
+        _lib.check(rc, "tzr_pooled_bwd_plan")
+        kjt._tzr_plan = (id(self), dst_names, ws)  # type: ignore[attr-defined]
+        return ws
+
+    def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
+        if self.fused_optimizer is None:
+            return  # frozen tables
+        cached = getattr(kjt, "_tzr_plan", None)
+        if cached is not None and cached[0] == id(self) and cached[1] == dst_names:
+            ws = cached[2]
+        else:
+            ws = self.plan_backward(kjt, dst_names)
+        layout = self._layout_for(dst_names)
+        meta = self._meta(kjt.keys(), layout)
+        B, N = kjt.stride(), kjt.values().numel()
+        uniform, offsets = self._kjt_args(kjt)
+        _, max_dim = self._bwd_dims()
+        widths = [sum(self._out_dim[k] for k in ks) for _, ks in layout]
+        gl = []
+        for g, w in zip(grads, widths):
+            if g is None:
+                g = torch.zeros(B, w, dtype=torch.float32, device=self._device)
+            g = g.contiguous()
+            if g.dtype != torch.float32:
+                g = g.float()
+            gl.append(g)
+        gd = (_lib.TzrDst * len(gl))()
+        for i, g in enumerate(gl):
+            gd[i].ptr = _lib.ptr(g)
+            gd[i].stride = g.stride(0)
+        cfg = self._opt_cfg
+        opt = _lib.TzrSparseOptim()
+        opt.kind = _OPT_KIND[cfg.kind]
+        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
+        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(self._device))
+        opt.eps = cfg.eps
+        opt.weight_decay = cfg.weight_decay
+        opt.max_gradient = cfg.max_gradient
+        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        rc = _lib.lib().tzr_pooled_bwd_apply(
+            _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), len(self._configs),
+            max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
+            1 if uniform else 0,
+            gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
+        )
+        _lib.check(rc, "tzr_pooled_bwd_apply")
+        kjt._tzr_plan = None  # type: ignore[attr-defined]
+
+    def _run(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
+        if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
+            return list(_PooledLookupFn.apply(self, kjt, dst_names, self._hook))
+        return self._launch_forward(kjt, dst_names)
+
+    # -- public API --------------------------------------------------------------------------
+    def forward(self, features: KeyedJaggedTensor) -> KeyedTensor:
+        """``self.ebc(kjt)`` of the reference: KeyedTensor [B, sum D] in table-then-feature order."""
+        (out,) = self._run(features, ("__all__",))
+        keys = [lk.out_key for lk in self._lookups]
+        return KeyedTensor(keys, [self._out_dim[k] for k in keys], out)
+
+    def forward_grouped(self, features: KeyedJaggedTensor, group_names: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:
+        """Pooled lookup written directly in feature-group layout (fuses regroup_as_dict)."""
+        if self._groups is None:
+            raise ValueError("EmbeddingBagCollection was built without groups")
+        names = tuple(group_names) if group_names is not None else tuple(self._groups)
+        outs = self._run(features, names)
+        return dict(zip(names, outs))
+
+    def bounds_check(self, features: KeyedJaggedTensor, mode: int = _lib.BOUNDS_WARNING) -> torch.Tensor:
+        """K4; returns the device counter (int64[1]) of out-of-range ids."""
+        meta = self._meta(features.keys(), self._default_layout())
+        cnt = torch.zeros(1, dtype=torch.int64, device=self._device)
+        rc = _lib.lib().tzr_bounds_check(
+            _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
+            _lib.ptr(features.values()), _lib.ptr(features.offsets()), features.stride(), mode,
+            _lib.ptr(cnt), _lib.stream_ptr(self._device),
+        )
+        _lib.check(rc, "tzr_bounds_check")
+        return cnt

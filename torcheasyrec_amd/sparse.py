@@ -1,0 +1,255 @@
+"""KeyedJaggedTensor / KeyedTensor containers with torchrec's field semantics.
+
+tzrec hands the embedding stack a ``torchrec.sparse.jagged_tensor.KeyedJaggedTensor`` built at
+/root/reference/tzrec/datasets/data_parser.py:576-585 (keys, values int64 key-major, lengths per
+(key, sample), optional weights, stride = B) and reads ``.keys() / .values() / .lengths() /
+.offsets() / .weights_or_none() / .stride() / .length_per_key()`` from it; pooled output comes back
+as a ``KeyedTensor`` (``.keys() / .length_per_key() / .values()``,
+/root/reference/tzrec/modules/embedding.py:943-947).  These classes keep those names and meanings;
+the offsets scan (K3) and the key permute (K1) run on the gfx950 kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+class KeyedTensor:
+    """Dense [B, sum(length_per_key)] tensor with named column blocks."""
+
+    def __init__(self, keys: Sequence[str], length_per_key: Sequence[int], values: torch.Tensor):
+        self._keys = list(keys)
+        self._length_per_key = [int(x) for x in length_per_key]
+        self._values = values
+
+    def keys(self) -> List[str]:
+        return self._keys
+
+    def length_per_key(self) -> List[int]:
+        return self._length_per_key
+
+    def values(self) -> torch.Tensor:
+        return self._values
+
+    def offset_per_key(self) -> List[int]:
+        out = [0]
+        for n in self._length_per_key:
+            out.append(out[-1] + n)
+        return out
+
+    def to_dict(self) -> Dict[str, torch.Tensor]:
+        off = self.offset_per_key()
+        return {k: self._values[:, off[i] : off[i + 1]] for i, k in enumerate(self._keys)}
+
+    def to(self, device, non_blocking: bool = False) -> "KeyedTensor":
+        return KeyedTensor(self._keys, self._length_per_key, self._values.to(device, non_blocking=non_blocking))
+
+    def record_stream(self, stream) -> None:
+        if self._values.is_cuda:
+            self._values.record_stream(stream)
+
+    @staticmethod
+    def regroup_as_dict(
+        keyed_tensors: Sequence["KeyedTensor"], groups: Sequence[Sequence[str]], keys: Sequence[str]
+    ) -> Dict[str, torch.Tensor]:
+        """Column-concat of each group's blocks (torchrec KeyedTensor.regroup_as_dict as used at
+        /root/reference/tzrec/modules/embedding.py:972-976).  The pooled-embedding blocks never take
+        this route in this package (the forward kernel writes group layout directly); it serves
+        the dense KeyedTensor and tests."""
+        blocks: Dict[str, torch.Tensor] = {}
+        for kt in keyed_tensors:
+            blocks.update(kt.to_dict())
+        return {name: torch.cat([blocks[k] for k in group], dim=1) for name, group in zip(keys, groups)}
+
+
+class KeyedJaggedTensor:
+    """Jagged ids for F keys x B samples, key-major (torchrec KJT field semantics)."""
+
+    def __init__(
+        self,
+        keys: Sequence[str],
+        values: torch.Tensor,
+        lengths: Optional[torch.Tensor] = None,
+        weights: Optional[torch.Tensor] = None,
+        offsets: Optional[torch.Tensor] = None,
+        stride: Optional[int] = None,
+        length_per_key: Optional[Sequence[int]] = None,
+        uniform_length: Optional[int] = None,
+    ) -> None:
+        self._keys = list(keys)
+        self._values = values
+        self._weights = weights
+        self._lengths = lengths
+        self._offsets = offsets
+        if stride is None:
+            if lengths is not None:
+                stride = lengths.numel() // max(len(self._keys), 1)
+            elif offsets is not None:
+                stride = (offsets.numel() - 1) // max(len(self._keys), 1)
+            else:
+                raise ValueError("KeyedJaggedTensor needs lengths, offsets or stride")
+        self._stride = int(stride)
+        self._length_per_key = list(length_per_key) if length_per_key is not None else None
+        # Host-side hint: every bag has exactly this many ids (1 for Criteo).  Known for free when
+        # the batch is assembled on CPU (dataloader workers); lets the kernels skip the offsets.
+        if uniform_length is None and lengths is not None and lengths.device.type == "cpu":
+            n = lengths.numel()
+            if n > 0 and values.numel() == n and bool((lengths == 1).all()):
+                uniform_length = 1
+        self._uniform_length = uniform_length
+
+    # -- torchrec accessors ----------------------------------------------------------------
+    def keys(self) -> List[str]:
+        return self._keys
+
+    def values(self) -> torch.Tensor:
+        return self._values
+
+    def weights_or_none(self) -> Optional[torch.Tensor]:
+        return self._weights
+
+    def weights(self) -> torch.Tensor:
+        if self._weights is None:
+            raise ValueError("KeyedJaggedTensor has no weights")
+        return self._weights
+
+    def stride(self) -> int:
+        return self._stride
+
+    def uniform_length(self) -> Optional[int]:
+        return self._uniform_length
+
+    def lengths(self) -> torch.Tensor:
+        if self._lengths is None:
+            assert self._offsets is not None
+            self._lengths = (self._offsets[1:] - self._offsets[:-1]).to(torch.int32)
+        return self._lengths
+
+    def offsets(self) -> torch.Tensor:
+        """[0] + cumsum(lengths), int64[F*B+1]: K3 on the device (fbgemm
+        asynchronous_complete_cumsum in the reference)."""
+        if self._offsets is None:
+            self._offsets = lengths_to_offsets(self.lengths())
+        return self._offsets
+
+    def offsets_or_none(self) -> Optional[torch.Tensor]:
+        return self._offsets
+
+    def length_per_key(self) -> List[int]:
+        if self._length_per_key is None:
+            off = self.offsets()[:: self._stride].cpu().tolist() if self._stride > 0 else [0] * (len(self._keys) + 1)
+            self._length_per_key = [int(off[i + 1] - off[i]) for i in range(len(self._keys))]
+        return self._length_per_key
+
+    @property
+    def device(self) -> torch.device:
+        return self._values.device
+
+    @staticmethod
+    def from_lengths_sync(keys, values, lengths, weights=None) -> "KeyedJaggedTensor":
+        return KeyedJaggedTensor(keys=keys, values=values, lengths=lengths, weights=weights)
+
+    # -- Pipelineable contract (tzrec Batch.to / record_stream, datasets/utils.py:344-408) ----
+    def to(self, device, non_blocking: bool = False) -> "KeyedJaggedTensor":
+        mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
+        return KeyedJaggedTensor(
+            self._keys, mv(self._values), mv(self._lengths), mv(self._weights), mv(self._offsets),
+            self._stride, self._length_per_key, self._uniform_length,
+        )
+
+    def pin_memory(self) -> "KeyedJaggedTensor":
+        pin = lambda t: None if t is None else t.pin_memory()  # noqa: E731
+        return KeyedJaggedTensor(
+            self._keys, pin(self._values), pin(self._lengths), pin(self._weights), pin(self._offsets),
+            self._stride, self._length_per_key, self._uniform_length,
+        )
+
+    def record_stream(self, stream) -> None:
+        for t in (self._values, self._lengths, self._weights, self._offsets):
+            if t is not None and t.is_cuda:
+                t.record_stream(stream)
+
+    # -- K1 --------------------------------------------------------------------------------
+    def permute(self, indices: Sequence[int]) -> "KeyedJaggedTensor":
+        """Output key t = input key indices[t] (torchrec KJT.permute -> fbgemm
+        permute_2D_sparse_data)."""
+        B, F, T = self._stride, len(self._keys), len(indices)
+        dev = self.device
+        lengths = self.lengths()
+        in_off = self.offsets()
+        lpk = self._length_per_key
+        if lpk is not None:
+            n_out = int(sum(lpk[i] for i in indices))
+        elif self._uniform_length is not None:
+            n_out = T * B * self._uniform_length
+        elif sorted(indices) == list(range(F)):
+            n_out = self._values.numel()
+        else:
+            n_out = int(sum(self.length_per_key()[i] for i in indices))  # host sync, like torchrec
+        perm = torch.tensor(list(indices), dtype=torch.int32, device=dev)
+        out_lengths = torch.empty(T * B, dtype=lengths.dtype, device=dev)
+        out_offsets = torch.empty(T * B + 1, dtype=torch.int64, device=dev)
+        out_values = torch.empty(n_out, dtype=torch.int64, device=dev)
+        out_weights = None if self._weights is None else torch.empty(n_out, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws_bytes = L.tzr_kjt_permute_workspace(T, B)
+        ws = _lib.workspace(ws_bytes, dev)
+        rc = L.tzr_kjt_permute(
+            _lib.ptr(perm), T, F, B, _lib.ptr(lengths), lengths.element_size(), _lib.ptr(in_off),
+            _lib.ptr(self._values), _lib.ptr(self._weights), _lib.ptr(out_lengths),
+            _lib.ptr(out_offsets), _lib.ptr(out_values), _lib.ptr(out_weights), n_out,
+            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev),
+        )
+        _lib.check(rc, "tzr_kjt_permute")
+        return KeyedJaggedTensor(
+            [self._keys[i] for i in indices], out_values, out_lengths, out_weights, out_offsets, B,
+            None if lpk is None else [lpk[i] for i in indices], self._uniform_length,
+        )
+
+
+def lengths_to_offsets(lengths: torch.Tensor) -> torch.Tensor:
+    """K3: exclusive scan of int32/int64 lengths into int64 offsets[n+1]."""
+    assert lengths.dtype in (torch.int32, torch.int64) and lengths.is_contiguous()
+    n = lengths.numel()
+    dev = lengths.device
+    out = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_lengths_to_offsets_workspace(n), dev)
+    rc = L.tzr_lengths_to_offsets(
+        _lib.ptr(lengths), lengths.element_size(), n, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+        _lib.stream_ptr(dev),
+    )
+    _lib.check(rc, "tzr_lengths_to_offsets")
+    return out
+
+
+def block_bucketize(
+    kjt: KeyedJaggedTensor, block_sizes: torch.Tensor, world_size: int, return_permute: bool = False
+):
+    """K2: split every bag by owning rank (row-wise sharding).  Returns a KJT with W*F keys
+    (rank-major) and, optionally, unbucketize_permute (fbgemm block_bucketize_sparse_features)."""
+    B, F, W = kjt.stride(), len(kjt.keys()), int(world_size)
+    dev = kjt.device
+    values, weights = kjt.values(), kjt.weights_or_none()
+    offsets = kjt.offsets()
+    lengths = kjt.lengths()
+    n = values.numel()
+    new_lengths = torch.empty(W * F * B, dtype=lengths.dtype, device=dev)
+    new_offsets = torch.empty(W * F * B + 1, dtype=torch.int64, device=dev)
+    new_values = torch.empty(n, dtype=torch.int64, device=dev)
+    new_weights = None if weights is None else torch.empty(n, dtype=torch.float32, device=dev)
+    unbucketize = torch.empty(n, dtype=torch.int64, device=dev) if return_permute else None
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_block_bucketize_workspace(F, B, W), dev)
+    rc = L.tzr_block_bucketize(
+        _lib.ptr(block_sizes), F, B, W, _lib.ptr(offsets), _lib.ptr(values), _lib.ptr(weights), n,
+        _lib.ptr(new_lengths), lengths.element_size(), _lib.ptr(new_offsets), _lib.ptr(new_values),
+        _lib.ptr(new_weights), _lib.ptr(unbucketize), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev),
+    )
+    _lib.check(rc, "tzr_block_bucketize")
+    keys = [f"{k}@{r}" for r in range(W) for k in kjt.keys()]
+    out = KeyedJaggedTensor(keys, new_values, new_lengths, new_weights, new_offsets, B)
+    return (out, unbucketize) if return_permute else out
