@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""DLRM-Criteo training throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of examples/dlrm_criteo.config (26 tables x dim 16, 204M rows,
+fused sparse Adagrad in backward, bottom/top MLPs, dot interaction, BCE, dense Adam) over one
+synthetic Criteo-shaped batch.  Headline workload: GLOBAL batch 65536 (65536/N per rank; strong
+scaling) with inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      HBM roofline of the dominant embedding kernel (pooled gather forward), achieved =
+                algorithmic bytes of one launch / average launch duration from HIP events recorded
+                around the launch inside the timed steps; peak 8.0 TB/s.
+  embedding     the north-star figure: algorithmic fwd+bwd bytes / (fwd + plan + apply time).
+  cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample of the workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured copy ceiling
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--global-batch", type=int, default=65536)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--optimizer", choices=["adagrad", "rowwise_adagrad"], default="adagrad")
+    ap.add_argument("--row-layout", choices=["interleaved", "split"], default="interleaved")
+    ap.add_argument("--rows-cap", type=int, default=0, help="debug: cap table rows (0 = real 40M tables)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
+    ap.add_argument("--tune", action="append", default=[], help="name=value passed to tzr_tune")
+    return ap.parse_args()
+
+
+class _Timers:
+    """HIP events around launches on torch's current stream (the stream the kernels run on)."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def start(self, name):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pairs.setdefault(name, []).append((e0, e1))
+        return e1
+
+    def mean_ms(self, name):
+        ps = self.pairs.get(name, [])
+        return float(np.mean([a.elapsed_time(b) for a, b in ps])) if ps else None
+
+
+def cpu_baseline(seconds: float):
+    """CPU oracle train step (oracle/tzrec_oracle.py, kind "port") on a bounded sample:
+    per-rank batch 8192, the five 40M-row tables scaled to 4M rows so the host holds them."""
+    from oracle import tzrec_oracle as orc
+    from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, synthetic_batch
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    rows = [min(r, 4_000_000) for r in CRITEO_ROWS]
+    B = 8192
+    g = torch.Generator().manual_seed(0)
+    W = [(torch.rand(r, 16, generator=g) * 2 - 1) * (1.0 / r) ** 0.5 for r in rows]
+    M = [np.zeros((r, 16), np.float32) for r in rows]
+
+    def mk(i, o):
+        return [(torch.randn(b, a, generator=g) * (1.0 / a) ** 0.5).requires_grad_(True) for a, b in zip(i, o)]
+
+    dw, fw = mk([NUM_DENSE, 64], [64, 16]), mk([783, 64], [64, 32])
+    db = [torch.zeros(64, requires_grad=True), torch.zeros(16, requires_grad=True)]
+    fb = [torch.zeros(64, requires_grad=True), torch.zeros(32, requires_grad=True)]
+    ow, ob = torch.randn(1, 32, generator=g).requires_grad_(True), torch.zeros(1, requires_grad=True)
+    params = dw + db + fw + fb + [ow, ob]
+    adam = torch.optim.Adam(params, lr=1e-3)
+    p = {"dim": 16, "dense_mlp": list(zip(dw, db)), "final_mlp": list(zip(fw, fb)), "output": (ow, ob),
+         "arch_with_sparse": True}
+    opt = orc.SparseOptim(kind="adagrad", lr=1e-3)
+    batches = [synthetic_batch(s, B, rows) for s in range(4)]
+
+    def step(i):
+        dense, kjt, label = batches[i % len(batches)]
+        blocks = [b.requires_grad_(True) for b in orc.pooled_lookup(W, ["sum"] * 26, kjt.values(), kjt.lengths(), B)]
+        loss = orc.bce_with_logits(orc.dlrm_forward(dense, torch.cat(blocks, dim=1), p), label)
+        adam.zero_grad()
+        grads = torch.autograd.grad(loss, blocks + params)
+        for q, gq in zip(params, grads[26:]):
+            q.grad = gq
+        adam.step()
+        vals = kjt.values().numpy()
+        for t in range(26):
+            w = W[t].numpy()
+            orc.sparse_update(w, M[t], vals[t * B:(t + 1) * B], grads[t].numpy(), opt)
+
+    step(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(n + 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {"value": n * B / el, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of the CPU oracle at batch {B}, 40M-row tables scaled to 4M rows, {el:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from torcheasyrec_amd import _build, _lib
+    from torcheasyrec_amd.criteo import (CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, algorithmic_bytes,
+                                         criteo_tables, synthetic_batch)
+    from torcheasyrec_amd.dlrm import DLRM, bce_with_logits
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+
+    _lib.use_library(_build.build())
+    assert _lib.backend() == "hip-gfx950"
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().tzr_tune(k.encode(), int(v)), f"tzr_tune {kv}")
+
+    rows = [min(r, args.rows_cap) for r in CRITEO_ROWS] if args.rows_cap else list(CRITEO_ROWS)
+    B_global = args.global_batch if args.scaling == "strong" else args.global_batch * world
+    B_local = B_global // world
+    torch.manual_seed(1234)
+    sopt = SparseOptimizerConfig(kind=args.optimizer, lr=1e-3)
+    if world == 1:
+        model = DLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
+                     row_layout=args.row_layout)
+        parallelism = "single GPU, all tables local (table-wise on one rank)"
+    else:
+        from torcheasyrec_amd.sharding import ShardedDLRM
+
+        model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
+                            row_layout=args.row_layout)
+        parallelism = model.describe()
+    dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True)
+
+    # synthetic batches, resident in HBM before the timed region
+    nb = max(1, min(args.n_batches, args.warmup + args.steps))
+    batches, host_vals = [], []
+    for s in range(nb):
+        dense, kjt, label = synthetic_batch(s, B_global, rows, dist=args.dist)
+        if world > 1:  # this rank's slice of the global batch
+            sl = slice(rank * B_local, (rank + 1) * B_local)
+            v = kjt.values().view(len(rows), B_global)[:, sl].reshape(-1).contiguous()
+            from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+            kjt = KeyedJaggedTensor(kjt.keys(), v, torch.ones(len(rows) * B_local, dtype=torch.int32), uniform_length=1)
+            dense, label = dense[sl].contiguous(), label[sl].contiguous()
+        host_vals.append(kjt.values().numpy())
+        batches.append((dense.to(dev), kjt.to(dev), label.to(dev)))
+    torch.cuda.synchronize()
+
+    timers = _Timers()
+    ebc = model.ebc if world == 1 else None
+
+    def train_step(i, timed):
+        dense, kjt, label = batches[i % nb]
+        if timed and ebc is not None:
+            ebc._timers = timers
+        logits = model(dense, kjt)
+        loss = bce_with_logits(logits, label)
+        loss.backward()
+        dense_opt.step()
+        dense_opt.zero_grad(set_to_none=True)
+        if ebc is not None:
+            ebc._timers = None
+        return loss
+
+    for i in range(args.warmup):
+        train_step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B_global * args.steps / elapsed
+
+    out = {
+        "metric": "samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, global batch 65536",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dlrm_criteo: 26 tables x dim 16 (204.2M rows, fp32), fused sparse "
+                               f"{args.optimizer} + dense Adam, ids {args.dist}",
+                   "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism,
+                   "row_layout": args.row_layout, "rows_cap": args.rows_cap or None},
+        "final_loss": float(loss.item()),
+    }
+    if rank == 0 and world == 1:
+        ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]
+        fwd_b = float(np.mean([a["fwd"] for a in ab]))
+        bwd_b = float(np.mean([a["bwd"] for a in ab]))
+        t_fwd, t_plan, t_apply = timers.mean_ms("fwd"), timers.mean_ms("plan"), timers.mean_ms("apply")
+        if t_fwd:
+            ach = fwd_b / (t_fwd * 1e-3)
+            out["roofline"] = {"bound": "hbm", "kernel": "tzr_pooled_fwd_kernel", "achieved": ach / 1e9,
+                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                               "traffic": None, "launch_ms": t_fwd, "algorithmic_bytes": fwd_b}
+        if t_fwd and t_plan is not None and t_apply:
+            tot = (t_fwd + t_plan + t_apply) * 1e-3
+            out["embedding"] = {
+                "fwd_ms": t_fwd, "bwd_plan_ms": t_plan, "bwd_apply_ms": t_apply,
+                "algorithmic_bytes_fwd": fwd_b, "algorithmic_bytes_bwd": bwd_b,
+                "unique_rows": float(np.mean([a["U"] for a in ab])),
+                "fwd_bwd_GBps": (fwd_b + bwd_b) / tot / 1e9, "frac_of_8TBps": (fwd_b + bwd_b) / tot / HBM_PEAK,
+                "apply_GBps": bwd_b / (t_apply * 1e-3) / 1e9,
+            }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""End-to-end DLRM / DeepFM train step vs the oracle: logits and loss within 1e-5 relative
+(north_star), updated tables within the fused-optimizer tolerance."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch  # noqa: E402
+from torcheasyrec_amd.dlrm import DLRM, DeepFM, bce_with_logits  # noqa: E402
+from torcheasyrec_amd.embedding import EmbeddingBagConfig, SparseOptimizerConfig  # noqa: E402
+
+
+def _lin(seq):
+    return [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seq if hasattr(m, "weight")]
+
+
+@pytest.mark.parametrize("kind,dist", [("adagrad", "uniform"), ("rowwise_adagrad", "zipf")])
+def test_dlrm_criteo_step(dev, kind, dist):
+    torch.manual_seed(1)
+    rows = [min(r, 3000) for r in CRITEO_ROWS]
+    B, lr = 96, 0.05
+    model = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev,
+                 sparse_optimizer=SparseOptimizerConfig(kind=kind, lr=lr))
+    dense, kjt, label = synthetic_batch(3, B, rows, dist=dist)
+    w0 = {n: w.detach().cpu().clone() for n, w in model.ebc.table_weights().items()}
+    logits = model(dense.to(dev), kjt.to(dev))
+    loss = bce_with_logits(logits, label.to(dev))
+    loss.backward()
+    dense_grads = [p.grad.detach().cpu().clone() for p in model.dense_parameters()]
+
+    tabs = [w0[f"{k}_emb"] for k in SPARSE_KEYS]
+    blocks = [b.clone().requires_grad_(True)
+              for b in orc.pooled_lookup(tabs, ["sum"] * 26, kjt.values(), kjt.lengths(), B)]
+    cpu_params = [p.detach().cpu().clone().requires_grad_(True) for p in model.dense_parameters()]
+    it = iter(cpu_params)
+    nd, nf = len(_lin(model.dense_mlp.mlp)), len(_lin(model.final_mlp.mlp))
+    p = {"dim": 16,
+         "dense_mlp": [(next(it), next(it)) for _ in range(nd)],
+         "final_mlp": [(next(it), next(it)) for _ in range(nf)],
+         "output": (next(it), next(it)), "arch_with_sparse": True}
+    ref_logits = orc.dlrm_forward(dense, torch.cat(blocks, dim=1), p)
+    ref_loss = orc.bce_with_logits(ref_logits, label)
+    grads = torch.autograd.grad(ref_loss, blocks + cpu_params)
+    block_grads, ref_dense_grads = grads[:26], grads[26:]
+    torch.testing.assert_close(logits.detach().cpu(), ref_logits.detach(), rtol=1e-5, atol=1e-5)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()) + 1e-7
+    for g, r in zip(dense_grads, ref_dense_grads):
+        torch.testing.assert_close(g, r, rtol=1e-4, atol=1e-6)
+    opt = orc.SparseOptim(kind=kind, lr=lr)
+    for t, k in enumerate(SPARSE_KEYS):
+        w = w0[f"{k}_emb"].numpy().copy()
+        m = np.zeros_like(w) if kind == "adagrad" else np.zeros(w.shape[0], np.float32)
+        orc.sparse_update(w, m, kjt.values().numpy()[t * B:(t + 1) * B], block_grads[t].numpy(), opt)
+        got = model.ebc.table_weights()[f"{k}_emb"].detach().cpu().numpy()
+        np.testing.assert_allclose(got, w, rtol=2e-4, atol=5e-6, err_msg=k)
+
+
+def test_deepfm_forward_backward(dev):
+    """DeepFM on Criteo-shaped groups: wide tables `*_emb_wide` (dim 4), fm/deep share `*_emb`."""
+    torch.manual_seed(2)
+    nfeat, B = 6, 40
+    rows = [50, 3, 1000, 7, 400, 12]
+    keys = SPARSE_KEYS[:nfeat]
+    g = torch.Generator().manual_seed(9)
+    init = {}
+    tables = []
+    for suffix, dim in (("_emb", 16), ("_emb_wide", 4)):
+        for k, r in zip(keys, rows):
+            w = (torch.rand(r, dim, generator=g) - 0.5) * 0.3
+            init[f"{k}{suffix}"] = w
+            tables.append(EmbeddingBagConfig(f"{k}{suffix}", dim, r, [k], "sum", init_fn=lambda t, w=w: t.copy_(w)))
+    groups = {"wide": [f"{k}@{k}_emb_wide" for k in keys], "fm": [f"{k}@{k}_emb" for k in keys],
+              "deep": [f"{k}@{k}_emb" for k in keys]}
+    model = DeepFM(tables, groups, NUM_DENSE, 16, deep_mlp=(32, 16), final_mlp=(8,), device=dev,
+                   sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.01))
+    dense, kjt, label = synthetic_batch(1, B, rows)
+    logits = model(dense.to(dev), kjt.to(dev))
+    loss = bce_with_logits(logits, label.to(dev))
+    loss.backward()
+
+    deep_t = [init[f"{k}_emb"] for k in keys]
+    wide_t = [init[f"{k}_emb_wide"] for k in keys]
+    bd = orc.pooled_lookup(deep_t, ["sum"] * nfeat, kjt.values(), kjt.lengths(), B)
+    bw = orc.pooled_lookup(wide_t, ["sum"] * nfeat, kjt.values(), kjt.lengths(), B)
+    p = {"dim": 16, "deep_mlp": _lin(model.deep_mlp.mlp), "final_mlp": _lin(model.final_mlp.mlp),
+         "output": (model.output_mlp.weight.detach().cpu(), model.output_mlp.bias.detach().cpu())}
+    emb = torch.cat(bd, dim=1)
+    ref = orc.deepfm_forward(torch.cat(bw, dim=1), emb, torch.cat([dense, emb], dim=1), p)
+    torch.testing.assert_close(logits.detach().cpu(), ref, rtol=1e-5, atol=1e-5)
+    # tables moved
+    for k in keys:
+        assert not torch.equal(model.ebc.table_weights()[f"{k}_emb"].detach().cpu(), init[f"{k}_emb"])

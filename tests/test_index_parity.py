@@ -1,0 +1,98 @@
+"""Index stage (K1-K4): bit-exact against the oracle, incl. empty / ragged / boundary cases."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd import _lib  # noqa: E402
+from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor, block_bucketize, lengths_to_offsets  # noqa: E402
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2048, 2049, 70000])
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+def test_lengths_to_offsets(dev, n, dtype):
+    if n == 70000 and dev.type == "cpu" and dtype == torch.int64:
+        pytest.skip("covered by int32 on the emulator")
+    rng = np.random.default_rng(n)
+    lengths = torch.from_numpy(rng.integers(0, 9, size=n)).to(dtype)
+    got = lengths_to_offsets(lengths.to(dev)).cpu().numpy()
+    ref = orc.lengths_to_offsets(lengths.numpy())
+    assert got.dtype == np.int64 and np.array_equal(got, ref)
+
+
+def _rand_kjt(rng, F, B, max_len, rows, weighted):
+    lens = rng.integers(0, max_len + 1, size=F * B).astype(np.int32)
+    if B > 3:
+        lens[rng.integers(0, F * B, size=F)] = 0
+    vals = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
+    w = rng.uniform(0, 1, size=len(vals)).astype(np.float32) if weighted else None
+    keys = [f"k{i}" for i in range(F)]
+    return keys, vals, lens, w
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("perm", [[2, 0, 1, 3], [3, 3, 0], [1], [0, 1, 2, 3]])
+def test_kjt_permute(dev, perm, weighted):
+    rng = np.random.default_rng(len(perm))
+    F, B = 4, 33
+    keys, vals, lens, w = _rand_kjt(rng, F, B, 5, 1000, weighted)
+    kjt = KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(lens),
+                            torch.from_numpy(w) if weighted else None).to(dev)
+    out = kjt.permute(perm)
+    rl, rv, rw = orc.kjt_permute(perm, lens, vals, w, B)
+    assert out.keys() == [keys[i] for i in perm]
+    assert np.array_equal(out.lengths().cpu().numpy(), rl)
+    assert np.array_equal(out.values().cpu().numpy(), rv)
+    assert np.array_equal(out.offsets().cpu().numpy(), orc.lengths_to_offsets(rl))
+    if weighted:
+        assert np.array_equal(out.weights().cpu().numpy(), rw)
+
+
+@pytest.mark.parametrize("W", [1, 2, 8])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_block_bucketize(dev, W, weighted):
+    rng = np.random.default_rng(W)
+    F, B = 3, 41
+    rows = [1000, 17, 40_000_000]
+    keys = [f"k{i}" for i in range(F)]
+    lens = rng.integers(0, 5, size=F * B).astype(np.int32)
+    off = orc.lengths_to_offsets(lens)
+    vals = np.concatenate([rng.integers(0, rows[f], size=int(off[(f + 1) * B] - off[f * B])) for f in range(F)]).astype(np.int64)
+    w = rng.uniform(0, 1, size=len(vals)).astype(np.float32) if weighted else None
+    block = np.array([(r + W - 1) // W for r in rows], dtype=np.int64)  # ceil(rows / W)
+    kjt = KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(lens),
+                            torch.from_numpy(w) if weighted else None).to(dev)
+    out, unb = block_bucketize(kjt, torch.from_numpy(block).to(dev), W, return_permute=True)
+    rl, rv, rw, ru = orc.block_bucketize(block, lens, vals, w, B, W)
+    assert np.array_equal(out.lengths().cpu().numpy(), rl)
+    assert np.array_equal(out.values().cpu().numpy(), rv)
+    assert np.array_equal(unb.cpu().numpy(), ru)
+    if weighted:
+        assert np.array_equal(out.weights().cpu().numpy(), rw)
+    # owner rank r only ever sees local ids inside its block
+    no = orc.lengths_to_offsets(rl)
+    for r in range(W):
+        for f in range(F):
+            seg = rv[no[(r * F + f) * B]: no[(r * F + f + 1) * B]]
+            assert (seg >= 0).all() and (seg < block[f]).all()
+
+
+@pytest.mark.parametrize("mode", [_lib.BOUNDS_FATAL, _lib.BOUNDS_WARNING, _lib.BOUNDS_IGNORE])
+def test_bounds_check(dev, mode):
+    rng = np.random.default_rng(7)
+    B = 50
+    cfgs = [EmbeddingBagConfig("t0", 16, 10, ["a"]), EmbeddingBagConfig("t1", 16, 1000, ["b"])]
+    ebc = EmbeddingBagCollection(cfgs, device=dev)
+    lens = rng.integers(0, 4, size=2 * B).astype(np.int32)
+    off = orc.lengths_to_offsets(lens)
+    vals = np.concatenate([rng.integers(-2, 14, size=int(off[B])), rng.integers(990, 1010, size=int(off[2 * B] - off[B]))]).astype(np.int64)
+    kjt = KeyedJaggedTensor(["a", "b"], torch.from_numpy(vals.copy()), torch.from_numpy(lens)).to(dev)
+    cnt = ebc.bounds_check(kjt, mode)
+    ref_vals, ref_bad = orc.bounds_check(vals, off, [10, 1000], B, clamp=mode != _lib.BOUNDS_FATAL)
+    assert int(cnt.item()) == (0 if mode == _lib.BOUNDS_IGNORE else ref_bad)
+    assert np.array_equal(kjt.values().cpu().numpy(), ref_vals)

@@ -1,0 +1,91 @@
+"""K9 dot interaction and K10 FM against the oracle restatement of the reference modules
+(/root/reference/tzrec/modules/interaction.py:57-91, fm.py:17-42).  fp32, 1e-5 relative."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.interaction import FactorizationMachine, InteractionArch, dot_interaction  # noqa: E402
+
+RTOL, ATOL = 1e-5, 1e-5
+
+
+@pytest.mark.parametrize("N", [2, 4, 16, 17, 27, 32])
+@pytest.mark.parametrize("B", [1, 5, 130])
+def test_interaction_arch_forward_backward(dev, N, B):
+    g = torch.Generator().manual_seed(N * 1000 + B)
+    x = torch.randn(B, N, 16, generator=g)
+    # asymmetric rows so a transposed fragment map cannot pass
+    x = x * torch.linspace(0.5, 1.5, N).view(1, N, 1)
+    m = InteractionArch(N)
+    assert m.output_dim() == N * (N - 1) // 2
+    xd = x.clone().to(dev).requires_grad_(True)
+    out = m(xd)
+    xr = x.clone().requires_grad_(True)
+    ref = orc.dot_interaction(xr)
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    go = torch.randn(ref.shape, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
+
+
+def test_shape_fixture_from_reference(dev):
+    """tzrec/modules/interaction_test.py:47-54: feature_num=4 -> output (10, 6)."""
+    m = InteractionArch(4)
+    out = m(torch.randn(10, 4, 16).to(dev))
+    assert tuple(out.shape) == (10, 6)
+
+
+@pytest.mark.parametrize("cat_dense,cat_sparse", [(True, True), (True, False), (False, True), (False, False)])
+def test_fused_dlrm_interaction(dev, cat_dense, cat_sparse):
+    """[interactions | dense | sparse] exactly as DLRM.predict concatenates it
+    (/root/reference/tzrec/models/dlrm.py:123-130)."""
+    B, F, D = 77, 26, 16
+    g = torch.Generator().manual_seed(3)
+    dense = torch.randn(B, D, generator=g)
+    sparse = torch.randn(B, F * D, generator=g)
+    dd = dense.clone().to(dev).requires_grad_(True)
+    sd = sparse.clone().to(dev).requires_grad_(True)
+    out = dot_interaction(dd, sd, D, cat_dense, cat_sparse)
+    dr = dense.clone().requires_grad_(True)
+    sr = sparse.clone().requires_grad_(True)
+    feat = torch.cat([dr.unsqueeze(1), sr.reshape(B, F, D)], dim=1)
+    parts = [orc.dot_interaction(feat)]
+    if cat_dense:
+        parts.append(dr)
+    if cat_sparse:
+        parts.append(sr)
+    ref = torch.cat(parts, dim=-1)
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    if cat_dense and cat_sparse:
+        assert out.shape[1] == 783  # 351 + 16 + 416, the DLRM-Criteo final-MLP input
+        assert torch.equal(out.detach().cpu()[:, 351:367], dense)  # pass-through is a copy
+        assert torch.equal(out.detach().cpu()[:, 367:], sparse)
+    go = torch.randn(ref.shape, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    torch.testing.assert_close(dd.grad.cpu(), dr.grad, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("B,F,D", [(4, 26, 16), (1, 3, 4), (300, 7, 32), (33, 2, 8)])
+def test_fm(dev, B, F, D):
+    g = torch.Generator().manual_seed(B + F + D)
+    x = torch.randn(B, F, D, generator=g)
+    xd = x.clone().to(dev).requires_grad_(True)
+    out = FactorizationMachine()(xd)
+    xr = x.clone().requires_grad_(True)
+    ref = orc.fm(xr)
+    assert tuple(out.shape) == (B, D)  # fm_test.py:23-32 asserts (4, 16)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    go = torch.randn(B, D, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)

@@ -1,0 +1,151 @@
+"""DLRM / DeepFM glue around the gfx950 embedding + interaction kernels.
+
+Mirrors the forward of the reference models:
+/root/reference/tzrec/models/dlrm.py:101-135, /root/reference/tzrec/models/deepfm.py:72-108,
+/root/reference/tzrec/modules/mlp.py:21-177 (Linear + ReLU per hidden unit),
+/root/reference/tzrec/models/rank_model.py:133-262 (logits -> BCEWithLogitsLoss, mean).
+The MLPs stay on PyTorch (hipBLASLt); everything sparse goes through libtzrec_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+from .interaction import FactorizationMachine, dot_interaction
+from .sparse import KeyedJaggedTensor
+
+
+class MLP(nn.Module):
+    """Stack of Linear+ReLU (reference Perceptron defaults: bias, no bn/ln/dropout)."""
+
+    def __init__(self, in_features: int, hidden_units: Sequence[int]) -> None:
+        super().__init__()
+        self.hidden_units = list(hidden_units)
+        layers: List[nn.Module] = []
+        d = in_features
+        for h in self.hidden_units:
+            layers += [nn.Linear(d, h), nn.ReLU()]
+            d = h
+        self.mlp = nn.Sequential(*layers)
+
+    def output_dim(self) -> int:
+        return self.hidden_units[-1]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.mlp(x)
+
+
+class DLRM(nn.Module):
+    """DLRM with dot interaction (``dlrm{}`` block of examples/dlrm_criteo.config)."""
+
+    def __init__(
+        self,
+        tables: Sequence[EmbeddingBagConfig],
+        sparse_features: Sequence[str],
+        dense_dim: int,
+        dense_mlp: Sequence[int] = (64, 16),
+        final_mlp: Sequence[int] = (64, 32),
+        arch_with_sparse: bool = True,
+        num_class: int = 1,
+        device: Optional[torch.device] = None,
+        sparse_optimizer: Optional[SparseOptimizerConfig] = None,
+        row_layout: str = "interleaved",
+    ) -> None:
+        super().__init__()
+        dims = {f: t.embedding_dim for t in tables for f in t.feature_names}
+        dset = {dims[f] for f in sparse_features}
+        if len(dset) != 1:
+            raise ValueError(f"sparse group feature dims must be the same, but we find {dset}")
+        self.dim = dset.pop()
+        if dense_mlp[-1] != self.dim:
+            raise ValueError("dense mlp last hidden_unit must be the same sparse feature dim")
+        self.num_sparse = len(sparse_features)
+        self.arch_with_sparse = arch_with_sparse
+        self.ebc = EmbeddingBagCollection(
+            tables, device=device, optimizer=sparse_optimizer, groups={"sparse": list(sparse_features)},
+            row_layout=row_layout,
+        )
+        self.dense_mlp = MLP(dense_dim, dense_mlp)
+        n = self.num_sparse + 1
+        feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
+        self.final_mlp = MLP(feat, final_mlp)
+        self.output_mlp = nn.Linear(self.final_mlp.output_dim(), num_class)
+        if device is not None:
+            self.dense_mlp.to(device)
+            self.final_mlp.to(device)
+            self.output_mlp.to(device)
+
+    def dense_parameters(self):
+        for m in (self.dense_mlp, self.final_mlp, self.output_mlp):
+            yield from m.parameters()
+
+    def predict_from_embeddings(self, dense: torch.Tensor, sparse: torch.Tensor) -> torch.Tensor:
+        d = self.dense_mlp(dense)
+        allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
+        return self.output_mlp(self.final_mlp(allf)).squeeze(1)
+
+    def forward(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
+        """-> logits [B] (probs = sigmoid(logits), rank_model.py:142-146)."""
+        sparse = self.ebc.forward_grouped(sparse_features)["sparse"]
+        return self.predict_from_embeddings(dense, sparse)
+
+
+class DeepFM(nn.Module):
+    """DeepFM with groups wide / fm / deep (examples/deepfm_criteo.config)."""
+
+    def __init__(
+        self,
+        tables: Sequence[EmbeddingBagConfig],
+        groups: Dict[str, List[str]],
+        dense_dim: int,
+        fm_dim: int,
+        deep_mlp: Sequence[int] = (512, 256, 128),
+        final_mlp: Optional[Sequence[int]] = (64,),
+        num_class: int = 1,
+        device: Optional[torch.device] = None,
+        sparse_optimizer: Optional[SparseOptimizerConfig] = None,
+    ) -> None:
+        super().__init__()
+        self.ebc = EmbeddingBagCollection(tables, device=device, optimizer=sparse_optimizer, groups=groups)
+        self.has_fm_group = "fm" in groups
+        self.fm_dim = fm_dim
+        dims = self.ebc._out_dim
+        deep_in = sum(dims[k] for k in groups["deep"]) + dense_dim
+        self.deep_mlp = MLP(deep_in, deep_mlp)
+        self.fm = FactorizationMachine()
+        final_dim = self.deep_mlp.output_dim()
+        self.final_mlp = None
+        if final_mlp:
+            self.final_mlp = MLP(1 + fm_dim + final_dim, final_mlp)
+            final_dim = self.final_mlp.output_dim()
+        self.output_mlp = nn.Linear(final_dim, num_class)
+        if device is not None:
+            self.to(device)
+
+    def dense_parameters(self):
+        mods = [self.deep_mlp, self.output_mlp] + ([self.final_mlp] if self.final_mlp is not None else [])
+        for m in mods:
+            yield from m.parameters()
+
+    def forward(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
+        g = self.ebc.forward_grouped(sparse_features)
+        y_wide = g["wide"].sum(dim=1, keepdim=True)
+        # dense (raw) features are columns of the deep group, before the embeddings
+        # (/root/reference/examples/deepfm_criteo.config deep group lists int_* first)
+        deep = torch.cat([dense, g["deep"]], dim=1)
+        y_deep = self.deep_mlp(deep)
+        fm_in = g["fm"] if self.has_fm_group else g["deep"]
+        y_fm = self.fm(fm_in.reshape(fm_in.shape[0], -1, self.fm_dim))
+        if self.final_mlp is not None:
+            y = self.output_mlp(self.final_mlp(torch.cat([y_wide, y_fm, y_deep], dim=1)))
+        else:
+            y = y_wide + y_fm.sum(dim=1, keepdim=True) + self.output_mlp(y_deep)
+        return y.squeeze(1)
+
+
+def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """BCEWithLogitsLoss(reduction="mean") on float labels (rank_model.py:190-191,233-240)."""
+    return nn.functional.binary_cross_entropy_with_logits(logits, labels.float(), reduction="mean")

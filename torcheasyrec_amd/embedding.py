@@ -200,6 +200,7 @@ class EmbeddingBagCollection(nn.Module):
         self._meta_cache: Dict[Tuple, _Meta] = {}
         self.fused_optimizer = FusedSparseOptimizer(optimizer, self) if optimizer is not None else None
         self._hook = torch.zeros(0, requires_grad=True, device=device)
+        self._timers = None  # bench.py: object with .start(name) -> event recorded after the launch
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
@@ -331,12 +332,15 @@ class EmbeddingBagCollection(nn.Module):
         for i, o in enumerate(outs):
             dsts[i].ptr = _lib.ptr(o)
             dsts[i].stride = o.stride(0)
+        ev = self._timers.start("fwd") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_fwd(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
             _lib.ptr(meta.d_slots), len(meta.slots_np), _lib.ptr(kjt.values()), _lib.ptr(offsets),
             _lib.ptr(kjt.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
             _lib.stream_ptr(self._device),
         )
+        if ev is not None:
+            ev.record()
         _lib.check(rc, "tzr_pooled_fwd")
         return outs
 
@@ -365,11 +369,14 @@ class EmbeddingBagCollection(nn.Module):
         NP = self._n_positions(kjt)
         nbytes = L.tzr_pooled_bwd_workspace(N, NP, len(self._lookups), len(self._configs), B, max_dim)
         ws = _lib.workspace(nbytes, self._device)
+        ev = self._timers.start("plan") if self._timers is not None else None
         rc = L.tzr_pooled_bwd_plan(
             _lib.ptr(meta.d_tables), len(self._configs), _lib.ptr(meta.d_feats), len(self._lookups),
             meta.n_keys, max_rows, max_dim, _lib.ptr(kjt.values()), _lib.ptr(offsets), N, NP, B,
             1 if uniform else 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
         )
+        if ev is not None:
+            ev.record()
         _lib.check(rc, "tzr_pooled_bwd_plan")
         kjt._tzr_plan = (id(self), dst_names, ws)  # type: ignore[attr-defined]
         return ws
@@ -409,12 +416,15 @@ class EmbeddingBagCollection(nn.Module):
         opt.weight_decay = cfg.weight_decay
         opt.max_gradient = cfg.max_gradient
         opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        ev = self._timers.start("apply") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_bwd_apply(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), len(self._configs),
             max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
             1 if uniform else 0,
             gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
         )
+        if ev is not None:
+            ev.record()
         _lib.check(rc, "tzr_pooled_bwd_apply")
         kjt._tzr_plan = None  # type: ignore[attr-defined]
 
