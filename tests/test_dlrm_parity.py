@@ -56,7 +56,9 @@ def test_dlrm_criteo_step(dev, kind, dist):
         m = np.zeros_like(w) if kind == "adagrad" else np.zeros(w.shape[0], np.float32)
         orc.sparse_update(w, m, kjt.values().numpy()[t * B:(t + 1) * B], block_grads[t].numpy(), opt)
         got = model.ebc.table_weights()[f"{k}_emb"].detach().cpu().numpy()
-        np.testing.assert_allclose(got, w, rtol=2e-4, atol=5e-6, err_msg=k)
+        # first Adagrad step moves a row by lr*g/(|g|+eps): where duplicate gradients nearly cancel
+        # the quotient is ill-conditioned, so bound the check by a fraction of the step (2e-3*lr)
+        np.testing.assert_allclose(got, w, rtol=2e-4, atol=2e-3 * lr, err_msg=k)
 
 
 def test_deepfm_forward_backward(dev):
