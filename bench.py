@@ -192,6 +192,8 @@ def main():
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
         loss.backward()
+        if world > 1:
+            model.allreduce_dense_grads()
         dense_opt.step()
         dense_opt.zero_grad(set_to_none=True)
         if ebc is not None:

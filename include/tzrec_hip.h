@@ -159,9 +159,13 @@ int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B,
  * 1049-1060 -> torchrec calculate_shard_sizes_and_offsets [upstream]).  For id x of key f:
  * dst = x / block_size[f] (clamped to W-1), local = x - dst*block_size[f].  Output is
  * rank-major: new_lengths[(r*F + f)*B + b]; ids keep their relative order inside each
- * (r, f, b) bag.  d_unbucketize_permute[i] = output position of input id i (nullable). */
+ * (r, f, b) bag.  d_unbucketize_permute[i] = output position of input id i (nullable).
+ * d_rank_offsets (nullable, int32[F]) rotates the owner: dst = (offset[f] + x / block_size[f]) mod W,
+ * which spreads tables with fewer rows than ranks (and table-wise placement: block_size = rows,
+ * offset = owner) over the node instead of piling them on rank 0. */
 size_t tzr_block_bucketize_workspace(int64_t F, int64_t B, int W);
-int tzr_block_bucketize(const int64_t* d_block_sizes, int F, int64_t B, int W,
+int tzr_block_bucketize(const int64_t* d_block_sizes, const int32_t* d_rank_offsets, int F,
+                        int64_t B, int W,
                         const int64_t* d_offsets, const int64_t* d_values, const float* d_weights,
                         int64_t n_values, void* d_new_lengths, int lengths_itemsize,
                         int64_t* d_new_offsets, int64_t* d_new_values, float* d_new_weights,
@@ -202,12 +206,32 @@ int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature
  *   adagrad          m += g*g;            w -= lr * g / (sqrt(m) + eps)
  *   rowwise adagrad  m += mean_d(g*g);    w -= lr * g / (sqrt(m) + eps)
  *   sgd              w -= lr * g
- * h_grads mirrors the forward's h_dsts (same buffer indices / strides). */
+ * grad_mode 0: h_grads mirrors the forward's h_dsts (same buffer indices / strides).
+ * grad_mode 1: h_grads[0] is float [n_values, stride], ONE gradient row per id (indexed by the id's
+ * position in `values`): the owner side of the sharded exchange. */
 int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
                          int n_tables, int max_dim, const int64_t* d_offsets,
                          const float* d_weights, int64_t n_values, int64_t n_positions, int64_t B,
-                         int uniform_bag_len, const TzrDst* h_grads, int n_dst,
+                         int uniform_bag_len, int grad_mode, const TzrDst* h_grads, int n_dst,
                          const TzrSparseOptim* h_optim, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- row-wise sharded exchange (one process per GPU, RCCL all-to-all between the stages) ---- */
+
+/* Owner side forward: out[j, 0:dim] = W_{table of key(j)}[ids[j], :] for j in [0, n_ids); ids
+ * arrive grouped by key, key k owning positions d_key_start[k] .. d_key_start[k+1] (device,
+ * int64[n_keys+1]); d_key_table[k] indexes d_tables.  Replaces the per-shard TBE lookup of
+ * torchrec's row-wise sharded EBC [upstream]; one row per id instead of a pooled partial per bag. */
+int tzr_rows_gather(const TzrTable* d_tables, const int32_t* d_key_table,
+                    const int64_t* d_key_start, int n_keys, const int64_t* d_ids, int64_t n_ids,
+                    float* d_out, int64_t out_stride, int dim, void* stream);
+
+/* Requester side backward: d_out[pos(i), 0:dim] = weight_i (/ len for mean) * sum over the feature
+ * groups of key f of grad[g][b, col_g(f) : +dim] for every id i of bag (f, b); pos(i) =
+ * d_positions[i] (the unbucketize permute) or i when null. */
+int tzr_lookup_grads(const TzrFeature* d_feats, int n_feats, const int64_t* d_offsets,
+                     const float* d_weights, int64_t B, int uniform_bag_len,
+                     const int64_t* d_positions, const TzrDst* h_grads, int n_dst, float* d_out,
+                     int64_t out_stride, int dim, void* stream);
 
 /* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
 int tzr_tune(const char* name, int value);

@@ -77,14 +77,17 @@ _SIGNATURES = {
     "tzr_kjt_permute": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _vp, _sz, _vp]),
     "tzr_block_bucketize_workspace": (_sz, [_i64, _i64, _i32]),
-    "tzr_block_bucketize": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp,
+    "tzr_block_bucketize": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp,
                                    _vp, _vp, _vp, _sz, _vp]),
     "tzr_pooled_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                               _i32, _i32, _vp]),
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),
-    "tzr_pooled_bwd_apply": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32,
+    "tzr_rows_gather": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "tzr_lookup_grads": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, C.POINTER(TzrDst), _i32, _vp,
+                                _i64, _i32, _vp]),
+    "tzr_pooled_bwd_apply": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                     C.POINTER(TzrDst), _i32, C.POINTER(TzrSparseOptim), _vp, _sz,
                                     _vp]),
     "tzr_dot_interaction_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,

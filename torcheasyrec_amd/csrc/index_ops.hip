@@ -243,36 +243,38 @@ extern "C" int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B
 // read-modify-writes: deterministic, ids keep their order inside every (rank, key, sample) bag).
 
 __global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_count_kernel(
-    const int64_t* __restrict__ block_sizes, int F, int64_t B, int W,
-    const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
+    const int64_t* __restrict__ block_sizes, const int32_t* __restrict__ rank_offsets, int F,
+    int64_t B, int W, const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
     void* __restrict__ new_lengths, int itemsize) {
   const int64_t bag = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x;
   if (bag >= (int64_t)F * B) return;
   const int64_t bs = block_sizes[bag / B];
+  const int64_t ro = rank_offsets ? rank_offsets[bag / B] : 0;
   const int64_t FB = (int64_t)F * B;
   for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
     int64_t r = values[i] / bs;
     r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
-    const int64_t o = r * FB + bag;
+    const int64_t o = ((r + ro) % W) * FB + bag;
     idx_store_len(new_lengths, itemsize, o, idx_load_len(new_lengths, itemsize, o) + 1);
   }
 }
 
 __global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_scatter_kernel(
-    const int64_t* __restrict__ block_sizes, int F, int64_t B, int W,
-    const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
+    const int64_t* __restrict__ block_sizes, const int32_t* __restrict__ rank_offsets, int F,
+    int64_t B, int W, const int64_t* __restrict__ offsets, const int64_t* __restrict__ values,
     const float* __restrict__ weights, int64_t* __restrict__ cursor /*[W*F*B] = new_offsets copy*/,
     int64_t* __restrict__ new_values, float* __restrict__ new_weights,
     int64_t* __restrict__ unbucketize) {
   const int64_t bag = (int64_t)blockIdx.x * IDX_THREADS + threadIdx.x;
   if (bag >= (int64_t)F * B) return;
   const int64_t bs = block_sizes[bag / B];
+  const int64_t ro = rank_offsets ? rank_offsets[bag / B] : 0;
   const int64_t FB = (int64_t)F * B;
   for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
     const int64_t id = values[i];
     int64_t r = id / bs;
     r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
-    const int64_t o = r * FB + bag;
+    const int64_t o = ((r + ro) % W) * FB + bag;
     const int64_t pos = cursor[o];
     cursor[o] = pos + 1;
     new_values[pos] = id - r * bs;
@@ -286,7 +288,8 @@ extern "C" size_t tzr_block_bucketize_workspace(int64_t F, int64_t B, int W) {
   return tzr_lengths_to_offsets_workspace(n) + tzr_align_up((size_t)n * 8) + 256;
 }
 
-extern "C" int tzr_block_bucketize(const int64_t* d_block_sizes, int F, int64_t B, int W,
+extern "C" int tzr_block_bucketize(const int64_t* d_block_sizes, const int32_t* d_rank_offsets,
+                                   int F, int64_t B, int W,
                                    const int64_t* d_offsets, const int64_t* d_values,
                                    const float* d_weights, int64_t n_values, void* d_new_lengths,
                                    int lengths_itemsize, int64_t* d_new_offsets,
@@ -313,13 +316,13 @@ extern "C" int tzr_block_bucketize(const int64_t* d_block_sizes, int F, int64_t 
     return TZR_ERR_LAUNCH;
   const unsigned gb = (unsigned)(((int64_t)F * B + IDX_THREADS - 1) / IDX_THREADS);
   hipLaunchKernelGGL(tzr_bucketize_count_kernel, dim3(gb), dim3(IDX_THREADS), 0, s, d_block_sizes,
-                     F, B, W, d_offsets, d_values, d_new_lengths, lengths_itemsize);
+                     d_rank_offsets, F, B, W, d_offsets, d_values, d_new_lengths, lengths_itemsize);
   const int rc = idx_scan(d_new_lengths, lengths_itemsize, n, d_new_offsets, ws, scan_ws, s);
   if (rc != TZR_OK) return rc;
   if (hipMemcpyAsync(cursor, d_new_offsets, (size_t)n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
     return TZR_ERR_LAUNCH;
   hipLaunchKernelGGL(tzr_bucketize_scatter_kernel, dim3(gb), dim3(IDX_THREADS), 0, s,
-                     d_block_sizes, F, B, W, d_offsets, d_values, d_weights, cursor, d_new_values,
+                     d_block_sizes, d_rank_offsets, F, B, W, d_offsets, d_values, d_weights, cursor, d_new_values,
                      d_new_weights, d_unbucketize_permute);
   TZR_CHECK_LAUNCH();
   return TZR_OK;

@@ -1,0 +1,389 @@
+// K7: fused backward + sparse optimizer, wavefront-level duplicate-row reduction (gfx950).
+//
+// Replaces fbgemm split_embedding_backward_codegen_{sgd,adagrad,rowwise_adagrad}_*_exact_
+// {warp,cta}_per_row_1 (optimizer fused into backward by apply_optimizer_in_backward,
+// /root/reference/tzrec/main.py:774-781).
+//
+// Input: the plan of pooled_bwd.hip -- per table, lookups sorted by (row, original position).
+// A workgroup owns one chunk of BWD_CH sorted positions (keys + sources staged once in LDS,
+// coalesced); each of its 4 waves reduces a range of BWD_RANGE positions tile by tile:
+//   * a tile = 64/(D/4) consecutive sorted lookups, one per lane group: ALL gradient gathers of a
+//     tile are independent loads in flight together (the HBM/MALL latency is paid once per tile,
+//     not once per duplicate);
+//   * duplicates are summed with a segmented inclusive scan over the lane groups (shuffles,
+//     log2 steps, fixed tree => bit-reproducible), runs crossing tiles ride a register carry;
+//   * the lane group on a run's LAST lookup performs the single read-modify-write of the row
+//     (weights + optimizer state).  Exactly one lane group in the whole grid touches a given row:
+//     no atomics, no cross-XCD L2 coherence hazard.
+//   * runs crossing a wave range are stitched through LDS records by wave 0, runs crossing a
+//     chunk through per-chunk records by tzr_bwd_stitch_kernel (a 65536-lookup run of a 3-row
+//     table is 32 chunk records long).
+#include "pooled_bwd.h"
+
+struct BwdGrads {
+  TzrDst d[TZR_MAX_DST];
+};
+
+struct BwdOpt {
+  int kind, wd_mode, clip;
+  const float* lr;
+  float eps, wd, max_grad;
+};
+
+// Gradient sources of one lookup (key -> table), resolved once per workgroup when the table is
+// read by a single key (the common case).
+struct BwdSrc {
+  const float* gp[TZR_MAX_FEAT_DST];  // group gradient buffer + first column
+  int64_t gs[TZR_MAX_FEAT_DST];       // sample stride
+  int n_dst;
+  int mean;
+};
+
+__device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature& ft, const BwdGrads& G) {
+  BwdSrc s;
+  s.n_dst = ft.n_dst;
+  s.mean = ft.pooling == TZR_POOL_MEAN;
+#pragma unroll
+  for (int d = 0; d < TZR_MAX_FEAT_DST; ++d) {
+    const int di = d < ft.n_dst ? ft.dst[d] : 0;
+    s.gp[d] = reinterpret_cast<const float*>(G.d[di].ptr) + ft.col[d];
+    s.gs[d] = G.d[di].stride;
+  }
+  return s;
+}
+
+// dL/d(row contribution) of the lookup at original position i, float4 chunk c of its row.
+//   grad_mode 0: pooled-output gradients per feature group (bag (key,b) -> grad[g][b, col..])
+//   grad_mode 1: one gradient row per id: G.d[0][i, :]
+__device__ __forceinline__ float4 bwd_lookup_grad(
+    const TzrFeature* __restrict__ feats, const TzrTable& tb, const int32_t* __restrict__ feat_by_order,
+    const BwdGrads& G, const BwdSrc& one, bool single, int grad_mode,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights,
+    const uint32_t* __restrict__ bag_of, int64_t B, int uniform, uint32_t i, int c) {
+  if (grad_mode == 1)
+    return tzr_ld4(reinterpret_cast<const float*>(G.d[0].ptr) + (int64_t)i * G.d[0].stride + 4 * c);
+  const uint32_t bag = uniform ? i : bag_of[i];
+  const uint32_t key = bag / (uint32_t)B;
+  const int64_t b = bag - key * (uint32_t)B;
+  BwdSrc s = one;
+  if (!single) {  // the lookup of this table that reads `key` (a table is read once per key)
+    int o = tb.first_order;
+    while (o + 1 < tb.first_order + tb.n_feats && feats[feat_by_order[o]].key != (int32_t)key) ++o;
+    s = bwd_resolve(feats[feat_by_order[o]], G);
+  }
+  float4 g = tzr_ld4(s.gp[0] + b * s.gs[0] + 4 * c);
+  for (int d = 1; d < s.n_dst; ++d) g = tzr_add4(g, tzr_ld4(s.gp[d] + b * s.gs[d] + 4 * c));
+  const bool mean = !uniform && s.mean;
+  if (weights || mean) {
+    float sc = weights ? weights[i] : 1.0f;
+    if (mean) {
+      const int64_t len = offsets[(int64_t)bag + 1] - offsets[bag];
+      if (len > 1) sc = sc / (float)len;
+    }
+    g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+  }
+  return g;
+}
+
+// Sum of v over the `lg` lanes of a row group (all 64 lanes call it).
+__device__ __forceinline__ float bwd_group_sum(float v, int lg, int lane_in_group, int lane) {
+  if ((lg & (lg - 1)) == 0) {
+    for (int m = lg >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  }
+  float s = 0.f;
+  const int g0 = lane - lane_in_group;
+  for (int l = 0; l < lg; ++l) s += __shfl(v, g0 + l, 64);
+  return s;
+}
+
+// ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g and the row's
+// current weights w4.  All 64 lanes of the wave must call (row-wise adagrad reduces in the group).
+__device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& opt, float lr,
+                                              int64_t row, int c, float4 g, float4 w4, bool active,
+                                              int lg, int lane_in_group, int lane) {
+  if (opt.clip) {
+    g.x = fminf(fmaxf(g.x, -opt.max_grad), opt.max_grad);
+    g.y = fminf(fmaxf(g.y, -opt.max_grad), opt.max_grad);
+    g.z = fminf(fmaxf(g.z, -opt.max_grad), opt.max_grad);
+    g.w = fminf(fmaxf(g.w, -opt.max_grad), opt.max_grad);
+  }
+  float* wp = reinterpret_cast<float*>(tb.w) + row * (int64_t)tb.w_stride + 4 * c;
+  if (opt.kind == TZR_OPT_ADAGRAD) {
+    if (active) {
+      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
+      float4 m4 = tzr_ld4(mp);
+      m4.x += g.x * g.x; m4.y += g.y * g.y; m4.z += g.z * g.z; m4.w += g.w * g.w;
+      tzr_st4(mp, m4);
+      w4.x -= lr * g.x / (sqrtf(m4.x) + opt.eps);
+      w4.y -= lr * g.y / (sqrtf(m4.y) + opt.eps);
+      w4.z -= lr * g.z / (sqrtf(m4.z) + opt.eps);
+      w4.w -= lr * g.w / (sqrtf(m4.w) + opt.eps);
+      tzr_st4(wp, w4);
+    }
+  } else if (opt.kind == TZR_OPT_ROWWISE_ADAGRAD) {
+    float4 gl = g;
+    if (opt.wd_mode == TZR_WD_L2) gl = tzr_fma4(opt.wd, w4, g);
+    float ss = active ? (gl.x * gl.x + gl.y * gl.y + gl.z * gl.z + gl.w * gl.w) : 0.f;
+    ss = bwd_group_sum(ss, lg, lane_in_group, lane);
+    // the row's scalar state is read by the group's first lane only and broadcast, so no lane
+    // can observe the store below
+    float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride;
+    float mold = (active && lane_in_group == 0) ? *mp : 0.f;
+    mold = __shfl(mold, lane - lane_in_group, 64);
+    if (active) {
+      const float mnew = mold + ss / (float)tb.dim;
+      const float mult = lr / (sqrtf(mnew) + opt.eps);
+      float corr = 1.0f;
+      if (opt.wd_mode == TZR_WD_L2) corr = 1.0f - mult * opt.wd;
+      else if (opt.wd_mode == TZR_WD_DECOUPLE) corr = 1.0f - lr * opt.wd;
+      w4.x = corr * w4.x - mult * g.x;
+      w4.y = corr * w4.y - mult * g.y;
+      w4.z = corr * w4.z - mult * g.z;
+      w4.w = corr * w4.w - mult * g.w;
+      tzr_st4(wp, w4);
+      if (lane_in_group == 0) *mp = mnew;
+    }
+  } else {  // SGD
+    if (active) {
+      w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
+      tzr_st4(wp, w4);
+    }
+  }
+}
+
+__device__ __forceinline__ float4 bwd_shfl4(float4 v, int src) {
+  return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64),
+                     __shfl(v.w, src, 64));
+}
+
+// One row update done by a whole wave acting as a single group (lanes >= D/4 idle): used by the
+// stitching steps, where runs are few.
+__device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const BwdOpt& opt, float lr,
+                                                   uint32_t key, float4 g, int lane) {
+  const bool on = lane < (tb.dim >> 2);
+  float4 w4 = tzr_zero4();
+  if (on) w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * lane);
+  bwd_apply_row(tb, opt, lr, (int64_t)key, lane, g, w4, on, TZR_WAVE, lane, lane);
+}
+
+__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
+    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
+    int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
+  __shared__ uint32_t sK[BWD_CH + 2];  // K[s-1], K[s..e), K[e] (sentinels at table ends)
+  __shared__ uint32_t sS[BWD_CH];
+  __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
+  __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
+  int t;
+  int64_t s, e, ts, te;
+  if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
+  const TzrTable tb = tables[t];
+  const int par = P.tab_npass[t] & 1;
+  const uint32_t* __restrict__ K = P.key[par];
+  const uint32_t* __restrict__ S = P.src[par];
+  const int n = (int)(e - s);
+  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+    sK[i + 1] = K[s + i];
+    sS[i] = S[s + i];
+  }
+  if (threadIdx.x == 0) {
+    sK[0] = s > ts ? K[s - 1] : BWD_SENT;
+    sK[n + 1] = e < te ? K[e] : BWD_SENT;
+  }
+  __syncthreads();
+
+  const int lg = tb.dim >> 2;    // lanes per row
+  const int gw = TZR_WAVE / lg;  // lookups per tile
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int gi = lane / lg;
+  const int c = lane - gi * lg;
+  const bool lane_on = gi < gw;
+  const float lr = *opt.lr;
+  const bool single = tb.n_feats == 1;
+  BwdSrc one = bwd_resolve(feats[P.feat_by_order[tb.first_order]], G);
+
+  const int r0 = wv * BWD_RANGE;             // range of this wave, chunk-relative
+  const int r1 = min(n, r0 + BWD_RANGE);
+  unsigned flags = 0;
+  const uint32_t leadkey = r0 < r1 ? sK[r0 + 1] : BWD_SENT;
+  bool lead_open = r0 < r1 && sK[r0] == leadkey;  // first run started before this range
+  bool cvalid = false;                            // carry: run continuing from the previous tile
+  uint32_t ckey = BWD_SENT;
+  float4 csum = tzr_zero4();
+
+  for (int t0 = r0; t0 < r1; t0 += gw) {
+    const int idx = t0 + gi;
+    const bool valid = lane_on && idx < r1;
+    const uint32_t key = valid ? sK[idx + 1] : BWD_SENT;
+    const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
+    const bool tail = valid && key != nxt;
+    float4 g = tzr_zero4();
+    if (valid)
+      g = bwd_lookup_grad(feats, tb, P.feat_by_order, G, one, single, grad_mode, offsets, weights,
+                          P.bag_of, B, uniform, sS[idx], c);
+    const bool in_lead = lead_open && key == leadkey;
+    const bool do_apply = tail && !in_lead;
+    float4 w4 = tzr_zero4();
+    if (do_apply)  // issued before the scan: overlaps the gradient gathers
+      w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * c);
+    // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
+    // distance d implies one run in between)
+    for (int d = 1; d < gw; d <<= 1) {
+      const uint32_t ok = __shfl_up(key, d * lg, 64);
+      const float4 ov = make_float4(__shfl_up(g.x, d * lg, 64), __shfl_up(g.y, d * lg, 64),
+                                    __shfl_up(g.z, d * lg, 64), __shfl_up(g.w, d * lg, 64));
+      if (gi >= d && ok == key) g = tzr_add4(ov, g);
+    }
+    if (cvalid && key == ckey) g = tzr_add4(csum, g);  // earlier lookups first
+    if (tail && in_lead) {  // the run inherited from the previous range ends here
+      rlead[wv][4 * c + 0] = g.x; rlead[wv][4 * c + 1] = g.y;
+      rlead[wv][4 * c + 2] = g.z; rlead[wv][4 * c + 3] = g.w;
+    }
+    if (__any(tail && in_lead)) {
+      flags |= BWD_LEAD;
+      lead_open = false;
+    }
+    bwd_apply_row(tb, opt, lr, (int64_t)key, c, g, w4, do_apply, lg, c, lane);
+    // carry out of the tile: its last valid lookup, if that run goes on
+    const int nv = min(gw, r1 - t0);
+    const int last = (nv - 1) * lg;
+    ckey = __shfl(key, last, 64);
+    cvalid = __shfl((int)(valid && !tail), last, 64) != 0;
+    csum = bwd_shfl4(g, last + (lane_on ? c : 0));
+  }
+  if (r0 < r1 && cvalid) {  // the last run continues past this range
+    float* dst = lead_open ? rlead[wv] : rtrail[wv];
+    if (lane_on && gi == 0) {
+      dst[4 * c + 0] = csum.x; dst[4 * c + 1] = csum.y; dst[4 * c + 2] = csum.z; dst[4 * c + 3] = csum.w;
+    }
+    flags |= lead_open ? (BWD_LEAD | BWD_LEAD_WHOLE) : BWD_TRAIL;
+  }
+  if (lane == 0) {
+    rflags[wv] = flags;
+    rlkey[wv] = leadkey;
+    rtkey[wv] = ckey;
+  }
+  __syncthreads();
+
+  // stitch the 4 ranges of the chunk (wave 0; control flow is wave-uniform)
+  if (wv != 0) return;
+  const bool on = lane < lg;
+  bool open = false;
+  uint32_t okey = BWD_SENT;
+  float4 osum = tzr_zero4();
+  unsigned cf = 0;
+  float4 clead = tzr_zero4();
+  for (int r = 0; r < BWD_WAVES; ++r) {
+    const unsigned f = rflags[r];
+    if (f & BWD_LEAD) {
+      float4 lv = tzr_zero4();
+      if (on) lv = make_float4(rlead[r][4 * lane], rlead[r][4 * lane + 1], rlead[r][4 * lane + 2],
+                               rlead[r][4 * lane + 3]);
+      if (open) {
+        osum = tzr_add4(osum, lv);
+        if (!(f & BWD_LEAD_WHOLE)) {
+          bwd_apply_row_wave(tb, opt, lr, okey, osum, lane);
+          open = false;
+        }
+      } else {  // still inside the run inherited from the previous chunk
+        clead = tzr_add4(clead, lv);
+        cf = BWD_LEAD | (f & BWD_LEAD_WHOLE);
+      }
+    }
+    if (f & BWD_TRAIL) {
+      open = true;
+      okey = rtkey[r];
+      osum = tzr_zero4();
+      if (on) osum = make_float4(rtrail[r][4 * lane], rtrail[r][4 * lane + 1], rtrail[r][4 * lane + 2],
+                                 rtrail[r][4 * lane + 3]);
+    }
+  }
+  if (open) cf |= BWD_TRAIL;
+  if (on) {
+    tzr_st4(P.clead + (size_t)blockIdx.x * max_dim + 4 * lane, clead);
+    tzr_st4(P.ctrail + (size_t)blockIdx.x * max_dim + 4 * lane, osum);
+  }
+  if (lane == 0) {
+    P.cflags[blockIdx.x] = cf;
+    P.clkey[blockIdx.x] = sK[1];
+    P.ctkey[blockIdx.x] = okey;
+  }
+}
+
+// Runs crossing chunk boundaries: the chunk holding the run's first lookup adds the leading
+// pieces of the following chunks (in order) and updates the row.  One wave per chunk.
+__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_stitch_kernel(
+    const TzrTable* __restrict__ tables, int T, BwdOpt opt, int max_dim, BwdPlan P) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int chunk = blockIdx.x * BWD_WAVES + threadIdx.x / TZR_WAVE;
+  int t;
+  int64_t s, e, ts, te;
+  if (!bwd_chunk(P, tables, T, chunk, &t, &s, &e, &ts, &te)) return;
+  if (!(P.cflags[chunk] & BWD_TRAIL)) return;
+  const TzrTable tb = tables[t];
+  const bool on = lane < (tb.dim >> 2);
+  const float lr = *opt.lr;
+  const uint32_t key = P.ctkey[chunk];
+  float4 sum = tzr_zero4();
+  if (on) sum = tzr_ld4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
+  for (int c2 = chunk + 1; c2 < P.tab_chunk[t + 1]; ++c2) {
+    const unsigned f = P.cflags[c2];
+    if (!(f & BWD_LEAD)) break;
+    if (on) sum = tzr_add4(sum, tzr_ld4(P.clead + (size_t)c2 * max_dim + 4 * lane));
+    if (!(f & BWD_LEAD_WHOLE)) break;
+  }
+  bwd_apply_row_wave(tb, opt, lr, key, sum, lane);
+}
+
+extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
+                                    int n_feats, int n_tables, int max_dim,
+                                    const int64_t* d_offsets, const float* d_weights,
+                                    int64_t n_values, int64_t n_positions, int64_t B,
+                                    int uniform_bag_len, int grad_mode, const TzrDst* h_grads,
+                                    int n_dst, const TzrSparseOptim* h_optim, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  if (!d_tables || !d_feats || !h_grads || !h_optim || n_tables <= 0 || n_feats <= 0 ||
+      n_values < 0 || B < 0 || n_dst <= 0 || n_dst > TZR_MAX_DST || max_dim <= 0 ||
+      max_dim > BWD_MAXDIM || (max_dim & 3) || (grad_mode != 0 && grad_mode != 1))
+    return TZR_ERR_INVALID;
+  const bool uniform = uniform_bag_len == 1;
+  if (!uniform && !d_offsets && grad_mode == 0) return TZR_ERR_INVALID;
+  if (!h_optim->d_lr) return TZR_ERR_INVALID;
+  if (h_optim->kind != TZR_OPT_SGD && h_optim->kind != TZR_OPT_ADAGRAD &&
+      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD)
+    return TZR_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
+  if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
+  BwdPlan P;
+  if (bwd_layout(&P, ws, n_values, n_positions, n_feats, n_tables, max_dim) > ws_bytes)
+    return TZR_ERR_WORKSPACE;
+  if (n_values == 0 || n_positions == 0 || B == 0) return TZR_OK;
+  BwdGrads G;
+  for (int i = 0; i < TZR_MAX_DST; ++i) {
+    G.d[i].ptr = 0;
+    G.d[i].stride = 0;
+  }
+  for (int i = 0; i < n_dst; ++i) {
+    if (!h_grads[i].ptr || (h_grads[i].stride & 3) || (h_grads[i].ptr & 15)) return TZR_ERR_INVALID;
+    G.d[i] = h_grads[i];
+  }
+  BwdOpt opt;
+  opt.kind = h_optim->kind;
+  opt.wd_mode = h_optim->weight_decay_mode;
+  opt.clip = h_optim->gradient_clipping;
+  opt.lr = reinterpret_cast<const float*>(h_optim->d_lr);
+  opt.eps = h_optim->eps;
+  opt.wd = h_optim->weight_decay;
+  opt.max_grad = h_optim->max_gradient;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned chunks = (unsigned)P.max_chunks;
+  hipLaunchKernelGGL(tzr_bwd_reduce_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
+                     n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
+                     max_dim, P);
+  hipLaunchKernelGGL(tzr_bwd_stitch_kernel, dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
+                     dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

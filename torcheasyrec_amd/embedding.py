@@ -420,7 +420,7 @@ class EmbeddingBagCollection(nn.Module):
         rc = _lib.lib().tzr_pooled_bwd_apply(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), len(self._configs),
             max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
-            1 if uniform else 0,
+            1 if uniform else 0, 0,
             gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
         )
         if ev is not None:

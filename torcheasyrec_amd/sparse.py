@@ -227,7 +227,8 @@ def lengths_to_offsets(lengths: torch.Tensor) -> torch.Tensor:
 
 
 def block_bucketize(
-    kjt: KeyedJaggedTensor, block_sizes: torch.Tensor, world_size: int, return_permute: bool = False
+    kjt: KeyedJaggedTensor, block_sizes: torch.Tensor, world_size: int, return_permute: bool = False,
+    rank_offsets: Optional[torch.Tensor] = None,
 ):
     """K2: split every bag by owning rank (row-wise sharding).  Returns a KJT with W*F keys
     (rank-major) and, optionally, unbucketize_permute (fbgemm block_bucketize_sparse_features)."""
@@ -245,7 +246,7 @@ def block_bucketize(
     L = _lib.lib()
     ws = _lib.workspace(L.tzr_block_bucketize_workspace(F, B, W), dev)
     rc = L.tzr_block_bucketize(
-        _lib.ptr(block_sizes), F, B, W, _lib.ptr(offsets), _lib.ptr(values), _lib.ptr(weights), n,
+        _lib.ptr(block_sizes), _lib.ptr(rank_offsets), F, B, W, _lib.ptr(offsets), _lib.ptr(values), _lib.ptr(weights), n,
         _lib.ptr(new_lengths), lengths.element_size(), _lib.ptr(new_offsets), _lib.ptr(new_values),
         _lib.ptr(new_weights), _lib.ptr(unbucketize), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev),
     )
