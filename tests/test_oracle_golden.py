@@ -1,0 +1,116 @@
+"""Pin the oracle's index stage against the reference's own golden vectors
+(tests/golden/reference_index_vectors.json, transcribed by make_reference_index_vectors.py from
+tzrec/features/id_feature_test.py and tzrec/datasets/data_parser_test.py) and check the C-ABI
+library exports every symbol include/tzrec_hip.h declares."""
+import ctypes
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+sys.path.insert(0, ROOT)
+from oracle import tzrec_oracle as orc  # noqa: E402
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_index_vectors.json")))
+
+
+@pytest.mark.parametrize("case", G["id_feature_parse"]["cases"])
+def test_id_feature_parse_matches_reference(case):
+    default = [int(case["default"])] if case["default"] != "" else None
+    v, l, w = orc.parse_sparse_feature(case["input"], default)
+    assert v.dtype == np.int64 and v.tolist() == case["values"]
+    assert l.tolist() == case["lengths"]
+    assert w is None
+
+
+def test_weighted_map_parse_matches_reference():
+    case = G["id_feature_parse_weighted"]["cases"][0]
+    v, l, w = orc.parse_sparse_feature(case["input"])
+    assert v.tolist() == case["values"] and l.tolist() == case["lengths"]
+    np.testing.assert_allclose(w, case["weights"])
+
+
+@pytest.mark.parametrize("name", ["data_parser_nofg", "data_parser_weighted"])
+def test_kjt_assembly_matches_reference(name):
+    case = G[name]
+    vals, lens, wts = [], [], []
+    for k in case["kjt"]["keys"]:
+        col = case["columns"][k]
+        v, l, w = orc.parse_sparse_feature(col["input"], col["default"], col["sep"], col.get("weighted", False))
+        vals.append(v)
+        lens.append(l)
+        wts.append(w)
+    kjt = orc.to_kjt(case["kjt"]["keys"], vals, lens, wts)
+    assert kjt["values"].tolist() == case["kjt"]["values"]
+    assert kjt["lengths"].tolist() == case["kjt"]["lengths"]
+    assert kjt["stride"] == 3
+    if "weights" in case["kjt"]:
+        np.testing.assert_allclose(kjt["weights"], case["kjt"]["weights"], rtol=1e-6)
+    else:
+        assert kjt["weights"] is None
+    # offsets of the pinned KJT (torchrec: [0] + cumsum(lengths))
+    off = orc.lengths_to_offsets(kjt["lengths"])
+    assert off[-1] == len(case["kjt"]["values"])
+
+
+def test_kjt_container_matches_reference_fields(emu_path):
+    """The package's KeyedJaggedTensor built from the pinned vectors exposes torchrec's fields."""
+    import torch
+
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    k = G["data_parser_nofg"]["kjt"]
+    kjt = KeyedJaggedTensor.from_lengths_sync(k["keys"], torch.tensor(k["values"]), torch.tensor(k["lengths"], dtype=torch.int32))
+    assert kjt.stride() == 3 and kjt.keys() == k["keys"]
+    assert kjt.offsets().tolist() == [0, 1, 2, 3, 5, 5, 6, 9, 10, 10]
+    assert kjt.length_per_key() == [3, 3, 4]
+
+
+def test_shape_fixtures():
+    import torch
+
+    f = G["shape_fixtures"]
+    x = torch.randn(f["interaction"]["batch"], f["interaction"]["feature_num"], 16)
+    assert list(orc.dot_interaction(x).shape) == f["interaction"]["output"]
+    assert list(orc.fm(torch.randn(*f["fm"]["input"])).shape) == f["fm"]["output"]
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tzrec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tzr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The hipcc-built library loads (no GPU needed for dlopen) and exports the whole header."""
+    from torcheasyrec_amd import _build, _lib
+
+    path = _build.build()
+    handle = ctypes.CDLL(path)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(handle, sym), f"{sym} declared in include/tzrec_hip.h but not exported"
+    assert set(_lib.EXPORTED_SYMBOLS) == set(declared), set(_lib.EXPORTED_SYMBOLS) ^ set(declared)
+    handle.tzr_backend.restype = ctypes.c_char_p
+    assert handle.tzr_backend() == b"hip-gfx950"
+
+
+def test_product_path_has_no_cpu_fallback(emu_path):
+    """With the real library selected, CPU tensors are refused loudly."""
+    import torch
+
+    from torcheasyrec_amd import _build, _lib
+
+    _lib.use_library(_build.build())
+    try:
+        with pytest.raises(_lib.TzrError):
+            _lib.ptr(torch.zeros(4))
+    finally:
+        _lib.use_library(emu_path)
