@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
+    ap.add_argument("--async-plan", action="store_true", help="run the backward index plan on a side stream")
+    ap.add_argument("--no-tunable-gemm", action="store_true",
+                    help="leave the MLP GEMMs on PyTorch's default hipBLASLt heuristics")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to tzr_tune")
     return ap.parse_args()
 
@@ -66,6 +70,25 @@ class _Timers:
     def mean_ms(self, name):
         ps = self.pairs.get(name, [])
         return float(np.mean([a.elapsed_time(b) for a, b in ps])) if ps else None
+
+
+def enable_tunable_gemm():
+    """The MLPs stay on PyTorch.  Its default hipBLASLt heuristic picks poor
+    kernels for the skinny fp32 GEMMs of DLRM (N = 64/32/16): PyTorch TunableOp selects among the
+    rocBLAS / hipBLASLt solutions instead (fp32 in, fp32 accumulate: numerics unchanged).  A tuning
+    file for the B=65536 shapes ships with the package; other shapes are tuned during warm-up."""
+    import shutil
+    import torch.cuda.tunable as tn
+
+    src = os.path.join(ROOT, "torcheasyrec_amd", "tunableop_gfx950.csv")
+    dst = f"/tmp/tzr_tunableop_{os.getpid()}.csv"
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+    tn.enable(True)
+    tn.tuning_enable(True)
+    tn.set_filename(dst, insert_device_ordinal=False)
+    if os.path.exists(dst):
+        tn.read_file(dst)
 
 
 def cpu_baseline(seconds: float):
@@ -131,6 +154,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # everything (warm-up, capture, replay, instrumented steps) runs on ONE non-default stream, so
+    # autograd's AccumulateGrad nodes and the captured graphs agree on it
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)
     if world > 1:
         import torch.distributed as dist
 
@@ -145,6 +172,8 @@ def main():
 
     _lib.use_library(_build.build())
     assert _lib.backend() == "hip-gfx950"
+    if not args.no_tunable_gemm:
+        enable_tunable_gemm()
     for kv in args.tune:
         k, v = kv.split("=")
         _lib.check(_lib.lib().tzr_tune(k.encode(), int(v)), f"tzr_tune {kv}")
@@ -164,9 +193,13 @@ def main():
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                             row_layout=args.row_layout)
         parallelism = model.describe()
-    dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True)
+    use_graph = world == 1 and not args.no_graph
+    # capturable: the dense Adam step lives inside the captured hipGraph
+    dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True, capturable=use_graph)
 
     # synthetic batches, resident in HBM before the timed region
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
     nb = max(1, min(args.n_batches, args.warmup + args.steps))
     batches, host_vals = [], []
     for s in range(nb):
@@ -174,8 +207,6 @@ def main():
         if world > 1:  # this rank's slice of the global batch
             sl = slice(rank * B_local, (rank + 1) * B_local)
             v = kjt.values().view(len(rows), B_global)[:, sl].reshape(-1).contiguous()
-            from torcheasyrec_amd.sparse import KeyedJaggedTensor
-
             kjt = KeyedJaggedTensor(kjt.keys(), v, torch.ones(len(rows) * B_local, dtype=torch.int32), uniform_length=1)
             dense, label = dense[sl].contiguous(), label[sl].contiguous()
         host_vals.append(kjt.values().numpy())
@@ -184,11 +215,10 @@ def main():
 
     timers = _Timers()
     ebc = model.ebc if world == 1 else None
+    if ebc is not None:
+        ebc.async_plan = args.async_plan
 
-    def train_step(i, timed):
-        dense, kjt, label = batches[i % nb]
-        if timed and ebc is not None:
-            ebc._timers = timers
+    def step_body(dense, kjt, label):
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
         loss.backward()
@@ -196,19 +226,39 @@ def main():
             model.allreduce_dense_grads()
         dense_opt.step()
         dense_opt.zero_grad(set_to_none=True)
-        if ebc is not None:
-            ebc._timers = None
         return loss
 
-    for i in range(args.warmup):
-        train_step(i, False)
+    for i in range(args.warmup):  # eager warm-up (also where TunableOp tunes unseen GEMM shapes)
+        loss = step_body(*batches[i % nb])
     torch.cuda.synchronize()
+
+    graphs = None
+    if use_graph:
+        # One hipGraph per distinct batch (inputs already in HBM, nothing is copied per step); all
+        # graphs share one memory pool since they never run concurrently.  A step = one replay:
+        # forward, backward with the fused sparse optimizer, dense Adam -- nothing is skipped.
+        graphs, pool, losses = [], None, []
+        del loss  # drop the eager autograd graph before capturing
+        for bi in range(nb):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=work_stream):
+                losses.append(step_body(*batches[bi]))
+            pool = g.pool()
+            graphs.append(g)
+        torch.cuda.synchronize()
+
+    def run_step(i):
+        if graphs is not None:
+            graphs[i % nb].replay()
+            return losses[i % nb]
+        return step_body(*batches[i % nb])
+
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = train_step(args.warmup + i, True)
+        loss = run_step(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -218,6 +268,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
+    # inside a captured graph); the kernels and inputs are the ones of the timed region
+    if ebc is not None:
+        ebc._timers = timers
+        ebc.async_plan = False
+        for i in range(min(args.steps, 10)):
+            step_body(*batches[i % nb])
+        torch.cuda.synchronize()
+        ebc._timers = None
     ms_per_step = elapsed / args.steps * 1e3
     value = B_global * args.steps / elapsed
 
@@ -230,7 +291,7 @@ def main():
                                f"{args.optimizer} + dense Adam, ids {args.dist}",
                    "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism,
                    "row_layout": args.row_layout, "rows_cap": args.rows_cap or None},
-        "final_loss": float(loss.item()),
+        "final_loss": final_loss, "launch": "hipGraph replay" if graphs is not None else "eager",
     }
     if rank == 0 and world == 1:
         ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]

@@ -289,9 +289,13 @@ def sparse_update(
     """
     if len(ids) == 0:
         return
-    uniq, inv = np.unique(ids, return_inverse=True)
-    g = np.zeros((len(uniq), w.shape[1]), dtype=np.float32)
-    np.add.at(g, inv, grads.astype(np.float32))
+    uniq, inv, counts = np.unique(ids, return_inverse=True, return_counts=True)
+    # stable sort keeps the lookup order inside each row's duplicates; reduceat then adds them
+    # sequentially in fp32 (same result as np.add.at, ~50x faster)
+    order = np.argsort(inv, kind="stable")
+    starts = np.zeros(len(uniq), dtype=np.int64)
+    np.cumsum(counts[:-1], out=starts[1:])
+    g = np.add.reduceat(np.ascontiguousarray(grads, dtype=np.float32)[order], starts, axis=0)
     if opt.gradient_clipping:
         np.clip(g, -opt.max_gradient, opt.max_gradient, out=g)
     lr = np.float32(opt.lr)

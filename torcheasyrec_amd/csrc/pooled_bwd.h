@@ -5,7 +5,7 @@
 
 #define BWD_THREADS 256
 #define BWD_WAVES (BWD_THREADS / TZR_WAVE)
-#define BWD_CH 2048  // sorted positions per chunk (= per workgroup in hist / scatter / reduce)
+#define BWD_CH 1024  // sorted positions per chunk (= per workgroup in hist / scatter / reduce)
 #define BWD_RB 9     // max radix digit width
 #define BWD_NB 512   // bins per chunk histogram row (1 << BWD_RB)
 #define BWD_RANGE (BWD_CH / BWD_WAVES)  // sorted positions reduced by one wave

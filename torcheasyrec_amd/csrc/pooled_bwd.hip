@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
   const int width = P.tab_width[t];
   const int shift = pass * width;
   const unsigned mask = (1u << width) - 1u;
-  const uint32_t* __restrict__ kin = P.key[pass & 1];
+  const uint32_t* __restrict__ kin = (pass & 1) ? P.key[1] : P.key[0];
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) h[i] = 0;
   __syncthreads();
   for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS)
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
   const int width = P.tab_width[t];
   const int shift = pass * width;
   const unsigned mask = (1u << width) - 1u;
-  const uint32_t* __restrict__ kin = P.key[pass & 1];
-  const uint32_t* __restrict__ sin = P.src[pass & 1];
-  uint32_t* __restrict__ kout = P.key[(pass + 1) & 1];
-  uint32_t* __restrict__ sout = P.src[(pass + 1) & 1];
+  const uint32_t* __restrict__ kin = (pass & 1) ? P.key[1] : P.key[0];
+  const uint32_t* __restrict__ sin = (pass & 1) ? P.src[1] : P.src[0];
+  uint32_t* __restrict__ kout = (pass & 1) ? P.key[0] : P.key[1];
+  uint32_t* __restrict__ sout = (pass & 1) ? P.src[0] : P.src[1];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   const unsigned* hrow = P.hist + (size_t)blockIdx.x * BWD_NB;

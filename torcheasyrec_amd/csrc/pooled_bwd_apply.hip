@@ -32,23 +32,33 @@ struct BwdOpt {
 
 // Gradient sources of one lookup (key -> table), resolved once per workgroup when the table is
 // read by a single key (the common case).
+// (scalar fields, no arrays: a runtime-indexed array in this struct lands in scratch memory and
+// turned into 4x write amplification on the first version of this kernel -- profiles/r01b)
 struct BwdSrc {
-  const float* gp[TZR_MAX_FEAT_DST];  // group gradient buffer + first column
-  int64_t gs[TZR_MAX_FEAT_DST];       // sample stride
+  const float *gp0, *gp1, *gp2, *gp3;  // group gradient buffer + first column
+  int64_t gs0, gs1, gs2, gs3;          // sample stride
   int n_dst;
   int mean;
 };
 
-__device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature& ft, const BwdGrads& G) {
+// `sG` = the gradient-buffer descriptors copied to LDS once per workgroup: run-time selection
+// indexes LDS, never a private copy of the kernel arguments.
+__device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature* __restrict__ ft,
+                                              const TzrDst* sG) {
   BwdSrc s;
-  s.n_dst = ft.n_dst;
-  s.mean = ft.pooling == TZR_POOL_MEAN;
-#pragma unroll
-  for (int d = 0; d < TZR_MAX_FEAT_DST; ++d) {
-    const int di = d < ft.n_dst ? ft.dst[d] : 0;
-    s.gp[d] = reinterpret_cast<const float*>(G.d[di].ptr) + ft.col[d];
-    s.gs[d] = G.d[di].stride;
-  }
+  const int n = ft->n_dst;
+  s.n_dst = n;
+  s.mean = ft->pooling == TZR_POOL_MEAN;
+  const int d0 = n > 0 ? ft->dst[0] : 0, d1 = n > 1 ? ft->dst[1] : 0;
+  const int d2 = n > 2 ? ft->dst[2] : 0, d3 = n > 3 ? ft->dst[3] : 0;
+  s.gp0 = reinterpret_cast<const float*>(sG[d0].ptr) + ft->col[0];
+  s.gp1 = reinterpret_cast<const float*>(sG[d1].ptr) + ft->col[1];
+  s.gp2 = reinterpret_cast<const float*>(sG[d2].ptr) + ft->col[2];
+  s.gp3 = reinterpret_cast<const float*>(sG[d3].ptr) + ft->col[3];
+  s.gs0 = sG[d0].stride;
+  s.gs1 = sG[d1].stride;
+  s.gs2 = sG[d2].stride;
+  s.gs3 = sG[d3].stride;
   return s;
 }
 
@@ -57,11 +67,11 @@ __device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature& ft, const BwdGra
 //   grad_mode 1: one gradient row per id: G.d[0][i, :]
 __device__ __forceinline__ float4 bwd_lookup_grad(
     const TzrFeature* __restrict__ feats, const TzrTable& tb, const int32_t* __restrict__ feat_by_order,
-    const BwdGrads& G, const BwdSrc& one, bool single, int grad_mode,
+    const TzrDst* sG, const BwdSrc& one, bool single, int grad_mode,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights,
     const uint32_t* __restrict__ bag_of, int64_t B, int uniform, uint32_t i, int c) {
   if (grad_mode == 1)
-    return tzr_ld4(reinterpret_cast<const float*>(G.d[0].ptr) + (int64_t)i * G.d[0].stride + 4 * c);
+    return tzr_ld4(reinterpret_cast<const float*>(sG[0].ptr) + (int64_t)i * sG[0].stride + 4 * c);
   const uint32_t bag = uniform ? i : bag_of[i];
   const uint32_t key = bag / (uint32_t)B;
   const int64_t b = bag - key * (uint32_t)B;
@@ -69,10 +79,12 @@ __device__ __forceinline__ float4 bwd_lookup_grad(
   if (!single) {  // the lookup of this table that reads `key` (a table is read once per key)
     int o = tb.first_order;
     while (o + 1 < tb.first_order + tb.n_feats && feats[feat_by_order[o]].key != (int32_t)key) ++o;
-    s = bwd_resolve(feats[feat_by_order[o]], G);
+    s = bwd_resolve(feats + feat_by_order[o], sG);
   }
-  float4 g = tzr_ld4(s.gp[0] + b * s.gs[0] + 4 * c);
-  for (int d = 1; d < s.n_dst; ++d) g = tzr_add4(g, tzr_ld4(s.gp[d] + b * s.gs[d] + 4 * c));
+  float4 g = tzr_ld4(s.gp0 + b * s.gs0 + 4 * c);
+  if (s.n_dst > 1) g = tzr_add4(g, tzr_ld4(s.gp1 + b * s.gs1 + 4 * c));
+  if (s.n_dst > 2) g = tzr_add4(g, tzr_ld4(s.gp2 + b * s.gs2 + 4 * c));
+  if (s.n_dst > 3) g = tzr_add4(g, tzr_ld4(s.gp3 + b * s.gs3 + 4 * c));
   const bool mean = !uniform && s.mean;
   if (weights || mean) {
     float sc = weights ? weights[i] : 1.0f;
@@ -97,11 +109,21 @@ __device__ __forceinline__ float bwd_group_sum(float v, int lg, int lane_in_grou
   return s;
 }
 
-// ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g and the row's
-// current weights w4.  All 64 lanes of the wave must call (row-wise adagrad reduces in the group).
+// Prefetch of the elementwise optimizer state of (row, chunk c): issued together with the weight
+// load, before the reduction, so the update itself waits on no memory.
+__device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOpt& opt, int64_t row,
+                                                 int c, bool active) {
+  if (active && opt.kind == TZR_OPT_ADAGRAD)
+    return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
+  return tzr_zero4();
+}
+
+// ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g, the row's current
+// weights w4 and (elementwise adagrad) state m4.  All 64 lanes of the wave must call (row-wise
+// adagrad reduces in the group).
 __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& opt, float lr,
-                                              int64_t row, int c, float4 g, float4 w4, bool active,
-                                              int lg, int lane_in_group, int lane) {
+                                              int64_t row, int c, float4 g, float4 w4, float4 m4,
+                                              bool active, int lg, int lane_in_group, int lane) {
   if (opt.clip) {
     g.x = fminf(fmaxf(g.x, -opt.max_grad), opt.max_grad);
     g.y = fminf(fmaxf(g.y, -opt.max_grad), opt.max_grad);
@@ -112,7 +134,6 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
   if (opt.kind == TZR_OPT_ADAGRAD) {
     if (active) {
       float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
-      float4 m4 = tzr_ld4(mp);
       m4.x += g.x * g.x; m4.y += g.y * g.y; m4.z += g.z * g.z; m4.w += g.w * g.w;
       tzr_st4(mp, m4);
       w4.x -= lr * g.x / (sqrtf(m4.x) + opt.eps);
@@ -164,7 +185,8 @@ __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const Bwd
   const bool on = lane < (tb.dim >> 2);
   float4 w4 = tzr_zero4();
   if (on) w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * lane);
-  bwd_apply_row(tb, opt, lr, (int64_t)key, lane, g, w4, on, TZR_WAVE, lane, lane);
+  const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, lane, on);
+  bwd_apply_row(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
 
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
@@ -175,13 +197,15 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   __shared__ uint32_t sS[BWD_CH];
   __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
   __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
+  __shared__ TzrDst sG[TZR_MAX_DST];
   int t;
   int64_t s, e, ts, te;
   if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
   const TzrTable tb = tables[t];
   const int par = P.tab_npass[t] & 1;
-  const uint32_t* __restrict__ K = P.key[par];
-  const uint32_t* __restrict__ S = P.src[par];
+  // selects, not P.key[par]: a runtime index into the by-value plan spills it to scratch
+  const uint32_t* __restrict__ K = par ? P.key[1] : P.key[0];
+  const uint32_t* __restrict__ S = par ? P.src[1] : P.src[0];
   const int n = (int)(e - s);
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
     sK[i + 1] = K[s + i];
@@ -190,6 +214,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   if (threadIdx.x == 0) {
     sK[0] = s > ts ? K[s - 1] : BWD_SENT;
     sK[n + 1] = e < te ? K[e] : BWD_SENT;
+#pragma unroll
+    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
   }
   __syncthreads();
 
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   const bool lane_on = gi < gw;
   const float lr = *opt.lr;
   const bool single = tb.n_feats == 1;
-  BwdSrc one = bwd_resolve(feats[P.feat_by_order[tb.first_order]], G);
+  const BwdSrc one = bwd_resolve(feats + P.feat_by_order[tb.first_order], sG);
 
   const int r0 = wv * BWD_RANGE;             // range of this wave, chunk-relative
   const int r1 = min(n, r0 + BWD_RANGE);
@@ -221,13 +247,14 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const bool tail = valid && key != nxt;
     float4 g = tzr_zero4();
     if (valid)
-      g = bwd_lookup_grad(feats, tb, P.feat_by_order, G, one, single, grad_mode, offsets, weights,
+      g = bwd_lookup_grad(feats, tb, P.feat_by_order, sG, one, single, grad_mode, offsets, weights,
                           P.bag_of, B, uniform, sS[idx], c);
     const bool in_lead = lead_open && key == leadkey;
     const bool do_apply = tail && !in_lead;
     float4 w4 = tzr_zero4();
     if (do_apply)  // issued before the scan: overlaps the gradient gathers
       w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * c);
+    const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, c, do_apply);
     // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
     // distance d implies one run in between)
     for (int d = 1; d < gw; d <<= 1) {
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
       flags |= BWD_LEAD;
       lead_open = false;
     }
-    bwd_apply_row(tb, opt, lr, (int64_t)key, c, g, w4, do_apply, lg, c, lane);
+    bwd_apply_row(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
     // carry out of the tile: its last valid lookup, if that run goes on
     const int nv = min(gw, r1 - t0);
     const int last = (nv - 1) * lg;

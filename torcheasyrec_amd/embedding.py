@@ -201,6 +201,8 @@ class EmbeddingBagCollection(nn.Module):
         self.fused_optimizer = FusedSparseOptimizer(optimizer, self) if optimizer is not None else None
         self._hook = torch.zeros(0, requires_grad=True, device=device)
         self._timers = None  # bench.py: object with .start(name) -> event recorded after the launch
+        self._side_stream = None
+        self.async_plan = device.type == "cuda"  # overlap the backward index plan with the forward
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
@@ -378,8 +380,30 @@ class EmbeddingBagCollection(nn.Module):
         if ev is not None:
             ev.record()
         _lib.check(rc, "tzr_pooled_bwd_plan")
-        kjt._tzr_plan = (id(self), dst_names, ws)  # type: ignore[attr-defined]
+        if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            ws.record_stream(torch.cuda.current_stream(self._device))
+        kjt._tzr_plan = (id(self), dst_names, ws, None)  # type: ignore[attr-defined]
         return ws
+
+    def plan_backward_async(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> None:
+        """Run K6 on a side HIP stream so it overlaps the forward and the dense MLPs (the reference's
+        TrainPipelineSparseDist runs the input dist of the next batch on its own stream for the same
+        reason, /root/reference/tzrec/utils/dist_util.py:221-303).  The backward waits on the event."""
+        if self._device.type != "cuda":
+            self.plan_backward(kjt, dst_names)
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self._device)
+        cur = torch.cuda.current_stream(self._device)
+        self._side_stream.wait_stream(cur)  # ids / descriptors were produced on the current stream
+        with torch.cuda.stream(self._side_stream):
+            ws = self.plan_backward(kjt, dst_names)
+            ev = torch.cuda.Event()
+            ev.record()
+        for t in (kjt.values(), kjt.offsets_or_none()):
+            if t is not None:
+                t.record_stream(self._side_stream)
+        kjt._tzr_plan = (id(self), dst_names, ws, ev)  # type: ignore[attr-defined]
 
     def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
         if self.fused_optimizer is None:
@@ -387,6 +411,9 @@ class EmbeddingBagCollection(nn.Module):
         cached = getattr(kjt, "_tzr_plan", None)
         if cached is not None and cached[0] == id(self) and cached[1] == dst_names:
             ws = cached[2]
+            if cached[3] is not None:
+                torch.cuda.current_stream(self._device).wait_event(cached[3])
+                ws.record_stream(torch.cuda.current_stream(self._device))
         else:
             ws = self.plan_backward(kjt, dst_names)
         layout = self._layout_for(dst_names)
@@ -430,6 +457,8 @@ class EmbeddingBagCollection(nn.Module):
 
     def _run(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
         if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
+            if self.async_plan and getattr(kjt, "_tzr_plan", None) is None:
+                self.plan_backward_async(kjt, dst_names)
             return list(_PooledLookupFn.apply(self, kjt, dst_names, self._hook))
         return self._launch_forward(kjt, dst_names)
 
