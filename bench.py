@@ -5,8 +5,9 @@
 
 One "step" = one full training step of examples/dlrm_criteo.config (26 tables x dim 16, 204M rows,
 fused sparse Adagrad in backward, bottom/top MLPs, dot interaction, BCE, dense Adam) over one
-synthetic Criteo-shaped batch.  Headline workload: GLOBAL batch 65536 (65536/N per rank; strong
-scaling) with inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+synthetic Criteo-shaped batch.  Headline workload: batch 65536 PER GPU (tzrec's batch_size is per
+rank: weak scaling; `--scaling strong` fixes the global batch at 65536 instead) with inputs already
+resident in HBM.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      HBM roofline of the dominant embedding kernel (pooled gather forward), achieved =
@@ -37,8 +38,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--global-batch", type=int, default=65536)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--global-batch", "--batch", dest="global_batch", type=int, default=65536,
+                    help="batch 65536: per rank under weak scaling (default), global under --scaling strong")
+    # tzrec's data_config.batch_size is PER RANK (tzrec/datasets/dataset.py:197,503-508), so
+    # "DLRM-Criteo batch 65536 at 1/2/4/8 GPUs" = 65536 samples per GPU per step: per-GPU work is
+    # fixed as N grows (weak scaling).  --scaling strong keeps the GLOBAL batch at 65536 instead
+    # (BASELINE.md's alternative reading; 8192 per rank at N=8).  At N=1 both are the same run.
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--optimizer", choices=["adagrad", "rowwise_adagrad"], default="adagrad")
     ap.add_argument("--row-layout", choices=["interleaved", "split"], default="interleaved")
@@ -46,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--async-plan", action="store_true", help="run the backward index plan on a side stream")
     ap.add_argument("--no-tunable-gemm", action="store_true",
@@ -158,11 +166,17 @@ def main():
     # autograd's AccumulateGrad nodes and the captured graphs agree on it
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from torcheasyrec_amd import _build, _lib
     from torcheasyrec_amd.criteo import (CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, algorithmic_bytes,
@@ -183,7 +197,7 @@ def main():
     B_local = B_global // world
     torch.manual_seed(1234)
     sopt = SparseOptimizerConfig(kind=args.optimizer, lr=1e-3)
-    if world == 1:
+    if not sharded:
         model = DLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                      row_layout=args.row_layout)
         parallelism = "single GPU, all tables local (table-wise on one rank)"
@@ -193,7 +207,7 @@ def main():
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                             row_layout=args.row_layout)
         parallelism = model.describe()
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not sharded and not args.no_graph
     # capturable: the dense Adam step lives inside the captured hipGraph
     dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True, capturable=use_graph)
 
@@ -214,7 +228,7 @@ def main():
     torch.cuda.synchronize()
 
     timers = _Timers()
-    ebc = model.ebc if world == 1 else None
+    ebc = model.ebc if not sharded else None
     if ebc is not None:
         ebc.async_plan = args.async_plan
 
@@ -222,7 +236,7 @@ def main():
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
         loss.backward()
-        if world > 1:
+        if sharded:
             model.allreduce_dense_grads()
         dense_opt.step()
         dense_opt.zero_grad(set_to_none=True)
@@ -283,7 +297,8 @@ def main():
     value = B_global * args.steps / elapsed
 
     out = {
-        "metric": "samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, global batch 65536",
+        "metric": "samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch 65536 "
+                  + ("per GPU (tzrec batch_size is per rank)" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -316,7 +331,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

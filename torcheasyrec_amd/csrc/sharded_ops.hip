@@ -10,27 +10,70 @@
 //             requester: K5 pooled gather over the received rows (ids = unbucketize positions)
 //   backward  requester: tzr_lookup_grads: one gradient row per id -> all-to-all
 //             owner:     K6 plan + K7 apply with per-id gradient rows (grad_mode 1)
+// Both kernels are HBM-bound gathers/scatters of 64-byte rows; all per-key / per-lookup metadata
+// is resolved once per workgroup into LDS so a lane's dependent chain is id -> row.
 #include "tzr_common.h"
 
 #define SH_THREADS 256
+#define SH_MAXKEYS 256  // keys (owner: W*F segments; requester: lookups) staged in LDS per pass
+
+struct ShKey {  // resolved key segment on the owner
+  const float* w;
+  int64_t rows;
+  int32_t w_stride;
+  int32_t dim;
+};
 
 // out[j, :] = W_{table(key(j))}[ids[j], :] for j in [0, n): key(j) = segment of key_start holding j.
 __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
     const TzrTable* __restrict__ tables, const int32_t* __restrict__ key_table,
     const int64_t* __restrict__ key_start, int n_keys, const int64_t* __restrict__ ids, int64_t n,
-    float* __restrict__ out, int64_t out_stride, int lg) {
-  const int64_t total = n * lg;
-  for (int64_t k = (int64_t)blockIdx.x * SH_THREADS + threadIdx.x; k < total;
-       k += (int64_t)gridDim.x * SH_THREADS) {
-    const int64_t j = k / lg;
-    const int c = (int)(k - j * lg);
-    const int64_t key = tzr_last_le(key_start, n_keys, j);
-    const TzrTable tb = tables[key_table[key]];
+    float* __restrict__ out, int64_t out_stride, int lg, int rows_per_block) {
+  __shared__ int64_t s_start[SH_MAXKEYS + 1];
+  __shared__ ShKey s_key[SH_MAXKEYS];
+  const int64_t j0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t j1 = min(n, j0 + rows_per_block);
+  // the keys overlapping this block's rows: [k0, k1]
+  int k0 = (int)tzr_last_le(key_start, n_keys, j0);
+  int k1 = (int)tzr_last_le(key_start, n_keys, j1 - 1);
+  const bool staged = k1 - k0 < SH_MAXKEYS;
+  if (staged) {
+    for (int k = k0 + threadIdx.x; k <= k1; k += SH_THREADS) {
+      const TzrTable tb = tables[key_table[k]];
+      ShKey e;
+      e.w = reinterpret_cast<const float*>(tb.w);
+      e.rows = tb.rows;
+      e.w_stride = tb.w_stride;
+      e.dim = tb.dim;
+      s_key[k - k0] = e;
+      s_start[k - k0] = key_start[k];
+    }
+    if (threadIdx.x == 0) s_start[k1 - k0 + 1] = key_start[k1 + 1];
+  }
+  __syncthreads();
+  const int64_t total = (j1 - j0) * lg;
+  for (int64_t k = threadIdx.x; k < total; k += SH_THREADS) {
+    const int64_t j = j0 + k / lg;
+    const int c = (int)(k % lg);
+    ShKey e;
+    if (staged) {
+      int a = 0, b = k1 - k0 + 1;  // s_start[a] <= j < s_start[b]
+      while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (s_start[m] <= j) a = m; else b = m;
+      }
+      e = s_key[a];
+    } else {
+      const TzrTable tb = tables[key_table[tzr_last_le(key_start, n_keys, j)]];
+      e.w = reinterpret_cast<const float*>(tb.w);
+      e.rows = tb.rows;
+      e.w_stride = tb.w_stride;
+      e.dim = tb.dim;
+    }
     int64_t id = ids[j];
-    if ((uint64_t)id >= (uint64_t)tb.rows) id = 0;
+    if ((uint64_t)id >= (uint64_t)e.rows) id = 0;
     float4 v = tzr_zero4();
-    if (4 * c < tb.dim)
-      v = tzr_ld4(reinterpret_cast<const float*>(tb.w) + id * (int64_t)tb.w_stride + 4 * c);
+    if (4 * c < e.dim) v = tzr_ld4(e.w + id * (int64_t)e.w_stride + 4 * c);
     tzr_st4(out + j * out_stride + 4 * c, v);
   }
 }
@@ -45,11 +88,11 @@ extern "C" int tzr_rows_gather(const TzrTable* d_tables, const int32_t* d_key_ta
   if (n_ids == 0) return TZR_OK;
   if (!d_ids || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return TZR_ERR_INVALID;
   const int lg = dim >> 2;
-  const int64_t total = n_ids * lg;
-  const unsigned grid = (unsigned)std::min<int64_t>(16384, (total + SH_THREADS - 1) / SH_THREADS);
+  const int rows_per_block = 1024;
+  const unsigned grid = (unsigned)((n_ids + rows_per_block - 1) / rows_per_block);
   hipLaunchKernelGGL(tzr_rows_gather_kernel, dim3(grid), dim3(SH_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_tables, d_key_table, d_key_start, n_keys,
-                     d_ids, n_ids, d_out, out_stride, lg);
+                     d_ids, n_ids, d_out, out_stride, lg, rows_per_block);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
@@ -58,34 +101,73 @@ struct ShGrads {
   TzrDst d[TZR_MAX_DST];
 };
 
+struct ShLookup {  // resolved requester lookup
+  const float* gp[TZR_MAX_FEAT_DST];  // group gradient buffer + first column (statically indexed)
+  int64_t gs[TZR_MAX_FEAT_DST];
+  int32_t key;
+  int32_t n_dst;
+  int32_t mean;
+  int32_t pad;
+};
+
 // out[pos[i], :] = scale_i * sum_{groups g of key f} grad_g[b, col_g(f) : +dim] for every id i of
-// bag (f, b); scale_i = weight_i (/ len(bag) for mean pooling).  thread = (sample, lookup, chunk).
+// bag (f, b); scale_i = weight_i (/ len(bag) for mean pooling).  workgroup = tile of samples x all
+// lookups; thread = (sample, lookup, chunk) with chunk fastest, so the D/4 lanes of a lookup read
+// one 64-byte gradient slice and write one 64-byte row.
 __global__ __launch_bounds__(SH_THREADS) void tzr_lookup_grads_kernel(
     const TzrFeature* __restrict__ feats, int n_feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ weights, int64_t B, int uniform,
     const int64_t* __restrict__ positions, ShGrads G, float* __restrict__ out, int64_t out_stride,
-    int lg) {
-  const int64_t total = B * n_feats * lg;
-  for (int64_t k = (int64_t)blockIdx.x * SH_THREADS + threadIdx.x; k < total;
-       k += (int64_t)gridDim.x * SH_THREADS) {
-    const int c = (int)(k % lg);
-    const int64_t r = k / lg;
-    const int f = (int)(r % n_feats);
-    const int64_t b = r / n_feats;
-    const TzrFeature ft = feats[f];
-    const int64_t bag = (int64_t)ft.key * B + b;
-    const int64_t st = uniform ? bag : offsets[bag];
-    const int64_t en = uniform ? bag + 1 : offsets[bag + 1];
-    if (st >= en) continue;
-    float4 g = tzr_zero4();
-    for (int d = 0; d < ft.n_dst; ++d)
-      g = tzr_add4(g, tzr_ld4(reinterpret_cast<const float*>(G.d[ft.dst[d]].ptr) +
-                              b * G.d[ft.dst[d]].stride + ft.col[d] + 4 * c));
-    const float inv = (ft.pooling == TZR_POOL_MEAN && en - st > 1) ? 1.0f / (float)(en - st) : 1.0f;
-    for (int64_t i = st; i < en; ++i) {
-      const float sc = (weights ? weights[i] : 1.0f) * inv;
-      const int64_t p = positions ? positions[i] : i;
-      tzr_st4(out + p * out_stride + 4 * c, make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc));
+    int lg, int tile_b) {
+  __shared__ ShLookup s_lk[SH_MAXKEYS];
+  __shared__ TzrDst s_g[TZR_MAX_DST];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < TZR_MAX_DST; ++i) s_g[i] = G.d[i];
+  }
+  __syncthreads();
+  const int64_t b0 = (int64_t)blockIdx.x * tile_b;
+  const int nb = (int)min((int64_t)tile_b, B - b0);
+  for (int f0 = 0; f0 < n_feats; f0 += SH_MAXKEYS) {
+    const int nf = min(SH_MAXKEYS, n_feats - f0);
+    __syncthreads();
+    for (int f = threadIdx.x; f < nf; f += SH_THREADS) {
+      const TzrFeature* ft = feats + f0 + f;
+      ShLookup e;
+      e.key = ft->key;
+      e.n_dst = ft->n_dst;
+      e.mean = ft->pooling == TZR_POOL_MEAN;
+      e.pad = 0;
+#pragma unroll
+      for (int d = 0; d < TZR_MAX_FEAT_DST; ++d) {
+        const int di = d < ft->n_dst ? ft->dst[d] : 0;
+        e.gp[d] = reinterpret_cast<const float*>(s_g[di].ptr) + ft->col[d];
+        e.gs[d] = s_g[di].stride;
+      }
+      s_lk[f] = e;
+    }
+    __syncthreads();
+    const int total = nb * nf * lg;
+    for (int k = threadIdx.x; k < total; k += SH_THREADS) {
+      const int c = k % lg;
+      const int r = k / lg;
+      const int f = r % nf;
+      const int64_t b = b0 + r / nf;
+      const ShLookup* e = &s_lk[f];
+      const int64_t bag = (int64_t)e->key * B + b;
+      const int64_t st = uniform ? bag : offsets[bag];
+      const int64_t en = uniform ? bag + 1 : offsets[bag + 1];
+      if (st >= en) continue;
+      float4 g = tzr_ld4(e->gp[0] + b * e->gs[0] + 4 * c);
+      if (e->n_dst > 1) g = tzr_add4(g, tzr_ld4(e->gp[1] + b * e->gs[1] + 4 * c));
+      if (e->n_dst > 2) g = tzr_add4(g, tzr_ld4(e->gp[2] + b * e->gs[2] + 4 * c));
+      if (e->n_dst > 3) g = tzr_add4(g, tzr_ld4(e->gp[3] + b * e->gs[3] + 4 * c));
+      const float inv = (e->mean && en - st > 1) ? 1.0f / (float)(en - st) : 1.0f;
+      for (int64_t i = st; i < en; ++i) {
+        const float sc = (weights ? weights[i] : 1.0f) * inv;
+        const int64_t p = positions ? positions[i] : i;
+        tzr_st4(out + p * out_stride + 4 * c, make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc));
+      }
     }
   }
 }
@@ -111,11 +193,11 @@ extern "C" int tzr_lookup_grads(const TzrFeature* d_feats, int n_feats, const in
     G.d[i] = h_grads[i];
   }
   const int lg = dim >> 2;
-  const int64_t total = B * n_feats * lg;
-  const unsigned grid = (unsigned)std::min<int64_t>(16384, (total + SH_THREADS - 1) / SH_THREADS);
+  const int tile_b = B <= 16384 ? 8 : 32;
+  const unsigned grid = (unsigned)((B + tile_b - 1) / tile_b);
   hipLaunchKernelGGL(tzr_lookup_grads_kernel, dim3(grid), dim3(SH_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_feats, n_feats, d_offsets, d_weights, B,
-                     (int)uniform, d_positions, G, d_out, out_stride, lg);
+                     (int)uniform, d_positions, G, d_out, out_stride, lg, tile_b);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -137,6 +137,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._hook = torch.zeros(0, requires_grad=True, device=self._device)
         self._req_meta: Dict[Tuple, dict] = {}
         self._own_meta: Optional[dict] = None
+        self._rows_buf: Dict[int, tuple] = {}
         self._timers = None
 
     # -- descriptors ---------------------------------------------------------------------------
@@ -224,6 +225,22 @@ class ShardedEmbeddingBagCollection(nn.Module):
         }
         return self._own_meta
 
+    def _recv_rows_buffer(self, n: int):
+        """Persistent [n, D] buffer for the rows coming back from their owners plus the one-table
+        descriptor that lets K5 pool over it (cached: no per-step upload)."""
+        hit = self._rows_buf.get(n)
+        if hit is None:
+            D = self.dim
+            rows_in = torch.empty(max(n, 1), D, dtype=torch.float32, device=self._device)
+            pt = np.zeros(1, dtype=_lib.TABLE_DT)
+            pt[0]["w"], pt[0]["rows"], pt[0]["dim"], pt[0]["w_stride"] = rows_in.data_ptr(), max(n, 1), D, D
+            pt[0]["n_feats"] = len(self._lookups)
+            hit = (rows_in, _lib.upload_struct(pt, self._device))
+            if len(self._rows_buf) > 8:
+                self._rows_buf.clear()
+            self._rows_buf[n] = hit
+        return hit
+
     # -- exchange ------------------------------------------------------------------------------
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits) -> None:
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
@@ -257,13 +274,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                      _lib.ptr(key_start), om["K"], _lib.ptr(recv_ids), n_recv,
                                      _lib.ptr(rows_out), D, D, stream), "tzr_rows_gather")
         # 4. rows back to the requesters (bucketized order)
-        rows_in = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+        rows_in, d_pt = self._recv_rows_buffer(N)
         self._a2a(rows_in[:N], rows_out[:n_recv], send_splits, recv_splits)
         # 5. requester: pooled gather over the received rows, ids = position in bucketized order
-        pt = np.zeros(1, dtype=_lib.TABLE_DT)
-        pt[0]["w"], pt[0]["rows"], pt[0]["dim"], pt[0]["w_stride"] = rows_in.data_ptr(), max(N, 1), D, D
-        pt[0]["n_feats"] = len(self._lookups)
-        d_pt = _lib.upload_struct(pt, dev)
         uniform = kjt.uniform_length() == 1
         offsets = None if uniform else kjt.offsets()
         outs = [torch.empty(B, w, dtype=torch.float32, device=dev) for w in rm["widths"]]
