@@ -1,0 +1,113 @@
+"""BASELINE config 1 (plumbing): a tzrec pipeline config in text format -> features / feature groups
+-> tables (naming, WIDE `_wide` dim 4, shared `embedding_name`, `feature@table`) -> model -> train
+steps through the pipeline; logits checked against the oracle's DeepFM restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.config import load_pipeline_spec, parse_text_proto  # noqa: E402
+from torcheasyrec_amd.criteo import CRITEO_ROWS  # noqa: E402
+from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, TrainPipeline  # noqa: E402
+from torcheasyrec_amd.rank_model import build_rank_model  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor  # noqa: E402
+
+HERE = os.path.dirname(__file__)
+REF = "/root/reference/examples"
+
+
+def test_text_format_parser_basics():
+    m = parse_text_proto('a { b: 1 c: "x\\ty" d: [1, 2, 3] e: FOO } a { b: 2.5 } # comment\nf: true')
+    assert len(m.many("a")) == 2 and m.many("a")[0].one("b") == 1 and m.many("a")[0].one("c") == "x\ty"
+    assert m.many("a")[0].many("d") == [1, 2, 3] and m.many("a")[0].one("e") == "FOO"
+    assert m.many("a")[1].one("b") == 2.5 and m.one("f") is True
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_example_configs_parse():
+    spec = load_pipeline_spec(open(os.path.join(REF, "dlrm_criteo.config")).read())
+    assert spec.model_name == "dlrm" and spec.batch_size == 8192
+    assert [f.num_embeddings for f in spec.features if f.is_sparse] == CRITEO_ROWS
+    assert sum(1 for f in spec.features if not f.is_sparse) == 13
+    assert spec.sparse_optimizer.kind == "adagrad" and abs(spec.sparse_optimizer.lr - 0.001) < 1e-9
+    assert [g.group_name for g in spec.feature_groups] == ["dense", "sparse"]
+    assert spec.model.one("arch_with_sparse") is True
+    assert spec.model.one("final").many("hidden_units") == [64, 32]
+    spec2 = load_pipeline_spec(open(os.path.join(REF, "deepfm_criteo.config")).read())
+    assert spec2.model_name == "deepfm"
+    assert [g.group_type for g in spec2.feature_groups] == ["WIDE", "DEEP", "DEEP"]
+    assert spec2.model.one("deep").many("hidden_units") == [512, 256, 128]
+
+
+def _batches(spec, n_rows, bs, seed=0):
+    rng = np.random.default_rng(seed)
+    sparse = [f for f in spec.features if f.is_sparse]
+    dense = [f for f in spec.features if not f.is_sparse]
+    ids = {f.name: rng.integers(0, f.num_embeddings, size=n_rows) for f in sparse}
+    dv = {f.name: np.log(rng.integers(0, 1000, size=(n_rows, f.value_dim)) + 3.0).astype(np.float32) for f in dense}
+    label = (rng.random(n_rows) < 0.25).astype(np.int64)
+    for s in range(0, n_rows, bs):
+        e = min(n_rows, s + bs)
+        kjt = KeyedJaggedTensor([f.name for f in sparse], torch.from_numpy(np.concatenate([ids[f.name][s:e] for f in sparse])),
+                                torch.ones(len(sparse) * (e - s), dtype=torch.int32))
+        kt = KeyedTensor([f.name for f in dense], [f.value_dim for f in dense],
+                         torch.from_numpy(np.concatenate([dv[f.name][s:e] for f in dense], axis=1)))
+        yield Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt}, {"label": torch.from_numpy(label[s:e])})
+
+
+def test_deepfm_config_to_training(dev):
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "deepfm_mini.config")).read())
+    torch.manual_seed(0)
+    model = build_rank_model(spec, device=dev)
+    eg = model.embedding_group
+    # table construction rules (tzrec/modules/embedding.py:744-786, 576-600, 826-827)
+    names = [c.name for c in eg.ebc.embedding_bag_configs()]
+    assert names == ["cat_0_emb_wide", "cat_1_emb_wide", "cat_2_emb_wide", "cat_0_emb", "cat_1_emb", "cat_2_emb"]
+    cfg = {c.name: c for c in eg.ebc.embedding_bag_configs()}
+    assert cfg["cat_0_emb_wide"].embedding_dim == 4 and cfg["cat_0_emb"].embedding_dim == 16
+    assert cfg["cat_2_emb"].feature_names == ["cat_2", "cat_3"]  # shared through embedding_name
+    assert cfg["cat_2_emb_wide"].feature_names == ["cat_2", "cat_3"]
+    assert eg.group_total_dim("wide") == 16 and eg.group_total_dim("fm") == 64 and eg.group_total_dim("deep") == 4 + 64
+    assert eg.group_dims("deep") == [1, 1, 2, 16, 16, 16, 16]
+    assert spec.sparse_optimizer.kind == "adagrad" and spec.batch_size == 250
+
+    # first batch: logits vs the oracle restatement of DeepFM.predict
+    first = next(_batches(spec, 1000, spec.batch_size))
+    w = {n: t.detach().cpu().clone() for n, t in eg.ebc.table_weights().items()}
+    with torch.no_grad():
+        logits = model(first.to(dev))["logits"].cpu()
+    kjt = first.sparse_features[BASE_DATA_GROUP]
+    B = kjt.stride()
+    deep_tabs = [w["cat_0_emb"], w["cat_1_emb"], w["cat_2_emb"], w["cat_2_emb"]]
+    wide_tabs = [w["cat_0_emb_wide"], w["cat_1_emb_wide"], w["cat_2_emb_wide"], w["cat_2_emb_wide"]]
+    bd = orc.pooled_lookup(deep_tabs, ["sum"] * 4, kjt.values(), kjt.lengths(), B)
+    bw = orc.pooled_lookup(wide_tabs, ["sum"] * 4, kjt.values(), kjt.lengths(), B)
+    lin = lambda seq: [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seq if hasattr(m, "weight")]  # noqa: E731
+    p = {"dim": 16, "deep_mlp": lin(model.deep_mlp.mlp), "final_mlp": lin(model.final_mlp.mlp),
+         "output": (model.output_mlp.weight.detach().cpu(), model.output_mlp.bias.detach().cpu())}
+    emb = torch.cat(bd, dim=1)
+    dense = first.dense_features[BASE_DATA_GROUP].values()
+    ref = orc.deepfm_forward(torch.cat(bw, dim=1), emb, torch.cat([dense, emb], dim=1), p)
+    torch.testing.assert_close(logits, ref, rtol=1e-5, atol=1e-5)
+
+    # 1k synthetic rows through pipeline.progress(): losses finite, tables move, StopIteration at end
+    opt = torch.optim.Adam(list(model.dense_parameters()), lr=spec.dense_lr)
+    pipe = TrainPipeline(model, opt, dev, model.loss)
+    it = iter(_batches(spec, 1000, spec.batch_size))
+    seen = []
+    while True:
+        try:
+            losses, preds, batch = pipe.progress(it)
+        except StopIteration:
+            break
+        seen.append(float(losses["binary_cross_entropy"]))
+        assert preds["probs"].shape == (batch.labels["label"].shape[0],)
+    assert len(seen) == 4 and all(np.isfinite(seen))
+    assert not torch.equal(eg.ebc.table_weights()["cat_0_emb"].detach().cpu(), w["cat_0_emb"])
+    # sparse LR schedulers mutate fused_optimizer.param_groups (tzrec/main.py:877-879)
+    model.fused_optimizer.param_groups[0]["lr"] = 0.01
+    assert abs(float(model.fused_optimizer.lr_device(dev).item()) - 0.01) < 1e-9

@@ -1,0 +1,218 @@
+"""Read tzrec pipeline configs (protobuf text format) without protoc / generated *_pb2 modules.
+
+The reference loads ``examples/*.config`` with ``text_format.Merge`` into ``EasyRecConfig``
+(/root/reference/tzrec/utils/config_util.py:25-48); the generated ``tzrec/protos/*_pb2.py`` cannot
+be produced here (no protoc).  The hot path only needs the few fields listed
+in SURVEY.md section 8 (feature_configs, model_config.feature_groups, the dlrm/deepfm blocks,
+train_config.sparse_optimizer, data_config.batch_size), so this module parses the text format
+generically and extracts those.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+from .embedding import SparseOptimizerConfig
+
+_TOKEN = re.compile(r'\s*(?:(#[^\n]*)|("(?:\\.|[^"\\])*")|([{}\[\]:,;<>])|([^\s{}\[\]:,;<>"]+))')
+
+
+class Msg(dict):
+    """A parsed message: field name -> list of values (scalars or Msg), in file order."""
+
+    def one(self, key: str, default: Any = None) -> Any:
+        v = self.get(key)
+        return v[-1] if v else default
+
+    def many(self, key: str) -> List[Any]:
+        return self.get(key, [])
+
+    def has(self, key: str) -> bool:
+        return key in self
+
+
+def _scalar(tok: str) -> Any:
+    if tok.startswith('"'):
+        return bytes(tok[1:-1], "utf-8").decode("unicode_escape")
+    if tok in ("true", "True"):
+        return True
+    if tok in ("false", "False"):
+        return False
+    try:
+        return int(tok)
+    except ValueError:
+        pass
+    try:
+        return float(tok)
+    except ValueError:
+        return tok  # enum identifier
+
+
+def parse_text_proto(text: str) -> Msg:
+    toks: List[str] = []
+    pos = 0
+    while pos < len(text):
+        m = _TOKEN.match(text, pos)
+        if not m:
+            if text[pos:].strip() == "":
+                break
+            raise ValueError(f"cannot tokenize config at offset {pos}: {text[pos:pos + 30]!r}")
+        pos = m.end()
+        if m.group(1):
+            continue
+        toks.append(m.group(2) or m.group(3) or m.group(4))
+    i = 0
+
+    def parse_msg(end: Optional[str]) -> Msg:
+        nonlocal i
+        out = Msg()
+        while i < len(toks):
+            t = toks[i]
+            if t == end:
+                i += 1
+                return out
+            if t in (",", ";"):
+                i += 1
+                continue
+            name = t
+            i += 1
+            if i < len(toks) and toks[i] == ":":
+                i += 1
+            t = toks[i]
+            if t in ("{", "<"):
+                i += 1
+                out.setdefault(name, []).append(parse_msg("}" if t == "{" else ">"))
+            elif t == "[":
+                i += 1
+                while toks[i] != "]":
+                    if toks[i] == ",":
+                        i += 1
+                        continue
+                    if toks[i] == "{":
+                        i += 1
+                        out.setdefault(name, []).append(parse_msg("}"))
+                    else:
+                        out.setdefault(name, []).append(_scalar(toks[i]))
+                        i += 1
+                i += 1
+            else:
+                out.setdefault(name, []).append(_scalar(t))
+                i += 1
+        if end is not None:
+            raise ValueError("unbalanced braces in config")
+        return out
+
+    return parse_msg(None)
+
+
+@dataclass
+class FeatureSpec:
+    """What the hot path needs from a tzrec feature (tzrec/features/feature.py:586-662,
+    id_feature.py:52-87, raw_feature.py:35-48)."""
+
+    name: str
+    kind: str  # "id_feature" | "raw_feature" | ...
+    is_sparse: bool
+    embedding_dim: int = 0
+    num_embeddings: int = 0
+    embedding_name: Optional[str] = None
+    pooling: str = "sum"
+    value_dim: int = 1
+
+
+@dataclass
+class FeatureGroupSpec:
+    group_name: str
+    feature_names: List[str]
+    group_type: str = "DEEP"  # DEEP | WIDE | SEQUENCE
+    embedding_name_suffix: Optional[str] = None
+
+
+@dataclass
+class PipelineSpec:
+    features: List[FeatureSpec] = field(default_factory=list)
+    feature_groups: List[FeatureGroupSpec] = field(default_factory=list)
+    model_name: str = ""
+    model: Msg = field(default_factory=Msg)
+    wide_embedding_dim: int = 0
+    num_class: int = 1
+    batch_size: int = 0
+    sparse_optimizer: Optional[SparseOptimizerConfig] = None
+    dense_lr: float = 1e-3
+    label_fields: List[str] = field(default_factory=list)
+
+
+def _num_embeddings(f: Msg, name: str) -> int:
+    """IdFeature.num_embeddings precedence (tzrec/features/id_feature.py:64-87)."""
+    if f.has("zch"):
+        return int(f.one("zch").one("zch_size"))
+    if f.has("dynamicemb"):
+        return int(f.one("dynamicemb").one("max_capacity"))
+    if f.has("hash_bucket_size"):
+        return int(f.one("hash_bucket_size"))
+    if f.has("num_buckets"):
+        return int(f.one("num_buckets"))
+    if f.has("vocab_list"):
+        return len(f.many("vocab_list"))
+    raise ValueError(f"IdFeature[{name}] must set hash_bucket_size or num_buckets or vocab_list or zch.zch_size")
+
+
+def sparse_optimizer_from_config(opt: Msg) -> SparseOptimizerConfig:
+    """create_sparse_optimizer mapping (tzrec/optim/optimizer_builder.py:30-97) for the kinds this
+    library fuses; field defaults from protos/optimizer.proto:76-139."""
+    table = {"sgd_optimizer": "sgd", "adagrad_optimizer": "adagrad", "rowwise_adagrad_optimizer": "rowwise_adagrad"}
+    for key, kind in table.items():
+        if opt.has(key):
+            m = opt.one(key)
+            return SparseOptimizerConfig(
+                kind=kind, lr=float(m.one("lr", 0.002)), weight_decay=float(m.one("weight_decay", 0.0)),
+                weight_decay_mode=str(m.one("weight_decay_mode", "NONE")).lower(),
+                gradient_clipping=bool(m.one("gradient_clipping", False)),
+                max_gradient=float(m.one("max_gradient", 1.0)),
+                initial_accumulator_value=float(m.one("initial_accumulator_value", 0.0)),
+            )
+    raise ValueError(f"Unknown optimizer: {[k for k in opt.keys()]}")
+
+
+def load_pipeline_spec(text: str) -> PipelineSpec:
+    cfg = parse_text_proto(text)
+    spec = PipelineSpec()
+    for fc in cfg.many("feature_configs"):
+        (kind, body), = fc.items()
+        f = body[-1]
+        name = f.one("feature_name") or f.one("sequence_name")
+        if kind == "id_feature":
+            spec.features.append(FeatureSpec(
+                name=name, kind=kind, is_sparse=True, embedding_dim=int(f.one("embedding_dim", 0)),
+                num_embeddings=_num_embeddings(f, name), embedding_name=f.one("embedding_name"),
+                pooling=str(f.one("pooling", "sum")).lower()))
+        elif kind == "raw_feature":
+            spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=False,
+                                             value_dim=int(f.one("value_dim", 1))))
+        else:
+            spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=f.has("embedding_dim"),
+                                             embedding_dim=int(f.one("embedding_dim", 0))))
+    mc = cfg.one("model_config", Msg())
+    for g in mc.many("feature_groups"):
+        spec.feature_groups.append(FeatureGroupSpec(
+            group_name=g.one("group_name"), feature_names=list(g.many("feature_names")),
+            group_type=str(g.one("group_type", "DEEP")), embedding_name_suffix=g.one("embedding_name_suffix")))
+    skip = {"feature_groups", "metrics", "losses", "num_class", "train_metrics", "variational_dropout",
+            "kd", "use_pareto_loss_weight", "pareto"}
+    for k, v in mc.items():
+        if k not in skip and isinstance(v[-1], Msg):
+            spec.model_name, spec.model = k, v[-1]
+    spec.num_class = int(mc.one("num_class", 1))
+    spec.wide_embedding_dim = int(spec.model.one("wide_embedding_dim", 0)) if spec.model else 0
+    tc = cfg.one("train_config", Msg())
+    if tc.has("sparse_optimizer"):
+        spec.sparse_optimizer = sparse_optimizer_from_config(tc.one("sparse_optimizer"))
+    if tc.has("dense_optimizer"):
+        for _, v in tc.one("dense_optimizer").items():
+            if isinstance(v[-1], Msg) and v[-1].has("lr"):
+                spec.dense_lr = float(v[-1].one("lr"))
+    dc = cfg.one("data_config", Msg())
+    spec.batch_size = int(dc.one("batch_size", 0))
+    spec.label_fields = list(dc.many("label_fields"))
+    return spec

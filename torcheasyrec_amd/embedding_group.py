@@ -1,0 +1,234 @@
+"""EmbeddingGroup: features + feature groups -> tables -> grouped tensors.
+
+Host-side mirror of ``tzrec.modules.embedding.EmbeddingGroup / EmbeddingGroupImpl`` for pooled
+(DEEP / WIDE) groups (/root/reference/tzrec/modules/embedding.py:167-536, 681-978):
+
+* table name = ``embedding_name`` or ``{feature}_emb`` (features/feature.py:615); WIDE groups append
+  ``_wide`` and force dim = ``wide_embedding_dim or 4`` (embedding.py:744-745,777-786); an optional
+  ``_{embedding_name_suffix}`` follows (:746-747);
+* tables with one name are shared iff rows, dim and pooling match, else an error (:576-600);
+* a feature that lands on more than one table is exposed as ``feature@table`` (:753-758,826-827);
+* a group's tensor is the column concat of its features in ``feature_names`` order; dense (raw)
+  features are columns of the dense KeyedTensor (:963-976).
+
+``forward(batch)`` returns ``{group_name: Tensor}`` like the reference (rank_model.py:116); the
+pooled blocks are written in group layout by the lookup kernel, so no regroup copy happens for
+groups made only of sparse features.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .config import FeatureGroupSpec, FeatureSpec
+from .embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+from .sparse import KeyedJaggedTensor, KeyedTensor
+
+BASE_DATA_GROUP = "__BASE__"  # tzrec/datasets/utils.py:28
+
+
+@dataclass
+class Batch:
+    """Input data batch (tzrec/datasets/utils.py:298-463): dense KeyedTensor, sparse KJT and labels
+    per data group; Pipelineable (to / record_stream / pin_memory)."""
+
+    dense_features: Dict[str, KeyedTensor] = field(default_factory=dict)
+    sparse_features: Dict[str, KeyedJaggedTensor] = field(default_factory=dict)
+    labels: Dict[str, torch.Tensor] = field(default_factory=dict)
+    sample_weights: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+    def to(self, device, non_blocking: bool = False) -> "Batch":
+        return Batch(
+            {k: v.to(device, non_blocking) for k, v in self.dense_features.items()},
+            {k: v.to(device, non_blocking) for k, v in self.sparse_features.items()},
+            {k: v.to(device, non_blocking=non_blocking) for k, v in self.labels.items()},
+            {k: v.to(device, non_blocking=non_blocking) for k, v in self.sample_weights.items()},
+        )
+
+    def record_stream(self, stream) -> None:
+        for v in self.dense_features.values():
+            v.record_stream(stream)
+        for v in self.sparse_features.values():
+            v.record_stream(stream)
+        for v in list(self.labels.values()) + list(self.sample_weights.values()):
+            if v.is_cuda:
+                v.record_stream(stream)
+
+    def pin_memory(self) -> "Batch":
+        return Batch(
+            {k: KeyedTensor(v.keys(), v.length_per_key(), v.values().pin_memory()) for k, v in self.dense_features.items()},
+            {k: v.pin_memory() for k, v in self.sparse_features.items()},
+            {k: v.pin_memory() for k, v in self.labels.items()},
+            {k: v.pin_memory() for k, v in self.sample_weights.items()},
+        )
+
+
+class EmbeddingGroup(nn.Module):
+    """Applies embedding lookups for the pooled feature groups of a model."""
+
+    def __init__(
+        self,
+        features: Sequence[FeatureSpec],
+        feature_groups: Sequence[FeatureGroupSpec],
+        wide_embedding_dim: Optional[int] = None,
+        device: Optional[torch.device] = None,
+        sparse_optimizer: Optional[SparseOptimizerConfig] = None,
+        row_layout: str = "interleaved",
+    ) -> None:
+        super().__init__()
+        name_to_feature = {f.name: f for f in features}
+        configs: "OrderedDict[str, EmbeddingBagConfig]" = OrderedDict()
+        feat_group_table: Dict[str, Dict[str, str]] = {}
+        for g in feature_groups:
+            if g.group_type == "SEQUENCE":
+                raise NotImplementedError("sequence groups are SURVEY.md section 8(f) 'next'")
+            for fname in g.feature_names:
+                f = name_to_feature[fname]
+                if f.is_sparse:
+                    t = f.embedding_name or f"{f.name}_emb"
+                    if g.group_type == "WIDE":
+                        t += "_wide"
+                    if g.embedding_name_suffix:
+                        t += "_" + g.embedding_name_suffix
+                    feat_group_table.setdefault(fname, {})[g.group_name] = t
+        shared = {f: len(set(m.values())) > 1 for f, m in feat_group_table.items()}
+        self._group_feature_names: "OrderedDict[str, List[str]]" = OrderedDict()
+        self._group_blocks: "OrderedDict[str, List[tuple]]" = OrderedDict()  # (kind, key, dim)
+        self._group_dims: Dict[str, "OrderedDict[str, int]"] = {}
+        for g in feature_groups:
+            is_wide = g.group_type == "WIDE"
+            blocks, dims = [], OrderedDict()
+            for fname in g.feature_names:
+                f = name_to_feature[fname]
+                if f.is_sparse:
+                    dim = (wide_embedding_dim or 4) if is_wide else f.embedding_dim
+                    tname = feat_group_table[fname][g.group_name]
+                    cfg = EmbeddingBagConfig(tname, dim, f.num_embeddings, [fname], f.pooling)
+                    if tname in configs:
+                        old = configs[tname]
+                        if (old.num_embeddings, old.embedding_dim, old.pooling) != (cfg.num_embeddings, dim, cfg.pooling):
+                            raise AssertionError(f"there is a mismatch between {cfg} and {old}, can not share embedding.")
+                        if fname not in old.feature_names:
+                            old.feature_names.append(fname)
+                    else:
+                        configs[tname] = cfg
+                    out_key = f"{fname}@{tname}" if shared[fname] else fname
+                    blocks.append(("sparse", out_key, dim))
+                    dims[fname] = dim
+                else:
+                    if is_wide:
+                        raise ValueError(f"dense feature [{fname}] should not be configured in wide group.")
+                    blocks.append(("dense", fname, f.value_dim))
+                    dims[fname] = f.value_dim
+            self._group_feature_names[g.group_name] = list(g.feature_names)
+            self._group_blocks[g.group_name] = blocks
+            self._group_dims[g.group_name] = dims
+        self._dense_dims = OrderedDict((f.name, f.value_dim) for f in features if not f.is_sparse)
+        self.has_sparse = len(configs) > 0
+        # the lookup writes, per group, the contiguous run(s) of sparse blocks; groups that mix dense
+        # columns in get one concat on top
+        ebc_groups = {g: [k for kind, k, _ in blocks if kind == "sparse"] for g, blocks in self._group_blocks.items()}
+        ebc_groups = {g: ks for g, ks in ebc_groups.items() if ks}
+        self.ebc = EmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
+                                          groups=ebc_groups, row_layout=row_layout) if self.has_sparse else None
+        if self.ebc is not None:
+            # a feature shared by several tables is named feature@table by the EBC only when the
+            # feature really feeds >1 table; align our keys with its naming
+            self._ebc_groups = {g: [self._ebc_key(k) for k in ks] for g, ks in ebc_groups.items()}
+            self.ebc._groups = self._ebc_groups
+
+    def _ebc_key(self, out_key: str) -> str:
+        return out_key if out_key in self.ebc._out_dim else out_key.split("@")[0]
+
+    # -- introspection used by the models (embedding.py:886-907) -----------------------------
+    def group_names(self) -> List[str]:
+        return list(self._group_feature_names)
+
+    def has_group(self, name: str) -> bool:
+        return name in self._group_feature_names
+
+    def group_dims(self, name: str) -> List[int]:
+        return list(self._group_dims[name].values())
+
+    def group_feature_dims(self, name: str) -> Dict[str, int]:
+        return self._group_dims[name]
+
+    def group_total_dim(self, name: str) -> int:
+        return sum(self._group_dims[name].values())
+
+    @property
+    def fused_optimizer(self):
+        return self.ebc.fused_optimizer if self.ebc is not None else None
+
+    def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        sparse = batch.sparse_features.get(BASE_DATA_GROUP)
+        dense = batch.dense_features.get(BASE_DATA_GROUP)
+        pooled = self.ebc.forward_grouped(sparse) if self.ebc is not None else {}
+        dense_cols = dense.to_dict() if dense is not None else {}
+        out: Dict[str, torch.Tensor] = {}
+        for g, blocks in self._group_blocks.items():
+            if all(kind == "sparse" for kind, _, _ in blocks):
+                out[g] = pooled[g]
+                continue
+            parts, col, run = [], 0, None
+            # pooled[g] holds the group's sparse blocks back to back, in order
+            for kind, key, dim in blocks:
+                if kind == "sparse":
+                    run = (run[0], run[1] + dim) if run else (col, col + dim)
+                    col += dim
+                else:
+                    if run:
+                        parts.append(pooled[g][:, run[0]:run[1]])
+                        run = None
+                    parts.append(dense_cols[key])
+            if run:
+                parts.append(pooled[g][:, run[0]:run[1]])
+            out[g] = torch.cat(parts, dim=1)
+        return out
+
+
+class TrainPipeline:
+    """Minimal ``pipeline.progress(iterator)`` (tzrec/utils/dist_util.py:221-303,336-377 ->
+    torchrec TrainPipelineSparseDist [upstream]): the next batch is copied host->device on a memcpy
+    stream while the current one computes; the backward index plan of the embedding lookup runs on
+    its own stream (the analogue of the data-dist stage); the sparse update happens inside
+    ``loss.backward()``; ``optimizer.step()`` only touches the dense parameters."""
+
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: torch.device, loss_fn) -> None:
+        self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
+        self._copy_stream = torch.cuda.Stream(device=self._device) if self._device.type == "cuda" else None
+        self._next: Optional[Batch] = None
+        self._exhausted = False
+
+    def _fetch(self, it) -> Optional[Batch]:
+        try:
+            b = next(it)
+        except StopIteration:
+            self._exhausted = True
+            return None
+        if self._copy_stream is None:
+            return b.to(self._device)
+        with torch.cuda.stream(self._copy_stream):
+            return b.to(self._device, non_blocking=True)
+
+    def progress(self, dataloader_iter):
+        if self._next is None and not self._exhausted:
+            self._next = self._fetch(dataloader_iter)
+        if self._next is None:
+            raise StopIteration
+        batch = self._next
+        if self._copy_stream is not None:
+            torch.cuda.current_stream(self._device).wait_stream(self._copy_stream)
+            batch.record_stream(torch.cuda.current_stream(self._device))
+        self._next = self._fetch(dataloader_iter)  # overlaps with the step below
+        self._opt.zero_grad(set_to_none=True)
+        predictions = self._model(batch)
+        losses = self._loss_fn(predictions, batch)
+        total = sum(losses.values())
+        total.backward()
+        self._opt.step()
+        return losses, predictions, batch

@@ -1,0 +1,129 @@
+"""Config-driven DLRM / DeepFM on top of EmbeddingGroup (the reference's model API surface).
+
+`build_rank_model(spec)` takes what `config.load_pipeline_spec` read from a tzrec pipeline config
+and builds the model the reference would build from the same file
+(/root/reference/tzrec/main.py:134-166 picks the class from the model_config oneof;
+/root/reference/tzrec/models/dlrm.py:26-135, deepfm.py:26-108, rank_model.py:83-262).
+`forward(batch) -> {"logits", "probs"}`; `loss(predictions, batch) -> {"binary_cross_entropy": ...}`.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .config import PipelineSpec
+from .dlrm import MLP
+from .embedding import SparseOptimizerConfig
+from .embedding_group import Batch, EmbeddingGroup
+from .interaction import FactorizationMachine, dot_interaction
+
+
+class RankModel(nn.Module):
+    def __init__(self, spec: PipelineSpec, device: Optional[torch.device], sparse_optimizer: Optional[SparseOptimizerConfig]) -> None:
+        super().__init__()
+        self._spec = spec
+        self._label = spec.label_fields[0] if spec.label_fields else "label"
+        self.embedding_group = EmbeddingGroup(
+            spec.features, spec.feature_groups, wide_embedding_dim=spec.wide_embedding_dim or None,
+            device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer)
+
+    def build_input(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        return self.embedding_group(batch)
+
+    def dense_parameters(self):
+        for n, p in self.named_parameters():
+            if not n.startswith("embedding_group."):
+                yield p
+
+    @property
+    def fused_optimizer(self):
+        return self.embedding_group.fused_optimizer
+
+    def _output_to_prediction(self, y: torch.Tensor) -> Dict[str, torch.Tensor]:
+        logits = torch.squeeze(y, dim=1)  # rank_model.py:142-146 (num_class == 1)
+        return {"logits": logits, "probs": torch.sigmoid(logits)}
+
+    def loss(self, predictions: Dict[str, torch.Tensor], batch: Batch) -> Dict[str, torch.Tensor]:
+        label = batch.labels[self._label].to(torch.float32)
+        return {"binary_cross_entropy": nn.functional.binary_cross_entropy_with_logits(predictions["logits"], label)}
+
+
+class ConfigDLRM(RankModel):
+    def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
+        super().__init__(spec, device, sparse_optimizer)
+        eg, m = self.embedding_group, spec.model
+        names = eg.group_names()
+        self._sparse_group = names[0] if len(names) == 1 else "sparse"
+        self._dense_group = "dense"
+        self.dense_mlp = None
+        if len(names) > 1 and eg.has_group(self._dense_group):
+            self.dense_mlp = MLP(eg.group_total_dim(self._dense_group), [int(x) for x in m.one("dense_mlp").many("hidden_units")])
+        dims = set(eg.group_dims(self._sparse_group))
+        if len(dims) > 1:
+            raise Exception(f"sparse group feature dims must be the same, but we find {dims}")
+        self._dim = dims.pop()
+        self._num_sparse = len(eg.group_dims(self._sparse_group))
+        if self.dense_mlp and self._dim != self.dense_mlp.output_dim():
+            raise Exception("dense mlp last hidden_unit must be the same sparse feature dim")
+        self._arch_with_sparse = bool(m.one("arch_with_sparse", True))
+        n = self._num_sparse + (1 if self.dense_mlp else 0)
+        feat = n * (n - 1) // 2 + (self._dim if self.dense_mlp else 0) + (self._num_sparse * self._dim if self._arch_with_sparse else 0)
+        self.final_mlp = MLP(feat, [int(x) for x in m.one("final").many("hidden_units")])
+        self.output_mlp = nn.Linear(self.final_mlp.output_dim(), spec.num_class)
+        if device is not None:
+            for mod in (self.dense_mlp, self.final_mlp, self.output_mlp):
+                if mod is not None:
+                    mod.to(device)
+
+    def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        g = self.build_input(batch)
+        sparse = g[self._sparse_group]
+        d = self.dense_mlp(g[self._dense_group]) if self.dense_mlp else None
+        allf = dot_interaction(d, sparse, self._dim, cat_dense=True, cat_sparse=self._arch_with_sparse)
+        return self._output_to_prediction(self.output_mlp(self.final_mlp(allf)))
+
+
+class ConfigDeepFM(RankModel):
+    def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
+        super().__init__(spec, device, sparse_optimizer)
+        eg, m = self.embedding_group, spec.model
+        self._has_fm = eg.has_group("fm")
+        fm_dims = eg.group_dims("fm" if self._has_fm else "deep")
+        assert len(set(fm_dims)) == 1, f"embedding dimension of fm features must be same. but got {set(fm_dims)}"
+        self._fm_n, self._fm_dim = len(fm_dims), fm_dims[0]
+        self.fm = FactorizationMachine()
+        self.deep_mlp = MLP(eg.group_total_dim("deep"), [int(x) for x in m.one("deep").many("hidden_units")])
+        final_dim = self.deep_mlp.output_dim()
+        self.final_mlp = None
+        if m.has("final"):
+            self.final_mlp = MLP(1 + self._fm_dim + final_dim, [int(x) for x in m.one("final").many("hidden_units")])
+            final_dim = self.final_mlp.output_dim()
+        self.output_mlp = nn.Linear(final_dim, spec.num_class)
+        if device is not None:
+            for mod in (self.deep_mlp, self.final_mlp, self.output_mlp):
+                if mod is not None:
+                    mod.to(device)
+
+    def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        g = self.build_input(batch)
+        y_wide = torch.sum(g["wide"], dim=1, keepdim=True)
+        y_deep = self.deep_mlp(g["deep"])
+        fm_feat = (g["fm"] if self._has_fm else g["deep"]).reshape(-1, self._fm_n, self._fm_dim)
+        y_fm = self.fm(fm_feat)
+        if self.final_mlp is not None:
+            y = self.output_mlp(self.final_mlp(torch.cat([y_wide, y_fm, y_deep], dim=1)))
+        else:
+            y = y_wide + torch.sum(y_fm, dim=1, keepdim=True) + self.output_mlp(y_deep)
+        return self._output_to_prediction(y)
+
+
+_MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM}
+
+
+def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None) -> RankModel:
+    """Class chosen by the model_config oneof name, as tzrec/main.py:151-153 does."""
+    if spec.model_name not in _MODELS:
+        raise NotImplementedError(f"model {spec.model_name!r} is outside SURVEY.md section 8")
+    return _MODELS[spec.model_name](spec, device, sparse_optimizer)
