@@ -57,9 +57,10 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     P.tab_start[t] = s;
     P.tab_chunk[t] = (int32_t)((e - s + BWD_CH - 1) / BWD_CH);
     const int bits = tb.rows <= 1 ? 0 : 64 - __clzll((long long)(tb.rows - 1));
-    const int npass = (bits + BWD_RB - 1) / BWD_RB;
+    // at least one pass: pass 0 is also the table-major regroup of the lookups
+    const int npass = bits == 0 ? 1 : (bits + BWD_RB - 1) / BWD_RB;
     P.tab_npass[t] = npass;
-    P.tab_width[t] = npass ? (bits + npass - 1) / npass : 0;
+    P.tab_width[t] = (bits + npass - 1) / npass;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -76,34 +77,33 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
   }
 }
 
-// Regroup lookups table-major: key[0][p] = local row, src[0][p] = original lookup position.
-__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_gather_kernel(
-    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
-    const int64_t* __restrict__ values, const int64_t* __restrict__ offsets, int64_t B,
-    int uniform, BwdPlan P) {
-  int t;
-  int64_t s, e, ts, te;
-  if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
-  const TzrTable tb = tables[t];
-  for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS) {
-    int o = tb.first_order;
-    while (o + 1 < tb.first_order + tb.n_feats && P.feat_start[o + 1] <= p) ++o;
-    const int64_t key = feats[P.feat_by_order[o]].key;
-    const int64_t fbase = uniform ? key * B : offsets[key * B];
-    const int64_t i = fbase + (p - P.feat_start[o]);
-    int64_t id = values[i];
-    if ((uint64_t)id >= (uint64_t)tb.rows) id = 0;  // memory safety; K4 reports/clamps
-    P.key[0][p] = (uint32_t)id;
-    P.src[0][p] = (uint32_t)i;
-    if (!uniform) {
-      const int64_t b = tzr_last_le(offsets + key * B, B, i);
-      P.bag_of[i] = (uint32_t)(key * B + b);  // same value from every table this key feeds
-    }
-  }
+// Table-major position p of table tb -> (local row, original lookup position): the lookups of a
+// table are the concatenation, in key order, of the id segments of the keys that read it.
+struct BwdSrcArgs {
+  const TzrFeature* feats;
+  const int64_t* values;
+  const int64_t* offsets;
+  int64_t B;
+  int uniform;
+};
+
+__device__ __forceinline__ void bwd_elem0(const BwdPlan& P, const TzrTable& tb, const BwdSrcArgs& A,
+                                          int64_t p, uint32_t* key_out, uint32_t* src_out,
+                                          int64_t* kjt_key_out) {
+  int o = tb.first_order;
+  while (o + 1 < tb.first_order + tb.n_feats && P.feat_start[o + 1] <= p) ++o;
+  const int64_t key = A.feats[P.feat_by_order[o]].key;
+  const int64_t fbase = A.uniform ? key * A.B : A.offsets[key * A.B];
+  const int64_t i = fbase + (p - P.feat_start[o]);
+  int64_t id = A.values[i];
+  if ((uint64_t)id >= (uint64_t)tb.rows) id = 0;  // memory safety; K4 reports/clamps
+  *key_out = (uint32_t)id;
+  *src_out = (uint32_t)i;
+  *kjt_key_out = key;
 }
 
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
-    const TzrTable* __restrict__ tables, int T, int pass, BwdPlan P) {
+    const TzrTable* __restrict__ tables, int T, int pass, BwdSrcArgs A, BwdPlan P) {
   __shared__ unsigned h[BWD_NB];
   int t;
   int64_t s, e, ts, te;
@@ -115,8 +115,18 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
   const uint32_t* __restrict__ kin = (pass & 1) ? P.key[1] : P.key[0];
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) h[i] = 0;
   __syncthreads();
-  for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS)
-    atomicAdd(&h[(kin[p] >> shift) & mask], 1u);
+  if (pass == 0) {
+    const TzrTable tb = tables[t];
+    for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS) {
+      uint32_t k, sv;
+      int64_t kk;
+      bwd_elem0(P, tb, A, p, &k, &sv, &kk);
+      atomicAdd(&h[k & mask], 1u);
+    }
+  } else {
+    for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS)
+      atomicAdd(&h[(kin[p] >> shift) & mask], 1u);
+  }
   __syncthreads();
   uint32_t* out = P.hist + (size_t)blockIdx.x * BWD_NB;
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) out[i] = h[i];
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
 
 // One workgroup per table, one thread per digit: exclusive scan over the table's chunks (in
 // place) and over digits -> binbase.  Chunk columns are read in batches of independent loads.
-#define BWD_SCAN_BATCH 16
+#define BWD_SCAN_BATCH 64
 __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(int T, int pass, BwdPlan P) {
   __shared__ unsigned tot[BWD_NB];
   const int t = blockIdx.x;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(int T, int pass, B
 // positions each wave ranks its lanes by digit with ballots (match-any), waves are ordered through
 // per-wave digit counts in LDS, rounds through the running per-digit base.
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
-    const TzrTable* __restrict__ tables, int T, int pass, BwdPlan P) {
+    const TzrTable* __restrict__ tables, int T, int pass, BwdSrcArgs A, BwdPlan P) {
   __shared__ unsigned base[BWD_NB];
   __shared__ unsigned wcnt[BWD_THREADS / TZR_WAVE][BWD_NB];
   int t;
@@ -184,12 +194,37 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
     for (int w = 0; w < BWD_THREADS / TZR_WAVE; ++w) wcnt[w][i] = 0;
   }
   __syncthreads();
+  // all of the chunk's keys / sources are loaded up front (independent coalesced loads): the
+  // ranking rounds below then run out of registers and pay one memory latency per workgroup
+  constexpr int kRounds = BWD_CH / BWD_THREADS;
+  uint32_t kreg[kRounds], sreg[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
+    kreg[r] = 0u;
+    sreg[r] = 0u;
+    if (p < e) {
+      if (pass == 0) {
+        int64_t kk;
+        bwd_elem0(P, tables[t], A, p, &kreg[r], &sreg[r], &kk);
+        if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
+          const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[r]);
+          P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
+        }
+      } else {
+        kreg[r] = kin[p];
+        sreg[r] = sin[p];
+      }
+    }
+  }
   const int rounds = (int)((e - s + BWD_THREADS - 1) / BWD_THREADS);
-  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    if (r >= rounds) break;  // uniform across the workgroup
     const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
     const bool valid = p < e;
-    const uint32_t k = valid ? kin[p] : 0u;
-    const uint32_t sv = valid ? sin[p] : 0u;
+    const uint32_t k = kreg[r];
+    const uint32_t sv = sreg[r];
     const unsigned d = (k >> shift) & mask;
     unsigned long long peers = __ballot(valid);
     for (int bit = 0; bit < width; ++bit) {
@@ -247,18 +282,22 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   if (!d_values) return TZR_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int bits = max_rows <= 1 ? 0 : 64 - __builtin_clzll((unsigned long long)(max_rows - 1));
-  const int max_pass = (bits + BWD_RB - 1) / BWD_RB;
+  const int max_pass = bits == 0 ? 1 : (bits + BWD_RB - 1) / BWD_RB;
   const unsigned chunks = (unsigned)P.max_chunks;
   hipLaunchKernelGGL(tzr_bwd_prep_kernel, dim3(1), dim3(BWD_THREADS), 0, s, d_tables, n_tables,
                      d_feats, n_feats, d_offsets, B, (int)uniform, P);
-  hipLaunchKernelGGL(tzr_bwd_gather_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                     n_tables, d_feats, d_values, d_offsets, B, (int)uniform, P);
+  BwdSrcArgs A;
+  A.feats = d_feats;
+  A.values = d_values;
+  A.offsets = d_offsets;
+  A.B = B;
+  A.uniform = (int)uniform;
   for (int pass = 0; pass < max_pass; ++pass) {
     hipLaunchKernelGGL(tzr_bwd_hist_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                       n_tables, pass, P);
+                       n_tables, pass, A, P);
     hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, n_tables, pass, P);
     hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                       n_tables, pass, P);
+                       n_tables, pass, A, P);
   }
   TZR_CHECK_LAUNCH();
   return TZR_OK;
