@@ -233,6 +233,22 @@ int tzr_lookup_grads(const TzrFeature* d_feats, int n_feats, const int64_t* d_of
                      const int64_t* d_positions, const TzrDst* h_grads, int n_dst, float* d_out,
                      int64_t out_stride, int dim, void* stream);
 
+/* ---- sequence path --------------------------------------------- */
+
+/* K12: jagged [N, dim] (+ offsets int64[B+1]) -> dense [B, max_len, dim]; positions past a
+ * sample's length get padding_value, sequences longer than max_len are truncated.  Replaces fbgemm
+ * jagged_to_padded_dense reached from JaggedTensor.to_padded_dense
+ * (tzrec/modules/embedding.py:1429,1480).  The unpooled lookup itself is tzr_rows_gather with one
+ * key segment per KJT key, its backward tzr_pooled_bwd_plan/apply with grad_mode 1. */
+int tzr_jagged_to_padded_dense(const float* d_values, int64_t values_stride,
+                               const int64_t* d_offsets, int64_t B, int64_t max_len, int dim,
+                               float padding_value, float* d_out, void* stream);
+/* backward of the above: d_values[offsets[b] + l, :] = d_dense[b, l, :] for l < min(len, max_len),
+ * zero for truncated positions. */
+int tzr_padded_dense_to_jagged(const float* d_dense, const int64_t* d_offsets, int64_t B,
+                               int64_t max_len, int dim, float* d_values, int64_t values_stride,
+                               void* stream);
+
 /* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
 int tzr_tune(const char* name, int value);
 

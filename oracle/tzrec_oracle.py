@@ -409,3 +409,43 @@ def deepfm_forward(wide, fm_in, deep, p: Dict[str, object]) -> torch.Tensor:
 def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """tzrec/models/rank_model.py:190-191,233-240: BCEWithLogitsLoss(reduction="mean") on float labels."""
     return tF.binary_cross_entropy_with_logits(logits, labels.float(), reduction="mean")
+
+
+# --------------------------------------------------------------------------------------------
+# sequence path (SURVEY.md section 8f rank 1)
+# --------------------------------------------------------------------------------------------
+
+
+def jagged_to_padded_dense(values: torch.Tensor, lengths: torch.Tensor, max_len: int, pad: float = 0.0) -> torch.Tensor:
+    """fbgemm jagged_to_padded_dense semantics [upstream] as used by JaggedTensor.to_padded_dense
+    (tzrec/modules/embedding.py:1429,1480): [N, D] -> [B, max_len, D], truncating long sequences."""
+    B, D = lengths.numel(), values.shape[1]
+    out = torch.full((B, max_len, D), float(pad), dtype=values.dtype)
+    s = 0
+    rows = []
+    for b in range(B):
+        n = int(lengths[b])
+        k = min(n, max_len)
+        rows.append((b, s, k))
+        s += n
+    # built with differentiable ops so autograd gives the jagged gradient (zero on truncated rows)
+    pieces = []
+    for b, s0, k in rows:
+        seg = values[s0:s0 + k]
+        fill = torch.full((max_len - k, D), float(pad), dtype=values.dtype)
+        pieces.append(torch.cat([seg, fill], dim=0))
+    return torch.stack(pieces, dim=0) if pieces else out
+
+
+def din_encoder(query, sequence, sequence_length, mlp_layers, linear):
+    """tzrec/modules/sequence.py:101-128 (DINEncoder.forward), max_seq_length = 0."""
+    L = sequence.shape[1]
+    mask = torch.arange(L).unsqueeze(0) < sequence_length.unsqueeze(1)
+    if query.shape[1] < sequence.shape[2]:
+        query = tF.pad(query, (0, sequence.shape[2] - query.shape[1]))
+    q = query.unsqueeze(1).expand(-1, L, -1)
+    a = torch.cat([q, sequence, q - sequence, q * sequence], dim=-1)
+    a = mlp(a, mlp_layers)
+    a = tF.linear(a, linear[0], linear[1]).transpose(1, 2)
+    scores = torch.where(mask.unsqueeze(1), a, torch.ones_like(a) * (-(2 ** 31) + 1))
+    return torch.matmul(torch.softmax(scores, dim=-1), sequence).squeeze(1)

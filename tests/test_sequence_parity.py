@@ -1,0 +1,90 @@
+"""Sequence path: unpooled EmbeddingCollection lookup, jagged->padded dense,
+DIN target attention, and the fused sparse update through it -- against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.embedding import SparseOptimizerConfig  # noqa: E402
+from torcheasyrec_amd.sequence import DINEncoder, EmbeddingCollection, EmbeddingConfig, jagged_to_padded_dense  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
+
+
+def _seq_kjt(rng, keys, rows, B, max_l):
+    lens = rng.integers(0, max_l + 1, size=len(keys) * B).astype(np.int32)
+    lens[rng.integers(0, len(lens), size=3)] = 0
+    vals = np.concatenate([rng.integers(0, rows[k], size=int(lens[i * B:(i + 1) * B].sum())) for i, k in enumerate(keys)]).astype(np.int64)
+    return KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(lens))
+
+
+@pytest.mark.parametrize("max_len", [1, 5, 12])
+def test_jagged_to_padded_dense(dev, max_len):
+    rng = np.random.default_rng(max_len)
+    B, D = 19, 8
+    lens = torch.from_numpy(rng.integers(0, 9, size=B).astype(np.int64))
+    lens[3] = 0
+    N = int(lens.sum())
+    v = torch.randn(N, D)
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    vd = v.clone().to(dev).requires_grad_(True)
+    out = jagged_to_padded_dense(vd, off.to(dev), max_len, -1.5)
+    vr = v.clone().requires_grad_(True)
+    ref = orc.jagged_to_padded_dense(vr, lens, max_len, -1.5)
+    assert torch.equal(out.detach().cpu(), ref.detach())  # a copy: bit-exact
+    g = torch.randn(B, max_len, D)
+    out.backward(g.to(dev))
+    ref.backward(g)
+    assert torch.equal(vd.grad.cpu(), vr.grad)
+
+
+def test_unpooled_lookup_and_din_training_step(dev):
+    """click_seq ids + target item id share one table (tzrec multi_tower_din style): lookup, pad,
+    DIN attention, loss; the shared table must receive the exact fused update."""
+    rng = np.random.default_rng(4)
+    B, D, L, rows, lr = 23, 16, 10, 300, 0.05
+    g = torch.Generator().manual_seed(1)
+    w0 = (torch.rand(rows, D, generator=g) - 0.5) * 0.4
+    ec = EmbeddingCollection([EmbeddingConfig("item_emb", D, rows, ["item_id", "click_seq__item_id"],
+                                              init_fn=lambda t: t.copy_(w0))],
+                             device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
+    torch.manual_seed(5)
+    din = DINEncoder(D, D, "seq", {"hidden_units": [32, 8]}).to(dev)
+    lens = rng.integers(0, L + 3, size=B).astype(np.int32)  # some longer than L (truncated)
+    lens[2] = 0
+    seq_ids = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
+    item_ids = rng.integers(0, rows, size=B).astype(np.int64)
+    kjt = KeyedJaggedTensor(["item_id", "click_seq__item_id"], torch.from_numpy(np.concatenate([item_ids, seq_ids])),
+                            torch.from_numpy(np.concatenate([np.ones(B, np.int32), lens])))
+    jts = ec(kjt.to(dev))
+    assert sorted(jts) == ["click_seq__item_id", "item_id"]
+    q = jts["item_id"].values()
+    seq = jts["click_seq__item_id"].to_padded_dense(L)
+    out = din({"seq.query": q, "seq.sequence": seq, "seq.sequence_length": torch.from_numpy(lens.astype(np.int64)).to(dev)})
+    tgt = torch.randn(B, D, generator=g)
+    loss = ((out - tgt.to(dev)) ** 2).mean()
+    loss.backward()
+
+    # oracle
+    wr = w0.clone().requires_grad_(True)
+    rows_q = wr[torch.from_numpy(item_ids)]
+    rows_s = wr[torch.from_numpy(seq_ids)]
+    torch.testing.assert_close(q.detach().cpu(), rows_q.detach(), rtol=0, atol=0)
+    lin = [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in din.mlp.mlp if hasattr(m, "weight")]
+    ref = orc.din_encoder(rows_q, orc.jagged_to_padded_dense(rows_s, torch.from_numpy(lens.astype(np.int64)), L),
+                          torch.from_numpy(lens.astype(np.int64)), lin, (din.linear.weight.detach().cpu(), din.linear.bias.detach().cpu()))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    ref_loss = ((ref - tgt) ** 2).mean()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()) + 1e-7
+    # per-id gradients (query ids then sequence ids = KJT value order) -> exact fused update
+    gq, gs = torch.autograd.grad(ref_loss, [rows_q, rows_s])
+    w = w0.numpy().copy()
+    m = np.zeros_like(w)
+    orc.sparse_update(w, m, np.concatenate([item_ids, seq_ids]), np.concatenate([gq.numpy(), gs.numpy()], axis=0),
+                      orc.SparseOptim(kind="adagrad", lr=lr))
+    got = ec.table_weights()["item_emb"].detach().cpu().numpy()
+    np.testing.assert_allclose(got, w, rtol=2e-4, atol=2e-3 * lr)

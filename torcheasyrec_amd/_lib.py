@@ -94,6 +94,8 @@ _SIGNATURES = {
                                        _i32, _vp]),
     "tzr_dot_interaction_bwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,
                                        _i32, _vp, _i64, _vp, _i64, _vp]),
+    "tzr_jagged_to_padded_dense": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, C.c_float, _vp, _vp]),
+    "tzr_padded_dense_to_jagged": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "tzr_fm_fwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     "tzr_fm_bwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
 }

@@ -1,0 +1,254 @@
+"""Sequence-embedding path (BASELINE config 4, multi_tower_din).
+
+Mirrors the pieces of ``SequenceEmbeddingGroupImpl`` the kernels sit under
+(/root/reference/tzrec/modules/embedding.py:993-1498): one torchrec ``EmbeddingCollection`` per
+embedding dim (:1193-1197) returning a ``JaggedTensor`` per key, ``to_padded_dense(max_len)``
+(:1429,1480), and the DIN target-attention encoder on the padded sequence
+(/root/reference/tzrec/modules/sequence.py:65-128).
+
+Kernels: the unpooled lookup is ``tzr_rows_gather`` (one row per id); its backward hands per-id
+gradient rows to the same sort + fused-optimizer kernels as the pooled path (``grad_mode`` 1), so
+duplicate ids inside and across sequences are summed exactly once per row; padding is
+``tzr_jagged_to_padded_dense`` / ``tzr_padded_dense_to_jagged``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .dlrm import MLP
+from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
+                        _WD_MODE)
+from .sparse import KeyedJaggedTensor
+
+
+@dataclass
+class EmbeddingConfig:
+    """torchrec EmbeddingConfig fields tzrec fills (tzrec/features/feature.py:638-662)."""
+
+    name: str
+    embedding_dim: int
+    num_embeddings: int
+    feature_names: List[str] = field(default_factory=list)
+    init_fn: Optional[object] = None
+
+
+class JaggedTensor:
+    """values [N, D] + lengths [B] (+ offsets [B+1]) of one key (torchrec JaggedTensor fields)."""
+
+    def __init__(self, values: torch.Tensor, lengths: torch.Tensor, offsets: torch.Tensor) -> None:
+        self._values, self._lengths, self._offsets = values, lengths, offsets
+
+    def values(self) -> torch.Tensor:
+        return self._values
+
+    def lengths(self) -> torch.Tensor:
+        return self._lengths
+
+    def offsets(self) -> torch.Tensor:
+        return self._offsets
+
+    def to_padded_dense(self, desired_length: int, padding_value: float = 0.0) -> torch.Tensor:
+        return jagged_to_padded_dense(self._values, self._offsets, desired_length, padding_value)
+
+
+class _J2PFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, offsets, max_len, pad):
+        values = values.contiguous()
+        B, D = offsets.numel() - 1, values.shape[1]
+        out = torch.empty(B, max_len, D, dtype=torch.float32, device=values.device)
+        rc = _lib.lib().tzr_jagged_to_padded_dense(_lib.ptr(values), values.stride(0), _lib.ptr(offsets), B,
+                                                   max_len, D, float(pad), _lib.ptr(out), _lib.stream_ptr(values.device))
+        _lib.check(rc, "tzr_jagged_to_padded_dense")
+        ctx.save_for_backward(offsets)
+        ctx.shape = (values.shape[0], D, max_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (offsets,) = ctx.saved_tensors
+        N, D, max_len = ctx.shape
+        g = g.contiguous()
+        gv = torch.empty(max(N, 1), D, dtype=torch.float32, device=g.device)
+        rc = _lib.lib().tzr_padded_dense_to_jagged(_lib.ptr(g), _lib.ptr(offsets), offsets.numel() - 1, max_len, D,
+                                                   _lib.ptr(gv), gv.stride(0), _lib.stream_ptr(g.device))
+        _lib.check(rc, "tzr_padded_dense_to_jagged")
+        return gv[:N], None, None, None
+
+
+def jagged_to_padded_dense(values: torch.Tensor, offsets: torch.Tensor, max_len: int, padding_value: float = 0.0) -> torch.Tensor:
+    """[N, D] + offsets[B+1] -> [B, max_len, D] (K12)."""
+    return _J2PFn.apply(values, offsets, int(max_len), float(padding_value))
+
+
+class _UnpooledLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ec, kjt, hook):
+        out = ec._launch_forward(kjt)
+        ctx.ec, ctx.kjt = ec, kjt
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.ec._launch_backward(ctx.kjt, g)
+        return None, None, None
+
+
+class EmbeddingCollection(nn.Module):
+    """Unpooled lookup: ``forward(KJT) -> {key: JaggedTensor}`` (one embedding row per id).  All
+    tables of one collection share ``embedding_dim`` (the reference builds one EC per dim)."""
+
+    def __init__(self, tables: Sequence[EmbeddingConfig], device=None, optimizer: Optional[SparseOptimizerConfig] = None,
+                 row_layout: str = "interleaved") -> None:
+        super().__init__()
+        dims = {t.embedding_dim for t in tables}
+        if len(dims) != 1:
+            raise ValueError("one EmbeddingCollection per embedding_dim")
+        self.dim = dims.pop()
+        self._device = torch.device(device) if device is not None else torch.device("cpu")
+        self._opt_cfg = optimizer
+        # storage, init and optimizer state are the pooled module's
+        self._store = EmbeddingBagCollection(
+            [EmbeddingBagConfig(t.name, t.embedding_dim, t.num_embeddings, list(t.feature_names), "sum", t.init_fn) for t in tables],
+            device=self._device, optimizer=optimizer, row_layout=row_layout)
+        self.fused_optimizer = self._store.fused_optimizer
+        self._meta_cache: Dict[tuple, dict] = {}
+        self._hook = torch.zeros(0, requires_grad=True, device=self._device)
+
+    def table_weights(self):
+        return self._store.table_weights()
+
+    def table_states(self):
+        return self._store.table_states()
+
+    def _meta(self, keys: Sequence[str]) -> dict:
+        ck = tuple(keys)
+        m = self._meta_cache.get(ck)
+        if m is not None:
+            return m
+        st = self._store
+        base = st._meta([lk.key for lk in st._lookups], st._default_layout()) if all(
+            lk.key in keys for lk in st._lookups) else None
+        if base is None:
+            raise KeyError("KeyedJaggedTensor lacks a key served by this EmbeddingCollection")
+        table_of = {lk.key: lk.table for lk in st._lookups}
+        K = len(keys)
+        kt = np.array([table_of.get(k, -1) for k in keys], dtype=np.int32)
+        if (kt < 0).any():
+            raise KeyError("EmbeddingCollection expects a KJT holding exactly the keys it serves")
+        tables = base.tables_np.copy()
+        feats = np.zeros(K, dtype=_lib.FEATURE_DT)
+        feats["dst"] = -1
+        order = np.lexsort((np.arange(K), kt))
+        rank_of = np.empty(K, dtype=np.int32)
+        rank_of[order] = np.arange(K, dtype=np.int32)
+        feats["table"], feats["key"], feats["order"] = kt, np.arange(K, dtype=np.int32), rank_of
+        for t in range(len(tables)):
+            mine = np.nonzero(kt == t)[0]
+            tables[t]["first_order"] = int(rank_of[mine].min()) if len(mine) else 0
+            tables[t]["n_feats"] = len(mine)
+        m = {"d_tables": _lib.upload_struct(tables, self._device), "d_feats": _lib.upload_struct(feats, self._device),
+             "d_key_table": torch.from_numpy(kt).to(self._device), "K": K, "T": len(tables),
+             "max_rows": int(max(c.num_embeddings for c in st._configs))}
+        self._meta_cache[ck] = m
+        return m
+
+    def _key_start(self, kjt: KeyedJaggedTensor) -> torch.Tensor:
+        return kjt.offsets()[:: kjt.stride()].contiguous()  # [K+1] start of every key segment
+
+    def _launch_forward(self, kjt: KeyedJaggedTensor) -> torch.Tensor:
+        m = self._meta(kjt.keys())
+        N = kjt.values().numel()
+        out = torch.empty(max(N, 1), self.dim, dtype=torch.float32, device=self._device)
+        ks = self._key_start(kjt)
+        kjt._tzr_key_start = ks  # type: ignore[attr-defined]
+        rc = _lib.lib().tzr_rows_gather(_lib.ptr(m["d_tables"]), _lib.ptr(m["d_key_table"]), _lib.ptr(ks), m["K"],
+                                        _lib.ptr(kjt.values()), N, _lib.ptr(out), self.dim, self.dim,
+                                        _lib.stream_ptr(self._device))
+        _lib.check(rc, "tzr_rows_gather")
+        return out[:N]
+
+    def _launch_backward(self, kjt: KeyedJaggedTensor, g: torch.Tensor) -> None:
+        if self.fused_optimizer is None:
+            return
+        m = self._meta(kjt.keys())
+        L = _lib.lib()
+        N = kjt.values().numel()
+        if N == 0:
+            return
+        g = g.contiguous().float()
+        ks = kjt._tzr_key_start  # type: ignore[attr-defined]
+        dev, stream = self._device, _lib.stream_ptr(self._device)
+        ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, N, m["K"], m["T"], 1, self.dim), dev)
+        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(m["d_tables"]), m["T"], _lib.ptr(m["d_feats"]), m["K"], m["K"],
+                                         m["max_rows"], self.dim, _lib.ptr(kjt.values()), _lib.ptr(ks), N, N, 1, 0,
+                                         _lib.ptr(ws), ws.numel(), stream), "tzr_pooled_bwd_plan")
+        cfg = self._opt_cfg
+        opt = _lib.TzrSparseOptim()
+        opt.kind = _OPT_KIND[cfg.kind]
+        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
+        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(dev))
+        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
+        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        g1 = (_lib.TzrDst * 1)()
+        g1[0].ptr, g1[0].stride = _lib.ptr(g), g.stride(0)
+        _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(m["d_tables"]), _lib.ptr(m["d_feats"]), m["K"], m["T"], self.dim,
+                                          _lib.ptr(ks), None, N, N, 1, 0, 1, g1, 1, opt, _lib.ptr(ws), ws.numel(),
+                                          stream), "tzr_pooled_bwd_apply")
+
+    def forward(self, features: KeyedJaggedTensor) -> Dict[str, JaggedTensor]:
+        if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
+            rows = _UnpooledLookupFn.apply(self, features, self._hook)
+        else:
+            rows = self._launch_forward(features)
+        B = features.stride()
+        off, lens = features.offsets(), features.lengths()
+        lpk = features.length_per_key()
+        out, start = {}, 0
+        for i, k in enumerate(features.keys()):
+            seg = rows[start:start + lpk[i]]
+            o = off[i * B:(i + 1) * B + 1] - off[i * B]
+            out[k] = JaggedTensor(seg, lens[i * B:(i + 1) * B], o)
+            start += lpk[i]
+        return out
+
+
+class DINEncoder(nn.Module):
+    """DIN target attention (same constructor/forward contract as the reference's DINEncoder,
+    tzrec/modules/sequence.py:65-128): scores = MLP([q, k, q-k, q*k]) -> masked softmax -> sum."""
+
+    def __init__(self, sequence_dim: int, query_dim: int, input: str, attn_mlp: Dict[str, object], max_seq_length: int = 0) -> None:
+        super().__init__()
+        if query_dim > sequence_dim:
+            raise ValueError("query_dim > sequence_dim not supported yet.")
+        self._query_dim, self._sequence_dim, self._max_seq_length = query_dim, sequence_dim, max_seq_length
+        self.mlp = MLP(sequence_dim * 4, list(attn_mlp["hidden_units"]))
+        self.linear = nn.Linear(self.mlp.hidden_units[-1], 1)
+        self._query_name = f"{input}.query"
+        self._sequence_name = f"{input}.sequence"
+        self._sequence_length_name = f"{input}.sequence_length"
+
+    def output_dim(self) -> int:
+        return self._sequence_dim
+
+    def forward(self, sequence_embedded: Dict[str, torch.Tensor]) -> torch.Tensor:
+        query = sequence_embedded[self._query_name]
+        sequence = sequence_embedded[self._sequence_name]
+        sequence_length = sequence_embedded[self._sequence_length_name]
+        if self._max_seq_length > 0:
+            sequence_length = torch.clamp_max(sequence_length, self._max_seq_length)
+            sequence = sequence[:, : self._max_seq_length, :]
+        L = sequence.size(1)
+        mask = torch.arange(L, device=sequence_length.device).unsqueeze(0) < sequence_length.unsqueeze(1)
+        if self._query_dim < self._sequence_dim:
+            query = nn.functional.pad(query, (0, self._sequence_dim - self._query_dim))
+        q = query.unsqueeze(1).expand(-1, L, -1)
+        a = self.linear(self.mlp(torch.cat([q, sequence, q - sequence, q * sequence], dim=-1))).transpose(1, 2)
+        scores = torch.where(mask.unsqueeze(1), a, torch.ones_like(a) * (-(2 ** 31) + 1))
+        return torch.matmul(torch.softmax(scores, dim=-1), sequence).squeeze(1)
