@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
+    ap.add_argument("--replicate-small", action="store_true",
+                    help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -232,7 +234,7 @@ def main():
         from torcheasyrec_amd.sharding import ShardedDLRM
 
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
-                            row_layout=args.row_layout)
+                            row_layout=args.row_layout, replicate_at_world1=args.replicate_small)
         parallelism = model.describe()
     use_graph = not sharded and not args.no_graph
     # capturable: the dense Adam step lives inside the captured hipGraph

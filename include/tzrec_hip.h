@@ -48,6 +48,9 @@ extern "C" {
 #define TZR_OPT_SGD 0
 #define TZR_OPT_ADAGRAD 1         /* elementwise state  [rows, D]  (torchrec.optim Adagrad) */
 #define TZR_OPT_ROWWISE_ADAGRAD 2 /* one scalar per row [rows]     (RowWiseAdagrad)         */
+#define TZR_OPT_ACCUMULATE 3      /* no update: the summed gradient of every touched row is
+                                     written to TzrTable.m (dense float [rows, dim]); used for
+                                     replicated (data_parallel) tables before the all-reduce  */
 
 #define TZR_WD_NONE 0
 #define TZR_WD_L2 1
@@ -214,6 +217,14 @@ int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats, in
                          const float* d_weights, int64_t n_values, int64_t n_positions, int64_t B,
                          int uniform_bag_len, int grad_mode, const TzrDst* h_grads, int n_dst,
                          const TzrSparseOptim* h_optim, void* ws, size_t ws_bytes, void* stream);
+
+/* Dense update of replicated (data_parallel) tables after their accumulated row gradients were
+ * all-reduced: for every row r of every table t with a non-zero gradient
+ * g = d_acc[(d_row_start[t] + r) * dim ...], apply h_optim exactly like K7 does for one row.  Rows
+ * whose gradient is all zero are left untouched (a sparse update never visits them). */
+int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables, const int64_t* d_row_start,
+                          int64_t total_rows, const float* d_acc, int dim,
+                          const TzrSparseOptim* h_optim, void* stream);
 
 /* ---- row-wise sharded exchange (one process per GPU, RCCL all-to-all between the stages) ---- */
 

@@ -40,8 +40,11 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
     keys = [f"cat_{i}" for i in range(F)]
     lr = 0.05
     tables = criteo_tables(rows, init="seeded")[:F]
-    model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev,
+    # rows > 100 -> row-wise shards, the small ones are replicated (data_parallel)
+    model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100,
                         sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
+    kinds = {n: p["sharding_type"] for n, p in model.ebc.plan().items()}
+    assert set(kinds.values()) == {"row_wise", "data_parallel"}
     Bg = 48
     Bl = Bg // world
     dense_g, kjt_g, label_g = synthetic_batch(2, Bg, rows)
@@ -98,7 +101,8 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
           for f in range(F)]
     loff = orc.lengths_to_offsets(kjt.lengths().numpy())
     ids = [kjt.values().numpy()[loff[f * Bl]:loff[(f + 1) * Bl]] for f in range(F)]
-    shards = {c.name: (model.ebc.shard_of(c.name), model.ebc.table_weights()[c.name].detach().numpy().copy()) for c in tables}
+    shards = {c.name: (model.ebc.shard_of(c.name), model.ebc.table_weights()[c.name].detach().numpy().copy(),
+                       kinds[c.name]) for c in tables}
     torch.save({"ids": ids, "lg": lg, "shards": shards}, os.path.join(result_dir, f"r{rank}.pt"))
     dist.barrier()
     if rank == 0:
@@ -112,11 +116,12 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
                               np.concatenate([pp["lg"][f] for pp in parts], axis=0), opt)
             covered = 0
             for pp in parts:
-                (lo, n), got = pp["shards"][cfg.name]
+                (lo, n), got, kind = pp["shards"][cfg.name]
                 if n > 0:
                     np.testing.assert_allclose(got[:n], w[lo:lo + n], rtol=2e-4, atol=2e-3 * lr, err_msg=cfg.name)
                 covered += n
-            assert covered == cfg.num_embeddings, (cfg.name, covered)
+            # row-wise: every row has one owner; data_parallel: every rank holds (the same) all rows
+            assert covered == cfg.num_embeddings * (world if kind == "data_parallel" else 1), (cfg.name, covered)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -132,6 +137,13 @@ def test_sharded_dlrm_world2(emu_path, mode):
 def test_row_wise_plan_spreads_small_tables():
     from torcheasyrec_amd.sharding import row_wise_plan
 
+    from torcheasyrec_amd.embedding import EmbeddingBagConfig
+    from torcheasyrec_amd.sharding import make_plan
+
+    plan = make_plan([EmbeddingBagConfig("big", 16, 40_000_000, ["a"]), EmbeddingBagConfig("tiny", 16, 3, ["b"])], 8)
+    assert plan["big"]["sharding_type"] == "row_wise" and plan["big"]["block"] == 5_000_000
+    assert plan["tiny"]["sharding_type"] == "data_parallel"
+    assert make_plan([EmbeddingBagConfig("tiny", 16, 3, ["b"])], 1)["tiny"]["sharding_type"] == "row_wise"
     blocks, rot = row_wise_plan([40_000_000, 3, 4, 10, 2], 8)
     assert blocks[0] == 5_000_000 and rot[0] == 0
     # tiny tables must not all start on rank 0

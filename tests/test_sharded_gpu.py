@@ -14,8 +14,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["adagrad", "rowwise_adagrad"])
-def test_sharded_world1_matches_unsharded(kind):
+@pytest.mark.parametrize("kind,replicate", [("adagrad", False), ("rowwise_adagrad", False), ("adagrad", True),
+                                            ("rowwise_adagrad", True)])
+def test_sharded_world1_matches_unsharded(kind, replicate):
     from torcheasyrec_amd import _lib
     from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.dlrm import DLRM, bce_with_logits
@@ -33,7 +34,10 @@ def test_sharded_world1_matches_unsharded(kind):
             torch.manual_seed(3)
             ref = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt)
             torch.manual_seed(3)
-            shd = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt)
+            # replicate=True: tables <= 4096 rows take the data_parallel path (ACCUMULATE + all-reduce +
+            # dense update) even at world 1, so those kernels run on hardware too
+            shd = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt,
+                              dp_max_rows=4096, replicate_at_world1=replicate)
             for pr, ps in zip(ref.dense_parameters(), shd.dense_parameters()):
                 ps.data.copy_(pr.data)
             for step in range(2):
@@ -44,7 +48,7 @@ def test_sharded_world1_matches_unsharded(kind):
                 l2 = bce_with_logits(shd(dense, kjt.to(dev)), label)
                 l2.backward()
                 shd.allreduce_dense_grads()
-                assert torch.equal(l1.detach(), l2.detach())
+                assert torch.equal(l1.detach(), l2.detach())  # forward is a copy on both paths
                 for pr, ps in zip(ref.dense_parameters(), shd.dense_parameters()):
                     torch.testing.assert_close(ps.grad, pr.grad, rtol=1e-6, atol=1e-7)
                     pr.grad = None
@@ -53,6 +57,8 @@ def test_sharded_world1_matches_unsharded(kind):
             for name, w in ref.ebc.table_weights().items():
                 lo, n = shd.ebc.shard_of(name)
                 got = shd.ebc.table_weights()[name][:n]
+                # row-wise at world 1 is the same kernel sequence (bit-identical); the replicated path
+                # sums duplicates in the same order but through the accumulate buffer
                 np.testing.assert_allclose(got.cpu().numpy(), w[lo:lo + n].cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=name)
         finally:
             dist.destroy_process_group()

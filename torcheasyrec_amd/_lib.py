@@ -21,7 +21,7 @@ TZR_OK = 0
 TZR_MAX_DST = 8
 TZR_MAX_FEAT_DST = 4
 POOL_SUM, POOL_MEAN = 0, 1
-OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD = 0, 1, 2
+OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE = 0, 1, 2, 3
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),
+    "tzr_dense_rows_update": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, C.POINTER(TzrSparseOptim), _vp]),
     "tzr_rows_gather": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     "tzr_lookup_grads": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, C.POINTER(TzrDst), _i32, _vp,
                                 _i64, _i32, _vp]),

@@ -165,6 +165,9 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       tzr_st4(wp, w4);
       if (lane_in_group == 0) *mp = mnew;
     }
+  } else if (opt.kind == TZR_OPT_ACCUMULATE) {
+    // replicated table: hand the summed row gradient to the all-reduce (tb.m = dense [rows, dim])
+    if (active) tzr_st4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, g);
   } else {  // SGD
     if (active) {
       w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
@@ -379,7 +382,7 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
   if (!uniform && !d_offsets && grad_mode == 0) return TZR_ERR_INVALID;
   if (!h_optim->d_lr) return TZR_ERR_INVALID;
   if (h_optim->kind != TZR_OPT_SGD && h_optim->kind != TZR_OPT_ADAGRAD &&
-      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD)
+      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD && h_optim->kind != TZR_OPT_ACCUMULATE)
     return TZR_ERR_UNSUPPORTED;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
   if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
@@ -411,6 +414,73 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
                      max_dim, P);
   hipLaunchKernelGGL(tzr_bwd_stitch_kernel, dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
                      dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// Dense update of replicated tables: lane group <-> row of the concatenated row space; the row's
+// gradient comes from the all-reduced accumulation buffer; rows with an all-zero gradient are
+// skipped (a sparse update never visits them).  Same per-row arithmetic as the sparse path.
+__global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
+    const TzrTable* __restrict__ tables, int T, const int64_t* __restrict__ row_start,
+    int64_t total_rows, const float* __restrict__ acc, int dim, BwdOpt opt) {
+  const int lg = dim >> 2;
+  const int gw = TZR_WAVE / lg;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int gi = lane / lg;
+  const int c = lane - gi * lg;
+  const bool lane_on = gi < gw;
+  const int gpb = gw * BWD_WAVES;
+  const float lr = *opt.lr;
+  const int64_t iters = (total_rows + (int64_t)gridDim.x * gpb - 1) / ((int64_t)gridDim.x * gpb);
+  for (int64_t it = 0; it < iters; ++it) {  // uniform trip count: the row update is wave-collective
+    const int64_t r = (it * gridDim.x + blockIdx.x) * gpb + wv * gw + gi;
+    const bool valid = lane_on && r < total_rows;
+    float4 g = tzr_zero4();
+    if (valid) g = tzr_ld4(acc + r * (int64_t)dim + 4 * c);
+    float nz = (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) ? 1.f : 0.f;
+    nz = bwd_group_sum(nz, lg, c, lane);
+    const bool active = valid && nz > 0.f;
+    int t = 0;
+    int64_t row = 0;
+    if (valid) {
+      t = (int)tzr_last_le(row_start, T, r);
+      row = r - row_start[t];
+    }
+    const TzrTable tb = tables[t];
+    float4 w4 = tzr_zero4();
+    if (active) w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + row * (int64_t)tb.w_stride + 4 * c);
+    const float4 m4 = bwd_load_state(tb, opt, row, c, active);
+    bwd_apply_row(tb, opt, lr, row, c, g, w4, m4, active, lg, c, lane);
+  }
+}
+
+extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
+                                     const int64_t* d_row_start, int64_t total_rows,
+                                     const float* d_acc, int dim, const TzrSparseOptim* h_optim,
+                                     void* stream) {
+  if (!d_tables || n_tables <= 0 || !d_row_start || total_rows < 0 || !h_optim || !h_optim->d_lr ||
+      dim <= 0 || (dim & 3) || dim > BWD_MAXDIM)
+    return TZR_ERR_INVALID;
+  if (h_optim->kind != TZR_OPT_SGD && h_optim->kind != TZR_OPT_ADAGRAD &&
+      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD)
+    return TZR_ERR_UNSUPPORTED;
+  if (total_rows == 0) return TZR_OK;
+  if (!d_acc || (reinterpret_cast<uintptr_t>(d_acc) & 15)) return TZR_ERR_INVALID;
+  BwdOpt opt;
+  opt.kind = h_optim->kind;
+  opt.wd_mode = h_optim->weight_decay_mode;
+  opt.clip = h_optim->gradient_clipping;
+  opt.lr = reinterpret_cast<const float*>(h_optim->d_lr);
+  opt.eps = h_optim->eps;
+  opt.wd = h_optim->weight_decay;
+  opt.max_grad = h_optim->max_gradient;
+  const int gpb = (TZR_WAVE / (dim >> 2)) * BWD_WAVES;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, (total_rows + gpb - 1) / gpb);
+  hipLaunchKernelGGL(tzr_dense_rows_update_kernel, dim3(grid), dim3(BWD_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
+                     d_acc, dim, opt);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -1,30 +1,36 @@
-"""Row-wise sharded EmbeddingBagCollection: one process per GPU, RCCL all-to-all over xGMI.
+"""Sharded EmbeddingBagCollection: one process per GPU, RCCL over xGMI.
 
 What it replaces.  In the reference, `DistributedModelParallel(module, plan, sharders)`
 (/root/reference/tzrec/utils/dist_util.py:164-195, /root/reference/tzrec/main.py:783-804) swaps the
 EBC for torchrec's sharded EBC [upstream 1.7.0]: KJTAllToAll (input dist) -> per-shard TBE lookup
 -> PooledEmbeddingsReduceScatter / AllToAll (output dist), with the sharding type per table chosen
-by the planner (`row_wise | table_wise | ...`, /root/reference/tzrec/protos/feature.proto:6-13).
+by the planner (`data_parallel | table_wise | row_wise | ...`,
+/root/reference/tzrec/protos/feature.proto:6-13).
 
-MI355X-first design.  xGMI is a point-to-point mesh, so bytes per link are what matters.  torchrec's
-row-wise output dist returns a dense [B_local, F*D] partial from every rank to every rank (7/8 of it
-zeros when bags hold one id).  Here the exchange is at id granularity:
+Placement ("plan", `make_plan`).
+  * `row_wise`: contiguous blocks of ceil(rows/W) rows (torchrec geometry,
+    /root/reference/tzrec/utils/plan_util.py:1049-1060); block q of table t lives on rank
+    (q + rot[t]) mod W.  With block = rows this is table-wise placement on rank rot[t].
+  * `data_parallel`: tables of at most `dp_max_rows` rows are replicated on every rank.  For
+    DLRM-Criteo that is 18 of 26 tables = 7.75 MB of weights but 69 % of all lookups, which therefore
+    never touch the network.
 
-  forward   requester: K2 bucketize ids by owner rank            -> all-to-all (ids)
-            owner:     tzr_rows_gather, one embedding row per id -> all-to-all (rows)
-            requester: K5 pooled gather over the received rows (ids = unbucketize positions),
-                       straight into feature-group layout
-  backward  requester: tzr_lookup_grads, one gradient row per id -> all-to-all (rows)
+MI355X-first exchange.  xGMI is a point-to-point mesh, so bytes per link are what matters.
+torchrec's row-wise output dist returns a dense [B_local, F*D] partial from every rank to every
+rank (7/8 zeros when bags hold one id).  Here the row-wise exchange is at id granularity:
+
+  forward   requester: K1 select the row-wise keys, K2 bucketize by owner -> all-to-all (ids)
+            owner:     tzr_rows_gather, one embedding row per id          -> all-to-all (rows)
+            requester: K5 pooled gather over the received rows (ids = unbucketize positions) and
+                       K5 over the replicated tables, both straight into feature-group layout
+  backward  requester: tzr_lookup_grads, one gradient row per id          -> all-to-all (rows)
             owner:     K6 plan + K7 fused optimizer with per-id gradients (grad_mode 1)
+            replicas:  K6 + K7 in ACCUMULATE mode (exact per-row sums) -> ONE all-reduce of the
+                       [sum rows, D] buffer -> tzr_dense_rows_update, identical on every rank
 
-Placement ("plan").  Every table is split in contiguous blocks of ceil(rows/W) rows (torchrec
-row-wise geometry, /root/reference/tzrec/utils/plan_util.py:1049-1060); block q of table t lives on
-rank (q + rot[t]) mod W.  rot spreads tables with fewer rows than ranks over the node; with
-block = rows it degenerates to table-wise placement on rank rot[t].  Dense parameters are
-data-parallel: gradients are all-reduced and averaged like DDP (dist_util.py:170); sparse
-gradients are NOT divided by the world size (torchrec behaviour).
-
-One host sync per step (the per-peer id counts that size the all-to-all), as in torchrec.
+Dense parameters are data-parallel (gradients averaged like DDP, dist_util.py:170); sparse
+gradients are summed over ranks, NOT divided by the world size (torchrec behaviour, SURVEY.md
+appendix A.7).  One host sync per step sizes the all-to-all, as in torchrec.
 """
 from __future__ import annotations
 
@@ -37,8 +43,8 @@ from torch import nn
 
 from . import _lib
 from .dlrm import MLP
-from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, FusedSparseOptimizer,
-                        SparseOptimizerConfig, _OPT_KIND, _WD_MODE)
+from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
+                        _WD_MODE)
 from .interaction import dot_interaction
 from .sparse import KeyedJaggedTensor, block_bucketize
 
@@ -67,6 +73,25 @@ def row_wise_plan(rows: Sequence[int], world: int) -> Tuple[List[int], List[int]
     return blocks, rot
 
 
+def make_plan(tables: Sequence[EmbeddingBagConfig], world: int, dp_max_rows: int = 65536,
+              replicate_at_world1: bool = False) -> Dict[str, dict]:
+    """{table: {"sharding_type": "data_parallel" | "row_wise", "block", "rot"}} -- the fields
+    tzrec persists from torchrec's plan (tzrec/utils/checkpoint_util.py:1152-1167)."""
+    plan: Dict[str, dict] = {}
+    # at world 1 replication is pointless (kept only as a switch to exercise that path on one GPU)
+    small_ok = world > 1 or replicate_at_world1
+    rw = [t for t in tables if not (small_ok and t.num_embeddings <= dp_max_rows)]
+    blocks, rot = row_wise_plan([t.num_embeddings for t in rw], world)
+    rw_names = {t.name: (b, o) for t, b, o in zip(rw, blocks, rot)}
+    for t in tables:
+        if t.name in rw_names:
+            plan[t.name] = {"sharding_type": "row_wise", "block": rw_names[t.name][0], "rot": rw_names[t.name][1],
+                            "ranks": list(range(world))}
+        else:
+            plan[t.name] = {"sharding_type": "data_parallel", "ranks": list(range(world))}
+    return plan
+
+
 class _ShardedLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, kjt, dst_names, hook):
@@ -81,10 +106,11 @@ class _ShardedLookupFn(torch.autograd.Function):
 
 
 class ShardedEmbeddingBagCollection(nn.Module):
-    """Row-wise sharded pooled lookup with the optimizer fused in backward.
+    """Sharded pooled lookup with the optimizer fused in backward.
 
     Same constructor surface as `EmbeddingBagCollection` (tables are the GLOBAL configs); all tables
-    must share one embedding_dim (DLRM / the fm+deep groups of DeepFM)."""
+    must share one embedding_dim (DLRM / the fm+deep groups of DeepFM) and every KJT key must feed
+    exactly one table."""
 
     def __init__(
         self,
@@ -94,6 +120,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
         groups: Optional[Dict[str, List[str]]] = None,
         row_layout: str = "interleaved",
         process_group: Optional[dist.ProcessGroup] = None,
+        dp_max_rows: int = 65536,
+        replicate_at_world1: bool = False,
     ) -> None:
         super().__init__()
         self.pg = process_group
@@ -106,14 +134,16 @@ class ShardedEmbeddingBagCollection(nn.Module):
             raise ValueError("sharded lookup needs one embedding_dim for all tables")
         self.dim = dims.pop()
         self._opt_cfg = optimizer
-        self.block, self.rot = row_wise_plan([t.num_embeddings for t in tables], self.W)
-        # local shard of every table: block q = (rank - rot) mod W
+        self._plan = make_plan(self._global, self.W, dp_max_rows, replicate_at_world1)
+        self._rw = [t for t in self._global if self._plan[t.name]["sharding_type"] == "row_wise"]
+        self._dp = [t for t in self._global if self._plan[t.name]["sharding_type"] == "data_parallel"]
+        self.block = {t.name: self._plan[t.name]["block"] for t in self._rw}
+        self.rot = {t.name: self._plan[t.name]["rot"] for t in self._rw}
+
+        # --- row-wise shards owned by this rank ---
         local_cfgs = []
-        for t, cfg in enumerate(self._global):
-            q = (self.rank - self.rot[t]) % self.W
-            lo = q * self.block[t]
-            n = max(0, min(self.block[t], cfg.num_embeddings - lo))
-            init = None
+        for cfg in self._rw:
+            lo, n = self.shard_of(cfg.name)
             if cfg.init_fn is not None:  # init the global table deterministically, keep my block
                 def init(w, cfg=cfg, lo=lo, n=n):  # noqa: E306
                     full = torch.empty(cfg.num_embeddings, cfg.embedding_dim)
@@ -124,15 +154,35 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 def init(w, rows=cfg.num_embeddings):  # noqa: E306
                     a = (1.0 / max(rows, 1)) ** 0.5  # same distribution as the unsharded table
                     w.uniform_(-a, a)
-            local_cfgs.append(EmbeddingBagConfig(cfg.name, cfg.embedding_dim, max(n, 1),
-                                                 list(cfg.feature_names), cfg.pooling, init))
-        self.shard_rows = [c.num_embeddings for c in local_cfgs]
-        # owner-side storage + optimizer state reuse the single-GPU module (storage only)
+            local_cfgs.append(EmbeddingBagConfig(cfg.name, cfg.embedding_dim, max(n, 1), list(cfg.feature_names),
+                                                 cfg.pooling, init))
         self.local = EmbeddingBagCollection(local_cfgs, device=self._device, optimizer=optimizer,
-                                            row_layout=row_layout)
-        self.fused_optimizer = self.local.fused_optimizer
-        # requester-side pooling runs K5 over the received rows: one pseudo table read by every key
-        self._lookups = self.local._lookups  # (key, table, out_key) in table-then-feature order
+                                            row_layout=row_layout) if local_cfgs else None
+        # --- replicated tables ---
+        self.replica = EmbeddingBagCollection(
+            [EmbeddingBagConfig(c.name, c.embedding_dim, c.num_embeddings, list(c.feature_names), c.pooling, c.init_fn)
+             for c in self._dp], device=self._device, optimizer=optimizer, row_layout=row_layout) if self._dp else None
+        if self.replica is not None:
+            for store in self.replica._storage:  # identical replicas: rank 0's values (and zero state)
+                dist.broadcast(store, src=0, group=self.pg)
+            for st in self.replica._states.values():
+                if st.data_ptr() not in {s.data_ptr() for s in self.replica._storage}:
+                    dist.broadcast(st, src=0, group=self.pg) if st.is_contiguous() else None
+            rows = [c.num_embeddings for c in self._dp]
+            self._dp_row_start = torch.tensor(np.concatenate([[0], np.cumsum(rows)]), dtype=torch.int64, device=self._device)
+            self._dp_rows = int(sum(rows))
+            self._dp_acc = torch.zeros(self._dp_rows, self.dim, dtype=torch.float32, device=self._device)
+        self.fused_optimizer = (self.local or self.replica).fused_optimizer
+        if self.local is not None and self.replica is not None:  # one lr handle drives both
+            self.replica.fused_optimizer.param_groups = self.local.fused_optimizer.param_groups
+        # lookups in table-then-feature order of the GLOBAL config list
+        self._lookups: List[Tuple[str, int, str]] = []  # (key, global table idx, out_key)
+        for t, cfg in enumerate(self._global):
+            for f in cfg.feature_names:
+                self._lookups.append((f, t, f))
+        keys = [k for k, _, _ in self._lookups]
+        if len(set(keys)) != len(keys):
+            raise ValueError("a KJT key feeds more than one sharded table")
         self._groups = groups
         self._hook = torch.zeros(0, requires_grad=True, device=self._device)
         self._req_meta: Dict[Tuple, dict] = {}
@@ -140,10 +190,38 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._rows_buf: Dict[int, tuple] = {}
         self._timers = None
 
+    # -- placement -------------------------------------------------------------------------------
+    def shard_of(self, name: str) -> Tuple[int, int]:
+        """(first global row, rows) of table `name` held by this rank (replicas: the whole table)."""
+        cfg = next(c for c in self._global if c.name == name)
+        if self._plan[name]["sharding_type"] == "data_parallel":
+            return 0, cfg.num_embeddings
+        b = self._plan[name]["block"]
+        q = (self.rank - self._plan[name]["rot"]) % self.W
+        lo = q * b
+        return lo, max(0, min(b, cfg.num_embeddings - lo))
+
+    def plan(self) -> Dict[str, dict]:
+        return self._plan
+
+    def table_weights(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for m in (self.local, self.replica):
+            if m is not None:
+                out.update(m.table_weights())
+        return out
+
+    def table_states(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for m in (self.local, self.replica):
+            if m is not None:
+                out.update(m.table_states())
+        return out
+
     # -- descriptors ---------------------------------------------------------------------------
     def _layout_for(self, dst_names):
         if dst_names == ("__all__",):
-            return [("__all__", [lk.out_key for lk in self._lookups])]
+            return [("__all__", [ok for _, _, ok in self._lookups])]
         return [(g, self._groups[g]) for g in dst_names]
 
     def _requester_meta(self, kjt_keys, layout) -> dict:
@@ -152,48 +230,73 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if m is not None:
             return m
         key_index = {k: i for i, k in enumerate(kjt_keys)}
-        Fn = len(self._lookups)
-        feats = np.zeros(Fn, dtype=_lib.FEATURE_DT)
-        feats["dst"] = -1
-        by_out = {lk.out_key: i for i, lk in enumerate(self._lookups)}
-        pool = {c.name: c.pooling for c in self._global}
-        for i, lk in enumerate(self._lookups):
-            feats[i]["table"] = 0
-            feats[i]["key"] = key_index[lk.key]
-            feats[i]["pooling"] = _lib.POOL_MEAN if pool[self._global[lk.table].name].lower() == "mean" else _lib.POOL_SUM
-            feats[i]["order"] = i
-        slots = []
+        # global column of every out_key in every destination
+        where: Dict[str, List[Tuple[int, int]]] = {}
         for d, (_, out_keys) in enumerate(layout):
             col = 0
             for ok in out_keys:
-                i = by_out[ok]
-                n = int(feats[i]["n_dst"])
-                feats[i]["dst"][n] = d
-                feats[i]["col"][n] = col
-                feats[i]["n_dst"] = n + 1
-                for c in range(self.dim // 4):
-                    slots.append((i, c, d, col + 4 * c))
+                where.setdefault(ok, []).append((d, col))
                 col += self.dim
-        # per-key bucketize geometry (keys not served by this module get block = 2^62: rank 0, unused)
-        blk = np.full(len(kjt_keys), 1 << 62, dtype=np.int64)
-        rot = np.zeros(len(kjt_keys), dtype=np.int32)
-        served = np.zeros(len(kjt_keys), dtype=bool)
-        key_table = np.zeros(len(kjt_keys), dtype=np.int32)
-        for lk in self._lookups:
-            k = key_index[lk.key]
-            if served[k]:
-                raise ValueError(f"key {lk.key} feeds more than one sharded table")
-            served[k] = True
-            blk[k], rot[k], key_table[k] = self.block[lk.table], self.rot[lk.table], lk.table
-        if not served.all():
-            raise ValueError("sharded lookup expects a KJT holding exactly the keys it serves")
-        m = {
-            "feats_np": feats, "slots_np": np.array(slots, dtype=_lib.SLOT_DT),
-            "d_feats": _lib.upload_struct(feats, self._device),
-            "d_slots": _lib.upload_struct(np.array(slots, dtype=_lib.SLOT_DT), self._device),
-            "blk": torch.from_numpy(blk).to(self._device), "rot": torch.from_numpy(rot).to(self._device),
-            "key_table": key_table, "widths": [len(ks) * self.dim for _, ks in layout],
-        }
+        pool = {c.name: c.pooling for c in self._global}
+        rw_names = [c.name for c in self._rw]
+        dp_names = [c.name for c in self._dp]
+
+        def build(part_lookups, table_index, key_of):
+            feats = np.zeros(len(part_lookups), dtype=_lib.FEATURE_DT)
+            feats["dst"] = -1
+            slots = []
+            for i, (key, t, ok) in enumerate(part_lookups):
+                feats[i]["table"] = table_index(t)
+                feats[i]["key"] = key_of(key)
+                feats[i]["pooling"] = _lib.POOL_MEAN if pool[self._global[t].name].lower() == "mean" else _lib.POOL_SUM
+                feats[i]["order"] = i
+                for n, (d, col) in enumerate(where.get(ok, [])):
+                    feats[i]["dst"][n], feats[i]["col"][n] = d, col
+                    feats[i]["n_dst"] = n + 1
+                    for c in range(self.dim // 4):
+                        slots.append((i, c, d, col + 4 * c))
+            slots = np.array(slots, dtype=_lib.SLOT_DT)
+            return feats, slots
+
+        rw_lk = [lk for lk in self._lookups if self._global[lk[1]].name in self.block]
+        dp_lk = [lk for lk in self._lookups if self._global[lk[1]].name not in self.block]
+        for key, _, _ in self._lookups:
+            if key not in key_index:
+                raise KeyError(f"KeyedJaggedTensor has no key {key!r}")
+        m = {"widths": [len(ks) * self.dim for _, ks in layout]}
+        if rw_lk:
+            rw_keys = [k for k, _, _ in rw_lk]  # order of the permuted sub-KJT
+            sub_index = {k: i for i, k in enumerate(rw_keys)}
+            feats, slots = build(rw_lk, lambda t: 0, lambda k: sub_index[k])
+            m.update({
+                "rw_perm": [key_index[k] for k in rw_keys], "rw_feats_np": feats, "rw_slots_n": len(slots),
+                "rw_d_feats": _lib.upload_struct(feats, self._device), "rw_d_slots": _lib.upload_struct(slots, self._device),
+                "rw_blk": torch.tensor([self.block[self._global[t].name] for _, t, _ in rw_lk], dtype=torch.int64, device=self._device),
+                "rw_rot": torch.tensor([self.rot[self._global[t].name] for _, t, _ in rw_lk], dtype=torch.int32, device=self._device),
+                "rw_key_table": np.array([rw_names.index(self._global[t].name) for _, t, _ in rw_lk], dtype=np.int32),
+                "rw_n": len(rw_lk),
+            })
+        if dp_lk:
+            feats, slots = build(dp_lk, lambda t: dp_names.index(self._global[t].name), lambda k: key_index[k])
+            # table descriptors of the replicas (weights + real state) and their ACCUMULATE twin
+            base = self.replica._meta([lk.key for lk in self.replica._lookups], self.replica._default_layout())
+            tables = base.tables_np.copy()
+            acc_tables = tables.copy()
+            rs = self._dp_row_start.cpu().numpy()
+            for t in range(len(tables)):
+                mine = [i for i, (_, tt, _) in enumerate(dp_lk) if dp_names.index(self._global[tt].name) == t]
+                for arr in (tables, acc_tables):
+                    arr[t]["first_order"] = mine[0] if mine else 0
+                    arr[t]["n_feats"] = len(mine)
+                acc_tables[t]["m"] = self._dp_acc.data_ptr() + int(rs[t]) * self.dim * 4
+                acc_tables[t]["m_stride"] = self.dim
+            m.update({
+                "dp_feats_np": feats, "dp_slots_n": len(slots), "dp_n": len(dp_lk),
+                "dp_d_feats": _lib.upload_struct(feats, self._device), "dp_d_slots": _lib.upload_struct(slots, self._device),
+                "dp_d_tables": _lib.upload_struct(tables, self._device),
+                "dp_d_acc_tables": _lib.upload_struct(acc_tables, self._device),
+                "dp_max_rows": int(max(c.num_embeddings for c in self._dp)), "n_keys": len(kjt_keys),
+            })
         self._req_meta[ck] = m
         return m
 
@@ -201,15 +304,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         """Descriptors of the owner side: W*F received keys (source-major), key (s, f) -> table."""
         if self._own_meta is not None:
             return self._own_meta
-        F, W, T = len(key_table), self.W, len(self._global)
+        F, W, T = len(key_table), self.W, len(self._rw)
         K = W * F
-        base = self.local._meta([lk.key for lk in self._lookups], self.local._default_layout())
+        base = self.local._meta([lk.key for lk in self.local._lookups], self.local._default_layout())
         tables = base.tables_np.copy()
         feats = np.zeros(K, dtype=_lib.FEATURE_DT)
         feats["dst"] = -1
         kt = np.tile(key_table, W).astype(np.int32)
-        # table-major order of the received keys: (table, source, key)
-        order = np.lexsort((np.arange(K), kt))
+        order = np.lexsort((np.arange(K), kt))  # table-major order of the received keys
         rank_of = np.empty(K, dtype=np.int32)
         rank_of[order] = np.arange(K, dtype=np.int32)
         feats["table"], feats["key"], feats["order"] = kt, np.arange(K, dtype=np.int32), rank_of
@@ -220,12 +322,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._own_meta = {
             "d_tables": _lib.upload_struct(tables, self._device),
             "d_feats": _lib.upload_struct(feats, self._device),
-            "d_key_table": torch.from_numpy(kt).to(self._device), "K": K,
-            "max_rows": int(max(self.shard_rows)),
+            "d_key_table": torch.from_numpy(kt).to(self._device), "K": K, "T": T,
+            "max_rows": int(max(c.num_embeddings for c in self.local.embedding_bag_configs())),
         }
         return self._own_meta
 
-    def _recv_rows_buffer(self, n: int):
+    def _recv_rows_buffer(self, n: int, n_lookups: int):
         """Persistent [n, D] buffer for the rows coming back from their owners plus the one-table
         descriptor that lets K5 pool over it (cached: no per-step upload)."""
         hit = self._rows_buf.get(n)
@@ -234,7 +336,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             rows_in = torch.empty(max(n, 1), D, dtype=torch.float32, device=self._device)
             pt = np.zeros(1, dtype=_lib.TABLE_DT)
             pt[0]["w"], pt[0]["rows"], pt[0]["dim"], pt[0]["w_stride"] = rows_in.data_ptr(), max(n, 1), D, D
-            pt[0]["n_feats"] = len(self._lookups)
+            pt[0]["n_feats"] = n_lookups
             hit = (rows_in, _lib.upload_struct(pt, self._device))
             if len(self._rows_buf) > 8:
                 self._rows_buf.clear()
@@ -245,63 +347,78 @@ class ShardedEmbeddingBagCollection(nn.Module):
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits) -> None:
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
 
+    def _optim_struct(self, kind: Optional[int] = None):
+        cfg = self._opt_cfg
+        opt = _lib.TzrSparseOptim()
+        opt.kind = _OPT_KIND[cfg.kind] if kind is None else kind
+        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
+        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(self._device))
+        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
+        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        return opt
+
     def _forward_impl(self, kjt: KeyedJaggedTensor, dst_names):
         L = _lib.lib()
         dev, W, D = self._device, self.W, self.dim
         layout = self._layout_for(dst_names)
         rm = self._requester_meta(kjt.keys(), layout)
-        om = self._owner_meta(rm["key_table"])
-        F, B = len(kjt.keys()), kjt.stride()
-        N = kjt.values().numel()
+        B = kjt.stride()
         stream = _lib.stream_ptr(dev)
-        # 1. requester: bucketize by owner rank
-        bkt, unb = block_bucketize(kjt, rm["blk"], W, return_permute=True, rank_offsets=rm["rot"])
-        # per (dest rank, key) id counts -> owners (they become the owners' key segments)
-        send_cnt = (bkt.offsets()[B::B] - bkt.offsets()[:-1:B]).contiguous()  # [W*F]
-        recv_cnt = torch.empty_like(send_cnt)
-        self._a2a(recv_cnt, send_cnt, None, None)
-        both = torch.stack([send_cnt.view(W, F).sum(1), recv_cnt.view(W, F).sum(1)]).cpu()  # host sync
-        send_splits, recv_splits = both[0].tolist(), both[1].tolist()
-        n_recv = int(sum(recv_splits))
-        # 2. ids to their owners
-        recv_ids = torch.empty(n_recv, dtype=torch.int64, device=dev)
-        self._a2a(recv_ids, bkt.values(), recv_splits, send_splits)
-        key_start = torch.zeros(W * F + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(recv_cnt, 0, out=key_start[1:])
-        # 3. owner: one row per received id
-        rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
-        _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]),
-                                     _lib.ptr(key_start), om["K"], _lib.ptr(recv_ids), n_recv,
-                                     _lib.ptr(rows_out), D, D, stream), "tzr_rows_gather")
-        # 4. rows back to the requesters (bucketized order)
-        rows_in, d_pt = self._recv_rows_buffer(N)
-        self._a2a(rows_in[:N], rows_out[:n_recv], send_splits, recv_splits)
-        # 5. requester: pooled gather over the received rows, ids = position in bucketized order
         uniform = kjt.uniform_length() == 1
-        offsets = None if uniform else kjt.offsets()
         outs = [torch.empty(B, w, dtype=torch.float32, device=dev) for w in rm["widths"]]
         dsts = (_lib.TzrDst * len(outs))()
         for i, o in enumerate(outs):
             dsts[i].ptr, dsts[i].stride = _lib.ptr(o), o.stride(0)
-        _lib.check(L.tzr_pooled_fwd(_lib.ptr(d_pt), _lib.ptr(rm["d_feats"]), len(self._lookups),
-                                    _lib.ptr(rm["d_slots"]), len(rm["slots_np"]), _lib.ptr(unb),
-                                    _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), B, dsts,
-                                    len(outs), 1 if uniform else 0, stream), "tzr_pooled_fwd")
-        state = {"kjt": kjt, "rm": rm, "om": om, "unb": unb, "recv_ids": recv_ids, "key_start": key_start,
-                 "send_splits": send_splits, "recv_splits": recv_splits, "n_recv": n_recv,
-                 "keep": (rows_in, d_pt)}
+        state = {"kjt": kjt, "rm": rm}
+
+        if "rw_n" in rm:
+            om = self._owner_meta(rm["rw_key_table"])
+            sub = kjt if rm["rw_perm"] == list(range(len(kjt.keys()))) else kjt.permute(rm["rw_perm"])
+            F, N = rm["rw_n"], sub.values().numel()
+            # 1. requester: bucketize by owner rank
+            bkt, unb = block_bucketize(sub, rm["rw_blk"], W, return_permute=True, rank_offsets=rm["rw_rot"])
+            send_cnt = (bkt.offsets()[B::B] - bkt.offsets()[:-1:B]).contiguous()  # [W*F] ids per (dest, key)
+            recv_cnt = torch.empty_like(send_cnt)
+            self._a2a(recv_cnt, send_cnt, None, None)
+            both = torch.stack([send_cnt.view(W, F).sum(1), recv_cnt.view(W, F).sum(1)]).cpu()  # host sync
+            send_splits, recv_splits = both[0].tolist(), both[1].tolist()
+            n_recv = int(sum(recv_splits))
+            # 2. ids to their owners
+            recv_ids = torch.empty(n_recv, dtype=torch.int64, device=dev)
+            self._a2a(recv_ids, bkt.values(), recv_splits, send_splits)
+            key_start = torch.zeros(W * F + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(recv_cnt, 0, out=key_start[1:])
+            # 3. owner: one row per received id
+            rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
+            _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(key_start),
+                                         om["K"], _lib.ptr(recv_ids), n_recv, _lib.ptr(rows_out), D, D, stream),
+                       "tzr_rows_gather")
+            # 4. rows back to the requesters (bucketized order)
+            rows_in, d_pt = self._recv_rows_buffer(N, F)
+            self._a2a(rows_in[:N], rows_out[:n_recv], send_splits, recv_splits)
+            # 5. requester: pooled gather over the received rows, ids = position in bucketized order
+            _lib.check(L.tzr_pooled_fwd(_lib.ptr(d_pt), _lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(rm["rw_d_slots"]),
+                                        rm["rw_slots_n"], _lib.ptr(unb), _lib.ptr(None if uniform else sub.offsets()),
+                                        _lib.ptr(sub.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
+                                        stream), "tzr_pooled_fwd")
+            state.update({"om": om, "sub": sub, "unb": unb, "recv_ids": recv_ids, "key_start": key_start,
+                          "send_splits": send_splits, "recv_splits": recv_splits, "n_recv": n_recv})
+        if "dp_n" in rm:  # replicated tables: purely local, same destination buffers
+            _lib.check(L.tzr_pooled_fwd(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
+                                        _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
+                                        _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
+                                        B, dsts, len(outs), 1 if uniform else 0, stream), "tzr_pooled_fwd")
         return outs, state
 
     def _backward_impl(self, st, grads) -> None:
         if self.fused_optimizer is None:
             return
         L = _lib.lib()
-        dev, W, D = self._device, self.W, self.dim
-        kjt, rm, om = st["kjt"], st["rm"], st["om"]
-        B, N, n_recv = kjt.stride(), kjt.values().numel(), st["n_recv"]
+        dev, D = self._device, self.dim
+        kjt, rm = st["kjt"], st["rm"]
+        B = kjt.stride()
         stream = _lib.stream_ptr(dev)
         uniform = kjt.uniform_length() == 1
-        offsets = None if uniform else kjt.offsets()
         gl = []
         for g, w in zip(grads, rm["widths"]):
             if g is None:
@@ -310,37 +427,52 @@ class ShardedEmbeddingBagCollection(nn.Module):
         gd = (_lib.TzrDst * len(gl))()
         for i, g in enumerate(gl):
             gd[i].ptr, gd[i].stride = _lib.ptr(g), g.stride(0)
-        # 1. requester: one gradient row per id, in bucketized order
-        grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
-        _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["d_feats"]), len(self._lookups), _lib.ptr(offsets),
-                                      _lib.ptr(kjt.weights_or_none()), B, 1 if uniform else 0,
-                                      _lib.ptr(st["unb"]), gd, len(gl), _lib.ptr(grow), D, D, stream),
-                   "tzr_lookup_grads")
-        # 2. to the owners
-        grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
-        self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"])
-        if n_recv == 0:
-            return
-        # 3. owner: sort by (table,row) + fused optimizer, gradients addressed per id
-        K, T = om["K"], len(self._global)
-        nbytes = L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D)
-        ws = _lib.workspace(nbytes, dev)
-        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K,
-                                         om["max_rows"], D, _lib.ptr(st["recv_ids"]),
-                                         _lib.ptr(st["key_start"]), n_recv, n_recv, 1, 0,
-                                         _lib.ptr(ws), ws.numel(), stream), "tzr_pooled_bwd_plan")
-        cfg = self._opt_cfg
-        opt = _lib.TzrSparseOptim()
-        opt.kind = _OPT_KIND[cfg.kind]
-        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
-        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(dev))
-        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
-        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
-        g1 = (_lib.TzrDst * 1)()
-        g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
-        _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_feats"]), K, T, D,
-                                          _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
-                                          opt, _lib.ptr(ws), ws.numel(), stream), "tzr_pooled_bwd_apply")
+
+        if "rw_n" in rm:
+            om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
+            N, F = sub.values().numel(), rm["rw_n"]
+            # 1. requester: one gradient row per id, in bucketized order
+            grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+            _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
+                                          _lib.ptr(sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
+                                          gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
+            # 2. to the owners
+            grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
+            self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"])
+            # 3. owner: sort by (table,row) + fused optimizer, gradients addressed per id
+            if n_recv > 0:
+                K, T = om["K"], om["T"]
+                ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
+                _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K,
+                                                 om["max_rows"], D, _lib.ptr(st["recv_ids"]), _lib.ptr(st["key_start"]),
+                                                 n_recv, n_recv, 1, 0, _lib.ptr(ws), ws.numel(), stream),
+                           "tzr_pooled_bwd_plan")
+                g1 = (_lib.TzrDst * 1)()
+                g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
+                _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_feats"]), K, T, D,
+                                                  _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
+                                                  self._optim_struct(), _lib.ptr(ws), ws.numel(), stream),
+                           "tzr_pooled_bwd_apply")
+        if "dp_n" in rm:
+            # replicas: exact per-row gradient sums of my samples -> all-reduce -> same dense update
+            N, n_dp, T = kjt.values().numel(), rm["dp_n"], len(self._dp)
+            offsets = None if uniform else kjt.offsets()
+            self._dp_acc.zero_()
+            NP = n_dp * B if uniform else N
+            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, NP, n_dp, T, B, D), dev)
+            _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T, _lib.ptr(rm["dp_d_feats"]), n_dp,
+                                             rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
+                                             _lib.ptr(offsets), N, NP, B, 1 if uniform else 0, _lib.ptr(ws),
+                                             ws.numel(), stream), "tzr_pooled_bwd_plan")
+            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_feats"]), n_dp, T, D,
+                                              _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, NP, B,
+                                              1 if uniform else 0, 0, gd, len(gl),
+                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
+                       "tzr_pooled_bwd_apply")
+            dist.all_reduce(self._dp_acc, group=self.pg)
+            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), T, _lib.ptr(self._dp_row_start),
+                                               self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
+                       "tzr_dense_rows_update")
 
     # -- public API ------------------------------------------------------------------------------
     def forward_grouped(self, features: KeyedJaggedTensor, group_names=None) -> Dict[str, torch.Tensor]:
@@ -351,26 +483,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
             outs, _ = self._forward_impl(features, names)
         return dict(zip(names, outs))
 
-    def shard_of(self, name: str) -> Tuple[int, int]:
-        """(first global row, rows) of table `name` held by this rank."""
-        t = [c.name for c in self._global].index(name)
-        q = (self.rank - self.rot[t]) % self.W
-        lo = q * self.block[t]
-        return lo, max(0, min(self.block[t], self._global[t].num_embeddings - lo))
-
-    def table_weights(self) -> Dict[str, torch.Tensor]:
-        return self.local.table_weights()
-
-    def table_states(self) -> Dict[str, torch.Tensor]:
-        return self.local.table_states()
-
 
 class ShardedDLRM(nn.Module):
-    """DLRM with row-wise sharded tables and data-parallel MLPs."""
+    """DLRM with sharded tables and data-parallel MLPs."""
 
     def __init__(self, tables, sparse_features, dense_dim, dense_mlp=(64, 16), final_mlp=(64, 32),
                  arch_with_sparse=True, device=None, sparse_optimizer=None, row_layout="interleaved",
-                 process_group=None) -> None:
+                 process_group=None, dp_max_rows: int = 65536, replicate_at_world1: bool = False) -> None:
         super().__init__()
         self.pg = process_group
         self.dim = tables[0].embedding_dim
@@ -378,7 +497,8 @@ class ShardedDLRM(nn.Module):
         self.arch_with_sparse = arch_with_sparse
         self.ebc = ShardedEmbeddingBagCollection(
             tables, device=device, optimizer=sparse_optimizer, groups={"sparse": list(sparse_features)},
-            row_layout=row_layout, process_group=process_group)
+            row_layout=row_layout, process_group=process_group, dp_max_rows=dp_max_rows,
+            replicate_at_world1=replicate_at_world1)
         self.dense_mlp = MLP(dense_dim, dense_mlp).to(device)
         n = self.num_sparse + 1
         feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
@@ -387,12 +507,12 @@ class ShardedDLRM(nn.Module):
         # same dense parameters on every rank (DDP broadcasts rank 0's at construction)
         for p in self.dense_parameters():
             dist.broadcast(p.data, src=0, group=self.pg)
-        self._flat = None
 
     def describe(self) -> str:
-        w = self.ebc.W
-        return (f"{w} ranks: all tables row-wise (block=ceil(rows/{w}), small tables rotated), id-granularity "
-                f"all-to-all (ids, rows, grads) over RCCL; MLPs data-parallel with all-reduce")
+        e = self.ebc
+        return (f"{e.W} ranks: {len(e._rw)} tables row-wise (block=ceil(rows/{e.W}), id-granularity all-to-all of "
+                f"ids/rows/grads over RCCL), {len(e._dp)} small tables data_parallel (local lookup, one all-reduce of "
+                f"row gradients); MLPs data-parallel with all-reduce")
 
     def dense_parameters(self):
         for m in (self.dense_mlp, self.final_mlp, self.output_mlp):
