@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
     ap.add_argument("--replicate-small", action="store_true",
                     help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sharded runs: op-by-op autograd step instead of ShardedTrainStep")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="sharded runs: do not run the next batch's input dist ahead on the side stream")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -261,7 +265,15 @@ def main():
     if ebc is not None:
         ebc.async_plan = args.async_plan
 
-    def step_body(dense, kjt, label):
+    train_step = None
+    if sharded and not args.no_pipeline:
+        from torcheasyrec_amd.sharded_step import ShardedTrainStep
+
+        train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch)
+
+    def step_body(dense, kjt, label, next_kjt=None):
+        if train_step is not None:
+            return train_step.step(dense, kjt, label, next_kjt=next_kjt)
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
         loss.backward()
@@ -294,7 +306,7 @@ def main():
         if graphs is not None:
             graphs[i % nb].replay()
             return losses[i % nb]
-        return step_body(*batches[i % nb])
+        return step_body(*batches[i % nb], next_kjt=batches[(i + 1) % nb][1])
 
     if world > 1:
         dist.barrier()
@@ -345,7 +357,9 @@ def main():
                                f"{args.optimizer} + dense Adam, ids {args.dist}",
                    "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism,
                    "row_layout": args.row_layout, "rows_cap": args.rows_cap or None},
-        "final_loss": final_loss, "launch": "hipGraph replay" if graphs is not None else "eager",
+        "final_loss": final_loss,
+        "launch": ("hipGraph replay" if graphs is not None else
+                   ("pipelined: input dist one batch ahead + hipGraph dense segment" if train_step is not None else "eager")),
     }
     if rank == 0 and world == 1:
         ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]

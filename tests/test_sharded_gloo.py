@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(__file__))
 
 
-def _worker(rank, world, init_file, emu_path, mode, result_dir):
+def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     from oracle import tzrec_oracle as orc
@@ -41,10 +41,12 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
     lr = 0.05
     tables = criteo_tables(rows, init="seeded")[:F]
     # rows > 100 -> row-wise shards, the small ones are replicated (data_parallel)
-    model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100,
+    # ... and one table is pinned table-wise (whole table on one rank) like a tzrec embedding_constraint
+    model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100, constraints={"cat_1_emb": "table_wise"},
                         sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
     kinds = {n: p["sharding_type"] for n, p in model.ebc.plan().items()}
-    assert set(kinds.values()) == {"row_wise", "data_parallel"}
+    assert set(kinds.values()) == {"row_wise", "table_wise", "data_parallel"}
+    assert len(model.ebc.plan()["cat_1_emb"]["ranks"]) == 1
     Bg = 48
     Bl = Bg // world
     dense_g, kjt_g, label_g = synthetic_batch(2, Bg, rows)
@@ -67,10 +69,22 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
     kjt = KeyedJaggedTensor(keys, torch.cat(vs), torch.cat(ls), torch.cat(ws) if ws else None)
     dense, label = dense_g[sl].contiguous(), label_g[sl].contiguous()
 
-    logits = model(dense, kjt)
-    loss = bce_with_logits(logits, label)
-    loss.backward()
-    model.allreduce_dense_grads()
+    if via_step:  # the pipelined train step (input dist split from lookup, dense segment via autograd.grad)
+        from torcheasyrec_amd.sharded_step import ShardedTrainStep
+
+        class _NoOpt:  # keep the dense weights: the checks below compare gradients
+            def step(self):
+                pass
+
+        ts = ShardedTrainStep(model, _NoOpt())
+        loss = ts.step(dense, kjt, label, next_kjt=kjt)
+        assert ts._ahead is not None and "recv_ids" in ts._ahead[1]  # next batch's input dist already ran
+        logits = ts._seg[Bl].logits
+    else:
+        logits = model(dense, kjt)
+        loss = bce_with_logits(logits, label)
+        loss.backward()
+        model.allreduce_dense_grads()
 
     # ---- oracle on this rank's samples (full tables) ----
     full = []
@@ -126,12 +140,12 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["uniform1", "jagged"])
-def test_sharded_dlrm_world2(emu_path, mode):
+@pytest.mark.parametrize("mode,via_step", [("uniform1", False), ("jagged", False), ("uniform1", True), ("jagged", True)])
+def test_sharded_dlrm_world2(emu_path, mode, via_step):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
-        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step), nprocs=world, join=True)
 
 
 def test_row_wise_plan_spreads_small_tables():
@@ -144,6 +158,14 @@ def test_row_wise_plan_spreads_small_tables():
     assert plan["big"]["sharding_type"] == "row_wise" and plan["big"]["block"] == 5_000_000
     assert plan["tiny"]["sharding_type"] == "data_parallel"
     assert make_plan([EmbeddingBagConfig("tiny", 16, 3, ["b"])], 1)["tiny"]["sharding_type"] == "row_wise"
+    mid = [EmbeddingBagConfig("big", 16, 40_000_000, ["a"]), EmbeddingBagConfig("mid", 16, 400_000, ["c"]),
+           EmbeddingBagConfig("mid2", 16, 300_000, ["d"])]
+    p = make_plan(mid, 8, tw_max_rows=1_000_000)
+    assert p["mid"]["sharding_type"] == "table_wise" and p["mid"]["block"] == 400_000 and len(p["mid"]["ranks"]) == 1
+    assert p["mid"]["ranks"] != p["mid2"]["ranks"]  # whole tables go to different owners
+    assert make_plan(mid, 8, constraints={"big": "table_wise"})["big"]["block"] == 40_000_000
+    with pytest.raises(ValueError):
+        make_plan(mid, 8, constraints={"big": "column_wise"})
     blocks, rot = row_wise_plan([40_000_000, 3, 4, 10, 2], 8)
     assert blocks[0] == 5_000_000 and rot[0] == 0
     # tiny tables must not all start on rank 0

@@ -1,0 +1,171 @@
+"""Training step of the sharded DLRM, organised the way MI355X wants it launched.
+
+A sharded step cannot be ONE hipGraph: the all-to-all split sizes depend on the ids and RCCL wants
+them on the host.  Issued op by op it is ~150 launches and host-bound (profiles/r01d).  So the step
+is cut along the data-dependent boundary:
+
+  input dist   (ids only)   bucketize -> counts all-to-all -> host sync -> ids all-to-all.
+                            Runs one batch AHEAD on a side HIP stream, so the host sync waits for
+                            work that was queued behind nothing, while the main stream is busy with
+                            the previous batch (reference: TrainPipelineSparseDist,
+                            /root/reference/tzrec/utils/dist_util.py:221-303).
+  lookup       (C-ABI)      owner row gather -> rows all-to-all -> pooled gather, straight into
+                            the static input buffer of ...
+  dense segment (hipGraph)  bottom MLP, dot interaction, top MLP, BCE loss and the whole autograd
+                            backward: static shapes, captured once per batch size, ONE launch.  Its
+                            outputs are d(loss)/d(pooled embeddings) and the dense gradients.
+  sparse bwd   (C-ABI)      per-id gradient rows -> all-to-all -> sort + fused optimizer on the
+                            owners; replicated tables: accumulate -> all-reduce -> dense update.
+  dense sync                one flat all-reduce (AVG) of the MLP gradients, fused Adam.
+
+Weights are only read by `lookup`, which runs after the previous step's sparse update on the same
+stream, so prefetching the input dist changes no value (tests/test_sharded_gloo.py runs both ways).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .dlrm import bce_with_logits
+from .sharding import ShardedDLRM
+from .sparse import KeyedJaggedTensor
+
+
+class _Segment:
+    """Static buffers + captured graph of the dense segment for one batch size."""
+
+    def __init__(self) -> None:
+        self.graph = None
+        self.dense = self.label = self.sparse = self.loss = self.logits = None
+        self.grads = None
+
+
+class ShardedTrainStep:
+    def __init__(self, model: ShardedDLRM, dense_optimizer: torch.optim.Optimizer,
+                 loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
+                 use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2) -> None:
+        self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
+        self.device = model.ebc._device
+        self.cuda = self.device.type == "cuda"
+        self.use_graph = self.cuda if use_graph is None else (use_graph and self.cuda)
+        self.prefetch = prefetch
+        self.warmup_iters = warmup_iters
+        self.params = list(model.dense_parameters())
+        self._seg: Dict[int, _Segment] = {}
+        self._seen: Dict[int, int] = {}
+        self._side = torch.cuda.Stream(self.device) if self.cuda else None
+        self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
+
+    # -- dense segment ---------------------------------------------------------------------------
+    def _dense_fwd_bwd(self, dense, sparse, label):
+        logits = self.model.dense_forward(dense, sparse)
+        loss = self.loss_fn(logits, label)
+        grads = torch.autograd.grad(loss, [sparse] + self.params)
+        return loss.detach(), logits.detach(), grads
+
+    def _segment(self, dense, label, width) -> _Segment:
+        B = dense.shape[0]
+        seg = self._seg.get(B)
+        if seg is None:
+            seg = _Segment()
+            seg.sparse = torch.zeros(B, width, dtype=torch.float32, device=self.device, requires_grad=True)
+            if self.use_graph:
+                seg.dense, seg.label = torch.empty_like(dense), torch.empty_like(label)
+            self._seg[B] = seg
+        return seg
+
+    def _run_dense(self, seg: _Segment, dense, label) -> None:
+        B = dense.shape[0]
+        if not self.use_graph:
+            seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(dense, seg.sparse, label)
+            return
+        seg.dense.copy_(dense)
+        seg.label.copy_(label)
+        if seg.graph is None:
+            n = self._seen.get(B, 0)
+            self._seen[B] = n + 1
+            if n < self.warmup_iters:  # eager: TunableOp / lazy inits must not happen under capture
+                seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
+                return
+            cur = torch.cuda.current_stream(self.device)
+            if cur == torch.cuda.default_stream(self.device):
+                raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
+                                   "non-default stream (torch.cuda.set_stream)")
+            seg.loss = seg.logits = seg.grads = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cur):
+                seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
+            seg.graph = g
+        seg.graph.replay()
+
+    # -- input dist, possibly one batch ahead ------------------------------------------------------
+    def _begin(self, kjt: KeyedJaggedTensor, after: Optional["torch.cuda.Event"] = None) -> dict:
+        ebc = self.model.ebc
+        if not self.cuda:
+            return ebc.input_dist_begin(kjt, ("sparse",))
+        # the ids must exist before the side stream reads them: either everything queued on the main
+        # stream so far, or (prefetch) just the point where this step started -- NOT the step's own
+        # work, or the prefetch would queue behind the dense segment it is meant to overlap
+        if after is not None:
+            self._side.wait_event(after)
+        else:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            return ebc.input_dist_begin(kjt, ("sparse",))
+
+    def _end(self, st: dict) -> dict:
+        ebc = self.model.ebc
+        if not self.cuda:
+            return ebc.input_dist_end(st)
+        with torch.cuda.stream(self._side):
+            st = ebc.input_dist_end(st)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        st["ready"] = ev
+        return st
+
+    def _consume(self, st: dict) -> None:
+        """Main stream takes over the tensors the side stream produced."""
+        if not self.cuda:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(st["ready"])
+        for v in st.values():
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
+        sub = st.get("sub")
+        if sub is not None:
+            for t in (sub.values(), sub.lengths(), sub.weights_or_none(), sub._offsets):
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
+
+    # -- one step --------------------------------------------------------------------------------
+    def step(self, dense: torch.Tensor, kjt: KeyedJaggedTensor, label: torch.Tensor,
+             next_kjt: Optional[KeyedJaggedTensor] = None) -> torch.Tensor:
+        """Forward, backward, sparse + dense optimizer for one batch; returns the (detached) loss.
+        `next_kjt` lets the input dist of the following batch overlap this one."""
+        model, ebc = self.model, self.model.ebc
+        t0 = None
+        if self.cuda:
+            t0 = torch.cuda.Event()
+            t0.record(torch.cuda.current_stream(self.device))
+        if self._ahead is not None and self._ahead[0] is kjt:
+            st = self._ahead[1]
+        else:
+            st = self._end(self._begin(kjt))
+        self._ahead = None
+        self._consume(st)
+        seg = self._segment(dense, label, st["rm"]["widths"][0])
+        ebc.lookup(st, [seg.sparse.detach()])
+        self._run_dense(seg, dense, label)
+        pending = self._begin(next_kjt, t0) if (next_kjt is not None and self.prefetch) else None
+        ebc.backward(st, [seg.grads[0]])
+        pg = list(seg.grads[1:])
+        model.allreduce_dense_grads(pg)
+        for p, g in zip(self.params, pg):
+            p.grad = g
+        self.opt.step()
+        if pending is not None:
+            self._ahead = (next_kjt, self._end(pending))
+        return seg.loss
