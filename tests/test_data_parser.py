@@ -1,0 +1,121 @@
+"""Host-side index stage (torcheasyrec_amd/data_parser.py) against (1) the reference's own test
+literals (tests/golden/reference_index_vectors.json) and (2) the oracle on random ragged columns of
+every supported arrow type.  Bit-exact: ids, lengths and weights are integers / parsed literals."""
+import json
+import os
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import tzrec_oracle as orc  # noqa: E402
+from torcheasyrec_amd.data_parser import (DataParser, parse_dense_column, parse_sequence_column,  # noqa: E402
+                                          parse_sparse_column)
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_index_vectors.json")))
+S3 = "\x03"
+
+
+def _default(d):
+    if d in (None, ""):
+        return None
+    return [int(x) for x in d] if isinstance(d, list) else [int(d)]
+
+
+@pytest.mark.parametrize("case", G["id_feature_parse"]["cases"])
+def test_id_feature_parse_golden(case):
+    c = parse_sparse_column("f", case["input"], default_value=_default(case["default"]))
+    assert c.values.tolist() == case["values"] and c.lengths.tolist() == case["lengths"]
+    assert c.values.dtype == np.int64 and c.lengths.dtype == np.int32
+
+
+def test_weighted_map_parse_golden():
+    case = G["id_feature_parse_weighted"]["cases"][0]
+    c = parse_sparse_column("f", case["input"], is_weighted=True)
+    assert c.values.tolist() == case["values"] and c.lengths.tolist() == case["lengths"]
+    np.testing.assert_array_equal(c.weights, np.asarray(case["weights"], np.float32))
+
+
+@pytest.mark.parametrize("name", ["data_parser_nofg", "data_parser_weighted"])
+def test_to_batch_golden(name):
+    g = G[name]
+    cols = {}
+    for k, spec in g["columns"].items():
+        if k.startswith("click_seq__"):
+            cols[k] = parse_sequence_column(k, spec["input"], sequence_delim=spec["sep"], default_value=_default(spec["default"]))
+        else:
+            cols[k] = parse_sparse_column(k, spec["input"], multival_sep=spec["sep"], default_value=_default(spec["default"]),
+                                          is_weighted=bool(spec.get("weighted")))
+    kjt = DataParser(g["kjt"]["keys"], sequence_keys=[k for k in cols if k.startswith("click_seq__")]).to_kjt(cols)
+    assert kjt.keys() == g["kjt"]["keys"]
+    assert kjt.values().tolist() == g["kjt"]["values"]
+    assert kjt.lengths().tolist() == g["kjt"]["lengths"]
+    assert kjt.stride() == 3
+    if "weights" in g["kjt"]:
+        np.testing.assert_array_equal(kjt.weights().numpy(), np.asarray(g["kjt"]["weights"], np.float32))
+    else:
+        assert kjt.weights_or_none() is None
+
+
+def _random_rows(rng, n, kind):
+    rows = []
+    for _ in range(n):
+        r = rng.integers(0, 6)
+        if r == 0:
+            rows.append(None)
+        elif r == 1 and kind != "int":
+            rows.append("" if kind in ("str", "wstr") else ([] if kind == "list" else None))
+        else:
+            ids = rng.integers(0, 1 << 40, size=rng.integers(1, 5)).tolist()
+            if kind == "int":
+                rows.append(int(ids[0]))
+            elif kind == "str":
+                rows.append(S3.join(map(str, ids)))
+            elif kind == "wstr":
+                rows.append(S3.join(f"{i}:{rng.integers(1, 9) / 4}" for i in ids))
+            elif kind == "list":
+                rows.append(ids)
+            else:  # map
+                rows.append({str(i): float(rng.integers(1, 9) / 4) for i in ids})
+    return rows
+
+
+@pytest.mark.parametrize("kind", ["int", "str", "wstr", "list", "map"])
+@pytest.mark.parametrize("default", [None, [0], [7, 9]])
+def test_sparse_parse_matches_oracle(kind, default):
+    if kind == "int" and default is not None and len(default) > 1:
+        default = default[:1]
+    rng = np.random.default_rng(hash((kind, str(default))) % 2**32)
+    rows = _random_rows(rng, 257, kind)
+    weighted = kind in ("wstr", "map")
+    ev, el, ew = orc.parse_sparse_feature(rows, default, S3, weighted)
+    arr = rows
+    if kind == "int":
+        arr = pa.array(rows, type=pa.int64())
+    elif kind == "list":
+        arr = pa.array(rows, type=pa.list_(pa.int64()))
+    c = parse_sparse_column("f", arr, S3, default, is_weighted=weighted)
+    np.testing.assert_array_equal(c.values, ev)
+    np.testing.assert_array_equal(c.lengths, el)
+    if weighted:
+        np.testing.assert_array_equal(c.weights, ew)
+    else:
+        assert c.weights is None
+
+
+def test_sequence_and_dense_columns():
+    c = parse_sequence_column("s", ["1" + S3 + "2;3", "", None, "4"], default_value=[0])
+    assert c.values.tolist() == [1, 2, 3, 0, 0, 4] and c.lengths.tolist() == [2, 1, 1, 1, 1] and c.seq_lengths.tolist() == [2, 1, 1, 1]
+    c = parse_sequence_column("s", pa.array([[[1, 2], [3]], [], None], type=pa.list_(pa.list_(pa.int64()))))
+    assert c.values.tolist() == [1, 2, 3] and c.lengths.tolist() == [2, 1] and c.seq_lengths.tolist() == [2, 0, 0]
+    d = parse_dense_column("d", ["0.5" + S3 + "1.5", "", "2" + S3 + "3"], default_value=[0.0, 0.0])
+    np.testing.assert_array_equal(d.values, np.asarray([[0.5, 1.5], [0, 0], [2, 3]], np.float32))
+    d = parse_dense_column("d", pa.array([1, None, 3]), default_value=[-1])
+    np.testing.assert_array_equal(d.values, np.asarray([[1], [-1], [3]], np.float32))
+    with pytest.raises(ValueError):
+        parse_dense_column("d", pa.array([1.0, None, 3.0]))
+    kt = DataParser([], ["a", "b"]).to_keyed_tensor({"a": parse_dense_column("a", [1.0, 2.0]),
+                                                    "b": parse_dense_column("b", ["1" + S3 + "2", "3" + S3 + "4"])})
+    assert kt.keys() == ["a", "b"] and kt.length_per_key() == [1, 2] and kt.values().tolist() == [[1, 1, 2], [2, 3, 4]]
