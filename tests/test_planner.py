@@ -1,0 +1,146 @@
+"""Sharding planner (torcheasyrec_amd/planner.py).
+
+1. The reference's own known-answer scenarios for its DynamicProgrammingProposer
+   (/root/reference/tzrec/utils/plan_util_test.py:297-447) -- same fake options / topologies, same
+   expected picks -- run against this package's proposer (duck-typed the same way).
+2. Property test: the vectorised reachable-cell DP equals the dense oracle on the reference's
+   seeds and problem sizes (plan_util_test.py:278-295, 424-438) and on larger random ones.
+3. The MI355X enumerator + partitioner + search on the DLRM-Criteo tables.
+"""
+import os
+import random
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle.planner_oracle import dense_dp_proposals  # noqa: E402
+from torcheasyrec_amd.planner import (GB, DynamicProgrammingProposer, PlannerError, TableSpec, Topology,  # noqa: E402
+                                      dp_proposals, plan_tables, plan_to_json)
+
+
+def _opt(fqn, hbm, ddr, perf):  # plan_util_test.py:158-167: one shard holding the whole option
+    st = SimpleNamespace(hbm=hbm, ddr=ddr)
+    return SimpleNamespace(fqn=fqn, shards=[SimpleNamespace(storage=st)], total_storage=st, total_perf=perf)
+
+
+def _topo(n, hbm, ddr, local=None):  # plan_util_test.py:170-181
+    return SimpleNamespace(devices=[SimpleNamespace(storage=SimpleNamespace(hbm=hbm, ddr=ddr)) for _ in range(n)],
+                           local_world_size=local or n)
+
+
+def _run(space, topo):  # plan_util_test.py:300-315
+    p = DynamicProgrammingProposer(hbm_bins_per_device=20, ddr_bins_per_device=20)
+    p.load(space)
+    p.propose()
+    p.feedback(partitionable=True, storage_constraint=topo)
+    out = []
+    prop = p.propose()
+    while prop:
+        out.append(prop)
+        p.feedback(partitionable=True, storage_constraint=topo)
+        prop = p.propose()
+    return out
+
+
+def test_reference_scenario_generous_ddr_prefers_fast_option():  # :317-333
+    opts = [_opt("table_a", 1000, 0, 50.0), _opt("table_a", 100, 900, 80.0), _opt("table_a", 100, 1000, 10.0)]
+    props = _run(opts, _topo(2, 2000, 2000))
+    assert min(props, key=lambda p: sum(o.total_perf for o in p))[0].total_perf == 10.0
+
+
+def test_reference_scenario_tight_ddr_rejects_it():  # :335-347
+    opts = [_opt("table_a", 100, 900, 80.0), _opt("table_a", 100, 1000, 10.0)]
+    props = _run(opts, _topo(1, 2000, 950))
+    assert props and all(p[0].total_perf == 80.0 for p in props)
+
+
+def test_reference_scenario_tied_options():  # :349-366
+    opts = [_opt("table_a", 1000, 0, 50.0), _opt("table_a", 1000, 1000, 50.0)]
+    props = _run(opts, _topo(1, 1100, 2000))
+    assert props and all(p[0].total_perf == 50.0 for p in props)
+
+
+def test_reference_scenario_joint_budget_forces_mixed_plan():  # :368-392
+    opts = [_opt("table_a", 1500, 0, 50.0), _opt("table_a", 100, 1500, 40.0),
+            _opt("table_b", 1500, 0, 50.0), _opt("table_b", 100, 1500, 40.0)]
+    props = _run(opts, _topo(1, 2000, 2000))
+    best = min(props, key=lambda p: sum(o.total_perf for o in p))
+    assert sorted("hbm" if o.shards[0].storage.ddr == 0 else "ddr" for o in best) == ["ddr", "hbm"]
+
+
+def test_reference_scenario_per_machine_ddr_prune():  # :394-415
+    topo = _topo(4, 2000, 500, local=2)
+    assert _run([_opt("t", 100, 1500, 10.0)], topo) == []
+    assert len(_run([_opt("t", 100, 900, 10.0)], topo)) > 0
+
+
+def test_reference_scenario_empty_search_space():  # :440-455
+    p = DynamicProgrammingProposer()
+    p.load([])
+    assert p.propose() == []
+    p.feedback(partitionable=True, storage_constraint=_topo(1, 1000, 1000))
+    assert p.propose() is None
+
+
+def _random_opts(seed, tables=5, options=4, hbm_bins=8, ddr_bins=8):  # plan_util_test.py:278-295
+    rng = random.Random(seed)
+    out = []
+    for _ in range(tables):
+        hbm = np.asarray([rng.uniform(0, hbm_bins / 2) for _ in range(options)], dtype=np.float32)
+        ddr = np.asarray([rng.uniform(0, ddr_bins / 2) for _ in range(options)], dtype=np.float32)
+        perf = np.asarray([rng.uniform(1, 100) for _ in range(options)], dtype=np.float32)
+        out.append((hbm, ddr, perf, np.arange(options, dtype=np.int32)))
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 7, 42, 1337])
+def test_dp_equals_dense_oracle_reference_seeds(seed):  # :424-438
+    opts = _random_opts(seed)
+    assert {tuple(p) for p in dp_proposals(opts, 8, 8)} == {tuple(p) for p in dense_dp_proposals(opts, 8, 8)}
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_dp_equals_dense_oracle_wider(seed):
+    rng = random.Random(1000 + seed)
+    tables, options = rng.randint(1, 9), rng.randint(1, 6)
+    hb, db = rng.choice([1, 5, 16, 40]), rng.choice([1, 3, 12])
+    opts = _random_opts(seed, tables, options, hb * 1.3, db * 1.3)
+    got, want = dp_proposals(opts, hb, db), dense_dp_proposals(opts, hb, db)
+    assert got == want  # same proposals in the same (decreasing HBM) order
+    for picks in got:  # every proposal respects the budgets
+        assert sum(float(opts[t][0][j]) for t, j in enumerate(picks)) < hb
+
+
+def _criteo():
+    from torcheasyrec_amd.criteo import CRITEO_ROWS
+
+    return [TableSpec(f"cat_{i}_emb", r, 16, [f"cat_{i}"]) for i, r in enumerate(CRITEO_ROWS)]
+
+
+def test_criteo_plan_on_one_mi355x_node():
+    plan = plan_tables(_criteo(), Topology(8), batch_size=8192)
+    kinds = {n: p["sharding_type"] for n, p in plan.items()}
+    big = [t.name for t in _criteo() if t.num_embeddings == 40_000_000]
+    tiny = [t.name for t in _criteo() if t.num_embeddings <= 1_000]
+    assert all(kinds[n] == "row_wise" for n in big)  # replication would all-reduce 2.5 GB per table per step
+    assert all(kinds[n] == "data_parallel" for n in tiny)  # no exchange for the tables that hold most lookups
+    assert all(p["block"] == 5_000_000 and p["ranks"] == list(range(8)) for n, p in plan.items() if n in big)
+    js = plan_to_json(plan)
+    assert '"compute_kernel": "fused"' in js and '"sharding_type": "row_wise"' in js
+
+
+def test_plan_respects_hbm_and_constraints():
+    tabs = [TableSpec("huge", 1_500_000_000, 16, ["a"]), TableSpec("small", 1000, 16, ["b"])]
+    # 1.5 G rows x (64 B weights + 64 B Adagrad) = 192 GB: fits one 288 GB device only before the
+    # reserve, so table_wise is out once the exchange buffers are counted; row_wise fits
+    plan = plan_tables(tabs, Topology(8), batch_size=8192)
+    assert plan["huge"]["sharding_type"] == "row_wise"
+    plan = plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["table_wise"]})
+    assert plan["small"]["sharding_type"] == "table_wise" and len(plan["small"]["ranks"]) == 1
+    with pytest.raises(PlannerError):
+        plan_tables(tabs, Topology(2, hbm_cap=40 * GB), batch_size=8192)
+    with pytest.raises(PlannerError):
+        plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["column_wise"]})

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(__file__))
 
 
-def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False):
+def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, planner=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     from oracle import tzrec_oracle as orc
@@ -42,10 +42,18 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False):
     tables = criteo_tables(rows, init="seeded")[:F]
     # rows > 100 -> row-wise shards, the small ones are replicated (data_parallel)
     # ... and one table is pinned table-wise (whole table on one rank) like a tzrec embedding_constraint
-    model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100, constraints={"cat_1_emb": "table_wise"},
-                        sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
+    if planner:  # placement chosen by the DP planner (every rank computes the same plan)
+        from torcheasyrec_amd.planner import TableSpec, Topology, plan_tables
+
+        plan = plan_tables([TableSpec(t.name, t.num_embeddings, 16, t.feature_names) for t in tables], Topology(world), 24,
+                           constraints={"cat_1_emb": ["table_wise"], "cat_5_emb": ["row_wise", "table_wise"]})
+        model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, plan=plan,
+                            sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
+    else:
+        model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100, constraints={"cat_1_emb": "table_wise"},
+                            sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
     kinds = {n: p["sharding_type"] for n, p in model.ebc.plan().items()}
-    assert set(kinds.values()) == {"row_wise", "table_wise", "data_parallel"}
+    assert "data_parallel" in kinds.values() and kinds["cat_1_emb"] == "table_wise"
     assert len(model.ebc.plan()["cat_1_emb"]["ranks"]) == 1
     Bg = 48
     Bl = Bg // world
@@ -140,12 +148,13 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,via_step", [("uniform1", False), ("jagged", False), ("uniform1", True), ("jagged", True)])
-def test_sharded_dlrm_world2(emu_path, mode, via_step):
+@pytest.mark.parametrize("mode,via_step,planner", [("uniform1", False, False), ("jagged", False, False),
+                                                   ("uniform1", True, False), ("jagged", True, True)])
+def test_sharded_dlrm_world2(emu_path, mode, via_step, planner):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
-        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step, planner), nprocs=world, join=True)
 
 
 def test_row_wise_plan_spreads_small_tables():

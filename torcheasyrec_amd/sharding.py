@@ -150,6 +150,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         replicate_at_world1: bool = False,
         constraints: Optional[Dict[str, str]] = None,
         tw_max_rows: int = 0,
+        plan: Optional[Dict[str, dict]] = None,
     ) -> None:
         super().__init__()
         self.pg = process_group
@@ -162,7 +163,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
             raise ValueError("sharded lookup needs one embedding_dim for all tables")
         self.dim = dims.pop()
         self._opt_cfg = optimizer
-        self._plan = make_plan(self._global, self.W, dp_max_rows, replicate_at_world1, constraints, tw_max_rows)
+        # `plan`: the output of planner.plan_tables (or a plan restored from a checkpoint); otherwise
+        # the size heuristic of make_plan
+        self._plan = plan if plan is not None else make_plan(self._global, self.W, dp_max_rows, replicate_at_world1,
+                                                             constraints, tw_max_rows)
+        missing = [t.name for t in self._global if t.name not in self._plan]
+        if missing:
+            raise ValueError(f"sharding plan has no entry for {missing}")
         # table_wise is the one-block case of the row-wise exchange (block = rows, owner = rot)
         self._rw = [t for t in self._global if self._plan[t.name]["sharding_type"] != "data_parallel"]
         self._dp = [t for t in self._global if self._plan[t.name]["sharding_type"] == "data_parallel"]
@@ -556,7 +563,8 @@ class ShardedDLRM(nn.Module):
     def __init__(self, tables, sparse_features, dense_dim, dense_mlp=(64, 16), final_mlp=(64, 32),
                  arch_with_sparse=True, device=None, sparse_optimizer=None, row_layout="interleaved",
                  process_group=None, dp_max_rows: int = 65536, replicate_at_world1: bool = False,
-                 constraints: Optional[Dict[str, str]] = None, tw_max_rows: int = 0) -> None:
+                 constraints: Optional[Dict[str, str]] = None, tw_max_rows: int = 0,
+                 plan: Optional[Dict[str, dict]] = None) -> None:
         super().__init__()
         self.pg = process_group
         self.dim = tables[0].embedding_dim
@@ -565,7 +573,7 @@ class ShardedDLRM(nn.Module):
         self.ebc = ShardedEmbeddingBagCollection(
             tables, device=device, optimizer=sparse_optimizer, groups={"sparse": list(sparse_features)},
             row_layout=row_layout, process_group=process_group, dp_max_rows=dp_max_rows,
-            replicate_at_world1=replicate_at_world1, constraints=constraints, tw_max_rows=tw_max_rows)
+            replicate_at_world1=replicate_at_world1, constraints=constraints, tw_max_rows=tw_max_rows, plan=plan)
         self.dense_mlp = MLP(dense_dim, dense_mlp).to(device)
         n = self.num_sparse + 1
         feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
