@@ -183,3 +183,75 @@ def test_row_wise_plan_spreads_small_tables():
     for rows, b, o in zip([40_000_000, 3, 4, 10, 2], blocks, rot):
         owned = sum(max(0, min(b, rows - ((r - o) % 8) * b)) for r in range(8))
         assert owned == rows
+
+
+def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
+    from torcheasyrec_amd.criteo import NUM_DENSE, criteo_tables, synthetic_batch
+    from torcheasyrec_amd.dlrm import DLRM, bce_with_logits
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+    from torcheasyrec_amd.sharding import ShardedDLRM
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    rows = [5000, 300, 3, 4, 17, 1000]
+    keys = [f"cat_{i}" for i in range(len(rows))]
+    sopt = SparseOptimizerConfig(kind="adagrad", lr=0.05)
+    torch.manual_seed(7)
+    a = ShardedDLRM(criteo_tables(rows, init="seeded")[:len(rows)], keys, NUM_DENSE, device=dev, dp_max_rows=100, sparse_optimizer=sopt)
+    dopt = torch.optim.Adam(list(a.dense_parameters()), lr=1e-2)
+    dense, kjt, label = synthetic_batch(3 + rank, 16, rows)
+    bce_with_logits(a(dense, kjt), label).backward()  # non-trivial weights AND optimizer state
+    a.allreduce_dense_grads()
+    dopt.step()
+    a.ebc.fused_optimizer.param_groups[0]["lr"] = 0.125
+    save_checkpoint(ckpt_dir, a, dopt)
+    assert read_plan(ckpt_dir)["ebc"]["cat_0_emb"] == {"sharding_type": "row_wise", "compute_kernel": "fused", "ranks": [0, 1]}
+
+    # restore under a DIFFERENT placement: cat_0 table-wise, everything else row-wise (no replicas)
+    torch.manual_seed(99)
+    b = ShardedDLRM(criteo_tables(rows)[:len(rows)], keys, NUM_DENSE, device=dev, dp_max_rows=0,
+                    constraints={"cat_0_emb": "table_wise"}, sparse_optimizer=sopt)
+    dopt_b = torch.optim.Adam(list(b.dense_parameters()), lr=1e-2)
+    restore_checkpoint(ckpt_dir, b, dopt_b)
+    assert b.ebc.fused_optimizer.param_groups[0]["lr"] == 0.125
+    for pa, pb in zip(a.dense_parameters(), b.dense_parameters()):
+        assert torch.equal(pa.data, pb.data)
+    assert dopt_b.state_dict()["state"][0]["exp_avg"].equal(dopt.state_dict()["state"][0]["exp_avg"])
+
+    def full(model, what):  # assemble global tables from all ranks' shards
+        out = {}
+        for cfg in model.ebc._global:
+            lo, n = model.ebc.shard_of(cfg.name)
+            src = (model.ebc.table_weights() if what == "w" else model.ebc.table_states())[cfg.name].detach()[:n].clone()
+            parts = [None] * world
+            dist.all_gather_object(parts, (lo, n, src))
+            t = torch.zeros(cfg.num_embeddings, 16)
+            for lo_, n_, s in parts:
+                t[lo_:lo_ + n_] = s
+            out[cfg.name] = t
+        return out
+
+    for what in ("w", "m"):
+        fa, fb = full(a, what), full(b, what)
+        for n in fa:
+            assert torch.equal(fa[n], fb[n]), (what, n)
+    # ... and into the unsharded module (every rank builds one; whole tables come from both files)
+    torch.manual_seed(5)
+    c = DLRM(criteo_tables(rows)[:len(rows)], keys, NUM_DENSE, device=dev, sparse_optimizer=sopt)
+    restore_checkpoint(ckpt_dir, c, strict=False)  # dense parameter names differ between the two model classes
+    fa_w, fa_m = full(a, "w"), full(a, "m")
+    for n in fa_w:
+        assert torch.equal(c.ebc.table_weights()[n].detach(), fa_w[n]), n
+        assert torch.equal(c.ebc.table_states()[n].detach(), fa_m[n]), n
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_checkpoint_reshards_across_plans(emu_path):
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_ckpt_worker, args=(world, os.path.join(d, "init"), emu_path, os.path.join(d, "ckpt")), nprocs=world, join=True)

@@ -1,0 +1,162 @@
+"""Checkpoint I/O for models whose tables live in this package's storage.
+
+What the reference writes (/root/reference/tzrec/utils/checkpoint_util.py:1109-1167): a directory
+with `model/` and `optimizer/` (torch.distributed.checkpoint of the sharded state dicts, so a run
+can resume under a different plan) and a `plan` JSON `{module_path: {param: {sharding_type,
+compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
+
+  <dir>/model/rank<r>.pt       {"dense": {param: tensor},
+                                "tables": {table: {"lo", "n", "weight"[n, D]}}}      rows [lo, lo+n)
+  <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "dense": optimizer.state_dict()}
+  <dir>/plan                   the reference's plan JSON (rank 0)
+  <dir>/meta.json              world size, {table: [rows, dim]}, format version (rank 0)
+
+Row shards are saved by their owner; replicated (data_parallel) tables and dense parameters by rank
+0 only.  `restore_checkpoint` reads whichever row ranges the CURRENT placement needs from whichever
+files hold them, so world size and sharding types may change between save and restore (the
+re-sharding torch DCP gives the reference).  Tensors are loaded with mmap, a shard is never
+materialised twice on the host.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+FORMAT_VERSION = 1
+
+
+def _rank_world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _ebc_of(model: nn.Module):
+    ebc = getattr(model, "ebc", None)
+    if ebc is None:
+        raise ValueError("model has no `.ebc` (EmbeddingBagCollection or ShardedEmbeddingBagCollection)")
+    return ebc
+
+
+def _placement(ebc) -> Dict[str, Tuple[int, int, int, str]]:
+    """{table: (first row held here, rows held here, total rows, sharding type)}"""
+    out = {}
+    if hasattr(ebc, "shard_of"):  # sharded module
+        rows = {c.name: c.num_embeddings for c in ebc._global}
+        for name, p in ebc.plan().items():
+            lo, n = ebc.shard_of(name)
+            out[name] = (lo, n, rows[name], p["sharding_type"])
+    else:
+        for c in ebc.embedding_bag_configs():
+            out[c.name] = (0, c.num_embeddings, c.num_embeddings, "table_wise")
+    return out
+
+
+def _dense_state(model: nn.Module) -> Dict[str, torch.Tensor]:
+    tables = {id(w) for w in _ebc_of(model).table_weights().values()}
+    return {n: p.detach().cpu() for n, p in model.named_parameters() if id(p) not in tables and ".embedding_bags." not in n}
+
+
+def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None,
+                    module_path: str = "ebc") -> None:
+    rank, world = _rank_world()
+    ebc = _ebc_of(model)
+    place = _placement(ebc)
+    for sub in ("model", "optimizer"):
+        os.makedirs(os.path.join(checkpoint_dir, sub), exist_ok=True)
+    weights, states = ebc.table_weights(), ebc.table_states()
+    m_tables, o_tables = {}, {}
+    for name, (lo, n, _, kind) in place.items():
+        if n == 0 or (kind == "data_parallel" and rank != 0):
+            continue
+        m_tables[name] = {"lo": lo, "n": n, "weight": weights[name].detach()[:n].cpu().contiguous()}
+        if name in states:
+            o_tables[name] = {"lo": lo, "n": n, "momentum1": states[name].detach()[:n].cpu().contiguous()}
+    torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables},
+               os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
+    fo = getattr(ebc, "fused_optimizer", None)
+    torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"],
+                "dense": dense_optimizer.state_dict() if (dense_optimizer is not None and rank == 0) else None},
+               os.path.join(checkpoint_dir, "optimizer", f"rank{rank}.pt"))
+    if rank == 0:
+        plan = ebc.plan() if hasattr(ebc, "plan") else {n: {"sharding_type": "table_wise", "ranks": [0]} for n in place}
+        js = {module_path: {f"{n}": {"sharding_type": p["sharding_type"], "compute_kernel": p.get("compute_kernel", "fused"),
+                                     "ranks": list(p["ranks"])} for n, p in plan.items()}}
+        with open(os.path.join(checkpoint_dir, "plan"), "w") as f:
+            json.dump(js, f)
+        dims = {c.name: [c.num_embeddings, c.embedding_dim]
+                for c in (ebc._global if hasattr(ebc, "_global") else ebc.embedding_bag_configs())}
+        with open(os.path.join(checkpoint_dir, "meta.json"), "w") as f:
+            json.dump({"format": FORMAT_VERSION, "world_size": world, "tables": dims}, f)
+    if world > 1:
+        dist.barrier()
+
+
+def _fill(dst: torch.Tensor, lo: int, n: int, pieces, field: str, name: str) -> int:
+    """Copy the parts of [lo, lo+n) that `pieces` (list of saved shards) hold into dst[:n]."""
+    done = 0
+    for p in pieces:
+        s, e = max(lo, p["lo"]), min(lo + n, p["lo"] + p["n"])
+        if s < e:
+            dst[s - lo:e - lo].copy_(p[field][s - p["lo"]:e - p["lo"]])
+            done += e - s
+    return done
+
+
+def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None,
+                       strict: bool = True) -> None:
+    rank, world = _rank_world()
+    meta = json.load(open(os.path.join(checkpoint_dir, "meta.json")))
+    if meta.get("format") != FORMAT_VERSION:
+        raise ValueError(f"checkpoint format {meta.get('format')} != {FORMAT_VERSION}")
+    saved_world = int(meta["world_size"])
+    ebc = _ebc_of(model)
+    place = _placement(ebc)
+    for name, (_, _, total, _) in place.items():
+        if name not in meta["tables"]:
+            if strict:
+                raise KeyError(f"checkpoint has no table {name}")
+            continue
+        if meta["tables"][name][0] != total:
+            raise ValueError(f"{name}: checkpoint has {meta['tables'][name][0]} rows, model {total}")
+    m_files = [torch.load(os.path.join(checkpoint_dir, "model", f"rank{r}.pt"), mmap=True, weights_only=True)
+               for r in range(saved_world)]
+    o_files = [torch.load(os.path.join(checkpoint_dir, "optimizer", f"rank{r}.pt"), mmap=True, weights_only=False)
+               for r in range(saved_world)]
+    weights, states = ebc.table_weights(), ebc.table_states()
+    with torch.no_grad():
+        for name, (lo, n, _, _) in place.items():
+            if n == 0 or name not in meta["tables"]:
+                continue
+            got = _fill(weights[name].detach(), lo, n, [f["tables"][name] for f in m_files if name in f["tables"]], "weight", name)
+            if got != n:
+                raise ValueError(f"{name}: rows [{lo}, {lo + n}) only partly present in the checkpoint ({got} of {n})")
+            if name in states:
+                pcs = [f["tables"][name] for f in o_files if name in f["tables"]]
+                if pcs:
+                    _fill(states[name].detach(), lo, n, pcs, "momentum1", name)
+                elif strict:
+                    raise KeyError(f"checkpoint has no optimizer state for {name}")
+        dense = m_files[0]["dense"]
+        mine = dict(model.named_parameters())
+        for n_, t in dense.items():
+            if n_ in mine:
+                mine[n_].data.copy_(t)
+            elif strict:
+                raise KeyError(f"checkpoint parameter {n_} not in the model")
+    fo = getattr(ebc, "fused_optimizer", None)
+    if fo is not None and o_files[0].get("sparse_lr") is not None:
+        fo.param_groups[0]["lr"] = o_files[0]["sparse_lr"]
+    if dense_optimizer is not None and o_files[0].get("dense") is not None:
+        dense_optimizer.load_state_dict(o_files[0]["dense"])
+    if world > 1:
+        dist.barrier()
+
+
+def read_plan(checkpoint_dir: str) -> Dict[str, dict]:
+    return json.load(open(os.path.join(checkpoint_dir, "plan")))
