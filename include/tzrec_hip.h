@@ -244,6 +244,38 @@ int tzr_lookup_grads(const TzrFeature* d_feats, int n_feats, const int64_t* d_of
                      const int64_t* d_positions, const TzrDst* h_grads, int n_dst, float* d_out,
                      int64_t out_stride, int dim, void* stream);
 
+/* ---- zero-collision hash ---------------------------------------- */
+
+#define TZR_ZCH_EMPTY INT64_MAX /* unoccupied cell / row (tzrec/utils/zch_util.py:29 ZCH_EMPTY_SLOT) */
+
+/* One managed-collision table: an open-addressing map raw id -> row plus per-row eviction metadata. */
+typedef struct TzrZchModule {
+  int64_t* keys;      /* [capacity] raw id per cell, TZR_ZCH_EMPTY when free                    */
+  int32_t* rows;      /* [capacity] remapped row of the cell's id                               */
+  int64_t* counts;    /* [zch_size] accesses per row           (written when profile != 0)      */
+  int64_t* last_iter; /* [zch_size] iteration of the last access                                */
+  int64_t capacity;   /* power of two, >= 2 * occupied rows                                     */
+  int64_t zch_size;   /* rows of the embedding table; ids not in the map go to row zch_size-1   */
+  int64_t reserved[2];
+} TzrZchModule; /* 64 bytes */
+
+/* K13: remap the ids of every KJT key through its module (d_key_module[key] = module index, -1 =
+ * pass through).  Replaces torchrec MCHManagedCollisionModule.remap + .profile [upstream], built by
+ * BaseFeature.mc_module (tzrec/features/feature.py:693-736) and applied in front of the lookup by
+ * ManagedCollisionEmbeddingBagCollection (tzrec/modules/embedding.py:856-864).  profile != 0 also
+ * bumps counts/last_iter of the rows hit and fills d_candidates (int64[n_values], positional):
+ * the raw id where it has no row yet (an admission candidate), TZR_ZCH_EMPTY elsewhere.
+ * d_out_values may alias d_values. */
+int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key_module, int n_keys,
+                  const int64_t* d_values, const int64_t* d_offsets, int64_t B, int uniform_bag_len,
+                  int64_t n_values, int64_t iter, int profile, int64_t* d_out_values,
+                  int64_t* d_candidates, void* stream);
+
+/* Rebuild a module's map from n distinct (raw id, row) pairs (after admission / eviction, or when
+ * restoring a checkpoint).  h_module is a HOST struct holding device pointers. */
+int tzr_zch_build(const TzrZchModule* h_module, const int64_t* d_ids, const int32_t* d_rows,
+                  int64_t n, void* stream);
+
 /* ---- sequence path --------------------------------------------- */
 
 /* K12: jagged [N, dim] (+ offsets int64[B+1]) -> dense [B, max_len, dim]; positions past a

@@ -1,0 +1,106 @@
+"""K13 zero-collision-hash remap vs oracle/zch_oracle.py: remapped ids every step (bit-exact), and
+the whole module state (raw id / count / last access per row) after admissions and evictions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle.zch_oracle import EMPTY, ZchTable  # noqa: E402
+from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
+from torcheasyrec_amd.zch import ManagedCollisionEmbeddingBagCollection, ZchConfig, dynamic_threshold_filter  # noqa: E402
+
+
+def _batch(rng, step, B, universe, jagged):
+    """Two ZCH keys sharing one table, one ZCH key on its own table, one plain key."""
+    F = 4
+    if jagged:
+        lens = rng.integers(0, 4, size=F * B).astype(np.int32)
+    else:
+        lens = np.ones(F * B, np.int32)
+    n = int(lens.sum())
+    # drifting popularity: later steps favour later ids, so residents go stale and get evicted
+    pick = np.minimum((rng.zipf(1.3, size=n) + step * 7) % len(universe), len(universe) - 1)
+    vals = universe[pick].astype(np.int64)
+    per_key = np.add.reduceat(lens, np.arange(0, F * B, B)) if B else np.zeros(F, int)
+    s3 = int(per_key[:3].sum())
+    vals[s3:] = rng.integers(0, 50, size=n - s3)  # the plain key indexes its 50-row table directly
+    return KeyedJaggedTensor(["u1", "u2", "item", "plain"], torch.from_numpy(vals), torch.from_numpy(lens),
+                             uniform_length=None if jagged else 1), per_key
+
+
+@pytest.mark.parametrize("policy,decay", [("lfu", 1.0), ("lru", 1.0), ("distance_lfu", 1.0), ("distance_lfu", 2.0)])
+@pytest.mark.parametrize("jagged", [False, True])
+def test_zch_matches_oracle(dev, policy, decay, jagged):
+    rng = np.random.default_rng(17)
+    universe = rng.integers(0, 1 << 50, size=400).astype(np.int64)
+    universe[5] = (1 << 63) - 2  # largest representable raw id
+    B = 96
+    Zu, Zi = 64, 33
+    filt = (lambda c: dynamic_threshold_filter(c, 0.5)) if policy == "lfu" else None
+    tables = [EmbeddingBagConfig("user_emb", 8, Zu, ["u1", "u2"]), EmbeddingBagConfig("item_emb", 8, Zi, ["item"]),
+              EmbeddingBagConfig("plain_emb", 8, 50, ["plain"])]
+    ebc = EmbeddingBagCollection(tables, device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=0.1))
+    mc = ManagedCollisionEmbeddingBagCollection(
+        ebc, {"user_emb": ZchConfig(Zu, 2, policy, decay, filt), "item_emb": ZchConfig(Zi, 3, policy, decay, filt)})
+    orc = {"user_emb": ZchTable(Zu, 2, policy, decay, filt), "item_emb": ZchTable(Zi, 3, policy, decay, filt)}
+    mc.train()
+    for step in range(1, 13):
+        kjt, per_key = _batch(rng, step, B, universe, jagged)
+        out, remapped = mc(kjt.to(dev))
+        v = kjt.values().numpy()
+        o = np.cumsum(np.concatenate([[0], per_key]))
+        want = np.concatenate([
+            orc["user_emb"].remap(v[o[0]:o[2]], step, True), orc["item_emb"].remap(v[o[2]:o[3]], step, True), v[o[3]:o[4]]
+        ]).astype(np.int64)
+        np.testing.assert_array_equal(remapped.values().cpu().numpy(), want, err_msg=f"step {step}")
+        assert out.values().shape == (B, 32)
+        for name, t in orc.items():
+            if step % t.interval == 0:
+                changed = t.update_and_evict(step)
+                assert mc.last_evicted[name].cpu().tolist() == changed, (name, step)
+    for name, t in orc.items():
+        m = mc.modules_by_table[name]
+        np.testing.assert_array_equal(m.row_ids.cpu().numpy(), np.asarray(t.row_ids, dtype=np.int64), err_msg=name)
+        occ = np.asarray(t.row_ids) != EMPTY
+        np.testing.assert_array_equal(m.counts.cpu().numpy()[occ], np.asarray(t.counts)[occ])
+        np.testing.assert_array_equal(m.last_iter.cpu().numpy()[occ], np.asarray(t.last_iter)[occ])
+        assert occ.sum() > 0 and not occ[-1]  # the shared last row never gets an owner
+        ids, rows = m.sorted_raw_ids()
+        k = int(occ.sum())
+        assert torch.equal(ids[:k].cpu(), torch.sort(torch.tensor(t.row_ids)[torch.from_numpy(occ)]).values)
+        assert bool((ids[k:] == EMPTY).all())
+    # eval: no profiling, no admission; unseen ids land on the shared row
+    mc.eval()
+    with torch.no_grad():
+        kjt = KeyedJaggedTensor(["u1", "u2", "item", "plain"], torch.tensor([123456789, int(universe[0]), 42, 7]),
+                                torch.ones(4, dtype=torch.int32), uniform_length=1)
+        _, rm = mc(kjt.to(dev))
+    r = rm.values().cpu().tolist()
+    assert r[0] == orc["user_emb"].row_of.get(123456789, Zu - 1) and r[3] == 7
+    assert r[1] == orc["user_emb"].row_of.get(int(universe[0]), Zu - 1)
+
+
+def test_zch_training_updates_the_remapped_rows(dev):
+    """End to end: once an id owns a row, its gradient lands on that row and nowhere else."""
+    Z = 16
+    ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, Z, ["k"])], device=dev,
+                                 optimizer=SparseOptimizerConfig(kind="sgd", lr=1.0))
+    mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(Z, 1)}, reset_evicted_rows=False)
+    mc.train()
+    ids = torch.tensor([10**12, 5, 10**12, 77], dtype=torch.int64)
+    kjt = KeyedJaggedTensor(["k"], ids, torch.ones(4, dtype=torch.int32), uniform_length=1).to(dev)
+    out, rm = mc(kjt)  # step 1: nothing resident yet -> all on the shared row, then admitted
+    assert rm.values().cpu().tolist() == [Z - 1] * 4
+    out.values().sum().backward()
+    w0 = ebc.table_weights()["t"].detach().clone()
+    out, rm = mc(kjt)  # step 2: rows 0,1,2 in (count desc, id asc) order: 10**12 (2 hits), 5, 77
+    assert rm.values().cpu().tolist() == [0, 1, 0, 2]
+    out.values().sum().backward()
+    w1 = ebc.table_weights()["t"].detach()
+    delta = (w0 - w1).cpu()
+    assert torch.allclose(delta[0], torch.full((4,), 2.0)) and torch.allclose(delta[1], torch.ones(4))
+    assert torch.allclose(delta[2], torch.ones(4)) and bool((delta[3:] == 0).all())

@@ -57,6 +57,14 @@ class TzrSparseOptim(C.Structure):
     ]
 
 
+class TzrZchModule(C.Structure):
+    _fields_ = [("keys", C.c_uint64), ("rows", C.c_uint64), ("counts", C.c_uint64), ("last_iter", C.c_uint64),
+                ("capacity", C.c_int64), ("zch_size", C.c_int64), ("reserved", C.c_int64 * 2)]
+
+
+ZCH_EMPTY = (1 << 63) - 1
+
+
 class TzrError(RuntimeError):
     pass
 
@@ -97,6 +105,8 @@ _SIGNATURES = {
                                        _i32, _vp, _i64, _vp, _i64, _vp]),
     "tzr_jagged_to_padded_dense": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, C.c_float, _vp, _vp]),
     "tzr_padded_dense_to_jagged": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
+    "tzr_zch_remap": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tzr_zch_build": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "tzr_fm_fwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     "tzr_fm_bwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
 }

@@ -1,0 +1,257 @@
+"""Zero-collision hash (managed collision) in front of the embedding lookup.
+
+Reference wiring: `BaseFeature.mc_module` builds one torchrec `MCHManagedCollisionModule` per
+`zch {...}` feature config (/root/reference/tzrec/features/feature.py:693-736; proto
+/root/reference/tzrec/protos/feature.proto:31-47; policies and admission filters documented in
+/root/reference/docs/source/feature/zch.md) and `ManagedCollisionEmbeddingBagCollection(ebc, mcc)`
+remaps every KJT before the lookup (/root/reference/tzrec/modules/embedding.py:856-864).  torchrec is
+not part of this stack; the semantics below restate its published behaviour and are fixed by
+`oracle/zch_oracle.py` (parity with torchrec itself is UNPINNED: no golden vectors exist in the
+reference for it):
+
+  * a table of `zch_size` rows; row `zch_size-1` is the shared row of ids that have no row (yet);
+  * every training step looks ids up (K13 `tzr_zch_remap`: open-addressing map in HBM), bumps
+    `count` / `last_iter` of the rows hit and records absent ids as admission candidates;
+  * every `eviction_interval` steps: candidates are coalesced (unique + counts), filtered by the
+    admission function, and compete with the resident ids by score
+        lfu           count
+        lru           1 / max(iter - last_iter, 1) ** decay_exponent
+        distance_lfu  count / max(iter - last_iter, 1) ** decay_exponent
+    for the `zch_size-1` real rows.  Order: score descending, residents before candidates, raw id
+    ascending.  Admitted candidates take the free / evicted rows in ascending row order; the rows
+    that changed owner are reported so the caller can re-initialise them.
+
+The periodic admission / eviction is a handful of torch sorts on the device (plumbing, off the hot
+path); the per-step remap is the HIP kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .embedding import EmbeddingBagCollection
+from .sparse import KeyedJaggedTensor, KeyedTensor
+
+EMPTY = _lib.ZCH_EMPTY
+
+
+@torch.no_grad()
+def dynamic_threshold_filter(id_counts: torch.Tensor, threshold_skew_multiplier: float = 10.0):
+    """Admit ids seen more than `multiplier` times the mean count (docs/source/feature/zch.md)."""
+    threshold = id_counts.sum() * (threshold_skew_multiplier / max(id_counts.numel(), 1))
+    return id_counts > threshold, threshold
+
+
+@torch.no_grad()
+def average_threshold_filter(id_counts: torch.Tensor):
+    threshold = id_counts.float().mean()
+    return id_counts.float() > threshold, threshold
+
+
+@torch.no_grad()
+def probabilistic_threshold_filter(id_counts: torch.Tensor, per_id_probability: float = 0.01):
+    score = 1 - torch.pow(torch.full_like(id_counts, 1 - per_id_probability, dtype=torch.float), id_counts)
+    threshold = torch.rand(id_counts.size(), device=id_counts.device)
+    return score > threshold, threshold
+
+
+@dataclass
+class ZchConfig:
+    zch_size: int
+    eviction_interval: int = 5
+    policy: str = "lfu"  # lfu | lru | distance_lfu
+    decay_exponent: float = 1.0
+    threshold_filtering_func: Optional[Callable] = None
+
+
+class ManagedCollisionModule:
+    """State of one ZCH table, all in HBM: the id->row map (cells), and per row its raw id, access
+    count and last access iteration."""
+
+    def __init__(self, cfg: ZchConfig, device: torch.device) -> None:
+        if cfg.zch_size < 2:
+            raise ValueError("zch_size must be >= 2 (the last row is the shared row of unseen ids)")
+        if cfg.policy not in ("lfu", "lru", "distance_lfu"):
+            raise ValueError(f"unknown eviction policy {cfg.policy!r}")
+        self.cfg, self.device = cfg, torch.device(device)
+        Z = cfg.zch_size
+        cap = 1
+        while cap < 2 * Z:
+            cap *= 2
+        self.capacity = cap
+        self.keys = torch.full((cap,), EMPTY, dtype=torch.int64, device=device)
+        self.rows = torch.zeros(cap, dtype=torch.int32, device=device)
+        self.counts = torch.zeros(Z, dtype=torch.int64, device=device)
+        self.last_iter = torch.zeros(Z, dtype=torch.int64, device=device)
+        self.row_ids = torch.full((Z,), EMPTY, dtype=torch.int64, device=device)  # raw id held by every row
+
+    def struct(self) -> "_lib.TzrZchModule":
+        m = _lib.TzrZchModule()
+        m.keys, m.rows, m.counts, m.last_iter = (_lib.ptr(self.keys), _lib.ptr(self.rows), _lib.ptr(self.counts),
+                                                 _lib.ptr(self.last_iter))
+        m.capacity, m.zch_size = self.capacity, self.cfg.zch_size
+        return m
+
+    def sorted_raw_ids(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(sorted raw ids padded with EMPTY, their rows): the view torchrec keeps as
+        `_mch_sorted_raw_ids` / `_mch_remapped_ids_mapping` (zch_util.py:29)."""
+        ids, order = torch.sort(self.row_ids, stable=True)
+        return ids, order
+
+    def rebuild(self) -> None:
+        occ = torch.nonzero(self.row_ids != EMPTY).squeeze(1)
+        ids = self.row_ids[occ].contiguous()
+        rows = occ.to(torch.int32).contiguous()
+        s = self.struct()
+        _lib.check(_lib.lib().tzr_zch_build(_lib.C.byref(s), _lib.ptr(ids), _lib.ptr(rows), ids.numel(),
+                                            _lib.stream_ptr(self.device)), "tzr_zch_build")
+
+    @torch.no_grad()
+    def update_and_evict(self, cand_ids: torch.Tensor, cur_iter: int) -> torch.Tensor:
+        """Admit candidates / evict residents.  Returns the rows whose owner changed."""
+        cfg, Z = self.cfg, self.cfg.zch_size
+        dev = self.device
+        new_ids, new_cnt = torch.unique(cand_ids, return_counts=True)
+        if cfg.threshold_filtering_func is not None and new_ids.numel():
+            keep, _ = cfg.threshold_filtering_func(new_cnt)
+            new_ids, new_cnt = new_ids[keep], new_cnt[keep]
+        if new_ids.numel() == 0:
+            return torch.zeros(0, dtype=torch.int64, device=dev)
+        res_rows = torch.nonzero(self.row_ids[:Z - 1] != EMPTY).squeeze(1)
+        res_ids = self.row_ids[res_rows]
+
+        def score(cnt, last):
+            dist = (cur_iter - last).clamp(min=1).double()
+            if cfg.policy == "lfu":
+                return cnt.double()
+            age = dist if cfg.decay_exponent == 1.0 else torch.pow(dist, cfg.decay_exponent)
+            return (1.0 / age) if cfg.policy == "lru" else cnt.double() / age
+
+        s_res = score(self.counts[res_rows], self.last_iter[res_rows])
+        s_new = score(new_cnt, torch.full_like(new_cnt, cur_iter))
+        ids = torch.cat([res_ids, new_ids])
+        sc = torch.cat([s_res, s_new])
+        is_new = torch.cat([torch.zeros_like(res_ids), torch.ones_like(new_ids)])
+        # order: score desc, residents first, raw id asc  (three stable sorts, least significant first)
+        o = torch.sort(ids, stable=True).indices
+        o = o[torch.sort(is_new[o], stable=True).indices]
+        o = o[torch.sort(sc[o], descending=True, stable=True).indices]
+        kept = o[:Z - 1]
+        kept_res = kept[kept < res_ids.numel()]
+        kept_new = kept[kept >= res_ids.numel()] - res_ids.numel()  # in admission order
+        held = torch.zeros(Z - 1, dtype=torch.bool, device=dev)
+        held[res_rows[kept_res]] = True
+        free = torch.nonzero(~held).squeeze(1)[:kept_new.numel()]  # ascending rows
+        self.row_ids[free] = new_ids[kept_new]
+        self.counts[free] = new_cnt[kept_new]
+        self.last_iter[free] = cur_iter
+        self.rebuild()
+        return free
+
+
+class ManagedCollisionEmbeddingBagCollection(nn.Module):
+    """`forward(kjt) -> (KeyedTensor, remapped kjt)` like torchrec's module of the same name: the keys
+    of tables listed in `zch` are remapped, then the wrapped collection does the lookup (its tables
+    must have `num_embeddings == zch_size`)."""
+
+    def __init__(self, ebc: EmbeddingBagCollection, zch: Dict[str, ZchConfig], reset_evicted_rows: bool = False) -> None:
+        super().__init__()
+        self.ebc = ebc
+        self._device = ebc.device
+        cfgs = {c.name: c for c in ebc.embedding_bag_configs()}
+        self.modules_by_table: Dict[str, ManagedCollisionModule] = {}
+        for name, z in zch.items():
+            if name not in cfgs:
+                raise KeyError(f"zch config for unknown table {name}")
+            if cfgs[name].num_embeddings != z.zch_size:
+                raise ValueError(f"{name}: num_embeddings {cfgs[name].num_embeddings} != zch_size {z.zch_size}")
+            self.modules_by_table[name] = ManagedCollisionModule(z, self._device)
+        self._order = list(self.modules_by_table)
+        self._key_module: Dict[str, int] = {}
+        for name in self._order:
+            for f in cfgs[name].feature_names:
+                self._key_module[f] = self._order.index(name)
+        self._d_mods: Optional[torch.Tensor] = None
+        self._km_cache: Dict[Tuple[str, ...], torch.Tensor] = {}
+        self._iter = 0
+        self._cand: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []  # (candidates, module per key, ids per key)
+        self._reset = reset_evicted_rows
+        self.last_evicted: Dict[str, torch.Tensor] = {}
+
+    @property
+    def fused_optimizer(self):
+        return self.ebc.fused_optimizer
+
+    def _modules_device(self) -> torch.Tensor:
+        if self._d_mods is None:
+            raw = b"".join(bytes(self.modules_by_table[n].struct()) for n in self._order)
+            self._d_mods = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self._device)
+        return self._d_mods
+
+    def remap(self, kjt: KeyedJaggedTensor, profile: bool) -> KeyedJaggedTensor:
+        keys = tuple(kjt.keys())
+        km = self._km_cache.get(keys)
+        if km is None:
+            km = torch.tensor([self._key_module.get(k, -1) for k in keys], dtype=torch.int32, device=self._device)
+            self._km_cache[keys] = km
+        values = kjt.values()
+        n = values.numel()
+        uniform = kjt.uniform_length() or 0
+        out = torch.empty_like(values)
+        cand = torch.empty_like(values) if profile else None
+        _lib.check(_lib.lib().tzr_zch_remap(
+            _lib.ptr(self._modules_device()), _lib.ptr(km), len(keys), _lib.ptr(values),
+            _lib.ptr(None if uniform else kjt.offsets()), kjt.stride(), uniform, n, self._iter, 1 if profile else 0,
+            _lib.ptr(out), _lib.ptr(cand), _lib.stream_ptr(self._device)), "tzr_zch_remap")
+        if profile:  # positional candidates of this step + where each key's segment ends
+            B = kjt.stride()
+            seg = (torch.full((len(keys),), B * uniform, dtype=torch.int64, device=self._device) if uniform
+                   else kjt.offsets()[::B].diff())
+            self._cand.append((cand, km, seg))
+        return KeyedJaggedTensor(kjt.keys(), out, kjt.lengths(), kjt.weights_or_none(), kjt._offsets, kjt.stride(),
+                                 uniform_length=kjt.uniform_length())
+
+    @torch.no_grad()
+    def _evict(self) -> None:
+        ids = torch.cat([c for c, _, _ in self._cand])
+        mods = torch.cat([torch.repeat_interleave(km, seg) for _, km, seg in self._cand])
+        live = ids != EMPTY
+        ids, mods = ids[live], mods[live]
+        due = [self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order]
+        for j, name in enumerate(self._order):
+            if not due[j]:
+                continue
+            mod = self.modules_by_table[name]
+            changed = mod.update_and_evict(ids[mods == j], self._iter)
+            self.last_evicted[name] = changed
+            if self._reset and changed.numel():
+                w = self.ebc.table_weights()[name]
+                a = (1.0 / mod.cfg.zch_size) ** 0.5
+                w.data[changed] = torch.empty(changed.numel(), w.shape[1], device=w.device).uniform_(-a, a)
+                st = self.ebc.table_states().get(name)
+                if st is not None:
+                    st[changed] = 0
+        if all(due):
+            self._cand = []
+        else:  # keep only the candidates of the modules that did not run
+            keep = torch.ones_like(mods, dtype=torch.bool)
+            for j, d in enumerate(due):
+                if d:
+                    keep &= mods != j
+            ids, mods = ids[keep], mods[keep]
+            uniq_mods = torch.arange(len(self._order), dtype=torch.int32, device=self._device)
+            self._cand = [(ids, uniq_mods[mods.long()], torch.ones_like(ids))] if ids.numel() else []
+
+    def forward(self, kjt: KeyedJaggedTensor) -> Tuple[KeyedTensor, KeyedJaggedTensor]:
+        training = self.training and torch.is_grad_enabled()
+        if training:
+            self._iter += 1
+        remapped = self.remap(kjt, profile=training)
+        out = self.ebc(remapped)
+        if training and any(self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order):
+            self._evict()
+        return out, remapped
