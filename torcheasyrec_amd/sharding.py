@@ -380,8 +380,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return hit
 
     # -- exchange ------------------------------------------------------------------------------
-    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits) -> None:
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg)
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, async_op: bool = False):
+        """async_op=True: the collective runs on RCCL's stream while the caller keeps queueing local
+        kernels; `.wait()` makes the current stream wait for it (no host block on a GPU)."""
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg, async_op=async_op)
 
     def _optim_struct(self, kind: Optional[int] = None):
         cfg = self._opt_cfg
@@ -453,6 +455,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if o.shape != (B, rm["widths"][i]) or o.stride(1) != 1:
                 raise ValueError("output buffer shape")
             dsts[i].ptr, dsts[i].stride = _lib.ptr(o), o.stride(0)
+        work = None
         if "rw_n" in rm:
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
             F, N = rm["rw_n"], sub.values().numel()
@@ -461,19 +464,21 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
                                          om["K"], _lib.ptr(st["recv_ids"]), n_recv, _lib.ptr(rows_out), D, D, stream),
                        "tzr_rows_gather")
-            # rows back to the requesters (bucketized order)
+            # rows back to the requesters (bucketized order) -- in flight while the replicas are read
             rows_in, d_pt = self._recv_rows_buffer(N, F)
-            self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"])
+            work = self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
+        if "dp_n" in rm:  # replicated tables: purely local, same destination buffers (other columns)
+            _lib.check(L.tzr_pooled_fwd(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
+                                        _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
+                                        _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
+                                        B, dsts, len(outs), 1 if uniform else 0, stream), "tzr_pooled_fwd")
+        if work is not None:
+            work.wait()
             # requester: pooled gather over the received rows, ids = position in bucketized order
             _lib.check(L.tzr_pooled_fwd(_lib.ptr(d_pt), _lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(rm["rw_d_slots"]),
                                         rm["rw_slots_n"], _lib.ptr(st["unb"]), _lib.ptr(None if uniform else sub.offsets()),
                                         _lib.ptr(sub.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
                                         stream), "tzr_pooled_fwd")
-        if "dp_n" in rm:  # replicated tables: purely local, same destination buffers
-            _lib.check(L.tzr_pooled_fwd(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
-                                        _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
-                                        _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
-                                        B, dsts, len(outs), 1 if uniform else 0, stream), "tzr_pooled_fwd")
         return outs
 
     def _forward_impl(self, kjt: KeyedJaggedTensor, dst_names):
@@ -501,49 +506,55 @@ class ShardedEmbeddingBagCollection(nn.Module):
         for i, g in enumerate(gl):
             gd[i].ptr, gd[i].stride = _lib.ptr(g), g.stride(0)
 
+        # Order of issue = overlap: the gradient all-to-all flies while the replicas' gradients are
+        # sorted and summed; their all-reduce flies while the owners sort and apply the exchanged rows.
+        w_rows = w_acc = None
         if "rw_n" in rm:
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
             N, F = sub.values().numel(), rm["rw_n"]
-            # 1. requester: one gradient row per id, in bucketized order
+            # requester: one gradient row per id, in bucketized order -> to the owners
             grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
             _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
                                           _lib.ptr(sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
                                           gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
-            # 2. to the owners
             grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
-            self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"])
-            # 3. owner: sort by (table,row) + fused optimizer, gradients addressed per id
+            w_rows = self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"], async_op=True)
+        if "dp_n" in rm:
+            # replicas: exact per-row gradient sums of my samples -> all-reduce -> same dense update
+            N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
+            offsets = None if uniform else kjt.offsets()
+            self._dp_acc.zero_()
+            NP = n_dp * B if uniform else N_all
+            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D), dev)
+            _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_feats"]), n_dp,
+                                             rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
+                                             _lib.ptr(offsets), N_all, NP, B, 1 if uniform else 0, _lib.ptr(ws),
+                                             ws.numel(), stream), "tzr_pooled_bwd_plan")
+            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_feats"]), n_dp, T_dp, D,
+                                              _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N_all, NP, B,
+                                              1 if uniform else 0, 0, gd, len(gl),
+                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
+                       "tzr_pooled_bwd_apply")
+            w_acc = dist.all_reduce(self._dp_acc, group=self.pg, async_op=True)
+        if w_rows is not None:
+            w_rows.wait()
+            # owner: sort by (table,row) + fused optimizer, gradients addressed per id
             if n_recv > 0:
                 K, T = om["K"], om["T"]
-                ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
+                ws2 = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
                 _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K,
                                                  om["max_rows"], D, _lib.ptr(st["recv_ids"]), _lib.ptr(st["key_start"]),
-                                                 n_recv, n_recv, 1, 0, _lib.ptr(ws), ws.numel(), stream),
+                                                 n_recv, n_recv, 1, 0, _lib.ptr(ws2), ws2.numel(), stream),
                            "tzr_pooled_bwd_plan")
                 g1 = (_lib.TzrDst * 1)()
                 g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
                 _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_feats"]), K, T, D,
                                                   _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
-                                                  self._optim_struct(), _lib.ptr(ws), ws.numel(), stream),
+                                                  self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream),
                            "tzr_pooled_bwd_apply")
-        if "dp_n" in rm:
-            # replicas: exact per-row gradient sums of my samples -> all-reduce -> same dense update
-            N, n_dp, T = kjt.values().numel(), rm["dp_n"], len(self._dp)
-            offsets = None if uniform else kjt.offsets()
-            self._dp_acc.zero_()
-            NP = n_dp * B if uniform else N
-            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, NP, n_dp, T, B, D), dev)
-            _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T, _lib.ptr(rm["dp_d_feats"]), n_dp,
-                                             rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
-                                             _lib.ptr(offsets), N, NP, B, 1 if uniform else 0, _lib.ptr(ws),
-                                             ws.numel(), stream), "tzr_pooled_bwd_plan")
-            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_feats"]), n_dp, T, D,
-                                              _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, NP, B,
-                                              1 if uniform else 0, 0, gd, len(gl),
-                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
-                       "tzr_pooled_bwd_apply")
-            dist.all_reduce(self._dp_acc, group=self.pg)
-            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), T, _lib.ptr(self._dp_row_start),
+        if w_acc is not None:
+            w_acc.wait()
+            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
                        "tzr_dense_rows_update")
 
