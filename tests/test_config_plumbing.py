@@ -111,3 +111,51 @@ def test_deepfm_config_to_training(dev):
     # sparse LR schedulers mutate fused_optimizer.param_groups (tzrec/main.py:877-879)
     model.fused_optimizer.param_groups[0]["lr"] = 0.01
     assert abs(float(model.fused_optimizer.lr_device(dev).item()) - 0.01) < 1e-9
+
+
+def test_zch_and_frozen_features_from_config(dev):
+    """`zch {...}` and `trainable: false` in a feature config reach the kernels: raw 64-bit ids are
+    remapped into zch_size rows before the lookup, the frozen table never moves."""
+    text = open(os.path.join(HERE, "golden", "deepfm_mini.config")).read()
+    text = text.replace('feature_configs { id_feature { feature_name: "cat_0" num_buckets: 1000 embedding_dim: 16 } }',
+                        'feature_configs { id_feature { feature_name: "cat_0" embedding_dim: 16 '
+                        'zch { zch_size: 64 eviction_interval: 2 distance_lfu { decay_exponent: 1.0 } '
+                        'threshold_filtering_func: "lambda x: dynamic_threshold_filter(x, 0.0)" } } }')
+    text = text.replace('feature_configs { id_feature { feature_name: "cat_1" num_buckets: 3 embedding_dim: 16 } }',
+                        'feature_configs { id_feature { feature_name: "cat_1" num_buckets: 3 embedding_dim: 16 trainable: false } }')
+    spec = load_pipeline_spec(text)
+    f0 = next(f for f in spec.features if f.name == "cat_0")
+    assert f0.num_embeddings == 64 and f0.zch is not None and not next(f for f in spec.features if f.name == "cat_1").trainable
+    torch.manual_seed(0)
+    model = build_rank_model(spec, device=dev)
+    eg = model.embedding_group
+    assert eg.mc is not None and set(eg.mc.modules_by_table) == {"cat_0_emb_wide", "cat_0_emb"}
+    assert eg.mc.modules_by_table["cat_0_emb"].cfg.policy == "distance_lfu"
+    frozen_before = {n: eg.ebc.table_weights()[n].detach().clone() for n in ("cat_1_emb", "cat_1_emb_wide")}
+    opt = torch.optim.Adam(list(model.dense_parameters()), lr=spec.dense_lr)
+    pipe = TrainPipeline(model, opt, dev, model.loss)
+
+    def batches():
+        for b in _batches(spec, 1000, spec.batch_size):  # cat_0 carries raw ids far outside any table
+            kjt = b.sparse_features[BASE_DATA_GROUP]
+            v = kjt.values().clone()
+            n0 = int(kjt.lengths()[:kjt.stride()].sum())
+            v[:n0] = (v[:n0] % 40) * 1_000_003 + (1 << 40)
+            b.sparse_features[BASE_DATA_GROUP] = KeyedJaggedTensor(kjt.keys(), v, kjt.lengths())
+            yield b
+
+    it = iter(batches())
+    n = 0
+    while True:
+        try:
+            losses, _, _ = pipe.progress(it)
+        except StopIteration:
+            break
+        assert np.isfinite(float(losses["binary_cross_entropy"]))
+        n += 1
+    assert n == 4
+    m = eg.mc.modules_by_table["cat_0_emb"]
+    held = m.row_ids[m.row_ids != (1 << 63) - 1]
+    assert 0 < held.numel() <= 40 and bool((held >= (1 << 40)).all())  # 40 distinct raw ids own rows now
+    for n_, w in frozen_before.items():
+        assert torch.equal(eg.ebc.table_weights()[n_].detach(), w), n_

@@ -282,3 +282,32 @@ def test_rowwise_weight_decay_modes(dev):
         opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.03, weight_decay=0.01, weight_decay_mode=mode)
         _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 100,
                            "uniform1", False, opt, steps=2)
+
+
+def test_frozen_table_is_left_out_of_the_fused_optimizer(dev):
+    """`trainable: false` (tzrec/features/feature.py:629, models/model.py:162-201): the table is read
+    in forward, never written in backward; its neighbours update exactly as if it were not there."""
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    rng = np.random.default_rng(3)
+    B = 50
+    lens = rng.integers(0, 4, size=3 * B).astype(np.int32)
+    rows = [40, 7, 300]
+    vals = np.concatenate([rng.integers(0, rows[f], size=int(lens[f * B:(f + 1) * B].sum())) for f in range(3)])
+    kjt = KeyedJaggedTensor(["a", "b", "c"], torch.from_numpy(vals.astype(np.int64)), torch.from_numpy(lens)).to(dev)
+    res = {}
+    for frozen in (False, True):
+        torch.manual_seed(0)
+        ebc = EmbeddingBagCollection(
+            [EmbeddingBagConfig("ta", 8, rows[0], ["a"]), EmbeddingBagConfig("tb", 8, rows[1], ["b"], trainable=not frozen),
+             EmbeddingBagConfig("tc", 8, rows[2], ["c"])], device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+        before = {n: w.detach().clone() for n, w in ebc.table_weights().items()}
+        g = torch.randn(B, 24, generator=torch.Generator().manual_seed(1)).to(dev)
+        (ebc(kjt).values() * g).sum().backward()
+        res[frozen] = ({n: w.detach().clone() for n, w in ebc.table_weights().items()}, before)
+    after_f, before_f = res[True]
+    assert torch.equal(after_f["tb"], before_f["tb"])  # frozen: bit-identical
+    assert not torch.equal(res[False][0]["tb"], res[False][1]["tb"])  # trainable twin did move
+    for n in ("ta", "tc"):
+        assert torch.equal(after_f[n], res[False][0][n])  # neighbours: same update either way

@@ -119,6 +119,8 @@ class FeatureSpec:
     embedding_name: Optional[str] = None
     pooling: str = "sum"
     value_dim: int = 1
+    trainable: bool = True
+    zch: Optional[Msg] = None  # the raw `zch {...}` block (see zch.zch_config_from_msg)
 
 
 @dataclass
@@ -186,7 +188,8 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
             spec.features.append(FeatureSpec(
                 name=name, kind=kind, is_sparse=True, embedding_dim=int(f.one("embedding_dim", 0)),
                 num_embeddings=_num_embeddings(f, name), embedding_name=f.one("embedding_name"),
-                pooling=str(f.one("pooling", "sum")).lower()))
+                pooling=str(f.one("pooling", "sum")).lower(), trainable=bool(f.one("trainable", True)),
+                zch=f.one("zch") if f.has("zch") else None))
         elif kind == "raw_feature":
             spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=False,
                                              value_dim=int(f.one("value_dim", 1))))

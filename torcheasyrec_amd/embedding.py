@@ -40,6 +40,9 @@ class EmbeddingBagConfig:
     feature_names: List[str] = field(default_factory=list)
     pooling: str = "sum"  # PoolingType.SUM / MEAN
     init_fn: Optional[Callable[[torch.Tensor], None]] = None
+    # tzrec sets `.trainable` from the feature config (feature.py:629); frozen tables are left out
+    # of the fused optimizer (BaseModel.sparse_parameters, tzrec/models/model.py:162-201)
+    trainable: bool = True
 
 
 @dataclass
@@ -129,6 +132,7 @@ class _Meta:
     def __init__(self) -> None:
         self.tables_np = self.feats_np = self.slots_np = None
         self.d_tables = self.d_feats = self.d_slots = None
+        self.d_bwd_tables = self.d_bwd_feats = None
         self.n_keys = 0
 
 
@@ -306,6 +310,24 @@ class EmbeddingBagCollection(nn.Module):
         meta.slots_np = np.array(slots, dtype=_lib.SLOT_DT)
         meta.d_tables = _lib.upload_struct(tables, self._device)
         meta.d_feats = _lib.upload_struct(feats, self._device)
+        # backward descriptors: lookups of frozen tables are marked "not owned" (table -1, ordered
+        # last), so the plan sorts nothing for them and the optimizer never touches their rows
+        frozen = [not cfg.trainable for cfg in self._configs]
+        meta.d_bwd_tables, meta.d_bwd_feats = meta.d_tables, meta.d_feats
+        if any(frozen):
+            bf, bt = feats.copy(), tables.copy()
+            live = [i for i, lk in enumerate(self._lookups) if not frozen[lk.table]]
+            dead = [i for i, lk in enumerate(self._lookups) if frozen[lk.table]]
+            for o, i in enumerate(live + dead):
+                bf[i]["order"] = o
+            for i in dead:
+                bf[i]["table"] = -1
+            for t in range(T):
+                mine = [i for i in live if self._lookups[i].table == t]
+                bt[t]["first_order"] = int(bf[mine[0]]["order"]) if mine else 0
+                bt[t]["n_feats"] = len(mine)
+            meta.d_bwd_tables = _lib.upload_struct(bt, self._device)
+            meta.d_bwd_feats = _lib.upload_struct(bf, self._device)
         meta.d_slots = _lib.upload_struct(meta.slots_np, self._device)
         meta.n_keys = len(kjt_keys)
         self._meta_cache[ck] = meta
@@ -373,7 +395,7 @@ class EmbeddingBagCollection(nn.Module):
         ws = _lib.workspace(nbytes, self._device)
         ev = self._timers.start("plan") if self._timers is not None else None
         rc = L.tzr_pooled_bwd_plan(
-            _lib.ptr(meta.d_tables), len(self._configs), _lib.ptr(meta.d_feats), len(self._lookups),
+            _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups),
             meta.n_keys, max_rows, max_dim, _lib.ptr(kjt.values()), _lib.ptr(offsets), N, NP, B,
             1 if uniform else 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
         )
@@ -445,7 +467,7 @@ class EmbeddingBagCollection(nn.Module):
         opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
         ev = self._timers.start("apply") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_bwd_apply(
-            _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), len(self._configs),
+            _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),
             max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
             1 if uniform else 0, 0,
             gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),

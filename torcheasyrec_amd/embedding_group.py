@@ -82,6 +82,7 @@ class EmbeddingGroup(nn.Module):
         super().__init__()
         name_to_feature = {f.name: f for f in features}
         configs: "OrderedDict[str, EmbeddingBagConfig]" = OrderedDict()
+        zch_blocks: Dict[str, object] = {}
         feat_group_table: Dict[str, Dict[str, str]] = {}
         for g in feature_groups:
             if g.group_type == "SEQUENCE":
@@ -107,7 +108,9 @@ class EmbeddingGroup(nn.Module):
                 if f.is_sparse:
                     dim = (wide_embedding_dim or 4) if is_wide else f.embedding_dim
                     tname = feat_group_table[fname][g.group_name]
-                    cfg = EmbeddingBagConfig(tname, dim, f.num_embeddings, [fname], f.pooling)
+                    cfg = EmbeddingBagConfig(tname, dim, f.num_embeddings, [fname], f.pooling, trainable=f.trainable)
+                    if f.zch is not None:
+                        zch_blocks[tname] = f.zch
                     if tname in configs:
                         old = configs[tname]
                         if (old.num_embeddings, old.embedding_dim, old.pooling) != (cfg.num_embeddings, dim, cfg.pooling):
@@ -140,6 +143,14 @@ class EmbeddingGroup(nn.Module):
             # feature really feeds >1 table; align our keys with its naming
             self._ebc_groups = {g: [self._ebc_key(k) for k in ks] for g, ks in ebc_groups.items()}
             self.ebc._groups = self._ebc_groups
+        # features with a `zch {...}` block: ids go through the managed-collision remap first
+        # (the reference keeps them in a second collection, embedding.py:856-864; here the remap passes
+        # the other keys through, so one collection serves both)
+        self.mc = None
+        if zch_blocks and self.ebc is not None:
+            from .zch import ManagedCollisionEmbeddingBagCollection, zch_config_from_msg
+
+            self.mc = ManagedCollisionEmbeddingBagCollection(self.ebc, {t: zch_config_from_msg(z) for t, z in zch_blocks.items()})
 
     def _ebc_key(self, out_key: str) -> str:
         return out_key if out_key in self.ebc._out_dim else out_key.split("@")[0]
@@ -167,7 +178,12 @@ class EmbeddingGroup(nn.Module):
     def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
         sparse = batch.sparse_features.get(BASE_DATA_GROUP)
         dense = batch.dense_features.get(BASE_DATA_GROUP)
+        if self.mc is not None:
+            self.mc.train(self.training)
+            sparse = self.mc.remap_step(sparse)
         pooled = self.ebc.forward_grouped(sparse) if self.ebc is not None else {}
+        if self.mc is not None:
+            self.mc.finish_step()
         dense_cols = dense.to_dict() if dense is not None else {}
         out: Dict[str, torch.Tensor] = {}
         for g, blocks in self._group_blocks.items():

@@ -59,6 +59,27 @@ def probabilistic_threshold_filter(id_counts: torch.Tensor, per_id_probability: 
     return score > threshold, threshold
 
 
+def zch_config_from_msg(z) -> "ZchConfig":
+    """`zch {...}` block of a feature config (protos/feature.proto:31-47) -> ZchConfig.  The
+    admission filter is a lambda STRING evaluated with the documented helpers in scope, exactly as
+    the reference does (tzrec/features/feature.py:700-714)."""
+    policy, decay = "lfu", 1.0
+    for k in ("lfu", "lru", "distance_lfu"):
+        if z.has(k):
+            policy = k
+            body = z.one(k)
+            decay = float(body.one("decay_exponent", 1.0)) if hasattr(body, "one") else 1.0
+    func = None
+    if z.has("threshold_filtering_func"):
+        from functools import partial
+
+        func = eval(str(z.one("threshold_filtering_func")), {  # noqa: S307 - config-provided, as in the reference
+            "partial": partial, "nn": nn, "torch": torch, "average_threshold_filter": average_threshold_filter,
+            "dynamic_threshold_filter": dynamic_threshold_filter,
+            "probabilistic_threshold_filter": probabilistic_threshold_filter})
+    return ZchConfig(int(z.one("zch_size")), int(z.one("eviction_interval", 5)), policy, decay, func)
+
+
 @dataclass
 class ZchConfig:
     zch_size: int
@@ -246,12 +267,24 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
             uniq_mods = torch.arange(len(self._order), dtype=torch.int32, device=self._device)
             self._cand = [(ids, uniq_mods[mods.long()], torch.ones_like(ids))] if ids.numel() else []
 
-    def forward(self, kjt: KeyedJaggedTensor) -> Tuple[KeyedTensor, KeyedJaggedTensor]:
+    def remap_step(self, kjt: KeyedJaggedTensor) -> KeyedJaggedTensor:
+        """First half of a step for callers that run the lookup themselves (EmbeddingGroup): remap, and
+        in training count the iteration and profile."""
         training = self.training and torch.is_grad_enabled()
         if training:
             self._iter += 1
-        remapped = self.remap(kjt, profile=training)
-        out = self.ebc(remapped)
-        if training and any(self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order):
+        self._pending_evict = training and any(
+            self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order)
+        return self.remap(kjt, profile=training)
+
+    def finish_step(self) -> None:
+        """Second half: admission / eviction when due (after the lookup read the old mapping)."""
+        if getattr(self, "_pending_evict", False):
             self._evict()
+            self._pending_evict = False
+
+    def forward(self, kjt: KeyedJaggedTensor) -> Tuple[KeyedTensor, KeyedJaggedTensor]:
+        remapped = self.remap_step(kjt)
+        out = self.ebc(remapped)
+        self.finish_step()
         return out, remapped
