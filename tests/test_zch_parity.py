@@ -104,3 +104,41 @@ def test_zch_training_updates_the_remapped_rows(dev):
     delta = (w0 - w1).cpu()
     assert torch.allclose(delta[0], torch.full((4,), 2.0)) and torch.allclose(delta[1], torch.ones(4))
     assert torch.allclose(delta[2], torch.ones(4)) and bool((delta[3:] == 0).all())
+
+
+def test_zch_state_survives_a_checkpoint(dev, tmp_path):
+    from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+
+    def build(seed):
+        torch.manual_seed(seed)
+        ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, 32, ["k"])], device=dev,
+                                     optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.ebc = ebc
+                self.mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(32, 2, "distance_lfu")})
+        return M()
+
+    a = build(0)
+    a.mc.train()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        ids = torch.from_numpy(rng.integers(0, 60, size=40) * 7919 + (1 << 45))
+        out, _ = a.mc(KeyedJaggedTensor(["k"], ids, torch.ones(40, dtype=torch.int32), uniform_length=1).to(dev))
+        out.values().sum().backward()
+    save_checkpoint(str(tmp_path), a)
+    b = build(1)
+    restore_checkpoint(str(tmp_path), b)
+    assert b.mc._iter == 5
+    probe = torch.from_numpy(np.arange(60) * 7919 + (1 << 45))
+    kjt = KeyedJaggedTensor(["k"], probe, torch.ones(60, dtype=torch.int32), uniform_length=1).to(dev)
+    a.mc.eval(), b.mc.eval()
+    with torch.no_grad():
+        oa, ra = a.mc(kjt)
+        ob, rb = b.mc(kjt)
+    assert torch.equal(ra.values(), rb.values()) and torch.equal(oa.values(), ob.values())
+    assert int((ra.values() != 31).sum()) > 0
+    for f in ("row_ids", "counts", "last_iter"):
+        assert torch.equal(getattr(a.mc.modules_by_table["t"], f), getattr(b.mc.modules_by_table["t"], f))

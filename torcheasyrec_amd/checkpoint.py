@@ -6,7 +6,8 @@ can resume under a different plan) and a `plan` JSON `{module_path: {param: {sha
 compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
 
   <dir>/model/rank<r>.pt       {"dense": {param: tensor},
-                                "tables": {table: {"lo", "n", "weight"[n, D]}}}      rows [lo, lo+n)
+                                "tables": {table: {"lo", "n", "weight"[n, D]}},      rows [lo, lo+n)
+                                "zch": {"iter", "tables": {table: {row_ids, counts, last_iter}}} | None}
   <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "dense": optimizer.state_dict()}
   <dir>/plan                   the reference's plan JSON (rank 0)
   <dir>/meta.json              world size, {table: [rows, dim]}, format version (rank 0)
@@ -37,10 +38,20 @@ def _rank_world() -> Tuple[int, int]:
 
 
 def _ebc_of(model: nn.Module):
-    ebc = getattr(model, "ebc", None)
-    if ebc is None:
-        raise ValueError("model has no `.ebc` (EmbeddingBagCollection or ShardedEmbeddingBagCollection)")
-    return ebc
+    for holder in (model, getattr(model, "embedding_group", None)):
+        ebc = getattr(holder, "ebc", None) if holder is not None else None
+        if ebc is not None:
+            return ebc
+    raise ValueError("model has no `.ebc` / `.embedding_group.ebc` (EmbeddingBagCollection or ShardedEmbeddingBagCollection)")
+
+
+def _mc_of(model: nn.Module):
+    """The managed-collision (ZCH) wrapper, if the model has one."""
+    for holder in (model, getattr(model, "embedding_group", None)):
+        mc = getattr(holder, "mc", None) if holder is not None else None
+        if mc is not None and hasattr(mc, "modules_by_table"):
+            return mc
+    return None
 
 
 def _placement(ebc) -> Dict[str, Tuple[int, int, int, str]]:
@@ -77,7 +88,12 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
         m_tables[name] = {"lo": lo, "n": n, "weight": weights[name].detach()[:n].cpu().contiguous()}
         if name in states:
             o_tables[name] = {"lo": lo, "n": n, "momentum1": states[name].detach()[:n].cpu().contiguous()}
-    torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables},
+    mc = _mc_of(model)
+    zch = None
+    if mc is not None and rank == 0:  # raw id / access count / last access of every row + the step counter
+        zch = {"iter": mc._iter, "tables": {n: {"row_ids": m.row_ids.cpu(), "counts": m.counts.cpu(), "last_iter": m.last_iter.cpu()}
+                                            for n, m in mc.modules_by_table.items()}}
+    torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables, "zch": zch},
                os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
     fo = getattr(ebc, "fused_optimizer", None)
     torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"],
@@ -149,6 +165,20 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                 mine[n_].data.copy_(t)
             elif strict:
                 raise KeyError(f"checkpoint parameter {n_} not in the model")
+    mc = _mc_of(model)
+    zch = m_files[0].get("zch")
+    if mc is not None and zch is not None:
+        mc._iter = int(zch["iter"])
+        mc._cand = []
+        for n, m in mc.modules_by_table.items():
+            if n in zch["tables"]:
+                z = zch["tables"][n]
+                m.row_ids.copy_(z["row_ids"])
+                m.counts.copy_(z["counts"])
+                m.last_iter.copy_(z["last_iter"])
+                m.rebuild()
+            elif strict:
+                raise KeyError(f"checkpoint has no zch state for {n}")
     fo = getattr(ebc, "fused_optimizer", None)
     if fo is not None and o_files[0].get("sparse_lr") is not None:
         fo.param_groups[0]["lr"] = o_files[0]["sparse_lr"]
