@@ -99,7 +99,8 @@ def enable_tunable_gemm():
     if os.path.exists(src):
         shutil.copy(src, dst)
     tn.enable(True)
-    tn.tuning_enable(True)
+    # profiling runs set TZR_TUNABLE_TUNING=0: use the shipped selections, never launch candidates
+    tn.tuning_enable(os.environ.get("TZR_TUNABLE_TUNING", "1") != "0")
     tn.set_filename(dst, insert_device_ordinal=False)
     if os.path.exists(dst):
         tn.read_file(dst)
@@ -109,9 +110,12 @@ def pmc_traffic(args, B_local):
     """HBM bytes per launch of the pooled forward kernel from the PMC passes kept under profiles/
     (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, see the file).  Only valid for the
     configuration it was recorded on; null otherwise."""
-    p = os.path.join(ROOT, "profiles", "r01c", "pmc_traffic.json")
-    if not (os.path.exists(p) and B_local == 65536 and args.dist == "uniform" and not args.rows_cap):
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))  # newest round last
+    if not (found and B_local == 65536 and args.dist == "uniform" and not args.rows_cap):
         return None
+    p = found[-1]
     try:
         return float(json.load(open(p))["kernels"]["tzr_pooled_fwd_kernel"]["traffic_corrected"])
     except Exception:
@@ -373,8 +377,8 @@ def main():
                                "traffic": pmc_traffic(args, B_local), "launch_ms": t_fwd,
                                "algorithmic_bytes": fwd_b,
                                "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe, profiles/r01c
-                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded in "
-                                                 "profiles/r01c/pmc_traffic.json (not measurable from inside bench.py)"}
+                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded in the newest "
+                                                 "profiles/r*/pmc_traffic.json (not measurable from inside bench.py)"}
         if t_fwd and t_plan is not None and t_apply:
             tot = (t_fwd + t_plan + t_apply) * 1e-3
             out["embedding"] = {

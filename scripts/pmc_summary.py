@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in
+separate runs, MI355X_MICROARCH.md: they do not fit one pass).
+
+    pmc_summary.py <fetch_dir> <write_dir> <out.json> [n_lookups]
+
+Counter values are KiB per dispatch.  Corrections applied, as calibrated with scripts/probe_hbm.hip on
+this chip (profiles/r01c/probe_hbm_access_patterns.txt): WRITE_SIZE is exact; FETCH_SIZE counts 64 B
+per fabric read request, i.e. exact for 64-byte row gathers and HALF of a wide streaming read -- so
+for the pooled forward the streamed id array (8 B x n_lookups) is added back once more at 1/2."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and "tzr_" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]) * 1024.0)
+    # skip the first (cold) dispatch of every kernel when there are several
+    return {k: sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0] for k, v in acc.items()}
+
+
+def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    ks = {}
+    for k in sorted(set(fe) | set(wr)):
+        ks[k] = {"FETCH_SIZE": fe.get(k), "WRITE_SIZE": wr.get(k)}
+    if "tzr_pooled_fwd_kernel" in ks:
+        e = ks["tzr_pooled_fwd_kernel"]
+        e["traffic_corrected"] = e["FETCH_SIZE"] + 0.5 * 8 * int(n_lookups) + e["WRITE_SIZE"]
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 "
+                         "--warmup 2 --no-cpu-baseline --no-graph; B=65536 uniform ids, adagrad interleaved",
+               "units": "bytes per launch (mean over dispatches after the first); see scripts/pmc_summary.py for the corrections",
+               "kernels": ks}, open(out, "w"), indent=1)
+    print(json.dumps(ks.get("tzr_pooled_fwd_kernel")))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
