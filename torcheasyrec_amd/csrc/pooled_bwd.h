@@ -17,6 +17,19 @@
 #define BWD_LEAD_WHOLE 2u  // ... and does not end inside it
 #define BWD_TRAIL 4u       // the last run continues past the end of this span
 
+// Everything a workgroup needs to know about its chunk, written once by the prep kernel: one
+// 48-byte load instead of a binary search over the chunk map plus three dependent table lookups at
+// the head of every hist / scatter / reduce workgroup (these kernels are latency-, not
+// bandwidth-bound: ~7 workgroups per CU, one pass each).
+struct BwdChunkDesc {
+  int32_t t;      // table, -1 for surplus chunks
+  int32_t width;  // digit width of the table's sort
+  int32_t npass;
+  int32_t last_chunk;  // first chunk of the NEXT table (stitch walks up to it)
+  int64_t s, e;        // positions [s, e) of the chunk
+  int64_t ts, te;      // positions of the whole table
+};
+
 struct BwdPlan {  // pointers into the caller workspace
   int64_t* feat_start;     // [F+1] start of each lookup (by order) in table-major position space
   int32_t* feat_by_order;  // [F]
@@ -24,8 +37,8 @@ struct BwdPlan {  // pointers into the caller workspace
   int32_t* tab_chunk;      // [T+1] first chunk of each table
   int32_t* tab_width;      // [T] digit width (0 = nothing to sort)
   int32_t* tab_npass;      // [T]
-  uint32_t* key[2];        // [N] local row id (ping-pong)
-  uint32_t* src[2];        // [N] original lookup position
+  uint2* ks[2];            // [N] {local row id, original lookup position} (ping-pong); one 8-byte
+                           //     element so a scattered element is ONE store, not two
   uint32_t* bag_of;        // [NV] bag index key*B+b of every lookup (only when bags are jagged)
   uint32_t* hist;          // [max_chunks * BWD_NB] chunk-exclusive digit counts
   uint32_t* binbase;       // [T * BWD_NB] global start of every (table, digit)
@@ -34,6 +47,7 @@ struct BwdPlan {  // pointers into the caller workspace
   uint32_t* ctkey;         // [max_chunks] key of the chunk's trailing open run
   float* clead;            // [max_chunks * max_dim]
   float* ctrail;           // [max_chunks * max_dim]
+  BwdChunkDesc* cdesc;     // [max_chunks]
   int64_t max_chunks;
 };
 
@@ -52,10 +66,7 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.tab_chunk = c.take<int32_t>(T + 1);
   q.tab_width = c.take<int32_t>(T);
   q.tab_npass = c.take<int32_t>(T);
-  for (int i = 0; i < 2; ++i) {
-    q.key[i] = c.take<uint32_t>(N);
-    q.src[i] = c.take<uint32_t>(N);
-  }
+  for (int i = 0; i < 2; ++i) q.ks[i] = c.take<uint2>(N);
   q.bag_of = c.take<uint32_t>(NV);
   q.hist = c.take<uint32_t>(q.max_chunks * BWD_NB);
   q.binbase = c.take<uint32_t>((size_t)T * BWD_NB);
@@ -64,29 +75,14 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.ctkey = c.take<uint32_t>(q.max_chunks);
   q.clead = c.take<float>((size_t)q.max_chunks * max_dim);
   q.ctrail = c.take<float>((size_t)q.max_chunks * max_dim);
+  q.cdesc = c.take<BwdChunkDesc>(q.max_chunks);
   if (p) *p = q;
   return c.off;
 }
 
-// chunk id -> (table, first position, end position, table span); false for surplus workgroups.
-__device__ __forceinline__ bool bwd_chunk(const BwdPlan& P, const TzrTable* tables, int T,
-                                          int chunk, int* t_out, int64_t* s_out, int64_t* e_out,
-                                          int64_t* tab_s_out, int64_t* tab_e_out) {
-  if (chunk >= P.tab_chunk[T]) return false;
-  int lo = 0, hi = T;  // last t with tab_chunk[t] <= chunk (the non-empty table holding it)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (P.tab_chunk[mid] <= chunk) lo = mid; else hi = mid;
-  }
-  const int t = lo;
-  const TzrTable tb = tables[t];
-  const int64_t ts = P.tab_start[t];
-  const int64_t te = tb.n_feats > 0 ? P.feat_start[tb.first_order + tb.n_feats] : ts;
-  const int64_t s = ts + (int64_t)(chunk - P.tab_chunk[t]) * BWD_CH;
-  *t_out = t;
-  *s_out = s;
-  *e_out = min(te, s + BWD_CH);
-  *tab_s_out = ts;
-  *tab_e_out = te;
-  return true;
+// chunk id -> its descriptor; false for surplus workgroups.
+__device__ __forceinline__ bool bwd_chunk(const BwdPlan& P, int chunk, BwdChunkDesc* d) {
+  if (chunk >= P.max_chunks) return false;
+  *d = P.cdesc[chunk];
+  return d->t >= 0;
 }

@@ -105,27 +105,69 @@ __device__ __forceinline__ void bwd_elem0(const BwdPlan& P, const TzrTable& tb, 
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
     const TzrTable* __restrict__ tables, int T, int pass, BwdSrcArgs A, BwdPlan P) {
   __shared__ unsigned h[BWD_NB];
-  int t;
-  int64_t s, e, ts, te;
-  if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
-  if (P.tab_npass[t] <= pass) return;
-  const int width = P.tab_width[t];
+  BwdChunkDesc cd;
+  if (pass == 0) {
+    // the first kernel after prep resolves chunk -> table once and leaves the descriptor for every
+    // later kernel of the plan and the apply (see BwdChunkDesc)
+    const int c = blockIdx.x;
+    cd.t = -1;
+    cd.width = cd.npass = cd.last_chunk = 0;
+    cd.s = cd.e = cd.ts = cd.te = 0;
+    if (c < P.tab_chunk[T]) {
+      int lo = 0, hi = T;  // last t with tab_chunk[t] <= c (the non-empty table holding it)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (P.tab_chunk[mid] <= c) lo = mid; else hi = mid;
+      }
+      const TzrTable tb = tables[lo];
+      cd.t = lo;
+      cd.width = P.tab_width[lo];
+      cd.npass = P.tab_npass[lo];
+      cd.last_chunk = P.tab_chunk[lo + 1];
+      cd.ts = P.tab_start[lo];
+      cd.te = tb.n_feats > 0 ? P.feat_start[tb.first_order + tb.n_feats] : cd.ts;
+      cd.s = cd.ts + (int64_t)(c - P.tab_chunk[lo]) * BWD_CH;
+      cd.e = min(cd.te, cd.s + (int64_t)BWD_CH);
+    }
+    if (threadIdx.x == 0) P.cdesc[c] = cd;
+    if (cd.t < 0) return;
+  } else if (!bwd_chunk(P, blockIdx.x, &cd)) {
+    return;
+  }
+  if (cd.npass <= pass) return;
+  const int t = cd.t;
+  const int64_t s = cd.s, e = cd.e;
+  const int width = cd.width;
   const int shift = pass * width;
   const unsigned mask = (1u << width) - 1u;
-  const uint32_t* __restrict__ kin = (pass & 1) ? P.key[1] : P.key[0];
+  const uint2* __restrict__ kin = (pass & 1) ? P.ks[1] : P.ks[0];
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) h[i] = 0;
-  __syncthreads();
+  // all of the chunk's keys are loaded before any is counted: independent loads in flight, one
+  // memory latency per workgroup instead of one per element
+  constexpr int kRounds = BWD_CH / BWD_THREADS;
+  uint32_t kreg[kRounds];
   if (pass == 0) {
     const TzrTable tb = tables[t];
-    for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS) {
-      uint32_t k, sv;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
+      uint32_t sv;
       int64_t kk;
-      bwd_elem0(P, tb, A, p, &k, &sv, &kk);
-      atomicAdd(&h[k & mask], 1u);
+      kreg[r] = 0u;
+      if (p < e) bwd_elem0(P, tb, A, p, &kreg[r], &sv, &kk);
     }
   } else {
-    for (int64_t p = s + threadIdx.x; p < e; p += BWD_THREADS)
-      atomicAdd(&h[(kin[p] >> shift) & mask], 1u);
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
+      kreg[r] = p < e ? kin[p].x : 0u;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
+    if (p < e) atomicAdd(&h[(kreg[r] >> shift) & mask], 1u);
   }
   __syncthreads();
   uint32_t* out = P.hist + (size_t)blockIdx.x * BWD_NB;
@@ -168,41 +210,50 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(int T, int pass, B
 
 // Stable scatter of one chunk.  Element order inside a chunk is position order; per round of 256
 // positions each wave ranks its lanes by digit with ballots (match-any), waves are ordered through
-// per-wave digit counts in LDS, rounds through the running per-digit base.
+// per-wave digit counts in LDS, rounds through the running per-digit count.  That gives every
+// element its index among the chunk's elements of the same digit; the elements are then laid out
+// digit-major in LDS and written back in THAT order, so lanes that are neighbours in a wave store to
+// neighbouring addresses whenever they share a digit (one 8-byte {key, src} store per element;
+// element-order stores are 2 x 4 bytes to unrelated lines, ~3x write amplification measured).
+static_assert(BWD_NB == 2 * BWD_THREADS, "the local digit scan gives two digits to every thread");
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
     const TzrTable* __restrict__ tables, int T, int pass, BwdSrcArgs A, BwdPlan P) {
-  __shared__ unsigned base[BWD_NB];
-  __shared__ unsigned wcnt[BWD_THREADS / TZR_WAVE][BWD_NB];
-  int t;
-  int64_t s, e, ts, te;
-  if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
-  if (P.tab_npass[t] <= pass) return;
-  const int width = P.tab_width[t];
+  __shared__ unsigned base0[BWD_NB];  // global position of the chunk's first element of each digit
+  __shared__ unsigned cnt[BWD_NB];    // running count of the digit over the rounds done so far
+  __shared__ unsigned lstart[BWD_NB]; // chunk-local start of each digit (digit-major order)
+  __shared__ unsigned wcnt[BWD_WAVES][BWD_NB];
+  __shared__ unsigned wtot[BWD_WAVES];
+  __shared__ uint2 stage[BWD_CH];
+  BwdChunkDesc cd;
+  if (!bwd_chunk(P, blockIdx.x, &cd)) return;
+  if (cd.npass <= pass) return;
+  const int t = cd.t;
+  const int64_t s = cd.s, e = cd.e;
+  const int width = cd.width;
   const int shift = pass * width;
   const unsigned mask = (1u << width) - 1u;
-  const uint32_t* __restrict__ kin = (pass & 1) ? P.key[1] : P.key[0];
-  const uint32_t* __restrict__ sin = (pass & 1) ? P.src[1] : P.src[0];
-  uint32_t* __restrict__ kout = (pass & 1) ? P.key[0] : P.key[1];
-  uint32_t* __restrict__ sout = (pass & 1) ? P.src[0] : P.src[1];
+  const uint2* __restrict__ kin = (pass & 1) ? P.ks[1] : P.ks[0];
+  uint2* __restrict__ kout = (pass & 1) ? P.ks[0] : P.ks[1];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   const unsigned* hrow = P.hist + (size_t)blockIdx.x * BWD_NB;
   const unsigned* bb = P.binbase + (size_t)t * BWD_NB;
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) {
-    base[i] = bb[i] + hrow[i];
+    base0[i] = bb[i] + hrow[i];
+    cnt[i] = 0;
 #pragma unroll
-    for (int w = 0; w < BWD_THREADS / TZR_WAVE; ++w) wcnt[w][i] = 0;
+    for (int w = 0; w < BWD_WAVES; ++w) wcnt[w][i] = 0;
   }
-  __syncthreads();
-  // all of the chunk's keys / sources are loaded up front (independent coalesced loads): the
-  // ranking rounds below then run out of registers and pay one memory latency per workgroup
+  // all of the chunk's elements are loaded up front (independent coalesced loads): the ranking
+  // rounds below then run out of registers and pay one memory latency per workgroup
   constexpr int kRounds = BWD_CH / BWD_THREADS;
-  uint32_t kreg[kRounds], sreg[kRounds];
+  uint32_t kreg[kRounds], sreg[kRounds], loc[kRounds];
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
     kreg[r] = 0u;
     sreg[r] = 0u;
+    loc[r] = 0u;
     if (p < e) {
       if (pass == 0) {
         int64_t kk;
@@ -212,20 +263,20 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
           P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
         }
       } else {
-        kreg[r] = kin[p];
-        sreg[r] = sin[p];
+        const uint2 v = kin[p];
+        kreg[r] = v.x;
+        sreg[r] = v.y;
       }
     }
   }
-  const int rounds = (int)((e - s + BWD_THREADS - 1) / BWD_THREADS);
+  __syncthreads();
+  const int n = (int)(e - s);
+  const int rounds = (n + BWD_THREADS - 1) / BWD_THREADS;
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     if (r >= rounds) break;  // uniform across the workgroup
-    const int64_t p = s + (int64_t)r * BWD_THREADS + threadIdx.x;
-    const bool valid = p < e;
-    const uint32_t k = kreg[r];
-    const uint32_t sv = sreg[r];
-    const unsigned d = (k >> shift) & mask;
+    const bool valid = r * BWD_THREADS + (int)threadIdx.x < n;
+    const unsigned d = (kreg[r] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
     for (int bit = 0; bit < width; ++bit) {
       const int on = (d >> bit) & 1;
@@ -236,23 +287,51 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
     if (valid && rank == 0) wcnt[wv][d] = (unsigned)__popcll(peers);
     __syncthreads();
     if (valid) {
-      unsigned pre = 0;
+      unsigned pre = cnt[d];
       for (int w = 0; w < wv; ++w) pre += wcnt[w][d];
-      const unsigned pos = base[d] + pre + (unsigned)rank;
-      kout[pos] = k;
-      sout[pos] = sv;
+      loc[r] = pre + (unsigned)rank;  // index among the chunk's elements with digit d
     }
     __syncthreads();
     for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) {
       unsigned tsum = 0;
 #pragma unroll
-      for (int w = 0; w < BWD_THREADS / TZR_WAVE; ++w) {
+      for (int w = 0; w < BWD_WAVES; ++w) {
         tsum += wcnt[w][i];
         wcnt[w][i] = 0;
       }
-      base[i] += tsum;
+      cnt[i] += tsum;
     }
     __syncthreads();
+  }
+  // lstart = exclusive scan of the digit totals: thread i owns digits 2i, 2i+1
+  {
+    const unsigned c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
+    unsigned v = c0 + c1;
+    for (int dd = 1; dd < TZR_WAVE; dd <<= 1) {
+      const unsigned o = __shfl_up(v, dd, TZR_WAVE);
+      if (lane >= dd) v += o;
+    }
+    if (lane == TZR_WAVE - 1) wtot[wv] = v;
+    __syncthreads();
+    unsigned pre = 0;
+    for (int w = 0; w < wv; ++w) pre += wtot[w];
+    const unsigned excl = pre + v - (c0 + c1);
+    lstart[2 * threadIdx.x] = excl;
+    lstart[2 * threadIdx.x + 1] = excl + c0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    if (r * BWD_THREADS + (int)threadIdx.x < n) {
+      const unsigned d = (kreg[r] >> shift) & mask;
+      stage[lstart[d] + loc[r]] = make_uint2(kreg[r], sreg[r]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+    const uint2 v = stage[i];
+    const unsigned d = (v.x >> shift) & mask;
+    kout[base0[d] + ((unsigned)i - lstart[d])] = v;
   }
 }
 

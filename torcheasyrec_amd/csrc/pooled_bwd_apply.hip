@@ -201,22 +201,23 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
   __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
   __shared__ TzrDst sG[TZR_MAX_DST];
-  int t;
-  int64_t s, e, ts, te;
-  if (!bwd_chunk(P, tables, T, blockIdx.x, &t, &s, &e, &ts, &te)) return;
+  BwdChunkDesc cd;
+  if (!bwd_chunk(P, blockIdx.x, &cd)) return;
+  const int t = cd.t;
+  const int64_t s = cd.s, e = cd.e, ts = cd.ts, te = cd.te;
   const TzrTable tb = tables[t];
-  const int par = P.tab_npass[t] & 1;
-  // selects, not P.key[par]: a runtime index into the by-value plan spills it to scratch
-  const uint32_t* __restrict__ K = par ? P.key[1] : P.key[0];
-  const uint32_t* __restrict__ S = par ? P.src[1] : P.src[0];
+  const int par = cd.npass & 1;
+  // selects, not P.ks[par]: a runtime index into the by-value plan spills it to scratch
+  const uint2* __restrict__ KS = par ? P.ks[1] : P.ks[0];
   const int n = (int)(e - s);
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-    sK[i + 1] = K[s + i];
-    sS[i] = S[s + i];
+    const uint2 v = KS[s + i];
+    sK[i + 1] = v.x;
+    sS[i] = v.y;
   }
   if (threadIdx.x == 0) {
-    sK[0] = s > ts ? K[s - 1] : BWD_SENT;
-    sK[n + 1] = e < te ? K[e] : BWD_SENT;
+    sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
+    sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
 #pragma unroll
     for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
   }
@@ -348,17 +349,16 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_stitch_kernel(
     const TzrTable* __restrict__ tables, int T, BwdOpt opt, int max_dim, BwdPlan P) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int chunk = blockIdx.x * BWD_WAVES + threadIdx.x / TZR_WAVE;
-  int t;
-  int64_t s, e, ts, te;
-  if (!bwd_chunk(P, tables, T, chunk, &t, &s, &e, &ts, &te)) return;
+  BwdChunkDesc cd;
+  if (!bwd_chunk(P, chunk, &cd)) return;
   if (!(P.cflags[chunk] & BWD_TRAIL)) return;
-  const TzrTable tb = tables[t];
+  const TzrTable tb = tables[cd.t];
   const bool on = lane < (tb.dim >> 2);
   const float lr = *opt.lr;
   const uint32_t key = P.ctkey[chunk];
   float4 sum = tzr_zero4();
   if (on) sum = tzr_ld4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
-  for (int c2 = chunk + 1; c2 < P.tab_chunk[t + 1]; ++c2) {
+  for (int c2 = chunk + 1; c2 < cd.last_chunk; ++c2) {
     const unsigned f = P.cflags[c2];
     if (!(f & BWD_LEAD)) break;
     if (on) sum = tzr_add4(sum, tzr_ld4(P.clead + (size_t)c2 * max_dim + 4 * lane));
