@@ -179,7 +179,8 @@ extern "C" int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feat
     dsts.d[i] = h_dsts[i];
   }
   int tile_b = g_tzr_fwd_tile_b;
-  if (tile_b <= 0) tile_b = B <= 16384 ? 8 : (B <= 32768 ? 16 : 32);
+  // measured on MI355X (scripts/fwd_sweep.py): B=65536 runs ~3 us faster with 128-sample tiles
+  if (tile_b <= 0) tile_b = B <= 16384 ? 8 : (B <= 32768 ? 16 : 128);
   dim3 grid((unsigned)((B + tile_b - 1) / tile_b), (unsigned)((n_slots + FWD_MAX_SLOTS - 1) / FWD_MAX_SLOTS));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool u1 = uniform_bag_len == 1;
