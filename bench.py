@@ -95,7 +95,9 @@ def enable_tunable_gemm():
     import torch.cuda.tunable as tn
 
     src = os.path.join(ROOT, "torcheasyrec_amd", "tunableop_gfx950.csv")
-    dst = f"/tmp/tzr_tunableop_{os.getpid()}.csv"
+    # TZR_TUNABLE_SAVE=<path>: TunableOp writes its table there at exit (shipped entries + whatever
+    # this run tuned) -- how torcheasyrec_amd/tunableop_gfx950.csv is refreshed
+    dst = os.environ.get("TZR_TUNABLE_SAVE") or f"/tmp/tzr_tunableop_{os.getpid()}.csv"
     if os.path.exists(src):
         shutil.copy(src, dst)
     tn.enable(True)

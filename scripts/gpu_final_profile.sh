@@ -8,7 +8,7 @@ R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-200 $O/bench.json
 cd /tmp
-export TZR_TUNABLE_TUNING=0
+# tuning stays on: the shipped table covers every shape of this run, so no candidate kernels appear
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $O/trace.log 2>&1; echo "trace rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2>&1; echo "pmc $c rc=$?"
