@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
     ap.add_argument("--replicate-small", action="store_true",
                     help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
+    ap.add_argument("--torch-bce", action="store_true", help="loss: torch BCE-with-logits instead of tzr_bce_logits")
+    ap.add_argument("--torch-adam", action="store_true", help="dense optimizer: torch.optim.Adam(fused) instead of tzr_dense_adam")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded runs: op-by-op autograd step instead of ShardedTrainStep")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -221,6 +223,9 @@ def main():
     from torcheasyrec_amd.criteo import (CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, algorithmic_bytes,
                                          criteo_tables, synthetic_batch)
     from torcheasyrec_amd.dlrm import DLRM, bce_with_logits
+    if args.torch_bce:
+        def bce_with_logits(logits, labels):  # noqa: F811 - A/B switch
+            return torch.nn.functional.binary_cross_entropy_with_logits(logits, labels.float())
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
 
     _lib.use_library(_build.build())
@@ -248,7 +253,12 @@ def main():
         parallelism = model.describe()
     use_graph = not sharded and not args.no_graph
     # capturable: the dense Adam step lives inside the captured hipGraph
-    dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True, capturable=use_graph)
+    if args.torch_adam:
+        dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True, capturable=use_graph)
+    else:  # same update, two launches for all ten tensors (torcheasyrec_amd/dense.py)
+        from torcheasyrec_amd.dense import FusedDenseAdam
+
+        dense_opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-3)
 
     # synthetic batches, resident in HBM before the timed region
     from torcheasyrec_amd.sparse import KeyedJaggedTensor

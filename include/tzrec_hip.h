@@ -244,6 +244,36 @@ int tzr_lookup_grads(const TzrFeature* d_feats, int n_feats, const int64_t* d_of
                      const int64_t* d_positions, const TzrDst* h_grads, int n_dst, float* d_out,
                      int64_t out_stride, int dim, void* stream);
 
+/* ---- dense glue of the training step -------------------------------------------------------- */
+
+/* BCEWithLogitsLoss(reduction="mean") and its gradient in two launches (elementwise + partial
+ * sums, fixed-order finish).  Replaces the
+ * torch.nn.BCEWithLogitsLoss forward+backward built by tzrec/models/rank_model.py:190-191,233-240
+ * (with sample weights: mean(loss_i * w_i), rank_model.py:260-273, w_i already normalised by the
+ * caller).  *d_loss = mean_i w_i*(max(x,0) - x*y + log1p(exp(-|x|))); d_grad_logits[i] =
+ * w_i*(sigmoid(x_i) - y_i)/B.  Labels: float32 (labels_are_float=1) or int32/int64. */
+size_t tzr_bce_logits_workspace(int64_t B);
+int tzr_bce_logits(const float* d_logits, const void* d_labels, int labels_itemsize,
+                   int labels_are_float, const float* d_sample_weight, int64_t B, float* d_loss,
+                   float* d_grad_logits, void* ws, size_t ws_bytes, void* stream);
+
+#define TZR_ADAM_MAX_TENSORS 32
+typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, float32 */
+  uint64_t param, grad, exp_avg, exp_avg_sq;
+  uint64_t state; /* float[3], zero-initialised by the caller: [0] step count of THIS tensor
+                     (torch counts steps per parameter), [1], [2] bias corrections */
+  int64_t numel;
+} TzrAdamTensor; /* 48 bytes */
+
+/* Adam step over every dense parameter tensor (torch.optim.Adam semantics, amsgrad off, L2
+ * weight decay): the dense optimizer TZRecOptimizer.step() runs after the fused sparse backward
+ * (tzrec/optim/optimizer.py:56-68; adam_optimizer of tzrec/optim/optimizer_builder.py).
+ * Only tensors that have a gradient this step are passed; their step counts are incremented
+ * here.  The learning rate is read from d_lr when non-null (so a captured hipGraph follows a
+ * scheduler), else `lr`.  h_tensors is a HOST array; 32 tensors per launch pair. */
+int tzr_dense_adam(const TzrAdamTensor* h_tensors, int n_tensors, const float* d_lr, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* ---- zero-collision hash ---------------------------------------- */
 
 #define TZR_ZCH_EMPTY INT64_MAX /* unoccupied cell / row (tzrec/utils/zch_util.py:29 ZCH_EMPTY_SLOT) */

@@ -1,0 +1,59 @@
+"""Fused BCE-with-logits and the two-launch Adam against the torch ops they replace (fp32, 1e-6)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from torcheasyrec_amd.dense import FusedDenseAdam, bce_with_logits  # noqa: E402
+
+
+@pytest.mark.parametrize("B,label_dtype,weighted", [(1, torch.float32, False), (1500, torch.int64, False),
+                                                    (2049, torch.float32, True), (1100, torch.int32, False)])
+def test_bce_matches_torch(dev, B, label_dtype, weighted):
+    g = torch.Generator().manual_seed(B)
+    x = (torch.randn(B, generator=g) * 6).requires_grad_(True)  # includes saturated logits
+    x.data[0] = 40.0
+    x.data[-1] = -40.0
+    y = (torch.rand(B, generator=g) < 0.3).to(label_dtype)
+    w = torch.rand(B, generator=g) + 0.5 if weighted else None
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x.double(), y.double(), weight=None if w is None else w.double())
+    ref.backward()
+    gref, x.grad = x.grad.clone(), None
+    xd = x.detach().to(dev).requires_grad_(True)
+    loss = bce_with_logits(xd, y.to(dev), None if w is None else w.to(dev))
+    (loss * 3.0).backward()  # upstream gradient is honoured
+    torch.testing.assert_close(loss.detach().cpu().double(), ref.detach(), rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(xd.grad.cpu().double(), 3.0 * gref.double(), rtol=2e-6, atol=1e-9)
+    assert loss.shape == ()
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adam_follows_torch_adam(dev, wd):
+    torch.manual_seed(0)
+    shapes = [(13, 64), (64,), (64, 16), (16,), (300, 7), (1,)] + [(3, 5)] * 28  # > 32 tensors: two launch pairs
+    ref = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+    o = FusedDenseAdam(mine, lr=1e-2, weight_decay=wd)
+    for step in range(7):
+        if step == 4:  # a scheduler changes the learning rate
+            o_ref.param_groups[0]["lr"] = 3e-3
+            o.param_groups[0]["lr"] = 3e-3
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(step * 100 + p.numel()))
+            p.grad = gr.clone()
+            q.grad = gr.to(dev)
+        if step == 5:
+            ref[2].grad = None  # a parameter without gradient is skipped
+            mine[2].grad = None
+        o_ref.step()
+        o.step()
+    for p, q in zip(ref, mine):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+    sd = o.state_dict()
+    o2 = FusedDenseAdam([torch.nn.Parameter(q.detach().clone()) for q in mine], lr=1.0)
+    o2.load_state_dict(sd)
+    assert o2.param_groups[0]["lr"] == 3e-3 and float(o2._state[0, 0]) == 7.0 and float(o2._state[2, 0]) == 6.0
+    assert torch.equal(o2.exp_avg[4], o.exp_avg[4])

@@ -57,6 +57,11 @@ class TzrSparseOptim(C.Structure):
     ]
 
 
+class TzrAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_uint64), ("grad", C.c_uint64), ("exp_avg", C.c_uint64), ("exp_avg_sq", C.c_uint64),
+                ("state", C.c_uint64), ("numel", C.c_int64)]
+
+
 class TzrZchModule(C.Structure):
     _fields_ = [("keys", C.c_uint64), ("rows", C.c_uint64), ("counts", C.c_uint64), ("last_iter", C.c_uint64),
                 ("capacity", C.c_int64), ("zch_size", C.c_int64), ("reserved", C.c_int64 * 2)]
@@ -105,6 +110,9 @@ _SIGNATURES = {
                                        _i32, _vp, _i64, _vp, _i64, _vp]),
     "tzr_jagged_to_padded_dense": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, C.c_float, _vp, _vp]),
     "tzr_padded_dense_to_jagged": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
+    "tzr_bce_logits_workspace": (_sz, [_i64]),
+    "tzr_bce_logits": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "tzr_dense_adam": (_i32, [_vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "tzr_zch_remap": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "tzr_zch_build": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "tzr_fm_fwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),

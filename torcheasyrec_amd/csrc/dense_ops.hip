@@ -1,0 +1,187 @@
+// Dense glue of a training step that PyTorch issues as dozens of 3-5 us launches at B = 65536:
+//
+//   tzr_bce_logits   BCEWithLogitsLoss(reduction="mean") forward AND d(loss)/d(logits) in two launches
+//                    (reference: /root/reference/tzrec/models/rank_model.py:190-191,233-240 builds
+//                    torch.nn.BCEWithLogitsLoss; PyTorch runs it as ~12 elementwise / reduce kernels
+//                    forward + backward, ~55 us per step)
+//   tzr_dense_adam   Adam over every dense parameter tensor in two launches (reference: the dense
+//                    optimizer stepped by TZRecOptimizer, /root/reference/tzrec/optim/optimizer.py:56-68,
+//                    built from `adam_optimizer` in optimizer_builder.py; torch's fused multi-tensor
+//                    Adam + its foreach helpers cost ~40 us for DLRM's 54 k parameters)
+//
+// Both are bandwidth-trivial (<1 MB); what they buy is launch count.  Deterministic: fixed-order
+// reductions, no float atomics.
+#include "tzr_common.h"
+
+#define DN_THREADS 256
+#define DN_ITEMS 4  // logits per thread
+#define DN_MAX_PARTS 4096
+
+// Stage 1: one logit per thread-item, per-workgroup partial sums in a fixed tree; stage 2: one
+// workgroup adds the partials in index order.  (A single workgroup walking all B logits is
+// latency-bound: 64 dependent round trips at B = 65536, measured slower than torch's 12 launches.)
+template <typename LabelT>
+__global__ __launch_bounds__(DN_THREADS) void tzr_bce_logits_kernel(
+    const float* __restrict__ logits, const LabelT* __restrict__ labels,
+    const float* __restrict__ sample_weight, int64_t B, int64_t per_wg, float* __restrict__ parts,
+    float* __restrict__ grad) {
+  __shared__ float part[DN_THREADS / TZR_WAVE];
+  const float inv = 1.0f / (float)B;
+  float acc = 0.f;
+  const int64_t lo = (int64_t)blockIdx.x * per_wg;
+  const int64_t hi = min(B, lo + per_wg);
+  for (int64_t base = lo; base < hi; base += DN_THREADS * DN_ITEMS) {
+    float x[DN_ITEMS], y[DN_ITEMS], w[DN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DN_ITEMS; ++j) {  // independent loads first
+      const int64_t i = base + (int64_t)j * DN_THREADS + threadIdx.x;
+      const bool ok = i < hi;
+      x[j] = ok ? logits[i] : 0.f;
+      y[j] = ok ? (float)labels[i] : 0.f;
+      w[j] = ok ? (sample_weight ? sample_weight[i] : 1.0f) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < DN_ITEMS; ++j) {
+      const int64_t i = base + (int64_t)j * DN_THREADS + threadIdx.x;
+      if (i >= hi) continue;
+      // loss = max(x,0) - x*y + log1p(exp(-|x|));  d/dx = sigmoid(x) - y
+      const float e = expf(-fabsf(x[j]));
+      acc += w[j] * (fmaxf(x[j], 0.f) - x[j] * y[j] + log1pf(e));
+      const float sig = x[j] >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+      grad[i] = w[j] * (sig - y[j]) * inv;
+    }
+  }
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  for (int d = TZR_WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, TZR_WAVE);
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int i = 0; i < DN_THREADS / TZR_WAVE; ++i) v += part[i];
+    parts[blockIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void tzr_bce_finish_kernel(const float* __restrict__ parts, int n,
+                                                                     float inv, float* __restrict__ loss) {
+  __shared__ float part[DN_THREADS / TZR_WAVE];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += DN_THREADS) acc += parts[i];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  for (int d = TZR_WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, TZR_WAVE);
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int i = 0; i < DN_THREADS / TZR_WAVE; ++i) v += part[i];
+    *loss = v * inv;
+  }
+}
+
+extern "C" size_t tzr_bce_logits_workspace(int64_t B) {
+  (void)B;
+  return (size_t)DN_MAX_PARTS * sizeof(float) + 256;
+}
+
+extern "C" int tzr_bce_logits(const float* d_logits, const void* d_labels, int labels_itemsize,
+                              int labels_are_float, const float* d_sample_weight, int64_t B,
+                              float* d_loss, float* d_grad_logits, void* ws, size_t ws_bytes,
+                              void* stream) {
+  if (!d_logits || !d_labels || !d_loss || !d_grad_logits || B <= 0) return TZR_ERR_INVALID;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < (size_t)DN_MAX_PARTS * sizeof(float))
+    return TZR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* parts = static_cast<float*>(ws);
+  const int64_t tile = DN_THREADS * DN_ITEMS;
+  int64_t n_wg = (B + tile - 1) / tile;
+  int64_t per_wg = tile;
+  if (n_wg > DN_MAX_PARTS) {  // very large batches: several tiles per workgroup
+    per_wg = ((B + DN_MAX_PARTS - 1) / DN_MAX_PARTS + tile - 1) / tile * tile;
+    n_wg = (B + per_wg - 1) / per_wg;
+  }
+#define TZR_BCE_LAUNCH(T)                                                                          \
+  hipLaunchKernelGGL(tzr_bce_logits_kernel<T>, dim3((unsigned)n_wg), dim3(DN_THREADS), 0, s, d_logits, \
+                     static_cast<const T*>(d_labels), d_sample_weight, B, per_wg, parts, d_grad_logits)
+  if (labels_are_float && labels_itemsize == 4) TZR_BCE_LAUNCH(float);
+  else if (!labels_are_float && labels_itemsize == 8) TZR_BCE_LAUNCH(int64_t);
+  else if (!labels_are_float && labels_itemsize == 4) TZR_BCE_LAUNCH(int32_t);
+  else return TZR_ERR_UNSUPPORTED;
+#undef TZR_BCE_LAUNCH
+  hipLaunchKernelGGL(tzr_bce_finish_kernel, dim3(1), dim3(DN_THREADS), 0, s, parts, (int)n_wg,
+                     1.0f / (float)B, d_loss);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------
+
+struct AdamTable {
+  TzrAdamTensor t[TZR_ADAM_MAX_TENSORS];
+  int n;
+};
+
+// Per tensor, state[0] = step (float, as torch keeps it for capturable optimizers; torch counts
+// steps per PARAMETER, so a tensor skipped for lack of a gradient does not age), [1] = 1 - b1^step,
+// [2] = 1 - b2^step.  A launch of its own so every workgroup of the apply reads ONE consistent step.
+__global__ __launch_bounds__(256) void tzr_adam_begin_kernel(AdamTable T, float b1, float b2) {
+  if ((int)threadIdx.x >= T.n) return;
+  float* state = reinterpret_cast<float*>(T.t[threadIdx.x].state);
+  const float step = state[0] + 1.0f;
+  state[0] = step;
+  state[1] = 1.0f - powf(b1, step);
+  state[2] = 1.0f - powf(b2, step);
+}
+
+__global__ __launch_bounds__(256) void tzr_adam_apply_kernel(AdamTable T, const float* __restrict__ lr_ptr,
+                                                             float lr_host, float b1, float b2, float eps,
+                                                             float weight_decay) {
+  const TzrAdamTensor a = T.t[blockIdx.y];
+  float* __restrict__ p = reinterpret_cast<float*>(a.param);
+  const float* __restrict__ g = reinterpret_cast<const float*>(a.grad);
+  float* __restrict__ m = reinterpret_cast<float*>(a.exp_avg);
+  float* __restrict__ v = reinterpret_cast<float*>(a.exp_avg_sq);
+  const float* __restrict__ state = reinterpret_cast<const float*>(a.state);
+  const float lr = lr_ptr ? *lr_ptr : lr_host;
+  const float bc1 = state[1], bc2 = state[2];
+  const float step_size = lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);  // L2 (torch.optim.Adam semantics)
+    const float mi = fmaf(1.0f - b1, gi - m[i], m[i]);          // lerp, as torch's fused kernel
+    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+extern "C" int tzr_dense_adam(const TzrAdamTensor* h_tensors, int n_tensors, const float* d_lr,
+                              float lr, float beta1, float beta2, float eps, float weight_decay,
+                              void* stream) {
+  if (!h_tensors || n_tensors <= 0) return TZR_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int base = 0; base < n_tensors; base += TZR_ADAM_MAX_TENSORS) {
+    AdamTable T;
+    T.n = std::min(TZR_ADAM_MAX_TENSORS, n_tensors - base);
+    int64_t mx = 0;
+    for (int i = 0; i < T.n; ++i) {
+      T.t[i] = h_tensors[base + i];
+      if (!T.t[i].param || !T.t[i].grad || !T.t[i].exp_avg || !T.t[i].exp_avg_sq || !T.t[i].state ||
+          T.t[i].numel < 0)
+        return TZR_ERR_INVALID;
+      mx = std::max(mx, T.t[i].numel);
+    }
+    hipLaunchKernelGGL(tzr_adam_begin_kernel, dim3(1), dim3(256), 0, s, T, beta1, beta2);
+    if (mx == 0) continue;
+    const unsigned gx = (unsigned)std::min<int64_t>(1024, (mx + 255) / 256);
+    hipLaunchKernelGGL(tzr_adam_apply_kernel, dim3(gx, (unsigned)T.n), dim3(256), 0, s, T, d_lr, lr, beta1,
+                       beta2, eps, weight_decay);
+  }
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

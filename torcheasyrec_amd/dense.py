@@ -1,0 +1,115 @@
+"""Dense glue of a training step behind the C ABI: fused BCE-with-logits (loss + gradient in one
+two launches) and a two-launch Adam over all dense parameters.
+
+At DLRM-Criteo's batch 65536 PyTorch runs BCEWithLogitsLoss forward+backward as ~12 and fused Adam as
+~4 launches of 3-5 us each (profiles/r01e/kernel_stats.csv); under a captured hipGraph that is pure
+launch serialisation.  Same math as the torch ops they replace
+(/root/reference/tzrec/models/rank_model.py:190-191,233-240; /root/reference/tzrec/optim/optimizer.py:56-68):
+tests compare against torch to 1e-6.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import _lib
+
+
+class _BceLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, sample_weight):
+        x = logits.contiguous().float()
+        y = labels.contiguous()
+        if y.dtype not in (torch.float32, torch.int32, torch.int64):
+            y = y.float()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        w = None if sample_weight is None else sample_weight.contiguous().float()
+        L = _lib.lib()
+        ws = _lib.workspace(L.tzr_bce_logits_workspace(x.numel()), x.device)
+        _lib.check(L.tzr_bce_logits(_lib.ptr(x), _lib.ptr(y), y.element_size(), 1 if y.is_floating_point() else 0,
+                                    _lib.ptr(w), x.numel(), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), ws.numel(),
+                                    _lib.stream_ptr(x.device)), "tzr_bce_logits")
+        ctx.save_for_backward(grad)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return (grad * grad_out).view(ctx.shape), None, None
+
+
+def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor, sample_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BCEWithLogitsLoss(reduction="mean"); with `sample_weight`: mean(loss_i * w_i)."""
+    return _BceLogitsFn.apply(logits, labels, sample_weight)
+
+
+class FusedDenseAdam:
+    """torch.optim.Adam (amsgrad off) for the dense parameters, two launches per step regardless of the
+    number of tensors.  `param_groups[0]["lr"]` may be changed between steps (it is mirrored into a
+    device scalar, so a captured hipGraph sees the new value)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0) -> None:
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
+                raise ValueError("FusedDenseAdam needs contiguous float32 parameters on one device")
+        self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay),
+                              "params": self.params}]
+        self.device = dev
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self._state = torch.zeros(len(self.params), 3, dtype=torch.float32, device=dev)  # per tensor: step, 1-b1^t, 1-b2^t
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self._lr_host = float(lr)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self, grads: Optional[List[torch.Tensor]] = None) -> None:
+        g = self.param_groups[0]
+        if g["lr"] != self._lr_host:
+            self._lr_dev.fill_(g["lr"])
+            self._lr_host = g["lr"]
+        rows = []
+        for i, p in enumerate(self.params):
+            gr = p.grad if grads is None else grads[i]
+            if gr is None:
+                continue
+            if gr.dtype != torch.float32 or not gr.is_contiguous():
+                gr = gr.contiguous().float()
+            rows.append((p, gr, self.exp_avg[i], self.exp_avg_sq[i], self._state[i]))
+        if not rows:
+            return
+        tab = (_lib.TzrAdamTensor * len(rows))()
+        for i, (p, gr, m, v, st) in enumerate(rows):
+            tab[i].param, tab[i].grad, tab[i].exp_avg, tab[i].exp_avg_sq = _lib.ptr(p.data), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v)
+            tab[i].state, tab[i].numel = _lib.ptr(st), p.numel()
+        b1, b2 = g["betas"]
+        _lib.check(_lib.lib().tzr_dense_adam(tab, len(rows), _lib.ptr(self._lr_dev), g["lr"], b1, b2,
+                                             g["eps"], g["weight_decay"], _lib.stream_ptr(self.device)), "tzr_dense_adam")
+
+    def state_dict(self) -> dict:
+        return {"state": {i: {"step": self._state[i, 0].clone(), "exp_avg": m, "exp_avg_sq": v}
+                          for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq))},
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        b1, b2 = self.param_groups[0]["betas"]
+        for i, st in sd["state"].items():
+            self.exp_avg[int(i)].copy_(st["exp_avg"])
+            self.exp_avg_sq[int(i)].copy_(st["exp_avg_sq"])
+            t = float(st["step"])
+            self._state[int(i)] = torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t])
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = v

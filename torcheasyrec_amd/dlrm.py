@@ -147,5 +147,8 @@ class DeepFM(nn.Module):
 
 
 def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-    """BCEWithLogitsLoss(reduction="mean") on float labels (rank_model.py:190-191,233-240)."""
-    return nn.functional.binary_cross_entropy_with_logits(logits, labels.float(), reduction="mean")
+    """BCEWithLogitsLoss(reduction="mean") (rank_model.py:190-191,233-240): loss and d(loss)/d(logits)
+    from one launch of `tzr_bce_logits` (torcheasyrec_amd/dense.py) instead of ~12 torch kernels."""
+    from .dense import bce_with_logits as fused
+
+    return fused(logits, labels)
