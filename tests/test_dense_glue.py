@@ -57,3 +57,26 @@ def test_adam_follows_torch_adam(dev, wd):
     o2.load_state_dict(sd)
     assert o2.param_groups[0]["lr"] == 3e-3 and float(o2._state[0, 0]) == 7.0 and float(o2._state[2, 0]) == 6.0
     assert torch.equal(o2.exp_avg[4], o.exp_avg[4])
+
+
+@pytest.mark.gpu
+def test_mlp_with_relu_in_the_gemm_epilogue_matches_linear_then_relu():
+    from torcheasyrec_amd import dlrm
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    mlp = dlrm.MLP(37, [64, 16]).to(dev)
+    x = torch.randn(513, 37, device=dev, requires_grad=True)
+    g = torch.randn(513, 16, device=dev)
+    out = {}
+    for fused in (True, False):
+        dlrm._FUSED_RELU = fused
+        for p in mlp.parameters():
+            p.grad = None
+        x.grad = None
+        y = mlp(x)
+        (y * g).sum().backward()
+        out[fused] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in mlp.parameters()]
+    dlrm._FUSED_RELU = True
+    for a, b in zip(out[True], out[False]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
