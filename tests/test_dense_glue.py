@@ -80,3 +80,25 @@ def test_mlp_with_relu_in_the_gemm_epilogue_matches_linear_then_relu():
     dlrm._FUSED_RELU = True
     for a, b in zip(out[True], out[False]):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_output_layer_as_gemv_matches_linear():
+    from torcheasyrec_amd import dlrm
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    lin = dlrm.OutputLinear(32, 1).to(dev)
+    x = torch.randn(1000, 32, device=dev, requires_grad=True)
+    g = torch.randn(1000, device=dev)
+    out = {}
+    for fast in (True, False):
+        dlrm._GEMV_OUTPUT = fast
+        lin.weight.grad = lin.bias.grad = x.grad = None
+        y = lin(x).squeeze(1)
+        (y * g).sum().backward()
+        out[fast] = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    dlrm._GEMV_OUTPUT = True
+    for a, b in zip(out[True], out[False]):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)  # 1000-term fp32 sums in a different order

@@ -20,6 +20,7 @@ from .sparse import KeyedJaggedTensor
 
 import os
 
+_GEMV_OUTPUT = os.environ.get("TZR_OUTPUT_GEMV", "1") == "1"  # A/B switch (name kept from the gemv experiment)
 _FUSED_RELU = os.environ.get("TZR_MLP_FUSED_RELU", "1") == "1"  # A/B switch; measured -23 us per DLRM step
 
 
@@ -39,6 +40,33 @@ class _LinearReluFn(torch.autograd.Function):
         g = torch.ops.aten.threshold_backward(gy, y, 0.0)
         gx = g @ weight if ctx.needs_input_grad[0] else None
         return gx, g.t() @ x, g.sum(0)
+
+
+class _Linear1Fn(torch.autograd.Function):
+    """Linear with ONE output unit.  Autograd's weight gradient for nn.Linear is gy^T @ x, a
+    [1, B] x [B, in] GEMM: one output tile and a 65536-long reduction -- 68 us on hipBLASLt at
+    B = 65536 for 8 MB of input (rocBLAS gemv is worse: ~380 us).  A broadcast multiply and a column
+    sum do it in two short launches."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        return gx, (x * gy).sum(0, keepdim=True), gy.sum(0)
+
+
+class OutputLinear(nn.Linear):
+    """The logits layer (same parameters / state_dict keys as nn.Linear)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _GEMV_OUTPUT and self.out_features == 1 and x.is_cuda and x.dim() == 2 and self.bias is not None:
+            return _Linear1Fn.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 class MLP(nn.Module):
@@ -102,7 +130,7 @@ class DLRM(nn.Module):
         n = self.num_sparse + 1
         feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
         self.final_mlp = MLP(feat, final_mlp)
-        self.output_mlp = nn.Linear(self.final_mlp.output_dim(), num_class)
+        self.output_mlp = OutputLinear(self.final_mlp.output_dim(), num_class)
         if device is not None:
             self.dense_mlp.to(device)
             self.final_mlp.to(device)
@@ -151,7 +179,7 @@ class DeepFM(nn.Module):
         if final_mlp:
             self.final_mlp = MLP(1 + fm_dim + final_dim, final_mlp)
             final_dim = self.final_mlp.output_dim()
-        self.output_mlp = nn.Linear(final_dim, num_class)
+        self.output_mlp = OutputLinear(final_dim, num_class)
         if device is not None:
             self.to(device)
 

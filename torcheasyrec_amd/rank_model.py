@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .config import PipelineSpec
-from .dlrm import MLP
+from .dlrm import MLP, OutputLinear
 from .embedding import SparseOptimizerConfig
 from .embedding_group import Batch, EmbeddingGroup
 from .interaction import FactorizationMachine, dot_interaction
@@ -71,7 +71,7 @@ class ConfigDLRM(RankModel):
         n = self._num_sparse + (1 if self.dense_mlp else 0)
         feat = n * (n - 1) // 2 + (self._dim if self.dense_mlp else 0) + (self._num_sparse * self._dim if self._arch_with_sparse else 0)
         self.final_mlp = MLP(feat, [int(x) for x in m.one("final").many("hidden_units")])
-        self.output_mlp = nn.Linear(self.final_mlp.output_dim(), spec.num_class)
+        self.output_mlp = OutputLinear(self.final_mlp.output_dim(), spec.num_class)
         if device is not None:
             for mod in (self.dense_mlp, self.final_mlp, self.output_mlp):
                 if mod is not None:
@@ -100,7 +100,7 @@ class ConfigDeepFM(RankModel):
         if m.has("final"):
             self.final_mlp = MLP(1 + self._fm_dim + final_dim, [int(x) for x in m.one("final").many("hidden_units")])
             final_dim = self.final_mlp.output_dim()
-        self.output_mlp = nn.Linear(final_dim, spec.num_class)
+        self.output_mlp = OutputLinear(final_dim, spec.num_class)
         if device is not None:
             for mod in (self.deep_mlp, self.final_mlp, self.output_mlp):
                 if mod is not None:

@@ -42,7 +42,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import _lib
-from .dlrm import MLP
+from .dlrm import MLP, OutputLinear
 from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
                         _WD_MODE)
 from .interaction import dot_interaction
@@ -589,7 +589,7 @@ class ShardedDLRM(nn.Module):
         n = self.num_sparse + 1
         feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
         self.final_mlp = MLP(feat, final_mlp).to(device)
-        self.output_mlp = nn.Linear(final_mlp[-1], 1).to(device)
+        self.output_mlp = OutputLinear(final_mlp[-1], 1).to(device)
         # the bottom MLP does not depend on the exchange: on a GPU it runs on a second HIP stream
         # while the id / row all-to-alls are in flight
         self.overlap_dense = True
