@@ -257,6 +257,15 @@ int tzr_bce_logits(const float* d_logits, const void* d_labels, int labels_items
                    int labels_are_float, const float* d_sample_weight, int64_t B, float* d_loss,
                    float* d_grad_logits, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of a Linear+ReLU layer up to the GEMMs: d_grad[b,n] = d_grad_y[b,n] * (d_y[b,n] > 0)
+ * and d_colsum[n] = sum_b d_grad[b,n] (the bias gradient), one pass.  Replaces
+ * threshold_backward + sum(0) in the autograd of tzrec/modules/mlp.py:37-177 (Perceptron =
+ * Linear + ReLU).  N multiple of 4, <= 1024; strides in floats, multiples of 4. */
+size_t tzr_relu_bwd_colsum_workspace(int64_t B, int N);
+int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const float* d_y,
+                        int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
+                        float* d_colsum, void* ws, size_t ws_bytes, void* stream);
+
 #define TZR_ADAM_MAX_TENSORS 32
 typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, float32 */
   uint64_t param, grad, exp_avg, exp_avg_sq;

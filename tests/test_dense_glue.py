@@ -102,3 +102,17 @@ def test_output_layer_as_gemv_matches_linear():
     for a, b in zip(out[True], out[False]):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)  # 1000-term fp32 sums in a different order
+
+
+@pytest.mark.parametrize("B,N", [(1, 4), (37, 16), (1000, 64), (5000, 32), (300, 1024), (70000, 8)])
+def test_relu_bwd_colsum_matches_torch(dev, B, N):
+    from torcheasyrec_amd.dense import relu_bwd_colsum
+
+    g = torch.Generator().manual_seed(B + N)
+    y = torch.relu(torch.randn(B, N, generator=g))
+    gy_full = torch.randn(B, N + 4, generator=g)
+    gy = gy_full[:, :N]  # row-strided input
+    ref = gy * (y > 0)
+    got, col = relu_bwd_colsum(gy.to(dev) if dev.type != "cpu" else gy, y.to(dev))
+    assert torch.equal(got.cpu(), ref)
+    torch.testing.assert_close(col.cpu().double(), ref.double().sum(0), rtol=1e-5, atol=1e-5 * (B ** 0.5))

@@ -9,7 +9,9 @@
 //                    built from `adam_optimizer` in optimizer_builder.py; torch's fused multi-tensor
 //                    Adam + its foreach helpers cost ~40 us for DLRM's 54 k parameters)
 //
-// Both are bandwidth-trivial (<1 MB); what they buy is launch count.  Deterministic: fixed-order
+//   tzr_relu_bwd_colsum  ReLU backward and the bias gradient of a Linear+ReLU layer from one pass
+//
+// They are bandwidth-light; what they buy is launch count and one re-read of the gradient.  Deterministic: fixed-order
 // reductions, no float atomics.
 #include "tzr_common.h"
 
@@ -111,6 +113,123 @@ extern "C" int tzr_bce_logits(const float* d_logits, const void* d_labels, int l
 #undef TZR_BCE_LAUNCH
   hipLaunchKernelGGL(tzr_bce_finish_kernel, dim3(1), dim3(DN_THREADS), 0, s, parts, (int)n_wg,
                      1.0f / (float)B, d_loss);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- ReLU backward + bias gradient ---------------------------------------------------------------
+// g = gy * (y > 0) and colsum[n] = sum_b g[b, n] from one pass over gy / y (PyTorch: threshold_backward
+// then a separate column reduction that re-reads g).  Row tiles accumulate per-thread column sums in a
+// fixed order, workgroup partials go to the workspace, a second launch adds them in index order.
+#define RB_THREADS 256
+#define RB_MAX_WG 1024
+
+#define RB_UNROLL 4
+__global__ __launch_bounds__(RB_THREADS) void tzr_relu_bwd_colsum_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ y, int64_t y_stride,
+    int64_t B, int N, int64_t rows_per_wg, float* __restrict__ g, int64_t g_stride,
+    float* __restrict__ parts) {
+  // thread -> (row lane r, float4 column c): N4 = N/4 column groups, RB_THREADS / N4 rows per sweep,
+  // RB_UNROLL sweeps loaded before any is used (these kernels are latency-, not bandwidth-bound)
+  __shared__ float4 red[RB_THREADS];
+  const int N4 = N >> 2;
+  const int rl = RB_THREADS / N4;
+  const int c = threadIdx.x % N4;
+  const int r = threadIdx.x / N4;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = min(B, lo + rows_per_wg);
+  float4 acc = tzr_zero4();
+  if (r < rl) {
+    for (int64_t b0 = lo + r; b0 < hi; b0 += (int64_t)rl * RB_UNROLL) {
+      float4 a[RB_UNROLL], v[RB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        a[u] = b < hi ? tzr_ld4(gy + b * gy_stride + 4 * c) : tzr_zero4();
+        v[u] = b < hi ? tzr_ld4(y + b * y_stride + 4 * c) : tzr_zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        if (b >= hi) continue;
+        float4 o;
+        o.x = v[u].x > 0.f ? a[u].x : 0.f;
+        o.y = v[u].y > 0.f ? a[u].y : 0.f;
+        o.z = v[u].z > 0.f ? a[u].z : 0.f;
+        o.w = v[u].w > 0.f ? a[u].w : 0.f;
+        tzr_st4(g + b * g_stride + 4 * c, o);
+        acc = tzr_add4(acc, o);
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (r == 0 && c < N4) {  // fixed order over the row lanes
+    float4 t = red[c];
+    for (int k = 1; k < rl; ++k) t = tzr_add4(t, red[k * N4 + c]);
+    tzr_st4(parts + (size_t)blockIdx.x * N + 4 * c, t);
+  }
+}
+
+// Column sums of parts[n_wg][N]: one workgroup per 64 columns, 16 slices of the partials per column
+// summed concurrently with 8 independent loads in flight each (a serial walk over 1024 partials is
+// 60 us of pure latency), then combined in slice order.
+#define RB_FIN_THREADS 1024
+__global__ __launch_bounds__(RB_FIN_THREADS) void tzr_colsum_finish_kernel(const float* __restrict__ parts,
+                                                                            int n_wg, int N,
+                                                                            float* __restrict__ out) {
+  __shared__ float red[RB_FIN_THREADS];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;  // 0..15
+  float t = 0.f;
+  if (col < N) {
+    for (int k0 = slice; k0 < n_wg; k0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 16 * u;
+        v[u] = k < n_wg ? parts[(size_t)k * N + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+  }
+  red[threadIdx.x] = t;
+  __syncthreads();
+  if (slice == 0 && col < N) {
+    float r = 0.f;
+    for (int sl = 0; sl < 16; ++sl) r += red[sl * 64 + (threadIdx.x & 63)];
+    out[col] = r;
+  }
+}
+
+extern "C" size_t tzr_relu_bwd_colsum_workspace(int64_t B, int N) {
+  (void)B;
+  return (size_t)RB_MAX_WG * (size_t)std::max(N, 4) * sizeof(float) + 256;
+}
+
+extern "C" int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const float* d_y,
+                                   int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
+                                   float* d_colsum, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_grad_y || !d_y || !d_grad || !d_colsum || B <= 0 || N <= 0) return TZR_ERR_INVALID;
+  if ((N & 3) || N > 4 * RB_THREADS || (grad_y_stride & 3) || (y_stride & 3) || (grad_stride & 3))
+    return TZR_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_relu_bwd_colsum_workspace(B, N) - 256)
+    return TZR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rl = RB_THREADS / (N >> 2);
+  // one unrolled batch of sweeps per workgroup, at most RB_MAX_WG workgroups
+  int64_t rows_per_wg = (int64_t)rl * RB_UNROLL;
+  int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  if (n_wg > RB_MAX_WG) {
+    rows_per_wg = ((B + RB_MAX_WG - 1) / RB_MAX_WG + rl * RB_UNROLL - 1) / (rl * RB_UNROLL) * (rl * RB_UNROLL);
+    n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  }
+  float* parts = static_cast<float*>(ws);
+  hipLaunchKernelGGL(tzr_relu_bwd_colsum_kernel, dim3((unsigned)n_wg), dim3(RB_THREADS), 0, s, d_grad_y,
+                     grad_y_stride, d_y, y_stride, B, N, rows_per_wg, d_grad, grad_stride, parts);
+  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts,
+                     (int)n_wg, N, d_colsum);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

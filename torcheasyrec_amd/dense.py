@@ -46,6 +46,19 @@ def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor, sample_weight: O
     return _BceLogitsFn.apply(logits, labels, sample_weight)
 
 
+def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor):
+    """(grad_y * (y > 0), its column sums): ReLU backward + bias gradient of a Linear+ReLU layer."""
+    B, N = y.shape
+    gy = grad_y if grad_y.stride(1) == 1 else grad_y.contiguous()
+    g = torch.empty(B, N, dtype=torch.float32, device=y.device)
+    col = torch.empty(N, dtype=torch.float32, device=y.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_relu_bwd_colsum_workspace(B, N), y.device)
+    _lib.check(L.tzr_relu_bwd_colsum(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
+                                     _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum")
+    return g, col
+
+
 class FusedDenseAdam:
     """torch.optim.Adam (amsgrad off) for the dense parameters, two launches per step regardless of the
     number of tensors.  `param_groups[0]["lr"]` may be changed between steps (it is mirrored into a

@@ -21,6 +21,7 @@ from .sparse import KeyedJaggedTensor
 import os
 
 _GEMV_OUTPUT = os.environ.get("TZR_OUTPUT_GEMV", "1") == "1"  # A/B switch (name kept from the gemv experiment)
+_FUSED_RELU_BWD = os.environ.get("TZR_MLP_FUSED_RELU_BWD", "1") == "1"  # A/B switch
 _FUSED_RELU = os.environ.get("TZR_MLP_FUSED_RELU", "1") == "1"  # A/B switch; measured -23 us per DLRM step
 
 
@@ -37,9 +38,15 @@ class _LinearReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        if _FUSED_RELU_BWD and y.shape[1] % 4 == 0 and y.shape[1] <= 1024 and gy.dtype == torch.float32:
+            from .dense import relu_bwd_colsum
+
+            g, gb = relu_bwd_colsum(gy, y)  # mask + bias gradient in one pass (tzr_relu_bwd_colsum)
+        else:
+            g = torch.ops.aten.threshold_backward(gy, y, 0.0)
+            gb = g.sum(0)
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        return gx, g.t() @ x, g.sum(0)
+        return gx, g.t() @ x, gb
 
 
 class _Linear1Fn(torch.autograd.Function):
