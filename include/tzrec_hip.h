@@ -266,6 +266,14 @@ int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const floa
                         int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
                         float* d_colsum, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of the one-unit logits layer y = x w^T + b (tzrec/models/rank_model.py output layer
+ * with num_class 1): d_grad_x[b,:] = gy[b] * w (nullable), d_grad_wb[0:N] = sum_b gy[b] * x[b,:],
+ * d_grad_wb[N] = sum_b gy[b] (d_grad_wb holds N + 4 floats).  One pass over x. */
+size_t tzr_head_bwd_workspace(int64_t B, int N);
+int tzr_head_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                 const float* d_w, int64_t B, int N, float* d_grad_x, int64_t grad_x_stride,
+                 float* d_grad_wb, void* ws, size_t ws_bytes, void* stream);
+
 #define TZR_ADAM_MAX_TENSORS 32
 typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, float32 */
   uint64_t param, grad, exp_avg, exp_avg_sq;

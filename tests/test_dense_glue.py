@@ -110,9 +110,26 @@ def test_relu_bwd_colsum_matches_torch(dev, B, N):
 
     g = torch.Generator().manual_seed(B + N)
     y = torch.relu(torch.randn(B, N, generator=g))
-    gy_full = torch.randn(B, N + 4, generator=g)
-    gy = gy_full[:, :N]  # row-strided input
+    gy_full = torch.randn(B, N + 5, generator=g)
+    gy = gy_full[:, 1:N + 1] if B % 2 else gy_full[:, :N]  # row-strided; odd B: misaligned rows as well
     ref = gy * (y > 0)
     got, col = relu_bwd_colsum(gy.to(dev) if dev.type != "cpu" else gy, y.to(dev))
     assert torch.equal(got.cpu(), ref)
     torch.testing.assert_close(col.cpu().double(), ref.double().sum(0), rtol=1e-5, atol=1e-5 * (B ** 0.5))
+
+
+@pytest.mark.parametrize("B,N", [(1, 4), (999, 32), (3000, 64), (70000, 8)])
+def test_head_bwd_matches_torch(dev, B, N):
+    from torcheasyrec_amd.dense import head_bwd
+
+    g = torch.Generator().manual_seed(B * 7 + N)
+    x = torch.randn(B, N, generator=g)
+    w = torch.randn(1, N, generator=g)
+    gy = torch.randn(B, 1, generator=g) / B
+    gx, gw, gb = head_bwd(gy.to(dev), x.to(dev), w.to(dev))
+    assert gx.shape == (B, N) and gw.shape == (1, N) and gb.shape == (1,)
+    torch.testing.assert_close(gx.cpu(), gy @ w, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(gw.cpu().double(), gy.double().t() @ x.double(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(gb.cpu().double(), gy.double().sum(0), rtol=1e-4, atol=1e-7)
+    gx2, _, _ = head_bwd(gy.to(dev), x.to(dev), w.to(dev), need_grad_x=False)
+    assert gx2 is None

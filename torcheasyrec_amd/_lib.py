@@ -114,6 +114,8 @@ _SIGNATURES = {
     "tzr_bce_logits": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tzr_relu_bwd_colsum_workspace": (_sz, [_i64, _i32]),
     "tzr_relu_bwd_colsum": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_head_bwd_workspace": (_sz, [_i64, _i32]),
+    "tzr_head_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_dense_adam": (_i32, [_vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "tzr_zch_remap": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "tzr_zch_build": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -234,6 +234,90 @@ extern "C" int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride,
   return TZR_OK;
 }
 
+// ---- backward of the one-unit logits layer ---------------------------------------------------------
+// y = x w^T + b with ONE output unit: gx[b,:] = gy[b] * w, gw[n] = sum_b gy[b] * x[b,n], gb = sum_b gy[b]
+// from one pass over x (PyTorch: a GEMM, a broadcast multiply and two reductions, ~35 us at B = 65536).
+__global__ __launch_bounds__(RB_THREADS) void tzr_head_bwd_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ x, int64_t x_stride,
+    const float* __restrict__ w, int64_t B, int N, int64_t rows_per_wg, float* __restrict__ gx,
+    int64_t gx_stride, float* __restrict__ parts /*[n_wg][N + 4]*/) {
+  __shared__ float4 red[RB_THREADS];
+  __shared__ float redb[RB_THREADS];
+  const int N4 = N >> 2;
+  const int rl = RB_THREADS / N4;
+  const int c = threadIdx.x % N4;
+  const int r = threadIdx.x / N4;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = min(B, lo + rows_per_wg);
+  float4 acc = tzr_zero4();
+  float accb = 0.f;
+  if (r < rl) {
+    const float4 w4 = tzr_ld4(w + 4 * c);
+    for (int64_t b0 = lo + r; b0 < hi; b0 += (int64_t)rl * RB_UNROLL) {
+      float4 v[RB_UNROLL];
+      float gs[RB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        v[u] = b < hi ? tzr_ld4(x + b * x_stride + 4 * c) : tzr_zero4();
+        gs[u] = b < hi ? gy[b * gy_stride] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        if (b >= hi) continue;
+        if (gx) tzr_st4(gx + b * gx_stride + 4 * c, make_float4(gs[u] * w4.x, gs[u] * w4.y, gs[u] * w4.z, gs[u] * w4.w));
+        acc = tzr_fma4(gs[u], v[u], acc);
+        if (c == 0) accb += gs[u];
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  redb[threadIdx.x] = accb;
+  __syncthreads();
+  if (r == 0 && c < N4) {
+    float4 t = red[c];
+    for (int k = 1; k < rl; ++k) t = tzr_add4(t, red[k * N4 + c]);
+    tzr_st4(parts + (size_t)blockIdx.x * (N + 4) + 4 * c, t);
+    if (c == 0) {
+      float tb = 0.f;
+      for (int k = 0; k < rl; ++k) tb += redb[k * N4];
+      float* pb = parts + (size_t)blockIdx.x * (N + 4) + N;
+      pb[0] = tb;
+      pb[1] = pb[2] = pb[3] = 0.f;
+    }
+  }
+}
+
+extern "C" size_t tzr_head_bwd_workspace(int64_t B, int N) {
+  (void)B;
+  return (size_t)RB_MAX_WG * (size_t)(N + 4) * sizeof(float) + 256;
+}
+
+extern "C" int tzr_head_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                            const float* d_w, int64_t B, int N, float* d_grad_x, int64_t grad_x_stride,
+                            float* d_grad_wb, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_grad_y || !d_x || !d_w || !d_grad_wb || B <= 0 || N <= 0) return TZR_ERR_INVALID;
+  if ((N & 3) || N > 4 * RB_THREADS || (x_stride & 3) || (d_grad_x && (grad_x_stride & 3))) return TZR_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_head_bwd_workspace(B, N) - 256)
+    return TZR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rl = RB_THREADS / (N >> 2);
+  int64_t rows_per_wg = (int64_t)rl * RB_UNROLL;
+  int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  if (n_wg > RB_MAX_WG) {
+    rows_per_wg = ((B + RB_MAX_WG - 1) / RB_MAX_WG + rl * RB_UNROLL - 1) / (rl * RB_UNROLL) * (rl * RB_UNROLL);
+    n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  }
+  float* parts = static_cast<float*>(ws);
+  hipLaunchKernelGGL(tzr_head_bwd_kernel, dim3((unsigned)n_wg), dim3(RB_THREADS), 0, s, d_grad_y, grad_y_stride,
+                     d_x, x_stride, d_w, B, N, rows_per_wg, d_grad_x, grad_x_stride, parts);
+  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((N + 4 + 63) / 64)), dim3(RB_FIN_THREADS), 0, s,
+                     parts, (int)n_wg, N + 4, d_grad_wb);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------
 
 struct AdamTable {

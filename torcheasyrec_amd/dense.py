@@ -46,10 +46,18 @@ def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor, sample_weight: O
     return _BceLogitsFn.apply(logits, labels, sample_weight)
 
 
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """Row-major view the float4 kernels can read: unit column stride, 16-byte aligned rows (a
+    gradient slice of a torch.cat is neither)."""
+    if t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    return t.clone(memory_format=torch.contiguous_format)  # .contiguous() keeps odd strides of 1-row tensors
+
+
 def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor):
     """(grad_y * (y > 0), its column sums): ReLU backward + bias gradient of a Linear+ReLU layer."""
     B, N = y.shape
-    gy = grad_y if grad_y.stride(1) == 1 else grad_y.contiguous()
+    gy, y = _rows16(grad_y), _rows16(y)
     g = torch.empty(B, N, dtype=torch.float32, device=y.device)
     col = torch.empty(N, dtype=torch.float32, device=y.device)
     L = _lib.lib()
@@ -57,6 +65,21 @@ def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor):
     _lib.check(L.tzr_relu_bwd_colsum(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                      _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum")
     return g, col
+
+
+def head_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_grad_x: bool = True):
+    """Backward of Linear(in, 1): (grad_x [B, in] | None, grad_weight [1, in], grad_bias [1])."""
+    B, N = x.shape
+    gy = grad_y.reshape(B)
+    xs = _rows16(x)
+    gx = torch.empty(B, N, dtype=torch.float32, device=x.device) if need_grad_x else None
+    wb = torch.empty(N + 4, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_head_bwd_workspace(B, N), x.device)
+    _lib.check(L.tzr_head_bwd(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight.reshape(-1)), B, N,
+                              _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(wb), _lib.ptr(ws), ws.numel(),
+                              _lib.stream_ptr(x.device)), "tzr_head_bwd")
+    return gx, wb[:N].unsqueeze(0), wb[N:N + 1]
 
 
 class FusedDenseAdam:

@@ -21,6 +21,7 @@ from .sparse import KeyedJaggedTensor
 import os
 
 _GEMV_OUTPUT = os.environ.get("TZR_OUTPUT_GEMV", "1") == "1"  # A/B switch (name kept from the gemv experiment)
+_FUSED_HEAD_BWD = os.environ.get("TZR_FUSED_HEAD_BWD", "1") == "1"  # A/B switch
 _FUSED_RELU_BWD = os.environ.get("TZR_MLP_FUSED_RELU_BWD", "1") == "1"  # A/B switch
 _FUSED_RELU = os.environ.get("TZR_MLP_FUSED_RELU", "1") == "1"  # A/B switch; measured -23 us per DLRM step
 
@@ -63,6 +64,10 @@ class _Linear1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
+        if _FUSED_HEAD_BWD and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.dtype == torch.float32:
+            from .dense import head_bwd
+
+            return head_bwd(gy, x, weight, ctx.needs_input_grad[0])  # one pass over x (tzr_head_bwd)
         gx = gy @ weight if ctx.needs_input_grad[0] else None
         return gx, (x * gy).sum(0, keepdim=True), gy.sum(0)
 
