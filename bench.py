@@ -299,7 +299,11 @@ def main():
         dense_opt.zero_grad(set_to_none=True)
         return loss
 
-    for i in range(args.warmup):  # eager warm-up (also where TunableOp tunes unseen GEMM shapes)
+    # eager warm-up (also where TunableOp tunes unseen GEMM shapes).  Graph capture needs lazy
+    # initialisation and tuning out of the way, so at least two eager steps run even for --warmup 0/1
+    # (untimed, like the requested ones)
+    loss = None
+    for i in range(max(args.warmup, 3 if train_step is not None else (2 if use_graph else 0))):  # 3: the pipelined step captures on its 3rd call
         loss = step_body(*batches[i % nb])
     torch.cuda.synchronize()
 
@@ -402,10 +406,15 @@ def main():
             }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which a pipe buffers until exit: flush it now
+    # so the JSON line is the LAST line of stdout
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
