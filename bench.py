@@ -406,13 +406,15 @@ def main():
             }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-    if sharded:
-        dist.destroy_process_group()
-    # RCCL prints its version banner through C stdio, which a pipe buffers until exit: flush it now
-    # so the JSON line is the LAST line of stdout
+    # RCCL prints its version banner through C stdio, which a pipe buffers until exit: every rank
+    # flushes it now, then a barrier, so rank 0's JSON line is the LAST line of the job's stdout
     import ctypes
 
     ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if sharded:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
 
