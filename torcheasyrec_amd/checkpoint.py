@@ -142,7 +142,7 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
             raise ValueError(f"{name}: checkpoint has {meta['tables'][name][0]} rows, model {total}")
     m_files = [torch.load(os.path.join(checkpoint_dir, "model", f"rank{r}.pt"), mmap=True, weights_only=True)
                for r in range(saved_world)]
-    o_files = [torch.load(os.path.join(checkpoint_dir, "optimizer", f"rank{r}.pt"), mmap=True, weights_only=False)
+    o_files = [torch.load(os.path.join(checkpoint_dir, "optimizer", f"rank{r}.pt"), mmap=True, weights_only=True)
                for r in range(saved_world)]
     weights, states = ebc.table_weights(), ebc.table_states()
     with torch.no_grad():
