@@ -1,0 +1,131 @@
+"""Error behaviour of the C ABI: bad arguments come back as negative status
+codes -- never a crash, never a launch -- and degenerate sizes (empty batch, zero ids) are TZR_OK
+no-ops.  Called straight through ctypes, on the emulator build here and on the gfx950 library under
+`-m gpu`."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from torcheasyrec_amd import _lib  # noqa: E402
+
+OK, INVALID, LAUNCH, WORKSPACE, UNSUPPORTED = 0, -1, -2, -3, -4
+
+
+def _buf(dev, n, dtype=torch.float32):
+    return torch.zeros(max(n, 1), dtype=dtype, device=dev)
+
+
+def test_index_ops_reject_bad_arguments(dev):
+    L = _lib.lib()
+    lens = _buf(dev, 8, torch.int32)
+    off = _buf(dev, 9, torch.int64)
+    ws = _lib.workspace(L.tzr_lengths_to_offsets_workspace(8), dev)
+    p = _lib.ptr
+    assert L.tzr_lengths_to_offsets(p(lens), 4, 8, None, p(ws), ws.numel(), None) == INVALID
+    assert L.tzr_lengths_to_offsets(p(lens), 3, 8, p(off), p(ws), ws.numel(), None) == INVALID
+    assert L.tzr_lengths_to_offsets(None, 4, 8, p(off), p(ws), ws.numel(), None) == INVALID
+    assert L.tzr_lengths_to_offsets(p(lens), 4, 8, p(off), None, 0, None) == WORKSPACE
+    assert L.tzr_lengths_to_offsets(p(lens), 4, 8, p(off), p(ws) + 8, ws.numel() - 8, None) == WORKSPACE  # misaligned
+    assert L.tzr_lengths_to_offsets(p(lens), 4, 8, p(off), p(ws), ws.numel(), None) == OK
+    assert L.tzr_lengths_to_offsets(None, 4, 0, p(off), p(ws), ws.numel(), None) == OK  # n = 0: offsets = [0]
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert int(off[0]) == 0
+
+
+def test_pooled_forward_rejects_bad_destinations(dev):
+    L = _lib.lib()
+    tables = _buf(dev, 48, torch.uint8)
+    feats = _buf(dev, 64, torch.uint8)
+    slots = _buf(dev, 16, torch.uint8)
+    vals = _buf(dev, 4, torch.int64)
+    out = _buf(dev, 64)
+    d = (_lib.TzrDst * 9)()
+    for i in range(9):
+        d[i].ptr, d[i].stride = _lib.ptr(out), 16
+    p = _lib.ptr
+    assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, p(vals), None, None, 4, d, 9, 1, None) == INVALID  # > TZR_MAX_DST
+    assert L.tzr_pooled_fwd(None, p(feats), 1, p(slots), 1, p(vals), None, None, 4, d, 1, 1, None) == INVALID
+    assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, p(vals), None, None, 4, d, 1, 0, None) == INVALID  # jagged without offsets
+    d[0].stride = 18
+    assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, p(vals), None, None, 4, d, 1, 1, None) == INVALID  # stride % 4
+    d[0].stride, d[0].ptr = 16, _lib.ptr(out) + 4
+    assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, p(vals), None, None, 4, d, 1, 1, None) == INVALID  # 16-byte alignment
+    d[0].ptr = _lib.ptr(out)
+    assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, None, None, None, 0, d, 1, 1, None) == OK  # empty batch
+
+
+def test_backward_plan_limits(dev):
+    L = _lib.lib()
+    tables, feats = _buf(dev, 48, torch.uint8), _buf(dev, 64, torch.uint8)
+    vals = _buf(dev, 4, torch.int64)
+    ws = _lib.workspace(L.tzr_pooled_bwd_workspace(4, 4, 1, 1, 4, 16), dev)
+    p = _lib.ptr
+    assert L.tzr_pooled_bwd_workspace(-1, 4, 1, 1, 4, 16) == 0
+    assert L.tzr_pooled_bwd_plan(p(tables), 1, p(feats), 1, 1, 10, 16, p(vals), None, 1 << 32, 4, 4, 1, p(ws), ws.numel(), None) == UNSUPPORTED
+    assert L.tzr_pooled_bwd_plan(p(tables), 1, p(feats), 1, 1, 10, 16, p(vals), None, 4, 4, 4, 0, p(ws), ws.numel(), None) == INVALID  # jagged, no offsets
+    assert L.tzr_pooled_bwd_plan(p(tables), 1, p(feats), 1, 1, 10, 16, p(vals), None, 4, 4, 4, 1, p(ws), 64, None) == WORKSPACE
+    assert L.tzr_pooled_bwd_plan(p(tables), 1, p(feats), 1, 1, 10, 16, p(vals), None, 4, 4, 4, 1, None, 0, None) == WORKSPACE
+    assert L.tzr_pooled_bwd_plan(p(tables), 1, p(feats), 1, 1, 10, 16, None, None, 0, 0, 4, 1, p(ws), ws.numel(), None) == OK  # no ids
+
+
+def test_interaction_and_jagged_shape_limits(dev):
+    L = _lib.lib()
+    x, out = _buf(dev, 4096), _buf(dev, 4096)
+    p = _lib.ptr
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 26 * 8, 26, 8, 2, p(out), 400, 0, 0, None) == UNSUPPORTED  # D != 16
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 40 * 16, 40, 16, 2, p(out), 1000, 0, 0, None) == UNSUPPORTED  # > 32 rows
+    assert L.tzr_dot_interaction_fwd(None, 0, None, 0, 26, 16, 2, p(out), 400, 0, 0, None) == INVALID
+    assert L.tzr_fm_fwd(p(x), 26 * 6, 26, 6, 2, p(out), 8, None) == UNSUPPORTED  # D % 4
+    off = _buf(dev, 3, torch.int64)
+    assert L.tzr_jagged_to_padded_dense(p(x), 6, p(off), 2, 4, 6, 0.0, p(out), None) == UNSUPPORTED  # dim % 4
+    assert L.tzr_jagged_to_padded_dense(p(x), 8, None, 2, 4, 8, 0.0, p(out), None) == INVALID
+
+
+def test_zch_and_dense_glue_argument_checks(dev):
+    L = _lib.lib()
+    keys = _buf(dev, 24, torch.int64)
+    rows = _buf(dev, 24, torch.int32)
+    m = _lib.TzrZchModule()
+    m.keys, m.rows, m.capacity, m.zch_size = _lib.ptr(keys), _lib.ptr(rows), 24, 8  # not a power of two
+    p = _lib.ptr
+    assert L.tzr_zch_build(C.byref(m), None, None, 0, None) == INVALID
+    m.capacity = 16
+    assert L.tzr_zch_build(C.byref(m), p(keys), p(rows), 9, None) == INVALID  # load factor > 1/2
+    assert L.tzr_zch_build(C.byref(m), None, None, 0, None) == OK
+    x, y = _buf(dev, 64), _buf(dev, 64)
+    ws = _lib.workspace(L.tzr_relu_bwd_colsum_workspace(4, 8), dev)
+    assert L.tzr_relu_bwd_colsum(p(x), 6, p(y), 6, 4, 6, p(x), 6, p(y), p(ws), ws.numel(), None) == UNSUPPORTED  # N % 4
+    assert L.tzr_relu_bwd_colsum(p(x), 8, p(y), 8, 4, 8, p(x), 8, p(y), None, 0, None) == WORKSPACE
+    assert L.tzr_relu_bwd_colsum(p(x), 8, p(y), 8, 0, 8, p(x), 8, p(y), p(ws), ws.numel(), None) == INVALID  # B <= 0
+    wb = _lib.workspace(L.tzr_bce_logits_workspace(4), dev)
+    assert L.tzr_bce_logits(p(x), p(y), 2, 1, None, 4, p(x), p(y), p(wb), wb.numel(), None) == UNSUPPORTED  # fp16 labels
+    assert L.tzr_bce_logits(p(x), p(y), 4, 1, None, 0, p(x), p(y), p(wb), wb.numel(), None) == INVALID
+    t = (_lib.TzrAdamTensor * 1)()
+    assert L.tzr_dense_adam(t, 1, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == INVALID  # null tensor pointers
+    assert L.tzr_dense_adam(None, 0, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == INVALID
+    assert L.tzr_tune(b"no_such_knob", 1) == INVALID and L.tzr_tune(None, 1) == INVALID
+
+
+def test_module_level_errors_are_python_exceptions(dev):
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 8, 10, ["k"])], device=dev)
+    kjt = KeyedJaggedTensor(["other"], torch.zeros(2, dtype=torch.int64), torch.ones(2, dtype=torch.int32)).to(dev)
+    with pytest.raises(KeyError):
+        ebc(kjt)
+    with pytest.raises(_lib.TzrError):  # host tensor into the device library (or the reverse on the emulator)
+        other = torch.device("cpu") if dev.type == "cuda" else None
+        if other is None:
+            raise _lib.TzrError("n/a on the emulator: it only ever sees host tensors")
+        _lib.ptr(torch.zeros(1, device=other))
+    # out-of-range ids never fault: they read row 0 (K4 reports them)
+    bad = KeyedJaggedTensor(["k"], torch.tensor([3, 10**12, -5]), torch.ones(3, dtype=torch.int32), uniform_length=1).to(dev)
+    out = ebc(bad).values()
+    w = ebc.table_weights()["t"].detach()
+    assert torch.equal(out[1], w[0]) and torch.equal(out[2], w[0]) and torch.equal(out[0], w[3])
