@@ -33,6 +33,9 @@
 extern "C" {
 #endif
 
+#define TZR_DT_F32 0
+#define TZR_DT_F16 1
+
 #define TZR_OK 0
 #define TZR_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, unsupported dim) */
 #define TZR_ERR_LAUNCH (-2)      /* hipLaunch / hipMemsetAsync reported an error */
@@ -65,15 +68,18 @@ extern "C" {
  * `dim` floats, rows are `*_stride` floats apart (stride 2*dim with m = w + dim gives the
  * interleaved [w|m] 128-byte row used for Adagrad at dim 16). */
 typedef struct TzrTable {
-  uint64_t w;       /* float* device address of weights row 0                                 */
+  uint64_t w;       /* device address of weights row 0: float* or, w_dtype = TZR_DT_F16, half*  */
   uint64_t m;       /* float* device address of optimizer state row 0 (0 for SGD)             */
   int64_t rows;     /* rows held by this shard                                                */
   int32_t dim;      /* embedding dim D (multiple of 4, <= 256)                                */
-  int32_t w_stride; /* floats between consecutive weight rows                                 */
+  int32_t w_stride; /* ELEMENTS (floats / halves) between consecutive weight rows               */
   int32_t m_stride; /* floats between consecutive state rows (rowwise adagrad: 1)             */
   int32_t first_order; /* smallest TzrFeature.order among the keys reading this table         */
   int32_t n_feats;  /* number of KJT keys reading this table (their orders are consecutive)   */
-  int32_t reserved;
+  int32_t w_dtype;  /* TZR_DT_F32 | TZR_DT_F16 (tzrec feature config `data_type`,
+                       tzrec/features/feature.py:346-356,626): half weights are widened to fp32
+                       on read; the fused optimizer computes in fp32 and rounds to nearest even
+                       on write; optimizer state is always fp32                              */
 } TzrTable; /* 48 bytes */
 
 /* One lookup = (KJT key -> table).  Usually one per key; a key read through two tables (DeepFM:
@@ -186,6 +192,13 @@ int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feats, int n_fe
                    const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
                    const int64_t* d_offsets, const float* d_weights, int64_t B,
                    const TzrDst* h_dsts, int n_dst, int uniform_bag_len, void* stream);
+/* Same, with flags.  TZR_FWD_MIXED_DTYPE: some table holds fp16 rows (TzrTable.w_dtype); without
+ * the flag (and in tzr_pooled_fwd) every table is read as fp32. */
+#define TZR_FWD_MIXED_DTYPE 1
+int tzr_pooled_fwd_ex(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                      const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
+                      const int64_t* d_offsets, const float* d_weights, int64_t B,
+                      const TzrDst* h_dsts, int n_dst, int uniform_bag_len, int flags, void* stream);
 
 /* K6: backward index plan = group the N lookups by (table, row), duplicates adjacent, original
  * order kept inside a row (stable segmented radix sort).  Replaces fbgemm

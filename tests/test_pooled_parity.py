@@ -313,3 +313,46 @@ def test_frozen_table_is_left_out_of_the_fused_optimizer(dev):
     assert not torch.equal(res[False][0]["tb"], res[False][1]["tb"])  # trainable twin did move
     for n in ("ta", "tc"):
         assert torch.equal(after_f[n], res[False][0][n])  # neighbours: same update either way
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "rowwise_adagrad"])
+def test_fp16_tables(dev, kind):
+    """`data_type: FP16` (tzrec/features/feature.py:346-356): half rows are widened exactly on read (so
+    L=1 pooling is still a bit-exact copy), the optimizer computes in fp32 and rounds to nearest even on
+    the way back; an fp32 table in the same collection is untouched by all of that."""
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    rng = np.random.default_rng(11)
+    B, D, lr = 200, 16, 0.1
+    rows = [50, 7]
+    ebc = EmbeddingBagCollection(
+        [EmbeddingBagConfig("half_t", D, rows[0], ["a"], data_type="FP16"), EmbeddingBagConfig("float_t", D, rows[1], ["b"])],
+        device=dev, optimizer=SparseOptimizerConfig(kind=kind, lr=lr))
+    wh = ebc.table_weights()["half_t"]
+    assert wh.dtype == torch.float16
+    ids = np.stack([rng.integers(0, rows[0], size=B), rng.integers(0, rows[1], size=B)]).astype(np.int64)
+    kjt = KeyedJaggedTensor(["a", "b"], torch.from_numpy(ids.reshape(-1)), torch.ones(2 * B, dtype=torch.int32), uniform_length=1).to(dev)
+    w0 = [wh.detach().cpu().float().numpy().copy(), ebc.table_weights()["float_t"].detach().cpu().numpy().copy()]
+    out = ebc(kjt).values()
+    assert torch.equal(out.detach().cpu()[:, :D], torch.from_numpy(w0[0])[ids[0]])  # exact widening
+    assert torch.equal(out.detach().cpu()[:, D:], torch.from_numpy(w0[1])[ids[1]])
+    g = torch.randn(B, 2 * D, generator=torch.Generator().manual_seed(2))
+    (out * g.to(dev)).sum().backward()
+    opt = orc.SparseOptim(kind=kind, lr=lr)
+    for t, name in enumerate(["half_t", "float_t"]):
+        w = w0[t].copy()
+        m = None if kind == "sgd" else (np.zeros_like(w) if kind == "adagrad" else np.zeros(rows[t], np.float32))
+        orc.sparse_update(w, m, ids[t], g[:, t * D:(t + 1) * D].numpy(), opt)
+        got = ebc.table_weights()[name].detach().cpu()
+        if t == 0:
+            assert got.dtype == torch.float16
+            want = torch.from_numpy(w).half()
+            # one fp32 ulp in the update can flip the half rounding of an element: allow 1 half ulp
+            torch.testing.assert_close(got.float(), want.float(), rtol=1e-3, atol=1e-5)
+            exact = (got == want).float().mean().item()
+            assert exact > 0.98, exact
+        else:
+            np.testing.assert_allclose(got.numpy(), w, rtol=2e-5, atol=2e-3 * lr)
+        if m is not None:
+            np.testing.assert_allclose(ebc.table_states()[name].detach().cpu().numpy(), m, rtol=2e-5, atol=1e-7)

@@ -255,3 +255,60 @@ def test_checkpoint_reshards_across_plans(emu_path):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_ckpt_worker, args=(world, os.path.join(d, "init"), emu_path, os.path.join(d, "ckpt")), nprocs=world, join=True)
+
+
+def _fp16_worker(rank, world, init_file, emu_path):
+    """FP16 tables through the sharded exchange (row-wise shards + a replicated table) must end where
+    the unsharded FP16 collection ends on the same global batch (that path is oracle-checked in
+    tests/test_pooled_parity.py::test_fp16_tables)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sharding import ShardedEmbeddingBagCollection
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    rows = [301, 40, 9]
+    keys = ["a", "b", "c"]
+
+    def seeded(t):
+        def f(w):
+            g = torch.Generator().manual_seed(100 + t)
+            w.copy_((torch.rand(w.shape, generator=g) - 0.5) * 0.2)
+        return f
+
+    cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t), data_type="FP16" if t != 1 else "FP32")  # noqa: E731
+                    for t, r in enumerate(rows)]
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    assert {p["sharding_type"] for p in sh.plan().values()} == {"row_wise", "data_parallel"}
+    ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
+    rng = np.random.default_rng(0)
+    Bg, Bl = 40, 20
+    ids = np.stack([rng.integers(0, r, size=Bg) for r in rows]).astype(np.int64)
+    g = torch.randn(Bg, 48, generator=torch.Generator().manual_seed(9))
+    mine = KeyedJaggedTensor(keys, torch.from_numpy(ids[:, rank * Bl:(rank + 1) * Bl].reshape(-1).copy()),
+                             torch.ones(3 * Bl, dtype=torch.int32), uniform_length=1)
+    out = sh.forward_grouped(mine)["g"]
+    full = KeyedJaggedTensor(keys, torch.from_numpy(ids.reshape(-1).copy()), torch.ones(3 * Bg, dtype=torch.int32), uniform_length=1)
+    out_ref = ref.forward_grouped(full)["g"]
+    assert torch.equal(out.detach(), out_ref.detach()[rank * Bl:(rank + 1) * Bl])  # widened fp16 rows cross the exchange exactly
+    (out * g[rank * Bl:(rank + 1) * Bl]).sum().backward()
+    (out_ref * g).sum().backward()
+    for t, r in enumerate(rows):
+        name = f"t{t}"
+        lo, n = sh.shard_of(name)
+        got = sh.table_weights()[name].detach()[:n]
+        want = ref.table_weights()[name].detach()[lo:lo + n]
+        assert got.dtype == want.dtype == (torch.float16 if t != 1 else torch.float32)
+        # same fp32 math up to summation order across ranks: at most one half ulp apart
+        torch.testing.assert_close(got.float(), want.float(), rtol=1e-3, atol=1e-5, msg=name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_fp16_tables_world2(emu_path):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)

@@ -21,6 +21,8 @@ TZR_OK = 0
 TZR_MAX_DST = 8
 TZR_MAX_FEAT_DST = 4
 POOL_SUM, POOL_MEAN = 0, 1
+DT_F32, DT_F16 = 0, 1
+FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE = 0, 1, 2, 3
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
@@ -30,7 +32,7 @@ _ERR = {-1: "TZR_ERR_INVALID", -2: "TZR_ERR_LAUNCH", -3: "TZR_ERR_WORKSPACE", -4
 # numpy mirrors of the header structs (host-side construction, then uploaded as bytes)
 TABLE_DT = np.dtype(
     [("w", "<u8"), ("m", "<u8"), ("rows", "<i8"), ("dim", "<i4"), ("w_stride", "<i4"),
-     ("m_stride", "<i4"), ("first_order", "<i4"), ("n_feats", "<i4"), ("reserved", "<i4")]
+     ("m_stride", "<i4"), ("first_order", "<i4"), ("n_feats", "<i4"), ("w_dtype", "<i4")]
 )
 FEATURE_DT = np.dtype(
     [("table", "<i4"), ("key", "<i4"), ("pooling", "<i4"), ("n_dst", "<i4"),
@@ -94,6 +96,8 @@ _SIGNATURES = {
                                    _vp, _vp, _vp, _sz, _vp]),
     "tzr_pooled_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                               _i32, _i32, _vp]),
+    "tzr_pooled_fwd_ex": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
+                                 _i32, _i32, _i32, _vp]),
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),

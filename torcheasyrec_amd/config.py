@@ -120,6 +120,7 @@ class FeatureSpec:
     pooling: str = "sum"
     value_dim: int = 1
     trainable: bool = True
+    data_type: str = "FP32"  # feature config `data_type` (FP32 | FP16)
     zch: Optional[Msg] = None  # the raw `zch {...}` block (see zch.zch_config_from_msg)
 
 
@@ -189,6 +190,7 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
                 name=name, kind=kind, is_sparse=True, embedding_dim=int(f.one("embedding_dim", 0)),
                 num_embeddings=_num_embeddings(f, name), embedding_name=f.one("embedding_name"),
                 pooling=str(f.one("pooling", "sum")).lower(), trainable=bool(f.one("trainable", True)),
+                data_type=str(f.one("data_type", "FP32")).upper(),
                 zch=f.one("zch") if f.has("zch") else None))
         elif kind == "raw_feature":
             spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=False,

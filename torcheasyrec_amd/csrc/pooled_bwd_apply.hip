@@ -130,7 +130,8 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
     g.z = fminf(fmaxf(g.z, -opt.max_grad), opt.max_grad);
     g.w = fminf(fmaxf(g.w, -opt.max_grad), opt.max_grad);
   }
-  float* wp = reinterpret_cast<float*>(tb.w) + row * (int64_t)tb.w_stride + 4 * c;
+  void* const wbase = reinterpret_cast<void*>(tb.w);
+  const int64_t woff = row * (int64_t)tb.w_stride + 4 * c;
   if (opt.kind == TZR_OPT_ADAGRAD) {
     if (active) {
       float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
@@ -140,7 +141,7 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       w4.y -= lr * g.y / (sqrtf(m4.y) + opt.eps);
       w4.z -= lr * g.z / (sqrtf(m4.z) + opt.eps);
       w4.w -= lr * g.w / (sqrtf(m4.w) + opt.eps);
-      tzr_st4(wp, w4);
+      tzr_stw4(wbase, tb.w_dtype, woff, w4);
     }
   } else if (opt.kind == TZR_OPT_ROWWISE_ADAGRAD) {
     float4 gl = g;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       w4.y = corr * w4.y - mult * g.y;
       w4.z = corr * w4.z - mult * g.z;
       w4.w = corr * w4.w - mult * g.w;
-      tzr_st4(wp, w4);
+      tzr_stw4(wbase, tb.w_dtype, woff, w4);
       if (lane_in_group == 0) *mp = mnew;
     }
   } else if (opt.kind == TZR_OPT_ACCUMULATE) {
@@ -171,7 +172,7 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
   } else {  // SGD
     if (active) {
       w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
-      tzr_st4(wp, w4);
+      tzr_stw4(wbase, tb.w_dtype, woff, w4);
     }
   }
 }
@@ -187,7 +188,7 @@ __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const Bwd
                                                    uint32_t key, float4 g, int lane) {
   const bool on = lane < (tb.dim >> 2);
   float4 w4 = tzr_zero4();
-  if (on) w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * lane);
+  if (on) w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * lane);
   const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, lane, on);
   bwd_apply_row(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const bool do_apply = tail && !in_lead;
     float4 w4 = tzr_zero4();
     if (do_apply)  // issued before the scan: overlaps the gradient gathers
-      w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + (int64_t)key * tb.w_stride + 4 * c);
+      w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * c);
     const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, c, do_apply);
     // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
     // distance d implies one run in between)
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
     }
     const TzrTable tb = tables[t];
     float4 w4 = tzr_zero4();
-    if (active) w4 = tzr_ld4(reinterpret_cast<const float*>(tb.w) + row * (int64_t)tb.w_stride + 4 * c);
+    if (active) w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, row * (int64_t)tb.w_stride + 4 * c);
     const float4 m4 = bwd_load_state(tb, opt, row, c, active);
     bwd_apply_row(tb, opt, lr, row, c, g, w4, m4, active, lg, c, lane);
   }

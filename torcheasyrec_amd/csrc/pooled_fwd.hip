@@ -27,18 +27,19 @@ struct FwdDsts {
 };
 
 struct FwdRSlot {  // resolved slot, 40 bytes
-  const float* w;  // table row 0 + chunk*4
+  const void* w;   // table row 0 + the slot's float4 column group (elements fp32 or fp16, see w_dtype)
   float* dst;      // destination buffer + col
   int64_t rows;    // ids outside [0, rows) read row 0 (memory safety; K4 counts / reports them)
   int32_t dst_stride;
   int32_t w_stride;
   int32_t feat;  // KJT key index
-  int32_t pooling;
+  int16_t pooling;
+  int16_t w_dtype;
 };
 
 int g_tzr_fwd_tile_b = 0;  // 0 = auto; set through tzr_tune("fwd_tile_b", v)
 
-template <bool UNIFORM1, bool WEIGHTED>
+template <bool UNIFORM1, bool WEIGHTED, bool MIXED>
 __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values,
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
     TzrFeature ft = feats[sl.feature];
     TzrTable tb = tables[ft.table];
     FwdRSlot r;
-    r.w = reinterpret_cast<const float*>(tb.w) + sl.chunk * 4;
+    r.w = reinterpret_cast<const char*>(tb.w) + (size_t)sl.chunk * 4 * (tb.w_dtype == TZR_DT_F16 ? 2 : 4);
+    r.w_dtype = (int16_t)tb.w_dtype;
     r.dst = reinterpret_cast<float*>(dsts.d[sl.dst].ptr) + sl.col;
     r.dst_stride = (int32_t)dsts.d[sl.dst].stride;
     r.w_stride = tb.w_stride;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
   const int total = nb * ns;
 
   for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * FWD_UNROLL) {
-    const float* wp[FWD_UNROLL];
+    const void* wp[FWD_UNROLL];
+    int wdt[FWD_UNROLL];
     float* dp[FWD_UNROLL];
     int64_t st[FWD_UNROLL], en[FWD_UNROLL];
     int32_t wstride[FWD_UNROLL];
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
       const int64_t b = b0 + bl;
       const int64_t bag = (int64_t)r.feat * B + b;
       wp[u] = r.w;
+      wdt[u] = MIXED ? r.w_dtype : TZR_DT_F32;  // fp32-only launches compile the branch away
       wstride[u] = r.w_stride;
       rows[u] = r.rows;
       pool[u] = r.pooling;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
 #pragma unroll
       for (int u = 0; u < FWD_UNROLL; ++u) {
         if (st[u] < en[u]) {
-          float4 v = tzr_ld4(wp[u] + id[u] * (int64_t)wstride[u]);
+          float4 v = tzr_ldw4(wp[u], wdt[u], id[u] * (int64_t)wstride[u]);
           if (WEIGHTED) {
             v.x *= sc[u]; v.y *= sc[u]; v.z *= sc[u]; v.w *= sc[u];
           }
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
 #pragma unroll
         for (int u = 0; u < FWD_UNROLL; ++u) {
           if (st[u] + j < en[u]) {
-            const float4 v = tzr_ld4(wp[u] + id[u] * (int64_t)wstride[u]);
+            const float4 v = tzr_ldw4(wp[u], wdt[u], id[u] * (int64_t)wstride[u]);
             // accumulation order = bag order, one fmaf per element (matches the oracle's
             // sequential fp32 sum up to fma contraction of the per-sample weight)
             acc[u] = WEIGHTED ? tzr_fma4(sc[u], v, acc[u]) : tzr_add4(acc[u], v);
@@ -158,12 +162,16 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
   }
 }
 
-extern "C" int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
-                              const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
-                              const int64_t* d_offsets, const float* d_weights, int64_t B,
-                              const TzrDst* h_dsts, int n_dst, int uniform_bag_len, void* stream) {
+// flags: TZR_FWD_MIXED_DTYPE = some table holds fp16 rows (TzrTable.w_dtype is honoured); without it
+// every table is read as fp32 and the kernel carries no per-row dtype test (measured: the test costs
+// 4-5 us of the 49 us DLRM-Criteo forward).
+extern "C" int tzr_pooled_fwd_ex(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                                 const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
+                                 const int64_t* d_offsets, const float* d_weights, int64_t B,
+                                 const TzrDst* h_dsts, int n_dst, int uniform_bag_len, int flags,
+                                 void* stream) {
   if (!d_tables || !d_feats || !d_slots || !h_dsts || n_feats <= 0 || n_slots <= 0 || B < 0 ||
-      n_dst <= 0 || n_dst > TZR_MAX_DST)
+      n_dst <= 0 || n_dst > TZR_MAX_DST || (flags & ~TZR_FWD_MIXED_DTYPE))
     return TZR_ERR_INVALID;
   if (uniform_bag_len != 1 && !d_offsets) return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
@@ -185,14 +193,29 @@ extern "C" int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feat
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool u1 = uniform_bag_len == 1;
   const bool wt = d_weights != nullptr;
-#define TZR_FWD_LAUNCH(U, W)                                                                     \
-  hipLaunchKernelGGL((tzr_pooled_fwd_kernel<U, W>), grid, dim3(FWD_THREADS), 0, s, d_tables,     \
+  const bool mx = (flags & TZR_FWD_MIXED_DTYPE) != 0;
+#define TZR_FWD_LAUNCH(U, W, M)                                                                  \
+  hipLaunchKernelGGL((tzr_pooled_fwd_kernel<U, W, M>), grid, dim3(FWD_THREADS), 0, s, d_tables,  \
                      d_feats, d_slots, n_slots, d_values, d_offsets, d_weights, B, tile_b, dsts)
-  if (u1 && wt) TZR_FWD_LAUNCH(true, true);
-  else if (u1) TZR_FWD_LAUNCH(true, false);
-  else if (wt) TZR_FWD_LAUNCH(false, true);
-  else TZR_FWD_LAUNCH(false, false);
+#define TZR_FWD_PICK(M)                      \
+  do {                                       \
+    if (u1 && wt) TZR_FWD_LAUNCH(true, true, M);        \
+    else if (u1) TZR_FWD_LAUNCH(true, false, M);        \
+    else if (wt) TZR_FWD_LAUNCH(false, true, M);        \
+    else TZR_FWD_LAUNCH(false, false, M);               \
+  } while (0)
+  if (mx) TZR_FWD_PICK(true);
+  else TZR_FWD_PICK(false);
+#undef TZR_FWD_PICK
 #undef TZR_FWD_LAUNCH
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+extern "C" int tzr_pooled_fwd(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
+                              const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
+                              const int64_t* d_offsets, const float* d_weights, int64_t B,
+                              const TzrDst* h_dsts, int n_dst, int uniform_bag_len, void* stream) {
+  return tzr_pooled_fwd_ex(d_tables, d_feats, n_feats, d_slots, n_slots, d_values, d_offsets, d_weights, B,
+                           h_dsts, n_dst, uniform_bag_len, 0, stream);
 }

@@ -18,10 +18,12 @@
 #define SH_MAXKEYS 256  // keys (owner: W*F segments; requester: lookups) staged in LDS per pass
 
 struct ShKey {  // resolved key segment on the owner
-  const float* w;
+  const void* w;
   int64_t rows;
   int32_t w_stride;
   int32_t dim;
+  int32_t w_dtype;
+  int32_t pad;
 };
 
 // out[j, :] = W_{table(key(j))}[ids[j], :] for j in [0, n): key(j) = segment of key_start holding j.
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
     for (int k = k0 + threadIdx.x; k <= k1; k += SH_THREADS) {
       const TzrTable tb = tables[key_table[k]];
       ShKey e;
-      e.w = reinterpret_cast<const float*>(tb.w);
+      e.w = reinterpret_cast<const void*>(tb.w);
+      e.w_dtype = tb.w_dtype;
       e.rows = tb.rows;
       e.w_stride = tb.w_stride;
       e.dim = tb.dim;
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
       e = s_key[a];
     } else {
       const TzrTable tb = tables[key_table[tzr_last_le(key_start, n_keys, j)]];
-      e.w = reinterpret_cast<const float*>(tb.w);
+      e.w = reinterpret_cast<const void*>(tb.w);
+      e.w_dtype = tb.w_dtype;
       e.rows = tb.rows;
       e.w_stride = tb.w_stride;
       e.dim = tb.dim;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
     int64_t id = ids[j];
     if ((uint64_t)id >= (uint64_t)e.rows) id = 0;
     float4 v = tzr_zero4();
-    if (4 * c < e.dim) v = tzr_ld4(e.w + id * (int64_t)e.w_stride + 4 * c);
+    if (4 * c < e.dim) v = tzr_ldw4(e.w, e.w_dtype, id * (int64_t)e.w_stride + 4 * c);
     tzr_st4(out + j * out_stride + 4 * c, v);
   }
 }

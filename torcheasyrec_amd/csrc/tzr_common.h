@@ -29,6 +29,27 @@ struct TzrCarver {
   }
 };
 
+// Four consecutive table weights starting at element `off` of a row-major table whose elements
+// are fp32 or fp16 (TzrTable.w_dtype); fp16 is widened exactly, stores round to nearest even.
+__device__ __forceinline__ float4 tzr_ldw4(const void* w, int dtype, int64_t off) {
+  if (dtype == TZR_DT_F16) {
+    struct alignas(8) H4 { _Float16 a, b, c, d; };
+    const H4 h = *reinterpret_cast<const H4*>(static_cast<const char*>(w) + off * 2);
+    return make_float4((float)h.a, (float)h.b, (float)h.c, (float)h.d);
+  }
+  return *reinterpret_cast<const float4*>(static_cast<const float*>(w) + off);
+}
+__device__ __forceinline__ void tzr_stw4(void* w, int dtype, int64_t off, float4 v) {
+  if (dtype == TZR_DT_F16) {
+    struct alignas(8) H4 { _Float16 a, b, c, d; };
+    H4 h;
+    h.a = (_Float16)v.x; h.b = (_Float16)v.y; h.c = (_Float16)v.z; h.d = (_Float16)v.w;
+    *reinterpret_cast<H4*>(static_cast<char*>(w) + off * 2) = h;
+    return;
+  }
+  *reinterpret_cast<float4*>(static_cast<float*>(w) + off) = v;
+}
+
 __device__ __forceinline__ float4 tzr_ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }

@@ -43,6 +43,10 @@ class EmbeddingBagConfig:
     # tzrec sets `.trainable` from the feature config (feature.py:629); frozen tables are left out
     # of the fused optimizer (BaseModel.sparse_parameters, tzrec/models/model.py:162-201)
     trainable: bool = True
+    # `data_type` of the feature config (tzrec/features/feature.py:346-356,626): "FP32" | "FP16".
+    # FP16 rows are widened to fp32 on read; the fused optimizer computes in fp32 and stores back
+    # with round-to-nearest-even; optimizer state stays fp32.
+    data_type: str = "FP32"
 
 
 @dataclass
@@ -199,6 +203,7 @@ class EmbeddingBagCollection(nn.Module):
                 self._lookups.append(_Lookup(f, t, out_key))
         self._out_dim = {lk.out_key: self._configs[lk.table].embedding_dim for lk in self._lookups}
         self._allocate()
+        self._has_fp16 = any(m.weight.dtype == torch.float16 for m in self.embedding_bags.values())
         self._groups = groups
         self._dst_layouts: Dict[Tuple[str, ...], List[Tuple[str, List[str]]]] = {}
         self._meta_cache: Dict[Tuple, _Meta] = {}
@@ -214,7 +219,15 @@ class EmbeddingBagCollection(nn.Module):
         init_m = self._opt_cfg.initial_accumulator_value if self._opt_cfg is not None else 0.0
         for cfg in self._configs:
             rows, D = cfg.num_embeddings, cfg.embedding_dim
-            if kind == "adagrad" and self._row_layout == "interleaved":
+            dt = cfg.data_type.upper()
+            if dt not in ("FP32", "FP16"):
+                raise ValueError(f"{cfg.name}: data_type {cfg.data_type!r} not supported (FP32 | FP16)")
+            if dt == "FP16":  # half weights, fp32 state, never interleaved (elements differ in size)
+                store = torch.empty(rows, D, dtype=torch.float16, device=self._device)
+                weight = store
+                state = (torch.full((rows, D), init_m, dtype=torch.float32, device=self._device) if kind == "adagrad"
+                         else torch.zeros(rows, dtype=torch.float32, device=self._device) if kind == "rowwise_adagrad" else None)
+            elif kind == "adagrad" and self._row_layout == "interleaved":
                 store = torch.empty(rows, 2 * D, dtype=torch.float32, device=self._device)
                 weight, state = store[:, :D], store[:, D:]
                 state.fill_(init_m)
@@ -301,6 +314,7 @@ class EmbeddingBagCollection(nn.Module):
             tables[t]["rows"] = cfg.num_embeddings
             tables[t]["dim"] = cfg.embedding_dim
             tables[t]["w_stride"] = w.stride(0)
+            tables[t]["w_dtype"] = _lib.DT_F16 if w.dtype == torch.float16 else _lib.DT_F32
             tables[t]["m_stride"] = (1 if kind == "rowwise_adagrad" else (st.stride(0) if st is not None else 0))
             mine = [i for i, lk in enumerate(self._lookups) if lk.table == t]
             tables[t]["first_order"] = mine[0] if mine else 0
@@ -357,11 +371,11 @@ class EmbeddingBagCollection(nn.Module):
             dsts[i].ptr = _lib.ptr(o)
             dsts[i].stride = o.stride(0)
         ev = self._timers.start("fwd") if self._timers is not None else None
-        rc = _lib.lib().tzr_pooled_fwd(
+        rc = _lib.lib().tzr_pooled_fwd_ex(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
             _lib.ptr(meta.d_slots), len(meta.slots_np), _lib.ptr(kjt.values()), _lib.ptr(offsets),
             _lib.ptr(kjt.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
-            _lib.stream_ptr(self._device),
+            _lib.FWD_MIXED_DTYPE if self._has_fp16 else 0, _lib.stream_ptr(self._device),
         )
         if ev is not None:
             ev.record()

@@ -108,7 +108,8 @@ class EmbeddingGroup(nn.Module):
                 if f.is_sparse:
                     dim = (wide_embedding_dim or 4) if is_wide else f.embedding_dim
                     tname = feat_group_table[fname][g.group_name]
-                    cfg = EmbeddingBagConfig(tname, dim, f.num_embeddings, [fname], f.pooling, trainable=f.trainable)
+                    cfg = EmbeddingBagConfig(tname, dim, f.num_embeddings, [fname], f.pooling, trainable=f.trainable,
+                                             data_type=f.data_type)
                     if f.zch is not None:
                         zch_blocks[tname] = f.zch
                     if tname in configs:

@@ -191,13 +191,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     a = (1.0 / max(rows, 1)) ** 0.5  # same distribution as the unsharded table
                     w.uniform_(-a, a)
             local_cfgs.append(EmbeddingBagConfig(cfg.name, cfg.embedding_dim, max(n, 1), list(cfg.feature_names),
-                                                 cfg.pooling, init))
+                                                 cfg.pooling, init, data_type=cfg.data_type))
         self.local = EmbeddingBagCollection(local_cfgs, device=self._device, optimizer=optimizer,
                                             row_layout=row_layout) if local_cfgs else None
         # --- replicated tables ---
         self.replica = EmbeddingBagCollection(
-            [EmbeddingBagConfig(c.name, c.embedding_dim, c.num_embeddings, list(c.feature_names), c.pooling, c.init_fn)
-             for c in self._dp], device=self._device, optimizer=optimizer, row_layout=row_layout) if self._dp else None
+            [EmbeddingBagConfig(c.name, c.embedding_dim, c.num_embeddings, list(c.feature_names), c.pooling, c.init_fn,
+                                data_type=c.data_type) for c in self._dp], device=self._device, optimizer=optimizer, row_layout=row_layout) if self._dp else None
         if self.replica is not None:
             for store in self.replica._storage:  # identical replicas: rank 0's values (and zero state)
                 dist.broadcast(store, src=0, group=self.pg)
@@ -468,10 +468,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
             rows_in, d_pt = self._recv_rows_buffer(N, F)
             work = self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
         if "dp_n" in rm:  # replicated tables: purely local, same destination buffers (other columns)
-            _lib.check(L.tzr_pooled_fwd(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
-                                        _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
-                                        _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
-                                        B, dsts, len(outs), 1 if uniform else 0, stream), "tzr_pooled_fwd")
+            _lib.check(L.tzr_pooled_fwd_ex(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
+                                           _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
+                                           _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
+                                           B, dsts, len(outs), 1 if uniform else 0,
+                                           _lib.FWD_MIXED_DTYPE if self.replica._has_fp16 else 0, stream), "tzr_pooled_fwd")
         if work is not None:
             work.wait()
             # requester: pooled gather over the received rows, ids = position in bucketized order
