@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--torch-adam", action="store_true", help="dense optimizer: torch.optim.Adam(fused) instead of tzr_dense_adam")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded runs: op-by-op autograd step instead of ShardedTrainStep")
+    ap.add_argument("--no-plan-ahead", action="store_true",
+                    help="sharded runs: keep the backward index plans (K6) on the main stream instead of one batch ahead")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="sharded runs: do not run the next batch's input dist ahead on the side stream")
     ap.add_argument("--force-sharded", action="store_true",
@@ -285,7 +287,8 @@ def main():
     if sharded and not args.no_pipeline:
         from torcheasyrec_amd.sharded_step import ShardedTrainStep
 
-        train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch)
+        train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
+                                      plan_ahead=not args.no_plan_ahead)
 
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:

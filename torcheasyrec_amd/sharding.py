@@ -482,6 +482,38 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                         stream), "tzr_pooled_fwd")
         return outs
 
+    # K6 depends on ids only: a pipeline may run both plans right after the input dist, one batch
+    # ahead on its side stream (`plan_ahead`), and the backward then starts at K7
+    def _plan_dp(self, st: dict) -> torch.Tensor:
+        L, dev, D = _lib.lib(), self._device, self.dim
+        kjt, rm, uniform = st["kjt"], st["rm"], st["uniform"]
+        B, N_all, n_dp, T_dp = kjt.stride(), kjt.values().numel(), rm["dp_n"], len(self._dp)
+        NP = n_dp * B if uniform else N_all
+        ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D), dev)
+        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_feats"]), n_dp,
+                                         rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
+                                         _lib.ptr(None if uniform else kjt.offsets()), N_all, NP, B, 1 if uniform else 0,
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
+        return ws
+
+    def _plan_rw(self, st: dict) -> torch.Tensor:
+        L, dev, D = _lib.lib(), self._device, self.dim
+        om, n_recv = st["om"], st["n_recv"]
+        K, T = om["K"], om["T"]
+        ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
+        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K, om["max_rows"], D,
+                                         _lib.ptr(st["recv_ids"]), _lib.ptr(st["key_start"]), n_recv, n_recv, 1, 0,
+                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
+        return ws
+
+    def plan_ahead(self, st: dict) -> dict:
+        if self.fused_optimizer is not None:
+            if "dp_n" in st["rm"]:
+                st["ws_dp"] = self._plan_dp(st)
+            if "rw_n" in st["rm"] and st.get("n_recv", 0) > 0:
+                st["ws_rw"] = self._plan_rw(st)
+        return st
+
     def _forward_impl(self, kjt: KeyedJaggedTensor, dst_names):
         st = self.input_dist_end(self.input_dist_begin(kjt, dst_names))
         return self.lookup(st), st
@@ -526,11 +558,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
             offsets = None if uniform else kjt.offsets()
             self._dp_acc.zero_()
             NP = n_dp * B if uniform else N_all
-            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D), dev)
-            _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_feats"]), n_dp,
-                                             rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
-                                             _lib.ptr(offsets), N_all, NP, B, 1 if uniform else 0, _lib.ptr(ws),
-                                             ws.numel(), stream), "tzr_pooled_bwd_plan")
+            ws = st.get("ws_dp")
+            if ws is None:
+                ws = self._plan_dp(st)
             _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_feats"]), n_dp, T_dp, D,
                                               _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N_all, NP, B,
                                               1 if uniform else 0, 0, gd, len(gl),
@@ -542,11 +572,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
             # owner: sort by (table,row) + fused optimizer, gradients addressed per id
             if n_recv > 0:
                 K, T = om["K"], om["T"]
-                ws2 = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
-                _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K,
-                                                 om["max_rows"], D, _lib.ptr(st["recv_ids"]), _lib.ptr(st["key_start"]),
-                                                 n_recv, n_recv, 1, 0, _lib.ptr(ws2), ws2.numel(), stream),
-                           "tzr_pooled_bwd_plan")
+                ws2 = st.get("ws_rw")
+                if ws2 is None:
+                    ws2 = self._plan_rw(st)
                 g1 = (_lib.TzrDst * 1)()
                 g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
                 _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_feats"]), K, T, D,
