@@ -172,6 +172,8 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 
 inline void __syncthreads() { emu::pool().block->arrive_and_wait(); }
+// lanes are OS threads here: a wave-level barrier has to be a real one
+inline void __builtin_amdgcn_wave_barrier() { emu::wave().bar.arrive_and_wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 

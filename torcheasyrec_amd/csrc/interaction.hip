@@ -41,6 +41,11 @@ __device__ __forceinline__ const float* ia_row(const float* dense, int64_t dense
                         : sparse + b * sparse_stride + (int64_t)(i - hd) * IA_D;
 }
 
+// Each wave stages through its own LDS slice, so producer and consumer lanes are always in the same
+// wave: LDS instructions of one wave execute in issue order, and all that is needed is that the
+// compiler keeps them in order -- not a workgroup barrier that would stall the other three waves.
+__device__ __forceinline__ void ia_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_kernel(
     const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
     int64_t sparse_stride, int n, int hd, int64_t B, float* __restrict__ out, int64_t out_stride,
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_kernel(
       if (j1 < n) tri[wv][i0 * (2 * n - i0 - 1) / 2 + j1 - i0 - 1] = c01[reg];
       if (i1 < j1 && j1 < n) tri[wv][i1 * (2 * n - i1 - 1) / 2 + j1 - i1 - 1] = c11[reg];
     }
-    __syncthreads();
+    ia_wave_sync();  // tri[wv] is private to this wave: no workgroup barrier needed
     if (on) {
       float* o = out + b * out_stride;
       for (int idx = lane; idx < P; idx += TZR_WAVE) o[idx] = tri[wv][idx];
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_kernel(
         if (16 + r < n) tzr_st4_a4(o + col + (16 + r - hd) * IA_D + 4 * q, a1);
       }
     }
-    __syncthreads();
+    ia_wave_sync();
   }
 }
 
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_kernel(
       }
       if (row1 && cat_sparse) p1 = tzr_ld4_a4(g + ps + (16 + r - hd) * IA_D + 4 * q);
     }
-    __syncthreads();
+    ia_wave_sync();  // S[wv] / Xs[wv] are private to this wave
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
     for (int ks = 0; ks < IA_MAXN / 4; ++ks) {
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_kernel(
       const float4 v = make_float4(d1[0] + p1.x, d1[1] + p1.y, d1[2] + p1.z, d1[3] + p1.w);
       tzr_st4(gsparse + b * gsparse_stride + (int64_t)(16 + r - hd) * IA_D + 4 * q, v);
     }
-    __syncthreads();
+    ia_wave_sync();
   }
 }
 
