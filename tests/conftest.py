@@ -41,6 +41,6 @@ def dev(request):
         return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.fail("gpu test selected but no HIP device is visible")
-    _lib.use_library(_lib.LIB_PATH)
+    _lib.use_native()
     assert _lib.backend().startswith("hip"), "GPU tests must run on the native gfx950 library"
     return torch.device("cuda", 0)

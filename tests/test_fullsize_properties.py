@@ -23,7 +23,7 @@ def _setup(kind, lr, dist="uniform"):
     from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig
 
-    _lib.use_library(_lib.LIB_PATH)
+    _lib.use_native()
     dev = torch.device("cuda", 0)
     torch.manual_seed(11)
     ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev,

@@ -23,7 +23,7 @@ def test_sharded_world1_matches_unsharded(kind, replicate):
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
     from torcheasyrec_amd.sharding import ShardedDLRM
 
-    _lib.use_library(_lib.LIB_PATH)
+    _lib.use_native()
     dev = torch.device("cuda", 0)
     with tempfile.TemporaryDirectory() as d:
         dist.init_process_group("nccl", init_method=f"file://{d}/init", rank=0, world_size=1, device_id=dev)
@@ -76,7 +76,7 @@ def test_pipelined_train_step_matches_autograd_path():
     from torcheasyrec_amd.sharded_step import ShardedTrainStep
     from torcheasyrec_amd.sharding import ShardedDLRM
 
-    _lib.use_library(_lib.LIB_PATH)
+    _lib.use_native()
     dev = torch.device("cuda", 0)
     work = torch.cuda.Stream(dev)
     with tempfile.TemporaryDirectory() as d, torch.cuda.stream(work):

@@ -145,6 +145,14 @@ def use_library(path: str) -> None:
     _backend = _lib.tzr_backend().decode()
 
 
+def use_native() -> None:
+    """Load the gfx950 library, compiling it first when the in-tree .so is missing or older than
+    its sources (a fresh checkout on a GPU box)."""
+    from . import _build
+
+    use_library(_build.build())
+
+
 def lib() -> C.CDLL:
     global _lib, _backend
     if _lib is None:
