@@ -171,7 +171,9 @@ int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B,
  * (r, f, b) bag.  d_unbucketize_permute[i] = output position of input id i (nullable).
  * d_rank_offsets (nullable, int32[F]) rotates the owner: dst = (offset[f] + x / block_size[f]) mod W,
  * which spreads tables with fewer rows than ranks (and table-wise placement: block_size = rows,
- * offset = owner) over the node instead of piling them on rank 0. */
+ * offset = owner) over the node instead of piling them on rank 0.
+ * block_size[f] == 0 selects hash routing for key f: dst = splitmix64(x) mod W and the id travels
+ * unchanged (zero-collision-hash tables, whose owners map raw ids to rows themselves). */
 size_t tzr_block_bucketize_workspace(int64_t F, int64_t B, int W);
 int tzr_block_bucketize(const int64_t* d_block_sizes, const int32_t* d_rank_offsets, int F,
                         int64_t B, int W,

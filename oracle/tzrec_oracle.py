@@ -175,6 +175,15 @@ def kjt_permute(permute, lengths, values, weights, B):
     )
 
 
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on int64 ids (two's complement), as the kernels hash raw ids."""
+    with np.errstate(over="ignore"):
+        z = x.astype(np.int64).view(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
 def block_bucketize(block_sizes, lengths, values, weights, B, W):
     """fbgemm block_bucketize_sparse_features semantics [upstream] for row-wise sharding.
 
@@ -189,7 +198,10 @@ def block_bucketize(block_sizes, lengths, values, weights, B, W):
     dest = np.empty(len(values), dtype=np.int64)
     for f in range(F):
         s, e = off[f * B], off[(f + 1) * B]
-        dest[s:e] = np.minimum(values[s:e] // block_sizes[f], W - 1)
+        if block_sizes[f] == 0:  # hash routing of raw ids (ZCH tables): splitmix64(id) mod W, id unchanged
+            dest[s:e] = (splitmix64(values[s:e]) % np.uint64(W)).astype(np.int64)
+        else:
+            dest[s:e] = np.minimum(values[s:e] // block_sizes[f], W - 1)
     bag_of = np.repeat(np.arange(F * B, dtype=np.int64), lengths.astype(np.int64))
     slot = dest * (F * B) + bag_of  # output bag index (r*F + f)*B + b
     np.add.at(new_lengths, slot, 1)

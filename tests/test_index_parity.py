@@ -96,3 +96,35 @@ def test_bounds_check(dev, mode):
     ref_vals, ref_bad = orc.bounds_check(vals, off, [10, 1000], B, clamp=mode != _lib.BOUNDS_FATAL)
     assert int(cnt.item()) == (0 if mode == _lib.BOUNDS_IGNORE else ref_bad)
     assert np.array_equal(kjt.values().cpu().numpy(), ref_vals)
+
+
+@pytest.mark.parametrize("W", [1, 2, 8])
+def test_block_bucketize_hash_routing(dev, W):
+    """block_size 0 = hash routing of raw 64-bit ids (ZCH tables): owner = splitmix64(id) mod W, the id
+    travels unchanged; other keys of the same call keep block routing."""
+    rng = np.random.default_rng(W + 50)
+    F, B = 2, 57
+    lens = rng.integers(0, 4, size=F * B).astype(np.int32)
+    off = orc.lengths_to_offsets(lens)
+    raw = rng.integers(-(1 << 62), 1 << 62, size=int(off[B])).astype(np.int64)  # any int64, negatives too
+    raw[:3] = [0, -1, (1 << 63) - 2]
+    blocked = rng.integers(0, 1000, size=int(off[2 * B] - off[B])).astype(np.int64)
+    vals = np.concatenate([raw, blocked])
+    block = np.array([0, (1000 + W - 1) // W], dtype=np.int64)
+    kjt = KeyedJaggedTensor(["zch_key", "plain"], torch.from_numpy(vals), torch.from_numpy(lens)).to(dev)
+    out, unb = block_bucketize(kjt, torch.from_numpy(block).to(dev), W, return_permute=True)
+    rl, rv, _, ru = orc.block_bucketize(block, lens, vals, None, B, W)
+    assert np.array_equal(out.lengths().cpu().numpy(), rl)
+    assert np.array_equal(out.values().cpu().numpy(), rv)
+    assert np.array_equal(unb.cpu().numpy(), ru)
+    # every raw id arrives unchanged at exactly the rank its hash names
+    no = orc.lengths_to_offsets(rl)
+    got = []
+    for r in range(W):
+        seg = rv[no[(r * F) * B]: no[(r * F + 1) * B]]
+        assert ((orc.splitmix64(seg) % np.uint64(W)).astype(np.int64) == r).all()
+        got.append(seg)
+    assert sorted(np.concatenate(got).tolist()) == sorted(raw.tolist())
+    if W == 8:  # the hash spreads: no rank is starved or flooded
+        counts = np.array([len(g) for g in got])
+        assert counts.min() > 0

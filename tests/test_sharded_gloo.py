@@ -312,3 +312,80 @@ def _fp16_worker(rank, world, init_file, emu_path):
 def test_sharded_fp16_tables_world2(emu_path):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
+def _zch_worker(rank, world, init_file, emu_path):
+    """Sharded ZCH: raw ids routed by hash, remapped by their owner, admission / eviction local to the
+    owner.  Every rank's map must follow oracle/zch_oracle.py fed with exactly the ids the hash sends
+    to that rank; pooled outputs must be the owners' rows at the oracle's row ids."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from oracle import tzrec_oracle as orc
+    from oracle.zch_oracle import EMPTY, ZchTable
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+    from torcheasyrec_amd.zch import ShardedManagedCollisionEmbeddingBagCollection, ZchConfig
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    Z, D, Bl = 48, 8, 24
+    keys = ["u1", "u2", "plain", "tiny"]
+    tables = [EmbeddingBagConfig("user_emb", D, Z, ["u1", "u2"]), EmbeddingBagConfig("plain_emb", D, 500, ["plain"]),
+              EmbeddingBagConfig("tiny_emb", D, 5, ["tiny"])]
+    torch.manual_seed(3)
+    m = ShardedManagedCollisionEmbeddingBagCollection(
+        tables, {"user_emb": ZchConfig(Z, 2, "distance_lfu")}, device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=0.5),
+        groups={"g": keys}, dp_max_rows=10)
+    kinds = {n: p["sharding_type"] for n, p in m.plan().items()}
+    assert kinds == {"user_emb": "row_wise", "plain_emb": "row_wise", "tiny_emb": "data_parallel"}
+    oracle = ZchTable(Z // world, 2, "distance_lfu")  # my share of the map
+    universe = np.random.default_rng(1).integers(-(1 << 60), 1 << 60, size=150).astype(np.int64)
+    m.train()
+    for step in range(1, 8):
+        batches = []
+        for r in range(world):  # both ranks' batches are reproducible everywhere
+            rng = np.random.default_rng(100 * step + r)
+            pick = np.minimum(rng.zipf(1.4, size=2 * Bl) + 9 * step, len(universe) - 1)
+            batches.append(np.concatenate([universe[pick], rng.integers(0, 500, size=Bl), rng.integers(0, 5, size=Bl)]).astype(np.int64))
+        kjt = KeyedJaggedTensor(keys, torch.from_numpy(batches[rank]), torch.ones(4 * Bl, dtype=torch.int32), uniform_length=1)
+        # what my oracle must see: per source rank, per zch key, the ids the hash sends to me -- in that order
+        want_rows = []
+        for src in range(world):
+            for k in range(2):
+                seg = batches[src][k * Bl:(k + 1) * Bl]
+                mine = seg[(orc.splitmix64(seg) % np.uint64(world)).astype(np.int64) == rank]
+                want_rows.append(oracle.remap(mine, step, True))
+        # owner tables BEFORE this step's update (to check the pooled output)
+        lo, n = m.sharded.shard_of("user_emb")
+        shard = m.sharded.table_weights()["user_emb"].detach()[:n].clone()
+        shards = [None] * world
+        dist.all_gather_object(shards, shard)
+        rows_by_owner = [None] * world
+        dist.all_gather_object(rows_by_owner, want_rows)
+        out = m.forward_grouped(kjt)["g"]
+        # my u1 block: for every sample, owner = hash(id), row = that owner's oracle row for it
+        for k in range(2):
+            seg = batches[rank][k * Bl:(k + 1) * Bl]
+            own = (orc.splitmix64(seg) % np.uint64(world)).astype(np.int64)
+            cursor = {o: 0 for o in range(world)}
+            for b in range(Bl):
+                o = int(own[b])
+                row = rows_by_owner[o][rank * 2 + k][cursor[o]]
+                cursor[o] += 1
+                assert torch.equal(out.detach()[b, k * D:(k + 1) * D], shards[o][row]), (step, k, b)
+        out.sum().backward()
+        if step % 2 == 0:
+            oracle.update_and_evict(step)
+        mod = m.mc.modules_by_table["user_emb"]
+        np.testing.assert_array_equal(mod.row_ids.numpy(), np.asarray(oracle.row_ids, dtype=np.int64), err_msg=f"step {step}")
+        occ = np.asarray(oracle.row_ids) != EMPTY
+        np.testing.assert_array_equal(mod.counts.numpy()[occ], np.asarray(oracle.counts)[occ])
+    assert occ.sum() > 5  # ids were admitted on this rank
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_zch_world2(emu_path):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_zch_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)

@@ -115,3 +115,57 @@ def test_pipelined_train_step_matches_autograd_path():
                 torch.testing.assert_close(b.ebc.table_weights()[name], w, rtol=1e-5, atol=1e-6, msg=name)
         finally:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_zch_world1_matches_unsharded_zch():
+    """One rank: hash routing sends everything to rank 0, whose share is the whole map -- the sharded
+    ZCH collection must then walk the same trajectory as the unsharded one (same admissions, same
+    evictions, same table rows), with the exchange kernels and RCCL in the loop."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+    from torcheasyrec_amd.zch import (ManagedCollisionEmbeddingBagCollection, ShardedManagedCollisionEmbeddingBagCollection,
+                                      ZchConfig)
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    with tempfile.TemporaryDirectory() as d:
+        dist.init_process_group("nccl", init_method=f"file://{d}/init", rank=0, world_size=1, device_id=dev)
+        try:
+            Z, D, B = 64, 16, 256
+            keys = ["u", "plain"]
+
+            def init(seed):
+                def f(w):
+                    w.copy_(((torch.rand(w.shape, generator=torch.Generator().manual_seed(seed)) - 0.5) * 0.2).to(w.device))
+                return f
+
+            tabs = lambda: [EmbeddingBagConfig("user_emb", D, Z, ["u"], init_fn=init(1)),  # noqa: E731
+                            EmbeddingBagConfig("plain_emb", D, 300, ["plain"], init_fn=init(2))]
+            opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+            zc = {"user_emb": ZchConfig(Z, 2, "lfu")}
+            a = ManagedCollisionEmbeddingBagCollection(EmbeddingBagCollection(tabs(), device=dev, optimizer=opt, groups={"g": keys}), zc)
+            b = ShardedManagedCollisionEmbeddingBagCollection(tabs(), zc, device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=0)
+            a.train(), b.train()
+            rng = np.random.default_rng(0)
+            universe = rng.integers(0, 1 << 55, size=200).astype(np.int64)
+            for step in range(6):
+                ids = np.concatenate([universe[np.minimum(rng.zipf(1.3, size=B) + 11 * step, 199)], rng.integers(0, 300, size=B)])
+                kjt = KeyedJaggedTensor(keys, torch.from_numpy(ids.astype(np.int64)), torch.ones(2 * B, dtype=torch.int32), uniform_length=1).to(dev)
+                g = torch.randn(B, 2 * D, device=dev, generator=torch.Generator(device=dev).manual_seed(step))
+                ra = a.remap_step(kjt)
+                oa = a.ebc.forward_grouped(ra)["g"]
+                (oa * g).sum().backward()
+                a.finish_step()
+                ob = b.forward_grouped(kjt)["g"]
+                assert torch.equal(oa.detach(), ob.detach()), step
+                (ob * g).sum().backward()
+            torch.cuda.synchronize()
+            ma, mb = a.modules_by_table["user_emb"], b.mc.modules_by_table["user_emb"]
+            assert torch.equal(ma.row_ids, mb.row_ids) and torch.equal(ma.counts, mb.counts)
+            assert int((ma.row_ids != (1 << 63) - 1).sum()) > 10
+            for n, w in a.ebc.table_weights().items():
+                torch.testing.assert_close(b.sharded.table_weights()[n], w, rtol=1e-6, atol=1e-7, msg=n)
+        finally:
+            dist.destroy_process_group()

@@ -239,6 +239,20 @@ extern "C" int tzr_kjt_permute(const int32_t* d_permute, int T, int F, int64_t B
 }
 
 // ---- K2 -------------------------------------------------------------------------------------
+// Owner of id x of key f: x / block_size[f] (row-wise blocks), or -- block_size[f] == 0 -- a hash of
+// the raw id (zero-collision-hash tables: raw ids are arbitrary 64-bit values, the owner maps them
+// to rows itself; the id travels unchanged).
+__device__ __forceinline__ uint64_t idx_mix(int64_t id) {  // splitmix64 finaliser (as in zch.hip)
+  uint64_t x = (uint64_t)id + 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ int64_t idx_owner(int64_t id, int64_t bs, int W) {
+  if (bs == 0) return (int64_t)(idx_mix(id) % (uint64_t)W);
+  const int64_t r = id / bs;
+  return r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+}
 // One thread per bag (a bag is owned by one thread, so its W counters / cursors are private plain
 // read-modify-writes: deterministic, ids keep their order inside every (rank, key, sample) bag).
 
@@ -252,8 +266,7 @@ __global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_count_kernel(
   const int64_t ro = rank_offsets ? rank_offsets[bag / B] : 0;
   const int64_t FB = (int64_t)F * B;
   for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
-    int64_t r = values[i] / bs;
-    r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+    const int64_t r = idx_owner(values[i], bs, W);
     const int64_t o = ((r + ro) % W) * FB + bag;
     idx_store_len(new_lengths, itemsize, o, idx_load_len(new_lengths, itemsize, o) + 1);
   }
@@ -272,8 +285,7 @@ __global__ __launch_bounds__(IDX_THREADS) void tzr_bucketize_scatter_kernel(
   const int64_t FB = (int64_t)F * B;
   for (int64_t i = offsets[bag]; i < offsets[bag + 1]; ++i) {
     const int64_t id = values[i];
-    int64_t r = id / bs;
-    r = r < 0 ? 0 : (r > W - 1 ? W - 1 : r);
+    const int64_t r = idx_owner(id, bs, W);
     const int64_t o = ((r + ro) % W) * FB + bag;
     const int64_t pos = cursor[o];
     cursor[o] = pos + 1;

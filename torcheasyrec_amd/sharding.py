@@ -225,6 +225,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._own_meta: Optional[dict] = None
         self._rows_buf: Dict[int, tuple] = {}
         self._timers = None
+        # set by ShardedManagedCollisionEmbeddingBagCollection: tables whose raw ids are routed by hash
+        # and mapped to rows by their owner (`_owner_remap(st) -> row ids of the received lookups`)
+        self._hash_routed = set()
+        self._owner_remap = None
 
     # -- placement -------------------------------------------------------------------------------
     def shard_of(self, name: str) -> Tuple[int, int]:
@@ -307,7 +311,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
             m.update({
                 "rw_perm": [key_index[k] for k in rw_keys], "rw_feats_np": feats, "rw_slots_n": len(slots),
                 "rw_d_feats": _lib.upload_struct(feats, self._device), "rw_d_slots": _lib.upload_struct(slots, self._device),
-                "rw_blk": torch.tensor([self.block[self._global[t].name] for _, t, _ in rw_lk], dtype=torch.int64, device=self._device),
+                # block 0 = hash routing of raw ids (zero-collision-hash tables, see zch.py)
+                "rw_blk": torch.tensor([0 if self._global[t].name in self._hash_routed else self.block[self._global[t].name]
+                                        for _, t, _ in rw_lk], dtype=torch.int64, device=self._device),
                 "rw_rot": torch.tensor([self.rot[self._global[t].name] for _, t, _ in rw_lk], dtype=torch.int32, device=self._device),
                 "rw_key_table": np.array([rw_names.index(self._global[t].name) for _, t, _ in rw_lk], dtype=np.int32),
                 "rw_n": len(rw_lk),
@@ -459,10 +465,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if "rw_n" in rm:
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
             F, N = rm["rw_n"], sub.values().numel()
-            # owner: one row per received id
+            # owner: one row per received id (ZCH tables: raw id -> row through the owner's map first)
+            st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
             rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
             _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
-                                         om["K"], _lib.ptr(st["recv_ids"]), n_recv, _lib.ptr(rows_out), D, D, stream),
+                                         om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(rows_out), D, D, stream),
                        "tzr_rows_gather")
             # rows back to the requesters (bucketized order) -- in flight while the replicas are read
             rows_in, d_pt = self._recv_rows_buffer(N, F)
@@ -502,15 +509,16 @@ class ShardedEmbeddingBagCollection(nn.Module):
         K, T = om["K"], om["T"]
         ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
         _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K, om["max_rows"], D,
-                                         _lib.ptr(st["recv_ids"]), _lib.ptr(st["key_start"]), n_recv, n_recv, 1, 0,
-                                         _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
+                                         _lib.ptr(st.get("owner_ids", st["recv_ids"])), _lib.ptr(st["key_start"]), n_recv,
+                                         n_recv, 1, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
         return ws
 
     def plan_ahead(self, st: dict) -> dict:
         if self.fused_optimizer is not None:
             if "dp_n" in st["rm"]:
                 st["ws_dp"] = self._plan_dp(st)
-            if "rw_n" in st["rm"] and st.get("n_recv", 0) > 0:
+            # (hash-routed tables: the row ids only exist after the owner's remap in `lookup`)
+            if "rw_n" in st["rm"] and st.get("n_recv", 0) > 0 and self._owner_remap is None:
                 st["ws_rw"] = self._plan_rw(st)
         return st
 
@@ -586,6 +594,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
                        "tzr_dense_rows_update")
+        self._after_backward(st)
+
+    def _after_backward(self, st: dict) -> None:
+        pass
 
     # -- public API ------------------------------------------------------------------------------
     def forward_grouped(self, features: KeyedJaggedTensor, group_names=None) -> Dict[str, torch.Tensor]:

@@ -288,3 +288,87 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         out = self.ebc(remapped)
         self.finish_step()
         return out, remapped
+
+
+class ShardedManagedCollisionEmbeddingBagCollection(nn.Module):
+    """ZCH tables across ranks (BASELINE config 5: `zch {...}` features on 8 GPUs).
+
+    torchrec shards an MCH module by raw-id value range and the embedding table row-wise next to it.
+    Same ownership here, spelled for the id-granularity exchange of `sharding.py`: a raw id belongs
+    to rank `splitmix64(id) mod W` (hash routing, `tzr_block_bucketize` with block size 0 -- raw ids
+    are arbitrary 64-bit values, a value range would pile them on one rank); that rank holds
+    `ceil(zch_size / W)` rows of the table AND the map raw id -> row for them.  So a lookup travels as a
+    raw id, the owner remaps it (K13) right before its row gather, and admission / eviction is a
+    purely local affair of every rank (no collective), run after the step's sparse update.
+
+    `forward_grouped(kjt)` like the wrapped module; tables named in `zch` must have
+    `num_embeddings == zch_size`; every rank's share needs >= 2 rows (one is the shared row of ids
+    without a row)."""
+
+    def __init__(self, tables, zch: Dict[str, ZchConfig], device, optimizer=None, groups=None, process_group=None,
+                 dp_max_rows: int = 65536, reset_evicted_rows: bool = False) -> None:
+        super().__init__()
+        from .embedding import EmbeddingBagConfig  # noqa: F401
+        from .sharding import ShardedEmbeddingBagCollection
+
+        cfgs = {c.name: c for c in tables}
+        for name, z in zch.items():
+            if name not in cfgs:
+                raise KeyError(f"zch config for unknown table {name}")
+            if cfgs[name].num_embeddings != z.zch_size:
+                raise ValueError(f"{name}: num_embeddings {cfgs[name].num_embeddings} != zch_size {z.zch_size}")
+        self.sharded = ShardedEmbeddingBagCollection(tables, device=device, optimizer=optimizer, groups=groups,
+                                                     process_group=process_group, dp_max_rows=dp_max_rows,
+                                                     constraints={n: "row_wise" for n in zch})
+        sh = self.sharded
+        sh._hash_routed = set(zch)
+        sh._owner_remap = self._owner_remap
+        sh._after_backward = self._after_backward
+        local = {}
+        for name, z in zch.items():
+            n = sh.shard_of(name)[1]
+            if n < 2:
+                raise ValueError(f"{name}: rank {sh.rank} would hold {n} rows; zch_size must be >= 2 * world size")
+            local[name] = ZchConfig(n, z.eviction_interval, z.policy, z.decay_exponent, z.threshold_filtering_func)
+        # the owner-side map + bookkeeping of this rank's share; its `ebc` is the local shard collection
+        self.mc = ManagedCollisionEmbeddingBagCollection(sh.local, local, reset_evicted_rows=reset_evicted_rows)
+        self._table_of_key = {f: c.name for c in tables for f in c.feature_names}
+        self._pseudo_keys: Optional[List[str]] = None
+        self._train_step = False
+
+    @property
+    def fused_optimizer(self):
+        return self.sharded.fused_optimizer
+
+    def plan(self):
+        return self.sharded.plan()
+
+    def _owner_remap(self, st: dict) -> torch.Tensor:
+        """Raw ids received from the requesters -> rows of my shard (keys of plain tables pass through)."""
+        sh = self.sharded
+        if self._pseudo_keys is None:
+            F = st["rm"]["rw_n"]
+            rw_keys = [k for k, t, _ in sh._lookups if sh._global[t].name in sh.block]
+            assert len(rw_keys) == F
+            self._pseudo_keys = [f"{k}@from{src}" for src in range(sh.W) for k in rw_keys]
+            for src in range(sh.W):
+                for k in rw_keys:
+                    t = self._table_of_key[k]
+                    if t in self.mc.modules_by_table:
+                        self.mc._key_module[f"{k}@from{src}"] = self.mc._order.index(t)
+        training = self._train_step  # decided outside: autograd.Function.forward runs with grad mode off
+        if training:
+            self.mc._iter += 1
+        # the received lookups as a one-sample KJT: key (source, feature) = segment of key_start
+        pseudo = KeyedJaggedTensor(self._pseudo_keys, st["recv_ids"], st["recv_cnt"], None, st["key_start"], 1)
+        st["zch_training"] = training
+        return self.mc.remap(pseudo, profile=training).values()
+
+    def _after_backward(self, st: dict) -> None:
+        if st.get("zch_training") and any(self.mc._iter % m.cfg.eviction_interval == 0 for m in self.mc.modules_by_table.values()):
+            self.mc._evict()
+
+    def forward_grouped(self, features: KeyedJaggedTensor, group_names=None):
+        self.sharded.train(self.training)
+        self._train_step = self.training and torch.is_grad_enabled() and self.sharded.fused_optimizer is not None
+        return self.sharded.forward_grouped(features, group_names)
