@@ -56,6 +56,9 @@ def parse_args():
                     help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
     ap.add_argument("--torch-bce", action="store_true", help="loss: torch BCE-with-logits instead of tzr_bce_logits")
     ap.add_argument("--torch-adam", action="store_true", help="dense optimizer: torch.optim.Adam(fused) instead of tzr_dense_adam")
+    ap.add_argument("--secondary-global-batch", type=int, default=None,
+                    help="sharded runs also time this global batch after the main loop (default at N > 1: the other "
+                         "scaling regime of --global-batch; 0 = off)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded runs: op-by-op autograd step instead of ShardedTrainStep")
     ap.add_argument("--no-plan-ahead", action="store_true",
@@ -266,16 +269,23 @@ def main():
     from torcheasyrec_amd.sparse import KeyedJaggedTensor
 
     nb = max(1, min(args.n_batches, args.warmup + args.steps))
-    batches, host_vals = [], []
-    for s in range(nb):
-        dense, kjt, label = synthetic_batch(s, B_global, rows, dist=args.dist)
-        if world > 1:  # this rank's slice of the global batch
-            sl = slice(rank * B_local, (rank + 1) * B_local)
-            v = kjt.values().view(len(rows), B_global)[:, sl].reshape(-1).contiguous()
-            kjt = KeyedJaggedTensor(kjt.keys(), v, torch.ones(len(rows) * B_local, dtype=torch.int32), uniform_length=1)
-            dense, label = dense[sl].contiguous(), label[sl].contiguous()
-        host_vals.append(kjt.values().numpy())
-        batches.append((dense.to(dev), kjt.to(dev), label.to(dev)))
+
+    def make_batches(Bg, seed0=0):
+        """nb batches of global size Bg; every rank keeps its contiguous slice."""
+        Bl = Bg // world
+        out, hv = [], []
+        for s in range(nb):
+            dense, kjt, label = synthetic_batch(seed0 + s, Bg, rows, dist=args.dist)
+            if world > 1 or Bl != Bg:
+                sl = slice(rank * Bl, (rank + 1) * Bl)
+                v = kjt.values().view(len(rows), Bg)[:, sl].reshape(-1).contiguous()
+                kjt = KeyedJaggedTensor(kjt.keys(), v, torch.ones(len(rows) * Bl, dtype=torch.int32), uniform_length=1)
+                dense, label = dense[sl].contiguous(), label[sl].contiguous()
+            hv.append(kjt.values().numpy())
+            out.append((dense.to(dev), kjt.to(dev), label.to(dev)))
+        return out, hv
+
+    batches, host_vals = make_batches(B_global)
     torch.cuda.synchronize()
 
     timers = _Timers()
@@ -348,6 +358,36 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.item())
 
+    # Secondary reading for N > 1: the OTHER scaling regime on the same model (BASELINE.md quotes the
+    # headline both ways: 65 536 per rank = tzrec's per-rank batch_size, and 65 536 global).  Same
+    # protocol (untimed warm-up, barrier + synchronize on both sides, max over ranks).
+    secondary = None
+    B2 = args.secondary_global_batch
+    if B2 is None:
+        B2 = (args.global_batch if args.scaling == "weak" else args.global_batch * world) if world > 1 else 0
+    if B2 and train_step is not None and B2 != B_global and B2 % world == 0:
+        b2, _ = make_batches(B2, seed0=1000)
+        for i in range(max(args.warmup, 4)):
+            step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        secondary = {"scaling": "strong" if args.scaling == "weak" else "weak", "global_batch": B2, "per_rank_batch": B2 // world,
+                     "value": B2 * args.steps / e2, "unit": "samples/s", "ms_per_step": e2 / args.steps * 1e3}
+
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     # inside a captured graph); the kernels and inputs are the ones of the timed region
     if ebc is not None:
@@ -381,6 +421,7 @@ def main():
                    "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism,
                    "row_layout": args.row_layout, "rows_cap": args.rows_cap or None},
         "final_loss": final_loss,
+        "secondary": secondary,
         "launch": ("hipGraph replay" if graphs is not None else
                    ("pipelined: input dist one batch ahead + hipGraph dense segment" if train_step is not None else "eager")),
     }
