@@ -389,3 +389,78 @@ def _zch_worker(rank, world, init_file, emu_path):
 def test_sharded_zch_world2(emu_path):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_zch_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
+def _seq_worker(rank, world, init_file, emu_path):
+    """Sharded unpooled (sequence) lookup: rows come back one per id in lookup order; the per-id
+    gradients reach the owners and the shards end where the unsharded collection ends on the global
+    batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+    from torcheasyrec_amd.sequence import EmbeddingCollection, EmbeddingConfig, ShardedEmbeddingCollection
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    D, Bl = 8, 9
+    keys = ["item_id", "click_seq__item_id", "cate_id"]
+    rows = {"item_emb": 300, "cate_emb": 40}
+
+    def seeded(t):
+        def f(w):
+            w.copy_((torch.rand(w.shape, generator=torch.Generator().manual_seed(50 + t)) - 0.5) * 0.3)
+        return f
+
+    cfgs = lambda: [EmbeddingConfig("item_emb", D, 300, ["item_id", "click_seq__item_id"], init_fn=seeded(0)),  # noqa: E731
+                    EmbeddingConfig("cate_emb", D, 40, ["cate_id"], init_fn=seeded(1))]
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+    sh = ShardedEmbeddingCollection(cfgs(), device=dev, optimizer=opt, constraints={"cate_emb": "table_wise"})
+    ref = EmbeddingCollection(cfgs(), device=dev, optimizer=opt)
+    per_rank = []
+    for r in range(world):
+        rng = np.random.default_rng(7 + r)
+        lens = np.concatenate([np.ones(Bl, np.int32), rng.integers(0, 6, size=Bl).astype(np.int32), np.ones(Bl, np.int32)])
+        vals = np.concatenate([rng.integers(0, 300, size=Bl), rng.integers(0, 300, size=int(lens[Bl:2 * Bl].sum())),
+                               rng.integers(0, 40, size=Bl)]).astype(np.int64)
+        per_rank.append((vals, lens))
+    vals, lens = per_rank[rank]
+    kjt = KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(lens))
+    out = sh(kjt)
+    with torch.no_grad():
+        want = ref(kjt)
+    assert list(out.keys()) == keys
+    g = {}
+    for k in keys:
+        assert torch.equal(out[k].values().detach(), want[k].values()), k  # a copy through two all-to-alls
+        assert torch.equal(out[k].lengths(), want[k].lengths())
+        g[k] = torch.randn(out[k].values().shape, generator=torch.Generator().manual_seed(rank * 10 + len(k)))
+    sum((out[k].values() * g[k]).sum() for k in keys).backward()
+    # reference: both ranks' lookups in one batch (rank-major samples per key), same gradients
+    gs = [None] * world
+    dist.all_gather_object(gs, g)
+    from oracle import tzrec_oracle as orc
+    off = [orc.lengths_to_offsets(l) for _, l in per_rank]
+    gv, gl, gg = [], [], {k: [] for k in keys}
+    for f, k in enumerate(keys):
+        for r in range(world):
+            v, l = per_rank[r]
+            gv.append(v[off[r][f * Bl]:off[r][(f + 1) * Bl]])
+            gl.append(l[f * Bl:(f + 1) * Bl])
+            gg[k].append(gs[r][k])
+    gk = KeyedJaggedTensor(keys, torch.from_numpy(np.concatenate(gv)), torch.from_numpy(np.concatenate(gl)))
+    ro = ref(gk)
+    sum((ro[k].values() * torch.cat(gg[k])).sum() for k in keys).backward()
+    for name in rows:
+        lo, n = sh.sharded.shard_of(name)
+        if n:
+            got = sh.table_weights()[name].detach()[:n]
+            torch.testing.assert_close(got, ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=2e-4, msg=name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sequence_lookup_world2(emu_path):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_seq_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)

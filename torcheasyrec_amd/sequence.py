@@ -219,6 +219,81 @@ class EmbeddingCollection(nn.Module):
         return out
 
 
+class _ShardedUnpooledFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ec, kjt, hook):
+        rows, st = ec._forward_impl(kjt)
+        ctx.ec, ctx.st = ec, st
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.ec._backward_impl(ctx.st, g)
+        return None, None, None
+
+
+class ShardedEmbeddingCollection(nn.Module):
+    """Unpooled lookup over tables sharded across ranks (BASELINE config 4 on 8 GPUs: the sequence
+    features of multi_tower_din).  It is the id-granularity exchange of `sharding.py` with the last
+    step left out: the rows come back from their owners one per id, and instead of pooling them the
+    requester just puts them back in lookup order; backward sends one gradient row per id to the
+    owner, whose sort + fused update is the per-id mode it already runs for pooled tables.
+
+    `forward(KJT) -> {key: JaggedTensor}` in the collection's key order (table, then feature).  All
+    tables take part in the exchange (row-wise by default, `constraints` for table-wise)."""
+
+    def __init__(self, tables: Sequence[EmbeddingConfig], device, optimizer: Optional[SparseOptimizerConfig] = None,
+                 process_group=None, constraints: Optional[Dict[str, str]] = None) -> None:
+        super().__init__()
+        from .sharding import ShardedEmbeddingBagCollection
+
+        self.sharded = ShardedEmbeddingBagCollection(
+            [EmbeddingBagConfig(t.name, t.embedding_dim, t.num_embeddings, list(t.feature_names), "sum", t.init_fn) for t in tables],
+            device=device, optimizer=optimizer, process_group=process_group, dp_max_rows=0, constraints=constraints)
+        self.dim = self.sharded.dim
+        self._device = torch.device(device)
+        self.fused_optimizer = self.sharded.fused_optimizer
+        self._hook = torch.zeros(0, requires_grad=True, device=self._device)
+
+    def table_weights(self):
+        return self.sharded.table_weights()
+
+    def _forward_impl(self, kjt: KeyedJaggedTensor):
+        sh = self.sharded
+        st = sh.input_dist_end(sh.input_dist_begin(kjt, ("__all__",)))
+        rows_in, _, work = sh.exchange_rows(st)
+        work.wait()
+        N = st["sub"].values().numel()
+        rows = rows_in[:N].index_select(0, st["unb"]) if N else rows_in[:0]  # bucketized order -> lookup order
+        return rows, st
+
+    def _backward_impl(self, st: dict, g: torch.Tensor) -> None:
+        N = st["sub"].values().numel()
+        grow = torch.empty(max(N, 1), self.dim, dtype=torch.float32, device=self._device)
+        if N:
+            grow[:N].index_copy_(0, st["unb"], g.contiguous().float())  # lookup order -> bucketized order
+        self.sharded._backward_impl(st, [], id_grads=grow)
+
+    def forward(self, features: KeyedJaggedTensor) -> Dict[str, JaggedTensor]:
+        if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
+            rows = _ShardedUnpooledFn.apply(self, features, self._hook)
+            st_sub = None
+        else:
+            rows, _ = self._forward_impl(features)
+        sh = self.sharded
+        rm = sh._requester_meta(features.keys(), sh._layout_for(("__all__",)))
+        perm = rm["rw_perm"]
+        sub = features if perm == list(range(len(features.keys()))) else features.permute(perm)
+        B = sub.stride()
+        off, lens, lpk = sub.offsets(), sub.lengths(), sub.length_per_key()
+        out, start = {}, 0
+        for i, k in enumerate(sub.keys()):
+            o = off[i * B:(i + 1) * B + 1] - off[i * B]
+            out[k] = JaggedTensor(rows[start:start + lpk[i]], lens[i * B:(i + 1) * B], o)
+            start += lpk[i]
+        return out
+
+
 class DINEncoder(nn.Module):
     """DIN target attention (same constructor/forward contract as the reference's DINEncoder,
     tzrec/modules/sequence.py:65-128): scores = MLP([q, k, q-k, q*k]) -> masked softmax -> sum."""

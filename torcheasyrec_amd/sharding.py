@@ -463,17 +463,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
             dsts[i].ptr, dsts[i].stride = _lib.ptr(o), o.stride(0)
         work = None
         if "rw_n" in rm:
-            om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
-            F, N = rm["rw_n"], sub.values().numel()
-            # owner: one row per received id (ZCH tables: raw id -> row through the owner's map first)
-            st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
-            rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
-            _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
-                                         om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(rows_out), D, D, stream),
-                       "tzr_rows_gather")
+            sub = st["sub"]
+            F = rm["rw_n"]
             # rows back to the requesters (bucketized order) -- in flight while the replicas are read
-            rows_in, d_pt = self._recv_rows_buffer(N, F)
-            work = self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
+            rows_in, d_pt, work = self.exchange_rows(st)
         if "dp_n" in rm:  # replicated tables: purely local, same destination buffers (other columns)
             _lib.check(L.tzr_pooled_fwd_ex(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
                                            _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
@@ -488,6 +481,22 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                         _lib.ptr(sub.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
                                         stream), "tzr_pooled_fwd")
         return outs
+
+    def exchange_rows(self, st: dict):
+        """Owner side of the forward: one embedding row per received id, sent back to the requesters.
+        Returns (rows_in [N, D] in bucketized order, its one-table descriptor, the in-flight all-to-all)."""
+        L, dev, D = _lib.lib(), self._device, self.dim
+        om, n_recv = st["om"], st["n_recv"]
+        F, N = st["rm"]["rw_n"], st["sub"].values().numel()
+        # ZCH tables: raw id -> row through the owner's map first
+        st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
+        rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
+                                     om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(rows_out), D, D,
+                                     _lib.stream_ptr(dev)), "tzr_rows_gather")
+        rows_in, d_pt = self._recv_rows_buffer(N, F)
+        work = self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
+        return rows_in, d_pt, work
 
     # K6 depends on ids only: a pipeline may run both plans right after the input dist, one batch
     # ahead on its side stream (`plan_ahead`), and the backward then starts at K7
@@ -530,7 +539,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         """Fused sparse optimizer step for the lookups of `st` given the pooled-output gradients."""
         self._backward_impl(st, grads)
 
-    def _backward_impl(self, st, grads) -> None:
+    def _backward_impl(self, st, grads, id_grads: Optional[torch.Tensor] = None) -> None:
+        """`grads`: gradients of the pooled outputs; or `id_grads` [N, D]: one gradient row per exchanged
+        lookup, already in bucketized order (the unpooled / sequence lookup)."""
         if self.fused_optimizer is None:
             return
         L = _lib.lib()
@@ -554,10 +565,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
             N, F = sub.values().numel(), rm["rw_n"]
             # requester: one gradient row per id, in bucketized order -> to the owners
-            grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
-            _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
-                                          _lib.ptr(sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
-                                          gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
+            if id_grads is not None:
+                grow = id_grads
+            else:
+                grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+                _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
+                                              _lib.ptr(sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
+                                              gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
             grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
             w_rows = self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"], async_op=True)
         if "dp_n" in rm:
