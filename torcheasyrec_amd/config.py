@@ -33,7 +33,7 @@ class Msg(dict):
 
 
 def _scalar(tok: str) -> Any:
-    if tok.startswith('"'):
+    if tok.startswith('"') or tok.startswith("'"):  # text format allows either quote
         return bytes(tok[1:-1], "utf-8").decode("unicode_escape")
     if tok in ("true", "True"):
         return True
@@ -120,6 +120,8 @@ class FeatureSpec:
     pooling: str = "sum"
     value_dim: int = 1
     trainable: bool = True
+    is_sequence: bool = False  # sub-feature of a `sequence_feature` block, named <sequence_name>__<feature_name>
+    sequence_length: int = 0
     data_type: str = "FP32"  # feature config `data_type` (FP32 | FP16)
     zch: Optional[Msg] = None  # the raw `zch {...}` block (see zch.zch_config_from_msg)
 
@@ -181,23 +183,34 @@ def sparse_optimizer_from_config(opt: Msg) -> SparseOptimizerConfig:
 def load_pipeline_spec(text: str) -> PipelineSpec:
     cfg = parse_text_proto(text)
     spec = PipelineSpec()
-    for fc in cfg.many("feature_configs"):
-        (kind, body), = fc.items()
-        f = body[-1]
-        name = f.one("feature_name") or f.one("sequence_name")
+    def one_feature(kind: str, f: Msg, prefix: str = "", seq_len: int = 0) -> FeatureSpec:
+        name = prefix + (f.one("feature_name") or f.one("sequence_name"))
+        seq = dict(is_sequence=bool(prefix), sequence_length=seq_len)
         if kind == "id_feature":
-            spec.features.append(FeatureSpec(
+            return FeatureSpec(
                 name=name, kind=kind, is_sparse=True, embedding_dim=int(f.one("embedding_dim", 0)),
                 num_embeddings=_num_embeddings(f, name), embedding_name=f.one("embedding_name"),
                 pooling=str(f.one("pooling", "sum")).lower(), trainable=bool(f.one("trainable", True)),
                 data_type=str(f.one("data_type", "FP32")).upper(),
-                zch=f.one("zch") if f.has("zch") else None))
-        elif kind == "raw_feature":
-            spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=False,
-                                             value_dim=int(f.one("value_dim", 1))))
+                zch=f.one("zch") if f.has("zch") else None, **seq)
+        if kind == "raw_feature":
+            nb = len(f.many("boundaries"))
+            if nb:  # bucketized raw feature = a sparse id in [0, len(boundaries)]  (raw_feature.py:50-60)
+                return FeatureSpec(name=name, kind=kind, is_sparse=True, embedding_dim=int(f.one("embedding_dim", 0)),
+                                   num_embeddings=nb + 1, embedding_name=f.one("embedding_name"), **seq)
+            return FeatureSpec(name=name, kind=kind, is_sparse=False, value_dim=int(f.one("value_dim", 1)), **seq)
+        return FeatureSpec(name=name, kind=kind, is_sparse=f.has("embedding_dim"), embedding_dim=int(f.one("embedding_dim", 0)), **seq)
+
+    for fc in cfg.many("feature_configs"):
+        (kind, body), = fc.items()
+        f = body[-1]
+        if kind == "sequence_feature":  # sub-features are named <sequence_name>__<feature_name> (feature.py)
+            sname, slen = f.one("sequence_name"), int(f.one("sequence_length", 0))
+            for sub in f.many("features"):
+                (skind, sbody), = sub.items()
+                spec.features.append(one_feature(skind, sbody[-1], prefix=f"{sname}__", seq_len=slen))
         else:
-            spec.features.append(FeatureSpec(name=name, kind=kind, is_sparse=f.has("embedding_dim"),
-                                             embedding_dim=int(f.one("embedding_dim", 0))))
+            spec.features.append(one_feature(kind, f))
     mc = cfg.one("model_config", Msg())
     for g in mc.many("feature_groups"):
         spec.feature_groups.append(FeatureGroupSpec(

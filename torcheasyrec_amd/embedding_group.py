@@ -84,9 +84,10 @@ class EmbeddingGroup(nn.Module):
         configs: "OrderedDict[str, EmbeddingBagConfig]" = OrderedDict()
         zch_blocks: Dict[str, object] = {}
         feat_group_table: Dict[str, Dict[str, str]] = {}
+        self._seq_groups = [g for g in feature_groups if g.group_type == "SEQUENCE"]
+        feature_groups = [g for g in feature_groups if g.group_type != "SEQUENCE"]
+        self._init_sequence_groups(name_to_feature, device, sparse_optimizer, row_layout)
         for g in feature_groups:
-            if g.group_type == "SEQUENCE":
-                raise NotImplementedError("sequence groups are SURVEY.md section 8(f) 'next'")
             for fname in g.feature_names:
                 f = name_to_feature[fname]
                 if f.is_sparse:
@@ -144,6 +145,11 @@ class EmbeddingGroup(nn.Module):
             # feature really feeds >1 table; align our keys with its naming
             self._ebc_groups = {g: [self._ebc_key(k) for k in ks] for g, ks in ebc_groups.items()}
             self.ebc._groups = self._ebc_groups
+        # one learning-rate handle for the pooled and the unpooled collections (sparse LR schedulers
+        # mutate fused_optimizer.param_groups, tzrec/main.py:877-879)
+        for ec in self.ecs.values():
+            if self.ebc is not None and ec.fused_optimizer is not None and self.ebc.fused_optimizer is not None:
+                ec.fused_optimizer.param_groups = self.ebc.fused_optimizer.param_groups
         # features with a `zch {...}` block: ids go through the managed-collision remap first
         # (the reference keeps them in a second collection, embedding.py:856-864; here the remap passes
         # the other keys through, so one collection serves both)
@@ -152,6 +158,72 @@ class EmbeddingGroup(nn.Module):
             from .zch import ManagedCollisionEmbeddingBagCollection, zch_config_from_msg
 
             self.mc = ManagedCollisionEmbeddingBagCollection(self.ebc, {t: zch_config_from_msg(z) for t, z in zch_blocks.items()})
+
+    # -- SEQUENCE groups (SequenceEmbeddingGroupImpl, tzrec/modules/embedding.py:993-1498) ---------------
+    # Every sparse feature of a sequence group is looked up UNPOOLED through its own tables (an
+    # EmbeddingCollection per embedding dim, embedding.py:1193-1197; tables are NOT shared with the
+    # pooled collection even when a feature also sits in a DEEP group).  Outputs per group g:
+    #   g.query            [B, sum D_q]      non-sequence features: the single id's row (raw features: values)
+    #   g.sequence         [B, Lmax, sum D_s] sequence features padded to the longest sequence of the batch
+    #   g.sequence_length  [B]               lengths of the group's first sequence feature
+    def _init_sequence_groups(self, name_to_feature, device, sparse_optimizer, row_layout) -> None:
+        from .sequence import EmbeddingCollection, EmbeddingConfig
+
+        self._seq_info: "OrderedDict[str, dict]" = OrderedDict()
+        by_dim: Dict[int, "OrderedDict[str, EmbeddingConfig]"] = {}
+        for g in self._seq_groups:
+            q, sq = [], []
+            for fname in g.feature_names:
+                f = name_to_feature[fname]
+                (sq if f.is_sequence else q).append(f)
+                if f.is_sparse:
+                    t = (f.embedding_name or f"{f.name}_emb") + (f"_{g.embedding_name_suffix}" if g.embedding_name_suffix else "")
+                    cfgs = by_dim.setdefault(f.embedding_dim, OrderedDict())
+                    if t in cfgs:
+                        if cfgs[t].num_embeddings != f.num_embeddings:
+                            raise AssertionError(f"there is a mismatch between tables named {t}, can not share embedding.")
+                        if fname not in cfgs[t].feature_names:
+                            cfgs[t].feature_names.append(fname)
+                    else:
+                        cfgs[t] = EmbeddingConfig(t, f.embedding_dim, f.num_embeddings, [fname])
+            if not sq:
+                raise ValueError(f"sequence group {g.group_name} has no sequence feature")
+            self._seq_info[g.group_name] = {
+                "query": q, "sequence": sq, "max_len": max(f.sequence_length for f in sq) or 0,
+                "query_dim": sum(f.embedding_dim if f.is_sparse else f.value_dim for f in q),
+                "sequence_dim": sum(f.embedding_dim if f.is_sparse else f.value_dim for f in sq)}
+        self.ecs = nn.ModuleDict({str(d): EmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
+                                                              row_layout=row_layout) for d, c in by_dim.items()})
+        self._ec_keys = {str(d): [f for c in cfgs.values() for f in c.feature_names] for d, cfgs in by_dim.items()}
+
+    def _forward_sequence_groups(self, sparse: KeyedJaggedTensor, dense_cols: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        from .sequence import jagged_to_padded_dense
+
+        jts = {}
+        index = {k: i for i, k in enumerate(sparse.keys())}
+        for d, ec in self.ecs.items():
+            keys = self._ec_keys[d]
+            jts.update(ec(sparse.permute([index[k] for k in keys])))
+        out: Dict[str, torch.Tensor] = {}
+        for g, info in self._seq_info.items():
+            qs = []
+            for f in info["query"]:
+                if f.is_sparse:  # single id per sample: its row (to_padded_dense(1).squeeze(1), embedding.py:1428-1430)
+                    jt = jts[f.name]
+                    qs.append(jagged_to_padded_dense(jt.values(), jt.offsets(), 1).squeeze(1))
+                else:
+                    qs.append(dense_cols[f.name])
+            if qs:
+                out[f"{g}.query"] = torch.cat(qs, dim=1)
+            first = jts[info["sequence"][0].name]
+            lens = first.lengths().to(torch.int64)
+            lmax = max(int(lens.max().item()) if lens.numel() else 0, 1)  # one host sync, as the reference's fx_int_item
+            if info["max_len"]:
+                lmax = min(lmax, info["max_len"])
+            out[f"{g}.sequence_length"] = lens
+            out[f"{g}.sequence"] = torch.cat(
+                [jagged_to_padded_dense(jts[f.name].values(), jts[f.name].offsets(), lmax) for f in info["sequence"]], dim=-1)
+        return out
 
     def _ebc_key(self, out_key: str) -> str:
         return out_key if out_key in self.ebc._out_dim else out_key.split("@")[0]
@@ -170,11 +242,18 @@ class EmbeddingGroup(nn.Module):
         return self._group_dims[name]
 
     def group_total_dim(self, name: str) -> int:
+        if "." in name:  # "<seq group>.query" / "<seq group>.sequence"
+            g, part = name.rsplit(".", 1)
+            return self._seq_info[g][f"{part}_dim"]
         return sum(self._group_dims[name].values())
 
     @property
     def fused_optimizer(self):
-        return self.ebc.fused_optimizer if self.ebc is not None else None
+        if self.ebc is not None:
+            return self.ebc.fused_optimizer
+        for ec in self.ecs.values():
+            return ec.fused_optimizer
+        return None
 
     def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
         sparse = batch.sparse_features.get(BASE_DATA_GROUP)
@@ -205,6 +284,8 @@ class EmbeddingGroup(nn.Module):
             if run:
                 parts.append(pooled[g][:, run[0]:run[1]])
             out[g] = torch.cat(parts, dim=1)
+        if self._seq_info:
+            out.update(self._forward_sequence_groups(batch.sparse_features.get(BASE_DATA_GROUP), dense_cols))
         return out
 
 

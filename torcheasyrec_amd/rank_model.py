@@ -119,7 +119,50 @@ class ConfigDeepFM(RankModel):
         return self._output_to_prediction(y)
 
 
-_MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM}
+class ConfigMultiTowerDIN(RankModel):
+    """`multi_tower_din {...}` (tzrec/models/multi_tower_din.py:36-111): one MLP tower per DEEP group,
+    one DIN target-attention tower per SEQUENCE group, concatenated, optional final MLP, logits layer."""
+
+    def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
+        super().__init__(spec, device, sparse_optimizer)
+        from .sequence import DINEncoder
+
+        eg, m = self.embedding_group, spec.model
+        self.towers = nn.ModuleDict()
+        total = 0
+        for tower in m.many("towers"):
+            g = str(tower.one("input"))
+            mlp = MLP(eg.group_total_dim(g), [int(x) for x in tower.one("mlp").many("hidden_units")])
+            self.towers[g] = mlp
+            total += mlp.output_dim()
+        self.din_towers = nn.ModuleList()
+        for tower in m.many("din_towers"):
+            g = str(tower.one("input"))
+            din = DINEncoder(eg.group_total_dim(f"{g}.sequence"), eg.group_total_dim(f"{g}.query"), g,
+                             attn_mlp={"hidden_units": [int(x) for x in tower.one("attn_mlp").many("hidden_units")]})
+            self.din_towers.append(din)
+            total += din.output_dim()
+        self.final_mlp = None
+        if m.has("final"):
+            self.final_mlp = MLP(total, [int(x) for x in m.one("final").many("hidden_units")])
+            total = self.final_mlp.output_dim()
+        self.output_mlp = OutputLinear(total, spec.num_class)
+        if device is not None:
+            for mod in (self.towers, self.din_towers, self.final_mlp, self.output_mlp):
+                if mod is not None:
+                    mod.to(device)
+
+    def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        g = self.build_input(batch)
+        outs = [mlp(g[name]) for name, mlp in self.towers.items()]
+        outs += [din(g) for din in self.din_towers]
+        y = torch.cat(outs, dim=-1)
+        if self.final_mlp is not None:
+            y = self.final_mlp(y)
+        return self._output_to_prediction(self.output_mlp(y))
+
+
+_MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": ConfigMultiTowerDIN}
 
 
 def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None) -> RankModel:
