@@ -252,3 +252,62 @@ def test_multi_tower_din_config_to_training(dev):
     assert n == 4
     for name, w in before.items():  # the unpooled tables were trained through the fused optimizer
         assert not torch.equal(ec.table_weights()[name].detach(), w), name
+
+
+def test_mmoe_with_zch_config_to_training(dev):
+    """BASELINE config 5 at the config level: `mmoe {...}` over a group whose user id goes through a
+    zero-collision hash (LFU eviction); two task towers, two labels, two losses."""
+    ref_cfg = os.path.join(REF, "mmoe_taobao.config")
+    if os.path.exists(ref_cfg):
+        big = load_pipeline_spec(open(ref_cfg).read())
+        assert big.model_name == "mmoe" and int(big.model.one("num_expert")) == 3
+        assert [str(t.one("tower_name")) for t in big.model.many("task_towers")] == ["ctr", "cvr"]
+        assert big.label_fields == ["clk", "buy"]
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "mmoe_mini.config")).read())
+    torch.manual_seed(0)
+    model = build_rank_model(spec, device=dev)
+    eg = model.embedding_group
+    assert eg.mc is not None and eg.mc.modules_by_table["user_id_emb"].cfg.policy == "lfu"
+    rng = np.random.default_rng(0)
+    users = rng.integers(1 << 40, 1 << 50, size=90).astype(np.int64)  # raw 64-bit user ids
+
+    def batches(n):
+        for _ in range(n):
+            b = 64
+            ids = np.concatenate([users[np.minimum(rng.zipf(1.5, size=b), 89)], rng.integers(0, 300, size=b), rng.integers(0, 20, size=b)])
+            kjt = KeyedJaggedTensor(["user_id", "adgroup_id", "pid"], torch.from_numpy(ids.astype(np.int64)), torch.ones(3 * b, dtype=torch.int32))
+            kt = KeyedTensor(["price"], [1], torch.from_numpy(rng.random((b, 1), dtype=np.float32)))
+            yield Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt},
+                        {"clk": torch.from_numpy((rng.random(b) < 0.3).astype(np.int64)), "buy": torch.from_numpy((rng.random(b) < 0.1).astype(np.int64))})
+
+    first = next(batches(1)).to(dev)
+    model.eval()
+    with torch.no_grad():
+        p = model(first)
+        x = eg(first)["all"]
+    lin = lambda seqm: [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seqm if hasattr(m, "weight")]  # noqa: E731
+    xe = x.cpu()
+    experts = torch.stack([orc.mlp(xe, lin(e.mlp)) for e in model.expert_mlps], dim=1)
+    for i, tower in enumerate(["ctr", "cvr"]):
+        gate = torch.softmax(torch.nn.functional.linear(xe, model.gate_finals[i].weight.detach().cpu(), model.gate_finals[i].bias.detach().cpu()), dim=1)
+        t_in = (gate.unsqueeze(2) * experts).sum(1)
+        y = orc.mlp(t_in, lin(model.task_mlps[i].mlp))
+        ref = torch.nn.functional.linear(y, model.task_outputs[i].weight.detach().cpu(), model.task_outputs[i].bias.detach().cpu()).squeeze(1)
+        torch.testing.assert_close(p[f"logits_{tower}"].cpu(), ref, rtol=1e-5, atol=1e-5)
+    model.train()
+    opt = torch.optim.Adam(list(model.dense_parameters()), lr=spec.dense_lr)
+    pipe = TrainPipeline(model, opt, dev, model.loss)
+    it = iter(batches(6))
+    n = 0
+    while True:
+        try:
+            losses, preds, _ = pipe.progress(it)
+        except StopIteration:
+            break
+        assert set(losses) == {"binary_cross_entropy_ctr", "binary_cross_entropy_cvr"}
+        assert all(np.isfinite(float(v.detach())) for v in losses.values())
+        n += 1
+    assert n == 6
+    m = eg.mc.modules_by_table["user_id_emb"]
+    held = m.row_ids[m.row_ids != (1 << 63) - 1]
+    assert held.numel() > 5 and bool((held >= (1 << 40)).all())  # raw user ids were admitted to rows

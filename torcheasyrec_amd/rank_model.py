@@ -162,7 +162,65 @@ class ConfigMultiTowerDIN(RankModel):
         return self._output_to_prediction(self.output_mlp(y))
 
 
-_MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": ConfigMultiTowerDIN}
+class ConfigMMoE(RankModel):
+    """`mmoe {...}` (tzrec/models/mmoe.py:36-96, tzrec/modules/mmoe.py:27-86): shared expert MLPs over
+    the (single) feature group, one softmax gate per task mixing them, a task tower (MLP + logits
+    layer) per task.  Predictions and losses carry the tower name as suffix, as the reference's
+    multi-task models do."""
+
+    def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
+        super().__init__(spec, device, sparse_optimizer)
+        eg, m = self.embedding_group, spec.model
+        self._group = eg.group_names()[0]
+        d_in = eg.group_total_dim(self._group)
+        hidden = [int(x) for x in m.one("expert_mlp").many("hidden_units")]
+        self.expert_mlps = nn.ModuleList([MLP(d_in, hidden) for _ in range(int(m.one("num_expert")))])
+        self.gate_mlps = None
+        gate_in = d_in
+        if m.has("gate_mlp"):
+            gh = [int(x) for x in m.one("gate_mlp").many("hidden_units")]
+            self.gate_mlps = nn.ModuleList([MLP(d_in, gh) for _ in m.many("task_towers")])
+            gate_in = gh[-1]
+        self._towers = [(str(t.one("tower_name")), str(t.one("label_name"))) for t in m.many("task_towers")]
+        self.gate_finals = nn.ModuleList([nn.Linear(gate_in, len(self.expert_mlps)) for _ in self._towers])
+        self.task_mlps = nn.ModuleList()
+        self.task_outputs = nn.ModuleList()
+        for t in m.many("task_towers"):
+            if int(t.one("num_class", 1)) != 1:
+                raise NotImplementedError("task towers with num_class > 1")
+            d = hidden[-1]
+            if t.has("mlp"):
+                th = [int(x) for x in t.one("mlp").many("hidden_units")]
+                self.task_mlps.append(MLP(d, th))
+                d = th[-1]
+            else:
+                self.task_mlps.append(nn.Identity())
+            self.task_outputs.append(OutputLinear(d, 1))
+        if device is not None:
+            for mod in (self.expert_mlps, self.gate_mlps, self.gate_finals, self.task_mlps, self.task_outputs):
+                if mod is not None:
+                    mod.to(device)
+
+    def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
+        x = self.build_input(batch)[self._group]
+        experts = torch.stack([e(x) for e in self.expert_mlps], dim=1)  # [B, E, H]
+        out: Dict[str, torch.Tensor] = {}
+        for i, (tower, _) in enumerate(self._towers):
+            g = self.gate_mlps[i](x) if self.gate_mlps is not None else x
+            gate = torch.softmax(self.gate_finals[i](g), dim=1).unsqueeze(1)
+            task_in = torch.matmul(gate, experts).squeeze(1)
+            logits = self.task_outputs[i](self.task_mlps[i](task_in)).squeeze(1)
+            out[f"logits_{tower}"], out[f"probs_{tower}"] = logits, torch.sigmoid(logits)
+        return out
+
+    def loss(self, predictions: Dict[str, torch.Tensor], batch: Batch) -> Dict[str, torch.Tensor]:
+        from .dlrm import bce_with_logits
+
+        return {f"binary_cross_entropy_{tower}": bce_with_logits(predictions[f"logits_{tower}"], batch.labels[label])
+                for tower, label in self._towers}
+
+
+_MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": ConfigMultiTowerDIN, "mmoe": ConfigMMoE}
 
 
 def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None) -> RankModel:
