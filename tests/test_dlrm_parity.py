@@ -22,7 +22,7 @@ def _lin(seq):
 def test_dlrm_criteo_step(dev, kind, dist):
     torch.manual_seed(1)
     rows = [min(r, 3000) for r in CRITEO_ROWS]
-    B, lr = 96, 0.05
+    B, lr = 40, 0.05
     model = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev,
                  sparse_optimizer=SparseOptimizerConfig(kind=kind, lr=lr))
     dense, kjt, label = synthetic_batch(3, B, rows, dist=dist)
