@@ -56,6 +56,20 @@ def main():
         us = e0.elapsed_time(e1) / 20 * 1e3
         res["profile" if profile else "lookup"] = {"us": us, "ids_per_s": n / (us * 1e-6),
                                                    "line_GBps": n * 144 / (us * 1e-6) / 1e9}
+    # one admission / eviction cycle with the table FULL (every candidate has to beat a resident)
+    mod.row_ids[:Z - 1] = torch.arange(1, Z, device=dev, dtype=torch.int64) * 2 + (1 << 61)
+    mod.counts[:Z - 1] = torch.randint(1, 50, (Z - 1,), device=dev, generator=g)
+    mod.rebuild()
+    cand_ids = torch.randint(0, 1 << 60, (n,), device=dev, generator=g, dtype=torch.int64)
+    cand_ids = cand_ids[torch.randint(0, n, (4 * n,), device=dev, generator=g)]  # duplicates: counts up to ~10
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    changed = mod.update_and_evict(cand_ids, 7)
+    e1.record()
+    torch.cuda.synchronize()
+    res["evict_cycle"] = {"ms": e0.elapsed_time(e1), "candidates": int(cand_ids.numel()), "rows_changed": int(changed.numel()),
+                          "peak_GB": torch.cuda.max_memory_allocated() / 2**30}
     hits = int((out != Z - 1).sum().item())
     res.update({"zch_rows": Z, "resident": int(raw.numel()), "ids": n, "hits": hits, "candidates": int((cand != _lib.ZCH_EMPTY).sum().item())})
     print(json.dumps(res))
