@@ -464,3 +464,102 @@ def _seq_worker(rank, world, init_file, emu_path):
 def test_sharded_sequence_lookup_world2(emu_path):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_seq_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
+def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
+    """A config-built rank model over a process group (the DistributedModelParallel seam): logits on my
+    slice equal the unsharded model's logits on the same samples; after one step the tables end
+    where the unsharded model's end on the GLOBAL batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.config import load_pipeline_spec
+    from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch
+    from torcheasyrec_amd.rank_model import build_rank_model
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    spec = load_pipeline_spec(open(os.path.join(os.path.dirname(__file__), "golden", cfg_name)).read())
+    torch.manual_seed(11)
+    ref = build_rank_model(spec, device=dev)
+    torch.manual_seed(11)
+    from torcheasyrec_amd.sharding import make_plan
+
+    plan = make_plan(ref.embedding_group.ebc.embedding_bag_configs(), world, dp_max_rows=50)  # big tables row-wise, small replicated
+    assert {p["sharding_type"] for p in plan.values()} == {"row_wise", "data_parallel"}
+    shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan)
+    # same starting tables: copy the reference's rows into my shards
+    for name, w in ref.embedding_group.ebc.table_weights().items():
+        lo, n = shd.embedding_group.ebc.shard_of(name)
+        shd.embedding_group.ebc.table_weights()[name].data[:n].copy_(w.data[lo:lo + n])
+    for d, ec in ref.embedding_group.ecs.items():
+        sec = shd.embedding_group.ecs[d]
+        for name, w in ec.table_weights().items():
+            lo, n = sec.sharded.shard_of(name)
+            sec.table_weights()[name].data[:n].copy_(w.data[lo:lo + n])
+    for pr, ps in zip(ref.dense_parameters(), shd.dense_parameters()):
+        ps.data.copy_(pr.data)
+    sparse = [f for f in spec.features if f.is_sparse]
+    dense = [f for f in spec.features if not f.is_sparse]
+    Bl = 10
+    parts = []
+    for r in range(world):
+        rng = np.random.default_rng(40 + r)
+        lens, vals = [], []
+        seq0 = None
+        for f in sparse:
+            if f.is_sequence:
+                ln = seq0 if seq0 is not None else rng.integers(0, 5, size=Bl).astype(np.int32)
+                seq0 = ln
+            else:
+                ln = np.ones(Bl, np.int32)
+            lens.append(ln)
+            vals.append(rng.integers(0, f.num_embeddings, size=int(ln.sum())))
+        parts.append((vals, lens, rng.random((Bl, sum(f.value_dim for f in dense)), dtype=np.float32),
+                      {l: (rng.random(Bl) < 0.4).astype(np.int64) for l in label_names}))
+
+    def batch_of(rs):
+        vals = [np.concatenate([parts[r][0][i] for r in rs]) for i in range(len(sparse))]
+        lens = [np.concatenate([parts[r][1][i] for r in rs]) for i in range(len(sparse))]
+        kjt = KeyedJaggedTensor([f.name for f in sparse], torch.from_numpy(np.concatenate(vals).astype(np.int64)), torch.from_numpy(np.concatenate(lens)))
+        kt = KeyedTensor([f.name for f in dense], [f.value_dim for f in dense], torch.from_numpy(np.concatenate([parts[r][2] for r in rs])))
+        return Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt}, {l: torch.from_numpy(np.concatenate([parts[r][3][l] for r in rs])) for l in label_names})
+
+    mine, full = batch_of([rank]), batch_of(list(range(world)))
+    ps = shd(mine)
+    pr = ref(full)
+    for k in ps:
+        if k.startswith("logits"):
+            torch.testing.assert_close(ps[k].detach(), pr[k].detach()[rank * Bl:(rank + 1) * Bl], rtol=1e-5, atol=1e-6)
+    # per-rank mean loss on the shards; the reference applies the SUM of the per-rank losses, whose
+    # sparse gradients are the un-averaged sum torchrec applies (SURVEY appendix A.7)
+    sum(shd.loss(ps, mine).values()).backward()
+    shd.allreduce_dense_grads()
+    ref_loss = 0
+    for r in range(world):
+        sub = {k: v[r * Bl:(r + 1) * Bl] for k, v in pr.items()}
+        lab = Batch({}, {}, {l: full.labels[l][r * Bl:(r + 1) * Bl] for l in label_names})
+        ref_loss = ref_loss + sum(ref.loss(sub, lab).values())
+    ref_loss.backward()
+    for qs, qr in zip(shd.dense_parameters(), ref.dense_parameters()):
+        torch.testing.assert_close(qs.grad, qr.grad / world, rtol=1e-4, atol=1e-6)
+    for name, w in ref.embedding_group.ebc.table_weights().items():
+        lo, n = shd.embedding_group.ebc.shard_of(name)
+        if n:
+            torch.testing.assert_close(shd.embedding_group.ebc.table_weights()[name].detach()[:n], w.detach()[lo:lo + n],
+                                       rtol=2e-4, atol=1e-4, msg=name)
+    for d, ec in ref.embedding_group.ecs.items():
+        sec = shd.embedding_group.ecs[d]
+        for name, w in ec.table_weights().items():
+            lo, n = sec.sharded.shard_of(name)
+            if n:
+                torch.testing.assert_close(sec.table_weights()[name].detach()[:n], w.detach()[lo:lo + n], rtol=2e-4, atol=1e-4, msg=name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,labels", [("din_mini.config", ["clk"])])
+def test_config_model_over_a_process_group(emu_path, cfg, labels):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels), nprocs=2, join=True)

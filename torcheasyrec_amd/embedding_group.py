@@ -78,8 +78,18 @@ class EmbeddingGroup(nn.Module):
         device: Optional[torch.device] = None,
         sparse_optimizer: Optional[SparseOptimizerConfig] = None,
         row_layout: str = "interleaved",
+        process_group=None,
+        plan: Optional[Dict[str, dict]] = None,
+        dp_max_rows: int = 65536,
     ) -> None:
+        """`process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
+        the reference, tzrec/main.py:783-804): pooled tables go to a ShardedEmbeddingBagCollection
+        (placement from `plan`, e.g. planner.plan_tables, or the size heuristic), sequence tables to
+        ShardedEmbeddingCollections, `zch` tables to the hash-routed sharded map.  Needs one embedding
+        dim across the pooled tables and no feature feeding two pooled tables (DLRM, multi_tower_din,
+        mmoe; DeepFM's wide + deep tables are not supported sharded)."""
         super().__init__()
+        self._pg, self._plan_in, self._dp_max_rows = process_group, plan, dp_max_rows
         name_to_feature = {f.name: f for f in features}
         configs: "OrderedDict[str, EmbeddingBagConfig]" = OrderedDict()
         zch_blocks: Dict[str, object] = {}
@@ -138,9 +148,26 @@ class EmbeddingGroup(nn.Module):
         # columns in get one concat on top
         ebc_groups = {g: [k for kind, k, _ in blocks if kind == "sparse"] for g, blocks in self._group_blocks.items()}
         ebc_groups = {g: ks for g, ks in ebc_groups.items() if ks}
-        self.ebc = EmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
-                                          groups=ebc_groups, row_layout=row_layout) if self.has_sparse else None
-        if self.ebc is not None:
+        self._sharded_zch = None
+        if self.has_sparse and self._pg is not None:
+            from .sharding import ShardedEmbeddingBagCollection
+
+            if zch_blocks:
+                from .zch import ShardedManagedCollisionEmbeddingBagCollection, zch_config_from_msg
+
+                self._sharded_zch = ShardedManagedCollisionEmbeddingBagCollection(
+                    list(configs.values()), {t: zch_config_from_msg(z) for t, z in zch_blocks.items()}, device=device,
+                    optimizer=sparse_optimizer, groups=ebc_groups, process_group=self._pg, dp_max_rows=self._dp_max_rows)
+                self.ebc = self._sharded_zch.sharded
+                zch_blocks = {}
+            else:
+                self.ebc = ShardedEmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
+                                                         groups=ebc_groups, row_layout=row_layout, process_group=self._pg,
+                                                         dp_max_rows=self._dp_max_rows, plan=self._plan_in)
+        else:
+            self.ebc = EmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
+                                              groups=ebc_groups, row_layout=row_layout) if self.has_sparse else None
+        if self.ebc is not None and self._pg is None:
             # a feature shared by several tables is named feature@table by the EBC only when the
             # feature really feeds >1 table; align our keys with its naming
             self._ebc_groups = {g: [self._ebc_key(k) for k in ks] for g, ks in ebc_groups.items()}
@@ -192,8 +219,14 @@ class EmbeddingGroup(nn.Module):
                 "query": q, "sequence": sq, "max_len": max(f.sequence_length for f in sq) or 0,
                 "query_dim": sum(f.embedding_dim if f.is_sparse else f.value_dim for f in q),
                 "sequence_dim": sum(f.embedding_dim if f.is_sparse else f.value_dim for f in sq)}
-        self.ecs = nn.ModuleDict({str(d): EmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
-                                                              row_layout=row_layout) for d, c in by_dim.items()})
+        if self._pg is not None:
+            from .sequence import ShardedEmbeddingCollection
+
+            self.ecs = nn.ModuleDict({str(d): ShardedEmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
+                                                                         process_group=self._pg) for d, c in by_dim.items()})
+        else:
+            self.ecs = nn.ModuleDict({str(d): EmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
+                                                                  row_layout=row_layout) for d, c in by_dim.items()})
         self._ec_keys = {str(d): [f for c in cfgs.values() for f in c.feature_names] for d, cfgs in by_dim.items()}
 
     def _forward_sequence_groups(self, sparse: KeyedJaggedTensor, dense_cols: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -261,7 +294,11 @@ class EmbeddingGroup(nn.Module):
         if self.mc is not None:
             self.mc.train(self.training)
             sparse = self.mc.remap_step(sparse)
-        pooled = self.ebc.forward_grouped(sparse) if self.ebc is not None else {}
+        if self._sharded_zch is not None:  # owner-side remap / eviction happen inside the sharded exchange
+            self._sharded_zch.train(self.training)
+            pooled = self._sharded_zch.forward_grouped(sparse)
+        else:
+            pooled = self.ebc.forward_grouped(sparse) if self.ebc is not None else {}
         if self.mc is not None:
             self.mc.finish_step()
         dense_cols = dense.to_dict() if dense is not None else {}
@@ -328,5 +365,7 @@ class TrainPipeline:
         losses = self._loss_fn(predictions, batch)
         total = sum(losses.values())
         total.backward()
+        if hasattr(self._model, "allreduce_dense_grads"):
+            self._model.allreduce_dense_grads()  # no-op unless the model was built over a process group
         self._opt.step()
         return losses, predictions, batch

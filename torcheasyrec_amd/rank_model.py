@@ -21,13 +21,37 @@ from .interaction import FactorizationMachine, dot_interaction
 
 
 class RankModel(nn.Module):
+    # set by build_rank_model(..., process_group=...): tables sharded over the group's ranks, dense
+    # parameters data-parallel (the DistributedModelParallel seam, tzrec/main.py:783-804)
+    _build_pg = None
+    _build_plan = None
+
     def __init__(self, spec: PipelineSpec, device: Optional[torch.device], sparse_optimizer: Optional[SparseOptimizerConfig]) -> None:
         super().__init__()
         self._spec = spec
         self._label = spec.label_fields[0] if spec.label_fields else "label"
+        self._pg = RankModel._build_pg
         self.embedding_group = EmbeddingGroup(
             spec.features, spec.feature_groups, wide_embedding_dim=spec.wide_embedding_dim or None,
-            device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer)
+            device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer,
+            process_group=self._pg, plan=RankModel._build_plan)
+
+    def sync_dense_parameters(self) -> None:
+        """Same dense parameters on every rank (DDP broadcasts rank 0's at construction)."""
+        if self._pg is not None:
+            import torch.distributed as dist
+
+            for p in self.dense_parameters():
+                dist.broadcast(p.data, src=0, group=self._pg)
+
+    def allreduce_dense_grads(self) -> None:
+        """DDP semantics for the dense parameters: average their gradients over the ranks (one flat
+        all-reduce); sparse gradients were already applied by the owners inside backward."""
+        if self._pg is None:
+            return
+        from .sharding import allreduce_average
+
+        allreduce_average([p.grad for p in self.dense_parameters() if p.grad is not None], self._pg)
 
     def build_input(self, batch: Batch) -> Dict[str, torch.Tensor]:
         return self.embedding_group(batch)
@@ -223,8 +247,17 @@ class ConfigMMoE(RankModel):
 _MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": ConfigMultiTowerDIN, "mmoe": ConfigMMoE}
 
 
-def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None) -> RankModel:
-    """Class chosen by the model_config oneof name, as tzrec/main.py:151-153 does."""
+def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None, process_group=None,
+                     plan: Optional[Dict[str, dict]] = None) -> RankModel:
+    """Class chosen by the model_config oneof name, as tzrec/main.py:151-153 does.  With
+    `process_group` the embedding tables are sharded over its ranks (`plan`: planner.plan_tables output
+    or None for the size heuristic) and the dense parameters are kept identical across ranks."""
     if spec.model_name not in _MODELS:
         raise NotImplementedError(f"model {spec.model_name!r} is outside SURVEY.md section 8")
-    return _MODELS[spec.model_name](spec, device, sparse_optimizer)
+    RankModel._build_pg, RankModel._build_plan = process_group, plan
+    try:
+        model = _MODELS[spec.model_name](spec, device, sparse_optimizer)
+    finally:
+        RankModel._build_pg, RankModel._build_plan = None, None
+    model.sync_dense_parameters()
+    return model

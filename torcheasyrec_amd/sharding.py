@@ -623,6 +623,21 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return dict(zip(names, outs))
 
 
+def allreduce_average(grads: Sequence[torch.Tensor], process_group=None) -> None:
+    """Average `grads` over the ranks in place: pack, ONE all-reduce, unpack (3 launches)."""
+    gs = [g for g in grads if g is not None]
+    if not gs:
+        return
+    world = dist.get_world_size(process_group)
+    flat = torch.cat([g.reshape(-1) for g in gs])
+    if flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group)
+    else:  # gloo has no AVG
+        dist.all_reduce(flat, group=process_group)
+        flat.div_(world)
+    torch._foreach_copy_(gs, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in gs]), gs)])
+
+
 class ShardedDLRM(nn.Module):
     """DLRM with sharded tables and data-parallel MLPs."""
 
