@@ -311,3 +311,28 @@ def test_mmoe_with_zch_config_to_training(dev):
     m = eg.mc.modules_by_table["user_id_emb"]
     held = m.row_ids[m.row_ids != (1 << 63) - 1]
     assert held.numel() > 5 and bool((held >= (1 << 40)).all())  # raw user ids were admitted to rows
+
+
+def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path):
+    from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
+
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "din_mini.config")).read())
+    torch.manual_seed(0)
+    a = build_rank_model(spec, device=dev)
+    opt = torch.optim.Adam(list(a.dense_parameters()), lr=spec.dense_lr)
+    pipe = TrainPipeline(a, opt, dev, a.loss)
+    it = iter(_din_batches(spec, 128, 64, seed=3))
+    for _ in range(2):
+        pipe.progress(it)
+    save_checkpoint(str(tmp_path), a, opt)
+    assert set(read_plan(str(tmp_path))) == {"embedding_group.ebc", "embedding_group.ecs.16"}
+    torch.manual_seed(9)
+    b = build_rank_model(spec, device=dev)
+    restore_checkpoint(str(tmp_path), b)
+    probe = next(_din_batches(spec, 64, 64, seed=8)).to(dev)
+    a.eval(), b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(probe)["logits"], b(probe)["logits"])
+    for n, w in a.embedding_group.ecs["16"].table_weights().items():
+        assert torch.equal(b.embedding_group.ecs["16"].table_weights()[n].detach(), w.detach()), n
+        assert torch.equal(b.embedding_group.ecs["16"].table_states()[n].detach(), a.embedding_group.ecs["16"].table_states()[n].detach())

@@ -6,7 +6,8 @@ can resume under a different plan) and a `plan` JSON `{module_path: {param: {sha
 compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
 
   <dir>/model/rank<r>.pt       {"dense": {param: tensor},
-                                "tables": {table: {"lo", "n", "weight"[n, D]}},      rows [lo, lo+n)
+                                "tables": {"<module path>/<table>": {"lo", "n", "weight"[n, D]}},   rows [lo, lo+n)
+                                           (module path: "ebc", "embedding_group.ebc", "embedding_group.ecs.<dim>")
                                 "zch": {"iter", "tables": {table: {row_ids, counts, last_iter}}} | None}
   <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "dense": optimizer.state_dict()}
   <dir>/plan                   the reference's plan JSON (rank 0)
@@ -37,12 +38,21 @@ def _rank_world() -> Tuple[int, int]:
     return 0, 1
 
 
-def _ebc_of(model: nn.Module):
-    for holder in (model, getattr(model, "embedding_group", None)):
-        ebc = getattr(holder, "ebc", None) if holder is not None else None
-        if ebc is not None:
-            return ebc
-    raise ValueError("model has no `.ebc` / `.embedding_group.ebc` (EmbeddingBagCollection or ShardedEmbeddingBagCollection)")
+def _collections(model: nn.Module):
+    """[(module path, collection)]: every table-holding collection of the model -- the pooled one
+    (`ebc`, plain or sharded) and, for config-built models with SEQUENCE groups, the unpooled ones."""
+    out = []
+    for path, holder in (("", model), ("embedding_group.", getattr(model, "embedding_group", None))):
+        if holder is None:
+            continue
+        ebc = getattr(holder, "ebc", None)
+        if ebc is not None and not any(c is ebc for _, c in out):
+            out.append((path + "ebc", ebc))
+        for d, ec in getattr(holder, "ecs", {}).items():
+            out.append((f"{path}ecs.{d}", getattr(ec, "sharded", None) or ec._store))
+    if not out:
+        raise ValueError("model has no `.ebc` / `.embedding_group.ebc` (EmbeddingBagCollection or ShardedEmbeddingBagCollection)")
+    return out
 
 
 def _mc_of(model: nn.Module):
@@ -69,25 +79,30 @@ def _placement(ebc) -> Dict[str, Tuple[int, int, int, str]]:
 
 
 def _dense_state(model: nn.Module) -> Dict[str, torch.Tensor]:
-    tables = {id(w) for w in _ebc_of(model).table_weights().values()}
+    tables = {id(w) for _, c in _collections(model) for w in c.table_weights().values()}
     return {n: p.detach().cpu() for n, p in model.named_parameters() if id(p) not in tables and ".embedding_bags." not in n}
 
 
-def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None,
-                    module_path: str = "ebc") -> None:
+def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None) -> None:
     rank, world = _rank_world()
-    ebc = _ebc_of(model)
-    place = _placement(ebc)
+    cols = _collections(model)
     for sub in ("model", "optimizer"):
         os.makedirs(os.path.join(checkpoint_dir, sub), exist_ok=True)
-    weights, states = ebc.table_weights(), ebc.table_states()
-    m_tables, o_tables = {}, {}
-    for name, (lo, n, _, kind) in place.items():
-        if n == 0 or (kind == "data_parallel" and rank != 0):
-            continue
-        m_tables[name] = {"lo": lo, "n": n, "weight": weights[name].detach()[:n].cpu().contiguous()}
-        if name in states:
-            o_tables[name] = {"lo": lo, "n": n, "momentum1": states[name].detach()[:n].cpu().contiguous()}
+    m_tables, o_tables, plan_js, dims = {}, {}, {}, {}
+    for path, col in cols:
+        weights, states = col.table_weights(), col.table_states()
+        for name, (lo, n, _, kind) in _placement(col).items():
+            if n == 0 or (kind == "data_parallel" and rank != 0):
+                continue
+            key = f"{path}/{name}"
+            m_tables[key] = {"lo": lo, "n": n, "weight": weights[name].detach()[:n].cpu().contiguous()}
+            if name in states:
+                o_tables[key] = {"lo": lo, "n": n, "momentum1": states[name].detach()[:n].cpu().contiguous()}
+        plan = col.plan() if hasattr(col, "plan") else {n: {"sharding_type": "table_wise", "ranks": [0]} for n in _placement(col)}
+        plan_js[path] = {n: {"sharding_type": p["sharding_type"], "compute_kernel": p.get("compute_kernel", "fused"),
+                             "ranks": list(p["ranks"])} for n, p in plan.items()}
+        for c in (col._global if hasattr(col, "_global") else col.embedding_bag_configs()):
+            dims[f"{path}/{c.name}"] = [c.num_embeddings, c.embedding_dim]
     mc = _mc_of(model)
     zch = None
     if mc is not None and rank == 0:  # raw id / access count / last access of every row + the step counter
@@ -95,18 +110,13 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
                                             for n, m in mc.modules_by_table.items()}}
     torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables, "zch": zch},
                os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
-    fo = getattr(ebc, "fused_optimizer", None)
+    fo = getattr(cols[0][1], "fused_optimizer", None)
     torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"],
                 "dense": dense_optimizer.state_dict() if (dense_optimizer is not None and rank == 0) else None},
                os.path.join(checkpoint_dir, "optimizer", f"rank{rank}.pt"))
     if rank == 0:
-        plan = ebc.plan() if hasattr(ebc, "plan") else {n: {"sharding_type": "table_wise", "ranks": [0]} for n in place}
-        js = {module_path: {f"{n}": {"sharding_type": p["sharding_type"], "compute_kernel": p.get("compute_kernel", "fused"),
-                                     "ranks": list(p["ranks"])} for n, p in plan.items()}}
         with open(os.path.join(checkpoint_dir, "plan"), "w") as f:
-            json.dump(js, f)
-        dims = {c.name: [c.num_embeddings, c.embedding_dim]
-                for c in (ebc._global if hasattr(ebc, "_global") else ebc.embedding_bag_configs())}
+            json.dump(plan_js, f)
         with open(os.path.join(checkpoint_dir, "meta.json"), "w") as f:
             json.dump({"format": FORMAT_VERSION, "world_size": world, "tables": dims}, f)
     if world > 1:
@@ -131,33 +141,36 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
     if meta.get("format") != FORMAT_VERSION:
         raise ValueError(f"checkpoint format {meta.get('format')} != {FORMAT_VERSION}")
     saved_world = int(meta["world_size"])
-    ebc = _ebc_of(model)
-    place = _placement(ebc)
-    for name, (_, _, total, _) in place.items():
-        if name not in meta["tables"]:
-            if strict:
-                raise KeyError(f"checkpoint has no table {name}")
-            continue
-        if meta["tables"][name][0] != total:
-            raise ValueError(f"{name}: checkpoint has {meta['tables'][name][0]} rows, model {total}")
+    cols = _collections(model)
+    for path, col in cols:
+        for name, (_, _, total, _) in _placement(col).items():
+            key = f"{path}/{name}"
+            if key not in meta["tables"]:
+                if strict:
+                    raise KeyError(f"checkpoint has no table {key}")
+                continue
+            if meta["tables"][key][0] != total:
+                raise ValueError(f"{key}: checkpoint has {meta['tables'][key][0]} rows, model {total}")
     m_files = [torch.load(os.path.join(checkpoint_dir, "model", f"rank{r}.pt"), mmap=True, weights_only=True)
                for r in range(saved_world)]
     o_files = [torch.load(os.path.join(checkpoint_dir, "optimizer", f"rank{r}.pt"), mmap=True, weights_only=True)
                for r in range(saved_world)]
-    weights, states = ebc.table_weights(), ebc.table_states()
     with torch.no_grad():
-        for name, (lo, n, _, _) in place.items():
-            if n == 0 or name not in meta["tables"]:
-                continue
-            got = _fill(weights[name].detach(), lo, n, [f["tables"][name] for f in m_files if name in f["tables"]], "weight", name)
-            if got != n:
-                raise ValueError(f"{name}: rows [{lo}, {lo + n}) only partly present in the checkpoint ({got} of {n})")
-            if name in states:
-                pcs = [f["tables"][name] for f in o_files if name in f["tables"]]
-                if pcs:
-                    _fill(states[name].detach(), lo, n, pcs, "momentum1", name)
-                elif strict:
-                    raise KeyError(f"checkpoint has no optimizer state for {name}")
+        for path, col in cols:
+            weights, states = col.table_weights(), col.table_states()
+            for name, (lo, n, _, _) in _placement(col).items():
+                key = f"{path}/{name}"
+                if n == 0 or key not in meta["tables"]:
+                    continue
+                got = _fill(weights[name].detach(), lo, n, [f["tables"][key] for f in m_files if key in f["tables"]], "weight", key)
+                if got != n:
+                    raise ValueError(f"{key}: rows [{lo}, {lo + n}) only partly present in the checkpoint ({got} of {n})")
+                if name in states:
+                    pcs = [f["tables"][key] for f in o_files if key in f["tables"]]
+                    if pcs:
+                        _fill(states[name].detach(), lo, n, pcs, "momentum1", key)
+                    elif strict:
+                        raise KeyError(f"checkpoint has no optimizer state for {key}")
         dense = m_files[0]["dense"]
         mine = dict(model.named_parameters())
         for n_, t in dense.items():
@@ -179,7 +192,7 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                 m.rebuild()
             elif strict:
                 raise KeyError(f"checkpoint has no zch state for {n}")
-    fo = getattr(ebc, "fused_optimizer", None)
+    fo = getattr(cols[0][1], "fused_optimizer", None)
     if fo is not None and o_files[0].get("sparse_lr") is not None:
         fo.param_groups[0]["lr"] = o_files[0]["sparse_lr"]
     if dense_optimizer is not None and o_files[0].get("dense") is not None:
