@@ -251,8 +251,8 @@ def test_backward_long_runs(dev):
     opt = SparseOptimizerConfig(kind="adagrad", lr=0.05)
     # 2600 lookups per table: the 1-row table is ONE run over three 1024-position chunks (leading piece,
     # whole-chunk piece, trailing piece), the 3-row table's runs cross chunk and wave-range boundaries
-    spec = [("t_mid", 300, 16, "sum", ["c0"]), ("t_one", 1, 16, "sum", ["c1"]), ("t_tiny", 3, 16, "sum", ["c2"])]
-    _run_backward_case(dev, spec, ["c0", "c1", "c2"], [300, 1, 3], 2600, "uniform1", False, opt, steps=1, rtol=5e-4)
+    spec = [("t_one", 1, 16, "sum", ["c0"]), ("t_tiny", 3, 16, "sum", ["c1"])]
+    _run_backward_case(dev, spec, ["c0", "c1"], [1, 3], 2600, "uniform1", False, opt, steps=1, rtol=5e-4)
 
 
 @pytest.mark.parametrize("kind,weighted", [("adagrad", False), ("rowwise_adagrad", True)])

@@ -342,7 +342,7 @@ def _zch_worker(rank, world, init_file, emu_path):
     oracle = ZchTable(Z // world, 2, "distance_lfu")  # my share of the map
     universe = np.random.default_rng(1).integers(-(1 << 60), 1 << 60, size=150).astype(np.int64)
     m.train()
-    for step in range(1, 8):
+    for step in range(1, 6):
         batches = []
         for r in range(world):  # both ranks' batches are reproducible everywhere
             rng = np.random.default_rng(100 * step + r)
