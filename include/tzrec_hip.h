@@ -182,6 +182,21 @@ int tzr_block_bucketize(const int64_t* d_block_sizes, const int32_t* d_rank_offs
                         int64_t* d_new_offsets, int64_t* d_new_values, float* d_new_weights,
                         int64_t* d_unbucketize_permute, void* ws, size_t ws_bytes, void* stream);
 
+/* Requester side of the sharded exchange for a KJT whose bags all hold `bag_len` ids (Criteo: 1):
+ * K1 + K2 restricted to what the id-granularity exchange consumes, in 3 launches instead of 13.
+ * For the n_sel selected keys (d_sel[f'] = KJT key index; block size / rank offset per selected key
+ * as in tzr_block_bucketize, block size 0 = hash routing):
+ *   d_out_ids[N']       local ids grouped by (owner rank, selected key), lookup order inside a group
+ *   d_unbucketize[N']   position in d_out_ids of lookup j of selected key f' at index f'*B*bag_len + j
+ *   d_counts[W*n_sel]   ids per (rank, key), rank-major (what the counts all-to-all sends)
+ * with N' = n_sel * B * bag_len.  W <= 64 and W * n_sel <= 256 in this build.  Same results as
+ * tzr_kjt_permute + tzr_block_bucketize (tests compare them). */
+size_t tzr_exchange_bucketize_workspace(int n_sel, int64_t n_per_key, int W);
+int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
+                           const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
+                           const int64_t* d_values, int64_t* d_out_ids, int64_t* d_unbucketize,
+                           int64_t* d_counts, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- pooled embedding lookup ------------------------------------------------------------- */
 
 /* K5 (+K8 fused): pooled gather forward.  Replaces torchrec EmbeddingBagCollection.forward ->

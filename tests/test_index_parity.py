@@ -128,3 +128,38 @@ def test_block_bucketize_hash_routing(dev, W):
     if W == 8:  # the hash spreads: no rank is starved or flooded
         counts = np.array([len(g) for g in got])
         assert counts.min() > 0
+
+
+@pytest.mark.parametrize("W,hashed", [(1, False), (2, False), (8, False), (8, True), (5, True)])
+def test_exchange_bucketize_equals_permute_then_bucketize(dev, W, hashed):
+    """The lean 3-launch bucketize of the sharded exchange (uniform bags, selected keys) gives exactly
+    what K1 permute + K2 bucketize give: ids by (rank, key) in lookup order, positions, counts."""
+    rng = np.random.default_rng(W * 3 + hashed)
+    F, B = 5, 2500  # 3 tiles per key, ragged last tile
+    rows = [1000, 17, 40_000_000, 300, 9]
+    keys = [f"k{i}" for i in range(F)]
+    vals = np.stack([rng.integers(0, rows[f], size=B) for f in range(F)]).astype(np.int64)
+    if hashed:
+        vals[1] = rng.integers(-(1 << 62), 1 << 62, size=B)
+    kjt = KeyedJaggedTensor(keys, torch.from_numpy(vals.reshape(-1).copy()), torch.ones(F * B, dtype=torch.int32), uniform_length=1).to(dev)
+    sel = [3, 1, 2]  # a subset, reordered
+    block = np.array([(rows[f] + W - 1) // W for f in sel], dtype=np.int64)
+    if hashed:
+        block[1] = 0  # key k1 routed by hash
+    rot = np.array([1 % W, 0, (W - 1)], dtype=np.int32)
+    d_blk, d_rot = torch.from_numpy(block).to(dev), torch.from_numpy(rot).to(dev)
+    want, want_unb = block_bucketize(kjt.permute(sel), d_blk, W, return_permute=True, rank_offsets=d_rot)
+    L = _lib.lib()
+    n = len(sel) * B
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    unb = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(W * len(sel), dtype=torch.int64, device=dev)
+    ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(len(sel), B, W), dev)
+    d_sel = torch.tensor(sel, dtype=torch.int32, device=dev)
+    _lib.check(L.tzr_exchange_bucketize(_lib.ptr(d_sel), len(sel), _lib.ptr(d_blk), _lib.ptr(d_rot), B, 1, W, _lib.ptr(kjt.values()),
+                                        _lib.ptr(out), _lib.ptr(unb), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+               "tzr_exchange_bucketize")
+    assert torch.equal(out, want.values())
+    assert torch.equal(unb, want_unb)
+    off = want.offsets()
+    assert torch.equal(cnt, off[B::B] - off[:-1:B])

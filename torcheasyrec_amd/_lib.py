@@ -94,6 +94,8 @@ _SIGNATURES = {
     "tzr_block_bucketize_workspace": (_sz, [_i64, _i64, _i32]),
     "tzr_block_bucketize": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp,
                                    _vp, _vp, _vp, _sz, _vp]),
+    "tzr_exchange_bucketize_workspace": (_sz, [_i32, _i64, _i32]),
+    "tzr_exchange_bucketize": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tzr_pooled_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                               _i32, _i32, _vp]),
     "tzr_pooled_fwd_ex": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),

@@ -339,3 +339,164 @@ extern "C" int tzr_block_bucketize(const int64_t* d_block_sizes, const int32_t* 
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
+
+// ---- exchange bucketize (uniform bags) --------------------------------------------------------------
+// The requester side of the sharded exchange only needs, for the SELECTED keys of a KJT whose bags
+// all hold L ids: the ids grouped by (owner rank, key) in lookup order, where every lookup went, and
+// how many ids each (rank, key) pair holds.  The general K2 above also materialises W*F*B bag
+// lengths and their scan (fbgemm's contract) after a K1 permute: 13 launches.  This is a stable
+// counting sort with W*F' buckets in 3: per-tile rank counts, one-workgroup scan, scatter.
+#define XB_THREADS 256
+#define XB_TILE 1024  // ids per workgroup
+
+__global__ __launch_bounds__(XB_THREADS) void tzr_xb_count_kernel(
+    const int32_t* __restrict__ sel, const int64_t* __restrict__ block_sizes,
+    const int32_t* __restrict__ rank_offsets, int W, int64_t n_per_key, const int64_t* __restrict__ values,
+    int32_t* __restrict__ tile_cnt /*[F'][tiles][W]*/) {
+  __shared__ int cnt[64];
+  const int f = blockIdx.y;
+  const int tiles = gridDim.x;
+  const int64_t base = (int64_t)sel[f] * n_per_key + (int64_t)blockIdx.x * XB_TILE;
+  const int64_t end = min((int64_t)sel[f] * n_per_key + n_per_key, base + XB_TILE);
+  const int64_t bs = block_sizes[f];
+  const int ro = rank_offsets ? rank_offsets[f] : 0;
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = base + threadIdx.x; i < end; i += XB_THREADS) {
+    const int d = (int)((idx_owner(values[i], bs, W) + ro) % W);
+    atomicAdd(&cnt[d], 1);  // integer counts: order independent
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < W) tile_cnt[((size_t)f * tiles + blockIdx.x) * W + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// exclusive prefix in (dest, key, tile) order, in place; cnt_out[dest*F + f] = ids of key f for dest
+__global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __restrict__ tile_cnt, int F, int tiles, int W,
+                                                                 int64_t* __restrict__ cnt_out) {
+  __shared__ int64_t seg_tot[XB_THREADS];
+  __shared__ int64_t seg_base[XB_THREADS];
+  // one (dest, key) segment per thread (W * F <= XB_THREADS, checked by the launcher)
+  const int s = threadIdx.x;
+  const int nseg = W * F;
+  int64_t tot = 0;
+  if (s < nseg) {
+    const int d = s / F, f = s % F;
+    for (int t = 0; t < tiles; ++t) tot += tile_cnt[((size_t)f * tiles + t) * W + d];
+    cnt_out[s] = tot;
+  }
+  seg_tot[s] = s < nseg ? tot : 0;
+  __syncthreads();
+  if (s == 0) {
+    int64_t run = 0;
+    for (int k = 0; k < nseg; ++k) {
+      seg_base[k] = run;
+      run += seg_tot[k];
+    }
+  }
+  __syncthreads();
+  if (s < nseg) {
+    const int d = s / F, f = s % F;
+    int64_t run = seg_base[s];
+    for (int t = 0; t < tiles; ++t) {
+      int32_t* p = tile_cnt + ((size_t)f * tiles + t) * W + d;
+      const int32_t c = *p;
+      *p = (int32_t)run;  // start of this tile's ids for (dest, key)
+      run += c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(XB_THREADS) void tzr_xb_scatter_kernel(
+    const int32_t* __restrict__ sel, const int64_t* __restrict__ block_sizes,
+    const int32_t* __restrict__ rank_offsets, int W, int64_t n_per_key, const int64_t* __restrict__ values,
+    const int32_t* __restrict__ tile_base, int64_t* __restrict__ out_ids, int64_t* __restrict__ unbucketize) {
+  __shared__ int run[64];                              // ids of each dest placed by earlier rounds / waves
+  __shared__ int wcnt[XB_THREADS / TZR_WAVE][64];
+  const int f = blockIdx.y;
+  const int tiles = gridDim.x;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int64_t key_base = (int64_t)sel[f] * n_per_key;
+  const int64_t base = key_base + (int64_t)blockIdx.x * XB_TILE;
+  const int64_t end = min(key_base + n_per_key, base + XB_TILE);
+  const int64_t bs = block_sizes[f];
+  const int ro = rank_offsets ? rank_offsets[f] : 0;
+  const int32_t* tb = tile_base + ((size_t)f * tiles + blockIdx.x) * W;
+  if (threadIdx.x < 64) run[threadIdx.x] = 0;
+  for (int w = 0; w < XB_THREADS / TZR_WAVE; ++w)
+    if (threadIdx.x < 64) wcnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  int bits = 0;
+  while ((1 << bits) < W) ++bits;
+  for (int64_t i0 = base; i0 < end; i0 += XB_THREADS) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool valid = i < end;
+    int64_t id = 0, r = 0;
+    int d = 0;
+    if (valid) {
+      id = values[i];
+      r = idx_owner(id, bs, W);
+      d = (int)((r + ro) % W);
+    }
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const int on = (d >> b) & 1;
+      const unsigned long long bm = __ballot(on);
+      peers &= on ? bm : ~bm;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) wcnt[wv][d] = (int)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      int pre = run[d];
+      for (int w = 0; w < wv; ++w) pre += wcnt[w][d];
+      const int64_t pos = (int64_t)tb[d] + pre + rank;
+      out_ids[pos] = id - r * bs;
+      unbucketize[(int64_t)f * n_per_key + (i - key_base)] = pos;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
+      int t = 0;
+      for (int w = 0; w < XB_THREADS / TZR_WAVE; ++w) {
+        t += wcnt[w][threadIdx.x];
+        wcnt[w][threadIdx.x] = 0;
+      }
+      run[threadIdx.x] += t;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t tzr_exchange_bucketize_workspace(int n_sel, int64_t n_per_key, int W) {
+  const int64_t tiles = (n_per_key + XB_TILE - 1) / XB_TILE;
+  return tzr_align_up((size_t)std::max<int64_t>(1, (int64_t)n_sel * tiles * W) * sizeof(int32_t)) + 256;
+}
+
+extern "C" int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
+                                      const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
+                                      const int64_t* d_values, int64_t* d_out_ids, int64_t* d_unbucketize,
+                                      int64_t* d_counts, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_sel || n_sel <= 0 || !d_block_sizes || B < 0 || bag_len <= 0 || W <= 0 || !d_counts)
+    return TZR_ERR_INVALID;
+  if (W > 64 || (int64_t)W * n_sel > XB_THREADS) return TZR_ERR_UNSUPPORTED;
+  const int64_t n_per_key = B * bag_len;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_per_key == 0) {
+    if (hipMemsetAsync(d_counts, 0, (size_t)W * n_sel * 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    return TZR_OK;
+  }
+  if (!d_values || !d_out_ids || !d_unbucketize) return TZR_ERR_INVALID;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) ||
+      ws_bytes < tzr_exchange_bucketize_workspace(n_sel, n_per_key, W) - 256)
+    return TZR_ERR_WORKSPACE;
+  const int64_t tiles = (n_per_key + XB_TILE - 1) / XB_TILE;
+  if (tiles > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;
+  int32_t* tile_cnt = static_cast<int32_t*>(ws);
+  hipLaunchKernelGGL(tzr_xb_count_kernel, dim3((unsigned)tiles, (unsigned)n_sel), dim3(XB_THREADS), 0, s, d_sel,
+                     d_block_sizes, d_rank_offsets, W, n_per_key, d_values, tile_cnt);
+  hipLaunchKernelGGL(tzr_xb_scan_kernel, dim3(1), dim3(XB_THREADS), 0, s, tile_cnt, n_sel, (int)tiles, W, d_counts);
+  hipLaunchKernelGGL(tzr_xb_scatter_kernel, dim3((unsigned)tiles, (unsigned)n_sel), dim3(XB_THREADS), 0, s, d_sel,
+                     d_block_sizes, d_rank_offsets, W, n_per_key, d_values, tile_cnt, d_out_ids, d_unbucketize);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

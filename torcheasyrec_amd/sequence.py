@@ -263,12 +263,12 @@ class ShardedEmbeddingCollection(nn.Module):
         st = sh.input_dist_end(sh.input_dist_begin(kjt, ("__all__",)))
         rows_in, _, work = sh.exchange_rows(st)
         work.wait()
-        N = st["sub"].values().numel()
+        N = st["N_rw"]
         rows = rows_in[:N].index_select(0, st["unb"]) if N else rows_in[:0]  # bucketized order -> lookup order
         return rows, st
 
     def _backward_impl(self, st: dict, g: torch.Tensor) -> None:
-        N = st["sub"].values().numel()
+        N = st["N_rw"]
         grow = torch.empty(max(N, 1), self.dim, dtype=torch.float32, device=self._device)
         if N:
             grow[:N].index_copy_(0, st["unb"], g.contiguous().float())  # lookup order -> bucketized order

@@ -310,6 +310,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             feats, slots = build(rw_lk, lambda t: 0, lambda k: sub_index[k])
             m.update({
                 "rw_perm": [key_index[k] for k in rw_keys], "rw_feats_np": feats, "rw_slots_n": len(slots),
+                "rw_sel": torch.tensor([key_index[k] for k in rw_keys], dtype=torch.int32, device=self._device),
                 "rw_d_feats": _lib.upload_struct(feats, self._device), "rw_d_slots": _lib.upload_struct(slots, self._device),
                 # block 0 = hash routing of raw ids (zero-collision-hash tables, see zch.py)
                 "rw_blk": torch.tensor([0 if self._global[t].name in self._hash_routed else self.block[self._global[t].name]
@@ -414,11 +415,27 @@ class ShardedEmbeddingBagCollection(nn.Module):
         st = {"kjt": kjt, "rm": rm, "uniform": kjt.uniform_length() == 1}
         if "rw_n" in rm:
             B = kjt.stride()
-            sub = kjt if rm["rw_perm"] == list(range(len(kjt.keys()))) else kjt.permute(rm["rw_perm"])
             F = rm["rw_n"]
-            bkt, unb = block_bucketize(sub, rm["rw_blk"], W, return_permute=True, rank_offsets=rm["rw_rot"])
             cnt = torch.empty(2, W * F, dtype=torch.int64, device=dev)  # [0] ids I send per (dest, key); [1] ids I receive
-            torch.sub(bkt.offsets()[B::B], bkt.offsets()[:-1:B], out=cnt[0])
+            if st["uniform"] and kjt.weights_or_none() is None and W <= 64 and W * F <= 256:
+                # one id per bag, no weights: the lean 3-launch bucketize on the selected keys (no K1
+                # permute, no W*F*B bag lengths); same outputs as the general path below
+                L = _lib.lib()
+                sub = None
+                N = F * B
+                out_ids = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
+                unb = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
+                ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, W), dev)
+                _lib.check(L.tzr_exchange_bucketize(_lib.ptr(rm["rw_sel"]), F, _lib.ptr(rm["rw_blk"]), _lib.ptr(rm["rw_rot"]), B, 1, W,
+                                                    _lib.ptr(kjt.values()), _lib.ptr(out_ids), _lib.ptr(unb), _lib.ptr(cnt[0]),
+                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize")
+                bkt_values, unb = out_ids[:N], unb[:N]
+            else:
+                sub = kjt if rm["rw_perm"] == list(range(len(kjt.keys()))) else kjt.permute(rm["rw_perm"])
+                N = sub.values().numel()
+                bkt, unb = block_bucketize(sub, rm["rw_blk"], W, return_permute=True, rank_offsets=rm["rw_rot"])
+                torch.sub(bkt.offsets()[B::B], bkt.offsets()[:-1:B], out=cnt[0])
+                bkt_values = bkt.values()
             self._a2a(cnt[1], cnt[0], None, None)
             recv_cnt = cnt[1]
             if dev.type == "cuda":  # per-rank totals are summed on the host: no extra launches
@@ -429,7 +446,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 st["counts_event"] = ev
             else:
                 host = cnt
-            st.update({"sub": sub, "bkt_values": bkt.values(), "unb": unb, "recv_cnt": recv_cnt, "counts_host": host})
+            st.update({"sub": sub, "N_rw": N, "bkt_values": bkt_values, "unb": unb, "recv_cnt": recv_cnt, "counts_host": host})
         return st
 
     def input_dist_end(self, st: dict) -> dict:
@@ -478,7 +495,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             # requester: pooled gather over the received rows, ids = position in bucketized order
             _lib.check(L.tzr_pooled_fwd(_lib.ptr(d_pt), _lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(rm["rw_d_slots"]),
                                         rm["rw_slots_n"], _lib.ptr(st["unb"]), _lib.ptr(None if uniform else sub.offsets()),
-                                        _lib.ptr(sub.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
+                                        _lib.ptr(None if sub is None else sub.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
                                         stream), "tzr_pooled_fwd")
         return outs
 
@@ -487,7 +504,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         Returns (rows_in [N, D] in bucketized order, its one-table descriptor, the in-flight all-to-all)."""
         L, dev, D = _lib.lib(), self._device, self.dim
         om, n_recv = st["om"], st["n_recv"]
-        F, N = st["rm"]["rw_n"], st["sub"].values().numel()
+        F, N = st["rm"]["rw_n"], st["N_rw"]
         # ZCH tables: raw id -> row through the owner's map first
         st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
         rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
@@ -563,14 +580,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
         w_rows = w_acc = None
         if "rw_n" in rm:
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
-            N, F = sub.values().numel(), rm["rw_n"]
+            N, F = st["N_rw"], rm["rw_n"]
             # requester: one gradient row per id, in bucketized order -> to the owners
             if id_grads is not None:
                 grow = id_grads
             else:
                 grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
                 _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
-                                              _lib.ptr(sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
+                                              _lib.ptr(None if sub is None else sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
                                               gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
             grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
             w_rows = self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"], async_op=True)
