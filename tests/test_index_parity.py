@@ -130,12 +130,12 @@ def test_block_bucketize_hash_routing(dev, W):
         assert counts.min() > 0
 
 
-@pytest.mark.parametrize("W,hashed", [(1, False), (2, False), (8, False), (8, True), (5, True)])
+@pytest.mark.parametrize("W,hashed", [(1, False), (8, False), (5, True)])
 def test_exchange_bucketize_equals_permute_then_bucketize(dev, W, hashed):
     """The lean 3-launch bucketize of the sharded exchange (uniform bags, selected keys) gives exactly
     what K1 permute + K2 bucketize give: ids by (rank, key) in lookup order, positions, counts."""
     rng = np.random.default_rng(W * 3 + hashed)
-    F, B = 5, 2500  # 3 tiles per key, ragged last tile
+    F, B = 5, 1100  # 2 tiles per key, ragged last tile
     rows = [1000, 17, 40_000_000, 300, 9]
     keys = [f"k{i}" for i in range(F)]
     vals = np.stack([rng.integers(0, rows[f], size=B) for f in range(F)]).astype(np.int64)
