@@ -378,9 +378,12 @@ int tzr_tune(const char* name, int value);
  * (tzrec/modules/interaction.py:80-91: bmm(X, X^T) then strict-upper-triangle gather, row-major
  * (i<j) order) fused with the concatenations of DLRM.predict (tzrec/models/dlrm.py:123-130).
  * X[b] = [dense[b] (optional, row 0); sparse[b, 0:F*D] as F rows of D].  n = F + (dense!=0).
- * out[b, 0 : n(n-1)/2] = X X^T upper triangle (exact fp32, MFMA 16x16x4 f32);
+ * out[b, 0 : n(n-1)/2] = X X^T upper triangle (exact fp32);
  * if cat_dense: out[b, P : P+D] = dense[b]; if cat_sparse: the F*D sparse floats follow.
- * D must be 16 and n <= 32 in this build. */
+ * D = 16 with n <= 32 (DLRM-Criteo) runs the MFMA 16x16x4 f32 kernels; any other shape with
+ * D % 4 == 0 a general LDS-staged VALU kernel, as long as one sample fits its 60 KB of LDS:
+ * n (D + 1) floats forward, n (D + 1) + n (n + 1) backward (e.g. n = 64, D = 128); beyond that
+ * TZR_ERR_UNSUPPORTED. */
 int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
                             int64_t sparse_stride, int F, int D, int64_t B, float* d_out,
                             int64_t out_stride, int cat_dense, int cat_sparse, void* stream);

@@ -287,9 +287,9 @@ def test_mmoe_with_zch_config_to_training(dev):
         x = eg(first)["all"]
     lin = lambda seqm: [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seqm if hasattr(m, "weight")]  # noqa: E731
     xe = x.cpu()
-    experts = torch.stack([orc.mlp(xe, lin(e.mlp)) for e in model.expert_mlps], dim=1)
+    experts = torch.stack([orc.mlp(xe, lin(e.mlp)) for e in model.mmoe.expert_mlps], dim=1)
     for i, tower in enumerate(["ctr", "cvr"]):
-        gate = torch.softmax(torch.nn.functional.linear(xe, model.gate_finals[i].weight.detach().cpu(), model.gate_finals[i].bias.detach().cpu()), dim=1)
+        gate = torch.softmax(torch.nn.functional.linear(xe, model.mmoe.gate_finals[i].weight.detach().cpu(), model.mmoe.gate_finals[i].bias.detach().cpu()), dim=1)
         t_in = (gate.unsqueeze(2) * experts).sum(1)
         y = orc.mlp(t_in, lin(model.task_mlps[i].mlp))
         ref = torch.nn.functional.linear(y, model.task_outputs[i].weight.detach().cpu(), model.task_outputs[i].bias.detach().cpu()).squeeze(1)

@@ -35,6 +35,54 @@ def test_interaction_arch_forward_backward(dev, N, B):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("N,D,B", [(5, 8, 3), (27, 32, 4), (40, 16, 3), (9, 128, 2), (64, 64, 2), (2, 4, 70)])
+def test_interaction_arch_general_shapes(dev, N, D, B):
+    """Shapes outside the MFMA specialisation (D = 16, n <= 32) take the general kernel."""
+    g = torch.Generator().manual_seed(N * 131 + D)
+    x = torch.randn(B, N, D, generator=g) * torch.linspace(0.5, 1.5, N).view(1, N, 1)
+    xd = x.clone().to(dev).requires_grad_(True)
+    out = InteractionArch(N)(xd)
+    xr = x.clone().requires_grad_(True)
+    ref = orc.dot_interaction(xr)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=ATOL * D / 16)
+    go = torch.randn(ref.shape, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL * max(1, N // 16))
+
+
+@pytest.mark.parametrize("cat_dense,cat_sparse", [(True, True), (False, True), (True, False)])
+def test_fused_dlrm_interaction_general_dim(dev, cat_dense, cat_sparse):
+    """the DLRM concatenation with embedding_dim = 32 (general kernel)"""
+    B, F, D = 6, 11, 32
+    g = torch.Generator().manual_seed(17)
+    dense = torch.randn(B, D, generator=g)
+    sparse = torch.randn(B, F * D, generator=g)
+    dd = dense.clone().to(dev).requires_grad_(True)
+    sd = sparse.clone().to(dev).requires_grad_(True)
+    out = dot_interaction(dd, sd, D, cat_dense, cat_sparse)
+    dr = dense.clone().requires_grad_(True)
+    sr = sparse.clone().requires_grad_(True)
+    parts = [orc.dot_interaction(torch.cat([dr.unsqueeze(1), sr.reshape(B, F, D)], dim=1))]
+    if cat_dense:
+        parts.append(dr)
+    if cat_sparse:
+        parts.append(sr)
+    ref = torch.cat(parts, dim=-1)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=RTOL, atol=2 * ATOL)
+    go = torch.randn(ref.shape, generator=g)
+    out.backward(go.to(dev))
+    ref.backward(go)
+    torch.testing.assert_close(dd.grad.cpu(), dr.grad, rtol=RTOL, atol=2 * ATOL)
+    torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=RTOL, atol=2 * ATOL)
+
+
+def test_interaction_shape_beyond_lds_is_refused(dev):
+    x = torch.randn(1, 200, 128).to(dev)
+    with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported|-3|tzr_dot_interaction"):
+        InteractionArch(200)(x)
+
+
 def test_shape_fixture_from_reference(dev):
     """tzrec/modules/interaction_test.py:47-54: feature_num=4 -> output (10, 6)."""
     m = InteractionArch(4)

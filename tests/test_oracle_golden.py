@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 sys.path.insert(0, ROOT)
@@ -114,3 +115,36 @@ def test_product_path_has_no_cpu_fallback(emu_path):
             _lib.ptr(torch.zeros(4))
     finally:
         _lib.use_library(emu_path)
+
+
+@pytest.mark.parametrize("kind,mode", [("adagrad", "sum"), ("adagrad", "mean"), ("sgd", "sum")])
+def test_oracle_sparse_update_matches_torch_sparse_optimizers(kind, mode):
+    """The fused-backward restatement (lookup_grads + sparse_update) against an independent
+    implementation that IS installed: nn.EmbeddingBag(sparse=True) + torch.optim.Adagrad / SGD on the
+    coalesced sparse gradient -- the 'duplicates summed, then ONE update per row' semantics fbgemm's
+    exact optimizers document.  (Row-wise Adagrad has no torch counterpart: still unpinned.)"""
+    rng = np.random.default_rng(5)
+    rows, D, B, lr, eps, acc0 = 37, 8, 24, 0.05, 1e-8, 0.1
+    bag = torch.nn.EmbeddingBag(rows, D, mode=mode, sparse=True, include_last_offset=True)
+    w = bag.weight.detach().numpy().copy()
+    m = np.full((rows, D), acc0 if kind == "adagrad" else 0.0, dtype=np.float32)
+    if kind == "adagrad":
+        opt = torch.optim.Adagrad(bag.parameters(), lr=lr, eps=eps, initial_accumulator_value=acc0)
+    else:
+        opt = torch.optim.SGD(bag.parameters(), lr=lr)
+    cfg = orc.SparseOptim(kind=kind, lr=lr, eps=eps, initial_accumulator_value=acc0)
+    for _ in range(4):
+        lengths = rng.integers(0, 5, size=B)
+        ids = rng.integers(0, 6, size=int(lengths.sum()))  # 6 hot rows: many duplicates
+        ids[::3] = rng.integers(0, rows, size=len(ids[::3]))
+        Gy = rng.standard_normal((B, D)).astype(np.float32)
+        off = np.concatenate([[0], np.cumsum(lengths)])
+        opt.zero_grad()
+        out = bag(torch.from_numpy(ids), torch.from_numpy(off))
+        (out * torch.from_numpy(Gy)).sum().backward()
+        opt.step()
+        g = orc.lookup_grads([Gy], lengths, B, [mode])
+        orc.sparse_update(w, m, ids, g, cfg)
+        np.testing.assert_allclose(w, bag.weight.detach().numpy(), rtol=2e-6, atol=2e-7)
+    if kind == "adagrad":
+        np.testing.assert_allclose(m, opt.state[bag.weight]["sum"].numpy(), rtol=2e-6, atol=1e-7)

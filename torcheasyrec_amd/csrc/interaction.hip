@@ -186,6 +186,125 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_kernel(
   }
 }
 
+// ---- general shapes --------------------------------------------------------------------------
+// The MFMA kernels above are specialised for the DLRM-Criteo shape (D = 16, n <= 32).  Any other
+// (n, D) the reference's InteractionArch accepts (D % 4 == 0) takes this path: one workgroup per
+// sample, X staged once in LDS with an odd row pitch, one output pair per thread per round.  Still
+// HBM-bound work (n*D floats in, n(n-1)/2 (+ pass-through) out per sample); the contraction is
+// n^2 D / 2 FMAs per sample on the VALU, fed from LDS: lanes of consecutive pairs share row i
+// (broadcast) and read consecutive rows j (pitch D + 1: conflict-free).
+#define IAG_CAP 15360  // floats of LDS per workgroup (60 KB)
+
+// pair index -> (i, j), i < j, row-major over the strict upper triangle
+__device__ __forceinline__ void iag_pair(int idx, int n, int* pi, int* pj) {
+  const float t = (float)(2 * n - 1);
+  int i = (int)((t - sqrtf(fmaxf(t * t - 8.f * (float)idx, 0.f))) * 0.5f);
+  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+  while (i + 1 <= n - 2 && (i + 1) * (2 * n - i - 2) / 2 <= idx) ++i;
+  while (i > 0 && i * (2 * n - i - 1) / 2 > idx) --i;
+  *pi = i;
+  *pj = idx - i * (2 * n - i - 1) / 2 + i + 1;
+}
+
+__device__ __forceinline__ void iag_stage_x(float* Xs, const float* dense, int64_t dense_stride,
+                                            const float* sparse, int64_t sparse_stride, int64_t b,
+                                            int n, int hd, int D) {
+  const int lg = D >> 2;
+  for (int e = threadIdx.x; e < n * lg; e += IA_THREADS) {
+    const int row = e / lg, c = e - row * lg;
+    const float* src = (hd && row == 0) ? dense + b * dense_stride
+                                        : sparse + b * sparse_stride + (int64_t)(row - hd) * D;
+    const float4 v = tzr_ld4(src + 4 * c);
+    float* d = Xs + row * (D + 1) + 4 * c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_general_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int D, int64_t B, float* __restrict__ out,
+    int64_t out_stride, int cat_dense, int cat_sparse) {
+  __shared__ float Xs[IAG_CAP];
+  const int P = n * (n - 1) / 2;
+  const int pitch = D + 1;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    iag_stage_x(Xs, dense, dense_stride, sparse, sparse_stride, b, n, hd, D);
+    __syncthreads();
+    float* o = out + b * out_stride;
+    for (int idx = threadIdx.x; idx < P; idx += IA_THREADS) {
+      int i, j;
+      iag_pair(idx, n, &i, &j);
+      const float* xi = Xs + i * pitch;
+      const float* xj = Xs + j * pitch;
+      float acc = 0.f;
+      for (int k = 0; k < D; ++k) acc = fmaf(xi[k], xj[k], acc);
+      o[idx] = acc;
+    }
+    int col = P;
+    if (cat_dense && hd) {
+      for (int k = threadIdx.x; k < D; k += IA_THREADS) o[col + k] = Xs[k];
+      col += D;
+    }
+    if (cat_sparse) {
+      const int F = n - hd;
+      for (int e = threadIdx.x; e < F * D; e += IA_THREADS) {
+        const int row = e / D, k = e - row * D;
+        o[col + e] = Xs[(row + hd) * pitch + k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dX[i][c] = sum_j S[i][j] X[j][c] (+ pass-through), S = G + G^T with a zero diagonal.
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_general_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int D, int64_t B, const float* __restrict__ gout,
+    int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
+    int64_t gdense_stride, float* __restrict__ gsparse, int64_t gsparse_stride) {
+  __shared__ float lds[IAG_CAP];
+  float* Xs = lds;                    // n x (D + 1)
+  float* S = lds + n * (D + 1);       // n x (n + 1)
+  const int P = n * (n - 1) / 2;
+  const int pitch = D + 1, sp = n + 1;
+  const int pd = P;
+  const int ps = P + ((cat_dense && hd) ? D : 0);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* g = gout + b * gout_stride;
+    iag_stage_x(Xs, dense, dense_stride, sparse, sparse_stride, b, n, hd, D);
+    for (int i = threadIdx.x; i < n; i += IA_THREADS) S[i * sp + i] = 0.f;
+    for (int idx = threadIdx.x; idx < P; idx += IA_THREADS) {
+      int i, j;
+      iag_pair(idx, n, &i, &j);
+      const float v = g[idx];
+      S[i * sp + j] = v;
+      S[j * sp + i] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * D; e += IA_THREADS) {
+      const int i = e / D, c = e - i * D;
+      const float* si = S + i * sp;
+      float acc = 0.f;
+      for (int j = 0; j < n; ++j) acc = fmaf(si[j], Xs[j * pitch + c], acc);
+      if (hd && i == 0) {
+        if (cat_dense) acc += g[pd + c];
+        gdense[b * gdense_stride + c] = acc;
+      } else {
+        if (cat_sparse) acc += g[ps + (i - hd) * D + c];
+        gsparse[b * gsparse_stride + (int64_t)(i - hd) * D + c] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static bool iag_fits(int n, int D, bool bwd) {
+  const int64_t need = (int64_t)n * (D + 1) + (bwd ? (int64_t)n * (n + 1) : 0);
+  return need <= IAG_CAP && n <= 2048;
+}
+
+static unsigned iag_grid(int64_t B) { return (unsigned)(B < 1 ? 1 : (B > 16384 ? 16384 : B)); }
+
 static unsigned ia_grid(int64_t B) {
   const int64_t wg = (B + IA_WAVES - 1) / IA_WAVES;
   return (unsigned)(wg < 1 ? 1 : (wg > 8192 ? 8192 : wg));
@@ -198,11 +317,19 @@ extern "C" int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_strid
   const int hd = d_dense ? 1 : 0;
   const int n = F + hd;
   if (!d_sparse || !d_out || F <= 0 || B < 0) return TZR_ERR_INVALID;
-  if (D != IA_D || n > IA_MAXN || n < 2) return TZR_ERR_UNSUPPORTED;
+  const bool mfma = (D == IA_D && n <= IA_MAXN);
+  if (n < 2 || D <= 0 || (D & 3) || (!mfma && !iag_fits(n, D, false))) return TZR_ERR_UNSUPPORTED;
   if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
       (reinterpret_cast<uintptr_t>(d_sparse) & 15) || (reinterpret_cast<uintptr_t>(d_dense) & 15))
     return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
+  if (!mfma) {
+    hipLaunchKernelGGL(tzr_dot_interaction_fwd_general_kernel, dim3(iag_grid(B)), dim3(IA_THREADS),
+                       0, static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
+                       sparse_stride, n, hd, D, B, d_out, out_stride, cat_dense, cat_sparse);
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
   hipLaunchKernelGGL(tzr_dot_interaction_fwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
                      sparse_stride, n, hd, B, d_out, out_stride, cat_dense, cat_sparse);
@@ -220,12 +347,22 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
   const int n = F + hd;
   if (!d_sparse || !d_grad_out || !d_grad_sparse || F <= 0 || B < 0) return TZR_ERR_INVALID;
   if (hd && !d_grad_dense) return TZR_ERR_INVALID;
-  if (D != IA_D || n > IA_MAXN || n < 2) return TZR_ERR_UNSUPPORTED;
+  const bool mfma = (D == IA_D && n <= IA_MAXN);
+  if (n < 2 || D <= 0 || (D & 3) || (!mfma && !iag_fits(n, D, true))) return TZR_ERR_UNSUPPORTED;
   if ((sparse_stride & 3) || (grad_sparse_stride & 3) || (hd && ((dense_stride | grad_dense_stride) & 3)) ||
       ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_grad_sparse) |
         reinterpret_cast<uintptr_t>(d_dense) | reinterpret_cast<uintptr_t>(d_grad_dense)) & 15))
     return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
+  if (!mfma) {
+    hipLaunchKernelGGL(tzr_dot_interaction_bwd_general_kernel, dim3(iag_grid(B)), dim3(IA_THREADS),
+                       0, static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
+                       sparse_stride, n, hd, D, B, d_grad_out, grad_out_stride, cat_dense,
+                       cat_sparse, d_grad_dense, grad_dense_stride, d_grad_sparse,
+                       grad_sparse_stride);
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
   hipLaunchKernelGGL(tzr_dot_interaction_bwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
                      sparse_stride, n, hd, B, d_grad_out, grad_out_stride, cat_dense, cat_sparse,

@@ -186,11 +186,40 @@ class ConfigMultiTowerDIN(RankModel):
         return self._output_to_prediction(self.output_mlp(y))
 
 
+class MMoE(nn.Module):
+    """Multi-gate mixture of experts, the reference module's constructor and forward
+    (tzrec/modules/mmoe.py:20-76): `num_expert` expert MLPs over the input, per task an optional
+    gate MLP and a Linear + softmax over the experts; returns one mixed tensor per task."""
+
+    def __init__(self, in_features: int, expert_mlp: Dict[str, object], num_expert: int, num_task: int,
+                 gate_mlp: Optional[Dict[str, object]] = None) -> None:
+        super().__init__()
+        self.num_expert, self.num_task = num_expert, num_task
+        self.expert_mlps = nn.ModuleList([MLP(in_features, list(expert_mlp["hidden_units"])) for _ in range(num_expert)])
+        gate_in = in_features
+        self.has_gate_mlp = gate_mlp is not None
+        if self.has_gate_mlp:
+            self.gate_mlps = nn.ModuleList([MLP(in_features, list(gate_mlp["hidden_units"])) for _ in range(num_task)])
+            gate_in = self.gate_mlps[0].hidden_units[-1]
+        self.gate_finals = nn.ModuleList([nn.Linear(gate_in, num_expert) for _ in range(num_task)])
+
+    def output_dim(self) -> int:
+        return self.expert_mlps[0].hidden_units[-1]
+
+    def forward(self, input: torch.Tensor):
+        experts = torch.stack([e(input) for e in self.expert_mlps], dim=1)  # [B, E, H]
+        result = []
+        for i in range(self.num_task):
+            g = self.gate_mlps[i](input) if self.has_gate_mlp else input
+            gate = torch.softmax(self.gate_finals[i](g), dim=1).unsqueeze(1)
+            result.append(torch.matmul(gate, experts).squeeze(1))
+        return result
+
+
 class ConfigMMoE(RankModel):
-    """`mmoe {...}` (tzrec/models/mmoe.py:36-96, tzrec/modules/mmoe.py:27-86): shared expert MLPs over
-    the (single) feature group, one softmax gate per task mixing them, a task tower (MLP + logits
-    layer) per task.  Predictions and losses carry the tower name as suffix, as the reference's
-    multi-task models do."""
+    """`mmoe {...}` (tzrec/models/mmoe.py:36-96): the MMoE module over the (single) feature group and
+    a task tower (MLP + logits layer) per task.  Predictions and losses carry the tower name as
+    suffix, as the reference's multi-task models do."""
 
     def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
         super().__init__(spec, device, sparse_optimizer)
@@ -198,15 +227,9 @@ class ConfigMMoE(RankModel):
         self._group = eg.group_names()[0]
         d_in = eg.group_total_dim(self._group)
         hidden = [int(x) for x in m.one("expert_mlp").many("hidden_units")]
-        self.expert_mlps = nn.ModuleList([MLP(d_in, hidden) for _ in range(int(m.one("num_expert")))])
-        self.gate_mlps = None
-        gate_in = d_in
-        if m.has("gate_mlp"):
-            gh = [int(x) for x in m.one("gate_mlp").many("hidden_units")]
-            self.gate_mlps = nn.ModuleList([MLP(d_in, gh) for _ in m.many("task_towers")])
-            gate_in = gh[-1]
+        gate = {"hidden_units": [int(x) for x in m.one("gate_mlp").many("hidden_units")]} if m.has("gate_mlp") else None
         self._towers = [(str(t.one("tower_name")), str(t.one("label_name"))) for t in m.many("task_towers")]
-        self.gate_finals = nn.ModuleList([nn.Linear(gate_in, len(self.expert_mlps)) for _ in self._towers])
+        self.mmoe = MMoE(d_in, {"hidden_units": hidden}, int(m.one("num_expert")), len(self._towers), gate)
         self.task_mlps = nn.ModuleList()
         self.task_outputs = nn.ModuleList()
         for t in m.many("task_towers"):
@@ -221,19 +244,14 @@ class ConfigMMoE(RankModel):
                 self.task_mlps.append(nn.Identity())
             self.task_outputs.append(OutputLinear(d, 1))
         if device is not None:
-            for mod in (self.expert_mlps, self.gate_mlps, self.gate_finals, self.task_mlps, self.task_outputs):
-                if mod is not None:
-                    mod.to(device)
+            for mod in (self.mmoe, self.task_mlps, self.task_outputs):
+                mod.to(device)
 
     def forward(self, batch: Batch) -> Dict[str, torch.Tensor]:
-        x = self.build_input(batch)[self._group]
-        experts = torch.stack([e(x) for e in self.expert_mlps], dim=1)  # [B, E, H]
+        task_inputs = self.mmoe(self.build_input(batch)[self._group])
         out: Dict[str, torch.Tensor] = {}
         for i, (tower, _) in enumerate(self._towers):
-            g = self.gate_mlps[i](x) if self.gate_mlps is not None else x
-            gate = torch.softmax(self.gate_finals[i](g), dim=1).unsqueeze(1)
-            task_in = torch.matmul(gate, experts).squeeze(1)
-            logits = self.task_outputs[i](self.task_mlps[i](task_in)).squeeze(1)
+            logits = self.task_outputs[i](self.task_mlps[i](task_inputs[i])).squeeze(1)
             out[f"logits_{tower}"], out[f"probs_{tower}"] = logits, torch.sigmoid(logits)
         return out
 
