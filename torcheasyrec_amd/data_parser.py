@@ -117,6 +117,8 @@ def _interleave(present: np.ndarray, counts: np.ndarray, flat: np.ndarray, defau
 def parse_sparse_column(name: str, col, multival_sep: str = chr(3), default_value: Optional[Sequence[int]] = None,
                         is_weighted: bool = False) -> SparseColumn:
     col = _arrow(col)
+    if pa.types.is_floating(col.type):
+        raise ValueError(f"{name} only support str|int|list<int>|map<int,double> dtype input, but get {col.type}.")
     if is_weighted and (pa.types.is_integer(col.type)):
         raise ValueError(f"{name}: an int column cannot be weighted")
     rg = _ragged(col, multival_sep, name)
@@ -198,6 +200,50 @@ def parse_dense_column(name: str, col, multival_sep: str = chr(3), default_value
                          "(null dense values need a default)")
     dim = int(lengths[0]) if len(lengths) else 1
     return DenseColumn(name, values.reshape(len(lengths), dim))
+
+
+@dataclass
+class SequenceDenseColumn:
+    name: str
+    values: np.ndarray  # float32 [sum seq_lengths, value_dim]
+    seq_lengths: np.ndarray  # int [B] steps per sample
+
+
+def parse_sequence_dense_column(name: str, col, sequence_delim: str = ";", multival_sep: str = chr(3), value_dim: int = 1,
+                                default_value: Optional[Sequence[float]] = None) -> SequenceDenseColumn:
+    """Sequence of `value_dim`-wide float rows per sample
+    (tzrec/features/feature.py:281-343, `_parse_fg_encoded_sequence_dense_feature_impl`): a string
+    column holds `step;step;...` with `multival_sep` inside a step, list columns hold
+    list<list<float>> (or list<float> when value_dim == 1).  A missing / empty row is ONE step
+    holding the default."""
+    col = _arrow(col)
+    t = col.type
+    if pa.types.is_string(t) or pa.types.is_large_string(t):
+        rg = _ragged(col, sequence_delim, name)
+        flat = pc.split_pattern(rg.tokens, multival_sep).values
+        data = flat.cast(pa.float32(), safe=False).to_numpy(zero_copy_only=False) if len(flat) else np.zeros(0, np.float32)
+        steps = rg.counts
+    elif pa.types.is_list(t) or pa.types.is_large_list(t):
+        rg = _ragged(col, "", name)
+        inner = rg.tokens
+        if pa.types.is_list(inner.type) or pa.types.is_large_list(inner.type):
+            inner = inner.flatten()
+        data = inner.cast(pa.float32(), safe=False).to_numpy(zero_copy_only=False) if len(inner) else np.zeros(0, np.float32)
+        steps = rg.counts
+    else:
+        raise ValueError(f"{name} only support str|list<float>|list<list<float>> dtype input, but get {t}.")
+    data = np.asarray(data, np.float32).reshape(-1, value_dim)
+    present = rg.present
+    seq = np.where(present, steps, 0)
+    if default_value is not None and not bool(present.all()):
+        d = np.asarray(list(default_value), np.float32).reshape(1, -1)
+        seq = np.where(present, steps, 1)
+        from_data = np.repeat(present, seq)
+        out = np.empty((int(seq.sum()), d.shape[1]), np.float32)
+        out[from_data] = data
+        out[~from_data] = d
+        data = out
+    return SequenceDenseColumn(name, data, seq)
 
 
 class DataParser:
