@@ -77,3 +77,24 @@ def test_parser_matches_reference_output(case):
             w = np.asarray(fixed, np.float32)
         assert len(got.weights) == len(got.values)
         np.testing.assert_array_equal(got.weights, w)
+
+
+_SPARSE = [c for c in _G if c["kind"] == "sparse" and "out" in c]
+
+
+@pytest.mark.parametrize("case", _SPARSE, ids=[f"{i}-{_id(c)}" for i, c in enumerate(_SPARSE)])
+def test_oracle_parse_matches_reference_output(case):
+    """pins oracle.parse_sparse_feature (the restatement the KJT / bucketize tests feed from)"""
+    from oracle import tzrec_oracle as orc
+
+    rows, a = case["rows"], case["args"]
+    if case["type"].startswith("map"):
+        rows = [None if r is None else {k: v for k, v in r} for r in rows]
+    d = a.get("default_value")
+    v, l, w = orc.parse_sparse_feature(rows, d, a.get("multival_sep", chr(3)), bool(a.get("is_weighted")))
+    np.testing.assert_array_equal(v, _arr(case["out"]["values"]))
+    np.testing.assert_array_equal(l, _arr(case["out"]["lengths"]))
+    wr = _arr(case["out"].get("weights"))
+    assert (w is None) == (wr is None)
+    if w is not None and not (d is not None and len(d) > 1):  # multi-id default: see the divergence note above
+        np.testing.assert_array_equal(w, wr)
