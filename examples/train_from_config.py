@@ -17,6 +17,7 @@ from torcheasyrec_amd import _lib  # noqa: E402
 from torcheasyrec_amd.config import load_pipeline_spec  # noqa: E402
 from torcheasyrec_amd.dense import FusedDenseAdam  # noqa: E402
 from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, TrainPipeline  # noqa: E402
+from torcheasyrec_amd.lr_scheduler import create_scheduler  # noqa: E402
 from torcheasyrec_amd.rank_model import build_rank_model  # noqa: E402
 from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor  # noqa: E402
 
@@ -41,6 +42,9 @@ def main(path):
     spec = load_pipeline_spec(open(path).read())
     model = build_rank_model(spec, device=dev)
     opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
+    # the `learning_rate` oneof of the two optimizer blocks (tzrec/main.py:877-882); stepped per step
+    # unless by_epoch (main.py:542-544)
+    schedulers = [create_scheduler(model.fused_optimizer, spec.sparse_optimizer_block), create_scheduler(opt, spec.dense_optimizer_block)]
     pipe = TrainPipeline(model, opt, dev, model.loss)
     it = iter(synthetic_batches(spec, 20 * (spec.batch_size or 1024), spec.batch_size or 1024))
     step = 0
@@ -50,6 +54,9 @@ def main(path):
         except StopIteration:
             break
         step += 1
+        for sch in schedulers:
+            if not sch.by_epoch:
+                sch.step()
         if step % 5 == 0:
             print(f"step {step}: " + ", ".join(f"{k}={float(v.detach()):.4f}" for k, v in losses.items()))
     print("tables:", {n: tuple(w.shape) for n, w in model.embedding_group.ebc.table_weights().items()})

@@ -146,6 +146,9 @@ class PipelineSpec:
     sparse_optimizer: Optional[SparseOptimizerConfig] = None
     dense_lr: float = 1e-3
     label_fields: List[str] = field(default_factory=list)
+    # the raw optimizer blocks (learning-rate schedules: lr_scheduler.create_scheduler)
+    sparse_optimizer_block: Optional[Msg] = None
+    dense_optimizer_block: Optional[Msg] = None
 
 
 def _num_embeddings(f: Msg, name: str) -> int:
@@ -226,7 +229,9 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
     tc = cfg.one("train_config", Msg())
     if tc.has("sparse_optimizer"):
         spec.sparse_optimizer = sparse_optimizer_from_config(tc.one("sparse_optimizer"))
+        spec.sparse_optimizer_block = tc.one("sparse_optimizer")
     if tc.has("dense_optimizer"):
+        spec.dense_optimizer_block = tc.one("dense_optimizer")
         for _, v in tc.one("dense_optimizer").items():
             if isinstance(v[-1], Msg) and v[-1].has("lr"):
                 spec.dense_lr = float(v[-1].one("lr"))
