@@ -77,8 +77,10 @@ def test_interaction_and_jagged_shape_limits(dev):
     L = _lib.lib()
     x, out = _buf(dev, 4096), _buf(dev, 4096)
     p = _lib.ptr
-    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 26 * 8, 26, 8, 2, p(out), 400, 0, 0, None) == UNSUPPORTED  # D != 16
-    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 40 * 16, 40, 16, 2, p(out), 1000, 0, 0, None) == UNSUPPORTED  # > 32 rows
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 26 * 6, 26, 6, 2, p(out), 400, 0, 0, None) == UNSUPPORTED  # D % 4
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 200 * 128, 200, 128, 2, p(out), 20000, 0, 0, None) == UNSUPPORTED  # one sample > 60 KB of LDS
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 16, 1, 16, 2, p(out), 16, 0, 0, None) == UNSUPPORTED  # a single row has no pairs
+    assert L.tzr_dot_interaction_fwd(None, 0, p(x), 26 * 8, 26, 8, 2, p(out), 400, 0, 0, None) == OK  # general kernel (D != 16)
     assert L.tzr_dot_interaction_fwd(None, 0, None, 0, 26, 16, 2, p(out), 400, 0, 0, None) == INVALID
     assert L.tzr_fm_fwd(p(x), 26 * 6, 26, 6, 2, p(out), 8, None) == UNSUPPORTED  # D % 4
     off = _buf(dev, 3, torch.int64)
