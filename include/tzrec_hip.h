@@ -380,9 +380,10 @@ int tzr_tune(const char* name, int value);
  * X[b] = [dense[b] (optional, row 0); sparse[b, 0:F*D] as F rows of D].  n = F + (dense!=0).
  * out[b, 0 : n(n-1)/2] = X X^T upper triangle (exact fp32);
  * if cat_dense: out[b, P : P+D] = dense[b]; if cat_sparse: the F*D sparse floats follow.
- * D = 16 with n <= 32 (DLRM-Criteo) runs the MFMA 16x16x4 f32 kernels; any other shape with
- * D % 4 == 0 a general LDS-staged VALU kernel, as long as one sample fits its 60 KB of LDS:
- * n (D + 1) floats forward, n (D + 1) + n (n + 1) backward (e.g. n = 64, D = 128); beyond that
+ * D = 16 with n <= 32 (DLRM-Criteo) runs kernels specialised for that shape; any other D % 4 == 0
+ * with n <= 64 the same MFMA 16x16x4 f32 scheme generalised (2 or 4 row blocks, a loop over
+ * 16-column blocks of D); n > 64 a general LDS-staged VALU kernel, as long as one sample fits its
+ * 60 KB of LDS: n (D + 1) floats forward, n (D + 1) + n (n + 1) backward; beyond that
  * TZR_ERR_UNSUPPORTED. */
 int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
                             int64_t sparse_stride, int F, int D, int64_t B, float* d_out,

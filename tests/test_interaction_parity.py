@@ -35,9 +35,11 @@ def test_interaction_arch_forward_backward(dev, N, B):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("N,D,B", [(5, 8, 3), (27, 32, 4), (40, 16, 3), (9, 128, 2), (64, 64, 2), (2, 4, 70)])
+@pytest.mark.parametrize("N,D,B", [(5, 8, 3), (27, 32, 4), (32, 20, 3), (33, 4, 3), (40, 16, 3), (9, 128, 2), (64, 64, 2), (64, 12, 5),
+                                   (2, 4, 70), (70, 8, 2), (100, 32, 1)])
 def test_interaction_arch_general_shapes(dev, N, D, B):
-    """Shapes outside the MFMA specialisation (D = 16, n <= 32) take the general kernel."""
+    """Shapes outside the D = 16, n <= 32 specialisation: generalised MFMA kernels up to 64 rows (2 or
+    4 row blocks, partial 16-column blocks), the LDS/VALU kernel beyond."""
     g = torch.Generator().manual_seed(N * 131 + D)
     x = torch.randn(B, N, D, generator=g) * torch.linspace(0.5, 1.5, N).view(1, N, 1)
     xd = x.clone().to(dev).requires_grad_(True)

@@ -298,6 +298,169 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_general_ke
   }
 }
 
+// ---- MFMA kernels for any D % 4 == 0 and n <= 64 ------------------------------------------------
+// Same wave-per-sample scheme as the D = 16 kernels above, generalised: NB row blocks of 16
+// (NB = 2: n <= 32, NB = 4: n <= 64) and a loop over 16-column blocks of D (the contraction index).
+// A lane (r = l & 15, q = l >> 4) loads the float4 X[16 bi + r][cb + 4q .. cb + 4q + 3] of every
+// row block; MFMA step e consumes element e of it, so the four steps of a column block cover its 16
+// contraction indices (lanes past D supply zeros).  The D = 16 kernels stay as they are: they are
+// on the measured DLRM-Criteo step.
+__device__ __forceinline__ const float* iam_row(const float* dense, int64_t dense_stride,
+                                                const float* sparse, int64_t sparse_stride,
+                                                int64_t b, int i, int hd, int D) {
+  return (hd && i == 0) ? dense + b * dense_stride
+                        : sparse + b * sparse_stride + (int64_t)(i - hd) * D;
+}
+
+template <int NB>
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int D, int64_t B, float* __restrict__ out,
+    int64_t out_stride, int cat_dense, int cat_sparse) {
+  constexpr int MAXN = 16 * NB;
+  constexpr int MAXP = MAXN * (MAXN - 1) / 2;
+  constexpr int NPAIR = NB * (NB + 1) / 2;
+  __shared__ float tri[IA_WAVES][MAXP + 16];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+  const int P = n * (n - 1) / 2;
+  const int colD = P;
+  const int colS = P + ((cat_dense && hd) ? D : 0);
+  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += (int64_t)gridDim.x * IA_WAVES) {
+    const int64_t b = b0 + wv;
+    const bool on = b < B;
+    float* o = out + b * out_stride;
+    f32x4 acc[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < D; cb += 16) {
+      const bool kin = on && (cb + 4 * q < D);
+      float x[NB][4];
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        const int row = 16 * bi + r;
+        float4 a = tzr_zero4();
+        if (kin && row < n) {
+          a = tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + cb + 4 * q);
+          if (hd && row == 0) {
+            if (cat_dense) tzr_st4_a4(o + colD + cb + 4 * q, a);
+          } else if (cat_sparse) {
+            tzr_st4_a4(o + colS + (int64_t)(row - hd) * D + cb + 4 * q, a);
+          }
+        }
+        x[bi][0] = a.x; x[bi][1] = a.y; x[bi][2] = a.z; x[bi][3] = a.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int p = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+          for (int bj = bi; bj < NB; ++bj, ++p)
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[bi][e], x[bj][e], acc[p], 0, 0, 0);
+      }
+    }
+    {
+      int p = 0;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = bi; bj < NB; ++bj, ++p)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = 16 * bi + 4 * q + reg, j = 16 * bj + r;
+            if (i < j && j < n) tri[wv][i * (2 * n - i - 1) / 2 + j - i - 1] = acc[p][reg];
+          }
+    }
+    ia_wave_sync();
+    if (on)
+      for (int idx = lane; idx < P; idx += TZR_WAVE) o[idx] = tri[wv][idx];
+    ia_wave_sync();
+  }
+}
+
+// dX^T = X^T S per 16-column block of D: A'[c][k] = X[k][cb + c] straight from global (each element
+// of X is read exactly once per sample; a lane quad reads four 64-byte row pieces), B'[k][i] = S[k][i]
+// from the wave's LDS image of S = G + G^T.  The accumulator of lane (r, q) is dX[16 bi + r][cb + 4q ..
+// cb + 4q + 3]: float4 stores.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int D, int64_t B, const float* __restrict__ gout,
+    int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
+    int64_t gdense_stride, float* __restrict__ gsparse, int64_t gsparse_stride) {
+  constexpr int MAXN = 16 * NB;
+  constexpr int SP = MAXN + 1;  // odd pitch: conflict-free column reads
+  constexpr int MAXP = MAXN * (MAXN - 1) / 2;
+  constexpr int THREADS = WAVES * TZR_WAVE;
+  __shared__ float S[WAVES][MAXN * SP];
+  __shared__ unsigned short ij[MAXP];  // idx -> (i << 8) | j
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+  const int P = n * (n - 1) / 2;
+  for (int idx = threadIdx.x; idx < P; idx += THREADS) {
+    int i, j;
+    iag_pair(idx, n, &i, &j);
+    ij[idx] = (unsigned short)((i << 8) | j);
+  }
+  for (int k = threadIdx.x; k < WAVES * MAXN * SP; k += THREADS) (&S[0][0])[k] = 0.f;
+  __syncthreads();
+  const int pd = P;
+  const int ps = P + ((cat_dense && hd) ? D : 0);
+  const int ksteps = (n + 3) >> 2;
+  for (int64_t b0 = (int64_t)blockIdx.x * WAVES; b0 < B; b0 += (int64_t)gridDim.x * WAVES) {
+    const int64_t b = b0 + wv;
+    const bool on = b < B;
+    const float* g = gout + b * gout_stride;
+    if (on) {
+      for (int idx = lane; idx < P; idx += TZR_WAVE) {
+        const float v = g[idx];
+        const int i = ij[idx] >> 8, j = ij[idx] & 255;
+        S[wv][i * SP + j] = v;
+        S[wv][j * SP + i] = v;
+      }
+    }
+    ia_wave_sync();  // S[wv] is private to this wave
+    for (int cb = 0; cb < D; cb += 16) {
+      const bool cin = on && (cb + r < D);          // operand column of this lane
+      const bool kin = on && (cb + 4 * q < D);      // output float4 of this lane
+      f32x4 d[NB];
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) d[bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = 4 * ks + q;  // contraction index = row of X / S
+        float xa = 0.f;
+        if (cin && k < n) xa = iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r];
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+          d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, S[wv][k * SP + 16 * bi + r], d[bi], 0, 0, 0);
+      }
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        const int row = 16 * bi + r;
+        if (kin && row < n) {
+          float4 v = make_float4(d[bi][0], d[bi][1], d[bi][2], d[bi][3]);
+          if (hd && row == 0) {
+            if (cat_dense) v = tzr_add4(v, tzr_ld4_a4(g + pd + cb + 4 * q));
+            tzr_st4(gdense + b * gdense_stride + cb + 4 * q, v);
+          } else {
+            if (cat_sparse) v = tzr_add4(v, tzr_ld4_a4(g + ps + (int64_t)(row - hd) * D + cb + 4 * q));
+            tzr_st4(gsparse + b * gsparse_stride + (int64_t)(row - hd) * D + cb + 4 * q, v);
+          }
+        }
+      }
+    }
+    ia_wave_sync();
+  }
+}
+
+static unsigned iam_grid(int64_t B, int waves) {
+  const int64_t wg = (B + waves - 1) / waves;
+  return (unsigned)(wg < 1 ? 1 : (wg > 16384 ? 16384 : wg));
+}
+
 static bool iag_fits(int n, int D, bool bwd) {
   const int64_t need = (int64_t)n * (D + 1) + (bwd ? (int64_t)n * (n + 1) : 0);
   return need <= IAG_CAP && n <= 2048;
@@ -318,11 +481,25 @@ extern "C" int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_strid
   const int n = F + hd;
   if (!d_sparse || !d_out || F <= 0 || B < 0) return TZR_ERR_INVALID;
   const bool mfma = (D == IA_D && n <= IA_MAXN);
-  if (n < 2 || D <= 0 || (D & 3) || (!mfma && !iag_fits(n, D, false))) return TZR_ERR_UNSUPPORTED;
+  if (n < 2 || D <= 0 || (D & 3) || (!mfma && n > 64 && !iag_fits(n, D, false))) return TZR_ERR_UNSUPPORTED;
   if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
       (reinterpret_cast<uintptr_t>(d_sparse) & 15) || (reinterpret_cast<uintptr_t>(d_dense) & 15))
     return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
+  if (!mfma && n <= 64) {
+    if (n <= 32)
+      hipLaunchKernelGGL((tzr_dot_interaction_fwd_mfma_kernel<2>), dim3(iam_grid(B, IA_WAVES)),
+                         dim3(IA_THREADS), 0, static_cast<hipStream_t>(stream), d_dense,
+                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_out, out_stride,
+                         cat_dense, cat_sparse);
+    else
+      hipLaunchKernelGGL((tzr_dot_interaction_fwd_mfma_kernel<4>), dim3(iam_grid(B, IA_WAVES)),
+                         dim3(IA_THREADS), 0, static_cast<hipStream_t>(stream), d_dense,
+                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_out, out_stride,
+                         cat_dense, cat_sparse);
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
   if (!mfma) {
     hipLaunchKernelGGL(tzr_dot_interaction_fwd_general_kernel, dim3(iag_grid(B)), dim3(IA_THREADS),
                        0, static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
@@ -348,12 +525,28 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
   if (!d_sparse || !d_grad_out || !d_grad_sparse || F <= 0 || B < 0) return TZR_ERR_INVALID;
   if (hd && !d_grad_dense) return TZR_ERR_INVALID;
   const bool mfma = (D == IA_D && n <= IA_MAXN);
-  if (n < 2 || D <= 0 || (D & 3) || (!mfma && !iag_fits(n, D, true))) return TZR_ERR_UNSUPPORTED;
+  if (n < 2 || D <= 0 || (D & 3) || (!mfma && n > 64 && !iag_fits(n, D, true))) return TZR_ERR_UNSUPPORTED;
   if ((sparse_stride & 3) || (grad_sparse_stride & 3) || (hd && ((dense_stride | grad_dense_stride) & 3)) ||
       ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_grad_sparse) |
         reinterpret_cast<uintptr_t>(d_dense) | reinterpret_cast<uintptr_t>(d_grad_dense)) & 15))
     return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
+  if (!mfma && n <= 64) {
+    if (n <= 32)
+      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<2, 4>), dim3(iam_grid(B, 4)),
+                         dim3(4 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
+                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
+                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
+                         d_grad_sparse, grad_sparse_stride);
+    else
+      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 2>), dim3(iam_grid(B, 2)),
+                         dim3(2 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
+                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
+                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
+                         d_grad_sparse, grad_sparse_stride);
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
   if (!mfma) {
     hipLaunchKernelGGL(tzr_dot_interaction_bwd_general_kernel, dim3(iag_grid(B)), dim3(IA_THREADS),
                        0, static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
