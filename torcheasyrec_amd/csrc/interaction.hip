@@ -334,15 +334,36 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kerne
     f32x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column blocks are software-pipelined: the loads of block cb + 16 are in flight while block cb
+    // is stored (pass-through) and multiplied
+    float4 nxt[NB];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      const int row = 16 * bi + r;
+      nxt[bi] = (on && 4 * q < D && row < n)
+                    ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + 4 * q)
+                    : tzr_zero4();
+    }
     for (int cb = 0; cb < D; cb += 16) {
       const bool kin = on && (cb + 4 * q < D);
+      float4 cur[NB];
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) cur[bi] = nxt[bi];
+      if (cb + 16 < D) {
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+          const int row = 16 * bi + r;
+          nxt[bi] = (on && cb + 16 + 4 * q < D && row < n)
+                        ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + cb + 16 + 4 * q)
+                        : tzr_zero4();
+        }
+      }
       float x[NB][4];
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) {
         const int row = 16 * bi + r;
-        float4 a = tzr_zero4();
+        const float4 a = cur[bi];
         if (kin && row < n) {
-          a = tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + cb + 4 * q);
           if (hd && row == 0) {
             if (cat_dense) tzr_st4_a4(o + colD + cb + 4 * q, a);
           } else if (cat_sparse) {
@@ -429,13 +450,22 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma
       f32x4 d[NB];
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) d[bi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int k = 4 * ks + q;  // contraction index = row of X / S
-        float xa = 0.f;
-        if (cin && k < n) xa = iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r];
+      // every operand load of the column block is issued before the MFMA chain starts (inside the
+      // chain each one would be a dependent global-memory round trip)
+      float xa[MAXN / 4];
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
-          d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, S[wv][k * SP + 16 * bi + r], d[bi], 0, 0, 0);
+      for (int ks = 0; ks < MAXN / 4; ++ks) {
+        const int k = 4 * ks + q;  // contraction index = row of X / S
+        xa[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r] : 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < MAXN / 4; ++ks) {
+        if (ks < ksteps) {  // wave-uniform
+          const int k = 4 * ks + q;
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi)
+            d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], S[wv][k * SP + 16 * bi + r], d[bi], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) {
