@@ -334,52 +334,48 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kerne
     f32x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // column blocks are software-pipelined: the loads of block cb + 16 are in flight while block cb
-    // is stored (pass-through) and multiplied
-    float4 nxt[NB];
+    // column blocks go in groups of G (64 columns at NB = 2): all loads of a group are issued
+    // before its pass-through stores and MFMAs, so a wave keeps G * NB float4 per lane in flight
+    constexpr int G = NB == 2 ? 4 : 2;
+    for (int cg = 0; cg < D; cg += 16 * G) {
+      float4 a[G][NB];
 #pragma unroll
-    for (int bi = 0; bi < NB; ++bi) {
-      const int row = 16 * bi + r;
-      nxt[bi] = (on && 4 * q < D && row < n)
-                    ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + 4 * q)
-                    : tzr_zero4();
-    }
-    for (int cb = 0; cb < D; cb += 16) {
-      const bool kin = on && (cb + 4 * q < D);
-      float4 cur[NB];
-#pragma unroll
-      for (int bi = 0; bi < NB; ++bi) cur[bi] = nxt[bi];
-      if (cb + 16 < D) {
+      for (int gi = 0; gi < G; ++gi)
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
-          const int row = 16 * bi + r;
-          nxt[bi] = (on && cb + 16 + 4 * q < D && row < n)
-                        ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + cb + 16 + 4 * q)
-                        : tzr_zero4();
+          const int row = 16 * bi + r, c = cg + 16 * gi + 4 * q;
+          a[gi][bi] = (on && c < D && row < n)
+                          ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + c)
+                          : tzr_zero4();
         }
-      }
-      float x[NB][4];
 #pragma unroll
-      for (int bi = 0; bi < NB; ++bi) {
-        const int row = 16 * bi + r;
-        const float4 a = cur[bi];
-        if (kin && row < n) {
-          if (hd && row == 0) {
-            if (cat_dense) tzr_st4_a4(o + colD + cb + 4 * q, a);
-          } else if (cat_sparse) {
-            tzr_st4_a4(o + colS + (int64_t)(row - hd) * D + cb + 4 * q, a);
+      for (int gi = 0; gi < G; ++gi) {
+        const int c = cg + 16 * gi + 4 * q;
+        if (cg + 16 * gi < D) {  // wave-uniform
+          float x[NB][4];
+#pragma unroll
+          for (int bi = 0; bi < NB; ++bi) {
+            const int row = 16 * bi + r;
+            const float4 v = a[gi][bi];
+            if (on && c < D && row < n) {
+              if (hd && row == 0) {
+                if (cat_dense) tzr_st4_a4(o + colD + c, v);
+              } else if (cat_sparse) {
+                tzr_st4_a4(o + colS + (int64_t)(row - hd) * D + c, v);
+              }
+            }
+            x[bi][0] = v.x; x[bi][1] = v.y; x[bi][2] = v.z; x[bi][3] = v.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int p = 0;
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+              for (int bj = bi; bj < NB; ++bj, ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[bi][e], x[bj][e], acc[p], 0, 0, 0);
           }
         }
-        x[bi][0] = a.x; x[bi][1] = a.y; x[bi][2] = a.z; x[bi][3] = a.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int p = 0;
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-          for (int bj = bi; bj < NB; ++bj, ++p)
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[bi][e], x[bj][e], acc[p], 0, 0, 0);
       }
     }
     {
@@ -444,19 +440,29 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma
       }
     }
     ia_wave_sync();  // S[wv] is private to this wave
+    // operand loads of column block cb + 16 are issued before the MFMA chain of block cb (inside
+    // the chain each one would be a dependent global-memory round trip)
+    float xn[MAXN / 4];
+#pragma unroll
+    for (int ks = 0; ks < MAXN / 4; ++ks) {
+      const int k = 4 * ks + q;  // contraction index = row of X / S
+      xn[ks] = (on && r < D && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[r] : 0.f;
+    }
     for (int cb = 0; cb < D; cb += 16) {
-      const bool cin = on && (cb + r < D);          // operand column of this lane
       const bool kin = on && (cb + 4 * q < D);      // output float4 of this lane
       f32x4 d[NB];
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) d[bi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // every operand load of the column block is issued before the MFMA chain starts (inside the
-      // chain each one would be a dependent global-memory round trip)
       float xa[MAXN / 4];
 #pragma unroll
-      for (int ks = 0; ks < MAXN / 4; ++ks) {
-        const int k = 4 * ks + q;  // contraction index = row of X / S
-        xa[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r] : 0.f;
+      for (int ks = 0; ks < MAXN / 4; ++ks) xa[ks] = xn[ks];
+      if (cb + 16 < D) {
+        const bool cin = on && (cb + 16 + r < D);   // operand column of this lane in the next block
+#pragma unroll
+        for (int ks = 0; ks < MAXN / 4; ++ks) {
+          const int k = 4 * ks + q;
+          xn[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + 16 + r] : 0.f;
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < MAXN / 4; ++ks) {
