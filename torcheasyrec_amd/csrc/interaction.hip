@@ -312,6 +312,22 @@ __device__ __forceinline__ const float* iam_row(const float* dense, int64_t dens
                         : sparse + b * sparse_stride + (int64_t)(i - hd) * D;
 }
 
+template <int G, int NB>
+__device__ __forceinline__ void iam_load_group(float4 (&a)[G][NB], const float* dense,
+                                               int64_t dense_stride, const float* sparse,
+                                               int64_t sparse_stride, int64_t b, bool on, int n,
+                                               int hd, int D, int cg, int r, int q) {
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi) {
+      const int row = 16 * bi + r, c = cg + 16 * gi + 4 * q;
+      a[gi][bi] = (on && c < D && row < n)
+                      ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + c)
+                      : tzr_zero4();
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kernel(
     const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
@@ -334,20 +350,25 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kerne
     f32x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // column blocks go in groups of G (64 columns at NB = 2): all loads of a group are issued
-    // before its pass-through stores and MFMAs, so a wave keeps G * NB float4 per lane in flight
-    constexpr int G = NB == 2 ? 4 : 2;
+    // column blocks go in groups of G: all loads of a group are issued before its pass-through stores
+    // and MFMAs.  NB = 2: G = 4 (64 columns, 8 float4 per lane in flight, 4 waves per SIMD);
+    // NB = 4: G = 1 with the next block prefetched (the 10 accumulators leave fewer registers).
+    constexpr int G = NB == 2 ? 4 : 1;
+    constexpr bool PF = NB != 2;
+    float4 nxt[G][NB];
+    if (PF) iam_load_group<G, NB>(nxt, dense, dense_stride, sparse, sparse_stride, b, on, n, hd, D, 0, r, q);
     for (int cg = 0; cg < D; cg += 16 * G) {
       float4 a[G][NB];
+      if (PF) {
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi)
+        for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
-          const int row = 16 * bi + r, c = cg + 16 * gi + 4 * q;
-          a[gi][bi] = (on && c < D && row < n)
-                          ? tzr_ld4(iam_row(dense, dense_stride, sparse, sparse_stride, b, row, hd, D) + c)
-                          : tzr_zero4();
-        }
+          for (int bi = 0; bi < NB; ++bi) a[gi][bi] = nxt[gi][bi];
+        if (cg + 16 * G < D)
+          iam_load_group<G, NB>(nxt, dense, dense_stride, sparse, sparse_stride, b, on, n, hd, D, cg + 16 * G, r, q);
+      } else {
+        iam_load_group<G, NB>(a, dense, dense_stride, sparse, sparse_stride, b, on, n, hd, D, cg, r, q);
+      }
 #pragma unroll
       for (int gi = 0; gi < G; ++gi) {
         const int c = cg + 16 * gi + 4 * q;
@@ -440,29 +461,20 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma
       }
     }
     ia_wave_sync();  // S[wv] is private to this wave
-    // operand loads of column block cb + 16 are issued before the MFMA chain of block cb (inside
-    // the chain each one would be a dependent global-memory round trip)
-    float xn[MAXN / 4];
-#pragma unroll
-    for (int ks = 0; ks < MAXN / 4; ++ks) {
-      const int k = 4 * ks + q;  // contraction index = row of X / S
-      xn[ks] = (on && r < D && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[r] : 0.f;
-    }
     for (int cb = 0; cb < D; cb += 16) {
+      const bool cin = on && (cb + r < D);          // operand column of this lane
       const bool kin = on && (cb + 4 * q < D);      // output float4 of this lane
       f32x4 d[NB];
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) d[bi] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // every operand load of the column block is issued before the MFMA chain starts (inside the
+      // chain each one would be a dependent global-memory round trip).  Prefetching the next
+      // block as well was measured slower: the extra registers cost a wave per SIMD.
       float xa[MAXN / 4];
 #pragma unroll
-      for (int ks = 0; ks < MAXN / 4; ++ks) xa[ks] = xn[ks];
-      if (cb + 16 < D) {
-        const bool cin = on && (cb + 16 + r < D);   // operand column of this lane in the next block
-#pragma unroll
-        for (int ks = 0; ks < MAXN / 4; ++ks) {
-          const int k = 4 * ks + q;
-          xn[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + 16 + r] : 0.f;
-        }
+      for (int ks = 0; ks < MAXN / 4; ++ks) {
+        const int k = 4 * ks + q;  // contraction index = row of X / S
+        xa[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r] : 0.f;
       }
 #pragma unroll
       for (int ks = 0; ks < MAXN / 4; ++ks) {
