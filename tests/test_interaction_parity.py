@@ -35,7 +35,7 @@ def test_interaction_arch_forward_backward(dev, N, B):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("N,D,B", [(5, 8, 3), (27, 32, 4), (32, 20, 3), (33, 4, 3), (40, 16, 3), (9, 128, 2), (64, 64, 2), (64, 12, 5),
+@pytest.mark.parametrize("N,D,B", [(5, 8, 3), (27, 32, 4), (32, 20, 3), (33, 4, 3), (40, 16, 3), (48, 8, 5), (49, 8, 3), (9, 128, 2), (64, 64, 2), (64, 12, 5),
                                    (2, 4, 70), (70, 8, 2), (100, 32, 1)])
 def test_interaction_arch_general_shapes(dev, N, D, B):
     """Shapes outside the D = 16, n <= 32 specialisation: generalised MFMA kernels up to 64 rows (2 or

@@ -422,17 +422,19 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kerne
 // of X is read exactly once per sample; a lane quad reads four 64-byte row pieces), B'[k][i] = S[k][i]
 // from the wave's LDS image of S = G + G^T.  The accumulator of lane (r, q) is dX[16 bi + r][cb + 4q ..
 // cb + 4q + 3]: float4 stores.
-template <int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma_kernel(
+// SCAP = floats of S per wave; the pitch is n | 1 (odd: conflict-free column reads), so up to 48 rows
+// fit a 4-wave workgroup.
+template <int NB, int WAVES, int SCAP>
+__global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 2))) void tzr_dot_interaction_bwd_mfma_kernel(
     const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
     int64_t sparse_stride, int n, int hd, int D, int64_t B, const float* __restrict__ gout,
     int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
     int64_t gdense_stride, float* __restrict__ gsparse, int64_t gsparse_stride) {
   constexpr int MAXN = 16 * NB;
-  constexpr int SP = MAXN + 1;  // odd pitch: conflict-free column reads
   constexpr int MAXP = MAXN * (MAXN - 1) / 2;
   constexpr int THREADS = WAVES * TZR_WAVE;
-  __shared__ float S[WAVES][MAXN * SP];
+  __shared__ float S[WAVES][SCAP];
+  const int SP = n | 1;
   __shared__ unsigned short ij[MAXP];  // idx -> (i << 8) | j
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma
     iag_pair(idx, n, &i, &j);
     ij[idx] = (unsigned short)((i << 8) | j);
   }
-  for (int k = threadIdx.x; k < WAVES * MAXN * SP; k += THREADS) (&S[0][0])[k] = 0.f;
+  for (int k = threadIdx.x; k < WAVES * SCAP; k += THREADS) (&S[0][0])[k] = 0.f;
   __syncthreads();
   const int pd = P;
   const int ps = P + ((cat_dense && hd) ? D : 0);
@@ -481,8 +483,11 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE) void tzr_dot_interaction_bwd_mfma
         if (ks < ksteps) {  // wave-uniform
           const int k = 4 * ks + q;
 #pragma unroll
-          for (int bi = 0; bi < NB; ++bi)
-            d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], S[wv][k * SP + 16 * bi + r], d[bi], 0, 0, 0);
+          for (int bi = 0; bi < NB; ++bi) {
+            const int col = 16 * bi + r;
+            const float sv = (k < n && col < n) ? S[wv][k * SP + col] : 0.f;
+            d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], sv, d[bi], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -581,13 +586,19 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
   if (B == 0) return TZR_OK;
   if (!mfma && n <= 64) {
     if (n <= 32)
-      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<2, 4>), dim3(iam_grid(B, 4)),
+      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<2, 4, 32 * 33>), dim3(iam_grid(B, 4)),
+                         dim3(4 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
+                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
+                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
+                         d_grad_sparse, grad_sparse_stride);
+    else if (n <= 48)
+      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 4, 48 * 49>), dim3(iam_grid(B, 4)),
                          dim3(4 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
                          dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
                          grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
                          d_grad_sparse, grad_sparse_stride);
     else
-      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 2>), dim3(iam_grid(B, 2)),
+      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 2, 64 * 65>), dim3(iam_grid(B, 2)),
                          dim3(2 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
                          dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
                          grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
