@@ -433,8 +433,11 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 
   constexpr int MAXN = 16 * NB;
   constexpr int MAXP = MAXN * (MAXN - 1) / 2;
   constexpr int THREADS = WAVES * TZR_WAVE;
+  // full-size S image: compile-time pitch, rows / columns past n stay zero; reduced image (33-48
+  // rows in a 4-wave workgroup): run-time pitch, reads past n are masked
+  constexpr bool RT = SCAP != MAXN * (MAXN + 1);
   __shared__ float S[WAVES][SCAP];
-  const int SP = n | 1;
+  const int SP = RT ? (n | 1) : MAXN + 1;
   __shared__ unsigned short ij[MAXP];  // idx -> (i << 8) | j
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 
 #pragma unroll
           for (int bi = 0; bi < NB; ++bi) {
             const int col = 16 * bi + r;
-            const float sv = (k < n && col < n) ? S[wv][k * SP + col] : 0.f;
+            const float sv = (!RT || (k < n && col < n)) ? S[wv][k * SP + col] : 0.f;
             d[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], sv, d[bi], 0, 0, 0);
           }
         }
