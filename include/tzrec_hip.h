@@ -369,6 +369,18 @@ int tzr_padded_dense_to_jagged(const float* d_dense, const int64_t* d_offsets, i
                                int64_t max_len, int dim, float* d_values, int64_t values_stride,
                                void* stream);
 
+/* Multi-valued sequence steps: replaces torch.segment_reduce(jt.values(), pooling,
+ * lengths=key_lengths) + nan_to_num in SequenceEmbeddingGroupImpl
+ * (tzrec/modules/embedding.py:1353-1366).  Segment s = rows [offsets[s], offsets[s+1]) of
+ * d_values [N, dim]; mode 0 = sum, 1 = mean (an empty segment gives a zero row).
+ * out [S, dim].  The backward writes every row of d_grad_values covered by a segment. */
+int tzr_segment_reduce_fwd(const float* d_values, int64_t values_stride, const int64_t* d_offsets,
+                           int64_t S, int dim, int mode, float* d_out, int64_t out_stride,
+                           void* stream);
+int tzr_segment_reduce_bwd(const float* d_grad_out, int64_t grad_out_stride,
+                           const int64_t* d_offsets, int64_t S, int dim, int mode,
+                           float* d_grad_values, int64_t grad_values_stride, void* stream);
+
 /* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
 int tzr_tune(const char* name, int value);
 

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from oracle import tzrec_oracle as orc  # noqa: E402
 from torcheasyrec_amd.config import load_pipeline_spec, parse_text_proto  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS  # noqa: E402
-from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, TrainPipeline  # noqa: E402
+from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, EmbeddingGroup, TrainPipeline  # noqa: E402
 from torcheasyrec_amd.rank_model import build_rank_model  # noqa: E402
 from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor  # noqa: E402
 
@@ -336,3 +336,65 @@ def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path):
     for n, w in a.embedding_group.ecs["16"].table_weights().items():
         assert torch.equal(b.embedding_group.ecs["16"].table_weights()[n].detach(), w.detach()), n
         assert torch.equal(b.embedding_group.ecs["16"].table_states()[n].detach(), a.embedding_group.ecs["16"].table_states()[n].detach())
+
+
+def test_multivalued_sequence_steps_are_pooled_per_step(dev):
+    """A sequence sub-feature with value_dim != 1 holds several ids per STEP: the unpooled rows of a
+    step are pooled (segment_reduce, tzrec/modules/embedding.py:1353-1366) before padding.  Columns ->
+    parse_sequence_column -> DataParser.to_kjt / to_mulval_lengths -> EmbeddingGroup, against
+    torch.segment_reduce on the tables; the fused update against autograd on dense tables."""
+    from torcheasyrec_amd.data_parser import DataParser, parse_sequence_column, parse_sparse_column
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+
+    spec = load_pipeline_spec("""
+    feature_configs { id_feature { feature_name: "item" num_buckets: 11 embedding_dim: 8 } }
+    feature_configs { sequence_feature { sequence_name: "hist" sequence_length: 4
+        features { id_feature { feature_name: "tags" num_buckets: 13 embedding_dim: 8 value_dim: 0 pooling: "mean" } }
+        features { id_feature { feature_name: "cat" num_buckets: 7 embedding_dim: 8 } } } }
+    model_config { feature_groups { group_name: "seq" group_type: SEQUENCE
+        feature_names: "item" feature_names: "hist__tags" feature_names: "hist__cat" } }
+    """)
+    tags = next(f for f in spec.features if f.name == "hist__tags")
+    assert (tags.value_dim, tags.pooling) == (0, "mean")
+    assert next(f for f in spec.features if f.name == "hist__cat").value_dim == 1
+    lr = 0.5
+    eg = EmbeddingGroup(spec.features, spec.feature_groups, device=dev, sparse_optimizer=SparseOptimizerConfig(kind="sgd", lr=lr))
+    S = chr(3)
+    cols = {
+        "item": parse_sparse_column("item", [3, 5, 3, 9]),
+        # steps per sample 3, 1, 5 (truncated to sequence_length 4), 2; ids per step 1-3
+        "hist__tags": parse_sequence_column("hist__tags", [f"1{S}2;3;4{S}5{S}6", "7", f"1;1{S}1;2;3{S}12;5", f"0;9{S}10"]),
+        "hist__cat": parse_sequence_column("hist__cat", ["1;2;3", "4", "1;1;2;3;5", "0;6"]),
+    }
+    parser = DataParser(["item", "hist__tags", "hist__cat"], sequence_keys=["hist__tags", "hist__cat"], sequence_mulval_keys=["hist__tags"])
+    batch = Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {BASE_DATA_GROUP: parser.to_mulval_lengths(cols)}).to(dev)
+    mv = batch.sequence_mulval_lengths[BASE_DATA_GROUP]
+    assert mv.keys() == ["hist__tags"] and mv.values().tolist() == [2, 1, 3, 1, 1, 2, 1, 2, 1, 1, 2] and mv.lengths().tolist() == [3, 1, 5, 2]
+
+    ec = eg.ecs["8"]
+    w0 = {n: t.detach().cpu().clone() for n, t in ec.table_weights().items()}
+    out = eg(batch)
+    assert out["seq.sequence_length"].tolist() == [3, 1, 5, 2]
+    assert tuple(out["seq.sequence"].shape) == (4, 4, 16) and tuple(out["seq.query"].shape) == (4, 8)
+
+    # reference composition on dense torch tables
+    wt = {n: w.clone().requires_grad_(True) for n, w in w0.items()}
+    tag_ids = torch.from_numpy(np.array(cols["hist__tags"].values))
+    step = torch.nan_to_num(torch.segment_reduce(wt["hist__tags_emb"][tag_ids], "mean", lengths=torch.from_numpy(cols["hist__tags"].lengths.astype(np.int64))), nan=0.0)
+    seq_len = torch.tensor([3, 1, 5, 2])
+    ref_seq = torch.cat([orc.jagged_to_padded_dense(step, seq_len, 4),
+                         orc.jagged_to_padded_dense(wt["hist__cat_emb"][torch.from_numpy(np.array(cols["hist__cat"].values))], seq_len, 4)], dim=-1)
+    ref_q = wt["item_emb"][torch.from_numpy(np.array(cols["item"].values))]
+    torch.testing.assert_close(out["seq.sequence"].detach().cpu(), ref_seq.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out["seq.query"].detach().cpu(), ref_q.detach(), rtol=0, atol=0)
+
+    g = torch.Generator().manual_seed(4)
+    gs, gq = torch.randn(ref_seq.shape, generator=g), torch.randn(ref_q.shape, generator=g)
+    ((out["seq.sequence"] * gs.to(dev)).sum() + (out["seq.query"] * gq.to(dev)).sum()).backward()
+    ((ref_seq * gs).sum() + (ref_q * gq).sum()).backward()
+    for n, w in ec.table_weights().items():
+        torch.testing.assert_close(w.detach().cpu(), w0[n] - lr * wt[n].grad, rtol=1e-5, atol=1e-6)
+
+    # a batch without the per-step counts is refused, not silently treated as longer sequences
+    with pytest.raises(KeyError, match="sequence_mulval_lengths"):
+        eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}).to(dev))

@@ -88,3 +88,28 @@ def test_unpooled_lookup_and_din_training_step(dev):
                       orc.SparseOptim(kind="adagrad", lr=lr))
     got = ec.table_weights()["item_emb"].detach().cpu().numpy()
     np.testing.assert_allclose(got, w, rtol=2e-4, atol=2e-3 * lr)
+
+
+@pytest.mark.parametrize("pooling", ["sum", "mean"])
+@pytest.mark.parametrize("D", [4, 16, 36])
+def test_segment_reduce_matches_torch(dev, pooling, D):
+    """multi-valued sequence steps (tzrec/modules/embedding.py:1353-1366): against
+    torch.segment_reduce + nan_to_num, forward and backward, empty segments included"""
+    from torcheasyrec_amd.sequence import segment_reduce
+
+    g = torch.Generator().manual_seed(D)
+    lengths = torch.tensor([2, 0, 1, 5, 0, 3, 1, 0], dtype=torch.int64)
+    N = int(lengths.sum())
+    x = torch.randn(N, D, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nan_to_num(torch.segment_reduce(xr, pooling, lengths=lengths), nan=0.0)
+    xd = x.clone().to(dev).requires_grad_(True)
+    out = segment_reduce(xd, lengths.to(dev), pooling)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    out.backward(go.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-6)
+    # no segments at all
+    e = segment_reduce(torch.zeros(0, D).to(dev), torch.zeros(0, dtype=torch.int64).to(dev), pooling)
+    assert tuple(e.shape) == (0, D)

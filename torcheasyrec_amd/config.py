@@ -195,6 +195,9 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
                 num_embeddings=_num_embeddings(f, name), embedding_name=f.one("embedding_name"),
                 pooling=str(f.one("pooling", "sum")).lower(), trainable=bool(f.one("trainable", True)),
                 data_type=str(f.one("data_type", "FP32")).upper(),
+                # id_feature.value_dim (tzrec/features/id_feature.py:42-50): configured, else 1 for a
+                # sequence sub-feature (single id per step) and 0 = "any number of ids" otherwise
+                value_dim=int(f.one("value_dim", 1 if prefix else 0)),
                 zch=f.one("zch") if f.has("zch") else None, **seq)
         if kind == "raw_feature":
             nb = len(f.many("boundaries"))

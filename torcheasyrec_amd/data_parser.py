@@ -253,9 +253,25 @@ class DataParser:
     reference does); `sequence_keys` are flattened like the reference's multi-value sequences: the
     KJT length of a sample is the total number of ids over its steps."""
 
-    def __init__(self, sparse_keys: Sequence[str], dense_keys: Sequence[str] = (), sequence_keys: Sequence[str] = ()):
+    def __init__(self, sparse_keys: Sequence[str], dense_keys: Sequence[str] = (), sequence_keys: Sequence[str] = (),
+                 sequence_mulval_keys: Sequence[str] = ()):
         self.sparse_keys, self.dense_keys = list(sparse_keys), list(dense_keys)
         self.sequence_keys = set(sequence_keys)
+        self.sequence_mulval_keys = [k for k in self.sparse_keys if k in set(sequence_mulval_keys)]
+
+    def to_mulval_lengths(self, cols: Dict[str, SparseColumn]) -> Optional[KeyedJaggedTensor]:
+        """Sequence features with value_dim != 1: KJT whose `values` are the ids per sequence step
+        (key_lengths) and whose `lengths` are the steps per sample (tzrec/datasets/data_parser.py:554-593);
+        `to_kjt` carries their ids flattened, one bag of all the sample's ids per sample."""
+        if not self.sequence_mulval_keys:
+            return None
+        cs = [cols[k] for k in self.sequence_mulval_keys]
+        for k, c in zip(self.sequence_mulval_keys, cs):
+            if c.seq_lengths is None:
+                raise ValueError(f"{k}: not a sequence column (parse it with parse_sequence_column)")
+        return KeyedJaggedTensor(self.sequence_mulval_keys,
+                                 torch.from_numpy(np.concatenate([c.lengths for c in cs]).astype(np.int64)),
+                                 torch.from_numpy(np.concatenate([c.seq_lengths for c in cs]).astype(np.int32)))
 
     def to_kjt(self, cols: Dict[str, SparseColumn]) -> KeyedJaggedTensor:
         any_weighted = any(cols[k].weights is not None for k in self.sparse_keys)

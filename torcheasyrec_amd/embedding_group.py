@@ -40,6 +40,9 @@ class Batch:
     sparse_features: Dict[str, KeyedJaggedTensor] = field(default_factory=dict)
     labels: Dict[str, torch.Tensor] = field(default_factory=dict)
     sample_weights: Dict[str, torch.Tensor] = field(default_factory=dict)
+    # multi-valued sequence features (value_dim != 1): per data group a KJT whose values are the ids
+    # per sequence STEP and whose lengths are the steps per sample (tzrec/datasets/data_parser.py:554-593)
+    sequence_mulval_lengths: Dict[str, KeyedJaggedTensor] = field(default_factory=dict)
 
     def to(self, device, non_blocking: bool = False) -> "Batch":
         return Batch(
@@ -47,12 +50,13 @@ class Batch:
             {k: v.to(device, non_blocking) for k, v in self.sparse_features.items()},
             {k: v.to(device, non_blocking=non_blocking) for k, v in self.labels.items()},
             {k: v.to(device, non_blocking=non_blocking) for k, v in self.sample_weights.items()},
+            {k: v.to(device, non_blocking) for k, v in self.sequence_mulval_lengths.items()},
         )
 
     def record_stream(self, stream) -> None:
         for v in self.dense_features.values():
             v.record_stream(stream)
-        for v in self.sparse_features.values():
+        for v in list(self.sparse_features.values()) + list(self.sequence_mulval_lengths.values()):
             v.record_stream(stream)
         for v in list(self.labels.values()) + list(self.sample_weights.values()):
             if v.is_cuda:
@@ -64,6 +68,7 @@ class Batch:
             {k: v.pin_memory() for k, v in self.sparse_features.items()},
             {k: v.pin_memory() for k, v in self.labels.items()},
             {k: v.pin_memory() for k, v in self.sample_weights.items()},
+            {k: v.pin_memory() for k, v in self.sequence_mulval_lengths.items()},
         )
 
 
@@ -228,15 +233,36 @@ class EmbeddingGroup(nn.Module):
             self.ecs = nn.ModuleDict({str(d): EmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
                                                                   row_layout=row_layout) for d, c in by_dim.items()})
         self._ec_keys = {str(d): [f for c in cfgs.values() for f in c.feature_names] for d, cfgs in by_dim.items()}
+        seen: Dict[str, FeatureSpec] = {}
+        for info in self._seq_info.values():
+            for f in info["sequence"]:
+                if f.is_sparse and f.value_dim != 1:
+                    seen.setdefault(f.name, f)
+        self._seq_mulval = list(seen.values())
 
-    def _forward_sequence_groups(self, sparse: KeyedJaggedTensor, dense_cols: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        from .sequence import jagged_to_padded_dense
+    def _forward_sequence_groups(self, sparse: KeyedJaggedTensor, dense_cols: Dict[str, torch.Tensor],
+                                 mulval: Optional[KeyedJaggedTensor] = None) -> Dict[str, torch.Tensor]:
+        from .sequence import JaggedTensor, jagged_to_padded_dense, segment_reduce
 
         jts = {}
         index = {k: i for i, k in enumerate(sparse.keys())}
         for d, ec in self.ecs.items():
             keys = self._ec_keys[d]
             jts.update(ec(sparse.permute([index[k] for k in keys])))
+        # multi-valued steps: the rows of a step's ids are pooled into one row per step
+        # (SequenceEmbeddingGroupImpl, tzrec/modules/embedding.py:1353-1366)
+        for f in self._seq_mulval:
+            if mulval is None or f.name not in mulval.keys():
+                raise KeyError(f"sequence feature {f.name} has value_dim {f.value_dim}: the batch must carry its "
+                               "per-step id counts in `sequence_mulval_lengths`")
+            i = mulval.keys().index(f.name)
+            Bm = mulval.stride()
+            lo, hi = int(mulval.offsets()[i * Bm]), int(mulval.offsets()[(i + 1) * Bm])
+            key_lengths = mulval.values()[lo:hi]
+            seq_lengths = mulval.lengths()[i * Bm:(i + 1) * Bm]
+            off = torch.zeros(Bm + 1, dtype=torch.int64, device=seq_lengths.device)
+            torch.cumsum(seq_lengths.to(torch.int64), 0, out=off[1:])
+            jts[f.name] = JaggedTensor(segment_reduce(jts[f.name].values(), key_lengths, f.pooling), seq_lengths, off)
         out: Dict[str, torch.Tensor] = {}
         for g, info in self._seq_info.items():
             qs = []
@@ -322,7 +348,8 @@ class EmbeddingGroup(nn.Module):
                 parts.append(pooled[g][:, run[0]:run[1]])
             out[g] = torch.cat(parts, dim=1)
         if self._seq_info:
-            out.update(self._forward_sequence_groups(batch.sparse_features.get(BASE_DATA_GROUP), dense_cols))
+            out.update(self._forward_sequence_groups(batch.sparse_features.get(BASE_DATA_GROUP), dense_cols,
+                                                     batch.sequence_mulval_lengths.get(BASE_DATA_GROUP)))
         return out
 
 

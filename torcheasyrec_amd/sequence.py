@@ -87,6 +87,42 @@ def jagged_to_padded_dense(values: torch.Tensor, offsets: torch.Tensor, max_len:
     return _J2PFn.apply(values, offsets, int(max_len), float(padding_value))
 
 
+class _SegmentReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, offsets, mode):
+        values = values.contiguous()
+        S, D = offsets.numel() - 1, values.shape[1]
+        out = torch.empty(max(S, 1), D, dtype=torch.float32, device=values.device)
+        _lib.check(_lib.lib().tzr_segment_reduce_fwd(_lib.ptr(values), values.stride(0), _lib.ptr(offsets), S, D, mode,
+                                                     _lib.ptr(out), out.stride(0), _lib.stream_ptr(values.device)),
+                   "tzr_segment_reduce_fwd")
+        ctx.save_for_backward(offsets)
+        ctx.cfg = (values.shape[0], D, mode)
+        return out[:S]
+
+    @staticmethod
+    def backward(ctx, g):
+        (offsets,) = ctx.saved_tensors
+        N, D, mode = ctx.cfg
+        g = g.contiguous()
+        gv = torch.empty(max(N, 1), D, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().tzr_segment_reduce_bwd(_lib.ptr(g), g.stride(0) if g.numel() else D, _lib.ptr(offsets),
+                                                     offsets.numel() - 1, D, mode, _lib.ptr(gv), gv.stride(0),
+                                                     _lib.stream_ptr(g.device)), "tzr_segment_reduce_bwd")
+        return gv[:N], None, None
+
+
+def segment_reduce(values: torch.Tensor, lengths: torch.Tensor, pooling: str = "sum") -> torch.Tensor:
+    """[N, D] rows + segment lengths [S] (sum = N) -> [S, D]: the rows of one multi-valued sequence
+    step pooled into the step's row (`torch.segment_reduce(values, pooling, lengths=...)` followed by
+    `nan_to_num` for the mean of an empty step, tzrec/modules/embedding.py:1353-1366)."""
+    if pooling not in ("sum", "mean"):
+        raise ValueError(f"segment_reduce pooling {pooling!r}: sum | mean")
+    off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=values.device)
+    torch.cumsum(lengths.to(torch.int64), 0, out=off[1:])
+    return _SegmentReduceFn.apply(values, off, 1 if pooling == "mean" else 0)
+
+
 class _UnpooledLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ec, kjt, hook):
