@@ -343,16 +343,17 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
     step are pooled (segment_reduce, tzrec/modules/embedding.py:1353-1366) before padding.  Columns ->
     parse_sequence_column -> DataParser.to_kjt / to_mulval_lengths -> EmbeddingGroup, against
     torch.segment_reduce on the tables; the fused update against autograd on dense tables."""
-    from torcheasyrec_amd.data_parser import DataParser, parse_sequence_column, parse_sparse_column
+    from torcheasyrec_amd.data_parser import DataParser, parse_sequence_column, parse_sequence_dense_column, parse_sparse_column
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
 
     spec = load_pipeline_spec("""
     feature_configs { id_feature { feature_name: "item" num_buckets: 11 embedding_dim: 8 } }
     feature_configs { sequence_feature { sequence_name: "hist" sequence_length: 4
         features { id_feature { feature_name: "tags" num_buckets: 13 embedding_dim: 8 value_dim: 0 pooling: "mean" } }
-        features { id_feature { feature_name: "cat" num_buckets: 7 embedding_dim: 8 } } } }
+        features { id_feature { feature_name: "cat" num_buckets: 7 embedding_dim: 8 } }
+        features { raw_feature { feature_name: "dwell" value_dim: 4 } } } }
     model_config { feature_groups { group_name: "seq" group_type: SEQUENCE
-        feature_names: "item" feature_names: "hist__tags" feature_names: "hist__cat" } }
+        feature_names: "item" feature_names: "hist__tags" feature_names: "hist__cat" feature_names: "hist__dwell" } }
     """)
     tags = next(f for f in spec.features if f.name == "hist__tags")
     assert (tags.value_dim, tags.pooling) == (0, "mean")
@@ -367,7 +368,11 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
         "hist__cat": parse_sequence_column("hist__cat", ["1;2;3", "4", "1;1;2;3;5", "0;6"]),
     }
     parser = DataParser(["item", "hist__tags", "hist__cat"], sequence_keys=["hist__tags", "hist__cat"], sequence_mulval_keys=["hist__tags"])
-    batch = Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {BASE_DATA_GROUP: parser.to_mulval_lengths(cols)}).to(dev)
+    rng = np.random.default_rng(2)
+    dwell_rows = [[[float(x) for x in rng.integers(-4, 5, size=4) / 4] for _ in range(n)] for n in (3, 1, 5, 2)]
+    dwell = parse_sequence_dense_column("hist__dwell", dwell_rows, value_dim=4)
+    batch = Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {BASE_DATA_GROUP: parser.to_mulval_lengths(cols)},
+                  DataParser.to_sequence_dense({"hist__dwell": dwell})).to(dev)
     mv = batch.sequence_mulval_lengths[BASE_DATA_GROUP]
     assert mv.keys() == ["hist__tags"] and mv.values().tolist() == [2, 1, 3, 1, 1, 2, 1, 2, 1, 1, 2] and mv.lengths().tolist() == [3, 1, 5, 2]
 
@@ -375,7 +380,8 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
     w0 = {n: t.detach().cpu().clone() for n, t in ec.table_weights().items()}
     out = eg(batch)
     assert out["seq.sequence_length"].tolist() == [3, 1, 5, 2]
-    assert tuple(out["seq.sequence"].shape) == (4, 4, 16) and tuple(out["seq.query"].shape) == (4, 8)
+    assert tuple(out["seq.sequence"].shape) == (4, 4, 20) and tuple(out["seq.query"].shape) == (4, 8)
+    assert eg.group_total_dim("seq.sequence") == 20
 
     # reference composition on dense torch tables
     wt = {n: w.clone().requires_grad_(True) for n, w in w0.items()}
@@ -383,7 +389,8 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
     step = torch.nan_to_num(torch.segment_reduce(wt["hist__tags_emb"][tag_ids], "mean", lengths=torch.from_numpy(cols["hist__tags"].lengths.astype(np.int64))), nan=0.0)
     seq_len = torch.tensor([3, 1, 5, 2])
     ref_seq = torch.cat([orc.jagged_to_padded_dense(step, seq_len, 4),
-                         orc.jagged_to_padded_dense(wt["hist__cat_emb"][torch.from_numpy(np.array(cols["hist__cat"].values))], seq_len, 4)], dim=-1)
+                         orc.jagged_to_padded_dense(wt["hist__cat_emb"][torch.from_numpy(np.array(cols["hist__cat"].values))], seq_len, 4),
+                         orc.jagged_to_padded_dense(torch.from_numpy(np.array(dwell.values)), seq_len, 4)], dim=-1)
     ref_q = wt["item_emb"][torch.from_numpy(np.array(cols["item"].values))]
     torch.testing.assert_close(out["seq.sequence"].detach().cpu(), ref_seq.detach(), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(out["seq.query"].detach().cpu(), ref_q.detach(), rtol=0, atol=0)
@@ -397,4 +404,6 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
 
     # a batch without the per-step counts is refused, not silently treated as longer sequences
     with pytest.raises(KeyError, match="sequence_mulval_lengths"):
-        eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}).to(dev))
+        eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {}, DataParser.to_sequence_dense({"hist__dwell": dwell})).to(dev))
+    with pytest.raises(KeyError, match="sequence_dense_features"):
+        eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {BASE_DATA_GROUP: parser.to_mulval_lengths(cols)}).to(dev))

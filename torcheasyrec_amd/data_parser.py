@@ -296,6 +296,16 @@ class DataParser:
             torch.from_numpy(np.concatenate(lens).astype(np.int32)),
             torch.from_numpy(np.concatenate(wts).astype(np.float32)) if any_weighted else None)
 
+    @staticmethod
+    def to_sequence_dense(cols: Dict[str, "SequenceDenseColumn"]) -> Dict[str, object]:
+        """{feature: JaggedTensor(values [steps, value_dim], lengths = steps per sample)} for
+        `Batch.sequence_dense_features` (tzrec/datasets/data_parser.py:450-456)."""
+        from .sequence import JaggedTensor
+
+        return {k: JaggedTensor.from_lengths(torch.from_numpy(np.array(c.values, dtype=np.float32)),
+                                             torch.from_numpy(np.asarray(c.seq_lengths).astype(np.int32)))
+                for k, c in cols.items()}
+
     def to_keyed_tensor(self, cols: Dict[str, DenseColumn]) -> KeyedTensor:
         mats = [cols[k].values for k in self.dense_keys]
         return KeyedTensor(self.dense_keys, [m.shape[1] for m in mats],

@@ -43,6 +43,9 @@ class Batch:
     # multi-valued sequence features (value_dim != 1): per data group a KJT whose values are the ids
     # per sequence STEP and whose lengths are the steps per sample (tzrec/datasets/data_parser.py:554-593)
     sequence_mulval_lengths: Dict[str, KeyedJaggedTensor] = field(default_factory=dict)
+    # dense (raw) sub-features of a sequence_feature block: feature name -> sequence.JaggedTensor with
+    # values [sum of steps, value_dim] and lengths = steps per sample (data_parser.py:450-456)
+    sequence_dense_features: Dict[str, object] = field(default_factory=dict)
 
     def to(self, device, non_blocking: bool = False) -> "Batch":
         return Batch(
@@ -51,12 +54,14 @@ class Batch:
             {k: v.to(device, non_blocking=non_blocking) for k, v in self.labels.items()},
             {k: v.to(device, non_blocking=non_blocking) for k, v in self.sample_weights.items()},
             {k: v.to(device, non_blocking) for k, v in self.sequence_mulval_lengths.items()},
+            {k: v.to(device, non_blocking) for k, v in self.sequence_dense_features.items()},
         )
 
     def record_stream(self, stream) -> None:
         for v in self.dense_features.values():
             v.record_stream(stream)
-        for v in list(self.sparse_features.values()) + list(self.sequence_mulval_lengths.values()):
+        for v in (list(self.sparse_features.values()) + list(self.sequence_mulval_lengths.values())
+                  + list(self.sequence_dense_features.values())):
             v.record_stream(stream)
         for v in list(self.labels.values()) + list(self.sample_weights.values()):
             if v.is_cuda:
@@ -69,6 +74,7 @@ class Batch:
             {k: v.pin_memory() for k, v in self.labels.items()},
             {k: v.pin_memory() for k, v in self.sample_weights.items()},
             {k: v.pin_memory() for k, v in self.sequence_mulval_lengths.items()},
+            {k: v.pin_memory() for k, v in self.sequence_dense_features.items()},
         )
 
 
@@ -241,10 +247,17 @@ class EmbeddingGroup(nn.Module):
         self._seq_mulval = list(seen.values())
 
     def _forward_sequence_groups(self, sparse: KeyedJaggedTensor, dense_cols: Dict[str, torch.Tensor],
-                                 mulval: Optional[KeyedJaggedTensor] = None) -> Dict[str, torch.Tensor]:
+                                 mulval: Optional[KeyedJaggedTensor] = None,
+                                 seq_dense: Optional[Dict[str, object]] = None) -> Dict[str, torch.Tensor]:
         from .sequence import JaggedTensor, jagged_to_padded_dense, segment_reduce
 
         jts = {}
+        for info in self._seq_info.values():  # raw sub-features of a sequence: values travel in the batch
+            for f in info["sequence"]:
+                if not f.is_sparse:
+                    if not seq_dense or f.name not in seq_dense:
+                        raise KeyError(f"sequence feature {f.name} is dense: the batch must carry it in `sequence_dense_features`")
+                    jts[f.name] = seq_dense[f.name]
         index = {k: i for i, k in enumerate(sparse.keys())}
         for d, ec in self.ecs.items():
             keys = self._ec_keys[d]
@@ -349,7 +362,8 @@ class EmbeddingGroup(nn.Module):
             out[g] = torch.cat(parts, dim=1)
         if self._seq_info:
             out.update(self._forward_sequence_groups(batch.sparse_features.get(BASE_DATA_GROUP), dense_cols,
-                                                     batch.sequence_mulval_lengths.get(BASE_DATA_GROUP)))
+                                                     batch.sequence_mulval_lengths.get(BASE_DATA_GROUP),
+                                                     batch.sequence_dense_features))
         return out
 
 
