@@ -148,3 +148,35 @@ def test_oracle_sparse_update_matches_torch_sparse_optimizers(kind, mode):
         np.testing.assert_allclose(w, bag.weight.detach().numpy(), rtol=2e-6, atol=2e-7)
     if kind == "adagrad":
         np.testing.assert_allclose(m, opt.state[bag.weight]["sum"].numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_kjt_host_views(emu_path):
+    """torchrec KJT conveniences tzrec calls on the batch (to_dict / [] / split / concat /
+    offset_per_key / from_offsets_sync): plain slices of the key-major layout"""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    lengths = torch.tensor([2, 0, 1, 1, 3, 0, 0, 2, 1], dtype=torch.int32)  # 3 keys x 3 samples
+    values = torch.arange(10, dtype=torch.int64) + 100
+    w = torch.arange(10, dtype=torch.float32) / 10
+    kjt = KeyedJaggedTensor.from_lengths_sync(["a", "b", "c"], values, lengths, w)
+    assert kjt.length_per_key() == [3, 4, 3] and kjt.offset_per_key() == [0, 3, 7, 10]
+    d = kjt.to_dict()
+    assert list(d) == ["a", "b", "c"]
+    assert d["b"].values().tolist() == [103, 104, 105, 106] and d["b"].lengths().tolist() == [1, 3, 0]
+    assert d["b"].offsets().tolist() == [0, 1, 4, 4] and d["b"].weights_or_none().tolist() == w[3:7].tolist()
+    assert kjt["c"].values().tolist() == [107, 108, 109]
+    ab, c = kjt.split([2, 1])
+    assert ab.keys() == ["a", "b"] and ab.values().tolist() == list(range(100, 107)) and ab.stride() == 3
+    assert c.keys() == ["c"] and c.lengths().tolist() == [0, 2, 1] and c.offsets().tolist() == [0, 0, 2, 3]
+    back = KeyedJaggedTensor.concat([c, ab])
+    assert back.keys() == ["c", "a", "b"] and back.values().tolist() == [107, 108, 109] + list(range(100, 107))
+    assert back.lengths().tolist() == [0, 2, 1, 2, 0, 1, 1, 3, 0] and back.weights().tolist() == torch.cat([w[7:], w[:7]]).tolist()
+    same = KeyedJaggedTensor.from_offsets_sync(["a", "b", "c"], values, kjt.offsets(), w)
+    assert same.lengths().tolist() == lengths.tolist() and same.stride() == 3
+    with pytest.raises(ValueError):
+        kjt.split([1, 1])
+    with pytest.raises(ValueError):
+        KeyedJaggedTensor.concat([ab, KeyedJaggedTensor(["z"], values[:2], torch.tensor([1, 1], dtype=torch.int32))])
+    assert KeyedJaggedTensor.empty().keys() == []

@@ -24,7 +24,7 @@ from . import _lib
 from .dlrm import MLP
 from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
                         _WD_MODE)
-from .sparse import KeyedJaggedTensor
+from .sparse import JaggedTensor, KeyedJaggedTensor  # noqa: F401  (JaggedTensor re-exported)
 
 
 @dataclass
@@ -36,44 +36,6 @@ class EmbeddingConfig:
     num_embeddings: int
     feature_names: List[str] = field(default_factory=list)
     init_fn: Optional[object] = None
-
-
-class JaggedTensor:
-    """values [N, D] + lengths [B] (+ offsets [B+1]) of one key (torchrec JaggedTensor fields)."""
-
-    def __init__(self, values: torch.Tensor, lengths: torch.Tensor, offsets: torch.Tensor) -> None:
-        self._values, self._lengths, self._offsets = values, lengths, offsets
-
-    def values(self) -> torch.Tensor:
-        return self._values
-
-    def lengths(self) -> torch.Tensor:
-        return self._lengths
-
-    def offsets(self) -> torch.Tensor:
-        return self._offsets
-
-    def to_padded_dense(self, desired_length: int, padding_value: float = 0.0) -> torch.Tensor:
-        return jagged_to_padded_dense(self._values, self._offsets, desired_length, padding_value)
-
-    # Pipelineable pieces a Batch needs for `sequence_dense_features`
-    def to(self, device, non_blocking: bool = False) -> "JaggedTensor":
-        return JaggedTensor(self._values.to(device, non_blocking=non_blocking), self._lengths.to(device, non_blocking=non_blocking),
-                            self._offsets.to(device, non_blocking=non_blocking))
-
-    def record_stream(self, stream) -> None:
-        for t in (self._values, self._lengths, self._offsets):
-            if t.is_cuda:
-                t.record_stream(stream)
-
-    def pin_memory(self) -> "JaggedTensor":
-        return JaggedTensor(self._values.pin_memory(), self._lengths.pin_memory(), self._offsets.pin_memory())
-
-    @staticmethod
-    def from_lengths(values: torch.Tensor, lengths: torch.Tensor) -> "JaggedTensor":
-        off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
-        torch.cumsum(lengths.to(torch.int64), 0, out=off[1:])
-        return JaggedTensor(values, lengths, off)
 
 
 class _J2PFn(torch.autograd.Function):

@@ -65,6 +65,51 @@ class KeyedTensor:
         return {name: torch.cat([blocks[k] for k in group], dim=1) for name, group in zip(keys, groups)}
 
 
+class JaggedTensor:
+    """values ([N, D] embedding rows, or [N] ids) + lengths [B] + offsets [B+1] of one key (torchrec
+    JaggedTensor fields)."""
+
+    def __init__(self, values: torch.Tensor, lengths: torch.Tensor, offsets: torch.Tensor,
+                 weights: Optional[torch.Tensor] = None) -> None:
+        self._values, self._lengths, self._offsets, self._weights = values, lengths, offsets, weights
+
+    def values(self) -> torch.Tensor:
+        return self._values
+
+    def lengths(self) -> torch.Tensor:
+        return self._lengths
+
+    def offsets(self) -> torch.Tensor:
+        return self._offsets
+
+    def to_padded_dense(self, desired_length: int, padding_value: float = 0.0) -> torch.Tensor:
+        from .sequence import jagged_to_padded_dense  # K12; float rows only
+
+        return jagged_to_padded_dense(self._values, self._offsets, desired_length, padding_value)
+
+    def weights_or_none(self) -> Optional[torch.Tensor]:
+        return self._weights
+
+    # Pipelineable pieces a Batch needs for `sequence_dense_features`
+    def to(self, device, non_blocking: bool = False) -> "JaggedTensor":
+        return JaggedTensor(self._values.to(device, non_blocking=non_blocking), self._lengths.to(device, non_blocking=non_blocking),
+                            self._offsets.to(device, non_blocking=non_blocking))
+
+    def record_stream(self, stream) -> None:
+        for t in (self._values, self._lengths, self._offsets):
+            if t.is_cuda:
+                t.record_stream(stream)
+
+    def pin_memory(self) -> "JaggedTensor":
+        return JaggedTensor(self._values.pin_memory(), self._lengths.pin_memory(), self._offsets.pin_memory())
+
+    @staticmethod
+    def from_lengths(values: torch.Tensor, lengths: torch.Tensor) -> "JaggedTensor":
+        off = torch.zeros(lengths.numel() + 1, dtype=torch.int64, device=lengths.device)
+        torch.cumsum(lengths.to(torch.int64), 0, out=off[1:])
+        return JaggedTensor(values, lengths, off)
+
+
 class KeyedJaggedTensor:
     """Jagged ids for F keys x B samples, key-major (torchrec KJT field semantics)."""
 
@@ -151,6 +196,70 @@ class KeyedJaggedTensor:
     @staticmethod
     def from_lengths_sync(keys, values, lengths, weights=None) -> "KeyedJaggedTensor":
         return KeyedJaggedTensor(keys=keys, values=values, lengths=lengths, weights=weights)
+
+    @staticmethod
+    def from_offsets_sync(keys, values, offsets, weights=None) -> "KeyedJaggedTensor":
+        return KeyedJaggedTensor(keys=keys, values=values, offsets=offsets.to(torch.int64), weights=weights)
+
+    @staticmethod
+    def empty(device=None, values_dtype=torch.int64, lengths_dtype=torch.int32) -> "KeyedJaggedTensor":
+        return KeyedJaggedTensor([], torch.empty(0, dtype=values_dtype, device=device),
+                                 torch.empty(0, dtype=lengths_dtype, device=device), stride=0)
+
+    def lengths_or_none(self) -> Optional[torch.Tensor]:
+        return self._lengths
+
+    def offset_per_key(self) -> List[int]:
+        out = [0]
+        for n in self.length_per_key():
+            out.append(out[-1] + n)
+        return out
+
+    # -- host-side views (torchrec KJT.to_dict / __getitem__ / split / concat): slices, no kernels --
+    def _key_slice(self, lo_key: int, hi_key: int) -> "KeyedJaggedTensor":
+        B, opk = self._stride, self.offset_per_key()
+        lo, hi = opk[lo_key], opk[hi_key]
+        off = None if self._offsets is None else self._offsets[lo_key * B:hi_key * B + 1] - lo
+        return KeyedJaggedTensor(
+            self._keys[lo_key:hi_key], self._values[lo:hi], self.lengths()[lo_key * B:hi_key * B],
+            None if self._weights is None else self._weights[lo:hi], off, B, self.length_per_key()[lo_key:hi_key],
+            self._uniform_length)
+
+    def __getitem__(self, key: str) -> JaggedTensor:
+        i = self._keys.index(key)
+        sub = self._key_slice(i, i + 1)
+        return JaggedTensor(sub._values, sub.lengths(), sub.offsets(), sub._weights)
+
+    def to_dict(self) -> Dict[str, JaggedTensor]:
+        return {k: self[k] for k in self._keys}
+
+    def split(self, segments: Sequence[int]) -> List["KeyedJaggedTensor"]:
+        """Consecutive groups of `segments[i]` keys each."""
+        if sum(segments) != len(self._keys):
+            raise ValueError(f"split segments {list(segments)} do not cover {len(self._keys)} keys")
+        out, k = [], 0
+        for n in segments:
+            out.append(self._key_slice(k, k + n))
+            k += n
+        return out
+
+    @staticmethod
+    def concat(kjt_list: Sequence["KeyedJaggedTensor"]) -> "KeyedJaggedTensor":
+        """Keys of all inputs, in order; all inputs share the stride (torchrec KJT.concat)."""
+        if not kjt_list:
+            raise ValueError("concat of no KeyedJaggedTensors")
+        strides = {k.stride() for k in kjt_list if len(k.keys())}
+        if len(strides) > 1:
+            raise ValueError(f"concat needs one stride, got {sorted(strides)}")
+        any_w = any(k.weights_or_none() is not None for k in kjt_list)
+        if any_w and not all(k.weights_or_none() is not None for k in kjt_list):
+            raise ValueError("concat: either every KeyedJaggedTensor carries weights or none does")
+        keys = [x for k in kjt_list for x in k.keys()]
+        uni = {k.uniform_length() for k in kjt_list}
+        return KeyedJaggedTensor(
+            keys, torch.cat([k.values() for k in kjt_list]), torch.cat([k.lengths() for k in kjt_list]),
+            torch.cat([k.weights() for k in kjt_list]) if any_w else None, None,
+            strides.pop() if strides else 0, None, uni.pop() if len(uni) == 1 else None)
 
     # -- Pipelineable contract (tzrec Batch.to / record_stream, datasets/utils.py:344-408) ----
     def to(self, device, non_blocking: bool = False) -> "KeyedJaggedTensor":
