@@ -119,3 +119,19 @@ def test_sequence_and_dense_columns():
     kt = DataParser([], ["a", "b"]).to_keyed_tensor({"a": parse_dense_column("a", [1.0, 2.0]),
                                                     "b": parse_dense_column("b", ["1" + S3 + "2", "3" + S3 + "4"])})
     assert kt.keys() == ["a", "b"] and kt.length_per_key() == [1, 2] and kt.values().tolist() == [[1, 1, 2], [2, 3, 4]]
+
+
+def test_use_mask_rows_are_nulled_before_parsing():
+    """tzrec/features/id_feature_test.py:190-213 (use_mask, fg_encoded_default_value ""): masked rows
+    become null, hence empty bags"""
+    from torcheasyrec_amd.data_parser import apply_sample_mask, parse_sparse_column
+
+    col = pa.array(["1\x032", "", None, "3"])
+    got = parse_sparse_column("id_feat", apply_sample_mask(col, pa.array([True, False, False, False])))
+    assert got.values.tolist() == [3] and got.lengths.tolist() == [0, 0, 0, 1]
+    got = parse_sparse_column("id_feat", apply_sample_mask(col, [False, False, False, True]), default_value=[7])
+    assert got.values.tolist() == [1, 2, 7, 7, 7] and got.lengths.tolist() == [2, 1, 1, 1]
+    ints = apply_sample_mask(pa.array([5, 6, 7], type=pa.int32()), [False, True, False])
+    assert parse_sparse_column("x", ints).lengths.tolist() == [1, 0, 1]
+    m = pa.array([[("1", 0.5)], [("2", 1.0)]], type=pa.map_(pa.string(), pa.float32()))
+    assert apply_sample_mask(m, [True, True]).null_count == 0  # maps are not masked (feature.py:879)

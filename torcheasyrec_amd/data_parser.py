@@ -59,6 +59,18 @@ def _arrow(col) -> pa.Array:
     return pa.array(col)
 
 
+def apply_sample_mask(col, mask) -> pa.Array:
+    """`use_mask` features during training: rows whose sample mask is set are nulled BEFORE parsing
+    (BaseFeature.parse, tzrec/features/feature.py:862-887; the mask column is drawn per batch by the
+    dataset, tzrec/datasets/dataset.py:356), so they take the default ids or an empty bag.  Map columns
+    are left alone, as in the reference."""
+    col = _arrow(col)
+    if mask is None or pa.types.is_map(col.type):
+        return col
+    mask = pa.array(np.asarray(mask, dtype=bool)) if not isinstance(mask, (pa.Array, pa.ChunkedArray)) else mask
+    return pc.if_else(mask, pa.nulls(len(col), col.type), col)
+
+
 def _offsets_lengths(arr) -> np.ndarray:
     off = arr.offsets.to_numpy()
     return (off[1:] - off[:-1]).astype(np.int64)
