@@ -17,7 +17,8 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from oracle.planner_oracle import dense_dp_proposals  # noqa: E402
-from torcheasyrec_amd.planner import (GB, DynamicProgrammingProposer, PlannerError, TableSpec, Topology,  # noqa: E402
+from torcheasyrec_amd.planner import (GB, DynamicProgrammingProposer, EmbeddingEnumerator, GreedyPartitioner,  # noqa: E402
+                                      PlannerError, TableSpec, Topology,
                                       dp_proposals, plan_tables, plan_to_json)
 
 
@@ -144,3 +145,69 @@ def test_plan_respects_hbm_and_constraints():
         plan_tables(tabs, Topology(2, hbm_cap=40 * GB), batch_size=8192)
     with pytest.raises(PlannerError):
         plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["column_wise"]})
+
+
+def _drive(proposer, space, topo):
+    """the reference's test loop (plan_util_test.py:60-77): every proposal through the partitioner"""
+    import copy
+
+    proposer.load(space)
+    best, best_plan, n = float("inf"), None, 0
+    p = proposer.propose()
+    while p:
+        n += 1
+        try:
+            GreedyPartitioner().partition(copy.deepcopy(p), topo)
+            perf = sum(o.total_perf for o in p)
+            if perf < best:
+                best, best_plan = perf, {o.fqn: o for o in p}
+        except PlannerError:
+            pass
+        proposer.feedback(partitionable=True, storage_constraint=topo)
+        p = proposer.propose()
+    return best, best_plan, n
+
+
+def _ref_tables():
+    # plan_util_test.py:44-52: rows 1000**i, dim 10*i (dims rounded up to the kernels' multiple of 4)
+    return [TableSpec(f"table_{i}", 1000 ** i, 4 * ((10 * i + 3) // 4), [f"feature_{i}"]) for i in range(1, 4)]
+
+
+def test_dp_best_equals_grid_search_best():
+    """plan_util_test.py:39-100 with this package's enumerator / partitioner: the best partitionable
+    DP proposal has the perf of the best combination an exhaustive grid search finds."""
+    import copy
+    import itertools
+
+    topo = Topology(2)
+    space = EmbeddingEnumerator(topo, batch_size=8196).enumerate(_ref_tables())
+    best_dp, plan_dp, n = _drive(DynamicProgrammingProposer(), space, topo)
+    assert n >= 2 and plan_dp is not None
+    by_table = {}
+    for o in space:
+        by_table.setdefault(o.fqn, []).append(o)
+    best_grid, plan_grid = float("inf"), None
+    for combo in itertools.product(*by_table.values()):
+        try:
+            GreedyPartitioner().partition(copy.deepcopy(list(combo)), topo)
+        except PlannerError:
+            continue
+        perf = sum(o.total_perf for o in combo)
+        if perf < best_grid:
+            best_grid, plan_grid = perf, {o.fqn: o for o in combo}
+    assert best_dp == pytest.approx(best_grid)
+    assert {k: v.sharding_type for k, v in plan_dp.items()} == {k: v.sharding_type for k, v in plan_grid.items()}
+
+
+def test_dp_with_prune_shards_the_table_no_single_device_holds():
+    """plan_util_test.py:102-146: a device cap that the biggest table exceeds on its own.  (Sizes adapted:
+    this planner also counts the optimizer state, so the table is 5e8 x 32 floats = 64 GB weights + 64 GB
+    Adagrad state against 100 GB devices.)  table_wise is pruned before the knapsack; the best plan shards
+    the table row_wise."""
+    tabs = _ref_tables()[:2] + [TableSpec("table_3", 500_000_000, 32, ["feature_3"])]
+    topo = Topology(2, hbm_cap=100 * GB)
+    space = EmbeddingEnumerator(topo, batch_size=8196).enumerate(tabs)
+    assert any(o.fqn == "table_3" and o.sharding_type == "table_wise" for o in space)  # enumerated, then pruned
+    _, plan, n = _drive(DynamicProgrammingProposer(), space, topo)
+    assert plan is not None and n >= 2
+    assert plan["table_3"].sharding_type == "row_wise"
