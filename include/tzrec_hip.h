@@ -381,6 +381,24 @@ int tzr_segment_reduce_bwd(const float* d_grad_out, int64_t grad_out_stride,
                            const int64_t* d_offsets, int64_t S, int dim, int mode,
                            float* d_grad_values, int64_t grad_values_stride, void* stream);
 
+/* ---- export ------------------------------------------------------------------------------ */
+
+/* Row-wise INT8 export of a table: replaces _quantize_quint8_rowwise_f16
+ * (tzrec/utils/quant_util.py:25-131; reached from tzrec/utils/export_util.py:2353 and the
+ * delta-embedding dump).  d_out[rows, dim + 4] bytes per row:
+ * [dim uint8 values][float16 scale][float16 offset] (QUint8RowwiseF16), byte-exact with the
+ * reference encoder.  d_w: float or (w_dtype = TZR_DT_F16) half rows, w_stride ELEMENTS apart.
+ * d_first_bad: int64[3] device scratch; after the stream has drained it holds the smallest row
+ * index with (0) a non-finite value, (1) an offset, (2) a scale outside the finite float16 range,
+ * INT64_MAX where there is none -- the conditions the reference raises ValueError for; such rows'
+ * output bytes are unspecified. */
+int tzr_quantize_rows_q8f16(const void* d_w, int w_dtype, int64_t w_stride, int64_t rows, int dim,
+                            uint8_t* d_out, int64_t* d_first_bad, void* stream);
+/* dequantize_quint8_rowwise_f16 (tzrec/utils/quant_util.py:158-196): out[r, c] = q * scale + offset
+ * (product rounded first), float32 [rows, dim]. */
+int tzr_dequantize_rows_q8f16(const uint8_t* d_rows, int64_t rows, int dim, float* d_out,
+                              int64_t out_stride, void* stream);
+
 /* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
 int tzr_tune(const char* name, int value);
 

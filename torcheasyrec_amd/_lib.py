@@ -116,6 +116,8 @@ _SIGNATURES = {
                                        _i32, _vp, _i64, _vp, _i64, _vp]),
     "tzr_jagged_to_padded_dense": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, C.c_float, _vp, _vp]),
     "tzr_padded_dense_to_jagged": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
+    "tzr_quantize_rows_q8f16": (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tzr_dequantize_rows_q8f16": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "tzr_segment_reduce_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "tzr_segment_reduce_bwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "tzr_bce_logits_workspace": (_sz, [_i64]),
