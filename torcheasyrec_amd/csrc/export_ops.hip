@@ -15,6 +15,7 @@
 
 #define EX_THREADS 256
 #define EX_FP16_MAX 65504.0f
+#define EX_U 4
 
 __device__ __forceinline__ float ex_group_min(float v, int lg, int lig, int lane) {
   if ((lg & (lg - 1)) == 0) {
@@ -71,40 +72,50 @@ __global__ __launch_bounds__(EX_THREADS) void tzr_quantize_rows_kernel(
   const int64_t row_bytes = D + 4;
   const int64_t waves = ((int64_t)gridDim.x * EX_THREADS) / TZR_WAVE;
   const int64_t wave0 = ((int64_t)blockIdx.x * EX_THREADS + threadIdx.x) / TZR_WAVE;
-  for (int64_t r0 = wave0 * gpw; r0 < rows; r0 += waves * gpw) {
-    const int64_t row = r0 + gi;
-    const bool on = gi < gpw && row < rows;
-    float4 v = tzr_zero4();
-    if (on) v = tzr_ldw4(w, w_dtype, row * w_stride + 4 * lig);
-    const int nonfinite = on && !(__builtin_isfinite(v.x) && __builtin_isfinite(v.y) &&
-                                  __builtin_isfinite(v.z) && __builtin_isfinite(v.w));
-    float mn = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
-    float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    // idle lanes of the last group must not take part in another row's reduction: groups are
-    // lg-aligned, and the generic path reads exactly the lg lanes of the group
-    mn = ex_group_min(mn, lg, lig, lane);
-    mx = ex_group_max(mx, lg, lig, lane);
-    const int bad_row = ex_group_or(nonfinite, lg, lig, lane);
-    if (!on) continue;
-    const float offset = ex_f16_round(mn);
-    const double vr64 = (double)mx - (double)offset;
-    const bool bad_offset = fabsf(mn) > EX_FP16_MAX;
-    const bool bad_scale = (!__builtin_isfinite(vr64) || fabs(vr64) > (double)EX_FP16_MAX * 255.0) && vr64 != 0.0;
-    if (lig == 0) {
-      if (bad_row) atomicMin(&bad[0], (unsigned long long)row);
-      else if (bad_offset) atomicMin(&bad[1], (unsigned long long)row);
-      else if (bad_scale) atomicMin(&bad[2], (unsigned long long)row);
+  // EX_U row slots per wave and iteration: all their loads are issued before the first reduction
+  for (int64_t r0 = wave0 * gpw * EX_U; r0 < rows; r0 += waves * gpw * EX_U) {
+    float4 v[EX_U];
+#pragma unroll
+    for (int u = 0; u < EX_U; ++u) {
+      const int64_t row = r0 + (int64_t)u * gpw + gi;
+      v[u] = (gi < gpw && row < rows) ? tzr_ldw4(w, w_dtype, row * w_stride + 4 * lig) : tzr_zero4();
     }
-    const float vr = mx - offset;
-    float scale = (vr != 0.0f) ? vr / 255.0f : 1.0f;
-    scale = ex_f16_round(scale);
-    if (scale == 0.0f) scale = 1.0f;
-    const unsigned sb = ex_f16_bits(scale);
-    unsigned char* o = out + row * row_bytes;
-    const unsigned word = ex_q(v.x, offset, scale) | (ex_q(v.y, offset, scale) << 8) |
-                          (ex_q(v.z, offset, scale) << 16) | (ex_q(v.w, offset, scale) << 24);
-    *reinterpret_cast<unsigned*>(o + 4 * lig) = word;
-    if (lig == 0) *reinterpret_cast<unsigned*>(o + D) = sb | (ex_f16_bits(mn) << 16);
+#pragma unroll
+    for (int u = 0; u < EX_U; ++u) {
+      const int64_t row = r0 + (int64_t)u * gpw + gi;
+      const bool on = gi < gpw && row < rows;
+      const float4 x = v[u];
+      const int nonfinite = on && !(__builtin_isfinite(x.x) && __builtin_isfinite(x.y) &&
+                                    __builtin_isfinite(x.z) && __builtin_isfinite(x.w));
+      float mn = fminf(fminf(x.x, x.y), fminf(x.z, x.w));
+      float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+      // every lane takes part in the shuffles; groups are lg-aligned, the tail lanes of a wave
+      // (gi >= gpw) reduce among themselves and are dropped
+      mn = ex_group_min(mn, lg, lig, lane);
+      mx = ex_group_max(mx, lg, lig, lane);
+      const int bad_row = ex_group_or(nonfinite, lg, lig, lane);
+      if (on) {
+        const float offset = ex_f16_round(mn);
+        const double vr64 = (double)mx - (double)offset;
+        const bool bad_offset = fabsf(mn) > EX_FP16_MAX;
+        const bool bad_scale = (!__builtin_isfinite(vr64) || fabs(vr64) > (double)EX_FP16_MAX * 255.0) && vr64 != 0.0;
+        if (lig == 0) {
+          if (bad_row) atomicMin(&bad[0], (unsigned long long)row);
+          else if (bad_offset) atomicMin(&bad[1], (unsigned long long)row);
+          else if (bad_scale) atomicMin(&bad[2], (unsigned long long)row);
+        }
+        const float vr = mx - offset;
+        float scale = (vr != 0.0f) ? vr / 255.0f : 1.0f;
+        scale = ex_f16_round(scale);
+        if (scale == 0.0f) scale = 1.0f;
+        const unsigned sb = ex_f16_bits(scale);
+        unsigned char* o = out + row * row_bytes;
+        const unsigned word = ex_q(x.x, offset, scale) | (ex_q(x.y, offset, scale) << 8) |
+                              (ex_q(x.z, offset, scale) << 16) | (ex_q(x.w, offset, scale) << 24);
+        *reinterpret_cast<unsigned*>(o + 4 * lig) = word;
+        if (lig == 0) *reinterpret_cast<unsigned*>(o + D) = sb | (ex_f16_bits(mn) << 16);
+      }
+    }
   }
 }
 
@@ -163,7 +174,7 @@ extern "C" int tzr_quantize_rows_q8f16(const void* d_w, int w_dtype, int64_t w_s
   if (rows > 0) {
     const int lg = dim >> 2;
     const int64_t gpw = TZR_WAVE / lg;
-    const int64_t waves = (rows + gpw - 1) / gpw;
+    const int64_t waves = (rows + gpw * EX_U - 1) / (gpw * EX_U);
     const int64_t wg = (waves + (EX_THREADS / TZR_WAVE) - 1) / (EX_THREADS / TZR_WAVE);
     hipLaunchKernelGGL(tzr_quantize_rows_kernel, dim3((unsigned)std::min<int64_t>(wg, 65536)),
                        dim3(EX_THREADS), 0, s, d_w, w_dtype, w_stride, rows, lg, d_out,
