@@ -38,6 +38,10 @@ __device__ __forceinline__ float ex_group_max(float v, int lg, int lig, int lane
   return r;
 }
 __device__ __forceinline__ int ex_group_or(int v, int lg, int lig, int lane) {
+  if ((lg & (lg - 1)) == 0) {
+    for (int m = lg >> 1; m > 0; m >>= 1) v |= __shfl_xor(v, m, 64);
+    return v;
+  }
   int r = 0;
   const int g0 = lane - lig;
   for (int l = 0; l < lg; ++l) r |= __shfl(v, g0 + l, 64);
