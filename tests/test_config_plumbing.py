@@ -376,6 +376,11 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
     mv = batch.sequence_mulval_lengths[BASE_DATA_GROUP]
     assert mv.keys() == ["hist__tags"] and mv.values().tolist() == [2, 1, 3, 1, 1, 2, 1, 2, 1, 1, 2] and mv.lengths().tolist() == [3, 1, 5, 2]
 
+    d = batch.to_dict()  # the reference's flat key names (datasets/utils.py:465-512)
+    assert d["hist__tags.key_lengths"].tolist() == [2, 1, 3, 1, 1, 2, 1, 2, 1, 1, 2] and d["hist__tags.lengths"].tolist() == [3, 1, 5, 2]
+    assert d["hist__cat.lengths"].tolist() == [3, 1, 5, 2] and d["item.values"].tolist() == [3, 5, 3, 9]
+    assert tuple(d["hist__dwell.values"].shape) == (11, 4) and d["hist__dwell.lengths"].tolist() == [3, 1, 5, 2]
+
     ec = eg.ecs["8"]
     w0 = {n: t.detach().cpu().clone() for n, t in ec.table_weights().items()}
     out = eg(batch)

@@ -67,6 +67,28 @@ class Batch:
             if v.is_cuda:
                 v.record_stream(stream)
 
+    def to_dict(self, sparse_dtype: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
+        """Flat feature-tensor dict with the reference's key names (tzrec/datasets/utils.py:465-512):
+        `<key>.values` / `.lengths` / `.weights` / `.key_lengths`, labels and sample weights by name."""
+        out: Dict[str, torch.Tensor] = {}
+        cast = (lambda t: t.to(sparse_dtype)) if sparse_dtype else (lambda t: t)
+        for kt in self.dense_features.values():
+            for k, v in kt.to_dict().items():
+                out[f"{k}.values"] = v
+        for kjt in self.sparse_features.values():
+            for k, jt in kjt.to_dict().items():
+                out[f"{k}.values"], out[f"{k}.lengths"] = cast(jt.values()), cast(jt.lengths())
+                if jt.weights_or_none() is not None:
+                    out[f"{k}.weights"] = jt.weights_or_none()
+        for kjt in self.sequence_mulval_lengths.values():
+            for k, jt in kjt.to_dict().items():
+                out[f"{k}.key_lengths"], out[f"{k}.lengths"] = cast(jt.values()), cast(jt.lengths())
+        for k, jt in self.sequence_dense_features.items():
+            out[f"{k}.values"], out[f"{k}.lengths"] = jt.values(), jt.lengths()
+        out.update(self.labels)
+        out.update(self.sample_weights)
+        return out
+
     def pin_memory(self) -> "Batch":
         return Batch(
             {k: KeyedTensor(v.keys(), v.length_per_key(), v.values().pin_memory()) for k, v in self.dense_features.items()},
