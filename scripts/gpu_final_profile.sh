@@ -7,8 +7,10 @@ TAG=${1:-r01e}
 R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-200 $O/bench.json
+if [ -z "${SKIP_EXTRA:-}" ]; then  # SKIP_EXTRA=1: only the default line (when GPU minutes are short)
 timeout 300 python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_b8192.json 2>> $O/bench.err; echo "bench b8192 rc=$?"
 timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline 2>> $O/bench.err | tail -1 > $O/sharded_w1_proxy_bench.json; echo "sharded proxy rc=$?"
+fi
 cd /tmp
 # tuning stays on: the shipped table covers every shape of this run, so no candidate kernels appear
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $O/trace.log 2>&1; echo "trace rc=$?"
