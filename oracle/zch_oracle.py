@@ -11,9 +11,7 @@ distance clamped to >= 1, total order of the competition, free rows handed out a
 
 Plain dictionaries and Python sorts; small cases only.
 """
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
-
-import numpy as np
+from typing import Callable, Dict, List, Optional, Sequence
 
 EMPTY = (1 << 63) - 1
 
