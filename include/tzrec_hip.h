@@ -51,6 +51,8 @@ extern "C" {
 #define TZR_OPT_SGD 0
 #define TZR_OPT_ADAGRAD 1         /* elementwise state  [rows, D]  (torchrec.optim Adagrad) */
 #define TZR_OPT_ROWWISE_ADAGRAD 2 /* one scalar per row [rows]     (RowWiseAdagrad)         */
+#define TZR_OPT_ADAM 4            /* elementwise exp_avg | exp_avg_sq [rows, 2 D] (torchrec.optim Adam):
+                                     state row = [m(D) | v(D)], m_stride >= 2 D             */
 #define TZR_OPT_ACCUMULATE 3      /* no update: the summed gradient of every touched row is
                                      written to TzrTable.m (dense float [rows, dim]); used for
                                      replicated (data_parallel) tables before the all-reduce  */
@@ -127,7 +129,17 @@ typedef struct TzrSparseOptim {
   float weight_decay;
   float max_gradient;        /* used when gradient_clipping != 0                                */
   int32_t gradient_clipping;
-} TzrSparseOptim;
+  float beta1;               /* TZR_OPT_ADAM (protos/optimizer.proto:89-96)                     */
+  float beta2;
+  uint64_t d_adam;           /* TZR_OPT_ADAM: float[4] DEVICE state {step, 1 - beta1^step,
+                                1 - beta2^step, -}, advanced once per training step by
+                                tzr_sparse_adam_tick (graph-replay safe)                        */
+} TzrSparseOptim; /* 48 bytes */
+
+/* Sparse Adam step counter: d_adam[0] += 1, d_adam[1] = 1 - beta1^step, d_adam[2] = 1 - beta2^step.
+ * Call once per training step BEFORE the step's tzr_pooled_bwd_apply / tzr_dense_rows_update calls
+ * (fbgemm's `iter`, incremented once per step [upstream]). */
+int tzr_sparse_adam_tick(float* d_adam, float beta1, float beta2, void* stream);
 
 /* ---- library identity ------------------------------------------------------------------- */
 const char* tzr_backend(void); /* "hip-gfx950" (the CPU lane emulator used by tests says "emu") */

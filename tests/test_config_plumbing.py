@@ -412,3 +412,45 @@ def test_multivalued_sequence_steps_are_pooled_per_step(dev):
         eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {}, DataParser.to_sequence_dense({"hist__dwell": dwell})).to(dev))
     with pytest.raises(KeyError, match="sequence_dense_features"):
         eg(Batch({}, {BASE_DATA_GROUP: parser.to_kjt(cols)}, {}, {}, {BASE_DATA_GROUP: parser.to_mulval_lengths(cols)}).to(dev))
+
+
+def test_sparse_adam_from_config_and_checkpoint(dev, tmp_path):
+    """`adam_optimizer` in `sparse_optimizer` (the one other kind the reference's configs use,
+    protos/optimizer.proto:89-96): parsed, trains, and a checkpoint carries the step counter so the
+    bias correction continues where it stopped."""
+    from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+
+    text = open(os.path.join(HERE, "golden", "deepfm_mini.config")).read()
+    assert "adagrad_optimizer" in text
+    text = text.replace("adagrad_optimizer", "adam_optimizer", 1)
+    spec = load_pipeline_spec(text)
+    so = spec.sparse_optimizer
+    assert so.kind == "adam" and (so.beta1, so.beta2) == (0.9, 0.999)
+    spec.sparse_optimizer.beta1, spec.sparse_optimizer.beta2 = 0.7, 0.9
+
+    def make():
+        torch.manual_seed(0)
+        return build_rank_model(spec, device=dev)
+
+    def steps(model, n, seed):
+        opt = torch.optim.Adam(list(model.dense_parameters()), lr=spec.dense_lr)
+        pipe = TrainPipeline(model, opt, dev, model.loss)
+        it = iter(_batches(spec, n * 16, 16, seed=seed))
+        for _ in range(n):
+            pipe.progress(it)
+
+    a = make()
+    steps(a, 3, seed=1)
+    fo = a.embedding_group.ebc.fused_optimizer
+    assert float(fo.adam_state(dev)[0]) == 3.0
+    st = next(iter(a.embedding_group.ebc.table_states().values()))
+    D = next(iter(a.embedding_group.ebc.table_weights().values())).shape[1]
+    assert st.shape[1] == 2 * D and float(st[:, D:].abs().sum()) > 0  # exp_avg_sq moved
+    save_checkpoint(str(tmp_path / "ck"), a)
+    b = make()
+    restore_checkpoint(str(tmp_path / "ck"), b)
+    assert float(b.embedding_group.ebc.fused_optimizer.adam_state(dev)[0]) == 3.0
+    steps(a, 2, seed=2)
+    steps(b, 2, seed=2)
+    for n, w in a.embedding_group.ebc.table_weights().items():
+        assert torch.equal(w.detach(), b.embedding_group.ebc.table_weights()[n].detach()), n

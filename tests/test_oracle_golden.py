@@ -180,3 +180,29 @@ def test_kjt_host_views(emu_path):
     with pytest.raises(ValueError):
         KeyedJaggedTensor.concat([ab, KeyedJaggedTensor(["z"], values[:2], torch.tensor([1, 1], dtype=torch.int32))])
     assert KeyedJaggedTensor.empty().keys() == []
+
+
+def test_oracle_sparse_adam_follows_torch_sparse_adam():
+    """The Adam restatement against torch.optim.SparseAdam over several steps with duplicates.  The two
+    differ only in where eps sits (fbgemm: sqrt(v / (1 - b2^t)) + eps; torch: sqrt(v) / sqrt(1 - b2^t)
+    + eps ... i.e. eps scaled by sqrt(1 - b2^t)), invisible at eps = 1e-8 for gradients of order 1."""
+    rng = np.random.default_rng(9)
+    rows, D, B, lr = 29, 4, 16, 0.01
+    bag = torch.nn.EmbeddingBag(rows, D, mode="sum", sparse=True, include_last_offset=True)
+    opt = torch.optim.SparseAdam(bag.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    w = bag.weight.detach().numpy().copy()
+    m = np.zeros((rows, 2 * D), np.float32)
+    cfg = orc.SparseOptim(kind="adam", lr=lr, eps=1e-8)
+    for step in range(1, 6):
+        lengths = rng.integers(0, 4, size=B)
+        ids = rng.integers(0, 7, size=int(lengths.sum()))
+        Gy = rng.standard_normal((B, D)).astype(np.float32)
+        off = np.concatenate([[0], np.cumsum(lengths)])
+        opt.zero_grad()
+        (bag(torch.from_numpy(ids), torch.from_numpy(off)) * torch.from_numpy(Gy)).sum().backward()
+        opt.step()
+        orc.sparse_update(w, m, ids, orc.lookup_grads([Gy], lengths, B, ["sum"]), cfg, step=step)
+        np.testing.assert_allclose(w, bag.weight.detach().numpy(), rtol=2e-5, atol=2e-6)
+    st = opt.state[bag.weight]
+    np.testing.assert_allclose(m[:, :D], st["exp_avg"].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(m[:, D:], st["exp_avg_sq"].numpy(), rtol=1e-4, atol=1e-8)  # v += (1-b2)(g^2 - v) vs b2 v + (1-b2) g^2

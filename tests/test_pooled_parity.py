@@ -179,11 +179,14 @@ def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups
         m_ref = {n: np.full_like(w_ref[n], opt_cfg.initial_accumulator_value) for n in w_ref}
     elif opt_cfg.kind == "rowwise_adagrad":
         m_ref = {n: np.zeros(w_ref[n].shape[0], np.float32) for n in w_ref}
+    elif opt_cfg.kind == "adam":
+        m_ref = {n: np.zeros((w_ref[n].shape[0], 2 * w_ref[n].shape[1]), np.float32) for n in w_ref}
     else:
         m_ref = {n: None for n in w_ref}
     oopt = orc.SparseOptim(kind=opt_cfg.kind, lr=opt_cfg.lr, eps=opt_cfg.eps,
                            weight_decay=opt_cfg.weight_decay, weight_decay_mode=opt_cfg.weight_decay_mode,
-                           gradient_clipping=opt_cfg.gradient_clipping, max_gradient=opt_cfg.max_gradient)
+                           gradient_clipping=opt_cfg.gradient_clipping, max_gradient=opt_cfg.max_gradient,
+                           beta1=opt_cfg.beta1, beta2=opt_cfg.beta2)
     pool_of = {name: pooling for name, _, _, pooling, _ in spec}
     for step in range(steps):
         kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted)
@@ -225,7 +228,7 @@ def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups
         for t, items in pend.items():
             ids = np.concatenate([i for i, _ in items])
             gr = np.concatenate([g for _, g in items], axis=0)
-            orc.sparse_update(w_ref[t], m_ref[t], ids, gr, oopt)
+            orc.sparse_update(w_ref[t], m_ref[t], ids, gr, oopt, step=step + 1)
     for n in inits:
         got = ebc.table_weights()[n].detach().cpu().numpy()
         np.testing.assert_allclose(got, w_ref[n], rtol=rtol, atol=1e-7, err_msg=f"weights of {n}")
@@ -239,6 +242,17 @@ def test_backward_uniform1(dev, kind):
     opt = SparseOptimizerConfig(kind=kind, lr=0.05)
     _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 200,
                        "uniform1", False, opt)
+
+
+@pytest.mark.parametrize("mode,weighted,wd", [("uniform1", False, 0.0), ("jagged", True, 0.01)])
+def test_backward_sparse_adam(dev, mode, weighted, wd):
+    """adam_optimizer (protos/optimizer.proto:89-96): state [exp_avg | exp_avg_sq], one step counter on
+    the device advanced per backward, bias correction as fbgemm's split Adam; 4 steps so the
+    correction terms move; clipping and weight decay in the second case"""
+    opt = SparseOptimizerConfig(kind="adam", lr=0.01, beta1=0.8, beta2=0.95, weight_decay=wd,
+                                gradient_clipping=weighted, max_gradient=0.9)
+    _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 120, mode, weighted, opt,
+                       steps=4, rtol=5e-5)
 
 
 def test_backward_long_runs(dev):

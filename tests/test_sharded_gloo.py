@@ -314,6 +314,60 @@ def test_sharded_fp16_tables_world2(emu_path):
         mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
+def _adam_worker(rank, world, init_file, emu_path):
+    """Sparse Adam through the sharded exchange: row-wise shards and the replicated table share ONE step
+    counter advanced once per backward, so after three steps every shard equals the unsharded collection's
+    rows (oracle-checked in tests/test_pooled_parity.py::test_backward_sparse_adam) on the global batches."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sharding import ShardedEmbeddingBagCollection
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    rows, keys = [301, 40, 9], ["a", "b", "c"]
+
+    def seeded(t):
+        def f(w):
+            g = torch.Generator().manual_seed(100 + t)
+            w.copy_((torch.rand(w.shape, generator=g) - 0.5) * 0.2)
+        return f
+
+    cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t)) for t, r in enumerate(rows)]  # noqa: E731
+    opt = SparseOptimizerConfig(kind="adam", lr=0.05, beta1=0.8, beta2=0.9, weight_decay=0.01)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    assert {p["sharding_type"] for p in sh.plan().values()} == {"row_wise", "data_parallel"}
+    ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
+    rng = np.random.default_rng(0)
+    Bg, Bl = 40, 20
+    for step in range(3):
+        ids = np.stack([rng.integers(0, min(r, 25), size=Bg) for r in rows]).astype(np.int64)  # duplicates across ranks
+        g = torch.randn(Bg, 48, generator=torch.Generator().manual_seed(9 + step))
+        mine = KeyedJaggedTensor(keys, torch.from_numpy(ids[:, rank * Bl:(rank + 1) * Bl].reshape(-1).copy()),
+                                 torch.ones(3 * Bl, dtype=torch.int32), uniform_length=1)
+        full = KeyedJaggedTensor(keys, torch.from_numpy(ids.reshape(-1).copy()), torch.ones(3 * Bg, dtype=torch.int32), uniform_length=1)
+        out = sh.forward_grouped(mine)["g"]
+        out_ref = ref.forward_grouped(full)["g"]
+        torch.testing.assert_close(out.detach(), out_ref.detach()[rank * Bl:(rank + 1) * Bl], rtol=1e-5, atol=1e-6)
+        (out * g[rank * Bl:(rank + 1) * Bl]).sum().backward()
+        (out_ref * g).sum().backward()
+    assert float(sh.fused_optimizer.adam_state(dev)[0]) == 3.0 == float(ref.fused_optimizer.adam_state(dev)[0])
+    for t in range(len(rows)):
+        name = f"t{t}"
+        lo, n = sh.shard_of(name)
+        torch.testing.assert_close(sh.table_weights()[name].detach()[:n], ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-6, msg=name)
+        torch.testing.assert_close(sh.table_states()[name].detach()[:n], ref.table_states()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-7, msg=name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sparse_adam_world2(emu_path):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_adam_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
 def _zch_worker(rank, world, init_file, emu_path):
     """Sharded ZCH: raw ids routed by hash, remapped by their owner, admission / eviction local to the
     owner.  Every rank's map must follow oracle/zch_oracle.py fed with exactly the ids the hash sends

@@ -23,7 +23,8 @@ TZR_MAX_FEAT_DST = 4
 POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
-OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE = 0, 1, 2, 3
+OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
+ABI_VERSION = 3  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -56,6 +57,9 @@ class TzrSparseOptim(C.Structure):
         ("weight_decay", C.c_float),
         ("max_gradient", C.c_float),
         ("gradient_clipping", C.c_int32),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("d_adam", C.c_uint64),
     ]
 
 
@@ -103,6 +107,7 @@ _SIGNATURES = {
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),
+    "tzr_sparse_adam_tick": (_i32, [_vp, C.c_float, C.c_float, _vp]),
     "tzr_dense_rows_update": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, C.POINTER(TzrSparseOptim), _vp]),
     "tzr_rows_gather": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     "tzr_lookup_grads": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, C.POINTER(TzrDst), _i32, _vp,
@@ -147,7 +152,12 @@ def _bind(path: str) -> C.CDLL:
 def use_library(path: str) -> None:
     """Load an explicit library file (tests: the lane-emulator build)."""
     global _lib, _backend
-    _lib = _bind(path)
+    loaded = _bind(path)
+    have = loaded.tzr_abi_version()
+    if have != ABI_VERSION:
+        raise TzrError(f"{path} speaks C-ABI version {have}, this package version {ABI_VERSION}: rebuild it "
+                       "(python -c 'import __graft_entry__ as g; g.build()')")
+    _lib = loaded
     _backend = _lib.tzr_backend().decode()
 
 

@@ -9,7 +9,8 @@ compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
                                 "tables": {"<module path>/<table>": {"lo", "n", "weight"[n, D]}},   rows [lo, lo+n)
                                            (module path: "ebc", "embedding_group.ebc", "embedding_group.ecs.<dim>")
                                 "zch": {"iter", "tables": {table: {row_ids, counts, last_iter}}} | None}
-  <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "dense": optimizer.state_dict()}
+  <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "adam_steps": {module path: step},
+                                "dense": optimizer.state_dict()}        (sparse Adam: momentum1 = [exp_avg | exp_avg_sq])
   <dir>/plan                   the reference's plan JSON (rank 0)
   <dir>/meta.json              world size, {table: [rows, dim]}, format version (rank 0)
 
@@ -111,7 +112,12 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
     torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables, "zch": zch},
                os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
     fo = getattr(cols[0][1], "fused_optimizer", None)
-    torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"],
+    adam_steps = {}
+    for path, col in cols:  # sparse Adam: the optimizer-wide step count of every collection
+        f = getattr(col, "fused_optimizer", None)
+        if f is not None and getattr(f, "cfg", None) is not None and f.cfg.kind == "adam" and f._adam is not None:
+            adam_steps[path] = float(f._adam[0])
+    torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"], "adam_steps": adam_steps,
                 "dense": dense_optimizer.state_dict() if (dense_optimizer is not None and rank == 0) else None},
                os.path.join(checkpoint_dir, "optimizer", f"rank{rank}.pt"))
     if rank == 0:
@@ -195,6 +201,11 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
     fo = getattr(cols[0][1], "fused_optimizer", None)
     if fo is not None and o_files[0].get("sparse_lr") is not None:
         fo.param_groups[0]["lr"] = o_files[0]["sparse_lr"]
+    for path, col in cols:
+        f = getattr(col, "fused_optimizer", None)
+        t = (o_files[0].get("adam_steps") or {}).get(path)
+        if f is not None and t is not None and f.cfg.kind == "adam":
+            f.set_adam_step(float(t))
     if dense_optimizer is not None and o_files[0].get("dense") is not None:
         dense_optimizer.load_state_dict(o_files[0]["dense"])
     if world > 1:

@@ -169,7 +169,8 @@ def _num_embeddings(f: Msg, name: str) -> int:
 def sparse_optimizer_from_config(opt: Msg) -> SparseOptimizerConfig:
     """create_sparse_optimizer mapping (tzrec/optim/optimizer_builder.py:30-97) for the kinds this
     library fuses; field defaults from protos/optimizer.proto:76-139."""
-    table = {"sgd_optimizer": "sgd", "adagrad_optimizer": "adagrad", "rowwise_adagrad_optimizer": "rowwise_adagrad"}
+    table = {"sgd_optimizer": "sgd", "adagrad_optimizer": "adagrad", "rowwise_adagrad_optimizer": "rowwise_adagrad",
+             "adam_optimizer": "adam"}
     for key, kind in table.items():
         if opt.has(key):
             m = opt.one(key)
@@ -179,6 +180,7 @@ def sparse_optimizer_from_config(opt: Msg) -> SparseOptimizerConfig:
                 gradient_clipping=bool(m.one("gradient_clipping", False)),
                 max_gradient=float(m.one("max_gradient", 1.0)),
                 initial_accumulator_value=float(m.one("initial_accumulator_value", 0.0)),
+                beta1=float(m.one("beta1", 0.9)), beta2=float(m.one("beta2", 0.999)),
             )
     raise ValueError(f"Unknown optimizer: {[k for k in opt.keys()]}")
 

@@ -28,6 +28,8 @@ struct BwdOpt {
   int kind, wd_mode, clip;
   const float* lr;
   float eps, wd, max_grad;
+  float beta1, beta2;
+  const float* adam;  // {step, 1 - beta1^step, 1 - beta2^step}
 };
 
 // Gradient sources of one lookup (key -> table), resolved once per workgroup when the table is
@@ -113,7 +115,7 @@ __device__ __forceinline__ float bwd_group_sum(float v, int lg, int lane_in_grou
 // load, before the reduction, so the update itself waits on no memory.
 __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOpt& opt, int64_t row,
                                                  int c, bool active) {
-  if (active && opt.kind == TZR_OPT_ADAGRAD)
+  if (active && (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ADAM))  // Adam: exp_avg
     return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
   return tzr_zero4();
 }
@@ -165,6 +167,27 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       w4.w = corr * w4.w - mult * g.w;
       tzr_stw4(wbase, tb.w_dtype, woff, w4);
       if (lane_in_group == 0) *mp = mnew;
+    }
+  } else if (opt.kind == TZR_OPT_ADAM) {
+    // fbgemm split Adam [upstream]: m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
+    // w -= lr * ((m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps) + wd * w); only touched rows move
+    if (active) {
+      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
+      float* vp = mp + tb.dim;
+      float4 v4 = tzr_ld4(vp);
+      const float b1 = opt.beta1, b2 = opt.beta2;
+      const float c1 = opt.adam[1], c2 = opt.adam[2];
+      m4.x = b1 * m4.x + (1.0f - b1) * g.x; m4.y = b1 * m4.y + (1.0f - b1) * g.y;
+      m4.z = b1 * m4.z + (1.0f - b1) * g.z; m4.w = b1 * m4.w + (1.0f - b1) * g.w;
+      v4.x = b2 * v4.x + (1.0f - b2) * g.x * g.x; v4.y = b2 * v4.y + (1.0f - b2) * g.y * g.y;
+      v4.z = b2 * v4.z + (1.0f - b2) * g.z * g.z; v4.w = b2 * v4.w + (1.0f - b2) * g.w * g.w;
+      tzr_st4(mp, m4);
+      tzr_st4(vp, v4);
+      w4.x -= lr * ((m4.x / c1) / (sqrtf(v4.x / c2) + opt.eps) + opt.wd * w4.x);
+      w4.y -= lr * ((m4.y / c1) / (sqrtf(v4.y / c2) + opt.eps) + opt.wd * w4.y);
+      w4.z -= lr * ((m4.z / c1) / (sqrtf(v4.z / c2) + opt.eps) + opt.wd * w4.z);
+      w4.w -= lr * ((m4.w / c1) / (sqrtf(v4.w / c2) + opt.eps) + opt.wd * w4.w);
+      tzr_stw4(wbase, tb.w_dtype, woff, w4);
     }
   } else if (opt.kind == TZR_OPT_ACCUMULATE) {
     // replicated table: hand the summed row gradient to the all-reduce (tb.m = dense [rows, dim])
@@ -383,8 +406,10 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
   if (!uniform && !d_offsets && grad_mode == 0) return TZR_ERR_INVALID;
   if (!h_optim->d_lr) return TZR_ERR_INVALID;
   if (h_optim->kind != TZR_OPT_SGD && h_optim->kind != TZR_OPT_ADAGRAD &&
-      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD && h_optim->kind != TZR_OPT_ACCUMULATE)
+      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD && h_optim->kind != TZR_OPT_ACCUMULATE &&
+      h_optim->kind != TZR_OPT_ADAM)
     return TZR_ERR_UNSUPPORTED;
+  if (h_optim->kind == TZR_OPT_ADAM && !h_optim->d_adam) return TZR_ERR_INVALID;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
   if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
   BwdPlan P;
@@ -408,6 +433,9 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
   opt.eps = h_optim->eps;
   opt.wd = h_optim->weight_decay;
   opt.max_grad = h_optim->max_gradient;
+  opt.beta1 = h_optim->beta1;
+  opt.beta2 = h_optim->beta2;
+  opt.adam = reinterpret_cast<const float*>(h_optim->d_adam);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned chunks = (unsigned)P.max_chunks;
   hipLaunchKernelGGL(tzr_bwd_reduce_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
@@ -464,8 +492,9 @@ extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
   if (!d_tables || n_tables <= 0 || !d_row_start || total_rows < 0 || !h_optim || !h_optim->d_lr ||
       dim <= 0 || (dim & 3) || dim > BWD_MAXDIM)
     return TZR_ERR_INVALID;
+  if (h_optim->kind == TZR_OPT_ADAM && !h_optim->d_adam) return TZR_ERR_INVALID;
   if (h_optim->kind != TZR_OPT_SGD && h_optim->kind != TZR_OPT_ADAGRAD &&
-      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD)
+      h_optim->kind != TZR_OPT_ROWWISE_ADAGRAD && h_optim->kind != TZR_OPT_ADAM)
     return TZR_ERR_UNSUPPORTED;
   if (total_rows == 0) return TZR_OK;
   if (!d_acc || (reinterpret_cast<uintptr_t>(d_acc) & 15)) return TZR_ERR_INVALID;
@@ -477,11 +506,32 @@ extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
   opt.eps = h_optim->eps;
   opt.wd = h_optim->weight_decay;
   opt.max_grad = h_optim->max_gradient;
+  opt.beta1 = h_optim->beta1;
+  opt.beta2 = h_optim->beta2;
+  opt.adam = reinterpret_cast<const float*>(h_optim->d_adam);
   const int gpb = (TZR_WAVE / (dim >> 2)) * BWD_WAVES;
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (total_rows + gpb - 1) / gpb);
   hipLaunchKernelGGL(tzr_dense_rows_update_kernel, dim3(grid), dim3(BWD_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
                      d_acc, dim, opt);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ---- sparse Adam step counter --------------------------------------------------------------------
+__global__ void tzr_sparse_adam_tick_kernel(float* st, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float t = st[0] + 1.0f;
+    st[0] = t;
+    st[1] = 1.0f - powf(beta1, t);
+    st[2] = 1.0f - powf(beta2, t);
+  }
+}
+
+extern "C" int tzr_sparse_adam_tick(float* d_adam, float beta1, float beta2, void* stream) {
+  if (!d_adam || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return TZR_ERR_INVALID;
+  hipLaunchKernelGGL(tzr_sparse_adam_tick_kernel, dim3(1), dim3(TZR_WAVE), 0,
+                     static_cast<hipStream_t>(stream), d_adam, beta1, beta2);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -53,7 +53,9 @@ class EmbeddingBagConfig:
 class SparseOptimizerConfig:
     """Fused sparse optimizer (/root/reference/tzrec/optim/optimizer_builder.py:30-97,
     protos/optimizer.proto:76-139): ``adagrad_optimizer`` -> kind "adagrad",
-    ``rowwise_adagrad_optimizer`` -> "rowwise_adagrad", ``sgd_optimizer`` -> "sgd"."""
+    ``rowwise_adagrad_optimizer`` -> "rowwise_adagrad", ``sgd_optimizer`` -> "sgd",
+    ``adam_optimizer`` -> "adam" (state [rows, 2 D]: exp_avg | exp_avg_sq; one step counter per
+    optimizer, bias-corrected as fbgemm's split Adam)."""
 
     kind: str = "adagrad"
     lr: float = 0.002
@@ -63,9 +65,12 @@ class SparseOptimizerConfig:
     gradient_clipping: bool = False
     max_gradient: float = 1.0
     initial_accumulator_value: float = 0.0
+    beta1: float = 0.9  # adam
+    beta2: float = 0.999
 
 
-_OPT_KIND = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "rowwise_adagrad": _lib.OPT_ROWWISE_ADAGRAD}
+_OPT_KIND = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "rowwise_adagrad": _lib.OPT_ROWWISE_ADAGRAD,
+             "adam": _lib.OPT_ADAM}
 _WD_MODE = {"none": _lib.WD_NONE, "l2": _lib.WD_L2, "decouple": _lib.WD_DECOUPLE}
 
 
@@ -81,6 +86,33 @@ class FusedSparseOptimizer:
         self.param_groups = [{"lr": float(cfg.lr), "params": list(ebc.table_weights().values())}]
         self._lr_dev: Optional[torch.Tensor] = None
         self._lr_host: Optional[float] = None
+        self._adam: Optional[torch.Tensor] = None  # device {step, 1 - b1^step, 1 - b2^step, -}
+
+    def adam_state(self, device: torch.device) -> torch.Tensor:
+        if self._adam is None or self._adam.device != device:
+            self._adam = torch.zeros(4, dtype=torch.float32, device=device)
+        return self._adam
+
+    def begin_step(self, device: torch.device) -> None:
+        """Once per training step, before the step's update kernels: advances Adam's step counter on
+        the device (one tiny launch, graph-capturable); nothing for the other optimizers."""
+        if self.cfg.kind == "adam":
+            _lib.check(_lib.lib().tzr_sparse_adam_tick(_lib.ptr(self.adam_state(device)), self.cfg.beta1, self.cfg.beta2,
+                                                       _lib.stream_ptr(device)), "tzr_sparse_adam_tick")
+
+    def optim_struct(self, device: torch.device, kind: Optional[int] = None) -> "_lib.TzrSparseOptim":
+        """The TzrSparseOptim every update launch of this optimizer passes (`kind` overrides the
+        configured one: TZR_OPT_ACCUMULATE for replicated tables)."""
+        cfg = self.cfg
+        opt = _lib.TzrSparseOptim()
+        opt.kind = _OPT_KIND[cfg.kind] if kind is None else kind
+        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
+        opt.d_lr = _lib.ptr(self.lr_device(device))
+        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
+        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        opt.beta1, opt.beta2 = cfg.beta1, cfg.beta2
+        opt.d_adam = _lib.ptr(self.adam_state(device)) if cfg.kind == "adam" else 0
+        return opt
 
     @property
     def params(self) -> Dict[str, torch.Tensor]:
@@ -106,6 +138,7 @@ class FusedSparseOptimizer:
         return {
             "state": {n: {"momentum1": s} for n, s in self._ebc.table_states().items()},
             "param_groups": [{"lr": self.param_groups[0]["lr"]}],
+            "adam_step": None if self._adam is None else float(self._adam[0]),
         }
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
@@ -115,6 +148,12 @@ class FusedSparseOptimizer:
                 dst.copy_(st["momentum1"])
         if sd.get("param_groups"):
             self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
+        if sd.get("adam_step") is not None and self.cfg.kind == "adam":
+            self.set_adam_step(float(sd["adam_step"]))
+
+    def set_adam_step(self, t: float, device: Optional[torch.device] = None) -> None:
+        st = self.adam_state(device or self._ebc._device)
+        st.copy_(torch.tensor([t, 1.0 - self.cfg.beta1 ** t, 1.0 - self.cfg.beta2 ** t, 0.0], dtype=torch.float32))
 
 
 class _Table(nn.Module):
@@ -226,7 +265,8 @@ class EmbeddingBagCollection(nn.Module):
                 store = torch.empty(rows, D, dtype=torch.float16, device=self._device)
                 weight = store
                 state = (torch.full((rows, D), init_m, dtype=torch.float32, device=self._device) if kind == "adagrad"
-                         else torch.zeros(rows, dtype=torch.float32, device=self._device) if kind == "rowwise_adagrad" else None)
+                         else torch.zeros(rows, dtype=torch.float32, device=self._device) if kind == "rowwise_adagrad"
+                         else torch.zeros(rows, 2 * D, dtype=torch.float32, device=self._device) if kind == "adam" else None)
             elif kind == "adagrad" and self._row_layout == "interleaved":
                 store = torch.empty(rows, 2 * D, dtype=torch.float32, device=self._device)
                 weight, state = store[:, :D], store[:, D:]
@@ -238,6 +278,8 @@ class EmbeddingBagCollection(nn.Module):
                     state = torch.full((rows, D), init_m, dtype=torch.float32, device=self._device)
                 elif kind == "rowwise_adagrad":
                     state = torch.zeros(rows, dtype=torch.float32, device=self._device)
+                elif kind == "adam":  # [exp_avg | exp_avg_sq]
+                    state = torch.zeros(rows, 2 * D, dtype=torch.float32, device=self._device)
                 else:
                     state = None
             if cfg.init_fn is not None:
@@ -470,15 +512,8 @@ class EmbeddingBagCollection(nn.Module):
         for i, g in enumerate(gl):
             gd[i].ptr = _lib.ptr(g)
             gd[i].stride = g.stride(0)
-        cfg = self._opt_cfg
-        opt = _lib.TzrSparseOptim()
-        opt.kind = _OPT_KIND[cfg.kind]
-        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
-        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(self._device))
-        opt.eps = cfg.eps
-        opt.weight_decay = cfg.weight_decay
-        opt.max_gradient = cfg.max_gradient
-        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        self.fused_optimizer.begin_step(self._device)
+        opt = self.fused_optimizer.optim_struct(self._device)
         ev = self._timers.start("apply") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_bwd_apply(
             _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),

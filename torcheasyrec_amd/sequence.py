@@ -22,8 +22,7 @@ from torch import nn
 
 from . import _lib
 from .dlrm import MLP
-from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
-                        _WD_MODE)
+from .embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
 from .sparse import JaggedTensor, KeyedJaggedTensor  # noqa: F401  (JaggedTensor re-exported)
 
 
@@ -206,13 +205,8 @@ class EmbeddingCollection(nn.Module):
         _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(m["d_tables"]), m["T"], _lib.ptr(m["d_feats"]), m["K"], m["K"],
                                          m["max_rows"], self.dim, _lib.ptr(kjt.values()), _lib.ptr(ks), N, N, 1, 0,
                                          _lib.ptr(ws), ws.numel(), stream), "tzr_pooled_bwd_plan")
-        cfg = self._opt_cfg
-        opt = _lib.TzrSparseOptim()
-        opt.kind = _OPT_KIND[cfg.kind]
-        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
-        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(dev))
-        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
-        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
+        self.fused_optimizer.begin_step(dev)
+        opt = self.fused_optimizer.optim_struct(dev)
         g1 = (_lib.TzrDst * 1)()
         g1[0].ptr, g1[0].stride = _lib.ptr(g), g.stride(0)
         _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(m["d_tables"]), _lib.ptr(m["d_feats"]), m["K"], m["T"], self.dim,

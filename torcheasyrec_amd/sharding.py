@@ -43,8 +43,7 @@ from torch import nn
 
 from . import _lib
 from .dlrm import MLP, OutputLinear
-from .embedding import (EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig, _OPT_KIND,
-                        _WD_MODE)
+from .embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
 from .interaction import dot_interaction
 from .sparse import KeyedJaggedTensor, block_bucketize
 
@@ -393,14 +392,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg, async_op=async_op)
 
     def _optim_struct(self, kind: Optional[int] = None):
-        cfg = self._opt_cfg
-        opt = _lib.TzrSparseOptim()
-        opt.kind = _OPT_KIND[cfg.kind] if kind is None else kind
-        opt.weight_decay_mode = _WD_MODE[cfg.weight_decay_mode.lower()]
-        opt.d_lr = _lib.ptr(self.fused_optimizer.lr_device(self._device))
-        opt.eps, opt.weight_decay, opt.max_gradient = cfg.eps, cfg.weight_decay, cfg.max_gradient
-        opt.gradient_clipping = 1 if cfg.gradient_clipping else 0
-        return opt
+        return self.fused_optimizer.optim_struct(self._device, kind)
 
     # The forward is three host-visible pieces so a train pipeline can run the first two one batch
     # ahead on a side stream (the reference's TrainPipelineSparseDist does the same with torchrec's
@@ -563,6 +555,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             return
         L = _lib.lib()
         dev, D = self._device, self.dim
+        self.fused_optimizer.begin_step(dev)  # Adam's step counter: once for the row-wise and the replicated tables
         kjt, rm, uniform = st["kjt"], st["rm"], st["uniform"]
         B = kjt.stride()
         stream = _lib.stream_ptr(dev)
