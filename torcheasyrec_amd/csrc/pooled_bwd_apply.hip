@@ -113,9 +113,14 @@ __device__ __forceinline__ float bwd_group_sum(float v, int lg, int lane_in_grou
 
 // Prefetch of the elementwise optimizer state of (row, chunk c): issued together with the weight
 // load, before the reduction, so the update itself waits on no memory.
+// (ADAM is a template parameter of everything below: with the Adam arithmetic as one more run-time
+// branch of the row update the reduce kernel needed 99 instead of 78 VGPRs, one wave per SIMD less,
+// and the DLRM-Criteo Adagrad step lost 17 us -- profiles/r01k.  The <false> instantiations are the
+// code that was there before.)
+template <bool ADAM>
 __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOpt& opt, int64_t row,
                                                  int c, bool active) {
-  if (active && (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ADAM))  // Adam: exp_avg
+  if (active && (ADAM || opt.kind == TZR_OPT_ADAGRAD))  // Adam: exp_avg
     return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
   return tzr_zero4();
 }
@@ -123,6 +128,7 @@ __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOp
 // ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g, the row's current
 // weights w4 and (elementwise adagrad) state m4.  All 64 lanes of the wave must call (row-wise
 // adagrad reduces in the group).
+template <bool ADAM>
 __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& opt, float lr,
                                               int64_t row, int c, float4 g, float4 w4, float4 m4,
                                               bool active, int lg, int lane_in_group, int lane) {
@@ -134,6 +140,29 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
   }
   void* const wbase = reinterpret_cast<void*>(tb.w);
   const int64_t woff = row * (int64_t)tb.w_stride + 4 * c;
+  if constexpr (ADAM) {
+    // fbgemm split Adam [upstream]: m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
+    // w -= lr * ((m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps) + wd * w); only touched rows move
+    if (active) {
+      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
+      float* vp = mp + tb.dim;
+      float4 v4 = tzr_ld4(vp);
+      const float b1 = opt.beta1, b2 = opt.beta2;
+      const float c1 = opt.adam[1], c2 = opt.adam[2];
+      m4.x = b1 * m4.x + (1.0f - b1) * g.x; m4.y = b1 * m4.y + (1.0f - b1) * g.y;
+      m4.z = b1 * m4.z + (1.0f - b1) * g.z; m4.w = b1 * m4.w + (1.0f - b1) * g.w;
+      v4.x = b2 * v4.x + (1.0f - b2) * g.x * g.x; v4.y = b2 * v4.y + (1.0f - b2) * g.y * g.y;
+      v4.z = b2 * v4.z + (1.0f - b2) * g.z * g.z; v4.w = b2 * v4.w + (1.0f - b2) * g.w * g.w;
+      tzr_st4(mp, m4);
+      tzr_st4(vp, v4);
+      w4.x -= lr * ((m4.x / c1) / (sqrtf(v4.x / c2) + opt.eps) + opt.wd * w4.x);
+      w4.y -= lr * ((m4.y / c1) / (sqrtf(v4.y / c2) + opt.eps) + opt.wd * w4.y);
+      w4.z -= lr * ((m4.z / c1) / (sqrtf(v4.z / c2) + opt.eps) + opt.wd * w4.z);
+      w4.w -= lr * ((m4.w / c1) / (sqrtf(v4.w / c2) + opt.eps) + opt.wd * w4.w);
+      tzr_stw4(wbase, tb.w_dtype, woff, w4);
+    }
+    return;
+  }
   if (opt.kind == TZR_OPT_ADAGRAD) {
     if (active) {
       float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
@@ -168,27 +197,6 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       tzr_stw4(wbase, tb.w_dtype, woff, w4);
       if (lane_in_group == 0) *mp = mnew;
     }
-  } else if (opt.kind == TZR_OPT_ADAM) {
-    // fbgemm split Adam [upstream]: m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
-    // w -= lr * ((m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps) + wd * w); only touched rows move
-    if (active) {
-      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
-      float* vp = mp + tb.dim;
-      float4 v4 = tzr_ld4(vp);
-      const float b1 = opt.beta1, b2 = opt.beta2;
-      const float c1 = opt.adam[1], c2 = opt.adam[2];
-      m4.x = b1 * m4.x + (1.0f - b1) * g.x; m4.y = b1 * m4.y + (1.0f - b1) * g.y;
-      m4.z = b1 * m4.z + (1.0f - b1) * g.z; m4.w = b1 * m4.w + (1.0f - b1) * g.w;
-      v4.x = b2 * v4.x + (1.0f - b2) * g.x * g.x; v4.y = b2 * v4.y + (1.0f - b2) * g.y * g.y;
-      v4.z = b2 * v4.z + (1.0f - b2) * g.z * g.z; v4.w = b2 * v4.w + (1.0f - b2) * g.w * g.w;
-      tzr_st4(mp, m4);
-      tzr_st4(vp, v4);
-      w4.x -= lr * ((m4.x / c1) / (sqrtf(v4.x / c2) + opt.eps) + opt.wd * w4.x);
-      w4.y -= lr * ((m4.y / c1) / (sqrtf(v4.y / c2) + opt.eps) + opt.wd * w4.y);
-      w4.z -= lr * ((m4.z / c1) / (sqrtf(v4.z / c2) + opt.eps) + opt.wd * w4.z);
-      w4.w -= lr * ((m4.w / c1) / (sqrtf(v4.w / c2) + opt.eps) + opt.wd * w4.w);
-      tzr_stw4(wbase, tb.w_dtype, woff, w4);
-    }
   } else if (opt.kind == TZR_OPT_ACCUMULATE) {
     // replicated table: hand the summed row gradient to the all-reduce (tb.m = dense [rows, dim])
     if (active) tzr_st4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, g);
@@ -207,15 +215,17 @@ __device__ __forceinline__ float4 bwd_shfl4(float4 v, int src) {
 
 // One row update done by a whole wave acting as a single group (lanes >= D/4 idle): used by the
 // stitching steps, where runs are few.
+template <bool ADAM>
 __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const BwdOpt& opt, float lr,
                                                    uint32_t key, float4 g, int lane) {
   const bool on = lane < (tb.dim >> 2);
   float4 w4 = tzr_zero4();
   if (on) w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * lane);
-  const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, lane, on);
-  bwd_apply_row(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
+  const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, lane, on);
+  bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
 
+template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     float4 w4 = tzr_zero4();
     if (do_apply)  // issued before the scan: overlaps the gradient gathers
       w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * c);
-    const float4 m4 = bwd_load_state(tb, opt, (int64_t)key, c, do_apply);
+    const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, c, do_apply);
     // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
     // distance d implies one run in between)
     for (int d = 1; d < gw; d <<= 1) {
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
       flags |= BWD_LEAD;
       lead_open = false;
     }
-    bwd_apply_row(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
+    bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
     // carry out of the tile: its last valid lookup, if that run goes on
     const int nv = min(gw, r1 - t0);
     const int last = (nv - 1) * lg;
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
       if (open) {
         osum = tzr_add4(osum, lv);
         if (!(f & BWD_LEAD_WHOLE)) {
-          bwd_apply_row_wave(tb, opt, lr, okey, osum, lane);
+          bwd_apply_row_wave<ADAM>(tb, opt, lr, okey, osum, lane);
           open = false;
         }
       } else {  // still inside the run inherited from the previous chunk
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
 
 // Runs crossing chunk boundaries: the chunk holding the run's first lookup adds the leading
 // pieces of the following chunks (in order) and updates the row.  One wave per chunk.
+template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_stitch_kernel(
     const TzrTable* __restrict__ tables, int T, BwdOpt opt, int max_dim, BwdPlan P) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_stitch_kernel(
     if (on) sum = tzr_add4(sum, tzr_ld4(P.clead + (size_t)c2 * max_dim + 4 * lane));
     if (!(f & BWD_LEAD_WHOLE)) break;
   }
-  bwd_apply_row_wave(tb, opt, lr, key, sum, lane);
+  bwd_apply_row_wave<ADAM>(tb, opt, lr, key, sum, lane);
 }
 
 extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
@@ -438,11 +449,19 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
   opt.adam = reinterpret_cast<const float*>(h_optim->d_adam);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned chunks = (unsigned)P.max_chunks;
-  hipLaunchKernelGGL(tzr_bwd_reduce_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                     n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
-                     max_dim, P);
-  hipLaunchKernelGGL(tzr_bwd_stitch_kernel, dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
-                     dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
+  if (opt.kind == TZR_OPT_ADAM) {
+    hipLaunchKernelGGL((tzr_bwd_reduce_kernel<true>), dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
+                       n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
+                       max_dim, P);
+    hipLaunchKernelGGL((tzr_bwd_stitch_kernel<true>), dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
+                       dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
+  } else {
+    hipLaunchKernelGGL((tzr_bwd_reduce_kernel<false>), dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
+                       n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
+                       max_dim, P);
+    hipLaunchKernelGGL((tzr_bwd_stitch_kernel<false>), dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
+                       dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
+  }
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
@@ -450,6 +469,7 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
 // Dense update of replicated tables: lane group <-> row of the concatenated row space; the row's
 // gradient comes from the all-reduced accumulation buffer; rows with an all-zero gradient are
 // skipped (a sparse update never visits them).  Same per-row arithmetic as the sparse path.
+template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
     const TzrTable* __restrict__ tables, int T, const int64_t* __restrict__ row_start,
     int64_t total_rows, const float* __restrict__ acc, int dim, BwdOpt opt) {
@@ -480,8 +500,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
     const TzrTable tb = tables[t];
     float4 w4 = tzr_zero4();
     if (active) w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, row * (int64_t)tb.w_stride + 4 * c);
-    const float4 m4 = bwd_load_state(tb, opt, row, c, active);
-    bwd_apply_row(tb, opt, lr, row, c, g, w4, m4, active, lg, c, lane);
+    const float4 m4 = bwd_load_state<ADAM>(tb, opt, row, c, active);
+    bwd_apply_row<ADAM>(tb, opt, lr, row, c, g, w4, m4, active, lg, c, lane);
   }
 }
 
@@ -511,9 +531,15 @@ extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
   opt.adam = reinterpret_cast<const float*>(h_optim->d_adam);
   const int gpb = (TZR_WAVE / (dim >> 2)) * BWD_WAVES;
   const unsigned grid = (unsigned)std::min<int64_t>(4096, (total_rows + gpb - 1) / gpb);
-  hipLaunchKernelGGL(tzr_dense_rows_update_kernel, dim3(grid), dim3(BWD_THREADS), 0,
-                     static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
-                     d_acc, dim, opt);
+  if (opt.kind == TZR_OPT_ADAM) {
+    hipLaunchKernelGGL((tzr_dense_rows_update_kernel<true>), dim3(grid), dim3(BWD_THREADS), 0,
+                       static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
+                       d_acc, dim, opt);
+  } else {
+    hipLaunchKernelGGL((tzr_dense_rows_update_kernel<false>), dim3(grid), dim3(BWD_THREADS), 0,
+                       static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
+                       d_acc, dim, opt);
+  }
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
