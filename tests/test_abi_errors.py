@@ -131,3 +131,39 @@ def test_module_level_errors_are_python_exceptions(dev):
     out = ebc(bad).values()
     w = ebc.table_weights()["t"].detach()
     assert torch.equal(out[1], w[0]) and torch.equal(out[2], w[0]) and torch.equal(out[0], w[3])
+
+
+def test_export_segment_reduce_and_adam_argument_checks(dev):
+    L = _lib.lib()
+    p = _lib.ptr
+    x, out = _buf(dev, 256), _buf(dev, 256)
+    q = _buf(dev, 512, torch.uint8)
+    bad = _buf(dev, 3, torch.int64)
+    off = _buf(dev, 5, torch.int64)
+    # INT8 export
+    assert L.tzr_quantize_rows_q8f16(p(x), _lib.DT_F32, 16, 4, 16, p(q), None, None) == INVALID          # no status scratch
+    assert L.tzr_quantize_rows_q8f16(p(x), _lib.DT_F32, 16, 4, 6, p(q), p(bad), None) == UNSUPPORTED     # dim % 4
+    assert L.tzr_quantize_rows_q8f16(p(x), _lib.DT_F32, 8, 4, 16, p(q), p(bad), None) == UNSUPPORTED     # stride < dim
+    assert L.tzr_quantize_rows_q8f16(p(x), 7, 16, 4, 16, p(q), p(bad), None) == UNSUPPORTED              # unknown dtype
+    assert L.tzr_quantize_rows_q8f16(None, _lib.DT_F32, 16, 4, 16, p(q), p(bad), None) == INVALID
+    assert L.tzr_quantize_rows_q8f16(None, _lib.DT_F32, 16, 0, 16, None, p(bad), None) == OK              # no rows
+    assert L.tzr_dequantize_rows_q8f16(p(q), 4, 16, p(out), 8, None) == UNSUPPORTED                       # out stride < dim
+    assert L.tzr_dequantize_rows_q8f16(None, 4, 16, p(out), 16, None) == INVALID
+    assert L.tzr_dequantize_rows_q8f16(None, 0, 16, None, 16, None) == OK
+    # segment reduce
+    assert L.tzr_segment_reduce_fwd(p(x), 16, None, 4, 16, 0, p(out), 16, None) == INVALID                # no offsets
+    assert L.tzr_segment_reduce_fwd(p(x), 16, p(off), 4, 16, 2, p(out), 16, None) == INVALID              # mode
+    assert L.tzr_segment_reduce_fwd(p(x), 16, p(off), 4, 10, 0, p(out), 16, None) == UNSUPPORTED          # dim % 4
+    assert L.tzr_segment_reduce_fwd(p(x), 16, p(off), 4, 16, 1, None, 16, None) == INVALID                # no output
+    assert L.tzr_segment_reduce_fwd(p(x), 16, p(off), 0, 16, 1, None, 16, None) == OK                     # no segments
+    assert L.tzr_segment_reduce_bwd(p(out), 16, p(off), 4, 16, 0, p(x), 8, None) == UNSUPPORTED           # stride < dim
+    # sparse Adam step counter
+    st = _buf(dev, 4)
+    assert L.tzr_sparse_adam_tick(None, 0.9, 0.999, None) == INVALID
+    assert L.tzr_sparse_adam_tick(p(st), 1.0, 0.999, None) == INVALID                                     # beta in [0, 1)
+    assert L.tzr_sparse_adam_tick(p(st), 0.9, -0.1, None) == INVALID
+    assert L.tzr_sparse_adam_tick(p(st), 0.5, 0.75, None) == OK
+    assert L.tzr_sparse_adam_tick(p(st), 0.5, 0.75, None) == OK
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert st.cpu().tolist()[:3] == [2.0, 0.75, 0.4375]
