@@ -1,0 +1,115 @@
+"""Batch assembly against OUTPUTS OF THE REFERENCE'S DataParser
+(tests/golden/reference_batch_vectors.json: the real `DataParser.parse` + `to_batch`,
+/root/reference/tzrec/datasets/data_parser.py:60-594, driven over stand-in feature objects and
+recording KJT containers by tests/golden/make_reference_batch_vectors.py).  Bit-exact: the flat
+`<key>.values / .lengths / .weights / .key_lengths` dict, the KeyedJaggedTensor fields per data group,
+`sequence_mulval_lengths`, `sequence_dense_features`, the dense KeyedTensor, labels, sample weights."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from torcheasyrec_amd import data_parser as dp  # noqa: E402
+from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch  # noqa: E402
+
+_G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_batch_vectors.json")))["cases"]
+
+
+def _arr(js):
+    return None if js is None else np.asarray(js["data"], dtype=js["dtype"]).reshape(js["shape"])
+
+
+def _same(got: torch.Tensor, want, what):
+    w = _arr(want)
+    g = got.detach().cpu().numpy()
+    assert g.shape == w.shape, (what, g.shape, w.shape)
+    assert g.dtype.kind == w.dtype.kind, (what, g.dtype, w.dtype)  # ids / lengths integer, values float
+    np.testing.assert_array_equal(g, w, err_msg=what)
+
+
+@pytest.mark.parametrize("case", _G, ids=[c["tag"] for c in _G])
+def test_batch_matches_reference_data_parser(case, emu_path):
+    from make_reference_parser_vectors import to_arrow
+    from torcheasyrec_amd import _lib
+
+    _lib.use_library(emu_path)  # KJT.offsets() for to_dict() runs the K3 kernel
+    cols = {k: to_arrow(v["rows"], v["type"]) for k, v in case["columns"].items()}
+    feats = case["features"]
+    sparse, dense, seq_dense = {}, {}, {}
+    for f in feats:
+        c, d = cols[f["name"]], f["default"]
+        if f["sequence"] and f["sparse"]:
+            sparse[f["name"]] = dp.parse_sequence_column(f["name"], c, default_value=d)
+        elif f["sequence"]:
+            seq_dense[f["name"]] = dp.parse_sequence_dense_column(f["name"], c, value_dim=f["value_dim"], default_value=d)
+        elif f["sparse"]:
+            sparse[f["name"]] = dp.parse_sparse_column(f["name"], c, default_value=d, is_weighted=f["weighted"])
+        else:
+            dense[f["name"]] = dp.parse_dense_column(f["name"], c, default_value=d)
+    skeys = [f["name"] for f in feats if f["sparse"]]
+    parser = dp.DataParser(skeys, [f["name"] for f in feats if not f["sparse"] and not f["sequence"]],
+                           sequence_keys=[f["name"] for f in feats if f["sequence"] and f["sparse"]],
+                           sequence_mulval_keys=[f["name"] for f in feats if f["sequence"] and f["sparse"] and f["value_dim"] != 1])
+    kjt = parser.to_kjt(sparse)
+    mv = parser.to_mulval_lengths(sparse)
+    batch = Batch(
+        {BASE_DATA_GROUP: parser.to_keyed_tensor(dense)} if dense else {}, {BASE_DATA_GROUP: kjt},
+        {k: dp.parse_label_column(k, cols[k]) for k in case["labels"]},
+        {k: dp.parse_sample_weight_column(k, cols[k]) for k in case["sample_weights"]},
+        {BASE_DATA_GROUP: mv} if mv is not None else {}, dp.DataParser.to_sequence_dense(seq_dense))
+
+    # the KeyedJaggedTensor the reference builds (data_parser.py:576-585)
+    want = case["kjt"]
+    assert kjt.keys() == want["keys"] and kjt.stride() == want["stride"] and kjt.length_per_key() == want["length_per_key"]
+    _same(kjt.values(), want["values"], "kjt.values")
+    _same(kjt.lengths(), want["lengths"], "kjt.lengths")
+    if want["weights"] is None:
+        assert kjt.weights_or_none() is None
+    else:
+        _same(kjt.weights(), want["weights"], "kjt.weights")
+    if "mulval" in case:
+        assert mv.keys() == case["mulval"]["keys"]
+        _same(mv.values(), case["mulval"]["values"], "mulval.values (key_lengths)")
+        _same(mv.lengths(), case["mulval"]["lengths"], "mulval.lengths (seq_lengths)")
+    else:
+        assert mv is None
+    if "dense" in case:
+        kt = batch.dense_features[BASE_DATA_GROUP]
+        assert kt.keys() == case["dense"]["keys"] and kt.length_per_key() == case["dense"]["length_per_key"]
+        _same(kt.values(), case["dense"]["values"], "dense.values")
+    assert set(batch.sequence_dense_features) == set(case["seq_dense"])
+    for k, v in case["seq_dense"].items():
+        _same(batch.sequence_dense_features[k].values(), v["values"], k + ".values")
+        _same(batch.sequence_dense_features[k].lengths(), v["lengths"], k + ".lengths")
+    for k, v in case["batch_labels"].items():
+        _same(batch.labels[k], v, k)
+        assert str(batch.labels[k].dtype).replace("torch.", "") == v["dtype"]
+    for k, v in case["batch_sample_weights"].items():
+        _same(batch.sample_weights[k], v, k)
+
+    # the flat tensor dict (DataParser.parse output = Batch.to_dict(), datasets/utils.py:465-512)
+    flat = batch.to_dict()
+    ref = {k: v for k, v in case["flat"].items() if k != "batch_size"}
+    # once a data group carries weights, to_batch gives every key of it weights of 1.0
+    # (data_parser.py:566-574), so Batch.to_dict() -- unlike the parser's own dict -- lists them
+    extra = set(flat) - set(ref)
+    assert all(k.endswith(".weights") and bool((flat[k] == 1.0).all()) for k in extra) and (not extra or want["weights"] is not None), extra
+    assert set(ref) <= set(flat), sorted(set(ref) - set(flat))
+    for k, v in ref.items():
+        _same(flat[k], v, "flat " + k)
+
+
+def test_label_and_weight_column_types():
+    import pyarrow as pa
+
+    assert dp.parse_label_column("y", pa.array([1, 0], type=pa.int32())).dtype == torch.int64
+    assert dp.parse_label_column("y", pa.array([1.0, 0.0], type=pa.float64())).dtype == torch.float32
+    with pytest.raises(ValueError, match="label column"):
+        dp.parse_label_column("y", pa.array(["a", "b"]))
+    with pytest.raises(ValueError, match="should be float"):
+        dp.parse_sample_weight_column("w", pa.array([1, 2]))

@@ -214,6 +214,25 @@ def parse_dense_column(name: str, col, multival_sep: str = chr(3), default_value
     return DenseColumn(name, values.reshape(len(lengths), dim))
 
 
+def parse_label_column(name: str, col) -> torch.Tensor:
+    """Label column -> tensor (tzrec/datasets/data_parser.py:226-262): float -> float32, int -> int64
+    (list-typed labels of the generative models are outside this path)."""
+    col = _arrow(col)
+    if pa.types.is_floating(col.type):
+        return torch.from_numpy(np.array(col.cast(pa.float32(), safe=False).to_numpy(zero_copy_only=False)))
+    if pa.types.is_integer(col.type):
+        return torch.from_numpy(np.array(col.cast(pa.int64(), safe=False).to_numpy(zero_copy_only=False)))
+    raise ValueError(f"label column [{name}] only support int | float dtype now.")
+
+
+def parse_sample_weight_column(name: str, col) -> torch.Tensor:
+    """tzrec/datasets/data_parser.py:264-272: sample weights must be a float column."""
+    col = _arrow(col)
+    if pa.types.is_floating(col.type):
+        return torch.from_numpy(np.array(col.cast(pa.float32(), safe=False).to_numpy(zero_copy_only=False)))
+    raise ValueError(f"sample weight column [{name}] should be float dtype.")
+
+
 @dataclass
 class SequenceDenseColumn:
     name: str
