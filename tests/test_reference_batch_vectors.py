@@ -113,3 +113,24 @@ def test_label_and_weight_column_types():
         dp.parse_label_column("y", pa.array(["a", "b"]))
     with pytest.raises(ValueError, match="should be float"):
         dp.parse_sample_weight_column("w", pa.array([1, 2]))
+
+
+@pytest.mark.parametrize("case", [c for c in _G if not any(f["sequence"] for f in c["features"])], ids=lambda c: c["tag"])
+def test_oracle_kjt_assembly_matches_reference(case):
+    """pins oracle.parse_sparse_feature + oracle.to_kjt (what the kernel tests feed from)"""
+    from oracle import tzrec_oracle as orc
+
+    per = []
+    for f in case["features"]:
+        if f["sparse"]:
+            rows = case["columns"][f["name"]]["rows"]
+            per.append(orc.parse_sparse_feature(rows, f["default"], chr(3), f["weighted"]))
+    got = orc.to_kjt([f["name"] for f in case["features"] if f["sparse"]], [p[0] for p in per], [p[1] for p in per], [p[2] for p in per])
+    want = case["kjt"]
+    assert got["keys"] == want["keys"] and got["stride"] == want["stride"] and got["length_per_key"] == want["length_per_key"]
+    np.testing.assert_array_equal(got["values"], _arr(want["values"]))
+    np.testing.assert_array_equal(got["lengths"], _arr(want["lengths"]))
+    if want["weights"] is None:
+        assert got["weights"] is None
+    else:
+        np.testing.assert_array_equal(got["weights"], _arr(want["weights"]))
