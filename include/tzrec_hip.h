@@ -411,6 +411,39 @@ int tzr_quantize_rows_q8f16(const void* d_w, int w_dtype, int64_t w_stride, int6
 int tzr_dequantize_rows_q8f16(const uint8_t* d_rows, int64_t rows, int dim, float* d_out,
                               int64_t out_stride, void* stream);
 
+/* ---- delta-embedding tracker ---------------------------------------- */
+
+/* Which rows were looked up since the last dump.  Replaces the id store of tzrec's ModelDeltaTracker
+ * (tzrec/utils/delta_embedding_dump.py:352-641): torchrec DeltaStoreTrec.append per lookup (:478-513)
+ * and compact / torch.cat(...).unique() per dump (:565-609).  Here the touched set of a table is a
+ * bitmap in HBM, one bit per LOCAL row, uint32 words, (rows + 31) / 32 of them, bit r & 31 of word
+ * r >> 5; the caller owns and zero-initialises it. */
+typedef struct TzrDeltaSeg {
+  uint32_t* bitmap; /* bitmap of the table this lookup segment reads; NULL = segment not tracked */
+  int64_t rows;     /* local rows of that table: ids outside [0, rows) are counted, not marked   */
+  int32_t key;      /* key segment of the id array the lookup reads (see tzr_delta_mark)         */
+  int32_t reserved;
+} TzrDeltaSeg; /* 24 bytes */
+
+/* record_lookup (delta_embedding_dump.py:478-513): mark the ids of n_segs lookup segments.  Segment
+ * s covers ids [o(k), o(k+1)) with k = d_segs[s].key and o(k) = d_key_offsets[k * key_stride], or
+ * k * key_stride * uniform_len when d_key_offsets is NULL (a KJT: key_stride = B and the offsets
+ * array, or uniform bags; the owner side of the sharded exchange: key_stride = 1 and the received
+ * key starts).  *d_oob (nullable, caller-zeroed accumulator) += ids outside their table -- the
+ * condition the reference raises ValueError for at dump time (:1026-1035). */
+int tzr_delta_mark(const TzrDeltaSeg* d_segs, int n_segs, const int64_t* d_ids,
+                   const int64_t* d_key_offsets, int64_t key_stride, int64_t uniform_len,
+                   int64_t n_ids, int64_t* d_oob, void* stream);
+/* get_unique (:565-609): *d_total += number of marked rows (caller-zeroed accumulator). */
+size_t tzr_delta_collect_workspace(int64_t rows);
+int tzr_delta_count(const uint32_t* d_bitmap, int64_t rows, int64_t* d_total, void* ws,
+                    size_t ws_bytes, void* stream);
+/* ... and the marked rows themselves, ascending, as id_base + local row (the reference's
+ * ids.unique(sorted=True) + shard row_offset, :976,1036) into d_out_ids[0 : min(count, capacity)];
+ * clear != 0 zeroes the bitmap in the same pass (delete_on_read). */
+int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int clear,
+                      int64_t* d_out_ids, int64_t capacity, void* ws, size_t ws_bytes, void* stream);
+
 /* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
 int tzr_tune(const char* name, int value);
 

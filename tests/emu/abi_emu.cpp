@@ -1,3 +1,3 @@
 // Identity of the CPU lane-emulator build of the kernels (tests only).
 extern "C" const char* tzr_backend(void) { return "emu"; }
-extern "C" int tzr_abi_version(void) { return 3; }
+extern "C" int tzr_abi_version(void) { return 4; }

@@ -215,6 +215,7 @@ inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }

@@ -1,0 +1,310 @@
+"""Delta-embedding tracker + dump: the HIP bitmap tracker against the CPU
+restatement of the reference's id store (oracle/delta_oracle.py), bit-exact (integer work), and the
+dumper's cadence / parquet contract against the reference's rules
+(/root/reference/tzrec/utils/delta_embedding_dump.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import delta_oracle as dorc  # noqa: E402
+from torcheasyrec_amd import _lib  # noqa: E402
+from torcheasyrec_amd import delta_embedding_dump as dd  # noqa: E402
+from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig  # noqa: E402
+from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
+
+
+def _mark(dev, bitmaps, rows, seg_table, seg_key, ids, key_offsets, key_stride, uniform_len, oob):
+    segs = np.zeros(len(seg_table), dtype=_lib.DELTA_SEG_DT)
+    for i, (t, k) in enumerate(zip(seg_table, seg_key)):
+        segs[i]["key"] = k
+        if t >= 0:
+            segs[i]["bitmap"], segs[i]["rows"] = bitmaps[t].data_ptr(), rows[t]
+    d = _lib.upload_struct(segs, dev)
+    _lib.check(_lib.lib().tzr_delta_mark(_lib.ptr(d), len(segs), _lib.ptr(ids), _lib.ptr(key_offsets), key_stride, uniform_len,
+                                         ids.numel(), _lib.ptr(oob), _lib.stream_ptr(dev)), "tzr_delta_mark")
+
+
+def _collect(dev, bitmap, rows, id_base=0, clear=0, capacity=None):
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_delta_collect_workspace(rows), dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(L.tzr_delta_count(_lib.ptr(bitmap), rows, _lib.ptr(total), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "count")
+    n = int(total.item())
+    cap = n if capacity is None else capacity
+    out = torch.full((max(cap, 1),), -7, dtype=torch.int64, device=dev)
+    _lib.check(L.tzr_delta_collect(_lib.ptr(bitmap), rows, id_base, clear, _lib.ptr(out), cap, _lib.ptr(ws), ws.numel(),
+                                   _lib.stream_ptr(dev)), "collect")
+    return n, out[:cap].cpu().numpy()
+
+
+@pytest.mark.parametrize("rows", [[1, 31, 33, 1000], [300000, 64, 131072 + 5]])
+def test_bitmap_kernels_match_set_semantics(dev, rows):
+    """mark (KJT addressing: offsets with stride B) -> words == oracle bitmap; count / collect == np.unique;
+    ids outside the table are counted, never marked; clear zeroes exactly what was read."""
+    rng = np.random.default_rng(11)
+    T, B = len(rows), 37
+    # keys: one per table plus a second feature on table 0 and an untracked key
+    seg_table = list(range(T)) + [0, -1]
+    K = len(seg_table)
+    lens = rng.integers(0, 5, size=K * B).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    vals = np.zeros(off[-1], dtype=np.int64)
+    want_oob = 0
+    for k, t in enumerate(seg_table):
+        s, e = off[k * B], off[(k + 1) * B]
+        r = rows[t] if t >= 0 else 50
+        vals[s:e] = rng.integers(0, r, size=e - s)
+        if t >= 0 and e - s > 3:  # two ids outside the table, one negative
+            vals[s], vals[s + 1] = r, -1
+            want_oob += 2
+    bitmaps = [torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev) for r in rows]
+    oob = torch.zeros(1, dtype=torch.int64, device=dev)
+    _mark(dev, bitmaps, rows, seg_table, list(range(K)), torch.from_numpy(vals).to(dev), torch.from_numpy(off).to(dev), B, 0, oob)
+    assert int(oob.item()) == want_oob
+    for t in range(T):
+        ids_t = np.concatenate([vals[off[k * B]:off[(k + 1) * B]] for k, tt in enumerate(seg_table) if tt == t])
+        np.testing.assert_array_equal(bitmaps[t].cpu().numpy().view(np.uint32), dorc.bitmap_of(ids_t, rows[t]))
+        uniq = np.unique(ids_t[(ids_t >= 0) & (ids_t < rows[t])])
+        n, got = _collect(dev, bitmaps[t], rows[t], id_base=1000 * t)
+        assert n == len(uniq)
+        np.testing.assert_array_equal(got, uniq + 1000 * t)
+        if len(uniq) > 2:  # short output buffer: the first `capacity` ids, nothing past it
+            n2, got2 = _collect(dev, bitmaps[t], rows[t], capacity=2)
+            assert n2 == len(uniq)
+            np.testing.assert_array_equal(got2, uniq[:2])
+        _collect(dev, bitmaps[t], rows[t], clear=1)
+        assert int(bitmaps[t].abs().sum()) == 0
+
+
+def test_bitmap_mark_uniform_and_owner_addressing(dev):
+    """the two other addressings of tzr_delta_mark: uniform bags without an offsets array, and the
+    owner side of the exchange (key_stride 1 over the received key starts); marking is idempotent."""
+    rng = np.random.default_rng(3)
+    rows, B = [500, 70], 64
+    vals = np.concatenate([rng.integers(0, rows[0], B), rng.integers(0, rows[1], B)]).astype(np.int64)
+    bm = [torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev) for r in rows]
+    for _ in range(2):
+        _mark(dev, bm, rows, [0, 1], [0, 1], torch.from_numpy(vals).to(dev), None, B, 1, None)
+    for t in range(2):
+        np.testing.assert_array_equal(bm[t].cpu().numpy().view(np.uint32), dorc.bitmap_of(vals[t * B:(t + 1) * B], rows[t]))
+    # owner side: 2 sources x 2 keys, key (s, f) -> table f
+    cnt = np.array([5, 0, 9, 4])
+    ks = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    ids = np.concatenate([rng.integers(0, rows[k % 2], c) for k, c in enumerate(cnt)]).astype(np.int64)
+    bm = [torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev) for r in rows]
+    _mark(dev, bm, rows, [0, 1, 0, 1], [0, 1, 2, 3], torch.from_numpy(ids).to(dev), torch.from_numpy(ks).to(dev), 1, 0, None)
+    for t in range(2):
+        mine = np.concatenate([ids[ks[k]:ks[k + 1]] for k in range(4) if k % 2 == t])
+        np.testing.assert_array_equal(bm[t].cpu().numpy().view(np.uint32), dorc.bitmap_of(mine, rows[t]))
+
+
+def test_abi_argument_checks(dev):
+    L = _lib.lib()
+    one = torch.zeros(4, dtype=torch.int64, device=dev)
+    assert L.tzr_delta_mark(None, 1, _lib.ptr(one), None, 1, 1, 4, None, None) == -1  # no segments array
+    assert L.tzr_delta_mark(_lib.ptr(one), 1, _lib.ptr(one), None, 1, 0, 4, None, None) == -1  # no offsets, no uniform length
+    assert L.tzr_delta_mark(_lib.ptr(one), 0, None, None, 1, 1, 0, None, None) == 0
+    ws = _lib.workspace(L.tzr_delta_collect_workspace(100), dev)
+    assert L.tzr_delta_count(_lib.ptr(one), 100, None, _lib.ptr(ws), ws.numel(), None) == -1
+    assert L.tzr_delta_count(_lib.ptr(one), 100, _lib.ptr(one), _lib.ptr(ws), 8, None) == -3  # workspace too small
+    assert L.tzr_delta_collect(_lib.ptr(one), 100, 0, 0, None, 5, _lib.ptr(ws), ws.numel(), None) == -1
+    assert L.tzr_delta_collect(_lib.ptr(one), 0, 0, 0, None, 0, None, 0, None) == 0
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, dev, dtype="FP32"):
+        super().__init__()
+        self.rows = [97, 4000, 5]
+        tables = [EmbeddingBagConfig(f"t{i}", 8, r, [f"f{i}"] if i else ["f0", "f0b"], "sum", data_type=dtype)
+                  for i, r in enumerate(self.rows)]
+        self.ebc = EmbeddingBagCollection(tables, device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+
+    def keys(self):
+        return ["f0", "f1", "f2", "f0b"]
+
+    def batch(self, seed, B=16):
+        rng = np.random.default_rng(seed)
+        tab = [0, 1, 2, 0]
+        lens = rng.integers(0, 3, size=4 * B).astype(np.int32)
+        vals = np.concatenate([rng.integers(0, self.rows[tab[k]], int(lens[k * B:(k + 1) * B].sum())) for k in range(4)]).astype(np.int64)
+        return KeyedJaggedTensor(self.keys(), torch.from_numpy(vals), torch.from_numpy(lens)), vals, lens, B
+
+    def step(self, kjt):
+        out = self.ebc(kjt.to(self.ebc.device)).values()
+        out.sum().backward()
+
+
+_F2FQN = {"f0": "ebc.embedding_bags.t0", "f0b": "ebc.embedding_bags.t0", "f1": "ebc.embedding_bags.t1", "f2": "ebc.embedding_bags.t2"}
+
+
+def test_tracker_equals_reference_store(dev):
+    """ModelDeltaTracker over training steps == cat + unique of the reference's store: FQNs, ids,
+    delete_on_read, pause_tracking, clear, two independent consumers."""
+    m = _Model(dev)
+    tr = dd.ModelDeltaTracker(m, consumers=["a", "b"])
+    assert tr.fqn_to_feature_names == {"ebc.embedding_bags.t0": ["f0", "f0b"], "ebc.embedding_bags.t1": ["f1"],
+                                       "ebc.embedding_bags.t2": ["f2"]}
+    store_a, store_b = dorc.DeltaStore(), dorc.DeltaStore()
+    for s in range(3):
+        kjt, vals, lens, B = m.batch(s)
+        m.step(kjt)
+        for st in (store_a, store_b):
+            dorc.record_kjt(st, _F2FQN, m.keys(), vals, lens, B)
+        tr.step()
+    with tr.pause_tracking():  # an eval pass leaves no trace
+        m.step(m.batch(99)[0])
+    got = {k: v.cpu().numpy() for k, v in tr.get_unique_ids("a").items()}
+    want = store_a.get_unique()
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k])
+    assert tr.get_unique_ids("a") == {}  # read once
+    kjt, vals, lens, B = m.batch(7)
+    m.step(kjt)
+    for st in (store_a, store_b):
+        dorc.record_kjt(st, _F2FQN, m.keys(), vals, lens, B)
+    for name, st in (("a", store_a), ("b", store_b)):  # b still holds the whole history
+        got, want = {k: v.cpu().numpy() for k, v in tr.get_unique_ids(name).items()}, st.get_unique()
+        assert set(got) == set(want)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k])
+    m.step(m.batch(8)[0])
+    tr.clear()
+    assert tr.get_unique_ids("a") == {} and tr.get_unique_ids("b") == {}
+    # record_lookup with the reference's signature
+    kjt, vals, lens, B = m.batch(9)
+    tr.record_lookup(kjt.to(dev), None, emb_module=m.ebc)
+    st = dorc.DeltaStore()
+    dorc.record_kjt(st, _F2FQN, m.keys(), vals, lens, B)
+    got, want = tr.get_unique_ids("a"), st.get_unique()
+    for k in want:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k])
+    with pytest.raises(ValueError, match="Embedding module is required"):
+        tr.record_lookup(kjt.to(dev), None)
+
+
+def test_out_of_range_ids_raise_at_read(dev):
+    m = _Model(dev)
+    tr = dd.ModelDeltaTracker(m)
+    bad = KeyedJaggedTensor(["f2"], torch.tensor([1, 5, 2], dtype=torch.int64), torch.tensor([1, 1, 1], dtype=torch.int32)).to(dev)
+    tr.record_lookup(bad, None, emb_module=m.ebc)
+    with pytest.raises(ValueError, match="outside the local row range"):
+        tr.get_unique()
+
+
+def _read(path):
+    import pyarrow.parquet as pq
+
+    return pq.read_table(path)
+
+
+@pytest.mark.parametrize("dtype", ["FP32", "FP16"])
+def test_dumper_rows_cadence_and_schema(dev, tmp_path, dtype):
+    """interval 2: steps 2 and 4 are dumped by maybe_dump, the trailing step 5 by final_dump, a final
+    step on a boundary is skipped; every file holds exactly the touched ids (ascending per table) with
+    the table's CURRENT rows, in the reference's schema and file naming."""
+    import pyarrow as pa
+
+    m = _Model(dev, dtype)
+    cfg = dd.DeltaEmbeddingDumpConfig(dump_interval_steps=2)
+    dumper = dd.DeltaEmbeddingDumper(m, cfg, str(tmp_path), dev)
+    dumper.start()
+    store = dorc.DeltaStore()
+    seen = {}
+    for step in range(1, 6):
+        kjt, vals, lens, B = m.batch(step)
+        m.step(kjt)
+        dorc.record_kjt(store, _F2FQN, m.keys(), vals, lens, B)
+        if step % 2 == 0:
+            seen[step] = (store.get_unique(), {n: w.detach().float().cpu().numpy().copy() for n, w in m.ebc.table_weights().items()})
+        dumper.maybe_dump(step)
+    seen[5] = (store.get_unique(), {n: w.detach().float().cpu().numpy().copy() for n, w in m.ebc.table_weights().items()})
+    assert dumper.final_dump(4) is None  # boundary: already written
+    path5 = dumper.final_dump(5)
+    out_dir = os.path.join(str(tmp_path), "delta_embedding_dump")
+    assert path5 == os.path.join(out_dir, "delta_embedding_step_5.parquet")
+    assert sorted(os.listdir(out_dir)) == [f"delta_embedding_step_{s}.parquet" for s in (2, 4, 5)]
+    want_schema = pa.schema([("global_step", pa.int64()), ("rank", pa.int32()), ("world_size", pa.int32()),
+                             ("feature_name", pa.string()), ("table_fqn", pa.string()), ("key_id", pa.int64()),
+                             ("embedding", pa.list_(pa.float32())), ("source", pa.string())])
+    for step, (ids_by_fqn, weights) in seen.items():
+        t = _read(os.path.join(out_dir, f"delta_embedding_step_{step}.parquet"))
+        assert t.schema.equals(want_schema)
+        assert set(t["global_step"].to_pylist()) == {step} and set(t["rank"].to_pylist()) == {0}
+        assert set(t["world_size"].to_pylist()) == {1} and set(t["source"].to_pylist()) == {"model_delta_tracker"}
+        fq = np.array(t["table_fqn"].to_pylist())
+        assert set(fq) == set(ids_by_fqn)
+        for fqn, ids in ids_by_fqn.items():
+            sel = fq == fqn
+            rows_want, keys_want = dorc.dump_rows(ids, weights[fqn.split(".")[-1]])
+            np.testing.assert_array_equal(np.array(t["key_id"].to_pylist())[sel], keys_want)
+            np.testing.assert_array_equal(np.array(t["embedding"].to_pylist(), dtype=np.float32)[sel], rows_want)  # bit-exact copy
+            names = set(np.array(t["feature_name"].to_pylist())[sel])
+            assert names == {"f0,f0b" if fqn.endswith("t0") else "f" + fqn[-1]}
+    assert dumper.final_dump(0) is None
+    with pytest.raises(ValueError, match="global_step must be > 0"):
+        dumper.dump(0)
+    assert dumper.dump(6) is None  # nothing touched since step 5, one process: no file
+
+
+def test_dumper_int8_rows_are_the_export_encoding(dev, tmp_path):
+    """quant_type INT8: the embedding column holds QUint8RowwiseF16 bytes of the touched rows -- the
+    encoder that tests/test_export_quant.py pins to the reference's outputs."""
+    import pyarrow as pa
+    from torcheasyrec_amd.export import distributed_quantize_embeddings
+
+    m = _Model(dev)
+    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=1, quant_type=dd.QUANT_INT8,
+                                                                    output_dir=str(tmp_path / "o"), file_prefix="d"), "unused", dev)
+    kjt, vals, lens, B = m.batch(1)
+    m.step(kjt)
+    dumper.maybe_dump(1)
+    t = _read(str(tmp_path / "o" / "d_step_1.parquet"))
+    assert t.schema.field("embedding").type == pa.list_(pa.uint8())
+    fq = np.array(t["table_fqn"].to_pylist())
+    emb = np.array(t["embedding"].to_pylist(), dtype=np.uint8)
+    assert emb.shape[1] == 8 + 4
+    for name, w in m.ebc.table_weights().items():
+        sel = fq == f"ebc.embedding_bags.{name}"
+        ids = torch.from_numpy(np.array(t["key_id"].to_pylist())[sel]).to(dev)
+        want = distributed_quantize_embeddings(w.detach()[ids].float().contiguous(), 8, name, "QUint8RowwiseF16")
+        np.testing.assert_array_equal(emb[sel], want.cpu().numpy())
+
+
+def test_config_validation(dev):
+    """reference :128-155"""
+    v = dd.validate_delta_embedding_dump_config
+    v(None, dev)
+    with pytest.raises(ValueError, match="only one of"):
+        v(dd.DeltaEmbeddingDumpConfig(dump_interval_steps=5, dump_interval_minutes=1), dev)
+    with pytest.raises(ValueError, match="dump_interval_minutes must be > 0"):
+        v(dd.DeltaEmbeddingDumpConfig(dump_interval_minutes=0), dev)
+    with pytest.raises(ValueError, match="dump_interval_steps must be > 0"):
+        v(dd.DeltaEmbeddingDumpConfig(dump_interval_steps=0), dev)
+    assert dd.DeltaEmbeddingDumpConfig().interval_steps == 1000
+    from torcheasyrec_amd.config import parse_text_proto as parse_text
+
+    msg = parse_text('delta_embedding_dump_config { dump_interval_steps: 50 file_prefix: "x" quant_type: DELTA_EMBEDDING_QUANT_INT8 }')
+    c = dd.delta_embedding_dump_config_from_msg(msg.one("delta_embedding_dump_config"))
+    assert (c.dump_interval_steps, c.file_prefix, c.quant_type, c.dump_interval_minutes) == (50, "x", dd.QUANT_INT8, None)
+
+
+def test_timed_cadence(dev, tmp_path, monkeypatch):
+    """dump_interval_minutes: fixed-rate deadlines, missed ones skipped (reference :812-838)."""
+    m = _Model(dev)
+    now = [100.0]
+    monkeypatch.setattr(dd.time, "monotonic", lambda: now[0])
+    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_minutes=1), str(tmp_path), dev)
+    dumper.start()
+    m.step(m.batch(1)[0])
+    dumper.maybe_dump(1)  # 0 s elapsed
+    now[0] += 200.0  # three deadlines passed: one dump, next deadline in the future
+    m.step(m.batch(2)[0])
+    dumper.maybe_dump(2)
+    assert dumper._next_dump_time == 100.0 + 4 * 60.0 and dumper._last_dump_step == 2
+    assert dumper.final_dump(2) is None  # the timed dump landed on the last step
+    assert os.listdir(os.path.join(str(tmp_path), "delta_embedding_dump")) == ["delta_embedding_step_2.parquet"]

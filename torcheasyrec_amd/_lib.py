@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 3  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 4  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -72,6 +72,9 @@ class TzrZchModule(C.Structure):
     _fields_ = [("keys", C.c_uint64), ("rows", C.c_uint64), ("counts", C.c_uint64), ("last_iter", C.c_uint64),
                 ("capacity", C.c_int64), ("zch_size", C.c_int64), ("reserved", C.c_int64 * 2)]
 
+
+DELTA_SEG_DT = np.dtype([("bitmap", "<u8"), ("rows", "<i8"), ("key", "<i4"), ("reserved", "<i4")])
+assert DELTA_SEG_DT.itemsize == 24
 
 ZCH_EMPTY = (1 << 63) - 1
 
@@ -134,6 +137,10 @@ _SIGNATURES = {
     "tzr_dense_adam": (_i32, [_vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "tzr_zch_remap": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "tzr_zch_build": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "tzr_delta_mark": (_i32, [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "tzr_delta_collect_workspace": (_sz, [_i64]),
+    "tzr_delta_count": (_i32, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_delta_collect": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp]),
     "tzr_fm_fwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp]),
     "tzr_fm_bwd": (_i32, [_vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),
 }

@@ -250,6 +250,8 @@ class EmbeddingBagCollection(nn.Module):
         self._hook = torch.zeros(0, requires_grad=True, device=device)
         self._timers = None  # bench.py: object with .start(name) -> event recorded after the launch
         self._side_stream = None
+        self._lookup_trackers: list = []  # register_post_lookup_tracker_fn
+        self._track_segs: Dict[Tuple[str, ...], tuple] = {}
         self.async_plan = device.type == "cuda"  # overlap the backward index plan with the forward
 
     # -- storage ---------------------------------------------------------------------------
@@ -526,7 +528,28 @@ class EmbeddingBagCollection(nn.Module):
         _lib.check(rc, "tzr_pooled_bwd_apply")
         kjt._tzr_plan = None  # type: ignore[attr-defined]
 
+    def register_post_lookup_tracker_fn(self, fn) -> None:
+        """torchrec's hook of the same name, which the reference's ModelDeltaTracker registers on every
+        sharded collection (/root/reference/tzrec/utils/delta_embedding_dump.py:423-427).  After each
+        lookup `fn(self, segs, ids, key_offsets, key_stride, uniform_len)` is called on the lookup's
+        stream: lookup segment i reads table `segs[i][0]` with the ids of key segment `segs[i][1]`
+        (addressing as in `tzr_delta_mark`)."""
+        self._lookup_trackers.append(fn)
+
+    def _notify_trackers(self, kjt: KeyedJaggedTensor) -> None:
+        keys = tuple(kjt.keys())
+        segs = self._track_segs.get(keys)
+        if segs is None:
+            index = {k: i for i, k in enumerate(keys)}
+            segs = tuple((self._configs[lk.table].name, index[lk.key]) for lk in self._lookups if lk.key in index)
+            self._track_segs[keys] = segs
+        uniform, offsets = self._kjt_args(kjt)
+        for fn in self._lookup_trackers:
+            fn(self, segs, kjt.values(), offsets, kjt.stride(), 1 if uniform else 0)
+
     def _run(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
+        if self._lookup_trackers:
+            self._notify_trackers(kjt)
         if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
             if self.async_plan and getattr(kjt, "_tzr_plan", None) is None:
                 self.plan_backward_async(kjt, dst_names)

@@ -136,6 +136,11 @@ class EmbeddingCollection(nn.Module):
         self.fused_optimizer = self._store.fused_optimizer
         self._meta_cache: Dict[tuple, dict] = {}
         self._hook = torch.zeros(0, requires_grad=True, device=self._device)
+        self._lookup_trackers: list = []
+
+    def register_post_lookup_tracker_fn(self, fn) -> None:
+        """See EmbeddingBagCollection.register_post_lookup_tracker_fn."""
+        self._lookup_trackers.append(fn)
 
     def table_weights(self):
         return self._store.table_weights()
@@ -214,6 +219,11 @@ class EmbeddingCollection(nn.Module):
                                           stream), "tzr_pooled_bwd_apply")
 
     def forward(self, features: KeyedJaggedTensor) -> Dict[str, JaggedTensor]:
+        if self._lookup_trackers:
+            table_of = {f: c.name for c in self._store.embedding_bag_configs() for f in c.feature_names}
+            segs = tuple((table_of[k], i) for i, k in enumerate(features.keys()))
+            for fn in self._lookup_trackers:
+                fn(self, segs, features.values(), features.offsets(), features.stride(), 0)
         if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
             rows = _UnpooledLookupFn.apply(self, features, self._hook)
         else:

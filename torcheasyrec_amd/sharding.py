@@ -228,6 +228,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
         # and mapped to rows by their owner (`_owner_remap(st) -> row ids of the received lookups`)
         self._hash_routed = set()
         self._owner_remap = None
+        self._lookup_trackers: list = []  # register_post_lookup_tracker_fn
+
+    def register_post_lookup_tracker_fn(self, fn) -> None:
+        """See EmbeddingBagCollection.register_post_lookup_tracker_fn.  A sharded collection reports what
+        torchrec's post-lookup tracker sees: the LOCAL rows each rank serves as an owner (the ids
+        received in the exchange, after the owner's zch remap) and its own lookups of replicated tables."""
+        self._lookup_trackers.append(fn)
 
     # -- placement -------------------------------------------------------------------------------
     def shard_of(self, name: str) -> Tuple[int, int]:
@@ -477,6 +484,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
             # rows back to the requesters (bucketized order) -- in flight while the replicas are read
             rows_in, d_pt, work = self.exchange_rows(st)
         if "dp_n" in rm:  # replicated tables: purely local, same destination buffers (other columns)
+            if self._lookup_trackers:
+                if "dp_track_segs" not in rm:
+                    index = {k: i for i, k in enumerate(kjt.keys())}
+                    dp = {c.name for c in self._dp}
+                    rm["dp_track_segs"] = tuple((self._global[t].name, index[k]) for k, t, _ in self._lookups if self._global[t].name in dp)
+                for fn in self._lookup_trackers:
+                    fn(self, rm["dp_track_segs"], kjt.values(), None if uniform else kjt.offsets(), B, 1 if uniform else 0)
             _lib.check(L.tzr_pooled_fwd_ex(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
                                            _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()),
                                            _lib.ptr(None if uniform else kjt.offsets()), _lib.ptr(kjt.weights_or_none()),
@@ -499,6 +513,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
         F, N = st["rm"]["rw_n"], st["N_rw"]
         # ZCH tables: raw id -> row through the owner's map first
         st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
+        if self._lookup_trackers and n_recv > 0:
+            if "track_segs" not in om:
+                names = [c.name for c in self._rw]
+                om["track_segs"] = tuple((names[t], k) for k, t in enumerate(np.tile(st["rm"]["rw_key_table"], self.W).tolist()))
+            for fn in self._lookup_trackers:
+                fn(self, om["track_segs"], st["owner_ids"], st["key_start"], 1, 0)
         rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
         _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
                                      om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(rows_out), D, D,
