@@ -46,6 +46,13 @@ def main(path):
     # unless by_epoch (main.py:542-544)
     schedulers = [create_scheduler(model.fused_optimizer, spec.sparse_optimizer_block), create_scheduler(opt, spec.dense_optimizer_block)]
     pipe = TrainPipeline(model, opt, dev, model.loss)
+    # train_config.delta_embedding_dump_config: the call sites of tzrec/main.py:805-811,900,547,611,928
+    dumper = None
+    if spec.delta_embedding_dump_config is not None:
+        from torcheasyrec_amd.delta_embedding_dump import DeltaEmbeddingDumper
+
+        dumper = DeltaEmbeddingDumper(model, spec.delta_embedding_dump_config, os.environ.get("MODEL_DIR", "experiments/model"), dev)
+        dumper.start()
     it = iter(synthetic_batches(spec, 20 * (spec.batch_size or 1024), spec.batch_size or 1024))
     step = 0
     while True:
@@ -57,8 +64,13 @@ def main(path):
         for sch in schedulers:
             if not sch.by_epoch:
                 sch.step()
+        if dumper is not None:
+            dumper.maybe_dump(step)
         if step % 5 == 0:
             print(f"step {step}: " + ", ".join(f"{k}={float(v.detach()):.4f}" for k, v in losses.items()))
+    if dumper is not None:
+        print("delta embedding dump:", dumper.final_dump(step))
+        dumper.close()
     print("tables:", {n: tuple(w.shape) for n, w in model.embedding_group.ebc.table_weights().items()})
 
 

@@ -149,6 +149,8 @@ class PipelineSpec:
     # the raw optimizer blocks (learning-rate schedules: lr_scheduler.create_scheduler)
     sparse_optimizer_block: Optional[Msg] = None
     dense_optimizer_block: Optional[Msg] = None
+    # train_config.delta_embedding_dump_config (train.proto:86-111) -> delta_embedding_dump.DeltaEmbeddingDumpConfig
+    delta_embedding_dump_config: Optional[object] = None
 
 
 def _num_embeddings(f: Msg, name: str) -> int:
@@ -240,6 +242,10 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
         for _, v in tc.one("dense_optimizer").items():
             if isinstance(v[-1], Msg) and v[-1].has("lr"):
                 spec.dense_lr = float(v[-1].one("lr"))
+    if tc.has("delta_embedding_dump_config"):  # enable_delta_embedding_dump, tzrec/main.py:691
+        from .delta_embedding_dump import delta_embedding_dump_config_from_msg
+
+        spec.delta_embedding_dump_config = delta_embedding_dump_config_from_msg(tc.one("delta_embedding_dump_config"))
     dc = cfg.one("data_config", Msg())
     spec.batch_size = int(dc.one("batch_size", 0))
     spec.label_fields = list(dc.many("label_fields"))
