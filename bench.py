@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--async-plan", action="store_true", help="run the backward index plan on a side stream")
     ap.add_argument("--no-tunable-gemm", action="store_true",
                     help="leave the MLP GEMMs on PyTorch's default hipBLASLt heuristics")
+    ap.add_argument("--delta-tracker", action="store_true",
+                    help="experiment: record every lookup in the delta-embedding tracker (tzr_delta_mark inside the step); off by default")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to tzr_tune")
     return ap.parse_args()
 
@@ -256,6 +258,11 @@ def main():
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                             row_layout=args.row_layout, replicate_at_world1=args.replicate_small)
         parallelism = model.describe()
+    delta_tracker = None
+    if args.delta_tracker:  # what train_config.delta_embedding_dump_config adds to a step (never part of the default line)
+        from torcheasyrec_amd.delta_embedding_dump import ModelDeltaTracker
+
+        delta_tracker = ModelDeltaTracker(model)
     use_graph = not sharded and not args.no_graph
     # capturable: the dense Adam step lives inside the captured hipGraph
     if args.torch_adam:
@@ -422,6 +429,7 @@ def main():
                    "row_layout": args.row_layout, "rows_cap": args.rows_cap or None},
         "final_loss": final_loss,
         "secondary": secondary,
+        **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if graphs is not None else
                    ("pipelined: input dist one batch ahead + hipGraph dense segment" if train_step is not None else "eager")),
     }

@@ -143,8 +143,9 @@ def test_plan_respects_hbm_and_constraints():
     assert plan["small"]["sharding_type"] == "table_wise" and len(plan["small"]["ranks"]) == 1
     with pytest.raises(PlannerError):
         plan_tables(tabs, Topology(2, hbm_cap=40 * GB), batch_size=8192)
-    with pytest.raises(PlannerError):
-        plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["column_wise"]})
+    with pytest.raises(PlannerError):  # torchrec types this runtime cannot execute (feature.proto:8)
+        plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["grid_shard"]})
+    assert plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["column_wise"]})["small"]["sharding_type"] == "column_wise"
 
 
 def _drive(proposer, space, topo):
@@ -211,3 +212,25 @@ def test_dp_with_prune_shards_the_table_no_single_device_holds():
     _, plan, n = _drive(DynamicProgrammingProposer(), space, topo)
     assert plan is not None and n >= 2
     assert plan["table_3"].sharding_type == "row_wise"
+
+
+def test_column_wise_is_enumerated_only_on_request():
+    """column_wise (feature.proto:8) is executable (sharding.MixedShardedEmbeddingBagCollection) but costs
+    one exchange lane per column shard, so the enumerator offers it only when a constraint names it."""
+    from torcheasyrec_amd.planner import EmbeddingEnumerator, TableSpec, Topology, plan_tables
+
+    top = Topology(8)
+    t = TableSpec("wide", 1_000_000, 64, ["w"])
+    kinds = {o.sharding_type for o in EmbeddingEnumerator(top, 1024).enumerate([t])}
+    assert kinds == {"data_parallel", "table_wise", "row_wise"}
+    (o,) = EmbeddingEnumerator(top, 1024, {"wide": ["column_wise"]}).enumerate([t])
+    assert o.sharding_type == "column_wise" and len(o.shards) == 8  # 64 / 8 = 8 columns per shard (a multiple of 4)
+    assert [s.size for s in o.shards] == [(1_000_000, 8)] * 8 and [s.offset for s in o.shards] == [(0, 8 * j) for j in range(8)]
+    # weights + elementwise Adagrad state of one column shard, plus its exchange buffers
+    assert all(s.storage.hbm >= 1_000_000 * 8 * 4 * 2 for s in o.shards)
+    assert all(s.perf >= 3 * top.collective_latency for s in o.shards)  # every shard pays its own three collectives
+    (o12,) = EmbeddingEnumerator(Topology(8), 1024, {"t": ["column_wise"]}).enumerate([TableSpec("t", 100, 12, ["f"])])
+    assert [s.size[1] for s in o12.shards] == [4, 4, 4]  # 12 columns: three shards of width 4
+    plan = plan_tables([t, TableSpec("small", 50, 16, ["s"])], top, 1024, constraints={"wide": ["column_wise"]})
+    assert plan["wide"]["sharding_type"] == "column_wise" and plan["wide"]["shard_dim"] == 8 and len(plan["wide"]["ranks"]) == 8
+    assert sorted(plan["wide"]["ranks"]) == list(range(8))  # equal shards spread over the least-loaded ranks

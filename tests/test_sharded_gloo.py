@@ -613,7 +613,142 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,labels", [("din_mini.config", ["clk"])])
+@pytest.mark.parametrize("cfg,labels", [("din_mini.config", ["clk"]), ("deepfm_mini.config", ["label"])])
 def test_config_model_over_a_process_group(emu_path, cfg, labels):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels), nprocs=2, join=True)
+
+
+def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
+    """MixedShardedEmbeddingBagCollection: wide (dim 4) + deep (dim 16) tables fed by the SAME features
+    (DeepFM), a column-wise table (two dim-8 column shards on different ranks) and a replicated one must
+    reproduce the unsharded collection on the global batch: outputs (bit-exact for one id per bag) and
+    every table shard after the fused Adagrad step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sharding import MixedShardedEmbeddingBagCollection
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+
+    def seeded(t):
+        def f(w):
+            g = torch.Generator().manual_seed(100 + t)
+            w.copy_((torch.rand(w.shape, generator=g) - 0.5) * 0.2)
+        return f
+
+    spec = [("wide_a", 4, 50, ["a"]), ("wide_b", 4, 301, ["b"]), ("deep_a", 16, 50, ["a"]), ("deep_b", 16, 301, ["b"]),
+            ("cw_c", 16, 120, ["c"]), ("tiny", 16, 7, ["d"])]
+    cfgs = lambda: [EmbeddingBagConfig(n, d, r, f, init_fn=seeded(t)) for t, (n, d, r, f) in enumerate(spec)]  # noqa: E731
+    groups = {"wide": ["a@wide_a", "b@wide_b"], "deep": ["a@deep_a", "b@deep_b", "c", "d"]}
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+    if planner:  # the same placement kinds, chosen by the planner under per-table constraints
+        from torcheasyrec_amd.planner import TableSpec, Topology, plan_tables
+
+        cons = {"cw_c": ["column_wise"], "deep_a": ["table_wise"], "tiny": ["data_parallel"], "wide_a": ["row_wise"],
+                "wide_b": ["row_wise"], "deep_b": ["row_wise"]}
+        pl = plan_tables([TableSpec(n, r, d, f) for n, d, r, f in spec], Topology(world), 24, constraints=cons)
+        assert pl["cw_c"]["sharding_type"] == "column_wise" and pl["cw_c"]["shard_dim"] == 8 and len(pl["cw_c"]["ranks"]) == 2
+        sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, plan=pl)
+    else:
+        sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, dp_max_rows=10,
+                                                constraints={"cw_c": "column_wise", "deep_a": "table_wise"})
+    plan = sh.sharding_plan()
+    assert set(sh.plan()) == {"wide_a", "wide_b", "deep_a", "deep_b", "cw_c@cw0", "cw_c@cw1", "tiny"}
+    assert plan["cw_c"]["sharding_type"] == "column_wise" and plan["cw_c"]["shard_dim"] == 8
+    assert planner or sorted(plan["cw_c"]["ranks"]) == [0, 1]  # the heuristic puts the two column shards on different ranks
+    assert plan["tiny"]["sharding_type"] == "data_parallel" and plan["deep_a"]["sharding_type"] == "table_wise"
+    assert plan["wide_b"]["sharding_type"] == "row_wise" and len(sh.lanes) == 4  # dims 4, 16, and one dim-8 lane per column shard of feature c
+    ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups)
+    keys, rows = ["a", "b", "c", "d"], [50, 301, 120, 7]
+    rng = np.random.default_rng(1)
+    Bg, Bl = 24, 12
+    if jagged:
+        lens = rng.integers(0, 4, size=(4, Bg)).astype(np.int32)
+    else:
+        lens = np.ones((4, Bg), dtype=np.int32)
+    ids = [[rng.integers(0, rows[f], size=int(lens[f, b])).astype(np.int64) for b in range(Bg)] for f in range(4)]
+
+    def kjt_of(samples):
+        vals = np.concatenate([ids[f][b] for f in range(4) for b in samples] + [np.zeros(0, np.int64)])
+        ln = np.concatenate([lens[f, list(samples)] for f in range(4)])
+        return KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(ln), uniform_length=None if jagged else 1)
+
+    mine, full = kjt_of(range(rank * Bl, (rank + 1) * Bl)), kjt_of(range(Bg))
+    out, out_ref = sh.forward_grouped(mine), ref.forward_grouped(full)
+    for g in groups:
+        got, want = out[g].detach(), out_ref[g].detach()[rank * Bl:(rank + 1) * Bl]
+        assert got.shape == want.shape == (Bl, 8 if g == "wide" else 64)
+        if jagged:
+            torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7, msg=g)
+        else:
+            assert torch.equal(got, want), g
+    with torch.no_grad():  # self.ebc(kjt): same block names and order as the unsharded collection
+        kt, kt_ref = sh(mine), ref(full)
+    assert kt.keys() == kt_ref.keys() == ["a@wide_a", "b@wide_b", "a@deep_a", "b@deep_b", "c", "d"]
+    torch.testing.assert_close(kt.values(), kt_ref.values()[rank * Bl:(rank + 1) * Bl], rtol=1e-6, atol=1e-7)
+    gw = torch.randn(Bg, 8, generator=torch.Generator().manual_seed(9))
+    gd = torch.randn(Bg, 64, generator=torch.Generator().manual_seed(10))
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    ((out["wide"] * gw[sl]).sum() + (out["deep"] * gd[sl]).sum()).backward()
+    ((out_ref["wide"] * gw).sum() + (out_ref["deep"] * gd).sum()).backward()
+    w_ref = {n: w.detach() for n, w in ref.table_weights().items()}
+    w = sh.table_weights()
+    for name, d, r, _ in spec:
+        if name == "cw_c":
+            for j, shard in enumerate(sh.column_shards(name)):
+                lo, n = sh.shard_of(shard)
+                assert n in (0, r)  # a column shard is a whole table on one rank
+                torch.testing.assert_close(w[shard].detach()[:n], w_ref[name][lo:lo + n, j * 8:(j + 1) * 8], rtol=1e-5, atol=1e-7, msg=shard)
+        else:
+            lo, n = sh.shard_of(name)
+            torch.testing.assert_close(w[name].detach()[:n], w_ref[name][lo:lo + n], rtol=1e-5, atol=1e-7, msg=name)
+    fresh = torch.empty(120, 16)
+    seeded(4)(fresh)
+    assert not torch.equal(w_ref["cw_c"], fresh)  # the step moved the table
+    if not jagged and not planner:
+        # checkpoint: tables are persisted as the runtime holds them (column shards `cw_c@cw<j>`) and come
+        # back under a different placement of the other tables
+        from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
+
+        class Holder(torch.nn.Module):
+            def __init__(self, ebc):
+                super().__init__()
+                self.ebc = ebc
+
+        ck = os.path.join(os.path.dirname(init_file), "ckpt")
+        save_checkpoint(ck, Holder(sh))
+        assert read_plan(ck)["ebc"]["cw_c@cw1"]["sharding_type"] == "table_wise"
+        other = MixedShardedEmbeddingBagCollection([EmbeddingBagConfig(n, d, r, f) for n, d, r, f in spec], device=dev, optimizer=opt,
+                                                   groups=groups, dp_max_rows=0, constraints={"cw_c": "column_wise", "wide_b": "table_wise"})
+        restore_checkpoint(ck, Holder(other))
+
+        def full(m, what):
+            out = {}
+            for cfg in m._global:
+                lo, n = m.shard_of(cfg.name)
+                src = (m.table_weights() if what == "w" else m.table_states())[cfg.name].detach()[:n].clone()
+                parts = [None] * world
+                dist.all_gather_object(parts, (lo, n, src))
+                t = torch.zeros(cfg.num_embeddings, cfg.embedding_dim)
+                for lo_, n_, s_ in parts:
+                    t[lo_:lo_ + n_] = s_
+                out[cfg.name] = t
+            return out
+
+        for what in ("w", "m"):
+            fa, fb = full(sh, what), full(other, what)
+            assert set(fa) == set(fb) and "cw_c@cw0" in fa
+            for n in fa:
+                assert torch.equal(fa[n], fb[n]), (what, n)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("jagged,planner", [(False, False), (True, False), (False, True)])
+def test_mixed_dims_and_column_wise_world2(emu_path, jagged, planner):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_mixed_worker, args=(2, os.path.join(d, "init"), emu_path, jagged, planner), nprocs=2, join=True)

@@ -333,32 +333,45 @@ def test_sequence_collection_is_one_site(dev):
     assert tr.get_unique_ids()["ec.embeddings.s"].cpu().tolist() == [0, 4, 9, 49]
 
 
-def test_zch_table_publishes_resident_raw_ids(dev, tmp_path):
-    """ZCH: the tracker sees remapped rows; the dump's key_id is the raw id resident in each touched
-    row, and rows nobody owns (the shared fallback row) are not published."""
+def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev, tmp_path):
+    """ZCH (reference :355-358, :515-550, :1043-1094): keys are RAW ids -- looked up (with or without a
+    row), admitted or evicted in the window -- each with the row the table serves it from at dump time:
+    its own row while held, the shared fallback row otherwise."""
     from torcheasyrec_amd.zch import ManagedCollisionEmbeddingBagCollection, ZchConfig
+
+    Z = 4  # three real rows + the shared row 3
 
     class M(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, 16, ["k"])], device=dev,
+            ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, Z, ["k"])], device=dev,
                                          optimizer=SparseOptimizerConfig(kind="sgd", lr=1.0))
-            self.mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(16, 1)})
+            self.mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(Z, 1)})
 
     m = M()
     m.train()
     dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=2), str(tmp_path), dev)
     assert list(dumper.tracker.fqn_to_feature_names) == ["mc.embedding_bags.t"] and "mc.embedding_bags.t" in dumper.tracker.zch_modules
-    ids = torch.tensor([10**12, 5, 10**12, 77], dtype=torch.int64)
-    kjt = KeyedJaggedTensor(["k"], ids, torch.ones(4, dtype=torch.int32), uniform_length=1).to(dev)
-    for step in (1, 2):  # step 1: everything on the shared row, then admitted; step 2: rows 0, 1, 2
+    big = 10**12
+    steps = {1: [big, 5, big, 77],   # nothing resident: all on the shared row; the round admits big, 5, 77
+             2: [big, 5, big, 77],   # rows 0, 1, 2
+             3: [900, 900, 900, 5],  # 900 has no row (3 sightings); LFU then keeps big (4), 5 (3), 900 (3): 77 is evicted
+             4: [5, 42, 5, 5]}       # 42 has no row and does not get one
+    want_keys = {2: [5, 77, big], 4: [5, 42, 77, 900]}
+    for step, ids in steps.items():
+        kjt = KeyedJaggedTensor(["k"], torch.tensor(ids, dtype=torch.int64), torch.ones(4, dtype=torch.int32), uniform_length=1).to(dev)
         out, _ = m.mc(kjt)
         out.values().sum().backward()
         dumper.maybe_dump(step)
-    t = _read(os.path.join(str(tmp_path), "delta_embedding_dump", "delta_embedding_step_2.parquet"))
-    w = m.mc.ebc.table_weights()["t"].detach().cpu().numpy()
-    assert t["key_id"].to_pylist() == [10**12, 5, 77]  # rows 0, 1, 2 in row order; the fallback row 15 has no key
-    np.testing.assert_array_equal(np.array(t["embedding"].to_pylist(), dtype=np.float32), w[:3])
+        if step in want_keys:
+            t = _read(os.path.join(str(tmp_path), "delta_embedding_dump", f"delta_embedding_step_{step}.parquet"))
+            assert t["key_id"].to_pylist() == want_keys[step]
+            row_ids = m.mc.modules_by_table["t"].row_ids.cpu().tolist()
+            w = m.mc.ebc.table_weights()["t"].detach().cpu().numpy()
+            rows = [row_ids.index(k) if k in row_ids else Z - 1 for k in want_keys[step]]
+            np.testing.assert_array_equal(np.array(t["embedding"].to_pylist(), dtype=np.float32), w[rows])
+            if step == 4:
+                assert rows == [1, 3, 3, 2]  # 5 keeps row 1, 900 took evicted 77's row 2, 42 and 77 are served by the shared row
 
 
 def _sharded_worker(rank, world, init_file, emu_path, out_dir):

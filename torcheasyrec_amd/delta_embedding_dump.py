@@ -16,9 +16,11 @@ tracking memory is constant (25.5 MB for all of DLRM-Criteo) and no sort ever ru
 read by `tzr_rows_gather` and, for `quant_type: DELTA_EMBEDDING_QUANT_INT8`, encoded by
 `tzr_quantize_rows_q8f16` on the device; only the finished bytes cross PCIe.
 
-Not built: the FeatureStore uploader (`feature_store_config`, a network service) and dynamicemb
-tables; zero-collision-hash tables publish the ids RESIDENT in the rows that were touched (an id
-evicted inside the window is not re-published with the fallback row, reference :515-550).
+Zero-collision-hash tables publish RAW ids like the reference (:355-358, :515-550, :1043-1094): the ids
+resident in the touched rows plus what the ZCH module reports per admission round (evicted, admitted,
+looked up without a row), each with the row the table serves it from at dump time (the shared fallback
+row once an id holds none).  Not built: the FeatureStore uploader (`feature_store_config`, a network
+service) and dynamicemb tables.
 """
 from __future__ import annotations
 
@@ -142,6 +144,7 @@ class _Site:
         self.module_fqn, self.module, self.segment = module_fqn, module, segment
         self.tables: Dict[str, Tuple[str, List[str], _TableShardInfo]] = {}  # table -> (fqn, features, shard)
         self.zch: Dict[str, object] = {}  # table -> ManagedCollisionModule (raw id per row)
+        self.zch_wrapper = None  # the ManagedCollisionEmbeddingBagCollection holding their pending candidates
 
     def weights(self) -> Dict[str, torch.Tensor]:
         return self.module.table_weights()
@@ -160,7 +163,7 @@ def _discover_sites(model: nn.Module) -> List[_Site]:
     is ONE site: its inner collections are not tracked a second time."""
     from .embedding import EmbeddingBagCollection
     from .sequence import EmbeddingCollection, ShardedEmbeddingCollection
-    from .sharding import ShardedEmbeddingBagCollection
+    from .sharding import MixedShardedEmbeddingBagCollection, ShardedEmbeddingBagCollection
     from .zch import ManagedCollisionEmbeddingBagCollection, ShardedManagedCollisionEmbeddingBagCollection
 
     sites: List[_Site] = []
@@ -177,8 +180,8 @@ def _discover_sites(model: nn.Module) -> List[_Site]:
         if isinstance(module, (ManagedCollisionEmbeddingBagCollection, ShardedManagedCollisionEmbeddingBagCollection)):
             inner = module.ebc if isinstance(module, ManagedCollisionEmbeddingBagCollection) else module.sharded
             site = _Site(fqn, inner, "embedding_bags")
-            site.zch = dict(module.modules_by_table if isinstance(module, ManagedCollisionEmbeddingBagCollection)
-                            else module.mc.modules_by_table)
+            site.zch_wrapper = module if isinstance(module, ManagedCollisionEmbeddingBagCollection) else module.mc
+            site.zch = dict(site.zch_wrapper.modules_by_table)
             consume(module)
         elif isinstance(module, ShardedEmbeddingCollection):
             site = _Site(fqn, module.sharded, "embeddings")
@@ -186,6 +189,8 @@ def _discover_sites(model: nn.Module) -> List[_Site]:
         elif isinstance(module, EmbeddingCollection):
             site = _Site(fqn, module, "embeddings")
             consume(module)
+        elif isinstance(module, MixedShardedEmbeddingBagCollection):
+            continue  # its lanes (ShardedEmbeddingBagCollections, `<fqn>.lanes.<i>`) are the sites
         elif isinstance(module, (ShardedEmbeddingBagCollection, EmbeddingBagCollection)):
             site = _Site(fqn, module, "embedding_bags")
             consume(module)
@@ -245,6 +250,15 @@ class ModelDeltaTracker:
                     self._bitmaps[c][fqn] = torch.zeros((max(info.local_rows, 0) + 31) // 32, dtype=torch.int32, device=dev)
             site.module.register_post_lookup_tracker_fn(self._record_segments)
         self._site_of_module = {id(s.module): s for s in self.sites}
+        # ZCH tables publish RAW ids (reference :355-358): rows touched -> the id resident in them, plus
+        # what the ZCH module reports per admission round (evicted / admitted / looked up without a row)
+        self._zch_fqn_by_mc_module = {id(m): fqn for fqn, m in self.zch_modules.items()}
+        self._zch_events: Dict[str, Dict[str, List[torch.Tensor]]] = {c: {f: [] for f in self.zch_modules} for c in self._consumers}
+        if self.zch_modules:
+            from .zch import register_post_zch_event_tracker_fn
+
+            for m in self.zch_modules.values():
+                register_post_zch_event_tracker_fn(m, self.record_zch_event)
         self._oob = torch.zeros(1, dtype=torch.int64, device=self._device) if self._device is not None else None
 
     # -- recording -----------------------------------------------------------------------------
@@ -305,6 +319,20 @@ class ModelDeltaTracker:
         segs = tuple((feature_to_table[k], i) for i, k in enumerate(kjt.keys()))
         self._record_segments(emb_module, segs, kjt.values(), kjt.offsets(), kjt.stride(), 0)
 
+    def record_zch_event(self, mc_module, evicted_raw_ids: torch.Tensor, admitted_raw_ids: torch.Tensor,
+                         absent_raw_ids: Optional[torch.Tensor] = None) -> None:
+        """Raw ids a ZCH table evicted / admitted this round (reference :515-550; recorded even while
+        tracking is paused, :431-434) and, third, the ids looked up without a row."""
+        fqn = self._zch_fqn_by_mc_module.get(id(mc_module))
+        if fqn is None:
+            raise ValueError(f"Unrecognized zch module for FQN delta tracking: {mc_module}")
+        parts = [t for t in (admitted_raw_ids, evicted_raw_ids[evicted_raw_ids != _lib.ZCH_EMPTY]) if t.numel() > 0]
+        if absent_raw_ids is not None and absent_raw_ids.numel() > 0 and self.pause_depth == 0:
+            parts.append(absent_raw_ids)
+        if parts:
+            for c in self._consumers:
+                self._zch_events[c][fqn].append(torch.cat(parts))
+
     # -- reading -------------------------------------------------------------------------------
     def get_unique(self, consumer: Optional[str] = None, top_percentage: Optional[float] = 1.0,
                    per_table_percentage=None, sorted_by_indices: Optional[bool] = True) -> Dict[str, UniqueRows]:
@@ -331,13 +359,28 @@ class ModelDeltaTracker:
                              "the feature's id space does not match the table it is embedded in.")
         out: Dict[str, UniqueRows] = {}
         for f, n in zip(fqns, host):
-            if n == 0:
-                continue
             ids = torch.empty(n, dtype=torch.int64, device=dev)
-            _lib.check(L.tzr_delta_collect(_lib.ptr(maps[f]), self._shard_info[f].local_rows, 0, 1 if self._delete_on_read else 0,
-                                           _lib.ptr(ids), n, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_delta_collect")
-            out[f] = UniqueRows(ids=ids, states=None)
+            if n:
+                _lib.check(L.tzr_delta_collect(_lib.ptr(maps[f]), self._shard_info[f].local_rows, 0, 1 if self._delete_on_read else 0,
+                                               _lib.ptr(ids), n, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_delta_collect")
+            if f in self.zch_modules:
+                ids = self._zch_raw_ids(consumer, f, ids)
+            if ids.numel():
+                out[f] = UniqueRows(ids=ids, states=None)
         return out
+
+    def _zch_raw_ids(self, consumer: str, fqn: str, rows: torch.Tensor) -> torch.Tensor:
+        """Touched rows of a ZCH table -> the raw ids to publish: ids resident in those rows, ids the
+        module admitted / evicted / saw without a row in the window, and the not-yet-coalesced
+        candidates of the running round (those stay with the module and show up again next time)."""
+        site, table = self._fqn_site[fqn]
+        resident = self.zch_modules[fqn].row_ids[rows]
+        parts = [resident[resident != _lib.ZCH_EMPTY]] + self._zch_events[consumer][fqn]
+        if self.pause_depth == 0 and site.zch_wrapper is not None:
+            parts.append(site.zch_wrapper.pending_candidates(table))
+        if self._delete_on_read:
+            self._zch_events[consumer][fqn] = []
+        return torch.unique(torch.cat(parts))
 
     def get_unique_ids(self, consumer: Optional[str] = None) -> Dict[str, torch.Tensor]:
         return {fqn: rows.ids for fqn, rows in self.get_unique(consumer=consumer).items()}
@@ -353,6 +396,8 @@ class ModelDeltaTracker:
             assert c in self._bitmaps, f"consumer {c} not found in {list(self._bitmaps)}"
             for bm in self._bitmaps[c].values():
                 bm.zero_()
+            for f in self._zch_events[c]:
+                self._zch_events[c][f] = []
         if self._oob is not None:
             self._oob.zero_()
 
@@ -510,15 +555,12 @@ class DeltaEmbeddingDumper:
 
     def _lookup_embeddings(self, fqn: str, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         weight = self._tracker.table_weight(fqn)
-        rows = gather_rows(weight, ids)
         zch = self._zch_modules.get(fqn)
         if zch is not None:
-            # key = the raw id resident in the row; rows nobody owns (the shared fallback row, rows
-            # freed by an eviction) have no key to publish
-            raw = zch.row_ids[ids]
-            keep = raw != _lib.ZCH_EMPTY
-            return rows[keep], raw[keep]
-        return rows, ids + self._tracker.shard_info(fqn).row_offset
+            # `ids` are RAW ids: publish the row the table serves each of them from right now -- its own
+            # row while it holds one, the shared fallback row once it does not (reference :1043-1094)
+            return gather_rows(weight, zch.lookup_rows(ids)), ids
+        return gather_rows(weight, ids), ids + self._tracker.shard_info(fqn).row_offset
 
     def _append_table_chunk(self, table_chunks: list, global_step: int, feature_name: str, table_fqn: str,
                             key_ids: torch.Tensor, embeddings: torch.Tensor, source: str) -> int:

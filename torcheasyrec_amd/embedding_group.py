@@ -118,9 +118,10 @@ class EmbeddingGroup(nn.Module):
         """`process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
         the reference, tzrec/main.py:783-804): pooled tables go to a ShardedEmbeddingBagCollection
         (placement from `plan`, e.g. planner.plan_tables, or the size heuristic), sequence tables to
-        ShardedEmbeddingCollections, `zch` tables to the hash-routed sharded map.  Needs one embedding
-        dim across the pooled tables and no feature feeding two pooled tables (DLRM, multi_tower_din,
-        mmoe; DeepFM's wide + deep tables are not supported sharded)."""
+        ShardedEmbeddingCollections, `zch` tables to the hash-routed sharded map.  Pooled tables of one
+        embedding dim with every feature on one table (DLRM, multi_tower_din, mmoe) take the single
+        exchange; several dims / a feature on two tables (DeepFM's wide + deep) / `column_wise` entries in
+        `plan` take MixedShardedEmbeddingBagCollection (one exchange lane per dim)."""
         super().__init__()
         self._pg, self._plan_in, self._dp_max_rows = process_group, plan, dp_max_rows
         name_to_feature = {f.name: f for f in features}
@@ -194,9 +195,20 @@ class EmbeddingGroup(nn.Module):
                 self.ebc = self._sharded_zch.sharded
                 zch_blocks = {}
             else:
-                self.ebc = ShardedEmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
-                                                         groups=ebc_groups, row_layout=row_layout, process_group=self._pg,
-                                                         dp_max_rows=self._dp_max_rows, plan=self._plan_in)
+                cfg_list = list(configs.values())
+                feats = [f for c in cfg_list for f in c.feature_names]
+                mixed = (len({c.embedding_dim for c in cfg_list}) > 1 or len(set(feats)) != len(feats)
+                         or any(p.get("sharding_type") == "column_wise" for p in (self._plan_in or {}).values()))
+                if mixed:  # DeepFM's wide + deep tables, column-wise tables: one exchange lane per embedding dim
+                    from .sharding import MixedShardedEmbeddingBagCollection
+
+                    self.ebc = MixedShardedEmbeddingBagCollection(cfg_list, device=device, optimizer=sparse_optimizer, groups=ebc_groups,
+                                                                  row_layout=row_layout, process_group=self._pg,
+                                                                  dp_max_rows=self._dp_max_rows, plan=self._plan_in)
+                else:
+                    self.ebc = ShardedEmbeddingBagCollection(cfg_list, device=device, optimizer=sparse_optimizer,
+                                                             groups=ebc_groups, row_layout=row_layout, process_group=self._pg,
+                                                             dp_max_rows=self._dp_max_rows, plan=self._plan_in)
         else:
             self.ebc = EmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
                                               groups=ebc_groups, row_layout=row_layout) if self.has_sparse else None

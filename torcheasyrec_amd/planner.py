@@ -9,7 +9,8 @@ the planner here is self-contained and speaks MI355X:
 
   Topology                8 x 288 GB HBM3E, xGMI full mesh (7 links x ~153 GB/s per GPU), host DDR
   EmbeddingEnumerator     per table, one ShardingOption for every sharding type the runtime can
-                          execute (data_parallel | table_wise | row_wise), with storage (weights +
+                          execute (data_parallel | table_wise | row_wise; column_wise when a
+                          constraint names it), with storage (weights +
                           fused-optimizer state + exchange buffers) and a perf estimate (seconds per
                           step from the measured gather / read-modify-write ceilings and link rate)
   DynamicProgrammingProposer
@@ -176,6 +177,23 @@ class EmbeddingEnumerator:
             for q in range(W):
                 rows = max(0, min(blk, t.num_embeddings - q * blk))
                 shards.append(Shard((rows, D), (q * blk, 0), Storage(weights(rows) + int(ids * (8 + 2 * row_b))), per_rank / W))
+        elif kind == "column_wise":
+            # k column shards of width D/k (sharding.MixedShardedEmbeddingBagCollection): every shard
+            # owner serves every id of the table's features with 1/k of the row, and every shard runs its
+            # OWN exchange lane -- three collectives (ids, rows, gradient rows) that no other table
+            # shares, so their launch + rendezvous latency is this option's to pay.  Enumerated only when
+            # a constraint names it.
+            q4 = D // 4
+            k = max(c for c in range(1, min(W, q4) + 1) if q4 % c == 0)
+            d = D // k
+            n = ids * W
+            piece_b = d * eb
+            piece_rmw = 2 * piece_b + 2 * (d * 4 if t.optimizer == "adagrad" else 4 if t.optimizer == "rowwise_adagrad" else 0)
+            wire = (n * (8 + 2 * piece_b) * (W - 1) / W) / top.a2a_bw
+            perf = n * piece_b / top.hbm_gather_bw + n * piece_rmw / top.hbm_rmw_bw + wire + 3 * top.collective_latency
+            st = t.num_embeddings * piece_b + (t.num_embeddings * d * 4 if t.optimizer == "adagrad" else
+                                                t.num_embeddings * 4 if t.optimizer == "rowwise_adagrad" else 0)
+            shards = [Shard((t.num_embeddings, d), (0, j * d), Storage(st + int(n * (8 + 2 * piece_b))), perf) for j in range(k)]
         else:
             raise PlannerError(f"{t.name}: sharding type {kind!r} is not executable by this runtime")
         return ShardingOption(t.name, kind, "fused", shards)
@@ -358,7 +376,8 @@ def plan_tables(tables: Sequence[TableSpec], topology: Topology, batch_size: int
                 proposer: Optional[DynamicProgrammingProposer] = None) -> Dict[str, dict]:
     """Search: every proposal of the DP that can be partitioned is scored by its summed perf; the best
     one becomes the plan.  Output entries carry what `ShardedEmbeddingBagCollection` needs
-    (`sharding_type`, `block`, `rot`, `ranks`) plus what the reference persists
+    (`sharding_type`, `block`, `rot`, `ranks`; column_wise: `ranks` = owner of every column shard, `shard_dim`;
+    executed by `MixedShardedEmbeddingBagCollection`) plus what the reference persists
     (`compute_kernel`) and the estimates (`perf`, `hbm`)."""
     space = EmbeddingEnumerator(topology, batch_size, constraints).enumerate(tables)
     proposer = proposer or DynamicProgrammingProposer()
@@ -390,6 +409,8 @@ def plan_tables(tables: Sequence[TableSpec], topology: Topology, batch_size: int
             e.update({"block": max(1, -(-rows[o.fqn] // W)), "rot": 0, "ranks": list(range(W))})
         elif o.sharding_type == "table_wise":
             e.update({"block": max(1, rows[o.fqn]), "rot": ranks[0], "ranks": [ranks[0]]})
+        elif o.sharding_type == "column_wise":
+            e.update({"ranks": list(ranks), "shard_dim": o.shards[0].size[1]})
         else:
             e.update({"ranks": list(range(W))})
         plan[o.fqn] = e

@@ -150,7 +150,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
         constraints: Optional[Dict[str, str]] = None,
         tw_max_rows: int = 0,
         plan: Optional[Dict[str, dict]] = None,
+        out_keys: Optional[Dict[Tuple[str, str], str]] = None,
+        out_dims: Optional[Dict[str, int]] = None,
     ) -> None:
+        """`out_keys[(feature, table)]`: name of that lookup's pooled block in `groups` (default: the
+        feature name); `out_dims[block]`: width of blocks of `groups` that OTHER collections fill in the
+        same output buffers (`MixedShardedEmbeddingBagCollection`: one collection per embedding dim)."""
         super().__init__()
         self.pg = process_group
         self.W = dist.get_world_size(self.pg)
@@ -214,7 +219,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._lookups: List[Tuple[str, int, str]] = []  # (key, global table idx, out_key)
         for t, cfg in enumerate(self._global):
             for f in cfg.feature_names:
-                self._lookups.append((f, t, f))
+                self._lookups.append((f, t, (out_keys or {}).get((f, cfg.name), f)))
+        self._out_dims = dict(out_dims or {})
         keys = [k for k, _, _ in self._lookups]
         if len(set(keys)) != len(keys):
             raise ValueError("a KJT key feeds more than one sharded table")
@@ -282,7 +288,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             col = 0
             for ok in out_keys:
                 where.setdefault(ok, []).append((d, col))
-                col += self.dim
+                col += self._out_dims.get(ok, self.dim)
         pool = {c.name: c.pooling for c in self._global}
         rw_names = [c.name for c in self._rw]
         dp_names = [c.name for c in self._dp]
@@ -309,7 +315,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         for key, _, _ in self._lookups:
             if key not in key_index:
                 raise KeyError(f"KeyedJaggedTensor has no key {key!r}")
-        m = {"widths": [len(ks) * self.dim for _, ks in layout]}
+        m = {"widths": [sum(self._out_dims.get(k, self.dim) for k in ks) for _, ks in layout]}
         if rw_lk:
             rw_keys = [k for k, _, _ in rw_lk]  # order of the permuted sub-KJT
             sub_index = {k: i for i, k in enumerate(rw_keys)}
@@ -746,3 +752,228 @@ class ShardedDLRM(nn.Module):
             dist.all_reduce(flat, group=self.pg)
             flat.div_(world)
         torch._foreach_copy_(gs, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in gs]), gs)])
+
+
+def _column_shards(dim: int, world: int) -> int:
+    """Default number of column shards of a `column_wise` table: the largest k <= world with dim / k a
+    multiple of 4 (the kernels' float4 granularity)."""
+    q = dim // 4
+    return max(k for k in range(1, min(world, q) + 1) if q % k == 0)
+
+
+class _MixedLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, kjt, dst_names, hook):
+        outs, states = mod._forward_impl(kjt, dst_names)
+        ctx.mod, ctx.states = mod, states
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.mod._backward_impl(ctx.states, grads)
+        return None, None, None, None
+
+
+class MixedShardedEmbeddingBagCollection(nn.Module):
+    """Sharded pooled lookup without the two restrictions of `ShardedEmbeddingBagCollection` -- tables
+    of several embedding dims (DeepFM: wide + deep tables) and features that feed more than one table --
+    plus `column_wise` sharding (/root/reference/tzrec/protos/feature.proto:8; torchrec splits a
+    table's columns into shards that live on different ranks, every shard owner serves every id of the
+    feature and the requester concatenates the pieces).
+
+    Built from what is there: the id-granularity exchange moves fixed-width rows, so the tables are
+    split into LANES -- one `ShardedEmbeddingBagCollection` per (embedding dim, no feature twice) --
+    that all write their blocks into the same feature-group buffers.  A `column_wise` table of dim D
+    with k shards becomes k table-wise tables `<name>@cw<j>` of dim D/k (same rows, same ids, columns
+    [j*D/k, (j+1)*D/k) of the table and of its initialiser), placed on different ranks; its pooled
+    block is the concatenation of the k pieces, which is simply where the k lanes write.  Each lane
+    runs its own id / row all-to-alls (k column shards of one feature are k lanes): column-wise is
+    for the few tables that are too wide for one rank's link, not for everything.
+
+    `plan[table]["sharding_type"] == "column_wise"` (with `ranks` = owner of every column shard) or
+    `constraints[table] = "column_wise"` selects it.  `forward_grouped` / `fused_optimizer` /
+    `table_weights` / `plan` as in the one-dim collection; the three-phase pipeline API is per lane."""
+
+    def __init__(self, tables: Sequence[EmbeddingBagConfig], device: torch.device, optimizer: Optional[SparseOptimizerConfig] = None,
+                 groups: Optional[Dict[str, List[str]]] = None, row_layout: str = "interleaved",
+                 process_group: Optional[dist.ProcessGroup] = None, dp_max_rows: int = 65536,
+                 constraints: Optional[Dict[str, str]] = None, tw_max_rows: int = 0,
+                 plan: Optional[Dict[str, dict]] = None) -> None:
+        super().__init__()
+        self.pg = process_group
+        self.W, self.rank = dist.get_world_size(self.pg), dist.get_rank(self.pg)
+        self._device = torch.device(device)
+        self._tables = list(tables)
+        constraints = dict(constraints or {})
+        feat_tables: Dict[str, List[str]] = {}
+        for cfg in self._tables:
+            for f in cfg.feature_names:
+                feat_tables.setdefault(f, []).append(cfg.name)
+        # block names of the user's groups: feature, or feature@table when the feature feeds > 1 table
+        # (the unsharded collection's rule, tzrec/modules/embedding.py:753-758,826-827)
+        block_of = {(f, cfg.name): (f if len(feat_tables[f]) == 1 else f"{f}@{cfg.name}") for cfg in self._tables for f in cfg.feature_names}
+        # -- column-wise tables -> table-wise column shards ----------------------------------------
+        self._cw: Dict[str, List[str]] = {}
+        virt: List[EmbeddingBagConfig] = []
+        v_constraints: Dict[str, str] = {}
+        v_plan: Optional[Dict[str, dict]] = {} if plan is not None else None
+        pieces: Dict[str, List[Tuple[str, int]]] = {}  # user block -> [(lane block, width)]
+        v_out_keys: Dict[Tuple[str, str], str] = {}
+        for cfg in self._tables:
+            entry = plan.get(cfg.name) if plan is not None else None
+            if plan is not None and entry is None:
+                raise ValueError(f"sharding plan has no entry for {cfg.name}")
+            kind = entry["sharding_type"] if entry is not None else constraints.get(cfg.name)
+            if kind == "column_wise":
+                D = cfg.embedding_dim
+                k = len(entry["ranks"]) if entry is not None and entry.get("ranks") else _column_shards(D, self.W)
+                if k < 1 or D % k or (D // k) % 4:
+                    raise ValueError(f"{cfg.name}: {k} column shards of a dim-{D} table (shard width must be a multiple of 4)")
+                d = D // k
+                self._cw[cfg.name] = []
+                for j in range(k):
+                    def init(w, cfg=cfg, j=j, d=d):  # noqa: E306
+                        full = torch.empty(cfg.num_embeddings, cfg.embedding_dim)
+                        if cfg.init_fn is not None:
+                            cfg.init_fn(full)
+                        else:
+                            a = (1.0 / max(cfg.num_embeddings, 1)) ** 0.5
+                            full.uniform_(-a, a)
+                        w.copy_(full[:, j * d:(j + 1) * d])
+                    name = f"{cfg.name}@cw{j}"
+                    virt.append(EmbeddingBagConfig(name, d, cfg.num_embeddings, list(cfg.feature_names), cfg.pooling, init,
+                                                   data_type=cfg.data_type))
+                    self._cw[cfg.name].append(name)
+                    if v_plan is not None:
+                        v_plan[name] = {"sharding_type": "table_wise", "block": cfg.num_embeddings, "rot": int(entry["ranks"][j]),
+                                        "ranks": [int(entry["ranks"][j])]}
+                    else:
+                        v_constraints[name] = "table_wise"
+                    for f in cfg.feature_names:
+                        v_out_keys[(f, name)] = f"{block_of[(f, cfg.name)]}@cw{j}"
+                        pieces.setdefault(block_of[(f, cfg.name)], []).append((v_out_keys[(f, name)], d))
+            else:
+                virt.append(cfg)
+                if v_plan is not None:
+                    v_plan[cfg.name] = entry
+                elif cfg.name in constraints:
+                    v_constraints[cfg.name] = constraints[cfg.name]
+                for f in cfg.feature_names:
+                    v_out_keys[(f, cfg.name)] = block_of[(f, cfg.name)]
+                    pieces[block_of[(f, cfg.name)]] = [(block_of[(f, cfg.name)], cfg.embedding_dim)]
+        if v_plan is None:  # ONE placement over everything, so the lanes balance together
+            v_plan = make_plan(virt, self.W, dp_max_rows, False, v_constraints, tw_max_rows)
+        self._virt = virt
+        self._global = virt  # what `plan()` / `shard_of` / `table_weights` are keyed by (checkpoint.py reads it)
+        self._vplan = v_plan
+        # -- lanes: same dim, no feature twice --------------------------------------------------------
+        lanes: List[List[EmbeddingBagConfig]] = []
+        for cfg in virt:
+            for lane in lanes:
+                if lane[0].embedding_dim == cfg.embedding_dim and not (set(cfg.feature_names) & {f for c in lane for f in c.feature_names}):
+                    lane.append(cfg)
+                    break
+            else:
+                lanes.append([cfg])
+        out_dims = {blk: w for ps in pieces.values() for blk, w in ps}
+        self._user_groups = groups
+        lane_groups = None if groups is None else {g: [blk for k in ks for blk, _ in pieces[k]] for g, ks in groups.items()}
+        self._widths = None if groups is None else {g: sum(w for k in ks for _, w in pieces[k]) for g, ks in groups.items()}
+        self._all_blocks = [blk for cfg in self._tables for f in cfg.feature_names for blk, _ in pieces[block_of[(f, cfg.name)]]]
+        self._all_width = sum(out_dims[b] for b in self._all_blocks)
+        self._block_of, self._pieces = block_of, pieces
+        self.lanes = nn.ModuleList()
+        for lane in lanes:
+            names = {c.name for c in lane}
+            g = dict(lane_groups) if lane_groups is not None else {}
+            g["__mixed_all__"] = self._all_blocks  # table-then-feature order of the GLOBAL config list
+            self.lanes.append(ShardedEmbeddingBagCollection(
+                lane, device=self._device, optimizer=optimizer, groups=g, row_layout=row_layout, process_group=self.pg,
+                plan={n: p for n, p in v_plan.items() if n in names},
+                out_keys={k: v for k, v in v_out_keys.items() if k[1] in names}, out_dims=out_dims))
+        self.fused_optimizer = self.lanes[0].fused_optimizer
+        for lane in list(self.lanes)[1:]:  # one lr handle drives every lane
+            if lane.fused_optimizer is not None:
+                lane.fused_optimizer.param_groups = self.fused_optimizer.param_groups
+                for part in (lane.local, lane.replica):
+                    if part is not None and part.fused_optimizer is not None:
+                        part.fused_optimizer.param_groups = self.fused_optimizer.param_groups
+        self._hook = torch.zeros(0, requires_grad=True, device=self._device)
+
+    # -- placement / state -------------------------------------------------------------------------
+    def plan(self) -> Dict[str, dict]:
+        """The plan the lanes execute (and checkpoints persist): a column-wise table appears as its
+        table-wise column shards `<name>@cw<j>`; `_global` lists the same tables."""
+        return self._vplan
+
+    def sharding_plan(self) -> Dict[str, dict]:
+        """Per configured table, torchrec's fields: column-wise tables as ONE entry with the owner rank of
+        every column shard (tzrec/utils/checkpoint_util.py:1152-1167)."""
+        out = {}
+        for cfg in self._tables:
+            if cfg.name in self._cw:
+                shards = self._cw[cfg.name]
+                out[cfg.name] = {"sharding_type": "column_wise", "ranks": [self._vplan[s]["ranks"][0] for s in shards],
+                                 "shard_dim": cfg.embedding_dim // len(shards)}
+            else:
+                out[cfg.name] = self._vplan[cfg.name]
+        return out
+
+    def column_shards(self, name: str) -> List[str]:
+        """Names of the column shards of a column-wise table, in column order (keys of `table_weights`)."""
+        return list(self._cw[name])
+
+    def _lane_of(self, name: str) -> ShardedEmbeddingBagCollection:
+        return next(lane for lane in self.lanes if any(c.name == name for c in lane._global))
+
+    def shard_of(self, name: str) -> Tuple[int, int]:
+        return self._lane_of(name).shard_of(name)
+
+    def table_weights(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for lane in self.lanes:
+            out.update(lane.table_weights())
+        return out
+
+    def table_states(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for lane in self.lanes:
+            out.update(lane.table_states())
+        return out
+
+    # -- lookup ----------------------------------------------------------------------------------------
+    def _forward_impl(self, kjt: KeyedJaggedTensor, dst_names):
+        B = kjt.stride()
+        widths = [self._all_width if n == "__mixed_all__" else self._widths[n] for n in dst_names]
+        outs = [torch.empty(B, w, dtype=torch.float32, device=self._device) for w in widths]
+        # every lane's input dist first (their count exchanges and host syncs back to back), then the lookups
+        states = [lane.input_dist_begin(kjt, dst_names) for lane in self.lanes]
+        states = [lane.input_dist_end(st) for lane, st in zip(self.lanes, states)]
+        for lane, st in zip(self.lanes, states):
+            lane.lookup(st, outs)
+        return outs, states
+
+    def _backward_impl(self, states, grads) -> None:
+        for lane, st in zip(self.lanes, states):
+            lane._backward_impl(st, grads)
+
+    def _run(self, features: KeyedJaggedTensor, names: Tuple[str, ...]) -> List[torch.Tensor]:
+        for lane in self.lanes:
+            lane.train(self.training)
+        if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:
+            return list(_MixedLookupFn.apply(self, features, names, self._hook))
+        return self._forward_impl(features, names)[0]
+
+    def forward_grouped(self, features: KeyedJaggedTensor, group_names=None) -> Dict[str, torch.Tensor]:
+        if self._user_groups is None:
+            raise ValueError("MixedShardedEmbeddingBagCollection was built without groups")
+        names = tuple(group_names) if group_names is not None else tuple(self._user_groups)
+        return dict(zip(names, self._run(features, names)))
+
+    def forward(self, features: KeyedJaggedTensor):
+        """KeyedTensor [B, sum D] in table-then-feature order, blocks named like the unsharded collection's."""
+        from .sparse import KeyedTensor
+
+        (out,) = self._run(features, ("__mixed_all__",))
+        keys = [self._block_of[(f, cfg.name)] for cfg in self._tables for f in cfg.feature_names]
+        return KeyedTensor(keys, [cfg.embedding_dim for cfg in self._tables for _ in cfg.feature_names], out)

@@ -109,6 +109,23 @@ class ManagedCollisionModule:
         self.counts = torch.zeros(Z, dtype=torch.int64, device=device)
         self.last_iter = torch.zeros(Z, dtype=torch.int64, device=device)
         self.row_ids = torch.full((Z,), EMPTY, dtype=torch.int64, device=device)  # raw id held by every row
+        self._event_trackers: list = []  # register_post_zch_event_tracker_fn
+
+    def lookup_rows(self, raw_ids: torch.Tensor) -> torch.Tensor:
+        """Row every raw id is served from right now (`zch_size - 1`, the shared row, for ids without a
+        row): K13 without profiling -- what the delta-embedding dump publishes
+        (/root/reference/tzrec/utils/delta_embedding_dump.py:1043-1094)."""
+        raw_ids = raw_ids.contiguous()
+        n = raw_ids.numel()
+        out = torch.empty_like(raw_ids)
+        if n == 0:
+            return out
+        mods = torch.frombuffer(bytearray(bytes(self.struct())), dtype=torch.uint8).to(self.device)
+        km = torch.zeros(1, dtype=torch.int32, device=self.device)
+        off = torch.tensor([0, n], dtype=torch.int64, device=self.device)
+        _lib.check(_lib.lib().tzr_zch_remap(_lib.ptr(mods), _lib.ptr(km), 1, _lib.ptr(raw_ids), _lib.ptr(off), 1, 0, n, 0, 0,
+                                            _lib.ptr(out), None, _lib.stream_ptr(self.device)), "tzr_zch_remap")
+        return out
 
     def struct(self) -> "_lib.TzrZchModule":
         m = _lib.TzrZchModule()
@@ -131,16 +148,22 @@ class ManagedCollisionModule:
         _lib.check(_lib.lib().tzr_zch_build(_lib.C.byref(s), _lib.ptr(ids), _lib.ptr(rows), ids.numel(),
                                             _lib.stream_ptr(self.device)), "tzr_zch_build")
 
+    def _notify(self, evicted: torch.Tensor, admitted: torch.Tensor, absent: torch.Tensor) -> None:
+        for fn in self._event_trackers:
+            fn(self, evicted, admitted, absent)
+
     @torch.no_grad()
     def update_and_evict(self, cand_ids: torch.Tensor, cur_iter: int) -> torch.Tensor:
         """Admit candidates / evict residents.  Returns the rows whose owner changed."""
         cfg, Z = self.cfg, self.cfg.zch_size
         dev = self.device
         new_ids, new_cnt = torch.unique(cand_ids, return_counts=True)
+        absent = new_ids  # every id looked up without a row since the last round, before the admission filter
         if cfg.threshold_filtering_func is not None and new_ids.numel():
             keep, _ = cfg.threshold_filtering_func(new_cnt)
             new_ids, new_cnt = new_ids[keep], new_cnt[keep]
         if new_ids.numel() == 0:
+            self._notify(absent[:0], absent[:0], absent)
             return torch.zeros(0, dtype=torch.int64, device=dev)
         res_rows = torch.nonzero(self.row_ids[:Z - 1] != EMPTY).squeeze(1)
         res_ids = self.row_ids[res_rows]
@@ -167,11 +190,22 @@ class ManagedCollisionModule:
         held = torch.zeros(Z - 1, dtype=torch.bool, device=dev)
         held[res_rows[kept_res]] = True
         free = torch.nonzero(~held).squeeze(1)[:kept_new.numel()]  # ascending rows
+        if self._event_trackers:
+            old = self.row_ids[free]
+            self._notify(old[old != EMPTY], new_ids[kept_new], absent)
         self.row_ids[free] = new_ids[kept_new]
         self.counts[free] = new_cnt[kept_new]
         self.last_iter[free] = cur_iter
         self.rebuild()
         return free
+
+
+def register_post_zch_event_tracker_fn(mc_module: ManagedCollisionModule, fn) -> None:
+    """The reference's hook of the same name (/root/reference/tzrec/utils/zch_util.py:105-134): after every
+    admission / eviction round `fn(mc_module, evicted_raw_ids, admitted_raw_ids, absent_raw_ids)` -- the ids
+    that lost their row, gained one, and (third argument, this library's addition: here lookups are recorded
+    as rows, so ids WITHOUT a row have to come from the ZCH module) the ids looked up without a row."""
+    mc_module._event_trackers.append(fn)
 
 
 class ManagedCollisionEmbeddingBagCollection(nn.Module):
@@ -266,6 +300,15 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
             ids, mods = ids[keep], mods[keep]
             uniq_mods = torch.arange(len(self._order), dtype=torch.int32, device=self._device)
             self._cand = [(ids, uniq_mods[mods.long()], torch.ones_like(ids))] if ids.numel() else []
+
+    def pending_candidates(self, table: str) -> torch.Tensor:
+        """Raw ids looked up without a row since `table`'s last admission round (not consumed)."""
+        j = self._order.index(table)
+        parts = []
+        for c, km, seg in self._cand:
+            mods = torch.repeat_interleave(km, seg)
+            parts.append(c[(mods == j) & (c != EMPTY)])
+        return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=self._device)
 
     def remap_step(self, kjt: KeyedJaggedTensor) -> KeyedJaggedTensor:
         """First half of a step for callers that run the lookup themselves (EmbeddingGroup): remap, and
