@@ -463,7 +463,7 @@ def test_config_model_through_the_train_pipeline(dev, tmp_path):
     dumper = dd.DeltaEmbeddingDumper(model, spec.delta_embedding_dump_config, "unused", dev)
     dumper.start()
     pipe = TrainPipeline(model, torch.optim.Adam(list(model.dense_parameters()), lr=1e-3), dev, model.loss)
-    it = iter(_batches(spec, 1000, spec.batch_size))  # 4 steps of 250
+    it = iter(_batches(spec, 240, 60))  # 4 steps of 60
     step = 0
     while True:
         try:
@@ -481,9 +481,9 @@ def test_config_model_through_the_train_pipeline(dev, tmp_path):
     assert set(fq) == {prefix + n for n in ("cat_0_emb_wide", "cat_1_emb_wide", "cat_2_emb_wide", "cat_0_emb", "cat_1_emb", "cat_2_emb")}
     names = dict(zip(fq, t["feature_name"].to_pylist()))
     assert names[prefix + "cat_2_emb"] == "cat_2,cat_3" and names[prefix + "cat_0_emb_wide"] == "cat_0"
-    rng = np.random.default_rng(0)  # regenerate the ids _batches drew: step 4 = rows 750..999
+    rng = np.random.default_rng(0)  # regenerate the ids _batches drew: step 4 = rows 180..239
     sparse = [f for f in spec.features if f.is_sparse]
-    ids4 = {f.name: rng.integers(0, f.num_embeddings, size=1000)[750:] for f in sparse}
+    ids4 = {f.name: rng.integers(0, f.num_embeddings, size=240)[180:] for f in sparse}
     key = np.array(t["key_id"].to_pylist())
     emb = t["embedding"].to_pylist()
     weights = model.embedding_group.ebc.table_weights()
@@ -494,3 +494,34 @@ def test_config_model_through_the_train_pipeline(dev, tmp_path):
         w = weights[table].detach().float().cpu().numpy()
         got = np.array([e for e, s in zip(emb, sel) if s], dtype=np.float32)
         np.testing.assert_array_equal(got, w[want])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_tracker_at_full_size_is_a_set(dist):
+    """BASELINE's full size (26 tables, 204.2 M rows, three batches of 65 536) through size-independent
+    properties: collected ids == torch.unique of everything marked (sortedness + set equality), marking
+    is idempotent, a cleared bitmap counts zero, and the popcount of the words equals the count."""
+    from torcheasyrec_amd.criteo import CRITEO_ROWS, synthetic_batch
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    B, T = 65536, len(CRITEO_ROWS)
+    bitmaps = [torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev) for r in CRITEO_ROWS]
+    oob = torch.zeros(1, dtype=torch.int64, device=dev)
+    batches = [synthetic_batch(s, B, CRITEO_ROWS, dist=dist)[1].values().to(dev) for s in range(3)]
+    for rep in range(2):  # second pass over the same batches: every bit already set
+        for v in batches:
+            _mark(dev, bitmaps, list(CRITEO_ROWS), list(range(T)), list(range(T)), v, None, B, 1, oob)
+        if rep == 0:
+            first = [b.clone() for b in bitmaps]
+    assert int(oob.item()) == 0
+    for t in range(T):
+        assert torch.equal(bitmaps[t], first[t])  # idempotent
+        want = torch.unique(torch.cat([v.view(T, B)[t] for v in batches]))
+        n, got = _collect(dev, bitmaps[t], CRITEO_ROWS[t])
+        assert n == want.numel()
+        assert torch.equal(torch.from_numpy(got).to(dev), want)  # ascending, exactly the marked set
+        n2, _ = _collect(dev, bitmaps[t], CRITEO_ROWS[t], clear=1)
+        assert n2 == n and int(torch.count_nonzero(bitmaps[t])) == 0
+        assert _collect(dev, bitmaps[t], CRITEO_ROWS[t])[0] == 0
