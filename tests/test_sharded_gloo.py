@@ -520,7 +520,7 @@ def test_sharded_sequence_lookup_world2(emu_path):
         mp.spawn(_seq_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
-def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
+def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, constraints_in_config=False):
     """A config-built rank model over a process group (the DistributedModelParallel seam): logits on my
     slice equal the unsharded model's logits on the same samples; after one step the tables end
     where the unsharded model's end on the GLOBAL batch."""
@@ -534,19 +534,44 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
 
     _lib.use_library(emu_path)
     dev = torch.device("cpu")
-    spec = load_pipeline_spec(open(os.path.join(os.path.dirname(__file__), "golden", cfg_name)).read())
+    text = open(os.path.join(os.path.dirname(__file__), "golden", cfg_name)).read()
+    if constraints_in_config:
+        # the placement comes from the config alone: a feature-level `embedding_constraints` (both tables that
+        # feature creates) and `train_config.global_embedding_constraints` for the rest -> the planner
+        text = text.replace('feature_name: "cat_0" num_buckets: 1000 embedding_dim: 16',
+                            'feature_name: "cat_0" num_buckets: 1000 embedding_dim: 16 embedding_constraints { sharding_types: "column_wise" }', 1)
+        text = text.replace("train_config {", 'train_config {\n  global_embedding_constraints { sharding_types: "row_wise" sharding_types: "data_parallel" }', 1)
+    spec = load_pipeline_spec(text)
     torch.manual_seed(11)
     ref = build_rank_model(spec, device=dev)
     torch.manual_seed(11)
     from torcheasyrec_amd.sharding import make_plan
 
-    plan = make_plan(ref.embedding_group.ebc.embedding_bag_configs(), world, dp_max_rows=50)  # big tables row-wise, small replicated
-    assert {p["sharding_type"] for p in plan.values()} == {"row_wise", "data_parallel"}
-    shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan)
+    if constraints_in_config:
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD)
+        sp = shd.embedding_group.ebc.sharding_plan()
+        assert sp["cat_0_emb"]["sharding_type"] == "column_wise" and sp["cat_0_emb"]["shard_dim"] == 8 and len(sp["cat_0_emb"]["ranks"]) == 2
+        assert sp["cat_0_emb_wide"]["sharding_type"] == "column_wise" and sp["cat_0_emb_wide"]["shard_dim"] == 4
+        assert {sp[t]["sharding_type"] for t in sp if not t.startswith("cat_0")} <= {"row_wise", "data_parallel"}
+        assert shd.embedding_group.parameter_constraints("embedding_group.") == {
+            "embedding_group.ebc.cat_0_emb_wide": {"sharding_types": ["column_wise"]}, "embedding_group.ebc.cat_0_emb": {"sharding_types": ["column_wise"]}}
+    else:
+        plan = make_plan(ref.embedding_group.ebc.embedding_bag_configs(), world, dp_max_rows=50)  # big tables row-wise, small replicated
+        assert {p["sharding_type"] for p in plan.values()} == {"row_wise", "data_parallel"}
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan)
+
+    def pieces(name, D):  # (table name the sharded collection holds, columns of the configured table)
+        cw = getattr(shd.embedding_group.ebc, "_cw", {})
+        if name in cw:
+            d = D // len(cw[name])
+            return [(s, slice(j * d, (j + 1) * d)) for j, s in enumerate(cw[name])]
+        return [(name, slice(None))]
+
     # same starting tables: copy the reference's rows into my shards
     for name, w in ref.embedding_group.ebc.table_weights().items():
-        lo, n = shd.embedding_group.ebc.shard_of(name)
-        shd.embedding_group.ebc.table_weights()[name].data[:n].copy_(w.data[lo:lo + n])
+        for held, cols in pieces(name, w.shape[1]):
+            lo, n = shd.embedding_group.ebc.shard_of(held)
+            shd.embedding_group.ebc.table_weights()[held].data[:n].copy_(w.data[lo:lo + n, cols])
     for d, ec in ref.embedding_group.ecs.items():
         sec = shd.embedding_group.ecs[d]
         for name, w in ec.table_weights().items():
@@ -581,7 +606,32 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
         return Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt}, {l: torch.from_numpy(np.concatenate([parts[r][3][l] for r in rs])) for l in label_names})
 
     mine, full = batch_of([rank]), batch_of(list(range(world)))
+    tracker = None
+    if cfg_name == "deepfm_mini.config" and not constraints_in_config:
+        # delta tracker over the exchange lanes of the mixed-dim collection: one FQN per table under the
+        # collection's own path, local rows of every lane's owner side
+        from torcheasyrec_amd.delta_embedding_dump import ModelDeltaTracker
+
+        tracker = ModelDeltaTracker(shd)
+        assert set(tracker.fqn_to_feature_names) == {f"embedding_group.ebc.embedding_bags.{n}" for n in ref.embedding_group.ebc.table_weights()}
     ps = shd(mine)
+    if tracker is not None:
+        got = tracker.get_unique_ids()
+        kj = full.sparse_features[BASE_DATA_GROUP]
+        off = kj.offsets().numpy()
+        Bf = kj.stride()
+        for c in ref.embedding_group.ebc.embedding_bag_configs():
+            lo, n = shd.embedding_group.ebc.shard_of(c.name)
+            kind = shd.embedding_group.ebc.plan()[c.name]["sharding_type"]
+            seen = []
+            for f in c.feature_names:
+                k = kj.keys().index(f)
+                s0, s1 = (k * Bf + rank * Bl, k * Bf + (rank + 1) * Bl) if kind == "data_parallel" else (k * Bf, (k + 1) * Bf)
+                seen.append(kj.values().numpy()[off[s0]:off[s1]])
+            seen = np.concatenate(seen)
+            want = np.unique(seen[(seen >= lo) & (seen < lo + n)]) - lo
+            fqn = f"embedding_group.ebc.embedding_bags.{c.name}"
+            np.testing.assert_array_equal(got[fqn].numpy() if fqn in got else np.zeros(0, np.int64), want)
     pr = ref(full)
     for k in ps:
         if k.startswith("logits"):
@@ -599,10 +649,11 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
     for qs, qr in zip(shd.dense_parameters(), ref.dense_parameters()):
         torch.testing.assert_close(qs.grad, qr.grad / world, rtol=1e-4, atol=1e-6)
     for name, w in ref.embedding_group.ebc.table_weights().items():
-        lo, n = shd.embedding_group.ebc.shard_of(name)
-        if n:
-            torch.testing.assert_close(shd.embedding_group.ebc.table_weights()[name].detach()[:n], w.detach()[lo:lo + n],
-                                       rtol=2e-4, atol=1e-4, msg=name)
+        for held, cols in pieces(name, w.shape[1]):
+            lo, n = shd.embedding_group.ebc.shard_of(held)
+            if n:
+                torch.testing.assert_close(shd.embedding_group.ebc.table_weights()[held].detach()[:n], w.detach()[lo:lo + n, cols],
+                                           rtol=2e-4, atol=1e-4, msg=held)
     for d, ec in ref.embedding_group.ecs.items():
         sec = shd.embedding_group.ecs[d]
         for name, w in ec.table_weights().items():
@@ -613,10 +664,11 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,labels", [("din_mini.config", ["clk"]), ("deepfm_mini.config", ["label"])])
-def test_config_model_over_a_process_group(emu_path, cfg, labels):
+@pytest.mark.parametrize("cfg,labels,in_config", [("din_mini.config", ["clk"], False), ("deepfm_mini.config", ["label"], False),
+                                                  ("deepfm_mini.config", ["label"], True)])
+def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels), nprocs=2, join=True)
+        mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config), nprocs=2, join=True)
 
 
 def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
@@ -719,6 +771,10 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
                 super().__init__()
                 self.ebc = ebc
 
+        from torcheasyrec_amd.delta_embedding_dump import ModelDeltaTracker
+
+        with pytest.raises(ValueError, match="does not support column-wise embedding sharding.*cw_c.*local_cols=8, global_cols=16"):
+            ModelDeltaTracker(Holder(sh))  # the reference fails fast too (delta_embedding_dump.py:253-266)
         ck = os.path.join(os.path.dirname(init_file), "ckpt")
         save_checkpoint(ck, Holder(sh))
         assert read_plan(ck)["ebc"]["cw_c@cw1"]["sharding_type"] == "table_wise"

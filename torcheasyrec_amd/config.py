@@ -124,6 +124,8 @@ class FeatureSpec:
     sequence_length: int = 0
     data_type: str = "FP32"  # feature config `data_type` (FP32 | FP16)
     zch: Optional[Msg] = None  # the raw `zch {...}` block (see zch.zch_config_from_msg)
+    # `embedding_constraints { sharding_types: ... }` (feature.proto:6-13, features/feature.py:832-845)
+    sharding_types: List[str] = field(default_factory=list)
 
 
 @dataclass
@@ -151,6 +153,8 @@ class PipelineSpec:
     dense_optimizer_block: Optional[Msg] = None
     # train_config.delta_embedding_dump_config (train.proto:86-111) -> delta_embedding_dump.DeltaEmbeddingDumpConfig
     delta_embedding_dump_config: Optional[object] = None
+    # train_config.global_embedding_constraints.sharding_types (train.proto:144, plan_util.py:170-179)
+    global_sharding_types: List[str] = field(default_factory=list)
 
 
 def _num_embeddings(f: Msg, name: str) -> int:
@@ -211,6 +215,14 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
             return FeatureSpec(name=name, kind=kind, is_sparse=False, value_dim=int(f.one("value_dim", 1)), **seq)
         return FeatureSpec(name=name, kind=kind, is_sparse=f.has("embedding_dim"), embedding_dim=int(f.one("embedding_dim", 0)), **seq)
 
+    _one_feature = one_feature
+
+    def one_feature(kind: str, f: Msg, prefix: str = "", seq_len: int = 0) -> FeatureSpec:  # noqa: F811
+        fs = _one_feature(kind, f, prefix, seq_len)
+        if f.has("embedding_constraints"):
+            fs.sharding_types = [str(t) for t in f.one("embedding_constraints").many("sharding_types")]
+        return fs
+
     for fc in cfg.many("feature_configs"):
         (kind, body), = fc.items()
         f = body[-1]
@@ -242,6 +254,8 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
         for _, v in tc.one("dense_optimizer").items():
             if isinstance(v[-1], Msg) and v[-1].has("lr"):
                 spec.dense_lr = float(v[-1].one("lr"))
+    if tc.has("global_embedding_constraints"):
+        spec.global_sharding_types = [str(t) for t in tc.one("global_embedding_constraints").many("sharding_types")]
     if tc.has("delta_embedding_dump_config"):  # enable_delta_embedding_dump, tzrec/main.py:691
         from .delta_embedding_dump import delta_embedding_dump_config_from_msg
 

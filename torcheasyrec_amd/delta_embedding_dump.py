@@ -190,7 +190,23 @@ def _discover_sites(model: nn.Module) -> List[_Site]:
             site = _Site(fqn, module, "embeddings")
             consume(module)
         elif isinstance(module, MixedShardedEmbeddingBagCollection):
-            continue  # its lanes (ShardedEmbeddingBagCollections, `<fqn>.lanes.<i>`) are the sites
+            if module._cw:  # the reference refuses too (train.proto:169-171, delta_embedding_dump.py:253-266)
+                name = sorted(module._cw)[0]
+                k = len(module._cw[name])
+                cols = next(c.embedding_dim for c in module._tables if c.name == name)
+                raise ValueError("delta_embedding_dump_config does not support column-wise embedding sharding. Please use "
+                                 f"table-wise, row-wise, or data-parallel sharding for table {name}. "
+                                 f"local_cols={cols // k}, global_cols={cols}, column_offset=0.")
+            # one site per exchange lane, all under the collection's own FQN (`<fqn>.embedding_bags.<table>`)
+            for lane in module.lanes:
+                lane_site = _Site(fqn, lane, "embedding_bags")
+                for cfg in lane._global:
+                    lo, n = lane.shard_of(cfg.name)
+                    lane_site.tables[cfg.name] = (".".join(filter(None, (fqn, "embedding_bags", cfg.name))), list(cfg.feature_names),
+                                                  _TableShardInfo(lo, n, cfg.num_embeddings, cfg.embedding_dim))
+                sites.append(lane_site)
+            consume(module)
+            continue
         elif isinstance(module, (ShardedEmbeddingBagCollection, EmbeddingBagCollection)):
             site = _Site(fqn, module, "embedding_bags")
             consume(module)
@@ -227,7 +243,13 @@ class ModelDeltaTracker:
         self.curr_batch_idx = 0
         self.pause_depth = 0
         self.sites = _discover_sites(model)
-        self.tracked_modules: Dict[str, nn.Module] = {s.module_fqn: s.module for s in self.sites}
+        self.tracked_modules: Dict[str, nn.Module] = {}
+        for s in self.sites:  # the lanes of a mixed-dim sharded collection share its FQN
+            key, i = s.module_fqn, 0
+            while key in self.tracked_modules:
+                i += 1
+                key = f"{s.module_fqn}#{i}"
+            self.tracked_modules[key] = s.module
         self.fqn_to_feature_names: Dict[str, List[str]] = {}
         self.zch_modules: Dict[str, object] = {}
         self._shard_info: Dict[str, _TableShardInfo] = {}

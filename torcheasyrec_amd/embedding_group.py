@@ -114,6 +114,8 @@ class EmbeddingGroup(nn.Module):
         process_group=None,
         plan: Optional[Dict[str, dict]] = None,
         dp_max_rows: int = 65536,
+        global_sharding_types: Sequence[str] = (),
+        batch_size: int = 1024,
     ) -> None:
         """`process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
         the reference, tzrec/main.py:783-804): pooled tables go to a ShardedEmbeddingBagCollection
@@ -127,6 +129,9 @@ class EmbeddingGroup(nn.Module):
         name_to_feature = {f.name: f for f in features}
         configs: "OrderedDict[str, EmbeddingBagConfig]" = OrderedDict()
         zch_blocks: Dict[str, object] = {}
+        # table -> sharding types of the feature config that created it; the rest fall back to the global ones
+        self._table_sharding_types: Dict[str, List[str]] = {}
+        self._global_sharding_types = list(global_sharding_types)
         feat_group_table: Dict[str, Dict[str, str]] = {}
         self._seq_groups = [g for g in feature_groups if g.group_type == "SEQUENCE"]
         feature_groups = [g for g in feature_groups if g.group_type != "SEQUENCE"]
@@ -157,6 +162,8 @@ class EmbeddingGroup(nn.Module):
                                              data_type=f.data_type)
                     if f.zch is not None:
                         zch_blocks[tname] = f.zch
+                    if getattr(f, "sharding_types", None) and tname not in self._table_sharding_types:
+                        self._table_sharding_types[tname] = list(f.sharding_types)
                     if tname in configs:
                         old = configs[tname]
                         if (old.num_embeddings, old.embedding_dim, old.pooling) != (cfg.num_embeddings, dim, cfg.pooling):
@@ -183,6 +190,19 @@ class EmbeddingGroup(nn.Module):
         ebc_groups = {g: [k for kind, k, _ in blocks if kind == "sparse"] for g, blocks in self._group_blocks.items()}
         ebc_groups = {g: ks for g, ks in ebc_groups.items() if ks}
         self._sharded_zch = None
+        if self.has_sparse and self._pg is not None and self._plan_in is None and not zch_blocks \
+                and (self._table_sharding_types or self._global_sharding_types):
+            # `embedding_constraints` / `global_embedding_constraints` of the config -> the planner picks among the
+            # allowed types per table (tzrec/main.py:783-799; per-table constraints win over the global ones)
+            import torch.distributed as dist
+
+            from .planner import TableSpec, Topology, plan_tables
+
+            cons = {t: list(self._table_sharding_types.get(t) or self._global_sharding_types) for t in configs}
+            kind = sparse_optimizer.kind if sparse_optimizer is not None else "sgd"
+            self._plan_in = plan_tables([TableSpec(c.name, c.num_embeddings, c.embedding_dim, list(c.feature_names), optimizer=kind)
+                                         for c in configs.values()], Topology(dist.get_world_size(self._pg)), max(int(batch_size), 1),
+                                        constraints={t: v for t, v in cons.items() if v})
         if self.has_sparse and self._pg is not None:
             from .sharding import ShardedEmbeddingBagCollection
 
@@ -335,6 +355,11 @@ class EmbeddingGroup(nn.Module):
         return out_key if out_key in self.ebc._out_dim else out_key.split("@")[0]
 
     # -- introspection used by the models (embedding.py:886-907) -----------------------------
+    def parameter_constraints(self, prefix: str = "") -> Dict[str, Dict[str, List[str]]]:
+        """{`<prefix>ebc.<table>`: {"sharding_types": [...]}} for the tables whose feature config carries
+        `embedding_constraints` (EmbeddingGroupImpl.parameter_constraints, tzrec/modules/embedding.py:898-907)."""
+        return {f"{prefix}ebc.{t}": {"sharding_types": list(v)} for t, v in self._table_sharding_types.items()}
+
     def group_names(self) -> List[str]:
         return list(self._group_feature_names)
 

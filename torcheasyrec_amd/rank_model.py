@@ -34,7 +34,8 @@ class RankModel(nn.Module):
         self.embedding_group = EmbeddingGroup(
             spec.features, spec.feature_groups, wide_embedding_dim=spec.wide_embedding_dim or None,
             device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer,
-            process_group=self._pg, plan=RankModel._build_plan)
+            process_group=self._pg, plan=RankModel._build_plan,
+            global_sharding_types=getattr(spec, "global_sharding_types", ()), batch_size=spec.batch_size or 1024)
 
     def sync_dense_parameters(self) -> None:
         """Same dense parameters on every rank (DDP broadcasts rank 0's at construction)."""
