@@ -45,7 +45,10 @@ def main(path):
     # the `learning_rate` oneof of the two optimizer blocks (tzrec/main.py:877-882); stepped per step
     # unless by_epoch (main.py:542-544)
     schedulers = [create_scheduler(model.fused_optimizer, spec.sparse_optimizer_block), create_scheduler(opt, spec.dense_optimizer_block)]
-    pipe = TrainPipeline(model, opt, dev, model.loss)
+    # train_config.grad_clipping / gradient_accumulation_steps around the dense optimizer (tzrec/main.py:848-876)
+    from torcheasyrec_amd.optimizer import build_train_optimizer
+
+    pipe = TrainPipeline(model, build_train_optimizer(opt, spec.grad_clipping, spec.gradient_accumulation_steps), dev, model.loss)
     # train_config.delta_embedding_dump_config: the call sites of tzrec/main.py:805-811,900,547,611,928
     dumper = None
     if spec.delta_embedding_dump_config is not None:

@@ -155,6 +155,8 @@ class PipelineSpec:
     delta_embedding_dump_config: Optional[object] = None
     # train_config.global_embedding_constraints.sharding_types (train.proto:144, plan_util.py:170-179)
     global_sharding_types: List[str] = field(default_factory=list)
+    gradient_accumulation_steps: int = 0  # train.proto:151
+    grad_clipping: Optional[object] = None  # train.proto:153 -> optimizer.GradClippingConfig
 
 
 def _num_embeddings(f: Msg, name: str) -> int:
@@ -254,6 +256,11 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
         for _, v in tc.one("dense_optimizer").items():
             if isinstance(v[-1], Msg) and v[-1].has("lr"):
                 spec.dense_lr = float(v[-1].one("lr"))
+    spec.gradient_accumulation_steps = int(tc.one("gradient_accumulation_steps", 0))
+    if tc.has("grad_clipping"):
+        from .optimizer import grad_clipping_from_msg
+
+        spec.grad_clipping = grad_clipping_from_msg(tc.one("grad_clipping"))
     if tc.has("global_embedding_constraints"):
         spec.global_sharding_types = [str(t) for t in tc.one("global_embedding_constraints").many("sharding_types")]
     if tc.has("delta_embedding_dump_config"):  # enable_delta_embedding_dump, tzrec/main.py:691
