@@ -206,7 +206,24 @@ def _read(path):
     return pq.read_table(path)
 
 
-@pytest.mark.parametrize("dtype", ["FP32", "FP16"])
+def test_fp16_table_rows_are_widened_exactly(dev, tmp_path):
+    """FP16 tables (`data_type: FP16`): the dump holds the half rows widened to float32, bit for bit."""
+    m = _Model(dev, "FP16")
+    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=1), str(tmp_path), dev)
+    kjt, vals, lens, B = m.batch(1)
+    m.step(kjt)
+    dumper.maybe_dump(1)
+    t = _read(os.path.join(str(tmp_path), "delta_embedding_dump", "delta_embedding_step_1.parquet"))
+    fq, key = np.array(t["table_fqn"].to_pylist()), np.array(t["key_id"].to_pylist())
+    emb = np.array(t["embedding"].to_pylist(), dtype=np.float32)
+    for name, w in m.ebc.table_weights().items():
+        assert w.dtype == torch.float16
+        sel = fq == f"ebc.embedding_bags.{name}"
+        assert sel.any()
+        np.testing.assert_array_equal(emb[sel], w.detach().float().cpu().numpy()[key[sel]])
+
+
+@pytest.mark.parametrize("dtype", ["FP32"])
 def test_dumper_rows_cadence_and_schema(dev, tmp_path, dtype):
     """interval 2: steps 2 and 4 are dumped by maybe_dump, the trailing step 5 by final_dump, a final
     step on a boundary is skipped; every file holds exactly the touched ids (ascending per table) with
