@@ -144,7 +144,7 @@ def test_plan_respects_hbm_and_constraints():
     with pytest.raises(PlannerError):
         plan_tables(tabs, Topology(2, hbm_cap=40 * GB), batch_size=8192)
     with pytest.raises(PlannerError):  # torchrec types this runtime cannot execute (feature.proto:8)
-        plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["grid_shard"]})
+        plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["key_value_wise"]})
     assert plan_tables(tabs, Topology(8), batch_size=8192, constraints={"small": ["column_wise"]})["small"]["sharding_type"] == "column_wise"
 
 
@@ -234,3 +234,17 @@ def test_column_wise_is_enumerated_only_on_request():
     plan = plan_tables([t, TableSpec("small", 50, 16, ["s"])], top, 1024, constraints={"wide": ["column_wise"]})
     assert plan["wide"]["sharding_type"] == "column_wise" and plan["wide"]["shard_dim"] == 8 and len(plan["wide"]["ranks"]) == 8
     assert sorted(plan["wide"]["ranks"]) == list(range(8))  # equal shards spread over the least-loaded ranks
+
+
+def test_hierarchical_types_have_their_single_node_meaning():
+    """table_row_wise / table_column_wise / grid_shard (feature.proto:8) on one node = row_wise / column_wise /
+    column shards that are row-wise; across hosts they are refused."""
+    from torcheasyrec_amd.planner import PlannerError, TableSpec, Topology, plan_tables
+
+    tabs = [TableSpec("a", 1000, 16, ["a"]), TableSpec("g", 5000, 32, ["g"]), TableSpec("c", 400, 16, ["c"])]
+    p = plan_tables(tabs, Topology(4), 256, constraints={"g": ["grid_shard"], "a": ["table_row_wise"], "c": ["table_column_wise"]})
+    assert (p["a"]["sharding_type"], p["a"]["block"], p["a"]["ranks"]) == ("table_row_wise", 250, [0, 1, 2, 3])
+    assert (p["g"]["sharding_type"], p["g"]["shard_dim"], p["g"]["ranks"]) == ("grid_shard", 8, [0, 1, 2, 3])
+    assert (p["c"]["sharding_type"], p["c"]["shard_dim"], len(p["c"]["ranks"])) == ("table_column_wise", 4, 4)
+    with pytest.raises(PlannerError, match="across hosts"):
+        plan_tables(tabs, Topology(8, local_world_size=4), 256, constraints={"g": ["grid_shard"]})

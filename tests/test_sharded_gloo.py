@@ -671,7 +671,7 @@ def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config):
         mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config), nprocs=2, join=True)
 
 
-def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
+def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=False):
     """MixedShardedEmbeddingBagCollection: wide (dim 4) + deep (dim 16) tables fed by the SAME features
     (DeepFM), a column-wise table (two dim-8 column shards on different ranks) and a replicated one must
     reproduce the unsharded collection on the global batch: outputs (bit-exact for one id per bag) and
@@ -705,13 +705,23 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
         pl = plan_tables([TableSpec(n, r, d, f) for n, d, r, f in spec], Topology(world), 24, constraints=cons)
         assert pl["cw_c"]["sharding_type"] == "column_wise" and pl["cw_c"]["shard_dim"] == 8 and len(pl["cw_c"]["ranks"]) == 2
         sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, plan=pl)
+    elif grid:  # torchrec's hierarchical types with their single-node meaning
+        sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, dp_max_rows=10,
+                                                constraints={"cw_c": "grid_shard", "deep_a": "table_wise", "wide_b": "table_row_wise"})
+        assert sh.sharding_plan()["cw_c"] == {"sharding_type": "grid_shard", "ranks": [0, 1], "shard_dim": 8}
+        assert sh.plan()["cw_c@cw1"]["sharding_type"] == "row_wise" and sh.shard_of("cw_c@cw1")[1] == 60  # half the rows here
+        sh._cw_kind = "grid_shard"
     else:
         sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, dp_max_rows=10,
                                                 constraints={"cw_c": "column_wise", "deep_a": "table_wise"})
     plan = sh.sharding_plan()
+    if grid:
+        plan = dict(plan, cw_c=dict(plan["cw_c"], sharding_type="column_wise"))
     assert set(sh.plan()) == {"wide_a", "wide_b", "deep_a", "deep_b", "cw_c@cw0", "cw_c@cw1", "tiny"}
     assert plan["cw_c"]["sharding_type"] == "column_wise" and plan["cw_c"]["shard_dim"] == 8
     assert planner or sorted(plan["cw_c"]["ranks"]) == [0, 1]  # the heuristic puts the two column shards on different ranks
+    if grid:
+        assert sh.sharding_plan()["wide_b"]["sharding_type"] == "row_wise"  # table_row_wise on one node
     assert plan["tiny"]["sharding_type"] == "data_parallel" and plan["deep_a"]["sharding_type"] == "table_wise"
     assert plan["wide_b"]["sharding_type"] == "row_wise" and len(sh.lanes) == 4  # dims 4, 16, and one dim-8 lane per column shard of feature c
     ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups)
@@ -753,7 +763,7 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
         if name == "cw_c":
             for j, shard in enumerate(sh.column_shards(name)):
                 lo, n = sh.shard_of(shard)
-                assert n in (0, r)  # a column shard is a whole table on one rank
+                assert grid or n in (0, r)  # a column shard is a whole table on one rank (grid: row-wise over both)
                 torch.testing.assert_close(w[shard].detach()[:n], w_ref[name][lo:lo + n, j * 8:(j + 1) * 8], rtol=1e-5, atol=1e-7, msg=shard)
         else:
             lo, n = sh.shard_of(name)
@@ -761,7 +771,7 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
     fresh = torch.empty(120, 16)
     seeded(4)(fresh)
     assert not torch.equal(w_ref["cw_c"], fresh)  # the step moved the table
-    if not jagged and not planner:
+    if not jagged and not planner and not grid:
         # checkpoint: tables are persisted as the runtime holds them (column shards `cw_c@cw<j>`) and come
         # back under a different placement of the other tables
         from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
@@ -804,7 +814,7 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("jagged,planner", [(False, False), (True, False), (False, True)])
-def test_mixed_dims_and_column_wise_world2(emu_path, jagged, planner):
+@pytest.mark.parametrize("jagged,planner,grid", [(False, False, False), (True, False, False), (False, True, False), (True, False, True)])
+def test_mixed_dims_and_column_wise_world2(emu_path, jagged, planner, grid):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_mixed_worker, args=(2, os.path.join(d, "init"), emu_path, jagged, planner), nprocs=2, join=True)
+        mp.spawn(_mixed_worker, args=(2, os.path.join(d, "init"), emu_path, jagged, planner, grid), nprocs=2, join=True)

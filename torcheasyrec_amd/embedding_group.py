@@ -218,7 +218,8 @@ class EmbeddingGroup(nn.Module):
                 cfg_list = list(configs.values())
                 feats = [f for c in cfg_list for f in c.feature_names]
                 mixed = (len({c.embedding_dim for c in cfg_list}) > 1 or len(set(feats)) != len(feats)
-                         or any(p.get("sharding_type") == "column_wise" for p in (self._plan_in or {}).values()))
+                         or any(p.get("sharding_type") in ("column_wise", "table_column_wise", "grid_shard", "table_row_wise")
+                                for p in (self._plan_in or {}).values()))
                 if mixed:  # DeepFM's wide + deep tables, column-wise tables: one exchange lane per embedding dim
                     from .sharding import MixedShardedEmbeddingBagCollection
 

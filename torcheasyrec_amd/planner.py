@@ -139,8 +139,25 @@ class EmbeddingEnumerator:
             return rows * 4
         return 0
 
+    # torchrec's hierarchical types priced with their single-node meaning (sharding.MixedShardedEmbeddingBagCollection)
+    _SINGLE_NODE_ALIAS = {"table_row_wise": "row_wise", "table_column_wise": "column_wise"}
+
     def _option(self, t: TableSpec, kind: str) -> ShardingOption:
         top, W, B = self.topology, self.topology.world_size, self.batch_size
+        if kind in self._SINGLE_NODE_ALIAS or kind == "grid_shard":
+            if top.local_world_size != W:
+                raise PlannerError(f"{t.name}: {kind} across hosts is not executable by this runtime (one node: local_world_size == world_size)")
+            if kind == "grid_shard":
+                # column shards that are each row-wise over the node: row_wise traffic and balance, one exchange
+                # lane (three collectives) per column shard
+                base = self._option(t, "row_wise")
+                q4 = t.embedding_dim // 4
+                k = max(c for c in range(1, min(W, q4) + 1) if q4 % c == 0)
+                for sh in base.shards:
+                    sh.perf += 3 * k * top.collective_latency / W
+                return ShardingOption(t.name, "grid_shard", "fused", base.shards)
+            base = self._option(t, self._SINGLE_NODE_ALIAS[kind])
+            return ShardingOption(t.name, kind, "fused", base.shards)
         D, eb = t.embedding_dim, t.bytes_per_element
         nfeat = max(1, len(t.feature_names))
         ids = B * nfeat * t.pooling_factor  # lookups of this table issued by ONE rank per step
@@ -356,12 +373,12 @@ class GreedyPartitioner:
             shard.rank = rank
 
         for o in proposal:
-            if o.sharding_type in ("row_wise", "data_parallel"):
+            if o.sharding_type in ("row_wise", "data_parallel", "table_row_wise", "grid_shard"):
                 if len(o.shards) != W:
                     raise PlannerError(f"{o.fqn}: {o.sharding_type} needs one shard per rank")
                 for q, sh in enumerate(o.shards):
                     take(q, sh)
-        singles = [o for o in proposal if o.sharding_type not in ("row_wise", "data_parallel")]
+        singles = [o for o in proposal if o.sharding_type not in ("row_wise", "data_parallel", "table_row_wise", "grid_shard")]
         for o in sorted(singles, key=lambda o: -(o.shards[0].storage.hbm + o.shards[0].storage.ddr)):
             for sh in o.shards:
                 fits = [r for r in range(W) if sh.storage.fits_in(free[r])]
@@ -405,8 +422,13 @@ def plan_tables(tables: Sequence[TableSpec], topology: Topology, batch_size: int
     for o, ranks in best:
         e = {"sharding_type": o.sharding_type, "compute_kernel": o.compute_kernel, "perf": o.total_perf,
              "hbm": o.total_storage.hbm}
-        if o.sharding_type == "row_wise":
+        if o.sharding_type in ("row_wise", "table_row_wise"):
             e.update({"block": max(1, -(-rows[o.fqn] // W)), "rot": 0, "ranks": list(range(W))})
+        elif o.sharding_type == "grid_shard":
+            q4 = o.shards[0].size[1] // 4
+            e.update({"ranks": list(range(W)), "shard_dim": o.shards[0].size[1] // max(c for c in range(1, min(W, q4) + 1) if q4 % c == 0)})
+        elif o.sharding_type == "table_column_wise":
+            e.update({"ranks": list(ranks), "shard_dim": o.shards[0].size[1]})
         elif o.sharding_type == "table_wise":
             e.update({"block": max(1, rows[o.fqn]), "rot": ranks[0], "ranks": [ranks[0]]})
         elif o.sharding_type == "column_wise":

@@ -791,7 +791,9 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
     for the few tables that are too wide for one rank's link, not for everything.
 
     `plan[table]["sharding_type"] == "column_wise"` (with `ranks` = owner of every column shard) or
-    `constraints[table] = "column_wise"` selects it.  `forward_grouped` / `fused_optimizer` /
+    `constraints[table] = "column_wise"` selects it.  torchrec's hierarchical types are accepted with their
+    single-node meaning: `table_row_wise` = `row_wise`, `table_column_wise` = `column_wise`, `grid_shard` =
+    column shards that are each row-wise over the node's ranks.  `forward_grouped` / `fused_optimizer` /
     `table_weights` / `plan` as in the one-dim collection; the three-phase pipeline API is per lane."""
 
     def __init__(self, tables: Sequence[EmbeddingBagConfig], device: torch.device, optimizer: Optional[SparseOptimizerConfig] = None,
@@ -814,6 +816,7 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
         block_of = {(f, cfg.name): (f if len(feat_tables[f]) == 1 else f"{f}@{cfg.name}") for cfg in self._tables for f in cfg.feature_names}
         # -- column-wise tables -> table-wise column shards ----------------------------------------
         self._cw: Dict[str, List[str]] = {}
+        self._grid: set = set()
         virt: List[EmbeddingBagConfig] = []
         v_constraints: Dict[str, str] = {}
         v_plan: Optional[Dict[str, dict]] = {} if plan is not None else None
@@ -824,13 +827,34 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
             if plan is not None and entry is None:
                 raise ValueError(f"sharding plan has no entry for {cfg.name}")
             kind = entry["sharding_type"] if entry is not None else constraints.get(cfg.name)
+            # torchrec's hierarchical types on ONE node (every rank is a local rank): table_row_wise = rows of a
+            # table over the ranks of its host = row_wise; table_column_wise = column shards on the ranks of one
+            # host = column_wise; grid_shard = column shards, each row-wise over a host = column shards that are
+            # row-wise tables instead of table-wise ones (feature.proto:8)
+            grid = kind == "grid_shard"
+            if kind == "table_row_wise":
+                kind = "row_wise"
+                if entry is not None:
+                    entry = dict(entry, sharding_type="row_wise", block=entry.get("block", max(1, -(-cfg.num_embeddings // self.W))),
+                                 rot=entry.get("rot", 0), ranks=entry.get("ranks", list(range(self.W))))
+                else:
+                    constraints[cfg.name] = "row_wise"
+            if kind in ("table_column_wise", "grid_shard"):
+                kind = "column_wise"
             if kind == "column_wise":
                 D = cfg.embedding_dim
-                k = len(entry["ranks"]) if entry is not None and entry.get("ranks") else _column_shards(D, self.W)
+                if entry is not None and entry.get("shard_dim"):
+                    k = D // int(entry["shard_dim"])
+                elif entry is not None and entry.get("ranks") and not grid:
+                    k = len(entry["ranks"])
+                else:
+                    k = _column_shards(D, self.W)
                 if k < 1 or D % k or (D // k) % 4:
                     raise ValueError(f"{cfg.name}: {k} column shards of a dim-{D} table (shard width must be a multiple of 4)")
                 d = D // k
                 self._cw[cfg.name] = []
+                if grid:
+                    self._grid.add(cfg.name)
                 for j in range(k):
                     def init(w, cfg=cfg, j=j, d=d):  # noqa: E306
                         full = torch.empty(cfg.num_embeddings, cfg.embedding_dim)
@@ -844,7 +868,13 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
                     virt.append(EmbeddingBagConfig(name, d, cfg.num_embeddings, list(cfg.feature_names), cfg.pooling, init,
                                                    data_type=cfg.data_type))
                     self._cw[cfg.name].append(name)
-                    if v_plan is not None:
+                    if grid:  # every column shard is itself row-wise over the node
+                        if v_plan is not None:
+                            v_plan[name] = {"sharding_type": "row_wise", "block": max(1, -(-cfg.num_embeddings // self.W)), "rot": 0,
+                                            "ranks": list(range(self.W))}
+                        else:
+                            v_constraints[name] = "row_wise"
+                    elif v_plan is not None:
                         v_plan[name] = {"sharding_type": "table_wise", "block": cfg.num_embeddings, "rot": int(entry["ranks"][j]),
                                         "ranks": [int(entry["ranks"][j])]}
                     else:
@@ -913,8 +943,11 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
         for cfg in self._tables:
             if cfg.name in self._cw:
                 shards = self._cw[cfg.name]
-                out[cfg.name] = {"sharding_type": "column_wise", "ranks": [self._vplan[s]["ranks"][0] for s in shards],
-                                 "shard_dim": cfg.embedding_dim // len(shards)}
+                if cfg.name in self._grid:
+                    out[cfg.name] = {"sharding_type": "grid_shard", "ranks": list(range(self.W)), "shard_dim": cfg.embedding_dim // len(shards)}
+                else:
+                    out[cfg.name] = {"sharding_type": "column_wise", "ranks": [self._vplan[s]["ranks"][0] for s in shards],
+                                     "shard_dim": cfg.embedding_dim // len(shards)}
             else:
                 out[cfg.name] = self._vplan[cfg.name]
         return out
