@@ -535,7 +535,12 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     _lib.use_library(emu_path)
     dev = torch.device("cpu")
     text = open(os.path.join(os.path.dirname(__file__), "golden", cfg_name)).read()
-    if constraints_in_config:
+    if constraints_in_config and cfg_name == "din_mini.config":
+        # a sequence sub-feature pinned table-wise by its own feature config
+        text = text.replace('features { id_feature { feature_name: "adgroup_id" num_buckets: 300 embedding_dim: 16 } }',
+                            'features { id_feature { feature_name: "adgroup_id" num_buckets: 300 embedding_dim: 16 '
+                            'embedding_constraints { sharding_types: "table_wise" } } }', 1)
+    elif constraints_in_config:
         # the placement comes from the config alone: a feature-level `embedding_constraints` (both tables that
         # feature creates) and `train_config.global_embedding_constraints` for the rest -> the planner
         text = text.replace('feature_name: "cat_0" num_buckets: 1000 embedding_dim: 16',
@@ -547,7 +552,12 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     torch.manual_seed(11)
     from torcheasyrec_amd.sharding import make_plan
 
-    if constraints_in_config:
+    if constraints_in_config and cfg_name == "din_mini.config":
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD)
+        seq_plan = shd.embedding_group.ecs["16"].sharded.plan()
+        assert seq_plan["click_seq__adgroup_id_emb"]["sharding_type"] == "table_wise" and len(seq_plan["click_seq__adgroup_id_emb"]["ranks"]) == 1
+        assert seq_plan["click_seq__cate_id_emb"]["sharding_type"] == "row_wise"
+    elif constraints_in_config:
         shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD)
         sp = shd.embedding_group.ebc.sharding_plan()
         assert sp["cat_0_emb"]["sharding_type"] == "column_wise" and sp["cat_0_emb"]["shard_dim"] == 8 and len(sp["cat_0_emb"]["ranks"]) == 2
@@ -665,7 +675,7 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
 
 
 @pytest.mark.parametrize("cfg,labels,in_config", [("din_mini.config", ["clk"], False), ("deepfm_mini.config", ["label"], False),
-                                                  ("deepfm_mini.config", ["label"], True)])
+                                                  ("deepfm_mini.config", ["label"], True), ("din_mini.config", ["clk"], True)])
 def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config), nprocs=2, join=True)

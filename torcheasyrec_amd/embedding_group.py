@@ -264,6 +264,7 @@ class EmbeddingGroup(nn.Module):
 
         self._seq_info: "OrderedDict[str, dict]" = OrderedDict()
         by_dim: Dict[int, "OrderedDict[str, EmbeddingConfig]"] = {}
+        seq_constraints: Dict[str, str] = {}
         for g in self._seq_groups:
             q, sq = [], []
             for fname in g.feature_names:
@@ -279,6 +280,14 @@ class EmbeddingGroup(nn.Module):
                             cfgs[t].feature_names.append(fname)
                     else:
                         cfgs[t] = EmbeddingConfig(t, f.embedding_dim, f.num_embeddings, [fname])
+                        allowed = list(getattr(f, "sharding_types", None) or self._global_sharding_types)
+                        if allowed:  # the unpooled exchange places a table row-wise (default) or table-wise
+                            ok = [k for k in allowed if k in ("row_wise", "table_wise", "table_row_wise")]
+                            if not ok:
+                                raise ValueError(f"sequence table {t}: sharding types {allowed} are not executable for unpooled "
+                                                 "lookups (row_wise or table_wise)")
+                            if "row_wise" not in ok and "table_row_wise" not in ok:
+                                seq_constraints[t] = "table_wise"
             if not sq:
                 raise ValueError(f"sequence group {g.group_name} has no sequence feature")
             self._seq_info[g.group_name] = {
@@ -288,8 +297,9 @@ class EmbeddingGroup(nn.Module):
         if self._pg is not None:
             from .sequence import ShardedEmbeddingCollection
 
-            self.ecs = nn.ModuleDict({str(d): ShardedEmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
-                                                                         process_group=self._pg) for d, c in by_dim.items()})
+            self.ecs = nn.ModuleDict({str(d): ShardedEmbeddingCollection(
+                list(c.values()), device=device, optimizer=sparse_optimizer, process_group=self._pg,
+                constraints={t: k for t, k in seq_constraints.items() if t in c} or None) for d, c in by_dim.items()})
         else:
             self.ecs = nn.ModuleDict({str(d): EmbeddingCollection(list(c.values()), device=device, optimizer=sparse_optimizer,
                                                                   row_layout=row_layout) for d, c in by_dim.items()})
