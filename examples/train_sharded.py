@@ -18,7 +18,7 @@ from torcheasyrec_amd import _lib  # noqa: E402
 from torcheasyrec_amd.config import load_pipeline_spec  # noqa: E402
 from torcheasyrec_amd.dense import FusedDenseAdam  # noqa: E402
 from torcheasyrec_amd.embedding_group import TrainPipeline  # noqa: E402
-from torcheasyrec_amd.planner import TableSpec, Topology, plan_tables, plan_to_json  # noqa: E402
+from torcheasyrec_amd.planner import plan_to_json  # noqa: E402
 from torcheasyrec_amd.rank_model import build_rank_model  # noqa: E402
 
 
@@ -33,19 +33,12 @@ def main(path):
     _lib.use_native()
     spec = load_pipeline_spec(open(path).read())
     bs = spec.batch_size or 1024
-    # placement: the DP planner over the pooled tables of the config (every rank computes the same plan)
-    pooled = {}
-    for g in spec.feature_groups:
-        if g.group_type != "SEQUENCE":
-            for n in g.feature_names:
-                f = next(x for x in spec.features if x.name == n)
-                if f.is_sparse:
-                    pooled[f.embedding_name or f"{f.name}_emb"] = TableSpec(f.embedding_name or f"{f.name}_emb", f.num_embeddings,
-                                                                           f.embedding_dim, [f.name])
-    plan = plan_tables(list(pooled.values()), Topology(world), bs) if world > 1 else None
-    if rank == 0 and plan is not None:
-        print(plan_to_json(plan))
-    model = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan)
+    # placement: the DP planner over the pooled tables of the config, under its `embedding_constraints` /
+    # `global_embedding_constraints` if it has any (every rank computes the same plan; tzrec/main.py:783-799)
+    model = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, use_planner=world > 1)
+    ebc = model.embedding_group.ebc
+    if rank == 0 and ebc is not None and world > 1:
+        print(plan_to_json(ebc.sharding_plan() if hasattr(ebc, "sharding_plan") else ebc.plan()))
     opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
     pipe = TrainPipeline(model, opt, dev, model.loss)
     it = iter(synthetic_batches(spec, 20 * bs, bs, seed=rank))

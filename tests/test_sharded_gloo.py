@@ -553,7 +553,8 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     from torcheasyrec_amd.sharding import make_plan
 
     if constraints_in_config and cfg_name == "din_mini.config":
-        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD)
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, use_planner=True)
+        assert all("perf" in p for p in shd.embedding_group.ebc.plan().values())  # the pooled tables were placed by the planner
         seq_plan = shd.embedding_group.ecs["16"].sharded.plan()
         assert seq_plan["click_seq__adgroup_id_emb"]["sharding_type"] == "table_wise" and len(seq_plan["click_seq__adgroup_id_emb"]["ranks"]) == 1
         assert seq_plan["click_seq__cate_id_emb"]["sharding_type"] == "row_wise"

@@ -116,6 +116,7 @@ class EmbeddingGroup(nn.Module):
         dp_max_rows: int = 65536,
         global_sharding_types: Sequence[str] = (),
         batch_size: int = 1024,
+        use_planner: bool = False,
     ) -> None:
         """`process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
         the reference, tzrec/main.py:783-804): pooled tables go to a ShardedEmbeddingBagCollection
@@ -191,7 +192,7 @@ class EmbeddingGroup(nn.Module):
         ebc_groups = {g: ks for g, ks in ebc_groups.items() if ks}
         self._sharded_zch = None
         if self.has_sparse and self._pg is not None and self._plan_in is None and not zch_blocks \
-                and (self._table_sharding_types or self._global_sharding_types):
+                and (self._table_sharding_types or self._global_sharding_types or use_planner):
             # `embedding_constraints` / `global_embedding_constraints` of the config -> the planner picks among the
             # allowed types per table (tzrec/main.py:783-799; per-table constraints win over the global ones)
             import torch.distributed as dist

@@ -25,6 +25,7 @@ class RankModel(nn.Module):
     # parameters data-parallel (the DistributedModelParallel seam, tzrec/main.py:783-804)
     _build_pg = None
     _build_plan = None
+    _build_use_planner = False
 
     def __init__(self, spec: PipelineSpec, device: Optional[torch.device], sparse_optimizer: Optional[SparseOptimizerConfig]) -> None:
         super().__init__()
@@ -35,7 +36,8 @@ class RankModel(nn.Module):
             spec.features, spec.feature_groups, wide_embedding_dim=spec.wide_embedding_dim or None,
             device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer,
             process_group=self._pg, plan=RankModel._build_plan,
-            global_sharding_types=getattr(spec, "global_sharding_types", ()), batch_size=spec.batch_size or 1024)
+            global_sharding_types=getattr(spec, "global_sharding_types", ()), batch_size=spec.batch_size or 1024,
+            use_planner=RankModel._build_use_planner)
 
     def sync_dense_parameters(self) -> None:
         """Same dense parameters on every rank (DDP broadcasts rank 0's at construction)."""
@@ -267,16 +269,18 @@ _MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": Config
 
 
 def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None, process_group=None,
-                     plan: Optional[Dict[str, dict]] = None) -> RankModel:
+                     plan: Optional[Dict[str, dict]] = None, use_planner: bool = False) -> RankModel:
     """Class chosen by the model_config oneof name, as tzrec/main.py:151-153 does.  With
     `process_group` the embedding tables are sharded over its ranks (`plan`: planner.plan_tables output
-    or None for the size heuristic) and the dense parameters are kept identical across ranks."""
+    or None: the planner under the config's `embedding_constraints` / `global_embedding_constraints` when it has
+    any or when `use_planner` is set, else the size heuristic) and the dense parameters are kept identical across
+    ranks."""
     if spec.model_name not in _MODELS:
         raise NotImplementedError(f"model {spec.model_name!r} is outside SURVEY.md section 8")
-    RankModel._build_pg, RankModel._build_plan = process_group, plan
+    RankModel._build_pg, RankModel._build_plan, RankModel._build_use_planner = process_group, plan, use_planner
     try:
         model = _MODELS[spec.model_name](spec, device, sparse_optimizer)
     finally:
-        RankModel._build_pg, RankModel._build_plan = None, None
+        RankModel._build_pg, RankModel._build_plan, RankModel._build_use_planner = None, None, False
     model.sync_dense_parameters()
     return model
