@@ -10,6 +10,9 @@ timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?";
 if [ -z "${SKIP_EXTRA:-}" ]; then  # SKIP_EXTRA=1: only the default line (when GPU minutes are short)
 timeout 300 python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_b8192.json 2>> $O/bench.err; echo "bench b8192 rc=$?"
 timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline 2>> $O/bench.err | tail -1 > $O/sharded_w1_proxy_bench.json; echo "sharded proxy rc=$?"
+# delta-embedding tracker: the default line with every lookup recorded, and the tracker on its own
+timeout 300 python bench.py --delta-tracker --no-cpu-baseline > $O/bench_delta_tracker.json 2>> $O/bench.err; echo "bench delta-tracker rc=$?"
+timeout 300 python scripts/bench_delta.py > $O/bench_delta.txt 2>> $O/bench.err; echo "bench_delta rc=$?"; cat $O/bench_delta.txt
 fi
 cd /tmp
 # tuning stays on: the shipped table covers every shape of this run, so no candidate kernels appear
