@@ -726,19 +726,24 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
         sh = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups, dp_max_rows=10,
                                                 constraints={"cw_c": "column_wise", "deep_a": "table_wise"})
     plan = sh.sharding_plan()
+    cw_d = 16 // min(world, 4)  # column shard width: 16 / (largest k <= world with 16 / k a multiple of 4)
     if grid:
         plan = dict(plan, cw_c=dict(plan["cw_c"], sharding_type="column_wise"))
-    assert set(sh.plan()) == {"wide_a", "wide_b", "deep_a", "deep_b", "cw_c@cw0", "cw_c@cw1", "tiny"}
-    assert plan["cw_c"]["sharding_type"] == "column_wise" and plan["cw_c"]["shard_dim"] == 8
-    assert planner or sorted(plan["cw_c"]["ranks"]) == [0, 1]  # the heuristic puts the two column shards on different ranks
+    assert set(sh.plan()) == {"wide_a", "wide_b", "deep_a", "deep_b", "tiny"} | {f"cw_c@cw{j}" for j in range(16 // cw_d)}
+    assert plan["cw_c"]["sharding_type"] == "column_wise" and plan["cw_c"]["shard_dim"] == cw_d
+    assert planner or sorted(plan["cw_c"]["ranks"]) == list(range(16 // cw_d))  # the heuristic spreads the column shards over the ranks
     if grid:
         assert sh.sharding_plan()["wide_b"]["sharding_type"] == "row_wise"  # table_row_wise on one node
     assert plan["tiny"]["sharding_type"] == "data_parallel" and plan["deep_a"]["sharding_type"] == "table_wise"
-    assert plan["wide_b"]["sharding_type"] == "row_wise" and len(sh.lanes) == 4  # dims 4, 16, and one dim-8 lane per column shard of feature c
+    assert plan["wide_b"]["sharding_type"] == "row_wise"
+    # world 2: dims 4, 16, and one dim-8 lane per column shard of feature c; world 4: the first dim-4 column shard rides
+    # in the wide tables' lane (same dim, feature c is not in it), the other three get their own
+    assert len(sh.lanes) == (4 if world == 2 else 5)
     ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups=groups)
     keys, rows = ["a", "b", "c", "d"], [50, 301, 120, 7]
     rng = np.random.default_rng(1)
-    Bg, Bl = 24, 12
+    Bg = 24
+    Bl = Bg // world
     if jagged:
         lens = rng.integers(0, 4, size=(4, Bg)).astype(np.int32)
     else:
@@ -775,14 +780,14 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
             for j, shard in enumerate(sh.column_shards(name)):
                 lo, n = sh.shard_of(shard)
                 assert grid or n in (0, r)  # a column shard is a whole table on one rank (grid: row-wise over both)
-                torch.testing.assert_close(w[shard].detach()[:n], w_ref[name][lo:lo + n, j * 8:(j + 1) * 8], rtol=1e-5, atol=1e-7, msg=shard)
+                torch.testing.assert_close(w[shard].detach()[:n], w_ref[name][lo:lo + n, j * cw_d:(j + 1) * cw_d], rtol=1e-5, atol=1e-7, msg=shard)
         else:
             lo, n = sh.shard_of(name)
             torch.testing.assert_close(w[name].detach()[:n], w_ref[name][lo:lo + n], rtol=1e-5, atol=1e-7, msg=name)
     fresh = torch.empty(120, 16)
     seeded(4)(fresh)
     assert not torch.equal(w_ref["cw_c"], fresh)  # the step moved the table
-    if not jagged and not planner and not grid:
+    if not jagged and not planner and not grid and world == 2:
         # checkpoint: tables are persisted as the runtime holds them (column shards `cw_c@cw<j>`) and come
         # back under a different placement of the other tables
         from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
@@ -829,3 +834,17 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
 def test_mixed_dims_and_column_wise_world2(emu_path, jagged, planner, grid):
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_mixed_worker, args=(2, os.path.join(d, "init"), emu_path, jagged, planner, grid), nprocs=2, join=True)
+
+
+def test_mixed_dims_and_column_wise_world4(emu_path):
+    """four ranks: four dim-4 column shards on four ranks, one of them sharing the wide tables' lane"""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_mixed_worker, args=(4, os.path.join(d, "init"), emu_path, True, False, False), nprocs=4, join=True)
+
+
+@pytest.mark.parametrize("world,mode,via_step,planner", [(4, "uniform1", False, False), (8, "jagged", True, True)])
+def test_sharded_dlrm_more_ranks(emu_path, world, mode, via_step, planner):
+    """the world sizes the scaling bench runs on hardware (1, 2, 4, 8): same worker, same oracle checks"""
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step, planner), nprocs=world, join=True)
