@@ -45,7 +45,7 @@ def _collect(dev, bitmap, rows, id_base=0, clear=0, capacity=None):
     return n, out[:cap].cpu().numpy()
 
 
-@pytest.mark.parametrize("rows", [[1, 31, 33, 1000], [300000, 64, 131072 + 5]])
+@pytest.mark.parametrize("rows", [[1, 31, 33, 1000], [64, 131072 + 5]])
 def test_bitmap_kernels_match_set_semantics(dev, rows):
     """mark (KJT addressing: offsets with stride B) -> words == oracle bitmap; count / collect == np.unique;
     ids outside the table are counted, never marked; clear zeroes exactly what was read."""
