@@ -14,9 +14,10 @@ from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerCo
 _lib.use_library(_build.build())
 dev = torch.device("cuda", 0)
 dist = sys.argv[1] if len(sys.argv) > 1 else "uniform"
-ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=1e-3),
+ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev, optimizer=SparseOptimizerConfig(kind=(sys.argv[3] if len(sys.argv) > 3 else "adagrad"), lr=1e-3),
                              groups={"sparse": SPARSE_KEYS})
-B = 65536
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+opt_kind = sys.argv[3] if len(sys.argv) > 3 else "adagrad"
 batches = [synthetic_batch(s, B, CRITEO_ROWS, dist=dist)[1].to(dev) for s in range(4)]
 g = torch.randn(B, 416, device=dev) * 1e-3
 torch.cuda.synchronize()

@@ -23,8 +23,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    deps = _sources() + [
-        os.path.join(CSRC, "tzr_common.h"),
+    deps = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
         os.path.join(ROOT, "include", "tzrec_hip.h"),
         os.path.join(HERE, "hip", "hip_runtime.h"),
     ]

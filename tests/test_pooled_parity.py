@@ -30,7 +30,8 @@ def _make_tables(spec, seed=0):
     return cfgs, inits
 
 
-def _make_kjt(keys, rows_per_key, B, rng, mode="uniform1", weighted=False):
+def _make_kjt(keys, rows_per_key, B, rng, mode="uniform1", weighted=False, idgen=None):
+    """idgen(rng, rows, n) -> int64[n] overrides the uniform id draw (hot rows, narrow ranges)."""
     vals, lens = [], []
     for k, rows in zip(keys, rows_per_key):
         if mode == "uniform1":
@@ -43,7 +44,10 @@ def _make_kjt(keys, rows_per_key, B, rng, mode="uniform1", weighted=False):
         else:
             raise ValueError(mode)
         lens.append(L)
-        vals.append(rng.integers(0, rows, size=int(L.sum())).astype(np.int64))
+        if idgen is not None:
+            vals.append(np.asarray(idgen(rng, rows, int(L.sum())), dtype=np.int64))
+        else:
+            vals.append(rng.integers(0, rows, size=int(L.sum())).astype(np.int64))
     values = torch.from_numpy(np.concatenate(vals))
     lengths = torch.from_numpy(np.concatenate(lens))
     weights = None
@@ -168,7 +172,7 @@ def test_forward_grouped_deepfm_layout(dev):
 
 
 def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups=None, steps=2, seed=3,
-                       rtol=2e-5):
+                       rtol=2e-5, idgen=None):
     rng = np.random.default_rng(seed)
     cfgs, inits = _make_tables(spec)
     ebc = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt_cfg, groups=groups)
@@ -189,7 +193,7 @@ def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups
                            beta1=opt_cfg.beta1, beta2=opt_cfg.beta2)
     pool_of = {name: pooling for name, _, _, pooling, _ in spec}
     for step in range(steps):
-        kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted)
+        kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted, idgen=idgen)
         kd = kjt.to(dev)
         if groups is None:
             out = ebc(kd).values()
@@ -267,6 +271,90 @@ def test_backward_long_runs(dev):
     # whole-chunk piece, trailing piece), the 3-row table's runs cross chunk and wave-range boundaries
     spec = [("t_one", 1, 16, "sum", ["c0"]), ("t_tiny", 3, 16, "sum", ["c1"])]
     _run_backward_case(dev, spec, ["c0", "c1"], [1, 3], 2600, "uniform1", False, opt, steps=1, rtol=5e-4)
+
+
+def _hot(frac, hot_ids):
+    """a fraction of the lookups hits a few hot rows (Zipf head / default id), the rest is uniform"""
+    def gen(rng, rows, n):
+        ids = rng.integers(0, rows, size=n)
+        hot = rng.random(n) < frac
+        ids[hot] = rng.choice(np.asarray(hot_ids) % rows, size=int(hot.sum()))
+        return ids
+    return gen
+
+
+def _narrow(lo, width):
+    """every id inside [lo, lo + width): many distinct rows in one or two buckets"""
+    return lambda rng, rows, n: lo % rows + rng.integers(0, min(width, rows), size=n)
+
+
+# (rows, B, id generator, also on the CPU lane emulator): what the plan's bucket partition, the
+# unit-local sort and the heavy kernel see.  The emulator runs the cheap half (one OS thread per lane).
+PLAN_CASES = {
+    "just_over_exact": (600, 700, None, True),                     # 513..1024 rows: 1-2 row ids per bucket
+    "light_units": (70000, 2100, None, True),                      # ~4 lookups per bucket, 3 units, 2 local passes
+    "three_pass": (1 << 22, 1100, None, True),                     # 2 units spanning ~21 bits of row id
+    "wide_rows": (40_000_000, 1500, None, False),                  # ~25 bits: 4 local passes
+    "hot_one_tile": (70000, 1500, _hot(0.45, [31337]), True),      # one heavy bucket < one heavy tile, rest light
+    "hot_two_in_bucket": (200000, 1800, _hot(0.6, [5000, 5001, 5003]), False),  # heavy bucket with 3 hot rows
+    "hot_multi_tile": (1 << 20, 3300, _hot(0.75, [777777]), True), # heavy bucket of ~2500 = 2 tiles, 3 unit slices
+    "hot_many_tiles": (1 << 20, 40000, _hot(0.5, [777777, 12]), False),  # two heavy buckets of ~10000
+    "narrow_dense": (1 << 22, 3000, _narrow(123456, 3000), False), # one bucket, ~1900 distinct rows, 12 bits inside
+    "narrow_two_buckets": (1 << 22, 1400, _narrow(8192 * 3 - 300, 700), True),  # straddles a bucket boundary
+}
+
+
+@pytest.mark.parametrize("case", sorted(PLAN_CASES))
+def test_backward_plan_shapes(dev, case):
+    """The backward plan on id distributions that exercise each of its paths (pooled_bwd.hip): exact
+    vs bucketed tables, units made of light buckets, heavy buckets (hot rows) sorted by the heavy
+    kernel in one and in several tiles, units mixing slices of heavy buckets with light ones."""
+    rows, B, idgen, on_emu = PLAN_CASES[case]
+    if dev.type == "cpu" and not on_emu:
+        pytest.skip("GPU-only size")
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.05, initial_accumulator_value=0.1)
+    spec = [("t_a", rows, 16, "sum", ["c0"]), ("t_small", 40, 16, "sum", ["c1"])]
+    # hot rows sum thousands of random-sign gradients: order-of-summation noise as in test_backward_long_runs
+    rtol = 5e-4 if case.startswith("hot") else 2e-5
+    _run_backward_case(dev, spec, ["c0", "c1"], [rows, 40], B, "uniform1", False, opt, steps=1, rtol=rtol,
+                       idgen=(lambda rng, r, n: idgen(rng, r, n) if (idgen and r == rows) else rng.integers(0, r, size=n)))
+
+
+def test_backward_plan_shared_jagged_hot(dev):
+    """two keys share a bucketed table, jagged bags, a hot row: table-major regrouping + bag_of + heavy"""
+    opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.02)
+    spec = [("u_emb", 50000, 8, "sum", ["user", "user_hist"]), ("i_emb", 3000, 16, "mean", ["item"])]
+    gen = _hot(0.5, [4242])
+    _run_backward_case(dev, spec, ["item", "user", "user_hist"], [3000, 50000, 50000], 300, "jagged", True, opt,
+                       steps=1, rtol=5e-4, idgen=gen)
+
+
+def test_backward_plan_prep_fallback(dev):
+    """more than BWD_GEO lookups/tables take the single-workgroup geometry kernel: forced here"""
+    from torcheasyrec_amd import _lib
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.05)
+    assert _lib.lib().tzr_tune(b"bwd_force_prep", 1) == 0
+    try:
+        _run_backward_case(dev, SPEC_MIXED, ["ctx", "item", "unused_key", "user", "user_hist", "wide_user"],
+                           [40, 57, 10, 1000, 1000, 1000], 45, "jagged", False, opt, steps=1)
+    finally:
+        _lib.lib().tzr_tune(b"bwd_force_prep", 0)
+
+
+def test_backward_plan_is_bit_reproducible(dev):
+    """same ids, same gradients -> bit-identical weights, hot rows and heavy buckets included"""
+    rng = np.random.default_rng(5)
+    rows, B = 100000, 1500
+    ids = _hot(0.5, [99, 12345])(rng, rows, B)
+    kjt = KeyedJaggedTensor(["a"], torch.from_numpy(ids.astype(np.int64)), torch.ones(B, dtype=torch.int32), uniform_length=1)
+    g = torch.randn(B, 16, generator=torch.Generator().manual_seed(1))
+    outs = []
+    for _ in range(2):
+        cfgs, _ = _make_tables([("t", rows, 16, "sum", ["a"])])
+        ebc = EmbeddingBagCollection(cfgs, device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+        (ebc(kjt.to(dev)).values() * g.to(dev)).sum().backward()
+        outs.append(ebc.table_weights()["t"].detach().cpu().clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("kind,weighted", [("adagrad", False), ("rowwise_adagrad", True)])

@@ -20,8 +20,8 @@ def sources():
 
 def _digest() -> str:
     h = hashlib.sha256()
-    deps = sources() + [os.path.join(CSRC, "tzr_common.h"),
-                        os.path.join(os.path.dirname(_HERE), "include", "tzrec_hip.h")]
+    deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(os.path.dirname(_HERE), "include", "tzrec_hip.h")]
     for p in deps:
         with open(p, "rb") as f:
             h.update(f.read())

@@ -4,9 +4,13 @@
 // {warp,cta}_per_row_1 (optimizer fused into backward by apply_optimizer_in_backward,
 // /root/reference/tzrec/main.py:774-781).
 //
-// Input: the plan of pooled_bwd.hip -- per table, lookups sorted by (row, original position).
-// A workgroup owns one chunk of BWD_CH sorted positions (keys + sources staged once in LDS,
-// coalesced); each of its 4 waves reduces a range of BWD_RANGE positions tile by tile:
+// Input: the plan of pooled_bwd.hip -- per table, lookups partitioned into buckets of consecutive
+// row ids, heavy buckets already sorted by (row, original position).
+// A workgroup owns one UNIT of the table's sorted positions (< BWD_CH + BWD_TH lookups: whole light
+// buckets and/or block-sized slices of heavy ones).  It first finishes the order of its light
+// buckets in LDS (stable counting passes on the row-id bits left inside the unit -- the passes 2
+// and 3 of round 1's global radix sort, now without leaving the CU), then each of its 4 waves
+// reduces a quarter of the unit tile by tile:
 //   * a tile = 64/(D/4) consecutive sorted lookups, one per lane group: ALL gradient gathers of a
 //     tile are independent loads in flight together (the HBM/MALL latency is paid once per tile,
 //     not once per duplicate);
@@ -16,8 +20,8 @@
 //     (weights + optimizer state).  Exactly one lane group in the whole grid touches a given row:
 //     no atomics, no cross-XCD L2 coherence hazard.
 //   * runs crossing a wave range are stitched through LDS records by wave 0, runs crossing a
-//     chunk through per-chunk records by tzr_bwd_stitch_kernel (a 65536-lookup run of a 3-row
-//     table is 32 chunk records long).
+//     unit (only possible inside a heavy bucket or an exact table) through per-unit records by
+//     tzr_bwd_stitch_kernel (a 65536-lookup run of a 3-row table is 32 unit records long).
 #include "pooled_bwd.h"
 
 struct BwdGrads {
@@ -225,31 +229,130 @@ __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const Bwd
   bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
 
+// Scratch of the reduce kernel: the unit-local sort and the boundary records of the wave ranges are
+// never live together.
+struct BwdReduceSort {
+  uint32_t pk[BWD_UMAX], ps[BWD_UMAX];  // ping-pong of the unit-local passes
+  BwdRankLds<BWD_LNB> L;
+};
+struct BwdReduceRec {
+  float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
+};
+union BwdReduceLds {
+  BwdReduceSort sort;
+  BwdReduceRec rec;
+};
+
 template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  __shared__ uint32_t sK[BWD_CH + 2];  // K[s-1], K[s..e), K[e] (sentinels at table ends)
-  __shared__ uint32_t sS[BWD_CH];
+  __shared__ uint32_t sK[BWD_UMAX + 2];  // K[s-1], K[s..e), K[e] (sentinels at table ends)
+  __shared__ uint32_t sS[BWD_UMAX];
   __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
-  __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
+  __shared__ uint32_t smm[2 * BWD_WAVES];
+  __shared__ BwdReduceLds U;
   __shared__ TzrDst sG[TZR_MAX_DST];
+  float (*rlead)[BWD_MAXDIM] = U.rec.rlead;
+  float (*rtrail)[BWD_MAXDIM] = U.rec.rtrail;
   BwdChunkDesc cd;
   if (!bwd_chunk(P, blockIdx.x, &cd)) return;
   const int t = cd.t;
-  const int64_t s = cd.s, e = cd.e, ts = cd.ts, te = cd.te;
-  const TzrTable tb = tables[t];
-  const int par = cd.npass & 1;
-  // selects, not P.ks[par]: a runtime index into the by-value plan spills it to scratch
-  const uint2* __restrict__ KS = par ? P.ks[1] : P.ks[0];
+  const int64_t ts = cd.ts, te = cd.te;
+  // the unit: sorted positions [s, e) of the table (pooled_bwd.hip, scan kernel)
+  const int64_t s = P.ucut[blockIdx.x];
+  const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)P.ucut[blockIdx.x + 1] : te;
   const int n = (int)(e - s);
-  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-    const uint2 v = KS[s + i];
-    sK[i + 1] = v.x;
-    sS[i] = v.y;
+  if (n <= 0 || n > BWD_UMAX) {  // an empty tail unit (n > BWD_UMAX cannot happen by construction)
+    if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;
+    return;
+  }
+  const TzrTable tb = tables[t];
+  const uint2* __restrict__ KS = P.ks[1];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  if (P.uflag[blockIdx.x]) {  // exact table or a slice of a heavy bucket: already in final order
+    for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+      const uint2 v = KS[s + i];
+      sK[i + 1] = v.x;
+      sS[i] = v.y;
+    }
+  } else {
+    // Whole light buckets (plus, possibly, sorted slices of heavy ones at either end), each bucket
+    // a contiguous range of row ids in bucket order: a stable LSD sort of (row id - smallest row id
+    // of the unit) over the bits that difference needs finishes the order.  Uniform ids at
+    // B = 65536 on a 40M-row table: ~9 buckets of ~128 lookups, 21 bits, 3 passes of 7 bits.
+    constexpr int kRounds = BWD_UMAX / BWD_THREADS;
+    const int pw = bwd_wave_span(n);
+    const int rounds = pw / TZR_WAVE;
+    uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
+    uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      kreg[r] = sreg[r] = 0u;
+      if (r < rounds && lp < n) {
+        vmask |= 1u << r;
+        const uint2 v = KS[s + lp];
+        kreg[r] = v.x;
+        sreg[r] = v.y;
+        kmin = min(kmin, v.x);
+        kmax = max(kmax, v.x);
+      }
+    }
+    for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) {
+      kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, TZR_WAVE));
+      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m, TZR_WAVE));
+    }
+    if (lane == 0) {
+      smm[wv] = kmin;
+      smm[BWD_WAVES + wv] = kmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      kmin = min(kmin, smm[w]);
+      kmax = max(kmax, smm[BWD_WAVES + w]);
+    }
+    const int bits = max(1, bwd_bits(kmax - kmin));
+    const int npass = (bits + BWD_LB - 1) / BWD_LB;
+    const int width = (bits + npass - 1) / npass;
+    const unsigned mask = (1u << width) - 1u;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int shift = pass * width;
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) dig[r] = ((kreg[r] - kmin) >> shift) & mask;
+      bwd_rank_tile<BWD_LNB, kRounds>(dig, vmask, rounds, width, U.sort.L, dest);
+      if (pass == npass - 1) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+          if ((vmask >> r) & 1u) {
+            sK[dest[r] + 1] = kreg[r];
+            sS[dest[r]] = sreg[r];
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+          if ((vmask >> r) & 1u) {
+            U.sort.pk[dest[r]] = kreg[r];
+            U.sort.ps[dest[r]] = sreg[r];
+          }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+          const int lp = wv * pw + r * TZR_WAVE + lane;
+          if ((vmask >> r) & 1u) {
+            kreg[r] = U.sort.pk[lp];
+            sreg[r] = U.sort.ps[lp];
+          }
+        }
+      }
+    }
   }
   if (threadIdx.x == 0) {
+    // the neighbours outside the unit are either in another bucket (another row id) or in the same
+    // heavy bucket, which is sorted in place: comparing with them is always meaningful
     sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
     sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
 #pragma unroll
@@ -259,8 +362,6 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
 
   const int lg = tb.dim >> 2;    // lanes per row
   const int gw = TZR_WAVE / lg;  // lookups per tile
-  const int lane = threadIdx.x & (TZR_WAVE - 1);
-  const int wv = threadIdx.x / TZR_WAVE;
   const int gi = lane / lg;
   const int c = lane - gi * lg;
   const bool lane_on = gi < gw;
@@ -268,8 +369,9 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   const bool single = tb.n_feats == 1;
   const BwdSrc one = bwd_resolve(feats + P.feat_by_order[tb.first_order], sG);
 
-  const int r0 = wv * BWD_RANGE;             // range of this wave, chunk-relative
-  const int r1 = min(n, r0 + BWD_RANGE);
+  const int range = (n + BWD_WAVES - 1) / BWD_WAVES;  // sorted positions reduced by one wave
+  const int r0 = min(n, wv * range);                  // range of this wave, unit-relative
+  const int r1 = min(n, r0 + range);
   unsigned flags = 0;
   const uint32_t leadkey = r0 < r1 ? sK[r0 + 1] : BWD_SENT;
   bool lead_open = r0 < r1 && sK[r0] == leadkey;  // first run started before this range

@@ -4,11 +4,16 @@
 #include "tzr_common.h"
 
 extern int g_tzr_fwd_tile_b;
+extern int g_tzr_bwd_force_prep;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
   if (!strcmp(name, "fwd_tile_b")) {
     g_tzr_fwd_tile_b = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_force_prep")) {
+    g_tzr_bwd_force_prep = value;
     return TZR_OK;
   }
   return TZR_ERR_INVALID;
