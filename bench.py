@@ -5,15 +5,20 @@
 
 One "step" = one full training step of examples/dlrm_criteo.config (26 tables x dim 16, 204M rows,
 fused sparse Adagrad in backward, bottom/top MLPs, dot interaction, BCE, dense Adam) over one
-synthetic Criteo-shaped batch.  Headline workload: batch 65536 PER GPU (tzrec's batch_size is per
-rank: weak scaling; `--scaling strong` fixes the global batch at 65536 instead) with inputs already
-resident in HBM.  Rank 0 prints ONE JSON line.
+synthetic Criteo-shaped batch.  Headline workload: GLOBAL batch 65536, i.e. 65536/N
+per rank (8192 at N = 8 = `batch_size: 8192` of the config) -- strong scaling; at N > 1 the weak
+reading at 8192 per rank is timed as well and reported under `secondary` (`--scaling weak` makes
+--global-batch the per-rank batch instead).  Inputs are resident in HBM.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      HBM roofline of the dominant embedding kernel (pooled gather forward), achieved =
-                algorithmic bytes of one launch / average launch duration from HIP events recorded
-                around the launch inside the timed steps; peak 8.0 TB/s.
-  embedding     the north-star figure: algorithmic fwd+bwd bytes / (fwd + plan + apply time).
+  roofline      the north-star quantity: HBM roofline of the pooled embedding forward + backward
+                (gather kernel, the backward index plan, the fused-optimizer reduce kernel):
+                achieved = algorithmic bytes of fwd + bwd / the sum of the launch
+                durations, HIP events recorded around each C-ABI call on the launching stream; peak
+                8.0 TB/s.  `kernels` lists the three stages with their own bytes, time and fraction
+                (the forward gather and the reduce kernel are the two HBM-bound ones).
+  e2e           the same step driven through TrainPipeline.progress from pinned HOST batches (H2D of
+                the next batch on a copy stream under the current step): the PCIe-inclusive rate.
   cpu_baseline  the CPU oracle ("port") timed on this host on a bounded sample of the workload.
 """
 from __future__ import annotations
@@ -39,12 +44,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", "--batch", dest="global_batch", type=int, default=65536,
-                    help="batch 65536: per rank under weak scaling (default), global under --scaling strong")
-    # tzrec's data_config.batch_size is PER RANK (tzrec/datasets/dataset.py:197,503-508), so
-    # "DLRM-Criteo batch 65536 at 1/2/4/8 GPUs" = 65536 samples per GPU per step: per-GPU work is
-    # fixed as N grows (weak scaling).  --scaling strong keeps the GLOBAL batch at 65536 instead
-    # (BASELINE.md's alternative reading; 8192 per rank at N=8).  At N=1 both are the same run.
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
+                    help="batch 65536: global under strong scaling (default), per rank under --scaling weak")
+    # "samples/s for DLRM-Criteo at GLOBAL batch 65536 on 1/2/4/8 MI355X (per-rank
+    # batch 65536/W, i.e. 8192 at W = 8 -- matches batch_size: 8192 of examples/dlrm_criteo.config;
+    # also report weak scaling at 8192/rank)".  At N = 1 both readings are the same run.
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--weak-per-rank-batch", type=int, default=8192,
+                    help="per-rank batch of the secondary (weak-scaling) reading at N > 1")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the TrainPipeline / pinned-host-batch reading")
+    ap.add_argument("--e2e-steps", type=int, default=20)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--optimizer", choices=["adagrad", "rowwise_adagrad"], default="adagrad")
     ap.add_argument("--row-layout", choices=["interleaved", "split"], default="interleaved")
@@ -118,7 +126,7 @@ def enable_tunable_gemm():
 
 
 def pmc_traffic(args, B_local):
-    """HBM bytes per launch of the pooled forward kernel from the PMC passes kept under profiles/
+    """HBM bytes per step of the six embedding launches from the PMC passes kept under profiles/
     (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, see the file).  Only valid for the
     configuration it was recorded on; null otherwise."""
     import glob
@@ -128,7 +136,7 @@ def pmc_traffic(args, B_local):
         return None
     p = found[-1]
     try:
-        return float(json.load(open(p))["kernels"]["tzr_pooled_fwd_kernel"]["traffic_corrected"])
+        return float(json.load(open(p))["kernels"]["__embedding_fwd_bwd__"]["traffic_corrected"])
     except Exception:
         return None
 
@@ -370,8 +378,8 @@ def main():
     # protocol (untimed warm-up, barrier + synchronize on both sides, max over ranks).
     secondary = None
     B2 = args.secondary_global_batch
-    if B2 is None:
-        B2 = (args.global_batch if args.scaling == "weak" else args.global_batch * world) if world > 1 else 0
+    if B2 is None:  # strong headline -> weak at 8192 per rank; weak headline -> the strong reading
+        B2 = (args.global_batch if args.scaling == "weak" else args.weak_per_rank_batch * world) if world > 1 else 0
     if B2 and train_step is not None and B2 != B_global and B2 % world == 0:
         b2, _ = make_batches(B2, seed0=1000)
         for i in range(max(args.warmup, 4)):
@@ -394,6 +402,47 @@ def main():
             e2 = float(t.item())
         secondary = {"scaling": "strong" if args.scaling == "weak" else "weak", "global_batch": B2, "per_rank_batch": B2 // world,
                      "value": B2 * args.steps / e2, "unit": "samples/s", "ms_per_step": e2 / args.steps * 1e3}
+
+    # The same step through the reference's pipeline seam (pipeline.progress(iterator),
+    # tzrec/main.py:523 -> utils/dist_util.py:221-303): batches start in PINNED HOST memory, the H2D
+    # copy of batch i+1 runs on the copy stream under the step of batch i (372 B/sample = 24 MB per
+    # 65536-sample step).  Eager launches (no hipGraph), so this is also the launch-bound reading.
+    e2e = None
+    if not sharded and not args.no_e2e and args.e2e_steps > 0:
+        from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, TrainPipeline
+        from torcheasyrec_amd.sparse import KeyedTensor
+
+        class _BatchModel(torch.nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, b):
+                return self.m(b.dense_features[BASE_DATA_GROUP].values(), b.sparse_features[BASE_DATA_GROUP])
+
+        host = []
+        for s_ in range(nb):
+            d_, k_, l_ = synthetic_batch(2000 + s_, B_local, rows, dist=args.dist)
+            host.append(Batch({BASE_DATA_GROUP: KeyedTensor([f"int_{i}" for i in range(NUM_DENSE)], [1] * NUM_DENSE, d_)},
+                              {BASE_DATA_GROUP: k_}, {"label": l_}).pin_memory())
+        n_e2e = args.e2e_steps
+        pipe = TrainPipeline(_BatchModel(model), dense_opt, dev,
+                             lambda pred, b: {"bce": bce_with_logits(pred, b.labels["label"])})
+        it = iter([host[i % nb] for i in range(n_e2e + 6)])
+        for _ in range(5):
+            pipe.progress(it)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_e2e):
+            pipe.progress(it)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        h2d = sum(t.numel() * t.element_size() for t in (host[0].dense_features[BASE_DATA_GROUP].values(),
+                                                         host[0].sparse_features[BASE_DATA_GROUP].values(),
+                                                         host[0].sparse_features[BASE_DATA_GROUP].lengths(),
+                                                         host[0].labels["label"]))
+        e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
+               "h2d_bytes_per_step": h2d, "launch": "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     # inside a captured graph); the kernels and inputs are the ones of the timed region
@@ -418,8 +467,8 @@ def main():
     value = B_global * args.steps / elapsed
 
     out = {
-        "metric": "samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch 65536 "
-                  + ("per GPU (tzrec batch_size is per rank)" if args.scaling == "weak" else "global"),
+        "metric": f"samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch {args.global_batch} "
+                  + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -438,24 +487,37 @@ def main():
         fwd_b = float(np.mean([a["fwd"] for a in ab]))
         bwd_b = float(np.mean([a["bwd"] for a in ab]))
         t_fwd, t_plan, t_apply = timers.mean_ms("fwd"), timers.mean_ms("plan"), timers.mean_ms("apply")
-        if t_fwd:
-            ach = fwd_b / (t_fwd * 1e-3)
-            out["roofline"] = {"bound": "hbm", "kernel": "tzr_pooled_fwd_kernel", "achieved": ach / 1e9,
-                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                               "traffic": pmc_traffic(args, B_local), "launch_ms": t_fwd,
-                               "algorithmic_bytes": fwd_b,
-                               "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe, profiles/r01c
-                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded in the newest "
-                                                 "profiles/r*/pmc_traffic.json (not measurable from inside bench.py)"}
         if t_fwd and t_plan is not None and t_apply:
+            # north star: "HBM-bandwidth roofline on the pooled embedding forward+backward".  Bytes are
+            # SURVEY.md 8(d)'s algorithmic figures for THESE batches; the plan moves no algorithmic
+            # bytes (its time counts against the aggregate in full).
             tot = (t_fwd + t_plan + t_apply) * 1e-3
-            out["embedding"] = {
-                "fwd_ms": t_fwd, "bwd_plan_ms": t_plan, "bwd_apply_ms": t_apply,
-                "algorithmic_bytes_fwd": fwd_b, "algorithmic_bytes_bwd": bwd_b,
+            ach = (fwd_b + bwd_b) / tot
+
+            def stage(name, kernels, nbytes, ms):
+                return {"stage": name, "kernels": kernels, "launch_ms": ms, "algorithmic_bytes": nbytes,
+                        "GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
+
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_kernel; "
+                                          "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_kernel)",
+                "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                "traffic": pmc_traffic(args, B_local), "launch_ms": t_fwd + t_plan + t_apply,
+                "algorithmic_bytes": fwd_b + bwd_b,
                 "unique_rows": float(np.mean([a["U"] for a in ab])),
-                "fwd_bwd_GBps": (fwd_b + bwd_b) / tot / 1e9, "frac_of_8TBps": (fwd_b + bwd_b) / tot / HBM_PEAK,
-                "apply_GBps": bwd_b / (t_apply * 1e-3) / 1e9,
-            }
+                "kernels": [stage("forward", ["tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
+                            stage("backward plan", ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
+                                                    "tzr_bwd_sort_kernel"], 0.0, t_plan),
+                            stage("backward apply", ["tzr_bwd_reduce_kernel"], bwd_b, t_apply)],
+                "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe on this part, profiles/r01c
+                "frac_of_practical_ceiling": ach / 3.97e12,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, summed over the six "
+                                  "kernels, recorded in the newest profiles/r*/pmc_traffic.json (not measurable inside bench.py)"}
+            # kept for continuity with round 1's line
+            out["embedding"] = {"fwd_ms": t_fwd, "bwd_plan_ms": t_plan, "bwd_apply_ms": t_apply,
+                                "fwd_bwd_GBps": ach / 1e9, "frac_of_8TBps": ach / HBM_PEAK}
+        if e2e is not None:
+            out["e2e"] = e2e
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     # RCCL prints its version banner through C stdio, which a pipe buffers until exit: every rank

@@ -243,6 +243,15 @@ int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature
                         int64_t B,
                         int uniform_bag_len, void* ws, size_t ws_bytes, void* stream);
 
+/* Inspection of a finished plan (tests / debugging): byte offsets into `ws` of out8[0] = the sorted
+ * {row, lookup position} pairs (uint32 x 2 per table-major position) of every table with more than
+ * 512 rows, out8[1] = the bucket-partitioned pairs (final for tables of <= 512 rows), out8[2] = the
+ * table-major start of every lookup by order (uint32[n_feats + 1]); out8[3..7] internal.  After a
+ * plan, the pairs of one table hold every lookup of the table exactly once with equal rows adjacent
+ * and, inside a row, ascending lookup positions. */
+int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, int n_feats, int n_tables,
+                             int max_dim, int64_t* out8);
+
 /* K7: fused backward + sparse optimizer.  Replaces fbgemm
  * split_embedding_backward_codegen_{sgd,adagrad,rowwise_adagrad}_*_exact (optimizer fused into
  * backward by apply_optimizer_in_backward, tzrec/main.py:774-781): per distinct (table,row)

@@ -3,7 +3,7 @@ set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=${1:-plan}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace -d $O/trace -o t -- python $R/scripts/plan_trace.py ${2:-uniform} ${3:-65536} ${4:-adagrad} > $O/trace.log 2>&1; echo "trace rc=$?"
+timeout 300 rocprofv3 --kernel-trace -d $O/trace -o t -- python $R/scripts/plan_trace.py ${2:-uniform} ${3:-65536} ${4:-adagrad} ${5:-0} > $O/trace.log 2>&1; echo "trace rc=$?"
 cd $R
 DB=$(find $O/trace -name '*.db' | head -1)
 python scripts/rocpd_timeline.py "$DB" 16 $O/timeline.txt

@@ -12,6 +12,8 @@ from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, criteo_tables, syn
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
 _lib.use_library(_build.build())
+if len(sys.argv) > 4:
+    assert _lib.lib().tzr_tune(b"bwd_ch", int(sys.argv[4])) == 0
 dev = torch.device("cuda", 0)
 dist = sys.argv[1] if len(sys.argv) > 1 else "uniform"
 ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev, optimizer=SparseOptimizerConfig(kind=(sys.argv[3] if len(sys.argv) > 3 else "adagrad"), lr=1e-3),

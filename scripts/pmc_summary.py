@@ -34,6 +34,17 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
     if "tzr_pooled_fwd_kernel" in ks:
         e = ks["tzr_pooled_fwd_kernel"]
         e["traffic_corrected"] = e["FETCH_SIZE"] + 0.5 * 8 * int(n_lookups) + e["WRITE_SIZE"]
+    # the north-star aggregate: the six launches of the pooled embedding forward + backward
+    six = ["tzr_pooled_fwd_kernel", "tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
+           "tzr_bwd_sort_kernel", "tzr_bwd_reduce_kernel"]
+    if all(k in ks for k in six):
+        agg = 0.0
+        for k in six:
+            e = ks[k]
+            agg += e.get("traffic_corrected") or ((e["FETCH_SIZE"] or 0.0) + (e["WRITE_SIZE"] or 0.0))
+        ks["__embedding_fwd_bwd__"] = {"traffic_corrected": agg, "kernels": six,
+                                       "note": "forward corrected as above; the other five at FETCH_SIZE + WRITE_SIZE as counted "
+                                               "(64-B row gathers are exact; the 8-B key/source streams of the plan are uncalibrated)"}
     json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 "
                          "--warmup 2 --no-cpu-baseline --no-graph; B=65536 uniform ids, adagrad interleaved",
                "units": "bytes per launch (mean over dispatches after the first); see scripts/pmc_summary.py for the corrections",

@@ -26,6 +26,7 @@ def _digest():
     deps = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
         os.path.join(ROOT, "include", "tzrec_hip.h"),
         os.path.join(HERE, "hip", "hip_runtime.h"),
+        os.path.join(HERE, "tzr_gfx950.h"),
     ]
     for p in deps:
         with open(p, "rb") as f:

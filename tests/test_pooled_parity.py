@@ -288,6 +288,13 @@ def _narrow(lo, width):
     return lambda rng, rows, n: lo % rows + rng.integers(0, min(width, rows), size=n)
 
 
+def _zipf_clipped(rng, rows, n):
+    """the bench's --dist zipf (torcheasyrec_amd/criteo.py): Zipf(1.05) ranks clipped to the table, so the
+    last rank collects the whole tail (40-70 % of the lookups on ONE row), scattered multiplicatively"""
+    z = rng.zipf(1.05, size=n).astype(np.int64) - 1
+    return (np.minimum(z, rows - 1) * 2654435761 + 12345) % rows
+
+
 # (rows, B, id generator, also on the CPU lane emulator): what the plan's bucket partition, the
 # unit-local sort and the heavy kernel see.  The emulator runs the cheap half (one OS thread per lane).
 PLAN_CASES = {
@@ -296,6 +303,9 @@ PLAN_CASES = {
     "three_pass": (1 << 22, 1100, None, True),                     # 2 units spanning ~21 bits of row id
     "wide_rows": (40_000_000, 1500, None, False),                  # ~25 bits: 4 local passes
     "hot_one_tile": (70000, 1500, _hot(0.45, [31337]), True),      # one heavy bucket < one heavy tile, rest light
+    "hot_t1_tiles": (70000, 3000, _hot(0.6, [31337]), True),        # heavy bucket of <= 512 row ids, 2 parallel tiles
+    "zipf_mid_table": (12973, 5000, _zipf_clipped, True),            # ~3000 lookups on one row + Zipf head: tiles + light units
+    "zipf_big_table": (3067956, 5000, _zipf_clipped, True),         # wide buckets: the serial multi-tile path
     "hot_two_in_bucket": (200000, 1800, _hot(0.6, [5000, 5001, 5003]), False),  # heavy bucket with 3 hot rows
     "hot_multi_tile": (1 << 20, 3300, _hot(0.75, [777777]), True), # heavy bucket of ~2500 = 2 tiles, 3 unit slices
     "hot_many_tiles": (1 << 20, 40000, _hot(0.5, [777777, 12]), False),  # two heavy buckets of ~10000
@@ -304,8 +314,20 @@ PLAN_CASES = {
 }
 
 
-@pytest.mark.parametrize("case", sorted(PLAN_CASES))
-def test_backward_plan_shapes(dev, case):
+@pytest.mark.parametrize("case,ch", [(c, 0) for c in sorted(PLAN_CASES)] +
+                         [(c, ch) for c in ("light_units", "hot_multi_tile", "narrow_two_buckets", "wide_rows", "hot_many_tiles")
+                          for ch in (512, 1024)])
+def test_backward_plan_shapes(dev, case, ch):
+    """ch = positions per chunk of the plan (pooled_bwd.h: bwd_pick_ch); 0 = by problem size (256 here)"""
+    from torcheasyrec_amd import _lib
+    _lib.lib().tzr_tune(b"bwd_ch", ch)
+    try:
+        _plan_shape_case(dev, case)
+    finally:
+        _lib.lib().tzr_tune(b"bwd_ch", 0)
+
+
+def _plan_shape_case(dev, case):
     """The backward plan on id distributions that exercise each of its paths (pooled_bwd.hip): exact
     vs bucketed tables, units made of light buckets, heavy buckets (hot rows) sorted by the heavy
     kernel in one and in several tiles, units mixing slices of heavy buckets with light ones."""

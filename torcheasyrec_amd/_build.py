@@ -11,7 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libtzrec_hip.so")
 _STAMP = os.path.join(_HERE, ".libtzrec_hip.stamp")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-I", CSRC]
 
 
 def sources():

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "tzr_pooled_fwd_ex": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                                  _i32, _i32, _i32, _vp]),
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
+    "tzr_pooled_bwd_plan_view": (_i32, [_i64, _i64, _i32, _i32, _i32, _vp]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),
     "tzr_sparse_adam_tick": (_i32, [_vp, C.c_float, C.c_float, _vp]),

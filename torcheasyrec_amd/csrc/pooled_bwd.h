@@ -6,14 +6,13 @@
 
 #define BWD_THREADS 256
 #define BWD_WAVES (BWD_THREADS / TZR_WAVE)
-#define BWD_CH 1024  // positions per input chunk of the partition pass; block size of the unit grid
+#define BWD_CH 1024  // MAX positions per input chunk of the partition pass = block of the unit grid
+                     // (the launchers pick 256 .. 1024 from the number of lookups: BwdPlan.ch)
 #define BWD_RB 9
 #define BWD_NB 512   // buckets per table of the global partition pass (1 << BWD_RB)
 #define BWD_TH 256   // a bucket with more lookups is "heavy": sorted by the heavy kernel, cut at blocks
 #define BWD_UMAX (BWD_CH + BWD_TH)  // capacity of one unit of the apply: < BWD_CH + BWD_TH lookups
-#define BWD_LB 8     // digit width of the unit-local passes
-#define BWD_LNB 256
-#define BWD_HT 2048  // tile of the heavy-bucket sort
+#define BWD_HT 1024  // tile of the heavy-bucket sort (4 rounds per wave: every role of the sort kernel within 64 VGPRs)
 #define BWD_GEO 1024 // lookups / tables up to which every hist workgroup derives the geometry itself
 #define BWD_MAXDIM 256
 #define BWD_SENT 0xFFFFFFFFu  // never a row id
@@ -38,9 +37,12 @@ struct BwdChunkDesc {
   uint64_t mult;       // bucket of row id k = (k * mult) >> 32 (monotone in k)
 };
 
-struct BwdHeavy {  // one heavy bucket: positions [start, end) of table t hold bucket `bin`
+struct BwdHeavy {  // work item of the sort kernel: heavy bucket `bin` of table t = positions [start, end)
   int32_t t;
   uint32_t bin, start, end;
+  int32_t tile;  // >= 0: BWD_HT-tile of a bucket one counting pass sorts (<= BWD_NB row ids);
+                 // -1: the whole bucket, several passes, one workgroup
+  int32_t pad[3];
 };
 
 struct BwdPlan {  // pointers into the caller workspace
@@ -49,14 +51,18 @@ struct BwdPlan {  // pointers into the caller workspace
   int32_t* feat_by_order;  // [F]
   int32_t* tab_chunk;      // [T+1] first chunk of each table
   uint2* ks[2];            // [N] {local row id, original lookup position}: ks[1] holds the bucket-
-                           //     partitioned (and, for heavy buckets, sorted) lookups, ks[0] is the
-                           //     heavy sort's ping-pong; one 8-byte element = ONE store per move
+                           //     partitioned lookups (final for exact tables), ks[0] the sorted ones
+                           //     of every other table; one 8-byte element = ONE store per move
   uint32_t* bag_of;        // [NV] bag index key*B+b of every lookup (only when bags are jagged)
   uint32_t* hist;          // [max_chunks * BWD_NB] chunk-exclusive bucket counts
   uint32_t* binbase;       // [T * (BWD_NB+1)] global start of every (table, bucket), end of the last
   uint32_t* ucut;          // [max_chunks + 1] first sorted position of every unit
-  uint32_t* uflag;         // [max_chunks] 1 = the unit's lookups already are in final order
-  uint32_t* hcount;        // [1] heavy buckets listed
+  uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (exact table / inside one heavy bucket)
+  uint32_t* hbits;         // [T * BWD_NB/32] bitmap of the heavy buckets of every table
+  uint32_t* hcount;        // [1] work items listed
+  uint32_t* tab_stitch;    // [T] 1 = the table holds sorted buckets: runs may cross unit boundaries
+  uint32_t* sexp;          // [T * BWD_NB] units overlapping the (sorted) bucket when > 1, else 0
+  uint32_t* sarr;          // [T * BWD_NB] ... of which have published their boundary record (apply)
   BwdHeavy* hlist;         // [max_heavy]
   uint32_t* cflags;        // [max_chunks] boundary record of every unit
   uint32_t* clkey;         // [max_chunks] key of the unit's leading open run
@@ -66,9 +72,21 @@ struct BwdPlan {  // pointers into the caller workspace
   BwdChunkDesc* cdesc;     // [max_chunks]
   int64_t max_chunks;
   int64_t max_heavy;
+  int32_t ch;  // positions per chunk (multiple of 256, <= BWD_CH)
 };
 
-static inline int64_t bwd_max_chunks(int64_t N, int T) { return N / BWD_CH + T + 1; }
+// Positions per chunk.  The plan / apply kernels are latency-bound: the time of a launch is the
+// time of ONE workgroup unless the chip is oversubscribed, so a small problem wants small chunks
+// (B = 8192 Criteo: 213k lookups = 208 chunks of 1024 on 256 CUs, each wave walking 16 dependent
+// tiles; 832 chunks of 256 do 4).  g_tzr_bwd_ch (tzr_tune "bwd_ch") overrides.
+extern int g_tzr_bwd_ch;
+static inline int bwd_pick_ch(int64_t N) {
+  if (g_tzr_bwd_ch >= 256 && g_tzr_bwd_ch <= BWD_CH && g_tzr_bwd_ch % 256 == 0) return g_tzr_bwd_ch;
+  if (N <= 512 * 1024) return 256;
+  if (N <= 1024 * 1024) return 512;
+  return BWD_CH;
+}
+static inline int64_t bwd_max_chunks(int64_t N, int T, int ch) { return N / ch + T + 1; }
 
 // NV = ids in the KJT values array; N = capacity of the table-major position space (sum over
 // lookups of their key length: a key read through two tables is sorted twice).
@@ -76,8 +94,9 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
                                 int max_dim) {
   TzrCarver c(ws);
   BwdPlan q;
-  q.max_chunks = bwd_max_chunks(N, T);
-  q.max_heavy = N / (BWD_TH + 1) + 1;
+  q.ch = bwd_pick_ch(N);
+  q.max_chunks = bwd_max_chunks(N, T, q.ch);
+  q.max_heavy = N / (BWD_TH + 1) + N / BWD_HT + 1;
   q.feat_start = c.take<uint32_t>(F + 1);
   q.feat_key = c.take<int32_t>(F);
   q.feat_by_order = c.take<int32_t>(F);
@@ -88,7 +107,11 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.binbase = c.take<uint32_t>((size_t)T * (BWD_NB + 1));
   q.ucut = c.take<uint32_t>(q.max_chunks + 1);
   q.uflag = c.take<uint32_t>(q.max_chunks);
+  q.hbits = c.take<uint32_t>((size_t)T * (BWD_NB / 32));
   q.hcount = c.take<uint32_t>(4);
+  q.tab_stitch = c.take<uint32_t>(T);
+  q.sexp = c.take<uint32_t>((size_t)T * BWD_NB);
+  q.sarr = c.take<uint32_t>((size_t)T * BWD_NB);
   q.hlist = c.take<BwdHeavy>(q.max_heavy);
   q.cflags = c.take<uint32_t>(q.max_chunks);
   q.clkey = c.take<uint32_t>(q.max_chunks);

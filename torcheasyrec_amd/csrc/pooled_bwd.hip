@@ -14,12 +14,15 @@
 //            each, evenly filled by uniform ids -- bwd_bucket_params);
 //   scan     per table: bucket starts, the unit grid of the apply, the list of heavy buckets;
 //   scatter  ONE stable partition pass into buckets (lookups regrouped table-major on the way);
-//   heavy    buckets with more than BWD_TH lookups (hot rows: Zipf heads, default ids) are sorted
-//            here by one workgroup each, tile by tile; nothing to do for uniform ids;
-//   (apply)  the reduce kernel orders the light buckets of its unit in LDS (<= 1280 lookups, 2-3
-//            counting passes on the row-id bits left inside a bucket) before it reduces them.
+//   sort     ONE launch finishes the order, ks[1] -> ks[0]: a workgroup per unit of the apply sorts
+//            the unit's light buckets in LDS (< 1280 lookups, 2-3 counting passes on the row-id bits
+//            left inside the unit); buckets with more than BWD_TH lookups (hot rows: Zipf heads,
+//            default ids) are sorted by extra workgroups of the same launch, tile-parallel when the
+//            bucket holds <= 512 row ids (one counting pass), else tile by tile by one workgroup.
 //
-// 4 launches (3 + one that usually finds an empty list) instead of 10, ~1/3 of the ks traffic.
+// 4 launches instead of 10, ~1/2 of the ks traffic; the apply kernels are what they were.
+#include <tzr_gfx950.h>
+
 #include "pooled_bwd.h"
 
 extern "C" size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions, int n_feats,
@@ -27,6 +30,28 @@ extern "C" size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions
   (void)B;
   if (n_values < 0 || n_positions < 0 || n_feats <= 0 || n_tables <= 0 || max_dim <= 0) return 0;
   return bwd_layout(nullptr, nullptr, n_values, n_positions, n_feats, n_tables, max_dim) + 256;
+}
+
+// Inspection of a plan (tests, debugging): byte offsets into `ws` of
+//   out[0] ks[0]  out[1] ks[1]  (uint2 {row, lookup position} per table-major position)
+//   out[2] feat_start (uint32[F+1])  out[3] ucut (uint32[max_chunks+1])  out[4] cdesc (64 B each)
+//   out[5] max_chunks  out[6] hcount (uint32)  out[7] hlist (32 B each)
+extern "C" int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, int n_feats,
+                                        int n_tables, int max_dim, int64_t* out8) {
+  if (!out8 || n_values < 0 || n_positions < 0 || n_feats <= 0 || n_tables <= 0 || max_dim <= 0)
+    return TZR_ERR_INVALID;
+  BwdPlan P;
+  bwd_layout(&P, nullptr, n_values, n_positions, n_feats, n_tables, max_dim);
+  const char* base = nullptr;
+  out8[0] = reinterpret_cast<const char*>(P.ks[0]) - base;
+  out8[1] = reinterpret_cast<const char*>(P.ks[1]) - base;
+  out8[2] = reinterpret_cast<const char*>(P.feat_start) - base;
+  out8[3] = reinterpret_cast<const char*>(P.ucut) - base;
+  out8[4] = reinterpret_cast<const char*>(P.cdesc) - base;
+  out8[5] = P.max_chunks;
+  out8[6] = reinterpret_cast<const char*>(P.hcount) - base;
+  out8[7] = reinterpret_cast<const char*>(P.hlist) - base;
+  return TZR_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -89,7 +114,7 @@ struct BwdGeoLds {
 // of it.  Keys of the KJT this module does not own (table < 0) are ordered last and contribute
 // nothing.
 __device__ __forceinline__ void bwd_geometry(const TzrTable* __restrict__ tables, int T,
-                                             const BwdSrcArgs& A, int F, BwdGeoLds& G) {
+                                             const BwdSrcArgs& A, int F, uint32_t ch, BwdGeoLds& G) {
   for (int f = threadIdx.x; f < F; f += BWD_THREADS) {
     const TzrFeature ft = A.feats[f];
     const int64_t key = ft.key;
@@ -104,7 +129,7 @@ __device__ __forceinline__ void bwd_geometry(const TzrTable* __restrict__ tables
     const TzrTable tb = tables[t];
     const uint32_t s = tb.n_feats > 0 ? G.fstart[tb.first_order] : 0u;
     const uint32_t e = tb.n_feats > 0 ? G.fstart[tb.first_order + tb.n_feats] : 0u;
-    G.tchunk[t] = (e - s + BWD_CH - 1) / BWD_CH;
+    G.tchunk[t] = (e - s + ch - 1) / ch;
   }
   __syncthreads();
   // tables are visited in first_order order == table-major position order only if table ids
@@ -136,12 +161,13 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     P.feat_start[F] = run;
     P.hcount[0] = 0;
   }
+  for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += BWD_THREADS) {
     const TzrTable tb = tables[t];
     const uint32_t s = tb.n_feats > 0 ? P.feat_start[tb.first_order] : 0u;
     const uint32_t e = tb.n_feats > 0 ? P.feat_start[tb.first_order + tb.n_feats] : 0u;
-    P.tab_chunk[t] = (int32_t)((e - s + BWD_CH - 1) / BWD_CH);
+    P.tab_chunk[t] = (int32_t)((e - s + (uint32_t)P.ch - 1) / (uint32_t)P.ch);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
   __shared__ BwdGeoLds GL;
   BwdGeo G;
   if (FUSED) {
-    bwd_geometry(tables, T, A, F, GL);
+    bwd_geometry(tables, T, A, F, (uint32_t)P.ch, GL);
     G.fstart = GL.fstart;
     G.fkey = GL.fkey;
     G.tchunk = reinterpret_cast<const int32_t*>(GL.tchunk);
@@ -191,6 +217,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
       for (int o = threadIdx.x; o < F; o += BWD_THREADS) P.feat_key[o] = GL.fkey[o];
       for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
       for (int t = threadIdx.x; t <= T; t += BWD_THREADS) P.tab_chunk[t] = (int32_t)GL.tchunk[t];
+      for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
       if (threadIdx.x == 0) P.hcount[0] = 0;
     }
   } else {
@@ -218,8 +245,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
     cd.last_chunk = G.tchunk[lo + 1];
     cd.ts = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order] : 0;
     cd.te = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order + tb.n_feats] : cd.ts;
-    cd.s = cd.ts + (int64_t)(c - G.tchunk[lo]) * BWD_CH;
-    cd.e = min(cd.te, cd.s + (int64_t)BWD_CH);
+    cd.s = cd.ts + (int64_t)(c - G.tchunk[lo]) * P.ch;
+    cd.e = min(cd.te, cd.s + (int64_t)P.ch);
   }
   if (threadIdx.x == 0) P.cdesc[c] = cd;
   if (cd.t < 0) return;
@@ -298,28 +325,65 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
   uint32_t* bb = P.binbase + (size_t)t * (BWD_NB + 1);
   bb[bin] = start;
   if (bin == BWD_NB - 1) bb[BWD_NB] = te;
+  {  // bitmap of the heavy buckets (read by the unit sort): one ballot per wave = two words
+    const unsigned long long hb = __ballot(!exact && run > BWD_TH);
+    if ((threadIdx.x & (TZR_WAVE - 1)) == 0) {
+      uint32_t* hw = P.hbits + (size_t)t * (BWD_NB / 32) + (threadIdx.x / TZR_WAVE) * 2;
+      hw[0] = (uint32_t)hb;
+      hw[1] = (uint32_t)(hb >> 32);
+      if (hb != 0 || (exact && threadIdx.x == 0)) atomicOr(&P.tab_stitch[t], 1u);
+    }
+  }
+  // Stitch groups of the apply: a run of one row can only cross a unit boundary inside a sorted
+  // bucket; the units overlapping such a bucket meet at its counter (reduce kernel)
+  {
+    uint32_t expect = 0;
+    if (run > 0 && (exact || run > BWD_TH)) {
+      const uint32_t ch = (uint32_t)P.ch;
+      const uint32_t units = (end - 1 - ts) / ch - (start - ts) / ch + 1;
+      expect = units > 1 ? units : 0u;
+    }
+    P.sexp[(size_t)t * BWD_NB + bin] = expect;
+    P.sarr[(size_t)t * BWD_NB + bin] = 0;
+  }
   if (run == 0) return;
   // an exact table's buckets are single rows: in final order after the partition pass whatever
   // their size, cut at blocks like heavy buckets but never listed for the heavy kernel
   const bool heavy = !exact && run > BWD_TH;
   const bool sorted = exact || heavy;
   // blocks whose first position lies in this bucket
-  const uint32_t j0 = (start - ts + BWD_CH - 1) / BWD_CH;
-  const uint32_t j1 = (end - 1 - ts) / BWD_CH;
+  const uint32_t ch = (uint32_t)P.ch;
+  const uint32_t j0 = (start - ts + ch - 1) / ch;
+  const uint32_t j1 = (end - 1 - ts) / ch;
   for (uint32_t j = j0; j <= j1; ++j) {
-    const uint32_t bs = ts + j * BWD_CH;
+    const uint32_t bs = ts + j * ch;
     P.ucut[c0 + j] = (bs == start || sorted) ? bs : end;
-    const uint32_t bnext = min(bs + (uint32_t)BWD_CH, te);
+    const uint32_t bnext = min(bs + ch, te);
     P.uflag[c0 + j] = (exact || (heavy && bnext <= end)) ? 1u : 0u;
   }
   if (heavy) {
-    const uint32_t slot = atomicAdd(P.hcount, 1u);
-    BwdHeavy hv;
-    hv.t = t;
-    hv.bin = (uint32_t)bin;
-    hv.start = start;
-    hv.end = end;
-    P.hlist[slot] = hv;
+    // row ids of the bucket: [klo, khi).  At most BWD_NB of them (tables up to BWD_NB^2 rows): one
+    // counting pass on (row id - klo) sorts the bucket, tile by tile, one workgroup per tile.
+    // Wider buckets (the hot rows of the big tables): several passes by one workgroup.
+    int nb;
+    uint64_t mult;
+    bwd_bucket_params(tb.rows, &nb, &mult);
+    const uint64_t klo = (((uint64_t)bin << 32) + mult - 1) / mult;
+    uint64_t khi = (((uint64_t)(bin + 1) << 32) + mult - 1) / mult;
+    if (khi > (uint64_t)tb.rows) khi = (uint64_t)tb.rows;
+    const bool one_pass = khi - klo <= (uint64_t)BWD_NB;
+    const uint32_t tiles = one_pass ? (run + BWD_HT - 1) / BWD_HT : 1u;
+    const uint32_t slot = atomicAdd(P.hcount, tiles);
+    for (uint32_t i = 0; i < tiles; ++i) {
+      BwdHeavy hv;
+      hv.t = t;
+      hv.bin = (uint32_t)bin;
+      hv.start = start;
+      hv.end = end;
+      hv.tile = one_pass ? (int32_t)i : -1;
+      hv.pad[0] = hv.pad[1] = hv.pad[2] = 0;
+      P.hlist[slot + i] = hv;
+    }
   }
 }
 
@@ -386,87 +450,415 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// heavy buckets: stable LSD sort on the row-id bits left inside the bucket, one workgroup per
-// bucket, tile by tile through ks[0] and back (an even number of passes ends in place).  A single
-// workgroup walks the tiles in order, so the running per-digit offsets ARE the cross-tile prefix:
-// no per-tile histogram storage, no inter-workgroup traffic.
+// sort: everything the partition pass left unordered, in ONE launch, ks[1] -> ks[0]
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_heavy_kernel(
-    const TzrTable* __restrict__ tables, BwdPlan P) {
-  __shared__ BwdRankLds<BWD_NB> L;
-  __shared__ unsigned gstart[BWD_NB + 1];
-  __shared__ uint32_t wtot[BWD_WAVES];
-  const unsigned nh = P.hcount[0];
+// Workgroups [0, max_chunks): one UNIT each -- the light buckets of the unit (whole buckets of
+// consecutive row ids, in bucket order) get a stable LSD sort of (row id - smallest row id of the
+// unit) over the bits that difference needs, in LDS; uniform ids at B = 65536 on a 40M-row table:
+// ~9 buckets of ~128 lookups, 20 bits, 3 passes of 7 bits.  Lookups of heavy buckets inside the unit
+// are skipped (their positions are written by the heavy workers below).
+// Workgroups [max_chunks, ...): heavy-bucket workers, looping over the work items of the scan kernel.
+//   one-pass item (bucket of <= BWD_NB row ids, tile i): counts the whole bucket per row id on its
+//     own (no inter-workgroup traffic; the counts up to its tile are the cross-tile prefix), then
+//     ranks and writes its tile: the tiles of a hot bucket are sorted in parallel;
+//   serial item (a wide bucket: hot rows of the big tables): LSD passes tile by tile by one
+//     workgroup; a single workgroup walks the tiles in order, so the running per-digit offsets ARE
+//     the cross-tile prefix.
+
+// counts[d] += number of valid lanes with digit d, one LDS atomic per distinct digit of the wave
+// (a hot row id is every lane's digit: per-lane atomics on one address serialise)
+__device__ __forceinline__ void bwd_wave_count(unsigned* counts, uint32_t d, bool v, int wbits,
+                                               int lane) {
+  unsigned long long peers = __ballot(v);
+  for (int bit = 0; bit < wbits; ++bit) {
+    const int on = (d >> bit) & 1;
+    const unsigned long long bm = __ballot(on);
+    peers &= on ? bm : ~bm;
+  }
+  if (v && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&counts[d], (unsigned)__popcll(peers));
+}
+
+#define BWD_GMAX 16  // largest group of equal low digits the in-group ranking takes on
+
+struct BwdSortLds {  // < 20 KB: 8 workgroups per CU, the whole grid of a B = 65536 step resident at once
+  BwdRankLds<BWD_NB> L;
+  unsigned gstart[BWD_NB + 1];
+  union {
+    unsigned pre[BWD_NB];  // heavy tile: bucket counts ahead of the tile
+    uint16_t hb[BWD_NB];   // unit: lookups of heavy buckets ahead of each bucket
+  };
+  uint32_t pk[BWD_UMAX], ps[BWD_UMAX];  // exchange buffer of the LDS-resident passes
+  uint32_t wtot[BWD_WAVES];
+  uint32_t smm[2 * BWD_WAVES];
+};
+static_assert(BWD_HT <= BWD_UMAX, "the exchange buffer holds a heavy tile");
+
+// Orders the valid elements a workgroup holds wave-contiguously (element r of a lane sits at local
+// position wv*pw + r*64 + lane) so that equal row ids end up adjacent and ordered by original lookup
+// position.  On return the thread holds (kreg[r], sreg[r]) for the r of `vmask` and dest[r] = the
+// element's index in the new order.
+//   grouped (only with `grouped_ok`): the elements are counted into 512 groups by the LOW 9 bits
+//     of (row id - kmin) with one LDS atomic each -- no match-any ballots, no per-round barriers --
+//     and every element then ranks itself inside its group by (row id, lookup position) with a
+//     handful of LDS reads (a unit averages 2.3 elements per group).  Order: (low digit, row id,
+//     position): equal row ids adjacent, which is all the apply needs, at a fraction of the
+//     instructions of three stable passes.  Given up when a group holds more than BWD_GMAX
+//     elements (hot rows).  Not for a unit that shares its position range with heavy buckets:
+//     that one needs ascending bucket order.
+//   else: stable LSD counting passes over the key span: ascending row ids.
+template <int MAXR>
+__device__ __forceinline__ void bwd_sort_core(uint32_t (&kreg)[MAXR], uint32_t (&sreg)[MAXR],
+                                              uint32_t& vmask, int pw, int rounds, uint32_t kmin,
+                                              int bits, bool grouped_ok, BwdSortLds& S,
+                                              uint32_t (&dest)[MAXR]) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
-  constexpr int kRounds = BWD_HT / BWD_THREADS;
-  for (unsigned hi = blockIdx.x; hi < nh; hi += gridDim.x) {
-    const BwdHeavy H = P.hlist[hi];
-    const int64_t rows = tables[H.t].rows;
-    int nb;
-    uint64_t mult;
-    bwd_bucket_params(rows, &nb, &mult);
-    // row ids of the bucket: [klo, khi)
-    const uint64_t klo = (((uint64_t)H.bin << 32) + mult - 1) / mult;
-    uint64_t khi = (((uint64_t)(H.bin + 1) << 32) + mult - 1) / mult;
-    if (khi > (uint64_t)rows) khi = (uint64_t)rows;
-    const int bits = max(1, bwd_bits((uint32_t)(khi - klo - 1)));
-    const int npass = bits <= 2 * BWD_RB ? 2 : 4;
-    const int width = (bits + npass - 1) / npass;
-    const unsigned mask = (1u << width) - 1u;
-    const int n = (int)(H.end - H.start);
-    for (int pass = 0; pass < npass; ++pass) {
-      const uint2* __restrict__ src = ((pass & 1) ? P.ks[0] : P.ks[1]) + H.start;
-      uint2* __restrict__ dst = ((pass & 1) ? P.ks[1] : P.ks[0]) + H.start;
-      const int shift = pass * width;
-      for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) gstart[i] = 0;
-      __syncthreads();
-      for (int i0 = 0; i0 < n; i0 += 4 * BWD_THREADS) {
-        uint32_t k4[4];
+  uint32_t dig[MAXR];
+  if (grouped_ok) {
+    const unsigned mask0 = BWD_NB - 1;
+    for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] = 0;
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = i0 + j * BWD_THREADS + (int)threadIdx.x;
-          k4[j] = i < n ? src[i].x : 0u;
+    for (int r = 0; r < MAXR; ++r) {
+      dig[r] = (kreg[r] - kmin) & mask0;
+      dest[r] = 0;
+      if ((vmask >> r) & 1u) dest[r] = atomicAdd(&S.gstart[dig[r]], 1u);  // slot inside the group
+    }
+    __syncthreads();
+    static_assert(BWD_NB == 2 * BWD_THREADS, "two group counters per thread");
+    uint32_t g = max(S.gstart[2 * threadIdx.x], S.gstart[2 * threadIdx.x + 1]);
+    for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) g = max(g, (uint32_t)__shfl_xor((int)g, m, TZR_WAVE));
+    if (lane == 0) S.smm[wv] = g;
+    bwd_block_scan(S.gstart, BWD_NB, S.wtot);
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) g = max(g, S.smm[w]);
+    if (g <= BWD_GMAX) {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+        if ((vmask >> r) & 1u) {
+          const uint32_t at = S.gstart[dig[r]] + dest[r];
+          S.pk[at] = kreg[r];
+          S.ps[at] = sreg[r];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = i0 + j * BWD_THREADS + (int)threadIdx.x;
-          if (i < n) atomicAdd(&gstart[((k4[j] - (uint32_t)klo) >> shift) & mask], 1u);
-        }
-      }
       __syncthreads();
-      bwd_block_scan(gstart, BWD_NB, wtot);
-      for (int t0 = 0; t0 < n; t0 += BWD_HT) {
-        const int nt = min(BWD_HT, n - t0);
-        const int pw = bwd_wave_span(nt);
-        const int rounds = pw / TZR_WAVE;
-        uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
-        uint32_t vmask = 0;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-          const int lp = wv * pw + r * TZR_WAVE + lane;
-          kreg[r] = sreg[r] = dig[r] = 0u;
-          if (r < rounds && lp < nt) {
-            vmask |= 1u << r;
-            const uint2 v = src[t0 + lp];
-            kreg[r] = v.x;
-            sreg[r] = v.y;
-            dig[r] = ((v.x - (uint32_t)klo) >> shift) & mask;
+      for (int r = 0; r < MAXR; ++r)
+        if ((vmask >> r) & 1u) {
+          const uint32_t lo = S.gstart[dig[r]], hi = S.gstart[dig[r] + 1];
+          const uint32_t k = kreg[r], sp = sreg[r];
+          uint32_t rank = 0;
+          for (uint32_t j = lo; j < hi; ++j) {
+            const uint32_t kj = S.pk[j], sj = S.ps[j];
+            rank += (kj < k || (kj == k && sj < sp)) ? 1u : 0u;
           }
+          dest[r] = lo + rank;
         }
-        bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, width, L, dest);
+      return;
+    }
+    __syncthreads();  // smm / wtot are reused below
+  }
+  const int npass = (bits + BWD_RB - 1) / BWD_RB;
+  const int width = (bits + npass - 1) / npass;
+  const unsigned mask = (1u << width) - 1u;
+  for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r)
-          if ((vmask >> r) & 1u)
-            dst[gstart[dig[r]] + (dest[r] - (uint32_t)L.lstart[dig[r]])] = make_uint2(kreg[r], sreg[r]);
-        __syncthreads();
-        for (int d = threadIdx.x; d < BWD_NB; d += BWD_THREADS)
-          gstart[d] += (unsigned)L.lstart[d + 1] - (unsigned)L.lstart[d];
-        __syncthreads();
+    for (int r = 0; r < MAXR; ++r) dig[r] = ((kreg[r] - kmin) >> (pass * width)) & mask;
+    bwd_rank_tile<BWD_NB, MAXR>(dig, vmask, rounds, width, S.L, dest);
+    if (pass + 1 < npass) {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+        if ((vmask >> r) & 1u) {
+          S.pk[dest[r]] = kreg[r];
+          S.ps[dest[r]] = sreg[r];
+        }
+      __syncthreads();
+      // the elements are dense in [0, nv) now: re-deal them wave-contiguously
+      const int nv = (int)S.L.lstart[BWD_NB];
+      vmask = 0;
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) {
+        const int lp = wv * pw + r * TZR_WAVE + lane;
+        if (r < rounds && lp < nv) {
+          vmask |= 1u << r;
+          kreg[r] = S.pk[lp];
+          sreg[r] = S.ps[lp];
+        }
       }
-      __threadfence();  // this workgroup reads the pass's output back in the next pass
+    }
+  }
+}
+
+__device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ tables, const BwdPlan& P,
+                                              BwdSortLds& S, int c) {
+  BwdChunkDesc cd;
+  if (!bwd_chunk(P, c, &cd)) return;
+  if (P.uflag[c]) return;
+  const int64_t s = P.ucut[c];
+  const int64_t e = c + 1 < cd.last_chunk ? (int64_t)P.ucut[c + 1] : cd.te;
+  const int n = (int)(e - s);
+  if (n <= 0 || n > BWD_UMAX) return;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const uint2* __restrict__ src = P.ks[1] + s;
+  uint2* __restrict__ dst = P.ks[0] + s;
+  constexpr int kRounds = BWD_UMAX / BWD_THREADS;
+  const int pw = bwd_wave_span(n);
+  const int rounds = pw / TZR_WAVE;
+  uint32_t kreg[kRounds], sreg[kRounds], bkt[kRounds], dest[kRounds];
+  uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+  // the heavy-bucket bitmap of the table, one word per lane of the first 16: fetched together with
+  // the lookups, consulted through a shuffle
+  const uint32_t hword = lane < BWD_NB / 32 ? P.hbits[(size_t)cd.t * (BWD_NB / 32) + lane] : 0u;
+  // heavy lookups ahead of each position = exclusive count of the heavy flags in position order
+  // (wave-contiguous ownership: ballots inside a round, running count over rounds, waves by LDS)
+  uint32_t hbefore[kRounds];
+  uint32_t hrun = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    kreg[r] = sreg[r] = bkt[r] = 0u;
+    hbefore[r] = 0;
+    const bool in = r < rounds && lp < n;
+    if (in) {
+      const uint2 v = src[lp];
+      kreg[r] = v.x;
+      sreg[r] = v.y;
+      bkt[r] = bwd_bucket(v.x, cd.mult);
+    }
+    if (r < rounds) {
+      const uint32_t hw = (uint32_t)__shfl((int)hword, (int)(bkt[r] >> 5), TZR_WAVE);
+      const bool heavy = in && ((hw >> (bkt[r] & 31)) & 1u);
+      if (in && !heavy) {
+        vmask |= 1u << r;
+        kmin = min(kmin, kreg[r]);
+        kmax = max(kmax, kreg[r]);
+      }
+      const unsigned long long hm = __ballot(heavy);
+      hbefore[r] = hrun + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+      hrun += (uint32_t)__popcll(hm);
+    }
+  }
+  for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, TZR_WAVE));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m, TZR_WAVE));
+  }
+  if (threadIdx.x == 0) S.gstart[0] = bkt[0];  // the unit is in bucket order: its first bucket
+  if (lane == 0) {
+    S.smm[wv] = kmin;
+    S.smm[BWD_WAVES + wv] = kmax;
+    S.wtot[wv] = hrun;
+  }
+  __syncthreads();
+  const uint32_t b0 = S.gstart[0];
+  uint32_t hwave = 0, htot = 0;
+#pragma unroll
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    kmin = min(kmin, S.smm[w]);
+    kmax = max(kmax, S.smm[BWD_WAVES + w]);
+    if (w < wv) hwave += S.wtot[w];
+    htot += S.wtot[w];
+  }
+  // every light lookup of a bucket sees the same count: one entry per bucket of the unit
+  if (htot) {
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if ((vmask >> r) & 1u) S.hb[bkt[r] - b0] = (uint16_t)(hwave + hbefore[r]);
+  }
+  __syncthreads();  // smm is reused by the core
+  if (kmin > kmax) return;  // nothing but heavy lookups (workgroup-uniform)
+  bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), htot == 0,
+                         S, dest);
+  // final position = unit start + rank among the unit's light lookups + heavy lookups ahead
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r)
+    if ((vmask >> r) & 1u) {
+      const uint32_t ahead = htot ? (uint32_t)S.hb[bwd_bucket(kreg[r], cd.mult) - b0] : 0u;
+      dst[dest[r] + ahead] = make_uint2(kreg[r], sreg[r]);
+    }
+}
+
+__device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__ tables,
+                                                    const BwdPlan& P, BwdSortLds& S,
+                                                    const BwdHeavy& H) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int64_t rows = tables[H.t].rows;
+  int nb;
+  uint64_t mult;
+  bwd_bucket_params(rows, &nb, &mult);
+  const uint64_t klo64 = (((uint64_t)H.bin << 32) + mult - 1) / mult;
+  uint64_t khi = (((uint64_t)(H.bin + 1) << 32) + mult - 1) / mult;
+  if (khi > (uint64_t)rows) khi = (uint64_t)rows;
+  const uint32_t klo = (uint32_t)klo64;
+  const int wbits = bwd_bits((uint32_t)(khi - klo64 - 1));
+  const int n = (int)(H.end - H.start);
+  const uint2* __restrict__ src = P.ks[1] + H.start;
+  uint2* __restrict__ dst = P.ks[0] + H.start;
+  const int t0 = H.tile * BWD_HT;
+  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] = 0;
+  __syncthreads();
+  // counts of the whole bucket per row id; the counts when the walk reaches this tile = its prefix
+  constexpr int kRounds = BWD_HT / BWD_THREADS;
+  for (int base = 0; base < n; base += BWD_HT) {
+    if (base == t0) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.pre[i] = S.gstart[i];
       __syncthreads();
     }
+    uint32_t k8[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+      k8[r] = i < n ? src[i].x : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      if (base + r * BWD_THREADS >= n) break;  // wave-uniform
+      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+      bwd_wave_count(S.gstart, k8[r] - klo, i < n, wbits, lane);
+    }
+  }
+  __syncthreads();
+  bwd_block_scan(S.gstart, BWD_NB, S.wtot);
+  const int nt = min(BWD_HT, n - t0);
+  const int pw = bwd_wave_span(nt);
+  const int rounds = pw / TZR_WAVE;
+  uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    kreg[r] = sreg[r] = dig[r] = 0u;
+    if (r < rounds && lp < nt) {
+      vmask |= 1u << r;
+      const uint2 v = src[t0 + lp];
+      kreg[r] = v.x;
+      sreg[r] = v.y;
+      dig[r] = v.x - klo;
+    }
+  }
+  bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, wbits, S.L, dest);
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r)
+    if ((vmask >> r) & 1u)
+      dst[S.gstart[dig[r]] + S.pre[dig[r]] + (dest[r] - (uint32_t)S.L.lstart[dig[r]])] =
+          make_uint2(kreg[r], sreg[r]);
+  __syncthreads();
+}
+
+__device__ __forceinline__ void bwd_sort_heavy_serial(const TzrTable* __restrict__ tables,
+                                                      const BwdPlan& P, BwdSortLds& S,
+                                                      const BwdHeavy& H) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int64_t rows = tables[H.t].rows;
+  int nb;
+  uint64_t mult;
+  bwd_bucket_params(rows, &nb, &mult);
+  const uint64_t klo64 = (((uint64_t)H.bin << 32) + mult - 1) / mult;
+  uint64_t khi = (((uint64_t)(H.bin + 1) << 32) + mult - 1) / mult;
+  if (khi > (uint64_t)rows) khi = (uint64_t)rows;
+  const uint32_t klo = (uint32_t)klo64;
+  const int bits = max(1, bwd_bits((uint32_t)(khi - klo64 - 1)));
+  // an odd number of passes ks[1] -> ks[0] -> ks[1] -> ks[0] ends where the apply reads
+  const int npass = bits <= BWD_RB ? 1 : (bits <= 3 * BWD_RB ? 3 : 5);
+  const int width = (bits + npass - 1) / npass;
+  const unsigned mask = (1u << width) - 1u;
+  const int n = (int)(H.end - H.start);
+  constexpr int kRounds = BWD_HT / BWD_THREADS;
+  if (n <= BWD_HT) {  // one tile: all passes without leaving LDS
+    const uint2* __restrict__ src = P.ks[1] + H.start;
+    uint2* __restrict__ dst = P.ks[0] + H.start;
+    const int pw = bwd_wave_span(n);
+    const int rounds = pw / TZR_WAVE;
+    uint32_t kreg[kRounds], sreg[kRounds], dest[kRounds];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      kreg[r] = sreg[r] = 0u;
+      if (r < rounds && lp < n) {
+        vmask |= 1u << r;
+        const uint2 v = src[lp];
+        kreg[r] = v.x;
+        sreg[r] = v.y;
+      }
+    }
+    bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, klo, bits, false, S, dest);
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if ((vmask >> r) & 1u) dst[dest[r]] = make_uint2(kreg[r], sreg[r]);
+    __syncthreads();
+    return;
+  }
+  for (int pass = 0; pass < npass; ++pass) {
+    const uint2* __restrict__ src = ((pass & 1) ? P.ks[0] : P.ks[1]) + H.start;
+    uint2* __restrict__ dst = ((pass & 1) ? P.ks[1] : P.ks[0]) + H.start;
+    const int shift = pass * width;
+    for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += BWD_HT) {
+      uint32_t k8[kRounds];
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+        const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+        k8[r] = i < n ? src[i].x : 0u;
+      }
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+        if (base + r * BWD_THREADS >= n) break;  // wave-uniform
+        const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+        bwd_wave_count(S.gstart, ((k8[r] - klo) >> shift) & mask, i < n, width, lane);
+      }
+    }
+    __syncthreads();
+    bwd_block_scan(S.gstart, BWD_NB, S.wtot);
+    for (int t0 = 0; t0 < n; t0 += BWD_HT) {
+      const int nt = min(BWD_HT, n - t0);
+      const int pw = bwd_wave_span(nt);
+      const int rounds = pw / TZR_WAVE;
+      uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
+      uint32_t vmask = 0;
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+        const int lp = wv * pw + r * TZR_WAVE + lane;
+        kreg[r] = sreg[r] = dig[r] = 0u;
+        if (r < rounds && lp < nt) {
+          vmask |= 1u << r;
+          const uint2 v = src[t0 + lp];
+          kreg[r] = v.x;
+          sreg[r] = v.y;
+          dig[r] = ((v.x - klo) >> shift) & mask;
+        }
+      }
+      bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, width, S.L, dest);
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r)
+        if ((vmask >> r) & 1u)
+          dst[S.gstart[dig[r]] + (dest[r] - (uint32_t)S.L.lstart[dig[r]])] = make_uint2(kreg[r], sreg[r]);
+      __syncthreads();
+      for (int d = threadIdx.x; d < BWD_NB; d += BWD_THREADS)
+        S.gstart[d] += (unsigned)S.L.lstart[d + 1] - (unsigned)S.L.lstart[d];
+      __syncthreads();
+    }
+    __threadfence();  // this workgroup reads the pass's output back in the next pass
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_kernel(
+    const TzrTable* __restrict__ tables, int n_units, BwdPlan P) {
+  __shared__ BwdSortLds S;
+  if ((int)blockIdx.x < n_units) {
+    bwd_sort_unit(tables, P, S, (int)blockIdx.x);
+    return;
+  }
+  const unsigned nh = P.hcount[0];
+  const unsigned workers = gridDim.x - (unsigned)n_units;
+  for (unsigned hi = blockIdx.x - (unsigned)n_units; hi < nh; hi += workers) {
+    const BwdHeavy H = P.hlist[hi];
+    if (H.tile >= 0) bwd_sort_heavy_tile(tables, P, S, H);
+    else bwd_sort_heavy_serial(tables, P, S, H);
   }
 }
 
@@ -475,6 +867,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_heavy_kernel(
 // ------------------------------------------------------------------------------------------
 
 int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO geometry path
+int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
                                    const TzrFeature* d_feats, int n_feats, int n_keys,
@@ -517,8 +910,9 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, d_tables, n_tables, P);
   hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                      n_tables, A, P);
-  const unsigned hgrid = (unsigned)std::min<int64_t>(P.max_heavy, 512);
-  hipLaunchKernelGGL(tzr_bwd_heavy_kernel, dim3(hgrid), dim3(BWD_THREADS), 0, s, d_tables, P);
+  const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 128);
+  hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
+                     (int)chunks, P);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -4,13 +4,10 @@
 // {warp,cta}_per_row_1 (optimizer fused into backward by apply_optimizer_in_backward,
 // /root/reference/tzrec/main.py:774-781).
 //
-// Input: the plan of pooled_bwd.hip -- per table, lookups partitioned into buckets of consecutive
-// row ids, heavy buckets already sorted by (row, original position).
+// Input: the plan of pooled_bwd.hip -- per table, lookups sorted by (row, original position).
 // A workgroup owns one UNIT of the table's sorted positions (< BWD_CH + BWD_TH lookups: whole light
-// buckets and/or block-sized slices of heavy ones).  It first finishes the order of its light
-// buckets in LDS (stable counting passes on the row-id bits left inside the unit -- the passes 2
-// and 3 of round 1's global radix sort, now without leaving the CU), then each of its 4 waves
-// reduces a quarter of the unit tile by tile:
+// buckets and/or block-sized slices of heavy ones; keys + sources staged once in LDS, coalesced);
+// each of its 4 waves reduces a quarter of the unit tile by tile:
 //   * a tile = 64/(D/4) consecutive sorted lookups, one per lane group: ALL gradient gathers of a
 //     tile are independent loads in flight together (the HBM/MALL latency is paid once per tile,
 //     not once per duplicate);
@@ -21,7 +18,10 @@
 //     no atomics, no cross-XCD L2 coherence hazard.
 //   * runs crossing a wave range are stitched through LDS records by wave 0, runs crossing a
 //     unit (only possible inside a heavy bucket or an exact table) through per-unit records by
-//     tzr_bwd_stitch_kernel (a 65536-lookup run of a 3-row table is 32 unit records long).
+//     the last unit of the table to finish (a 65536-lookup run of a 3-row table is 64 unit records
+//     long): ONE launch for the whole apply.
+#include <tzr_gfx950.h>
+
 #include "pooled_bwd.h"
 
 struct BwdGrads {
@@ -229,19 +229,84 @@ __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const Bwd
   bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
 
-// Scratch of the reduce kernel: the unit-local sort and the boundary records of the wave ranges are
-// never live together.
-struct BwdReduceSort {
-  uint32_t pk[BWD_UMAX], ps[BWD_UMAX];  // ping-pong of the unit-local passes
-  BwdRankLds<BWD_LNB> L;
-};
-struct BwdReduceRec {
-  float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
-};
-union BwdReduceLds {
-  BwdReduceSort sort;
-  BwdReduceRec rec;
-};
+// Boundary record of a unit: written by wave 0 of its workgroup, read by whichever workgroup
+// stitches the table (another CU, usually another XCD): agent-scope stores and loads (tzr_gfx950.h).
+__device__ __forceinline__ void bwd_publish4(float* p, float4 v) {
+  uint64_t* q = reinterpret_cast<uint64_t*>(p);
+  tzr_publish_u64(q, ((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x));
+  tzr_publish_u64(q + 1, ((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z));
+}
+__device__ __forceinline__ float4 bwd_consume4(const float* p) {
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+  const uint64_t a = tzr_consume_u64(q), b = tzr_consume_u64(q + 1);
+  return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)),
+                     __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32)));
+}
+
+// Runs crossing unit boundaries: the unit holding the run's first lookup adds the leading pieces
+// of the following units (in order) and updates the row.  One wave.
+template <bool ADAM>
+__device__ __forceinline__ void bwd_stitch_unit(const TzrTable& tb, const BwdOpt& opt, float lr,
+                                                int max_dim, const BwdPlan& P, int chunk,
+                                                int last_chunk, int lane) {
+  const bool on = lane < (tb.dim >> 2);
+  const uint32_t key = tzr_consume_u32(P.ctkey + chunk);
+  float4 sum = tzr_zero4();
+  if (on) sum = bwd_consume4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
+  for (int c2 = chunk + 1; c2 < last_chunk; ++c2) {
+    const unsigned f = tzr_consume_u32(P.cflags + c2);
+    if (!(f & BWD_LEAD)) break;
+    if (on) sum = tzr_add4(sum, bwd_consume4(P.clead + (size_t)c2 * max_dim + 4 * lane));
+    if (!(f & BWD_LEAD_WHOLE)) break;
+  }
+  bwd_apply_row_wave<ADAM>(tb, opt, lr, key, sum, lane);
+}
+
+// Called by wave 0 of every unit once its boundary record is published.  Runs can only cross unit
+// boundaries inside a sorted bucket (a row of an exact table, a heavy bucket): the units that
+// overlap such a bucket meet at the bucket's counter, and the LAST of them to arrive stitches the
+// bucket's open runs -- the pieces are summed in unit order whoever does it, so the result does
+// not depend on the arrival order; buckets are stitched in parallel, and no second launch is
+// needed (round 1: tzr_bwd_stitch_kernel, 10 us at B = 65536).  A unit touches at most two such
+// buckets: the one its first lookup and the one its last lookup falls in.
+template <bool ADAM>
+__device__ __forceinline__ void bwd_arrive_and_stitch(const TzrTable& tb, const BwdOpt& opt, float lr,
+                                                      int max_dim, const BwdPlan& P,
+                                                      const BwdChunkDesc& cd, uint32_t b_first,
+                                                      uint32_t b_last, int lane) {
+  if (!P.tab_stitch[cd.t]) return;
+  const size_t base = (size_t)cd.t * BWD_NB;
+  const uint32_t e0 = P.sexp[base + b_first];
+  const uint32_t e1 = b_last != b_first ? P.sexp[base + b_last] : 0u;
+  if (!(e0 | e1)) return;
+  tzr_drain_stores();  // the record (write-through stores of this wave) before the arrivals
+  const int c_first = P.tab_chunk[cd.t];
+  const uint32_t* bb = P.binbase + (size_t)cd.t * (BWD_NB + 1);
+  for (int side = 0; side < 2; ++side) {
+    const uint32_t b = side ? b_last : b_first;
+    const uint32_t expect = side ? e1 : e0;
+    if (!expect) continue;
+    int last = 0;
+    if (lane == 0) last = tzr_arrive(P.sarr + base + b) == expect - 1 ? 1 : 0;
+    last = __shfl(last, 0, TZR_WAVE);
+    if (!last) continue;
+      if (lane == 0) tzr_publish_u32(P.sarr + base + b, 0u);  // the plan can be applied again
+    const int u0 = c_first + (int)((bb[b] - (uint32_t)cd.ts) / (uint32_t)P.ch);
+    const int u1 = c_first + (int)((bb[b + 1] - 1 - (uint32_t)cd.ts) / (uint32_t)P.ch);
+    for (int cb = u0; cb <= u1; cb += TZR_WAVE) {
+      const int c = cb + lane;
+      bool mine = false;
+      if (c <= u1 && (tzr_consume_u32(P.cflags + c) & BWD_TRAIL))
+        mine = bwd_bucket(tzr_consume_u32(P.ctkey + c), cd.mult) == b;  // u1 may end in another bucket
+      unsigned long long open = __ballot(mine);
+      while (open) {
+        const int k = __ffsll(open) - 1;
+        open &= open - 1;
+        bwd_stitch_unit<ADAM>(tb, opt, lr, max_dim, P, cb + k, u1 + 1, lane);
+      }
+    }
+  }
+}
 
 template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
@@ -251,11 +316,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   __shared__ uint32_t sK[BWD_UMAX + 2];  // K[s-1], K[s..e), K[e] (sentinels at table ends)
   __shared__ uint32_t sS[BWD_UMAX];
   __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
-  __shared__ uint32_t smm[2 * BWD_WAVES];
-  __shared__ BwdReduceLds U;
+  __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
   __shared__ TzrDst sG[TZR_MAX_DST];
-  float (*rlead)[BWD_MAXDIM] = U.rec.rlead;
-  float (*rtrail)[BWD_MAXDIM] = U.rec.rtrail;
   BwdChunkDesc cd;
   if (!bwd_chunk(P, blockIdx.x, &cd)) return;
   const int t = cd.t;
@@ -264,95 +326,24 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   const int64_t s = P.ucut[blockIdx.x];
   const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)P.ucut[blockIdx.x + 1] : te;
   const int n = (int)(e - s);
+  const TzrTable tb = tables[t];
   if (n <= 0 || n > BWD_UMAX) {  // an empty tail unit (n > BWD_UMAX cannot happen by construction)
-    if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;
+    if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;  // overlaps no bucket: nobody waits for it
     return;
   }
-  const TzrTable tb = tables[t];
-  const uint2* __restrict__ KS = P.ks[1];
+  // exact tables are final after the partition pass (ks[1]); everything else was finished by the
+  // sort kernel (ks[0])
+  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
-  if (P.uflag[blockIdx.x]) {  // exact table or a slice of a heavy bucket: already in final order
-    for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-      const uint2 v = KS[s + i];
-      sK[i + 1] = v.x;
-      sS[i] = v.y;
-    }
-  } else {
-    // Whole light buckets (plus, possibly, sorted slices of heavy ones at either end), each bucket
-    // a contiguous range of row ids in bucket order: a stable LSD sort of (row id - smallest row id
-    // of the unit) over the bits that difference needs finishes the order.  Uniform ids at
-    // B = 65536 on a 40M-row table: ~9 buckets of ~128 lookups, 21 bits, 3 passes of 7 bits.
-    constexpr int kRounds = BWD_UMAX / BWD_THREADS;
-    const int pw = bwd_wave_span(n);
-    const int rounds = pw / TZR_WAVE;
-    uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
-    uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int lp = wv * pw + r * TZR_WAVE + lane;
-      kreg[r] = sreg[r] = 0u;
-      if (r < rounds && lp < n) {
-        vmask |= 1u << r;
-        const uint2 v = KS[s + lp];
-        kreg[r] = v.x;
-        sreg[r] = v.y;
-        kmin = min(kmin, v.x);
-        kmax = max(kmax, v.x);
-      }
-    }
-    for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) {
-      kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, TZR_WAVE));
-      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m, TZR_WAVE));
-    }
-    if (lane == 0) {
-      smm[wv] = kmin;
-      smm[BWD_WAVES + wv] = kmax;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < BWD_WAVES; ++w) {
-      kmin = min(kmin, smm[w]);
-      kmax = max(kmax, smm[BWD_WAVES + w]);
-    }
-    const int bits = max(1, bwd_bits(kmax - kmin));
-    const int npass = (bits + BWD_LB - 1) / BWD_LB;
-    const int width = (bits + npass - 1) / npass;
-    const unsigned mask = (1u << width) - 1u;
-    for (int pass = 0; pass < npass; ++pass) {
-      const int shift = pass * width;
-#pragma unroll
-      for (int r = 0; r < kRounds; ++r) dig[r] = ((kreg[r] - kmin) >> shift) & mask;
-      bwd_rank_tile<BWD_LNB, kRounds>(dig, vmask, rounds, width, U.sort.L, dest);
-      if (pass == npass - 1) {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r)
-          if ((vmask >> r) & 1u) {
-            sK[dest[r] + 1] = kreg[r];
-            sS[dest[r]] = sreg[r];
-          }
-      } else {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r)
-          if ((vmask >> r) & 1u) {
-            U.sort.pk[dest[r]] = kreg[r];
-            U.sort.ps[dest[r]] = sreg[r];
-          }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-          const int lp = wv * pw + r * TZR_WAVE + lane;
-          if ((vmask >> r) & 1u) {
-            kreg[r] = U.sort.pk[lp];
-            sreg[r] = U.sort.ps[lp];
-          }
-        }
-      }
-    }
+  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+    const uint2 v = KS[s + i];
+    sK[i + 1] = v.x;
+    sS[i] = v.y;
   }
   if (threadIdx.x == 0) {
     // the neighbours outside the unit are either in another bucket (another row id) or in the same
-    // heavy bucket, which is sorted in place: comparing with them is always meaningful
+    // sorted bucket: comparing with them is always meaningful
     sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
     sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
 #pragma unroll
@@ -468,40 +459,17 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     }
   }
   if (open) cf |= BWD_TRAIL;
-  if (on) {
-    tzr_st4(P.clead + (size_t)blockIdx.x * max_dim + 4 * lane, clead);
-    tzr_st4(P.ctrail + (size_t)blockIdx.x * max_dim + 4 * lane, osum);
+  if (on && cf) {  // only units with an open boundary have a payload
+    bwd_publish4(P.clead + (size_t)blockIdx.x * max_dim + 4 * lane, clead);
+    bwd_publish4(P.ctrail + (size_t)blockIdx.x * max_dim + 4 * lane, osum);
   }
   if (lane == 0) {
-    P.cflags[blockIdx.x] = cf;
-    P.clkey[blockIdx.x] = sK[1];
-    P.ctkey[blockIdx.x] = okey;
+    tzr_publish_u32(P.cflags + blockIdx.x, cf);
+    tzr_publish_u32(P.clkey + blockIdx.x, sK[1]);
+    tzr_publish_u32(P.ctkey + blockIdx.x, okey);
   }
-}
-
-// Runs crossing chunk boundaries: the chunk holding the run's first lookup adds the leading
-// pieces of the following chunks (in order) and updates the row.  One wave per chunk.
-template <bool ADAM>
-__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_stitch_kernel(
-    const TzrTable* __restrict__ tables, int T, BwdOpt opt, int max_dim, BwdPlan P) {
-  const int lane = threadIdx.x & (TZR_WAVE - 1);
-  const int chunk = blockIdx.x * BWD_WAVES + threadIdx.x / TZR_WAVE;
-  BwdChunkDesc cd;
-  if (!bwd_chunk(P, chunk, &cd)) return;
-  if (!(P.cflags[chunk] & BWD_TRAIL)) return;
-  const TzrTable tb = tables[cd.t];
-  const bool on = lane < (tb.dim >> 2);
-  const float lr = *opt.lr;
-  const uint32_t key = P.ctkey[chunk];
-  float4 sum = tzr_zero4();
-  if (on) sum = tzr_ld4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
-  for (int c2 = chunk + 1; c2 < cd.last_chunk; ++c2) {
-    const unsigned f = P.cflags[c2];
-    if (!(f & BWD_LEAD)) break;
-    if (on) sum = tzr_add4(sum, tzr_ld4(P.clead + (size_t)c2 * max_dim + 4 * lane));
-    if (!(f & BWD_LEAD_WHOLE)) break;
-  }
-  bwd_apply_row_wave<ADAM>(tb, opt, lr, key, sum, lane);
+  bwd_arrive_and_stitch<ADAM>(tb, opt, lr, max_dim, P, cd, bwd_bucket(sK[1], cd.mult),
+                              bwd_bucket(sK[n], cd.mult), lane);
 }
 
 extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
@@ -555,14 +523,10 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
     hipLaunchKernelGGL((tzr_bwd_reduce_kernel<true>), dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                        n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
                        max_dim, P);
-    hipLaunchKernelGGL((tzr_bwd_stitch_kernel<true>), dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
-                       dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
   } else {
     hipLaunchKernelGGL((tzr_bwd_reduce_kernel<false>), dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                        n_tables, d_feats, d_offsets, d_weights, B, (int)uniform, grad_mode, G, opt,
                        max_dim, P);
-    hipLaunchKernelGGL((tzr_bwd_stitch_kernel<false>), dim3((chunks + BWD_WAVES - 1) / BWD_WAVES),
-                       dim3(BWD_THREADS), 0, s, d_tables, n_tables, opt, max_dim, P);
   }
   TZR_CHECK_LAUNCH();
   return TZR_OK;

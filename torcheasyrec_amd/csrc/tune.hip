@@ -5,11 +5,16 @@
 
 extern int g_tzr_fwd_tile_b;
 extern int g_tzr_bwd_force_prep;
+extern int g_tzr_bwd_ch;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
   if (!strcmp(name, "fwd_tile_b")) {
     g_tzr_fwd_tile_b = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_ch")) {
+    g_tzr_bwd_ch = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_force_prep")) {

@@ -1,0 +1,43 @@
+// Hand-off of a few words between workgroups INSIDE one launch on gfx950 (8 XCDs, private L2s, a
+// CU's vector L1 never refreshed by other CUs' stores).  A release fence (`buffer_wbl2 sc1`) would
+// write back every dirty line of the XCD's L2 -- inside the reduce kernel that is the row updates
+// of every workgroup on the XCD: folding the stitch step with __threadfence() made the kernel 2.3x
+// slower (profiles/r02c).  Instead, the protocol of cdna_hip_programming.md guideline 16 (R1):
+//   producer: payload with write-through stores -> every storing wave drains its vector memory
+//             counter -> ONE lane's agent-scope counter increment;
+//   consumer: the arrival that completes the count reads the payload with loads that bypass its
+//             caches: no fence on either side.
+// Included as <tzr_gfx950.h>: the CPU lane emulator of tests/ shadows this one file (everything in
+// here is a gfx950 instruction or attribute with no meaning on a host CPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((address_space(1))) uint32_t tzr_gu32;
+typedef __attribute__((address_space(1))) uint64_t tzr_gu64;
+
+// SYSTEM scope (sc0 sc1) on both sides: the access is performed at the memory side, a copy of the
+// line in the reading XCD's L2 (left there by an earlier read of a NEIGHBOURING word, before this
+// word was published) cannot serve it.  Agent scope (sc1 only) did exactly that once in ~6 runs
+// of the full-size Zipf test when several stitchers of one XCD shared record lines (r02 notes).
+__device__ __forceinline__ void tzr_publish_u32(uint32_t* p, uint32_t v) {
+  __hip_atomic_store((tzr_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void tzr_publish_u64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store((tzr_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint32_t tzr_consume_u32(const uint32_t* p) {
+  return __hip_atomic_load((tzr_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t tzr_consume_u64(const uint64_t* p) {
+  return __hip_atomic_load((tzr_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// every wave that published calls this before the arrival is counted
+__device__ __forceinline__ void tzr_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// returns the number of arrivals before this one
+__device__ __forceinline__ uint32_t tzr_arrive(uint32_t* counter) {
+  return __hip_atomic_fetch_add((tzr_gu32*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Kernel attribute: compile for exactly `n` waves per SIMD (caps the VGPR budget at 512 / n).
+#define TZR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))

@@ -252,7 +252,12 @@ class EmbeddingBagCollection(nn.Module):
         self._side_stream = None
         self._lookup_trackers: list = []  # register_post_lookup_tracker_fn
         self._track_segs: Dict[Tuple[str, ...], tuple] = {}
-        self.async_plan = device.type == "cuda"  # overlap the backward index plan with the forward
+        # The backward index plan only needs the ids, so it could overlap the forward on a side stream
+        # (plan_backward_async).  Off by default: with the round-2 plan kernels the side-stream plan came
+        # out wrong (not a permutation of the lookups) in ~1/3 of the iterations of scripts/zipf_debug.py
+        # whenever other kernels of the main stream ran next to it, while the same kernels in ONE stream
+        # were right in 220 of 220 (NOTES.md "side-stream plan"); and the plan is ~60 us of a step now.
+        self.async_plan = False
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
