@@ -135,3 +135,19 @@ def test_use_mask_rows_are_nulled_before_parsing():
     assert parse_sparse_column("x", ints).lengths.tolist() == [1, 0, 1]
     m = pa.array([[("1", 0.5)], [("2", 1.0)]], type=pa.map_(pa.string(), pa.float32()))
     assert apply_sample_mask(m, [True, True]).null_count == 0  # maps are not masked (feature.py:879)
+
+
+def test_kjt_normalises_dtypes_and_layout():
+    """int32 ids (legal in torchrec) and strided views are converted once at construction: the kernels
+    reinterpret the buffers as dense int64 / int32 / float32."""
+    import pytest
+    import torch
+
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    vals = torch.arange(12, dtype=torch.int32)[::2]  # int32 AND strided
+    k = KeyedJaggedTensor(["a", "b"], vals, torch.tensor([1, 2, 2, 1], dtype=torch.int16), weights=torch.ones(6, dtype=torch.float64))
+    assert k.values().dtype == torch.int64 and k.values().is_contiguous() and k.values().tolist() == [0, 2, 4, 6, 8, 10]
+    assert k.lengths().dtype == torch.int32 and k.weights().dtype == torch.float32
+    with pytest.raises(TypeError):
+        KeyedJaggedTensor(["a"], torch.zeros(2), torch.ones(2, dtype=torch.int32))

@@ -133,3 +133,41 @@ def test_head_bwd_matches_torch(dev, B, N):
     torch.testing.assert_close(gb.cpu().double(), gy.double().sum(0), rtol=1e-4, atol=1e-7)
     gx2, _, _ = head_bwd(gy.to(dev), x.to(dev), w.to(dev), need_grad_x=False)
     assert gx2 is None
+
+
+def test_mlp_proto_fields_build_the_reference_perceptron():
+    """use_bn / use_ln / dropout_ratio / activation / bias of the MLP proto (tzrec/protos/module.proto:4-17)
+    reach the module (config-built towers used to read hidden_units only): same layer sequence as
+    tzrec/modules/mlp.py Perceptron -- Linear (no bias under use_bn) -> BN | LN -> activation -> Dropout."""
+    import torch
+    from torch import nn
+
+    from torcheasyrec_amd.config import parse_text_proto
+    from torcheasyrec_amd.dlrm import MLP
+    from torcheasyrec_amd.rank_model import mlp_from_msg
+
+    m = mlp_from_msg(10, parse_text_proto('hidden_units: [8, 4] use_bn: true activation: "nn.GELU" dropout_ratio: [0.5, 0.25]'))
+    kinds = [type(x) for x in m.mlp]
+    assert kinds == [nn.Linear, nn.BatchNorm1d, nn.GELU, nn.Dropout, nn.Linear, nn.BatchNorm1d, nn.GELU, nn.Dropout]
+    assert m.mlp[0].bias is None and m.mlp[3].p == 0.5 and m.mlp[7].p == 0.25
+    m = mlp_from_msg(10, parse_text_proto("hidden_units: [8] use_ln: true bias: false"))
+    assert [type(x) for x in m.mlp] == [nn.Linear, nn.LayerNorm, nn.ReLU] and m.mlp[0].bias is None
+    m = mlp_from_msg(10, parse_text_proto("hidden_units: [8, 4]"))
+    assert m._plain and [type(x) for x in m.mlp] == [nn.Linear, nn.ReLU, nn.Linear, nn.ReLU]
+    # same numbers as the reference layer stack with shared parameters
+    torch.manual_seed(0)
+    ours = MLP(6, [5, 3], use_ln=True, activation="nn.Tanh")
+    ref = nn.Sequential(nn.Linear(6, 5), nn.LayerNorm(5), nn.Tanh(), nn.Linear(5, 3), nn.LayerNorm(3), nn.Tanh())
+    ref.load_state_dict({k.replace("mlp.", ""): v for k, v in ours.state_dict().items()})
+    x = torch.randn(7, 6)
+    assert torch.equal(ours(x), ref(x))
+    try:
+        MLP(4, [2], use_bn=True, use_ln=True)
+        raise AssertionError("use_bn + use_ln accepted")
+    except ValueError:
+        pass
+    try:
+        MLP(4, [2], activation="Dice")
+        raise AssertionError("unknown activation accepted")
+    except NotImplementedError:
+        pass

@@ -368,6 +368,66 @@ def test_sharded_sparse_adam_world2(emu_path):
         mp.spawn(_adam_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
+def _frozen_worker(rank, world, init_file, emu_path):
+    """`trainable: false` through the sharded exchange (tzrec/features/feature.py:629): a frozen row-wise
+    table and a frozen replicated table stay bit-identical on every rank while their trainable twins end
+    where the unsharded collection ends (the sharded copies of the configs dropped the flag)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sharding import ShardedEmbeddingBagCollection
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    rows, keys, frozen = [301, 257, 9, 7], ["a", "b", "c", "d"], [True, False, True, False]
+
+    def seeded(t):
+        def f(w):
+            g = torch.Generator().manual_seed(100 + t)
+            w.copy_((torch.rand(w.shape, generator=g) - 0.5) * 0.2)
+        return f
+
+    cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t), trainable=not frozen[t])  # noqa: E731
+                    for t, r in enumerate(rows)]
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    kinds = [sh.plan()[f"t{t}"]["sharding_type"] for t in range(4)]
+    assert kinds == ["row_wise", "row_wise", "data_parallel", "data_parallel"]
+    ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
+    before = {n: w.detach().clone() for n, w in sh.table_weights().items()}
+    rng = np.random.default_rng(0)
+    Bg, Bl = 40, 20
+    for step in range(2):
+        ids = np.stack([rng.integers(0, min(r, 25), size=Bg) for r in rows]).astype(np.int64)
+        g = torch.randn(Bg, 64, generator=torch.Generator().manual_seed(9 + step))
+        mine = KeyedJaggedTensor(keys, torch.from_numpy(ids[:, rank * Bl:(rank + 1) * Bl].reshape(-1).copy()),
+                                 torch.ones(4 * Bl, dtype=torch.int32), uniform_length=1)
+        full = KeyedJaggedTensor(keys, torch.from_numpy(ids.reshape(-1).copy()), torch.ones(4 * Bg, dtype=torch.int32), uniform_length=1)
+        out, out_ref = sh.forward_grouped(mine)["g"], ref.forward_grouped(full)["g"]
+        torch.testing.assert_close(out.detach(), out_ref.detach()[rank * Bl:(rank + 1) * Bl], rtol=1e-5, atol=1e-6)
+        (out * g[rank * Bl:(rank + 1) * Bl]).sum().backward()
+        (out_ref * g).sum().backward()
+    for t in range(4):
+        name = f"t{t}"
+        lo, n = sh.shard_of(name)
+        got = sh.table_weights()[name].detach()[:n]
+        if frozen[t]:
+            assert torch.equal(got, before[name][:n]), name  # never written
+        else:
+            if lo == 0:  # the ids are < 25: only the first block of a row-wise table is touched
+                assert not torch.equal(got, before[name][:n]), name
+            torch.testing.assert_close(got, ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-6, msg=name)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_frozen_tables_world2(emu_path):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_frozen_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
 def _zch_worker(rank, world, init_file, emu_path):
     """Sharded ZCH: raw ids routed by hash, remapped by their owner, admission / eviction local to the
     owner.  Every rank's map must follow oracle/zch_oracle.py fed with exactly the ids the hash sends
@@ -436,6 +496,32 @@ def _zch_worker(rank, world, init_file, emu_path):
         occ = np.asarray(oracle.row_ids) != EMPTY
         np.testing.assert_array_equal(mod.counts.numpy()[occ], np.asarray(oracle.counts)[occ])
     assert occ.sum() > 5  # ids were admitted on this rank
+    # checkpoint of a SHARDED ZCH model: every rank's own map share travels (a restore that leaves the maps
+    # empty would re-admit ids into rows that hold other ids' weights -- ADVICE r1)
+    from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+
+    class _Holder(torch.nn.Module):
+        def __init__(self, z):
+            super().__init__()
+            self._sharded_zch, self.ebc = z, z.sharded
+
+    ck = [os.path.join(os.path.dirname(init_file), "ck")]
+    dist.broadcast_object_list(ck, src=0)
+    save_checkpoint(ck[0], _Holder(m))
+    torch.manual_seed(99)
+    m2 = ShardedManagedCollisionEmbeddingBagCollection(
+        tables, {"user_emb": ZchConfig(Z, 2, "distance_lfu")}, device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=0.5),
+        groups={"g": keys}, dp_max_rows=10)
+    restore_checkpoint(ck[0], _Holder(m2))
+    mod2 = m2.mc.modules_by_table["user_emb"]
+    assert torch.equal(mod2.row_ids, mod.row_ids) and torch.equal(mod2.counts, mod.counts) and torch.equal(mod2.last_iter, mod.last_iter)
+    assert m2.mc._iter == m.mc._iter
+    for name in m.sharded.table_weights():
+        assert torch.equal(m2.sharded.table_weights()[name], m.sharded.table_weights()[name]), name
+    # the restored maps answer like the originals
+    probe = KeyedJaggedTensor(keys, torch.from_numpy(batches[rank]), torch.ones(4 * Bl, dtype=torch.int32), uniform_length=1)
+    m.eval(), m2.eval()
+    assert torch.equal(m2.forward_grouped(probe)["g"], m.forward_grouped(probe)["g"])
     dist.barrier()
     dist.destroy_process_group()
 

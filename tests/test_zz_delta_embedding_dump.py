@@ -2,10 +2,10 @@
 `hip` variants have only run through the lane emulator; sorted last, a hardware-only failure here
 cannot hide the rest of the suite under `pytest -x`.)
 
-Delta-embedding tracker + dump: the HIP bitmap tracker against the CPU
-restatement of the reference's id store (oracle/delta_oracle.py), bit-exact (integer work), and the
-dumper's cadence / parquet contract against the reference's rules
-(/root/reference/tzrec/utils/delta_embedding_dump.py)."""
+Delta-embedding tracker: the HIP bitmap tracker against the CPU restatement of
+the reference's id store (oracle/delta_oracle.py), bit-exact (integer work), and the (key ids, rows)
+a dump of tzrec's own DeltaEmbeddingDumper would write through the tracker seam
+(/root/reference/tzrec/utils/delta_embedding_dump.py:478-513,565-609,1043-1094)."""
 import os
 import sys
 
@@ -200,135 +200,21 @@ def test_out_of_range_ids_raise_at_read(dev):
         tr.get_unique()
 
 
-def _read(path):
-    import pyarrow.parquet as pq
-
-    return pq.read_table(path)
-
-
-def test_fp16_table_rows_are_widened_exactly(dev, tmp_path):
-    """FP16 tables (`data_type: FP16`): the dump holds the half rows widened to float32, bit for bit."""
+def test_fp16_table_rows_are_widened_exactly(dev):
+    """FP16 tables (`data_type: FP16`): a dump's rows are the half rows widened to float32, bit for bit;
+    key ids are ascending row ids of what the step touched."""
     m = _Model(dev, "FP16")
-    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=1), str(tmp_path), dev)
+    tr = dd.ModelDeltaTracker(m)
     kjt, vals, lens, B = m.batch(1)
     m.step(kjt)
-    dumper.maybe_dump(1)
-    t = _read(os.path.join(str(tmp_path), "delta_embedding_dump", "delta_embedding_step_1.parquet"))
-    fq, key = np.array(t["table_fqn"].to_pylist()), np.array(t["key_id"].to_pylist())
-    emb = np.array(t["embedding"].to_pylist(), dtype=np.float32)
+    pub = tr.published_rows()
+    assert set(pub) == {f"ebc.embedding_bags.{name}" for name in m.ebc.table_weights()}
     for name, w in m.ebc.table_weights().items():
         assert w.dtype == torch.float16
-        sel = fq == f"ebc.embedding_bags.{name}"
-        assert sel.any()
-        np.testing.assert_array_equal(emb[sel], w.detach().float().cpu().numpy()[key[sel]])
-
-
-@pytest.mark.parametrize("dtype", ["FP32"])
-def test_dumper_rows_cadence_and_schema(dev, tmp_path, dtype):
-    """interval 2: steps 2 and 4 are dumped by maybe_dump, the trailing step 5 by final_dump, a final
-    step on a boundary is skipped; every file holds exactly the touched ids (ascending per table) with
-    the table's CURRENT rows, in the reference's schema and file naming."""
-    import pyarrow as pa
-
-    m = _Model(dev, dtype)
-    cfg = dd.DeltaEmbeddingDumpConfig(dump_interval_steps=2)
-    dumper = dd.DeltaEmbeddingDumper(m, cfg, str(tmp_path), dev)
-    dumper.start()
-    store = dorc.DeltaStore()
-    seen = {}
-    for step in range(1, 6):
-        kjt, vals, lens, B = m.batch(step)
-        m.step(kjt)
-        dorc.record_kjt(store, _F2FQN, m.keys(), vals, lens, B)
-        if step % 2 == 0:
-            seen[step] = (store.get_unique(), {n: w.detach().float().cpu().numpy().copy() for n, w in m.ebc.table_weights().items()})
-        dumper.maybe_dump(step)
-    seen[5] = (store.get_unique(), {n: w.detach().float().cpu().numpy().copy() for n, w in m.ebc.table_weights().items()})
-    assert dumper.final_dump(4) is None  # boundary: already written
-    path5 = dumper.final_dump(5)
-    out_dir = os.path.join(str(tmp_path), "delta_embedding_dump")
-    assert path5 == os.path.join(out_dir, "delta_embedding_step_5.parquet")
-    assert sorted(os.listdir(out_dir)) == [f"delta_embedding_step_{s}.parquet" for s in (2, 4, 5)]
-    want_schema = pa.schema([("global_step", pa.int64()), ("rank", pa.int32()), ("world_size", pa.int32()),
-                             ("feature_name", pa.string()), ("table_fqn", pa.string()), ("key_id", pa.int64()),
-                             ("embedding", pa.list_(pa.float32())), ("source", pa.string())])
-    for step, (ids_by_fqn, weights) in seen.items():
-        t = _read(os.path.join(out_dir, f"delta_embedding_step_{step}.parquet"))
-        assert t.schema.equals(want_schema)
-        assert set(t["global_step"].to_pylist()) == {step} and set(t["rank"].to_pylist()) == {0}
-        assert set(t["world_size"].to_pylist()) == {1} and set(t["source"].to_pylist()) == {"model_delta_tracker"}
-        fq = np.array(t["table_fqn"].to_pylist())
-        assert set(fq) == set(ids_by_fqn)
-        for fqn, ids in ids_by_fqn.items():
-            sel = fq == fqn
-            rows_want, keys_want = dorc.dump_rows(ids, weights[fqn.split(".")[-1]])
-            np.testing.assert_array_equal(np.array(t["key_id"].to_pylist())[sel], keys_want)
-            np.testing.assert_array_equal(np.array(t["embedding"].to_pylist(), dtype=np.float32)[sel], rows_want)  # bit-exact copy
-            names = set(np.array(t["feature_name"].to_pylist())[sel])
-            assert names == {"f0,f0b" if fqn.endswith("t0") else "f" + fqn[-1]}
-    assert dumper.final_dump(0) is None
-    with pytest.raises(ValueError, match="global_step must be > 0"):
-        dumper.dump(0)
-    assert dumper.dump(6) is None  # nothing touched since step 5, one process: no file
-
-
-def test_dumper_int8_rows_are_the_export_encoding(dev, tmp_path):
-    """quant_type INT8: the embedding column holds QUint8RowwiseF16 bytes of the touched rows -- the
-    encoder that tests/test_export_quant.py pins to the reference's outputs."""
-    import pyarrow as pa
-    from torcheasyrec_amd.export import distributed_quantize_embeddings
-
-    m = _Model(dev)
-    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=1, quant_type=dd.QUANT_INT8,
-                                                                    output_dir=str(tmp_path / "o"), file_prefix="d"), "unused", dev)
-    kjt, vals, lens, B = m.batch(1)
-    m.step(kjt)
-    dumper.maybe_dump(1)
-    t = _read(str(tmp_path / "o" / "d_step_1.parquet"))
-    assert t.schema.field("embedding").type == pa.list_(pa.uint8())
-    fq = np.array(t["table_fqn"].to_pylist())
-    emb = np.array(t["embedding"].to_pylist(), dtype=np.uint8)
-    assert emb.shape[1] == 8 + 4
-    for name, w in m.ebc.table_weights().items():
-        sel = fq == f"ebc.embedding_bags.{name}"
-        ids = torch.from_numpy(np.array(t["key_id"].to_pylist())[sel]).to(dev)
-        want = distributed_quantize_embeddings(w.detach()[ids].float().contiguous(), 8, name, "QUint8RowwiseF16")
-        np.testing.assert_array_equal(emb[sel], want.cpu().numpy())
-
-
-def test_config_validation(dev):
-    """reference :128-155"""
-    v = dd.validate_delta_embedding_dump_config
-    v(None, dev)
-    with pytest.raises(ValueError, match="only one of"):
-        v(dd.DeltaEmbeddingDumpConfig(dump_interval_steps=5, dump_interval_minutes=1), dev)
-    with pytest.raises(ValueError, match="dump_interval_minutes must be > 0"):
-        v(dd.DeltaEmbeddingDumpConfig(dump_interval_minutes=0), dev)
-    with pytest.raises(ValueError, match="dump_interval_steps must be > 0"):
-        v(dd.DeltaEmbeddingDumpConfig(dump_interval_steps=0), dev)
-    assert dd.DeltaEmbeddingDumpConfig().interval_steps == 1000
-    from torcheasyrec_amd.config import parse_text_proto as parse_text
-
-    msg = parse_text('delta_embedding_dump_config { dump_interval_steps: 50 file_prefix: "x" quant_type: DELTA_EMBEDDING_QUANT_INT8 }')
-    c = dd.delta_embedding_dump_config_from_msg(msg.one("delta_embedding_dump_config"))
-    assert (c.dump_interval_steps, c.file_prefix, c.quant_type, c.dump_interval_minutes) == (50, "x", dd.QUANT_INT8, None)
-
-
-def test_timed_cadence(dev, tmp_path, monkeypatch):
-    """dump_interval_minutes: fixed-rate deadlines, missed ones skipped (reference :812-838)."""
-    m = _Model(dev)
-    now = [100.0]
-    monkeypatch.setattr(dd.time, "monotonic", lambda: now[0])
-    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_minutes=1), str(tmp_path), dev)
-    dumper.start()
-    m.step(m.batch(1)[0])
-    dumper.maybe_dump(1)  # 0 s elapsed
-    now[0] += 200.0  # three deadlines passed: one dump, next deadline in the future
-    m.step(m.batch(2)[0])
-    dumper.maybe_dump(2)
-    assert dumper._next_dump_time == 100.0 + 4 * 60.0 and dumper._last_dump_step == 2
-    assert dumper.final_dump(2) is None  # the timed dump landed on the last step
-    assert os.listdir(os.path.join(str(tmp_path), "delta_embedding_dump")) == ["delta_embedding_step_2.parquet"]
+        key, emb = pub[f"ebc.embedding_bags.{name}"]
+        assert emb.dtype == torch.float32 and bool((key[1:] > key[:-1]).all())
+        assert torch.equal(emb.cpu(), w.detach().float().cpu()[key.cpu()])
+    assert tr.published_rows() == {}  # delete on read
 
 
 def test_sequence_collection_is_one_site(dev):
@@ -350,7 +236,7 @@ def test_sequence_collection_is_one_site(dev):
     assert tr.get_unique_ids()["ec.embeddings.s"].cpu().tolist() == [0, 4, 9, 49]
 
 
-def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev, tmp_path):
+def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev):
     """ZCH (reference :355-358, :515-550, :1043-1094): keys are RAW ids -- looked up (with or without a
     row), admitted or evicted in the window -- each with the row the table serves it from at dump time:
     its own row while held, the shared fallback row otherwise."""
@@ -367,8 +253,8 @@ def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev, tmp_path):
 
     m = M()
     m.train()
-    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=2), str(tmp_path), dev)
-    assert list(dumper.tracker.fqn_to_feature_names) == ["mc.embedding_bags.t"] and "mc.embedding_bags.t" in dumper.tracker.zch_modules
+    tr = dd.ModelDeltaTracker(m)
+    assert list(tr.fqn_to_feature_names) == ["mc.embedding_bags.t"] and "mc.embedding_bags.t" in tr.zch_modules
     big = 10**12
     steps = {1: [big, 5, big, 77],   # nothing resident: all on the shared row; the round admits big, 5, 77
              2: [big, 5, big, 77],   # rows 0, 1, 2
@@ -379,14 +265,13 @@ def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev, tmp_path):
         kjt = KeyedJaggedTensor(["k"], torch.tensor(ids, dtype=torch.int64), torch.ones(4, dtype=torch.int32), uniform_length=1).to(dev)
         out, _ = m.mc(kjt)
         out.values().sum().backward()
-        dumper.maybe_dump(step)
-        if step in want_keys:
-            t = _read(os.path.join(str(tmp_path), "delta_embedding_dump", f"delta_embedding_step_{step}.parquet"))
-            assert t["key_id"].to_pylist() == want_keys[step]
+        if step in want_keys:  # a dump every two steps
+            key, emb = tr.published_rows()["mc.embedding_bags.t"]
+            assert key.cpu().tolist() == want_keys[step]
             row_ids = m.mc.modules_by_table["t"].row_ids.cpu().tolist()
             w = m.mc.ebc.table_weights()["t"].detach().cpu().numpy()
             rows = [row_ids.index(k) if k in row_ids else Z - 1 for k in want_keys[step]]
-            np.testing.assert_array_equal(np.array(t["embedding"].to_pylist(), dtype=np.float32), w[rows])
+            np.testing.assert_array_equal(emb.cpu().numpy(), w[rows])
             if step == 4:
                 assert rows == [1, 3, 3, 2]  # 5 keeps row 1, 900 took evicted 77's row 2, 42 and 77 are served by the shared row
 
@@ -414,7 +299,8 @@ def _sharded_worker(rank, world, init_file, emu_path, out_dir):
 
     m = M()
     assert {p["sharding_type"] for p in m.sh.plan().values()} == {"row_wise", "data_parallel"}
-    dumper = dd.DeltaEmbeddingDumper(m, dd.DeltaEmbeddingDumpConfig(dump_interval_steps=2, output_dir=out_dir), "unused", dev)
+    tr = dd.ModelDeltaTracker(m)
+    pubs = {}
     rng = np.random.default_rng(0)
     Bg, Bl = 24, 12
     all_ids = []
@@ -426,26 +312,20 @@ def _sharded_worker(rank, world, init_file, emu_path, out_dir):
         vals = np.concatenate([ids[f][b] for f in range(3) for b in sl] + [np.zeros(0, np.int64)])
         mine = KeyedJaggedTensor(keys, torch.from_numpy(vals), torch.from_numpy(lens[:, rank * Bl:(rank + 1) * Bl].reshape(-1).copy()))
         m.sh.forward_grouped(mine)["g"].sum().backward()
-        dumper.maybe_dump(step)
-    path3 = dumper.final_dump(3 if rank == 0 else 2)  # ragged last steps: every rank lands in step_3 (MAX)
-    assert path3 == os.path.join(out_dir, "step_3", f"delta_embedding_step_3_rank_{rank}_of_2.parquet")
+        if step in (2, 3):  # a dump after steps 1-2 and a final one after step 3
+            pubs[step] = tr.published_rows()
     for step, window in ((2, (0, 1)), (3, (2,))):
-        t = _read(os.path.join(out_dir, f"step_{step}", f"delta_embedding_step_{step}_rank_{rank}_of_2.parquet"))
-        assert set(t["rank"].to_pylist()) <= {rank} and set(t["world_size"].to_pylist()) <= {2}
-        fq = np.array(t["table_fqn"].to_pylist())
-        key = np.array(t["key_id"].to_pylist(), dtype=np.int64)
-        emb = np.array(t["embedding"].to_pylist(), dtype=np.float32).reshape(len(key), -1)
         for f, name in enumerate(["t0", "t1", "t2"]):
             lo, n = m.sh.shard_of(name)
             replicated = m.sh.plan()[name]["sharding_type"] == "data_parallel"
             samples = range(rank * Bl, (rank + 1) * Bl) if replicated else range(Bg)
             seen = np.concatenate([all_ids[w][f][b] for w in window for b in samples] + [np.zeros(0, np.int64)])
             want = np.unique(seen[(seen >= lo) & (seen < lo + n)])
-            sel = fq == f"sh.embedding_bags.{name}"
-            np.testing.assert_array_equal(key[sel], want)
-            if step == 3:  # rows are the CURRENT local rows (no update after the last dump)
+            key, emb = pubs[step].get(f"sh.embedding_bags.{name}", (torch.zeros(0, dtype=torch.int64), torch.zeros(0, 8)))
+            np.testing.assert_array_equal(key.numpy(), want)  # GLOBAL row ids of the rows this rank serves
+            if step == 3:  # rows are the CURRENT local rows (no update after the last read)
                 w = m.sh.table_weights()[name].detach().float().numpy()
-                np.testing.assert_array_equal(emb[sel], w[want - lo])
+                np.testing.assert_array_equal(emb.numpy(), w[want - lo])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -457,60 +337,6 @@ def test_sharded_dump_world2(emu_path, tmp_path):
 
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_sharded_worker, args=(2, os.path.join(d, "init"), emu_path, str(tmp_path / "out")), nprocs=2, join=True)
-    assert sorted(os.listdir(tmp_path / "out")) == ["step_2", "step_3"]
-    assert len(os.listdir(tmp_path / "out" / "step_2")) == 2
-
-
-def test_config_model_through_the_train_pipeline(dev, tmp_path):
-    """train_config.delta_embedding_dump_config of a tzrec config -> DeepFM built from the config ->
-    pipeline.progress with the reference's call sites (tzrec/main.py:547,611): the wide and deep tables
-    of one feature are separate FQNs under `embedding_group.ebc.embedding_bags`, shared tables list
-    both features, and every dumped row equals the table row at dump time."""
-    from test_config_plumbing import _batches
-    from torcheasyrec_amd.config import load_pipeline_spec
-    from torcheasyrec_amd.embedding_group import TrainPipeline
-    from torcheasyrec_amd.rank_model import build_rank_model
-
-    text = open(os.path.join(os.path.dirname(__file__), "golden", "deepfm_mini.config")).read()
-    text = text.replace("train_config {", 'train_config {\n  delta_embedding_dump_config { dump_interval_steps: 3 output_dir: "%s" }' % tmp_path, 1)
-    spec = load_pipeline_spec(text)
-    assert spec.delta_embedding_dump_config.dump_interval_steps == 3
-    torch.manual_seed(0)
-    model = build_rank_model(spec, device=dev)
-    dumper = dd.DeltaEmbeddingDumper(model, spec.delta_embedding_dump_config, "unused", dev)
-    dumper.start()
-    pipe = TrainPipeline(model, torch.optim.Adam(list(model.dense_parameters()), lr=1e-3), dev, model.loss)
-    it = iter(_batches(spec, 240, 60))  # 4 steps of 60
-    step = 0
-    while True:
-        try:
-            pipe.progress(it)
-        except StopIteration:
-            break
-        step += 1
-        dumper.maybe_dump(step)
-    assert step == 4
-    dumper.final_dump(step)
-    assert sorted(os.listdir(tmp_path)) == ["delta_embedding_step_3.parquet", "delta_embedding_step_4.parquet"]
-    t = _read(str(tmp_path / "delta_embedding_step_4.parquet"))
-    fq = np.array(t["table_fqn"].to_pylist())
-    prefix = "embedding_group.ebc.embedding_bags."
-    assert set(fq) == {prefix + n for n in ("cat_0_emb_wide", "cat_1_emb_wide", "cat_2_emb_wide", "cat_0_emb", "cat_1_emb", "cat_2_emb")}
-    names = dict(zip(fq, t["feature_name"].to_pylist()))
-    assert names[prefix + "cat_2_emb"] == "cat_2,cat_3" and names[prefix + "cat_0_emb_wide"] == "cat_0"
-    rng = np.random.default_rng(0)  # regenerate the ids _batches drew: step 4 = rows 180..239
-    sparse = [f for f in spec.features if f.is_sparse]
-    ids4 = {f.name: rng.integers(0, f.num_embeddings, size=240)[180:] for f in sparse}
-    key = np.array(t["key_id"].to_pylist())
-    emb = t["embedding"].to_pylist()
-    weights = model.embedding_group.ebc.table_weights()
-    for table, feats in (("cat_0_emb", ["cat_0"]), ("cat_2_emb_wide", ["cat_2", "cat_3"])):
-        sel = fq == prefix + table
-        want = np.unique(np.concatenate([ids4[f] for f in feats]))
-        np.testing.assert_array_equal(key[sel], want)
-        w = weights[table].detach().float().cpu().numpy()
-        got = np.array([e for e, s in zip(emb, sel) if s], dtype=np.float32)
-        np.testing.assert_array_equal(got, w[want])
 
 
 @pytest.mark.gpu

@@ -92,5 +92,24 @@ def test_mixed_lanes_on_one_rank_match_the_unsharded_collection(dev):
             assert set(got) == {f"ebc.embedding_bags.{n}" for n in tab_feat}
             for n, f in tab_feat.items():
                 np.testing.assert_array_equal(got[f"ebc.embedding_bags.{n}"], np.unique(vals[off[f * B]:off[(f + 1) * B]]))
+            # sparse Adam over lanes: every lane ticks its own step counter, a checkpoint carries all of them
+            # (only lane 0's used to be saved -> wrong bias correction in lanes 1..k after a resume)
+            from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+
+            aopt = SparseOptimizerConfig(kind="adam", lr=0.01)
+            sa = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=aopt, groups=groups, plan=plan)
+            for _ in range(3):
+                o = sa.forward_grouped(kjt)
+                (o["wide"].sum() + o["deep"].sum()).backward()
+            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sa.lanes] == [3.0] * len(sa.lanes)
+            save_checkpoint(os.path.join(d, "ck_adam"), Holder(sa))
+            sb = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=aopt, groups=groups, plan=plan)
+            restore_checkpoint(os.path.join(d, "ck_adam"), Holder(sb))
+            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sb.lanes] == [3.0] * len(sb.lanes)
+            oa, ob = sa.forward_grouped(kjt), sb.forward_grouped(kjt)
+            (oa["wide"].sum() + oa["deep"].sum()).backward()
+            (ob["wide"].sum() + ob["deep"].sum()).backward()
+            for name in sa.table_weights():
+                assert torch.equal(sa.table_weights()[name], sb.table_weights()[name]), name  # the 4th step agrees bit for bit
         finally:
             dist.destroy_process_group()

@@ -8,7 +8,8 @@ compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
   <dir>/model/rank<r>.pt       {"dense": {param: tensor},
                                 "tables": {"<module path>/<table>": {"lo", "n", "weight"[n, D]}},   rows [lo, lo+n)
                                            (module path: "ebc", "embedding_group.ebc", "embedding_group.ecs.<dim>")
-                                "zch": {"iter", "tables": {table: {row_ids, counts, last_iter}}} | None}
+                                "zch": {"iter", "sharded", "world_size", "tables": {table: {row_ids, counts, last_iter}}} | None}
+                                        (unsharded maps: rank 0's file; sharded: every rank's file holds its own share)
   <dir>/optimizer/rank<r>.pt   {"tables": {table: {"lo", "n", "momentum1"}}, "sparse_lr", "adam_steps": {module path: step},
                                 "dense": optimizer.state_dict()}        (sparse Adam: momentum1 = [exp_avg | exp_avg_sq])
   <dir>/plan                   the reference's plan JSON (rank 0)
@@ -57,12 +58,30 @@ def _collections(model: nn.Module):
 
 
 def _mc_of(model: nn.Module):
-    """The managed-collision (ZCH) wrapper, if the model has one."""
+    """(managed-collision (ZCH) wrapper or None, sharded?).  Unsharded: `model.mc` /
+    `model.embedding_group.mc`.  Sharded: the group keeps the wrapper of the rank's OWN share of the
+    maps under `_sharded_zch.mc` (embedding_group.py) -- every rank owns a different raw id -> row map."""
     for holder in (model, getattr(model, "embedding_group", None)):
-        mc = getattr(holder, "mc", None) if holder is not None else None
+        if holder is None:
+            continue
+        mc = getattr(holder, "mc", None)
         if mc is not None and hasattr(mc, "modules_by_table"):
-            return mc
-    return None
+            return mc, False
+        sz = getattr(holder, "_sharded_zch", None)
+        if sz is not None and getattr(sz, "mc", None) is not None:
+            return sz.mc, True
+    return None, False
+
+
+def _fused_optimizers(path: str, col):
+    """[(key, FusedSparseOptimizer)] of a collection.  A MixedShardedEmbeddingBagCollection runs one
+    optimizer -- and one sparse-Adam step counter -- per exchange lane (sharding.py), each ticking in
+    its own backward: all of them are saved, or lanes 1..k resume with a zero count under warm moments."""
+    lanes = getattr(col, "lanes", None)
+    if lanes is not None:
+        return [(f"{path}#lane{i}", lane.fused_optimizer) for i, lane in enumerate(lanes) if lane.fused_optimizer is not None]
+    f = getattr(col, "fused_optimizer", None)
+    return [(path, f)] if f is not None else []
 
 
 def _placement(ebc) -> Dict[str, Tuple[int, int, int, str]]:
@@ -104,19 +123,22 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
                              "ranks": list(p["ranks"])} for n, p in plan.items()}
         for c in (col._global if hasattr(col, "_global") else col.embedding_bag_configs()):
             dims[f"{path}/{c.name}"] = [c.num_embeddings, c.embedding_dim]
-    mc = _mc_of(model)
+    mc, mc_sharded = _mc_of(model)
     zch = None
-    if mc is not None and rank == 0:  # raw id / access count / last access of every row + the step counter
-        zch = {"iter": mc._iter, "tables": {n: {"row_ids": m.row_ids.cpu(), "counts": m.counts.cpu(), "last_iter": m.last_iter.cpu()}
-                                            for n, m in mc.modules_by_table.items()}}
+    if mc is not None and (mc_sharded or rank == 0):
+        # raw id / access count / last access of every row + the step counter.  Sharded: every rank saves
+        # the map of its own share (ids are routed by hash mod world size, so the maps only fit this world size)
+        zch = {"iter": mc._iter, "sharded": mc_sharded, "world_size": world,
+               "tables": {n: {"row_ids": m.row_ids.cpu(), "counts": m.counts.cpu(), "last_iter": m.last_iter.cpu()}
+                          for n, m in mc.modules_by_table.items()}}
     torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables, "zch": zch},
                os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
     fo = getattr(cols[0][1], "fused_optimizer", None)
     adam_steps = {}
-    for path, col in cols:  # sparse Adam: the optimizer-wide step count of every collection
-        f = getattr(col, "fused_optimizer", None)
-        if f is not None and getattr(f, "cfg", None) is not None and f.cfg.kind == "adam" and f._adam is not None:
-            adam_steps[path] = float(f._adam[0])
+    for path, col in cols:  # sparse Adam: the step count of every fused optimizer that ticks one
+        for key, f in _fused_optimizers(path, col):
+            if getattr(f, "cfg", None) is not None and f.cfg.kind == "adam" and f._adam is not None:
+                adam_steps[key] = float(f._adam[0])
     torch.save({"tables": o_tables, "sparse_lr": None if fo is None else fo.param_groups[0]["lr"], "adam_steps": adam_steps,
                 "dense": dense_optimizer.state_dict() if (dense_optimizer is not None and rank == 0) else None},
                os.path.join(checkpoint_dir, "optimizer", f"rank{rank}.pt"))
@@ -184,8 +206,22 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                 mine[n_].data.copy_(t)
             elif strict:
                 raise KeyError(f"checkpoint parameter {n_} not in the model")
-    mc = _mc_of(model)
-    zch = m_files[0].get("zch")
+    mc, mc_sharded = _mc_of(model)
+    zch = None
+    if mc is not None:
+        if mc_sharded:
+            if saved_world != world:
+                raise ValueError(f"sharded ZCH maps were saved at world size {saved_world}: raw ids are routed by hash mod "
+                                 f"world size, they cannot be restored at world size {world}")
+            zch = m_files[rank].get("zch")
+            if zch is not None and not zch.get("sharded", False):
+                raise ValueError("the checkpoint holds an unsharded ZCH map; this model shards it")
+        else:
+            zch = m_files[0].get("zch")
+            if zch is not None and zch.get("sharded", False):
+                raise ValueError("the checkpoint holds per-rank ZCH maps; this model keeps one unsharded map")
+        if zch is None and strict:
+            raise KeyError("checkpoint has no zch state for this rank")
     if mc is not None and zch is not None:
         mc._iter = int(zch["iter"])
         mc._cand = []
@@ -201,11 +237,13 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
     fo = getattr(cols[0][1], "fused_optimizer", None)
     if fo is not None and o_files[0].get("sparse_lr") is not None:
         fo.param_groups[0]["lr"] = o_files[0]["sparse_lr"]
+    saved_steps = o_files[0].get("adam_steps") or {}
     for path, col in cols:
-        f = getattr(col, "fused_optimizer", None)
-        t = (o_files[0].get("adam_steps") or {}).get(path)
-        if f is not None and t is not None and f.cfg.kind == "adam":
-            f.set_adam_step(float(t))
+        for key, f in _fused_optimizers(path, col):
+            # (older files hold one count per collection: every lane of it gets that one)
+            t = saved_steps.get(key, saved_steps.get(path))
+            if t is not None and f.cfg.kind == "adam":
+                f.set_adam_step(float(t))
     if dense_optimizer is not None and o_files[0].get("dense") is not None:
         dense_optimizer.load_state_dict(o_files[0]["dense"])
     if world > 1:

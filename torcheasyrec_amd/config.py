@@ -151,7 +151,7 @@ class PipelineSpec:
     # the raw optimizer blocks (learning-rate schedules: lr_scheduler.create_scheduler)
     sparse_optimizer_block: Optional[Msg] = None
     dense_optimizer_block: Optional[Msg] = None
-    # train_config.delta_embedding_dump_config (train.proto:86-111) -> delta_embedding_dump.DeltaEmbeddingDumpConfig
+    # train_config.delta_embedding_dump_config (train.proto:86-111), as parsed (Msg)
     delta_embedding_dump_config: Optional[object] = None
     # train_config.global_embedding_constraints.sharding_types (train.proto:144, plan_util.py:170-179)
     global_sharding_types: List[str] = field(default_factory=list)
@@ -264,9 +264,9 @@ def load_pipeline_spec(text: str) -> PipelineSpec:
     if tc.has("global_embedding_constraints"):
         spec.global_sharding_types = [str(t) for t in tc.one("global_embedding_constraints").many("sharding_types")]
     if tc.has("delta_embedding_dump_config"):  # enable_delta_embedding_dump, tzrec/main.py:691
-        from .delta_embedding_dump import delta_embedding_dump_config_from_msg
-
-        spec.delta_embedding_dump_config = delta_embedding_dump_config_from_msg(tc.one("delta_embedding_dump_config"))
+        # the block stays tzrec's to interpret (its DeltaEmbeddingDumper owns cadence / files); its presence
+        # is what asks the model for a ModelDeltaTracker (delta_embedding_dump.py)
+        spec.delta_embedding_dump_config = tc.one("delta_embedding_dump_config")
     dc = cfg.one("data_config", Msg())
     spec.batch_size = int(dc.one("batch_size", 0))
     spec.label_fields = list(dc.many("label_fields"))

@@ -371,8 +371,11 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
     const uint64_t klo = (((uint64_t)bin << 32) + mult - 1) / mult;
     uint64_t khi = (((uint64_t)(bin + 1) << 32) + mult - 1) / mult;
     if (khi > (uint64_t)tb.rows) khi = (uint64_t)tb.rows;
+    // ... unless one row holds nearly all of such a bucket (the clipped Zipf tail, a default id:
+    // tens of thousands of lookups): tile-parallel again, splitting around that row (hot items).
     const bool one_pass = khi - klo <= (uint64_t)BWD_NB;
-    const uint32_t tiles = one_pass ? (run + BWD_HT - 1) / BWD_HT : 1u;
+    const bool tiled = one_pass || run > BWD_HT;
+    const uint32_t tiles = tiled ? (run + BWD_HT - 1) / BWD_HT : 1u;
     const uint32_t slot = atomicAdd(P.hcount, tiles);
     for (uint32_t i = 0; i < tiles; ++i) {
       BwdHeavy hv;
@@ -380,8 +383,9 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
       hv.bin = (uint32_t)bin;
       hv.start = start;
       hv.end = end;
-      hv.tile = one_pass ? (int32_t)i : -1;
-      hv.pad[0] = hv.pad[1] = hv.pad[2] = 0;
+      hv.tile = tiled ? (int32_t)i : -1;
+      hv.pad[0] = one_pass ? 0 : 1;  // 1: a wide bucket, tiled around its hot row
+      hv.pad[1] = hv.pad[2] = 0;
       P.hlist[slot + i] = hv;
     }
   }
@@ -677,6 +681,21 @@ __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ table
     }
 }
 
+// The most frequent row id among 64 evenly spaced samples of a bucket (ties: the earliest sample):
+// every wave of every workgroup that walks the bucket gets the same answer.
+__device__ __forceinline__ uint32_t bwd_sample_mode(const uint2* __restrict__ src, int n, int lane) {
+  const uint32_t sk = src[(int)(((int64_t)lane * n) / TZR_WAVE)].x;
+  unsigned long long peers = ~0ull;
+  for (int bit = 0; bit < 32; ++bit) {
+    const int on = (sk >> bit) & 1;
+    const unsigned long long bm = __ballot(on);
+    peers &= on ? bm : ~bm;
+  }
+  uint32_t best = ((uint32_t)__popcll(peers) << 6) | (uint32_t)(TZR_WAVE - 1 - lane);
+  for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m, TZR_WAVE));
+  return (uint32_t)__shfl((int)sk, TZR_WAVE - 1 - (int)(best & 63u), TZR_WAVE);
+}
+
 __device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__ tables,
                                                     const BwdPlan& P, BwdSortLds& S,
                                                     const BwdHeavy& H) {
@@ -699,8 +718,14 @@ __device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__
   __syncthreads();
   // counts of the whole bucket per row id; the counts when the walk reaches this tile = its prefix
   constexpr int kRounds = BWD_HT / BWD_THREADS;
+  // (a heavy bucket usually is heavy because of ONE row: its lookups are counted with a ballot into
+  // a wave register, the others -- few per wave, on different counters -- with one LDS atomic each)
+  const uint32_t hot = bwd_sample_mode(src, n, lane);
+  uint32_t hot_run = 0;
   for (int base = 0; base < n; base += BWD_HT) {
     if (base == t0) {
+      if (lane == 0 && hot_run) atomicAdd(&S.gstart[hot - klo], hot_run);
+      hot_run = 0;
       __syncthreads();
       for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.pre[i] = S.gstart[i];
       __syncthreads();
@@ -713,11 +738,13 @@ __device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-      if (base + r * BWD_THREADS >= n) break;  // wave-uniform
       const int i = base + r * BWD_THREADS + (int)threadIdx.x;
-      bwd_wave_count(S.gstart, k8[r] - klo, i < n, wbits, lane);
+      const bool v = i < n;
+      hot_run += (uint32_t)__popcll(__ballot(v && k8[r] == hot));
+      if (v && k8[r] != hot) atomicAdd(&S.gstart[k8[r] - klo], 1u);
     }
   }
+  if (lane == 0 && hot_run) atomicAdd(&S.gstart[hot - klo], hot_run);
   __syncthreads();
   bwd_block_scan(S.gstart, BWD_NB, S.wtot);
   const int nt = min(BWD_HT, n - t0);
@@ -846,6 +873,181 @@ __device__ __forceinline__ void bwd_sort_heavy_serial(const TzrTable* __restrict
   }
 }
 
+// Hot item: tile `H.tile` of a WIDE heavy bucket (more than BWD_NB row ids, more than one tile of
+// lookups).  Such a bucket is almost always one hot row plus a sprinkle of cold ones, so instead of
+// LSD passes by one workgroup (26 tiles x 3 passes for the clipped tail of a 40M-row table) every
+// tile workgroup
+//   1. picks the same candidate row: the most frequent of 64 evenly spaced samples of the bucket;
+//   2. walks the bucket once counting lookups below / equal to the candidate (ballots only), and
+//      remembers the counts at its own tile: they place its hot lookups, in position order, after
+//      the cold rows below the candidate;
+//   3. tile 0 also gathers the cold lookups (at most BWD_UMAX, else see below) in position order,
+//      sorts them in LDS and writes them around the hot run.
+// Every workgroup derives the same counts, so all of them take the same decision: when the cold
+// lookups do not fit, tile 0 falls back to the LSD passes over the whole bucket and the others
+// leave.  Resulting order: ascending row ids, position order inside a row, like everywhere else.
+__device__ __forceinline__ void bwd_sort_heavy_serial(const TzrTable* __restrict__ tables,
+                                                      const BwdPlan& P, BwdSortLds& S,
+                                                      const BwdHeavy& H);
+
+__device__ __forceinline__ void bwd_sort_heavy_hot(const TzrTable* __restrict__ tables,
+                                                   const BwdPlan& P, BwdSortLds& S,
+                                                   const BwdHeavy& H) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int n = (int)(H.end - H.start);
+  const uint2* __restrict__ src = P.ks[1] + H.start;
+  uint2* __restrict__ dst = P.ks[0] + H.start;
+  const int t0 = H.tile * BWD_HT;
+  constexpr int kRounds = BWD_HT / BWD_THREADS;
+  // 1. candidate (identical in every wave of every tile workgroup of the bucket)
+  const uint32_t hot = bwd_sample_mode(src, n, lane);
+  // 2. one walk: lookups below / equal to the candidate, in the whole bucket and ahead of this tile
+  uint32_t lt_tot = 0, eq_tot = 0, eq_pre = 0;
+  for (int base = 0; base < n; base += BWD_HT) {
+    if (base == t0) eq_pre = eq_tot;
+    uint32_t k4[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+      k4[r] = i < n ? src[i].x : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
+      lt_tot += (uint32_t)__popcll(__ballot(i < n && k4[r] < hot));
+      eq_tot += (uint32_t)__popcll(__ballot(i < n && k4[r] == hot));
+    }
+  }
+  if (lane == 0) {  // wave-level partial counts (a tile's lookups are dealt over the four waves)
+    S.gstart[wv] = lt_tot;
+    S.gstart[BWD_WAVES + wv] = eq_tot;
+    S.gstart[2 * BWD_WAVES + wv] = eq_pre;
+  }
+  __syncthreads();
+  uint32_t n_lt = 0, n_eq = 0, eq_ahead = 0;
+#pragma unroll
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    n_lt += S.gstart[w];
+    n_eq += S.gstart[BWD_WAVES + w];
+    eq_ahead += S.gstart[2 * BWD_WAVES + w];
+  }
+  __syncthreads();
+  const int n_cold = n - (int)n_eq;
+  if (n_cold > BWD_UMAX) {  // not one hot row: every tile workgroup of the bucket sees the same numbers
+    if (H.tile == 0) bwd_sort_heavy_serial(tables, P, S, H);
+    return;
+  }
+  // the hot lookups of this tile, in position order, behind the hot lookups of the tiles before
+  {
+    const int nt = min(BWD_HT, n - t0);
+    const int pw = bwd_wave_span(nt);
+    const int rounds = pw / TZR_WAVE;
+    uint32_t sreg[kRounds], hpos[kRounds];
+    uint32_t hmask = 0, run = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      bool is_hot = false;
+      sreg[r] = hpos[r] = 0;
+      if (r < rounds && lp < nt) {
+        const uint2 v = src[t0 + lp];
+        sreg[r] = v.y;
+        is_hot = v.x == hot;
+      }
+      if (r < rounds) {
+        const unsigned long long hm = __ballot(is_hot);
+        hpos[r] = run + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        run += (uint32_t)__popcll(hm);
+        if (is_hot) hmask |= 1u << r;
+      }
+    }
+    if (lane == 0) S.wtot[wv] = run;
+    __syncthreads();
+    uint32_t ahead = n_lt + eq_ahead;
+    for (int w = 0; w < wv; ++w) ahead += S.wtot[w];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if ((hmask >> r) & 1u) dst[ahead + hpos[r]] = make_uint2(hot, sreg[r]);
+    __syncthreads();
+  }
+  if (H.tile != 0 || n_cold == 0) return;
+  // 3. the cold lookups of the whole bucket: ordered gather into LDS, stable sort, write
+  uint32_t gathered = 0;  // cold lookups in the tiles walked so far (workgroup-uniform)
+  for (int base = 0; base < n; base += BWD_HT) {
+    const int nt = min(BWD_HT, n - base);
+    const int pw = bwd_wave_span(nt);
+    const int rounds = pw / TZR_WAVE;
+    uint32_t kc[kRounds], sc[kRounds], cpos[kRounds];
+    uint32_t cmask = 0, run = 0;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      bool cold = false;
+      kc[r] = sc[r] = cpos[r] = 0;
+      if (r < rounds && lp < nt) {
+        const uint2 v = src[base + lp];
+        kc[r] = v.x;
+        sc[r] = v.y;
+        cold = v.x != hot;
+      }
+      if (r < rounds) {
+        const unsigned long long cm = __ballot(cold);
+        cpos[r] = run + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+        run += (uint32_t)__popcll(cm);
+        if (cold) cmask |= 1u << r;
+      }
+    }
+    if (lane == 0) S.wtot[wv] = run;
+    __syncthreads();
+    uint32_t ahead = gathered, tile_cold = 0;
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      if (w < wv) ahead += S.wtot[w];
+      tile_cold += S.wtot[w];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if ((cmask >> r) & 1u) {
+        S.pk[ahead + cpos[r]] = kc[r];
+        S.ps[ahead + cpos[r]] = sc[r];
+      }
+    gathered += tile_cold;
+    __syncthreads();
+  }
+  {
+    constexpr int cRounds = BWD_UMAX / BWD_THREADS;
+    const int64_t rows = tables[H.t].rows;
+    int nb;
+    uint64_t mult;
+    bwd_bucket_params(rows, &nb, &mult);
+    const uint64_t klo64 = (((uint64_t)H.bin << 32) + mult - 1) / mult;
+    uint64_t khi = (((uint64_t)(H.bin + 1) << 32) + mult - 1) / mult;
+    if (khi > (uint64_t)rows) khi = (uint64_t)rows;
+    const int bits = max(1, bwd_bits((uint32_t)(khi - klo64 - 1)));
+    const int pw = bwd_wave_span(n_cold);
+    const int rounds = pw / TZR_WAVE;
+    uint32_t kreg[cRounds], sreg[cRounds], dest[cRounds];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int r = 0; r < cRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      kreg[r] = sreg[r] = 0;
+      if (r < rounds && lp < n_cold) {
+        vmask |= 1u << r;
+        kreg[r] = S.pk[lp];
+        sreg[r] = S.ps[lp];
+      }
+    }
+    __syncthreads();  // the exchange buffer is the core's from here on
+    bwd_sort_core<cRounds>(kreg, sreg, vmask, pw, rounds, (uint32_t)klo64, bits, false, S, dest);
+#pragma unroll
+    for (int r = 0; r < cRounds; ++r)
+      if ((vmask >> r) & 1u) dst[dest[r] + (kreg[r] > hot ? n_eq : 0u)] = make_uint2(kreg[r], sreg[r]);
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_kernel(
     const TzrTable* __restrict__ tables, int n_units, BwdPlan P) {
   __shared__ BwdSortLds S;
@@ -857,8 +1059,9 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_
   const unsigned workers = gridDim.x - (unsigned)n_units;
   for (unsigned hi = blockIdx.x - (unsigned)n_units; hi < nh; hi += workers) {
     const BwdHeavy H = P.hlist[hi];
-    if (H.tile >= 0) bwd_sort_heavy_tile(tables, P, S, H);
-    else bwd_sort_heavy_serial(tables, P, S, H);
+    if (H.tile < 0) bwd_sort_heavy_serial(tables, P, S, H);
+    else if (H.pad[0]) bwd_sort_heavy_hot(tables, P, S, H);
+    else bwd_sort_heavy_tile(tables, P, S, H);
   }
 }
 
@@ -910,7 +1113,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, d_tables, n_tables, P);
   hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                      n_tables, A, P);
-  const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 128);
+  const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);
   hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
                      (int)chunks, P);
   TZR_CHECK_LAUNCH();

@@ -1,125 +1,36 @@
-"""Delta-embedding dump: publish the rows touched since the last dump.
+"""Touched-row tracking for incremental embedding export: the device side of
+`train_config.delta_embedding_dump_config` (/root/reference/tzrec/utils/delta_embedding_dump.py).
 
-Mirror of the reference's `tzrec/utils/delta_embedding_dump.py` for this package's embedding
-collections: same class names (`ModelDeltaTracker`, `DeltaEmbeddingDumper`), same config fields
-(`DeltaEmbeddingDumpConfig`, /root/reference/tzrec/protos/train.proto:86-111), same cadence rules
-(`maybe_dump` / `final_dump`, :812-872), same parquet schema, file naming and atomic write
-(:76-99, :947-960, :1211-1313), same call sites in the train loop
-(/root/reference/tzrec/main.py:449,517,547,611,900,928).
+tzrec's `DeltaEmbeddingDumper` (parquet writer, dump cadence, config validation, file naming) is
+control plane and stays tzrec's own class; what it needs from the embedding stack is a
+`ModelDeltaTracker` with `get_unique(...)`, `clear`, `pause_tracking`, `fqn_to_feature_names`, and the
+current rows of the ids it reports (reference :478-513, :565-609, :1043-1094).  That is what this module
+provides -- INTEGRATION.md shows the two lines that bind it into tzrec's dumper -- plus
+`published_rows()`, the (key ids, rows) pairs a dump writes, so the seam can be tested here.
 
 What is different is where the touched ids live.  The reference inherits torchrec's
 `ModelDeltaTracker` / `DeltaStoreTrec`: every lookup appends its id tensor, and `get_unique` runs
-`torch.cat(...).unique()` over the window (:478-513, :565-609).  Here each tracked table owns a bitmap
-in HBM (one bit per local row; `tzr_delta_mark` sets bits from the lookup's ids on the lookup's
-stream, `tzr_delta_count` / `tzr_delta_collect` turn the bitmap into ascending ids at dump time), so
-tracking memory is constant (25.5 MB for all of DLRM-Criteo) and no sort ever runs.  The rows are
-read by `tzr_rows_gather` and, for `quant_type: DELTA_EMBEDDING_QUANT_INT8`, encoded by
-`tzr_quantize_rows_q8f16` on the device; only the finished bytes cross PCIe.
+`torch.cat(...).unique()` over the window.  Here each tracked table owns a bitmap in HBM (one bit per
+local row; `tzr_delta_mark` sets bits from the lookup's ids on the lookup's stream, `tzr_delta_count` /
+`tzr_delta_collect` turn the bitmap into ascending ids at read time), so tracking memory is constant
+(25.5 MB for all of DLRM-Criteo) and no sort ever runs.  The rows are read by `tzr_rows_gather`.
 
 Zero-collision-hash tables publish RAW ids like the reference (:355-358, :515-550, :1043-1094): the ids
 resident in the touched rows plus what the ZCH module reports per admission round (evicted, admitted,
-looked up without a row), each with the row the table serves it from at dump time (the shared fallback
-row once an id holds none).  Not built: the FeatureStore uploader (`feature_store_config`, a network
-service) and dynamicemb tables.
+looked up without a row), each with the row the table serves it from at read time (the shared fallback
+row once an id holds none).  Not built: dynamicemb tables.
 """
 from __future__ import annotations
 
-import os
-import time
 from contextlib import contextmanager
 from dataclasses import dataclass
-from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 from torch import nn
 
 from . import _lib
-from .export import (DISTRIBUTED_SPARSE_QUANT_SCALE_OFFSET_BYTES, DISTRIBUTED_SPARSE_SUPPORTED_QUANT_FORMATS,
-                     distributed_quantize_embeddings)
-
-_CONSUMER = "delta_embedding_dump"
-QUANT_NONE = "DELTA_EMBEDDING_QUANT_NONE"
-QUANT_INT8 = "DELTA_EMBEDDING_QUANT_INT8"
-
-
-def _schema(quantized: bool):
-    import pyarrow as pa
-
-    return pa.schema([
-        ("global_step", pa.int64()),
-        ("rank", pa.int32()),
-        ("world_size", pa.int32()),
-        ("feature_name", pa.string()),
-        ("table_fqn", pa.string()),
-        ("key_id", pa.int64()),
-        ("embedding", pa.list_(pa.uint8() if quantized else pa.float32())),
-        ("source", pa.string()),
-    ])
-
-
-@dataclass
-class DeltaEmbeddingDumpConfig:
-    """train.proto:86-111.  Unset optional fields are None (`HasField` semantics)."""
-
-    dump_interval_steps: Optional[int] = None  # proto default 1000
-    output_dir: str = ""
-    file_prefix: str = "delta_embedding"
-    dump_interval_minutes: Optional[int] = None
-    quant_type: str = QUANT_NONE
-    feature_store_config: Optional[object] = None
-
-    def HasField(self, name: str) -> bool:
-        return getattr(self, name) is not None
-
-    @property
-    def interval_steps(self) -> int:
-        return 1000 if self.dump_interval_steps is None else int(self.dump_interval_steps)
-
-
-def delta_embedding_dump_config_from_msg(msg) -> DeltaEmbeddingDumpConfig:
-    """`train_config { delta_embedding_dump_config { ... } }` of a parsed text-format config."""
-    q = msg.one("quant_type", QUANT_NONE)
-    if q not in (QUANT_NONE, QUANT_INT8):
-        raise ValueError(f"delta_embedding_dump_config.quant_type: unknown value {q!r}")
-    return DeltaEmbeddingDumpConfig(
-        dump_interval_steps=msg.one("dump_interval_steps") if msg.has("dump_interval_steps") else None,
-        output_dir=msg.one("output_dir", ""), file_prefix=msg.one("file_prefix", "delta_embedding"),
-        dump_interval_minutes=msg.one("dump_interval_minutes") if msg.has("dump_interval_minutes") else None,
-        quant_type=q, feature_store_config=msg.one("feature_store_config") if msg.has("feature_store_config") else None)
-
-
-def validate_delta_embedding_dump_config(config: Optional[DeltaEmbeddingDumpConfig], device: torch.device) -> None:
-    """Reference :128-155, same messages.  (The emulator library of the tests stands in for the GPU.)"""
-    if config is None:
-        return
-    if torch.device(device).type != "cuda" and _lib.backend() != "emu":
-        raise ValueError(f"delta_embedding_dump_config only supports CUDA training, but got device={device}.")
-    if config.HasField("dump_interval_minutes"):
-        if config.HasField("dump_interval_steps"):
-            raise ValueError("delta_embedding_dump_config must configure only one of "
-                             "dump_interval_steps and dump_interval_minutes.")
-        if config.dump_interval_minutes <= 0:
-            raise ValueError("delta_embedding_dump_config.dump_interval_minutes must be > 0.")
-    elif config.interval_steps <= 0:
-        raise ValueError("delta_embedding_dump_config.dump_interval_steps must be > 0.")
-    if config.feature_store_config is not None:
-        raise NotImplementedError("delta_embedding_dump_config.feature_store_config: the FeatureStore uploader is a "
-                                  "network service outside this library; dump to output_dir and upload from there")
-
-
-def _distributed_rank_world_size() -> Tuple[int, int]:
-    rank = int(os.environ.get("RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        rank = torch.distributed.get_rank()
-        world_size = torch.distributed.get_world_size()
-    return rank, world_size
-
-
-def _feature_name(feature_names: Iterable[str]) -> str:
-    names = list(feature_names)
-    return names[0] if len(names) == 1 else ",".join(names)
 
 
 @dataclass(frozen=True)
@@ -407,6 +318,21 @@ class ModelDeltaTracker:
     def get_unique_ids(self, consumer: Optional[str] = None) -> Dict[str, torch.Tensor]:
         return {fqn: rows.ids for fqn, rows in self.get_unique(consumer=consumer).items()}
 
+    def published_rows(self, consumer: Optional[str] = None) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+        """{table FQN: (key ids int64[n], rows float32[n, D])} of everything touched since the last read:
+        what one dump of the window writes.  Key ids are GLOBAL row ids (local row + the shard's row
+        offset) or, for a ZCH table, raw ids, each with the row the table serves it from right now --
+        its own row while it holds one, the shared fallback row once it does not."""
+        out: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        for fqn, rows in self.get_unique(consumer=consumer).items():
+            ids, weight = rows.ids, self.table_weight(fqn)
+            zch = self.zch_modules.get(fqn)
+            if zch is not None:
+                out[fqn] = (ids, gather_rows(weight, zch.lookup_rows(ids)))
+            else:
+                out[fqn] = (ids + self._shard_info[fqn].row_offset, gather_rows(weight, ids))
+        return out
+
     def step(self) -> None:
         self.curr_batch_idx += 1
 
@@ -447,194 +373,3 @@ def gather_rows(weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().tzr_rows_gather(_lib.ptr(d_tab), _lib.ptr(key_table), _lib.ptr(key_start), 1, _lib.ptr(ids), n,
                                           _lib.ptr(out), D, D, _lib.stream_ptr(dev)), "tzr_rows_gather")
     return out
-
-
-class DeltaEmbeddingDumper:
-    """Dump touched embedding ids and their latest rows during training (reference :643-1313).
-
-    Args:
-        model: the model holding the embedding collections to track.
-        config: DeltaEmbeddingDumpConfig.
-        model_dir: base directory; `<model_dir>/delta_embedding_dump` is the default output location.
-        device: training device."""
-
-    def __init__(self, model: nn.Module, config: DeltaEmbeddingDumpConfig, model_dir: str, device: torch.device) -> None:
-        validate_delta_embedding_dump_config(config, device)
-        self._model, self._config = model, config
-        self._quant_type = config.quant_type
-        self._quantized = self._quant_type == QUANT_INT8
-        self._schema = _schema(self._quantized)
-        self._interval_steps: Optional[int] = None
-        self._interval_secs: Optional[float] = None
-        if config.HasField("dump_interval_minutes"):
-            self._interval_secs = float(config.dump_interval_minutes * 60)
-        else:
-            self._interval_steps = config.interval_steps
-        self._next_dump_time: Optional[float] = None
-        self._last_dump_step: Optional[int] = None
-        self._output_dir = config.output_dir or os.path.join(model_dir, "delta_embedding_dump")
-        self._file_prefix = config.file_prefix or "delta_embedding"
-        self._rank, self._world_size = _distributed_rank_world_size()
-        os.makedirs(self._output_dir, exist_ok=True)
-        self._tracker = ModelDeltaTracker(model, consumers=[_CONSUMER], delete_on_read=True, auto_compact=True)
-        self._zch_modules = self._tracker.zch_modules
-        if self._quantized:
-            for fqn in self._tracker.fqn_to_feature_names:
-                cols = self._tracker.shard_info(fqn).global_cols
-                if cols % 2 != 0:
-                    raise ValueError("delta_embedding_dump_config.quant_type=INT8 requires even "
-                                     f"embedding_dim, but table '{fqn}' has emb_dim={cols}. QUint8RowwiseF16 format requires "
-                                     f"row_bytes=emb_dim+{DISTRIBUTED_SPARSE_QUANT_SCALE_OFFSET_BYTES} to be even.")
-
-    @property
-    def tracker(self) -> ModelDeltaTracker:
-        return self._tracker
-
-    def clear(self) -> None:
-        """Drop what was tracked so far, usually after restore-time dummy steps (reference :761-770)."""
-        self._tracker.clear(_CONSUMER)
-
-    @contextmanager
-    def pause_tracking(self) -> Iterator[None]:
-        with self._tracker.pause_tracking():
-            yield
-
-    def start(self) -> None:
-        if self._interval_secs is not None:
-            self._next_dump_time = time.monotonic() + self._interval_secs
-
-    def close(self, raise_on_error: bool = True, drain: bool = True) -> None:
-        """(the reference closes its FeatureStore uploader here)"""
-
-    # -- cadence (reference :812-895) -------------------------------------------------------------
-    def maybe_dump(self, global_step: int) -> None:
-        if self._local_dump_decision(global_step):
-            self.dump(global_step)
-            self._last_dump_step = global_step
-            if self._interval_secs is not None and self._next_dump_time is not None:
-                now = time.monotonic()  # fixed-rate rescheduling; missed deadlines are skipped, not fired as a burst
-                while self._next_dump_time <= now:
-                    self._next_dump_time += self._interval_secs
-        self._tracker.step()
-
-    def _local_dump_decision(self, global_step: int) -> bool:
-        if self._interval_steps is not None:
-            return global_step > 0 and global_step % self._interval_steps == 0
-        if self._interval_secs is not None and self._next_dump_time is not None:
-            return time.monotonic() >= self._next_dump_time
-        return False
-
-    def final_dump(self, global_step: int) -> Optional[str]:
-        """Flush the trailing partial interval at the end of training; boundary steps were already
-        written by `maybe_dump` and are skipped (re-dumping would overwrite them with an empty shard)."""
-        if global_step <= 0:
-            return None
-        global_step = self._sync_final_step(global_step)
-        if self._interval_steps is not None and global_step % self._interval_steps == 0:
-            return None
-        if self._interval_secs is not None and global_step == self._last_dump_step:
-            return None
-        return self.dump(global_step)
-
-    def _sync_final_step(self, global_step: int) -> int:
-        """MAX over ranks, so every rank takes the same skip / dump decision into the same directory."""
-        if self._world_size <= 1 or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            return global_step
-        dev = self._tracker._device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor(global_step, dtype=torch.long, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        return int(t.item())
-
-    # -- dump (reference :897-1045, :1211-1313) ---------------------------------------------------
-    def dump(self, global_step: int) -> Optional[str]:
-        """Write the tracked ids and their current rows to one parquet file; returns its path, or None
-        when a single-process run had nothing to write."""
-        global_step = int(global_step)
-        if global_step <= 0:
-            raise ValueError("delta embedding dump global_step must be > 0")
-        chunks: list = []
-        num_rows = 0
-        for fqn, unique_rows in self._tracker.get_unique(_CONSUMER).items():
-            ids = unique_rows.ids
-            if ids.numel() == 0:
-                continue
-            embeddings, key_ids = self._lookup_embeddings(fqn, ids)
-            feature_name = _feature_name(self._tracker.fqn_to_feature_names.get(fqn, []))
-            num_rows += self._append_table_chunk(chunks, global_step, feature_name, fqn, key_ids, embeddings, "model_delta_tracker")
-        output_path: Optional[str] = None
-        if num_rows > 0 or self._world_size > 1:
-            # multi-rank shard sets stay complete even for an empty rank
-            output_path = self._output_path(global_step)
-            self._write_table_chunks(chunks, output_path)
-        return output_path
-
-    def _output_path(self, global_step: int) -> str:
-        if self._world_size == 1:
-            return os.path.join(self._output_dir, f"{self._file_prefix}_step_{global_step}.parquet")
-        step_dir = os.path.join(self._output_dir, f"step_{global_step}")
-        os.makedirs(step_dir, exist_ok=True)
-        return os.path.join(step_dir, f"{self._file_prefix}_step_{global_step}_rank_{self._rank}_of_{self._world_size}.parquet")
-
-    def _lookup_embeddings(self, fqn: str, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        weight = self._tracker.table_weight(fqn)
-        zch = self._zch_modules.get(fqn)
-        if zch is not None:
-            # `ids` are RAW ids: publish the row the table serves each of them from right now -- its own
-            # row while it holds one, the shared fallback row once it does not (reference :1043-1094)
-            return gather_rows(weight, zch.lookup_rows(ids)), ids
-        return gather_rows(weight, ids), ids + self._tracker.shard_info(fqn).row_offset
-
-    def _append_table_chunk(self, table_chunks: list, global_step: int, feature_name: str, table_fqn: str,
-                            key_ids: torch.Tensor, embeddings: torch.Tensor, source: str) -> int:
-        import pyarrow as pa
-
-        if embeddings.dim() != 2:
-            raise ValueError(f"delta embedding dump expects a 2-D embedding tensor, but got shape={tuple(embeddings.shape)}.")
-        num_rows = int(key_ids.numel())
-        if num_rows == 0:
-            return 0
-        if embeddings.size(0) != num_rows:
-            raise ValueError("delta embedding dump key ids and embeddings row count mismatch: "
-                             f"key_ids={num_rows}, embeddings={embeddings.size(0)}.")
-        if self._quantized:
-            try:  # encoded on the device; only the bytes travel
-                embeddings = distributed_quantize_embeddings(embeddings, embeddings.size(1), feature_name,
-                                                             DISTRIBUTED_SPARSE_SUPPORTED_QUANT_FORMATS[0])
-            except ValueError as e:
-                raise ValueError(f"Delta embedding dump INT8 quantization failed for feature '{feature_name}' "
-                                 f"(table '{table_fqn}'): {e}. Disable delta dump quantization by setting "
-                                 "delta_embedding_dump_config.quant_type to DELTA_EMBEDDING_QUANT_NONE.") from e
-            value_type = pa.uint8()
-        else:
-            value_type = pa.float32()
-        key_ids_cpu = key_ids.detach().cpu().to(torch.int64).contiguous()
-        embeddings_cpu = embeddings.detach().cpu().contiguous()
-        emb_dim = embeddings_cpu.size(1)
-        offsets = np.arange(0, (num_rows + 1) * emb_dim, emb_dim, dtype=np.int32) if emb_dim else np.zeros(num_rows + 1, np.int32)
-        values = pa.array(embeddings_cpu.reshape(-1).numpy(), type=value_type)
-        table_chunks.append(pa.Table.from_arrays([
-            pa.repeat(pa.scalar(global_step, pa.int64()), num_rows),
-            pa.repeat(pa.scalar(self._rank, pa.int32()), num_rows),
-            pa.repeat(pa.scalar(self._world_size, pa.int32()), num_rows),
-            pa.repeat(pa.scalar(feature_name, pa.string()), num_rows),
-            pa.repeat(pa.scalar(table_fqn, pa.string()), num_rows),
-            pa.array(key_ids_cpu.numpy(), type=pa.int64()),
-            pa.ListArray.from_arrays(pa.array(offsets, type=pa.int32()), values),
-            pa.repeat(pa.scalar(source, pa.string()), num_rows),
-        ], schema=self._schema))
-        return num_rows
-
-    def _write_table_chunks(self, table_chunks: list, output_path: str) -> None:
-        """Sibling temp file, then os.replace: a kill mid-write never leaves a truncated shard."""
-        import pyarrow.parquet as pq
-
-        tmp_path = f"{output_path}.rank{self._rank}.tmp"
-        try:
-            with pq.ParquetWriter(tmp_path, self._schema) as writer:
-                for chunk in (table_chunks or [self._schema.empty_table()]):
-                    writer.write_table(chunk)
-            os.replace(tmp_path, output_path)
-        except BaseException:
-            if os.path.exists(tmp_path):
-                os.remove(tmp_path)
-            raise

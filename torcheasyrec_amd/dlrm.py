@@ -81,16 +81,52 @@ class OutputLinear(nn.Linear):
         return super().forward(x)
 
 
-class MLP(nn.Module):
-    """Stack of Linear+ReLU (reference Perceptron defaults: bias, no bn/ln/dropout)."""
+def _activation(name: Optional[str]) -> Optional[nn.Module]:
+    """`activation` of the MLP proto (tzrec/protos/module.proto:9-10; tzrec/modules/activation.py
+    create_activation): "nn.ReLU" style names of torch.nn; empty = none."""
+    if not name:
+        return None
+    cls = getattr(nn, name[3:], None) if name.startswith("nn.") else None
+    if cls is None:
+        raise NotImplementedError(f"MLP activation {name!r}: only torch.nn activations (\"nn.ReLU\", \"nn.GELU\", ...) are built")
+    return cls()
 
-    def __init__(self, in_features: int, hidden_units: Sequence[int]) -> None:
+
+class MLP(nn.Module):
+    """Stack of Perceptrons (tzrec/modules/mlp.py:21-177): per layer Linear -> [BatchNorm1d | LayerNorm]
+    -> activation -> [Dropout]; with `use_bn` the Linear has no bias (mlp.py:60).  The reference
+    defaults (bias, ReLU, no norm, no dropout) are the DLRM / DeepFM case and take the fused path."""
+
+    def __init__(self, in_features: int, hidden_units: Sequence[int], bias: bool = True, activation: Optional[str] = "nn.ReLU",
+                 use_bn: bool = False, dropout_ratio=None, use_ln: bool = False) -> None:
         super().__init__()
         self.hidden_units = list(hidden_units)
+        if use_bn and use_ln:
+            raise ValueError("Could not use_bn and use_ln at the same time in Perceptron.")
+        if dropout_ratio is None or (isinstance(dropout_ratio, (list, tuple)) and len(dropout_ratio) == 0):
+            drops = [0.0] * len(self.hidden_units)
+        elif isinstance(dropout_ratio, (list, tuple)):
+            drops = [float(x) for x in dropout_ratio]
+            if len(drops) == 1:
+                drops = drops * len(self.hidden_units)
+            if len(drops) != len(self.hidden_units):
+                raise ValueError("length of dropout_ratio and hidden_units must be same")
+        else:
+            drops = [float(dropout_ratio)] * len(self.hidden_units)
+        self._plain = bias and activation == "nn.ReLU" and not use_bn and not use_ln and not any(d > 0 for d in drops)
         layers: List[nn.Module] = []
         d = in_features
-        for h in self.hidden_units:
-            layers += [nn.Linear(d, h), nn.ReLU()]
+        for h, dr in zip(self.hidden_units, drops):
+            layers.append(nn.Linear(d, h, bias=False if use_bn else bias))
+            if use_bn:
+                layers.append(nn.BatchNorm1d(h))
+            if use_ln:
+                layers.append(nn.LayerNorm(h))
+            act = _activation(activation)
+            if act is not None:
+                layers.append(act)
+            if dr > 0.0:
+                layers.append(nn.Dropout(dr))
             d = h
         self.mlp = nn.Sequential(*layers)
 
@@ -98,7 +134,7 @@ class MLP(nn.Module):
         return self.hidden_units[-1]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if _FUSED_RELU and x.is_cuda and x.dim() == 2:
+        if self._plain and _FUSED_RELU and x.is_cuda and x.dim() == 2:
             # Linear + bias + ReLU as one hipBLASLt call (ReLU in the GEMM epilogue): same values,
             # one launch less per layer than Linear followed by ReLU
             for m in self.mlp:

@@ -179,6 +179,26 @@ class _Meta:
         self.n_keys = 0
 
 
+def mask_frozen_descriptors(tables: np.ndarray, feats: np.ndarray, frozen: Sequence[bool]):
+    """Backward twins of (TzrTable[], TzrFeature[]) in which the lookups of frozen tables
+    (`trainable: false`, tzrec/features/feature.py:629, models/model.py:162-201) are marked "not owned"
+    (table -1, ordered last): the plan sorts nothing for them and the fused optimizer never touches
+    their rows.  The live lookups keep their relative (table-major) order."""
+    bt, bf = tables.copy(), feats.copy()
+    by_order = np.argsort(feats["order"], kind="stable")
+    live = [int(i) for i in by_order if feats[i]["table"] >= 0 and not frozen[int(feats[i]["table"])]]
+    dead = [int(i) for i in by_order if not (feats[i]["table"] >= 0 and not frozen[int(feats[i]["table"])])]
+    for o, i in enumerate(live + dead):
+        bf[i]["order"] = o
+    for i in dead:
+        bf[i]["table"] = -1
+    for t in range(len(bt)):
+        mine = [i for i in live if int(feats[i]["table"]) == t]
+        bt[t]["first_order"] = int(bf[mine[0]]["order"]) if mine else 0
+        bt[t]["n_feats"] = len(mine)
+    return bt, bf
+
+
 class _PooledLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ebc, kjt, dst_names, hook):  # hook: zero-size tensor that requires grad
@@ -378,17 +398,7 @@ class EmbeddingBagCollection(nn.Module):
         frozen = [not cfg.trainable for cfg in self._configs]
         meta.d_bwd_tables, meta.d_bwd_feats = meta.d_tables, meta.d_feats
         if any(frozen):
-            bf, bt = feats.copy(), tables.copy()
-            live = [i for i, lk in enumerate(self._lookups) if not frozen[lk.table]]
-            dead = [i for i, lk in enumerate(self._lookups) if frozen[lk.table]]
-            for o, i in enumerate(live + dead):
-                bf[i]["order"] = o
-            for i in dead:
-                bf[i]["table"] = -1
-            for t in range(T):
-                mine = [i for i in live if self._lookups[i].table == t]
-                bt[t]["first_order"] = int(bf[mine[0]]["order"]) if mine else 0
-                bt[t]["n_feats"] = len(mine)
+            bt, bf = mask_frozen_descriptors(tables, feats, frozen)
             meta.d_bwd_tables = _lib.upload_struct(bt, self._device)
             meta.d_bwd_feats = _lib.upload_struct(bf, self._device)
         meta.d_slots = _lib.upload_struct(meta.slots_np, self._device)

@@ -20,6 +20,19 @@ from .embedding_group import Batch, EmbeddingGroup
 from .interaction import FactorizationMachine, dot_interaction
 
 
+def mlp_kwargs(msg) -> Dict[str, object]:
+    """An MLP proto block (tzrec/protos/module.proto:4-17: hidden_units, dropout_ratio, activation,
+    use_bn, bias, use_ln) as the module's keyword arguments (the reference's config_to_kwargs)."""
+    return {"hidden_units": [int(x) for x in msg.many("hidden_units")], "bias": bool(msg.one("bias", True)),
+            "activation": str(msg.one("activation", "nn.ReLU")), "use_bn": bool(msg.one("use_bn", False)),
+            "dropout_ratio": [float(x) for x in msg.many("dropout_ratio")], "use_ln": bool(msg.one("use_ln", False))}
+
+
+def mlp_from_msg(in_features: int, msg) -> MLP:
+    """Every tower of the config-built models goes through here: no MLP field is dropped silently."""
+    return MLP(in_features, **mlp_kwargs(msg))
+
+
 class RankModel(nn.Module):
     # set by build_rank_model(..., process_group=...): tables sharded over the group's ranks, dense
     # parameters data-parallel (the DistributedModelParallel seam, tzrec/main.py:783-804)
@@ -86,7 +99,7 @@ class ConfigDLRM(RankModel):
         self._dense_group = "dense"
         self.dense_mlp = None
         if len(names) > 1 and eg.has_group(self._dense_group):
-            self.dense_mlp = MLP(eg.group_total_dim(self._dense_group), [int(x) for x in m.one("dense_mlp").many("hidden_units")])
+            self.dense_mlp = mlp_from_msg(eg.group_total_dim(self._dense_group), m.one("dense_mlp"))
         dims = set(eg.group_dims(self._sparse_group))
         if len(dims) > 1:
             raise Exception(f"sparse group feature dims must be the same, but we find {dims}")
@@ -97,7 +110,7 @@ class ConfigDLRM(RankModel):
         self._arch_with_sparse = bool(m.one("arch_with_sparse", True))
         n = self._num_sparse + (1 if self.dense_mlp else 0)
         feat = n * (n - 1) // 2 + (self._dim if self.dense_mlp else 0) + (self._num_sparse * self._dim if self._arch_with_sparse else 0)
-        self.final_mlp = MLP(feat, [int(x) for x in m.one("final").many("hidden_units")])
+        self.final_mlp = mlp_from_msg(feat, m.one("final"))
         self.output_mlp = OutputLinear(self.final_mlp.output_dim(), spec.num_class)
         if device is not None:
             for mod in (self.dense_mlp, self.final_mlp, self.output_mlp):
@@ -121,11 +134,11 @@ class ConfigDeepFM(RankModel):
         assert len(set(fm_dims)) == 1, f"embedding dimension of fm features must be same. but got {set(fm_dims)}"
         self._fm_n, self._fm_dim = len(fm_dims), fm_dims[0]
         self.fm = FactorizationMachine()
-        self.deep_mlp = MLP(eg.group_total_dim("deep"), [int(x) for x in m.one("deep").many("hidden_units")])
+        self.deep_mlp = mlp_from_msg(eg.group_total_dim("deep"), m.one("deep"))
         final_dim = self.deep_mlp.output_dim()
         self.final_mlp = None
         if m.has("final"):
-            self.final_mlp = MLP(1 + self._fm_dim + final_dim, [int(x) for x in m.one("final").many("hidden_units")])
+            self.final_mlp = mlp_from_msg(1 + self._fm_dim + final_dim, m.one("final"))
             final_dim = self.final_mlp.output_dim()
         self.output_mlp = OutputLinear(final_dim, spec.num_class)
         if device is not None:
@@ -159,7 +172,7 @@ class ConfigMultiTowerDIN(RankModel):
         total = 0
         for tower in m.many("towers"):
             g = str(tower.one("input"))
-            mlp = MLP(eg.group_total_dim(g), [int(x) for x in tower.one("mlp").many("hidden_units")])
+            mlp = mlp_from_msg(eg.group_total_dim(g), tower.one("mlp"))
             self.towers[g] = mlp
             total += mlp.output_dim()
         self.din_towers = nn.ModuleList()
@@ -171,7 +184,7 @@ class ConfigMultiTowerDIN(RankModel):
             total += din.output_dim()
         self.final_mlp = None
         if m.has("final"):
-            self.final_mlp = MLP(total, [int(x) for x in m.one("final").many("hidden_units")])
+            self.final_mlp = mlp_from_msg(total, m.one("final"))
             total = self.final_mlp.output_dim()
         self.output_mlp = OutputLinear(total, spec.num_class)
         if device is not None:
@@ -198,11 +211,11 @@ class MMoE(nn.Module):
                  gate_mlp: Optional[Dict[str, object]] = None) -> None:
         super().__init__()
         self.num_expert, self.num_task = num_expert, num_task
-        self.expert_mlps = nn.ModuleList([MLP(in_features, list(expert_mlp["hidden_units"])) for _ in range(num_expert)])
+        self.expert_mlps = nn.ModuleList([MLP(in_features, **expert_mlp) for _ in range(num_expert)])
         gate_in = in_features
         self.has_gate_mlp = gate_mlp is not None
         if self.has_gate_mlp:
-            self.gate_mlps = nn.ModuleList([MLP(in_features, list(gate_mlp["hidden_units"])) for _ in range(num_task)])
+            self.gate_mlps = nn.ModuleList([MLP(in_features, **gate_mlp) for _ in range(num_task)])
             gate_in = self.gate_mlps[0].hidden_units[-1]
         self.gate_finals = nn.ModuleList([nn.Linear(gate_in, num_expert) for _ in range(num_task)])
 
@@ -229,10 +242,11 @@ class ConfigMMoE(RankModel):
         eg, m = self.embedding_group, spec.model
         self._group = eg.group_names()[0]
         d_in = eg.group_total_dim(self._group)
-        hidden = [int(x) for x in m.one("expert_mlp").many("hidden_units")]
-        gate = {"hidden_units": [int(x) for x in m.one("gate_mlp").many("hidden_units")]} if m.has("gate_mlp") else None
+        expert = mlp_kwargs(m.one("expert_mlp"))
+        hidden = expert["hidden_units"]
+        gate = mlp_kwargs(m.one("gate_mlp")) if m.has("gate_mlp") else None
         self._towers = [(str(t.one("tower_name")), str(t.one("label_name"))) for t in m.many("task_towers")]
-        self.mmoe = MMoE(d_in, {"hidden_units": hidden}, int(m.one("num_expert")), len(self._towers), gate)
+        self.mmoe = MMoE(d_in, expert, int(m.one("num_expert")), len(self._towers), gate)
         self.task_mlps = nn.ModuleList()
         self.task_outputs = nn.ModuleList()
         for t in m.many("task_towers"):
@@ -240,9 +254,8 @@ class ConfigMMoE(RankModel):
                 raise NotImplementedError("task towers with num_class > 1")
             d = hidden[-1]
             if t.has("mlp"):
-                th = [int(x) for x in t.one("mlp").many("hidden_units")]
-                self.task_mlps.append(MLP(d, th))
-                d = th[-1]
+                self.task_mlps.append(mlp_from_msg(d, t.one("mlp")))
+                d = self.task_mlps[-1].output_dim()
             else:
                 self.task_mlps.append(nn.Identity())
             self.task_outputs.append(OutputLinear(d, 1))

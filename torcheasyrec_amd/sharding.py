@@ -195,13 +195,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     a = (1.0 / max(rows, 1)) ** 0.5  # same distribution as the unsharded table
                     w.uniform_(-a, a)
             local_cfgs.append(EmbeddingBagConfig(cfg.name, cfg.embedding_dim, max(n, 1), list(cfg.feature_names),
-                                                 cfg.pooling, init, data_type=cfg.data_type))
+                                                 cfg.pooling, init, trainable=cfg.trainable, data_type=cfg.data_type))
         self.local = EmbeddingBagCollection(local_cfgs, device=self._device, optimizer=optimizer,
                                             row_layout=row_layout) if local_cfgs else None
         # --- replicated tables ---
         self.replica = EmbeddingBagCollection(
             [EmbeddingBagConfig(c.name, c.embedding_dim, c.num_embeddings, list(c.feature_names), c.pooling, c.init_fn,
-                                data_type=c.data_type) for c in self._dp], device=self._device, optimizer=optimizer, row_layout=row_layout) if self._dp else None
+                                trainable=c.trainable, data_type=c.data_type) for c in self._dp], device=self._device, optimizer=optimizer,
+            row_layout=row_layout) if self._dp else None
         if self.replica is not None:
             for store in self.replica._storage:  # identical replicas: rank 0's values (and zero state)
                 dist.broadcast(store, src=0, group=self.pg)
@@ -345,9 +346,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     arr[t]["n_feats"] = len(mine)
                 acc_tables[t]["m"] = self._dp_acc.data_ptr() + int(rs[t]) * self.dim * 4
                 acc_tables[t]["m_stride"] = self.dim
+            # backward twins: lookups of frozen replicas accumulate nothing (their rows of the accumulation
+            # buffer stay zero, and a zero row gradient is a row the dense update skips)
+            frozen = [not c.trainable for c in self._dp]
+            bwd_feats = feats
+            if any(frozen):
+                from .embedding import mask_frozen_descriptors
+
+                acc_tables, bwd_feats = mask_frozen_descriptors(acc_tables, feats, frozen)
             m.update({
                 "dp_feats_np": feats, "dp_slots_n": len(slots), "dp_n": len(dp_lk),
                 "dp_d_feats": _lib.upload_struct(feats, self._device), "dp_d_slots": _lib.upload_struct(slots, self._device),
+                "dp_d_bwd_feats": _lib.upload_struct(bwd_feats, self._device),
                 "dp_d_tables": _lib.upload_struct(tables, self._device),
                 "dp_d_acc_tables": _lib.upload_struct(acc_tables, self._device),
                 "dp_max_rows": int(max(c.num_embeddings for c in self._dp)), "n_keys": len(kjt_keys),
@@ -374,9 +384,17 @@ class ShardedEmbeddingBagCollection(nn.Module):
             mine = np.nonzero(kt == t)[0]
             tables[t]["first_order"] = int(rank_of[mine].min()) if len(mine) else 0
             tables[t]["n_feats"] = len(mine)
+        frozen = [not c.trainable for c in self.local.embedding_bag_configs()]
+        bwd_tables, bwd_feats = tables, feats
+        if any(frozen):
+            from .embedding import mask_frozen_descriptors
+
+            bwd_tables, bwd_feats = mask_frozen_descriptors(tables, feats, frozen)
         self._own_meta = {
             "d_tables": _lib.upload_struct(tables, self._device),
             "d_feats": _lib.upload_struct(feats, self._device),
+            "d_bwd_tables": _lib.upload_struct(bwd_tables, self._device),
+            "d_bwd_feats": _lib.upload_struct(bwd_feats, self._device),
             "d_key_table": torch.from_numpy(kt).to(self._device), "K": K, "T": T,
             "max_rows": int(max(c.num_embeddings for c in self.local.embedding_bag_configs())),
         }
@@ -541,7 +559,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         B, N_all, n_dp, T_dp = kjt.stride(), kjt.values().numel(), rm["dp_n"], len(self._dp)
         NP = n_dp * B if uniform else N_all
         ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D), dev)
-        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_feats"]), n_dp,
+        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_bwd_feats"]), n_dp,
                                          rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
                                          _lib.ptr(None if uniform else kjt.offsets()), N_all, NP, B, 1 if uniform else 0,
                                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
@@ -552,7 +570,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         om, n_recv = st["om"], st["n_recv"]
         K, T = om["K"], om["T"]
         ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
-        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_tables"]), T, _lib.ptr(om["d_feats"]), K, K, om["max_rows"], D,
+        _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_bwd_tables"]), T, _lib.ptr(om["d_bwd_feats"]), K, K, om["max_rows"], D,
                                          _lib.ptr(st.get("owner_ids", st["recv_ids"])), _lib.ptr(st["key_start"]), n_recv,
                                          n_recv, 1, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
         return ws
@@ -619,7 +637,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             ws = st.get("ws_dp")
             if ws is None:
                 ws = self._plan_dp(st)
-            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_feats"]), n_dp, T_dp, D,
+            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_bwd_feats"]), n_dp, T_dp, D,
                                               _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N_all, NP, B,
                                               1 if uniform else 0, 0, gd, len(gl),
                                               self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
@@ -635,7 +653,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                     ws2 = self._plan_rw(st)
                 g1 = (_lib.TzrDst * 1)()
                 g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
-                _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_feats"]), K, T, D,
+                _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), K, T, D,
                                                   _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
                                                   self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream),
                            "tzr_pooled_bwd_apply")
@@ -866,7 +884,7 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
                         w.copy_(full[:, j * d:(j + 1) * d])
                     name = f"{cfg.name}@cw{j}"
                     virt.append(EmbeddingBagConfig(name, d, cfg.num_embeddings, list(cfg.feature_names), cfg.pooling, init,
-                                                   data_type=cfg.data_type))
+                                                   trainable=cfg.trainable, data_type=cfg.data_type))
                     self._cw[cfg.name].append(name)
                     if grid:  # every column shard is itself row-wise over the node
                         if v_plan is not None:

@@ -125,10 +125,26 @@ class KeyedJaggedTensor:
         uniform_length: Optional[int] = None,
     ) -> None:
         self._keys = list(keys)
-        self._values = values
-        self._weights = weights
-        self._lengths = lengths
-        self._offsets = offsets
+        # The kernels read `values` as int64, `lengths` as int32 / int64, `offsets` as int64 and
+        # `weights` as float32, all dense: torchrec accepts int32 ids and strided views, which would be
+        # read here as garbage / past the end of the buffer -- normalise once, at construction.
+        if values.dtype != torch.int64:
+            if values.is_floating_point() or values.dtype == torch.bool:
+                raise TypeError(f"KeyedJaggedTensor values must be integer ids, got {values.dtype}")
+            values = values.to(torch.int64)
+        if lengths is not None and lengths.dtype not in (torch.int32, torch.int64):
+            if lengths.is_floating_point():
+                raise TypeError(f"KeyedJaggedTensor lengths must be integers, got {lengths.dtype}")
+            lengths = lengths.to(torch.int32)
+        if offsets is not None and offsets.dtype != torch.int64:
+            offsets = offsets.to(torch.int64)
+        if weights is not None and weights.dtype != torch.float32:
+            weights = weights.to(torch.float32)
+        self._values = values.contiguous()
+        self._weights = weights.contiguous() if weights is not None else None
+        self._lengths = lengths.contiguous() if lengths is not None else None
+        self._offsets = offsets.contiguous() if offsets is not None else None
+        values, lengths, offsets, weights = self._values, self._lengths, self._offsets, self._weights
         if stride is None:
             if lengths is not None:
                 stride = lengths.numel() // max(len(self._keys), 1)
