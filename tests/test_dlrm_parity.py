@@ -18,13 +18,19 @@ def _lin(seq):
     return [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seq if hasattr(m, "weight")]
 
 
-@pytest.mark.parametrize("kind,dist", [("adagrad", "uniform"), ("rowwise_adagrad", "zipf")])
-def test_dlrm_criteo_step(dev, kind, dist):
+@pytest.mark.parametrize("kind,dist,acc0", [("adagrad", "uniform", 0.0), ("rowwise_adagrad", "zipf", 0.0),
+                                            ("adagrad", "zipf", 0.1), ("rowwise_adagrad", "uniform", 0.1)])
+def test_dlrm_criteo_step(dev, kind, dist, acc0):
+    """acc0 = accumulator before the step.  From 0.1 (`initial_accumulator_value`) the update is well
+    conditioned and weights AND state must match the oracle within 1e-5 relative (the north star's fp32
+    tolerance); the wider band is kept for the zero-accumulator case only (see below)."""
     torch.manual_seed(1)
     rows = [min(r, 3000) for r in CRITEO_ROWS]
     B, lr = 40, 0.05
     model = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev,
                  sparse_optimizer=SparseOptimizerConfig(kind=kind, lr=lr))
+    for st in model.ebc.table_states().values():
+        st.fill_(acc0)
     dense, kjt, label = synthetic_batch(3, B, rows, dist=dist)
     w0 = {n: w.detach().cpu().clone() for n, w in model.ebc.table_weights().items()}
     logits = model(dense.to(dev), kjt.to(dev))
@@ -53,12 +59,17 @@ def test_dlrm_criteo_step(dev, kind, dist):
     opt = orc.SparseOptim(kind=kind, lr=lr)
     for t, k in enumerate(SPARSE_KEYS):
         w = w0[f"{k}_emb"].numpy().copy()
-        m = np.zeros_like(w) if kind == "adagrad" else np.zeros(w.shape[0], np.float32)
+        m = np.full_like(w, acc0) if kind == "adagrad" else np.full(w.shape[0], acc0, np.float32)
         orc.sparse_update(w, m, kjt.values().numpy()[t * B:(t + 1) * B], block_grads[t].numpy(), opt)
         got = model.ebc.table_weights()[f"{k}_emb"].detach().cpu().numpy()
-        # first Adagrad step moves a row by lr*g/(|g|+eps): where duplicate gradients nearly cancel
-        # the quotient is ill-conditioned, so bound the check by a fraction of the step (2e-3*lr)
-        np.testing.assert_allclose(got, w, rtol=2e-4, atol=2e-3 * lr, err_msg=k)
+        if acc0 > 0:
+            np.testing.assert_allclose(got, w, rtol=1e-5, atol=1e-7, err_msg=k)
+            np.testing.assert_allclose(model.ebc.table_states()[f"{k}_emb"].detach().cpu().numpy(), m, rtol=1e-5, atol=1e-8, err_msg=k)
+        else:
+            # first Adagrad step from a ZERO accumulator moves a row by lr*g/(|g|+eps): where duplicate
+            # gradients nearly cancel the quotient is ill-conditioned, so bound the check by a fraction of
+            # the step (2e-3*lr)
+            np.testing.assert_allclose(got, w, rtol=2e-4, atol=2e-3 * lr, err_msg=k)
 
 
 def test_deepfm_forward_backward(dev):

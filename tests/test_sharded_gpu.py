@@ -1,6 +1,7 @@
 """Sharded path on the real GPU with a world-size-1 RCCL group: the all-to-all calls, the owner /
-requester kernels and the per-id-gradient fused update run on hardware and must reproduce the
-unsharded module bit-for-bit (L=1: pooled output is a copy; one rank => same rows, same order)."""
+requester kernels and the per-id-gradient fused update run on hardware and must reproduce the CPU
+oracle's trajectory (1e-5) and the unsharded module (L=1: pooled output is a copy; one rank => same
+rows, same order)."""
 import os
 import sys
 import tempfile
@@ -40,8 +41,31 @@ def test_sharded_world1_matches_unsharded(kind, replicate):
                               dp_max_rows=4096, replicate_at_world1=replicate)
             for pr, ps in zip(ref.dense_parameters(), shd.dense_parameters()):
                 ps.data.copy_(pr.data)
+            # a non-zero accumulator keeps the first Adagrad step well conditioned: the CPU-oracle comparison
+            # below holds at the north star's 1e-5 (the sharded path was only compared with itself)
+            for mod in (ref.ebc, shd.ebc):
+                for st in mod.table_states().values():
+                    st.fill_(0.1)
+            from oracle import tzrec_oracle as orc
+
+            w_or = {n: w.detach().cpu().numpy().copy() for n, w in ref.ebc.table_weights().items()}
+            m_or = {n: (np.full_like(w_or[n], 0.1) if kind == "adagrad" else np.full(w_or[n].shape[0], 0.1, np.float32)) for n in w_or}
+            oopt = orc.SparseOptim(kind=kind, lr=lr)
+
+            def lin(seq):
+                return [(m.weight.detach().cpu(), m.bias.detach().cpu()) for m in seq if hasattr(m, "weight")]
+
+            p_or = {"dim": 16, "dense_mlp": lin(ref.dense_mlp.mlp), "final_mlp": lin(ref.final_mlp.mlp),
+                    "output": (ref.output_mlp.weight.detach().cpu(), ref.output_mlp.bias.detach().cpu()), "arch_with_sparse": True}
             for step in range(2):
                 dense, kjt, label = synthetic_batch(step, B, rows, dist="zipf" if step else "uniform")
+                # the oracle's step on the host: same weights, same batch
+                blocks = [b.clone().requires_grad_(True) for b in orc.pooled_lookup(
+                    [torch.from_numpy(w_or[f"{k}_emb"]) for k in SPARSE_KEYS], ["sum"] * 26, kjt.values(), kjt.lengths(), B)]
+                l_or = orc.bce_with_logits(orc.dlrm_forward(dense, torch.cat(blocks, dim=1), p_or), label)
+                g_or = torch.autograd.grad(l_or, blocks)
+                for t, k in enumerate(SPARSE_KEYS):
+                    orc.sparse_update(w_or[f"{k}_emb"], m_or[f"{k}_emb"], kjt.values().numpy()[t * B:(t + 1) * B], g_or[t].numpy(), oopt)
                 dense, label = dense.to(dev), label.to(dev)
                 l1 = bce_with_logits(ref(dense, kjt.to(dev)), label)
                 l1.backward()
@@ -49,6 +73,7 @@ def test_sharded_world1_matches_unsharded(kind, replicate):
                 l2.backward()
                 shd.allreduce_dense_grads()
                 assert torch.equal(l1.detach(), l2.detach())  # forward is a copy on both paths
+                assert abs(float(l2) - float(l_or)) <= 1e-5 * abs(float(l_or)) + 1e-7, (step, float(l2), float(l_or))
                 for pr, ps in zip(ref.dense_parameters(), shd.dense_parameters()):
                     torch.testing.assert_close(ps.grad, pr.grad, rtol=1e-6, atol=1e-7)
                     pr.grad = None
@@ -60,6 +85,10 @@ def test_sharded_world1_matches_unsharded(kind, replicate):
                 # row-wise at world 1 is the same kernel sequence (bit-identical); the replicated path
                 # sums duplicates in the same order but through the accumulate buffer
                 np.testing.assert_allclose(got.cpu().numpy(), w[lo:lo + n].cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=name)
+                # ... and against the CPU oracle's trajectory, weights and optimizer state
+                np.testing.assert_allclose(got.cpu().numpy(), w_or[name][lo:lo + n], rtol=1e-5, atol=1e-7, err_msg=f"oracle {name}")
+                np.testing.assert_allclose(shd.ebc.table_states()[name][:n].cpu().numpy(), m_or[name][lo:lo + n], rtol=1e-5, atol=1e-8,
+                                           err_msg=f"oracle state {name}")
         finally:
             dist.destroy_process_group()
 
