@@ -530,12 +530,28 @@ __device__ __forceinline__ void bwd_sort_core(uint32_t (&kreg)[MAXR], uint32_t (
     }
     __syncthreads();
     static_assert(BWD_NB == 2 * BWD_THREADS, "two group counters per thread");
-    uint32_t g = max(S.gstart[2 * threadIdx.x], S.gstart[2 * threadIdx.x + 1]);
+    // exclusive scan of the 512 group counts (two per thread: one wave scan, one barrier) + the largest group
+    const uint32_t c0 = S.gstart[2 * threadIdx.x], c1 = S.gstart[2 * threadIdx.x + 1];
+    uint32_t g = max(c0, c1);
+    uint32_t incl = c0 + c1;
+    for (int dd = 1; dd < TZR_WAVE; dd <<= 1) {
+      const uint32_t o = __shfl_up(incl, dd, TZR_WAVE);
+      if (lane >= dd) incl += o;
+    }
     for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) g = max(g, (uint32_t)__shfl_xor((int)g, m, TZR_WAVE));
-    if (lane == 0) S.smm[wv] = g;
-    bwd_block_scan(S.gstart, BWD_NB, S.wtot);
+    if (lane == TZR_WAVE - 1) S.wtot[wv] = incl;
+    if (lane == 0) S.smm[BWD_WAVES + wv] = g;
+    __syncthreads();
+    uint32_t excl = incl - (c0 + c1);
 #pragma unroll
-    for (int w = 0; w < BWD_WAVES; ++w) g = max(g, S.smm[w]);
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      if (w < wv) excl += S.wtot[w];
+      g = max(g, S.smm[BWD_WAVES + w]);
+    }
+    S.gstart[2 * threadIdx.x] = excl;
+    S.gstart[2 * threadIdx.x + 1] = excl + c0;
+    if (threadIdx.x == BWD_THREADS - 1) S.gstart[BWD_NB] = excl + c0 + c1;
+    __syncthreads();
     if (g <= BWD_GMAX) {
 #pragma unroll
       for (int r = 0; r < MAXR; ++r)
@@ -545,18 +561,30 @@ __device__ __forceinline__ void bwd_sort_core(uint32_t (&kreg)[MAXR], uint32_t (
           S.ps[at] = sreg[r];
         }
       __syncthreads();
+      // rank inside the group by (row id, lookup position): the groups of a thread's elements are walked
+      // together, member j of every group per step, so the LDS reads of one step are independent
+      uint32_t lo[MAXR], len[MAXR];
+      uint32_t steps = 0;
 #pragma unroll
-      for (int r = 0; r < MAXR; ++r)
+      for (int r = 0; r < MAXR; ++r) {
+        lo[r] = len[r] = 0;
+        dest[r] = 0;
         if ((vmask >> r) & 1u) {
-          const uint32_t lo = S.gstart[dig[r]], hi = S.gstart[dig[r] + 1];
-          const uint32_t k = kreg[r], sp = sreg[r];
-          uint32_t rank = 0;
-          for (uint32_t j = lo; j < hi; ++j) {
-            const uint32_t kj = S.pk[j], sj = S.ps[j];
-            rank += (kj < k || (kj == k && sj < sp)) ? 1u : 0u;
-          }
-          dest[r] = lo + rank;
+          lo[r] = S.gstart[dig[r]];
+          len[r] = S.gstart[dig[r] + 1] - lo[r];
+          steps = max(steps, len[r]);
         }
+      }
+      for (uint32_t j = 0; j < steps; ++j) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+          if (j < len[r]) {
+            const uint32_t kj = S.pk[lo[r] + j], sj = S.ps[lo[r] + j];
+            dest[r] += (kj < kreg[r] || (kj == kreg[r] && sj < sreg[r])) ? 1u : 0u;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) dest[r] += lo[r];
       return;
     }
     __syncthreads();  // smm / wtot are reused below

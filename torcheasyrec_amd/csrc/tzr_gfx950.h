@@ -16,21 +16,19 @@
 typedef __attribute__((address_space(1))) uint32_t tzr_gu32;
 typedef __attribute__((address_space(1))) uint64_t tzr_gu64;
 
-// SYSTEM scope (sc0 sc1) on both sides: the access is performed at the memory side, a copy of the
-// line in the reading XCD's L2 (left there by an earlier read of a NEIGHBOURING word, before this
-// word was published) cannot serve it.  Agent scope (sc1 only) did exactly that once in ~6 runs
-// of the full-size Zipf test when several stitchers of one XCD shared record lines (r02 notes).
+// Agent scope (sc1) on both sides (guideline 16: sc1 loads may replace the consumer's acquire when the
+// producer stored sc1).
 __device__ __forceinline__ void tzr_publish_u32(uint32_t* p, uint32_t v) {
-  __hip_atomic_store((tzr_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((tzr_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void tzr_publish_u64(uint64_t* p, uint64_t v) {
-  __hip_atomic_store((tzr_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((tzr_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t tzr_consume_u32(const uint32_t* p) {
-  return __hip_atomic_load((tzr_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __hip_atomic_load((tzr_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint64_t tzr_consume_u64(const uint64_t* p) {
-  return __hip_atomic_load((tzr_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __hip_atomic_load((tzr_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // every wave that published calls this before the arrival is counted
 __device__ __forceinline__ void tzr_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
