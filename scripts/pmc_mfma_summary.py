@@ -35,7 +35,12 @@ def main(d, out):
         if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
             e["mfma_flop"] = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
         if m.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-            e["mfma_busy_share_of_simd_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * SIMDS)
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0  # reported summed over the 8 XCDs (a 58 us kernel reads 1.16 M = 8 x 145 k)
+            e["kernel_cycles"] = cyc
+            e["mfma_busy_share_of_simd_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS)
+            if "mfma_flop" in e:
+                e["mfma_tflops_while_running"] = e["mfma_flop"] / (cyc / 2.4e9) / 1e12
+                e["frac_of_f32_mfma_peak"] = e["mfma_tflops_while_running"] * 1e12 / PEAK_F32_MFMA
         res[name] = e
     json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
                          "GRBM_GUI_ACTIVE -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph",
