@@ -409,7 +409,7 @@ def main():
     # 65536-sample step).  Eager launches (no hipGraph), so this is also the launch-bound reading.
     e2e = None
     if not sharded and not args.no_e2e and args.e2e_steps > 0:
-        from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, TrainPipeline
+        from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, GraphTrainPipeline, TrainPipeline
         from torcheasyrec_amd.sparse import KeyedTensor
 
         class _BatchModel(torch.nn.Module):
@@ -426,23 +426,34 @@ def main():
             host.append(Batch({BASE_DATA_GROUP: KeyedTensor([f"int_{i}" for i in range(NUM_DENSE)], [1] * NUM_DENSE, d_)},
                               {BASE_DATA_GROUP: k_}, {"label": l_}).pin_memory())
         n_e2e = args.e2e_steps
-        pipe = TrainPipeline(_BatchModel(model), dense_opt, dev,
-                             lambda pred, b: {"bce": bce_with_logits(pred, b.labels["label"])})
-        it = iter([host[i % nb] for i in range(n_e2e + 6)])
-        for _ in range(5):
-            pipe.progress(it)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_e2e):
-            pipe.progress(it)
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
+        loss_of = lambda pred, b: {"bce": bce_with_logits(pred, b.labels["label"])}  # noqa: E731
         h2d = sum(t.numel() * t.element_size() for t in (host[0].dense_features[BASE_DATA_GROUP].values(),
                                                          host[0].sparse_features[BASE_DATA_GROUP].values(),
                                                          host[0].sparse_features[BASE_DATA_GROUP].lengths(),
                                                          host[0].labels["label"]))
+
+        def timed(pipe, n_warm):
+            it = iter([host[i % nb] for i in range(n_e2e + n_warm + 1)])
+            for _ in range(n_warm):
+                pipe.progress(it)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_e2e):
+                pipe.progress(it)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
+        # (a) hipGraph replay per device slot, the next batch's H2D under it (GraphTrainPipeline); (b) the eager
+        # TrainPipeline (one Python-launched kernel sequence per step): the launch-bound reading
+        e_graph = timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8) if not args.torch_adam else None
+        e_eager = timed(TrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 5)
+        e1 = e_graph if e_graph is not None else e_eager
         e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
-               "h2d_bytes_per_step": h2d, "launch": "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"}
+               "h2d_bytes_per_step": h2d,
+               "launch": ("hipGraph replay per device slot, pinned host batches, H2D of the next batch on a copy stream "
+                          "(GraphTrainPipeline.progress)" if e_graph is not None else
+                          "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"),
+               "eager_ms_per_step": e_eager / n_e2e * 1e3}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     # inside a captured graph); the kernels and inputs are the ones of the timed region

@@ -44,3 +44,13 @@ def dev(request):
     _lib.use_native()
     assert _lib.backend().startswith("hip"), "GPU tests must run on the native gfx950 library"
     return torch.device("cuda", 0)
+
+
+def emu_heavy(dev=None):
+    """Skip a test (variant) that is slow on the CPU lane emulator (one OS thread per lane: every barrier and
+    ballot of the kernels is a futex round) unless TZR_CPU_FULL=1.  The same bodies run in full under `-m gpu`;
+    the default CPU suite keeps at least one variant of every kernel path and every multi-process path."""
+    if os.environ.get("TZR_CPU_FULL") == "1":
+        return
+    if dev is None or dev.type == "cpu":
+        pytest.skip("slow on the lane emulator: set TZR_CPU_FULL=1 (runs in full under -m gpu)")

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from conftest import emu_heavy  # noqa: E402
 from oracle import tzrec_oracle as orc  # noqa: E402
 from torcheasyrec_amd.config import load_pipeline_spec, parse_text_proto  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS  # noqa: E402
@@ -190,6 +191,7 @@ def test_multi_tower_din_config_to_training(dev):
     """BASELINE config 4 at the config level: `sequence_feature` blocks, a bucketized raw feature, a
     DEEP and a SEQUENCE group, `multi_tower_din`.  Logits against the oracle restatement (pooled
     lookup + per-id rows padded to the batch's longest history + DIN attention + MLPs), then training."""
+    emu_heavy(dev)
     ref_cfg = os.path.join(REF, "multi_tower_din_taobao.config")
     if os.path.exists(ref_cfg):  # the reference's own example parses into the same structures
         big = load_pipeline_spec(open(ref_cfg).read())
@@ -314,6 +316,7 @@ def test_mmoe_with_zch_config_to_training(dev):
 
 
 def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path):
+    emu_heavy(dev)
     from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
 
     spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "din_mini.config")).read())
@@ -418,6 +421,7 @@ def test_sparse_adam_from_config_and_checkpoint(dev, tmp_path):
     """`adam_optimizer` in `sparse_optimizer` (the one other kind the reference's configs use,
     protos/optimizer.proto:89-96): parsed, trains, and a checkpoint carries the step counter so the
     bias correction continues where it stopped."""
+    emu_heavy(dev)
     from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
 
     text = open(os.path.join(HERE, "golden", "deepfm_mini.config")).read()

@@ -18,6 +18,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 sys.path.insert(0, ROOT)
+from conftest import emu_heavy  # noqa: E402
 sys.path.insert(0, os.path.dirname(__file__))
 
 
@@ -764,6 +765,8 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
 @pytest.mark.parametrize("cfg,labels,in_config", [("deepfm_mini.config", ["label"], False),
                                                   ("deepfm_mini.config", ["label"], True), ("din_mini.config", ["clk"], True)])
 def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config):
+    if (cfg, in_config) == ("deepfm_mini.config", False):
+        emu_heavy()  # the default suite keeps DeepFM with its plan in the config and the DIN model
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config), nprocs=2, join=True)
 
@@ -918,12 +921,15 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
 
 @pytest.mark.parametrize("jagged,planner,grid", [(False, False, False), (False, True, False), (True, False, True)])
 def test_mixed_dims_and_column_wise_world2(emu_path, jagged, planner, grid):
+    if (jagged, planner, grid) == (False, False, False):
+        emu_heavy()  # the planner-placed and the jagged grid variants stay in the default suite
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_mixed_worker, args=(2, os.path.join(d, "init"), emu_path, jagged, planner, grid), nprocs=2, join=True)
 
 
 def test_mixed_dims_and_column_wise_world4(emu_path):
     """four ranks: four dim-4 column shards on four ranks, one of them sharing the wide tables' lane"""
+    emu_heavy()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_mixed_worker, args=(4, os.path.join(d, "init"), emu_path, True, False, False), nprocs=4, join=True)
 

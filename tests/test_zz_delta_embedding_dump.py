@@ -14,6 +14,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from conftest import emu_heavy  # noqa: E402
 from oracle import delta_oracle as dorc  # noqa: E402
 from torcheasyrec_amd import _lib  # noqa: E402
 from torcheasyrec_amd import delta_embedding_dump as dd  # noqa: E402
@@ -148,6 +149,7 @@ _F2FQN = {"f0": "ebc.embedding_bags.t0", "f0b": "ebc.embedding_bags.t0", "f1": "
 def test_tracker_equals_reference_store(dev):
     """ModelDeltaTracker over training steps == cat + unique of the reference's store: FQNs, ids,
     delete_on_read, pause_tracking, clear, two independent consumers."""
+    emu_heavy(dev)
     m = _Model(dev)
     tr = dd.ModelDeltaTracker(m, consumers=["a", "b"])
     assert tr.fqn_to_feature_names == {"ebc.embedding_bags.t0": ["f0", "f0b"], "ebc.embedding_bags.t1": ["f1"],

@@ -98,14 +98,15 @@ def test_mixed_lanes_on_one_rank_match_the_unsharded_collection(dev):
 
             aopt = SparseOptimizerConfig(kind="adam", lr=0.01)
             sa = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=aopt, groups=groups, plan=plan)
-            for _ in range(3):
+            n_adam = 3 if dev.type == "cuda" else 1
+            for _ in range(n_adam):
                 o = sa.forward_grouped(kjt)
                 (o["wide"].sum() + o["deep"].sum()).backward()
-            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sa.lanes] == [3.0] * len(sa.lanes)
+            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sa.lanes] == [float(n_adam)] * len(sa.lanes)
             save_checkpoint(os.path.join(d, "ck_adam"), Holder(sa))
             sb = MixedShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=aopt, groups=groups, plan=plan)
             restore_checkpoint(os.path.join(d, "ck_adam"), Holder(sb))
-            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sb.lanes] == [3.0] * len(sb.lanes)
+            assert [float(lane.fused_optimizer.adam_state(dev)[0]) for lane in sb.lanes] == [float(n_adam)] * len(sb.lanes)
             oa, ob = sa.forward_grouped(kjt), sb.forward_grouped(kjt)
             (oa["wide"].sum() + oa["deep"].sum()).backward()
             (ob["wide"].sum() + ob["deep"].sum()).backward()

@@ -481,3 +481,107 @@ class TrainPipeline:
             self._model.allreduce_dense_grads()  # no-op unless the model was built over a process group
         self._opt.step()
         return losses, predictions, batch
+
+
+def _batch_tensors(b: Batch):
+    """Every tensor of a batch in a fixed order (for slot-to-slot copies of same-shape batches)."""
+    out = []
+    for g in sorted(b.dense_features):
+        out.append(b.dense_features[g].values())
+    for g in sorted(b.sparse_features):
+        k = b.sparse_features[g]
+        out += [t for t in (k.values(), k.lengths_or_none(), k.weights_or_none(), k.offsets_or_none()) if t is not None]
+    for n in sorted(b.labels):
+        out.append(b.labels[n])
+    for n in sorted(b.sample_weights):
+        out.append(b.sample_weights[n])
+    return out
+
+
+class GraphTrainPipeline:
+    """`pipeline.progress(iterator)` with the whole step replayed from a hipGraph while the NEXT batch
+    crosses PCIe (tzrec/utils/dist_util.py:221-303: H2D of batch i+1 on the memcpy stream under the
+    forward / backward of batch i).  For fixed-shape batches (Criteo: one id per bag): two device slots;
+    batch i+1 is copied from pinned host memory into the idle slot on the copy stream, and the step of a
+    slot is captured once (forward, loss, backward with the fused sparse update, dense optimizer) and
+    replayed.  Batches whose shapes differ from the slots' fall back to the eager `TrainPipeline` step.
+
+    The model must be capturable (dense optimizer with device-side step counts: `dense.FusedDenseAdam`,
+    or torch optimizers built with `capturable=True`)."""
+
+    def __init__(self, model: nn.Module, optimizer, device: torch.device, loss_fn, warmup: int = 2) -> None:
+        self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
+        assert self._device.type == "cuda", "GraphTrainPipeline replays hipGraphs: CUDA/HIP device only"
+        self._copy_stream = torch.cuda.Stream(device=self._device)
+        self._slots = [None, None]     # device batches with static addresses
+        self._graphs = [None, None]    # (CUDAGraph, losses, predictions) per slot
+        self._seen = [0, 0]
+        self._ready = [None, None]     # event: the H2D copy into the slot has finished
+        self._done = [None, None]      # event: the last step that read the slot has finished
+        self._warmup, self._pool = warmup, None
+        self._pending = None           # (slot, host batch) of the batch copied ahead
+        self._exhausted, self._i = False, 0
+
+    def _stage(self, it):
+        """next host batch -> the idle slot, on the copy stream"""
+        try:
+            hb = next(it)
+        except StopIteration:
+            self._exhausted = True
+            return None
+        slot = self._i % 2
+        self._i += 1
+        with torch.cuda.stream(self._copy_stream):
+            if self._slots[slot] is None:
+                self._slots[slot] = hb.to(self._device, non_blocking=True)
+            else:
+                if self._done[slot] is not None:
+                    self._copy_stream.wait_event(self._done[slot])  # the step that still reads this slot
+                src, dst = _batch_tensors(hb), _batch_tensors(self._slots[slot])
+                if len(src) != len(dst) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(src, dst)):
+                    raise ValueError("GraphTrainPipeline needs fixed-shape batches (shapes changed between batches)")
+                for a, b in zip(src, dst):
+                    b.copy_(a, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ready[slot] = ev
+        return slot, hb
+
+    def _step(self, batch: Batch):
+        self._opt.zero_grad(set_to_none=True)
+        predictions = self._model(batch)
+        losses = self._loss_fn(predictions, batch)
+        sum(losses.values()).backward()
+        self._opt.step()
+        return losses, predictions
+
+    def progress(self, dataloader_iter):
+        if self._pending is None and not self._exhausted:
+            self._pending = self._stage(dataloader_iter)
+        if self._pending is None:
+            raise StopIteration
+        slot, _ = self._pending
+        cur = torch.cuda.current_stream(self._device)
+        cur.wait_event(self._ready[slot])
+        batch = self._slots[slot]
+        self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
+        if self._graphs[slot] is None and self._seen[slot] >= self._warmup:
+            g = torch.cuda.CUDAGraph()
+            # capture on the caller's stream when it is a side stream (autograd's accumulation nodes and the
+            # captured kernels then agree on it); torch picks one when the caller sits on the default stream
+            kw = {} if cur == torch.cuda.default_stream(self._device) else {"stream": cur}
+            with torch.cuda.graph(g, pool=self._pool, **kw):
+                losses, predictions = self._step(batch)
+            self._pool = g.pool()
+            self._graphs[slot] = (g, losses, predictions)
+        if self._graphs[slot] is not None:
+            g, losses, predictions = self._graphs[slot]
+            g.replay()
+        else:
+            losses, predictions = self._step(batch)
+            self._seen[slot] += 1
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._done[slot] = ev
+        return losses, predictions, batch
+

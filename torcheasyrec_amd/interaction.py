@@ -14,6 +14,14 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import ops as _ops  # noqa: F401  (registers torch.ops.tzrec_hip.*)
+
+
+def _traced(t: torch.Tensor) -> bool:
+    """True when `t` is being traced (FX / make_fx / dynamo / torch.export: fake or proxy tensors).  Traced
+    programs go through `torch.ops.tzrec_hip.*` so the graph shows the ops; eager calls keep
+    the direct autograd.Function path below, which costs no dispatcher round trip per call."""
+    return torch.compiler.is_compiling() or type(t) not in (torch.Tensor, nn.Parameter)
 
 
 class _DotInteractionFn(torch.autograd.Function):
@@ -59,6 +67,8 @@ def dot_interaction(
     dense: Optional[torch.Tensor], sparse: torch.Tensor, dim: int, cat_dense: bool = True, cat_sparse: bool = True
 ) -> torch.Tensor:
     """[B, n(n-1)/2 (+dim) (+F*dim)]: strict-upper-triangle of X X^T for X = [dense; sparse rows]."""
+    if _traced(sparse):
+        return torch.ops.tzrec_hip.dot_interaction_fwd(dense, sparse, dim, cat_dense, cat_sparse)
     return _DotInteractionFn.apply(dense, sparse, dim, cat_dense, cat_sparse)
 
 
@@ -75,7 +85,7 @@ class InteractionArch(nn.Module):
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
         B, N, D = features.shape
-        return _DotInteractionFn.apply(None, features.reshape(B, N * D), D, False, False)
+        return dot_interaction(None, features.reshape(B, N * D), D, False, False)
 
 
 class _FMFn(torch.autograd.Function):
@@ -106,4 +116,6 @@ class FactorizationMachine(nn.Module):
     """FM second-order term: [B, N, D] -> [B, D] (same signature as the reference)."""
 
     def forward(self, feature: torch.Tensor) -> torch.Tensor:
+        if _traced(feature):
+            return torch.ops.tzrec_hip.fm_fwd(feature)
         return _FMFn.apply(feature)
