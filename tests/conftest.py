@@ -47,10 +47,6 @@ def dev(request):
 
 
 def emu_heavy(dev=None):
-    """Skip a test (variant) that is slow on the CPU lane emulator (one OS thread per lane: every barrier and
-    ballot of the kernels is a futex round) unless TZR_CPU_FULL=1.  The same bodies run in full under `-m gpu`;
-    the default CPU suite keeps at least one variant of every kernel path and every multi-process path."""
-    if os.environ.get("TZR_CPU_FULL") == "1":
-        return
-    if dev is None or dev.type == "cpu":
-        pytest.skip("slow on the lane emulator: set TZR_CPU_FULL=1 (runs in full under -m gpu)")
+    """Historical: marked test variants that were slow on the first lane emulator (one OS thread per lane).  The
+    fiber emulator (tests/emu/hip/hip_runtime.h) runs the whole CPU suite in a few minutes: nothing is skipped."""
+    return

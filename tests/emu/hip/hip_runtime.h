@@ -2,9 +2,9 @@
 //
 // There is no GPU in the authoring container, so the logic of the HIP kernels (index math, scans,
 // stable ranking, MFMA fragment maps) is exercised on CPU by compiling the *unchanged* .hip sources
-// with the host clang against this header, which shadows <hip/hip_runtime.h>.  One OS thread per
-// lane, one workgroup at a time; __syncthreads() is a real barrier, wave ops exchange through a
-// per-wave buffer.  Nothing in the product (`torcheasyrec_amd/`) can reach this file: the library it
+// with the host clang against this header, which shadows <hip/hip_runtime.h>.  One fiber per lane
+// on one OS thread, one workgroup at a time; __syncthreads() and the wave ops are cooperative
+// barriers, wave ops exchange through a per-wave buffer.  Nothing in the product (`torcheasyrec_amd/`) can reach this file: the library it
 // produces reports tzr_backend() == "emu" and is loaded only by tests/ through an explicit path.
 // It is not a fallback and is never timed.
 #pragma once
@@ -49,77 +49,146 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 #define __restrict__
 #endif
 
+// Scheduling: every lane of a workgroup is a FIBER (own stack, hand-rolled x86-64 context switch,
+// tests/emu/abi_emu.cpp) and the whole workgroup runs on the calling OS thread.  A lane runs until it
+// reaches a wave-level op or __syncthreads(), then yields round-robin; the last lane to arrive releases
+// the barrier.  (The first version ran one OS thread per lane with std::barrier: every ballot was two
+// 64-thread futex rounds, every __syncthreads() a 256-thread one -- the CPU suite spent 25 of its 30
+// CPU-minutes in the kernel's futex code.)
+extern "C" void tzr_emu_switch(void** save_sp, void* load_sp);
+
 namespace emu {
 static constexpr int kWave = 64;
 static constexpr int kMaxThreads = 1024;
+static constexpr size_t kStack = 256 * 1024;
 
 struct Wave {
-  std::barrier<> bar{kWave};
+  int arrived = 0;
+  unsigned gen = 0;
+  int finished = 0;
   alignas(64) unsigned char buf[kWave][64];
-  unsigned long long mask;
 };
 
-struct Pool {
-  std::vector<std::thread> threads;
-  std::unique_ptr<std::barrier<>> start, done, block;
-  std::vector<std::unique_ptr<Wave>> waves;
-  int nthreads = 0;
+struct Lane {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  bool done = true;
+  uint3_emu tidx{0, 0, 0};
+};
+
+struct Sched {
+  std::vector<Lane> lanes;
+  std::vector<Wave> waves;
+  int n = 0, cur = 0, finished = 0;
+  int block_arrived = 0;
+  unsigned block_gen = 0;
+  void* main_sp = nullptr;
   std::function<void()> fn;
-  dim3 grid, blk;
-  unsigned cur_block = 0;
-  bool quit = false;
+  uint3_emu bidx{0, 0, 0};
 };
-inline Pool& pool() { static Pool p; return p; }
-
-inline thread_local uint3_emu t_threadIdx, t_blockIdx;
-inline thread_local int t_tid = 0;
+inline Sched& sched() { static Sched s; return s; }
 inline dim3 g_blockDim, g_gridDim;
 
-inline void worker(int tid) {
-  Pool& p = pool();
-  t_tid = tid;
-  for (;;) {
-    p.start->arrive_and_wait();
-    if (p.quit) return;
-    unsigned nblocks = p.grid.x * p.grid.y * p.grid.z;
-    for (unsigned b = 0; b < nblocks; ++b) {
-      t_blockIdx.x = b % p.grid.x;
-      t_blockIdx.y = (b / p.grid.x) % p.grid.y;
-      t_blockIdx.z = b / (p.grid.x * p.grid.y);
-      t_threadIdx.x = tid % p.blk.x;
-      t_threadIdx.y = (tid / p.blk.x) % p.blk.y;
-      t_threadIdx.z = tid / (p.blk.x * p.blk.y);
-      p.fn();
-      p.block->arrive_and_wait();
-    }
-    p.done->arrive_and_wait();
+inline int lane() { return sched().cur % kWave; }
+inline Wave& wave() { return sched().waves[sched().cur / kWave]; }
+
+inline void switch_to(int next) {
+  Sched& S = sched();
+  const int prev = S.cur;
+  S.cur = next;
+  tzr_emu_switch(&S.lanes[prev].sp, S.lanes[next].sp);
+}
+
+// next unfinished lane after `from` inside [lo, hi), wrapping; -1 if `from` is the only one left
+inline int next_lane(int from, int lo, int hi) {
+  Sched& S = sched();
+  for (int k = 1; k < hi - lo; ++k) {
+    const int c = lo + (from - lo + k) % (hi - lo);
+    if (!S.lanes[c].done) return c;
   }
+  return -1;
 }
 
-inline void shutdown() {
-  Pool& p = pool();
-  if (p.nthreads == 0) return;
-  p.quit = true;
-  p.start->arrive_and_wait();
-  for (auto& t : p.threads) t.join();
-  p.threads.clear();
-  p.nthreads = 0;
-  p.quit = false;
+inline void yield_in(int lo, int hi) {
+  const int nx = next_lane(sched().cur, lo, hi);
+  if (nx < 0) {
+    fprintf(stderr, "emu: lane %d waits on a barrier no other lane can reach (divergent barrier)\n", sched().cur);
+    abort();
+  }
+  switch_to(nx);
 }
 
-inline void ensure(int n) {
-  Pool& p = pool();
-  if (p.nthreads == n) return;
-  shutdown();
-  p.nthreads = n;
-  p.start = std::make_unique<std::barrier<>>(n + 1);
-  p.done = std::make_unique<std::barrier<>>(n + 1);
-  p.block = std::make_unique<std::barrier<>>(n);
-  p.waves.clear();
-  for (int w = 0; w < (n + kWave - 1) / kWave; ++w) p.waves.emplace_back(std::make_unique<Wave>());
-  for (int i = 0; i < n; ++i) p.threads.emplace_back(worker, i);
-  static bool reg = false;
-  if (!reg) { reg = true; atexit(shutdown); }
+inline void wave_barrier() {
+  Sched& S = sched();
+  const int w = S.cur / kWave;
+  Wave& W = S.waves[w];
+  const unsigned g = W.gen;
+  if (++W.arrived == kWave - W.finished) {
+    W.arrived = 0;
+    ++W.gen;
+    return;
+  }
+  while (W.gen == g) yield_in(w * kWave, (w + 1) * kWave);
+}
+
+inline void block_barrier() {
+  Sched& S = sched();
+  const unsigned g = S.block_gen;
+  if (++S.block_arrived == S.n - S.finished) {
+    S.block_arrived = 0;
+    ++S.block_gen;
+    return;
+  }
+  while (S.block_gen == g) yield_in(0, S.n);
+}
+
+// first frame of every fiber
+inline void lane_entry() {
+  Sched& S = sched();
+  S.fn();
+  // this lane has left the kernel: barriers stop waiting for it
+  Lane& L = S.lanes[S.cur];
+  L.done = true;
+  ++S.finished;
+  Wave& W = S.waves[S.cur / kWave];
+  ++W.finished;
+  if (W.arrived > 0 && W.arrived == kWave - W.finished) { W.arrived = 0; ++W.gen; }
+  if (S.block_arrived > 0 && S.block_arrived == S.n - S.finished) { S.block_arrived = 0; ++S.block_gen; }
+  const int nx = next_lane(S.cur, 0, S.n);
+  if (nx >= 0) {
+    switch_to(nx);
+  } else {
+    void* dummy;
+    tzr_emu_switch(&dummy, S.main_sp);
+  }
+  abort();  // a finished fiber is never resumed
+}
+extern "C" inline void tzr_emu_lane_entry_thunk() { lane_entry(); }
+
+inline void prepare(int n) {
+  Sched& S = sched();
+  if ((int)S.lanes.size() < n) {
+    const size_t old = S.lanes.size();
+    S.lanes.resize(n);
+    for (size_t i = old; i < (size_t)n; ++i) S.lanes[i].stack = static_cast<char*>(aligned_alloc(64, kStack));
+  }
+  S.waves.assign((n + kWave - 1) / kWave, Wave{});
+  S.n = n;
+  S.finished = 0;
+  S.block_arrived = 0;
+  S.block_gen = 0;
+  for (int i = 0; i < n; ++i) {
+    Lane& L = S.lanes[i];
+    L.done = false;
+    // [r15 r14 r13 r12 rbx rbp][return address = entry thunk]; the slot of the return address is 16-byte
+    // aligned so that the thunk starts with rsp = 8 (mod 16), like after a call
+    uintptr_t top = (reinterpret_cast<uintptr_t>(L.stack) + kStack) & ~uintptr_t(15);
+    void** ret = reinterpret_cast<void**>(top - 16);
+    *ret = reinterpret_cast<void*>(&tzr_emu_lane_entry_thunk);
+    void** regs = ret - 6;
+    for (int k = 0; k < 6; ++k) regs[k] = nullptr;
+    L.sp = regs;
+  }
 }
 
 template <class F>
@@ -129,35 +198,43 @@ inline void launch(dim3 grid, dim3 blk, F&& f) {
     fprintf(stderr, "emu: block size %d must be a multiple of 64 and <= 1024\n", n);
     abort();
   }
-  if (grid.x * grid.y * grid.z == 0) return;
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  if (nblocks == 0) return;
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  ensure(n);
-  Pool& p = pool();
-  p.grid = grid; p.blk = blk; g_blockDim = blk; g_gridDim = grid;
-  p.fn = std::function<void()>(f);
-  p.start->arrive_and_wait();
-  p.done->arrive_and_wait();
+  Sched& S = sched();
+  g_blockDim = blk;
+  g_gridDim = grid;
+  S.fn = std::function<void()>(f);
+  for (unsigned b = 0; b < nblocks; ++b) {
+    prepare(n);
+    S.bidx.x = b % grid.x;
+    S.bidx.y = (b / grid.x) % grid.y;
+    S.bidx.z = b / (grid.x * grid.y);
+    for (int tid = 0; tid < n; ++tid) {
+      S.lanes[tid].tidx.x = tid % blk.x;
+      S.lanes[tid].tidx.y = (tid / blk.x) % blk.y;
+      S.lanes[tid].tidx.z = tid / (blk.x * blk.y);
+    }
+    S.cur = 0;
+    tzr_emu_switch(&S.main_sp, S.lanes[0].sp);  // returns when the last lane of the workgroup has finished
+  }
 }
-
-inline Wave& wave() { return *pool().waves[t_tid / kWave]; }
-inline int lane() { return t_tid % kWave; }
 
 template <class T>
 inline T exchange(T v, int src_lane) {
   static_assert(sizeof(T) <= 64, "emu exchange payload too large");
-  Wave& w = wave();
-  memcpy(w.buf[lane()], &v, sizeof(T));
-  w.bar.arrive_and_wait();
+  memcpy(wave().buf[lane()], &v, sizeof(T));
+  wave_barrier();
   T r;
-  memcpy(&r, w.buf[src_lane & (kWave - 1)], sizeof(T));
-  w.bar.arrive_and_wait();
+  memcpy(&r, wave().buf[src_lane & (kWave - 1)], sizeof(T));
+  wave_barrier();
   return r;
 }
 }  // namespace emu
 
-#define threadIdx (emu::t_threadIdx)
-#define blockIdx (emu::t_blockIdx)
+#define threadIdx (emu::sched().lanes[emu::sched().cur].tidx)
+#define blockIdx (emu::sched().bidx)
 #define blockDim (emu::g_blockDim)
 #define gridDim (emu::g_gridDim)
 #define warpSize 64
@@ -171,9 +248,9 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 
-inline void __syncthreads() { emu::pool().block->arrive_and_wait(); }
+inline void __syncthreads() { emu::block_barrier(); }
 // lanes are OS threads here: a wave-level barrier has to be a real one
-inline void __builtin_amdgcn_wave_barrier() { emu::wave().bar.arrive_and_wait(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
@@ -201,14 +278,16 @@ template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
   return emu::exchange(v, s);
 }
 inline unsigned long long __ballot(int pred) {
-  emu::Wave& w = emu::wave();
   int l = emu::lane();
   unsigned char b = pred ? 1 : 0;
-  w.buf[l][0] = b;
-  w.bar.arrive_and_wait();
+  emu::wave().buf[l][0] = b;
+  emu::wave_barrier();
   unsigned long long m = 0;
-  for (int i = 0; i < 64; ++i) m |= (unsigned long long)w.buf[i][0] << i;
-  w.bar.arrive_and_wait();
+  emu::Wave& w = emu::wave();
+  // lanes that have left the kernel do not vote
+  for (int i = 0; i < 64; ++i)
+    if (!emu::sched().lanes[(emu::sched().cur / 64) * 64 + i].done) m |= (unsigned long long)w.buf[i][0] << i;
+  emu::wave_barrier();
   return m;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
@@ -271,11 +350,11 @@ typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
 // C/D: reg r of lane l is D[row=(l>>4)*4+r][col=l&15]; exact f32, k-ordered fmaf chain
 // (cdna_hip_programming.md section 3).
 inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
-  emu::Wave& w = emu::wave();
   int l = emu::lane();
   float ab[2] = {a, b};
-  memcpy(w.buf[l], ab, 8);
-  w.bar.arrive_and_wait();
+  memcpy(emu::wave().buf[l], ab, 8);
+  emu::wave_barrier();
+  emu::Wave& w = emu::wave();
   emu_f32x4 d = c;
   int col = l & 15;
   for (int r = 0; r < 4; ++r) {
@@ -289,7 +368,7 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
     }
     d[r] = acc;
   }
-  w.bar.arrive_and_wait();
+  emu::wave_barrier();
   return d;
 }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu::exchange(v, 0); }

@@ -300,18 +300,18 @@ def _zipf_clipped(rng, rows, n):
 PLAN_CASES = {
     "just_over_exact": (600, 700, None, True),                     # 513..1024 rows: 1-2 row ids per bucket
     "light_units": (70000, 1300, None, True),                      # ~4 lookups per bucket, grouped unit sort
-    "three_pass": (1 << 22, 1100, None, False),                    # units spanning ~21 bits of row id
+    "three_pass": (1 << 22, 1100, None, True),                    # units spanning ~21 bits of row id
     "wide_rows": (40_000_000, 1500, None, False),                  # ~25 bits
-    "hot_one_tile": (70000, 1500, _hot(0.45, [31337]), False),     # one heavy bucket < one heavy tile, rest light
+    "hot_one_tile": (70000, 1500, _hot(0.45, [31337]), True),     # one heavy bucket < one heavy tile, rest light
     "hot_t1_tiles": (70000, 2200, _hot(0.6, [31337]), True),       # heavy bucket of <= 512 row ids, 2 parallel tiles
     "zipf_mid_table": (12973, 2600, _zipf_clipped, True),          # ~3000 lookups on one row + Zipf head: tiles + mixed units
-    "zipf_big_table": (3067956, 5000, _zipf_clipped, False),       # wide buckets: hot-row tiles
-    "hot_two_in_bucket": (200000, 1800, _hot(0.6, [5000, 5001, 5003]), False),  # wide heavy bucket with 3 hot rows
+    "zipf_big_table": (3067956, 5000, _zipf_clipped, True),       # wide buckets: hot-row tiles
+    "hot_two_in_bucket": (200000, 1800, _hot(0.6, [5000, 5001, 5003]), True),  # wide heavy bucket with 3 hot rows
     "hot_multi_tile": (1 << 20, 2000, _hot(0.75, [777777]), True), # wide heavy bucket of ~2500 = 3 hot-row tiles
-    "hot_many_tiles": (1 << 20, 40000, _hot(0.5, [777777, 12]), False),  # two heavy buckets of ~10000
-    "narrow_dense": (1 << 22, 3000, _narrow(123456, 3000), False), # one wide bucket, ~1900 distinct rows: LSD fallback
+    "hot_many_tiles": (1 << 20, 40000, _hot(0.5, [777777, 12]), True),  # two heavy buckets of ~10000
+    "narrow_dense": (1 << 22, 3000, _narrow(123456, 3000), True), # one wide bucket, ~1900 distinct rows: LSD fallback
     "narrow_fallback": (1 << 20, 1700, _narrow(123456, 1600), True),  # the same at emulator size
-    "narrow_two_buckets": (1 << 22, 1400, _narrow(8192 * 3 - 300, 700), False),  # straddles a bucket boundary
+    "narrow_two_buckets": (1 << 22, 1400, _narrow(8192 * 3 - 300, 700), True),  # straddles a bucket boundary
 }
 
 
@@ -336,8 +336,7 @@ def _plan_shape_case(dev, case, ch=0):
     if dev.type == "cpu" and not on_emu:
         pytest.skip("GPU-only size")
     opt = SparseOptimizerConfig(kind="adagrad", lr=0.05, initial_accumulator_value=0.1)
-    if dev.type == "cpu" and (ch == 512 or (ch and case != "hot_multi_tile")):
-        pytest.skip("the emulator runs the 1024 chunk on one case only")
+
     spec = [("t_a", rows, 16 if rows < (1 << 20) else 4, "sum", ["c0"]), ("t_small", 40, 16, "sum", ["c1"])]
     # hot rows sum thousands of random-sign gradients: order-of-summation noise as in test_backward_long_runs
     rtol = 5e-4 if case.startswith(("hot", "zipf")) else 2e-5

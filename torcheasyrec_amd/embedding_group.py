@@ -483,14 +483,19 @@ class TrainPipeline:
         return losses, predictions, batch
 
 
-def _batch_tensors(b: Batch):
-    """Every tensor of a batch in a fixed order (for slot-to-slot copies of same-shape batches)."""
+def _batch_tensors(b: Batch, skip_constant: bool = True):
+    """Every tensor of a batch that changes from batch to batch, in a fixed order (for slot-to-slot copies of
+    same-shape batches)."""
     out = []
     for g in sorted(b.dense_features):
         out.append(b.dense_features[g].values())
     for g in sorted(b.sparse_features):
         k = b.sparse_features[g]
-        out += [t for t in (k.values(), k.lengths_or_none(), k.weights_or_none(), k.offsets_or_none()) if t is not None]
+        # one id per bag (Criteo): the lengths are all ones and the offsets unused -- constant across batches, so
+        # they stay in the slot and never cross PCIe again (6.8 of 24.4 MB per step at B = 65 536)
+        const_lengths = skip_constant and k.uniform_length() == 1
+        out += [t for t in (k.values(), None if const_lengths else k.lengths_or_none(), k.weights_or_none(),
+                            None if const_lengths else k.offsets_or_none()) if t is not None]
     for n in sorted(b.labels):
         out.append(b.labels[n])
     for n in sorted(b.sample_weights):
