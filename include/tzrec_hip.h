@@ -209,6 +209,32 @@ int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int64_t* d_blo
                            const int64_t* d_values, int64_t* d_out_ids, int64_t* d_unbucketize,
                            int64_t* d_counts, void* ws, size_t ws_bytes, void* stream);
 
+/* Capacity-bounded form of the same (the reference's input dist is torchrec's KJTAllToAll reached
+ * from TrainPipelineSparseDist, tzrec/utils/dist_util.py:221-303, whose split sizes cross the host every step):
+ * every destination rank owns a FIXED slice of `d_message`, so the ids all-to-all has equal splits known
+ * without reading anything back, and the whole sharded step keeps static shapes.
+ *   S = tzr_exchange_message_stride(n_sel, capacity) = n_sel + 1 + capacity   (int64 words per destination)
+ *   d_message[d*S + f']          ids of selected key f' sent to rank d (clamped to what fits)
+ *   d_message[d*S + n_sel]       1 if this rank had to DROP ids for any destination, else 0
+ *   d_message[d*S + n_sel+1 ..]  the ids, grouped by key, lookup order inside a key
+ *   d_unbucketize[N']            position (in words from the start of d_message) of every lookup's id; a
+ *                                dropped lookup points at its destination's first id slot
+ * A step whose overflow word is set anywhere must be redone through the exact exchange (the caller checks the
+ * flag tzr_exchange_owner_segments returns before it uses anything computed from the message). */
+int64_t tzr_exchange_message_stride(int n_sel, int64_t capacity);
+int tzr_exchange_bucketize_capped(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
+                                  const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
+                                  const int64_t* d_values, int64_t capacity, int64_t* d_message,
+                                  int64_t* d_unbucketize, void* ws, size_t ws_bytes, void* stream);
+/* Owner side: the received message (W slices of S words, source-rank major) -> key segments over its W*S
+ * positions for tzr_rows_gather / tzr_pooled_bwd_plan / _apply (ids pointer = d_message itself):
+ *   key s*(n_sel+1)          dead (the words before rank s's ids: unused capacity of rank s-1 + the header)
+ *   key s*(n_sel+1) + 1 + f' the ids of selected key f' from rank s
+ *   key W*(n_sel+1)          dead (unused capacity of the last rank)
+ * d_key_start: int64[W*(n_sel+1) + 2].  *d_overflow = 1 when any source rank dropped ids. */
+int tzr_exchange_owner_segments(const int64_t* d_message, int W, int n_sel, int64_t capacity,
+                                int64_t* d_key_start, int64_t* d_overflow, void* stream);
+
 /* ---- pooled embedding lookup ------------------------------------------------------------- */
 
 /* K5 (+K8 fused): pooled gather forward.  Replaces torchrec EmbeddingBagCollection.forward ->
@@ -281,7 +307,8 @@ int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables, const int64_t*
 
 /* Owner side forward: out[j, 0:dim] = W_{table of key(j)}[ids[j], :] for j in [0, n_ids); ids
  * arrive grouped by key, key k owning positions d_key_start[k] .. d_key_start[k+1] (device,
- * int64[n_keys+1]); d_key_table[k] indexes d_tables.  Replaces the per-shard TBE lookup of
+ * int64[n_keys+1]); d_key_table[k] indexes d_tables (< 0: a dead key, its output rows are left
+ * untouched).  Replaces the per-shard TBE lookup of
  * torchrec's row-wise sharded EBC [upstream]; one row per id instead of a pooled partial per bag. */
 int tzr_rows_gather(const TzrTable* d_tables, const int32_t* d_key_table,
                     const int64_t* d_key_start, int n_keys, const int64_t* d_ids, int64_t n_ids,
@@ -453,7 +480,13 @@ int tzr_delta_count(const uint32_t* d_bitmap, int64_t rows, int64_t* d_total, vo
 int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int clear,
                       int64_t* d_out_ids, int64_t capacity, void* ws, size_t ws_bytes, void* stream);
 
-/* Tuning knobs for experiments (fwd_tile_b, ...); returns TZR_ERR_INVALID for unknown names. */
+/* Process-wide knobs; returns TZR_ERR_INVALID for unknown names.
+ *   fwd_tile_b          samples per workgroup of the pooled forward (0 = by problem size)
+ *   bwd_ch              lookups per chunk of the backward plan: 256 / 512 / 768 / 1024 (0 = by problem size)
+ *   bwd_force_prep      1: geometry prologue as its own launch (the > 1024 features path)
+ *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per
+ *                       1024-lookup tile.  Same plan, slower under heavy skew.  Set it when plans are built on a
+ *                       stream other than the one the rest of the step runs on (NOTES.md, "Side-stream plan"). */
 int tzr_tune(const char* name, int value);
 
 /* ---- feature interaction ----------------------------------------------------------------- */

@@ -24,6 +24,7 @@ def run(iters, dbg, B=65536, seed=0, variant=0):
     ebc = EmbeddingBagCollection([EmbeddingBagConfig(f"t{i}", 16, r, [k]) for i, (r, k) in enumerate(zip(rows, keys))],
                                  device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=lr))
     rng = np.random.default_rng(seed)
+    _lib.lib().tzr_tune(b"bwd_one_wg_heavy", int(os.environ.get("TZR_ONE_WG_HEAVY", "0")))
     bad = 0
     import time
     t0 = time.time()

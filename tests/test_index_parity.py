@@ -163,3 +163,81 @@ def test_exchange_bucketize_equals_permute_then_bucketize(dev, W, hashed):
     assert torch.equal(unb, want_unb)
     off = want.offsets()
     assert torch.equal(cnt, off[B::B] - off[:-1:B])
+
+
+def _capped_message_from_dense(ids, unb, cnt, W, F, cap):
+    """numpy restatement of the capacity-bounded layout (include/tzrec_hip.h: tzr_exchange_bucketize_capped) from the
+    dense bucketize result: per destination the clamped counts, the overflow word, the first `cap` ids."""
+    S = F + 1 + cap
+    msg = np.full(W * S, -7, dtype=np.int64)  # -7: words the kernel must leave alone
+    cnt = cnt.reshape(W, F)
+    start = np.concatenate([[0], np.cumsum(cnt.reshape(-1))])
+    over = int((cnt.sum(1) > cap).any())
+    new_pos = np.empty(len(ids), dtype=np.int64)
+    for d in range(W):
+        run = 0
+        for f in range(F):
+            keep = min(int(cnt[d, f]), cap - run)
+            msg[d * S + f] = keep
+            s0 = start[d * F + f]
+            msg[d * S + F + 1 + run: d * S + F + 1 + run + keep] = ids[s0:s0 + keep]
+            new_pos[s0:s0 + keep] = d * S + F + 1 + run + np.arange(keep)
+            new_pos[s0 + keep:s0 + int(cnt[d, f])] = d * S + F  # dropped
+            run += keep
+        msg[d * S + F] = over
+    return msg, new_pos[unb], over
+
+
+@pytest.mark.parametrize("W,cap,hashed", [(1, 4000, False), (4, 2000, False), (4, 700, False), (8, 100, True), (3, 1, False)])
+def test_exchange_bucketize_capped(dev, W, cap, hashed):
+    """Fixed-capacity message layout = the dense bucketize re-laid per destination; overflow clamps and flags;
+    the owner-side segments kernel turns the received headers into key segments with dead gaps."""
+    rng = np.random.default_rng(W * 5 + cap)
+    F, B = 3, 1100
+    rows = [1000, 17, 40_000_000, 300, 9]
+    keys = [f"k{i}" for i in range(5)]
+    vals = np.stack([rng.integers(0, rows[f], size=B) for f in range(5)]).astype(np.int64)
+    if hashed:
+        vals[1] = rng.integers(-(1 << 62), 1 << 62, size=B)
+    kjt = KeyedJaggedTensor(keys, torch.from_numpy(vals.reshape(-1).copy()), torch.ones(5 * B, dtype=torch.int32), uniform_length=1).to(dev)
+    sel = [3, 1, 2]
+    block = np.array([(rows[f] + W - 1) // W for f in sel], dtype=np.int64)
+    if hashed:
+        block[1] = 0
+    rot = np.array([1 % W, 0, (W - 1)], dtype=np.int32)
+    d_blk, d_rot = torch.from_numpy(block).to(dev), torch.from_numpy(rot).to(dev)
+    L = _lib.lib()
+    n = F * B
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    unb = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(W * F, dtype=torch.int64, device=dev)
+    ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, W), dev)
+    d_sel = torch.tensor(sel, dtype=torch.int32, device=dev)
+    _lib.check(L.tzr_exchange_bucketize(_lib.ptr(d_sel), F, _lib.ptr(d_blk), _lib.ptr(d_rot), B, 1, W, _lib.ptr(kjt.values()),
+                                        _lib.ptr(out), _lib.ptr(unb), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+               "tzr_exchange_bucketize")
+    S = L.tzr_exchange_message_stride(F, cap)
+    assert S == F + 1 + cap
+    want_msg, want_unb, want_over = _capped_message_from_dense(out.cpu().numpy(), unb.cpu().numpy(), cnt.cpu().numpy(), W, F, cap)
+    msg = torch.full((W * S,), -7, dtype=torch.int64, device=dev)
+    unb2 = torch.empty(n, dtype=torch.int64, device=dev)
+    _lib.check(L.tzr_exchange_bucketize_capped(_lib.ptr(d_sel), F, _lib.ptr(d_blk), _lib.ptr(d_rot), B, 1, W, _lib.ptr(kjt.values()),
+                                               cap, _lib.ptr(msg), _lib.ptr(unb2), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+               "tzr_exchange_bucketize_capped")
+    assert np.array_equal(msg.cpu().numpy(), want_msg)
+    assert np.array_equal(unb2.cpu().numpy(), want_unb)
+    assert want_over == int(cap in (700, 100, 1))  # the cases meant to overflow do
+    # owner side (a world where every rank sent this very message): key segments + the flag
+    ks = torch.full((W * (F + 1) + 2,), -1, dtype=torch.int64, device=dev)
+    flag = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    _lib.check(L.tzr_exchange_owner_segments(_lib.ptr(msg), W, F, cap, _lib.ptr(ks), _lib.ptr(flag), _lib.stream_ptr(dev)),
+               "tzr_exchange_owner_segments")
+    ks, m = ks.cpu().numpy(), want_msg
+    assert int(flag.item()) == want_over
+    assert ks[0] == 0 and ks[-1] == W * S and np.all(np.diff(ks) >= 0)
+    for s in range(W):
+        run = s * S + F + 1
+        for f in range(F):
+            assert ks[s * (F + 1) + 1 + f] == run
+            run += m[s * S + f]
+        assert ks[(s + 1) * (F + 1)] == run  # the next dead key starts where this rank's ids end

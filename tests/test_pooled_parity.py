@@ -344,6 +344,17 @@ def _plan_shape_case(dev, case, ch=0):
                        idgen=(lambda rng, r, n: idgen(rng, r, n) if (idgen and r == rows) else rng.integers(0, r, size=n)))
 
 
+@pytest.mark.parametrize("case", ["hot_multi_tile", "hot_many_tiles", "zipf_mid_table", "narrow_dense", "hot_two_in_bucket"])
+def test_backward_plan_one_workgroup_heavy(dev, case):
+    """tzr_tune("bwd_one_wg_heavy"): heavy buckets by one workgroup each (the setting for plans built on another stream)"""
+    from torcheasyrec_amd import _lib
+    assert _lib.lib().tzr_tune(b"bwd_one_wg_heavy", 1) == 0
+    try:
+        _plan_shape_case(dev, case)
+    finally:
+        _lib.lib().tzr_tune(b"bwd_one_wg_heavy", 0)
+
+
 def test_backward_plan_shared_jagged_hot(dev):
     """two keys share a bucketed table, jagged bags, a hot row: table-major regrouping + bag_of + heavy"""
     opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.02)

@@ -22,7 +22,7 @@ from conftest import emu_heavy  # noqa: E402
 sys.path.insert(0, os.path.dirname(__file__))
 
 
-def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, planner=False):
+def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, planner=False, exchange="exact"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     from oracle import tzrec_oracle as orc
@@ -52,7 +52,11 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
                             sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
     else:
         model = ShardedDLRM(tables, keys, NUM_DENSE, device=dev, dp_max_rows=100, constraints={"cat_1_emb": "table_wise"},
-                            sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr))
+                            sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=lr),
+                            exchange="exact" if exchange == "exact" else "capacity",
+                            capacity_factor=0.5 if exchange == "overflow" else 1.5)
+        if exchange == "overflow":  # no slack: some destination gets more than half the even share
+            model.ebc.capacity_slack = 0
     kinds = {n: p["sharding_type"] for n, p in model.ebc.plan().items()}
     assert "data_parallel" in kinds.values() and kinds["cat_1_emb"] == "table_wise"
     assert len(model.ebc.plan()["cat_1_emb"]["ranks"]) == 1
@@ -88,12 +92,21 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
         ts = ShardedTrainStep(model, _NoOpt())
         loss = ts.step(dense, kjt, label, next_kjt=kjt)
         assert ts._ahead is not None and "recv_ids" in ts._ahead[1]  # next batch's input dist already ran
+        n_dist = 2
         logits = ts._seg[Bl].logits
     else:
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
         loss.backward()
         model.allreduce_dense_grads()
+        n_dist = 1
+    stats = model.ebc.exchange_stats
+    if mode == "jagged" or exchange == "exact":  # ragged / weighted bags always take the exact exchange
+        assert stats == {"capacity_batches": 0, "overflow_retries": 0}
+    elif exchange == "capacity":
+        assert stats == {"capacity_batches": n_dist, "overflow_retries": 0}
+    else:  # every rank saw the overflow word and redid the batch through the exact exchange
+        assert stats == {"capacity_batches": 0, "overflow_retries": n_dist}
 
     # ---- oracle on this rank's samples (full tables) ----
     full = []
@@ -156,6 +169,18 @@ def test_sharded_dlrm_world2(emu_path, mode, via_step, planner):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
         mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step, planner), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,mode,via_step,exchange", [(2, "uniform1", False, "capacity"), (2, "uniform1", True, "capacity"),
+                                                          (2, "uniform1", False, "overflow"), (2, "uniform1", True, "overflow"),
+                                                          (4, "uniform1", True, "capacity"), (4, "uniform1", False, "overflow"),
+                                                          (2, "jagged", False, "capacity")])
+def test_sharded_dlrm_capacity_exchange(emu_path, world, mode, via_step, exchange):
+    """Capacity-bounded exchange (fixed message slices, one ids all-to-all, no counts through the host): same
+    logits / gradients / shards as the unsharded oracle; a batch that does not fit is redone exactly by all ranks."""
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step, False, exchange), nprocs=world, join=True)
 
 
 def test_row_wise_plan_spreads_small_tables():

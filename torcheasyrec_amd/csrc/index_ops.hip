@@ -370,11 +370,16 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_count_kernel(
   if ((int)threadIdx.x < W) tile_cnt[((size_t)f * tiles + blockIdx.x) * W + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// exclusive prefix in (dest, key, tile) order, in place; cnt_out[dest*F + f] = ids of key f for dest
+// exclusive prefix in (dest, key, tile) order, in place; cnt_out[dest*F + f] = ids of key f for dest.
+// S > 0 (capacity-bounded exchange): dest d owns the fixed slice [d*S, (d+1)*S) of the message -- F counts,
+// one overflow word, then at most S - F - 1 ids.  Counts are clamped to what fits (the scatter drops the
+// rest) and every destination is told whether this rank dropped anything for anybody.
 __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __restrict__ tile_cnt, int F, int tiles, int W,
-                                                                 int64_t* __restrict__ cnt_out) {
+                                                                 int64_t* __restrict__ cnt_out, int64_t S) {
   __shared__ int64_t seg_tot[XB_THREADS];
   __shared__ int64_t seg_base[XB_THREADS];
+  __shared__ int64_t seg_keep[XB_THREADS];
+  __shared__ int dropped;
   // one (dest, key) segment per thread (W * F <= XB_THREADS, checked by the launcher)
   const int s = threadIdx.x;
   const int nseg = W * F;
@@ -382,20 +387,36 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __rest
   if (s < nseg) {
     const int d = s / F, f = s % F;
     for (int t = 0; t < tiles; ++t) tot += tile_cnt[((size_t)f * tiles + t) * W + d];
-    cnt_out[s] = tot;
+    if (S == 0) cnt_out[s] = tot;
   }
   seg_tot[s] = s < nseg ? tot : 0;
   __syncthreads();
   if (s == 0) {
     int64_t run = 0;
+    int over = 0;
     for (int k = 0; k < nseg; ++k) {
+      if (S > 0 && k % F == 0) run = (int64_t)(k / F) * S + F + 1;
       seg_base[k] = run;
-      run += seg_tot[k];
+      int64_t keep = seg_tot[k];
+      if (S > 0) {
+        const int64_t room = (int64_t)(k / F + 1) * S - run;
+        if (keep > room) {
+          keep = room;
+          over = 1;
+        }
+      }
+      seg_keep[k] = keep;
+      run += keep;
     }
+    dropped = over;
   }
   __syncthreads();
   if (s < nseg) {
     const int d = s / F, f = s % F;
+    if (S > 0) {
+      cnt_out[(int64_t)d * S + f] = seg_keep[s];
+      if (f == 0) cnt_out[(int64_t)d * S + F] = dropped;
+    }
     int64_t run = seg_base[s];
     for (int t = 0; t < tiles; ++t) {
       int32_t* p = tile_cnt + ((size_t)f * tiles + t) * W + d;
@@ -409,7 +430,8 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __rest
 __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scatter_kernel(
     const int32_t* __restrict__ sel, const int64_t* __restrict__ block_sizes,
     const int32_t* __restrict__ rank_offsets, int W, int64_t n_per_key, const int64_t* __restrict__ values,
-    const int32_t* __restrict__ tile_base, int64_t* __restrict__ out_ids, int64_t* __restrict__ unbucketize) {
+    const int32_t* __restrict__ tile_base, int64_t* __restrict__ out_ids, int64_t* __restrict__ unbucketize,
+    int64_t S, int F) {
   __shared__ int run[64];                              // ids of each dest placed by earlier rounds / waves
   __shared__ int wcnt[XB_THREADS / TZR_WAVE][64];
   const int f = blockIdx.y;
@@ -450,8 +472,9 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scatter_kernel(
     if (valid) {
       int pre = run[d];
       for (int w = 0; w < wv; ++w) pre += wcnt[w][d];
-      const int64_t pos = (int64_t)tb[d] + pre + rank;
-      out_ids[pos] = id - r * bs;
+      int64_t pos = (int64_t)tb[d] + pre + rank;
+      if (S > 0 && pos >= (int64_t)(d + 1) * S) pos = (int64_t)d * S + F;  // over capacity: dropped (flagged by the scan)
+      else out_ids[pos] = id - r * bs;
       unbucketize[(int64_t)f * n_per_key + (i - key_base)] = pos;
     }
     __syncthreads();
@@ -472,17 +495,21 @@ extern "C" size_t tzr_exchange_bucketize_workspace(int n_sel, int64_t n_per_key,
   return tzr_align_up((size_t)std::max<int64_t>(1, (int64_t)n_sel * tiles * W) * sizeof(int32_t)) + 256;
 }
 
-extern "C" int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
-                                      const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
-                                      const int64_t* d_values, int64_t* d_out_ids, int64_t* d_unbucketize,
-                                      int64_t* d_counts, void* ws, size_t ws_bytes, void* stream) {
+static int xb_launch(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes, const int32_t* d_rank_offsets,
+                     int64_t B, int bag_len, int W, const int64_t* d_values, int64_t* d_out_ids,
+                     int64_t* d_unbucketize, int64_t* d_counts, int64_t S, void* ws, size_t ws_bytes, void* stream) {
   if (!d_sel || n_sel <= 0 || !d_block_sizes || B < 0 || bag_len <= 0 || W <= 0 || !d_counts)
     return TZR_ERR_INVALID;
   if (W > 64 || (int64_t)W * n_sel > XB_THREADS) return TZR_ERR_UNSUPPORTED;
   const int64_t n_per_key = B * bag_len;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_per_key == 0) {
-    if (hipMemsetAsync(d_counts, 0, (size_t)W * n_sel * 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    if (S == 0) {
+      if (hipMemsetAsync(d_counts, 0, (size_t)W * n_sel * 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    } else {
+      for (int d = 0; d < W; ++d)
+        if (hipMemsetAsync(d_counts + (int64_t)d * S, 0, (size_t)(n_sel + 1) * 8, s) != hipSuccess) return TZR_ERR_LAUNCH;
+    }
     return TZR_OK;
   }
   if (!d_values || !d_out_ids || !d_unbucketize) return TZR_ERR_INVALID;
@@ -491,12 +518,85 @@ extern "C" int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int
     return TZR_ERR_WORKSPACE;
   const int64_t tiles = (n_per_key + XB_TILE - 1) / XB_TILE;
   if (tiles > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;
+  if (S > 0 && (int64_t)W * S > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;  // tile starts are 32-bit positions
   int32_t* tile_cnt = static_cast<int32_t*>(ws);
   hipLaunchKernelGGL(tzr_xb_count_kernel, dim3((unsigned)tiles, (unsigned)n_sel), dim3(XB_THREADS), 0, s, d_sel,
                      d_block_sizes, d_rank_offsets, W, n_per_key, d_values, tile_cnt);
-  hipLaunchKernelGGL(tzr_xb_scan_kernel, dim3(1), dim3(XB_THREADS), 0, s, tile_cnt, n_sel, (int)tiles, W, d_counts);
+  hipLaunchKernelGGL(tzr_xb_scan_kernel, dim3(1), dim3(XB_THREADS), 0, s, tile_cnt, n_sel, (int)tiles, W, d_counts, S);
   hipLaunchKernelGGL(tzr_xb_scatter_kernel, dim3((unsigned)tiles, (unsigned)n_sel), dim3(XB_THREADS), 0, s, d_sel,
-                     d_block_sizes, d_rank_offsets, W, n_per_key, d_values, tile_cnt, d_out_ids, d_unbucketize);
+                     d_block_sizes, d_rank_offsets, W, n_per_key, d_values, tile_cnt, d_out_ids, d_unbucketize, S,
+                     n_sel);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+extern "C" int tzr_exchange_bucketize(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
+                                      const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
+                                      const int64_t* d_values, int64_t* d_out_ids, int64_t* d_unbucketize,
+                                      int64_t* d_counts, void* ws, size_t ws_bytes, void* stream) {
+  return xb_launch(d_sel, n_sel, d_block_sizes, d_rank_offsets, B, bag_len, W, d_values, d_out_ids, d_unbucketize,
+                   d_counts, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int64_t tzr_exchange_message_stride(int n_sel, int64_t capacity) {
+  if (n_sel <= 0 || capacity < 0) return 0;
+  return (int64_t)n_sel + 1 + capacity;
+}
+
+extern "C" int tzr_exchange_bucketize_capped(const int32_t* d_sel, int n_sel, const int64_t* d_block_sizes,
+                                             const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
+                                             const int64_t* d_values, int64_t capacity, int64_t* d_message,
+                                             int64_t* d_unbucketize, void* ws, size_t ws_bytes, void* stream) {
+  if (capacity <= 0 || !d_message) return TZR_ERR_INVALID;
+  const int64_t S = tzr_exchange_message_stride(n_sel, capacity);
+  return xb_launch(d_sel, n_sel, d_block_sizes, d_rank_offsets, B, bag_len, W, d_values, d_message, d_unbucketize,
+                   d_message, S, ws, ws_bytes, stream);
+}
+
+// Owner side of the capacity-bounded exchange: the W received message slices -> key segments over the
+// positions [0, W*S) of the received buffer.  Per source rank s: one dead key (the gap before its ids: the
+// previous rank's unused capacity + this slice's header), then its n_sel keys; a last dead key closes the
+// buffer.  *d_overflow = 1 if any rank reported dropped ids (or a header is not a valid count list).
+__global__ __launch_bounds__(64) void tzr_xb_owner_segments_kernel(const int64_t* __restrict__ msg, int W, int F,
+                                                                   int64_t S, int64_t* __restrict__ key_start,
+                                                                   int64_t* __restrict__ overflow) {
+  __shared__ int64_t s_end[64];
+  __shared__ int s_over;
+  const int s = threadIdx.x;
+  if (s == 0) s_over = 0;
+  __syncthreads();
+  int64_t run = (int64_t)s * S + F + 1;
+  if (s < W) {
+    const int64_t* h = msg + (int64_t)s * S;
+    int bad = h[F] != 0;
+    for (int f = 0; f < F; ++f) {
+      int64_t c = h[f];
+      const int64_t room = (int64_t)(s + 1) * S - run;
+      if (c < 0 || c > room) {
+        c = c < 0 ? 0 : room;
+        bad = 1;
+      }
+      key_start[(int64_t)s * (F + 1) + 1 + f] = run;
+      run += c;
+    }
+    s_end[s] = run;
+    if (bad) atomicOr(&s_over, 1);
+  }
+  __syncthreads();
+  if (s < W) key_start[(int64_t)s * (F + 1)] = s == 0 ? 0 : s_end[s - 1];
+  if (s == 0) {
+    key_start[(int64_t)W * (F + 1)] = s_end[W - 1];
+    key_start[(int64_t)W * (F + 1) + 1] = (int64_t)W * S;
+    *overflow = s_over;
+  }
+}
+
+extern "C" int tzr_exchange_owner_segments(const int64_t* d_message, int W, int n_sel, int64_t capacity,
+                                           int64_t* d_key_start, int64_t* d_overflow, void* stream) {
+  if (!d_message || W <= 0 || n_sel <= 0 || capacity <= 0 || !d_key_start || !d_overflow) return TZR_ERR_INVALID;
+  if (W > 64) return TZR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(tzr_xb_owner_segments_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_message,
+                     W, n_sel, tzr_exchange_message_stride(n_sel, capacity), d_key_start, d_overflow);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
 // bucket.
 #define BWD_SCAN_BATCH 64
 __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __restrict__ tables,
-                                                              int T, BwdPlan P) {
+                                                              int T, int one_wg_heavy, BwdPlan P) {
   __shared__ unsigned tot[BWD_NB];
   const int t = blockIdx.x;
   const int c0 = P.tab_chunk[t];
@@ -374,7 +374,8 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
     // ... unless one row holds nearly all of such a bucket (the clipped Zipf tail, a default id:
     // tens of thousands of lookups): tile-parallel again, splitting around that row (hot items).
     const bool one_pass = khi - klo <= (uint64_t)BWD_NB;
-    const bool tiled = one_pass || run > BWD_HT;
+    // (one_wg_heavy: every heavy bucket by ONE workgroup -- tzr_tune("bwd_one_wg_heavy"), see NOTES.md)
+    const bool tiled = !one_wg_heavy && (one_pass || run > BWD_HT);
     const uint32_t tiles = tiled ? (run + BWD_HT - 1) / BWD_HT : 1u;
     const uint32_t slot = atomicAdd(P.hcount, tiles);
     for (uint32_t i = 0; i < tiles; ++i) {
@@ -558,10 +559,10 @@ __device__ __forceinline__ void bwd_sort_core(uint32_t (&kreg)[MAXR], uint32_t (
         if ((vmask >> r) & 1u) {
           const uint32_t at = S.gstart[dig[r]] + dest[r];
           S.pk[at] = kreg[r];
-          S.ps[at] = sreg[r];
+          S.ps[at] = (uint32_t)(wv * pw + r * TZR_WAVE + lane);  // arrival (= table-major) position
         }
       __syncthreads();
-      // rank inside the group by (row id, lookup position): the groups of a thread's elements are walked
+      // rank inside the group by (row id, arrival position): the groups of a thread's elements are walked
       // together, member j of every group per step, so the LDS reads of one step are independent
       uint32_t lo[MAXR], len[MAXR];
       uint32_t steps = 0;
@@ -580,7 +581,7 @@ __device__ __forceinline__ void bwd_sort_core(uint32_t (&kreg)[MAXR], uint32_t (
         for (int r = 0; r < MAXR; ++r)
           if (j < len[r]) {
             const uint32_t kj = S.pk[lo[r] + j], sj = S.ps[lo[r] + j];
-            dest[r] += (kj < kreg[r] || (kj == kreg[r] && sj < sreg[r])) ? 1u : 0u;
+            dest[r] += (kj < kreg[r] || (kj == kreg[r] && sj < (uint32_t)(wv * pw + r * TZR_WAVE + lane))) ? 1u : 0u;
           }
       }
 #pragma unroll
@@ -1099,6 +1100,7 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_
 
 int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO geometry path
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
+int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
                                    const TzrFeature* d_feats, int n_feats, int n_keys,
@@ -1138,7 +1140,8 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
     hipLaunchKernelGGL(tzr_bwd_hist_kernel<true>, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                        n_tables, n_feats, A, P);
   }
-  hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, d_tables, n_tables, P);
+  hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, d_tables, n_tables,
+                     g_tzr_bwd_one_wg_heavy, P);
   hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                      n_tables, A, P);
   const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);

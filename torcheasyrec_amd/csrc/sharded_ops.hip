@@ -26,7 +26,27 @@ struct ShKey {  // resolved key segment on the owner
   int32_t pad;
 };
 
-// out[j, :] = W_{table(key(j))}[ids[j], :] for j in [0, n): key(j) = segment of key_start holding j.
+__device__ __forceinline__ void sh_resolve_key(const TzrTable* __restrict__ tables, int t, ShKey* e) {
+  if (t < 0) {  // dead key
+    e->w = nullptr;
+    e->w_dtype = 0;
+    e->rows = 0;
+    e->w_stride = 0;
+    e->dim = -1;
+    e->pad = 0;
+    return;
+  }
+  const TzrTable tb = tables[t];
+  e->w = reinterpret_cast<const void*>(tb.w);
+  e->w_dtype = tb.w_dtype;
+  e->rows = tb.rows;
+  e->w_stride = tb.w_stride;
+  e->dim = tb.dim;
+  e->pad = 0;
+}
+
+// out[j, :] = W_{table(key(j))}[ids[j], :] for j in [0, n): key(j) = segment of key_start holding j
+// (key_table[k] < 0: a dead key, its positions are left untouched).
 __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
     const TzrTable* __restrict__ tables, const int32_t* __restrict__ key_table,
     const int64_t* __restrict__ key_start, int n_keys, const int64_t* __restrict__ ids, int64_t n,
@@ -41,13 +61,8 @@ __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
   const bool staged = k1 - k0 < SH_MAXKEYS;
   if (staged) {
     for (int k = k0 + threadIdx.x; k <= k1; k += SH_THREADS) {
-      const TzrTable tb = tables[key_table[k]];
       ShKey e;
-      e.w = reinterpret_cast<const void*>(tb.w);
-      e.w_dtype = tb.w_dtype;
-      e.rows = tb.rows;
-      e.w_stride = tb.w_stride;
-      e.dim = tb.dim;
+      sh_resolve_key(tables, key_table[k], &e);
       s_key[k - k0] = e;
       s_start[k - k0] = key_start[k];
     }
@@ -67,13 +82,9 @@ __global__ __launch_bounds__(SH_THREADS) void tzr_rows_gather_kernel(
       }
       e = s_key[a];
     } else {
-      const TzrTable tb = tables[key_table[tzr_last_le(key_start, n_keys, j)]];
-      e.w = reinterpret_cast<const void*>(tb.w);
-      e.w_dtype = tb.w_dtype;
-      e.rows = tb.rows;
-      e.w_stride = tb.w_stride;
-      e.dim = tb.dim;
+      sh_resolve_key(tables, key_table[tzr_last_le(key_start, n_keys, j)], &e);
     }
+    if (e.dim < 0) continue;  // dead key: positions nobody reads (capacity-bounded exchange)
     int64_t id = ids[j];
     if ((uint64_t)id >= (uint64_t)e.rows) id = 0;
     float4 v = tzr_zero4();

@@ -6,6 +6,7 @@
 extern int g_tzr_fwd_tile_b;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
+extern int g_tzr_bwd_one_wg_heavy;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
@@ -15,6 +16,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_ch")) {
     g_tzr_bwd_ch = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_one_wg_heavy")) {
+    g_tzr_bwd_one_wg_heavy = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_force_prep")) {

@@ -60,6 +60,12 @@ class ShardedTrainStep:
         self._seg: Dict[int, _Segment] = {}
         self._seen: Dict[int, int] = {}
         self._side = torch.cuda.Stream(self.device) if self.cuda else None
+        if self.cuda and plan_ahead:
+            # plans built on the side stream: tile-parallel heavy buckets misbehaved there (NOTES.md, "Side-stream
+            # plan"), one workgroup per heavy bucket did not -- process-wide, this process plans through this step
+            from . import _lib
+
+            _lib.check(_lib.lib().tzr_tune(b"bwd_one_wg_heavy", 1), "tzr_tune")
         self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
 
     # -- dense segment ---------------------------------------------------------------------------

@@ -152,8 +152,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
         plan: Optional[Dict[str, dict]] = None,
         out_keys: Optional[Dict[Tuple[str, str], str]] = None,
         out_dims: Optional[Dict[str, int]] = None,
+        exchange: str = "exact",
+        capacity_factor: float = 1.25,
     ) -> None:
-        """`out_keys[(feature, table)]`: name of that lookup's pooled block in `groups` (default: the
+        """`exchange`: "exact" = split sizes through the host every step (counts all-to-all, D2H, sync);
+        "capacity" = fixed slices of `capacity_factor` x the even share per destination, no read-back on the way
+        (`input_dist_begin`), a batch that does not fit is redone through the exact exchange before anything
+        uses it.  `out_keys[(feature, table)]`: name of that lookup's pooled block in `groups` (default: the
         feature name); `out_dims[block]`: width of blocks of `groups` that OTHER collections fill in the
         same output buffers (`MixedShardedEmbeddingBagCollection`: one collection per embedding dim)."""
         super().__init__()
@@ -228,7 +233,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._groups = groups
         self._hook = torch.zeros(0, requires_grad=True, device=self._device)
         self._req_meta: Dict[Tuple, dict] = {}
-        self._own_meta: Optional[dict] = None
+        self._own_meta: Dict[bool, dict] = {}
+        if exchange not in ("exact", "capacity"):
+            raise ValueError(f"exchange = {exchange!r}: 'exact' or 'capacity'")
+        self.exchange = exchange
+        self.capacity_factor = float(capacity_factor)
+        self.capacity_slack = 64  # ids on top of factor x even share (small batches are lumpy)
+        self.exchange_stats = {"capacity_batches": 0, "overflow_retries": 0}
         self._rows_buf: Dict[int, tuple] = {}
         self._timers = None
         # set by ShardedManagedCollisionEmbeddingBagCollection: tables whose raw ids are routed by hash
@@ -365,18 +376,25 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self._req_meta[ck] = m
         return m
 
-    def _owner_meta(self, key_table: np.ndarray) -> dict:
-        """Descriptors of the owner side: W*F received keys (source-major), key (s, f) -> table."""
-        if self._own_meta is not None:
-            return self._own_meta
+    def _owner_meta(self, key_table: np.ndarray, capped: bool = False) -> dict:
+        """Descriptors of the owner side: W*F received keys (source-major), key (s, f) -> table.
+        `capped`: the key list of the capacity-bounded message (`tzr_exchange_owner_segments`): per source
+        rank one dead key (table -1) ahead of its F keys, one more dead key at the end."""
+        hit = self._own_meta.get(capped)
+        if hit is not None:
+            return hit
         F, W, T = len(key_table), self.W, len(self._rw)
-        K = W * F
+        if capped:
+            kt = np.concatenate([np.concatenate([[-1], key_table]) for _ in range(W)] + [[-1]]).astype(np.int32)
+        else:
+            kt = np.tile(key_table, W).astype(np.int32)
+        K = len(kt)
+        real = np.nonzero(kt >= 0)[0]
         base = self.local._meta([lk.key for lk in self.local._lookups], self.local._default_layout())
         tables = base.tables_np.copy()
         feats = np.zeros(K, dtype=_lib.FEATURE_DT)
         feats["dst"] = -1
-        kt = np.tile(key_table, W).astype(np.int32)
-        order = np.lexsort((np.arange(K), kt))  # table-major order of the received keys
+        order = np.lexsort((np.arange(K), np.where(kt >= 0, kt, T)))  # table-major order of the received keys, dead last
         rank_of = np.empty(K, dtype=np.int32)
         rank_of[order] = np.arange(K, dtype=np.int32)
         feats["table"], feats["key"], feats["order"] = kt, np.arange(K, dtype=np.int32), rank_of
@@ -386,19 +404,22 @@ class ShardedEmbeddingBagCollection(nn.Module):
             tables[t]["n_feats"] = len(mine)
         frozen = [not c.trainable for c in self.local.embedding_bag_configs()]
         bwd_tables, bwd_feats = tables, feats
-        if any(frozen):
+        if any(frozen) or capped:
             from .embedding import mask_frozen_descriptors
 
             bwd_tables, bwd_feats = mask_frozen_descriptors(tables, feats, frozen)
-        self._own_meta = {
+        names = [c.name for c in self._rw]
+        hit = {
             "d_tables": _lib.upload_struct(tables, self._device),
             "d_feats": _lib.upload_struct(feats, self._device),
             "d_bwd_tables": _lib.upload_struct(bwd_tables, self._device),
             "d_bwd_feats": _lib.upload_struct(bwd_feats, self._device),
             "d_key_table": torch.from_numpy(kt).to(self._device), "K": K, "T": T,
             "max_rows": int(max(c.num_embeddings for c in self.local.embedding_bag_configs())),
+            "track_segs": tuple((names[int(kt[k])], int(k)) for k in real),
         }
-        return self._own_meta
+        self._own_meta[capped] = hit
+        return hit
 
     def _recv_rows_buffer(self, n: int, n_lookups: int):
         """Persistent [n, D] buffer for the rows coming back from their owners plus the one-table
@@ -431,16 +452,50 @@ class ShardedEmbeddingBagCollection(nn.Module):
     #   input_dist_begin  bucketize by owner, exchange the per-(rank, key) counts, start their D2H copy
     #   input_dist_end    wait for the counts (the one host sync of a step), ids all-to-all
     #   lookup            owner row gather, rows all-to-all, pooled gather into the output buffers
-    def input_dist_begin(self, kjt: KeyedJaggedTensor, dst_names) -> dict:
+    def exchange_capacity(self, n_keys: int, B: int) -> int:
+        """ids one rank may send to one destination per batch in the capacity-bounded exchange"""
+        total = n_keys * B
+        return max(1, min(total, int(np.ceil(self.capacity_factor * total / self.W)) + self.capacity_slack))
+
+    def input_dist_begin(self, kjt: KeyedJaggedTensor, dst_names, exact: bool = False) -> dict:
         dev, W = self._device, self.W
         layout = self._layout_for(dst_names)
         rm = self._requester_meta(kjt.keys(), layout)
-        st = {"kjt": kjt, "rm": rm, "uniform": kjt.uniform_length() == 1}
+        st = {"kjt": kjt, "rm": rm, "uniform": kjt.uniform_length() == 1, "dst_names": dst_names}
+        lean = "rw_n" in rm and st["uniform"] and kjt.weights_or_none() is None and W <= 64 and W * rm["rw_n"] <= 256
+        if lean and self.exchange == "capacity" and not exact and self._owner_remap is None and kjt.stride() > 0:
+            # fixed slices: ONE all-to-all carries counts, overflow word and ids; nothing is read back here
+            L = _lib.lib()
+            B, F = kjt.stride(), rm["rw_n"]
+            N, C = F * B, self.exchange_capacity(rm["rw_n"], kjt.stride())
+            S = int(L.tzr_exchange_message_stride(F, C))
+            msg = torch.empty(2, W * S, dtype=torch.int64, device=dev)  # [0] what I send, [1] what I receive
+            unb = torch.empty(N, dtype=torch.int64, device=dev)
+            ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, W), dev)
+            _lib.check(L.tzr_exchange_bucketize_capped(_lib.ptr(rm["rw_sel"]), F, _lib.ptr(rm["rw_blk"]), _lib.ptr(rm["rw_rot"]), B, 1, W,
+                                                       _lib.ptr(kjt.values()), C, _lib.ptr(msg[0]), _lib.ptr(unb), _lib.ptr(ws),
+                                                       ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
+            self._a2a(msg[1], msg[0], None, None)
+            seg = torch.empty(W * (F + 1) + 3, dtype=torch.int64, device=dev)  # key starts, then the overflow word
+            _lib.check(L.tzr_exchange_owner_segments(_lib.ptr(msg[1]), W, F, C, _lib.ptr(seg), _lib.ptr(seg[-1:]),
+                                                     _lib.stream_ptr(dev)), "tzr_exchange_owner_segments")
+            if dev.type == "cuda":
+                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                host.copy_(seg[-1:], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                st["flag_event"] = ev
+            else:
+                host = seg[-1:]
+            st.update({"cap": C, "sub": None, "N_rw": N, "N_pad": W * S, "unb": unb, "msg": msg, "recv_ids": msg[1],
+                       "key_start": seg[:-1], "n_recv": W * S, "send_splits": None, "recv_splits": None,
+                       "om": self._owner_meta(rm["rw_key_table"], capped=True), "flag_host": host})
+            return st
         if "rw_n" in rm:
             B = kjt.stride()
             F = rm["rw_n"]
             cnt = torch.empty(2, W * F, dtype=torch.int64, device=dev)  # [0] ids I send per (dest, key); [1] ids I receive
-            if st["uniform"] and kjt.weights_or_none() is None and W <= 64 and W * F <= 256:
+            if lean:
                 # one id per bag, no weights: the lean 3-launch bucketize on the selected keys (no K1
                 # permute, no W*F*B bag lengths); same outputs as the general path below
                 L = _lib.lib()
@@ -474,6 +529,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
 
     def input_dist_end(self, st: dict) -> dict:
         rm, dev, W = st["rm"], self._device, self.W
+        if "cap" in st and "flag_host" in st:
+            # the overflow word is the same on every rank (each slice carries its sender's, the owner kernel ORs
+            # all W of them), so all ranks redo the batch together.  Under a pipeline this event was recorded a
+            # batch ago: no wait.
+            if "flag_event" in st:
+                st.pop("flag_event").synchronize()
+            over = int(st.pop("flag_host").item())
+            if over:
+                self.exchange_stats["overflow_retries"] += 1
+                return self.input_dist_end(self.input_dist_begin(st["kjt"], st["dst_names"], exact=True))
+            self.exchange_stats["capacity_batches"] += 1
+            return st
         if "rw_n" in rm and "recv_ids" not in st:
             if "counts_event" in st:
                 st["counts_event"].synchronize()  # host sync: all-to-all split sizes live on the host
@@ -538,17 +605,15 @@ class ShardedEmbeddingBagCollection(nn.Module):
         # ZCH tables: raw id -> row through the owner's map first
         st["owner_ids"] = st["recv_ids"] if self._owner_remap is None else self._owner_remap(st)
         if self._lookup_trackers and n_recv > 0:
-            if "track_segs" not in om:
-                names = [c.name for c in self._rw]
-                om["track_segs"] = tuple((names[t], k) for k, t in enumerate(np.tile(st["rm"]["rw_key_table"], self.W).tolist()))
             for fn in self._lookup_trackers:
                 fn(self, om["track_segs"], st["owner_ids"], st["key_start"], 1, 0)
         rows_out = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
         _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
                                      om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(rows_out), D, D,
                                      _lib.stream_ptr(dev)), "tzr_rows_gather")
-        rows_in, d_pt = self._recv_rows_buffer(N, F)
-        work = self._a2a(rows_in[:N], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
+        n_back = st.get("N_pad", N)  # capacity-bounded: rows come back in the fixed slices the ids left in
+        rows_in, d_pt = self._recv_rows_buffer(n_back, F)
+        work = self._a2a(rows_in[:n_back], rows_out[:n_recv], st["send_splits"], st["recv_splits"], async_op=True)
         return rows_in, d_pt, work
 
     # K6 depends on ids only: a pipeline may run both plans right after the input dist, one batch
@@ -585,6 +650,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         return st
 
     def _forward_impl(self, kjt: KeyedJaggedTensor, dst_names):
+        # (a lone forward checks the overflow word right away: the same host wait the exact exchange has)
         st = self.input_dist_end(self.input_dist_begin(kjt, dst_names))
         return self.lookup(st), st
 
@@ -619,15 +685,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
             om, sub, n_recv = st["om"], st["sub"], st["n_recv"]
             N, F = st["N_rw"], rm["rw_n"]
             # requester: one gradient row per id, in bucketized order -> to the owners
+            n_out = st.get("N_pad", N)
             if id_grads is not None:
+                if n_out != N:
+                    raise ValueError("per-id gradients go through the exact exchange")
                 grow = id_grads
             else:
-                grow = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+                grow = torch.empty(max(n_out, 1), D, dtype=torch.float32, device=dev)
                 _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(None if uniform else sub.offsets()),
                                               _lib.ptr(None if sub is None else sub.weights_or_none()), B, 1 if uniform else 0, _lib.ptr(st["unb"]),
                                               gd, len(gl), _lib.ptr(grow), D, D, stream), "tzr_lookup_grads")
             grecv = torch.empty(max(n_recv, 1), D, dtype=torch.float32, device=dev)
-            w_rows = self._a2a(grecv[:n_recv], grow[:N], st["recv_splits"], st["send_splits"], async_op=True)
+            w_rows = self._a2a(grecv[:n_recv], grow[:n_out], st["recv_splits"], st["send_splits"], async_op=True)
         if "dp_n" in rm:
             # replicas: exact per-row gradient sums of my samples -> all-reduce -> same dense update
             N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
@@ -699,7 +768,7 @@ class ShardedDLRM(nn.Module):
                  arch_with_sparse=True, device=None, sparse_optimizer=None, row_layout="interleaved",
                  process_group=None, dp_max_rows: int = 65536, replicate_at_world1: bool = False,
                  constraints: Optional[Dict[str, str]] = None, tw_max_rows: int = 0,
-                 plan: Optional[Dict[str, dict]] = None) -> None:
+                 plan: Optional[Dict[str, dict]] = None, exchange: str = "exact", capacity_factor: float = 1.25) -> None:
         super().__init__()
         self.pg = process_group
         self.dim = tables[0].embedding_dim
@@ -708,7 +777,8 @@ class ShardedDLRM(nn.Module):
         self.ebc = ShardedEmbeddingBagCollection(
             tables, device=device, optimizer=sparse_optimizer, groups={"sparse": list(sparse_features)},
             row_layout=row_layout, process_group=process_group, dp_max_rows=dp_max_rows,
-            replicate_at_world1=replicate_at_world1, constraints=constraints, tw_max_rows=tw_max_rows, plan=plan)
+            replicate_at_world1=replicate_at_world1, constraints=constraints, tw_max_rows=tw_max_rows, plan=plan,
+            exchange=exchange, capacity_factor=capacity_factor)
         self.dense_mlp = MLP(dense_dim, dense_mlp).to(device)
         n = self.num_sparse + 1
         feat = n * (n - 1) // 2 + self.dim + (self.num_sparse * self.dim if arch_with_sparse else 0)
@@ -818,7 +888,7 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
                  groups: Optional[Dict[str, List[str]]] = None, row_layout: str = "interleaved",
                  process_group: Optional[dist.ProcessGroup] = None, dp_max_rows: int = 65536,
                  constraints: Optional[Dict[str, str]] = None, tw_max_rows: int = 0,
-                 plan: Optional[Dict[str, dict]] = None) -> None:
+                 plan: Optional[Dict[str, dict]] = None, exchange: str = "exact", capacity_factor: float = 1.25) -> None:
         super().__init__()
         self.pg = process_group
         self.W, self.rank = dist.get_world_size(self.pg), dist.get_rank(self.pg)
@@ -938,7 +1008,8 @@ class MixedShardedEmbeddingBagCollection(nn.Module):
             self.lanes.append(ShardedEmbeddingBagCollection(
                 lane, device=self._device, optimizer=optimizer, groups=g, row_layout=row_layout, process_group=self.pg,
                 plan={n: p for n, p in v_plan.items() if n in names},
-                out_keys={k: v for k, v in v_out_keys.items() if k[1] in names}, out_dims=out_dims))
+                out_keys={k: v for k, v in v_out_keys.items() if k[1] in names}, out_dims=out_dims,
+                exchange=exchange, capacity_factor=capacity_factor))
         self.fused_optimizer = self.lanes[0].fused_optimizer
         for lane in list(self.lanes)[1:]:  # one lr handle drives every lane
             if lane.fused_optimizer is not None:
