@@ -73,6 +73,13 @@ def parse_args():
                     help="sharded runs: keep the backward index plans (K6) on the main stream instead of one batch ahead")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="sharded runs: do not run the next batch's input dist ahead on the side stream")
+    ap.add_argument("--exchange", choices=["exact", "capacity"], default="exact",
+                    help="sharded runs: 'capacity' = fixed-size message slices (one ids all-to-all, no counts through the "
+                         "host); a batch that overflows is redone through the exact exchange")
+    ap.add_argument("--capacity-factor", type=float, default=1.25)
+    ap.add_argument("--step-graph", action="store_true",
+                    help="sharded runs with --exchange capacity: everything after the input dist (lookup, collectives, dense "
+                         "segment, sparse + dense optimizers) as ONE hipGraph per pipeline slot")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -264,8 +271,9 @@ def main():
         from torcheasyrec_amd.sharding import ShardedDLRM
 
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
-                            row_layout=args.row_layout, replicate_at_world1=args.replicate_small)
-        parallelism = model.describe()
+                            row_layout=args.row_layout, replicate_at_world1=args.replicate_small,
+                            exchange=args.exchange, capacity_factor=args.capacity_factor)
+        parallelism = model.describe() + (f"; exchange: {args.exchange}" + (f" x{args.capacity_factor}" if args.exchange == "capacity" else ""))
     delta_tracker = None
     if args.delta_tracker:  # what train_config.delta_embedding_dump_config adds to a step (never part of the default line)
         from torcheasyrec_amd.delta_embedding_dump import ModelDeltaTracker
@@ -313,7 +321,7 @@ def main():
         from torcheasyrec_amd.sharded_step import ShardedTrainStep
 
         train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
-                                      plan_ahead=not args.no_plan_ahead)
+                                      plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph)
 
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:
@@ -331,7 +339,8 @@ def main():
     # initialisation and tuning out of the way, so at least two eager steps run even for --warmup 0/1
     # (untimed, like the requested ones)
     loss = None
-    for i in range(max(args.warmup, 3 if train_step is not None else (2 if use_graph else 0))):  # 3: the pipelined step captures on its 3rd call
+    # 3: the pipelined step captures on its 3rd call; 6: the two pipeline slots of --step-graph each capture on their 3rd
+    for i in range(max(args.warmup, (6 if args.step_graph else 3) if train_step is not None else (2 if use_graph else 0))):
         loss = step_body(*batches[i % nb])
     torch.cuda.synchronize()
 
@@ -491,8 +500,13 @@ def main():
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if graphs is not None else
-                   ("pipelined: input dist one batch ahead + hipGraph dense segment" if train_step is not None else "eager")),
+                   (("pipelined: input dist one batch ahead + ONE hipGraph for the rest of the step" if args.step_graph else
+                     "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }
+    if sharded:
+        out["exchange"] = dict(model.ebc.exchange_stats, kind=args.exchange)
+        if train_step is not None and args.step_graph:
+            out["exchange"].update(graph_steps=train_step.graph_steps, eager_steps=train_step.eager_steps)
     if rank == 0 and world == 1:
         ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]
         fwd_b = float(np.mean([a["fwd"] for a in ab]))

@@ -31,6 +31,18 @@ def emu_path():
     return build()
 
 
+@pytest.fixture(autouse=True)
+def _default_knobs():
+    """tzr_tune knobs are process-wide (ShardedTrainStep sets bwd_one_wg_heavy for its side-stream plans): every
+    test starts from the defaults of whichever library is loaded."""
+    yield
+    from torcheasyrec_amd import _lib
+
+    if _lib._lib is not None:
+        for name in (b"fwd_tile_b", b"bwd_ch", b"bwd_force_prep", b"bwd_one_wg_heavy"):
+            _lib.lib().tzr_tune(name, 0)
+
+
 @pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
 def dev(request):
     from torcheasyrec_amd import _lib

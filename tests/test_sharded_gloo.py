@@ -89,11 +89,18 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
             def step(self):
                 pass
 
-        ts = ShardedTrainStep(model, _NoOpt())
+        whole = exchange != "exact" and mode == "uniform1"  # the whole-step path (one hipGraph per slot on a GPU)
+        ts = ShardedTrainStep(model, _NoOpt(), step_graph=exchange != "exact")
         loss = ts.step(dense, kjt, label, next_kjt=kjt)
         assert ts._ahead is not None and "recv_ids" in ts._ahead[1]  # next batch's input dist already ran
         n_dist = 2
-        logits = ts._seg[Bl].logits
+        if exchange == "capacity" and whole:
+            assert (ts.graph_steps, ts.eager_steps) == (1, 0)
+            assert ts._ahead[1]["slot_key"][0] == 1  # the next batch sits in the other slot
+            logits = ts._slots[(0, tuple(keys), Bl)]["logits"]
+        else:
+            assert ts.graph_steps == 0
+            logits = ts._seg[Bl].logits
     else:
         logits = model(dense, kjt)
         loss = bce_with_logits(logits, label)
@@ -965,3 +972,61 @@ def test_sharded_dlrm_more_ranks(emu_path, world, mode, via_step, planner):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
         mp.spawn(_worker, args=(world, init_file, emu_path, mode, d, via_step, planner), nprocs=world, join=True)
+
+
+def _slots_worker(rank, world, init_file, emu_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.criteo import NUM_DENSE, criteo_tables, synthetic_batch
+    from torcheasyrec_amd.dense import FusedDenseAdam
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+    from torcheasyrec_amd.sharded_step import ShardedTrainStep
+    from torcheasyrec_amd.sharding import ShardedDLRM
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    rows = [5000, 300, 3, 4, 17, 1000, 2, 64]
+    keys = [f"cat_{i}" for i in range(len(rows))]
+    Bg, steps = 32 * world, 6
+    Bl = Bg // world
+    batches = []
+    for s in range(steps):
+        dense, kjt, label = synthetic_batch(10 + s, Bg, rows)
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        v = kjt.values().view(len(rows), Bg)[:, sl].reshape(-1).contiguous()
+        if s == 3:  # one lumpy batch: every id of the big table in rank 0's block -> over capacity -> exact retry
+            v.view(len(rows), Bl)[0] = torch.arange(Bl) % 100
+            v.view(len(rows), Bl)[5] = torch.arange(Bl) % 50
+            v.view(len(rows), Bl)[1] = torch.arange(Bl) % 30
+        batches.append((dense[sl].contiguous(), KeyedJaggedTensor(keys, v, torch.ones(len(rows) * Bl, dtype=torch.int32), uniform_length=1),
+                        label[sl].contiguous()))
+    runs = {}
+    for name, kw, skw in (("exact", {}, {}), ("capacity", {"exchange": "capacity", "capacity_factor": 1.3}, {"step_graph": True})):
+        torch.manual_seed(7)
+        model = ShardedDLRM(criteo_tables(rows, init="seeded"), keys, NUM_DENSE, device=dev, dp_max_rows=100,
+                            sparse_optimizer=SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05), **kw)
+        model.ebc.capacity_slack = 8
+        ts = ShardedTrainStep(model, FusedDenseAdam(list(model.dense_parameters()), lr=1e-2), **skw)
+        losses = [float(ts.step(*batches[i], next_kjt=batches[i + 1][1] if i + 1 < steps else None)) for i in range(steps)]
+        runs[name] = (losses, {n: w.detach().clone() for n, w in model.ebc.table_weights().items()},
+                      [p.detach().clone() for p in model.dense_parameters()], dict(model.ebc.exchange_stats), ts.graph_steps, ts.eager_steps)
+    (la, wa, da, _, _, _), (lb, wb, db, stats, n_graph, n_eager) = runs["exact"], runs["capacity"]
+    assert stats["overflow_retries"] == 1 and stats["capacity_batches"] == steps - 1, stats
+    assert (n_graph, n_eager) == (steps - 1, 1)
+    assert la == lb  # same kernels on the same rows in the same order: bit for bit
+    for n in wa:
+        assert torch.equal(wa[n], wb[n]), n
+    for a, b in zip(da, db):
+        assert torch.equal(a, b)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_whole_step_slots_equal_the_exact_pipeline(emu_path):
+    """Six steps through the two pipeline slots of the whole-step path (capacity-bounded exchange, static buffers,
+    one overflowing batch redone exactly) = the exact pipelined step, bit for bit: losses, table shards, dense weights."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_slots_worker, args=(world, os.path.join(d, "init"), emu_path), nprocs=world, join=True)

@@ -198,3 +198,51 @@ def test_sharded_zch_world1_matches_unsharded_zch():
                 torch.testing.assert_close(b.sharded.table_weights()[n], w, rtol=1e-6, atol=1e-7, msg=n)
         finally:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [2048, 8192])
+def test_whole_step_graph_world1(B):
+    """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
+    all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
+    pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
+    from torcheasyrec_amd.dense import FusedDenseAdam
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+    from torcheasyrec_amd.sharded_step import ShardedTrainStep
+    from torcheasyrec_amd.sharding import ShardedDLRM
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    work = torch.cuda.Stream(dev)
+    with tempfile.TemporaryDirectory() as d, torch.cuda.stream(work):
+        dist.init_process_group("nccl", init_method=f"file://{d}/init", rank=0, world_size=1, device_id=dev)
+        try:
+            rows = [min(r, 50000) for r in CRITEO_ROWS]
+            opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05)
+            steps = 10
+            batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows)) for s in range(steps)]
+            out = {}
+            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True})):
+                torch.manual_seed(3)
+                m = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt,
+                                dp_max_rows=4096, replicate_at_world1=True, **kw)
+                ts = ShardedTrainStep(m, FusedDenseAdam(list(m.dense_parameters()), lr=1e-2), use_graph=True, **skw)
+                losses = []
+                for s, (dense, kjt, label) in enumerate(batches):
+                    losses.append(ts.step(dense, kjt, label, next_kjt=batches[s + 1][1] if s + 1 < steps else None).clone())
+                torch.cuda.synchronize()
+                out[name] = (torch.stack(losses).cpu(), [p.detach().clone() for p in m.dense_parameters()],
+                             {n: w.detach().clone() for n, w in m.ebc.table_weights().items()}, ts, m)
+            ts, m = out["graph"][3], out["graph"][4]
+            assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
+            assert ts.graph_steps == steps and ts.eager_steps == 0
+            assert all(sl["graph"] is not None for sl in ts._slots.values()) and len(ts._slots) == 2
+            assert torch.equal(out["exact"][0], out["graph"][0])
+            for a, b in zip(out["exact"][1], out["graph"][1]):
+                assert torch.equal(a, b)
+            for n, w in out["exact"][2].items():
+                assert torch.equal(w, out["graph"][2][n]), n
+        finally:
+            dist.destroy_process_group()

@@ -23,6 +23,13 @@ is cut along the data-dependent boundary:
 
 Weights are only read by `lookup`, which runs after the previous step's sparse update on the same
 stream, so prefetching the input dist changes no value (tests/test_sharded_gloo.py runs both ways).
+
+`step_graph=True` (with `ShardedEmbeddingBagCollection(exchange="capacity")`): the capacity-bounded exchange
+has fixed split sizes, so everything after the input dist -- lookup with its rows all-to-all, dense segment,
+gradient all-to-all, sort + fused optimizer, dense all-reduce, Adam -- is captured as ONE hipGraph per
+pipeline slot (two slots: batch i+1 is laid out by its input dist while the graph of batch i runs).  The
+overflow word of a batch is read on the host BEFORE its graph is launched (the input dist ran a batch
+earlier), so a batch that does not fit simply takes the eager exact path; nothing is ever undone.
 """
 from __future__ import annotations
 
@@ -48,7 +55,7 @@ class ShardedTrainStep:
     def __init__(self, model: ShardedDLRM, dense_optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
                  use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2,
-                 plan_ahead: bool = True) -> None:
+                 plan_ahead: bool = True, step_graph: bool = False) -> None:
         self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
         self.device = model.ebc._device
         self.cuda = self.device.type == "cuda"
@@ -67,6 +74,18 @@ class ShardedTrainStep:
 
             _lib.check(_lib.lib().tzr_tune(b"bwd_one_wg_heavy", 1), "tzr_tune")
         self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
+        # whole-step graphs: static inputs + one captured graph per pipeline slot
+        self.step_graph = bool(step_graph)
+        if self.step_graph and model.ebc.exchange != "capacity":
+            raise ValueError("step_graph needs the capacity-bounded exchange (fixed all-to-all split sizes)")
+        self._slots: Dict[tuple, dict] = {}
+        self._next_slot = 0
+        self.graph_steps = self.eager_steps = 0
+        if self.step_graph and model.ebc.input_dist_group is None and model.ebc.W > 1:
+            import torch.distributed as dist
+
+            # the ids all-to-all of batch i+1 runs while the captured collectives of batch i replay: its own communicator
+            model.ebc.input_dist_group = dist.new_group(backend=dist.get_backend(model.ebc.pg))
 
     # -- dense segment ---------------------------------------------------------------------------
     def _dense_fwd_bwd(self, dense, sparse, label):
@@ -111,10 +130,29 @@ class ShardedTrainStep:
         seg.graph.replay()
 
     # -- input dist, possibly one batch ahead ------------------------------------------------------
+    def _static_kjt(self, kjt: KeyedJaggedTensor) -> tuple:
+        """(slot id, KJT over the slot's static id buffer) for a uniform one-id-per-bag batch, else (None, kjt)"""
+        if not self.step_graph or kjt.uniform_length() != 1 or kjt.weights_or_none() is not None:
+            return None, kjt
+        k = self._next_slot
+        self._next_slot ^= 1
+        key = (k, tuple(kjt.keys()), kjt.stride())
+        sl = self._slots.get(key)
+        if sl is None:
+            vals = torch.empty_like(kjt.values(), device=self.device)
+            sl = {"kjt": KeyedJaggedTensor(list(kjt.keys()), vals, kjt.lengths().to(self.device).clone(), uniform_length=1),
+                  "graph": None, "seen": 0, "dense": None, "label": None}
+            self._slots[key] = sl
+        sl["kjt"].values().copy_(kjt.values(), non_blocking=True)
+        return key, sl["kjt"]
+
     def _begin(self, kjt: KeyedJaggedTensor, after: Optional["torch.cuda.Event"] = None) -> dict:
         ebc = self.model.ebc
         if not self.cuda:
-            return ebc.input_dist_begin(kjt, ("sparse",))
+            key, skjt = self._static_kjt(kjt)
+            st = ebc.input_dist_begin(skjt, ("sparse",), slot=None if key is None else key[0])
+            st["slot_key"] = key
+            return st
         # the ids must exist before the side stream reads them: either everything queued on the main
         # stream so far, or (prefetch) just the point where this step started -- NOT the step's own
         # work, or the prefetch would queue behind the dense segment it is meant to overlap
@@ -123,7 +161,10 @@ class ShardedTrainStep:
         else:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
-            return ebc.input_dist_begin(kjt, ("sparse",))
+            key, skjt = self._static_kjt(kjt)
+            st = ebc.input_dist_begin(skjt, ("sparse",), slot=None if key is None else key[0])
+            st["slot_key"] = key
+            return st
 
     def _end(self, st: dict) -> dict:
         ebc = self.model.ebc
@@ -169,6 +210,10 @@ class ShardedTrainStep:
             st = self._end(self._begin(kjt))
         self._ahead = None
         self._consume(st)
+        if self.step_graph and "cap" in st and st.get("slot_key") is not None:
+            return self._step_whole(st, dense, label, next_kjt, t0)
+        if self.step_graph:
+            self.eager_steps += 1
         seg = self._segment(dense, label, st["rm"]["widths"][0])
         ebc.lookup(st, [seg.sparse.detach()])
         self._run_dense(seg, dense, label)
@@ -182,3 +227,47 @@ class ShardedTrainStep:
         if pending is not None:
             self._ahead = (next_kjt, self._end(pending))
         return seg.loss
+
+    # -- whole-step graph ------------------------------------------------------------------------------
+    def _body(self, st: dict, sl: dict) -> None:
+        """everything of a step after the input dist, on static buffers only"""
+        model, ebc = self.model, self.model.ebc
+        ebc.lookup(st, [sl["sparse"].detach()])
+        sl["loss"], sl["logits"], grads = self._dense_fwd_bwd(sl["dense"], sl["sparse"], sl["label"])
+        ebc.backward(st, [grads[0]])
+        pg = list(grads[1:])
+        model.allreduce_dense_grads(pg)
+        for p, g in zip(self.params, pg):
+            p.grad = g
+        self.opt.step()
+
+    def _step_whole(self, st: dict, dense, label, next_kjt, t0) -> torch.Tensor:
+        sl = self._slots[st["slot_key"]]
+        if sl["dense"] is None:
+            sl["dense"], sl["label"] = torch.empty_like(dense, device=self.device), torch.empty_like(label, device=self.device)
+            sl["sparse"] = torch.zeros(dense.shape[0], st["rm"]["widths"][0], dtype=torch.float32, device=self.device, requires_grad=True)
+        sl["dense"].copy_(dense, non_blocking=True)
+        sl["label"].copy_(label, non_blocking=True)
+        if not (self.use_graph and self.cuda):
+            self._body(st, sl)
+        elif sl["graph"] is None:
+            sl["seen"] += 1
+            if sl["seen"] <= self.warmup_iters:  # eager: lazy inits / RCCL channel setup must not happen under capture
+                self._body(st, sl)
+            else:
+                cur = torch.cuda.current_stream(self.device)
+                if cur == torch.cuda.default_stream(self.device):
+                    raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
+                                       "non-default stream (torch.cuda.set_stream)")
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cur):
+                    self._body(st, sl)
+                sl["graph"], sl["st"] = g, st  # the captured kernels read this state's buffers: keep them alive
+                g.replay()
+        else:
+            sl["graph"].replay()
+        self.graph_steps += 1
+        if next_kjt is not None and self.prefetch:
+            self._ahead = (next_kjt, self._end(self._begin(next_kjt, t0)))
+        return sl["loss"]
+

@@ -240,6 +240,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self.capacity_factor = float(capacity_factor)
         self.capacity_slack = 64  # ids on top of factor x even share (small batches are lumpy)
         self.exchange_stats = {"capacity_batches": 0, "overflow_retries": 0}
+        self.input_dist_group = None  # process group of the ids all-to-all (default: `process_group`); a step captured
+        #                               in a hipGraph replays its collectives while the next batch's input dist runs
+        self._slot_bufs: Dict[Tuple, dict] = {}
         self._rows_buf: Dict[int, tuple] = {}
         self._timers = None
         # set by ShardedManagedCollisionEmbeddingBagCollection: tables whose raw ids are routed by hash
@@ -457,11 +460,29 @@ class ShardedEmbeddingBagCollection(nn.Module):
         total = n_keys * B
         return max(1, min(total, int(np.ceil(self.capacity_factor * total / self.W)) + self.capacity_slack))
 
-    def input_dist_begin(self, kjt: KeyedJaggedTensor, dst_names, exact: bool = False) -> dict:
+    def _slot(self, slot, what: str, shape, dtype, pinned: bool = False) -> torch.Tensor:
+        """Persistent buffer `what` of pipeline slot `slot` (None: a fresh tensor).  A captured step reads the
+        input dist's products at fixed addresses; two slots alternate so batch i+1 is laid out while i runs."""
+        if slot is None:
+            return torch.empty(shape, dtype=dtype, pin_memory=True) if pinned else torch.empty(shape, dtype=dtype, device=self._device)
+        key = (slot, what, tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),), dtype)
+        hit = self._slot_bufs.get(key)
+        if hit is None:
+            hit = torch.empty(shape, dtype=dtype, pin_memory=True) if pinned else torch.empty(shape, dtype=dtype, device=self._device)
+            self._slot_bufs[key] = hit
+        return hit
+
+    def _slot_workspace(self, slot, what: str, nbytes: int) -> torch.Tensor:
+        if slot is None:
+            return _lib.workspace(nbytes, self._device)
+        t = self._slot(slot, what, int(nbytes) + 256, torch.uint8)
+        return t[(-t.data_ptr()) % 256:]
+
+    def input_dist_begin(self, kjt: KeyedJaggedTensor, dst_names, exact: bool = False, slot=None) -> dict:
         dev, W = self._device, self.W
         layout = self._layout_for(dst_names)
         rm = self._requester_meta(kjt.keys(), layout)
-        st = {"kjt": kjt, "rm": rm, "uniform": kjt.uniform_length() == 1, "dst_names": dst_names}
+        st = {"kjt": kjt, "rm": rm, "uniform": kjt.uniform_length() == 1, "dst_names": dst_names, "slot": slot}
         lean = "rw_n" in rm and st["uniform"] and kjt.weights_or_none() is None and W <= 64 and W * rm["rw_n"] <= 256
         if lean and self.exchange == "capacity" and not exact and self._owner_remap is None and kjt.stride() > 0:
             # fixed slices: ONE all-to-all carries counts, overflow word and ids; nothing is read back here
@@ -469,18 +490,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
             B, F = kjt.stride(), rm["rw_n"]
             N, C = F * B, self.exchange_capacity(rm["rw_n"], kjt.stride())
             S = int(L.tzr_exchange_message_stride(F, C))
-            msg = torch.empty(2, W * S, dtype=torch.int64, device=dev)  # [0] what I send, [1] what I receive
-            unb = torch.empty(N, dtype=torch.int64, device=dev)
+            msg = self._slot(slot, "msg", (2, W * S), torch.int64)  # [0] what I send, [1] what I receive
+            unb = self._slot(slot, "unb", N, torch.int64)
             ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, W), dev)
             _lib.check(L.tzr_exchange_bucketize_capped(_lib.ptr(rm["rw_sel"]), F, _lib.ptr(rm["rw_blk"]), _lib.ptr(rm["rw_rot"]), B, 1, W,
                                                        _lib.ptr(kjt.values()), C, _lib.ptr(msg[0]), _lib.ptr(unb), _lib.ptr(ws),
                                                        ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
-            self._a2a(msg[1], msg[0], None, None)
-            seg = torch.empty(W * (F + 1) + 3, dtype=torch.int64, device=dev)  # key starts, then the overflow word
+            dist.all_to_all_single(msg[1], msg[0], group=self.input_dist_group or self.pg)
+            seg = self._slot(slot, "seg", W * (F + 1) + 3, torch.int64)  # key starts, then the overflow word
             _lib.check(L.tzr_exchange_owner_segments(_lib.ptr(msg[1]), W, F, C, _lib.ptr(seg), _lib.ptr(seg[-1:]),
                                                      _lib.stream_ptr(dev)), "tzr_exchange_owner_segments")
             if dev.type == "cuda":
-                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                host = self._slot(slot, "flag", 1, torch.int64, pinned=True)
                 host.copy_(seg[-1:], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
@@ -538,7 +559,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             over = int(st.pop("flag_host").item())
             if over:
                 self.exchange_stats["overflow_retries"] += 1
-                return self.input_dist_end(self.input_dist_begin(st["kjt"], st["dst_names"], exact=True))
+                return self.input_dist_end(self.input_dist_begin(st["kjt"], st["dst_names"], exact=True, slot=st["slot"]))
             self.exchange_stats["capacity_batches"] += 1
             return st
         if "rw_n" in rm and "recv_ids" not in st:
@@ -623,7 +644,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         kjt, rm, uniform = st["kjt"], st["rm"], st["uniform"]
         B, N_all, n_dp, T_dp = kjt.stride(), kjt.values().numel(), rm["dp_n"], len(self._dp)
         NP = n_dp * B if uniform else N_all
-        ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D), dev)
+        ws = self._slot_workspace(st.get("slot") if "cap" in st else None, "ws_dp", L.tzr_pooled_bwd_workspace(N_all, NP, n_dp, T_dp, B, D))
         _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_bwd_feats"]), n_dp,
                                          rm["n_keys"], rm["dp_max_rows"], D, _lib.ptr(kjt.values()),
                                          _lib.ptr(None if uniform else kjt.offsets()), N_all, NP, B, 1 if uniform else 0,
@@ -634,7 +655,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         L, dev, D = _lib.lib(), self._device, self.dim
         om, n_recv = st["om"], st["n_recv"]
         K, T = om["K"], om["T"]
-        ws = _lib.workspace(L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D), dev)
+        ws = self._slot_workspace(st.get("slot") if "cap" in st else None, "ws_rw", L.tzr_pooled_bwd_workspace(n_recv, n_recv, K, T, 1, D))
         _lib.check(L.tzr_pooled_bwd_plan(_lib.ptr(om["d_bwd_tables"]), T, _lib.ptr(om["d_bwd_feats"]), K, K, om["max_rows"], D,
                                          _lib.ptr(st.get("owner_ids", st["recv_ids"])), _lib.ptr(st["key_start"]), n_recv,
                                          n_recv, 1, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
