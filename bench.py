@@ -391,7 +391,7 @@ def main():
         B2 = (args.global_batch if args.scaling == "weak" else args.weak_per_rank_batch * world) if world > 1 else 0
     if B2 and train_step is not None and B2 != B_global and B2 % world == 0:
         b2, _ = make_batches(B2, seed0=1000)
-        for i in range(max(args.warmup, 4)):
+        for i in range(max(args.warmup, 7 if args.step_graph else 4)):
             step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
         torch.cuda.synchronize()
         if world > 1:
