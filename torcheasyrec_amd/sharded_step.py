@@ -27,7 +27,8 @@ stream, so prefetching the input dist changes no value (tests/test_sharded_gloo.
 `step_graph=True` (with `ShardedEmbeddingBagCollection(exchange="capacity")`): the capacity-bounded exchange
 has fixed split sizes, so everything after the input dist -- lookup with its rows all-to-all, dense segment,
 gradient all-to-all, sort + fused optimizer, dense all-reduce, Adam -- is captured as ONE hipGraph per
-pipeline slot (two slots: batch i+1 is laid out by its input dist while the graph of batch i runs).  The
+pipeline slot (two slots: batch i+1 is laid out by its input dist while the graph of batch i runs) -- in
+practice three graphs with the RCCL calls issued eagerly between them (`_step_whole`).  The
 overflow word of a batch is read on the host BEFORE its graph is launched (the input dist ran a batch
 earlier), so a batch that does not fit simply takes the eager exact path; nothing is ever undone.
 """
@@ -228,18 +229,44 @@ class ShardedTrainStep:
             self._ahead = (next_kjt, self._end(pending))
         return seg.loss
 
-    # -- whole-step graph ------------------------------------------------------------------------------
-    def _body(self, st: dict, sl: dict) -> None:
-        """everything of a step after the input dist, on static buffers only"""
-        model, ebc = self.model, self.model.ebc
-        ebc.lookup(st, [sl["sparse"].detach()])
+    # -- whole-step graphs ------------------------------------------------------------------------------
+    # The step after the input dist = three runs of kernels on static buffers (one hipGraph each) with the RCCL
+    # calls between them issued eagerly:
+    #   G0  owner row gather, replicas' pooled lookup
+    #       rows all-to-all
+    #   G1  pooled gather, dense forward + backward, per-id gradient rows, replicas' row sums, dense gradients packed
+    #       gradient all-to-all, all-reduce of the replicas' row sums, all-reduce of the dense gradients
+    #   G2  owners' sort + fused optimizer, replicas' dense row update, dense gradients unpacked, Adam
+    def _seg0(self, st: dict, sl: dict) -> None:
+        self.model.ebc.seg_owner_rows(st, [sl["sparse"].detach()])
+
+    def _seg1(self, st: dict, sl: dict) -> None:
+        from .sharding import pack_dense_grads
+
+        ebc = self.model.ebc
+        ebc.seg_pool(st, [sl["sparse"].detach()])
         sl["loss"], sl["logits"], grads = self._dense_fwd_bwd(sl["dense"], sl["sparse"], sl["label"])
-        ebc.backward(st, [grads[0]])
-        pg = list(grads[1:])
-        model.allreduce_dense_grads(pg)
-        for p, g in zip(self.params, pg):
+        ebc.seg_grads(st, [grads[0]])
+        sl["grads"] = list(grads[1:])
+        sl["flat"] = pack_dense_grads(sl["grads"])
+
+    def _seg2(self, st: dict, sl: dict) -> None:
+        from .sharding import unpack_dense_grads
+
+        self.model.ebc.seg_apply(st)
+        unpack_dense_grads(sl["flat"], sl["grads"])
+        for p, g in zip(self.params, sl["grads"]):
             p.grad = g
         self.opt.step()
+
+    def _coll0(self, st: dict, sl: dict) -> None:
+        self.model.ebc.coll_rows(st)
+
+    def _coll1(self, st: dict, sl: dict) -> None:
+        from .sharding import allreduce_flat_average
+
+        self.model.ebc.coll_grads(st)
+        allreduce_flat_average(sl["flat"], self.model.pg)
 
     def _step_whole(self, st: dict, dense, label, next_kjt, t0) -> torch.Tensor:
         sl = self._slots[st["slot_key"]]
@@ -248,26 +275,33 @@ class ShardedTrainStep:
             sl["sparse"] = torch.zeros(dense.shape[0], st["rm"]["widths"][0], dtype=torch.float32, device=self.device, requires_grad=True)
         sl["dense"].copy_(dense, non_blocking=True)
         sl["label"].copy_(label, non_blocking=True)
-        if not (self.use_graph and self.cuda):
-            self._body(st, sl)
-        elif sl["graph"] is None:
+        segs, colls = (self._seg0, self._seg1, self._seg2), (self._coll0, self._coll1, None)
+        capture = False
+        if self.use_graph and self.cuda and sl["graph"] is None:
             sl["seen"] += 1
-            if sl["seen"] <= self.warmup_iters:  # eager: lazy inits / RCCL channel setup must not happen under capture
-                self._body(st, sl)
-            else:
-                cur = torch.cuda.current_stream(self.device)
-                if cur == torch.cuda.default_stream(self.device):
-                    raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
-                                       "non-default stream (torch.cuda.set_stream)")
+            capture = sl["seen"] > self.warmup_iters  # before: eager (lazy inits, GEMM tuning, RCCL channel setup)
+            if capture and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
+                raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
+                                   "non-default stream (torch.cuda.set_stream)")
+        if capture:
+            sl["st"] = st  # the captured kernels read this state's buffers: keep them alive
+            graphs = []
+        for i, (seg, coll) in enumerate(zip(segs, colls)):
+            if capture:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cur):
-                    self._body(st, sl)
-                sl["graph"], sl["st"] = g, st  # the captured kernels read this state's buffers: keep them alive
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device)):
+                    seg(st, sl)
+                graphs.append(g)
                 g.replay()
-        else:
-            sl["graph"].replay()
+            elif sl["graph"] is not None:
+                sl["graph"][i].replay()
+            else:
+                seg(st, sl)
+            if coll is not None:
+                coll(sl.get("st", st) if sl["graph"] is not None else st, sl)
+        if capture:
+            sl["graph"] = graphs
         self.graph_steps += 1
         if next_kjt is not None and self.prefetch:
             self._ahead = (next_kjt, self._end(self._begin(next_kjt, t0)))
         return sl["loss"]
-

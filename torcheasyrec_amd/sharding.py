@@ -757,6 +757,121 @@ class ShardedEmbeddingBagCollection(nn.Module):
     def _after_backward(self, st: dict) -> None:
         pass
 
+    # -- the step cut at its collectives ---------------------------------------------------------------------
+    # `ShardedTrainStep(step_graph=True)`: every `seg_*` below is kernels on static buffers only (one hipGraph per
+    # run of them), every `coll_*` is the RCCL calls between two such runs, issued eagerly (RCCL kernels captured
+    # into a hipGraph took the process down at hipStreamEndCapture on this stack: profiles/r02p).  Same kernels,
+    # same arguments, same order per table as `lookup` / `_backward_impl`; only the overlap of a collective with the
+    # replicas' kernels is given up.  Capacity-bounded states only (`"cap" in st`).
+    def _dst_array(self, outs: Sequence[torch.Tensor], B: int, widths: Sequence[int]):
+        dsts = (_lib.TzrDst * len(outs))()
+        for i, o in enumerate(outs):
+            if o.shape != (B, widths[i]) or o.stride(1) != 1:
+                raise ValueError("output buffer shape")
+            dsts[i].ptr, dsts[i].stride = _lib.ptr(o), o.stride(0)
+        return dsts
+
+    def seg_owner_rows(self, st: dict, outs: List[torch.Tensor]) -> None:
+        """owner: one row per received id (-> `coll_rows`); replicated tables: pooled straight into `outs`"""
+        L, dev, D = _lib.lib(), self._device, self.dim
+        kjt, rm = st["kjt"], st["rm"]
+        B, stream = kjt.stride(), _lib.stream_ptr(dev)
+        if "rw_n" in rm:
+            om, n_recv = st["om"], st["n_recv"]
+            st["owner_ids"] = st["recv_ids"]
+            for fn in self._lookup_trackers:
+                fn(self, om["track_segs"], st["owner_ids"], st["key_start"], 1, 0)
+            st["rows_out"] = self._slot(st["slot"], "rows_out", (n_recv, D), torch.float32)
+            _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
+                                         om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(st["rows_out"]), D, D, stream),
+                       "tzr_rows_gather")
+        if "dp_n" in rm:
+            if self._lookup_trackers:
+                if "dp_track_segs" not in rm:
+                    index = {k: i for i, k in enumerate(kjt.keys())}
+                    dp = {c.name for c in self._dp}
+                    rm["dp_track_segs"] = tuple((self._global[t].name, index[k]) for k, t, _ in self._lookups if self._global[t].name in dp)
+                for fn in self._lookup_trackers:
+                    fn(self, rm["dp_track_segs"], kjt.values(), None, B, 1)
+            _lib.check(L.tzr_pooled_fwd_ex(_lib.ptr(rm["dp_d_tables"]), _lib.ptr(rm["dp_d_feats"]), rm["dp_n"],
+                                           _lib.ptr(rm["dp_d_slots"]), rm["dp_slots_n"], _lib.ptr(kjt.values()), None,
+                                           None, B, self._dst_array(outs, B, rm["widths"]), len(outs), 1,
+                                           _lib.FWD_MIXED_DTYPE if self.replica._has_fp16 else 0, stream), "tzr_pooled_fwd")
+
+    def coll_rows(self, st: dict) -> None:
+        if "rw_n" in st["rm"]:
+            rows_in, _ = self._recv_rows_buffer(st["N_pad"], st["rm"]["rw_n"])
+            dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg)
+
+    def seg_pool(self, st: dict, outs: List[torch.Tensor]) -> None:
+        """requester: pooled gather over the rows that came back (ids = their positions in the message)"""
+        rm = st["rm"]
+        if "rw_n" in rm:
+            B, F = st["kjt"].stride(), rm["rw_n"]
+            _, d_pt = self._recv_rows_buffer(st["N_pad"], F)
+            _lib.check(_lib.lib().tzr_pooled_fwd(_lib.ptr(d_pt), _lib.ptr(rm["rw_d_feats"]), F, _lib.ptr(rm["rw_d_slots"]),
+                                                 rm["rw_slots_n"], _lib.ptr(st["unb"]), None, None, B,
+                                                 self._dst_array(outs, B, rm["widths"]), len(outs), 1,
+                                                 _lib.stream_ptr(self._device)), "tzr_pooled_fwd")
+
+    def seg_grads(self, st: dict, grads: Sequence[torch.Tensor]) -> None:
+        """requester: one gradient row per id into the message layout (-> `coll_grads`); replicas: row sums"""
+        if self.fused_optimizer is None:
+            return
+        L, dev, D = _lib.lib(), self._device, self.dim
+        self.fused_optimizer.begin_step(dev)
+        kjt, rm = st["kjt"], st["rm"]
+        B, stream = kjt.stride(), _lib.stream_ptr(dev)
+        gl = [g.contiguous().float() for g in grads]
+        st["_grads_alive"] = gl
+        gd = self._dst_array(gl, B, rm["widths"])
+        if "rw_n" in rm:
+            st["grow"] = self._slot(st["slot"], "grow", (st["N_pad"], D), torch.float32)
+            _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), rm["rw_n"], None, None, B, 1, _lib.ptr(st["unb"]), gd, len(gl),
+                                          _lib.ptr(st["grow"]), D, D, stream), "tzr_lookup_grads")
+        if "dp_n" in rm:
+            N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
+            self._dp_acc.zero_()
+            ws = st.get("ws_dp")
+            if ws is None:
+                ws = st["ws_dp"] = self._plan_dp(st)
+            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_bwd_feats"]), n_dp, T_dp, D,
+                                              None, None, N_all, n_dp * B, B, 1, 0, gd, len(gl),
+                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
+                       "tzr_pooled_bwd_apply")
+
+    def coll_grads(self, st: dict) -> None:
+        if self.fused_optimizer is None:
+            return
+        rm = st["rm"]
+        if "rw_n" in rm:
+            st["grecv"] = self._slot(st["slot"], "grecv", (st["n_recv"], self.dim), torch.float32)
+            dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg)
+        if "dp_n" in rm:
+            dist.all_reduce(self._dp_acc, group=self.pg)
+
+    def seg_apply(self, st: dict) -> None:
+        """owner: sort + fused optimizer over the received gradient rows; replicas: the dense row update"""
+        if self.fused_optimizer is None:
+            return
+        L, dev, D = _lib.lib(), self._device, self.dim
+        rm, stream = st["rm"], _lib.stream_ptr(dev)
+        if "rw_n" in rm:
+            om, n_recv = st["om"], st["n_recv"]
+            ws2 = st.get("ws_rw")
+            if ws2 is None:
+                ws2 = st["ws_rw"] = self._plan_rw(st)
+            g1 = (_lib.TzrDst * 1)()
+            g1[0].ptr, g1[0].stride = _lib.ptr(st["grecv"]), st["grecv"].stride(0)
+            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), om["K"], om["T"], D,
+                                              _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
+                                              self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream), "tzr_pooled_bwd_apply")
+        if "dp_n" in rm:
+            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
+                                               self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
+                       "tzr_dense_rows_update")
+        self._after_backward(st)
+
     # -- public API ------------------------------------------------------------------------------
     def forward_grouped(self, features: KeyedJaggedTensor, group_names=None) -> Dict[str, torch.Tensor]:
         names = tuple(group_names) if group_names is not None else tuple(self._groups)
@@ -861,6 +976,22 @@ class ShardedDLRM(nn.Module):
             dist.all_reduce(flat, group=self.pg)
             flat.div_(world)
         torch._foreach_copy_(gs, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in gs]), gs)])
+
+
+def pack_dense_grads(grads: Sequence[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([g.reshape(-1) for g in grads])
+
+
+def allreduce_flat_average(flat: torch.Tensor, process_group=None) -> None:
+    if flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group)
+    else:  # gloo has no AVG
+        dist.all_reduce(flat, group=process_group)
+        flat.div_(dist.get_world_size(process_group))
+
+
+def unpack_dense_grads(flat: torch.Tensor, grads: Sequence[torch.Tensor]) -> None:
+    torch._foreach_copy_(list(grads), [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
 def _column_shards(dim: int, world: int) -> int:
