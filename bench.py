@@ -73,13 +73,15 @@ def parse_args():
                     help="sharded runs: keep the backward index plans (K6) on the main stream instead of one batch ahead")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="sharded runs: do not run the next batch's input dist ahead on the side stream")
-    ap.add_argument("--exchange", choices=["exact", "capacity"], default="exact",
+    ap.add_argument("--exchange", choices=["auto", "exact", "capacity"], default="auto",
                     help="sharded runs: 'capacity' = fixed-size message slices (one ids all-to-all, no counts through the "
-                         "host); a batch that overflows is redone through the exact exchange")
+                         "host); a batch that overflows is redone through the exact exchange.  'auto': capacity + "
+                         "--step-graph when the per-rank batch is <= 16384 (the launch-bound regime: 0.47 vs 0.65 ms at 8192 "
+                         "on the 1-rank proxy, but 1.13 vs 1.09 ms at 65536 -- profiles/r02q), else exact")
     ap.add_argument("--capacity-factor", type=float, default=1.25)
     ap.add_argument("--step-graph", action="store_true",
-                    help="sharded runs with --exchange capacity: everything after the input dist (lookup, collectives, dense "
-                         "segment, sparse + dense optimizers) as ONE hipGraph per pipeline slot")
+                    help="sharded runs with --exchange capacity: everything after the input dist (lookups, dense segment, "
+                         "sparse + dense optimizers) replayed from three hipGraphs per pipeline slot, RCCL calls between them")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -261,6 +263,12 @@ def main():
     rows = [min(r, args.rows_cap) for r in CRITEO_ROWS] if args.rows_cap else list(CRITEO_ROWS)
     B_global = args.global_batch if args.scaling == "strong" else args.global_batch * world
     B_local = B_global // world
+    if args.exchange == "auto":
+        small = sharded and not args.no_pipeline and not args.no_graph and B_local <= 16384
+        args.exchange = "capacity" if small else "exact"
+        args.step_graph = args.step_graph or small
+    if args.step_graph and args.exchange != "capacity":
+        raise SystemExit("--step-graph needs --exchange capacity")
     torch.manual_seed(1234)
     sopt = SparseOptimizerConfig(kind=args.optimizer, lr=1e-3)
     if not sharded:
@@ -500,7 +508,7 @@ def main():
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if graphs is not None else
-                   (("pipelined: input dist one batch ahead + ONE hipGraph for the rest of the step" if args.step_graph else
+                   (("pipelined: input dist one batch ahead + three hipGraphs for the rest of the step, RCCL calls between them" if args.step_graph else
                      "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }
     if sharded:
