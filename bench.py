@@ -347,8 +347,8 @@ def main():
     # initialisation and tuning out of the way, so at least two eager steps run even for --warmup 0/1
     # (untimed, like the requested ones)
     loss = None
-    # 3: the pipelined step captures on its 3rd call; 6: the two pipeline slots of --step-graph each capture on their 3rd
-    for i in range(max(args.warmup, (6 if args.step_graph else 3) if train_step is not None else (2 if use_graph else 0))):
+    # 3: the pipelined step captures on its 3rd call; 10: the two pipeline slots of --step-graph capture on their 3rd (step) and 4th (input dist) visits
+    for i in range(max(args.warmup, (10 if args.step_graph else 3) if train_step is not None else (2 if use_graph else 0))):
         loss = step_body(*batches[i % nb])
     torch.cuda.synchronize()
 
@@ -399,7 +399,7 @@ def main():
         B2 = (args.global_batch if args.scaling == "weak" else args.weak_per_rank_batch * world) if world > 1 else 0
     if B2 and train_step is not None and B2 != B_global and B2 % world == 0:
         b2, _ = make_batches(B2, seed0=1000)
-        for i in range(max(args.warmup, 7 if args.step_graph else 4)):
+        for i in range(max(args.warmup, 10 if args.step_graph else 4)):
             step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
         torch.cuda.synchronize()
         if world > 1:

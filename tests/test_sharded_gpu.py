@@ -221,7 +221,7 @@ def test_whole_step_graph_world1(B):
         try:
             rows = [min(r, 50000) for r in CRITEO_ROWS]
             opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05)
-            steps = 10
+            steps = 12
             batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows)) for s in range(steps)]
             out = {}
             for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True})):
@@ -238,7 +238,7 @@ def test_whole_step_graph_world1(B):
             ts, m = out["graph"][3], out["graph"][4]
             assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
             assert ts.graph_steps == steps and ts.eager_steps == 0
-            assert all(sl["graph"] is not None for sl in ts._slots.values()) and len(ts._slots) == 2
+            assert all(sl["graph"] is not None and sl.get("in_graphs") is not None for sl in ts._slots.values()) and len(ts._slots) == 2
             assert torch.equal(out["exact"][0], out["graph"][0])
             for a, b in zip(out["exact"][1], out["graph"][1]):
                 assert torch.equal(a, b)

@@ -151,6 +151,8 @@ class ShardedTrainStep:
         ebc = self.model.ebc
         if not self.cuda:
             key, skjt = self._static_kjt(kjt)
+            if key is not None and ebc.cap_eligible(skjt, ("sparse",)):
+                return self._begin_graphed(self._slots[key], key, skjt)
             st = ebc.input_dist_begin(skjt, ("sparse",), slot=None if key is None else key[0])
             st["slot_key"] = key
             return st
@@ -163,9 +165,50 @@ class ShardedTrainStep:
             self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             key, skjt = self._static_kjt(kjt)
+            if key is not None and ebc.cap_eligible(skjt, ("sparse",)):
+                return self._begin_graphed(self._slots[key], key, skjt)
             st = ebc.input_dist_begin(skjt, ("sparse",), slot=None if key is None else key[0])
             st["slot_key"] = key
             return st
+
+    def _begin_graphed(self, sl: dict, key: tuple, skjt: KeyedJaggedTensor) -> dict:
+        """Capacity-bounded input dist of a slot with its two kernel runs replayed from hipGraphs (bucketize | ids
+        all-to-all | owner segments, overflow word to the host, both backward plans): 5 host calls instead of 17.
+        Runs on the side stream (the caller's stream context)."""
+        ebc = self.model.ebc
+        st = {"kjt": skjt, "rm": ebc._requester_meta(skjt.keys(), ebc._layout_for(("sparse",))), "uniform": True,
+              "dst_names": ("sparse",), "slot": key[0], "slot_key": key}
+        ebc.cap_state(st, key[0])
+        ig = sl.get("in_graphs")
+        if ig is not None:
+            ig[0].replay()
+            ebc.cap_exchange(st)
+            ig[1].replay()
+            for k in ("ws_dp", "ws_rw"):  # the plans live in the slot's workspaces
+                if k in sl["in_st"]:
+                    st[k] = sl["in_st"][k]
+            st["planned"] = True
+        else:
+            sl["seen_in"] = sl.get("seen_in", 0) + 1
+            if sl["seen_in"] <= self.warmup_iters + 1 or not (self.use_graph and self.cuda):
+                ebc.cap_bucketize(st)
+                ebc.cap_exchange(st)
+                ebc.cap_segments(st)
+            else:
+                g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g0, stream=self._side):
+                    ebc.cap_bucketize(st)
+                g0.replay()
+                ebc.cap_exchange(st)
+                with torch.cuda.graph(g1, stream=self._side):
+                    ebc.cap_segments(st)
+                    if self.plan_ahead:
+                        ebc.plan_ahead(st)
+                g1.replay()
+                sl["in_graphs"], sl["in_st"] = (g0, g1), st
+                st["planned"] = True
+        ebc.cap_flag_event(st)
+        return st
 
     def _end(self, st: dict) -> dict:
         ebc = self.model.ebc
@@ -173,7 +216,7 @@ class ShardedTrainStep:
             return ebc.input_dist_end(st)
         with torch.cuda.stream(self._side):
             st = ebc.input_dist_end(st)
-            if self.plan_ahead:
+            if self.plan_ahead and not st.get("planned"):
                 st = ebc.plan_ahead(st)  # K6 of both backward halves needs ids only
             ev = torch.cuda.Event()
             ev.record(self._side)

@@ -478,6 +478,52 @@ class ShardedEmbeddingBagCollection(nn.Module):
         t = self._slot(slot, what, int(nbytes) + 256, torch.uint8)
         return t[(-t.data_ptr()) % 256:]
 
+    # the capacity-bounded input dist in its pieces (a pipeline replays the kernel runs from hipGraphs: with a slot
+    # every buffer below is persistent, so `cap_state` is host work only)
+    def cap_state(self, st: dict, slot) -> dict:
+        kjt, rm, W = st["kjt"], st["rm"], self.W
+        B, F = kjt.stride(), rm["rw_n"]
+        N, C = F * B, self.exchange_capacity(F, B)
+        S = int(_lib.lib().tzr_exchange_message_stride(F, C))
+        msg = self._slot(slot, "msg", (2, W * S), torch.int64)  # [0] what I send, [1] what I receive
+        seg = self._slot(slot, "seg", W * (F + 1) + 3, torch.int64)  # key starts, then the overflow word
+        host = self._slot(slot, "flag", 1, torch.int64, pinned=True) if self._device.type == "cuda" else seg[-1:]
+        st.update({"cap": C, "sub": None, "N_rw": N, "N_pad": W * S, "unb": self._slot(slot, "unb", N, torch.int64), "msg": msg,
+                   "recv_ids": msg[1], "seg": seg, "key_start": seg[:-1], "n_recv": W * S, "send_splits": None,
+                   "recv_splits": None, "om": self._owner_meta(rm["rw_key_table"], capped=True), "flag_host": host})
+        return st
+
+    def cap_bucketize(self, st: dict) -> None:
+        L, dev, kjt, rm = _lib.lib(), self._device, st["kjt"], st["rm"]
+        B, F = kjt.stride(), rm["rw_n"]
+        ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, self.W), dev)
+        _lib.check(L.tzr_exchange_bucketize_capped(_lib.ptr(rm["rw_sel"]), F, _lib.ptr(rm["rw_blk"]), _lib.ptr(rm["rw_rot"]), B, 1, self.W,
+                                                   _lib.ptr(kjt.values()), st["cap"], _lib.ptr(st["msg"][0]), _lib.ptr(st["unb"]),
+                                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
+
+    def cap_exchange(self, st: dict) -> None:
+        dist.all_to_all_single(st["msg"][1], st["msg"][0], group=self.input_dist_group or self.pg)
+
+    def cap_segments(self, st: dict) -> None:
+        seg = st["seg"]
+        _lib.check(_lib.lib().tzr_exchange_owner_segments(_lib.ptr(st["msg"][1]), self.W, st["rm"]["rw_n"], st["cap"], _lib.ptr(seg),
+                                                          _lib.ptr(seg[-1:]), _lib.stream_ptr(self._device)),
+                   "tzr_exchange_owner_segments")
+        if self._device.type == "cuda":
+            st["flag_host"].copy_(seg[-1:], non_blocking=True)
+
+    def cap_flag_event(self, st: dict) -> None:
+        if self._device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._device))
+            st["flag_event"] = ev
+
+    def cap_eligible(self, kjt: KeyedJaggedTensor, dst_names) -> bool:
+        """would `input_dist_begin` take the capacity-bounded exchange for this batch?"""
+        rm = self._requester_meta(kjt.keys(), self._layout_for(dst_names))
+        return ("rw_n" in rm and self.exchange == "capacity" and kjt.uniform_length() == 1 and kjt.weights_or_none() is None
+                and self.W <= 64 and self.W * rm["rw_n"] <= 256 and self._owner_remap is None and kjt.stride() > 0)
+
     def input_dist_begin(self, kjt: KeyedJaggedTensor, dst_names, exact: bool = False, slot=None) -> dict:
         dev, W = self._device, self.W
         layout = self._layout_for(dst_names)
@@ -486,31 +532,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
         lean = "rw_n" in rm and st["uniform"] and kjt.weights_or_none() is None and W <= 64 and W * rm["rw_n"] <= 256
         if lean and self.exchange == "capacity" and not exact and self._owner_remap is None and kjt.stride() > 0:
             # fixed slices: ONE all-to-all carries counts, overflow word and ids; nothing is read back here
-            L = _lib.lib()
-            B, F = kjt.stride(), rm["rw_n"]
-            N, C = F * B, self.exchange_capacity(rm["rw_n"], kjt.stride())
-            S = int(L.tzr_exchange_message_stride(F, C))
-            msg = self._slot(slot, "msg", (2, W * S), torch.int64)  # [0] what I send, [1] what I receive
-            unb = self._slot(slot, "unb", N, torch.int64)
-            ws = _lib.workspace(L.tzr_exchange_bucketize_workspace(F, B, W), dev)
-            _lib.check(L.tzr_exchange_bucketize_capped(_lib.ptr(rm["rw_sel"]), F, _lib.ptr(rm["rw_blk"]), _lib.ptr(rm["rw_rot"]), B, 1, W,
-                                                       _lib.ptr(kjt.values()), C, _lib.ptr(msg[0]), _lib.ptr(unb), _lib.ptr(ws),
-                                                       ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
-            dist.all_to_all_single(msg[1], msg[0], group=self.input_dist_group or self.pg)
-            seg = self._slot(slot, "seg", W * (F + 1) + 3, torch.int64)  # key starts, then the overflow word
-            _lib.check(L.tzr_exchange_owner_segments(_lib.ptr(msg[1]), W, F, C, _lib.ptr(seg), _lib.ptr(seg[-1:]),
-                                                     _lib.stream_ptr(dev)), "tzr_exchange_owner_segments")
-            if dev.type == "cuda":
-                host = self._slot(slot, "flag", 1, torch.int64, pinned=True)
-                host.copy_(seg[-1:], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-                st["flag_event"] = ev
-            else:
-                host = seg[-1:]
-            st.update({"cap": C, "sub": None, "N_rw": N, "N_pad": W * S, "unb": unb, "msg": msg, "recv_ids": msg[1],
-                       "key_start": seg[:-1], "n_recv": W * S, "send_splits": None, "recv_splits": None,
-                       "om": self._owner_meta(rm["rw_key_table"], capped=True), "flag_host": host})
+            self.cap_state(st, slot)
+            self.cap_bucketize(st)
+            self.cap_exchange(st)
+            self.cap_segments(st)
+            self.cap_flag_event(st)
             return st
         if "rw_n" in rm:
             B = kjt.stride()
