@@ -16,8 +16,10 @@ if [ -z "${SKIP_EXTRA:-}" ]; then
 timeout 300 python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_b8192.json 2>> $O/bench.err; echo "bench b8192 rc=$?"
 timeout 300 python bench.py --optimizer rowwise_adagrad --no-cpu-baseline --no-e2e > $O/bench_rowwise_adagrad.json 2>> $O/bench.err; echo "bench rowwise rc=$?"
 timeout 300 python bench.py --dist zipf --no-cpu-baseline --no-e2e > $O/bench_zipf.json 2>> $O/bench.err; echo "bench zipf rc=$?"
+# 1-rank RCCL proxies of the sharded step: the default (--exchange auto: exact at 65536, capacity + step graphs at 8192) and the exact exchange at 8192
 timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline 2>> $O/bench.err | tail -1 > $O/sharded_w1_proxy_bench.json; echo "sharded proxy rc=$?"
 timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline --global-batch 8192 2>> $O/bench.err | tail -1 > $O/sharded_w1_proxy_bench_b8192.json; echo "sharded proxy b8192 rc=$?"
+timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline --global-batch 8192 --exchange exact 2>> $O/bench.err | tail -1 > $O/sharded_w1_proxy_bench_b8192_exact.json; echo "sharded proxy b8192 exact rc=$?"
 fi
 cd /tmp
 # tuning stays on: the shipped table covers every shape of this run, so no candidate kernels appear
@@ -26,6 +28,7 @@ if [ -z "${SKIP_PMC:-}" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph > /dev/null 2>&1; echo "pmc $c rc=$?"
 done
+if [ -z "${SKIP_MFMA:-}" ]; then
 # MFMA activity of the dot-interaction kernels (north star: "MFMA utilisation for the interaction against the chip's peak")
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|GRBM_GUI_ACTIVE|SQ_BUSY_CYC" | cut -c1-160 | head -40 > $O/pmc_mfma_counters_available.txt
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph > $O/pmc_mfma.log 2>&1; rc=$?; echo "pmc mfma rc=$rc"
@@ -34,10 +37,11 @@ if [ $rc -ne 0 ]; then  # a counter name this rocprofv3 does not know: the two t
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph >> $O/pmc_mfma.log 2>&1; echo "pmc mfma (reduced) rc=$?"
 fi
 fi
+fi
 cd $R
 if [ -z "${SKIP_PMC:-}" ]; then
 python scripts/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json
-python scripts/pmc_mfma_summary.py $O/pmc_mfma $O/pmc_mfma.json || tail -5 $O/pmc_mfma.log
+[ -z "${SKIP_MFMA:-}" ] && { python scripts/pmc_mfma_summary.py $O/pmc_mfma $O/pmc_mfma.json || tail -5 $O/pmc_mfma.log; }
 fi
 S=$(find $O/trace -name '*kernel_stats.csv' | head -1); cp "$S" $O/kernel_stats.csv
 grep tzr_ $O/kernel_stats.csv | cut -c1-60,200-400 | head -24

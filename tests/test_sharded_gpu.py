@@ -201,8 +201,8 @@ def test_sharded_zch_world1_matches_unsharded_zch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [2048, 8192])
-def test_whole_step_graph_world1(B):
+@pytest.mark.parametrize("B,graph_input_dist", [(2048, True), (8192, False)])
+def test_whole_step_graph_world1(B, graph_input_dist):
     """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
     all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
     pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed."""
@@ -224,7 +224,7 @@ def test_whole_step_graph_world1(B):
             steps = 12
             batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows)) for s in range(steps)]
             out = {}
-            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True})):
+            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True, "graph_input_dist": graph_input_dist})):
                 torch.manual_seed(3)
                 m = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt,
                                 dp_max_rows=4096, replicate_at_world1=True, **kw)
@@ -238,7 +238,7 @@ def test_whole_step_graph_world1(B):
             ts, m = out["graph"][3], out["graph"][4]
             assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
             assert ts.graph_steps == steps and ts.eager_steps == 0
-            assert all(sl["graph"] is not None and sl.get("in_graphs") is not None for sl in ts._slots.values()) and len(ts._slots) == 2
+            assert all(sl["graph"] is not None and (sl.get("in_graphs") is not None) == graph_input_dist for sl in ts._slots.values()) and len(ts._slots) == 2
             assert torch.equal(out["exact"][0], out["graph"][0])
             for a, b in zip(out["exact"][1], out["graph"][1]):
                 assert torch.equal(a, b)

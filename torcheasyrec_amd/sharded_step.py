@@ -56,7 +56,7 @@ class ShardedTrainStep:
     def __init__(self, model: ShardedDLRM, dense_optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
                  use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2,
-                 plan_ahead: bool = True, step_graph: bool = False) -> None:
+                 plan_ahead: bool = True, step_graph: bool = False, graph_input_dist: bool = False) -> None:
         self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
         self.device = model.ebc._device
         self.cuda = self.device.type == "cuda"
@@ -77,6 +77,9 @@ class ShardedTrainStep:
         self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
         # whole-step graphs: static inputs + one captured graph per pipeline slot
         self.step_graph = bool(step_graph)
+        # also replay the input dist's two kernel runs from hipGraphs (5 host calls instead of 17): bit-identical, but
+        # not faster on the 1-rank proxy (profiles/r02r: 0.58 vs ~0.55 ms at 8192 on the same slow box) -> opt-in
+        self.graph_input_dist = bool(graph_input_dist)
         if self.step_graph and model.ebc.exchange != "capacity":
             raise ValueError("step_graph needs the capacity-bounded exchange (fixed all-to-all split sizes)")
         self._slots: Dict[tuple, dict] = {}
@@ -190,7 +193,7 @@ class ShardedTrainStep:
             st["planned"] = True
         else:
             sl["seen_in"] = sl.get("seen_in", 0) + 1
-            if sl["seen_in"] <= self.warmup_iters + 1 or not (self.use_graph and self.cuda):
+            if sl["seen_in"] <= self.warmup_iters + 1 or not (self.graph_input_dist and self.use_graph and self.cuda):
                 ebc.cap_bucketize(st)
                 ebc.cap_exchange(st)
                 ebc.cap_segments(st)
