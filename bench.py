@@ -444,10 +444,12 @@ def main():
                               {BASE_DATA_GROUP: k_}, {"label": l_}).pin_memory())
         n_e2e = args.e2e_steps
         loss_of = lambda pred, b: {"bce": bce_with_logits(pred, b.labels["label"])}  # noqa: E731
-        h2d = sum(t.numel() * t.element_size() for t in (host[0].dense_features[BASE_DATA_GROUP].values(),
-                                                         host[0].sparse_features[BASE_DATA_GROUP].values(),
-                                                         host[0].sparse_features[BASE_DATA_GROUP].lengths(),
-                                                         host[0].labels["label"]))
+        # (the lengths of one-id-per-bag keys are constant: GraphTrainPipeline keeps them in its device slots, the eager
+        # pipeline moves the whole Batch)
+        h2d_graph = sum(t.numel() * t.element_size() for t in (host[0].dense_features[BASE_DATA_GROUP].values(),
+                                                               host[0].sparse_features[BASE_DATA_GROUP].values(),
+                                                               host[0].labels["label"]))
+        h2d_eager = h2d_graph + host[0].sparse_features[BASE_DATA_GROUP].lengths().numel() * host[0].sparse_features[BASE_DATA_GROUP].lengths().element_size()
 
         def timed(pipe, n_warm):
             it = iter([host[i % nb] for i in range(n_e2e + n_warm + 1)])
@@ -464,13 +466,17 @@ def main():
         # TrainPipeline (one Python-launched kernel sequence per step): the launch-bound reading
         e_graph = timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8) if not args.torch_adam else None
         e_eager = timed(TrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 5)
-        e1 = e_graph if e_graph is not None else e_eager
+        # the faster of the two is the e2e reading (graph replay wins when the step is launch-bound: batch 8192; at
+        # 65536 the copy stream's H2D next to the HBM-bound replay costs more than the eager pipeline's launch gaps)
+        use_graph_pipe = e_graph is not None and e_graph <= e_eager
+        e1 = e_graph if use_graph_pipe else e_eager
         e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
-               "h2d_bytes_per_step": h2d,
+               "h2d_bytes_per_step": h2d_graph if use_graph_pipe else h2d_eager,
                "launch": ("hipGraph replay per device slot, pinned host batches, H2D of the next batch on a copy stream "
-                          "(GraphTrainPipeline.progress)" if e_graph is not None else
+                          "(GraphTrainPipeline.progress)" if use_graph_pipe else
                           "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"),
-               "eager_ms_per_step": e_eager / n_e2e * 1e3}
+               "eager_ms_per_step": e_eager / n_e2e * 1e3,
+               "graph_ms_per_step": None if e_graph is None else e_graph / n_e2e * 1e3}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     # inside a captured graph); the kernels and inputs are the ones of the timed region
