@@ -401,6 +401,30 @@ int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key_module, in
 int tzr_zch_build(const TzrZchModule* h_module, const int64_t* d_ids, const int32_t* d_rows,
                   int64_t n, void* stream);
 
+/* Admission / eviction round (torchrec MCHManagedCollisionModule eviction policies LFU / LRU / DistanceLFU
+ * [upstream 1.7.0] as tzrec configures them, tzrec/features/feature.py:693-736, docs/source/feature/zch.md):
+ * residents and candidates are ranked together (score descending, residents first, raw id ascending) and the first
+ * zch_size - 1 stay.  The entries to drop are found by radix SELECTION on the reversed order instead of sorting:
+ * tzr_zch_select_hist counts, over the residents (d_row_ids[r] != TZR_ZCH_EMPTY, r < zch_size - 1) and the n_new
+ * candidates that match what is known of the threshold, one digit of the drop key
+ *   field 0: bits [shift, shift + bits) of the score image, given its higher bits t1
+ *   field 1: the kind (bin 0 candidates, bin 1 residents) of the entries whose score image is t1
+ *   field 2: bits [shift, shift + bits) of the id image of the entries with score image t1 and kind t2, given its
+ *            higher bits t3
+ * into d_bins[2048] (uint64, zeroed by the call); the caller reads them, extends the threshold and calls again
+ * (torcheasyrec_amd/zch.py: at most 13 passes, each ONE streaming read of the three per-row arrays).
+ * policy: 0 LFU (count), 1 LRU (1 / age), 2 DistanceLFU (count / age), age = max(cur_iter - last, 1) ^ decay_exponent.
+ * tzr_zch_select_mark then writes d_row_kept[zch_size - 1] / d_new_kept[n_new] = 1 for every entry ABOVE the threshold
+ * (t1, t2, t3) (drop_none != 0: everything live stays).  h_module is a HOST struct holding device pointers. */
+int tzr_zch_select_hist(const TzrZchModule* h_module, const int64_t* d_row_ids, const int64_t* d_new_ids,
+                        const int64_t* d_new_cnt, int64_t n_new, int64_t cur_iter, int policy,
+                        double decay_exponent, int field, int shift, int bits, uint64_t t1, int t2,
+                        uint64_t t3, uint64_t* d_bins, void* stream);
+int tzr_zch_select_mark(const TzrZchModule* h_module, const int64_t* d_row_ids, const int64_t* d_new_ids,
+                        const int64_t* d_new_cnt, int64_t n_new, int64_t cur_iter, int policy,
+                        double decay_exponent, int drop_none, uint64_t t1, int t2, uint64_t t3,
+                        uint8_t* d_row_kept, uint8_t* d_new_kept, void* stream);
+
 /* ---- sequence path --------------------------------------------- */
 
 /* K12: jagged [N, dim] (+ offsets int64[B+1]) -> dense [B, max_len, dim]; positions past a

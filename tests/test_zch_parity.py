@@ -142,3 +142,56 @@ def test_zch_state_survives_a_checkpoint(dev, tmp_path):
     assert int((ra.values() != 31).sum()) > 0
     for f in ("row_ids", "counts", "last_iter"):
         assert torch.equal(getattr(a.mc.modules_by_table["t"], f), getattr(b.mc.modules_by_table["t"], f))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_eviction_selection_equals_the_sorted_ranking(dev, seed):
+    """`ManagedCollisionModule._select_kept` (radix selection of the entries that lose, csrc/zch_evict.hip) = the
+    oracle's ranking done with a plain sort: score descending, residents first, raw id ascending, first Z - 1 stay.
+    Random tables built to hit every branch: many equal scores (ties decided by kind, then by id), negative and huge
+    ids, empty rows, more / fewer candidates than free rows, every policy."""
+    from torcheasyrec_amd.zch import ManagedCollisionModule
+
+    rng = np.random.default_rng(500 + seed)
+    Z = int(rng.choice([3, 17, 64, 300, 2500]))
+    policy = ["lfu", "lru", "distance_lfu"][seed % 3]
+    decay = float(rng.choice([1.0, 1.0, 2.0, 0.5]))
+    m = ManagedCollisionModule(ZchConfig(Z, 5, policy, decay), dev)
+    cur = 40
+    fill = float(rng.choice([0.0, 0.5, 0.9, 1.0]))
+    occupied = rng.random(Z - 1) < fill
+    wide = seed % 4 == 0  # ids across the whole int64 range (sign bit, high bits) or a dense small range
+    pool = rng.integers(-(1 << 62), 1 << 62, size=4 * Z) if wide else rng.permutation(8 * Z) - 2 * Z
+    pool = np.unique(pool)
+    rng.shuffle(pool)
+    res_ids = np.full(Z, EMPTY, dtype=np.int64)
+    res_ids[:Z - 1][occupied] = pool[:int(occupied.sum())]
+    hi = int(rng.choice([2, 3, 50]))  # few distinct counts / ages -> many ties
+    counts = rng.integers(1, hi + 1, size=Z).astype(np.int64)
+    last = cur - rng.integers(0, hi + 1, size=Z).astype(np.int64)
+    n = int(rng.choice([1, 2, Z // 2 + 1, Z + 5]))
+    new_ids = np.sort(pool[int(occupied.sum()):int(occupied.sum()) + n])
+    n = len(new_ids)
+    new_cnt = rng.integers(1, hi + 1, size=n).astype(np.int64)
+    m.row_ids.copy_(torch.from_numpy(res_ids))
+    m.counts.copy_(torch.from_numpy(counts))
+    m.last_iter.copy_(torch.from_numpy(last))
+    row_kept, new_kept = m._select_kept(torch.from_numpy(new_ids).to(dev), torch.from_numpy(new_cnt).to(dev), cur)
+
+    def score(c, la):
+        dist = float(max(cur - la, 1))
+        if policy == "lfu":
+            return float(c)
+        age = dist if decay == 1.0 else dist ** decay
+        return 1.0 / age if policy == "lru" else float(c) / age
+
+    entries = [(-score(counts[r], last[r]), 0, int(res_ids[r]), r) for r in range(Z - 1) if res_ids[r] != EMPTY]
+    entries += [(-score(new_cnt[j], cur), 1, int(new_ids[j]), j) for j in range(n)]
+    entries.sort(key=lambda e: e[:3])
+    kept = entries[:Z - 1]
+    want_rows = np.zeros(Z - 1, np.uint8)
+    want_new = np.zeros(n, np.uint8)
+    for e in kept:
+        (want_new if e[1] else want_rows)[e[3]] = 1
+    assert np.array_equal(row_kept.cpu().numpy(), want_rows)
+    assert np.array_equal(new_kept.cpu().numpy(), want_new)

@@ -29,6 +29,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -152,6 +153,63 @@ class ManagedCollisionModule:
         for fn in self._event_trackers:
             fn(self, evicted, admitted, absent)
 
+    def _select_kept(self, new_ids: torch.Tensor, new_cnt: torch.Tensor, cur_iter: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(row_kept uint8[Z - 1], new_kept uint8[n]): 1 = the resident keeps its row / the candidate gets one.
+        MSB-first radix selection of the D-th smallest "drop key" (score image, kind, id image): every pass is one
+        streaming read of row_ids / counts / last_iter into 2 048 bins that the host narrows (<= 13 passes)."""
+        L, dev, cfg = _lib.lib(), self.device, self.cfg
+        Zp, n = cfg.zch_size - 1, new_ids.numel()
+        new_ids, new_cnt = new_ids.contiguous(), new_cnt.contiguous()
+        s = self.struct()
+        pol = {"lfu": 0, "lru": 1, "distance_lfu": 2}[cfg.policy]
+        bins = torch.empty(2048, dtype=torch.int64, device=dev)
+        row_kept = torch.empty(Zp, dtype=torch.uint8, device=dev)
+        new_kept = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        FULL = (1 << 64) - 1
+
+        def hist(field, shift, bits, t1, t2, t3):
+            _lib.check(L.tzr_zch_select_hist(_lib.C.byref(s), _lib.ptr(self.row_ids), _lib.ptr(new_ids), _lib.ptr(new_cnt), n, cur_iter,
+                                             pol, float(cfg.decay_exponent), field, shift, bits, t1, t2, t3, _lib.ptr(bins),
+                                             _lib.stream_ptr(dev)), "tzr_zch_select_hist")
+            return bins[:1 << bits].cpu().numpy()  # the one host wait of a pass
+
+        def mark(drop_none, t1=0, t2=0, t3=0):
+            _lib.check(L.tzr_zch_select_mark(_lib.C.byref(s), _lib.ptr(self.row_ids), _lib.ptr(new_ids), _lib.ptr(new_cnt), n, cur_iter,
+                                             pol, float(cfg.decay_exponent), drop_none, t1, t2, t3, _lib.ptr(row_kept),
+                                             _lib.ptr(new_kept), _lib.stream_ptr(dev)), "tzr_zch_select_mark")
+            return row_kept, new_kept[:n]
+
+        def narrow(h, need):
+            c = np.cumsum(h)
+            d = int(np.searchsorted(c, need, side="left"))  # first bin whose running count reaches `need`
+            return d, need - (int(c[d - 1]) if d else 0), int(h[d])
+
+        digits = ((53, 11), (42, 11), (31, 11), (20, 11), (9, 11), (0, 9))
+        need, t1 = None, 0
+        for shift, bits in digits:  # the score image
+            h = hist(0, shift, bits, t1, 0, 0)
+            if need is None:
+                need = int(h.sum()) - Zp  # residents + candidates - rows = how many lose
+                if need <= 0:
+                    return mark(1)
+            d, need, in_bin = narrow(h, need)
+            t1 = (t1 << bits) | d
+            if in_bin == need:  # the whole bin loses: the threshold is its largest possible key
+                return mark(0, ((t1 + 1) << shift) - 1, 1, FULL)
+        h = hist(1, 0, 1, t1, 0, 0)  # equal scores: candidates lose before residents ...
+        t2 = 0
+        if need > int(h[0]):
+            need, t2 = need - int(h[0]), 1
+        elif need == int(h[0]):
+            return mark(0, t1, 0, FULL)
+        t3 = 0
+        for shift, bits in digits:  # ... and inside a kind the larger raw id first
+            d, need, in_bin = narrow(hist(2, shift, bits, t1, t2, t3), need)
+            t3 = (t3 << bits) | d
+            if in_bin == need:
+                return mark(0, t1, t2, ((t3 + 1) << shift) - 1)
+        raise AssertionError("drop keys are unique: the last digit always resolves")
+
     @torch.no_grad()
     def update_and_evict(self, cand_ids: torch.Tensor, cur_iter: int) -> torch.Tensor:
         """Admit candidates / evict residents.  Returns the rows whose owner changed."""
@@ -165,31 +223,16 @@ class ManagedCollisionModule:
         if new_ids.numel() == 0:
             self._notify(absent[:0], absent[:0], absent)
             return torch.zeros(0, dtype=torch.int64, device=dev)
-        res_rows = torch.nonzero(self.row_ids[:Z - 1] != EMPTY).squeeze(1)
-        res_ids = self.row_ids[res_rows]
-
-        def score(cnt, last):
-            dist = (cur_iter - last).clamp(min=1).double()
-            if cfg.policy == "lfu":
-                return cnt.double()
-            age = dist if cfg.decay_exponent == 1.0 else torch.pow(dist, cfg.decay_exponent)
-            return (1.0 / age) if cfg.policy == "lru" else cnt.double() / age
-
-        s_res = score(self.counts[res_rows], self.last_iter[res_rows])
-        s_new = score(new_cnt, torch.full_like(new_cnt, cur_iter))
-        ids = torch.cat([res_ids, new_ids])
-        sc = torch.cat([s_res, s_new])
-        is_new = torch.cat([torch.zeros_like(res_ids), torch.ones_like(new_ids)])
-        # order: score desc, residents first, raw id asc  (three stable sorts, least significant first)
-        o = torch.sort(ids, stable=True).indices
-        o = o[torch.sort(is_new[o], stable=True).indices]
-        o = o[torch.sort(sc[o], descending=True, stable=True).indices]
-        kept = o[:Z - 1]
-        kept_res = kept[kept < res_ids.numel()]
-        kept_new = kept[kept >= res_ids.numel()] - res_ids.numel()  # in admission order
-        held = torch.zeros(Z - 1, dtype=torch.bool, device=dev)
-        held[res_rows[kept_res]] = True
-        free = torch.nonzero(~held).squeeze(1)[:kept_new.numel()]  # ascending rows
+        # Who stays: residents and candidates ranked together (score desc, residents first, raw id asc), the first
+        # Z - 1 keep / get a row.  At most len(new_ids) entries can lose, and which ones is a rank query -- radix
+        # selection on the reversed order over the per-row arrays in place (csrc/zch_evict.hip) instead of sorting
+        # residents + candidates three times.
+        row_kept, new_kept = self._select_kept(new_ids, new_cnt, cur_iter)
+        kept_new = torch.nonzero(new_kept).squeeze(1)  # ascending raw id (torch.unique's order) ...
+        # ... into admission order: score descending (a candidate's age is 1: its score is its count, or 1 for lru)
+        if cfg.policy != "lru" and kept_new.numel() > 1:
+            kept_new = kept_new[torch.sort(new_cnt[kept_new], descending=True, stable=True).indices]
+        free = torch.nonzero(row_kept == 0).squeeze(1)[:kept_new.numel()]  # ascending rows
         if self._event_trackers:
             old = self.row_ids[free]
             self._notify(old[old != EMPTY], new_ids[kept_new], absent)
