@@ -372,6 +372,7 @@ int tzr_dense_adam(const TzrAdamTensor* h_tensors, int n_tensors, const float* d
 /* ---- zero-collision hash ---------------------------------------- */
 
 #define TZR_ZCH_EMPTY INT64_MAX /* unoccupied cell / row (tzrec/utils/zch_util.py:29 ZCH_EMPTY_SLOT) */
+#define TZR_ZCH_TOMB (INT64_MAX - 1) /* cell whose id was evicted (tzr_zch_update); as a raw id: served from the shared row, never admitted */
 
 /* One managed-collision table: an open-addressing map raw id -> row plus per-row eviction metadata. */
 typedef struct TzrZchModule {
@@ -400,6 +401,12 @@ int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key_module, in
  * restoring a checkpoint).  h_module is a HOST struct holding device pointers. */
 int tzr_zch_build(const TzrZchModule* h_module, const int64_t* d_ids, const int32_t* d_rows,
                   int64_t n, void* stream);
+
+/* The same after an admission / eviction round, touching only what changed: the n ids d_old_ids[i] (TZR_ZCH_EMPTY: the
+ * row was free) leave the map, the n distinct ids d_new_ids[i] enter it with rows d_rows[i].  Evicted cells become
+ * tombstones that later insertions reuse; the caller rebuilds (tzr_zch_build) when too many have piled up. */
+int tzr_zch_update(const TzrZchModule* h_module, const int64_t* d_old_ids, const int64_t* d_new_ids,
+                   const int32_t* d_rows, int64_t n, void* stream);
 
 /* Admission / eviction round (torchrec MCHManagedCollisionModule eviction policies LFU / LRU / DistanceLFU
  * [upstream 1.7.0] as tzrec configures them, tzrec/features/feature.py:693-736, docs/source/feature/zch.md):

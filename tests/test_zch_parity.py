@@ -195,3 +195,35 @@ def test_eviction_selection_equals_the_sorted_ranking(dev, seed):
         (want_new if e[1] else want_rows)[e[3]] = 1
     assert np.array_equal(row_kept.cpu().numpy(), want_rows)
     assert np.array_equal(new_kept.cpu().numpy(), want_new)
+
+
+def test_zch_map_stays_consistent_under_churn(dev):
+    """40 admission / eviction rounds on a full table (every round evicts): after each, the id -> row map (updated in
+    place with tombstones, rebuilt now and then) answers exactly what the per-row id array says -- residents map to
+    their rows, evicted and never-seen ids and the two sentinel values map to the shared row."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.zch import ManagedCollisionModule
+
+    rng = np.random.default_rng(3)
+    Z = 200
+    m = ManagedCollisionModule(ZchConfig(Z, 1, "lru", 1.0), dev)
+    universe = np.unique(rng.integers(-(1 << 40), 1 << 40, size=3000))
+    seen_rebuilds, seen_inplace, ever = 0, 0, set()
+    for it in range(1, 41):
+        cand = rng.choice(universe, size=int(rng.integers(5, 120)))
+        cand = cand[~np.isin(cand, m.row_ids.cpu().numpy())]  # candidates are ids WITHOUT a row (what remap reports)
+        before = m._tombstones
+        m.update_and_evict(torch.from_numpy(cand).to(dev), it)
+        seen_rebuilds += int(m._tombstones == 0 and before > 0)
+        seen_inplace += int(m._tombstones > before)
+        ever.update(cand.tolist())
+        row_ids = m.row_ids.cpu().numpy()
+        resident = {int(x): r for r, x in enumerate(row_ids[:Z - 1]) if x != _lib.ZCH_EMPTY}
+        probe = np.array(sorted(ever) + [_lib.ZCH_EMPTY, _lib.ZCH_EMPTY - 1, 12345678901], dtype=np.int64)
+        got = m.lookup_rows(torch.from_numpy(probe).to(dev)).cpu().numpy()
+        want = np.array([resident.get(int(x), Z - 1) for x in probe])
+        assert np.array_equal(got, want), f"round {it}"
+        # touch some residents so the LRU order keeps moving
+        hit = rng.choice(list(resident.values()), size=min(20, len(resident)), replace=False)
+        m.last_iter[torch.from_numpy(hit).to(dev)] = it
+    assert seen_rebuilds >= 1 and seen_inplace >= 10  # both the in-place update and the rebuild ran

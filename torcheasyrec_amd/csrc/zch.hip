@@ -50,7 +50,8 @@ __global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_remap_kernel(
     int64_t row = M.zch_size - 1;
     bool hit = false;
     uint64_t h = zch_mix(id) & mask;
-    for (int64_t probe = 0; probe < M.capacity; ++probe) {
+    // (the two sentinel values are never ids of the map: they are served from the shared row and never admitted)
+    for (int64_t probe = 0; probe < M.capacity && id != TZR_ZCH_TOMB && id != TZR_ZCH_EMPTY; ++probe) {
       const int64_t k = M.keys[h];
       if (k == id) {
         row = M.rows[h];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_remap_kernel(
         atomicAdd(reinterpret_cast<unsigned long long*>(M.counts + row), 1ull);
         M.last_iter[row] = iter;  // every writer stores the same value
       }
-      candidates[i] = hit ? TZR_ZCH_EMPTY : id;
+      candidates[i] = (hit || id == TZR_ZCH_TOMB) ? TZR_ZCH_EMPTY : id;
     }
   }
 }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_insert_kernel(
   for (int64_t i = (int64_t)blockIdx.x * ZCH_THREADS + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * ZCH_THREADS) {
     const int64_t id = ids[i];
-    if (id == TZR_ZCH_EMPTY) continue;
+    if (id == TZR_ZCH_EMPTY || id == TZR_ZCH_TOMB) continue;
     uint64_t h = zch_mix(id) & mask;
     for (int64_t probe = 0; probe < M.capacity; ++probe) {
       const unsigned long long prev =
@@ -98,6 +99,68 @@ __global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_insert_kernel(
       h = (h + 1) & mask;
     }
   }
+}
+
+// Incremental form of the rebuild after an admission / eviction round: the ids that lost their row leave a
+// tombstone (lookups walk over it, it never equals an id), the admitted ids take the first free or tombstone
+// cell of their probe sequence.  Two launches (all deletions before any insertion).
+__global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_delete_kernel(TzrZchModule M, const int64_t* __restrict__ ids,
+                                                                     int64_t n) {
+  const uint64_t mask = (uint64_t)M.capacity - 1;
+  for (int64_t i = (int64_t)blockIdx.x * ZCH_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * ZCH_THREADS) {
+    const int64_t id = ids[i];
+    if (id == TZR_ZCH_EMPTY || id == TZR_ZCH_TOMB) continue;
+    uint64_t h = zch_mix(id) & mask;
+    for (int64_t probe = 0; probe < M.capacity; ++probe) {
+      const int64_t k = M.keys[h];
+      if (k == id) {
+        M.keys[h] = TZR_ZCH_TOMB;
+        break;
+      }
+      if (k == TZR_ZCH_EMPTY) break;
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+__global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_reinsert_kernel(TzrZchModule M, const int64_t* __restrict__ ids,
+                                                                       const int32_t* __restrict__ rows, int64_t n) {
+  const uint64_t mask = (uint64_t)M.capacity - 1;
+  for (int64_t i = (int64_t)blockIdx.x * ZCH_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * ZCH_THREADS) {
+    const int64_t id = ids[i];
+    if (id == TZR_ZCH_EMPTY || id == TZR_ZCH_TOMB) continue;
+    uint64_t h = zch_mix(id) & mask;
+    bool done = false;
+    for (int64_t probe = 0; probe < M.capacity && !done; ++probe) {
+      unsigned long long* cell = reinterpret_cast<unsigned long long*>(M.keys + h);
+      unsigned long long k = *reinterpret_cast<volatile unsigned long long*>(cell);
+      while (k == (unsigned long long)TZR_ZCH_EMPTY || k == (unsigned long long)TZR_ZCH_TOMB) {
+        const unsigned long long prev = atomicCAS(cell, k, (unsigned long long)id);
+        if (prev == k) {
+          M.rows[h] = rows[i];
+          done = true;
+          break;
+        }
+        k = prev;  // somebody else took the cell (or it changed kind): look again
+      }
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+extern "C" int tzr_zch_update(const TzrZchModule* h_module, const int64_t* d_old_ids, const int64_t* d_new_ids,
+                              const int32_t* d_rows, int64_t n, void* stream) {
+  if (!h_module || !h_module->keys || !h_module->rows || h_module->capacity <= 0 ||
+      (h_module->capacity & (h_module->capacity - 1)) || n < 0)
+    return TZR_ERR_INVALID;
+  if (n == 0) return TZR_OK;
+  if (!d_old_ids || !d_new_ids || !d_rows) return TZR_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned g = (unsigned)std::min<int64_t>(4096, (n + ZCH_THREADS - 1) / ZCH_THREADS);
+  hipLaunchKernelGGL(tzr_zch_delete_kernel, dim3(g), dim3(ZCH_THREADS), 0, s, *h_module, d_old_ids, n);
+  hipLaunchKernelGGL(tzr_zch_reinsert_kernel, dim3(g), dim3(ZCH_THREADS), 0, s, *h_module, d_new_ids, d_rows, n);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
 }
 
 extern "C" int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key_module, int n_keys,

@@ -111,6 +111,7 @@ class ManagedCollisionModule:
         self.last_iter = torch.zeros(Z, dtype=torch.int64, device=device)
         self.row_ids = torch.full((Z,), EMPTY, dtype=torch.int64, device=device)  # raw id held by every row
         self._event_trackers: list = []  # register_post_zch_event_tracker_fn
+        self._tombstones = 0  # upper bound of the evicted cells still in the map (tzr_zch_update)
 
     def lookup_rows(self, raw_ids: torch.Tensor) -> torch.Tensor:
         """Row every raw id is served from right now (`zch_size - 1`, the shared row, for ids without a
@@ -148,6 +149,7 @@ class ManagedCollisionModule:
         s = self.struct()
         _lib.check(_lib.lib().tzr_zch_build(_lib.C.byref(s), _lib.ptr(ids), _lib.ptr(rows), ids.numel(),
                                             _lib.stream_ptr(self.device)), "tzr_zch_build")
+        self._tombstones = 0
 
     def _notify(self, evicted: torch.Tensor, admitted: torch.Tensor, absent: torch.Tensor) -> None:
         for fn in self._event_trackers:
@@ -233,13 +235,22 @@ class ManagedCollisionModule:
         if cfg.policy != "lru" and kept_new.numel() > 1:
             kept_new = kept_new[torch.sort(new_cnt[kept_new], descending=True, stable=True).indices]
         free = torch.nonzero(row_kept == 0).squeeze(1)[:kept_new.numel()]  # ascending rows
+        old = self.row_ids[free]
+        admitted = new_ids[kept_new].contiguous()
         if self._event_trackers:
-            old = self.row_ids[free]
-            self._notify(old[old != EMPTY], new_ids[kept_new], absent)
-        self.row_ids[free] = new_ids[kept_new]
+            self._notify(old[old != EMPTY], admitted, absent)
+        self.row_ids[free] = admitted
         self.counts[free] = new_cnt[kept_new]
         self.last_iter[free] = cur_iter
-        self.rebuild()
+        # the id -> row map: only the rows that changed hands (evicted ids leave a tombstone that insertions reuse);
+        # a full rebuild once tombstones could fill an eighth of the cells
+        self._tombstones += free.numel()
+        if self._tombstones > self.capacity // 8:
+            self.rebuild()
+        else:
+            s, old, rows32 = self.struct(), old.contiguous(), free.to(torch.int32).contiguous()
+            _lib.check(_lib.lib().tzr_zch_update(_lib.C.byref(s), _lib.ptr(old), _lib.ptr(admitted), _lib.ptr(rows32), free.numel(),
+                                                 _lib.stream_ptr(self.device)), "tzr_zch_update")
         return free
 
 
