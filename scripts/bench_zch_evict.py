@@ -81,8 +81,15 @@ def main():
     t0 = time.perf_counter()
     changed = m.update_and_evict(cand, cur)
     sync()
-    print(f"whole round (unique + selection + row hand-out + map rebuild of {rows} ids): {(time.perf_counter() - t0) * 1e3:.1f} ms, "
-          f"{changed.numel()} rows changed owner", flush=True)
+    print(f"whole round, first call (unique + selection + row hand-out + map update in place; cold allocator): "
+          f"{(time.perf_counter() - t0) * 1e3:.1f} ms, {changed.numel()} rows changed owner", flush=True)
+    # a second round with other candidates (ids 3r + 3: never resident, never seen): the steady-state cost
+    cand2 = (new_ids + 1).repeat_interleave(new_cnt.clamp(max=3))
+    sync()
+    t0 = time.perf_counter()
+    changed = m.update_and_evict(cand2, cur + 5)
+    sync()
+    print(f"whole round, second call: {(time.perf_counter() - t0) * 1e3:.1f} ms, {changed.numel()} rows changed owner", flush=True)
 
 
 if __name__ == "__main__":
