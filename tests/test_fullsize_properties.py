@@ -43,6 +43,24 @@ def test_forward_is_exact_gather_at_full_size():
     assert torch.equal(ebc(kjt).values().detach(), out)
 
 
+def _row_sums(index: torch.Tensor, x: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """out[r] = sum of x[i] over index[i] == r, in fp64, WITHOUT atomics: fp64 index_add_ with tens of thousands of
+    duplicates of one row (Zipf ids) serialises on that row and takes minutes per table.  Stable sort by row, prefix
+    sum, difference at the run ends (fp64 prefix sums of <= 65 536 terms: error far below the bounds checked)."""
+    order = torch.argsort(index, stable=True)
+    si = index[order]
+    cs = x.double()[order].cumsum(0)
+    end = torch.ones(si.numel(), dtype=torch.bool, device=si.device)
+    end[:-1] = si[1:] != si[:-1]
+    e = end.nonzero().squeeze(1)
+    seg = cs[e].clone()
+    seg[1:] -= cs[e[:-1]]
+    out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=torch.float64, device=x.device)
+    out[si[e]] = seg
+    return out
+
+
+
 @pytest.mark.parametrize("dist", ["uniform", "zipf"])
 def test_sgd_update_is_linear_and_conserved_at_full_size(dist):
     lr = 0.5
@@ -62,18 +80,18 @@ def test_sgd_update_is_linear_and_conserved_at_full_size(dist):
         # 3-row table, thousands on zipf hot rows); a dropped or doubled contribution would be O(lr)
         eps32 = 1.2e-7
         if n in before:  # whole table: index_add equivalence + conservation
-            exp = before[n].double().index_add(0, ids[f], gf, alpha=-lr)
-            bound = 1e-6 + 4 * eps32 * lr * torch.zeros_like(exp).index_add_(0, ids[f], gf.abs()) + 1e-6 * exp.abs()
+            exp = before[n].double() - lr * _row_sums(ids[f], gf, before[n].shape[0])
+            bound = 1e-6 + 4 * eps32 * lr * _row_sums(ids[f], gf.abs(), before[n].shape[0]) + 1e-6 * exp.abs()
             err = (w.double() - exp).abs()
             assert bool((err <= bound).all()), f"{n}: max err {float(err.max())} bound {float(bound[err.argmax() // 16].max())}"
             delta = (before[n].double() - w.double()).sum()
             torch.testing.assert_close(delta, lr * gf.sum(), rtol=1e-5, atol=1e-2)
         else:  # 40M-row tables: check the touched rows (duplicates are rare but handled)
             uniq, inv = torch.unique(ids[f], return_inverse=True)
-            gsum = torch.zeros(uniq.numel(), 16, dtype=torch.float64, device=dev).index_add_(0, inv, gf)
+            gsum = _row_sums(inv, gf, uniq.numel())
             first = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).scatter_(0, inv, torch.arange(B, device=dev))
             exp = touched_before[n][first].double() - lr * gsum
-            gabs = torch.zeros(uniq.numel(), 16, dtype=torch.float64, device=dev).index_add_(0, inv, gf.abs())
+            gabs = _row_sums(inv, gf.abs(), uniq.numel())
             err = (w[uniq].double() - exp).abs()
             assert bool((err <= 1e-6 + 4 * eps32 * lr * gabs + 1e-6 * exp.abs()).all()), f"{n}: max err {float(err.max())}"
 
@@ -110,7 +128,7 @@ def test_zero_gradient_is_idempotent_and_runs_are_deterministic():
 def test_adagrad_values_at_full_size(kind, dist):
     """Adagrad / row-wise Adagrad VALUES at B = 65536 on the real 204 M-row tables, two steps on
     two different batches, against an fp64 reference built on the device from torch.unique +
-    index_add_ and the oracle's formula (oracle/tzrec_oracle.py sparse_update: duplicates summed
+    segmented sums and the oracle's formula (oracle/tzrec_oracle.py sparse_update: duplicates summed
     first, one update per row, eps 1e-8; /root/reference/tzrec/optim/optimizer_builder.py:53-71).
     The accumulator starts at 0.1 so the first step is well conditioned: weights and state within
     1e-5 relative (the north star's fp32 tolerance), plus the fp32 order-of-summation term of rows
@@ -149,8 +167,8 @@ def test_adagrad_values_at_full_size(kind, dist):
         torch.cuda.synchronize()
         for f, n in enumerate(ebc.table_weights()):
             gf = g[:, f * D:(f + 1) * D].double()
-            gs = torch.zeros(uniq[f].numel(), D, dtype=torch.float64, device=dev).index_add_(0, inv[f], gf)
-            ga = torch.zeros(uniq[f].numel(), D, dtype=torch.float64, device=dev).index_add_(0, inv[f], gf.abs())
+            gs = _row_sums(inv[f], gf, uniq[f].numel())
+            ga = _row_sums(inv[f], gf.abs(), uniq[f].numel())
             if kind == "adagrad":
                 m_ref = m_before[f] + gs * gs
                 w_ref = w_before[f] - lr * gs / (m_ref.sqrt() + eps)
