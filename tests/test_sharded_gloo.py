@@ -181,6 +181,7 @@ def test_sharded_dlrm_world2(emu_path, mode, via_step, planner):
 @pytest.mark.parametrize("world,mode,via_step,exchange", [(2, "uniform1", False, "capacity"), (2, "uniform1", True, "capacity"),
                                                           (2, "uniform1", False, "overflow"), (2, "uniform1", True, "overflow"),
                                                           (4, "uniform1", True, "capacity"), (4, "uniform1", False, "overflow"),
+                                                          (8, "uniform1", True, "capacity"), (8, "uniform1", True, "overflow"),
                                                           (2, "jagged", False, "capacity")])
 def test_sharded_dlrm_capacity_exchange(emu_path, world, mode, via_step, exchange):
     """Capacity-bounded exchange (fixed message slices, one ids all-to-all, no counts through the host): same
@@ -1024,9 +1025,9 @@ def _slots_worker(rank, world, init_file, emu_path):
     dist.destroy_process_group()
 
 
-def test_whole_step_slots_equal_the_exact_pipeline(emu_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_whole_step_slots_equal_the_exact_pipeline(emu_path, world):
     """Six steps through the two pipeline slots of the whole-step path (capacity-bounded exchange, static buffers,
     one overflowing batch redone exactly) = the exact pipelined step, bit for bit: losses, table shards, dense weights."""
-    world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_slots_worker, args=(world, os.path.join(d, "init"), emu_path), nprocs=world, join=True)
