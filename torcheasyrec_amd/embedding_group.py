@@ -514,7 +514,11 @@ class GraphTrainPipeline:
     The model must be capturable (dense optimizer with device-side step counts: `dense.FusedDenseAdam`,
     or torch optimizers built with `capturable=True`)."""
 
-    def __init__(self, model: nn.Module, optimizer, device: torch.device, loss_fn, warmup: int = 2) -> None:
+    def __init__(self, model: nn.Module, optimizer, device: torch.device, loss_fn, warmup: int = 2,
+                 stage_first: bool = True) -> None:
+        """`stage_first`: queue the next batch's H2D before (True) or after (False) this step's launch -- the order
+        matters when the copy stream and the compute stream land on the same hardware queue."""
+        self._stage_first = bool(stage_first)
         self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
         assert self._device.type == "cuda", "GraphTrainPipeline replays hipGraphs: CUDA/HIP device only"
         self._copy_stream = torch.cuda.Stream(device=self._device)
@@ -569,7 +573,8 @@ class GraphTrainPipeline:
         cur = torch.cuda.current_stream(self._device)
         cur.wait_event(self._ready[slot])
         batch = self._slots[slot]
-        self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
+        if self._stage_first:
+            self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
         if self._graphs[slot] is None and self._seen[slot] >= self._warmup:
             g = torch.cuda.CUDAGraph()
             # capture on the caller's stream when it is a side stream (autograd's accumulation nodes and the
@@ -588,5 +593,7 @@ class GraphTrainPipeline:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._done[slot] = ev
+        if not self._stage_first:
+            self._pending = self._stage(dataloader_iter)  # ... queued behind the launch of the step above
         return losses, predictions, batch
 
