@@ -465,14 +465,8 @@ def main():
         # (a) hipGraph replay per device slot, the next batch's H2D under it (GraphTrainPipeline); (b) the eager
         # TrainPipeline (one Python-launched kernel sequence per step): the launch-bound reading
         e_graph = timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8) if not args.torch_adam else None
-        e_graph_late = (timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of, stage_first=False), 8)
-                        if not args.torch_adam else None)
-        graph_order = "H2D queued before the step"
-        if e_graph_late is not None and e_graph_late < e_graph:
-            e_graph, graph_order = e_graph_late, "H2D queued after the step's launch"
         e_eager = timed(TrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 5)
-        # the faster of the two is the e2e reading (graph replay wins when the step is launch-bound: batch 8192; at
-        # 65536 the copy stream's H2D next to the HBM-bound replay costs more than the eager pipeline's launch gaps)
+        # the faster of the two is the e2e reading (both queue the next batch's H2D behind the step's launch)
         use_graph_pipe = e_graph is not None and e_graph <= e_eager
         e1 = e_graph if use_graph_pipe else e_eager
         e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
@@ -481,9 +475,7 @@ def main():
                           "(GraphTrainPipeline.progress)" if use_graph_pipe else
                           "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"),
                "eager_ms_per_step": e_eager / n_e2e * 1e3,
-               "graph_ms_per_step": None if e_graph is None else e_graph / n_e2e * 1e3,
-               "graph_h2d_order": None if e_graph is None else graph_order,
-               "graph_ms_per_step_h2d_after_launch": None if e_graph_late is None else e_graph_late / n_e2e * 1e3}
+               "graph_ms_per_step": None if e_graph is None else e_graph / n_e2e * 1e3}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     # inside a captured graph); the kernels and inputs are the ones of the timed region
