@@ -43,7 +43,7 @@ def test_graph_pipeline_matches_eager_pipeline():
     res = []
     work = torch.cuda.Stream(dev)
     with torch.cuda.stream(work):
-        for cls, kw in ((TrainPipeline, {}), (GraphTrainPipeline, {}), (GraphTrainPipeline, {"stage_first": True}), (TrainPipeline, {"fetch_first": True})):
+        for cls, kw in ((TrainPipeline, {}), (GraphTrainPipeline, {}), (GraphTrainPipeline, {"stage_first": True}), (TrainPipeline, {"fetch_first": False})):
             model = M()
             opt = FusedDenseAdam(list(model.m.dense_parameters()), lr=1e-2)
             pipe = cls(model, opt, dev, loss_of, **kw)

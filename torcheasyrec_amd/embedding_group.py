@@ -446,7 +446,7 @@ class TrainPipeline:
     ``loss.backward()``; ``optimizer.step()`` only touches the dense parameters."""
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: torch.device, loss_fn,
-                 fetch_first: bool = False) -> None:
+                 fetch_first: bool = True) -> None:
         self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
         self._fetch_first = bool(fetch_first)
         self._copy_stream = torch.cuda.Stream(device=self._device) if self._device.type == "cuda" else None
@@ -484,8 +484,9 @@ class TrainPipeline:
             self._model.allreduce_dense_grads()  # no-op unless the model was built over a process group
         self._opt.step()
         if not self._fetch_first:
-            # queued behind the step's launches: with the copy queued FIRST the step's kernels started only after the
-            # copy had finished (measured: 1.21 -> 0.88 ms per step for the graph pipeline, profiles/r02u)
+            # queued behind the step's launches (what GraphTrainPipeline does: one launch, copy right behind it).  For
+            # this eager pipeline it is the slower order (1.29 vs 1.13 ms at B = 65 536, profiles/r02u: the copy only
+            # starts once the host has queued the ~60 launches of the step), hence fetch_first = True by default
             self._next = self._fetch(dataloader_iter)
         return losses, predictions, batch
 
