@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--weak-per-rank-batch", type=int, default=8192,
                     help="per-rank batch of the secondary (weak-scaling) reading at N > 1")
     ap.add_argument("--no-e2e", action="store_true", help="skip the TrainPipeline / pinned-host-batch reading")
-    ap.add_argument("--e2e-steps", type=int, default=20)
+    ap.add_argument("--e2e-steps", type=int, default=40)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--optimizer", choices=["adagrad", "rowwise_adagrad"], default="adagrad")
     ap.add_argument("--row-layout", choices=["interleaved", "split"], default="interleaved")
