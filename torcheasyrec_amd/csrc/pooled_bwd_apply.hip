@@ -126,6 +126,10 @@ __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOp
                                                  int c, bool active) {
   if (active && (ADAM || opt.kind == TZR_OPT_ADAGRAD))  // Adam: exp_avg
     return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
+  // row-wise Adagrad: the row's scalar, fetched by the group's first lane (c == lane in group at every call site)
+  // together with the weights -- not after the gradient reduction, where its latency was exposed once per run
+  if (!ADAM && active && c == 0 && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
+    return make_float4(reinterpret_cast<const float*>(tb.m)[row * (int64_t)tb.m_stride], 0.f, 0.f, 0.f);
   return tzr_zero4();
 }
 
@@ -186,7 +190,7 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
     // the row's scalar state is read by the group's first lane only and broadcast, so no lane
     // can observe the store below
     float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride;
-    float mold = (active && lane_in_group == 0) ? *mp : 0.f;
+    float mold = (active && lane_in_group == 0) ? m4.x : 0.f;  // loaded by bwd_load_state
     mold = __shfl(mold, lane - lane_in_group, 64);
     if (active) {
       const float mnew = mold + ss / (float)tb.dim;
