@@ -315,7 +315,8 @@ def test_mmoe_with_zch_config_to_training(dev):
     assert held.numel() > 5 and bool((held >= (1 << 40)).all())  # raw user ids were admitted to rows
 
 
-def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path):
+@pytest.mark.parametrize("tables_format", ["files", "dcp"])
+def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path, tables_format):
     emu_heavy(dev)
     from torcheasyrec_amd.checkpoint import read_plan, restore_checkpoint, save_checkpoint
 
@@ -327,7 +328,7 @@ def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path):
     it = iter(_din_batches(spec, 48, 24, seed=3))
     for _ in range(2):
         pipe.progress(it)
-    save_checkpoint(str(tmp_path), a, opt)
+    save_checkpoint(str(tmp_path), a, opt, tables_format=tables_format)
     assert set(read_plan(str(tmp_path))) == {"embedding_group.ebc", "embedding_group.ecs.16"}
     torch.manual_seed(9)
     b = build_rank_model(spec, device=dev)

@@ -219,7 +219,7 @@ def test_row_wise_plan_spreads_small_tables():
         assert owned == rows
 
 
-def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir):
+def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir, tables_format="files"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     from torcheasyrec_amd import _lib
@@ -242,7 +242,10 @@ def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir):
     a.allreduce_dense_grads()
     dopt.step()
     a.ebc.fused_optimizer.param_groups[0]["lr"] = 0.125
-    save_checkpoint(ckpt_dir, a, dopt)
+    save_checkpoint(ckpt_dir, a, dopt, tables_format=tables_format)
+    if tables_format == "dcp" and rank == 0:  # the bulk went through torch.distributed.checkpoint
+        assert {".metadata", "__0_0.distcp", "__1_0.distcp"} <= set(os.listdir(os.path.join(ckpt_dir, "model", "dcp")))
+        assert os.path.getsize(os.path.join(ckpt_dir, "model", "rank0.pt")) < 20000
     assert read_plan(ckpt_dir)["ebc"]["cat_0_emb"] == {"sharding_type": "row_wise", "compute_kernel": "fused", "ranks": [0, 1]}
 
     # restore under a DIFFERENT placement: cat_0 table-wise, everything else row-wise (no replicas)
@@ -285,10 +288,14 @@ def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir):
     dist.destroy_process_group()
 
 
-def test_checkpoint_reshards_across_plans(emu_path):
+@pytest.mark.parametrize("tables_format", ["files", "dcp"])
+def test_checkpoint_reshards_across_plans(emu_path, tables_format):
+    """save under one placement, restore under another; "dcp": tables, their optimizer state and the dense parameters
+    through torch.distributed.checkpoint (ShardedTensor per table, DCP's own re-sharding on load)"""
     world = 2
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_ckpt_worker, args=(world, os.path.join(d, "init"), emu_path, os.path.join(d, "ckpt")), nprocs=world, join=True)
+        mp.spawn(_ckpt_worker, args=(world, os.path.join(d, "init"), emu_path, os.path.join(d, "ckpt"), tables_format), nprocs=world,
+                 join=True)
 
 
 def _fp16_worker(rank, world, init_file, emu_path):

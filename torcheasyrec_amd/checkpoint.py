@@ -15,6 +15,14 @@ compute_kernel, ranks}}}`.  The same directory contract here, over plain files:
   <dir>/plan                   the reference's plan JSON (rank 0)
   <dir>/meta.json              world size, {table: [rows, dim]}, format version (rank 0)
 
+`save_checkpoint(..., tables_format="dcp")` puts the bulk -- table rows, their optimizer state and the dense
+parameters -- through torch.distributed.checkpoint itself, as the reference does (`save(model.state_dict(),
+checkpoint_id=<dir>/model)`, :1127-1133): `<dir>/model/dcp/` and `<dir>/optimizer/dcp/` hold `.metadata` + `__<rank>_0.distcp`
+with one entry per table named like torchrec's parameters, `<module path>.embedding_bags.<table>.weight` (/ `.momentum1`):
+a ShardedTensor whose shards are the row ranges the ranks own (replicated tables and dense parameters: plain tensors,
+written once), so DCP's own planner re-shards on load.  The small remainder (ZCH maps, step counters, dense optimizer
+state, plan, meta) stays in the files above.
+
 Row shards are saved by their owner; replicated (data_parallel) tables and dense parameters by rank
 0 only.  `restore_checkpoint` reads whichever row ranges the CURRENT placement needs from whichever
 files hold them, so world size and sharding types may change between save and restore (the
@@ -103,7 +111,32 @@ def _dense_state(model: nn.Module) -> Dict[str, torch.Tensor]:
     return {n: p.detach().cpu() for n, p in model.named_parameters() if id(p) not in tables and ".embedding_bags." not in n}
 
 
-def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None) -> None:
+def _dcp_entry(local: Optional[torch.Tensor], lo: int, n: int, full_shape, sharded: bool):
+    """A table (or its state) as torch.distributed.checkpoint wants it: a ShardedTensor whose one local shard is rows
+    [lo, lo + n) of `full_shape` when the table is spread over ranks (collective: every rank calls, owners of no rows
+    with no shard), the plain tensor otherwise."""
+    if not sharded:
+        return local
+    from torch.distributed._shard.sharded_tensor import Shard, ShardedTensor, ShardMetadata
+
+    rank = dist.get_rank()
+    shards = []
+    if n > 0:
+        shards.append(Shard(local, ShardMetadata(shard_offsets=[lo] + [0] * (len(full_shape) - 1),
+                                                 shard_sizes=[n] + list(full_shape[1:]), placement=f"rank:{rank}/cpu")))
+    return ShardedTensor._init_from_local_shards(shards, list(full_shape))
+
+
+def _dcp_key(path: str, name: str, field: str) -> str:
+    return f"{path}.embedding_bags.{name}.{field}"
+
+
+def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Optional[torch.optim.Optimizer] = None,
+                    tables_format: str = "files") -> None:
+    if tables_format not in ("files", "dcp"):
+        raise ValueError("tables_format: 'files' or 'dcp'")
+    use_dcp = tables_format == "dcp"
+    dcp_model, dcp_optim = {}, {}
     rank, world = _rank_world()
     cols = _collections(model)
     for sub in ("model", "optimizer"):
@@ -111,7 +144,15 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
     m_tables, o_tables, plan_js, dims = {}, {}, {}, {}
     for path, col in cols:
         weights, states = col.table_weights(), col.table_states()
-        for name, (lo, n, _, kind) in _placement(col).items():
+        for name, (lo, n, total, kind) in _placement(col).items():
+            if use_dcp:  # every rank takes part for every table (ShardedTensor construction is a collective)
+                spread = world > 1 and kind != "data_parallel" and hasattr(col, "shard_of")
+                w = weights[name].detach()[:n].cpu().contiguous()
+                dcp_model[_dcp_key(path, name, "weight")] = _dcp_entry(w, lo, n, [total] + list(w.shape[1:]), spread)
+                if name in states:
+                    m = states[name].detach()[:n].cpu().contiguous()
+                    dcp_optim[_dcp_key(path, name, "momentum1")] = _dcp_entry(m, lo, n, [total] + list(m.shape[1:]), spread)
+                continue
             if n == 0 or (kind == "data_parallel" and rank != 0):
                 continue
             key = f"{path}/{name}"
@@ -131,7 +172,15 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
         zch = {"iter": mc._iter, "sharded": mc_sharded, "world_size": world,
                "tables": {n: {"row_ids": m.row_ids.cpu(), "counts": m.counts.cpu(), "last_iter": m.last_iter.cpu()}
                           for n, m in mc.modules_by_table.items()}}
-    torch.save({"dense": _dense_state(model) if rank == 0 else {}, "tables": m_tables, "zch": zch},
+    if use_dcp:
+        import torch.distributed.checkpoint as dcp
+
+        for n_, t in _dense_state(model).items():
+            dcp_model[f"dense.{n_}"] = t
+        dcp.save(dcp_model, checkpoint_id=os.path.join(checkpoint_dir, "model", "dcp"), no_dist=world == 1)
+        if dcp_optim:
+            dcp.save(dcp_optim, checkpoint_id=os.path.join(checkpoint_dir, "optimizer", "dcp"), no_dist=world == 1)
+    torch.save({"dense": _dense_state(model) if (rank == 0 and not use_dcp) else {}, "tables": m_tables, "zch": zch},
                os.path.join(checkpoint_dir, "model", f"rank{rank}.pt"))
     fo = getattr(cols[0][1], "fused_optimizer", None)
     adam_steps = {}
@@ -146,7 +195,8 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
         with open(os.path.join(checkpoint_dir, "plan"), "w") as f:
             json.dump(plan_js, f)
         with open(os.path.join(checkpoint_dir, "meta.json"), "w") as f:
-            json.dump({"format": FORMAT_VERSION, "world_size": world, "tables": dims}, f)
+            json.dump({"format": FORMAT_VERSION, "world_size": world, "tables": dims, "tables_format": tables_format,
+                       "dcp_optimizer_state": bool(dcp_optim)}, f)
     if world > 1:
         dist.barrier()
 
@@ -183,8 +233,13 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                for r in range(saved_world)]
     o_files = [torch.load(os.path.join(checkpoint_dir, "optimizer", f"rank{r}.pt"), mmap=True, weights_only=True)
                for r in range(saved_world)]
+    use_dcp = meta.get("tables_format", "files") == "dcp"
+    if use_dcp:
+        _restore_dcp(checkpoint_dir, model, cols, meta, strict, world)
     with torch.no_grad():
         for path, col in cols:
+            if use_dcp:
+                break
             weights, states = col.table_weights(), col.table_states()
             for name, (lo, n, _, _) in _placement(col).items():
                 key = f"{path}/{name}"
@@ -199,7 +254,7 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                         _fill(states[name].detach(), lo, n, pcs, "momentum1", key)
                     elif strict:
                         raise KeyError(f"checkpoint has no optimizer state for {key}")
-        dense = m_files[0]["dense"]
+        dense = {} if use_dcp else m_files[0]["dense"]
         mine = dict(model.named_parameters())
         for n_, t in dense.items():
             if n_ in mine:
@@ -248,6 +303,48 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
         dense_optimizer.load_state_dict(o_files[0]["dense"])
     if world > 1:
         dist.barrier()
+
+
+def _restore_dcp(checkpoint_dir: str, model: nn.Module, cols, meta: dict, strict: bool, world: int) -> None:
+    """Tables, their optimizer state and the dense parameters from `<dir>/{model,optimizer}/dcp`: the template names the
+    rows THIS placement holds, torch.distributed.checkpoint reads them from whichever saved shards overlap."""
+    import torch.distributed.checkpoint as dcp
+
+    m_dir, o_dir = os.path.join(checkpoint_dir, "model", "dcp"), os.path.join(checkpoint_dir, "optimizer", "dcp")
+    saved = set(dcp.FileSystemReader(m_dir).read_metadata().state_dict_metadata)
+    tm, to, back = {}, {}, []
+    for path, col in cols:
+        weights, states = col.table_weights(), col.table_states()
+        for name, (lo, n, total, kind) in _placement(col).items():
+            if f"{path}/{name}" not in meta["tables"]:
+                continue
+            spread = world > 1 and kind != "data_parallel" and hasattr(col, "shard_of")
+            w = torch.empty((n,) + tuple(weights[name].shape[1:]), dtype=weights[name].dtype)
+            tm[_dcp_key(path, name, "weight")] = _dcp_entry(w, lo, n, [total] + list(w.shape[1:]), spread)
+            back.append((weights[name], w, n))
+            if name in states and meta.get("dcp_optimizer_state"):
+                m = torch.empty((n,) + tuple(states[name].shape[1:]), dtype=states[name].dtype)
+                to[_dcp_key(path, name, "momentum1")] = _dcp_entry(m, lo, n, [total] + list(m.shape[1:]), spread)
+                back.append((states[name], m, n))
+    dense = {f"dense.{n_}": torch.empty_like(t) for n_, t in _dense_state(model).items()}
+    missing = [k for k in dense if k not in saved]
+    if missing and strict:
+        raise KeyError(f"checkpoint has no dense parameter(s) {missing}")
+    extra = [k for k in saved if k.startswith("dense.") and k not in dense]
+    if extra and strict:
+        raise KeyError(f"checkpoint parameter(s) {extra} not in the model")
+    dense = {k: t for k, t in dense.items() if k in saved}
+    tm.update(dense)
+    dcp.load(tm, checkpoint_id=m_dir, no_dist=world == 1)
+    if to:
+        dcp.load(to, checkpoint_id=o_dir, no_dist=world == 1)
+    with torch.no_grad():
+        for dst, src, n in back:
+            if n > 0:
+                dst.detach()[:n].copy_(src)
+        mine = dict(model.named_parameters())
+        for k, t in dense.items():
+            mine[k[len("dense."):]].data.copy_(t)
 
 
 def read_plan(checkpoint_dir: str) -> Dict[str, dict]:
