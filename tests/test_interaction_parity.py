@@ -16,7 +16,12 @@ RTOL, ATOL = 1e-5, 1e-5
 
 @pytest.mark.parametrize("N", [2, 4, 16, 17, 27, 32])
 @pytest.mark.parametrize("B", [1, 5, 70])
-def test_interaction_arch_forward_backward(dev, N, B):
+@pytest.mark.parametrize("pipe", [0, 1])
+def test_interaction_arch_forward_backward(dev, N, B, pipe):
+    from torcheasyrec_amd import _lib
+
+    _lib.lib().tzr_tune(b"ia_bwd_pipe", pipe)
+    _lib.lib().tzr_tune(b"ia_bwd_wgs", 2 * pipe)
     g = torch.Generator().manual_seed(N * 1000 + B)
     x = torch.randn(B, N, 16, generator=g)
     # asymmetric rows so a transposed fragment map cannot pass
@@ -92,10 +97,24 @@ def test_shape_fixture_from_reference(dev):
     assert tuple(out.shape) == (10, 6)
 
 
+@pytest.fixture(params=[(0, 0), (1, 0), (1, 3), (0, 2)], ids=["default", "pipe", "pipe-3wg", "2wg"])
+def ia_bwd_variant(request):
+    """tzr_tune knobs of the D = 16 backward: the software-pipelined kernel and / or a grid smaller than the batch
+    (a wave then walks several samples: loop carried state, the tail sample that does not exist)"""
+    from torcheasyrec_amd import _lib
+
+    pipe, wgs = request.param
+    yield lambda: (_lib.lib().tzr_tune(b"ia_bwd_pipe", pipe), _lib.lib().tzr_tune(b"ia_bwd_wgs", wgs))
+    if _lib._lib is not None:
+        _lib.lib().tzr_tune(b"ia_bwd_pipe", 0)
+        _lib.lib().tzr_tune(b"ia_bwd_wgs", 0)
+
+
 @pytest.mark.parametrize("cat_dense,cat_sparse", [(True, True), (True, False), (False, True), (False, False)])
-def test_fused_dlrm_interaction(dev, cat_dense, cat_sparse):
+def test_fused_dlrm_interaction(dev, cat_dense, cat_sparse, ia_bwd_variant):
     """[interactions | dense | sparse] exactly as DLRM.predict concatenates it
     (/root/reference/tzrec/models/dlrm.py:123-130)."""
+    ia_bwd_variant()
     B, F, D = 77, 26, 16
     g = torch.Generator().manual_seed(3)
     dense = torch.randn(B, D, generator=g)

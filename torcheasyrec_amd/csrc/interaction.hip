@@ -186,6 +186,119 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_kernel(
   }
 }
 
+// The same backward with the NEXT sample's global loads in flight while the current one is contracted: a wave walks
+// many samples (grid sized to the chip, not to the batch), so the prologue above is paid once per ~10 samples and the
+// dependent chain  load -> LDS -> MFMA -> store  of one sample overlaps the loads of the next.
+struct IaBwdRegs {
+  float gv[(IA_MAXP + TZR_WAVE - 1) / TZR_WAVE];  // pair gradients idx = lane + 64 k
+  float4 a0, a1, p0, p1;                          // X rows r / 16+r, pass-through gradients of those rows
+};
+
+__device__ __forceinline__ void ia_bwd_fetch(IaBwdRegs& R, const float* __restrict__ dense, int64_t dense_stride,
+                                             const float* __restrict__ sparse, int64_t sparse_stride, int n, int hd,
+                                             int64_t b, bool on, const float* __restrict__ gout, int64_t gout_stride,
+                                             int cat_dense, int cat_sparse, int P, int pd, int ps, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  R.a0 = R.a1 = R.p0 = R.p1 = tzr_zero4();
+#pragma unroll
+  for (int k = 0; k < (IA_MAXP + TZR_WAVE - 1) / TZR_WAVE; ++k) R.gv[k] = 0.f;
+  if (!on) return;
+  const float* g = gout + b * gout_stride;
+#pragma unroll
+  for (int k = 0; k < (IA_MAXP + TZR_WAVE - 1) / TZR_WAVE; ++k) {
+    const int idx = lane + TZR_WAVE * k;
+    if (idx < P) R.gv[k] = g[idx];
+  }
+  const bool row0 = r < n, row1 = 16 + r < n;
+  if (row0) R.a0 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, r, hd) + 4 * q);
+  if (row1) R.a1 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, 16 + r, hd) + 4 * q);
+  if (row0) {
+    if (hd && r == 0) { if (cat_dense) R.p0 = tzr_ld4_a4(g + pd + 4 * q); }
+    else if (cat_sparse) R.p0 = tzr_ld4_a4(g + ps + (r - hd) * IA_D + 4 * q);
+  }
+  if (row1 && cat_sparse) R.p1 = tzr_ld4_a4(g + ps + (16 + r - hd) * IA_D + 4 * q);
+}
+
+__global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_bwd_pipe_kernel(
+    const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
+    int64_t sparse_stride, int n, int hd, int64_t B, const float* __restrict__ gout,
+    int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
+    int64_t gdense_stride, float* __restrict__ gsparse, int64_t gsparse_stride) {
+  __shared__ float S[IA_WAVES][IA_MAXN * (IA_MAXN + 1)];
+  __shared__ float Xs[IA_WAVES][IA_MAXN * (IA_D + 1)];
+  __shared__ unsigned short ij[IA_MAXP];  // idx -> (i << 8) | j
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int r = lane & 15, q = lane >> 4;
+  const int P = n * (n - 1) / 2;
+  for (int idx = threadIdx.x; idx < P; idx += IA_THREADS) {
+    int i = 0, rem = idx;
+    while (rem >= n - 1 - i) {
+      rem -= n - 1 - i;
+      ++i;
+    }
+    ij[idx] = (unsigned short)((i << 8) | (i + 1 + rem));
+  }
+  for (int k = threadIdx.x; k < IA_WAVES * IA_MAXN * (IA_MAXN + 1); k += IA_THREADS)
+    (&S[0][0])[k] = 0.f;
+  for (int k = threadIdx.x; k < IA_WAVES * IA_MAXN * (IA_D + 1); k += IA_THREADS)
+    (&Xs[0][0])[k] = 0.f;
+  __syncthreads();
+  const int pd = P;
+  const int ps = P + ((cat_dense && hd) ? IA_D : 0);
+  const int64_t step = (int64_t)gridDim.x * IA_WAVES;
+  int64_t b = (int64_t)blockIdx.x * IA_WAVES + wv;
+  IaBwdRegs cur;
+  ia_bwd_fetch(cur, dense, dense_stride, sparse, sparse_stride, n, hd, b, b < B, gout, gout_stride, cat_dense,
+               cat_sparse, P, pd, ps, lane);
+  // (all waves of the workgroup make the same number of trips: the loop runs on the workgroup's first sample)
+  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += step, b += step) {
+    const bool on = b < B;
+    const bool row0 = on && r < n, row1 = on && 16 + r < n;
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < (IA_MAXP + TZR_WAVE - 1) / TZR_WAVE; ++k) {
+        const int idx = lane + TZR_WAVE * k;
+        if (idx < P) {
+          const int i = ij[idx] >> 8, j = ij[idx] & 255;
+          S[wv][i * (IA_MAXN + 1) + j] = cur.gv[k];
+          S[wv][j * (IA_MAXN + 1) + i] = cur.gv[k];
+        }
+      }
+      float* xr0 = &Xs[wv][r * (IA_D + 1) + 4 * q];
+      float* xr1 = &Xs[wv][(16 + r) * (IA_D + 1) + 4 * q];
+      xr0[0] = cur.a0.x; xr0[1] = cur.a0.y; xr0[2] = cur.a0.z; xr0[3] = cur.a0.w;
+      xr1[0] = cur.a1.x; xr1[1] = cur.a1.y; xr1[2] = cur.a1.z; xr1[3] = cur.a1.w;
+    }
+    const float4 p0 = cur.p0, p1 = cur.p1;
+    IaBwdRegs nxt;  // the next sample of this wave: its loads fly over the contraction below
+    ia_bwd_fetch(nxt, dense, dense_stride, sparse, sparse_stride, n, hd, b + step, b + step < B, gout, gout_stride,
+                 cat_dense, cat_sparse, P, pd, ps, lane);
+    ia_wave_sync();
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+    for (int ks = 0; ks < IA_MAXN / 4; ++ks) {
+      const int k = 4 * ks + q;
+      const float xa = Xs[wv][k * (IA_D + 1) + r];
+      const float s0 = S[wv][k * (IA_MAXN + 1) + r];
+      const float s1 = S[wv][k * (IA_MAXN + 1) + 16 + r];
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, s0, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, s1, d1, 0, 0, 0);
+    }
+    if (row0) {
+      const float4 v = make_float4(d0[0] + p0.x, d0[1] + p0.y, d0[2] + p0.z, d0[3] + p0.w);
+      if (hd && r == 0) tzr_st4(gdense + b * gdense_stride + 4 * q, v);
+      else tzr_st4(gsparse + b * gsparse_stride + (int64_t)(r - hd) * IA_D + 4 * q, v);
+    }
+    if (row1) {
+      const float4 v = make_float4(d1[0] + p1.x, d1[1] + p1.y, d1[2] + p1.z, d1[3] + p1.w);
+      tzr_st4(gsparse + b * gsparse_stride + (int64_t)(16 + r - hd) * IA_D + 4 * q, v);
+    }
+    ia_wave_sync();
+    cur = nxt;
+  }
+}
+
 // ---- general shapes --------------------------------------------------------------------------
 // The MFMA kernels above are specialised for the DLRM-Criteo shape (D = 16, n <= 32).  Any other
 // (n, D) the reference's InteractionArch accepts (D % 4 == 0) takes this path: one workgroup per
@@ -524,6 +637,9 @@ static bool iag_fits(int n, int D, bool bwd) {
 
 static unsigned iag_grid(int64_t B) { return (unsigned)(B < 1 ? 1 : (B > 16384 ? 16384 : B)); }
 
+int g_tzr_ia_bwd_pipe = 0;  // tzr_tune("ia_bwd_pipe"): 1 = the software-pipelined backward (D = 16, n <= 32)
+int g_tzr_ia_bwd_wgs = 0;   // tzr_tune("ia_bwd_wgs"): workgroups of that backward (0 = one per 4 samples, <= 8192)
+
 static unsigned ia_grid(int64_t B) {
   const int64_t wg = (B + IA_WAVES - 1) / IA_WAVES;
   return (unsigned)(wg < 1 ? 1 : (wg > 8192 ? 8192 : wg));
@@ -618,7 +734,17 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
     TZR_CHECK_LAUNCH();
     return TZR_OK;
   }
-  hipLaunchKernelGGL(tzr_dot_interaction_bwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
+  unsigned grid = ia_grid(B);
+  if (g_tzr_ia_bwd_wgs > 0 && (unsigned)g_tzr_ia_bwd_wgs < grid) grid = (unsigned)g_tzr_ia_bwd_wgs;
+  if (g_tzr_ia_bwd_pipe) {
+    hipLaunchKernelGGL(tzr_dot_interaction_bwd_pipe_kernel, dim3(grid), dim3(IA_THREADS), 0,
+                       static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse, sparse_stride, n, hd, B,
+                       d_grad_out, grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
+                       d_grad_sparse, grad_sparse_stride);
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
+  hipLaunchKernelGGL(tzr_dot_interaction_bwd_kernel, dim3(grid), dim3(IA_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
                      sparse_stride, n, hd, B, d_grad_out, grad_out_stride, cat_dense, cat_sparse,
                      d_grad_dense, grad_dense_stride, d_grad_sparse, grad_sparse_stride);

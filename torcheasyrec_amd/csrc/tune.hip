@@ -7,6 +7,8 @@ extern int g_tzr_fwd_tile_b;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
+extern int g_tzr_ia_bwd_pipe;
+extern int g_tzr_ia_bwd_wgs;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
@@ -20,6 +22,14 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_one_wg_heavy")) {
     g_tzr_bwd_one_wg_heavy = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "ia_bwd_pipe")) {
+    g_tzr_ia_bwd_pipe = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "ia_bwd_wgs")) {
+    g_tzr_ia_bwd_wgs = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_force_prep")) {
