@@ -45,8 +45,8 @@ def main():
         dense.grad = sparse.grad = None
 
     ref = None
-    for pipe, wgs in ((0, 0), (0, 4096), (0, 2048), (0, 1536), (1, 0), (1, 4096), (1, 3072), (1, 2048), (1, 1536), (1, 1024), (1, 768)):
-        L.tzr_tune(b"ia_bwd_pipe", pipe)
+    for plain, wgs in ((1, 0), (1, 4096), (1, 1536), (0, 0), (0, 8192), (0, 4096), (0, 3072), (0, 2048), (0, 1024), (0, 768)):
+        L.tzr_tune(b"ia_bwd_plain", plain)
         L.tzr_tune(b"ia_bwd_wgs", wgs)
         fb_out = dot_interaction(dense, sparse, D, True, True)
         fb_out.backward(go)
@@ -55,8 +55,8 @@ def main():
         if ref is None:
             ref = g
         t = timed(fb) - t_f
-        print(f"B={B} pipe={pipe} wgs={wgs or 'auto':>5}: bwd {t:6.1f} us = {by_b / t / 1e6:4.2f} TB/s   same grads: {bool(torch.equal(g, ref))}", flush=True)
-    L.tzr_tune(b"ia_bwd_pipe", 0)
+        print(f"B={B} plain={plain} wgs={wgs or 'auto':>5}: bwd {t:6.1f} us = {by_b / t / 1e6:4.2f} TB/s   same grads: {bool(torch.equal(g, ref))}", flush=True)
+    L.tzr_tune(b"ia_bwd_plain", 0)
     L.tzr_tune(b"ia_bwd_wgs", 0)
 
 

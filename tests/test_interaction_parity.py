@@ -16,12 +16,12 @@ RTOL, ATOL = 1e-5, 1e-5
 
 @pytest.mark.parametrize("N", [2, 4, 16, 17, 27, 32])
 @pytest.mark.parametrize("B", [1, 5, 70])
-@pytest.mark.parametrize("pipe", [0, 1])
-def test_interaction_arch_forward_backward(dev, N, B, pipe):
+@pytest.mark.parametrize("plain", [0, 1])
+def test_interaction_arch_forward_backward(dev, N, B, plain):
     from torcheasyrec_amd import _lib
 
-    _lib.lib().tzr_tune(b"ia_bwd_pipe", pipe)
-    _lib.lib().tzr_tune(b"ia_bwd_wgs", 2 * pipe)
+    _lib.lib().tzr_tune(b"ia_bwd_plain", plain)
+    _lib.lib().tzr_tune(b"ia_bwd_wgs", 0 if plain else 2)  # pipelined: two workgroups walk the whole batch
     g = torch.Generator().manual_seed(N * 1000 + B)
     x = torch.randn(B, N, 16, generator=g)
     # asymmetric rows so a transposed fragment map cannot pass
@@ -97,16 +97,16 @@ def test_shape_fixture_from_reference(dev):
     assert tuple(out.shape) == (10, 6)
 
 
-@pytest.fixture(params=[(0, 0), (1, 0), (1, 3), (0, 2)], ids=["default", "pipe", "pipe-3wg", "2wg"])
+@pytest.fixture(params=[(0, 0), (1, 0), (0, 3), (1, 2)], ids=["default", "plain", "pipelined-3wg", "plain-2wg"])
 def ia_bwd_variant(request):
-    """tzr_tune knobs of the D = 16 backward: the software-pipelined kernel and / or a grid smaller than the batch
+    """tzr_tune knobs of the D = 16 backward: the software-pipelined kernel (default) or the plain one, a grid smaller than the batch
     (a wave then walks several samples: loop carried state, the tail sample that does not exist)"""
     from torcheasyrec_amd import _lib
 
     pipe, wgs = request.param
-    yield lambda: (_lib.lib().tzr_tune(b"ia_bwd_pipe", pipe), _lib.lib().tzr_tune(b"ia_bwd_wgs", wgs))
+    yield lambda: (_lib.lib().tzr_tune(b"ia_bwd_plain", pipe), _lib.lib().tzr_tune(b"ia_bwd_wgs", wgs))
     if _lib._lib is not None:
-        _lib.lib().tzr_tune(b"ia_bwd_pipe", 0)
+        _lib.lib().tzr_tune(b"ia_bwd_plain", 0)
         _lib.lib().tzr_tune(b"ia_bwd_wgs", 0)
 
 

@@ -637,8 +637,9 @@ static bool iag_fits(int n, int D, bool bwd) {
 
 static unsigned iag_grid(int64_t B) { return (unsigned)(B < 1 ? 1 : (B > 16384 ? 16384 : B)); }
 
-int g_tzr_ia_bwd_pipe = 0;  // tzr_tune("ia_bwd_pipe"): 1 = the software-pipelined backward (D = 16, n <= 32)
-int g_tzr_ia_bwd_wgs = 0;   // tzr_tune("ia_bwd_wgs"): workgroups of that backward (0 = one per 4 samples, <= 8192)
+int g_tzr_ia_bwd_plain = 0;  // tzr_tune("ia_bwd_plain"): 1 = the backward without the software pipeline (A/B; D = 16, n <= 32)
+int g_tzr_ia_bwd_wgs = 0;    // tzr_tune("ia_bwd_wgs"): workgroups of that backward (0 = one per 4 samples, at most 3 072
+                             // pipelined / 8 192 plain -- profiles/r02x: 114.7 -> 91.5 us per forward + backward pair)
 
 static unsigned ia_grid(int64_t B) {
   const int64_t wg = (B + IA_WAVES - 1) / IA_WAVES;
@@ -735,8 +736,9 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
     return TZR_OK;
   }
   unsigned grid = ia_grid(B);
-  if (g_tzr_ia_bwd_wgs > 0 && (unsigned)g_tzr_ia_bwd_wgs < grid) grid = (unsigned)g_tzr_ia_bwd_wgs;
-  if (g_tzr_ia_bwd_pipe) {
+  const unsigned cap = g_tzr_ia_bwd_wgs > 0 ? (unsigned)g_tzr_ia_bwd_wgs : (g_tzr_ia_bwd_plain ? grid : 3072u);
+  if (cap < grid) grid = cap;
+  if (!g_tzr_ia_bwd_plain) {
     hipLaunchKernelGGL(tzr_dot_interaction_bwd_pipe_kernel, dim3(grid), dim3(IA_THREADS), 0,
                        static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse, sparse_stride, n, hd, B,
                        d_grad_out, grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,

@@ -7,7 +7,7 @@ extern int g_tzr_fwd_tile_b;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
-extern int g_tzr_ia_bwd_pipe;
+extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 
 extern "C" int tzr_tune(const char* name, int value) {
@@ -24,8 +24,8 @@ extern "C" int tzr_tune(const char* name, int value) {
     g_tzr_bwd_one_wg_heavy = value;
     return TZR_OK;
   }
-  if (!strcmp(name, "ia_bwd_pipe")) {
-    g_tzr_ia_bwd_pipe = value;
+  if (!strcmp(name, "ia_bwd_plain")) {
+    g_tzr_ia_bwd_plain = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_wgs")) {
