@@ -517,6 +517,7 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   bwd_force_prep      1: geometry prologue as its own launch (the > 1024 features path)
  *   ia_bwd_plain        1: the D = 16 dot-interaction backward without its software pipeline (A/B switch)
  *   ia_bwd_wgs          workgroups of that backward (0 = by batch size)
+ *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
  *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per
  *                       1024-lookup tile.  Same plan, slower under heavy skew.  Set it when plans are built on a
  *                       stream other than the one the rest of the step runs on (NOTES.md, "Side-stream plan"). */

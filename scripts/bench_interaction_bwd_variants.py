@@ -44,8 +44,15 @@ def main():
         o.backward(go)
         dense.grad = sparse.grad = None
 
+    by_f = 4 * B * (n * D + out.shape[1])
+    for wgs in (0, 4096, 3072, 2048, 1536, 1024):
+        L.tzr_tune(b"ia_fwd_wgs", wgs)
+        o2 = dot_interaction(dense, sparse, D, True, True)
+        t = timed(lambda: dot_interaction(dense, sparse, D, True, True))
+        print(f"B={B} forward wgs={wgs or 'auto':>5}: {t:6.1f} us = {by_f / t / 1e6:4.2f} TB/s   same output: {bool(torch.equal(o2, out))}", flush=True)
+    L.tzr_tune(b"ia_fwd_wgs", 0)
     ref = None
-    for plain, wgs in ((1, 0), (1, 4096), (1, 1536), (0, 0), (0, 8192), (0, 4096), (0, 3072), (0, 2048), (0, 1024), (0, 768)):
+    for plain, wgs in ((1, 0), (0, 0), (0, 8192), (0, 2048)):
         L.tzr_tune(b"ia_bwd_plain", plain)
         L.tzr_tune(b"ia_bwd_wgs", wgs)
         fb_out = dot_interaction(dense, sparse, D, True, True)

@@ -22,6 +22,7 @@ def test_interaction_arch_forward_backward(dev, N, B, plain):
 
     _lib.lib().tzr_tune(b"ia_bwd_plain", plain)
     _lib.lib().tzr_tune(b"ia_bwd_wgs", 0 if plain else 2)  # pipelined: two workgroups walk the whole batch
+    _lib.lib().tzr_tune(b"ia_fwd_wgs", 0 if plain else 3)
     g = torch.Generator().manual_seed(N * 1000 + B)
     x = torch.randn(B, N, 16, generator=g)
     # asymmetric rows so a transposed fragment map cannot pass
@@ -104,7 +105,8 @@ def ia_bwd_variant(request):
     from torcheasyrec_amd import _lib
 
     pipe, wgs = request.param
-    yield lambda: (_lib.lib().tzr_tune(b"ia_bwd_plain", pipe), _lib.lib().tzr_tune(b"ia_bwd_wgs", wgs))
+    yield lambda: (_lib.lib().tzr_tune(b"ia_bwd_plain", pipe), _lib.lib().tzr_tune(b"ia_bwd_wgs", wgs),
+                   _lib.lib().tzr_tune(b"ia_fwd_wgs", wgs))
     if _lib._lib is not None:
         _lib.lib().tzr_tune(b"ia_bwd_plain", 0)
         _lib.lib().tzr_tune(b"ia_bwd_wgs", 0)

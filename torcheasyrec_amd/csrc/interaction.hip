@@ -55,14 +55,25 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_kernel(
   const int wv = threadIdx.x / TZR_WAVE;
   const int r = lane & 15, q = lane >> 4;
   const int P = n * (n - 1) / 2;
-  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += (int64_t)gridDim.x * IA_WAVES) {
+  const int64_t step = (int64_t)gridDim.x * IA_WAVES;
+  // the rows of the wave's NEXT sample are fetched before the current one is contracted and stored (a wave walks
+  // several samples when the grid is smaller than the batch)
+  float4 n0 = tzr_zero4(), n1 = tzr_zero4();
+  {
+    const int64_t b = (int64_t)blockIdx.x * IA_WAVES + wv;
+    if (b < B) {
+      if (r < n) n0 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, r, hd) + 4 * q);
+      if (16 + r < n) n1 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, 16 + r, hd) + 4 * q);
+    }
+  }
+  for (int64_t b0 = (int64_t)blockIdx.x * IA_WAVES; b0 < B; b0 += step) {
     const int64_t b = b0 + wv;
     const bool on = b < B;
-    float4 a0 = tzr_zero4(), a1 = tzr_zero4();
-    if (on) {
-      if (r < n) a0 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, r, hd) + 4 * q);
-      if (16 + r < n)
-        a1 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b, 16 + r, hd) + 4 * q);
+    const float4 a0 = n0, a1 = n1;
+    n0 = n1 = tzr_zero4();
+    if (b + step < B) {
+      if (r < n) n0 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b + step, r, hd) + 4 * q);
+      if (16 + r < n) n1 = tzr_ld4(ia_row(dense, dense_stride, sparse, sparse_stride, b + step, 16 + r, hd) + 4 * q);
     }
     f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c11 = c00;
     const float x0[4] = {a0.x, a0.y, a0.z, a0.w};
@@ -637,6 +648,7 @@ static bool iag_fits(int n, int D, bool bwd) {
 
 static unsigned iag_grid(int64_t B) { return (unsigned)(B < 1 ? 1 : (B > 16384 ? 16384 : B)); }
 
+int g_tzr_ia_fwd_wgs = 0;    // tzr_tune("ia_fwd_wgs"): workgroups of the D = 16 forward (0 = one per 4 samples, <= 8192)
 int g_tzr_ia_bwd_plain = 0;  // tzr_tune("ia_bwd_plain"): 1 = the backward without the software pipeline (A/B; D = 16, n <= 32)
 int g_tzr_ia_bwd_wgs = 0;    // tzr_tune("ia_bwd_wgs"): workgroups of that backward (0 = one per 4 samples, at most 3 072
                              // pipelined / 8 192 plain -- profiles/r02x: 114.7 -> 91.5 us per forward + backward pair)
@@ -680,7 +692,9 @@ extern "C" int tzr_dot_interaction_fwd(const float* d_dense, int64_t dense_strid
     TZR_CHECK_LAUNCH();
     return TZR_OK;
   }
-  hipLaunchKernelGGL(tzr_dot_interaction_fwd_kernel, dim3(ia_grid(B)), dim3(IA_THREADS), 0,
+  unsigned fgrid = ia_grid(B);
+  if (g_tzr_ia_fwd_wgs > 0 && (unsigned)g_tzr_ia_fwd_wgs < fgrid) fgrid = (unsigned)g_tzr_ia_fwd_wgs;
+  hipLaunchKernelGGL(tzr_dot_interaction_fwd_kernel, dim3(fgrid), dim3(IA_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_dense, dense_stride, d_sparse,
                      sparse_stride, n, hd, B, d_out, out_stride, cat_dense, cat_sparse);
   TZR_CHECK_LAUNCH();

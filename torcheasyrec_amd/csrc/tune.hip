@@ -9,6 +9,7 @@ extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
+extern int g_tzr_ia_fwd_wgs;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
@@ -26,6 +27,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "ia_bwd_plain")) {
     g_tzr_ia_bwd_plain = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "ia_fwd_wgs")) {
+    g_tzr_ia_fwd_wgs = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_wgs")) {
