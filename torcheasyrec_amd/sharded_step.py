@@ -85,11 +85,9 @@ class ShardedTrainStep:
         self._slots: Dict[tuple, dict] = {}
         self._next_slot = 0
         self.graph_steps = self.eager_steps = 0
-        if self.step_graph and model.ebc.input_dist_group is None and model.ebc.W > 1:
-            import torch.distributed as dist
-
-            # the ids all-to-all of batch i+1 runs while the captured collectives of batch i replay: its own communicator
-            model.ebc.input_dist_group = dist.new_group(backend=dist.get_backend(model.ebc.pg))
+        # (the ids all-to-all of batch i+1 is issued from the side stream on the collection's own process group, like the
+        # exact exchange's: every RCCL call of the step is eager, torch orders them on the group's stream in issue order --
+        # `ebc.input_dist_group` can name another communicator for it)
 
     # -- dense segment ---------------------------------------------------------------------------
     def _dense_fwd_bwd(self, dense, sparse, label):
