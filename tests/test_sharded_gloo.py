@@ -647,7 +647,7 @@ def test_sharded_sequence_lookup_world2(emu_path):
         mp.spawn(_seq_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
-def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, constraints_in_config=False):
+def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, constraints_in_config=False, exchange="exact"):
     """A config-built rank model over a process group (the DistributedModelParallel seam): logits on my
     slice equal the unsharded model's logits on the same samples; after one step the tables end
     where the unsharded model's end on the GLOBAL batch."""
@@ -680,13 +680,13 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     from torcheasyrec_amd.sharding import make_plan
 
     if constraints_in_config and cfg_name == "din_mini.config":
-        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, use_planner=True)
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, use_planner=True, exchange=exchange)
         assert all("perf" in p for p in shd.embedding_group.ebc.plan().values())  # the pooled tables were placed by the planner
         seq_plan = shd.embedding_group.ecs["16"].sharded.plan()
         assert seq_plan["click_seq__adgroup_id_emb"]["sharding_type"] == "table_wise" and len(seq_plan["click_seq__adgroup_id_emb"]["ranks"]) == 1
         assert seq_plan["click_seq__cate_id_emb"]["sharding_type"] == "row_wise"
     elif constraints_in_config:
-        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD)
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, exchange=exchange)
         sp = shd.embedding_group.ebc.sharding_plan()
         assert sp["cat_0_emb"]["sharding_type"] == "column_wise" and sp["cat_0_emb"]["shard_dim"] == 8 and len(sp["cat_0_emb"]["ranks"]) == 2
         assert sp["cat_0_emb_wide"]["sharding_type"] == "column_wise" and sp["cat_0_emb_wide"]["shard_dim"] == 4
@@ -696,7 +696,7 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     else:
         plan = make_plan(ref.embedding_group.ebc.embedding_bag_configs(), world, dp_max_rows=50)  # big tables row-wise, small replicated
         assert {p["sharding_type"] for p in plan.values()} == {"row_wise", "data_parallel"}
-        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan)
+        shd = build_rank_model(spec, device=dev, process_group=dist.group.WORLD, plan=plan, exchange=exchange)
 
     def pieces(name, D):  # (table name the sharded collection holds, columns of the configured table)
         cw = getattr(shd.embedding_group.ebc, "_cw", {})
@@ -802,13 +802,18 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg,labels,in_config", [("deepfm_mini.config", ["label"], False),
-                                                  ("deepfm_mini.config", ["label"], True), ("din_mini.config", ["clk"], True)])
-def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config):
+@pytest.mark.parametrize("cfg,labels,in_config,exchange", [("deepfm_mini.config", ["label"], False, "exact"),
+                                                           ("deepfm_mini.config", ["label"], True, "exact"),
+                                                           ("din_mini.config", ["clk"], True, "exact"),
+                                                           ("deepfm_mini.config", ["label"], True, "capacity"),
+                                                           ("din_mini.config", ["clk"], True, "capacity")])
+def test_config_model_over_a_process_group(emu_path, cfg, labels, in_config, exchange):
+    """(exchange = "capacity": the fixed-slice ids exchange under config-built models -- DeepFM's mixed lanes, DIN's pooled
+    tables; lanes whose bags are ragged or weighted fall back to the exact exchange per call)"""
     if (cfg, in_config) == ("deepfm_mini.config", False):
         emu_heavy()  # the default suite keeps DeepFM with its plan in the config and the DIN model
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config), nprocs=2, join=True)
+        mp.spawn(_config_worker, args=(2, os.path.join(d, "init"), emu_path, cfg, labels, in_config, exchange), nprocs=2, join=True)
 
 
 def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=False):

@@ -116,9 +116,11 @@ class EmbeddingGroup(nn.Module):
         dp_max_rows: int = 65536,
         global_sharding_types: Sequence[str] = (),
         batch_size: int = 1024,
+        exchange: str = "exact",
         use_planner: bool = False,
     ) -> None:
-        """`process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
+        """`exchange`: "exact" | "capacity" ids exchange of the sharded pooled collections (sharding.py).
+        `process_group`: shard the tables over its ranks (the seam DistributedModelParallel fills in
         the reference, tzrec/main.py:783-804): pooled tables go to a ShardedEmbeddingBagCollection
         (placement from `plan`, e.g. planner.plan_tables, or the size heuristic), sequence tables to
         ShardedEmbeddingCollections, `zch` tables to the hash-routed sharded map.  Pooled tables of one
@@ -226,11 +228,11 @@ class EmbeddingGroup(nn.Module):
 
                     self.ebc = MixedShardedEmbeddingBagCollection(cfg_list, device=device, optimizer=sparse_optimizer, groups=ebc_groups,
                                                                   row_layout=row_layout, process_group=self._pg,
-                                                                  dp_max_rows=self._dp_max_rows, plan=self._plan_in)
+                                                                  dp_max_rows=self._dp_max_rows, plan=self._plan_in, exchange=exchange)
                 else:
                     self.ebc = ShardedEmbeddingBagCollection(cfg_list, device=device, optimizer=sparse_optimizer,
                                                              groups=ebc_groups, row_layout=row_layout, process_group=self._pg,
-                                                             dp_max_rows=self._dp_max_rows, plan=self._plan_in)
+                                                             dp_max_rows=self._dp_max_rows, plan=self._plan_in, exchange=exchange)
         else:
             self.ebc = EmbeddingBagCollection(list(configs.values()), device=device, optimizer=sparse_optimizer,
                                               groups=ebc_groups, row_layout=row_layout) if self.has_sparse else None

@@ -39,6 +39,7 @@ class RankModel(nn.Module):
     _build_pg = None
     _build_plan = None
     _build_use_planner = False
+    _build_exchange = "exact"
 
     def __init__(self, spec: PipelineSpec, device: Optional[torch.device], sparse_optimizer: Optional[SparseOptimizerConfig]) -> None:
         super().__init__()
@@ -50,7 +51,7 @@ class RankModel(nn.Module):
             device=device, sparse_optimizer=sparse_optimizer if sparse_optimizer is not None else spec.sparse_optimizer,
             process_group=self._pg, plan=RankModel._build_plan,
             global_sharding_types=getattr(spec, "global_sharding_types", ()), batch_size=spec.batch_size or 1024,
-            use_planner=RankModel._build_use_planner)
+            use_planner=RankModel._build_use_planner, exchange=RankModel._build_exchange)
 
     def sync_dense_parameters(self) -> None:
         """Same dense parameters on every rank (DDP broadcasts rank 0's at construction)."""
@@ -282,7 +283,7 @@ _MODELS = {"dlrm": ConfigDLRM, "deepfm": ConfigDeepFM, "multi_tower_din": Config
 
 
 def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None, process_group=None,
-                     plan: Optional[Dict[str, dict]] = None, use_planner: bool = False) -> RankModel:
+                     plan: Optional[Dict[str, dict]] = None, use_planner: bool = False, exchange: str = "exact") -> RankModel:
     """Class chosen by the model_config oneof name, as tzrec/main.py:151-153 does.  With
     `process_group` the embedding tables are sharded over its ranks (`plan`: planner.plan_tables output
     or None: the planner under the config's `embedding_constraints` / `global_embedding_constraints` when it has
@@ -291,9 +292,11 @@ def build_rank_model(spec: PipelineSpec, device=None, sparse_optimizer=None, pro
     if spec.model_name not in _MODELS:
         raise NotImplementedError(f"model {spec.model_name!r} is outside SURVEY.md section 8")
     RankModel._build_pg, RankModel._build_plan, RankModel._build_use_planner = process_group, plan, use_planner
+    RankModel._build_exchange = exchange  # "capacity": fixed-slice ids exchange for the sharded pooled tables (sharding.py)
     try:
         model = _MODELS[spec.model_name](spec, device, sparse_optimizer)
     finally:
         RankModel._build_pg, RankModel._build_plan, RankModel._build_use_planner = None, None, False
+        RankModel._build_exchange = "exact"
     model.sync_dense_parameters()
     return model
