@@ -1037,7 +1037,7 @@ def _slots_worker(rank, world, init_file, emu_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_whole_step_slots_equal_the_exact_pipeline(emu_path, world):
     """Six steps through the two pipeline slots of the whole-step path (capacity-bounded exchange, static buffers,
     one overflowing batch redone exactly) = the exact pipelined step, bit for bit: losses, table shards, dense weights."""
