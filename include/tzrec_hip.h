@@ -226,6 +226,12 @@ int tzr_exchange_bucketize_capped(const int32_t* d_sel, int n_sel, const int64_t
                                   const int32_t* d_rank_offsets, int64_t B, int bag_len, int W,
                                   const int64_t* d_values, int64_t capacity, int64_t* d_message,
                                   int64_t* d_unbucketize, void* ws, size_t ws_bytes, void* stream);
+/* The same layout from a DENSE bucketize result (ragged / weighted bags: tzr_block_bucketize): d_counts[W*n_sel] ids per
+ * (rank, key), d_ids[n_ids] rank-major, d_unbucketize[n_ids] = dense position of every lookup -> d_message as above and
+ * d_unbucketize_out[n_ids] = message position of every lookup (may alias d_unbucketize). */
+int tzr_exchange_pad(const int64_t* d_counts, int W, int n_sel, int64_t capacity, const int64_t* d_ids,
+                     const int64_t* d_unbucketize, int64_t n_ids, int64_t* d_message,
+                     int64_t* d_unbucketize_out, void* stream);
 /* Owner side: the received message (W slices of S words, source-rank major) -> key segments over its W*S
  * positions for tzr_rows_gather / tzr_pooled_bwd_plan / _apply (ids pointer = d_message itself):
  *   key s*(n_sel+1)          dead (the words before rank s's ids: unused capacity of rank s-1 + the header)

@@ -57,6 +57,8 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
                             capacity_factor=0.5 if exchange == "overflow" else 1.5)
         if exchange == "overflow":  # no slack: some destination gets more than half the even share
             model.ebc.capacity_slack = 0
+        if mode == "jagged":  # ragged bags (0..3 ids): slices sized for 1.5 ids per bag (0.4 in the overflow case)
+            model.ebc.capacity_bag_len = 0.4 if exchange == "overflow" else 1.5
     kinds = {n: p["sharding_type"] for n, p in model.ebc.plan().items()}
     assert "data_parallel" in kinds.values() and kinds["cat_1_emb"] == "table_wise"
     assert len(model.ebc.plan()["cat_1_emb"]["ranks"]) == 1
@@ -108,9 +110,9 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
         model.allreduce_dense_grads()
         n_dist = 1
     stats = model.ebc.exchange_stats
-    if mode == "jagged" or exchange == "exact":  # ragged / weighted bags always take the exact exchange
+    if exchange == "exact":
         assert stats == {"capacity_batches": 0, "overflow_retries": 0}
-    elif exchange == "capacity":
+    elif exchange == "capacity":  # (ragged / weighted bags: the dense bucketize re-laid by tzr_exchange_pad)
         assert stats == {"capacity_batches": n_dist, "overflow_retries": 0}
     else:  # every rank saw the overflow word and redid the batch through the exact exchange
         assert stats == {"capacity_batches": 0, "overflow_retries": n_dist}
@@ -182,7 +184,8 @@ def test_sharded_dlrm_world2(emu_path, mode, via_step, planner):
                                                           (2, "uniform1", False, "overflow"), (2, "uniform1", True, "overflow"),
                                                           (4, "uniform1", True, "capacity"), (4, "uniform1", False, "overflow"),
                                                           (8, "uniform1", True, "capacity"), (8, "uniform1", True, "overflow"),
-                                                          (2, "jagged", False, "capacity")])
+                                                          (2, "jagged", False, "capacity"), (2, "jagged", True, "capacity"),
+                                                          (2, "jagged", False, "overflow"), (4, "jagged", True, "overflow")])
 def test_sharded_dlrm_capacity_exchange(emu_path, world, mode, via_step, exchange):
     """Capacity-bounded exchange (fixed message slices, one ids all-to-all, no counts through the host): same
     logits / gradients / shards as the unsharded oracle; a batch that does not fit is redone exactly by all ranks."""

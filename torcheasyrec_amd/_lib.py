@@ -105,6 +105,7 @@ _SIGNATURES = {
     "tzr_exchange_bucketize": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "tzr_exchange_message_stride": (_i64, [_i32, _i64]),
     "tzr_exchange_bucketize_capped": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "tzr_exchange_pad": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "tzr_exchange_owner_segments": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "tzr_pooled_fwd": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                               _i32, _i32, _vp]),

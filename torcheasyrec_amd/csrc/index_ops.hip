@@ -553,6 +553,74 @@ extern "C" int tzr_exchange_bucketize_capped(const int32_t* d_sel, int n_sel, co
                    d_message, S, ws, ws_bytes, stream);
 }
 
+// The capacity-bounded layout from a DENSE bucketize result (the general path: ragged / weighted bags go through
+// tzr_block_bucketize, whose output is rank-major without gaps): ids re-laid into the fixed slices, every lookup's
+// position remapped, headers written.  One launch; every workgroup derives the W slice bases from the W*F counts.
+__global__ __launch_bounds__(XB_THREADS) void tzr_xb_pad_kernel(const int64_t* __restrict__ counts /*[W][F]*/, int W, int F,
+                                                                int64_t S, const int64_t* __restrict__ ids,
+                                                                const int64_t* __restrict__ unb, int64_t N,
+                                                                int64_t* __restrict__ msg, int64_t* __restrict__ unb_out) {
+  __shared__ int64_t s_tot[64];
+  __shared__ int64_t s_start[65];
+  __shared__ int s_over;
+  const int64_t cap = S - F - 1;
+  if ((int)threadIdx.x < W) {
+    int64_t t = 0;
+    for (int f = 0; f < F; ++f) t += counts[(int64_t)threadIdx.x * F + f];
+    s_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    int over = 0;
+    for (int d = 0; d < W; ++d) {
+      s_start[d] = run;
+      run += s_tot[d];
+      over |= s_tot[d] > cap;
+    }
+    s_start[W] = run;
+    s_over = over;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && (int)threadIdx.x < W) {  // headers: clamped counts (the first `cap` ids of a slice stay) + flag
+    const int d = threadIdx.x;
+    int64_t run = 0;
+    for (int f = 0; f < F; ++f) {
+      int64_t c = counts[(int64_t)d * F + f];
+      if (c > cap - run) c = cap - run;
+      msg[(int64_t)d * S + f] = c;
+      run += c;
+    }
+    msg[(int64_t)d * S + F] = s_over;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * XB_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * XB_THREADS) {
+    const int64_t p = unb[i];
+    int d = 0;
+    while (d + 1 < W && s_start[d + 1] <= p) ++d;
+    const int64_t off = p - s_start[d];
+    int64_t pos = (int64_t)d * S + F;  // over capacity: dropped
+    if (off < cap) {
+      pos = (int64_t)d * S + F + 1 + off;
+      msg[pos] = ids[p];
+    }
+    unb_out[i] = pos;
+  }
+}
+
+extern "C" int tzr_exchange_pad(const int64_t* d_counts, int W, int n_sel, int64_t capacity, const int64_t* d_ids,
+                                const int64_t* d_unbucketize, int64_t n_ids, int64_t* d_message,
+                                int64_t* d_unbucketize_out, void* stream) {
+  if (!d_counts || W <= 0 || n_sel <= 0 || capacity <= 0 || n_ids < 0 || !d_message) return TZR_ERR_INVALID;
+  if (W > 64) return TZR_ERR_UNSUPPORTED;
+  if (n_ids > 0 && (!d_ids || !d_unbucketize || !d_unbucketize_out)) return TZR_ERR_INVALID;
+  const int64_t S = tzr_exchange_message_stride(n_sel, capacity);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n_ids + XB_THREADS - 1) / XB_THREADS));
+  hipLaunchKernelGGL(tzr_xb_pad_kernel, dim3(grid), dim3(XB_THREADS), 0, static_cast<hipStream_t>(stream), d_counts, W,
+                     n_sel, S, d_ids, d_unbucketize, n_ids, d_message, d_unbucketize_out);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
 // Owner side of the capacity-bounded exchange: the W received message slices -> key segments over the
 // positions [0, W*S) of the received buffer.  Per source rank s: one dead key (the gap before its ids: the
 // previous rank's unused capacity + this slice's header), then its n_sel keys; a last dead key closes the

@@ -239,6 +239,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         self.exchange = exchange
         self.capacity_factor = float(capacity_factor)
         self.capacity_slack = 64  # ids on top of factor x even share (small batches are lumpy)
+        # ragged / weighted bags: slices must have the SAME size on every rank, so they cannot follow a rank's own id
+        # count -- they are sized for this many ids per bag on average (None: such batches take the exact exchange)
+        self.capacity_bag_len: Optional[float] = None
         self.exchange_stats = {"capacity_batches": 0, "overflow_retries": 0}
         self.input_dist_group = None  # process group of the ids all-to-all (default: `process_group`); a step captured
         #                               in a hipGraph replays its collectives while the next batch's input dist runs
@@ -455,10 +458,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
     #   input_dist_begin  bucketize by owner, exchange the per-(rank, key) counts, start their D2H copy
     #   input_dist_end    wait for the counts (the one host sync of a step), ids all-to-all
     #   lookup            owner row gather, rows all-to-all, pooled gather into the output buffers
-    def exchange_capacity(self, n_keys: int, B: int) -> int:
-        """ids one rank may send to one destination per batch in the capacity-bounded exchange"""
-        total = n_keys * B
-        return max(1, min(total, int(np.ceil(self.capacity_factor * total / self.W)) + self.capacity_slack))
+    def exchange_capacity(self, n_keys: int, B: int, n_ids: Optional[int] = None) -> int:
+        """ids one rank may send to one destination per batch in the capacity-bounded exchange (`n_ids`: the
+        batch's id count when bags are ragged; default one id per bag)"""
+        if n_ids is None:
+            total = n_keys * B
+            return max(1, min(total, int(np.ceil(self.capacity_factor * total / self.W)) + self.capacity_slack))
+        # ragged bags: sized from the configured average bag length, NOT from n_ids (which differs between ranks)
+        return max(1, int(np.ceil(self.capacity_factor * n_keys * B * float(self.capacity_bag_len) / self.W)) + self.capacity_slack)
 
     def _slot(self, slot, what: str, shape, dtype, pinned: bool = False) -> torch.Tensor:
         """Persistent buffer `what` of pipeline slot `slot` (None: a fresh tensor).  A captured step reads the
@@ -480,10 +487,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
 
     # the capacity-bounded input dist in its pieces (a pipeline replays the kernel runs from hipGraphs: with a slot
     # every buffer below is persistent, so `cap_state` is host work only)
-    def cap_state(self, st: dict, slot) -> dict:
+    def cap_state(self, st: dict, slot, n_ids: Optional[int] = None) -> dict:
         kjt, rm, W = st["kjt"], st["rm"], self.W
         B, F = kjt.stride(), rm["rw_n"]
-        N, C = F * B, self.exchange_capacity(F, B)
+        N = F * B if n_ids is None else int(n_ids)
+        C = self.exchange_capacity(F, B, n_ids)
         S = int(_lib.lib().tzr_exchange_message_stride(F, C))
         msg = self._slot(slot, "msg", (2, W * S), torch.int64)  # [0] what I send, [1] what I receive
         seg = self._slot(slot, "seg", W * (F + 1) + 3, torch.int64)  # key starts, then the overflow word
@@ -561,6 +569,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 bkt, unb = block_bucketize(sub, rm["rw_blk"], W, return_permute=True, rank_offsets=rm["rw_rot"])
                 torch.sub(bkt.offsets()[B::B], bkt.offsets()[:-1:B], out=cnt[0])
                 bkt_values = bkt.values()
+                if (self.exchange == "capacity" and self.capacity_bag_len is not None and not exact and self._owner_remap is None
+                        and W <= 64 and B > 0):
+                    # ragged / weighted bags: the dense bucketize result re-laid into the fixed slices (tzr_exchange_pad)
+                    self.cap_state(st, slot, n_ids=N)
+                    st["sub"] = sub
+                    _lib.check(_lib.lib().tzr_exchange_pad(_lib.ptr(cnt[0]), W, F, st["cap"], _lib.ptr(bkt_values), _lib.ptr(unb), N,
+                                                           _lib.ptr(st["msg"][0]), _lib.ptr(st["unb"]), _lib.stream_ptr(dev)),
+                               "tzr_exchange_pad")
+                    self.cap_exchange(st)
+                    self.cap_segments(st)
+                    self.cap_flag_event(st)
+                    return st
             self._a2a(cnt[1], cnt[0], None, None)
             recv_cnt = cnt[1]
             if dev.type == "cuda":  # per-rank totals are summed on the host: no extra launches
