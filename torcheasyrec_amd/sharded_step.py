@@ -43,6 +43,13 @@ from .sharding import ShardedDLRM
 from .sparse import KeyedJaggedTensor
 
 
+# Captures here run in a process that owns a process group: its watchdog thread polls the completion events of the
+# eager collectives (hipEventQuery) whenever it wakes up, also while this thread is capturing.  In the default "global"
+# capture mode such a call from ANOTHER thread is an error that takes the process down (one unexplained crash of
+# tests/test_sharded_gpu.py in round 2 fits: rare, timing dependent); "thread_local" only polices the capturing thread.
+_CAPTURE_MODE = "thread_local"
+
+
 class _Segment:
     """Static buffers + captured graph of the dense segment for one batch size."""
 
@@ -126,7 +133,7 @@ class ShardedTrainStep:
                                    "non-default stream (torch.cuda.set_stream)")
             seg.loss = seg.logits = seg.grads = None
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cur):
+            with torch.cuda.graph(g, stream=cur, capture_error_mode=_CAPTURE_MODE):
                 seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
             seg.graph = g
         seg.graph.replay()
@@ -197,11 +204,11 @@ class ShardedTrainStep:
                 ebc.cap_segments(st)
             else:
                 g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g0, stream=self._side):
+                with torch.cuda.graph(g0, stream=self._side, capture_error_mode=_CAPTURE_MODE):
                     ebc.cap_bucketize(st)
                 g0.replay()
                 ebc.cap_exchange(st)
-                with torch.cuda.graph(g1, stream=self._side):
+                with torch.cuda.graph(g1, stream=self._side, capture_error_mode=_CAPTURE_MODE):
                     ebc.cap_segments(st)
                     if self.plan_ahead:
                         ebc.plan_ahead(st)
@@ -333,7 +340,7 @@ class ShardedTrainStep:
         for i, (seg, coll) in enumerate(zip(segs, colls)):
             if capture:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device)):
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device), capture_error_mode=_CAPTURE_MODE):
                     seg(st, sl)
                 graphs.append(g)
                 g.replay()
