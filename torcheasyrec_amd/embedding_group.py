@@ -530,6 +530,13 @@ class GraphTrainPipeline:
         Queued first, the copy did not overlap the replay at all (1.21 ms per step at B = 65 536 = step + copy);
         queued after the launch it hides under it (0.88 ms; profiles/r02u)."""
         self._stage_first = bool(stage_first)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # a sharded model's step contains RCCL calls; captured into a hipGraph they took the process down on this
+            # stack (profiles/r02p) -- sharded_step.ShardedTrainStep(step_graph=True) cuts the step at its collectives
+            raise RuntimeError("GraphTrainPipeline captures the whole step in one hipGraph: single-process models only "
+                               "(sharded models: sharded_step.ShardedTrainStep)")
         self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
         assert self._device.type == "cuda", "GraphTrainPipeline replays hipGraphs: CUDA/HIP device only"
         self._copy_stream = torch.cuda.Stream(device=self._device)
