@@ -944,6 +944,17 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
         other = MixedShardedEmbeddingBagCollection([EmbeddingBagConfig(n, d, r, f) for n, d, r, f in spec], device=dev, optimizer=opt,
                                                    groups=groups, dp_max_rows=0, constraints={"cw_c": "column_wise", "wide_b": "table_wise"})
         restore_checkpoint(ck, Holder(other))
+        # ... and the same through torch.distributed.checkpoint (one ShardedTensor per virtual table), into a third placement
+        ck2 = os.path.join(os.path.dirname(init_file), "ckpt_dcp")
+        save_checkpoint(ck2, Holder(sh), tables_format="dcp")
+        third = MixedShardedEmbeddingBagCollection([EmbeddingBagConfig(n, d, r, f) for n, d, r, f in spec], device=dev, optimizer=opt,
+                                                   groups=groups, dp_max_rows=0, constraints={"cw_c": "column_wise", "deep_a": "table_wise"})
+        restore_checkpoint(ck2, Holder(third))
+        for n_, w in third.table_weights().items():
+            lo3, n3 = third.shard_of(n_)
+            lo1, n1 = other.shard_of(n_)
+            if n3 and (lo3, n3) == (lo1, n1):  # same rows held by both restored collections: same values
+                assert torch.equal(w.detach()[:n3], other.table_weights()[n_].detach()[:n1]), n_
 
         def full(m, what):
             out = {}
