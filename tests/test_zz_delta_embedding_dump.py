@@ -278,7 +278,7 @@ def test_zch_table_publishes_raw_ids_with_the_row_served_now(dev):
                 assert rows == [1, 3, 3, 2]  # 5 keeps row 1, 900 took evicted 77's row 2, 42 and 77 are served by the shared row
 
 
-def _sharded_worker(rank, world, init_file, emu_path, out_dir):
+def _sharded_worker(rank, world, init_file, emu_path, out_dir, exchange="exact"):
     """Row-wise shards + a replicated table over two ranks: every rank dumps the rows IT serves (global
     key ids = local row + the shard's row offset); the union over ranks of the row-wise tables is the set
     of ids of the global batch; replicated tables report each rank's own lookups."""
@@ -297,7 +297,8 @@ def _sharded_worker(rank, world, init_file, emu_path, out_dir):
         def __init__(self):
             super().__init__()
             self.sh = ShardedEmbeddingBagCollection(cfgs, device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1),
-                                                    groups={"g": keys}, dp_max_rows=10)
+                                                    groups={"g": keys}, dp_max_rows=10, exchange=exchange)
+            self.sh.capacity_bag_len = 1.5  # ragged bags (0..2 ids): slice size of the capacity-bounded exchange
 
     m = M()
     assert {p["sharding_type"] for p in m.sh.plan().values()} == {"row_wise", "data_parallel"}
@@ -316,6 +317,8 @@ def _sharded_worker(rank, world, init_file, emu_path, out_dir):
         m.sh.forward_grouped(mine)["g"].sum().backward()
         if step in (2, 3):  # a dump after steps 1-2 and a final one after step 3
             pubs[step] = tr.published_rows()
+    if exchange == "capacity":  # the tracker saw the owner's key segments of the padded message (dead keys skipped)
+        assert m.sh.exchange_stats["capacity_batches"] == 3 and m.sh.exchange_stats["overflow_retries"] == 0
     for step, window in ((2, (0, 1)), (3, (2,))):
         for f, name in enumerate(["t0", "t1", "t2"]):
             lo, n = m.sh.shard_of(name)
@@ -332,13 +335,14 @@ def _sharded_worker(rank, world, init_file, emu_path, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_dump_world2(emu_path, tmp_path):
+@pytest.mark.parametrize("exchange", ["exact", "capacity"])
+def test_sharded_dump_world2(emu_path, tmp_path, exchange):
     import tempfile
 
     import torch.multiprocessing as mp
 
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_sharded_worker, args=(2, os.path.join(d, "init"), emu_path, str(tmp_path / "out")), nprocs=2, join=True)
+        mp.spawn(_sharded_worker, args=(2, os.path.join(d, "init"), emu_path, str(tmp_path / "out"), exchange), nprocs=2, join=True)
 
 
 @pytest.mark.gpu
