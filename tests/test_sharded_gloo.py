@@ -412,7 +412,7 @@ def test_sharded_sparse_adam_world2(emu_path):
         mp.spawn(_adam_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
-def _frozen_worker(rank, world, init_file, emu_path):
+def _frozen_worker(rank, world, init_file, emu_path, exchange="exact"):
     """`trainable: false` through the sharded exchange (tzrec/features/feature.py:629): a frozen row-wise
     table and a frozen replicated table stay bit-identical on every rank while their trainable twins end
     where the unsharded collection ends (the sharded copies of the configs dropped the flag)."""
@@ -436,7 +436,8 @@ def _frozen_worker(rank, world, init_file, emu_path):
     cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t), trainable=not frozen[t])  # noqa: E731
                     for t, r in enumerate(rows)]
     opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
-    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10, exchange=exchange,
+                                       capacity_factor=4.0)  # (the ids below all fall into rank 0's block: 2x the even share)
     kinds = [sh.plan()[f"t{t}"]["sharding_type"] for t in range(4)]
     assert kinds == ["row_wise", "row_wise", "data_parallel", "data_parallel"]
     ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
@@ -453,6 +454,8 @@ def _frozen_worker(rank, world, init_file, emu_path):
         torch.testing.assert_close(out.detach(), out_ref.detach()[rank * Bl:(rank + 1) * Bl], rtol=1e-5, atol=1e-6)
         (out * g[rank * Bl:(rank + 1) * Bl]).sum().backward()
         (out_ref * g).sum().backward()
+    if exchange == "capacity":  # frozen tables' lookups AND the padded message's dead keys are left out of the plan
+        assert sh.exchange_stats == {"capacity_batches": 2, "overflow_retries": 0}
     for t in range(4):
         name = f"t{t}"
         lo, n = sh.shard_of(name)
@@ -467,9 +470,10 @@ def _frozen_worker(rank, world, init_file, emu_path):
     dist.destroy_process_group()
 
 
-def test_sharded_frozen_tables_world2(emu_path):
+@pytest.mark.parametrize("exchange", ["exact", "capacity"])
+def test_sharded_frozen_tables_world2(emu_path, exchange):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_frozen_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+        mp.spawn(_frozen_worker, args=(2, os.path.join(d, "init"), emu_path, exchange), nprocs=2, join=True)
 
 
 def _zch_worker(rank, world, init_file, emu_path):
