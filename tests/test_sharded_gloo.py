@@ -358,7 +358,7 @@ def test_sharded_fp16_tables_world2(emu_path):
         mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
 
 
-def _adam_worker(rank, world, init_file, emu_path):
+def _adam_worker(rank, world, init_file, emu_path, exchange="exact"):
     """Sparse Adam through the sharded exchange: row-wise shards and the replicated table share ONE step
     counter advanced once per backward, so after three steps every shard equals the unsharded collection's
     rows (oracle-checked in tests/test_pooled_parity.py::test_backward_sparse_adam) on the global batches."""
@@ -381,7 +381,8 @@ def _adam_worker(rank, world, init_file, emu_path):
 
     cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t)) for t, r in enumerate(rows)]  # noqa: E731
     opt = SparseOptimizerConfig(kind="adam", lr=0.05, beta1=0.8, beta2=0.9, weight_decay=0.01)
-    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10, exchange=exchange,
+                                       capacity_factor=4.0)  # (ids < 25 all live in rank 0's block)
     assert {p["sharding_type"] for p in sh.plan().values()} == {"row_wise", "data_parallel"}
     ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
     rng = np.random.default_rng(0)
@@ -398,6 +399,10 @@ def _adam_worker(rank, world, init_file, emu_path):
         (out * g[rank * Bl:(rank + 1) * Bl]).sum().backward()
         (out_ref * g).sum().backward()
     assert float(sh.fused_optimizer.adam_state(dev)[0]) == 3.0 == float(ref.fused_optimizer.adam_state(dev)[0])
+    if exchange == "capacity":
+        # Adam moves a row even on a zero gradient: the unused slots of the padded message must never reach the
+        # optimizer (dead keys), or rows nobody looked up would drift
+        assert sh.exchange_stats == {"capacity_batches": 3, "overflow_retries": 0}
     for t in range(len(rows)):
         name = f"t{t}"
         lo, n = sh.shard_of(name)
@@ -407,9 +412,10 @@ def _adam_worker(rank, world, init_file, emu_path):
     dist.destroy_process_group()
 
 
-def test_sharded_sparse_adam_world2(emu_path):
+@pytest.mark.parametrize("exchange", ["exact", "capacity"])
+def test_sharded_sparse_adam_world2(emu_path, exchange):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_adam_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+        mp.spawn(_adam_worker, args=(2, os.path.join(d, "init"), emu_path, exchange), nprocs=2, join=True)
 
 
 def _frozen_worker(rank, world, init_file, emu_path, exchange="exact"):
