@@ -301,7 +301,7 @@ def test_checkpoint_reshards_across_plans(emu_path, tables_format):
                  join=True)
 
 
-def _fp16_worker(rank, world, init_file, emu_path):
+def _fp16_worker(rank, world, init_file, emu_path, exchange="exact"):
     """FP16 tables through the sharded exchange (row-wise shards + a replicated table) must end where
     the unsharded FP16 collection ends on the same global batch (that path is oracle-checked in
     tests/test_pooled_parity.py::test_fp16_tables)."""
@@ -326,7 +326,8 @@ def _fp16_worker(rank, world, init_file, emu_path):
     cfgs = lambda: [EmbeddingBagConfig(f"t{t}", 16, r, [keys[t]], init_fn=seeded(t), data_type="FP16" if t != 1 else "FP32")  # noqa: E731
                     for t, r in enumerate(rows)]
     opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
-    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10)
+    sh = ShardedEmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys}, dp_max_rows=10, exchange=exchange,
+                                       capacity_factor=4.0)
     assert {p["sharding_type"] for p in sh.plan().values()} == {"row_wise", "data_parallel"}
     ref = EmbeddingBagCollection(cfgs(), device=dev, optimizer=opt, groups={"g": keys})
     rng = np.random.default_rng(0)
@@ -353,9 +354,10 @@ def _fp16_worker(rank, world, init_file, emu_path):
     dist.destroy_process_group()
 
 
-def test_sharded_fp16_tables_world2(emu_path):
+@pytest.mark.parametrize("exchange", ["exact", "capacity"])
+def test_sharded_fp16_tables_world2(emu_path, exchange):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+        mp.spawn(_fp16_worker, args=(2, os.path.join(d, "init"), emu_path, exchange), nprocs=2, join=True)
 
 
 def _adam_worker(rank, world, init_file, emu_path, exchange="exact"):
