@@ -121,6 +121,66 @@ def test_forward_uniform1_bitexact(dev, B):
     assert torch.equal(out.values().cpu(), ref)  # a copy: bit-exact
 
 
+@pytest.mark.parametrize("tile_b", [0, 8, 32, 64])
+def test_forward_uniform1_lds_ids_kernel(dev, tile_b):
+    """The one-id-per-bag kernel that stages a tile's ids in LDS (tzr_pooled_fwd_u1_kernel): more slots
+    than one workgroup row holds (3 rows of 128), mixed dims, a key read through two tables and copied
+    into two groups, a key of the batch nobody reads, out-of-range ids (-> row 0), sub-tiled id passes
+    (groups x tile > 1024) and a ragged last tile -- bit-exact against the oracle and against the
+    general kernel (tzr_tune fwd_variant = 1)."""
+    from torcheasyrec_amd import _lib
+
+    rng = np.random.default_rng(100 + tile_b)
+    B = 77
+    dims = [16, 4, 8, 32]
+    spec, keys, rows = [], [], []
+    for i in range(44):
+        r = 50 if i == 3 else int(rng.integers(1, 400))
+        spec.append((f"t{i}", r, dims[i % 4], "sum", [f"k{i}"]))
+        keys.append(f"k{i}")
+        rows.append(r)
+    spec.append(("t_second", 50, 16, "sum", ["k3"]))  # k3 read through two tables
+    keys.insert(5, "nobody")
+    rows.insert(5, 9)
+    cfgs, inits = _make_tables(spec)
+    feats = [f"k{i}" if i != 3 else "k3@t3" for i in range(44)] + ["k3@t_second"]
+    groups = {"all": feats, "some": [feats[7], feats[44], feats[0], feats[3]]}
+    ebc = EmbeddingBagCollection(cfgs, device=dev, groups=groups)
+    kjt = _make_kjt(keys, rows, B, rng)
+    v = kjt.values().clone()
+    v[rng.integers(0, v.numel(), size=9)] = 10 ** 9  # out of range: read row 0
+    v[0] = -1
+    kjt = KeyedJaggedTensor(keys, v, kjt.lengths(), uniform_length=1)
+    L = _lib.lib()
+    assert L.tzr_tune(b"fwd_tile_b", tile_b) == 0
+    out = {g: t.cpu() for g, t in ebc.forward_grouped(kjt.to(dev)).items()}
+    assert L.tzr_tune(b"fwd_variant", 1) == 0
+    try:
+        gen = {g: t.cpu() for g, t in ebc.forward_grouped(kjt.to(dev)).items()}
+    finally:
+        L.tzr_tune(b"fwd_variant", 0)
+    safe = v.clone()
+    for i, r in enumerate(rows):
+        seg = safe[i * B:(i + 1) * B]
+        seg[(seg < 0) | (seg >= r)] = 0
+    blocks, _ = _oracle_blocks(spec, inits, KeyedJaggedTensor(keys, safe, kjt.lengths(), uniform_length=1), _lookup_list(spec))
+    ref = orc.regroup(blocks, groups)
+    for g in groups:
+        assert torch.equal(out[g], ref[g]), g
+        assert torch.equal(gen[g], ref[g]), g
+
+
+def test_forward_uniform1_single_slot(dev):
+    """One table of dim 4 = one float4 slot per sample (the k / n_slots quotient of the LDS-ids kernel at n = 1)."""
+    rng = np.random.default_rng(2)
+    spec = [("w", 23, 4, "sum", ["k"])]
+    cfgs, inits = _make_tables(spec)
+    ebc = EmbeddingBagCollection(cfgs, device=dev)
+    kjt = _make_kjt(["k"], [23], 1000, rng)
+    out = ebc(kjt.to(dev))
+    assert torch.equal(out.values().cpu(), inits["w"][kjt.values()])
+
+
 SPEC_MIXED = [
     ("u_emb", 1000, 16, "sum", ["user", "user_hist"]),  # shared table, two keys
     ("i_emb", 57, 8, "mean", ["item"]),

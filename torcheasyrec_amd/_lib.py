@@ -176,6 +176,18 @@ def use_library(path: str) -> None:
                        "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = loaded
     _backend = _lib.tzr_backend().decode()
+    apply_env_tune()
+
+
+def apply_env_tune() -> None:
+    """Experiment knobs from the environment: TZR_TUNE="name=value,name=value" (tzr_tune of include/tzrec_hip.h)."""
+    spec = os.environ.get("TZR_TUNE", "")
+    if not spec or _lib is None:
+        return
+    for kv in spec.split(","):
+        name, _, val = kv.partition("=")
+        if _lib.tzr_tune(name.strip().encode(), int(val)) != TZR_OK:
+            raise TzrError(f"TZR_TUNE: unknown knob {name!r}")
 
 
 def use_native() -> None:

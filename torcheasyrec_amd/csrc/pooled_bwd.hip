@@ -1077,16 +1077,22 @@ __device__ __forceinline__ void bwd_sort_heavy_hot(const TzrTable* __restrict__ 
   }
 }
 
+__global__ void tzr_bwd_nop_kernel(uint32_t* p) {
+  if (p == nullptr && threadIdx.x == 12345u) *p = 0;  // never true: an empty launch = one more kernel boundary
+}
+
+// first_block: offset added to blockIdx.x (the debug split launches the heavy workers on their own)
 __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_kernel(
-    const TzrTable* __restrict__ tables, int n_units, BwdPlan P) {
+    const TzrTable* __restrict__ tables, int n_units, unsigned first_block, unsigned total_blocks, BwdPlan P) {
   __shared__ BwdSortLds S;
-  if ((int)blockIdx.x < n_units) {
-    bwd_sort_unit(tables, P, S, (int)blockIdx.x);
+  const unsigned bid = blockIdx.x + first_block;
+  if ((int)bid < n_units) {
+    bwd_sort_unit(tables, P, S, (int)bid);
     return;
   }
   const unsigned nh = P.hcount[0];
-  const unsigned workers = gridDim.x - (unsigned)n_units;
-  for (unsigned hi = blockIdx.x - (unsigned)n_units; hi < nh; hi += workers) {
+  const unsigned workers = total_blocks - (unsigned)n_units;
+  for (unsigned hi = bid - (unsigned)n_units; hi < nh; hi += workers) {
     const BwdHeavy H = P.hlist[hi];
     if (H.tile < 0) bwd_sort_heavy_serial(tables, P, S, H);
     else if (H.pad[0]) bwd_sort_heavy_hot(tables, P, S, H);
@@ -1101,6 +1107,7 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_
 int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO geometry path
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
+int g_tzr_bwd_debug = 0;         // tzr_tune("bwd_debug"): bit 0/2 empty launch before/behind the sort, bit 1 sort split in two launches
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
                                    const TzrFeature* d_feats, int n_feats, int n_keys,
@@ -1145,8 +1152,19 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                      n_tables, A, P);
   const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);
-  hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
-                     (int)chunks, P);
+  if (g_tzr_bwd_debug & 1)  // one more kernel boundary between the partition pass and the sort
+    hipLaunchKernelGGL(tzr_bwd_nop_kernel, dim3(1), dim3(64), 0, s, P.hcount);
+  if (g_tzr_bwd_debug & 2) {  // units and heavy workers as two launches
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, (int)chunks, 0u,
+                       chunks + workers, P);
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(workers), dim3(BWD_THREADS), 0, s, d_tables, (int)chunks, chunks,
+                       chunks + workers, P);
+  } else {
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
+                       (int)chunks, 0u, chunks + workers, P);
+  }
+  if (g_tzr_bwd_debug & 4)  // ... and one behind the sort
+    hipLaunchKernelGGL(tzr_bwd_nop_kernel, dim3(1), dim3(64), 0, s, P.hcount);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

@@ -4,9 +4,12 @@
 #include "tzr_common.h"
 
 extern int g_tzr_fwd_tile_b;
+extern int g_tzr_fwd_variant;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
+extern int g_tzr_bwd_debug;
+extern int g_tzr_bwd_apply_pipe;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_fwd_wgs;
@@ -17,12 +20,24 @@ extern "C" int tzr_tune(const char* name, int value) {
     g_tzr_fwd_tile_b = value;
     return TZR_OK;
   }
+  if (!strcmp(name, "fwd_variant")) {
+    g_tzr_fwd_variant = value;
+    return TZR_OK;
+  }
   if (!strcmp(name, "bwd_ch")) {
     g_tzr_bwd_ch = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_one_wg_heavy")) {
     g_tzr_bwd_one_wg_heavy = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_apply_pipe")) {
+    g_tzr_bwd_apply_pipe = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_debug")) {
+    g_tzr_bwd_debug = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_plain")) {
