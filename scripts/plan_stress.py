@@ -122,7 +122,7 @@ def main():
     total_bad = 0
     for case in cases:
         mode, *knobs = case.split(":")
-        for name in (b"bwd_debug", b"bwd_one_wg_heavy", b"bwd_ch"):
+        for name in (b"bwd_one_wg_heavy", b"bwd_ch"):
             L.tzr_tune(name, 0)
         for kv in knobs:
             name, v = kv.split("=")

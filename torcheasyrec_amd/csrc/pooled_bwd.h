@@ -13,7 +13,9 @@
 #define BWD_TH 256   // a bucket with more lookups is "heavy": sorted by the heavy kernel, cut at blocks
 #define BWD_UMAX (BWD_CH + BWD_TH)  // capacity of one unit of the apply: < BWD_CH + BWD_TH lookups
 #define BWD_HT 1024  // tile of the heavy-bucket sort (4 rounds per wave: every role of the sort kernel within 64 VGPRs)
-#define BWD_GEO 1024 // lookups / tables up to which every hist workgroup derives the geometry itself
+#define BWD_GEO 1024 // lookups / tables up to which every partition workgroup derives the geometry itself
+#define BWD_LROW (BWD_NB + 4)  // uint16 entries per chunk row of bucket starts (NB + 1 used; 8-byte stores)
+#define BWD_SEGB 256           // chunks per batch when a bucket range is gathered from the chunk slabs
 #define BWD_MAXDIM 256
 #define BWD_SENT 0xFFFFFFFFu  // never a row id
 
@@ -22,27 +24,37 @@
 #define BWD_LEAD_WHOLE 2u  // ... and does not end inside it
 #define BWD_TRAIL 4u       // the last run continues past the end of this span
 
-// Everything a workgroup needs to know about its chunk, written once by the hist kernel: one
+// Everything a workgroup needs to know about its chunk, written once by the partition kernel: one
 // load instead of a binary search over the chunk map plus dependent table lookups at the head of
 // every scatter / reduce workgroup (these kernels are latency-, not bandwidth-bound).
-// Chunk c of a table is (a) the c-th block of BWD_CH table-major INPUT positions for hist / scatter
-// and (b) the c-th UNIT of sorted positions [ucut[c], ucut[c+1]) for reduce / stitch.
+// Chunk c of a table is (a) the c-th block of BWD_CH table-major INPUT positions for the partition
+// kernel (its slab) and (b) the c-th UNIT of sorted positions [ucut[c], ucut[c+1]) for sort / reduce.
 struct BwdChunkDesc {
   int32_t t;           // table, -1 for surplus chunks
   int32_t nb;          // buckets of the table's partition pass (<= BWD_NB)
-  int32_t exact;       // every bucket is one row id: the partition pass alone is the sort
+  int32_t exact;       // every bucket is one row id
   int32_t last_chunk;  // first chunk of the NEXT table (stitch walks up to it)
+  int32_t first_chunk; // first chunk of this table
+  int32_t pad;
   int64_t s, e;        // input positions [s, e) of the chunk
   int64_t ts, te;      // positions of the whole table
   uint64_t mult;       // bucket of row id k = (k * mult) >> 32 (monotone in k)
 };
 
-struct BwdHeavy {  // work item of the sort kernel: heavy bucket `bin` of table t = positions [start, end)
+// Work item of the sort kernel: heavy bucket `bin` of table t = sorted positions [start, binbase[bin+1]).
+// Its lookups sit in the chunk slabs of the table (bucket `bin` of every chunk, in chunk order =
+// table-major order); a TILE is the lookups of chunks [c_begin, c_end) (relative to the table's first
+// chunk): `nt` <= BWD_HT of them, `prefix` lookups of the bucket ahead of it.
+#define BWD_HK_ONEPASS 0  // bucket of <= BWD_NB row ids: one counting pass, tile-parallel
+#define BWD_HK_HOT 1      // wide bucket with more than one tile: split around its hot row, tile-parallel
+#define BWD_HK_SERIAL 2   // the whole bucket by one workgroup (c_begin = 0, c_end = chunks of the table)
+#define BWD_HK_COPY 3     // bucket = one row (exact table): the tile is copied, chunk order IS the order
+struct BwdHeavy {
   int32_t t;
-  uint32_t bin, start, end;
-  int32_t tile;  // >= 0: BWD_HT-tile of a bucket one counting pass sorts (<= BWD_NB row ids);
-                 // -1: the whole bucket, several passes, one workgroup
-  int32_t pad[3];
+  uint32_t bin, start, nt;
+  int32_t c_begin, c_end;
+  uint32_t prefix;
+  int32_t kind;
 };
 
 struct BwdPlan {  // pointers into the caller workspace
@@ -50,16 +62,19 @@ struct BwdPlan {  // pointers into the caller workspace
   int32_t* feat_key;       // [F] KJT key of the lookup with that order
   int32_t* feat_by_order;  // [F]
   int32_t* tab_chunk;      // [T+1] first chunk of each table
-  uint2* ks[2];            // [N] {local row id, original lookup position}: ks[1] holds the bucket-
-                           //     partitioned lookups (final for exact tables), ks[0] the sorted ones
-                           //     of every other table; one 8-byte element = ONE store per move
+  uint2* ks[3];            // [N] {local row id, original lookup position}: ks[1] holds the chunk SLABS
+                           //     (chunk c = input positions [s, e) of its table, stably ordered by bucket
+                           //     inside the chunk), ks[0] the sorted lookups of every table, ks[2] is the
+                           //     ping-pong scratch of the serial heavy path; 8-byte elements = ONE store per move
   uint32_t* bag_of;        // [NV] bag index key*B+b of every lookup (only when bags are jagged)
-  uint32_t* hist;          // [max_chunks * BWD_NB] chunk-exclusive bucket counts
+  uint16_t* lst;           // [max_chunks * BWD_LROW] slab-local start of every bucket of every chunk (+ total)
   uint32_t* binbase;       // [T * (BWD_NB+1)] global start of every (table, bucket), end of the last
   uint32_t* ucut;          // [max_chunks + 1] first sorted position of every unit
-  uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (exact table / inside one heavy bucket)
+  uint32_t* ub0;           // [max_chunks + 1] first bucket a unit may hold light lookups of
+  uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (the unit lies inside one heavy bucket)
   uint32_t* hbits;         // [T * BWD_NB/32] bitmap of the heavy buckets of every table
-  uint32_t* hcount;        // [1] work items listed
+  uint32_t* tarr;          // [T] chunks of the table that have published their slab (zeroed before the launch)
+  uint32_t* hcount;        // [1] work items listed (tarr + T: zeroed by the same memset)
   uint32_t* tab_stitch;    // [T] 1 = the table holds sorted buckets: runs may cross unit boundaries
   uint32_t* sexp;          // [T * BWD_NB] units overlapping the (sorted) bucket when > 1, else 0
   uint32_t* sarr;          // [T * BWD_NB] ... of which have published their boundary record (apply)
@@ -96,19 +111,22 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   BwdPlan q;
   q.ch = bwd_pick_ch(N);
   q.max_chunks = bwd_max_chunks(N, T, q.ch);
-  q.max_heavy = N / (BWD_TH + 1) + N / BWD_HT + 1;
+  // every heavy bucket is at least one item; greedy tiles of whole chunks: any two neighbours hold more than BWD_HT
+  q.max_heavy = N / (BWD_TH + 1) + 2 * (N / BWD_HT) + 2;
   q.feat_start = c.take<uint32_t>(F + 1);
   q.feat_key = c.take<int32_t>(F);
   q.feat_by_order = c.take<int32_t>(F);
   q.tab_chunk = c.take<int32_t>(T + 1);
-  for (int i = 0; i < 2; ++i) q.ks[i] = c.take<uint2>(N);
+  for (int i = 0; i < 3; ++i) q.ks[i] = c.take<uint2>(N);
   q.bag_of = c.take<uint32_t>(NV);
-  q.hist = c.take<uint32_t>(q.max_chunks * BWD_NB);
+  q.lst = c.take<uint16_t>((size_t)q.max_chunks * BWD_LROW);
   q.binbase = c.take<uint32_t>((size_t)T * (BWD_NB + 1));
   q.ucut = c.take<uint32_t>(q.max_chunks + 1);
+  q.ub0 = c.take<uint32_t>(q.max_chunks + 1);
   q.uflag = c.take<uint32_t>(q.max_chunks);
   q.hbits = c.take<uint32_t>((size_t)T * (BWD_NB / 32));
-  q.hcount = c.take<uint32_t>(4);
+  q.tarr = c.take<uint32_t>((size_t)T + 4);
+  q.hcount = q.tarr + T;
   q.tab_stitch = c.take<uint32_t>(T);
   q.sexp = c.take<uint32_t>((size_t)T * BWD_NB);
   q.sarr = c.take<uint32_t>((size_t)T * BWD_NB);
@@ -174,7 +192,10 @@ __device__ __forceinline__ void bwd_rank_tile(const uint32_t (&dig)[MAXR], uint3
   const int wv = tid / TZR_WAVE;
   for (int i = tid; i < BWD_WAVES * NB_; i += BWD_THREADS) (&L.wcnt[0][0])[i] = 0;
   __syncthreads();
-  volatile uint16_t* wrow = L.wcnt[wv];
+  // (accessed as LDS, never through a generic pointer: a `volatile uint16_t*` here made this hipcc emit
+  // an illegal compare against src_shared_base once the sort kernel grew; the asm statements keep the
+  // compiler from moving the read past the write, the LDS keeps a wave's accesses in order)
+  uint16_t* wrow = L.wcnt[wv];
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t loc[MAXR];
 #pragma unroll
@@ -191,9 +212,13 @@ __device__ __forceinline__ void bwd_rank_tile(const uint32_t (&dig)[MAXR], uint3
       }
       const uint32_t rank = (uint32_t)__popcll(peers & lt);
       const uint32_t pre = v ? (uint32_t)wrow[d] : 0u;
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
       if (v && rank == 0) wrow[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
       loc[r] = pre + rank;
     }
   }

@@ -335,9 +335,7 @@ __device__ __forceinline__ void bwd_reduce_body(
     if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;  // overlaps no bucket: nobody waits for it
     return;
   }
-  // exact tables are final after the partition pass (ks[1]); everything else was finished by the
-  // sort kernel (ks[0])
-  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
+  const uint2* __restrict__ KS = P.ks[0];  // the sort kernel's output
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) {

@@ -1,0 +1,392 @@
+// The partition pass of the backward plan (K6, see pooled_bwd.hip) as device functions: included by
+// pooled_bwd.hip (its own launch) and by pooled_fwd.hip (the same workgroups inside the forward's
+// launch: the pass depends on the ids only and its ~15 us of latency-bound work disappear under the
+// forward's memory traffic).
+#pragma once
+#include <tzr_gfx950.h>
+
+#include "pooled_bwd.h"
+
+
+struct BwdSrcArgs {
+  const TzrFeature* feats;
+  const int64_t* values;
+  const int64_t* offsets;
+  int64_t B;
+  int uniform;
+};
+
+struct BwdGeo {  // table-major geometry, in LDS (fused) or in the workspace
+  const uint32_t* fstart;  // [F+1]
+  const int32_t* fkey;     // [F]
+  const int32_t* tchunk;   // [T+1]
+};
+
+// In-place exclusive scan of a[0..n) by the whole workgroup; a[n] = total.
+__device__ __forceinline__ void bwd_block_scan(uint32_t* a, int n, uint32_t* wtot) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (TZR_WAVE - 1);
+  const int wv = tid / TZR_WAVE;
+  uint32_t carry = 0;
+  for (int base = 0; base < n; base += BWD_THREADS) {
+    const int i = base + tid;
+    const uint32_t v = i < n ? a[i] : 0u;
+    uint32_t incl = v;
+    for (int dd = 1; dd < TZR_WAVE; dd <<= 1) {
+      const uint32_t o = __shfl_up(incl, dd, TZR_WAVE);
+      if (lane >= dd) incl += o;
+    }
+    if (lane == TZR_WAVE - 1) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t pre = carry, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      if (w < wv) pre += wtot[w];
+      tot += wtot[w];
+    }
+    if (i < n) a[i] = pre + incl - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) a[n] = carry;
+  __syncthreads();
+}
+
+struct BwdGeoLds {
+  uint32_t fstart[BWD_GEO + 1];
+  int32_t fkey[BWD_GEO];
+  uint32_t tchunk[BWD_GEO + 1];
+  uint32_t wtot[BWD_WAVES];
+};
+
+// Table-major segment starts and the chunk map, derived by every hist workgroup on its own
+// (F + T small loads and two block scans) so that the plan needs no single-workgroup launch ahead
+// of it.  Keys of the KJT this module does not own (table < 0) are ordered last and contribute
+// nothing.
+__device__ __forceinline__ void bwd_geometry(const TzrTable* __restrict__ tables, int T,
+                                             const BwdSrcArgs& A, int F, uint32_t ch, BwdGeoLds& G) {
+  for (int f = threadIdx.x; f < F; f += BWD_THREADS) {
+    const TzrFeature ft = A.feats[f];
+    const int64_t key = ft.key;
+    const int64_t n =
+        ft.table < 0 ? 0 : (A.uniform ? A.B : A.offsets[(key + 1) * A.B] - A.offsets[key * A.B]);
+    G.fstart[ft.order] = (uint32_t)n;
+    G.fkey[ft.order] = ft.key;
+  }
+  __syncthreads();
+  bwd_block_scan(G.fstart, F, G.wtot);
+  for (int t = threadIdx.x; t < T; t += BWD_THREADS) {
+    const TzrTable tb = tables[t];
+    const uint32_t s = tb.n_feats > 0 ? G.fstart[tb.first_order] : 0u;
+    const uint32_t e = tb.n_feats > 0 ? G.fstart[tb.first_order + tb.n_feats] : 0u;
+    G.tchunk[t] = (e - s + ch - 1) / ch;
+  }
+  __syncthreads();
+  // tables are visited in first_order order == table-major position order only if table ids
+  // follow it; starts are absolute, so the chunk map just needs a prefix in table-id order
+  bwd_block_scan(G.tchunk, T, G.wtot);
+}
+
+// Table-major position p of table tb -> (local row, original lookup position): the lookups of a
+// table are the concatenation, in key order, of the id segments of the keys that read it.
+__device__ __forceinline__ void bwd_elem0(const BwdGeo& G, const TzrTable& tb, const BwdSrcArgs& A,
+                                          int64_t p, uint32_t* key_out, uint32_t* src_out,
+                                          int64_t* kjt_key_out) {
+  int o = tb.first_order;
+  while (o + 1 < tb.first_order + tb.n_feats && (int64_t)G.fstart[o + 1] <= p) ++o;
+  const int64_t key = G.fkey[o];
+  const int64_t fbase = A.uniform ? key * A.B : A.offsets[key * A.B];
+  const int64_t i = fbase + (p - (int64_t)G.fstart[o]);
+  int64_t id = A.values[i];
+  if ((uint64_t)id >= (uint64_t)tb.rows) id = 0;  // memory safety; K4 reports/clamps
+  *key_out = (uint32_t)id;
+  *src_out = (uint32_t)i;
+  *kjt_key_out = key;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// table scan: by the last chunk of the table to arrive
+// ------------------------------------------------------------------------------------------
+struct BwdPartLds {
+  // (L first: a generic pointer to the LDS object at offset 0 -- the geometry arrays, read through BwdGeo --
+  // trips "Illegal instruction detected: Operand has incorrect register class" in this hipcc)
+  BwdRankLds<BWD_NB> L;
+  union {
+    BwdGeoLds G;           // prologue: table-major geometry
+    uint2 stage[BWD_CH];   // then: the chunk in slab order
+  };
+  uint32_t tot[BWD_NB + 1];  // table scan: bucket totals, then bucket starts
+  uint32_t wtot[BWD_WAVES];
+  uint32_t flag, any_heavy;
+};
+
+__device__ __forceinline__ uint16_t bwd_consume_u16(const uint16_t* p) {
+  // 2-byte entries of a chunk row another workgroup of this launch published: read through the
+  // aligned 8-byte word that holds them (the publish granule)
+  const uint64_t w = tzr_consume_u64(reinterpret_cast<const uint64_t*>(p - ((reinterpret_cast<uintptr_t>(p) & 7) >> 1)));
+  return (uint16_t)(w >> (8 * (reinterpret_cast<uintptr_t>(p) & 7)));
+}
+
+// Units of the apply.  Cut points = bucket boundaries + the BWD_CH-block boundaries that fall
+// INSIDE a heavy bucket; unit j of a table starts at the first cut point at or after block j
+// (ts + j * ch).  So a unit is a whole number of light buckets (which the sort kernel orders in LDS)
+// and/or block-sized slices of heavy buckets (ordered by the heavy workers), it holds fewer
+// than BWD_CH + BWD_TH lookups, and a run of one row can only cross a unit boundary inside a heavy
+// bucket.
+__device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChunkDesc& cd,
+                                               int one_wg_heavy, const BwdPlan& P, BwdPartLds& S) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (TZR_WAVE - 1);
+  const int t = cd.t;
+  const int c0 = cd.first_chunk;
+  const int C = cd.last_chunk - cd.first_chunk;
+  const uint32_t ts = (uint32_t)cd.ts, te = (uint32_t)cd.te;
+  const uint32_t ch = (uint32_t)P.ch;
+  // 1. bucket totals = column sums of the chunks' counts.  Thread q of a half owns buckets 4q .. 4q+3
+  //    (one published 8-byte word of a row + the first entry of the next word), the two halves of the
+  //    workgroup take even / odd chunks; 8 chunks of independent loads in flight per thread.
+  {
+    const int half = tid >> 7, q = tid & 127;
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    constexpr int kBatch = 8;
+    for (int cb = half; cb < C; cb += 2 * kBatch) {
+      uint64_t a[kBatch], b[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const int c = cb + 2 * j;
+        a[j] = b[j] = 0;
+        if (c < C) {
+          const uint64_t* row = reinterpret_cast<const uint64_t*>(P.lst + (size_t)(c0 + c) * BWD_LROW);
+          a[j] = tzr_consume_u64(row + q);
+          b[j] = tzr_consume_u64(row + q + 1);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const uint32_t e0 = (uint32_t)(a[j] & 0xFFFFu), e1 = (uint32_t)((a[j] >> 16) & 0xFFFFu);
+        const uint32_t e2 = (uint32_t)((a[j] >> 32) & 0xFFFFu), e3 = (uint32_t)(a[j] >> 48);
+        const uint32_t e4 = (uint32_t)(b[j] & 0xFFFFu);
+        acc[0] += e1 - e0; acc[1] += e2 - e1; acc[2] += e3 - e2; acc[3] += e4 - e3;
+      }
+    }
+    if (half == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S.tot[4 * q + j] = acc[j];
+    }
+    if (tid == 0) S.any_heavy = 0;
+    __syncthreads();
+    if (half == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S.tot[4 * q + j] += acc[j];
+    }
+    __syncthreads();
+  }
+  bwd_block_scan(S.tot, BWD_NB, S.wtot);  // exclusive: S.tot[b] = lookups in buckets < b, S.tot[NB] = all
+  uint32_t* bb = P.binbase + (size_t)t * (BWD_NB + 1);
+  const int64_t rows = tb.rows;
+  const bool exact = rows <= BWD_NB;
+  for (int r = 0; r < BWD_NB / BWD_THREADS; ++r) {  // workgroup-uniform
+    const int bin = r * BWD_THREADS + tid;
+    const uint32_t start = ts + S.tot[bin];
+    const uint32_t end = ts + S.tot[bin + 1];
+    const uint32_t run = end - start;
+    bb[bin] = start;
+    if (bin == BWD_NB - 1) bb[BWD_NB] = te;
+    const bool heavy = run > BWD_TH;
+    {  // bitmap of the heavy buckets (read by the unit sort): one ballot per wave = two words
+      const unsigned long long hb = __ballot(heavy);
+      if (lane == 0) {
+        uint32_t* hw = P.hbits + (size_t)t * (BWD_NB / 32) + (bin / TZR_WAVE) * 2;
+        hw[0] = (uint32_t)hb;
+        hw[1] = (uint32_t)(hb >> 32);
+        if (hb != 0) atomicOr(&S.any_heavy, 1u);
+      }
+    }
+    // Stitch groups of the apply: a run of one row can only cross a unit boundary inside a heavy
+    // bucket; the units overlapping such a bucket meet at its counter (reduce kernel)
+    {
+      uint32_t expect = 0;
+      if (heavy) {
+        const uint32_t units = (end - 1 - ts) / ch - (start - ts) / ch + 1;
+        expect = units > 1 ? units : 0u;
+      }
+      P.sexp[(size_t)t * BWD_NB + bin] = expect;
+      P.sarr[(size_t)t * BWD_NB + bin] = 0;
+    }
+    if (run == 0) continue;
+    // blocks whose first position lies in this bucket
+    const uint32_t j0 = (start - ts + ch - 1) / ch;
+    const uint32_t j1 = (end - 1 - ts) / ch;
+    for (uint32_t j = j0; j <= j1; ++j) {
+      const uint32_t bs = ts + j * ch;
+      const bool here = bs == start || heavy;
+      P.ucut[c0 + j] = here ? bs : end;
+      P.ub0[c0 + j] = here ? (uint32_t)bin : (uint32_t)bin + 1u;
+      const uint32_t bnext = min(bs + ch, te);
+      P.uflag[c0 + j] = (heavy && bnext <= end) ? 1u : 0u;
+    }
+    if (!heavy) continue;
+    // row ids of the bucket: [klo, khi).  At most BWD_NB of them (tables up to BWD_NB^2 rows): one
+    // counting pass on (row id - klo) sorts the bucket, tile by tile, one workgroup per tile.  A wider
+    // bucket is heavy because of ONE row nearly always (the clipped Zipf tail, a default id): tiles
+    // again, splitting around that row; a wide bucket of a single tile is sorted in LDS by one workgroup.
+    int kind;
+    if (exact) {
+      kind = BWD_HK_COPY;
+    } else {
+      int nb;
+      uint64_t mult;
+      bwd_bucket_params(rows, &nb, &mult);
+      const uint64_t klo = (((uint64_t)bin << 32) + mult - 1) / mult;
+      uint64_t khi = (((uint64_t)(bin + 1) << 32) + mult - 1) / mult;
+      if (khi > (uint64_t)rows) khi = (uint64_t)rows;
+      kind = khi - klo <= (uint64_t)BWD_NB ? BWD_HK_ONEPASS : (run > BWD_HT ? BWD_HK_HOT : BWD_HK_SERIAL);
+      if (one_wg_heavy) kind = BWD_HK_SERIAL;  // tzr_tune("bwd_one_wg_heavy"): no tile parallelism
+    }
+    BwdHeavy hv;
+    hv.t = t;
+    hv.bin = (uint32_t)bin;
+    hv.start = start;
+    hv.nt = run;
+    hv.kind = kind;
+    if (kind == BWD_HK_SERIAL) {
+      hv.c_begin = 0;
+      hv.c_end = C;
+      hv.prefix = 0;
+      const uint32_t slot = atomicAdd(P.hcount, 1u);
+      if (slot < (uint32_t)P.max_heavy) P.hlist[slot] = hv;
+      continue;
+    }
+    // greedy tiles of whole chunks, at most BWD_HT lookups each (one chunk holds at most ch <= BWD_HT)
+    uint32_t acc = 0, prefix = 0;
+    int tile_c0 = 0;
+    for (int c = 0; c <= C; ++c) {
+      uint32_t n_c = 0;
+      if (c < C) {
+        const uint16_t* row = P.lst + (size_t)(c0 + c) * BWD_LROW;
+        n_c = (uint32_t)bwd_consume_u16(row + bin + 1) - (uint32_t)bwd_consume_u16(row + bin);
+      }
+      if (c == C || acc + n_c > BWD_HT) {
+        if (acc > 0) {
+          hv.c_begin = tile_c0;
+          hv.c_end = c;
+          hv.prefix = prefix;
+          hv.nt = acc;
+          const uint32_t slot = atomicAdd(P.hcount, 1u);
+          if (slot < (uint32_t)P.max_heavy) P.hlist[slot] = hv;
+        }
+        prefix += acc;
+        acc = 0;
+        tile_c0 = c;
+      }
+      acc += n_c;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) P.tab_stitch[t] = S.any_heavy;
+}
+
+// ------------------------------------------------------------------------------------------
+// part: one chunk -> its slab
+// ------------------------------------------------------------------------------------------
+// Element order inside a chunk is table-major position order; bwd_rank_tile gives every element its
+// index in the chunk's stable bucket-sorted order; the elements are laid out in THAT order in LDS and
+// written back from there: one coalesced 8-byte {key, src} store per element.
+template <bool FUSED>
+__device__ __forceinline__ void bwd_part_body(const TzrTable* __restrict__ tables, int T, int F,
+                                              const BwdSrcArgs& A, const BwdPlan& P, int one_wg_heavy,
+                                              BwdPartLds& S, int c) {
+  BwdGeo G;
+  if (FUSED) {
+    bwd_geometry(tables, T, A, F, (uint32_t)P.ch, S.G);
+    G.fstart = S.G.fstart;
+    G.fkey = S.G.fkey;
+    G.tchunk = reinterpret_cast<const int32_t*>(S.G.tchunk);
+    if (c == 0) {  // the later kernels of the plan and the apply read it from the workspace
+      for (int o = threadIdx.x; o <= F; o += BWD_THREADS) P.feat_start[o] = S.G.fstart[o];
+      for (int o = threadIdx.x; o < F; o += BWD_THREADS) P.feat_key[o] = S.G.fkey[o];
+      for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
+      for (int t = threadIdx.x; t <= T; t += BWD_THREADS) P.tab_chunk[t] = (int32_t)S.G.tchunk[t];
+    }
+  } else {
+    G.fstart = P.feat_start;
+    G.fkey = P.feat_key;
+    G.tchunk = P.tab_chunk;
+  }
+  BwdChunkDesc cd;
+  cd.t = -1;
+  cd.nb = cd.exact = cd.last_chunk = cd.first_chunk = cd.pad = 0;
+  cd.s = cd.e = cd.ts = cd.te = 0;
+  cd.mult = 0;
+  TzrTable tb;
+  tb.rows = 0;
+  if (c < G.tchunk[T]) {
+    int lo = 0, hi = T;  // last t with tchunk[t] <= c (the non-empty table holding it)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (G.tchunk[mid] <= c) lo = mid; else hi = mid;
+    }
+    tb = tables[lo];
+    cd.t = lo;
+    bwd_bucket_params(tb.rows, &cd.nb, &cd.mult);
+    cd.exact = tb.rows <= BWD_NB;
+    cd.first_chunk = G.tchunk[lo];
+    cd.last_chunk = G.tchunk[lo + 1];
+    cd.ts = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order] : 0;
+    cd.te = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order + tb.n_feats] : cd.ts;
+    cd.s = cd.ts + (int64_t)(c - G.tchunk[lo]) * P.ch;
+    cd.e = min(cd.te, cd.s + (int64_t)P.ch);
+  }
+  if (threadIdx.x == 0) P.cdesc[c] = cd;
+  if (cd.t < 0) return;
+  const int n = (int)(cd.e - cd.s);
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  // all of the chunk's elements are loaded up front (independent coalesced loads): the ranking
+  // then runs out of registers and pays one memory latency per workgroup
+  constexpr int kRounds = BWD_CH / BWD_THREADS;
+  const int pw = bwd_wave_span(n);
+  const int rounds = pw / TZR_WAVE;
+  uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    kreg[r] = sreg[r] = dig[r] = 0u;
+    if (r < rounds && lp < n) {
+      vmask |= 1u << r;
+      int64_t kk;
+      bwd_elem0(G, tb, A, cd.s + lp, &kreg[r], &sreg[r], &kk);
+      dig[r] = bwd_bucket(kreg[r], cd.mult);
+      if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
+        const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[r]);
+        P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
+      }
+    }
+  }
+  __syncthreads();  // the geometry in LDS is dead from here on: its space becomes the slab stage
+  bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, bwd_bits((uint32_t)cd.nb - 1u), S.L, dest);
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r)
+    if ((vmask >> r) & 1u) S.stage[dest[r]] = make_uint2(kreg[r], sreg[r]);
+  __syncthreads();
+  uint2* __restrict__ slab = P.ks[1] + cd.s;
+  for (int i = threadIdx.x; i < n; i += BWD_THREADS) slab[i] = S.stage[i];
+  // the chunk's row of bucket starts, published for the table scan (another workgroup of this launch)
+  {
+    uint64_t* row = reinterpret_cast<uint64_t*>(P.lst + (size_t)c * BWD_LROW);
+    for (int i = threadIdx.x; i < BWD_LROW / 4; i += BWD_THREADS) {
+      uint64_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w |= (uint64_t)S.L.lstart[min(4 * i + j, BWD_NB)] << (16 * j);
+      tzr_publish_u64(row + i, w);
+    }
+  }
+  tzr_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    S.flag = tzr_arrive(P.tarr + cd.t) == (uint32_t)(cd.last_chunk - cd.first_chunk) - 1u ? 1u : 0u;
+  __syncthreads();
+  if (S.flag) bwd_table_scan(tb, cd, one_wg_heavy, P, S);
+}

@@ -8,7 +8,6 @@ extern int g_tzr_fwd_variant;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
-extern int g_tzr_bwd_debug;
 extern int g_tzr_bwd_apply_pipe;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
@@ -34,10 +33,6 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_apply_pipe")) {
     g_tzr_bwd_apply_pipe = value;
-    return TZR_OK;
-  }
-  if (!strcmp(name, "bwd_debug")) {
-    g_tzr_bwd_debug = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_plain")) {
