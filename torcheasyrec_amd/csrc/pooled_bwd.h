@@ -44,18 +44,30 @@ struct BwdChunkDesc {
 // Work item of the sort kernel: heavy bucket `bin` of table t = sorted positions [start, binbase[bin+1]).
 // Its lookups sit in the chunk slabs of the table (bucket `bin` of every chunk, in chunk order =
 // table-major order); a TILE is the lookups of chunks [c_begin, c_end) (relative to the table's first
-// chunk): `nt` <= BWD_HT of them, `prefix` lookups of the bucket ahead of it.
+// chunk).  Tiles are cut by a rule that needs no per-chunk data (bwd_tile_chunks: about BWD_HT / 2 lookups
+// when the bucket is spread evenly); a tile worker takes whatever its chunks hold, BWD_HT lookups at a time.
 #define BWD_HK_ONEPASS 0  // bucket of <= BWD_NB row ids: one counting pass, tile-parallel
 #define BWD_HK_HOT 1      // wide bucket with more than one tile: split around its hot row, tile-parallel
 #define BWD_HK_SERIAL 2   // the whole bucket by one workgroup (c_begin = 0, c_end = chunks of the table)
 #define BWD_HK_COPY 3     // bucket = one row (exact table): the tile is copied, chunk order IS the order
 struct BwdHeavy {
   int32_t t;
-  uint32_t bin, start, nt;
+  uint32_t bin, start;
   int32_t c_begin, c_end;
-  uint32_t prefix;
   int32_t kind;
+  int32_t pad[2];
 };
+// chunks per tile of a heavy bucket of `run` lookups in a table of C chunks
+static inline __host__ __device__ uint32_t bwd_tile_chunks(uint32_t run, uint32_t C) {
+  const uint64_t g = ((uint64_t)(BWD_HT / 2) * C) / run;
+  return g < 1 ? 1u : (uint32_t)g;
+}
+// The work items of table t (sorted positions from ts, index t) are listed from hlist[bwd_hbase(ts, t)]:
+// a heavy bucket of `run` lookups makes at most 4 * run / BWD_HT + 1 tiles and there are at most
+// n_t / (BWD_TH + 1) heavy buckets, so the regions of consecutive tables never overlap.
+static inline __host__ __device__ uint32_t bwd_hbase(uint32_t ts, uint32_t t) {
+  return 4u * (ts / BWD_HT) + ts / (BWD_TH + 1) + 8u * t;
+}
 
 struct BwdPlan {  // pointers into the caller workspace
   uint32_t* feat_start;    // [F+1] start of each lookup (by order) in table-major position space
@@ -74,7 +86,7 @@ struct BwdPlan {  // pointers into the caller workspace
   uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (the unit lies inside one heavy bucket)
   uint32_t* hbits;         // [T * BWD_NB/32] bitmap of the heavy buckets of every table
   uint32_t* tarr;          // [T] chunks of the table that have published their slab (zeroed before the launch)
-  uint32_t* hcount;        // [1] work items listed (tarr + T: zeroed by the same memset)
+  uint32_t* tcount;        // [T] work items of the table (heavy tiles), listed from hlist[bwd_hbase(ts, t)]
   uint32_t* tab_stitch;    // [T] 1 = the table holds sorted buckets: runs may cross unit boundaries
   uint32_t* sexp;          // [T * BWD_NB] units overlapping the (sorted) bucket when > 1, else 0
   uint32_t* sarr;          // [T * BWD_NB] ... of which have published their boundary record (apply)
@@ -111,8 +123,7 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   BwdPlan q;
   q.ch = bwd_pick_ch(N);
   q.max_chunks = bwd_max_chunks(N, T, q.ch);
-  // every heavy bucket is at least one item; greedy tiles of whole chunks: any two neighbours hold more than BWD_HT
-  q.max_heavy = N / (BWD_TH + 1) + 2 * (N / BWD_HT) + 2;
+  q.max_heavy = 4 * (N / BWD_HT) + N / (BWD_TH + 1) + 8 * (int64_t)T + 8;  // bwd_hbase(N, T)
   q.feat_start = c.take<uint32_t>(F + 1);
   q.feat_key = c.take<int32_t>(F);
   q.feat_by_order = c.take<int32_t>(F);
@@ -126,7 +137,7 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.uflag = c.take<uint32_t>(q.max_chunks);
   q.hbits = c.take<uint32_t>((size_t)T * (BWD_NB / 32));
   q.tarr = c.take<uint32_t>((size_t)T + 4);
-  q.hcount = q.tarr + T;
+  q.tcount = c.take<uint32_t>((size_t)T + 4);
   q.tab_stitch = c.take<uint32_t>(T);
   q.sexp = c.take<uint32_t>((size_t)T * BWD_NB);
   q.sarr = c.take<uint32_t>((size_t)T * BWD_NB);

@@ -44,7 +44,7 @@ extern "C" size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions
 //   out[0] ks[0]  sorted pairs (uint2 {row, lookup position} per table-major position)
 //   out[1] ks[1]  the chunk slabs
 //   out[2] feat_start (uint32[F+1])  out[3] ucut (uint32[max_chunks+1])  out[4] cdesc (64 B each)
-//   out[5] max_chunks  out[6] hcount (uint32)  out[7] hlist (32 B each)
+//   out[5] max_chunks  out[6] tcount (uint32[T]: work items per table)  out[7] hlist (32 B each)
 extern "C" int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, int n_feats,
                                         int n_tables, int max_dim, int64_t* out8) {
   if (!out8 || n_values < 0 || n_positions < 0 || n_feats <= 0 || n_tables <= 0 || max_dim <= 0)
@@ -58,7 +58,7 @@ extern "C" int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, i
   out8[3] = reinterpret_cast<const char*>(P.ucut) - base;
   out8[4] = reinterpret_cast<const char*>(P.cdesc) - base;
   out8[5] = P.max_chunks;
-  out8[6] = reinterpret_cast<const char*>(P.hcount) - base;
+  out8[6] = reinterpret_cast<const char*>(P.tcount) - base;
   out8[7] = reinterpret_cast<const char*>(P.hlist) - base;
   return TZR_OK;
 }
@@ -105,6 +105,10 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     }
     P.tab_chunk[T] = run;
   }
+}
+
+__global__ void tzr_bwd_zero_kernel(uint32_t* tarr, uint32_t* tcount, int T) {
+  for (int t = threadIdx.x; t < T; t += blockDim.x) tarr[t] = tcount[t] = 0;
 }
 
 template <bool FUSED>
@@ -495,55 +499,60 @@ __device__ __forceinline__ uint32_t bwd_sample_mode(const BwdSortLds& S, const u
   return (uint32_t)__shfl((int)sk, TZR_WAVE - 1 - (int)(best & 63u), TZR_WAVE);
 }
 
-// The nt lookups of chunks [c_begin, c_end) of bucket `bin`, dealt wave-contiguously (lookup lp of the
-// tile at round r of lane l of wave w with lp = w*pw + r*64 + l).  All threads call.
+// Lookups [w0, w0 + wn) of the current chunk batch (wn <= MAXR * 256), dealt wave-contiguously (lookup lp of
+// the window at round r of lane l of wave w with lp = w*pw + r*64 + l).  Returns the mask of valid rounds.
 template <int MAXR>
-__device__ __forceinline__ uint32_t bwd_tile_load(BwdSortLds& S, const BwdPlan& P, const BwdHeavyCtx& X, uint32_t bin,
-                                                  int c_begin, int c_end, int nt, int pw, int rounds,
-                                                  uint32_t (&kreg)[MAXR], uint32_t (&sreg)[MAXR]) {
+__device__ __forceinline__ uint32_t bwd_window_load(const BwdSortLds& S, const uint2* __restrict__ ks1, int nc,
+                                                    int w0, int wn, int pw, int rounds,
+                                                    uint32_t (&kreg)[MAXR], uint32_t (&sreg)[MAXR]) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   uint32_t vmask = 0;
 #pragma unroll
-  for (int r = 0; r < MAXR; ++r) kreg[r] = sreg[r] = 0u;
-  int lf = 0;
-  for (int ca = c_begin; ca < c_end; ca += BWD_SEGB) {
-    const int nc = min(BWD_SEGB, c_end - ca);
-    const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, bin, bin + 1);
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-      const int lp = wv * pw + r * TZR_WAVE + lane;
-      if (r < rounds && lp < nt && lp >= lf && lp < lf + m) {
-        const uint2 v = bwd_segs_get(S, P.ks[1], nc, (uint32_t)(lp - lf));
-        kreg[r] = v.x;
-        sreg[r] = v.y;
-        vmask |= 1u << r;
-      }
+  for (int r = 0; r < MAXR; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    kreg[r] = sreg[r] = 0u;
+    if (r < rounds && lp < wn) {
+      const uint2 v = bwd_segs_get(S, ks1, nc, (uint32_t)(w0 + lp));
+      kreg[r] = v.x;
+      sreg[r] = v.y;
+      vmask |= 1u << r;
     }
-    lf += m;
-    __syncthreads();
   }
   return vmask;
+}
+
+// lookups of bucket `bin` in chunks [0, c_end) of the table (workgroup-uniform; ends with a barrier)
+__device__ __forceinline__ uint32_t bwd_count_before(BwdSortLds& S, const BwdPlan& P, const BwdHeavyCtx& X,
+                                                     uint32_t bin, int c_end) {
+  uint32_t tot = 0;
+  for (int ca = 0; ca < c_end; ca += BWD_SEGB) {
+    const int nc = min(BWD_SEGB, c_end - ca);
+    tot += (uint32_t)bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, bin, bin + 1);
+    __syncthreads();
+  }
+  return tot;
 }
 
 // bucket = one row (exact table): chunk order is the final order
 __device__ __forceinline__ void bwd_heavy_copy(const TzrTable* __restrict__ tables, const BwdPlan& P,
                                                BwdSortLds& S, const BwdHeavy& H) {
   const BwdHeavyCtx X = bwd_heavy_ctx(tables, P, H);
-  uint2* __restrict__ dst = P.ks[0] + H.start + H.prefix;
-  int off = 0;
+  uint32_t off = bwd_count_before(S, P, X, H.bin, H.c_begin);
+  uint2* __restrict__ dst = P.ks[0] + H.start;
   for (int ca = H.c_begin; ca < H.c_end; ca += BWD_SEGB) {
     const int nc = min(BWD_SEGB, H.c_end - ca);
     const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, H.bin, H.bin + 1);
     for (int i = threadIdx.x; i < m; i += BWD_THREADS) dst[off + i] = bwd_segs_get(S, P.ks[1], nc, (uint32_t)i);
-    off += m;
+    off += (uint32_t)m;
     __syncthreads();
   }
 }
 
 // bucket of <= BWD_NB row ids: the tile's workgroup counts the whole bucket per row id on its own
-// (no inter-workgroup traffic; the counts of the lookups ahead of its tile are the cross-tile prefix),
-// then ranks and writes its tile: the tiles of a hot bucket are sorted in parallel.
+// (no inter-workgroup traffic; the counts of the lookups in the chunks ahead of its tile are the
+// cross-tile prefix), then ranks and writes its tile, BWD_HT lookups at a time: the tiles of a hot
+// bucket are sorted in parallel.
 __device__ __forceinline__ void bwd_heavy_onepass(const TzrTable* __restrict__ tables, const BwdPlan& P,
                                                   BwdSortLds& S, const BwdHeavy& H) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
@@ -554,12 +563,13 @@ __device__ __forceinline__ void bwd_heavy_onepass(const TzrTable* __restrict__ t
   // (a heavy bucket usually is heavy because of ONE row: its lookups are counted with ballots into
   // wave registers, the others -- few per wave, on different counters -- with one LDS atomic each)
   uint32_t hot = BWD_SENT, hot_tot = 0, hot_pre = 0;
-  uint32_t fbase = 0;
   constexpr int kU = 4;
   for (int ca = 0; ca < X.C; ca += BWD_SEGB) {
     const int nc = min(BWD_SEGB, X.C - ca);
     const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, H.bin, H.bin + 1);
     if (ca == 0) hot = bwd_sample_mode(S, ks1, nc, m, lane);
+    // lookups of the batch that sit in chunks ahead of the tile: a prefix of the batch
+    const int nah = H.c_begin <= ca ? 0 : (H.c_begin >= ca + nc ? m : (int)S.spre[H.c_begin - ca]);
     for (int base = 0; base < m; base += BWD_THREADS * kU) {
       uint32_t k8[kU];
 #pragma unroll
@@ -571,7 +581,7 @@ __device__ __forceinline__ void bwd_heavy_onepass(const TzrTable* __restrict__ t
       for (int u = 0; u < kU; ++u) {
         const int i = base + u * BWD_THREADS + (int)threadIdx.x;
         const bool v = i < m;
-        const bool ahead = fbase + (uint32_t)i < H.prefix;
+        const bool ahead = i < nah;
         const bool is_hot = v && k8[u] == hot;
         hot_tot += (uint32_t)__popcll(__ballot(is_hot));
         hot_pre += (uint32_t)__popcll(__ballot(is_hot && ahead));
@@ -581,7 +591,6 @@ __device__ __forceinline__ void bwd_heavy_onepass(const TzrTable* __restrict__ t
         }
       }
     }
-    fbase += (uint32_t)m;
     __syncthreads();
   }
   if (lane == 0 && hot_tot) {
@@ -591,20 +600,29 @@ __device__ __forceinline__ void bwd_heavy_onepass(const TzrTable* __restrict__ t
   __syncthreads();
   bwd_block_scan(S.gstart, BWD_NB, S.wtot);
   constexpr int kRounds = BWD_HT / BWD_THREADS;
-  const int nt = (int)H.nt;
-  const int pw = bwd_wave_span(nt);
-  const int rounds = pw / TZR_WAVE;
-  uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
-  const uint32_t vmask = bwd_tile_load<kRounds>(S, P, X, H.bin, H.c_begin, H.c_end, nt, pw, rounds, kreg, sreg);
+  for (int ca = H.c_begin; ca < H.c_end; ca += BWD_SEGB) {
+    const int nc = min(BWD_SEGB, H.c_end - ca);
+    const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, H.bin, H.bin + 1);
+    for (int w0 = 0; w0 < m; w0 += BWD_HT) {
+      const int wn = min(BWD_HT, m - w0);
+      const int pw = bwd_wave_span(wn);
+      const int rounds = pw / TZR_WAVE;
+      uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
+      const uint32_t vmask = bwd_window_load<kRounds>(S, ks1, nc, w0, wn, pw, rounds, kreg, sreg);
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) dig[r] = ((vmask >> r) & 1u) ? kreg[r] - X.klo : 0u;
-  bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, X.wbits, S.L, dest);
+      for (int r = 0; r < kRounds; ++r) dig[r] = ((vmask >> r) & 1u) ? kreg[r] - X.klo : 0u;
+      bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, X.wbits, S.L, dest);
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r)
-    if ((vmask >> r) & 1u)
-      dst[S.gstart[dig[r]] + S.pre[dig[r]] + (dest[r] - (uint32_t)S.L.lstart[dig[r]])] =
-          make_uint2(kreg[r], sreg[r]);
-  __syncthreads();
+      for (int r = 0; r < kRounds; ++r)
+        if ((vmask >> r) & 1u)
+          dst[S.gstart[dig[r]] + S.pre[dig[r]] + (dest[r] - (uint32_t)S.L.lstart[dig[r]])] =
+              make_uint2(kreg[r], sreg[r]);
+      __syncthreads();
+      for (int d = threadIdx.x; d < BWD_NB; d += BWD_THREADS)  // the next window's lookups come behind these
+        S.pre[d] += (unsigned)S.L.lstart[d + 1] - (unsigned)S.L.lstart[d];
+      __syncthreads();
+    }
+  }
 }
 
 // The whole bucket by one workgroup.  One tile: every pass in LDS.  More: the lookups are first copied
@@ -617,12 +635,14 @@ __device__ __forceinline__ void bwd_heavy_serial(const TzrTable* __restrict__ ta
   const BwdHeavyCtx X = bwd_heavy_ctx(tables, P, H);
   const int n = X.n;
   constexpr int kRounds = BWD_HT / BWD_THREADS;
-  if (n <= BWD_HT) {
+  if (n <= BWD_HT && X.C <= BWD_SEGB) {  // one batch of chunks, one tile: every pass in LDS
     uint2* __restrict__ dst = P.ks[0] + H.start;
-    const int pw = bwd_wave_span(n);
+    const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, 0, X.C, H.bin, H.bin + 1);
+    const int pw = bwd_wave_span(m);
     const int rounds = pw / TZR_WAVE;
     uint32_t kreg[kRounds], sreg[kRounds], dest[kRounds];
-    uint32_t vmask = bwd_tile_load<kRounds>(S, P, X, H.bin, 0, X.C, n, pw, rounds, kreg, sreg);
+    uint32_t vmask = bwd_window_load<kRounds>(S, P.ks[1], X.C, 0, m, pw, rounds, kreg, sreg);
+    __syncthreads();
     bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, X.klo, X.bits, false, S, dest);
 #pragma unroll
     for (int r = 0; r < kRounds; ++r)
@@ -728,11 +748,13 @@ __device__ __forceinline__ void bwd_heavy_hot(const TzrTable* __restrict__ table
   constexpr int kRounds = BWD_HT / BWD_THREADS;
   constexpr int kU = 4;
   uint32_t hot = BWD_SENT;
-  uint32_t lt_tot = 0, eq_tot = 0, eq_pre = 0, fbase = 0;
+  uint32_t lt_tot = 0, eq_tot = 0, eq_pre = 0;
   for (int ca = 0; ca < X.C; ca += BWD_SEGB) {
     const int nc = min(BWD_SEGB, X.C - ca);
     const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, H.bin, H.bin + 1);
     if (ca == 0) hot = bwd_sample_mode(S, ks1, nc, m, lane);
+    // lookups of the batch that sit in chunks ahead of the tile: a prefix of the batch
+    const int nah = H.c_begin <= ca ? 0 : (H.c_begin >= ca + nc ? m : (int)S.spre[H.c_begin - ca]);
     for (int base = 0; base < m; base += BWD_THREADS * kU) {
       uint32_t k4[kU];
 #pragma unroll
@@ -746,10 +768,9 @@ __device__ __forceinline__ void bwd_heavy_hot(const TzrTable* __restrict__ table
         const bool v = i < m;
         lt_tot += (uint32_t)__popcll(__ballot(v && k4[u] < hot));
         eq_tot += (uint32_t)__popcll(__ballot(v && k4[u] == hot));
-        eq_pre += (uint32_t)__popcll(__ballot(v && k4[u] == hot && fbase + (uint32_t)i < H.prefix));
+        eq_pre += (uint32_t)__popcll(__ballot(v && k4[u] == hot && i < nah));
       }
     }
-    fbase += (uint32_t)m;
     __syncthreads();
   }
   if (lane == 0) {  // wave-level partial counts (a batch's lookups are dealt over the four waves)
@@ -773,31 +794,43 @@ __device__ __forceinline__ void bwd_heavy_hot(const TzrTable* __restrict__ table
   }
   // the hot lookups of this tile, in table-major order, behind the hot lookups of the tiles before
   {
-    const int nt = (int)H.nt;
-    const int pw = bwd_wave_span(nt);
-    const int rounds = pw / TZR_WAVE;
-    uint32_t kreg[kRounds], sreg[kRounds], hpos[kRounds];
-    const uint32_t vmask = bwd_tile_load<kRounds>(S, P, X, H.bin, H.c_begin, H.c_end, nt, pw, rounds, kreg, sreg);
-    uint32_t hmask = 0, run = 0;
+    uint32_t ahead0 = n_lt + eq_ahead;  // workgroup-uniform: first position for the next window's hot lookups
+    for (int ca = H.c_begin; ca < H.c_end; ca += BWD_SEGB) {
+      const int nc = min(BWD_SEGB, H.c_end - ca);
+      const int m = bwd_segs_build(S, P, X.first_chunk, X.ts, ca, nc, H.bin, H.bin + 1);
+      for (int w0 = 0; w0 < m; w0 += BWD_HT) {
+        const int wn = min(BWD_HT, m - w0);
+        const int pw = bwd_wave_span(wn);
+        const int rounds = pw / TZR_WAVE;
+        uint32_t kreg[kRounds], sreg[kRounds], hpos[kRounds];
+        const uint32_t vmask = bwd_window_load<kRounds>(S, ks1, nc, w0, wn, pw, rounds, kreg, sreg);
+        uint32_t hmask = 0, run = 0;
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      hpos[r] = 0;
-      if (r < rounds) {
-        const bool is_hot = ((vmask >> r) & 1u) && kreg[r] == hot;
-        const unsigned long long hm = __ballot(is_hot);
-        hpos[r] = run + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-        run += (uint32_t)__popcll(hm);
-        if (is_hot) hmask |= 1u << r;
+        for (int r = 0; r < kRounds; ++r) {
+          hpos[r] = 0;
+          if (r < rounds) {
+            const bool is_hot = ((vmask >> r) & 1u) && kreg[r] == hot;
+            const unsigned long long hm = __ballot(is_hot);
+            hpos[r] = run + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+            run += (uint32_t)__popcll(hm);
+            if (is_hot) hmask |= 1u << r;
+          }
+        }
+        if (lane == 0) S.wtot[wv] = run;
+        __syncthreads();
+        uint32_t ahead = ahead0, win_hot = 0;
+#pragma unroll
+        for (int w = 0; w < BWD_WAVES; ++w) {
+          if (w < wv) ahead += S.wtot[w];
+          win_hot += S.wtot[w];
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+          if ((hmask >> r) & 1u) dst[ahead + hpos[r]] = make_uint2(hot, sreg[r]);
+        ahead0 += win_hot;
+        __syncthreads();
       }
     }
-    if (lane == 0) S.wtot[wv] = run;
-    __syncthreads();
-    uint32_t ahead = n_lt + eq_ahead;
-    for (int w = 0; w < wv; ++w) ahead += S.wtot[w];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r)
-      if ((hmask >> r) & 1u) dst[ahead + hpos[r]] = make_uint2(hot, sreg[r]);
-    __syncthreads();
   }
   if (H.c_begin != 0 || n_cold == 0) return;
   // 3. the cold lookups of the whole bucket: ordered gather into LDS, stable sort, write
@@ -872,21 +905,48 @@ __device__ __forceinline__ void bwd_heavy_hot(const TzrTable* __restrict__ table
   }
 }
 
-__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_sort_kernel(
-    const TzrTable* __restrict__ tables, int n_units, BwdPlan P) {
+__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(7) void tzr_bwd_sort_kernel(
+    const TzrTable* __restrict__ tables, int n_tables, int n_units, BwdPlan P) {
   __shared__ BwdSortLds S;
   if ((int)blockIdx.x < n_units) {
     bwd_sort_unit(tables, P, S, (int)blockIdx.x);
     return;
   }
-  const unsigned nh = min(P.hcount[0], (unsigned)P.max_heavy);
+  // the heavy work items: tcount[t] of them in the region of table t; this worker takes items w, w + W, ...
+  // of the concatenation (table by table: the prefix over <= a few hundred tables lives in LDS)
   const unsigned workers = gridDim.x - (unsigned)n_units;
-  for (unsigned hi = blockIdx.x - (unsigned)n_units; hi < nh; hi += workers) {
-    const BwdHeavy H = P.hlist[hi];
-    if (H.kind == BWD_HK_COPY) bwd_heavy_copy(tables, P, S, H);
-    else if (H.kind == BWD_HK_ONEPASS) bwd_heavy_onepass(tables, P, S, H);
-    else if (H.kind == BWD_HK_HOT) bwd_heavy_hot(tables, P, S, H);
-    else bwd_heavy_serial(tables, P, S, H);
+  const unsigned w = blockIdx.x - (unsigned)n_units;
+  unsigned base = 0;  // items of the tables before `t0`
+  for (int t0 = 0; t0 < n_tables; t0 += BWD_SEGB) {
+    const int nt = min(BWD_SEGB, n_tables - t0);
+    for (int j = threadIdx.x; j < nt; j += BWD_THREADS) S.spre[j] = P.tcount[t0 + j];
+    __syncthreads();
+    bwd_block_scan(S.spre, nt, S.wtot);
+    const unsigned tot = S.spre[nt];
+    // first item of this worker at or after `base`
+    unsigned hi = base + ((w + workers - base % workers) % workers);
+    for (; hi < base + tot; hi += workers) {
+      const unsigned rel = hi - base;
+      int lo = 0, up = nt;
+      while (up - lo > 1) {
+        const int mid = (lo + up) >> 1;
+        if (S.spre[mid] <= rel) lo = mid; else up = mid;
+      }
+      const int t = t0 + lo;
+      const unsigned idx = rel - S.spre[lo];
+      __syncthreads();  // the heavy paths reuse the segment tables
+      const BwdHeavy H = P.hlist[bwd_hbase(P.feat_start[tables[t].first_order], (uint32_t)t) + idx];
+      if (H.kind == BWD_HK_COPY) bwd_heavy_copy(tables, P, S, H);
+      else if (H.kind == BWD_HK_ONEPASS) bwd_heavy_onepass(tables, P, S, H);
+      else if (H.kind == BWD_HK_HOT) bwd_heavy_hot(tables, P, S, H);
+      else bwd_heavy_serial(tables, P, S, H);
+      __syncthreads();
+      // the table prefix was overwritten: rebuild it
+      for (int j = threadIdx.x; j < nt; j += BWD_THREADS) S.spre[j] = P.tcount[t0 + j];
+      __syncthreads();
+      bwd_block_scan(S.spre, nt, S.wtot);
+    }
+    base += tot;
     __syncthreads();
   }
 }
@@ -928,8 +988,9 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   A.offsets = d_offsets;
   A.B = B;
   A.uniform = (int)uniform;
-  // the per-table arrival counters + the work-item counter start at zero
-  if (hipMemsetAsync(P.tarr, 0, sizeof(uint32_t) * ((size_t)n_tables + 4), s) != hipSuccess) return TZR_ERR_LAUNCH;
+  // the per-table arrival counters and item counts start at zero (a launch of our own: hipMemsetAsync of
+  // these 200 bytes runs as two 5 us fill kernels on this stack)
+  hipLaunchKernelGGL(tzr_bwd_zero_kernel, dim3(1), dim3(BWD_THREADS), 0, s, P.tarr, P.tcount, n_tables);
   if (n_feats > BWD_GEO || n_tables > BWD_GEO || g_tzr_bwd_force_prep) {
     hipLaunchKernelGGL(tzr_bwd_prep_kernel, dim3(1), dim3(BWD_THREADS), 0, s, d_tables, n_tables, A,
                        n_feats, P);
@@ -941,7 +1002,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   }
   const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);
   hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
-                     (int)chunks, P);
+                     n_tables, (int)chunks, P);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

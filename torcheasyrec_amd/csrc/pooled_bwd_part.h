@@ -118,15 +118,8 @@ struct BwdPartLds {
   };
   uint32_t tot[BWD_NB + 1];  // table scan: bucket totals, then bucket starts
   uint32_t wtot[BWD_WAVES];
-  uint32_t flag, any_heavy;
+  uint32_t flag, any_heavy, nitems;
 };
-
-__device__ __forceinline__ uint16_t bwd_consume_u16(const uint16_t* p) {
-  // 2-byte entries of a chunk row another workgroup of this launch published: read through the
-  // aligned 8-byte word that holds them (the publish granule)
-  const uint64_t w = tzr_consume_u64(reinterpret_cast<const uint64_t*>(p - ((reinterpret_cast<uintptr_t>(p) & 7) >> 1)));
-  return (uint16_t)(w >> (8 * (reinterpret_cast<uintptr_t>(p) & 7)));
-}
 
 // Units of the apply.  Cut points = bucket boundaries + the BWD_CH-block boundaries that fall
 // INSIDE a heavy bucket; unit j of a table starts at the first cut point at or after block j
@@ -174,7 +167,7 @@ __device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChun
 #pragma unroll
       for (int j = 0; j < 4; ++j) S.tot[4 * q + j] = acc[j];
     }
-    if (tid == 0) S.any_heavy = 0;
+    if (tid == 0) S.any_heavy = S.nitems = 0;
     __syncthreads();
     if (half == 1) {
 #pragma unroll
@@ -244,47 +237,29 @@ __device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChun
       kind = khi - klo <= (uint64_t)BWD_NB ? BWD_HK_ONEPASS : (run > BWD_HT ? BWD_HK_HOT : BWD_HK_SERIAL);
       if (one_wg_heavy) kind = BWD_HK_SERIAL;  // tzr_tune("bwd_one_wg_heavy"): no tile parallelism
     }
+    // tiles = runs of G whole chunks; the slots come from a workgroup-local counter (one table = one
+    // workgroup here: no global atomics), the items go to the table's own region of the list
+    const uint32_t G = kind == BWD_HK_SERIAL ? (uint32_t)C : bwd_tile_chunks(run, (uint32_t)C);
+    const uint32_t ntiles = ((uint32_t)C + G - 1) / G;
+    const uint32_t slot0 = atomicAdd(&S.nitems, ntiles);
     BwdHeavy hv;
     hv.t = t;
     hv.bin = (uint32_t)bin;
     hv.start = start;
-    hv.nt = run;
     hv.kind = kind;
-    if (kind == BWD_HK_SERIAL) {
-      hv.c_begin = 0;
-      hv.c_end = C;
-      hv.prefix = 0;
-      const uint32_t slot = atomicAdd(P.hcount, 1u);
-      if (slot < (uint32_t)P.max_heavy) P.hlist[slot] = hv;
-      continue;
-    }
-    // greedy tiles of whole chunks, at most BWD_HT lookups each (one chunk holds at most ch <= BWD_HT)
-    uint32_t acc = 0, prefix = 0;
-    int tile_c0 = 0;
-    for (int c = 0; c <= C; ++c) {
-      uint32_t n_c = 0;
-      if (c < C) {
-        const uint16_t* row = P.lst + (size_t)(c0 + c) * BWD_LROW;
-        n_c = (uint32_t)bwd_consume_u16(row + bin + 1) - (uint32_t)bwd_consume_u16(row + bin);
-      }
-      if (c == C || acc + n_c > BWD_HT) {
-        if (acc > 0) {
-          hv.c_begin = tile_c0;
-          hv.c_end = c;
-          hv.prefix = prefix;
-          hv.nt = acc;
-          const uint32_t slot = atomicAdd(P.hcount, 1u);
-          if (slot < (uint32_t)P.max_heavy) P.hlist[slot] = hv;
-        }
-        prefix += acc;
-        acc = 0;
-        tile_c0 = c;
-      }
-      acc += n_c;
+    hv.pad[0] = hv.pad[1] = 0;
+    BwdHeavy* list = P.hlist + bwd_hbase(ts, (uint32_t)t);
+    for (uint32_t k = 0; k < ntiles; ++k) {
+      hv.c_begin = (int32_t)(k * G);
+      hv.c_end = (int32_t)min((k + 1) * G, (uint32_t)C);
+      list[slot0 + k] = hv;
     }
   }
   __syncthreads();
-  if (tid == 0) P.tab_stitch[t] = S.any_heavy;
+  if (tid == 0) {
+    P.tab_stitch[t] = S.any_heavy;
+    P.tcount[t] = S.nitems;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
