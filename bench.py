@@ -495,7 +495,7 @@ def main():
         ebc._timers = timers
         for i in range(min(args.steps, 10)):
             kjt_i = batches[i % nb][1]
-            ebc._launch_forward(kjt_i, ("sparse",))
+            ebc._launch_forward(kjt_i, ("sparse",), with_plan=True)
             ebc.plan_backward(kjt_i, ("sparse",))
             ebc._launch_backward(kjt_i, ("sparse",), [gbuf])
         torch.cuda.synchronize()

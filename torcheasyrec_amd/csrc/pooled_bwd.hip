@@ -107,10 +107,6 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
   }
 }
 
-__global__ void tzr_bwd_zero_kernel(uint32_t* tarr, uint32_t* tcount, int T) {
-  for (int t = threadIdx.x; t < T; t += blockDim.x) tarr[t] = tcount[t] = 0;
-}
-
 template <bool FUSED>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_part_kernel(
     const TzrTable* __restrict__ tables, int T, int F, BwdSrcArgs A, int one_wg_heavy, BwdPlan P) {
@@ -959,25 +955,23 @@ int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
 
+static void bwd_launch_sort(const TzrTable* d_tables, int n_tables, const BwdPlan& P, hipStream_t s) {
+  const unsigned chunks = (unsigned)P.max_chunks;
+  const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);
+  hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
+                     n_tables, (int)chunks, P);
+}
+
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
                                    const TzrFeature* d_feats, int n_feats, int n_keys,
                                    int64_t max_rows, int max_dim, const int64_t* d_values, const int64_t* d_offsets,
                                    int64_t n_values, int64_t n_positions, int64_t B,
                                    int uniform_bag_len, void* ws,
                                    size_t ws_bytes, void* stream) {
-  if (!d_tables || !d_feats || n_tables <= 0 || n_feats <= 0 || n_values < 0 || B < 0 ||
-      max_dim <= 0 || max_rows < 0)
-    return TZR_ERR_INVALID;
-  const bool uniform = uniform_bag_len == 1;
-  if (!uniform && !d_offsets) return TZR_ERR_INVALID;
-  if (n_keys <= 0) return TZR_ERR_INVALID;
-  if (n_values >= (1LL << 32) || (int64_t)n_keys * B >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
-  if (max_rows > (1LL << 32)) return TZR_ERR_UNSUPPORTED;  // row ids travel as 32-bit keys
-  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
   BwdPlan P;
-  if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
-  if (bwd_layout(&P, ws, n_values, n_positions, n_feats, n_tables, max_dim) > ws_bytes)
-    return TZR_ERR_WORKSPACE;
+  const int rc = bwd_plan_check(d_tables, n_tables, d_feats, n_feats, n_keys, max_rows, max_dim, d_offsets, n_values,
+                                n_positions, B, uniform_bag_len, ws, ws_bytes, &P);
+  if (rc != TZR_OK) return rc;
   if (n_values == 0 || B == 0) return TZR_OK;
   if (!d_values) return TZR_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -987,7 +981,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   A.values = d_values;
   A.offsets = d_offsets;
   A.B = B;
-  A.uniform = (int)uniform;
+  A.uniform = (int)(uniform_bag_len == 1);
   // the per-table arrival counters and item counts start at zero (a launch of our own: hipMemsetAsync of
   // these 200 bytes runs as two 5 us fill kernels on this stack)
   hipLaunchKernelGGL(tzr_bwd_zero_kernel, dim3(1), dim3(BWD_THREADS), 0, s, P.tarr, P.tcount, n_tables);
@@ -1000,9 +994,23 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
     hipLaunchKernelGGL(tzr_bwd_part_kernel<true>, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                        n_tables, n_feats, A, g_tzr_bwd_one_wg_heavy, P);
   }
-  const unsigned workers = (unsigned)std::min<int64_t>(P.max_heavy, 1024);
-  hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
-                     n_tables, (int)chunks, P);
+  bwd_launch_sort(d_tables, n_tables, P, s);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// The second launch of the plan on its own: after tzr_pooled_fwd_plan ran the partition pass inside the
+// forward's launch.
+extern "C" int tzr_pooled_bwd_plan_finish(const TzrTable* d_tables, int n_tables, int n_feats, int max_dim,
+                                          int64_t n_values, int64_t n_positions, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  if (!d_tables || n_tables <= 0 || n_feats <= 0 || n_values < 0 || max_dim <= 0) return TZR_ERR_INVALID;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
+  if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
+  BwdPlan P;
+  if (bwd_layout(&P, ws, n_values, n_positions, n_feats, n_tables, max_dim) > ws_bytes) return TZR_ERR_WORKSPACE;
+  if (n_values == 0) return TZR_OK;
+  bwd_launch_sort(d_tables, n_tables, P, static_cast<hipStream_t>(stream));
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

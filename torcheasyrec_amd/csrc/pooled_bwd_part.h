@@ -105,6 +105,29 @@ __device__ __forceinline__ void bwd_elem0(const BwdGeo& G, const TzrTable& tb, c
 }
 
 
+// the per-table arrival counters and item counts of a plan start at zero (one tiny launch ahead of the
+// partition pass, wherever that runs)
+static __global__ void tzr_bwd_zero_kernel(uint32_t* tarr, uint32_t* tcount, int T) {
+  for (int t = threadIdx.x; t < T; t += blockDim.x) tarr[t] = tcount[t] = 0;
+}
+
+// argument checks + workspace layout shared by the entry points that start a plan
+static inline int bwd_plan_check(const TzrTable* d_tables, int n_tables, const TzrFeature* d_feats, int n_feats,
+                                 int n_keys, int64_t max_rows, int max_dim, const int64_t* d_offsets,
+                                 int64_t n_values, int64_t n_positions, int64_t B, int uniform_bag_len, void* ws,
+                                 size_t ws_bytes, BwdPlan* P) {
+  if (!d_tables || !d_feats || n_tables <= 0 || n_feats <= 0 || n_values < 0 || B < 0 || max_dim <= 0 || max_rows < 0)
+    return TZR_ERR_INVALID;
+  if (uniform_bag_len != 1 && !d_offsets) return TZR_ERR_INVALID;
+  if (n_keys <= 0) return TZR_ERR_INVALID;
+  if (n_values >= (1LL << 32) || (int64_t)n_keys * B >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
+  if (max_rows > (1LL << 32)) return TZR_ERR_UNSUPPORTED;  // row ids travel as 32-bit keys
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
+  if (n_positions < 0 || n_positions >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
+  if (bwd_layout(P, ws, n_values, n_positions, n_feats, n_tables, max_dim) > ws_bytes) return TZR_ERR_WORKSPACE;
+  return TZR_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // table scan: by the last chunk of the table to arrive
 // ------------------------------------------------------------------------------------------

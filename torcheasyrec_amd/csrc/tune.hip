@@ -5,6 +5,7 @@
 
 extern int g_tzr_fwd_tile_b;
 extern int g_tzr_fwd_variant;
+extern int g_tzr_fwd_plan_fuse;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
@@ -21,6 +22,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "fwd_variant")) {
     g_tzr_fwd_variant = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "fwd_plan_fuse")) {
+    g_tzr_fwd_plan_fuse = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_ch")) {
