@@ -13,7 +13,10 @@
 #define BWD_TH 256   // a bucket with more lookups is "heavy": sorted by the heavy kernel, cut at blocks
 #define BWD_UMAX (BWD_CH + BWD_TH)  // capacity of one unit of the apply: < BWD_CH + BWD_TH lookups
 #define BWD_HT 1024  // tile of the heavy-bucket sort (4 rounds per wave: every role of the sort kernel within 64 VGPRs)
-#define BWD_GEO 1024 // lookups / tables up to which every partition workgroup derives the geometry itself
+#define BWD_GEO 256  // lookups / tables up to which every partition workgroup derives the geometry itself
+#define BWD_SUB 1024  // lookups ranked at a time by a partition workgroup (one sub-tile of its chunk)
+#define BWD_PK 4      // a partition chunk = up to BWD_PK unit blocks: 4x fewer workgroups pay the pass's fixed
+                      // costs (geometry, publish, arrival) and a table scan reads 4x fewer rows
 #define BWD_LROW (BWD_NB + 4)  // uint16 entries per chunk row of bucket starts (NB + 1 used; 8-byte stores)
 #define BWD_SEGB 256           // chunks per batch when a bucket range is gathered from the chunk slabs
 #define BWD_MAXDIM 256
@@ -35,7 +38,7 @@ struct BwdChunkDesc {
   int32_t exact;       // every bucket is one row id
   int32_t last_chunk;  // first chunk of the NEXT table (stitch walks up to it)
   int32_t first_chunk; // first chunk of this table
-  int32_t pad;
+  int32_t first_pchunk; // first PARTITION chunk of this table
   int64_t s, e;        // input positions [s, e) of the chunk
   int64_t ts, te;      // positions of the whole table
   uint64_t mult;       // bucket of row id k = (k * mult) >> 32 (monotone in k)
@@ -73,13 +76,14 @@ struct BwdPlan {  // pointers into the caller workspace
   uint32_t* feat_start;    // [F+1] start of each lookup (by order) in table-major position space
   int32_t* feat_key;       // [F] KJT key of the lookup with that order
   int32_t* feat_by_order;  // [F]
-  int32_t* tab_chunk;      // [T+1] first chunk of each table
+  int32_t* tab_chunk;      // [T+1] first chunk (unit) of each table
+  int32_t* tab_pchunk;     // [T+1] first partition chunk of each table
   uint2* ks[3];            // [N] {local row id, original lookup position}: ks[1] holds the chunk SLABS
-                           //     (chunk c = input positions [s, e) of its table, stably ordered by bucket
-                           //     inside the chunk), ks[0] the sorted lookups of every table, ks[2] is the
+                           //     (partition chunk q = pch input positions of its table, stably ordered by
+                           //     bucket inside the chunk), ks[0] the sorted lookups of every table, ks[2] is the
                            //     ping-pong scratch of the serial heavy path; 8-byte elements = ONE store per move
   uint32_t* bag_of;        // [NV] bag index key*B+b of every lookup (only when bags are jagged)
-  uint16_t* lst;           // [max_chunks * BWD_LROW] slab-local start of every bucket of every chunk (+ total)
+  uint16_t* lst;           // [max_pchunks * BWD_LROW] slab-local start of every bucket of every partition chunk (+ total)
   uint32_t* binbase;       // [T * (BWD_NB+1)] global start of every (table, bucket), end of the last
   uint32_t* ucut;          // [max_chunks + 1] first sorted position of every unit
   uint32_t* ub0;           // [max_chunks + 1] first bucket a unit may hold light lookups of
@@ -97,9 +101,12 @@ struct BwdPlan {  // pointers into the caller workspace
   float* clead;            // [max_chunks * max_dim]
   float* ctrail;           // [max_chunks * max_dim]
   BwdChunkDesc* cdesc;     // [max_chunks]
+  uint64_t* prof;          // [max_chunks * 8] phase timestamps of the partition pass (tzr_tune("bwd_prof"); else unused)
   int64_t max_chunks;
+  int64_t max_pchunks;
   int64_t max_heavy;
-  int32_t ch;  // positions per chunk (multiple of 256, <= BWD_CH)
+  int32_t ch;   // positions per unit block (multiple of 256, <= BWD_CH)
+  int32_t pch;  // positions per partition chunk (ch * 1 .. BWD_PK)
 };
 
 // Positions per chunk.  The plan / apply kernels are latency-bound: the time of a launch is the
@@ -114,6 +121,14 @@ static inline int bwd_pick_ch(int64_t N) {
   return BWD_CH;
 }
 static inline int64_t bwd_max_chunks(int64_t N, int T, int ch) { return N / ch + T + 1; }
+// Unit blocks per partition chunk: as many (up to BWD_PK) as still leave ~400 partition workgroups.
+// g_tzr_bwd_pk (tzr_tune "bwd_pk") overrides.
+extern int g_tzr_bwd_pk;
+static inline int bwd_pick_pk(int64_t N, int ch) {
+  if (g_tzr_bwd_pk >= 1 && g_tzr_bwd_pk <= BWD_PK) return g_tzr_bwd_pk;
+  const int64_t k = N / ((int64_t)ch * 400);
+  return k < 1 ? 1 : (k > BWD_PK ? BWD_PK : (int)k);
+}
 
 // NV = ids in the KJT values array; N = capacity of the table-major position space (sum over
 // lookups of their key length: a key read through two tables is sorted twice).
@@ -122,15 +137,18 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   TzrCarver c(ws);
   BwdPlan q;
   q.ch = bwd_pick_ch(N);
+  q.pch = q.ch * bwd_pick_pk(N, q.ch);
   q.max_chunks = bwd_max_chunks(N, T, q.ch);
+  q.max_pchunks = bwd_max_chunks(N, T, q.pch);
   q.max_heavy = 4 * (N / BWD_HT) + N / (BWD_TH + 1) + 8 * (int64_t)T + 8;  // bwd_hbase(N, T)
   q.feat_start = c.take<uint32_t>(F + 1);
   q.feat_key = c.take<int32_t>(F);
   q.feat_by_order = c.take<int32_t>(F);
   q.tab_chunk = c.take<int32_t>(T + 1);
+  q.tab_pchunk = c.take<int32_t>(T + 1);
   for (int i = 0; i < 3; ++i) q.ks[i] = c.take<uint2>(N);
   q.bag_of = c.take<uint32_t>(NV);
-  q.lst = c.take<uint16_t>((size_t)q.max_chunks * BWD_LROW);
+  q.lst = c.take<uint16_t>((size_t)q.max_pchunks * BWD_LROW);
   q.binbase = c.take<uint32_t>((size_t)T * (BWD_NB + 1));
   q.ucut = c.take<uint32_t>(q.max_chunks + 1);
   q.ub0 = c.take<uint32_t>(q.max_chunks + 1);
@@ -148,6 +166,7 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.clead = c.take<float>((size_t)q.max_chunks * max_dim);
   q.ctrail = c.take<float>((size_t)q.max_chunks * max_dim);
   q.cdesc = c.take<BwdChunkDesc>(q.max_chunks);
+  q.prof = c.take<uint64_t>((size_t)q.max_pchunks * 8);
   if (p) *p = q;
   return c.off;
 }

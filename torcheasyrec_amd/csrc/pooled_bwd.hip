@@ -33,6 +33,8 @@
 
 #include "pooled_bwd.h"
 
+extern int g_tzr_bwd_prof;
+
 extern "C" size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions, int n_feats,
                                            int n_tables, int64_t B, int max_dim) {
   (void)B;
@@ -59,7 +61,7 @@ extern "C" int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, i
   out8[4] = reinterpret_cast<const char*>(P.cdesc) - base;
   out8[5] = P.max_chunks;
   out8[6] = reinterpret_cast<const char*>(P.tcount) - base;
-  out8[7] = reinterpret_cast<const char*>(P.hlist) - base;
+  out8[7] = g_tzr_bwd_prof ? reinterpret_cast<const char*>(P.prof) - base : reinterpret_cast<const char*>(P.hlist) - base;
   return TZR_OK;
 }
 
@@ -94,16 +96,20 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     const uint32_t s = tb.n_feats > 0 ? P.feat_start[tb.first_order] : 0u;
     const uint32_t e = tb.n_feats > 0 ? P.feat_start[tb.first_order + tb.n_feats] : 0u;
     P.tab_chunk[t] = (int32_t)((e - s + (uint32_t)P.ch - 1) / (uint32_t)P.ch);
+    P.tab_pchunk[t] = (int32_t)((e - s + (uint32_t)P.pch - 1) / (uint32_t)P.pch);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int32_t run = 0;
+    int32_t run = 0, prun = 0;
     for (int t = 0; t < T; ++t) {
-      const int32_t n = P.tab_chunk[t];
+      const int32_t n = P.tab_chunk[t], pn = P.tab_pchunk[t];
       P.tab_chunk[t] = run;
+      P.tab_pchunk[t] = prun;
       run += n;
+      prun += pn;
     }
     P.tab_chunk[T] = run;
+    P.tab_pchunk[T] = prun;
   }
 }
 
@@ -155,7 +161,7 @@ struct BwdSortLds {  // ~22 KB: 7 workgroups per CU
 static_assert(BWD_HT <= BWD_UMAX, "the exchange buffer holds a heavy tile");
 
 // ---- gathering a bucket range from the chunk slabs ----------------------------------------------
-// Buckets [lo, hi) of chunks [ca, ca + nc) of a table (relative chunk indices, nc <= BWD_SEGB): the
+// Buckets [lo, hi) of PARTITION chunks [ca, ca + nc) of a table (relative chunk indices, nc <= BWD_SEGB): the
 // lookups of chunk j are ks[1][sbeg[j] ... + (spre[j+1] - spre[j])).  Returns their number.  All
 // threads call; ends with a barrier.
 __device__ __forceinline__ int bwd_segs_build(BwdSortLds& S, const BwdPlan& P, int first_chunk, uint32_t ts,
@@ -164,7 +170,7 @@ __device__ __forceinline__ int bwd_segs_build(BwdSortLds& S, const BwdPlan& P, i
     const uint16_t* row = P.lst + (size_t)(first_chunk + ca + j) * BWD_LROW;
     const uint32_t a = row[lo], b = row[hi];
     S.spre[j] = b - a;
-    S.sbeg[j] = ts + (uint32_t)(ca + j) * (uint32_t)P.ch + a;
+    S.sbeg[j] = ts + (uint32_t)(ca + j) * (uint32_t)P.pch + a;
   }
   __syncthreads();
   bwd_block_scan(S.spre, nc, S.wtot);
@@ -320,7 +326,7 @@ __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ table
   const int tid = threadIdx.x;
   const int lane = tid & (TZR_WAVE - 1);
   const int wv = tid / TZR_WAVE;
-  const int C = cd.last_chunk - cd.first_chunk;
+  const int C = (int)((cd.te - cd.ts + P.pch - 1) / P.pch);  // partition chunks of the table
   const uint32_t* hbits = P.hbits + (size_t)cd.t * (BWD_NB / 32);
   // heavy buckets inside the range cut it into light sub-ranges (rare: none under uniform ids)
   if (tid < BWD_NB / 32) {
@@ -379,7 +385,7 @@ __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ table
     const uint32_t lo = S.sub_lo[q], hi = S.sub_hi[q];
     for (int ca = 0; ca < C; ca += BWD_SEGB) {
       const int nc = min(BWD_SEGB, C - ca);
-      const int m = bwd_segs_build(S, P, cd.first_chunk, (uint32_t)cd.ts, ca, nc, lo, hi);
+      const int m = bwd_segs_build(S, P, cd.first_pchunk, (uint32_t)cd.ts, ca, nc, lo, hi);
       if (n + m <= BWD_UMAX) {
         for (int i = tid; i < m; i += BWD_THREADS) {
           const uint2 v = bwd_segs_get(S, ks1, nc, (uint32_t)i);
@@ -463,8 +469,8 @@ __device__ __forceinline__ BwdHeavyCtx bwd_heavy_ctx(const TzrTable* __restrict_
                                                      const BwdHeavy& H) {
   BwdHeavyCtx X;
   const BwdChunkDesc cd = P.cdesc[P.tab_chunk[H.t]];
-  X.first_chunk = cd.first_chunk;
-  X.C = cd.last_chunk - cd.first_chunk;
+  X.first_chunk = cd.first_pchunk;  // partition chunks: where the bucket's lookups sit
+  X.C = (int)((cd.te - cd.ts + P.pch - 1) / P.pch);
   X.ts = (uint32_t)cd.ts;
   const int64_t rows = tables[H.t].rows;
   const uint64_t klo64 = (((uint64_t)H.bin << 32) + cd.mult - 1) / cd.mult;
@@ -952,8 +958,10 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(7) void tzr_bwd_sort_
 // ------------------------------------------------------------------------------------------
 
 int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO geometry path
-int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
+int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per unit block (0 = by problem size)
+int g_tzr_bwd_pk = 0;          // tzr_tune("bwd_pk"): unit blocks per partition chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
+int g_tzr_bwd_prof = 0;          // tzr_tune("bwd_prof"): the partition pass records phase timestamps per chunk (BwdPlan.prof)
 
 static void bwd_launch_sort(const TzrTable* d_tables, int n_tables, const BwdPlan& P, hipStream_t s) {
   const unsigned chunks = (unsigned)P.max_chunks;
@@ -975,7 +983,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   if (n_values == 0 || B == 0) return TZR_OK;
   if (!d_values) return TZR_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned chunks = (unsigned)P.max_chunks;
+  const unsigned chunks = (unsigned)P.max_pchunks;
   BwdSrcArgs A;
   A.feats = d_feats;
   A.values = d_values;
@@ -989,10 +997,10 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
     hipLaunchKernelGGL(tzr_bwd_prep_kernel, dim3(1), dim3(BWD_THREADS), 0, s, d_tables, n_tables, A,
                        n_feats, P);
     hipLaunchKernelGGL(tzr_bwd_part_kernel<false>, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                       n_tables, n_feats, A, g_tzr_bwd_one_wg_heavy, P);
+                       n_tables, n_feats, A, (g_tzr_bwd_one_wg_heavy & 1) | (g_tzr_bwd_prof ? 2 : 0), P);
   } else {
     hipLaunchKernelGGL(tzr_bwd_part_kernel<true>, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
-                       n_tables, n_feats, A, g_tzr_bwd_one_wg_heavy, P);
+                       n_tables, n_feats, A, (g_tzr_bwd_one_wg_heavy & 1) | (g_tzr_bwd_prof ? 2 : 0), P);
   }
   bwd_launch_sort(d_tables, n_tables, P, s);
   TZR_CHECK_LAUNCH();

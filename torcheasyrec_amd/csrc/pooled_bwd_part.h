@@ -20,6 +20,7 @@ struct BwdGeo {  // table-major geometry, in LDS (fused) or in the workspace
   const uint32_t* fstart;  // [F+1]
   const int32_t* fkey;     // [F]
   const int32_t* tchunk;   // [T+1]
+  const int32_t* tpchunk;  // [T+1]
 };
 
 // In-place exclusive scan of a[0..n) by the whole workgroup; a[n] = total.
@@ -56,35 +57,52 @@ struct BwdGeoLds {
   uint32_t fstart[BWD_GEO + 1];
   int32_t fkey[BWD_GEO];
   uint32_t tchunk[BWD_GEO + 1];
+  uint32_t tpchunk[BWD_GEO + 1];  // partition chunks
+  int64_t trows[BWD_GEO];     // the fields of TzrTable the plan reads: the descriptor is loaded ONCE,
+  int32_t tfirst[BWD_GEO];    // together with the feature descriptors (one round trip for the geometry)
+  int32_t tnfeats[BWD_GEO];
   uint32_t wtot[BWD_WAVES];
 };
 
-// Table-major segment starts and the chunk map, derived by every hist workgroup on its own
-// (F + T small loads and two block scans) so that the plan needs no single-workgroup launch ahead
-// of it.  Keys of the KJT this module does not own (table < 0) are ordered last and contribute
-// nothing.
+// Table-major segment starts and the chunk map, derived by every partition workgroup on its own
+// (F + T small loads -- issued together, one round trip -- and two block scans) so that the plan needs
+// no single-workgroup launch ahead of it.  Keys of the KJT this module does not own (table < 0) are
+// ordered last and contribute nothing.
 __device__ __forceinline__ void bwd_geometry(const TzrTable* __restrict__ tables, int T,
-                                             const BwdSrcArgs& A, int F, uint32_t ch, BwdGeoLds& G) {
-  for (int f = threadIdx.x; f < F; f += BWD_THREADS) {
-    const TzrFeature ft = A.feats[f];
+                                             const BwdSrcArgs& A, int F, uint32_t ch, uint32_t pch, BwdGeoLds& G) {
+  static_assert(BWD_GEO <= BWD_THREADS, "one feature and one table descriptor per thread");
+  const int i = threadIdx.x;
+  TzrFeature ft;
+  TzrTable tb;
+  ft.table = -1; ft.key = 0; ft.order = 0;
+  tb.rows = 0; tb.first_order = 0; tb.n_feats = 0;
+  if (i < F) ft = A.feats[i];
+  if (i < T) tb = tables[i];
+  if (i < F) {
     const int64_t key = ft.key;
     const int64_t n =
         ft.table < 0 ? 0 : (A.uniform ? A.B : A.offsets[(key + 1) * A.B] - A.offsets[key * A.B]);
     G.fstart[ft.order] = (uint32_t)n;
     G.fkey[ft.order] = ft.key;
   }
+  if (i < T) {
+    G.trows[i] = tb.rows;
+    G.tfirst[i] = tb.first_order;
+    G.tnfeats[i] = tb.n_feats;
+  }
   __syncthreads();
   bwd_block_scan(G.fstart, F, G.wtot);
-  for (int t = threadIdx.x; t < T; t += BWD_THREADS) {
-    const TzrTable tb = tables[t];
+  if (i < T) {
     const uint32_t s = tb.n_feats > 0 ? G.fstart[tb.first_order] : 0u;
     const uint32_t e = tb.n_feats > 0 ? G.fstart[tb.first_order + tb.n_feats] : 0u;
-    G.tchunk[t] = (e - s + ch - 1) / ch;
+    G.tchunk[i] = (e - s + ch - 1) / ch;
+    G.tpchunk[i] = (e - s + pch - 1) / pch;
   }
   __syncthreads();
   // tables are visited in first_order order == table-major position order only if table ids
-  // follow it; starts are absolute, so the chunk map just needs a prefix in table-id order
+  // follow it; starts are absolute, so the chunk maps just need a prefix in table-id order
   bwd_block_scan(G.tchunk, T, G.wtot);
+  bwd_block_scan(G.tpchunk, T, G.wtot);
 }
 
 // Table-major position p of table tb -> (local row, original lookup position): the lookups of a
@@ -136,10 +154,11 @@ struct BwdPartLds {
   // trips "Illegal instruction detected: Operand has incorrect register class" in this hipcc)
   BwdRankLds<BWD_NB> L;
   union {
-    BwdGeoLds G;           // prologue: table-major geometry
-    uint2 stage[BWD_CH];   // then: the chunk in slab order
+    BwdGeoLds G;             // prologue: table-major geometry
+    uint2 stage[BWD_SUB];    // then: one sub-tile in slab order
   };
-  uint32_t tot[BWD_NB + 1];  // table scan: bucket totals, then bucket starts
+  uint32_t tot[BWD_NB + 1];  // chunk: bucket counts -> slab-local bucket starts; table scan: bucket totals -> starts
+  uint16_t run[BWD_NB];      // chunk: lookups of each bucket placed by the sub-tiles so far
   uint32_t wtot[BWD_WAVES];
   uint32_t flag, any_heavy, nitems;
 };
@@ -155,10 +174,11 @@ __device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChun
   const int tid = threadIdx.x;
   const int lane = tid & (TZR_WAVE - 1);
   const int t = cd.t;
-  const int c0 = cd.first_chunk;
-  const int C = cd.last_chunk - cd.first_chunk;
+  const int c0 = cd.first_chunk;    // unit blocks
+  const int q0 = cd.first_pchunk;   // partition chunks: the rows read here
   const uint32_t ts = (uint32_t)cd.ts, te = (uint32_t)cd.te;
   const uint32_t ch = (uint32_t)P.ch;
+  const int C = (int)((te - ts + (uint32_t)P.pch - 1) / (uint32_t)P.pch);
   // 1. bucket totals = column sums of the chunks' counts.  Thread q of a half owns buckets 4q .. 4q+3
   //    (one published 8-byte word of a row + the first entry of the next word), the two halves of the
   //    workgroup take even / odd chunks; 8 chunks of independent loads in flight per thread.
@@ -173,7 +193,7 @@ __device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChun
         const int c = cb + 2 * j;
         a[j] = b[j] = 0;
         if (c < C) {
-          const uint64_t* row = reinterpret_cast<const uint64_t*>(P.lst + (size_t)(c0 + c) * BWD_LROW);
+          const uint64_t* row = reinterpret_cast<const uint64_t*>(P.lst + (size_t)(q0 + c) * BWD_LROW);
           a[j] = tzr_consume_u64(row + q);
           b[j] = tzr_consume_u64(row + q + 1);
         }
@@ -286,105 +306,184 @@ __device__ __forceinline__ void bwd_table_scan(const TzrTable& tb, const BwdChun
 }
 
 // ------------------------------------------------------------------------------------------
-// part: one chunk -> its slab
+// part: one partition chunk -> its slab
 // ------------------------------------------------------------------------------------------
-// Element order inside a chunk is table-major position order; bwd_rank_tile gives every element its
-// index in the chunk's stable bucket-sorted order; the elements are laid out in THAT order in LDS and
-// written back from there: one coalesced 8-byte {key, src} store per element.
+// A partition chunk is up to BWD_PK unit blocks of one table (pch positions).  All its lookups are loaded up
+// front (independent coalesced loads: one memory latency per workgroup), their buckets counted with LDS
+// atomics -> slab-local bucket starts (the row published for the table scan), then the lookups are ranked
+// sub-tile by sub-tile (BWD_SUB at a time, stable: bwd_rank_tile + the running count of each bucket) and
+// written to their slab position, staged through LDS so that neighbouring lanes store neighbouring
+// elements whenever they share a bucket.
+#define BWD_PROF(k)                                                                    \
+  do {                                                                                 \
+    if (prof_on && threadIdx.x == 0) P.prof[(size_t)q * 8 + (k)] = wall_clock64();     \
+  } while (0)
+
 template <bool FUSED>
 __device__ __forceinline__ void bwd_part_body(const TzrTable* __restrict__ tables, int T, int F,
                                               const BwdSrcArgs& A, const BwdPlan& P, int one_wg_heavy,
-                                              BwdPartLds& S, int c) {
+                                              BwdPartLds& S, int q) {
+  const bool prof_on = (one_wg_heavy & 2) != 0;  // bit 1 of the knob word: phase timestamps (tzr_tune("bwd_prof"))
+  one_wg_heavy &= 1;
+  BWD_PROF(0);
   BwdGeo G;
   if (FUSED) {
-    bwd_geometry(tables, T, A, F, (uint32_t)P.ch, S.G);
+    bwd_geometry(tables, T, A, F, (uint32_t)P.ch, (uint32_t)P.pch, S.G);
     G.fstart = S.G.fstart;
     G.fkey = S.G.fkey;
     G.tchunk = reinterpret_cast<const int32_t*>(S.G.tchunk);
-    if (c == 0) {  // the later kernels of the plan and the apply read it from the workspace
+    G.tpchunk = reinterpret_cast<const int32_t*>(S.G.tpchunk);
+    if (q == 0) {  // the later kernels of the plan and the apply read it from the workspace
       for (int o = threadIdx.x; o <= F; o += BWD_THREADS) P.feat_start[o] = S.G.fstart[o];
       for (int o = threadIdx.x; o < F; o += BWD_THREADS) P.feat_key[o] = S.G.fkey[o];
       for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
-      for (int t = threadIdx.x; t <= T; t += BWD_THREADS) P.tab_chunk[t] = (int32_t)S.G.tchunk[t];
+      for (int t = threadIdx.x; t <= T; t += BWD_THREADS) {
+        P.tab_chunk[t] = (int32_t)S.G.tchunk[t];
+        P.tab_pchunk[t] = (int32_t)S.G.tpchunk[t];
+      }
     }
   } else {
     G.fstart = P.feat_start;
     G.fkey = P.feat_key;
     G.tchunk = P.tab_chunk;
+    G.tpchunk = P.tab_pchunk;
   }
+  if (q == 0) {  // unit blocks behind the last table: nobody's
+    BwdChunkDesc none;
+    none.t = -1;
+    none.nb = none.exact = none.last_chunk = none.first_chunk = none.first_pchunk = 0;
+    none.s = none.e = none.ts = none.te = 0;
+    none.mult = 0;
+    for (int64_t c = (int64_t)G.tchunk[T] + threadIdx.x; c < P.max_chunks; c += BWD_THREADS) P.cdesc[c] = none;
+  }
+  if (q >= G.tpchunk[T]) return;
   BwdChunkDesc cd;
-  cd.t = -1;
-  cd.nb = cd.exact = cd.last_chunk = cd.first_chunk = cd.pad = 0;
-  cd.s = cd.e = cd.ts = cd.te = 0;
-  cd.mult = 0;
   TzrTable tb;
-  tb.rows = 0;
-  if (c < G.tchunk[T]) {
-    int lo = 0, hi = T;  // last t with tchunk[t] <= c (the non-empty table holding it)
+  {
+    int lo = 0, hi = T;  // last t with tpchunk[t] <= q (the non-empty table holding it)
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (G.tchunk[mid] <= c) lo = mid; else hi = mid;
+      if (G.tpchunk[mid] <= q) lo = mid; else hi = mid;
     }
-    tb = tables[lo];
+    if (FUSED) {  // the descriptor fields the plan reads sit in LDS already
+      tb.rows = S.G.trows[lo];
+      tb.first_order = S.G.tfirst[lo];
+      tb.n_feats = S.G.tnfeats[lo];
+    } else {
+      tb = tables[lo];
+    }
     cd.t = lo;
     bwd_bucket_params(tb.rows, &cd.nb, &cd.mult);
     cd.exact = tb.rows <= BWD_NB;
     cd.first_chunk = G.tchunk[lo];
     cd.last_chunk = G.tchunk[lo + 1];
+    cd.first_pchunk = G.tpchunk[lo];
     cd.ts = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order] : 0;
     cd.te = tb.n_feats > 0 ? (int64_t)G.fstart[tb.first_order + tb.n_feats] : cd.ts;
-    cd.s = cd.ts + (int64_t)(c - G.tchunk[lo]) * P.ch;
-    cd.e = min(cd.te, cd.s + (int64_t)P.ch);
   }
-  if (threadIdx.x == 0) P.cdesc[c] = cd;
-  if (cd.t < 0) return;
-  const int n = (int)(cd.e - cd.s);
-  const int lane = threadIdx.x & (TZR_WAVE - 1);
-  const int wv = threadIdx.x / TZR_WAVE;
-  // all of the chunk's elements are loaded up front (independent coalesced loads): the ranking
-  // then runs out of registers and pays one memory latency per workgroup
-  constexpr int kRounds = BWD_CH / BWD_THREADS;
-  const int pw = bwd_wave_span(n);
-  const int rounds = pw / TZR_WAVE;
-  uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
-  uint32_t vmask = 0;
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int lp = wv * pw + r * TZR_WAVE + lane;
-    kreg[r] = sreg[r] = dig[r] = 0u;
-    if (r < rounds && lp < n) {
-      vmask |= 1u << r;
-      int64_t kk;
-      bwd_elem0(G, tb, A, cd.s + lp, &kreg[r], &sreg[r], &kk);
-      dig[r] = bwd_bucket(kreg[r], cd.mult);
-      if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
-        const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[r]);
-        P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
+  const int64_t qs = cd.ts + (int64_t)(q - cd.first_pchunk) * P.pch;  // this workgroup's positions [qs, qe)
+  const int64_t qe = min(cd.te, qs + (int64_t)P.pch);
+  const int n = (int)(qe - qs);
+  {  // descriptors of the unit blocks the chunk covers
+    const int pk = P.pch / P.ch;
+    if ((int)threadIdx.x < pk) {
+      const int64_t s = qs + (int64_t)threadIdx.x * P.ch;
+      if (s < cd.te) {
+        BwdChunkDesc u = cd;
+        u.s = s;
+        u.e = min(cd.te, s + (int64_t)P.ch);
+        P.cdesc[cd.first_chunk + (s - cd.ts) / P.ch] = u;
       }
     }
   }
-  __syncthreads();  // the geometry in LDS is dead from here on: its space becomes the slab stage
-  bwd_rank_tile<BWD_NB, kRounds>(dig, vmask, rounds, bwd_bits((uint32_t)cd.nb - 1u), S.L, dest);
+  BWD_PROF(1);
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  // sub-tile j = positions [j * BWD_SUB, ...) of the chunk, dealt wave-contiguously inside the sub-tile
+  constexpr int kSubR = BWD_SUB / BWD_THREADS;  // rounds per sub-tile
+  constexpr int kMaxSub = BWD_PK * BWD_CH / BWD_SUB;
+  const int nsub = (n + BWD_SUB - 1) / BWD_SUB;
+  uint32_t kreg[kMaxSub * kSubR], sreg[kMaxSub * kSubR];
+  uint32_t vmask = 0;  // bit j * kSubR + r
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r)
-    if ((vmask >> r) & 1u) S.stage[dest[r]] = make_uint2(kreg[r], sreg[r]);
+  for (int j = 0; j < kMaxSub; ++j) {
+    const int nj = min(BWD_SUB, n - j * BWD_SUB);  // <= 0: past the chunk (workgroup-uniform)
+    const int pw = nj > 0 ? bwd_wave_span(nj) : 0;
+#pragma unroll
+    for (int r = 0; r < kSubR; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      kreg[j * kSubR + r] = sreg[j * kSubR + r] = 0u;
+      if (r * TZR_WAVE < pw && lp < nj) {
+        vmask |= 1u << (j * kSubR + r);
+        int64_t kk;
+        bwd_elem0(G, tb, A, qs + j * BWD_SUB + lp, &kreg[j * kSubR + r], &sreg[j * kSubR + r], &kk);
+        if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
+          const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[j * kSubR + r]);
+          P.bag_of[sreg[j * kSubR + r]] = (uint32_t)(kk * A.B + b);
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i <= BWD_NB; i += BWD_THREADS) S.tot[i] = 0;
+  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.run[i] = 0;
+  __syncthreads();  // (the geometry in LDS is dead from here on: its space becomes the stage)
+  BWD_PROF(2);
+#pragma unroll
+  for (int i = 0; i < kMaxSub * kSubR; ++i)
+    if ((vmask >> i) & 1u) atomicAdd(&S.tot[bwd_bucket(kreg[i], cd.mult)], 1u);
   __syncthreads();
-  uint2* __restrict__ slab = P.ks[1] + cd.s;
-  for (int i = threadIdx.x; i < n; i += BWD_THREADS) slab[i] = S.stage[i];
-  // the chunk's row of bucket starts, published for the table scan (another workgroup of this launch)
+  bwd_block_scan(S.tot, BWD_NB, S.wtot);  // slab-local start of every bucket, S.tot[NB] = n
+  BWD_PROF(3);
+  // the chunk's row of bucket starts: published for the table scan (another workgroup of this launch), and the
+  // arrival counted, BEFORE the slab is written -- the scan reads rows only, and it is the tail of the launch's
+  // longest dependent chain
   {
-    uint64_t* row = reinterpret_cast<uint64_t*>(P.lst + (size_t)c * BWD_LROW);
+    uint64_t* row = reinterpret_cast<uint64_t*>(P.lst + (size_t)q * BWD_LROW);
     for (int i = threadIdx.x; i < BWD_LROW / 4; i += BWD_THREADS) {
       uint64_t w = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w |= (uint64_t)S.L.lstart[min(4 * i + j, BWD_NB)] << (16 * j);
+      for (int j = 0; j < 4; ++j) w |= (uint64_t)(S.tot[min(4 * i + j, BWD_NB)] & 0xFFFFu) << (16 * j);
       tzr_publish_u64(row + i, w);
     }
   }
   tzr_drain_stores();
   __syncthreads();
-  if (threadIdx.x == 0)
-    S.flag = tzr_arrive(P.tarr + cd.t) == (uint32_t)(cd.last_chunk - cd.first_chunk) - 1u ? 1u : 0u;
-  __syncthreads();
-  if (S.flag) bwd_table_scan(tb, cd, one_wg_heavy, P, S);
+  BWD_PROF(4);
+  if (threadIdx.x == 0) {
+    const uint32_t Cp = (uint32_t)((cd.te - cd.ts + P.pch - 1) / P.pch);
+    S.flag = tzr_arrive(P.tarr + cd.t) == Cp - 1u ? 1u : 0u;
+  }
+  uint2* __restrict__ slab = P.ks[1] + qs;
+  const int wbits = bwd_bits((uint32_t)cd.nb - 1u);
+#pragma unroll
+  for (int j = 0; j < kMaxSub; ++j) {
+    if (j < nsub) {  // workgroup-uniform
+      const int nj = min(BWD_SUB, n - j * BWD_SUB);
+      const int rounds = bwd_wave_span(nj) / TZR_WAVE;
+      uint32_t dig[kSubR], dest[kSubR];
+      const uint32_t vm = (vmask >> (j * kSubR)) & ((1u << kSubR) - 1u);
+#pragma unroll
+      for (int r = 0; r < kSubR; ++r) dig[r] = ((vm >> r) & 1u) ? bwd_bucket(kreg[j * kSubR + r], cd.mult) : 0u;
+      bwd_rank_tile<BWD_NB, kSubR>(dig, vm, rounds, wbits, S.L, dest);
+      // sub-tile order first (LDS), then out: lanes that are neighbours in a wave store neighbouring elements
+#pragma unroll
+      for (int r = 0; r < kSubR; ++r)
+        if ((vm >> r) & 1u) S.stage[dest[r]] = make_uint2(kreg[j * kSubR + r], sreg[j * kSubR + r]);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nj; i += BWD_THREADS) {
+        const uint2 v = S.stage[i];
+        const uint32_t d = bwd_bucket(v.x, cd.mult);
+        slab[S.tot[d] + (uint32_t)S.run[d] + ((uint32_t)i - (uint32_t)S.L.lstart[d])] = v;
+      }
+      __syncthreads();
+      for (int d = threadIdx.x; d < BWD_NB; d += BWD_THREADS)
+        S.run[d] = (uint16_t)(S.run[d] + (S.L.lstart[d + 1] - S.L.lstart[d]));
+      __syncthreads();
+    }
+  }
+  BWD_PROF(5);
+  if (S.flag) {
+    bwd_table_scan(tb, cd, one_wg_heavy, P, S);
+    BWD_PROF(6);
+  }
 }

@@ -318,20 +318,25 @@ __global__ __launch_bounds__(FWD_THREADS) TZR_WAVES_PER_EU(6) void tzr_pooled_fw
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
     int tile_b, FwdDsts dsts, const TzrTable* __restrict__ bwd_tables, int T, int F, BwdSrcArgs A,
-    int one_wg_heavy, BwdPlan P, int n_part, int n_fwd) {
+    int one_wg_heavy, BwdPlan P, int n_part, int n_fwd, int mix) {
   __shared__ FwdPlanLds L;
   // roles interleaved in dispatch order -- chunk, tile, chunk, tile, ... -- so that both kinds are resident
   // from the first wave of workgroups on: with the chunks first the forward only started when they were done
   // (measured: 80 us fused = 30 + 50)
+  // `mix` chunks, then one tile, repeated until one kind runs out; the rest follows
   const int b = (int)blockIdx.x;
-  const int pairs = min(n_part, n_fwd);
+  const int period = mix + 1;
+  const int groups = min(n_part / mix, n_fwd);  // whole groups of (mix chunks + 1 tile)
   int role_part, idx;
-  if (b < 2 * pairs) {
-    role_part = !(b & 1);
-    idx = b >> 1;
+  if (b < groups * period) {
+    const int g = b / period, r = b - g * period;
+    role_part = r < mix;
+    idx = role_part ? g * mix + r : g;
   } else {
-    role_part = n_part > n_fwd;
-    idx = b - pairs;
+    const int rest = b - groups * period;           // blocks after the interleaved region
+    const int part_left = n_part - groups * mix;    // chunks first: they carry the longer dependent chain
+    role_part = rest < part_left;
+    idx = role_part ? groups * mix + rest : groups + (rest - part_left);
   }
   if (role_part) {
     bwd_part_body<true>(bwd_tables, T, F, A, P, one_wg_heavy, L.part, idx);
@@ -401,7 +406,9 @@ extern "C" int tzr_pooled_fwd_ex(const TzrTable* d_tables, const TzrFeature* d_f
 
 extern int g_tzr_bwd_one_wg_heavy;
 extern int g_tzr_bwd_force_prep;
+extern int g_tzr_bwd_prof;
 int g_tzr_fwd_plan_fuse = 1;  // tzr_tune("fwd_plan_fuse"): 0 = tzr_pooled_fwd_plan never fuses
+int g_tzr_fwd_plan_mix = 1;   // tzr_tune("fwd_plan_mix"): plan chunks per forward tile in the fused launch's dispatch order
 
 // Forward + the partition pass of the backward plan in ONE launch (tzr_pooled_fwd_plan_kernel) when the
 // batch has one id per bag, fp32 tables, no per-sample weights and at most FWD1_SLOTS slots; *fused = 1 then,
@@ -446,12 +453,12 @@ extern "C" int tzr_pooled_fwd_plan(const TzrTable* d_tables, const TzrFeature* d
   A.B = B;
   A.uniform = 1;
   const int tb1 = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 32 : (B >= 8192 ? 16 : 8));
-  const unsigned n_part = (unsigned)P.max_chunks;
+  const unsigned n_part = (unsigned)P.max_pchunks;
   const unsigned n_fwd = (unsigned)((B + tb1 - 1) / tb1);
   hipLaunchKernelGGL(tzr_bwd_zero_kernel, dim3(1), dim3(BWD_THREADS), 0, s, P.tarr, P.tcount, n_tables);
   hipLaunchKernelGGL(tzr_pooled_fwd_plan_kernel, dim3(n_part + n_fwd), dim3(FWD_THREADS), 0, s, d_tables, d_feats,
                      d_slots, n_slots, d_values, B, tb1, dsts, d_bwd_tables, n_tables, n_bwd_feats, A,
-                     g_tzr_bwd_one_wg_heavy, P, (int)n_part, (int)n_fwd);
+                     (g_tzr_bwd_one_wg_heavy & 1) | (g_tzr_bwd_prof ? 2 : 0), P, (int)n_part, (int)n_fwd, std::max(1, g_tzr_fwd_plan_mix));
   TZR_CHECK_LAUNCH();
   *fused = 1;
   return TZR_OK;

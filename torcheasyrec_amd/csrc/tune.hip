@@ -6,9 +6,12 @@
 extern int g_tzr_fwd_tile_b;
 extern int g_tzr_fwd_variant;
 extern int g_tzr_fwd_plan_fuse;
+extern int g_tzr_fwd_plan_mix;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
+extern int g_tzr_bwd_pk;
 extern int g_tzr_bwd_one_wg_heavy;
+extern int g_tzr_bwd_prof;
 extern int g_tzr_bwd_apply_pipe;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
@@ -24,12 +27,24 @@ extern "C" int tzr_tune(const char* name, int value) {
     g_tzr_fwd_variant = value;
     return TZR_OK;
   }
+  if (!strcmp(name, "fwd_plan_mix")) {
+    g_tzr_fwd_plan_mix = value;
+    return TZR_OK;
+  }
   if (!strcmp(name, "fwd_plan_fuse")) {
     g_tzr_fwd_plan_fuse = value;
     return TZR_OK;
   }
+  if (!strcmp(name, "bwd_pk")) {
+    g_tzr_bwd_pk = value;
+    return TZR_OK;
+  }
   if (!strcmp(name, "bwd_ch")) {
     g_tzr_bwd_ch = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_prof")) {
+    g_tzr_bwd_prof = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_one_wg_heavy")) {
