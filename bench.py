@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--weak-per-rank-batch", type=int, default=8192,
                     help="per-rank batch of the secondary (weak-scaling) reading at N > 1")
     ap.add_argument("--no-e2e", action="store_true", help="skip the TrainPipeline / pinned-host-batch reading")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the secondary readings (config 2 at batch 8192, Zipf ids, row-wise Adagrad)")
     ap.add_argument("--e2e-steps", type=int, default=40)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--optimizer", choices=["adagrad", "rowwise_adagrad"], default="adagrad")
@@ -135,19 +137,27 @@ def enable_tunable_gemm():
 
 
 def pmc_traffic(args, B_local):
-    """HBM bytes per step of the six embedding launches from the PMC passes kept under profiles/
-    (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, see the file).  Only valid for the
-    configuration it was recorded on; null otherwise."""
+    """HBM bytes per step of the six embedding launches from the rocprofv3 PMC passes kept under profiles/
+    (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, scripts/pmc_summary.py).  Counters cannot be read
+    inside this process, so the figure comes from a file -- but only from one recorded on THIS library: the
+    summary carries the digest of the kernel sources it was measured on (torcheasyrec_amd/_build._digest), and a
+    file of another digest (a kernel changed since) is refused.  Returns (bytes | None, why)."""
     import glob
 
+    from torcheasyrec_amd import _build
+
+    if not (B_local == 65536 and args.dist == "uniform" and not args.rows_cap and args.optimizer == "adagrad"):
+        return None, "recorded for B = 65536, uniform ids, adagrad only"
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))  # newest round last
-    if not (found and B_local == 65536 and args.dist == "uniform" and not args.rows_cap):
-        return None
-    p = found[-1]
-    try:
-        return float(json.load(open(p))["kernels"]["__embedding_fwd_bwd__"]["traffic_corrected"])
-    except Exception:
-        return None
+    dig = _build._digest()
+    for p in reversed(found):
+        try:
+            d = json.load(open(p))
+            if d.get("lib_digest") == dig:
+                return float(d["kernels"]["__embedding_fwd_bwd__"]["traffic_corrected"]), os.path.relpath(p, ROOT)
+        except Exception:
+            continue
+    return None, f"no profiles/r*/pmc_traffic.json recorded on library digest {dig[:16]} (kernels changed since the last PMC pass)"
 
 
 def cpu_baseline(seconds: float):
@@ -482,6 +492,92 @@ def main():
                "graph_ms_per_step": None if e_graph is None else e_graph / n_e2e * 1e3}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
+    def embedding_stages(ebc_, kjts, host_values, Bl, optimizer, iters=10):
+        """HIP events around the three C-ABI calls of the embedding path on the launching stream (a GPU-side sleep
+        first, so the host is not in the gaps) -> stage times + the roofline fraction of SURVEY 8(d)'s bytes."""
+        tm = _Timers()
+        gbuf = torch.randn(Bl, 26 * 16, device=dev) * 1e-3
+        for i in range(2):
+            ebc_._launch_forward(kjts[i % len(kjts)], ("sparse",))
+            ebc_.plan_backward(kjts[i % len(kjts)], ("sparse",))
+            ebc_._launch_backward(kjts[i % len(kjts)], ("sparse",), [gbuf])
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(2.0e7))
+        ebc_._timers = tm
+        for i in range(iters):
+            k = kjts[i % len(kjts)]
+            ebc_._launch_forward(k, ("sparse",))
+            ebc_.plan_backward(k, ("sparse",))
+            ebc_._launch_backward(k, ("sparse",), [gbuf])
+        torch.cuda.synchronize()
+        ebc_._timers = None
+        ab = [algorithmic_bytes(hv, Bl, rows, optimizer=optimizer) for hv in host_values]
+        nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
+        f, p_, a_ = tm.mean_ms("fwd"), tm.mean_ms("plan"), tm.mean_ms("apply")
+        return {"fwd_ms": f, "bwd_plan_ms": p_, "bwd_apply_ms": a_, "algorithmic_bytes": nbytes,
+                "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
+
+    # N = 1: the other readings BASELINE.json / the north star ask for, on the same box in the same process:
+    # config 2 (examples/dlrm_criteo.config at its own batch_size 8192: whole step + embedding stages), the
+    # Criteo-like Zipf ids, and the north star's optimizer (row-wise Adagrad; its own tables: 13 GB + 0.8 GB state)
+    if rank == 0 and world == 1 and not sharded and not args.no_secondary and args.optimizer == "adagrad" \
+            and args.dist == "uniform" and not args.rows_cap and B_global == 65536:
+        secondary = {}
+        # (a) config 2: batch 8192 on one GPU, hipGraph replay like the headline
+        B2 = 8192
+        b2 = []
+        h2 = []
+        for s_ in range(4):
+            d_, k_, l_ = synthetic_batch(2000 + s_, B2, rows)
+            h2.append(k_.values().numpy())
+            b2.append((d_.to(dev), k_.to(dev), l_.to(dev)))
+        for i in range(3):
+            step_body(*b2[i % 4])
+        torch.cuda.synchronize()
+        g2, pool2 = [], None
+        for bi in range(4):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, pool=pool2, stream=work_stream):
+                step_body(*b2[bi])
+            pool2 = g_.pool()
+            g2.append(g_)
+        torch.cuda.synchronize()
+        for i in range(5):
+            g2[i % 4].replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n2 = max(args.steps, 30)
+        for i in range(n2):
+            g2[i % 4].replay()
+        torch.cuda.synchronize()
+        e2_ = time.perf_counter() - t1
+        secondary["config2_batch8192"] = {"config": "examples/dlrm_criteo.config, 1 GPU, batch 8192 (BASELINE.json configs[1])",
+                                          "value": B2 * n2 / e2_, "unit": "samples/s", "ms_per_step": e2_ / n2 * 1e3,
+                                          "embedding": embedding_stages(ebc, [b[1] for b in b2], h2, B2, "adagrad")}
+        del g2
+        # (b) Zipf(1.05) ids at the headline batch: embedding stages
+        bz, hz = [], []
+        for s_ in range(4):
+            _, k_, _ = synthetic_batch(3000 + s_, B_global, rows, dist="zipf")
+            hz.append(k_.values().numpy())
+            bz.append(k_.to(dev))
+        secondary["zipf_ids_batch65536"] = {"config": "ids Zipf(1.05) clipped to the table (SURVEY 8d secondary distribution)",
+                                            "embedding": embedding_stages(ebc, bz, hz, B_global, "adagrad")}
+        del bz
+        # (c) row-wise Adagrad, the optimizer the north star names: its own collection (weights [rows, 16] + [rows] state)
+        try:
+            from torcheasyrec_amd.embedding import EmbeddingBagCollection
+
+            ebc_rw = EmbeddingBagCollection(criteo_tables(rows), device=dev, optimizer=SparseOptimizerConfig(kind="rowwise_adagrad", lr=1e-3),
+                                            groups={"sparse": SPARSE_KEYS})
+            secondary["rowwise_adagrad_batch65536"] = {
+                "config": "fused row-wise Adagrad (protos/optimizer.proto:133-139), uniform ids",
+                "embedding": embedding_stages(ebc_rw, [b[1] for b in batches[:4]], host_vals[:4], B_global, "rowwise_adagrad")}
+            del ebc_rw
+        except Exception as e:  # e.g. not enough free HBM next to the main model
+            secondary["rowwise_adagrad_batch65536"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+
     # inside a captured graph); the kernels and inputs are the ones of the timed region
     if ebc is not None:
         # The three C-ABI calls of the embedding path (pooled forward, backward plan, backward
@@ -495,7 +591,7 @@ def main():
         ebc._timers = timers
         for i in range(min(args.steps, 10)):
             kjt_i = batches[i % nb][1]
-            ebc._launch_forward(kjt_i, ("sparse",), with_plan=True)
+            ebc._launch_forward(kjt_i, ("sparse",))
             ebc.plan_backward(kjt_i, ("sparse",))
             ebc._launch_backward(kjt_i, ("sparse",), [gbuf])
         torch.cuda.synchronize()
@@ -535,6 +631,7 @@ def main():
             # bytes (its time counts against the aggregate in full).
             tot = (t_fwd + t_plan + t_apply) * 1e-3
             ach = (fwd_b + bwd_b) / tot
+            traffic, traffic_src = pmc_traffic(args, B_local)
 
             def stage(name, kernels, nbytes, ms):
                 return {"stage": name, "kernels": kernels, "launch_ms": ms, "algorithmic_bytes": nbytes,
@@ -544,7 +641,7 @@ def main():
                 "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_kernel; "
                                           "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_kernel)",
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                "traffic": pmc_traffic(args, B_local), "launch_ms": t_fwd + t_plan + t_apply,
+                "traffic": traffic, "launch_ms": t_fwd + t_plan + t_apply,
                 "algorithmic_bytes": fwd_b + bwd_b,
                 "unique_rows": float(np.mean([a["U"] for a in ab])),
                 "kernels": [stage("forward", ["tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
@@ -553,8 +650,9 @@ def main():
                             stage("backward apply", ["tzr_bwd_reduce_kernel"], bwd_b, t_apply)],
                 "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe on this part, profiles/r01c
                 "frac_of_practical_ceiling": ach / 3.97e12,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, summed over the six "
-                                  "kernels, recorded in the newest profiles/r*/pmc_traffic.json (not measurable inside bench.py)"}
+                "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command on this library "
+                                   f"(digest-matched), summed over the six kernels: {traffic_src}") if traffic is not None
+                                  else f"null: {traffic_src}"}
             # kept for continuity with round 1's line
             out["embedding"] = {"fwd_ms": t_fwd, "bwd_plan_ms": t_plan, "bwd_apply_ms": t_apply,
                                 "fwd_bwd_GBps": ach / 1e9, "frac_of_8TBps": ach / HBM_PEAK}

@@ -275,29 +275,12 @@ int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature
                         int64_t B,
                         int uniform_bag_len, void* ws, size_t ws_bytes, void* stream);
 
-/* The pooled forward (tzr_pooled_fwd_ex) and the FIRST launch of tzr_pooled_bwd_plan for the same batch in one
- * launch: both depend on the ids only, and the plan's partition pass (latency-bound, ~40 us at B = 65536) runs
- * under the forward's memory traffic instead of behind it.  Arguments: those of tzr_pooled_fwd_ex, then those of
- * tzr_pooled_bwd_plan (d_bwd_tables / d_bwd_feats are the backward's descriptors).  Fused when the batch has one
- * id per bag, fp32 tables, no per-sample weights and at most 128 slots: *fused = 1 and the caller completes the
- * plan with tzr_pooled_bwd_plan_finish before tzr_pooled_bwd_apply.  Otherwise *fused = 0: only the forward ran
- * (ws untouched) and the caller plans with tzr_pooled_bwd_plan. */
-int tzr_pooled_fwd_plan(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
-                        const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
-                        const int64_t* d_offsets, const float* d_weights, int64_t B,
-                        const TzrDst* h_dsts, int n_dst, int uniform_bag_len, int flags,
-                        const TzrTable* d_bwd_tables, int n_tables, const TzrFeature* d_bwd_feats,
-                        int n_bwd_feats, int n_keys, int64_t max_rows, int max_dim, int64_t n_values,
-                        int64_t n_positions, void* ws, size_t ws_bytes, int* fused, void* stream);
-/* Second (last) launch of the plan after a fused tzr_pooled_fwd_plan on the same workspace. */
-int tzr_pooled_bwd_plan_finish(const TzrTable* d_tables, int n_tables, int n_feats, int max_dim,
-                               int64_t n_values, int64_t n_positions, void* ws, size_t ws_bytes, void* stream);
-
 /* Inspection of a finished plan (tests / debugging): byte offsets into `ws` of out8[0] = the sorted
- * {row, lookup position} pairs (uint32 x 2 per table-major position) of every table, out8[1] = the
- * chunk slabs of the partition pass, out8[2] = the table-major start of every lookup by order
- * (uint32[n_feats + 1]); out8[3..7] internal.  After a plan, the pairs of one table hold every lookup
- * of the table exactly once with equal rows adjacent and, inside a row, ascending lookup positions. */
+ * {row, lookup position} pairs (uint32 x 2 per table-major position) of every table with more than
+ * 512 rows, out8[1] = the bucket-partitioned pairs (final for tables of <= 512 rows), out8[2] = the
+ * table-major start of every lookup by order (uint32[n_feats + 1]); out8[3..7] internal.  After a
+ * plan, the pairs of one table hold every lookup of the table exactly once with equal rows adjacent
+ * and, inside a row, ascending lookup positions. */
 int tzr_pooled_bwd_plan_view(int64_t n_values, int64_t n_positions, int n_feats, int n_tables,
                              int max_dim, int64_t* out8);
 

@@ -18,7 +18,7 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = [b"fwd_tile_b", b"fwd_variant", b"fwd_plan_fuse", b"fwd_plan_mix", b"bwd_ch", b"bwd_pk", b"bwd_one_wg_heavy", b"bwd_force_prep"]
+KNOBS = [b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
 
 
 class Timers:
@@ -59,14 +59,13 @@ def main():
             g = torch.randn(B, 416, device=dev) * 1e-3
             for spec in args.sets:
                 for k in KNOBS:
-                    L.tzr_tune(k, 1 if k in (b"fwd_plan_fuse", b"fwd_plan_mix") else 0)
-                L.tzr_tune(b"bwd_apply_pipe", -1)
+                    L.tzr_tune(k, 0)
                 for kv in [x for x in spec.split(",") if x]:
                     name, v = kv.split("=")
                     assert L.tzr_tune(name.encode(), int(v)) == 0, kv
                 for i in range(3):
                     kjt = batches[i % 4]
-                    ebc._launch_forward(kjt, ("sparse",), with_plan=True)
+                    ebc._launch_forward(kjt, ("sparse",))
                     ebc.plan_backward(kjt, ("sparse",))
                     ebc._launch_backward(kjt, ("sparse",), [g])
                 torch.cuda.synchronize()
@@ -75,7 +74,7 @@ def main():
                 ebc._timers = tm
                 for i in range(args.iters):
                     kjt = batches[i % 4]
-                    ebc._launch_forward(kjt, ("sparse",), with_plan=True)
+                    ebc._launch_forward(kjt, ("sparse",))
                     ebc.plan_backward(kjt, ("sparse",))
                     ebc._launch_backward(kjt, ("sparse",), [g])
                 torch.cuda.synchronize()

@@ -140,7 +140,7 @@ def run_case(mode, knobs, iters, emu, ebc, batches, g, noise_a, noise_b, side, d
         if mode == "main":
             ws = ebc.plan_backward(kjt)
         elif mode == "main_apply":
-            ebc._launch_forward(kjt, ("__all__",), with_plan=True)
+            ebc._launch_forward(kjt, ("__all__",))
             ws = ebc.plan_backward(kjt)
             ebc._launch_backward(kjt, ("__all__",), [g])
         elif mode == "main_noise":  # the plan in the main stream, unrelated kernels on the side stream
@@ -165,14 +165,14 @@ def run_case(mode, knobs, iters, emu, ebc, batches, g, noise_a, noise_b, side, d
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 ws = ebc.plan_backward(kjt)
-            ebc._launch_forward(kjt, ("__all__",), with_plan=True)
+            ebc._launch_forward(kjt, ("__all__",))
         elif mode == "side_apply":
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 ws = ebc.plan_backward(kjt)
                 ev = torch.cuda.Event()
                 ev.record()
-            ebc._launch_forward(kjt, ("__all__",), with_plan=True)
+            ebc._launch_forward(kjt, ("__all__",))
             (noise_b[: B * 16 * F].view(B, -1) * g).sum()
             cur.wait_event(ev)
             ebc._launch_backward(kjt, ("__all__",), [g])

@@ -25,7 +25,7 @@ g = torch.randn(B, 416, device=dev) * 1e-3
 torch.cuda.synchronize()
 for i in range(12):
     kjt = batches[i % 4]
-    ebc._launch_forward(kjt, ("sparse",), with_plan=True)
+    ebc._launch_forward(kjt, ("sparse",))
     ebc.plan_backward(kjt, ("sparse",))
     ebc._launch_backward(kjt, ("sparse",), [g])
 torch.cuda.synchronize()

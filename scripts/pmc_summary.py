@@ -45,7 +45,10 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
         ks["__embedding_fwd_bwd__"] = {"traffic_corrected": agg, "kernels": six,
                                        "note": "forward corrected as above; the other five at FETCH_SIZE + WRITE_SIZE as counted "
                                                "(64-B row gathers are exact; the 8-B key/source streams of the plan are uncalibrated)"}
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 "
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from torcheasyrec_amd import _build  # the digest of the kernel sources these counters were measured on
+
+    json.dump({"lib_digest": _build._digest(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 "
                          "--warmup 2 --no-cpu-baseline --no-graph; B=65536 uniform ids, adagrad interleaved",
                "units": "bytes per launch (mean over dispatches after the first); see scripts/pmc_summary.py for the corrections",
                "kernels": ks}, open(out, "w"), indent=1)

@@ -294,7 +294,6 @@ inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
-inline unsigned long long wall_clock64() { return 0; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 5  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 4  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -111,9 +111,6 @@ _SIGNATURES = {
                               _i32, _i32, _vp]),
     "tzr_pooled_fwd_ex": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst),
                                  _i32, _i32, _i32, _vp]),
-    "tzr_pooled_fwd_plan": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i64, C.POINTER(TzrDst), _i32, _i32, _i32,
-                                   _vp, _i32, _vp, _i32, _i32, _i64, _i32, _i64, _i64, _vp, _sz, C.POINTER(C.c_int), _vp]),
-    "tzr_pooled_bwd_plan_finish": (_i32, [_vp, _i32, _i32, _i32, _i64, _i64, _vp, _sz, _vp]),
     "tzr_pooled_bwd_workspace": (_sz, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "tzr_pooled_bwd_plan_view": (_i32, [_i64, _i64, _i32, _i32, _i32, _vp]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,

@@ -13,12 +13,7 @@
 #define BWD_TH 256   // a bucket with more lookups is "heavy": sorted by the heavy kernel, cut at blocks
 #define BWD_UMAX (BWD_CH + BWD_TH)  // capacity of one unit of the apply: < BWD_CH + BWD_TH lookups
 #define BWD_HT 1024  // tile of the heavy-bucket sort (4 rounds per wave: every role of the sort kernel within 64 VGPRs)
-#define BWD_GEO 256  // lookups / tables up to which every partition workgroup derives the geometry itself
-#define BWD_SUB 1024  // lookups ranked at a time by a partition workgroup (one sub-tile of its chunk)
-#define BWD_PK 4      // a partition chunk = up to BWD_PK unit blocks: 4x fewer workgroups pay the pass's fixed
-                      // costs (geometry, publish, arrival) and a table scan reads 4x fewer rows
-#define BWD_LROW (BWD_NB + 4)  // uint16 entries per chunk row of bucket starts (NB + 1 used; 8-byte stores)
-#define BWD_SEGB 256           // chunks per batch when a bucket range is gathered from the chunk slabs
+#define BWD_GEO 1024 // lookups / tables up to which every hist workgroup derives the geometry itself
 #define BWD_MAXDIM 256
 #define BWD_SENT 0xFFFFFFFFu  // never a row id
 
@@ -27,70 +22,46 @@
 #define BWD_LEAD_WHOLE 2u  // ... and does not end inside it
 #define BWD_TRAIL 4u       // the last run continues past the end of this span
 
-// Everything a workgroup needs to know about its chunk, written once by the partition kernel: one
+// Everything a workgroup needs to know about its chunk, written once by the hist kernel: one
 // load instead of a binary search over the chunk map plus dependent table lookups at the head of
 // every scatter / reduce workgroup (these kernels are latency-, not bandwidth-bound).
-// Chunk c of a table is (a) the c-th block of BWD_CH table-major INPUT positions for the partition
-// kernel (its slab) and (b) the c-th UNIT of sorted positions [ucut[c], ucut[c+1]) for sort / reduce.
+// Chunk c of a table is (a) the c-th block of BWD_CH table-major INPUT positions for hist / scatter
+// and (b) the c-th UNIT of sorted positions [ucut[c], ucut[c+1]) for reduce / stitch.
 struct BwdChunkDesc {
   int32_t t;           // table, -1 for surplus chunks
   int32_t nb;          // buckets of the table's partition pass (<= BWD_NB)
-  int32_t exact;       // every bucket is one row id
+  int32_t exact;       // every bucket is one row id: the partition pass alone is the sort
   int32_t last_chunk;  // first chunk of the NEXT table (stitch walks up to it)
-  int32_t first_chunk; // first chunk of this table
-  int32_t first_pchunk; // first PARTITION chunk of this table
   int64_t s, e;        // input positions [s, e) of the chunk
   int64_t ts, te;      // positions of the whole table
   uint64_t mult;       // bucket of row id k = (k * mult) >> 32 (monotone in k)
 };
 
-// Work item of the sort kernel: heavy bucket `bin` of table t = sorted positions [start, binbase[bin+1]).
-// Its lookups sit in the chunk slabs of the table (bucket `bin` of every chunk, in chunk order =
-// table-major order); a TILE is the lookups of chunks [c_begin, c_end) (relative to the table's first
-// chunk).  Tiles are cut by a rule that needs no per-chunk data (bwd_tile_chunks: about BWD_HT / 2 lookups
-// when the bucket is spread evenly); a tile worker takes whatever its chunks hold, BWD_HT lookups at a time.
-#define BWD_HK_ONEPASS 0  // bucket of <= BWD_NB row ids: one counting pass, tile-parallel
-#define BWD_HK_HOT 1      // wide bucket with more than one tile: split around its hot row, tile-parallel
-#define BWD_HK_SERIAL 2   // the whole bucket by one workgroup (c_begin = 0, c_end = chunks of the table)
-#define BWD_HK_COPY 3     // bucket = one row (exact table): the tile is copied, chunk order IS the order
-struct BwdHeavy {
+struct BwdHeavy {  // work item of the sort kernel: heavy bucket `bin` of table t = positions [start, end)
   int32_t t;
-  uint32_t bin, start;
-  int32_t c_begin, c_end;
-  int32_t kind;
-  int32_t pad[2];
+  uint32_t bin, start, end;
+  int32_t tile;  // >= 0: BWD_HT-tile of a bucket one counting pass sorts (<= BWD_NB row ids);
+                 // -1: the whole bucket, several passes, one workgroup
+  int32_t pad[3];
 };
-// chunks per tile of a heavy bucket of `run` lookups in a table of C chunks
-static inline __host__ __device__ uint32_t bwd_tile_chunks(uint32_t run, uint32_t C) {
-  const uint64_t g = ((uint64_t)(BWD_HT / 2) * C) / run;
-  return g < 1 ? 1u : (uint32_t)g;
-}
-// The work items of table t (sorted positions from ts, index t) are listed from hlist[bwd_hbase(ts, t)]:
-// a heavy bucket of `run` lookups makes at most 4 * run / BWD_HT + 1 tiles and there are at most
-// n_t / (BWD_TH + 1) heavy buckets, so the regions of consecutive tables never overlap.
-static inline __host__ __device__ uint32_t bwd_hbase(uint32_t ts, uint32_t t) {
-  return 4u * (ts / BWD_HT) + ts / (BWD_TH + 1) + 8u * t;
-}
 
 struct BwdPlan {  // pointers into the caller workspace
   uint32_t* feat_start;    // [F+1] start of each lookup (by order) in table-major position space
   int32_t* feat_key;       // [F] KJT key of the lookup with that order
   int32_t* feat_by_order;  // [F]
-  int32_t* tab_chunk;      // [T+1] first chunk (unit) of each table
-  int32_t* tab_pchunk;     // [T+1] first partition chunk of each table
-  uint2* ks[3];            // [N] {local row id, original lookup position}: ks[1] holds the chunk SLABS
-                           //     (partition chunk q = pch input positions of its table, stably ordered by
-                           //     bucket inside the chunk), ks[0] the sorted lookups of every table, ks[2] is the
-                           //     ping-pong scratch of the serial heavy path; 8-byte elements = ONE store per move
+  int32_t* tab_chunk;      // [T+1] first chunk of each table
+  uint2* ks[3];            // [N] {local row id, original lookup position}: ks[1] holds the bucket-
+                           //     partitioned lookups (final for exact tables), ks[0] the sorted ones
+                           //     of every other table; one 8-byte element = ONE store per move.
+                           //     ks[2]: ping-pong partner of ks[0] in the multi-pass (serial) heavy path --
+                           //     ks[1] is read-only for the whole sort launch (other workgroups walk it)
   uint32_t* bag_of;        // [NV] bag index key*B+b of every lookup (only when bags are jagged)
-  uint16_t* lst;           // [max_pchunks * BWD_LROW] slab-local start of every bucket of every partition chunk (+ total)
+  uint32_t* hist;          // [max_chunks * BWD_NB] chunk-exclusive bucket counts
   uint32_t* binbase;       // [T * (BWD_NB+1)] global start of every (table, bucket), end of the last
   uint32_t* ucut;          // [max_chunks + 1] first sorted position of every unit
-  uint32_t* ub0;           // [max_chunks + 1] first bucket a unit may hold light lookups of
-  uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (the unit lies inside one heavy bucket)
+  uint32_t* uflag;         // [max_chunks] 1 = nothing for the unit sort (exact table / inside one heavy bucket)
   uint32_t* hbits;         // [T * BWD_NB/32] bitmap of the heavy buckets of every table
-  uint32_t* tarr;          // [T] chunks of the table that have published their slab (zeroed before the launch)
-  uint32_t* tcount;        // [T] work items of the table (heavy tiles), listed from hlist[bwd_hbase(ts, t)]
+  uint32_t* hcount;        // [1] work items listed
   uint32_t* tab_stitch;    // [T] 1 = the table holds sorted buckets: runs may cross unit boundaries
   uint32_t* sexp;          // [T * BWD_NB] units overlapping the (sorted) bucket when > 1, else 0
   uint32_t* sarr;          // [T * BWD_NB] ... of which have published their boundary record (apply)
@@ -101,12 +72,9 @@ struct BwdPlan {  // pointers into the caller workspace
   float* clead;            // [max_chunks * max_dim]
   float* ctrail;           // [max_chunks * max_dim]
   BwdChunkDesc* cdesc;     // [max_chunks]
-  uint64_t* prof;          // [max_chunks * 8] phase timestamps of the partition pass (tzr_tune("bwd_prof"); else unused)
   int64_t max_chunks;
-  int64_t max_pchunks;
   int64_t max_heavy;
-  int32_t ch;   // positions per unit block (multiple of 256, <= BWD_CH)
-  int32_t pch;  // positions per partition chunk (ch * 1 .. BWD_PK)
+  int32_t ch;  // positions per chunk (multiple of 256, <= BWD_CH)
 };
 
 // Positions per chunk.  The plan / apply kernels are latency-bound: the time of a launch is the
@@ -121,14 +89,6 @@ static inline int bwd_pick_ch(int64_t N) {
   return BWD_CH;
 }
 static inline int64_t bwd_max_chunks(int64_t N, int T, int ch) { return N / ch + T + 1; }
-// Unit blocks per partition chunk: as many (up to BWD_PK) as still leave ~400 partition workgroups.
-// g_tzr_bwd_pk (tzr_tune "bwd_pk") overrides.
-extern int g_tzr_bwd_pk;
-static inline int bwd_pick_pk(int64_t N, int ch) {
-  if (g_tzr_bwd_pk >= 1 && g_tzr_bwd_pk <= BWD_PK) return g_tzr_bwd_pk;
-  const int64_t k = N / ((int64_t)ch * 400);
-  return k < 1 ? 1 : (k > BWD_PK ? BWD_PK : (int)k);
-}
 
 // NV = ids in the KJT values array; N = capacity of the table-major position space (sum over
 // lookups of their key length: a key read through two tables is sorted twice).
@@ -137,25 +97,20 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   TzrCarver c(ws);
   BwdPlan q;
   q.ch = bwd_pick_ch(N);
-  q.pch = q.ch * bwd_pick_pk(N, q.ch);
   q.max_chunks = bwd_max_chunks(N, T, q.ch);
-  q.max_pchunks = bwd_max_chunks(N, T, q.pch);
-  q.max_heavy = 4 * (N / BWD_HT) + N / (BWD_TH + 1) + 8 * (int64_t)T + 8;  // bwd_hbase(N, T)
+  q.max_heavy = N / (BWD_TH + 1) + N / BWD_HT + 1;
   q.feat_start = c.take<uint32_t>(F + 1);
   q.feat_key = c.take<int32_t>(F);
   q.feat_by_order = c.take<int32_t>(F);
   q.tab_chunk = c.take<int32_t>(T + 1);
-  q.tab_pchunk = c.take<int32_t>(T + 1);
   for (int i = 0; i < 3; ++i) q.ks[i] = c.take<uint2>(N);
   q.bag_of = c.take<uint32_t>(NV);
-  q.lst = c.take<uint16_t>((size_t)q.max_pchunks * BWD_LROW);
+  q.hist = c.take<uint32_t>(q.max_chunks * BWD_NB);
   q.binbase = c.take<uint32_t>((size_t)T * (BWD_NB + 1));
   q.ucut = c.take<uint32_t>(q.max_chunks + 1);
-  q.ub0 = c.take<uint32_t>(q.max_chunks + 1);
   q.uflag = c.take<uint32_t>(q.max_chunks);
   q.hbits = c.take<uint32_t>((size_t)T * (BWD_NB / 32));
-  q.tarr = c.take<uint32_t>((size_t)T + 4);
-  q.tcount = c.take<uint32_t>((size_t)T + 4);
+  q.hcount = c.take<uint32_t>(4);
   q.tab_stitch = c.take<uint32_t>(T);
   q.sexp = c.take<uint32_t>((size_t)T * BWD_NB);
   q.sarr = c.take<uint32_t>((size_t)T * BWD_NB);
@@ -166,7 +121,6 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.clead = c.take<float>((size_t)q.max_chunks * max_dim);
   q.ctrail = c.take<float>((size_t)q.max_chunks * max_dim);
   q.cdesc = c.take<BwdChunkDesc>(q.max_chunks);
-  q.prof = c.take<uint64_t>((size_t)q.max_pchunks * 8);
   if (p) *p = q;
   return c.off;
 }
@@ -222,10 +176,7 @@ __device__ __forceinline__ void bwd_rank_tile(const uint32_t (&dig)[MAXR], uint3
   const int wv = tid / TZR_WAVE;
   for (int i = tid; i < BWD_WAVES * NB_; i += BWD_THREADS) (&L.wcnt[0][0])[i] = 0;
   __syncthreads();
-  // (accessed as LDS, never through a generic pointer: a `volatile uint16_t*` here made this hipcc emit
-  // an illegal compare against src_shared_base once the sort kernel grew; the asm statements keep the
-  // compiler from moving the read past the write, the LDS keeps a wave's accesses in order)
-  uint16_t* wrow = L.wcnt[wv];
+  volatile uint16_t* wrow = L.wcnt[wv];
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t loc[MAXR];
 #pragma unroll
@@ -242,13 +193,9 @@ __device__ __forceinline__ void bwd_rank_tile(const uint32_t (&dig)[MAXR], uint3
       }
       const uint32_t rank = (uint32_t)__popcll(peers & lt);
       const uint32_t pre = v ? (uint32_t)wrow[d] : 0u;
-      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
       if (v && rank == 0) wrow[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
-      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
       loc[r] = pre + rank;
     }
   }

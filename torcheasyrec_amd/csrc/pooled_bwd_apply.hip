@@ -312,7 +312,7 @@ __device__ __forceinline__ void bwd_arrive_and_stitch(const TzrTable& tb, const 
   }
 }
 
-template <bool ADAM, bool PIPE>
+template <bool ADAM>
 __device__ __forceinline__ void bwd_reduce_body(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
@@ -335,7 +335,9 @@ __device__ __forceinline__ void bwd_reduce_body(
     if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;  // overlaps no bucket: nobody waits for it
     return;
   }
-  const uint2* __restrict__ KS = P.ks[0];  // the sort kernel's output
+  // exact tables are final after the partition pass (ks[1]); everything else was finished by the
+  // sort kernel (ks[0])
+  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
@@ -372,119 +374,46 @@ __device__ __forceinline__ void bwd_reduce_body(
   uint32_t ckey = BWD_SENT;
   float4 csum = tzr_zero4();
 
-  if constexpr (PIPE) {
-    // Software pipeline, two tiles deep: the control state of a tile (which lanes end a run, whether
-    // the run is the one inherited from the previous range) is a function of the keys in LDS alone,
-    // so the loads of tile i+1 -- gradient rows, weights, state -- are issued BEFORE tile i's are
-    // waited for.  A wave then has two tiles of independent loads in flight instead of one (the loop
-    // is a chain of ~16 memory round trips per wave otherwise).  Same arithmetic, same order.
-    struct Ctl {
-      uint32_t key;
-      bool valid, tail, in_lead, do_apply, ends_lead;
-    };
-    auto control = [&](int t0) {
-      Ctl q;
-      const int idx = t0 + gi;
-      q.valid = lane_on && idx < r1;
-      q.key = q.valid ? sK[idx + 1] : BWD_SENT;
-      const uint32_t nxt = q.valid ? sK[idx + 2] : BWD_SENT;
-      q.tail = q.valid && q.key != nxt;
-      q.in_lead = lead_open && q.key == leadkey;
-      q.do_apply = q.tail && !q.in_lead;
-      q.ends_lead = __any(q.tail && q.in_lead);
-      if (q.ends_lead) {
-        flags |= BWD_LEAD;
-        lead_open = false;
-      }
-      return q;
-    };
-    auto issue = [&](int t0, const Ctl& q, float4& g, float4& w4, float4& m4) {
-      g = tzr_zero4();
-      w4 = tzr_zero4();
-      if (q.valid)
-        g = bwd_lookup_grad(feats, tb, P.feat_by_order, sG, one, single, grad_mode, offsets, weights,
-                            P.bag_of, B, uniform, sS[t0 + gi], c);
-      if (q.do_apply)
-        w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)q.key * tb.w_stride + 4 * c);
-      m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)q.key, c, q.do_apply);
-    };
-    Ctl qc, qn;
-    float4 g, w4, m4, gn = tzr_zero4(), wn = tzr_zero4(), mn = tzr_zero4();
-    if (r0 < r1) {
-      qc = control(r0);
-      issue(r0, qc, g, w4, m4);
+for (int t0 = r0; t0 < r1; t0 += gw) {
+    const int idx = t0 + gi;
+    const bool valid = lane_on && idx < r1;
+    const uint32_t key = valid ? sK[idx + 1] : BWD_SENT;
+    const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
+    const bool tail = valid && key != nxt;
+    float4 g = tzr_zero4();
+    if (valid)
+      g = bwd_lookup_grad(feats, tb, P.feat_by_order, sG, one, single, grad_mode, offsets, weights,
+                          P.bag_of, B, uniform, sS[idx], c);
+    const bool in_lead = lead_open && key == leadkey;
+    const bool do_apply = tail && !in_lead;
+    float4 w4 = tzr_zero4();
+    if (do_apply)  // issued before the scan: overlaps the gradient gathers
+      w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * c);
+    const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, c, do_apply);
+    // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
+    // distance d implies one run in between)
+    for (int d = 1; d < gw; d <<= 1) {
+      const uint32_t ok = __shfl_up(key, d * lg, 64);
+      const float4 ov = make_float4(__shfl_up(g.x, d * lg, 64), __shfl_up(g.y, d * lg, 64),
+                                    __shfl_up(g.z, d * lg, 64), __shfl_up(g.w, d * lg, 64));
+      if (gi >= d && ok == key) g = tzr_add4(ov, g);
     }
-    for (int t0 = r0; t0 < r1; t0 += gw) {
-      const bool more = t0 + gw < r1;  // wave-uniform
-      if (more) {
-        qn = control(t0 + gw);
-        issue(t0 + gw, qn, gn, wn, mn);
-      }
-      const uint32_t key = qc.key;
-      for (int d = 1; d < gw; d <<= 1) {
-        const uint32_t ok = __shfl_up(key, d * lg, 64);
-        const float4 ov = make_float4(__shfl_up(g.x, d * lg, 64), __shfl_up(g.y, d * lg, 64),
-                                      __shfl_up(g.z, d * lg, 64), __shfl_up(g.w, d * lg, 64));
-        if (gi >= d && ok == key) g = tzr_add4(ov, g);
-      }
-      if (cvalid && key == ckey) g = tzr_add4(csum, g);  // earlier lookups first
-      if (qc.tail && qc.in_lead) {  // the run inherited from the previous range ends here
-        rlead[wv][4 * c + 0] = g.x; rlead[wv][4 * c + 1] = g.y;
-        rlead[wv][4 * c + 2] = g.z; rlead[wv][4 * c + 3] = g.w;
-      }
-      bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, c, g, w4, m4, qc.do_apply, lg, c, lane);
-      const int nv = min(gw, r1 - t0);
-      const int last = (nv - 1) * lg;
-      ckey = __shfl(key, last, 64);
-      cvalid = __shfl((int)(qc.valid && !qc.tail), last, 64) != 0;
-      csum = bwd_shfl4(g, last + (lane_on ? c : 0));
-      qc = qn;
-      g = gn;
-      w4 = wn;
-      m4 = mn;
+    if (cvalid && key == ckey) g = tzr_add4(csum, g);  // earlier lookups first
+    if (tail && in_lead) {  // the run inherited from the previous range ends here
+      rlead[wv][4 * c + 0] = g.x; rlead[wv][4 * c + 1] = g.y;
+      rlead[wv][4 * c + 2] = g.z; rlead[wv][4 * c + 3] = g.w;
     }
-  } else {
-  for (int t0 = r0; t0 < r1; t0 += gw) {
-      const int idx = t0 + gi;
-      const bool valid = lane_on && idx < r1;
-      const uint32_t key = valid ? sK[idx + 1] : BWD_SENT;
-      const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
-      const bool tail = valid && key != nxt;
-      float4 g = tzr_zero4();
-      if (valid)
-        g = bwd_lookup_grad(feats, tb, P.feat_by_order, sG, one, single, grad_mode, offsets, weights,
-                            P.bag_of, B, uniform, sS[idx], c);
-      const bool in_lead = lead_open && key == leadkey;
-      const bool do_apply = tail && !in_lead;
-      float4 w4 = tzr_zero4();
-      if (do_apply)  // issued before the scan: overlaps the gradient gathers
-        w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * c);
-      const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, c, do_apply);
-      // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
-      // distance d implies one run in between)
-      for (int d = 1; d < gw; d <<= 1) {
-        const uint32_t ok = __shfl_up(key, d * lg, 64);
-        const float4 ov = make_float4(__shfl_up(g.x, d * lg, 64), __shfl_up(g.y, d * lg, 64),
-                                      __shfl_up(g.z, d * lg, 64), __shfl_up(g.w, d * lg, 64));
-        if (gi >= d && ok == key) g = tzr_add4(ov, g);
-      }
-      if (cvalid && key == ckey) g = tzr_add4(csum, g);  // earlier lookups first
-      if (tail && in_lead) {  // the run inherited from the previous range ends here
-        rlead[wv][4 * c + 0] = g.x; rlead[wv][4 * c + 1] = g.y;
-        rlead[wv][4 * c + 2] = g.z; rlead[wv][4 * c + 3] = g.w;
-      }
-      if (__any(tail && in_lead)) {
-        flags |= BWD_LEAD;
-        lead_open = false;
-      }
-      bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
-      // carry out of the tile: its last valid lookup, if that run goes on
-      const int nv = min(gw, r1 - t0);
-      const int last = (nv - 1) * lg;
-      ckey = __shfl(key, last, 64);
-      cvalid = __shfl((int)(valid && !tail), last, 64) != 0;
-      csum = bwd_shfl4(g, last + (lane_on ? c : 0));
+    if (__any(tail && in_lead)) {
+      flags |= BWD_LEAD;
+      lead_open = false;
     }
+    bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
+    // carry out of the tile: its last valid lookup, if that run goes on
+    const int nv = min(gw, r1 - t0);
+    const int last = (nv - 1) * lg;
+    ckey = __shfl(key, last, 64);
+    cvalid = __shfl((int)(valid && !tail), last, 64) != 0;
+    csum = bwd_shfl4(g, last + (lane_on ? c : 0));
   }
   if (r0 < r1 && cvalid) {  // the last run continues past this range
     float* dst = lead_open ? rlead[wv] : rtrail[wv];
@@ -552,18 +481,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  bwd_reduce_body<ADAM, false>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+  bwd_reduce_body<ADAM>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
 }
-
-// two tiles of loads in flight per wave; 5 waves per SIMD (96 VGPRs)
-__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(5) void tzr_bwd_reduce_pipe_kernel(
-    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
-    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
-    int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  bwd_reduce_body<false, true>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
-}
-
-int g_tzr_bwd_apply_pipe = -1;  // tzr_tune("bwd_apply_pipe"): 1 = two tiles of loads in flight per wave, 0 = one, -1 = default
 
 extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
                                     int n_feats, int n_tables, int max_dim,
@@ -617,8 +536,6 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
                      d_weights, B, (int)uniform, grad_mode, G, opt, max_dim, P)
   if (opt.kind == TZR_OPT_ADAM) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<true>));  // Adam holds two state rows per lane: no registers for a second tile
-  } else if (g_tzr_bwd_apply_pipe > 0) {  // default: the one-tile loop until the pipelined one is measured
-    TZR_REDUCE_LAUNCH(tzr_bwd_reduce_pipe_kernel);
   } else {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<false>));
   }

@@ -17,7 +17,6 @@
 //   * ids of a tile are `tile_b` consecutive int64 per feature (key-major KJT), re-used from L1 by
 //     the lanes of the tile.
 #include "tzr_common.h"
-#include "pooled_bwd_part.h"
 
 #define FWD_THREADS 256
 #define FWD_UNROLL 4
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
 #define FWD1_SLOTS 128    // slots per workgroup row (blockIdx.y); DLRM-Criteo: 104
 #define FWD1_MAX_IDS 1024 // ids of a (sub-)tile held in LDS: groups x samples
 
-int g_tzr_fwd_variant = 0;  // tzr_tune("fwd_variant"): 0 = by shape, 1 = general kernel only
+int g_tzr_fwd_variant = 0;  // tzr_tune("fwd_variant"): 0 = by shape, 1 = general kernel only, 2 = LDS-ids kernel whenever eligible
 
 struct Fwd1Slot {  // 24 bytes
   const float* w;  // table row 0 + the slot's float4 column group
@@ -183,33 +182,20 @@ struct Fwd1Slot {  // 24 bytes
   int32_t w_stride;
 };
 
-struct Fwd1Lds {
-  Fwd1Slot rs[FWD1_SLOTS];
-  int64_t srows[FWD1_SLOTS];   // per slot, then compacted per id group
-  int64_t grows[FWD1_SLOTS];
-  int64_t sid[FWD1_MAX_IDS];
-  int32_t sfeat[FWD1_SLOTS];   // KJT key index, same
-  int32_t gfeat[FWD1_SLOTS];
-  uint32_t wsum[FWD_THREADS / TZR_WAVE];
-  uint16_t gid[FWD1_SLOTS];    // id group of a slot (consecutive slots of one key share it)
-};
-
-// tile `bx` of tile_b samples, slot row `by`
-__device__ __forceinline__ void fwd_u1_body(
+__global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
-    int tile_b, const FwdDsts& dsts, Fwd1Lds& L, int bx, int by) {
-  Fwd1Slot* rs = L.rs;
-  int64_t* srows = L.srows;
-  int32_t* sfeat = L.sfeat;
-  int64_t* grows = L.grows;
-  int32_t* gfeat = L.gfeat;
-  uint16_t* gid = L.gid;
-  int64_t* sid = L.sid;
-  uint32_t* wsum = L.wsum;
+    int tile_b, FwdDsts dsts) {
+  __shared__ Fwd1Slot rs[FWD1_SLOTS];
+  __shared__ int64_t srows[FWD1_SLOTS];   // per slot, then compacted per id group
+  __shared__ int32_t sfeat[FWD1_SLOTS];   // KJT key index, same
+  __shared__ int64_t grows[FWD1_SLOTS];
+  __shared__ int32_t gfeat[FWD1_SLOTS];
+  __shared__ uint16_t gid[FWD1_SLOTS];    // id group of a slot (consecutive slots of one key share it)
+  __shared__ int64_t sid[FWD1_MAX_IDS];
+  __shared__ uint32_t wsum[FWD_THREADS / TZR_WAVE];
   static_assert(FWD1_SLOTS <= FWD_THREADS, "one slot per thread in the prologue");
-  static_assert(FWD_THREADS == BWD_THREADS, "the fused launch runs both roles with one block size");
-  const int s0 = by * FWD1_SLOTS;
+  const int s0 = blockIdx.y * FWD1_SLOTS;
   const int ns = min(FWD1_SLOTS, n_slots - s0);
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
@@ -256,7 +242,7 @@ __device__ __forceinline__ void fwd_u1_body(
     ngroups = (int)tot;
   }
   __syncthreads();
-  const int64_t b0 = (int64_t)bx * tile_b;
+  const int64_t b0 = (int64_t)blockIdx.x * tile_b;
   const int nb = (int)min((int64_t)tile_b, B - b0);
   const int sub = min(nb, FWD1_MAX_IDS / ngroups);  // samples per LDS pass (ngroups <= FWD1_SLOTS: >= 8)
   // k / ns by multiplication: the quotient is at most one short (ns = 1: 2^32 does not fit, 2^32 - 1 is one short too)
@@ -298,53 +284,6 @@ __device__ __forceinline__ void fwd_u1_body(
   }
 }
 
-__global__ __launch_bounds__(FWD_THREADS) TZR_WAVES_PER_EU(6) void tzr_pooled_fwd_u1_kernel(
-    const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
-    const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
-    int tile_b, FwdDsts dsts) {
-  __shared__ Fwd1Lds L;
-  fwd_u1_body(tables, feats, slots, n_slots, values, B, tile_b, dsts, L, (int)blockIdx.x, (int)blockIdx.y);
-}
-
-// The forward AND the partition pass of the backward plan (pooled_bwd_part.h) in one launch: both read the
-// batch's ids and nothing else of each other.  Workgroups [0, n_part) are chunks of the plan (they come first:
-// the table scans at their tail are the longest dependent chain of the launch), the rest forward tiles.  The
-// partition's ~40 us of latency-bound work run under the forward's memory traffic instead of behind it.
-union FwdPlanLds {
-  Fwd1Lds fwd;
-  BwdPartLds part;
-};
-__global__ __launch_bounds__(FWD_THREADS) TZR_WAVES_PER_EU(6) void tzr_pooled_fwd_plan_kernel(
-    const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
-    const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
-    int tile_b, FwdDsts dsts, const TzrTable* __restrict__ bwd_tables, int T, int F, BwdSrcArgs A,
-    int one_wg_heavy, BwdPlan P, int n_part, int n_fwd, int mix) {
-  __shared__ FwdPlanLds L;
-  // roles interleaved in dispatch order -- chunk, tile, chunk, tile, ... -- so that both kinds are resident
-  // from the first wave of workgroups on: with the chunks first the forward only started when they were done
-  // (measured: 80 us fused = 30 + 50)
-  // `mix` chunks, then one tile, repeated until one kind runs out; the rest follows
-  const int b = (int)blockIdx.x;
-  const int period = mix + 1;
-  const int groups = min(n_part / mix, n_fwd);  // whole groups of (mix chunks + 1 tile)
-  int role_part, idx;
-  if (b < groups * period) {
-    const int g = b / period, r = b - g * period;
-    role_part = r < mix;
-    idx = role_part ? g * mix + r : g;
-  } else {
-    const int rest = b - groups * period;           // blocks after the interleaved region
-    const int part_left = n_part - groups * mix;    // chunks first: they carry the longer dependent chain
-    role_part = rest < part_left;
-    idx = role_part ? groups * mix + rest : groups + (rest - part_left);
-  }
-  if (role_part) {
-    bwd_part_body<true>(bwd_tables, T, F, A, P, one_wg_heavy, L.part, idx);
-    return;
-  }
-  fwd_u1_body(tables, feats, slots, n_slots, values, B, tile_b, dsts, L.fwd, idx, 0);
-}
-
 // flags: TZR_FWD_MIXED_DTYPE = some table holds fp16 rows (TzrTable.w_dtype is honoured); without it
 // every table is read as fp32 and the kernel carries no per-row dtype test (measured: the test costs
 // 4-5 us of the 49 us DLRM-Criteo forward).
@@ -373,7 +312,10 @@ extern "C" int tzr_pooled_fwd_ex(const TzrTable* d_tables, const TzrFeature* d_f
   const bool wt = d_weights != nullptr;
   const bool mx = (flags & TZR_FWD_MIXED_DTYPE) != 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (u1 && !wt && !mx && g_tzr_fwd_variant != 1) {
+  // measured on MI355X (profiles/r03a/emb_ab.txt): equal on uniform ids at B = 65536 (48-49 us both), 42.6 vs
+  // 45.2 us on Zipf ids; at B = 8192 the general kernel is faster (9.9 vs 10.9-12.4 us: the prologue is paid by
+  // more, smaller workgroups) -- so by batch size unless forced (fwd_variant 2)
+  if (u1 && !wt && !mx && (g_tzr_fwd_variant == 2 || (g_tzr_fwd_variant == 0 && B >= 32768))) {
     // tiles of 32 samples at Criteo batch sizes: 26 id groups x 32 = 832 ids per workgroup in LDS
     const int tb1 = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 32 : (B >= 8192 ? 16 : 8));
     dim3 grid1((unsigned)((B + tb1 - 1) / tb1), (unsigned)((n_slots + FWD1_SLOTS - 1) / FWD1_SLOTS));
@@ -401,66 +343,6 @@ extern "C" int tzr_pooled_fwd_ex(const TzrTable* d_tables, const TzrFeature* d_f
 #undef TZR_FWD_PICK
 #undef TZR_FWD_LAUNCH
   TZR_CHECK_LAUNCH();
-  return TZR_OK;
-}
-
-extern int g_tzr_bwd_one_wg_heavy;
-extern int g_tzr_bwd_force_prep;
-extern int g_tzr_bwd_prof;
-int g_tzr_fwd_plan_fuse = 1;  // tzr_tune("fwd_plan_fuse"): 0 = tzr_pooled_fwd_plan never fuses
-int g_tzr_fwd_plan_mix = 1;   // tzr_tune("fwd_plan_mix"): plan chunks per forward tile in the fused launch's dispatch order
-
-// Forward + the partition pass of the backward plan in ONE launch (tzr_pooled_fwd_plan_kernel) when the
-// batch has one id per bag, fp32 tables, no per-sample weights and at most FWD1_SLOTS slots; *fused = 1 then,
-// and the plan is completed with tzr_pooled_bwd_plan_finish.  Otherwise the plain forward runs, *fused = 0,
-// and the caller plans with tzr_pooled_bwd_plan as before.
-extern "C" int tzr_pooled_fwd_plan(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats,
-                                   const TzrSlot* d_slots, int n_slots, const int64_t* d_values,
-                                   const int64_t* d_offsets, const float* d_weights, int64_t B,
-                                   const TzrDst* h_dsts, int n_dst, int uniform_bag_len, int flags,
-                                   const TzrTable* d_bwd_tables, int n_tables, const TzrFeature* d_bwd_feats,
-                                   int n_bwd_feats, int n_keys, int64_t max_rows, int max_dim, int64_t n_values,
-                                   int64_t n_positions, void* ws, size_t ws_bytes, int* fused, void* stream) {
-  if (!fused) return TZR_ERR_INVALID;
-  *fused = 0;
-  const bool eligible = g_tzr_fwd_plan_fuse && uniform_bag_len == 1 && !d_weights && !(flags & TZR_FWD_MIXED_DTYPE) &&
-                        n_slots > 0 && n_slots <= FWD1_SLOTS && g_tzr_fwd_variant != 1 && B > 0 && n_values > 0 &&
-                        n_bwd_feats <= BWD_GEO && n_tables <= BWD_GEO && !g_tzr_bwd_force_prep && d_values;
-  if (!eligible)
-    return tzr_pooled_fwd_ex(d_tables, d_feats, n_feats, d_slots, n_slots, d_values, d_offsets, d_weights, B, h_dsts,
-                             n_dst, uniform_bag_len, flags, stream);
-  if (!d_tables || !d_feats || !d_slots || !h_dsts || n_feats <= 0 || n_dst <= 0 || n_dst > TZR_MAX_DST)
-    return TZR_ERR_INVALID;
-  BwdPlan P;
-  const int rc = bwd_plan_check(d_bwd_tables, n_tables, d_bwd_feats, n_bwd_feats, n_keys, max_rows, max_dim, d_offsets,
-                                n_values, n_positions, B, uniform_bag_len, ws, ws_bytes, &P);
-  if (rc != TZR_OK) return rc;
-  FwdDsts dsts;
-  for (int i = 0; i < TZR_MAX_DST; ++i) {
-    dsts.d[i].ptr = 0;
-    dsts.d[i].stride = 0;
-  }
-  for (int i = 0; i < n_dst; ++i) {
-    if (!h_dsts[i].ptr || (h_dsts[i].stride & 3) || (h_dsts[i].ptr & 15)) return TZR_ERR_INVALID;
-    if (h_dsts[i].stride > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;
-    dsts.d[i] = h_dsts[i];
-  }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  BwdSrcArgs A;
-  A.feats = d_bwd_feats;
-  A.values = d_values;
-  A.offsets = d_offsets;
-  A.B = B;
-  A.uniform = 1;
-  const int tb1 = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 32 : (B >= 8192 ? 16 : 8));
-  const unsigned n_part = (unsigned)P.max_pchunks;
-  const unsigned n_fwd = (unsigned)((B + tb1 - 1) / tb1);
-  hipLaunchKernelGGL(tzr_bwd_zero_kernel, dim3(1), dim3(BWD_THREADS), 0, s, P.tarr, P.tcount, n_tables);
-  hipLaunchKernelGGL(tzr_pooled_fwd_plan_kernel, dim3(n_part + n_fwd), dim3(FWD_THREADS), 0, s, d_tables, d_feats,
-                     d_slots, n_slots, d_values, B, tb1, dsts, d_bwd_tables, n_tables, n_bwd_feats, A,
-                     (g_tzr_bwd_one_wg_heavy & 1) | (g_tzr_bwd_prof ? 2 : 0), P, (int)n_part, (int)n_fwd, std::max(1, g_tzr_fwd_plan_mix));
-  TZR_CHECK_LAUNCH();
-  *fused = 1;
   return TZR_OK;
 }
 

@@ -5,14 +5,10 @@
 
 extern int g_tzr_fwd_tile_b;
 extern int g_tzr_fwd_variant;
-extern int g_tzr_fwd_plan_fuse;
-extern int g_tzr_fwd_plan_mix;
 extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
-extern int g_tzr_bwd_pk;
 extern int g_tzr_bwd_one_wg_heavy;
-extern int g_tzr_bwd_prof;
-extern int g_tzr_bwd_apply_pipe;
+extern int g_tzr_bwd_debug;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_fwd_wgs;
@@ -27,32 +23,16 @@ extern "C" int tzr_tune(const char* name, int value) {
     g_tzr_fwd_variant = value;
     return TZR_OK;
   }
-  if (!strcmp(name, "fwd_plan_mix")) {
-    g_tzr_fwd_plan_mix = value;
-    return TZR_OK;
-  }
-  if (!strcmp(name, "fwd_plan_fuse")) {
-    g_tzr_fwd_plan_fuse = value;
-    return TZR_OK;
-  }
-  if (!strcmp(name, "bwd_pk")) {
-    g_tzr_bwd_pk = value;
-    return TZR_OK;
-  }
   if (!strcmp(name, "bwd_ch")) {
     g_tzr_bwd_ch = value;
-    return TZR_OK;
-  }
-  if (!strcmp(name, "bwd_prof")) {
-    g_tzr_bwd_prof = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_one_wg_heavy")) {
     g_tzr_bwd_one_wg_heavy = value;
     return TZR_OK;
   }
-  if (!strcmp(name, "bwd_apply_pipe")) {
-    g_tzr_bwd_apply_pipe = value;
+  if (!strcmp(name, "bwd_debug")) {
+    g_tzr_bwd_debug = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_plain")) {

@@ -112,11 +112,18 @@ class FusedDenseAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self, grads: Optional[List[torch.Tensor]] = None) -> None:
+    def sync_lr(self) -> None:
+        """Mirror ``param_groups[0]["lr"]`` into the device scalar the kernel reads.  `step` does it itself outside a
+        graph capture; a captured step must not (the fill would be replayed): call this before every replay."""
         g = self.param_groups[0]
         if g["lr"] != self._lr_host:
             self._lr_dev.fill_(g["lr"])
             self._lr_host = g["lr"]
+
+    def step(self, grads: Optional[List[torch.Tensor]] = None) -> None:
+        g = self.param_groups[0]
+        if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.sync_lr()
         rows = []
         for i, p in enumerate(self.params):
             gr = p.grad if grads is None else grads[i]
@@ -149,3 +156,28 @@ class FusedDenseAdam:
             self._state[int(i)] = torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t])
         for k, v in sd["param_groups"][0].items():
             self.param_groups[0][k] = v
+
+
+def sync_learning_rates(model, optimizer=None) -> None:
+    """Before replaying a hipGraph that contains update kernels: copy every learning rate a scheduler may have changed
+    (fused sparse optimizers of the model's collections, the dense optimizer behind its wrappers) into the device
+    scalars the captured kernels read.  No-ops when nothing changed; never call it under capture."""
+    seen = set()
+    mods = list(model.modules()) if hasattr(model, "modules") else []
+    for m in mods:
+        for name in ("fused_optimizer",):
+            try:
+                fo = getattr(m, name, None)
+            except Exception:
+                fo = None
+            if fo is not None and id(fo) not in seen and hasattr(fo, "sync_lr"):
+                seen.add(id(fo))
+                fo.sync_lr()
+    opt = optimizer
+    hops = 0
+    while opt is not None and hops < 8:
+        if hasattr(opt, "sync_lr"):
+            opt.sync_lr()
+            break
+        opt = getattr(opt, "_optimizer", None)
+        hops += 1

@@ -17,7 +17,6 @@ KeyedTensor`` with keys in table-then-feature order).  Differences by design:
 """
 from __future__ import annotations
 
-import ctypes as C
 import math
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -120,14 +119,29 @@ class FusedSparseOptimizer:
         return self._ebc.table_weights()
 
     def lr_device(self, device: torch.device) -> torch.Tensor:
-        lr = float(self.param_groups[0]["lr"])
+        """The device scalar the update kernels read.  Outside a graph capture it is refreshed from
+        ``param_groups[0]["lr"]`` here; UNDER capture nothing is written (a captured ``fill_`` would reset the
+        learning rate on every replay): whoever replays graphs calls ``sync_lr`` before each replay."""
         if self._lr_dev is None or self._lr_dev.device != device:
+            lr = float(self.param_groups[0]["lr"])
             self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=device)
             self._lr_host = lr
-        elif lr != self._lr_host:
+        elif not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.sync_lr(device)
+        return self._lr_dev
+
+    def sync_lr(self, device: Optional[torch.device] = None) -> None:
+        """Mirror ``param_groups[0]["lr"]`` (which schedulers mutate, /root/reference/tzrec/main.py:877-879) into the
+        device scalar.  Call outside capture, before every replay of a graph that holds update kernels."""
+        if self._lr_dev is None:
+            if device is None:
+                return
+            self.lr_device(device)
+            return
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
             self._lr_dev.fill_(lr)
             self._lr_host = lr
-        return self._lr_dev
 
     def zero_grad(self, set_to_none: bool = True) -> None:  # tables never hold .grad
         pass
@@ -203,7 +217,7 @@ def mask_frozen_descriptors(tables: np.ndarray, feats: np.ndarray, frozen: Seque
 class _PooledLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ebc, kjt, dst_names, hook):  # hook: zero-size tensor that requires grad
-        outs = ebc._launch_forward(kjt, dst_names, with_plan=True)
+        outs = ebc._launch_forward(kjt, dst_names)
         ctx.ebc, ctx.kjt, ctx.dst_names = ebc, kjt, dst_names
         return tuple(outs)
 
@@ -279,7 +293,6 @@ class EmbeddingBagCollection(nn.Module):
         # whenever other kernels of the main stream ran next to it, while the same kernels in ONE stream
         # were right in 220 of 220 (NOTES.md "side-stream plan"); and the plan is ~60 us of a step now.
         self.async_plan = False
-        self.fuse_plan = True  # the training forward carries the plan's first launch when the library can fuse it
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
@@ -420,10 +433,7 @@ class EmbeddingBagCollection(nn.Module):
         offsets = None if uniform else kjt.offsets()
         return uniform, offsets
 
-    def _launch_forward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], with_plan: bool = False) -> List[torch.Tensor]:
-        """K5 (+K8).  `with_plan` (the training forward): the first launch of the backward plan rides in the same
-        launch when the library can fuse it (tzr_pooled_fwd_plan: one id per bag, fp32 tables, no per-sample
-        weights); the plan is then completed by `plan_backward` / `_launch_backward` (tzr_pooled_bwd_plan_finish)."""
+    def _launch_forward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
         layout = self._layout_for(dst_names)
         meta = self._meta(kjt.keys(), layout)
         B = kjt.stride()
@@ -434,53 +444,17 @@ class EmbeddingBagCollection(nn.Module):
         for i, o in enumerate(outs):
             dsts[i].ptr = _lib.ptr(o)
             dsts[i].stride = o.stride(0)
-        flags = _lib.FWD_MIXED_DTYPE if self._has_fp16 else 0
-        if (with_plan and self.fuse_plan and self.fused_optimizer is not None and uniform and kjt.weights_or_none() is None
-                and not self._has_fp16 and getattr(kjt, "_tzr_plan", None) is None and kjt.values().numel() > 0):
-            L = _lib.lib()
-            N = kjt.values().numel()
-            max_rows, max_dim = self._bwd_dims()
-            NP = self._n_positions(kjt)
-            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, NP, len(self._lookups), len(self._configs), B, max_dim), self._device)
-            fused = C.c_int(0)
-            ev = self._timers.start("fwd") if self._timers is not None else None
-            rc = L.tzr_pooled_fwd_plan(
-                _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
-                _lib.ptr(meta.d_slots), len(meta.slots_np), _lib.ptr(kjt.values()), _lib.ptr(offsets),
-                None, B, dsts, len(outs), 1, flags,
-                _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), meta.n_keys,
-                max_rows, max_dim, N, NP, _lib.ptr(ws), ws.numel(), C.byref(fused), _lib.stream_ptr(self._device),
-            )
-            if ev is not None:
-                ev.record()
-            _lib.check(rc, "tzr_pooled_fwd_plan")
-            if fused.value:
-                if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-                    ws.record_stream(torch.cuda.current_stream(self._device))
-                kjt._tzr_plan = (id(self), dst_names, ws, None, "part")  # type: ignore[attr-defined]
-            return outs
         ev = self._timers.start("fwd") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_fwd_ex(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
             _lib.ptr(meta.d_slots), len(meta.slots_np), _lib.ptr(kjt.values()), _lib.ptr(offsets),
             _lib.ptr(kjt.weights_or_none()), B, dsts, len(outs), 1 if uniform else 0,
-            flags, _lib.stream_ptr(self._device),
+            _lib.FWD_MIXED_DTYPE if self._has_fp16 else 0, _lib.stream_ptr(self._device),
         )
         if ev is not None:
             ev.record()
         _lib.check(rc, "tzr_pooled_fwd")
         return outs
-
-    def _finish_plan(self, kjt: KeyedJaggedTensor, ws: torch.Tensor, dst_names: Tuple[str, ...]) -> None:
-        """second launch of a plan whose partition pass ran inside the forward's launch"""
-        _, max_dim = self._bwd_dims()
-        ev = self._timers.start("plan") if self._timers is not None else None
-        rc = _lib.lib().tzr_pooled_bwd_plan_finish(
-            _lib.ptr(self._meta(kjt.keys(), self._layout_for(dst_names)).d_bwd_tables), len(self._configs), len(self._lookups), max_dim,
-            kjt.values().numel(), self._n_positions(kjt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device))
-        if ev is not None:
-            ev.record()
-        _lib.check(rc, "tzr_pooled_bwd_plan_finish")
 
     def _bwd_dims(self) -> Tuple[int, int]:
         return (max(c.num_embeddings for c in self._configs), max(c.embedding_dim for c in self._configs))
@@ -498,11 +472,6 @@ class EmbeddingBagCollection(nn.Module):
     def plan_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> torch.Tensor:
         """K6: build the backward index plan for this batch (depends on ids only, so callers may run
         it early on a side stream).  Returns the workspace holding the plan."""
-        cached = getattr(kjt, "_tzr_plan", None)
-        if cached is not None and cached[0] == id(self) and cached[1] == dst_names and cached[4] == "part":
-            self._finish_plan(kjt, cached[2], dst_names)
-            kjt._tzr_plan = cached[:4] + ("done",)  # type: ignore[attr-defined]
-            return cached[2]
         layout = self._layout_for(dst_names)
         meta = self._meta(kjt.keys(), layout)
         L = _lib.lib()
@@ -523,7 +492,7 @@ class EmbeddingBagCollection(nn.Module):
         _lib.check(rc, "tzr_pooled_bwd_plan")
         if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
             ws.record_stream(torch.cuda.current_stream(self._device))
-        kjt._tzr_plan = (id(self), dst_names, ws, None, "done")  # type: ignore[attr-defined]
+        kjt._tzr_plan = (id(self), dst_names, ws, None)  # type: ignore[attr-defined]
         return ws
 
     def plan_backward_async(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> None:
@@ -544,7 +513,7 @@ class EmbeddingBagCollection(nn.Module):
         for t in (kjt.values(), kjt.offsets_or_none()):
             if t is not None:
                 t.record_stream(self._side_stream)
-        kjt._tzr_plan = (id(self), dst_names, ws, ev, "done")  # type: ignore[attr-defined]
+        kjt._tzr_plan = (id(self), dst_names, ws, ev)  # type: ignore[attr-defined]
 
     def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
         if self.fused_optimizer is None:
@@ -552,8 +521,6 @@ class EmbeddingBagCollection(nn.Module):
         cached = getattr(kjt, "_tzr_plan", None)
         if cached is not None and cached[0] == id(self) and cached[1] == dst_names:
             ws = cached[2]
-            if cached[4] == "part":
-                self._finish_plan(kjt, ws, dst_names)
             if cached[3] is not None:
                 torch.cuda.current_stream(self._device).wait_event(cached[3])
                 ws.record_stream(torch.cuda.current_stream(self._device))

@@ -593,6 +593,9 @@ class GraphTrainPipeline:
         batch = self._slots[slot]
         if self._stage_first:
             self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
+        from .dense import sync_learning_rates
+
+        sync_learning_rates(self._model, self._opt)  # outside capture: the graphs read the rates from device scalars
         if self._graphs[slot] is None and self._seen[slot] >= self._warmup:
             g = torch.cuda.CUDAGraph()
             # capture on the caller's stream when it is a side stream (autograd's accumulation nodes and the

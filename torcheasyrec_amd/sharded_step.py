@@ -75,12 +75,9 @@ class ShardedTrainStep:
         self._seg: Dict[int, _Segment] = {}
         self._seen: Dict[int, int] = {}
         self._side = torch.cuda.Stream(self.device) if self.cuda else None
-        if self.cuda and plan_ahead:
-            # plans built on the side stream: tile-parallel heavy buckets misbehaved there (NOTES.md, "Side-stream
-            # plan"), one workgroup per heavy bucket did not -- process-wide, this process plans through this step
-            from . import _lib
-
-            _lib.check(_lib.lib().tzr_tune(b"bwd_one_wg_heavy", 1), "tzr_tune")
+        # (round 2 set tzr_tune("bwd_one_wg_heavy") here for its side-stream plans; round 3 could not reproduce that
+        # failure -- round 2's own binary passes 200 / 200 on the round-3 boxes, the current one 3 000 iterations in
+        # every stream arrangement, NOTES.md "Side-stream plan" -- and the knob is gone from the default path)
         self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
         # whole-step graphs: static inputs + one captured graph per pipeline slot
         self.step_graph = bool(step_graph)
@@ -252,6 +249,14 @@ class ShardedTrainStep:
         """Forward, backward, sparse + dense optimizer for one batch; returns the (detached) loss.
         `next_kjt` lets the input dist of the following batch overlap this one."""
         model, ebc = self.model, self.model.ebc
+        if self.cuda:  # the captured update kernels read learning rates from device scalars: refresh them outside capture
+            from .dense import sync_learning_rates
+
+            sync_learning_rates(model, self.opt)
+            for lane in (getattr(ebc, "local", None), getattr(ebc, "replica", None)):
+                fo = getattr(lane, "fused_optimizer", None) if lane is not None else None
+                if fo is not None:
+                    fo.sync_lr()
         t0 = None
         if self.cuda:
             t0 = torch.cuda.Event()
