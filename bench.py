@@ -638,13 +638,13 @@ def main():
                         "GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
 
             out["roofline"] = {
-                "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_kernel; "
+                "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_u1_kernel / tzr_pooled_fwd_kernel; "
                                           "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_kernel)",
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "traffic": traffic, "launch_ms": t_fwd + t_plan + t_apply,
                 "algorithmic_bytes": fwd_b + bwd_b,
                 "unique_rows": float(np.mean([a["U"] for a in ab])),
-                "kernels": [stage("forward", ["tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
+                "kernels": [stage("forward", ["tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
                             stage("backward plan", ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
                                                     "tzr_bwd_sort_kernel"], 0.0, t_plan),
                             stage("backward apply", ["tzr_bwd_reduce_kernel"], bwd_b, t_apply)],

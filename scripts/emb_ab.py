@@ -18,7 +18,7 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = [b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
+KNOBS = [b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
 
 
 class Timers:
@@ -43,13 +43,15 @@ def main():
     ap.add_argument("--B", default="65536")
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--layout", default="interleaved")
     ap.add_argument("sets", nargs="*", default=[""])
     args = ap.parse_args()
     _lib.use_library(_build.build())
     L = _lib.lib()
     dev = torch.device("cuda", 0)
     ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev,
-                                 optimizer=SparseOptimizerConfig(kind=args.opt, lr=1e-3), groups={"sparse": SPARSE_KEYS})
+                                 optimizer=SparseOptimizerConfig(kind=args.opt, lr=1e-3), groups={"sparse": SPARSE_KEYS},
+                                 row_layout=args.layout)
     for B in [int(x) for x in args.B.split(",")]:
         for dist in args.dist.split(","):
             host = [synthetic_batch(s, B, CRITEO_ROWS, dist=dist)[1] for s in range(4)]
@@ -81,7 +83,7 @@ def main():
                 ebc._timers = None
                 f, p, a = tm.us("fwd"), tm.us("plan"), tm.us("apply")
                 tot = f[0] + p[0] + a[0]
-                print(f"B {B:6d} {dist:8s} {args.opt:16s} [{spec or 'defaults':40s}] fwd {f[0]:6.1f} (med {f[1]:6.1f} min {f[2]:6.1f})  "
+                print(f"B {B:6d} {dist:8s} {args.opt + '/' + args.layout[:5]:22s} [{spec or 'defaults':40s}] fwd {f[0]:6.1f} (med {f[1]:6.1f} min {f[2]:6.1f})  "
                       f"plan {p[0]:6.1f} ({p[1]:6.1f} {p[2]:6.1f})  apply {a[0]:6.1f} ({a[1]:6.1f} {a[2]:6.1f})  "
                       f"sum {tot:6.1f} us  frac {nbytes / (tot * 1e-6) / 8e12:.3f}", flush=True)
 

@@ -374,7 +374,7 @@ __device__ __forceinline__ void bwd_reduce_body(
   uint32_t ckey = BWD_SENT;
   float4 csum = tzr_zero4();
 
-for (int t0 = r0; t0 < r1; t0 += gw) {
+  for (int t0 = r0; t0 < r1; t0 += gw) {
     const int idx = t0 + gi;
     const bool valid = lane_on && idx < r1;
     const uint32_t key = valid ? sK[idx + 1] : BWD_SENT;
@@ -484,6 +484,21 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
   bwd_reduce_body<ADAM>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
 }
 
+// the same body compiled for 7 / 8 waves per SIMD (72 / 64 VGPRs); tzr_tune("bwd_apply_waves") = 6 | 7 | 8, 0 = 7
+__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(7) void tzr_bwd_reduce_w7_kernel(
+    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
+    int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
+  bwd_reduce_body<false>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+}
+__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_reduce_w8_kernel(
+    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
+    int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
+  bwd_reduce_body<false>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+}
+int g_tzr_bwd_apply_waves = 0;
+
 extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
                                     int n_feats, int n_tables, int max_dim,
                                     const int64_t* d_offsets, const float* d_weights,
@@ -536,8 +551,16 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
                      d_weights, B, (int)uniform, grad_mode, G, opt, max_dim, P)
   if (opt.kind == TZR_OPT_ADAM) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<true>));  // Adam holds two state rows per lane: no registers for a second tile
-  } else {
+  } else if (g_tzr_bwd_apply_waves == 6) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<false>));
+  } else if (g_tzr_bwd_apply_waves == 8) {
+    TZR_REDUCE_LAUNCH(tzr_bwd_reduce_w8_kernel);
+  } else {
+    // 7 waves per SIMD = 1792 workgroups resident: the whole unit grid of a B = 65536 Criteo step (1691) runs in
+    // one wave of workgroups.  At 6 (77 VGPRs, what the compiler picks unasked) the last 155 units waited for a
+    // free slot and finished a full workgroup time after the rest: 88.4 -> 78.9 us (row-wise Adagrad 92.9 -> 78.6),
+    // profiles/r03n.  8 waves (64 VGPRs) spills: 88.0 us.
+    TZR_REDUCE_LAUNCH(tzr_bwd_reduce_w7_kernel);
   }
 #undef TZR_REDUCE_LAUNCH
   TZR_CHECK_LAUNCH();

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
 // 2048 workgroups at B = 65536 (~13 KB of LDS each: the register file, not LDS, bounds residency).
 #define FWD1_UNROLL 8
 #define FWD1_SLOTS 128    // slots per workgroup row (blockIdx.y); DLRM-Criteo: 104
-#define FWD1_MAX_IDS 1024 // ids of a (sub-)tile held in LDS: groups x samples
+#define FWD1_MAX_IDS 2048 // ids of a (sub-)tile held in LDS: groups x samples
 
 int g_tzr_fwd_variant = 0;  // tzr_tune("fwd_variant"): 0 = by shape, 1 = general kernel only, 2 = LDS-ids kernel whenever eligible
 

@@ -9,6 +9,7 @@ extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
 extern int g_tzr_bwd_debug;
+extern int g_tzr_bwd_apply_waves;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_fwd_wgs;
@@ -29,6 +30,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_one_wg_heavy")) {
     g_tzr_bwd_one_wg_heavy = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_apply_waves")) {
+    g_tzr_bwd_apply_waves = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_debug")) {

@@ -313,6 +313,13 @@ class EmbeddingBagCollection(nn.Module):
                 store = torch.empty(rows, 2 * D, dtype=torch.float32, device=self._device)
                 weight, state = store[:, :D], store[:, D:]
                 state.fill_(init_m)
+            elif kind == "rowwise_adagrad" and self._row_layout == "interleaved":
+                # [w(D) | m | pad]: the row's scalar state sits in the 64-byte sector NEXT to its weights (same
+                # 128-byte line and DRAM page at D = 16) instead of in a [rows] array of its own, where every touched
+                # row cost a second, unrelated sector fetch + a 4-byte write into a third line.  Twice the table
+                # bytes (as the interleaved Adagrad layout): HBM is sized for it (26 GB for DLRM-Criteo of 288 GB).
+                store = torch.zeros(rows, 2 * D, dtype=torch.float32, device=self._device)
+                weight, state = store[:, :D], store[:, D]
             else:
                 store = torch.empty(rows, D, dtype=torch.float32, device=self._device)
                 weight = store
@@ -399,7 +406,7 @@ class EmbeddingBagCollection(nn.Module):
             tables[t]["dim"] = cfg.embedding_dim
             tables[t]["w_stride"] = w.stride(0)
             tables[t]["w_dtype"] = _lib.DT_F16 if w.dtype == torch.float16 else _lib.DT_F32
-            tables[t]["m_stride"] = (1 if kind == "rowwise_adagrad" else (st.stride(0) if st is not None else 0))
+            tables[t]["m_stride"] = st.stride(0) if st is not None else 0  # row-wise Adagrad: one float per row
             mine = [i for i, lk in enumerate(self._lookups) if lk.table == t]
             tables[t]["first_order"] = mine[0] if mine else 0
             tables[t]["n_feats"] = len(mine)
