@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--n-batches", type=int, default=8, help="distinct synthetic batches cycled through")
     ap.add_argument("--replicate-small", action="store_true",
                     help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
+    ap.add_argument("--layerwise-loss", action="store_true",
+                    help="A/B: logits then tzr_bce_logits as separate autograd nodes instead of DLRM.forward_loss")
     ap.add_argument("--torch-bce", action="store_true", help="loss: torch BCE-with-logits instead of tzr_bce_logits")
     ap.add_argument("--torch-adam", action="store_true", help="dense optimizer: torch.optim.Adam(fused) instead of tzr_dense_adam")
     ap.add_argument("--secondary-global-batch", type=int, default=None,
@@ -344,8 +346,13 @@ def main():
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:
             return train_step.step(dense, kjt, label, next_kjt=next_kjt)
-        logits = model(dense, kjt)
-        loss = bce_with_logits(logits, label)
+        if not sharded and not args.torch_bce and not args.layerwise_loss:
+            # the training forward of a one-label rank model = logits + loss (TrainWrapper.forward, tzrec/models/model.py:271-297):
+            # the bottom MLP and the top MLP's tail + loss + their backward run as whole-stack kernels (csrc/mlp_ops.hip)
+            loss, _ = model.forward_loss(dense, kjt, label)
+        else:
+            logits = model(dense, kjt)
+            loss = bce_with_logits(logits, label)
         loss.backward()
         if sharded:
             model.allreduce_dense_grads()
@@ -446,6 +453,11 @@ def main():
 
             def forward(self, b):
                 return self.m(b.dense_features[BASE_DATA_GROUP].values(), b.sparse_features[BASE_DATA_GROUP])
+
+            def loss_and_predictions(self, b):  # what TrainWrapper.forward returns: losses + predictions in one call
+                loss, logits = self.m.forward_loss(b.dense_features[BASE_DATA_GROUP].values(), b.sparse_features[BASE_DATA_GROUP],
+                                                   b.labels["label"])
+                return {"bce": loss}, logits
 
         host = []
         for s_ in range(nb):
@@ -639,7 +651,7 @@ def main():
 
             out["roofline"] = {
                 "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_u1_kernel / tzr_pooled_fwd_kernel; "
-                                          "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_kernel)",
+                                          "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_w7_kernel)",
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "traffic": traffic, "launch_ms": t_fwd + t_plan + t_apply,
                 "algorithmic_bytes": fwd_b + bwd_b,
@@ -647,7 +659,7 @@ def main():
                 "kernels": [stage("forward", ["tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
                             stage("backward plan", ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
                                                     "tzr_bwd_sort_kernel"], 0.0, t_plan),
-                            stage("backward apply", ["tzr_bwd_reduce_kernel"], bwd_b, t_apply)],
+                            stage("backward apply", ["tzr_bwd_reduce_w7_kernel"], bwd_b, t_apply)],
                 "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe on this part, profiles/r01c
                 "frac_of_practical_ceiling": ach / 3.97e12,
                 "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command on this library "

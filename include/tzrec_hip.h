@@ -438,6 +438,29 @@ int tzr_zch_select_mark(const TzrZchModule* h_module, const int64_t* d_row_ids, 
                         double decay_exponent, int drop_none, uint64_t t1, int t2, uint64_t t3,
                         uint8_t* d_row_kept, uint8_t* d_new_kept, void* stream);
 
+/* ---- small dense layer stacks (tzrec.modules.mlp.MLP, models/dlrm.py:101-135) ----------------
+ * The MLPs stay on PyTorch / hipBLASLt in general; the three calls below take over the layer stacks whose GEMMs are
+ * too skinny to be worth a launch each (N = 64 / 32 / 16 / 1): all fp32, row-major, `*_stride` in floats.
+ * tzr_mlp2_fwd: ha = relu(x Wa^T + ba) [B, H1], hb = relu(ha Wb^T + bb) [B, H2]; Wa [H1, K0], Wb [H2, H1] as
+ * nn.Linear stores them; K0 <= 32, H1 <= 64, H2 <= 32 (TZR_ERR_UNSUPPORTED beyond).
+ * tzr_mlp2_bwd: from dhb = d(loss)/d(hb): the four parameter gradients (no input gradient: x is data).
+ * tzr_mlp_tail: y2 = relu(y1 W2^T + b2), logit = y2 . w3 + b3, loss = mean BCE-with-logits(logit, label) -- and its
+ * whole backward: g1 = d(loss)/d(pre-activation of y1) (y1 is a ReLU output: masked where y1 == 0), db1 = column sums
+ * of g1 (the bias gradient of the layer that produced y1), dW2, db2, dw3, d_scalars = {d(loss)/d(b3), loss}.
+ * ws: tzr_mlp_workspace() bytes.  Deterministic (fixed-order reductions). */
+size_t tzr_mlp_workspace(void);
+int tzr_mlp2_fwd(const float* d_x, int64_t x_stride, int64_t B, int K0, const float* d_Wa, const float* d_ba, int H1,
+                 const float* d_Wb, const float* d_bb, int H2, float* d_ha, int64_t ha_stride, float* d_hb,
+                 int64_t hb_stride, void* stream);
+int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride, const float* d_ha,
+                 int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0, int H1, int H2,
+                 const float* d_Wb, float* d_dWa, float* d_dba, float* d_dWb, float* d_dbb, void* ws, size_t ws_bytes,
+                 void* stream);
+int tzr_mlp_tail(const float* d_y1, int64_t y1_stride, const void* d_labels, int labels_itemsize, int labels_are_float,
+                 int64_t B, int H1, const float* d_W2, const float* d_b2, int H2, const float* d_w3, const float* d_b3,
+                 float* d_logits, float* d_g1, int64_t g1_stride, float* d_dW2, float* d_db2, float* d_dw3,
+                 float* d_scalars, float* d_db1, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- sequence path --------------------------------------------- */
 
 /* K12: jagged [N, dim] (+ offsets int64[B+1]) -> dense [B, max_len, dim]; positions past a

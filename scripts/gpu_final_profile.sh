@@ -23,18 +23,18 @@ timeout 300 python bench.py --force-sharded --replicate-small --no-cpu-baseline 
 fi
 cd /tmp
 # tuning stays on: the shipped table covers every shape of this run, so no candidate kernels appear
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-graph > $O/trace.log 2>&1; echo "trace rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-graph --no-secondary > $O/trace.log 2>&1; echo "trace rc=$?"
 if [ -z "${SKIP_PMC:-}" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph > /dev/null 2>&1; echo "pmc $c rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph --no-secondary > /dev/null 2>&1; echo "pmc $c rc=$?"
 done
 if [ -z "${SKIP_MFMA:-}" ]; then
 # MFMA activity of the dot-interaction kernels (north star: "MFMA utilisation for the interaction against the chip's peak")
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|GRBM_GUI_ACTIVE|SQ_BUSY_CYC" | cut -c1-160 | head -40 > $O/pmc_mfma_counters_available.txt
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph > $O/pmc_mfma.log 2>&1; rc=$?; echo "pmc mfma rc=$rc"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph --no-secondary > $O/pmc_mfma.log 2>&1; rc=$?; echo "pmc mfma rc=$rc"
 if [ $rc -ne 0 ]; then  # a counter name this rocprofv3 does not know: the two that exist everywhere
   rm -rf $O/pmc_mfma
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph >> $O/pmc_mfma.log 2>&1; echo "pmc mfma (reduced) rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-graph --no-secondary >> $O/pmc_mfma.log 2>&1; echo "pmc mfma (reduced) rc=$?"
 fi
 fi
 fi

@@ -128,7 +128,7 @@ def test_pipelined_train_step_matches_autograd_path():
             batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows, dist="zipf" if s % 2 else "uniform"))
                        for s in range(6)]
             for s, (dense, kjt, label) in enumerate(batches):
-                la = bce_with_logits(a(dense, kjt), label)
+                la, _ = a.forward_loss(dense, kjt, label)  # the same loss kernels as the pipelined step (dense_loss)
                 la.backward()
                 a.allreduce_dense_grads()
                 opt_a.step()

@@ -362,9 +362,23 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_count_kernel(
   const int ro = rank_offsets ? rank_offsets[f] : 0;
   if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int64_t i = base + threadIdx.x; i < end; i += XB_THREADS) {
-    const int d = (int)((idx_owner(values[i], bs, W) + ro) % W);
-    atomicAdd(&cnt[d], 1);  // integer counts: order independent
+  // one LDS atomic per distinct destination of a wave (match-any by ballots): at W = 8 every counter is hit
+  // by 1/8 of the tile, at W = 1 by all of it -- per-lane atomics on so few addresses serialise (45 us at
+  // B = 65536 on the 1-rank proxy, profiles/r03r)
+  int bits = 0;
+  while ((1 << bits) < W) ++bits;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  for (int64_t i0 = base; i0 < end; i0 += XB_THREADS) {  // workgroup-uniform trip count
+    const int64_t i = i0 + threadIdx.x;
+    const bool valid = i < end;
+    const int d = valid ? (int)((idx_owner(values[i], bs, W) + ro) % W) : 0;
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const int on = (d >> b) & 1;
+      const unsigned long long bm = __ballot(on);
+      peers &= on ? bm : ~bm;
+    }
+    if (valid && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&cnt[d], (int)__popcll(peers));  // integer counts: order independent
   }
   __syncthreads();
   if ((int)threadIdx.x < W) tile_cnt[((size_t)f * tiles + blockIdx.x) * W + threadIdx.x] = cnt[threadIdx.x];
@@ -386,7 +400,14 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __rest
   int64_t tot = 0;
   if (s < nseg) {
     const int d = s / F, f = s % F;
-    for (int t = 0; t < tiles; ++t) tot += tile_cnt[((size_t)f * tiles + t) * W + d];
+    // (16 tiles of independent loads at a time: tile by tile this was a chain of `tiles` round trips)
+    for (int t0 = 0; t0 < tiles; t0 += 16) {
+      int32_t c16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c16[j] = t0 + j < tiles ? tile_cnt[((size_t)f * tiles + t0 + j) * W + d] : 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tot += c16[j];
+    }
     if (S == 0) cnt_out[s] = tot;
   }
   seg_tot[s] = s < nseg ? tot : 0;
@@ -418,11 +439,15 @@ __global__ __launch_bounds__(XB_THREADS) void tzr_xb_scan_kernel(int32_t* __rest
       if (f == 0) cnt_out[(int64_t)d * S + F] = dropped;
     }
     int64_t run = seg_base[s];
-    for (int t = 0; t < tiles; ++t) {
-      int32_t* p = tile_cnt + ((size_t)f * tiles + t) * W + d;
-      const int32_t c = *p;
-      *p = (int32_t)run;  // start of this tile's ids for (dest, key)
-      run += c;
+    for (int t0 = 0; t0 < tiles; t0 += 16) {
+      int32_t c16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c16[j] = t0 + j < tiles ? tile_cnt[((size_t)f * tiles + t0 + j) * W + d] : 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (t0 + j < tiles) tile_cnt[((size_t)f * tiles + t0 + j) * W + d] = (int32_t)run;  // start of this tile's ids for (dest, key)
+        run += c16[j];
+      }
     }
   }
 }

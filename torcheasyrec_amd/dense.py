@@ -82,6 +82,125 @@ def head_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_g
     return gx, wb[:N].unsqueeze(0), wb[N:N + 1]
 
 
+# ---- small layer stacks as whole-stack kernels (csrc/mlp_ops.hip) -------------------------------------------------
+MLP2_MAX = (32, 64, 32)  # input, hidden, output widths tzr_mlp2_* take
+TAIL_MAX = (64, 32)      # input, hidden widths tzr_mlp_tail takes
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+class _Mlp2Fn(torch.autograd.Function):
+    """relu(relu(x Wa^T + ba) Wb^T + bb): forward in one launch, the four parameter gradients in one launch + a finish
+    (tzr_mlp2_fwd / tzr_mlp2_bwd).  `x` is data (no input gradient): the bottom MLP of DLRM on the dense features."""
+
+    @staticmethod
+    def forward(ctx, x, Wa, ba, Wb, bb):
+        B, K0 = x.shape
+        H1, H2 = Wa.shape[0], Wb.shape[0]
+        xs = x if (x.dtype == torch.float32 and x.stride(1) == 1) else x.contiguous().float()
+        ha = torch.empty(B, H1, dtype=torch.float32, device=x.device)
+        hb = torch.empty(B, H2, dtype=torch.float32, device=x.device)
+        Wa_, Wb_, ba_, bb_ = _f32c(Wa), _f32c(Wb), _f32c(ba), _f32c(bb)
+        _lib.check(_lib.lib().tzr_mlp2_fwd(_lib.ptr(xs), xs.stride(0), B, K0, _lib.ptr(Wa_), _lib.ptr(ba_), H1, _lib.ptr(Wb_),
+                                           _lib.ptr(bb_), H2, _lib.ptr(ha), ha.stride(0), _lib.ptr(hb), hb.stride(0),
+                                           _lib.stream_ptr(x.device)), "tzr_mlp2_fwd")
+        ctx.save_for_backward(xs, ha, hb, Wb_)
+        ctx.dims = (K0, H1, H2)
+        return hb
+
+    @staticmethod
+    def backward(ctx, dhb):
+        xs, ha, hb, Wb_ = ctx.saved_tensors
+        K0, H1, H2 = ctx.dims
+        B = xs.shape[0]
+        g = _rows16(dhb) if dhb.dtype == torch.float32 else dhb.float().contiguous()
+        dWa = torch.empty(H1, K0, dtype=torch.float32, device=xs.device)
+        dba = torch.empty(H1, dtype=torch.float32, device=xs.device)
+        dWb = torch.empty(H2, H1, dtype=torch.float32, device=xs.device)
+        dbb = torch.empty(H2, dtype=torch.float32, device=xs.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.tzr_mlp_workspace(), xs.device)
+        _lib.check(L.tzr_mlp2_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(hb), hb.stride(0), _lib.ptr(ha), ha.stride(0), _lib.ptr(xs),
+                                  xs.stride(0), B, K0, H1, H2, _lib.ptr(Wb_), _lib.ptr(dWa), _lib.ptr(dba), _lib.ptr(dWb),
+                                  _lib.ptr(dbb), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(xs.device)), "tzr_mlp2_bwd")
+        return None, dWa, dba, dWb, dbb
+
+
+def mlp2(x, Wa, ba, Wb, bb):
+    """Two-layer ReLU MLP through the fused kernels; the caller checks `mlp2_fits` first."""
+    return _Mlp2Fn.apply(x, Wa, ba, Wb, bb)
+
+
+def mlp2_fits(x: torch.Tensor, linears) -> bool:
+    if len(linears) != 2 or x.dim() != 2 or x.requires_grad or x.shape[0] == 0:
+        return False
+    a, b = linears
+    if a.bias is None or b.bias is None or a.weight.dtype != torch.float32:
+        return False
+    return a.in_features <= MLP2_MAX[0] and a.out_features <= MLP2_MAX[1] and b.out_features <= MLP2_MAX[2]
+
+
+class _TopLossFn(torch.autograd.Function):
+    """The top MLP of a ranking model from its wide input to the loss, forward AND backward of everything behind the
+    first GEMM in one launch: y1 = relu(z W1^T + b1) stays one hipBLASLt call (ReLU in its epilogue); tzr_mlp_tail then
+    computes y2, the logit, mean BCE-with-logits and -- the loss being the end of the graph -- the gradients of W2, b2,
+    w3, b3, b1 and g1 = d(loss)/d(z W1^T + b1) right away.  backward() only runs the two products of the first layer
+    (dz = g1 W1, dW1 = g1^T z), scaled by the incoming gradient of the loss.  Returns (loss, logits); `logits` is for
+    predictions / metrics and carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, z, W1, b1, W2, b2, w3, b3, labels):
+        y1 = torch._addmm_activation(b1, z, W1.t(), use_gelu=False)
+        B, H1 = y1.shape
+        H2 = W2.shape[0]
+        dev = z.device
+        y = labels.contiguous()
+        if y.dtype not in (torch.float32, torch.int32, torch.int64):
+            y = y.float()
+        logits = torch.empty(B, dtype=torch.float32, device=dev)
+        g1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
+        dW2 = torch.empty(H2, H1, dtype=torch.float32, device=dev)
+        db2 = torch.empty(H2, dtype=torch.float32, device=dev)
+        dw3 = torch.empty(1, H2, dtype=torch.float32, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        db1 = torch.empty(H1, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.tzr_mlp_workspace(), dev)
+        W2_, b2_, w3_, b3_ = _f32c(W2), _f32c(b2), _f32c(w3), _f32c(b3)
+        _lib.check(L.tzr_mlp_tail(_lib.ptr(y1), y1.stride(0), _lib.ptr(y), y.element_size(), 1 if y.is_floating_point() else 0,
+                                  B, H1, _lib.ptr(W2_), _lib.ptr(b2_), H2, _lib.ptr(w3_), _lib.ptr(b3_), _lib.ptr(logits),
+                                  _lib.ptr(g1), g1.stride(0), _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(dw3), _lib.ptr(scal),
+                                  _lib.ptr(db1), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_mlp_tail")
+        ctx.save_for_backward(z, W1, g1, dW2, db2, dw3, scal, db1)
+        ctx.mark_non_differentiable(logits)
+        return scal[1], logits
+
+    @staticmethod
+    def backward(ctx, gl, _glogits):
+        z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
+        # the incoming gradient of the (scalar) loss scales everything; it is folded into the small operands so the
+        # [B, *] tensors are touched by the two GEMMs only
+        dz = (g1 @ (W1 * gl)) if ctx.needs_input_grad[0] else None
+        dW1 = (g1.t() @ z) * gl
+        return dz, dW1, db1 * gl, dW2 * gl, db2 * gl, dw3 * gl, scal[0:1] * gl, None
+
+
+def top_loss_fits(z: torch.Tensor, linears, out_linear) -> bool:
+    if len(linears) != 2 or z.dim() != 2 or not z.is_cuda and _lib.backend() != "emu":
+        return False
+    a, b = linears
+    if a.bias is None or b.bias is None or out_linear.bias is None or out_linear.out_features != 1:
+        return False
+    return a.out_features <= TAIL_MAX[0] and b.out_features <= TAIL_MAX[1] and a.weight.dtype == torch.float32
+
+
+def top_loss(z, l1, l2, out_linear, labels):
+    """(mean BCE-with-logits loss, logits [B]) of relu(relu(z W1^T + b1) W2^T + b2) w3^T + b3 -- see _TopLossFn."""
+    return _TopLossFn.apply(z, l1.weight, l1.bias, l2.weight, l2.bias, out_linear.weight, out_linear.bias, labels)
+
+
 class FusedDenseAdam:
     """torch.optim.Adam (amsgrad off) for the dense parameters, two launches per step regardless of the
     number of tensors.  `param_groups[0]["lr"]` may be changed between steps (it is mirrored into a

@@ -24,6 +24,15 @@ _GEMV_OUTPUT = os.environ.get("TZR_OUTPUT_GEMV", "1") == "1"  # A/B switch (name
 _FUSED_HEAD_BWD = os.environ.get("TZR_FUSED_HEAD_BWD", "1") == "1"  # A/B switch
 _FUSED_RELU_BWD = os.environ.get("TZR_MLP_FUSED_RELU_BWD", "1") == "1"  # A/B switch
 _FUSED_RELU = os.environ.get("TZR_MLP_FUSED_RELU", "1") == "1"  # A/B switch; measured -23 us per DLRM step
+_FUSED_MLP2 = os.environ.get("TZR_FUSED_MLP2", "1") == "1"  # A/B switch: bottom MLP through tzr_mlp2_fwd / bwd
+_FUSED_TOP_LOSS = os.environ.get("TZR_FUSED_TOP_LOSS", "1") == "1"  # A/B switch: DLRM.forward_loss through tzr_mlp_tail
+
+
+def _on_emulator() -> bool:
+    from . import _lib
+
+    return _lib._lib is not None and _lib.backend() == "emu"
+
 
 
 class _LinearReluFn(torch.autograd.Function):
@@ -133,7 +142,16 @@ class MLP(nn.Module):
     def output_dim(self) -> int:
         return self.hidden_units[-1]
 
+    def linears(self) -> List[nn.Linear]:
+        return [m for m in self.mlp if isinstance(m, nn.Linear)]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._plain and _FUSED_MLP2 and x.dim() == 2 and (x.is_cuda or _on_emulator()):
+            from .dense import mlp2, mlp2_fits
+
+            lin = self.linears()
+            if mlp2_fits(x, lin):  # a small two-layer stack on data (the bottom MLP): one launch each way
+                return mlp2(x, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
         if self._plain and _FUSED_RELU and x.is_cuda and x.dim() == 2:
             # Linear + bias + ReLU as one hipBLASLt call (ReLU in the GEMM epilogue): same values,
             # one launch less per layer than Linear followed by ReLU
@@ -197,6 +215,26 @@ class DLRM(nn.Module):
         """-> logits [B] (probs = sigmoid(logits), rank_model.py:142-146)."""
         sparse = self.ebc.forward_grouped(sparse_features)["sparse"]
         return self.predict_from_embeddings(dense, sparse)
+
+    def loss_from_embeddings(self, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor):
+        """(mean BCE-with-logits loss, logits [B]) -- what `TrainWrapper.forward` computes for a one-label rank model
+        (/root/reference/tzrec/models/model.py:271-297, rank_model.py:219-262).  When the top MLP is the two-layer ReLU
+        stack + one-unit output of the DLRM config, everything behind its first GEMM -- second layer, logit, loss and
+        their whole backward -- is one launch (`dense.top_loss`); otherwise logits and loss the plain way."""
+        d = self.dense_mlp(dense)
+        allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
+        if _FUSED_TOP_LOSS and self.final_mlp._plain and (allf.is_cuda or _on_emulator()):
+            from .dense import top_loss, top_loss_fits
+
+            lin = self.final_mlp.linears()
+            if top_loss_fits(allf, lin, self.output_mlp):
+                return top_loss(allf, lin[0], lin[1], self.output_mlp, labels)
+        logits = self.output_mlp(self.final_mlp(allf)).squeeze(1)
+        return bce_with_logits(logits, labels), logits.detach()
+
+    def forward_loss(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor, labels: torch.Tensor):
+        sparse = self.ebc.forward_grouped(sparse_features)["sparse"]
+        return self.loss_from_embeddings(dense, sparse, labels)
 
 
 class DeepFM(nn.Module):

@@ -440,6 +440,18 @@ class EmbeddingGroup(nn.Module):
         return out
 
 
+def _losses_and_predictions(model, loss_fn, batch):
+    """The training forward of the reference's TrainWrapper (/root/reference/tzrec/models/model.py:271-297) is
+    predictions AND losses in one call; a model that offers `loss_and_predictions(batch) -> (losses, predictions)` gets
+    to compute them together (DLRM: the top MLP's tail, the loss and their backward in one launch), any other model
+    is called for its predictions and `loss_fn(predictions, batch)` follows."""
+    fused = getattr(model, "loss_and_predictions", None)
+    if fused is not None:
+        return fused(batch)
+    predictions = model(batch)
+    return loss_fn(predictions, batch), predictions
+
+
 class TrainPipeline:
     """Minimal ``pipeline.progress(iterator)`` (tzrec/utils/dist_util.py:221-303,336-377 ->
     torchrec TrainPipelineSparseDist [upstream]): the next batch is copied host->device on a memcpy
@@ -478,8 +490,7 @@ class TrainPipeline:
         if self._fetch_first:
             self._next = self._fetch(dataloader_iter)  # overlaps with the step below
         self._opt.zero_grad(set_to_none=True)
-        predictions = self._model(batch)
-        losses = self._loss_fn(predictions, batch)
+        losses, predictions = _losses_and_predictions(self._model, self._loss_fn, batch)
         total = sum(losses.values())
         total.backward()
         if hasattr(self._model, "allreduce_dense_grads"):
@@ -576,8 +587,7 @@ class GraphTrainPipeline:
 
     def _step(self, batch: Batch):
         self._opt.zero_grad(set_to_none=True)
-        predictions = self._model(batch)
-        losses = self._loss_fn(predictions, batch)
+        losses, predictions = _losses_and_predictions(self._model, self._loss_fn, batch)
         sum(losses.values()).backward()
         self._opt.step()
         return losses, predictions

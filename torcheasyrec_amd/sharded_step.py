@@ -95,8 +95,11 @@ class ShardedTrainStep:
 
     # -- dense segment ---------------------------------------------------------------------------
     def _dense_fwd_bwd(self, dense, sparse, label):
-        logits = self.model.dense_forward(dense, sparse)
-        loss = self.loss_fn(logits, label)
+        if self.loss_fn is bce_with_logits and hasattr(self.model, "dense_loss"):
+            loss, logits = self.model.dense_loss(dense, sparse, label)  # the top MLP's tail + loss + their backward: one launch
+        else:
+            logits = self.model.dense_forward(dense, sparse)
+            loss = self.loss_fn(logits, label)
         grads = torch.autograd.grad(loss, [sparse] + self.params)
         return loss.detach(), logits.detach(), grads
 

@@ -991,6 +991,23 @@ class ShardedDLRM(nn.Module):
         allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
         return self.output_mlp(self.final_mlp(allf)).squeeze(1)
 
+    def dense_loss(self, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor):
+        """(mean BCE-with-logits loss over this rank's samples, logits [B]): `dense_forward` + the loss with everything
+        behind the top MLP's first GEMM in one launch when the stack fits (torcheasyrec_amd.dense.top_loss; the
+        unsharded DLRM.loss_from_embeddings does the same)."""
+        from .dlrm import _FUSED_TOP_LOSS, _on_emulator, bce_with_logits
+
+        d = self.dense_mlp(dense)
+        allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
+        if _FUSED_TOP_LOSS and self.final_mlp._plain and (allf.is_cuda or _on_emulator()):
+            from .dense import top_loss, top_loss_fits
+
+            lin = self.final_mlp.linears()
+            if top_loss_fits(allf, lin, self.output_mlp):
+                return top_loss(allf, lin[0], lin[1], self.output_mlp, labels)
+        logits = self.output_mlp(self.final_mlp(allf)).squeeze(1)
+        return bce_with_logits(logits, labels), logits.detach()
+
     def forward(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
         if dense.is_cuda and self.overlap_dense:
             cur = torch.cuda.current_stream(dense.device)
@@ -1007,6 +1024,11 @@ class ShardedDLRM(nn.Module):
             d = self.dense_mlp(dense)
         allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
         return self.output_mlp(self.final_mlp(allf)).squeeze(1)
+
+    def forward_loss(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor, labels: torch.Tensor):
+        """(loss, logits): the op-by-op training forward with the same loss path as the pipelined step (`dense_loss`)."""
+        sparse = self.ebc.forward_grouped(sparse_features)["sparse"]
+        return self.dense_loss(dense, sparse, labels)
 
     def allreduce_dense_grads(self, grads: Optional[Sequence[torch.Tensor]] = None) -> None:
         """DDP semantics: average dense gradients over ranks -- one flat all-reduce (217 KB), three
