@@ -91,6 +91,17 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
 
+def weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g^T x ([H, B] x [B, K]) -- the weight gradient of a Linear layer.  One output tile of 64 x 783 and a 65536-long
+    reduction is the worst shape for a GEMM library: as 16 batched products over slices of the batch plus a 16-way sum
+    (fixed order: deterministic) it takes 77 instead of 120 us at B = 65536 (scripts/gemm_variants.py, profiles/r03z)."""
+    B = g.shape[0]
+    S = 16
+    if B >= 16384 and B % S == 0 and g.is_contiguous() and x.is_contiguous():
+        return torch.bmm(g.view(S, B // S, g.shape[1]).transpose(1, 2), x.view(S, B // S, x.shape[1])).sum(0)
+    return g.t() @ x
+
+
 class _Mlp2Fn(torch.autograd.Function):
     """relu(relu(x Wa^T + ba) Wb^T + bb): forward in one launch, the four parameter gradients in one launch + a finish
     (tzr_mlp2_fwd / tzr_mlp2_bwd).  `x` is data (no input gradient): the bottom MLP of DLRM on the dense features."""
@@ -183,8 +194,9 @@ class _TopLossFn(torch.autograd.Function):
         # the incoming gradient of the (scalar) loss scales everything; it is folded into the small operands so the
         # [B, *] tensors are touched by the two GEMMs only
         dz = (g1 @ (W1 * gl)) if ctx.needs_input_grad[0] else None
-        dW1 = (g1.t() @ z) * gl
-        return dz, dW1, db1 * gl, dW2 * gl, db2 * gl, dw3 * gl, scal[0:1] * gl, None
+        # ... and one multi-tensor launch scales the six parameter gradients (six separate 5 us multiplies otherwise)
+        outs = torch._foreach_mul([weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1]], gl)
+        return (dz, *outs, None)
 
 
 def top_loss_fits(z: torch.Tensor, linears, out_linear) -> bool:

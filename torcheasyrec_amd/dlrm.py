@@ -56,7 +56,9 @@ class _LinearReluFn(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(gy, y, 0.0)
             gb = g.sum(0)
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        return gx, g.t() @ x, gb
+        from .dense import weight_grad
+
+        return gx, weight_grad(g, x), gb
 
 
 class _Linear1Fn(torch.autograd.Function):
