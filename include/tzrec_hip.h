@@ -547,6 +547,7 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   ia_bwd_plain        1: the D = 16 dot-interaction backward without its software pipeline (A/B switch)
  *   ia_bwd_wgs          workgroups of that backward (0 = by batch size)
  *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
+ *   it_wgs              persistent workgroups of the fused interaction + first-layer kernels (0 = 256, one per CU)
  *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per
  *                       1024-lookup tile.  Same plan, slower under heavy skew.  Set it when plans are built on a
  *                       stream other than the one the rest of the step runs on (NOTES.md, "Side-stream plan"). */
@@ -575,6 +576,27 @@ int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_stride, const fl
                             const float* d_grad_out, int64_t grad_out_stride, int cat_dense,
                             int cat_sparse, float* d_grad_dense, int64_t grad_dense_stride,
                             float* d_grad_sparse, int64_t grad_sparse_stride, void* stream);
+
+/* K9b: the dot interaction FUSED with the first Linear of the MLP behind it (DLRM.predict,
+ * tzrec/models/dlrm.py:123-135: `final_mlp(cat(interaction, dense, sparse))`, first layer [P + D n -> H]).
+ * Layout of the interaction row as tzr_dot_interaction_fwd writes it with cat_dense = (dense != 0), cat_sparse = 1:
+ * [P pairs | dense row | sparse rows], width P + D n.  W1 is the nn.Linear weight [H, ldw >= width], row-major.
+ * Supported: D = 16, H = 64, ceil(P / 16) + n <= 56, i.e. n <= 29 (tzr_dot_interaction_top_supported; otherwise
+ * TZR_ERR_UNSUPPORTED and the caller runs the unfused ops).  fp32 MFMA, fixed summation order (deterministic).
+ *   _top_fwd: y1[b] = act(z[b] W1^T + bias) (relu != 0: ReLU), [B, H]; the interaction row z[b] itself is written
+ *             only when d_z is non-null (training keeps it for the weight gradient; inference does not need it).
+ *   _top_bwd: from g1 = d(loss)/d(z W1^T + bias) [B, H]: grad_dense / grad_sparse = the interaction backward of
+ *             dz = scale * g1 W1, with dz never leaving the chip.  d_scale: device scalar or null (= 1). */
+int tzr_dot_interaction_top_supported(int F, int D, int has_dense, int H);
+int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                int64_t sparse_stride, int F, int D, int64_t B, const float* d_W1, int64_t ldw,
+                                const float* d_bias, int H, int relu, float* d_z, int64_t z_stride, float* d_y1,
+                                int64_t y1_stride, void* stream);
+int tzr_dot_interaction_top_bwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1, int64_t g1_stride,
+                                int H, const float* d_W1, int64_t ldw, const float* d_scale, float* d_grad_dense,
+                                int64_t grad_dense_stride, float* d_grad_sparse, int64_t grad_sparse_stride,
+                                void* stream);
 
 /* K10: FM second order.  Replaces tzrec FactorizationMachine.forward
  * (tzrec/modules/fm.py:27-42): out[b,:] = 0.5*((sum_f x_f)^2 - sum_f x_f^2), x:[B,F,D]. */

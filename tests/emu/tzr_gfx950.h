@@ -12,3 +12,5 @@ inline uint64_t tzr_consume_u64(const uint64_t* p) { return __atomic_load_n(p, _
 inline void tzr_drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline uint32_t tzr_arrive(uint32_t* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_SEQ_CST); }
 #define TZR_WAVES_PER_EU(n)
+inline void tzr_lds_barrier() { __syncthreads(); }
+#define TZR_OPAQUE(x) ((void)(x))

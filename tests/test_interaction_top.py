@@ -1,0 +1,151 @@
+"""The dot interaction fused with the first layer behind it (csrc/interaction_top.hip) against the unfused ops
+(tzr_dot_interaction_fwd / bwd + torch GEMMs) and against plain torch autograd.  fp32 MFMA in another summation
+order than the GEMM library: forward to 2e-6 of the largest entry, gradients to 1e-5 of the largest entry."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+
+from torcheasyrec_amd import _lib  # noqa: E402
+
+
+def _close(a, b, rtol):
+    scale = float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= rtol * scale + 1e-9, (float((a - b).abs().max()), scale)
+
+
+def _torch_z(dense, sparse, D):
+    B = sparse.shape[0]
+    X = torch.cat([dense.unsqueeze(1), sparse.view(B, -1, D)], dim=1)
+    n = X.shape[1]
+    iu = torch.triu_indices(n, n, offset=1, device=X.device)
+    pairs = torch.bmm(X, X.transpose(1, 2))[:, iu[0], iu[1]]
+    return torch.cat([pairs, dense, sparse], dim=1)
+
+
+@pytest.mark.parametrize("B,F", [(1, 26), (16, 26), (37, 26), (600, 26), (50, 3), (33, 1), (40, 28), (21, 15), (35, 31)])
+def test_top_fwd_bwd_match_torch(dev, B, F):
+    D, H = 16, 64
+    torch.manual_seed(B * 31 + F)
+    L = _lib.lib()
+    assert L.tzr_dot_interaction_top_supported(F, D, 1, H) == 1
+    dense = torch.randn(B, D, device=dev, requires_grad=True)
+    sparse = torch.randn(B, F * D, device=dev, requires_grad=True)
+    n = F + 1
+    width = n * (n - 1) // 2 + D * n
+    lin = torch.nn.Linear(width, H).to(dev)
+    g1 = torch.randn(B, H, device=dev)
+    scale = torch.tensor([0.5], device=dev)
+    z_ref = _torch_z(dense, sparse, D)
+    pre = lin(z_ref)
+    (pre * g1 * 0.5).sum().backward()
+    stream = _lib.stream_ptr(sparse.device)
+    for with_z in (True, False):
+        z = torch.full((B, width), float("nan"), device=dev) if with_z else None
+        y1 = torch.empty(B, H, device=dev)
+        _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight),
+                                                 width, _lib.ptr(lin.bias), H, 1, _lib.ptr(z), width, _lib.ptr(y1), H, stream), "fwd")
+        _close(y1, torch.relu(pre).detach(), 2e-6)
+        if with_z:
+            _close(z, z_ref.detach(), 1e-6)
+    ypre = torch.empty(B, H, device=dev)
+    _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight), width,
+                                             None, H, 0, None, 0, _lib.ptr(ypre), H, stream), "fwd")
+    _close(ypre, (pre - lin.bias).detach(), 2e-6)
+    gd, gs = torch.full_like(dense, float("nan")), torch.full_like(sparse, float("nan"))
+    _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H,
+                                             _lib.ptr(lin.weight), width, _lib.ptr(scale), _lib.ptr(gd), D, _lib.ptr(gs), F * D,
+                                             stream), "bwd")
+    _close(gd, dense.grad, 1e-5)
+    _close(gs, sparse.grad, 1e-5)
+
+
+def test_top_unsupported_shapes(dev):
+    L = _lib.lib()
+    assert L.tzr_dot_interaction_top_supported(26, 16, 1, 64) == 1
+    assert L.tzr_dot_interaction_top_supported(26, 16, 1, 32) == 0
+    assert L.tzr_dot_interaction_top_supported(26, 8, 1, 64) == 0
+    assert L.tzr_dot_interaction_top_supported(31, 16, 1, 64) == 1  # n = 32: 31 pair blocks + 32 rows = 63 <= 64
+    assert L.tzr_dot_interaction_top_supported(32, 16, 1, 64) == 0
+    x = torch.zeros(4, 64, device=dev)
+    rc = L.tzr_dot_interaction_top_fwd(None, 0, _lib.ptr(x), 64, 8, 8, 4, _lib.ptr(x), 64, None, 64, 1, None, 0, _lib.ptr(x), 64,
+                                       _lib.stream_ptr(x.device))
+    assert rc == -4  # TZR_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("B", [5, 100])
+def test_interaction_top_loss_matches_unfused(dev, B):
+    """DLRM head: the fused autograd function against top_loss(dot_interaction(...)), every gradient."""
+    from torcheasyrec_amd.dense import interaction_top_fits, interaction_top_loss, top_loss
+    from torcheasyrec_amd.interaction import dot_interaction
+
+    D, F = 16, 26
+    torch.manual_seed(B)
+    width = 27 * 26 // 2 + 27 * D
+    l1, l2, lo = torch.nn.Linear(width, 64).to(dev), torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 1).to(dev)
+    dense = torch.randn(B, D, device=dev, requires_grad=True)
+    sparse = torch.randn(B, F * D, device=dev, requires_grad=True)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+    assert interaction_top_fits(dense, sparse, D, l1)
+    ps = [dense, sparse, l1.weight, l1.bias, l2.weight, l2.bias, lo.weight, lo.bias]
+    loss_ref, logits_ref = top_loss(dot_interaction(dense, sparse, D, True, True), l1, l2, lo, y)
+    (loss_ref * 0.25).backward()
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    loss, logits = interaction_top_loss(dense, sparse, D, l1, l2, lo, y)
+    torch.testing.assert_close(logits, logits_ref, rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref)) + 1e-7
+    (loss * 0.25).backward()
+    for w, p in zip(want, ps):
+        _close(p.grad, w, 1e-5)
+
+
+def test_dlrm_predict_without_grad_uses_fused_first_layer(dev):
+    """Inference (torch.no_grad) runs interaction + first top layer fused; logits equal the layer-wise path."""
+    from torcheasyrec_amd.criteo import SPARSE_KEYS, criteo_tables, synthetic_batch
+    from torcheasyrec_amd.dlrm import DLRM
+    from torcheasyrec_amd.embedding import SparseOptimizerConfig
+
+    rows = [50 + 3 * i for i in range(26)]
+    torch.manual_seed(3)
+    m = DLRM(criteo_tables(rows), SPARSE_KEYS, dense_dim=13, device=dev, sparse_optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.01))
+    dense, kjt, _ = synthetic_batch(5, 48, rows)
+    dense, kjt = dense.to(dev), kjt.to(dev)
+    want = m(dense, kjt).detach()
+    with torch.no_grad():
+        got = m(dense, kjt)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,wgs", [(600, 3), (97, 2), (256, 1), (33, 2)])
+def test_top_persistent_loop_over_many_tiles(dev, B, wgs):
+    """Few workgroups, many tiles each: the software pipeline (rows of tile t + G produced beside the product of tile t,
+    double-buffered z tile, g1 / X fetched a tile ahead), a partial last tile, odd and even trip counts."""
+    D, H, F = 16, 64, 26
+    torch.manual_seed(B + wgs)
+    L = _lib.lib()
+    dense = torch.randn(B, D, device=dev, requires_grad=True)
+    sparse = torch.randn(B, F * D, device=dev, requires_grad=True)
+    width = 27 * 26 // 2 + D * 27
+    lin = torch.nn.Linear(width, H).to(dev)
+    g1 = torch.randn(B, H, device=dev)
+    z_ref = _torch_z(dense, sparse, D)
+    pre = lin(z_ref)
+    (pre * g1).sum().backward()
+    stream = _lib.stream_ptr(sparse.device)
+    assert L.tzr_tune(b"it_wgs", wgs) == 0
+    z = torch.full((B, width), float("nan"), device=dev)
+    y1 = torch.empty(B, H, device=dev)
+    _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight), width,
+                                             _lib.ptr(lin.bias), H, 0, _lib.ptr(z), width, _lib.ptr(y1), H, stream), "fwd")
+    _close(y1, pre.detach(), 2e-6)
+    _close(z, z_ref.detach(), 1e-6)
+    gd, gs = torch.full_like(dense, float("nan")), torch.full_like(sparse, float("nan"))
+    _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H,
+                                             _lib.ptr(lin.weight), width, None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, stream), "bwd")
+    _close(gd, dense.grad, 1e-5)
+    _close(gs, sparse.grad, 1e-5)

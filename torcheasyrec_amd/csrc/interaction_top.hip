@@ -1,0 +1,663 @@
+// K9b: the DLRM dot interaction FUSED with the first layer of the MLP behind it (gfx950).
+//
+// In DLRM.predict (/root/reference/tzrec/models/dlrm.py:123-135) the interaction output
+//   z[b] = [ strict upper triangle of X_b X_b^T | dense row | sparse rows ]          (P + 16 n floats, 783 for Criteo)
+// feeds `final_mlp`, whose first Linear is [P + 16 n -> 64].  Unfused, the 205 MB z row (B = 65 536) is written by the
+// interaction forward, read by a GEMM, written again as dz by another GEMM and read by the interaction backward.  Here
+//
+//   tzr_dot_interaction_top_fwd:  y1 = act(z W1^T + b1) with the z tile produced in LDS (and written to HBM only when
+//                                 the caller wants it: training keeps it for the weight gradient g1^T z);
+//   tzr_dot_interaction_top_bwd:  dz tile = g1 tile [16 x 64] . W1 [64 x (P + 16 n)] scattered straight into the
+//                                 per-sample symmetric S matrices / pass-through rows that the interaction backward
+//                                 contracts with X (dX = (G + G^T) X + pass-through): dz never exists in HBM.
+//
+// Both are exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 6.6 GFLOP at B = 65 536 = 42 us at the 157 TFLOP/s peak) with W1
+// (200 KB: more than the LDS) resident in REGISTERS for the whole launch: one persistent workgroup of 16 waves per CU, the
+// columns of W1 regrouped into "virtual" 16-column blocks (pair blocks: pair index 16 v + r, padded; then one block per
+// X row), every wave owning a slice of them.  A tile is 16 samples (the rows of one MFMA block), one sample per wave for
+// the per-sample work.  Four waves per SIMD is the point of the shape: each wave's LDS / memory latencies are covered
+// by the MFMAs of the other three (an 8-wave version with twice the work per wave ran at half the MFMA rate, and
+// interleaving the instruction streams by hand inside a wave did not help).
+#include "tzr_common.h"
+#include <tzr_gfx950.h>
+
+#define IT_THREADS 1024
+#define IT_WAVES (IT_THREADS / TZR_WAVE)
+#define IT_TS 16                     // samples per tile = rows of one MFMA block = waves
+#define IT_H 64                      // width of the layer behind the interaction
+#define IT_KS (IT_H / 4)             // MFMA k-steps of the g1 . W1 product
+#define IT_D 16
+#define IT_MAXBLK 64                 // virtual column blocks: ceil(P / 16) + n <= 64, i.e. n <= 32
+#define IT_BPW (IT_MAXBLK / IT_WAVES)  // backward: column blocks per wave (4)
+#define IT_KB (IT_MAXBLK / 4)        // forward: blocks per K-group (16)
+#define IT_SROW 33                   // row pitch of one S matrix (odd: conflict-free column reads)
+#define IT_SS (32 * IT_SROW + 1)     // floats per sample in S
+#define IT_PS (32 * IT_D)            // floats per sample of pass-through gradients
+#define IT_XS (32 * (IT_D + 1))      // floats of one X image
+#define IT_ZP (16 * IT_MAXBLK + 4)   // floats per sample of the LDS z tile (virtual columns; +4: banks of the b128 A-operand reads)
+#define IT_YP (IT_H + 1)
+
+typedef float it_f32x4 __attribute__((ext_vector_type(4)));
+
+// -DIT_PROF (scripts/bench_interaction_top.py --prof builds a second library with it): every wave sums the shader
+// clocks it spends in each phase of the tile loop into a global table; not compiled into the product.
+#ifdef IT_PROF
+#define IT_PROF_DECL uint64_t it_tl = __builtin_amdgcn_s_memtime(), it_ts[6] = {0, 0, 0, 0, 0, 0}
+#define IT_PROF_MARK(i) do { const uint64_t it_now = __builtin_amdgcn_s_memtime(); it_ts[i] += it_now - it_tl; it_tl = it_now; } while (0)
+#define IT_PROF_DUMP(tab) do { if (tab && lane == 0) for (int i_ = 0; i_ < 6; ++i_) (tab)[((size_t)blockIdx.x * IT_WAVES + wv) * 6 + i_] = it_ts[i_]; } while (0)
+extern "C" uint64_t* g_tzr_it_prof;
+uint64_t* g_tzr_it_prof = nullptr;
+extern "C" void tzr_it_prof_table(uint64_t* d_table) { g_tzr_it_prof = d_table; }
+#else
+#define IT_PROF_DECL
+#define IT_PROF_MARK(i)
+#define IT_PROF_DUMP(tab)
+#endif
+
+struct __attribute__((packed, aligned(4))) it_f4u {
+  float x, y, z, w;
+};
+__device__ __forceinline__ void it_st4_a4(float* p, float4 v) {  // 16-byte store to a 4-byte aligned address
+  it_f4u u;
+  u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+  *reinterpret_cast<it_f4u*>(p) = u;
+}
+
+__device__ __forceinline__ const float* it_row(const float* dense, int64_t dense_stride, const float* sparse,
+                                               int64_t sparse_stride, int64_t b, int i, int hd) {
+  return (hd && i == 0) ? dense + b * dense_stride : sparse + b * sparse_stride + (int64_t)(i - hd) * IT_D;
+}
+
+// X rows min(r, n - 1) / min(16 + r, n - 1), columns 4 q .. 4 q + 3, of sample b (clamped into the batch: a sample behind
+// it reads the last one, nothing of it is stored)
+struct ItX {
+  float4 lo, hi;
+};
+__device__ __forceinline__ ItX it_fetch_x(const float* dense, int64_t dense_stride, const float* sparse, int64_t sparse_stride,
+                                          int64_t b, int64_t B, int n, int hd, int r, int q) {
+  const int rr0 = r < n ? r : n - 1, rr1 = 16 + r < n ? 16 + r : n - 1;
+  b = b < B ? b : B - 1;
+  ItX x;
+  x.lo = tzr_ld4(it_row(dense, dense_stride, sparse, sparse_stride, b, rr0, hd) + 4 * q);
+  x.hi = tzr_ld4(it_row(dense, dense_stride, sparse, sparse_stride, b, rr1, hd) + 4 * q);
+  return x;
+}
+
+// virtual column c (pairs padded to a multiple of 16, then the X rows) -> column of z / W1, or -1 for a pad slot
+__device__ __forceinline__ int it_real_col(int c, int P, int npb, int nblk) {
+  if (c < P) return c;
+  if (c < 16 * npb || c >= 16 * nblk) return -1;
+  return c - (16 * npb - P);
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// wave w owns column blocks w, w + 16, ... (at most 4: 4 x 16 B-operand registers per lane).  Per tile: every wave
+// multiplies the tile's g1 fragment with its blocks, scatters the accumulators into LDS, and behind a barrier contracts
+// ONE sample of the tile the way tzr_dot_interaction_bwd_kernel does.  HBM traffic: X in, dX out, g1 in (243 MB at
+// B = 65 536) instead of 243 + 2 x 205 MB.
+struct ItBwdArgs {
+  const float *dense, *sparse, *g1, *W1, *scale;
+  float *gdense, *gsparse;
+  int64_t dense_stride, sparse_stride, g1_stride, ldw, gdense_stride, gsparse_stride, B;
+  int n, hd;
+  uint64_t* prof;
+};
+
+#define IT_GP (IT_H + 4)              // row pitch of the g1 tile in LDS (68: the b128 A-operand reads spread over the banks)
+
+// NB column blocks per wave with their W1 fragments in registers; XL: wave 0 owns one more (block 16 NB: the 49th of
+// DLRM-Criteo) whose fragment lives in LDS -- a fourth block in registers is 64 of the 128 a lane has and spills.
+template <int NB, bool XL>
+__device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __restrict__ off, float* __restrict__ S,
+                                            float* __restrict__ PT, float* __restrict__ xs, float* __restrict__ Gs,
+                                            float* __restrict__ Wx, int lane, int wv, int P, int npb, int nblk) {
+  const int r = lane & 15, q = lane >> 4;
+  const int n = a.n;
+  // ---- W1 fragments (B operand: lane supplies W[k = 16 q + ks][column of (block, r)]); blocks behind the wave's last stay
+  // zero.  Staged through LDS in slabs of 16 blocks x 64 rows so the global loads are coalesced runs: lanes asking for
+  // their own elements straight from L2 (4 to 16 lines per load, every CU the same lines at once) took 11 - 24 us.
+  float Wf[NB][IT_KS];
+  {
+    const float sc = a.scale ? *a.scale : 1.f;
+    float* Wl = S;  // [64 rows][256 + 1]: the slab (S is zeroed afterwards)
+    const int c = threadIdx.x & 255, k0 = threadIdx.x >> 8;  // thread -> slab column, rows k0, k0 + 4, ...
+    // (every wave walks all slabs: the loads are the workgroup's; the next slab's loads fly while this one is handed out)
+    float w[16];
+    int col = it_real_col(c, P, npb, nblk);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = a.W1[(int64_t)(k0 + 4 * i) * a.ldw + (col >= 0 ? col : 0)];
+#pragma unroll
+    for (int m = 0; m < IT_BPW; ++m) {
+      float wn[16];
+      const int coln = m + 1 < IT_BPW ? it_real_col(256 * (m + 1) + c, P, npb, nblk) : -1;
+      if (m + 1 < IT_BPW) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wn[i] = a.W1[(int64_t)(k0 + 4 * i) * a.ldw + (coln >= 0 ? coln : 0)];
+      }
+      __syncthreads();  // the previous slab has been read
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Wl[(k0 + 4 * i) * 257 + c] = col >= 0 ? sc * w[i] : 0.f;
+      __syncthreads();
+      if (m < NB) {
+#pragma unroll
+        for (int ks = 0; ks < IT_KS; ++ks) Wf[m][ks] = Wl[(16 * q + ks) * 257 + 16 * wv + r];
+      } else if (XL && m == NB && wv == 0) {
+#pragma unroll
+        for (int ks = 0; ks < IT_KS; ++ks) Wx[ks * TZR_WAVE + lane] = Wl[(16 * q + ks) * 257 + r];
+      }
+      if (m + 1 < IT_BPW) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = wn[i];
+        col = coln;
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < IT_TS * IT_SS; k += IT_THREADS) S[k] = 0.f;  // diagonals and rows >= n stay zero
+  }
+  const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
+  const int64_t G = gridDim.x;
+  const int nks = (n + 3) >> 2;
+  const bool v0 = r < n, v1 = 16 + r < n;
+  int64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  // the g1 tile goes through LDS (one element per thread, double-buffered): every wave needs all of it as its A operand,
+  // and sixteen copies from L2 would cost more than the HBM traffic of the whole kernel
+  const int gs = threadIdx.x >> 6, gh = threadIdx.x & 63;
+  const unsigned goff = (unsigned)gs * (unsigned)a.g1_stride + (unsigned)gh;  // (< 2^32: checked by the launcher)
+  auto g1_elem = [&](int64_t tt) {
+    const float* base = a.g1 + tt * IT_TS * a.g1_stride;  // scalar
+    return (tt < ntiles && tt * IT_TS + gs < a.B) ? base[goff] : 0.f;
+  };
+  Gs[gs * IT_GP + gh] = g1_elem(t);
+  float gnext = g1_elem(t + G);
+  ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, t * IT_TS + wv, a.B, n, a.hd, r, q);
+  const float* ss = S + wv * IT_SS;
+  const float* pt = PT + wv * IT_PS;
+  int cur = 0;
+  __syncthreads();
+  IT_PROF_DECL;
+  for (; t < ntiles; t += G, cur ^= 1) {
+    // ---- dz[:, blocks of this wave] = g1 tile . W1[:, those columns]; A operand: lane (i = r, q) reads g1[i][16 q ..
+    // 16 q + 15], k-step ks uses element 16 q + ks (the contraction order is free as long as the W1 fragment agrees)
+    it_f32x4 acc[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = it_f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      const float* gp = Gs + cur * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float4 av = tzr_ld4(gp + 4 * k4);
+        const float ag[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int m = 0; m < NB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[e], Wf[m][4 * k4 + e], acc[m], 0, 0, 0);
+      }
+    }
+    it_f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+    if (XL && wv == 0) {
+      const float* gp = Gs + cur * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float4 av = tzr_ld4(gp + 4 * k4);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wx[(4 * k4 + 0) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
+      }
+    }
+    IT_PROF_MARK(0);  // product
+    tzr_lds_barrier();  // every wave is done reading S / PT of the previous tile and this tile's g1
+    IT_PROF_MARK(1);  // wait 1
+    // accumulator reg j of lane (r, q) = dz[sample 4 q + j][column of (block, r)] -> S (both triangles) / PT
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      const int v = wv + IT_WAVES * m;
+      const int om = off[m * (IT_THREADS / 4)];
+      if (v < npb) {
+        if (om >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            S[(4 * q + j) * IT_SS + (om & 0xFFFF)] = acc[m][j];
+            S[(4 * q + j) * IT_SS + (om >> 16)] = acc[m][j];
+          }
+        }
+      } else if (om >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PT[(4 * q + j) * IT_PS + om] = acc[m][j];
+      }
+    }
+    if (XL && wv == 0) {
+      const int om = off[NB * (IT_THREADS / 4)];
+      if (IT_WAVES * NB < npb) {
+        if (om >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            S[(4 * q + j) * IT_SS + (om & 0xFFFF)] = accx[j];
+            S[(4 * q + j) * IT_SS + (om >> 16)] = accx[j];
+          }
+        }
+      } else if (om >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PT[(4 * q + j) * IT_PS + om] = accx[j];
+      }
+    }
+    // the next tile's g1 element (loaded an iteration ago) into the other buffer
+    Gs[(cur ^ 1) * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
+    tzr_lds_barrier();
+    IT_PROF_MARK(2);  // scatter + wait 2
+    // ---- dX = S X + pass-through of sample wv of the tile (transposed product, see interaction.hip)
+    {
+      const float4 x0 = v0 ? X.lo : tzr_zero4(), x1 = v1 ? X.hi : tzr_zero4();
+      float* p0 = xs + r * (IT_D + 1) + 4 * q;
+      float* p1 = xs + (16 + r) * (IT_D + 1) + 4 * q;
+      p0[0] = x0.x; p0[1] = x0.y; p0[2] = x0.z; p0[3] = x0.w;
+      p1[0] = x1.x; p1[1] = x1.y; p1[2] = x1.z; p1[3] = x1.w;
+    }
+    const int64_t b = t * IT_TS + wv;
+    // the next tile's X rows take off (their registers were just copied into the LDS image), and the g1 element of the
+    // tile after it.  Order matters: hipcc waits for a loop-carried load with s_waitcnt vmcnt(0), i.e. for EVERYTHING in
+    // flight -- so nothing may be issued shortly before such a wait (the g1 load used to sit in front of the barrier
+    // above: every wave then stood 2 - 4 k clocks here waiting for it, profiles/r03ak).
+    gnext = g1_elem(t + 2 * G);
+    X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + G < ntiles ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
+    __builtin_amdgcn_wave_barrier();  // the X image is private to this wave
+    IT_PROF_MARK(3);  // X image (with the wait for the X rows), prefetch issue
+    it_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < nks) {
+        const int k = 4 * ks + q;
+        const float xv = xs[k * (IT_D + 1) + r];
+        const float s0 = ss[k * IT_SROW + r];
+        const float s1 = ss[k * IT_SROW + 16 + r];
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s0, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s1, d1, 0, 0, 0);
+      }
+    }
+    IT_PROF_MARK(4);  // contraction
+    int rq = r * IT_D + 4 * q;
+    TZR_OPAQUE(rq);  // (recomputed per tile, not hoisted and spilled)
+    if (b < a.B) {
+      if (v0) {
+        const float4 p = tzr_ld4(pt + rq);
+        const float4 v = make_float4(d0[0] + p.x, d0[1] + p.y, d0[2] + p.z, d0[3] + p.w);
+        // (b is wave-uniform: scalar row bases, the lane part from rq)
+        if (a.hd && r == 0) tzr_st4(a.gdense + b * a.gdense_stride + rq, v);
+        else tzr_st4(a.gsparse + b * a.gsparse_stride + (rq - IT_D * a.hd), v);
+      }
+      if (v1) {
+        const float4 p = tzr_ld4(pt + 16 * IT_D + rq);
+        const float4 v = make_float4(d1[0] + p.x, d1[1] + p.y, d1[2] + p.z, d1[3] + p.w);
+        tzr_st4(a.gsparse + b * a.gsparse_stride + (rq + IT_D * (16 - a.hd)), v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    IT_PROF_MARK(5);  // pass-through + stores
+  }
+  IT_PROF_DUMP(a.prof);
+}
+
+__global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_bwd_kernel(ItBwdArgs a) {
+  __shared__ float S[IT_TS * IT_SS];        // per sample of the tile: G + G^T, 32 x 33
+  __shared__ float PT[IT_TS * IT_PS];       // per sample: pass-through gradients, row-major [n][16]
+  __shared__ float Xs[IT_WAVES][IT_XS];     // per wave: the X image of its sample
+  __shared__ float Gs[2 * IT_TS * IT_GP];   // the g1 tile, double-buffered
+  __shared__ float Wx[IT_KS * TZR_WAVE];    // W1 fragment of wave 0's extra block (it_bwd_loop<NB, true>)
+  // LDS offsets of the lane's column of block m: pair (i, j) -> S[i][j] | S[j][i] << 16; pass-through -> PT[i][r]; -1 = none
+  // (a table in LDS rather than registers: 128 per lane at four waves per SIMD)
+  __shared__ int offt[IT_BPW][IT_THREADS / 4];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));  // (scalar: per-wave bases stay in SGPRs)
+  const int r = lane & 15, q = lane >> 4;
+  const int n = a.n;
+  const int P = n * (n - 1) / 2;
+  const int npb = (P + 15) >> 4, nblk = npb + n;
+  int* const off = &offt[0][wv * 16 + r];
+  if (q == 0) {
+#pragma unroll
+    for (int m = 0; m < IT_BPW; ++m) {
+      const int v = wv + IT_WAVES * m;
+      int om = -1;
+      if (v < npb) {
+        const int p = 16 * v + r;
+        if (p < P) {
+          int i = 0, rem = p;
+          while (rem >= n - 1 - i) {
+            rem -= n - 1 - i;
+            ++i;
+          }
+          const int j = i + 1 + rem;
+          om = (i * IT_SROW + j) | ((j * IT_SROW + i) << 16);
+        }
+      } else if (v < nblk) {
+        om = (v - npb) * IT_D + r;
+      }
+      off[m * (IT_THREADS / 4)] = om;
+    }
+  }
+  // DLRM-Criteo: 49 blocks = 3 per wave and one more for wave 0 (fragment in LDS); up to 48: 3 per wave, zero-weighted;
+  // more: 4 per wave in registers (spills, correct)
+  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  else it_bwd_loop<4, false>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+// The virtual column blocks are the CONTRACTION index here.  Wave w = (K-group kg = w >> 2, output block hb = w & 3):
+// it multiplies the z columns of the blocks of its K-group (a quarter of them: 13 / 12 / 12 / 12 for Criteo) with the
+// matching W1 columns of its 16 outputs (B operand W1[h = 16 hb + r][column 4 q + kk of block v]: 4 registers per block;
+// A operand: one ds_read_b128 per block) into a partial [16 samples x 16 outputs]; the four partials of an output are
+// summed through LDS in fixed order (deterministic), bias and ReLU applied, y1 written as one contiguous 4 KB run per
+// tile.  The z tile is double-buffered: the row of tile t + G (pairwise products by MFMA, LDS scatter, the stores of z to
+// HBM) is produced right behind the product of tile t, with one barrier pair per tile.
+struct ItFwdArgs {
+  const float *dense, *sparse, *W1, *bias;
+  float *z, *y1;
+  int64_t dense_stride, sparse_stride, ldw, z_stride, y1_stride, B;
+  int n, hd, relu;
+  uint64_t* prof;
+};
+
+// one sample's row of the z tile: pairwise products by MFMA scattered into `zs`, X rows behind them; `o` != null: the
+// same row out to HBM.  Lanes without a valid target write to a per-lane trash slot or repeat a neighbour's store (same
+// address, same value) instead of branching.
+__device__ __forceinline__ void it_fwd_row(const ItX X, float* __restrict__ zs, float* __restrict__ trash, float* __restrict__ o,
+                                           int n, int P, int pt0, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const bool v0 = r < n, v1 = 16 + r < n;
+  const int rr0 = v0 ? r : n - 1, rr1 = v1 ? 16 + r : n - 1;
+  const float4 a0 = v0 ? X.lo : tzr_zero4(), a1 = v1 ? X.hi : tzr_zero4();
+  it_f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c11 = c00;
+  const float x0[4] = {a0.x, a0.y, a0.z, a0.w};
+  const float x1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x0[e], c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x1[e], c01, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], x1[e], c11, 0, 0, 0);
+  }
+  // strict upper triangle, row-major (i < j): idx(i, j) = i (2 n - i - 1) / 2 + j - i - 1; from row i to row i + 1 the
+  // offset of column j moves by n - i - 2
+  int t0 = (4 * q) * (2 * n - 4 * q - 1) / 2 - 4 * q - 1, t1 = (16 + 4 * q) * (2 * n - 4 * q - 17) / 2 - 4 * q - 17;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i0 = 4 * q + reg, i1 = 16 + i0;
+    const int j0 = r, j1 = 16 + r;
+    *((i0 < j0 && j0 < n) ? zs + t0 + j0 : trash) = c00[reg];
+    *((j1 < n) ? zs + t0 + j1 : trash) = c01[reg];
+    *((i1 < j1 && j1 < n) ? zs + t1 + j1 : trash) = c11[reg];
+    t0 += n - i0 - 2;
+    t1 += n - i1 - 2;
+  }
+  tzr_st4(zs + pt0 + IT_D * rr0 + 4 * q, X.lo);  // (lanes of a row >= n repeat row n - 1: same address, same value)
+  tzr_st4(zs + pt0 + IT_D * rr1 + 4 * q, X.hi);
+  if (o) {
+    __builtin_amdgcn_wave_barrier();  // the row was written by this wave only
+    it_st4_a4(o + P + IT_D * rr0 + 4 * q, X.lo);
+    it_st4_a4(o + P + IT_D * rr1 + 4 * q, X.hi);
+  }
+}
+
+// ... and the pairs of that row out to HBM (apart from it_fwd_row so that the caller can put the next prefetch between)
+__device__ __forceinline__ void it_fwd_row_pairs_out(const float* __restrict__ zs, float* __restrict__ o, int P, int lane) {
+  if (o) {
+    // rounds of 64 lanes with the index clamped (a lane behind the end repeats the last pair's store) rather than a
+    // loop -- hipcc unrolls and vectorises that one, hoists its bounds out of the tile loop and spills them
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < 5 || TZR_WAVE * k < P) {
+        int idx = lane + TZR_WAVE * k;
+        idx = idx < P ? idx : P - 1;
+        o[idx] = zs[idx];
+      }
+      if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (four rounds in flight: registers)
+    }
+  }
+}
+
+// NB whole blocks [vfirst, vfirst + base) per wave (`base` of them real, the rest zero weights) and one k-step of each of
+// the REM left-over blocks 4 base + j (k-step kg of it): every wave runs the same 4 NB + REM MFMAs per tile.
+template <int NB, int REM>
+__device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restrict__ Zs, float* __restrict__ Ys,
+                                            float* __restrict__ trash, int lane, int wv, int P, int npb, int base, int rem) {
+  const int r = lane & 15, q = lane >> 4;
+  const int kg = wv >> 2, hb = wv & 3;
+  const int n = a.n;
+  const int pt0 = 16 * npb;  // virtual column of X row 0
+  const int vfirst = kg * base, vlast = vfirst + base;
+  // W1 fragments [block of the group][kk] for this wave's 16 outputs; pad columns and blocks behind the group are zero.
+  // Staged through LDS (the z tile's space) in two halves of 32 rows so the global loads are coalesced runs.
+  float Wf[NB][4];
+  float Wx[REM > 0 ? REM : 1];  // ... and for k-step kg of the left-over blocks
+  {
+    const int nblk = npb + n;
+    float* Wl = Zs;  // [32 rows][IT_ZP]
+    const int c = threadIdx.x;  // thread -> virtual column (16 nblk <= 1024 of them)
+    const int col = c < 16 * nblk ? it_real_col(c, P, npb, nblk) : -1;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      float w[2][16];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[g][i] = a.W1[(int64_t)(32 * half + 16 * g + i) * a.ldw + (col >= 0 ? col : 0)];
+      __syncthreads();  // the previous half has been read
+      if (c < IT_ZP) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Wl[(16 * g + i) * IT_ZP + c] = col >= 0 ? w[g][i] : 0.f;
+      }
+      __syncthreads();
+      if ((hb >> 1) == half) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          const int v = vfirst + m;
+          const float4 w = tzr_ld4(Wl + (16 * (hb & 1) + r) * IT_ZP + 16 * (v < vlast ? v : vfirst) + 4 * q);
+          const float keep = v < vlast ? 1.f : 0.f;
+          Wf[m][0] = keep * w.x; Wf[m][1] = keep * w.y; Wf[m][2] = keep * w.z; Wf[m][3] = keep * w.w;
+        }
+#pragma unroll
+        for (int j = 0; j < REM; ++j)
+          Wx[j] = j < rem ? Wl[(16 * (hb & 1) + r) * IT_ZP + 16 * (4 * base + j) + 4 * q + kg] : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * IT_TS * IT_ZP; k += IT_THREADS) Zs[k] = 0.f;  // the pad slots behind the last pair stay zero
+    __syncthreads();
+  }
+  const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
+  const int64_t G = gridDim.x;
+  int64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  {
+    const int64_t b = t * IT_TS + wv;
+    const ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, b, a.B, n, a.hd, r, q);
+    float* o = (a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
+    it_fwd_row(X, Zs + wv * IT_ZP, trash, o, n, P, pt0, lane);
+    it_fwd_row_pairs_out(Zs + wv * IT_ZP, o, P, lane);
+  }
+  ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + G < ntiles ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
+  int cur = 0;
+  // (the bias of this thread's two outputs, read ONCE: a load inside the loop is waited for with vmcnt(0), prefetches and all)
+  float bias0 = a.bias ? a.bias[2 * (lane & 31)] : 0.f, bias1 = a.bias ? a.bias[2 * (lane & 31) + 1] : 0.f;
+  TZR_OPAQUE(bias0);  // (forces the wait for these loads HERE, not -- as vmcnt(0) -- at their first use inside the loop)
+  TZR_OPAQUE(bias1);
+  IT_PROF_DECL;
+  for (; t < ntiles; t += G, cur ^= 1) {
+    const float* zb = Zs + cur * (IT_TS * IT_ZP);
+    tzr_lds_barrier();  // tile t complete in zb; the other buffer and Ys free
+    IT_PROF_MARK(0);  // wait 1
+    // ---- partial y1[:, 16 hb ..] over the z columns of this wave's K-group
+    // Half of the waves (two of the four on every SIMD) produce the next tile's row BEFORE the product, the other half
+    // behind it: in lockstep all sixteen would be in their LDS / store phase at once and the MFMA pipe would idle.
+    const bool row_first = (wv >> 2) & 1;
+    auto next_row = [&]() {
+    // ---- the row of sample wv of tile t + G into the other buffer (and out to HBM); then tile t + 2 G's X rows take off
+      if (t + G < ntiles) {
+        const int64_t b = (t + G) * IT_TS + wv;
+        float* zs = Zs + (cur ^ 1) * (IT_TS * IT_ZP) + wv * IT_ZP;
+        float* o = (a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
+        it_fwd_row(X, zs, trash, o, n, P, pt0, lane);
+        // (as early as the X registers are free: a row-first wave gets back here barely an HBM round trip later)
+        X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + 2 * G < ntiles ? t + 2 * G : t) * IT_TS + wv, a.B, n, a.hd,
+                       r, q);
+        it_fwd_row_pairs_out(zs, o, P, lane);
+      }
+    };
+    if (row_first) next_row();
+    IT_PROF_MARK(1);  // row (first half of the waves)
+    it_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      // A operand of block m, k-steps 0..3 = columns 4 q + kk: one ds_read_b128, issued two blocks ahead of its MFMAs and
+      // pinned there (left alone, hipcc hoists all NB reads to the top: 52 registers, and spills W1 fragments)
+      const float* zr = zb + r * IT_ZP + 4 * q;
+      auto rd = [&](int m) {
+        const int v = vfirst + m;
+        return tzr_ld4(zr + 16 * (v < vlast ? v : vfirst));  // (a block behind the group: zero weights on valid data)
+      };
+      float4 av[3];
+      av[0] = rd(0);
+      av[1] = rd(1 < NB ? 1 : 0);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        if (m + 2 < NB) av[(m + 2) % 3] = rd(m + 2);
+        const float4 c = av[m % 3];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, Wf[m][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, Wf[m][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, Wf[m][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, Wf[m][3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < REM; ++j)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[16 * (4 * base + (j < rem ? j : 0)) + kg], Wx[j], acc, 0, 0, 0);
+    }
+    // accumulator reg j of lane (r, q) = partial y1[sample 4 q + j][h = 16 hb + r]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ys[kg * (IT_TS * IT_YP) + (4 * q + j) * IT_YP + 16 * hb + r] = acc[j];
+    IT_PROF_MARK(2);  // product
+    if (!row_first) next_row();
+    IT_PROF_MARK(3);  // row (second half)
+    tzr_lds_barrier();
+    IT_PROF_MARK(4);  // wait 2
+    // ---- sum of the four partials in K-group order, bias, activation -- by the waves that produced their row BEHIND the
+    // product only (thread -> sample, two outputs): hipcc waits for the prefetched X rows with s_waitcnt vmcnt(0), and a
+    // y1 store issued here would be in flight when a row-first wave reaches that wait right behind the barrier (it stood
+    // there 5 k clocks per tile, profiles/r03ak)
+    if (!row_first) {
+      const int t8 = ((wv >> 3) << 2) | (wv & 3);  // 0..7 among the row-second waves
+      const int s = 2 * t8 + (lane >> 5), h = 2 * (lane & 31);
+      float v0 = bias0, v1 = bias1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v0 += Ys[g * (IT_TS * IT_YP) + s * IT_YP + h];
+        v1 += Ys[g * (IT_TS * IT_YP) + s * IT_YP + h + 1];
+      }
+      if (a.relu) {
+        v0 = v0 > 0.f ? v0 : 0.f;
+        v1 = v1 > 0.f ? v1 : 0.f;
+      }
+      const int64_t b = t * IT_TS + s;
+      if (b < a.B) {
+        a.y1[b * a.y1_stride + h] = v0;
+        a.y1[b * a.y1_stride + h + 1] = v1;
+      }
+    }
+    IT_PROF_MARK(5);  // sum of the partials
+  }
+  IT_PROF_DUMP(a.prof);
+}
+
+__global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a) {
+  __shared__ float Zs[2 * IT_TS * IT_ZP];
+  __shared__ float Ys[4 * IT_TS * IT_YP];
+  __shared__ float trash[IT_THREADS];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));  // (scalar: per-wave bases stay in SGPRs)
+  const int n = a.n;
+  const int P = n * (n - 1) / 2;
+  const int npb = (P + 15) >> 4, nblk = npb + n;
+  // K-group kg: whole blocks [kg base, kg base + base), base = nblk / 4, and one k-step of each of the nblk % 4 blocks left
+  const int base = nblk >> 2, rem = nblk & 3;
+  float* tr = trash + threadIdx.x;
+  // Criteo: 12 blocks + 1 k-step per wave (49 MFMAs, 49 registers of W1); other shapes run the longest body, zero-weighted
+  if (base == 12 && rem == 1) it_fwd_loop<12, 1>(a, Zs, Ys, tr, lane, wv, P, npb, base, rem);
+  else it_fwd_loop<IT_KB, 3>(a, Zs, Ys, tr, lane, wv, P, npb, base, rem);
+}
+
+int g_tzr_it_wgs = 0;  // tzr_tune("it_wgs"): workgroups of the fused kernels (0 = one per CU)
+
+static unsigned it_grid(int64_t B) {
+  const int64_t cus = g_tzr_it_wgs > 0 ? g_tzr_it_wgs : 256;  // MI355X: 256 CUs, one persistent workgroup each
+  const int64_t tiles = (B + IT_TS - 1) / IT_TS;
+  return (unsigned)(tiles < cus ? (tiles < 1 ? 1 : tiles) : cus);
+}
+
+extern "C" int tzr_dot_interaction_top_supported(int F, int D, int has_dense, int H) {
+  const int n = F + (has_dense ? 1 : 0);
+  if (D != IT_D || H != IT_H || n < 2 || n > 32) return 0;
+  return ((n * (n - 1) / 2 + 15) / 16 + n) <= IT_MAXBLK ? 1 : 0;
+}
+
+extern "C" int tzr_dot_interaction_top_bwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                           int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1,
+                                           int64_t g1_stride, int H, const float* d_W1, int64_t ldw,
+                                           const float* d_scale, float* d_grad_dense, int64_t grad_dense_stride,
+                                           float* d_grad_sparse, int64_t grad_sparse_stride, void* stream) {
+  const int hd = d_dense ? 1 : 0;
+  const int n = F + hd;
+  if (!d_sparse || !d_g1 || !d_W1 || !d_grad_sparse || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (hd && !d_grad_dense) return TZR_ERR_INVALID;
+  if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
+  if (ldw < n * (n - 1) / 2 + IT_D * n) return TZR_ERR_INVALID;
+  if ((sparse_stride & 3) || (grad_sparse_stride & 3) || (g1_stride & 3) || (hd && ((dense_stride | grad_dense_stride) & 3)) ||
+      ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_grad_sparse) | reinterpret_cast<uintptr_t>(d_g1) |
+        reinterpret_cast<uintptr_t>(d_dense) | reinterpret_cast<uintptr_t>(d_grad_dense)) & 15))
+    return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ItBwdArgs a;
+  a.dense = d_dense; a.sparse = d_sparse; a.g1 = d_g1; a.W1 = d_W1; a.scale = d_scale; a.gdense = d_grad_dense; a.gsparse = d_grad_sparse;
+  a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.g1_stride = g1_stride; a.ldw = ldw;
+  a.gdense_stride = grad_dense_stride; a.gsparse_stride = grad_sparse_stride; a.B = B; a.n = n; a.hd = hd;
+#ifdef IT_PROF
+  a.prof = g_tzr_it_prof;
+#else
+  a.prof = nullptr;
+#endif
+  hipLaunchKernelGGL(tzr_ia_top_bwd_kernel, dim3(it_grid(B)), dim3(IT_THREADS), 0, st, a);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+extern "C" int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                           int64_t sparse_stride, int F, int D, int64_t B, const float* d_W1,
+                                           int64_t ldw, const float* d_bias, int H, int relu, float* d_z,
+                                           int64_t z_stride, float* d_y1, int64_t y1_stride, void* stream) {
+  const int hd = d_dense ? 1 : 0;
+  const int n = F + hd;
+  if (!d_sparse || !d_W1 || !d_y1 || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
+  const int width = n * (n - 1) / 2 + IT_D * n;
+  if (ldw < width || (d_z && z_stride < width)) return TZR_ERR_INVALID;
+  if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
+      ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_dense)) & 15) ||
+      (reinterpret_cast<uintptr_t>(d_y1) & 3) || (reinterpret_cast<uintptr_t>(d_z) & 3))
+    return TZR_ERR_INVALID;
+  if (B == 0) return TZR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ItFwdArgs a;
+  a.dense = d_dense; a.sparse = d_sparse; a.W1 = d_W1; a.bias = d_bias; a.z = d_z; a.y1 = d_y1;
+  a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.ldw = ldw; a.z_stride = z_stride; a.y1_stride = y1_stride;
+  a.B = B; a.n = n; a.hd = hd; a.relu = relu;
+#ifdef IT_PROF
+  a.prof = g_tzr_it_prof;
+#else
+  a.prof = nullptr;
+#endif
+  hipLaunchKernelGGL(tzr_ia_top_fwd_kernel, dim3(it_grid(B)), dim3(IT_THREADS), 0, st, a);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

@@ -39,3 +39,14 @@ __device__ __forceinline__ uint32_t tzr_arrive(uint32_t* counter) {
 
 // Kernel attribute: compile for exactly `n` waves per SIMD (caps the VGPR budget at 512 / n).
 #define TZR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+// Workgroup barrier for hand-offs through LDS that leaves the vector-memory counter alone.  __syncthreads() is a
+// release fence as well: with a global store in flight hipcc emits s_waitcnt vmcnt(0) in front of s_barrier, and on
+// gfx9 loads share that counter -- in a persistent loop every prefetch and every output store would land on the next
+// barrier.  Only for kernels whose waves exchange nothing through global memory.
+__device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Make a lane value opaque to the optimiser at this point.  Used inside persistent loops on cheap, loop-invariant lane
+// arithmetic (an LDS offset): hipcc otherwise hoists it out of the loop, runs out of registers and SPILLS it -- and the
+// reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
+#define TZR_OPAQUE(x) asm volatile("" : "+v"(x))

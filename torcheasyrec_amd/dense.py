@@ -153,6 +153,31 @@ def mlp2_fits(x: torch.Tensor, linears) -> bool:
     return a.in_features <= MLP2_MAX[0] and a.out_features <= MLP2_MAX[1] and b.out_features <= MLP2_MAX[2]
 
 
+def _mlp_tail(y1, labels, W2, b2, w3, b3):
+    """tzr_mlp_tail on y1 = relu(first layer): -> (logits, g1, dW2, db2, dw3, scal = {d loss / d b3, loss}, db1)."""
+    B, H1 = y1.shape
+    H2 = W2.shape[0]
+    dev = y1.device
+    y = labels.contiguous()
+    if y.dtype not in (torch.float32, torch.int32, torch.int64):
+        y = y.float()
+    logits = torch.empty(B, dtype=torch.float32, device=dev)
+    g1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
+    dW2 = torch.empty(H2, H1, dtype=torch.float32, device=dev)
+    db2 = torch.empty(H2, dtype=torch.float32, device=dev)
+    dw3 = torch.empty(1, H2, dtype=torch.float32, device=dev)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    db1 = torch.empty(H1, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_mlp_workspace(), dev)
+    W2_, b2_, w3_, b3_ = _f32c(W2), _f32c(b2), _f32c(w3), _f32c(b3)
+    _lib.check(L.tzr_mlp_tail(_lib.ptr(y1), y1.stride(0), _lib.ptr(y), y.element_size(), 1 if y.is_floating_point() else 0,
+                              B, H1, _lib.ptr(W2_), _lib.ptr(b2_), H2, _lib.ptr(w3_), _lib.ptr(b3_), _lib.ptr(logits),
+                              _lib.ptr(g1), g1.stride(0), _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(dw3), _lib.ptr(scal),
+                              _lib.ptr(db1), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_mlp_tail")
+    return logits, g1, dW2, db2, dw3, scal, db1
+
+
 class _TopLossFn(torch.autograd.Function):
     """The top MLP of a ranking model from its wide input to the loss, forward AND backward of everything behind the
     first GEMM in one launch: y1 = relu(z W1^T + b1) stays one hipBLASLt call (ReLU in its epilogue); tzr_mlp_tail then
@@ -164,26 +189,7 @@ class _TopLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, W1, b1, W2, b2, w3, b3, labels):
         y1 = torch._addmm_activation(b1, z, W1.t(), use_gelu=False)
-        B, H1 = y1.shape
-        H2 = W2.shape[0]
-        dev = z.device
-        y = labels.contiguous()
-        if y.dtype not in (torch.float32, torch.int32, torch.int64):
-            y = y.float()
-        logits = torch.empty(B, dtype=torch.float32, device=dev)
-        g1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
-        dW2 = torch.empty(H2, H1, dtype=torch.float32, device=dev)
-        db2 = torch.empty(H2, dtype=torch.float32, device=dev)
-        dw3 = torch.empty(1, H2, dtype=torch.float32, device=dev)
-        scal = torch.empty(2, dtype=torch.float32, device=dev)
-        db1 = torch.empty(H1, dtype=torch.float32, device=dev)
-        L = _lib.lib()
-        ws = _lib.workspace(L.tzr_mlp_workspace(), dev)
-        W2_, b2_, w3_, b3_ = _f32c(W2), _f32c(b2), _f32c(w3), _f32c(b3)
-        _lib.check(L.tzr_mlp_tail(_lib.ptr(y1), y1.stride(0), _lib.ptr(y), y.element_size(), 1 if y.is_floating_point() else 0,
-                                  B, H1, _lib.ptr(W2_), _lib.ptr(b2_), H2, _lib.ptr(w3_), _lib.ptr(b3_), _lib.ptr(logits),
-                                  _lib.ptr(g1), g1.stride(0), _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(dw3), _lib.ptr(scal),
-                                  _lib.ptr(db1), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_mlp_tail")
+        logits, g1, dW2, db2, dw3, scal, db1 = _mlp_tail(y1, labels, W2, b2, w3, b3)
         ctx.save_for_backward(z, W1, g1, dW2, db2, dw3, scal, db1)
         ctx.mark_non_differentiable(logits)
         return scal[1], logits
@@ -211,6 +217,88 @@ def top_loss_fits(z: torch.Tensor, linears, out_linear) -> bool:
 def top_loss(z, l1, l2, out_linear, labels):
     """(mean BCE-with-logits loss, logits [B]) of relu(relu(z W1^T + b1) W2^T + b2) w3^T + b3 -- see _TopLossFn."""
     return _TopLossFn.apply(z, l1.weight, l1.bias, l2.weight, l2.bias, out_linear.weight, out_linear.bias, labels)
+
+
+class _InteractionTopLossFn(torch.autograd.Function):
+    """DLRM from the embeddings to the loss: dot interaction + first top-MLP layer as one kernel per direction
+    (tzr_dot_interaction_top_fwd / _bwd, csrc/interaction_top.hip), the rest of the top MLP + loss + their backward as
+    tzr_mlp_tail.  The interaction row z [B, P + 16 n] is written once (the weight gradient g1^T z reads it); its
+    gradient dz = g1 W1 never exists in HBM.  Same returns as _TopLossFn."""
+
+    @staticmethod
+    def forward(ctx, dense, sparse, D, W1, b1, W2, b2, w3, b3, labels):
+        B = sparse.shape[0]
+        F = sparse.shape[1] // D
+        sparse = sparse.contiguous()
+        dense = dense.contiguous()
+        n = F + 1
+        width = n * (n - 1) // 2 + D * n
+        H1 = W1.shape[0]
+        dev = sparse.device
+        z = torch.empty(B, width, dtype=torch.float32, device=dev)
+        y1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
+        W1_, b1_ = _f32c(W1), _f32c(b1)
+        _lib.check(_lib.lib().tzr_dot_interaction_top_fwd(
+            _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(W1_), W1_.stride(0),
+            _lib.ptr(b1_), H1, 1, _lib.ptr(z), z.stride(0), _lib.ptr(y1), y1.stride(0), _lib.stream_ptr(dev)),
+            "tzr_dot_interaction_top_fwd")
+        logits, g1, dW2, db2, dw3, scal, db1 = _mlp_tail(y1, labels, W2, b2, w3, b3)
+        ctx.save_for_backward(dense, sparse, z, W1_, g1, dW2, db2, dw3, scal, db1)
+        ctx.cfg = (F, D)
+        ctx.mark_non_differentiable(logits)
+        return scal[1], logits
+
+    @staticmethod
+    def backward(ctx, gl, _glogits):
+        dense, sparse, z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
+        F, D = ctx.cfg
+        B = sparse.shape[0]
+        gl32 = gl.reshape(1).to(torch.float32)
+        gd = gs = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gs = torch.empty_like(sparse)
+            gd = torch.empty_like(dense)
+            _lib.check(_lib.lib().tzr_dot_interaction_top_bwd(
+                _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0),
+                g1.shape[1], _lib.ptr(W1), W1.stride(0), _lib.ptr(gl32), _lib.ptr(gd), gd.stride(0), _lib.ptr(gs),
+                gs.stride(0), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_bwd")
+        outs = torch._foreach_mul([weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1]], gl)
+        return (gd, gs, None, *outs, None)
+
+
+def interaction_top_fits(dense: torch.Tensor, sparse: torch.Tensor, D: int, first_linear) -> bool:
+    """Whether the fused interaction + first-layer kernels take this shape (D = 16, H = 64, n <= 29, fp32)."""
+    if dense is None or sparse.dim() != 2 or dense.dim() != 2 or dense.shape[1] != D or sparse.shape[1] % D:
+        return False
+    if sparse.dtype != torch.float32 or dense.dtype != torch.float32 or first_linear.weight.dtype != torch.float32:
+        return False
+    F = sparse.shape[1] // D
+    n = F + 1
+    if first_linear.in_features != n * (n - 1) // 2 + D * n:
+        return False
+    return bool(_lib.lib().tzr_dot_interaction_top_supported(F, D, 1, first_linear.out_features))
+
+
+def interaction_first_layer(dense, sparse, D, l1) -> torch.Tensor:
+    """relu(l1(dot_interaction(dense, sparse))) without the interaction row ever reaching HBM -- inference only
+    (no autograd graph is recorded; training goes through interaction_top_loss)."""
+    B = sparse.shape[0]
+    F = sparse.shape[1] // D
+    sparse = sparse.detach().contiguous()
+    dense = dense.detach().contiguous()
+    W1, b1 = _f32c(l1.weight.detach()), _f32c(l1.bias.detach())
+    y1 = torch.empty(B, W1.shape[0], dtype=torch.float32, device=sparse.device)
+    _lib.check(_lib.lib().tzr_dot_interaction_top_fwd(
+        _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(W1), W1.stride(0), _lib.ptr(b1),
+        W1.shape[0], 1, None, 0, _lib.ptr(y1), y1.stride(0), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_fwd")
+    return y1
+
+
+def interaction_top_loss(dense, sparse, D, l1, l2, out_linear, labels):
+    """(mean BCE-with-logits loss, logits [B]) of the DLRM head on (dense-MLP output, pooled sparse block):
+    top_loss(dot_interaction(dense, sparse), ...) with the interaction row's gradient kept on chip."""
+    return _InteractionTopLossFn.apply(dense, sparse, D, l1.weight, l1.bias, l2.weight, l2.bias, out_linear.weight,
+                                       out_linear.bias, labels)
 
 
 class FusedDenseAdam:

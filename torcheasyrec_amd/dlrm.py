@@ -26,6 +26,10 @@ _FUSED_RELU_BWD = os.environ.get("TZR_MLP_FUSED_RELU_BWD", "1") == "1"  # A/B sw
 _FUSED_RELU = os.environ.get("TZR_MLP_FUSED_RELU", "1") == "1"  # A/B switch; measured -23 us per DLRM step
 _FUSED_MLP2 = os.environ.get("TZR_FUSED_MLP2", "1") == "1"  # A/B switch: bottom MLP through tzr_mlp2_fwd / bwd
 _FUSED_TOP_LOSS = os.environ.get("TZR_FUSED_TOP_LOSS", "1") == "1"  # A/B switch: DLRM.forward_loss through tzr_mlp_tail
+# A/B switch: interaction + first top layer as one kernel per direction (csrc/interaction_top.hip); below MIN_B samples the
+# persistent kernels' prologue (W1 into registers, 200 KB per workgroup) is not amortised
+_FUSED_IA_TOP = os.environ.get("TZR_FUSED_IA_TOP", "1") == "1"
+_FUSED_IA_TOP_MIN_B = int(os.environ.get("TZR_FUSED_IA_TOP_MIN_B", "0"))
 
 
 def _on_emulator() -> bool:
@@ -164,6 +168,29 @@ class MLP(nn.Module):
         return self.mlp(x)
 
 
+def head_loss(model, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor):
+    """(mean BCE-with-logits loss, logits [B]) of a DLRM head (`dense_mlp`, `final_mlp`, `output_mlp`, `dim`,
+    `arch_with_sparse` of `model`) on the dense features and the pooled sparse block; shared by DLRM and ShardedDLRM."""
+    d = model.dense_mlp(dense)
+    fused = _FUSED_TOP_LOSS and model.final_mlp._plain and (sparse.is_cuda or _on_emulator())
+    if fused and _FUSED_IA_TOP and model.arch_with_sparse and sparse.shape[0] >= _FUSED_IA_TOP_MIN_B:
+        from .dense import interaction_top_fits, interaction_top_loss, top_loss_fits
+
+        lin = model.final_mlp.linears()
+        # (top_loss_fits only looks at the layer widths and the device of its first argument)
+        if interaction_top_fits(d, sparse, model.dim, lin[0]) and top_loss_fits(sparse, lin, model.output_mlp):
+            return interaction_top_loss(d, sparse, model.dim, lin[0], lin[1], model.output_mlp, labels)
+    allf = dot_interaction(d, sparse, model.dim, cat_dense=True, cat_sparse=model.arch_with_sparse)
+    if fused:
+        from .dense import top_loss, top_loss_fits
+
+        lin = model.final_mlp.linears()
+        if top_loss_fits(allf, lin, model.output_mlp):
+            return top_loss(allf, lin[0], lin[1], model.output_mlp, labels)
+    logits = model.output_mlp(model.final_mlp(allf)).squeeze(1)
+    return bce_with_logits(logits, labels), logits.detach()
+
+
 class DLRM(nn.Module):
     """DLRM with dot interaction (``dlrm{}`` block of examples/dlrm_criteo.config)."""
 
@@ -210,6 +237,16 @@ class DLRM(nn.Module):
 
     def predict_from_embeddings(self, dense: torch.Tensor, sparse: torch.Tensor) -> torch.Tensor:
         d = self.dense_mlp(dense)
+        if (not torch.is_grad_enabled() and _FUSED_IA_TOP and self.final_mlp._plain and self.arch_with_sparse
+                and (sparse.is_cuda or _on_emulator()) and sparse.shape[0] >= _FUSED_IA_TOP_MIN_B):
+            from .dense import interaction_first_layer, interaction_top_fits
+
+            lin = self.final_mlp.linears()
+            if interaction_top_fits(d, sparse, self.dim, lin[0]):  # inference: the interaction row stays on chip
+                y = interaction_first_layer(d, sparse, self.dim, lin[0])
+                for l in lin[1:]:
+                    y = torch.relu(l(y))
+                return self.output_mlp(y).squeeze(1)
         allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
         return self.output_mlp(self.final_mlp(allf)).squeeze(1)
 
@@ -223,16 +260,7 @@ class DLRM(nn.Module):
         (/root/reference/tzrec/models/model.py:271-297, rank_model.py:219-262).  When the top MLP is the two-layer ReLU
         stack + one-unit output of the DLRM config, everything behind its first GEMM -- second layer, logit, loss and
         their whole backward -- is one launch (`dense.top_loss`); otherwise logits and loss the plain way."""
-        d = self.dense_mlp(dense)
-        allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
-        if _FUSED_TOP_LOSS and self.final_mlp._plain and (allf.is_cuda or _on_emulator()):
-            from .dense import top_loss, top_loss_fits
-
-            lin = self.final_mlp.linears()
-            if top_loss_fits(allf, lin, self.output_mlp):
-                return top_loss(allf, lin[0], lin[1], self.output_mlp, labels)
-        logits = self.output_mlp(self.final_mlp(allf)).squeeze(1)
-        return bce_with_logits(logits, labels), logits.detach()
+        return head_loss(self, dense, sparse, labels)
 
     def forward_loss(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor, labels: torch.Tensor):
         sparse = self.ebc.forward_grouped(sparse_features)["sparse"]

@@ -995,18 +995,9 @@ class ShardedDLRM(nn.Module):
         """(mean BCE-with-logits loss over this rank's samples, logits [B]): `dense_forward` + the loss with everything
         behind the top MLP's first GEMM in one launch when the stack fits (torcheasyrec_amd.dense.top_loss; the
         unsharded DLRM.loss_from_embeddings does the same)."""
-        from .dlrm import _FUSED_TOP_LOSS, _on_emulator, bce_with_logits
+        from .dlrm import head_loss
 
-        d = self.dense_mlp(dense)
-        allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
-        if _FUSED_TOP_LOSS and self.final_mlp._plain and (allf.is_cuda or _on_emulator()):
-            from .dense import top_loss, top_loss_fits
-
-            lin = self.final_mlp.linears()
-            if top_loss_fits(allf, lin, self.output_mlp):
-                return top_loss(allf, lin[0], lin[1], self.output_mlp, labels)
-        logits = self.output_mlp(self.final_mlp(allf)).squeeze(1)
-        return bce_with_logits(logits, labels), logits.detach()
+        return head_loss(self, dense, sparse, labels)
 
     def forward(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
         if dense.is_cuda and self.overlap_dense:
