@@ -2,7 +2,7 @@
 # fused interaction + first top layer: parity on the GPU, bench A/B, kernel stats
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-TAG=${1:-r03ac}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
+TAG=${1:-r03aq}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_interaction_top.py tests/test_mlp_fused.py tests/test_sharded_gpu.py -m gpu -q -x > $O/tests.log 2>&1; echo "tests rc=$?"; grep -E "passed|failed" $O/tests.log | tail -1
 for v in 1 0 ; do
   TZR_FUSED_IA_TOP=$v timeout 400 python bench.py --no-cpu-baseline --no-e2e --no-secondary > $O/bench_fused$v.json 2>> $O/bench.err; python -c "
@@ -11,6 +11,6 @@ import json; d=json.load(open('$O/bench_fused$v.json')); print('[fused=$v]', rou
 import json; d=json.load(open('$O/bench8k_fused$v.json')); print('[8192 fused=$v]', round(d['value']/1e6,2),'M/s', round(d['ms_per_step'],4),'ms loss', d['final_loss'])"
 done
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-e2e --no-secondary > $O/trace.log 2>&1
+TZR_TUNABLE_TUNING=0 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o trace --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-e2e --no-secondary > $O/trace.log 2>&1
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-150
 rm -rf $O/prof

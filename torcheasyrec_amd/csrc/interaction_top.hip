@@ -31,7 +31,7 @@
 #define IT_BPW (IT_MAXBLK / IT_WAVES)  // backward: column blocks per wave (4)
 #define IT_KB (IT_MAXBLK / 4)        // forward: blocks per K-group (16)
 #define IT_SROW 33                   // row pitch of one S matrix (odd: conflict-free column reads)
-#define IT_SS (32 * IT_SROW + 1)     // floats per sample in S
+#define IT_SS (32 * IT_SROW + 4)     // floats per sample in S (1060: the four sample groups of an accumulator scatter land 16 banks apart)
 #define IT_PS (32 * IT_D)            // floats per sample of pass-through gradients
 #define IT_XS (32 * (IT_D + 1))      // floats of one X image
 #define IT_ZP (16 * IT_MAXBLK + 4)   // floats per sample of the LDS z tile (virtual columns; +4: banks of the b128 A-operand reads)
@@ -176,36 +176,44 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
   int cur = 0;
   __syncthreads();
   IT_PROF_DECL;
+  it_f32x4 acc[NB], accx;
+  const bool product_first = (wv >> 2) & 1;
+  bool have = false;  // acc already holds this tile's product (computed during the previous tile by a product-first wave)
   for (; t < ntiles; t += G, cur ^= 1) {
     // ---- dz[:, blocks of this wave] = g1 tile . W1[:, those columns]; A operand: lane (i = r, q) reads g1[i][16 q ..
     // 16 q + 15], k-step ks uses element 16 q + ks (the contraction order is free as long as the W1 fragment agrees)
-    it_f32x4 acc[NB];
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = it_f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      const float* gp = Gs + cur * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const float4 av = tzr_ld4(gp + 4 * k4);
-        const float ag[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int m = 0; m < NB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[e], Wf[m][4 * k4 + e], acc[m], 0, 0, 0);
+    // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
+    // of this one, the other half behind it: in lockstep all sixteen would sit in the LDS-latency-bound contraction at
+    // once with the MFMA pipe mostly idle, then all in the product.
+    auto product = [&](int buf) {
+  #pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = it_f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        const float* gp = Gs + buf * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
+  #pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const float4 av = tzr_ld4(gp + 4 * k4);
+          const float ag[4] = {av.x, av.y, av.z, av.w};
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+  #pragma unroll
+            for (int m = 0; m < NB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[e], Wf[m][4 * k4 + e], acc[m], 0, 0, 0);
+        }
       }
-    }
-    it_f32x4 accx = {0.f, 0.f, 0.f, 0.f};
-    if (XL && wv == 0) {
-      const float* gp = Gs + cur * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const float4 av = tzr_ld4(gp + 4 * k4);
-        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wx[(4 * k4 + 0) * TZR_WAVE + lane], accx, 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
+      accx = it_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (XL && wv == 0) {
+        const float* gp = Gs + buf * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
+  #pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const float4 av = tzr_ld4(gp + 4 * k4);
+          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wx[(4 * k4 + 0) * TZR_WAVE + lane], accx, 0, 0, 0);
+          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
+          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
+          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
+        }
       }
-    }
+    };
+    if (!have) product(cur);
     IT_PROF_MARK(0);  // product
     tzr_lds_barrier();  // every wave is done reading S / PT of the previous tile and this tile's g1
     IT_PROF_MARK(1);  // wait 1
@@ -246,6 +254,8 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
     Gs[(cur ^ 1) * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
     tzr_lds_barrier();
     IT_PROF_MARK(2);  // scatter + wait 2
+    have = product_first && t + G < ntiles;
+    if (have) product(cur ^ 1);
     // ---- dX = S X + pass-through of sample wv of the tile (transposed product, see interaction.hip)
     {
       const float4 x0 = v0 ? X.lo : tzr_zero4(), x1 = v1 ? X.hi : tzr_zero4();
@@ -364,6 +374,7 @@ struct ItFwdArgs {
 // address, same value) instead of branching.
 __device__ __forceinline__ void it_fwd_row(const ItX X, float* __restrict__ zs, float* __restrict__ trash, float* __restrict__ o,
                                            int n, int P, int pt0, int lane) {
+  TZR_OPAQUE(lane);  // (the lane arithmetic below is redone per row: hoisted out of the tile loop it is a dozen registers, spilled)
   const int r = lane & 15, q = lane >> 4;
   const bool v0 = r < n, v1 = 16 + r < n;
   const int rr0 = v0 ? r : n - 1, rr1 = v1 ? 16 + r : n - 1;
@@ -499,11 +510,14 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
         const int64_t b = (t + G) * IT_TS + wv;
         float* zs = Zs + (cur ^ 1) * (IT_TS * IT_ZP) + wv * IT_ZP;
         float* o = (a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
+        // the X rows of the tile after that take off FIRST (into a second set of registers): a row-first wave is back
+        // here ~3 k clocks after its last row, less than an HBM round trip under this load -- it stood 5 k clocks per tile
+        // waiting for rows fetched at the end of the previous row (profiles/r03an)
+        const ItX Xn = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + 2 * G < ntiles ? t + 2 * G : t) * IT_TS + wv,
+                                  a.B, n, a.hd, r, q);
         it_fwd_row(X, zs, trash, o, n, P, pt0, lane);
-        // (as early as the X registers are free: a row-first wave gets back here barely an HBM round trip later)
-        X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + 2 * G < ntiles ? t + 2 * G : t) * IT_TS + wv, a.B, n, a.hd,
-                       r, q);
         it_fwd_row_pairs_out(zs, o, P, lane);
+        X = Xn;
       }
     };
     if (row_first) next_row();
