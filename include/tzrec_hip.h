@@ -547,6 +547,8 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   ia_bwd_plain        1: the D = 16 dot-interaction backward without its software pipeline (A/B switch)
  *   ia_bwd_wgs          workgroups of that backward (0 = by batch size)
  *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
+ *   mlp_mfma            -1: tzr_mlp2_* / tzr_mlp_tail use their general LDS-tiled kernels for every shape (0: the MFMA
+ *                       kernels of mlp_mfma.hip where the shape is DLRM-Criteo's)
  *   it_wgs              persistent workgroups of the fused interaction + first-layer kernels (0 = 256, one per CU)
  *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per
  *                       1024-lookup tile.  Same plan, slower under heavy skew.  Set it when plans are built on a

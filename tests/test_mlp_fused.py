@@ -97,3 +97,57 @@ def test_dlrm_forward_loss_matches_layerwise_step(dev):
         _close(a, b)
     for n in wa:
         torch.testing.assert_close(wa[n], wb[n], rtol=1e-5, atol=1e-7, msg=n)
+
+
+@pytest.mark.parametrize("knob", [-1, 0, 2])
+def test_top_loss_kernel_variants_agree(dev, knob):
+    """The 64 -> 32 -> 1 tail on the matrix cores (mlp_mfma.hip; knob 2: two workgroups, several tiles per wave) and on
+    the general LDS-tiled kernel (knob -1) against torch autograd."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.dense import top_loss
+
+    B, K = 700, 48
+    torch.manual_seed(11)
+    l1, l2, lo = torch.nn.Linear(K, 64).to(dev), torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 1).to(dev)
+    z = torch.randn(B, K, device=dev, requires_grad=True)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+    logits_ref = lo(torch.relu(l2(torch.relu(l1(z))))).squeeze(1)
+    loss_ref = torch.nn.functional.binary_cross_entropy_with_logits(logits_ref, y.float())
+    loss_ref.backward()
+    ps = [z, l1.weight, l1.bias, l2.weight, l2.bias, lo.weight, lo.bias]
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    assert _lib.lib().tzr_tune(b"mlp_mfma", knob) == 0
+    loss, logits = top_loss(z, l1, l2, lo, y)
+    torch.testing.assert_close(logits, logits_ref.detach(), rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref)) + 1e-7
+    loss.backward()
+    for w, p in zip(want, ps):
+        _close(p.grad, w)
+
+
+@pytest.mark.parametrize("knob", [-1, 0, 2])
+@pytest.mark.parametrize("B,K0", [(700, 13), (33, 16), (50, 5)])
+def test_mlp2_kernel_variants_agree(dev, knob, B, K0):
+    """The 13 -> 64 -> 16 stack on the matrix cores (knob 2: two workgroups, several tiles per wave) and on the general
+    LDS-tiled kernels (knob -1) against torch autograd."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.dense import mlp2
+
+    torch.manual_seed(B + K0)
+    la, lb = torch.nn.Linear(K0, 64).to(dev), torch.nn.Linear(64, 16).to(dev)
+    x = torch.randn(B, K0, device=dev)
+    g = torch.randn(B, 16, device=dev)
+    ref = torch.relu(lb(torch.relu(la(x))))
+    ref.backward(g)
+    ps = (la.weight, la.bias, lb.weight, lb.bias)
+    want = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    assert _lib.lib().tzr_tune(b"mlp_mfma", knob) == 0
+    out = mlp2(x, *ps)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    out.backward(g)
+    for w, p in zip(want, ps):
+        _close(p.grad, w)

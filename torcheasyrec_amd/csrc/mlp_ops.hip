@@ -19,6 +19,15 @@
 // one finish pass in workgroup order): bit-reproducible, no float atomics.
 #include "tzr_common.h"
 
+int g_tzr_mlp_mfma = 0;  // tzr_tune("mlp_mfma"): -1 = the general LDS-tiled kernels for every shape (A/B, tests); 0 = MFMA kernels where the shape fits
+int tzr_mlp_tail64_launch(const float* d_y1, int64_t y1_stride, const void* d_labels, int labels_itemsize, int labels_are_float,
+                          int64_t B, const float* d_W2, const float* d_b2, const float* d_w3, const float* d_b3, float* d_logits,
+                          float* d_g1, int64_t g1_stride, float* parts, hipStream_t s);  // mlp_mfma.hip
+void tzr_mlp2_fwd16_launch(const float* d_x, int64_t xs, int64_t B, int K0, const float* d_Wa, const float* d_ba, const float* d_Wb,
+                           const float* d_bb, float* d_ha, int64_t has, float* d_hb, int64_t hbs, hipStream_t s);
+int tzr_mlp2_bwd16_launch(const float* d_dhb, int64_t dhbs, const float* d_hb, int64_t hbs, const float* d_ha, int64_t has,
+                          const float* d_x, int64_t xs, int64_t B, int K0, const float* d_Wb, float* parts, int P, hipStream_t s);
+
 #define ML_THREADS 256
 #define ML_TS 64      // samples per tile
 #define ML_K0 32      // max input width of tzr_mlp2
@@ -170,6 +179,14 @@ extern "C" int tzr_mlp2_fwd(const float* d_x, int64_t x_stride, int64_t B, int K
   if (!d_x || !d_Wa || !d_Wb || !d_ha || !d_hb || B < 0 || K0 <= 0 || H1 <= 0 || H2 <= 0) return TZR_ERR_INVALID;
   if (K0 > ML_K0 || H1 > ML_H1 || H2 > ML_H2) return TZR_ERR_UNSUPPORTED;
   if (B == 0) return TZR_OK;
+  // the DLRM-Criteo shape runs on the matrix cores, one wave per 16-sample tile (mlp_mfma.hip)
+  if (g_tzr_mlp_mfma >= 0 && K0 <= 16 && H1 == 64 && H2 == 16 && !(ha_stride & 3) && !(reinterpret_cast<uintptr_t>(d_ha) & 15) &&
+      !(reinterpret_cast<uintptr_t>(d_Wb) & 15)) {
+    tzr_mlp2_fwd16_launch(d_x, x_stride, B, K0, d_Wa, d_ba, d_Wb, d_bb, d_ha, ha_stride, d_hb, hb_stride,
+                          static_cast<hipStream_t>(stream));
+    TZR_CHECK_LAUNCH();
+    return TZR_OK;
+  }
   const int64_t tiles = (B + ML_TS - 1) / ML_TS;
   hipLaunchKernelGGL(tzr_mlp2_fwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(ML_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_x, x_stride, B, K0, d_Wa, d_ba, H1, d_Wb, d_bb, H2, d_ha,
@@ -326,11 +343,15 @@ extern "C" int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float*
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_mlp_workspace() - 256) return TZR_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t tiles = (B + ML_TS - 1) / ML_TS;
-  const int G = (int)std::min<int64_t>(tiles, ML_MAX_WG);
+  int G = (int)std::min<int64_t>(tiles, ML_MAX_WG);
   const int P = H2 * H1 + H2 + H1 * K0 + H1;
   float* parts = static_cast<float*>(ws);
-  hipLaunchKernelGGL(tzr_mlp2_bwd_kernel, dim3(G), dim3(ML_THREADS), 0, s, d_dhb, dhb_stride, d_hb, hb_stride, d_ha,
-                     ha_stride, d_x, x_stride, B, K0, H1, H2, d_Wb, parts, P);
+  if (g_tzr_mlp_mfma >= 0 && K0 <= 16 && H1 == 64 && H2 == 16 && !((ha_stride | hb_stride | dhb_stride) & 3) &&
+      !((reinterpret_cast<uintptr_t>(d_ha) | reinterpret_cast<uintptr_t>(d_hb) | reinterpret_cast<uintptr_t>(d_dhb)) & 15))
+    G = tzr_mlp2_bwd16_launch(d_dhb, dhb_stride, d_hb, hb_stride, d_ha, ha_stride, d_x, x_stride, B, K0, d_Wb, parts, P, s);
+  else
+    hipLaunchKernelGGL(tzr_mlp2_bwd_kernel, dim3(G), dim3(ML_THREADS), 0, s, d_dhb, dhb_stride, d_hb, hb_stride, d_ha,
+                       ha_stride, d_x, x_stride, B, K0, H1, H2, d_Wb, parts, P);
   MlParts out;
   for (int i = 0; i < 6; ++i) {
     out.dst[i] = nullptr;
@@ -504,9 +525,17 @@ extern "C" int tzr_mlp_tail(const float* d_y1, int64_t y1_stride, const void* d_
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_mlp_workspace() - 256) return TZR_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t tiles = (B + ML_TS - 1) / ML_TS;
-  const int G = (int)std::min<int64_t>(tiles, ML_MAX_WG);
+  int G = (int)std::min<int64_t>(tiles, ML_MAX_WG);
   const int P = H2 * H1 + 2 * H2 + 2 + H1;
   float* parts = static_cast<float*>(ws);
+  // the DLRM-Criteo shape runs on the matrix cores, one wave per 16-sample tile (mlp_mfma.hip)
+  const bool mfma = g_tzr_mlp_mfma >= 0 && H1 == 64 && H2 == 32 && !((y1_stride | g1_stride) & 3) &&
+                    !((reinterpret_cast<uintptr_t>(d_y1) | reinterpret_cast<uintptr_t>(d_g1)) & 15);
+  if (mfma) {
+    G = tzr_mlp_tail64_launch(d_y1, y1_stride, d_labels, labels_itemsize, labels_are_float, B, d_W2, d_b2, d_w3, d_b3, d_logits,
+                              d_g1, g1_stride, parts, s);
+    if (G < 0) return TZR_ERR_UNSUPPORTED;
+  } else {
 #define TZR_TAIL_LAUNCH(T)                                                                                         \
   hipLaunchKernelGGL(tzr_mlp_tail_kernel<T>, dim3(G), dim3(ML_THREADS), 0, s, d_y1, y1_stride,                     \
                      static_cast<const T*>(d_labels), B, H1, d_W2, d_b2, H2, d_w3, d_b3, d_logits, d_g1, g1_stride, \
@@ -516,6 +545,7 @@ extern "C" int tzr_mlp_tail(const float* d_y1, int64_t y1_stride, const void* d_
   else if (!labels_are_float && labels_itemsize == 4) TZR_TAIL_LAUNCH(int32_t);
   else return TZR_ERR_UNSUPPORTED;
 #undef TZR_TAIL_LAUNCH
+  }
   MlParts out;
   out.dst[0] = d_dW2; out.n[0] = H2 * H1;
   out.dst[1] = d_db2; out.n[1] = H2;
