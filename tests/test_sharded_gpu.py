@@ -14,10 +14,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind,replicate", [("adagrad", False), ("rowwise_adagrad", False), ("adagrad", True),
-                                            ("rowwise_adagrad", True)])
-def test_sharded_world1_matches_unsharded(kind, replicate):
+def _body_sharded_world1_matches_unsharded(kind, replicate):
     from torcheasyrec_amd import _lib
     from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.dlrm import DLRM, bce_with_logits
@@ -90,11 +87,10 @@ def test_sharded_world1_matches_unsharded(kind, replicate):
                 np.testing.assert_allclose(shd.ebc.table_states()[name][:n].cpu().numpy(), m_or[name][lo:lo + n], rtol=1e-5, atol=1e-8,
                                            err_msg=f"oracle state {name}")
         finally:
-            dist.destroy_process_group()
+            pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
 
 
-@pytest.mark.gpu
-def test_pipelined_train_step_matches_autograd_path():
+def _body_pipelined_train_step_matches_autograd_path():
     """ShardedTrainStep (input dist one batch ahead on a side stream, dense segment replayed from a
     hipGraph, fused Adam) follows the same trajectory as the op-by-op autograd path: same losses,
     same dense weights, same tables after 6 steps."""
@@ -143,11 +139,10 @@ def test_pipelined_train_step_matches_autograd_path():
             for name, w in a.ebc.table_weights().items():
                 torch.testing.assert_close(b.ebc.table_weights()[name], w, rtol=1e-5, atol=1e-6, msg=name)
         finally:
-            dist.destroy_process_group()
+            pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
 
 
-@pytest.mark.gpu
-def test_sharded_zch_world1_matches_unsharded_zch():
+def _body_sharded_zch_world1_matches_unsharded_zch():
     """One rank: hash routing sends everything to rank 0, whose share is the whole map -- the sharded
     ZCH collection must then walk the same trajectory as the unsharded one (same admissions, same
     evictions, same table rows), with the exchange kernels and RCCL in the loop."""
@@ -197,12 +192,10 @@ def test_sharded_zch_world1_matches_unsharded_zch():
             for n, w in a.ebc.table_weights().items():
                 torch.testing.assert_close(b.sharded.table_weights()[n], w, rtol=1e-6, atol=1e-7, msg=n)
         finally:
-            dist.destroy_process_group()
+            pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,graph_input_dist", [(2048, True), (8192, False)])
-def test_whole_step_graph_world1(B, graph_input_dist):
+def _body_whole_step_graph_world1(B, graph_input_dist):
     """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
     all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
     pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed."""
@@ -245,4 +238,43 @@ def test_whole_step_graph_world1(B, graph_input_dist):
             for n, w in out["exact"][2].items():
                 assert torch.equal(w, out["graph"][2][n]), n
         finally:
-            dist.destroy_process_group()
+            pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
+
+
+def _isolated(body, *args):
+    """Run `_body_<body>(*args)` in a process of its own and require its OK marker.  The bodies create a one-rank RCCL
+    process group and capture hipGraphs next to it; tearing that group down in-process aborted the interpreter (inside
+    `destroy_process_group`, no message) in 2 of 4 runs of round 3 -- AFTER every assertion had passed -- and an abort
+    takes the whole pytest session with it.  The child prints the marker behind the body's last assertion and leaves
+    with os._exit: no teardown of the group, no interpreter shutdown."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (f"import os, sys; sys.path.insert(0, {here!r}); sys.path.insert(0, {os.path.dirname(here)!r}); "
+            f"import test_sharded_gpu as m; m._body_{body}(*{args!r}); print('TZR_ISOLATED_OK', flush=True); os._exit(0)")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "TZR_ISOLATED_OK" in p.stdout, (p.stdout[-4000:] + "\n---- stderr ----\n" + p.stderr[-4000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,replicate", [("adagrad", False), ("rowwise_adagrad", False), ("adagrad", True),
+                                            ("rowwise_adagrad", True)])
+def test_sharded_world1_matches_unsharded(kind, replicate):
+    _isolated("sharded_world1_matches_unsharded", kind, replicate)
+
+
+@pytest.mark.gpu
+def test_pipelined_train_step_matches_autograd_path():
+    _isolated("pipelined_train_step_matches_autograd_path")
+
+
+@pytest.mark.gpu
+def test_sharded_zch_world1_matches_unsharded_zch():
+    _isolated("sharded_zch_world1_matches_unsharded_zch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,graph_input_dist", [(2048, True), (8192, False)])
+def test_whole_step_graph_world1(B, graph_input_dist):
+    _isolated("whole_step_graph_world1", B, graph_input_dist)
+
