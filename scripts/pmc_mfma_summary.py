@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""MFMA activity of the dot-interaction kernels from one rocprofv3 PMC pass.
+"""MFMA activity of the dot-interaction kernels (stand-alone and fused with the first top-MLP layer) and of the small-MLP
+kernels from one rocprofv3 PMC pass.
 
     pmc_mfma_summary.py <pmc_dir> <out.json>
 
@@ -24,7 +25,7 @@ def main(d, out):
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "interaction" not in k:
+        if "interaction" not in k and "tzr_ia_top" not in k and "tzr_mlp" not in k:  # the MFMA kernels of the dense half
             continue
         name = k.split("(")[0].replace("void ", "").split("<")[0]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
