@@ -25,7 +25,9 @@ def _digest() -> str:
     for p in deps:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    # (the flags without the absolute include path: the same sources must give the same digest wherever the tree lies --
+    # the GPU box runs from a scratch copy, and bench.py matches profiles/*/pmc_traffic.json by this digest)
+    h.update(" ".join(f for f in FLAGS if f != CSRC).encode())
     return h.hexdigest()
 
 
