@@ -138,6 +138,49 @@ def enable_tunable_gemm():
         tn.read_file(dst)
 
 
+def interaction_top_rooflines(dev, B):
+    """tzr_dot_interaction_top_fwd / _bwd at the DLRM-Criteo shape (27 rows of 16, first top layer 783 -> 64), alone:
+    median of 20 launches, HIP events on the launching stream."""
+    from torcheasyrec_amd import _lib
+
+    L = _lib.lib()
+    D, F, H = 16, 26, 64
+    n = F + 1
+    P = n * (n - 1) // 2
+    width = P + D * n
+    st = _lib.stream_ptr(dev)
+    dense, sparse = torch.randn(B, D, device=dev), torch.randn(B, F * D, device=dev)
+    W1, b1, g1 = torch.randn(H, width, device=dev) * 0.05, torch.randn(H, device=dev), torch.randn(B, H, device=dev)
+    z, y1 = torch.empty(B, width, device=dev), torch.empty(B, H, device=dev)
+    gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
+
+    def fwd():
+        _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1),
+                                                 H, 1, _lib.ptr(z), width, _lib.ptr(y1), H, st), "tzr_dot_interaction_top_fwd")
+
+    def bwd():
+        _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, _lib.ptr(W1),
+                                                 width, None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, st), "tzr_dot_interaction_top_bwd")
+
+    out = {"peak": 157.3, "unit": "TFLOP/s", "bound": "mfma", "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact)"}
+    for name, fn, flop in (("forward", fwd, B * (2.0 * width * H + 2.0 * P * D)),
+                           ("backward", bwd, B * (2.0 * width * H + 2.0 * n * n * D))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(1e7))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a_, b_ in ev:
+            a_.record()
+            fn()
+            b_.record()
+        torch.cuda.synchronize()
+        ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)[10]
+        out[name] = {"kernel": f"tzr_ia_top_{'fwd' if name == 'forward' else 'bwd'}_kernel", "launch_ms": ms, "algorithmic_flop": flop,
+                     "achieved": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 157.3e12}
+    return out
+
+
 def pmc_traffic(args, B_local):
     """HBM bytes per step of the six embedding launches from the rocprofv3 PMC passes kept under profiles/
     (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, scripts/pmc_summary.py).  Counters cannot be read
@@ -589,6 +632,13 @@ def main():
         except Exception as e:  # e.g. not enough free HBM next to the main model
             secondary["rowwise_adagrad_batch65536"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+        # (d) the MFMA-bound kernels of the step: dot interaction fused with the first top-MLP layer, timed alone with
+        # HIP events; flops = the ALGORITHMIC ones (layer 2 x 783 x 64 per sample; pairwise products / dX = (G + G^T) X),
+        # against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+        try:
+            secondary["interaction_first_layer_mfma"] = interaction_top_rooflines(dev, B_global)
+        except Exception as e:
+            secondary["interaction_first_layer_mfma"] = {"error": repr(e)[:200]}
 
     # inside a captured graph); the kernels and inputs are the ones of the timed region
     if ebc is not None:

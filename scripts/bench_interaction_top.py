@@ -105,7 +105,7 @@ def prof():
     gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
     tab = torch.zeros(256 * 16 * 6, dtype=torch.int64, device=dev)
     L.tzr_it_prof_table(ctypes.c_void_p(tab.data_ptr()))
-    names = {"bwd": ["product", "wait1", "scatter+wait2", "x-image", "contract", "pt+stores"],
+    names = {"bwd": ["wait", "x-image", "product(first)", "contract", "pt+stores", "product(second)"],
              "fwd+z": ["wait1", "row(first)", "product", "row(second)", "wait2", "reduce"],
              "fwd": ["wait1", "row(first)", "product", "row(second)", "wait2", "reduce"]}
     for kind in ("bwd", "fwd+z", "fwd"):

@@ -296,6 +296,7 @@ inline int __all(int pred) { return __ballot(pred) == ~0ull; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }

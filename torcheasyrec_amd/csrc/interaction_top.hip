@@ -107,19 +107,28 @@ struct ItBwdArgs {
 
 // NB column blocks per wave with their W1 fragments in registers; XL: wave 0 owns one more (block 16 NB: the 49th of
 // DLRM-Criteo) whose fragment lives in LDS -- a fourth block in registers is 64 of the 128 a lane has and spills.
+//
+// The dz tile lies in LDS exactly as a GEMM would write it -- [16 samples][virtual columns], pairs first -- and the
+// contraction picks G[i][j] out of it by pair index (S = G + G^T is never materialised: one LDS write per element, no offset
+// table).  Two such tiles (when they fit: 16 nblk + 4 <= IT_ZPD) make ONE barrier per tile enough: the product of tile
+// t + G goes into the other buffer while the samples of tile t are still being contracted.
+#define IT_ZPD 884  // pitch up to which two dz tiles fit beside the X images (n <= 29)
+
 template <int NB, bool XL>
-__device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __restrict__ off, float* __restrict__ S,
-                                            float* __restrict__ PT, float* __restrict__ xs, float* __restrict__ Gs,
+__device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ Gs,
                                             float* __restrict__ Wx, int lane, int wv, int P, int npb, int nblk) {
   const int r = lane & 15, q = lane >> 4;
   const int n = a.n;
+  const int zp = 16 * nblk + 4;           // pitch of a sample's dz row
+  const bool dbl = zp <= IT_ZPD;          // two dz tiles fit
+  const int zt = IT_TS * zp;              // floats per tile
   // ---- W1 fragments (B operand: lane supplies W[k = 16 q + ks][column of (block, r)]); blocks behind the wave's last stay
   // zero.  Staged through LDS in slabs of 16 blocks x 64 rows so the global loads are coalesced runs: lanes asking for
   // their own elements straight from L2 (4 to 16 lines per load, every CU the same lines at once) took 11 - 24 us.
   float Wf[NB][IT_KS];
   {
     const float sc = a.scale ? *a.scale : 1.f;
-    float* Wl = S;  // [64 rows][256 + 1]: the slab (S is zeroed afterwards)
+    float* Wl = Z;  // [64 rows][256 + 1]: the slab
     const int c = threadIdx.x & 255, k0 = threadIdx.x >> 8;  // thread -> slab column, rows k0, k0 + 4, ...
     // (every wave walks all slabs: the loads are the workgroup's; the next slab's loads fly while this one is handed out)
     float w[16];
@@ -152,12 +161,9 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < IT_TS * IT_SS; k += IT_THREADS) S[k] = 0.f;  // diagonals and rows >= n stay zero
   }
   const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
   const int64_t G = gridDim.x;
-  const int nks = (n + 3) >> 2;
-  const bool v0 = r < n, v1 = 16 + r < n;
   int64_t t = blockIdx.x;
   if (t >= ntiles) return;
   // the g1 tile goes through LDS (one element per thread, double-buffered): every wave needs all of it as its A operand,
@@ -168,95 +174,64 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
     const float* base = a.g1 + tt * IT_TS * a.g1_stride;  // scalar
     return (tt < ntiles && tt * IT_TS + gs < a.B) ? base[goff] : 0.f;
   };
-  Gs[gs * IT_GP + gh] = g1_elem(t);
-  float gnext = g1_elem(t + G);
-  ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, t * IT_TS + wv, a.B, n, a.hd, r, q);
-  const float* ss = S + wv * IT_SS;
-  const float* pt = PT + wv * IT_PS;
-  int cur = 0;
-  __syncthreads();
-  IT_PROF_DECL;
-  it_f32x4 acc[NB], accx;
-  const bool product_first = (wv >> 2) & 1;
-  bool have = false;  // acc already holds this tile's product (computed during the previous tile by a product-first wave)
-  for (; t < ntiles; t += G, cur ^= 1) {
-    // ---- dz[:, blocks of this wave] = g1 tile . W1[:, those columns]; A operand: lane (i = r, q) reads g1[i][16 q ..
-    // 16 q + 15], k-step ks uses element 16 q + ks (the contraction order is free as long as the W1 fragment agrees)
-    // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
-    // of this one, the other half behind it: in lockstep all sixteen would sit in the LDS-latency-bound contraction at
-    // once with the MFMA pipe mostly idle, then all in the product.
-    auto product = [&](int buf) {
-  #pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = it_f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        const float* gp = Gs + buf * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
-  #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const float4 av = tzr_ld4(gp + 4 * k4);
-          const float ag[4] = {av.x, av.y, av.z, av.w};
-  #pragma unroll
-          for (int e = 0; e < 4; ++e)
-  #pragma unroll
-            for (int m = 0; m < NB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[e], Wf[m][4 * k4 + e], acc[m], 0, 0, 0);
-        }
-      }
-      accx = it_f32x4{0.f, 0.f, 0.f, 0.f};
-      if (XL && wv == 0) {
-        const float* gp = Gs + buf * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
-  #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const float4 av = tzr_ld4(gp + 4 * k4);
-          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wx[(4 * k4 + 0) * TZR_WAVE + lane], accx, 0, 0, 0);
-          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
-          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
-          accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
-        }
-      }
-    };
-    if (!have) product(cur);
-    IT_PROF_MARK(0);  // product
-    tzr_lds_barrier();  // every wave is done reading S / PT of the previous tile and this tile's g1
-    IT_PROF_MARK(1);  // wait 1
-    // accumulator reg j of lane (r, q) = dz[sample 4 q + j][column of (block, r)] -> S (both triangles) / PT
+  // dz[:, blocks of this wave] of the g1 tile in Gs[gbuf] -> dz tile zbuf.  A operand: lane (i = r, q) reads g1[i][16 q ..
+  // 16 q + 15], k-step ks uses element 16 q + ks (the contraction order is free as long as the W1 fragment agrees);
+  // accumulator reg j of lane (r, q) = dz[sample 4 q + j][column r of the block]
+  auto product = [&](int gbuf, int zbuf) {
+    const float* gp = Gs + gbuf * (IT_TS * IT_GP) + r * IT_GP + 16 * q;
+    float* zo = Z + zbuf * zt + (4 * q) * zp + r;
+    it_f32x4 acc[NB];
 #pragma unroll
-    for (int m = 0; m < NB; ++m) {
-      const int v = wv + IT_WAVES * m;
-      const int om = off[m * (IT_THREADS / 4)];
-      if (v < npb) {
-        if (om >= 0) {
+    for (int m = 0; m < NB; ++m) acc[m] = it_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            S[(4 * q + j) * IT_SS + (om & 0xFFFF)] = acc[m][j];
-            S[(4 * q + j) * IT_SS + (om >> 16)] = acc[m][j];
-          }
-        }
-      } else if (om >= 0) {
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const float4 av = tzr_ld4(gp + 4 * k4);
+      const float ag[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) PT[(4 * q + j) * IT_PS + om] = acc[m][j];
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[e], Wf[m][4 * k4 + e], acc[m], 0, 0, 0);
     }
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+      if (wv + IT_WAVES * m < nblk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zo[j * zp + 16 * (wv + IT_WAVES * m)] = acc[m][j];
+      }
     if (XL && wv == 0) {
-      const int om = off[NB * (IT_THREADS / 4)];
-      if (IT_WAVES * NB < npb) {
-        if (om >= 0) {
+      it_f32x4 accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            S[(4 * q + j) * IT_SS + (om & 0xFFFF)] = accx[j];
-            S[(4 * q + j) * IT_SS + (om >> 16)] = accx[j];
-          }
-        }
-      } else if (om >= 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) PT[(4 * q + j) * IT_PS + om] = accx[j];
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float4 av = tzr_ld4(gp + 4 * k4);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, Wx[(4 * k4 + 0) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zo[j * zp + 16 * (IT_WAVES * NB)] = accx[j];
     }
-    // the next tile's g1 element (loaded an iteration ago) into the other buffer
-    Gs[(cur ^ 1) * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
-    tzr_lds_barrier();
-    IT_PROF_MARK(2);  // scatter + wait 2
-    have = product_first && t + G < ntiles;
-    if (have) product(cur ^ 1);
-    // ---- dX = S X + pass-through of sample wv of the tile (transposed product, see interaction.hip)
+  };
+  Gs[gs * IT_GP + gh] = g1_elem(t);
+  Gs[IT_TS * IT_GP + gs * IT_GP + gh] = g1_elem(t + G);
+  ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, t * IT_TS + wv, a.B, n, a.hd, r, q);
+  __syncthreads();
+  product(0, 0);
+  // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
+  // of this one, the other half behind it: in lockstep all sixteen would sit in the LDS-latency-bound contraction at
+  // once with the MFMA pipe mostly idle, then all in the product.
+  const bool product_first = (wv >> 2) & 1;
+  const bool v0 = r < n, v1 = 16 + r < n;
+  IT_PROF_DECL;
+  int cur = 0;
+  for (; t < ntiles; t += G, cur ^= 1) {
+    tzr_lds_barrier();  // the dz tile of t is complete; every wave is done with tile t - G (its dz tile, its g1 tile)
+    IT_PROF_MARK(0);  // wait
+    const bool more = t + G < ntiles;
+    const int zcur = dbl ? cur : 0;
+    // ---- the X image of this wave's sample; then the loads of the tiles ahead take off (X rows of t + G into the registers
+    // just copied, the g1 element of t + 2 G).  Order matters: hipcc waits for a loop-carried load with s_waitcnt vmcnt(0),
+    // i.e. for EVERYTHING in flight -- nothing may be issued shortly before such a wait (profiles/r03ak).
     {
       const float4 x0 = v0 ? X.lo : tzr_zero4(), x1 = v1 ? X.hi : tzr_zero4();
       float* p0 = xs + r * (IT_D + 1) + 4 * q;
@@ -264,35 +239,49 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
       p0[0] = x0.x; p0[1] = x0.y; p0[2] = x0.z; p0[3] = x0.w;
       p1[0] = x1.x; p1[1] = x1.y; p1[2] = x1.z; p1[3] = x1.w;
     }
-    const int64_t b = t * IT_TS + wv;
-    // the next tile's X rows take off (their registers were just copied into the LDS image), and the g1 element of the
-    // tile after it.  Order matters: hipcc waits for a loop-carried load with s_waitcnt vmcnt(0), i.e. for EVERYTHING in
-    // flight -- so nothing may be issued shortly before such a wait (the g1 load used to sit in front of the barrier
-    // above: every wave then stood 2 - 4 k clocks here waiting for it, profiles/r03ak).
-    gnext = g1_elem(t + 2 * G);
-    X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + G < ntiles ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
+    const float gnext = g1_elem(t + 2 * G);
+    X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (more ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
     __builtin_amdgcn_wave_barrier();  // the X image is private to this wave
-    IT_PROF_MARK(3);  // X image (with the wait for the X rows), prefetch issue
+    IT_PROF_MARK(1);  // X image, prefetch issue
+    if (dbl && more && product_first) product(cur ^ 1, cur ^ 1);
+    IT_PROF_MARK(2);  // product (first half of the waves)
+    // ---- dX = (G + G^T) X + pass-through of sample wv of the tile (transposed product, see interaction.hip): S[k][i] is
+    // the dz element of pair (min, max) of (k, i), zero on the diagonal and beyond n
+    const float* zs = Z + zcur * zt + wv * zp;
     it_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+    const int b2n1 = 2 * n - 1;
+    int lo = lane;
+    TZR_OPAQUE(lo);  // (the pair indices below are redone per tile: hoisted out of the loop they are 14 registers, spilled)
+    const int rr = lo & 15, qq = lo >> 4;
+    // (all eight k-steps, no branch on n: one straight block lets the compiler batch the index arithmetic and the LDS
+    // reads; rows of the X image beyond n are zero and pairs beyond n read as zero)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      if (ks < nks) {
-        const int k = 4 * ks + q;
-        const float xv = xs[k * (IT_D + 1) + r];
-        const float s0 = ss[k * IT_SROW + r];
-        const float s1 = ss[k * IT_SROW + 16 + r];
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s0, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s1, d1, 0, 0, 0);
+      const int k = 4 * ks + qq;
+      const float xv = xs[k * (IT_D + 1) + rr];
+      float sv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * h + rr;
+        const int i = k < c ? k : c, j = k < c ? c : k;
+        const bool ok = i != j && j < n;
+        const int idx = (int)(__umul24((unsigned)i, (unsigned)(b2n1 - i)) >> 1) + j - i - 1;
+        const float v = zs[ok ? idx : 0];
+        sv[h] = ok ? v : 0.f;
       }
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, sv[0], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, sv[1], d1, 0, 0, 0);
     }
-    IT_PROF_MARK(4);  // contraction
+    IT_PROF_MARK(3);  // contraction
+    const int64_t b = t * IT_TS + wv;
     int rq = r * IT_D + 4 * q;
     TZR_OPAQUE(rq);  // (recomputed per tile, not hoisted and spilled)
+    const float* pt = zs + 16 * npb;
     if (b < a.B) {
+      // (b is wave-uniform: scalar row bases, the lane part from rq)
       if (v0) {
         const float4 p = tzr_ld4(pt + rq);
         const float4 v = make_float4(d0[0] + p.x, d0[1] + p.y, d0[2] + p.z, d0[3] + p.w);
-        // (b is wave-uniform: scalar row bases, the lane part from rq)
         if (a.hd && r == 0) tzr_st4(a.gdense + b * a.gdense_stride + rq, v);
         else tzr_st4(a.gsparse + b * a.gsparse_stride + (rq - IT_D * a.hd), v);
       }
@@ -302,55 +291,31 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, const int* __res
         tzr_st4(a.gsparse + b * a.gsparse_stride + (rq + IT_D * (16 - a.hd)), v);
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    IT_PROF_MARK(5);  // pass-through + stores
+    IT_PROF_MARK(4);  // pass-through + stores
+    if (!dbl) tzr_lds_barrier();  // one dz tile only: every wave must be done with it before the next product lands
+    if (more && !(dbl && product_first)) product(cur ^ 1, dbl ? cur ^ 1 : 0);
+    // the g1 tile of t + 2 G takes the buffer the product of tile t read (a tile ago: every wave is past it)
+    Gs[cur * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
+    IT_PROF_MARK(5);  // product (second half), g1 hand-over
   }
   IT_PROF_DUMP(a.prof);
 }
 
 __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_bwd_kernel(ItBwdArgs a) {
-  __shared__ float S[IT_TS * IT_SS];        // per sample of the tile: G + G^T, 32 x 33
-  __shared__ float PT[IT_TS * IT_PS];       // per sample: pass-through gradients, row-major [n][16]
+  __shared__ __attribute__((aligned(16))) float Z[2 * IT_TS * IT_ZPD];  // the dz tile(s); 2 x 16 x 884 >= 16 x 1028
   __shared__ float Xs[IT_WAVES][IT_XS];     // per wave: the X image of its sample
-  __shared__ float Gs[2 * IT_TS * IT_GP];   // the g1 tile, double-buffered
+  __shared__ __attribute__((aligned(16))) float Gs[2 * IT_TS * IT_GP];   // the g1 tile, double-buffered
   __shared__ float Wx[IT_KS * TZR_WAVE];    // W1 fragment of wave 0's extra block (it_bwd_loop<NB, true>)
-  // LDS offsets of the lane's column of block m: pair (i, j) -> S[i][j] | S[j][i] << 16; pass-through -> PT[i][r]; -1 = none
-  // (a table in LDS rather than registers: 128 per lane at four waves per SIMD)
-  __shared__ int offt[IT_BPW][IT_THREADS / 4];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));  // (scalar: per-wave bases stay in SGPRs)
-  const int r = lane & 15, q = lane >> 4;
   const int n = a.n;
   const int P = n * (n - 1) / 2;
   const int npb = (P + 15) >> 4, nblk = npb + n;
-  int* const off = &offt[0][wv * 16 + r];
-  if (q == 0) {
-#pragma unroll
-    for (int m = 0; m < IT_BPW; ++m) {
-      const int v = wv + IT_WAVES * m;
-      int om = -1;
-      if (v < npb) {
-        const int p = 16 * v + r;
-        if (p < P) {
-          int i = 0, rem = p;
-          while (rem >= n - 1 - i) {
-            rem -= n - 1 - i;
-            ++i;
-          }
-          const int j = i + 1 + rem;
-          om = (i * IT_SROW + j) | ((j * IT_SROW + i) << 16);
-        }
-      } else if (v < nblk) {
-        om = (v - npb) * IT_D + r;
-      }
-      off[m * (IT_THREADS / 4)] = om;
-    }
-  }
   // DLRM-Criteo: 49 blocks = 3 per wave and one more for wave 0 (fragment in LDS); up to 48: 3 per wave, zero-weighted;
   // more: 4 per wave in registers (spills, correct)
-  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
-  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
-  else it_bwd_loop<4, false>(a, off, S, PT, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  else it_bwd_loop<4, false>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
