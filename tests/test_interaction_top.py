@@ -149,3 +149,46 @@ def test_top_persistent_loop_over_many_tiles(dev, B, wgs):
                                              _lib.ptr(lin.weight), width, None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, stream), "bwd")
     _close(gd, dense.grad, 1e-5)
     _close(gs, sparse.grad, 1e-5)
+
+
+@pytest.mark.gpu
+def test_top_kernels_at_full_batch_match_the_unfused_ops():
+    """B = 65 536 (BASELINE config 1's global batch on one GPU), the DLRM-Criteo shape: the fused kernels against
+    tzr_dot_interaction_fwd / _bwd + torch GEMMs on the same inputs -- z bit-identical (the same fmaf chains), y1 and
+    the input gradients to 2e-6 / 1e-5 of the largest entry (another summation order of the 783-long products)."""
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    L = _lib.lib()
+    B, D, F, H = 65536, 16, 26, 64
+    torch.manual_seed(5)
+    n = F + 1
+    width = n * (n - 1) // 2 + D * n
+    dense, sparse = torch.randn(B, D, device=dev), torch.randn(B, F * D, device=dev)
+    W1, b1, g1 = torch.randn(H, width, device=dev) * 0.05, torch.randn(H, device=dev), torch.randn(B, H, device=dev)
+    st = _lib.stream_ptr(dev)
+    z_ref = torch.empty(B, width, device=dev)
+    _lib.check(L.tzr_dot_interaction_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(z_ref), width, 1, 1, st), "fwd")
+    y_ref = torch.relu(torch.addmm(b1, z_ref, W1.t()))
+    dz = g1 @ W1
+    gd_ref, gs_ref = torch.empty_like(dense), torch.empty_like(sparse)
+    _lib.check(L.tzr_dot_interaction_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(dz), width, 1, 1, _lib.ptr(gd_ref), D,
+                                         _lib.ptr(gs_ref), F * D, st), "bwd")
+    z, y1 = torch.full((B, width), float("nan"), device=dev), torch.empty(B, H, device=dev)
+    _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1), H, 1,
+                                             _lib.ptr(z), width, _lib.ptr(y1), H, st), "top_fwd")
+    gd, gs = torch.full_like(dense, float("nan")), torch.full_like(sparse, float("nan"))
+    _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, _lib.ptr(W1), width,
+                                             None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, st), "top_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(z, z_ref)
+    _close(y1, y_ref, 2e-6)
+    _close(gd, gd_ref, 1e-5)
+    _close(gs, gs_ref, 1e-5)
+    # deterministic: a second launch gives the same bits
+    y2, gs2 = torch.empty_like(y1), torch.empty_like(gs)
+    _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1), H, 1,
+                                             None, 0, _lib.ptr(y2), H, st), "top_fwd")
+    _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, _lib.ptr(W1), width,
+                                             None, _lib.ptr(gd), D, _lib.ptr(gs2), F * D, st), "top_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(gs, gs2)
