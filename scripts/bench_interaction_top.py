@@ -78,8 +78,13 @@ def main():
             print(f"B {B}: fused (it_wgs {wgs:4d})  top_fwd+z {timed(top_fwd(_lib.ptr(z))):6.1f}  top_fwd (no z) {timed(top_fwd(None)):6.1f}  "
                   f"top_bwd {timed(top_bwd):6.1f} us", flush=True)
         L.tzr_tune(b"it_wgs", 0)
+        for sg in [int(x) for x in os.environ.get("IT_STAGGER", "").split(",") if x]:
+            L.tzr_tune(b"it_stagger", sg)
+            print(f"B {B}: it_stagger {sg}: top_bwd {timed(top_bwd):6.1f} us", flush=True)
+        L.tzr_tune(b"it_stagger", 0)
         for dbg in [int(x) for x in os.environ.get("IT_DEBUG", "").split(",") if x]:
-            L.tzr_tune(b"it_debug", dbg)  # timing experiment: phases switched off (results are wrong)
+            if L.tzr_tune(b"it_debug", dbg) != 0:
+                break  # (the phase-skipping knob existed in the first versions only: profiles/r03ae)
             print(f"B {B}: it_debug {dbg}: top_fwd+z {timed(top_fwd(_lib.ptr(z))):6.1f}  top_fwd (no z) {timed(top_fwd(None)):6.1f}  "
                   f"top_bwd {timed(top_bwd):6.1f} us", flush=True)
         L.tzr_tune(b"it_debug", 0)

@@ -99,7 +99,7 @@ struct ItBwdArgs {
   const float *dense, *sparse, *g1, *W1, *scale;
   float *gdense, *gsparse;
   int64_t dense_stride, sparse_stride, g1_stride, ldw, gdense_stride, gsparse_stride, B;
-  int n, hd;
+  int n, hd, stagger;
   uint64_t* prof;
 };
 
@@ -220,7 +220,7 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
   // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
   // of this one, the other half behind it: in lockstep all sixteen would sit in the LDS-latency-bound contraction at
   // once with the MFMA pipe mostly idle, then all in the product.
-  const bool product_first = (wv >> 2) & 1;
+  const bool product_first = a.stagger == 2 ? false : (((wv >> 2) & 1) != (a.stagger == 1));
   const bool v0 = r < n, v1 = 16 + r < n;
   IT_PROF_DECL;
   int cur = 0;
@@ -566,6 +566,7 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a)
   else it_fwd_loop<IT_KB, 3>(a, Zs, Ys, tr, lane, wv, P, npb, base, rem);
 }
 
+int g_tzr_it_stagger = 0;  // tzr_tune("it_stagger"): which half of the waves runs the next product first (0 / 1), 2 = none (experiments)
 int g_tzr_it_wgs = 0;  // tzr_tune("it_wgs"): workgroups of the fused kernels (0 = one per CU)
 
 static unsigned it_grid(int64_t B) {
@@ -601,6 +602,7 @@ extern "C" int tzr_dot_interaction_top_bwd(const float* d_dense, int64_t dense_s
   a.dense = d_dense; a.sparse = d_sparse; a.g1 = d_g1; a.W1 = d_W1; a.scale = d_scale; a.gdense = d_grad_dense; a.gsparse = d_grad_sparse;
   a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.g1_stride = g1_stride; a.ldw = ldw;
   a.gdense_stride = grad_dense_stride; a.gsparse_stride = grad_sparse_stride; a.B = B; a.n = n; a.hd = hd;
+  a.stagger = g_tzr_it_stagger;
 #ifdef IT_PROF
   a.prof = g_tzr_it_prof;
 #else

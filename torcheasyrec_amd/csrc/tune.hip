@@ -14,6 +14,7 @@ extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_fwd_wgs;
 extern int g_tzr_it_wgs;
+extern int g_tzr_it_stagger;
 extern int g_tzr_mlp_mfma;
 
 extern "C" int tzr_tune(const char* name, int value) {
@@ -52,6 +53,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "mlp_mfma")) {
     g_tzr_mlp_mfma = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "it_stagger")) {
+    g_tzr_it_stagger = value;
     return TZR_OK;
   }
   if (!strcmp(name, "it_wgs")) {
