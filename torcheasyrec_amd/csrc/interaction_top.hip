@@ -375,20 +375,19 @@ __device__ __forceinline__ void it_fwd_row(const ItX X, float* __restrict__ zs, 
   }
 }
 
-// ... and the pairs of that row out to HBM (apart from it_fwd_row so that the caller can put the next prefetch between)
+// ... and the pairs of that row out to HBM (apart from it_fwd_row so that the caller can put the next prefetch between):
+// 16 bytes per lane (the row starts 4-byte aligned only: unaligned dwordx4 stores), the last P % 4 elements one by one
 __device__ __forceinline__ void it_fwd_row_pairs_out(const float* __restrict__ zs, float* __restrict__ o, int P, int lane) {
   if (o) {
-    // rounds of 64 lanes with the index clamped (a lane behind the end repeats the last pair's store) rather than a
-    // loop -- hipcc unrolls and vectorises that one, hoists its bounds out of the tile loop and spills them
+    const int n4 = P >> 2;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < 5 || TZR_WAVE * k < P) {
-        int idx = lane + TZR_WAVE * k;
-        idx = idx < P ? idx : P - 1;
-        o[idx] = zs[idx];
-      }
-      if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (four rounds in flight: registers)
+    for (int k = 0; k < 2; ++k) {  // P <= 496: at most 124 groups of four
+      int i4 = lane + TZR_WAVE * k;
+      i4 = i4 < n4 ? i4 : n4 - 1;  // (a lane behind the end repeats the last group's store)
+      if (n4 > 0) it_st4_a4(o + 4 * i4, tzr_ld4(zs + 4 * i4));
     }
+    const int rest = 4 * n4 + (lane & 3);
+    if (rest < P && lane < 4) o[rest] = zs[rest];
   }
 }
 
