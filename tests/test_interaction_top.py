@@ -192,3 +192,50 @@ def test_top_kernels_at_full_batch_match_the_unfused_ops():
                                              None, _lib.ptr(gd), D, _lib.ptr(gs2), F * D, st), "top_bwd")
     torch.cuda.synchronize()
     assert torch.equal(y1, y2) and torch.equal(gs, gs2)
+
+
+@pytest.mark.parametrize("F,with_dense", [(26, True), (27, False), (9, False)])
+def test_top_kernels_with_row_strides_and_without_a_dense_row(dev, F, with_dense):
+    """Inputs that are views into wider buffers (row strides larger than the row) and the no-dense-row form of the C
+    entry points (X = the sparse rows only)."""
+    D, H, B = 16, 64, 70
+    torch.manual_seed(F)
+    L = _lib.lib()
+    n = F + (1 if with_dense else 0)
+    width = n * (n - 1) // 2 + D * n
+    dbuf = torch.randn(B, D + 8, device=dev)
+    sbuf = torch.randn(B, F * D + 12, device=dev)
+    gbuf = torch.randn(B, H + 4, device=dev)
+    dense = dbuf[:, :D].detach().clone().requires_grad_(True) if with_dense else None
+    sparse = sbuf[:, :F * D].detach().clone().requires_grad_(True)
+    g1 = gbuf[:, :H]
+    W1buf = torch.randn(H, width + 5, device=dev) * 0.1
+    W1 = W1buf[:, :width]  # ldw > width
+    b1 = torch.randn(H, device=dev)
+    X = sparse.view(B, F, D) if not with_dense else torch.cat([dense.unsqueeze(1), sparse.view(B, F, D)], dim=1)
+    iu = torch.triu_indices(n, n, offset=1, device=X.device)
+    z_ref = torch.cat([torch.bmm(X, X.transpose(1, 2))[:, iu[0], iu[1]]] + ([dense] if with_dense else []) + [sparse], dim=1)
+    pre = z_ref @ W1.t() + b1
+    (pre * g1).sum().backward()
+    st = _lib.stream_ptr(sparse.device)
+    dptr, dstride = (_lib.ptr(dbuf), D + 8) if with_dense else (None, 0)
+    zbuf = torch.full((B, width + 3), float("nan"), device=dev)
+    ybuf = torch.empty(B, H + 2, device=dev)
+    _lib.check(L.tzr_dot_interaction_top_fwd(dptr, dstride, _lib.ptr(sbuf), F * D + 12, F, D, B, _lib.ptr(W1buf), width + 5, _lib.ptr(b1), H,
+                                             0, _lib.ptr(zbuf), width + 3, _lib.ptr(ybuf), H + 2, st), "fwd")
+    with torch.no_grad():
+        dbuf_ok = not with_dense or torch.equal(dbuf[:, :D], dense)
+    assert dbuf_ok
+    _close(ybuf[:, :H], pre.detach(), 2e-6)
+    _close(zbuf[:, :width], z_ref.detach(), 1e-6)
+    assert torch.isnan(zbuf[:, width:]).all()
+    gdb = torch.full((B, D + 8), float("nan"), device=dev)
+    gsb = torch.full((B, F * D + 12), float("nan"), device=dev)
+    _lib.check(L.tzr_dot_interaction_top_bwd(dptr, dstride, _lib.ptr(sbuf), F * D + 12, F, D, B, _lib.ptr(gbuf), H + 4, H, _lib.ptr(W1buf),
+                                             width + 5, None, _lib.ptr(gdb) if with_dense else None, D + 8, _lib.ptr(gsb), F * D + 12, st),
+               "bwd")
+    _close(gsb[:, :F * D], sparse.grad, 1e-5)
+    assert torch.isnan(gsb[:, F * D:]).all()
+    if with_dense:
+        _close(gdb[:, :D], dense.grad, 1e-5)
+        assert torch.isnan(gdb[:, D:]).all()
