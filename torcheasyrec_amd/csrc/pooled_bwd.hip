@@ -725,6 +725,25 @@ __device__ __forceinline__ uint32_t bwd_sample_mode(const uint2* __restrict__ sr
   return (uint32_t)__shfl((int)sk, TZR_WAVE - 1 - (int)(best & 63u), TZR_WAVE);
 }
 
+// A tile workgroup of a heavy bucket has to look at the WHOLE bucket once (counts ahead of its tile, totals).  Walked
+// tile by tile by the whole workgroup that is a chain of one L2 round trip per tile -- 43 of them for the 43-tile bucket a
+// clipped Zipf tail makes (70 us: the sort launch of a skewed batch, profiles/r03bg).  Here every WAVE takes whole
+// segments of BWD_HT positions (w, w + 4, ...) with the sixteen key loads of a lane in flight together: a quarter of the
+// round trips, each four times as wide.  f(seg, valid, key) is called for the sixteen elements of a lane in position
+// order; `seg` is wave-uniform.
+#define BWD_SEGL (BWD_HT / TZR_WAVE)
+template <class F>
+__device__ __forceinline__ void bwd_walk_segments(const uint2* __restrict__ src, int n, int wv, int lane, F&& f) {
+  for (int seg = wv; seg * BWD_HT < n; seg += BWD_WAVES) {
+    const int base = seg * BWD_HT + lane;
+    uint32_t k[BWD_SEGL];
+#pragma unroll
+    for (int j = 0; j < BWD_SEGL; ++j) k[j] = base + j * TZR_WAVE < n ? src[base + j * TZR_WAVE].x : 0u;
+#pragma unroll
+    for (int j = 0; j < BWD_SEGL; ++j) f(seg, j, base + j * TZR_WAVE < n, k[j]);
+  }
+}
+
 __device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__ tables,
                                                     const BwdPlan& P, BwdSortLds& S,
                                                     const BwdHeavy& H) {
@@ -743,37 +762,29 @@ __device__ __forceinline__ void bwd_sort_heavy_tile(const TzrTable* __restrict__
   const uint2* __restrict__ src = P.ks[1] + H.start;
   uint2* __restrict__ dst = P.ks[0] + H.start;
   const int t0 = H.tile * BWD_HT;
-  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] = 0;
+  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] = S.pre[i] = 0;
   __syncthreads();
-  // counts of the whole bucket per row id; the counts when the walk reaches this tile = its prefix
+  // counts of the bucket per row id: S.pre collects the segments ahead of this tile, S.gstart the others (added below)
   constexpr int kRounds = BWD_HT / BWD_THREADS;
   // (a heavy bucket usually is heavy because of ONE row: its lookups are counted with a ballot into
   // a wave register, the others -- few per wave, on different counters -- with one LDS atomic each)
   const uint32_t hot = bwd_sample_mode(src, n, lane);
-  uint32_t hot_run = 0;
-  for (int base = 0; base < n; base += BWD_HT) {
-    if (base == t0) {
-      if (lane == 0 && hot_run) atomicAdd(&S.gstart[hot - klo], hot_run);
-      hot_run = 0;
-      __syncthreads();
-      for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.pre[i] = S.gstart[i];
-      __syncthreads();
-    }
-    uint32_t k8[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
-      k8[r] = i < n ? src[i].x : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
-      const bool v = i < n;
-      hot_run += (uint32_t)__popcll(__ballot(v && k8[r] == hot));
-      if (v && k8[r] != hot) atomicAdd(&S.gstart[k8[r] - klo], 1u);
+  {
+    const int tseg = t0 / BWD_HT;
+    uint32_t hot_pre = 0, hot_post = 0;
+    bwd_walk_segments(src, n, wv, lane, [&](int seg, int, bool v, uint32_t k) {
+      const bool before = seg < tseg;  // wave-uniform
+      const uint32_t c = (uint32_t)__popcll(__ballot(v && k == hot));
+      if (before) hot_pre += c; else hot_post += c;
+      if (v && k != hot) atomicAdd(before ? &S.pre[k - klo] : &S.gstart[k - klo], 1u);
+    });
+    if (lane == 0) {
+      if (hot_pre) atomicAdd(&S.pre[hot - klo], hot_pre);
+      if (hot_post) atomicAdd(&S.gstart[hot - klo], hot_post);
     }
   }
-  if (lane == 0 && hot_run) atomicAdd(&S.gstart[hot - klo], hot_run);
+  __syncthreads();
+  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.gstart[i] += S.pre[i];
   __syncthreads();
   bwd_block_scan(S.gstart, BWD_NB, S.wtot);
   const int nt = min(BWD_HT, n - t0);
@@ -937,20 +948,24 @@ __device__ __forceinline__ void bwd_sort_heavy_hot(const TzrTable* __restrict__ 
   const uint32_t hot = bwd_sample_mode(src, n, lane);
   // 2. one walk: lookups below / equal to the candidate, in the whole bucket and ahead of this tile
   uint32_t lt_tot = 0, eq_tot = 0, eq_pre = 0;
-  for (int base = 0; base < n; base += BWD_HT) {
-    if (base == t0) eq_pre = eq_tot;
-    uint32_t k4[kRounds];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
-      k4[r] = i < n ? src[i].x : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int i = base + r * BWD_THREADS + (int)threadIdx.x;
-      lt_tot += (uint32_t)__popcll(__ballot(i < n && k4[r] < hot));
-      eq_tot += (uint32_t)__popcll(__ballot(i < n && k4[r] == hot));
-    }
+  const int nseg = (n + BWD_HT - 1) / BWD_HT;
+  const bool seg_lists = H.tile == 0 && nseg < BWD_NB;  // tile 0 also notes the cold lookups of every segment (step 3)
+  {
+    const int tseg = t0 / BWD_HT;
+    uint32_t eq_seg = 0;
+    int cur_seg = -1;
+    bwd_walk_segments(src, n, wv, lane, [&](int seg, int j, bool v, uint32_t k) {
+      if (seg != cur_seg) {  // (wave-uniform: a new segment of this wave)
+        cur_seg = seg;
+        eq_seg = 0;
+      }
+      lt_tot += (uint32_t)__popcll(__ballot(v && k < hot));
+      const uint32_t c = (uint32_t)__popcll(__ballot(v && k == hot));
+      eq_tot += c;
+      eq_seg += c;
+      if (seg < tseg) eq_pre += c;
+      if (seg_lists && j == BWD_SEGL - 1 && lane == 0) S.pre[seg] = (uint32_t)min(BWD_HT, n - seg * BWD_HT) - eq_seg;
+    });
   }
   if (lane == 0) {  // wave-level partial counts (a tile's lookups are dealt over the four waves)
     S.gstart[wv] = lt_tot;
@@ -1006,47 +1021,72 @@ __device__ __forceinline__ void bwd_sort_heavy_hot(const TzrTable* __restrict__ 
   }
   if (H.tile != 0 || n_cold == 0) return;
   // 3. the cold lookups of the whole bucket: ordered gather into LDS, stable sort, write
-  uint32_t gathered = 0;  // cold lookups in the tiles walked so far (workgroup-uniform)
-  for (int base = 0; base < n; base += BWD_HT) {
-    const int nt = min(BWD_HT, n - base);
-    const int pw = bwd_wave_span(nt);
-    const int rounds = pw / TZR_WAVE;
-    uint32_t kc[kRounds], sc[kRounds], cpos[kRounds];
-    uint32_t cmask = 0, run = 0;
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-      const int lp = wv * pw + r * TZR_WAVE + lane;
-      bool cold = false;
-      kc[r] = sc[r] = cpos[r] = 0;
-      if (r < rounds && lp < nt) {
-        const uint2 v = src[base + lp];
-        kc[r] = v.x;
-        sc[r] = v.y;
-        cold = v.x != hot;
-      }
-      if (r < rounds) {
-        const unsigned long long cm = __ballot(cold);
-        cpos[r] = run + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-        run += (uint32_t)__popcll(cm);
-        if (cold) cmask |= 1u << r;
-      }
-    }
-    if (lane == 0) S.wtot[wv] = run;
+  if (seg_lists) {
+    // S.pre[seg] = cold lookups of segment seg (noted by the walk above) -> their offsets; then every wave places the
+    // cold lookups of its segments: position order = segment, round, lane.  No workgroup barrier per tile.
+    for (int i = nseg + (int)threadIdx.x; i < BWD_NB; i += BWD_THREADS) S.pre[i] = 0;
     __syncthreads();
-    uint32_t ahead = gathered, tile_cold = 0;
-#pragma unroll
-    for (int w = 0; w < BWD_WAVES; ++w) {
-      if (w < wv) ahead += S.wtot[w];
-      tile_cold += S.wtot[w];
-    }
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r)
-      if ((cmask >> r) & 1u) {
-        S.pk[ahead + cpos[r]] = kc[r];
-        S.ps[ahead + cpos[r]] = sc[r];
+    bwd_block_scan(S.pre, BWD_NB - 1, S.wtot);  // (the scan stores the total behind its last element: S.pre[BWD_NB - 1])
+    uint32_t run = 0;
+    int cur_seg = -1;
+    bwd_walk_segments(src, n, wv, lane, [&](int seg, int j, bool v, uint32_t k) {
+      if (seg != cur_seg) {
+        cur_seg = seg;
+        run = S.pre[seg];
       }
-    gathered += tile_cold;
+      const bool cold = v && k != hot;
+      const unsigned long long cm = __ballot(cold);
+      if (cold) {
+        const uint32_t pos = run + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+        S.pk[pos] = k;
+        S.ps[pos] = src[seg * BWD_HT + j * TZR_WAVE + lane].y;
+      }
+      run += (uint32_t)__popcll(cm);
+    });
     __syncthreads();
+  } else {
+    uint32_t gathered = 0;  // cold lookups in the tiles walked so far (workgroup-uniform)
+    for (int base = 0; base < n; base += BWD_HT) {
+      const int nt = min(BWD_HT, n - base);
+      const int pw = bwd_wave_span(nt);
+      const int rounds = pw / TZR_WAVE;
+      uint32_t kc[kRounds], sc[kRounds], cpos[kRounds];
+      uint32_t cmask = 0, run = 0;
+  #pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+        const int lp = wv * pw + r * TZR_WAVE + lane;
+        bool cold = false;
+        kc[r] = sc[r] = cpos[r] = 0;
+        if (r < rounds && lp < nt) {
+          const uint2 v = src[base + lp];
+          kc[r] = v.x;
+          sc[r] = v.y;
+          cold = v.x != hot;
+        }
+        if (r < rounds) {
+          const unsigned long long cm = __ballot(cold);
+          cpos[r] = run + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+          run += (uint32_t)__popcll(cm);
+          if (cold) cmask |= 1u << r;
+        }
+      }
+      if (lane == 0) S.wtot[wv] = run;
+      __syncthreads();
+      uint32_t ahead = gathered, tile_cold = 0;
+  #pragma unroll
+      for (int w = 0; w < BWD_WAVES; ++w) {
+        if (w < wv) ahead += S.wtot[w];
+        tile_cold += S.wtot[w];
+      }
+  #pragma unroll
+      for (int r = 0; r < kRounds; ++r)
+        if ((cmask >> r) & 1u) {
+          S.pk[ahead + cpos[r]] = kc[r];
+          S.ps[ahead + cpos[r]] = sc[r];
+        }
+      gathered += tile_cold;
+      __syncthreads();
+    }
   }
   {
     constexpr int cRounds = BWD_UMAX / BWD_THREADS;
