@@ -50,6 +50,24 @@ from .sparse import KeyedJaggedTensor
 _CAPTURE_MODE = "thread_local"
 
 
+def _quiesce_process_group(device) -> None:
+    """Call right before opening a hipGraph capture next to an RCCL process group.  The group's watchdog thread polls the
+    completion event of every collective it still lists (every ~100 ms, `hipEventQuery`); on this ROCm stack such a query
+    fails with hipErrorCapturedEvent while a capture is open in the process -- the watchdog throws, the process aborts
+    (1 run in 4 - 6 of the step-graph tests in round 3, `profiles/r03bk`: always within the first capture).  After a device
+    synchronize every listed collective has completed; a few watchdog periods later the list is empty and there is
+    nothing left to poll during the capture.  Captures happen once per batch shape / pipeline slot: the wait is paid a
+    handful of times per run."""
+    import time
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    torch.cuda.synchronize(device)
+    time.sleep(0.35)
+
+
 class _Segment:
     """Static buffers + captured graph of the dense segment for one batch size."""
 
@@ -133,6 +151,7 @@ class ShardedTrainStep:
                                    "non-default stream (torch.cuda.set_stream)")
             seg.loss = seg.logits = seg.grads = None
             g = torch.cuda.CUDAGraph()
+            _quiesce_process_group(self.device)
             with torch.cuda.graph(g, stream=cur, capture_error_mode=_CAPTURE_MODE):
                 seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
             seg.graph = g
@@ -204,10 +223,12 @@ class ShardedTrainStep:
                 ebc.cap_segments(st)
             else:
                 g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                _quiesce_process_group(self.device)
                 with torch.cuda.graph(g0, stream=self._side, capture_error_mode=_CAPTURE_MODE):
                     ebc.cap_bucketize(st)
                 g0.replay()
                 ebc.cap_exchange(st)
+                _quiesce_process_group(self.device)
                 with torch.cuda.graph(g1, stream=self._side, capture_error_mode=_CAPTURE_MODE):
                     ebc.cap_segments(st)
                     if self.plan_ahead:
@@ -348,6 +369,7 @@ class ShardedTrainStep:
         for i, (seg, coll) in enumerate(zip(segs, colls)):
             if capture:
                 g = torch.cuda.CUDAGraph()
+                _quiesce_process_group(self.device)
                 with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device), capture_error_mode=_CAPTURE_MODE):
                     seg(st, sl)
                 graphs.append(g)
