@@ -373,6 +373,7 @@ PLAN_CASES = {
     "hot_two_in_bucket": (200000, 1800, _hot(0.6, [5000, 5001, 5003]), True),  # wide heavy bucket with 3 hot rows
     "hot_multi_tile": (1 << 20, 2000, _hot(0.75, [777777]), True), # wide heavy bucket of ~2500 = 3 hot-row tiles
     "hot_many_tiles": (1 << 20, 40000, _hot(0.5, [777777, 12]), True),  # two heavy buckets of ~10000
+    "many_chunks": (70000, 70000, None, True),                     # 273 chunks per table: the scan launch works in 3 slices
     "narrow_dense": (1 << 22, 3000, _narrow(123456, 3000), True), # one wide bucket, ~1900 distinct rows: LSD fallback
     "narrow_fallback": (1 << 20, 1700, _narrow(123456, 1600), True),  # the same at emulator size
     "narrow_two_buckets": (1 << 22, 1400, _narrow(8192 * 3 - 300, 700), True),  # straddles a bucket boundary
@@ -403,7 +404,7 @@ def _plan_shape_case(dev, case, ch=0):
 
     spec = [("t_a", rows, 16 if rows < (1 << 20) else 4, "sum", ["c0"]), ("t_small", 40, 16, "sum", ["c1"])]
     # hot rows sum thousands of random-sign gradients: order-of-summation noise as in test_backward_long_runs
-    rtol = 5e-4 if case.startswith(("hot", "zipf")) else 2e-5
+    rtol = 5e-4 if case.startswith(("hot", "zipf", "many")) else 2e-5  # (many_chunks: 1 750 gradients per row of the 40-row table)
     _run_backward_case(dev, spec, ["c0", "c1"], [rows, 40], B, "uniform1", False, opt, steps=1, rtol=rtol,
                        idgen=(lambda rng, r, n: idgen(rng, r, n) if (idgen and r == rows) else rng.integers(0, r, size=n)))
 

@@ -72,6 +72,10 @@ struct BwdPlan {  // pointers into the caller workspace
   float* clead;            // [max_chunks * max_dim]
   float* ctrail;           // [max_chunks * max_dim]
   BwdChunkDesc* cdesc;     // [max_chunks]
+  uint32_t* stot;          // [T * nslices * BWD_NB] scan slices: bucket counts of a slice of a table's chunks, then
+                           //     (in place) the slice's base = counts of the slices before it (only when nslices > 1)
+  uint32_t* scnt;          // [T] slices of the table that have arrived (zeroed by the hist launch)
+  int32_t nslices;         // workgroups per table of the scan launch
   int64_t max_chunks;
   int64_t max_heavy;
   int32_t ch;  // positions per chunk (multiple of 256, <= BWD_CH)
@@ -89,6 +93,17 @@ static inline int bwd_pick_ch(int64_t N) {
   return BWD_CH;
 }
 static inline int64_t bwd_max_chunks(int64_t N, int T, int ch) { return N / ch + T + 1; }
+// One workgroup per table walks that table's chunks in the scan launch (per bucket: a prefix over the chunks, 4 KB of
+// counters per chunk, read and written, through a single CU): 1 628 chunks of 256 lookups -- the one item table of the
+// sequence path, 417 k ids -- made that launch 128 us (profiles/r03bp).  When the average table has more than 128 chunks
+// the walk is cut into slices of ~128 chunks, a workgroup each; the last to arrive finishes the table.
+#define BWD_MAXSL 16
+static inline int bwd_pick_slices(int64_t N, int T, int ch) {
+  const int64_t avg = N / ((int64_t)(T > 0 ? T : 1) * ch);
+  if (avg <= 128) return 1;
+  const int64_t s = (avg + 127) / 128;
+  return (int)(s > BWD_MAXSL ? BWD_MAXSL : s);
+}
 
 // NV = ids in the KJT values array; N = capacity of the table-major position space (sum over
 // lookups of their key length: a key read through two tables is sorted twice).
@@ -121,6 +136,9 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.clead = c.take<float>((size_t)q.max_chunks * max_dim);
   q.ctrail = c.take<float>((size_t)q.max_chunks * max_dim);
   q.cdesc = c.take<BwdChunkDesc>(q.max_chunks);
+  q.nslices = bwd_pick_slices(N, T, q.ch);
+  q.stot = c.take<uint32_t>(q.nslices > 1 ? (size_t)T * q.nslices * BWD_NB : 1);
+  q.scnt = c.take<uint32_t>(T > 0 ? T : 1);
   if (p) *p = q;
   return c.off;
 }

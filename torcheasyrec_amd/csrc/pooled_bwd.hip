@@ -141,6 +141,8 @@ __device__ __forceinline__ void bwd_geometry(const TzrTable* __restrict__ tables
 // workspace (serial prefixes), the hist workgroups read it from there.
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     const TzrTable* __restrict__ tables, int T, BwdSrcArgs A, int F, BwdPlan P) {
+  if (P.nslices > 1)
+    for (int o = threadIdx.x; o < T; o += BWD_THREADS) P.scnt[o] = 0;  // arrivals of the scan launch's slices
   for (int f = threadIdx.x; f < F; f += BWD_THREADS) {
     const TzrFeature ft = A.feats[f];
     const int64_t key = ft.key;
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
     G.fkey = GL.fkey;
     G.tchunk = reinterpret_cast<const int32_t*>(GL.tchunk);
     if (blockIdx.x == 0) {  // the later kernels of the plan and the apply read it from the workspace
+      if (P.nslices > 1)
+        for (int o = threadIdx.x; o < T; o += BWD_THREADS) P.scnt[o] = 0;  // arrivals of the scan launch's slices
       for (int o = threadIdx.x; o <= F; o += BWD_THREADS) P.feat_start[o] = GL.fstart[o];
       for (int o = threadIdx.x; o < F; o += BWD_THREADS) P.feat_key[o] = GL.fkey[o];
       for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
@@ -290,26 +294,50 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
 __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __restrict__ tables,
                                                               int T, int one_wg_heavy, BwdPlan P) {
   __shared__ unsigned tot[BWD_NB];
-  const int t = blockIdx.x;
+  __shared__ int s_last;
+  const int nsl = P.nslices;
+  const int t = nsl > 1 ? (int)blockIdx.x / nsl : (int)blockIdx.x;
+  const int sl = nsl > 1 ? (int)blockIdx.x % nsl : 0;
   const int c0 = P.tab_chunk[t];
   const int C = P.tab_chunk[t + 1] - c0;
-  if (C <= 0) return;
+  if (C <= 0 && nsl == 1) return;
   const TzrTable tb = tables[t];
   const uint32_t ts = P.feat_start[tb.first_order];
   const uint32_t te = P.feat_start[tb.first_order + tb.n_feats];
   const bool exact = tb.rows <= BWD_NB;
   const int bin = threadIdx.x;
+  // this workgroup's slice of the table's chunks (all of them when the launch has one workgroup per table)
+  const int SL = (C + nsl - 1) / nsl;
+  const int cs = min(C, sl * SL), ce = min(C, cs + SL);
   unsigned run = 0;
-  for (int cb = 0; cb < C; cb += BWD_SCAN_BATCH) {
+  for (int cb = cs; cb < ce; cb += BWD_SCAN_BATCH) {
     unsigned v[BWD_SCAN_BATCH];
 #pragma unroll
     for (int j = 0; j < BWD_SCAN_BATCH; ++j)
-      v[j] = (cb + j < C) ? P.hist[(size_t)(c0 + cb + j) * BWD_NB + bin] : 0u;
+      v[j] = (cb + j < ce) ? P.hist[(size_t)(c0 + cb + j) * BWD_NB + bin] : 0u;
 #pragma unroll
     for (int j = 0; j < BWD_SCAN_BATCH; ++j) {
-      if (cb + j < C) P.hist[(size_t)(c0 + cb + j) * BWD_NB + bin] = run;
+      if (cb + j < ce) P.hist[(size_t)(c0 + cb + j) * BWD_NB + bin] = run;
       run += v[j];
     }
+  }
+  if (nsl > 1) {
+    // the slice's bucket counts go out write-through; the workgroup that completes the table's arrivals turns them
+    // into slice bases (the scatter launch adds them to the chunk-exclusive counts) and finishes the table
+    uint32_t* st = P.stot + ((size_t)t * nsl) * BWD_NB;
+    tzr_publish_u32(st + (size_t)sl * BWD_NB + bin, run);
+    tzr_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = tzr_arrive(P.scnt + t) == (uint32_t)(nsl - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    run = 0;
+    for (int s2 = 0; s2 < nsl; ++s2) {
+      const uint32_t v = tzr_consume_u32(st + (size_t)s2 * BWD_NB + bin);
+      st[(size_t)s2 * BWD_NB + bin] = run;
+      run += v;
+    }
+    if (C <= 0) return;
   }
   tot[bin] = run;
   __syncthreads();
@@ -414,7 +442,14 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
   const int wv = threadIdx.x / TZR_WAVE;
   const unsigned* hrow = P.hist + (size_t)blockIdx.x * BWD_NB;
   const unsigned* bb = P.binbase + (size_t)t * (BWD_NB + 1);
-  for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) base0[i] = bb[i] + hrow[i];
+  if (P.nslices > 1) {  // the scan launch worked in slices of the table's chunks: + the counts of the slices before this one
+    const int c0 = P.tab_chunk[t], C = P.tab_chunk[t + 1] - c0;
+    const int SL = (C + P.nslices - 1) / P.nslices;
+    const unsigned* sb = P.stot + ((size_t)t * P.nslices + ((int)blockIdx.x - c0) / SL) * BWD_NB;
+    for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) base0[i] = bb[i] + hrow[i] + sb[i];
+  } else {
+    for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) base0[i] = bb[i] + hrow[i];
+  }
   BwdGeo G;
   G.fstart = P.feat_start;
   G.fkey = P.feat_key;
@@ -1191,7 +1226,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
     hipLaunchKernelGGL(tzr_bwd_hist_kernel<true>, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                        n_tables, n_feats, A, P);
   }
-  hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables), dim3(BWD_NB), 0, s, d_tables, n_tables,
+  hipLaunchKernelGGL(tzr_bwd_scan_kernel, dim3(n_tables * P.nslices), dim3(BWD_NB), 0, s, d_tables, n_tables,
                      g_tzr_bwd_one_wg_heavy, P);
   hipLaunchKernelGGL(tzr_bwd_scatter_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables,
                      n_tables, A, P);
