@@ -546,6 +546,7 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   bwd_force_prep      1: geometry prologue as its own launch (the > 1024 features path)
  *   ia_bwd_plain        1: the D = 16 dot-interaction backward without its software pipeline (A/B switch)
  *   ia_bwd_wgs          workgroups of that backward (0 = by batch size)
+ *   ia_gen_wgs          workgroups of the generalised MFMA backward (D != 16 or 33-64 rows; 0 = the resident set)
  *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
  *   mlp_mfma            -1: tzr_mlp2_* / tzr_mlp_tail use their general LDS-tiled kernels for every shape (0: the MFMA
  *                       kernels of mlp_mfma.hip where the shape is DLRM-Criteo's)

@@ -160,3 +160,66 @@ def test_fm(dev, B, F, D):
     out.backward(go.to(dev))
     ref.backward(go)
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("F,D,B,wgs", [(39, 16, 7, 0), (47, 24, 9, 1), (63, 32, 5, 2), (63, 32, 9, 1), (48, 8, 3, 0), (20, 40, 11, 2), (8, 128, 5, 1), (15, 24, 9, 2), (1, 8, 6, 0)])
+def test_fused_dlrm_interaction_persistent_rows(dev, F, D, B, wgs):
+    """The generalised MFMA backward (D != 16 or 33-64 rows) behind the DLRM concatenation: batched pair-gradient
+    loads, pass-through gradients, the next sample's loads in flight (49-64 rows), and a grid smaller than the
+    batch (tzr_tune "ia_gen_wgs": one or two workgroups walk every sample)."""
+    from torcheasyrec_amd import _lib
+
+    _lib.lib().tzr_tune(b"ia_gen_wgs", wgs)
+    try:
+        for cat_dense, cat_sparse in ((True, True), (False, True), (False, False)):
+            g = torch.Generator().manual_seed(F + D)
+            dense = torch.randn(B, D, generator=g)
+            sparse = torch.randn(B, F * D, generator=g)
+            dd = dense.clone().to(dev).requires_grad_(True)
+            sd = sparse.clone().to(dev).requires_grad_(True)
+            out = dot_interaction(dd, sd, D, cat_dense, cat_sparse)
+            dr = dense.clone().requires_grad_(True)
+            sr = sparse.clone().requires_grad_(True)
+            parts = [orc.dot_interaction(torch.cat([dr.unsqueeze(1), sr.reshape(B, F, D)], dim=1))]
+            if cat_dense:
+                parts.append(dr)
+            if cat_sparse:
+                parts.append(sr)
+            ref = torch.cat(parts, dim=-1)
+            go = torch.randn(ref.shape, generator=g)
+            out.backward(go.to(dev))
+            ref.backward(go)
+            torch.testing.assert_close(dd.grad.cpu(), dr.grad, rtol=RTOL, atol=4 * ATOL)
+            torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=RTOL, atol=4 * ATOL)
+    finally:
+        _lib.lib().tzr_tune(b"ia_gen_wgs", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,D", [(39, 16), (63, 32), (26, 32), (8, 128)])
+def test_persistent_backward_walks_a_large_batch(F, D):
+    """B = 9 001 on the chip: the resident grid of the generalised backward (768 / 1 024 workgroups) takes two to five
+    samples per wave, the last round is partial, and (49-64 rows) the next sample's loads are in flight across the
+    stores.  Against torch autograd in fp64 on the same inputs, 1e-5 of the largest entry; a second launch is bit-identical."""
+    from torcheasyrec_amd import _lib
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    B = 9001
+    g = torch.Generator(device="cpu").manual_seed(F * 7 + D)
+    dense = torch.randn(B, D, generator=g).to(dev).requires_grad_(True)
+    sparse = torch.randn(B, F * D, generator=g).to(dev).requires_grad_(True)
+    out = dot_interaction(dense, sparse, D, True, True)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gd, gs = torch.autograd.grad(out, (dense, sparse), go, retain_graph=True)
+    gd2, gs2 = torch.autograd.grad(out, (dense, sparse), go)
+    assert torch.equal(gd, gd2) and torch.equal(gs, gs2)
+    d64 = dense.detach().double().requires_grad_(True)
+    s64 = sparse.detach().double().requires_grad_(True)
+    x = torch.cat([d64.unsqueeze(1), s64.reshape(B, F, D)], dim=1)
+    iu = torch.triu_indices(F + 1, F + 1, 1, device=dev)
+    ref = torch.cat([torch.bmm(x, x.transpose(1, 2))[:, iu[0], iu[1]], d64, s64], dim=1)
+    torch.testing.assert_close(out.detach().double(), ref.detach(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    rd, rs = torch.autograd.grad(ref, (d64, s64), go.double())
+    torch.testing.assert_close(gd.double(), rd, rtol=1e-5, atol=1e-5 * float(rd.abs().max()))
+    torch.testing.assert_close(gs.double(), rs, rtol=1e-5, atol=1e-5 * float(rs.abs().max()))

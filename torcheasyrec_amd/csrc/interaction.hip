@@ -547,9 +547,9 @@ __global__ __launch_bounds__(IA_THREADS) void tzr_dot_interaction_fwd_mfma_kerne
 // from the wave's LDS image of S = G + G^T.  The accumulator of lane (r, q) is dX[16 bi + r][cb + 4q ..
 // cb + 4q + 3]: float4 stores.
 // SCAP = floats of S per wave; the pitch is n | 1 (odd: conflict-free column reads), so up to 48 rows
-// fit a 4-wave workgroup.
-template <int NB, int WAVES, int SCAP>
-__global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 2))) void tzr_dot_interaction_bwd_mfma_kernel(
+// fit a 4-wave workgroup.  NB = 1 (up to 16 rows), 2 (32), 4 (48 in a 4-wave, 64 in a 2-wave workgroup).
+template <int NB, int WAVES, int SCAP, bool XS>
+__global__ __launch_bounds__(WAVES * TZR_WAVE, (NB <= 2 ? 4 : (WAVES == 4 ? 3 : 2))) void tzr_dot_interaction_bwd_mfma_kernel(
     const float* __restrict__ dense, int64_t dense_stride, const float* __restrict__ sparse,
     int64_t sparse_stride, int n, int hd, int D, int64_t B, const float* __restrict__ gout,
     int64_t gout_stride, int cat_dense, int cat_sparse, float* __restrict__ gdense,
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 
   const int SP = RT ? (n | 1) : MAXN + 1;
   __shared__ unsigned short ij[MAXP];  // idx -> (i << 8) | j
   const int lane = threadIdx.x & (TZR_WAVE - 1);
-  const int wv = threadIdx.x / TZR_WAVE;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / TZR_WAVE);  // scalar: sample bases stay in SGPRs
   const int r = lane & 15, q = lane >> 4;
   const int P = n * (n - 1) / 2;
   for (int idx = threadIdx.x; idx < P; idx += THREADS) {
@@ -577,33 +577,86 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 
   const int pd = P;
   const int ps = P + ((cat_dense && hd) ? D : 0);
   const int ksteps = (n + 3) >> 2;
-  for (int64_t b0 = (int64_t)blockIdx.x * WAVES; b0 < B; b0 += (int64_t)gridDim.x * WAVES) {
+  // One wave walks its samples alone (2-3 waves per SIMD at 33-64 rows), so every global round trip it
+  // waits for is exposed; the order of the memory operations is the design (profiles/r03bt, n = 64 / D = 32:
+  // 1 131 -> 523 us):
+  //  - the pair gradients arrive GB x 64 at a time: one round trip per batch, not one per value;
+  //  - every operand load of a column block is issued before its MFMA chain starts (inside the chain
+  //    each one would be a dependent round trip): the first block's ahead of the S image, the next
+  //    block's between the chain and the stores of the current one, into the registers the chain has released;
+  //  - the pass-through gradients of a block are loaded ahead of its chain, not between chain and store;
+  //  - XS: the next sample's first batch and first operands are issued ahead of this sample's last
+  //    stores.  It costs ~90 VGPRs, so it pays only where LDS, not the register file, sets the occupancy.
+  constexpr int GB = NB == 1 ? 2 : (WAVES == 4 ? 8 : 16);
+  float xa[MAXN / 4];
+  float gv[GB];
+  auto load_xa = [&](int64_t bb, int cb) {
+    const bool cin = bb < B && (cb + r < D);  // operand column of this lane
+    const float* sp = sparse + bb * sparse_stride;  // wave-uniform bases, 32-bit lane offsets
+    const float* dp = hd ? dense + bb * dense_stride : sp;
+    const int c = cb + r;
+#pragma unroll
+    for (int ks = 0; ks < MAXN / 4; ++ks) {
+      const int k = 4 * ks + q;  // contraction index = row of X / S
+      const float* p = sp + (unsigned)((k - (ks ? hd : (k ? hd : 0))) * D + c);
+      if (ks == 0 && hd && k == 0) p = dp + (unsigned)c;
+      xa[ks] = (cin && k < n) ? *p : 0.f;
+    }
+  };
+  auto load_gv = [&](int64_t bb, int base) {
+    if (bb < B) {
+      const float* gb = gout + bb * gout_stride;
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int idx = base + u * TZR_WAVE + lane;
+        gv[u] = gb[idx < P ? idx : P - 1];
+      }
+    }
+  };
+  const int64_t bstep = (int64_t)gridDim.x * WAVES;
+  if (XS) {
+    load_xa((int64_t)blockIdx.x * WAVES + wv, 0);
+    load_gv((int64_t)blockIdx.x * WAVES + wv, 0);
+  }
+  for (int64_t b0 = (int64_t)blockIdx.x * WAVES; b0 < B; b0 += bstep) {
     const int64_t b = b0 + wv;
     const bool on = b < B;
     const float* g = gout + b * gout_stride;
+    float* gsp = gsparse + b * gsparse_stride;
+    float* gdp = hd ? gdense + b * gdense_stride : gsp;
+    if (!XS) load_xa(b, 0);
     if (on) {
-      for (int idx = lane; idx < P; idx += TZR_WAVE) {
-        const float v = g[idx];
-        const int i = ij[idx] >> 8, j = ij[idx] & 255;
-        S[wv][i * SP + j] = v;
-        S[wv][j * SP + i] = v;
+      for (int base = 0; base < P; base += GB * TZR_WAVE) {
+        if (!XS || base) load_gv(b, base);
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int idx = base + u * TZR_WAVE + lane;
+          if (idx < P) {
+            const int i = ij[idx] >> 8, j = ij[idx] & 255;
+            S[wv][i * SP + j] = gv[u];
+            S[wv][j * SP + i] = gv[u];
+          }
+        }
       }
     }
     ia_wave_sync();  // S[wv] is private to this wave
     for (int cb = 0; cb < D; cb += 16) {
-      const bool cin = on && (cb + r < D);          // operand column of this lane
       const bool kin = on && (cb + 4 * q < D);      // output float4 of this lane
       f32x4 d[NB];
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) d[bi] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // every operand load of the column block is issued before the MFMA chain starts (inside the
-      // chain each one would be a dependent global-memory round trip).  Prefetching the next
-      // block as well was measured slower: the extra registers cost a wave per SIMD.
-      float xa[MAXN / 4];
+      float4 pt[NB];
 #pragma unroll
-      for (int ks = 0; ks < MAXN / 4; ++ks) {
-        const int k = 4 * ks + q;  // contraction index = row of X / S
-        xa[ks] = (cin && k < n) ? iam_row(dense, dense_stride, sparse, sparse_stride, b, k, hd, D)[cb + r] : 0.f;
+      for (int bi = 0; bi < NB; ++bi) {
+        const int row = 16 * bi + r;
+        pt[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kin && row < n) {
+          if (hd && row == 0) {
+            if (cat_dense) pt[bi] = tzr_ld4_a4(g + (unsigned)(pd + cb + 4 * q));
+          } else if (cat_sparse) {
+            pt[bi] = tzr_ld4_a4(g + (unsigned)(ps + (row - hd) * D + cb + 4 * q));
+          }
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < MAXN / 4; ++ks) {
@@ -617,20 +670,26 @@ __global__ __launch_bounds__(WAVES * TZR_WAVE, (NB == 2 ? 4 : (WAVES == 4 ? 3 : 
           }
         }
       }
+      // the chain has released xa: the next operands are requested ahead of the stores (S is rewritten
+      // only after them)
+      if (!XS && cb + 16 < D) load_xa(b, cb + 16);
+      if (XS && cb + 16 >= D) {
+        load_xa(b + bstep, 0);
+        load_gv(b + bstep, 0);
+      }
 #pragma unroll
       for (int bi = 0; bi < NB; ++bi) {
         const int row = 16 * bi + r;
         if (kin && row < n) {
-          float4 v = make_float4(d[bi][0], d[bi][1], d[bi][2], d[bi][3]);
+          const float4 v = tzr_add4(make_float4(d[bi][0], d[bi][1], d[bi][2], d[bi][3]), pt[bi]);
           if (hd && row == 0) {
-            if (cat_dense) v = tzr_add4(v, tzr_ld4_a4(g + pd + cb + 4 * q));
-            tzr_st4(gdense + b * gdense_stride + cb + 4 * q, v);
+            tzr_st4(gdp + (unsigned)(cb + 4 * q), v);
           } else {
-            if (cat_sparse) v = tzr_add4(v, tzr_ld4_a4(g + ps + (int64_t)(row - hd) * D + cb + 4 * q));
-            tzr_st4(gsparse + b * gsparse_stride + (int64_t)(row - hd) * D + cb + 4 * q, v);
+            tzr_st4(gsp + (unsigned)((row - hd) * D + cb + 4 * q), v);
           }
         }
       }
+      if (XS && cb + 16 < D) load_xa(b, cb + 16);  // (ahead of the stores it would not fit the register file)
     }
     ia_wave_sync();
   }
@@ -644,6 +703,17 @@ static unsigned iam_grid(int64_t B, int waves) {
 static bool iag_fits(int n, int D, bool bwd) {
   const int64_t need = (int64_t)n * (D + 1) + (bwd ? (int64_t)n * (n + 1) : 0);
   return need <= IAG_CAP && n <= 2048;
+}
+
+int g_tzr_ia_gen_wgs = 0;  // tzr_tune("ia_gen_wgs"): workgroups of the 2-64-row MFMA backward for D != 16 (0 = the resident set)
+
+// persistent grid: exactly the workgroups that are resident at once (256 CUs x per_cu) walk the batch --
+// the pair-index table and the zeroed S image are set up once per workgroup, and no second, partial round
+// of workgroups trails the first (profiles/r03bt: n = 40: 402 -> 285 us from the grid alone)
+static unsigned iam_bwd_grid(int64_t B, int waves, int per_cu) {
+  unsigned g = iam_grid(B, waves);
+  const unsigned cap = g_tzr_ia_gen_wgs > 0 ? (unsigned)g_tzr_ia_gen_wgs : 256u * (unsigned)per_cu;
+  return g < cap ? g : cap;
 }
 
 static unsigned iag_grid(int64_t B) { return (unsigned)(B < 1 ? 1 : (B > 16384 ? 16384 : B)); }
@@ -719,24 +789,23 @@ extern "C" int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_strid
     return TZR_ERR_INVALID;
   if (B == 0) return TZR_OK;
   if (!mfma && n <= 64) {
-    if (n <= 32)
-      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<2, 4, 32 * 33>), dim3(iam_grid(B, 4)),
-                         dim3(4 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
-                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
-                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
-                         d_grad_sparse, grad_sparse_stride);
-    else if (n <= 48)
-      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 4, 48 * 49>), dim3(iam_grid(B, 4)),
-                         dim3(4 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
-                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
-                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
-                         d_grad_sparse, grad_sparse_stride);
-    else
-      hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<4, 2, 64 * 65>), dim3(iam_grid(B, 2)),
-                         dim3(2 * TZR_WAVE), 0, static_cast<hipStream_t>(stream), d_dense,
-                         dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out,
-                         grad_out_stride, cat_dense, cat_sparse, d_grad_dense, grad_dense_stride,
-                         d_grad_sparse, grad_sparse_stride);
+#define IAB_LAUNCH(NB_, W_, SCAP_, XS_, PER_CU_)                                                               \
+  hipLaunchKernelGGL((tzr_dot_interaction_bwd_mfma_kernel<NB_, W_, SCAP_, XS_>),                                 \
+                     dim3(iam_bwd_grid(B, W_, PER_CU_)), dim3(W_ * TZR_WAVE), 0, static_cast<hipStream_t>(stream), \
+                     d_dense, dense_stride, d_sparse, sparse_stride, n, hd, D, B, d_grad_out, grad_out_stride,  \
+                     cat_dense, cat_sparse, d_grad_dense, grad_dense_stride, d_grad_sparse, grad_sparse_stride)
+    // row blocks, cross-sample prefetch and workgroups per CU as measured (profiles/r03bt): the prefetch
+    // pays only where the LDS image, not the register file, limits the occupancy (49-64 rows)
+    if (n <= 16) {
+      IAB_LAUNCH(1, 4, 16 * 17, false, 4);
+    } else if (n <= 32) {
+      IAB_LAUNCH(2, 4, 32 * 33, false, 4);
+    } else if (n <= 48) {
+      IAB_LAUNCH(4, 4, 48 * 49, false, 3);
+    } else {
+      IAB_LAUNCH(4, 2, 64 * 65, true, 4);
+    }
+#undef IAB_LAUNCH
     TZR_CHECK_LAUNCH();
     return TZR_OK;
   }

@@ -12,6 +12,7 @@ extern int g_tzr_bwd_debug;
 extern int g_tzr_bwd_apply_waves;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
+extern int g_tzr_ia_gen_wgs;
 extern int g_tzr_ia_fwd_wgs;
 extern int g_tzr_it_wgs;
 extern int g_tzr_it_stagger;
@@ -61,6 +62,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "it_wgs")) {
     g_tzr_it_wgs = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "ia_gen_wgs")) {
+    g_tzr_ia_gen_wgs = value;
     return TZR_OK;
   }
   if (!strcmp(name, "ia_bwd_wgs")) {
