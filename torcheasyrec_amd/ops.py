@@ -216,7 +216,11 @@ def _pooled_bwd(kind: int, tables, states, d_tables, d_feats, values, offsets, w
     B, N = stride, values.numel()
     F, T = d_feats.numel() // _lib.FEATURE_DT.itemsize, d_tables.numel() // _lib.TABLE_DT.itemsize
     uniform = offsets is None
-    NP = F * B if uniform else N * F  # capacity of the table-major position space
+    # capacity of the table-major position space.  Ragged bags: a key read through k tables contributes its ids k times
+    # (EmbeddingBagCollection._n_positions knows k from its lookups: N * max k); the op sees only device descriptors, so it
+    # takes the bound that holds for every sharing pattern, N * F -- F times the module's workspace when no key is shared
+    # (ADVICE round 2 suggested N: too small as soon as two tables read one key).
+    NP = F * B if uniform else N * F
     max_dim = max(int(t.shape[1]) for t in tables)
     ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, NP, F, T, B, max_dim), dev)
     rc = L.tzr_pooled_bwd_plan(_lib.ptr(d_tables), T, _lib.ptr(d_feats), F, n_keys, max_rows, max_dim, _lib.ptr(values), _lib.ptr(offsets),

@@ -598,8 +598,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
         rm, dev, W = st["rm"], self._device, self.W
         if "cap" in st and "flag_host" in st:
             # the overflow word is the same on every rank (each slice carries its sender's, the owner kernel ORs
-            # all W of them), so all ranks redo the batch together.  Under a pipeline this event was recorded a
-            # batch ago: no wait.
+            # all W of them), so all ranks redo the batch together.  This IS a host wait: ShardedTrainStep calls
+            # _end(_begin(next)) back to back, so the host blocks until the side stream has run the next batch's
+            # bucketize + ids all-to-all + flag copy.  Those were queued behind the START of the current step only
+            # and run beside it, while the host has already queued the whole current step: the wait ends long
+            # before the main stream drains -- but it is a wait, not "recorded a batch ago" (ADVICE round 2).
             if "flag_event" in st:
                 st.pop("flag_event").synchronize()
             over = int(st.pop("flag_host").item())
