@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument("--step-graph", action="store_true",
                     help="sharded runs with --exchange capacity: everything after the input dist (lookups, dense segment, "
                          "sparse + dense optimizers) replayed from three hipGraphs per pipeline slot, RCCL calls between them")
+    ap.add_argument("--overlap-collectives", choices=["auto", "on", "off"], default="auto",
+                    help="--step-graph runs: five graphs with the gradient all-to-all / all-reduces issued async between them "
+                         "(auto = on; off: three graphs, every collective waited for where it is issued)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -384,7 +387,8 @@ def main():
         from torcheasyrec_amd.sharded_step import ShardedTrainStep
 
         train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
-                                      plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph)
+                                      plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph,
+                                      overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives])
 
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:
@@ -675,7 +679,7 @@ def main():
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if graphs is not None else
-                   (("pipelined: input dist one batch ahead + three hipGraphs for the rest of the step, RCCL calls between them" if args.step_graph else
+                   ((f"pipelined: input dist one batch ahead + {'five' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them" if args.step_graph else
                      "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }
     if sharded:

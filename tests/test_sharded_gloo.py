@@ -1044,7 +1044,9 @@ def _slots_worker(rank, world, init_file, emu_path):
         batches.append((dense[sl].contiguous(), KeyedJaggedTensor(keys, v, torch.ones(len(rows) * Bl, dtype=torch.int32), uniform_length=1),
                         label[sl].contiguous()))
     runs = {}
-    for name, kw, skw in (("exact", {}, {}), ("capacity", {"exchange": "capacity", "capacity_factor": 1.3}, {"step_graph": True})):
+    cap = {"exchange": "capacity", "capacity_factor": 1.3}
+    for name, kw, skw in (("exact", {}, {}), ("capacity", cap, {"step_graph": True, "overlap_collectives": False}),
+                          ("capacity_overlap", cap, {"step_graph": True})):  # the default: the five-segment order
         torch.manual_seed(7)
         model = ShardedDLRM(criteo_tables(rows, init="seeded"), keys, NUM_DENSE, device=dev, dp_max_rows=100,
                             sparse_optimizer=SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05), **kw)
@@ -1053,7 +1055,15 @@ def _slots_worker(rank, world, init_file, emu_path):
         losses = [float(ts.step(*batches[i], next_kjt=batches[i + 1][1] if i + 1 < steps else None)) for i in range(steps)]
         runs[name] = (losses, {n: w.detach().clone() for n, w in model.ebc.table_weights().items()},
                       [p.detach().clone() for p in model.dense_parameters()], dict(model.ebc.exchange_stats), ts.graph_steps, ts.eager_steps)
-    (la, wa, da, _, _, _), (lb, wb, db, stats, n_graph, n_eager) = runs["exact"], runs["capacity"]
+    assert ts.overlap_collectives
+    for other in ("capacity", "capacity_overlap"):
+        _check_slots_run(runs["exact"], runs[other], steps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_slots_run(exact, capacity, steps):
+    (la, wa, da, _, _, _), (lb, wb, db, stats, n_graph, n_eager) = exact, capacity
     assert stats["overflow_retries"] == 1 and stats["capacity_batches"] == steps - 1, stats
     assert (n_graph, n_eager) == (steps - 1, 1)
     assert la == lb  # same kernels on the same rows in the same order: bit for bit
@@ -1061,8 +1071,6 @@ def _slots_worker(rank, world, init_file, emu_path):
         assert torch.equal(wa[n], wb[n]), n
     for a, b in zip(da, db):
         assert torch.equal(a, b)
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

@@ -195,10 +195,12 @@ def _body_sharded_zch_world1_matches_unsharded_zch():
             pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
 
 
-def _body_whole_step_graph_world1(B, graph_input_dist):
+def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
     """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
     all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
-    pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed."""
+    pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed.  `overlap`: the five-graph
+    order (collectives issued async behind the graph that feeds them, waited for in front of the one that reads them),
+    which is the default."""
     from torcheasyrec_amd import _lib
     from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.dense import FusedDenseAdam
@@ -217,7 +219,7 @@ def _body_whole_step_graph_world1(B, graph_input_dist):
             steps = 12
             batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows)) for s in range(steps)]
             out = {}
-            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True, "graph_input_dist": graph_input_dist})):
+            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True, "graph_input_dist": graph_input_dist, "overlap_collectives": overlap})):
                 torch.manual_seed(3)
                 m = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt,
                                 dp_max_rows=4096, replicate_at_world1=True, **kw)
@@ -230,8 +232,9 @@ def _body_whole_step_graph_world1(B, graph_input_dist):
                              {n: w.detach().clone() for n, w in m.ebc.table_weights().items()}, ts, m)
             ts, m = out["graph"][3], out["graph"][4]
             assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
-            assert ts.graph_steps == steps and ts.eager_steps == 0
+            assert ts.graph_steps == steps and ts.eager_steps == 0 and ts.overlap_collectives == overlap
             assert all(sl["graph"] is not None and (sl.get("in_graphs") is not None) == graph_input_dist for sl in ts._slots.values()) and len(ts._slots) == 2
+            assert all(len(sl["graph"]) == (5 if overlap else 3) for sl in ts._slots.values())
             assert torch.equal(out["exact"][0], out["graph"][0])
             for a, b in zip(out["exact"][1], out["graph"][1]):
                 assert torch.equal(a, b)
@@ -286,7 +289,7 @@ def test_sharded_zch_world1_matches_unsharded_zch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,graph_input_dist", [(2048, True), (8192, False)])
-def test_whole_step_graph_world1(B, graph_input_dist):
-    _isolated("whole_step_graph_world1", B, graph_input_dist)
+@pytest.mark.parametrize("B,graph_input_dist,overlap", [(2048, True, False), (8192, False, False), (8192, False, True)])
+def test_whole_step_graph_world1(B, graph_input_dist, overlap):
+    _isolated("whole_step_graph_world1", B, graph_input_dist, overlap)
 

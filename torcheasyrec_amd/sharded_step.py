@@ -28,7 +28,8 @@ stream, so prefetching the input dist changes no value (tests/test_sharded_gloo.
 has fixed split sizes, so everything after the input dist -- lookup with its rows all-to-all, dense segment,
 gradient all-to-all, sort + fused optimizer, dense all-reduce, Adam -- is captured as ONE hipGraph per
 pipeline slot (two slots: batch i+1 is laid out by its input dist while the graph of batch i runs) -- in
-practice three graphs with the RCCL calls issued eagerly between them (`_step_whole`).  The
+practice three graphs with the RCCL calls issued eagerly between them, five when the collectives are issued async
+so that they fly under the neighbouring graph (`_step_whole`, the default).  The
 overflow word of a batch is read on the host BEFORE its graph is launched (the input dist ran a batch
 earlier), so a batch that does not fit simply takes the eager exact path; nothing is ever undone.
 """
@@ -81,7 +82,8 @@ class ShardedTrainStep:
     def __init__(self, model: ShardedDLRM, dense_optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
                  use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2,
-                 plan_ahead: bool = True, step_graph: bool = False, graph_input_dist: bool = False) -> None:
+                 plan_ahead: bool = True, step_graph: bool = False, graph_input_dist: bool = False,
+                 overlap_collectives: Optional[bool] = None) -> None:
         self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
         self.device = model.ebc._device
         self.cuda = self.device.type == "cuda"
@@ -107,6 +109,15 @@ class ShardedTrainStep:
         self._slots: Dict[tuple, dict] = {}
         self._next_slot = 0
         self.graph_steps = self.eager_steps = 0
+        # whole-step path: five graphs instead of three, so that the gradient all-to-all flies under the replicated
+        # tables' row sums and their all-reduce (+ the dense gradients') under the owners' sort + fused optimizer --
+        # the order of issue the eager exact path has always had (`_backward_impl`).  On one rank there is nothing to
+        # hide (RCCL's self copies take 12 us), and the two extra graph launches cost nothing measurable either
+        # (0.408 vs 0.412 ms at 8 192, profiles/r03bx) -- so it is the default everywhere and the one-rank GPU tests
+        # run the order the ranks of a real job run.
+        if overlap_collectives is None:
+            overlap_collectives = True
+        self.overlap_collectives = bool(overlap_collectives)
         # (the ids all-to-all of batch i+1 is issued from the side stream on the collection's own process group, like the
         # exact exchange's: every RCCL call of the step is eager, torch orders them on the group's stream in issue order --
         # `ebc.input_dist_group` can name another communicator for it)
@@ -317,27 +328,44 @@ class ShardedTrainStep:
     #   G1  pooled gather, dense forward + backward, per-id gradient rows, replicas' row sums, dense gradients packed
     #       gradient all-to-all, all-reduce of the replicas' row sums, all-reduce of the dense gradients
     #   G2  owners' sort + fused optimizer, replicas' dense row update, dense gradients unpacked, Adam
+    # `overlap_collectives` (the default) cuts G1 behind the per-id gradient rows and G2 behind the owners'
+    # update, five graphs: G1a | gradient all-to-all issued | G1b (replicas' row sums, pack) | both all-reduces issued,
+    # all-to-all waited for | G2a (owners' sort + optimizer) | all-reduces waited for | G2b.
     def _seg0(self, st: dict, sl: dict) -> None:
         self.model.ebc.seg_owner_rows(st, [sl["sparse"].detach()])
 
-    def _seg1(self, st: dict, sl: dict) -> None:
-        from .sharding import pack_dense_grads
-
+    def _seg1a(self, st: dict, sl: dict) -> None:
         ebc = self.model.ebc
         ebc.seg_pool(st, [sl["sparse"].detach()])
         sl["loss"], sl["logits"], grads = self._dense_fwd_bwd(sl["dense"], sl["sparse"], sl["label"])
-        ebc.seg_grads(st, [grads[0]])
+        ebc.seg_grads_rw(st, [grads[0]])
         sl["grads"] = list(grads[1:])
+
+    def _seg1b(self, st: dict, sl: dict) -> None:
+        from .sharding import pack_dense_grads
+
+        self.model.ebc.seg_grads_dp(st)
         sl["flat"] = pack_dense_grads(sl["grads"])
 
-    def _seg2(self, st: dict, sl: dict) -> None:
+    def _seg1(self, st: dict, sl: dict) -> None:
+        self._seg1a(st, sl)
+        self._seg1b(st, sl)
+
+    def _seg2a(self, st: dict, sl: dict) -> None:
+        self.model.ebc.seg_apply_rw(st)
+
+    def _seg2b(self, st: dict, sl: dict) -> None:
         from .sharding import unpack_dense_grads
 
-        self.model.ebc.seg_apply(st)
+        self.model.ebc.seg_apply_dp(st)
         unpack_dense_grads(sl["flat"], sl["grads"])
         for p, g in zip(self.params, sl["grads"]):
             p.grad = g
         self.opt.step()
+
+    def _seg2(self, st: dict, sl: dict) -> None:
+        self._seg2a(st, sl)
+        self._seg2b(st, sl)
 
     def _coll0(self, st: dict, sl: dict) -> None:
         self.model.ebc.coll_rows(st)
@@ -348,6 +376,28 @@ class ShardedTrainStep:
         self.model.ebc.coll_grads(st)
         allreduce_flat_average(sl["flat"], self.model.pg)
 
+    # the overlapped order: a collective is ISSUED (async: RCCL's stream takes it from here) right behind the graph
+    # that produced its input, and WAITED FOR (the current stream, not the host) right in front of the graph that
+    # reads its output
+    def _coll1a(self, st: dict, sl: dict) -> None:
+        sl["works"] = [self.model.ebc.coll_grads_rw(st, async_op=self.cuda)]
+
+    def _coll1b(self, st: dict, sl: dict) -> None:
+        from .sharding import allreduce_flat_average
+
+        rows = sl["works"]
+        sl["works"] = [self.model.ebc.coll_grads_dp(st, async_op=self.cuda), allreduce_flat_average(sl["flat"], self.model.pg, async_op=self.cuda)]
+        self._wait(rows)
+
+    def _coll2a(self, st: dict, sl: dict) -> None:
+        self._wait(sl.pop("works"))
+
+    @staticmethod
+    def _wait(works) -> None:
+        for w in works:
+            if w is not None:
+                w.wait()
+
     def _step_whole(self, st: dict, dense, label, next_kjt, t0) -> torch.Tensor:
         sl = self._slots[st["slot_key"]]
         if sl["dense"] is None:
@@ -355,7 +405,11 @@ class ShardedTrainStep:
             sl["sparse"] = torch.zeros(dense.shape[0], st["rm"]["widths"][0], dtype=torch.float32, device=self.device, requires_grad=True)
         sl["dense"].copy_(dense, non_blocking=True)
         sl["label"].copy_(label, non_blocking=True)
-        segs, colls = (self._seg0, self._seg1, self._seg2), (self._coll0, self._coll1, None)
+        if self.overlap_collectives:
+            segs = (self._seg0, self._seg1a, self._seg1b, self._seg2a, self._seg2b)
+            colls = (self._coll0, self._coll1a, self._coll1b, self._coll2a, None)
+        else:
+            segs, colls = (self._seg0, self._seg1, self._seg2), (self._coll0, self._coll1, None)
         capture = False
         if self.use_graph and self.cuda and sl["graph"] is None:
             sl["seen"] += 1

@@ -865,6 +865,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
 
     def seg_grads(self, st: dict, grads: Sequence[torch.Tensor]) -> None:
         """requester: one gradient row per id into the message layout (-> `coll_grads`); replicas: row sums"""
+        self.seg_grads_rw(st, grads)
+        self.seg_grads_dp(st)
+
+    def seg_grads_rw(self, st: dict, grads: Sequence[torch.Tensor]) -> None:
+        """first half of `seg_grads`: the per-id gradient rows (everything the gradient all-to-all waits for)"""
         if self.fused_optimizer is None:
             return
         L, dev, D = _lib.lib(), self._device, self.dim
@@ -873,12 +878,22 @@ class ShardedEmbeddingBagCollection(nn.Module):
         B, stream = kjt.stride(), _lib.stream_ptr(dev)
         gl = [g.contiguous().float() for g in grads]
         st["_grads_alive"] = gl
-        gd = self._dst_array(gl, B, rm["widths"])
         if "rw_n" in rm:
+            gd = self._dst_array(gl, B, rm["widths"])
             st["grow"] = self._slot(st["slot"], "grow", (st["N_pad"], D), torch.float32)
             _lib.check(L.tzr_lookup_grads(_lib.ptr(rm["rw_d_feats"]), rm["rw_n"], None, None, B, 1, _lib.ptr(st["unb"]), gd, len(gl),
                                           _lib.ptr(st["grow"]), D, D, stream), "tzr_lookup_grads")
+
+    def seg_grads_dp(self, st: dict) -> None:
+        """second half: the replicated tables' exact per-row gradient sums of my samples (-> their all-reduce)"""
+        if self.fused_optimizer is None:
+            return
+        L, dev, D = _lib.lib(), self._device, self.dim
+        kjt, rm = st["kjt"], st["rm"]
+        B, stream = kjt.stride(), _lib.stream_ptr(dev)
         if "dp_n" in rm:
+            gl = st["_grads_alive"]
+            gd = self._dst_array(gl, B, rm["widths"])
             N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
             self._dp_acc.zero_()
             ws = st.get("ws_dp")
@@ -890,17 +905,29 @@ class ShardedEmbeddingBagCollection(nn.Module):
                        "tzr_pooled_bwd_apply")
 
     def coll_grads(self, st: dict) -> None:
-        if self.fused_optimizer is None:
-            return
-        rm = st["rm"]
-        if "rw_n" in rm:
-            st["grecv"] = self._slot(st["slot"], "grecv", (st["n_recv"], self.dim), torch.float32)
-            dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg)
-        if "dp_n" in rm:
-            dist.all_reduce(self._dp_acc, group=self.pg)
+        self.coll_grads_rw(st)
+        self.coll_grads_dp(st)
+
+    def coll_grads_rw(self, st: dict, async_op: bool = False):
+        """the gradient all-to-all; `async_op`: returns the work handle (the caller's stream waits on `.wait()`)"""
+        if self.fused_optimizer is None or "rw_n" not in st["rm"]:
+            return None
+        st["grecv"] = self._slot(st["slot"], "grecv", (st["n_recv"], self.dim), torch.float32)
+        return dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg, async_op=async_op)
+
+    def coll_grads_dp(self, st: dict, async_op: bool = False):
+        """the all-reduce of the replicated tables' row sums"""
+        if self.fused_optimizer is None or "dp_n" not in st["rm"]:
+            return None
+        return dist.all_reduce(self._dp_acc, group=self.pg, async_op=async_op)
 
     def seg_apply(self, st: dict) -> None:
         """owner: sort + fused optimizer over the received gradient rows; replicas: the dense row update"""
+        self.seg_apply_rw(st)
+        self.seg_apply_dp(st)
+
+    def seg_apply_rw(self, st: dict) -> None:
+        """first half of `seg_apply`: needs the gradient all-to-all only"""
         if self.fused_optimizer is None:
             return
         L, dev, D = _lib.lib(), self._device, self.dim
@@ -915,6 +942,13 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), om["K"], om["T"], D,
                                               _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
                                               self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream), "tzr_pooled_bwd_apply")
+
+    def seg_apply_dp(self, st: dict) -> None:
+        """second half: needs the all-reduced row sums of the replicated tables"""
+        if self.fused_optimizer is None:
+            return
+        L, dev, D = _lib.lib(), self._device, self.dim
+        rm, stream = st["rm"], _lib.stream_ptr(dev)
         if "dp_n" in rm:
             _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
@@ -1044,12 +1078,13 @@ def pack_dense_grads(grads: Sequence[torch.Tensor]) -> torch.Tensor:
     return torch.cat([g.reshape(-1) for g in grads])
 
 
-def allreduce_flat_average(flat: torch.Tensor, process_group=None) -> None:
+def allreduce_flat_average(flat: torch.Tensor, process_group=None, async_op: bool = False):
     if flat.is_cuda:
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group)
-    else:  # gloo has no AVG
-        dist.all_reduce(flat, group=process_group)
-        flat.div_(dist.get_world_size(process_group))
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group, async_op=async_op)
+    # gloo has no AVG (and nothing to overlap with on the CPU: always finished on return)
+    dist.all_reduce(flat, group=process_group)
+    flat.div_(dist.get_world_size(process_group))
+    return None
 
 
 def unpack_dense_grads(flat: torch.Tensor, grads: Sequence[torch.Tensor]) -> None:
