@@ -249,3 +249,49 @@ def test_exchange_bucketize_capped(dev, W, cap, hashed):
             assert ks[s * (F + 1) + 1 + f] == run
             run += m[s * S + f]
         assert ks[(s + 1) * (F + 1)] == run  # the next dead key starts where this rank's ids end
+
+
+@pytest.mark.parametrize("n_keys,per_key,dim", [(7, 500, 16), (40, 33, 8), (300, 9, 16), (3, 1, 4), (600, 2, 12), (1500, 0, 16)])
+def test_rows_gather_matches_indexing(dev, n_keys, per_key, dim):
+    """tzr_rows_gather (owner side of the id-granularity exchange): out[j] = W_table(key(j))[ids[j]] over key segments,
+    several workgroups and several keys per workgroup (1 500 keys, half of them empty: more segments in one workgroup's rows
+    than its LDS stages), fp32 and fp16 tables of different widths, dead keys left untouched, out-of-range ids read row 0, a padded
+    output stride."""
+    rng = np.random.default_rng(n_keys * 31 + dim)
+    T = 4
+    rows = [11, 257, 1000, 5]
+    dims = [dim, dim, max(4, dim - 4), dim]
+    ws = [torch.from_numpy(rng.standard_normal((rows[t], dims[t])).astype(np.float32)) for t in range(T)]
+    ws[1] = ws[1].half()
+    wd = [w.to(dev) for w in ws]
+    tables = np.zeros(T, dtype=_lib.TABLE_DT)
+    for t in range(T):
+        tables[t]["w"], tables[t]["rows"], tables[t]["dim"] = wd[t].data_ptr(), rows[t], dims[t]
+        tables[t]["w_stride"], tables[t]["w_dtype"] = wd[t].stride(0), _lib.DT_F16 if wd[t].dtype == torch.float16 else _lib.DT_F32
+    key_table = rng.integers(-1, T, size=n_keys).astype(np.int32)
+    counts = rng.integers(0, 2 * per_key + 1, size=n_keys) if per_key else rng.integers(0, 2, size=n_keys)
+    key_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(key_start[-1])
+    ids = np.zeros(n, dtype=np.int64)
+    for k in range(n_keys):
+        t = key_table[k]
+        hi = rows[t] if t >= 0 else 10
+        ids[key_start[k]:key_start[k + 1]] = rng.integers(0, hi, size=counts[k])
+    if n:
+        ids[rng.integers(0, n, size=max(1, n // 50))] = 10 ** 9  # out of range: row 0, as the pooled forward does
+    stride = dim + 4
+    out = torch.full((max(n, 1), stride), -7.0, dtype=torch.float32, device=dev)
+    rc = _lib.lib().tzr_rows_gather(_lib.ptr(_lib.upload_struct(tables, dev)), _lib.ptr(torch.from_numpy(key_table).to(dev)),
+                                    _lib.ptr(torch.from_numpy(key_start).to(dev)), n_keys, _lib.ptr(torch.from_numpy(ids).to(dev)), n,
+                                    _lib.ptr(out), stride, dim, _lib.stream_ptr(dev))
+    _lib.check(rc, "tzr_rows_gather")
+    want = np.full((max(n, 1), stride), -7.0, dtype=np.float32)
+    for k in range(n_keys):
+        t = key_table[k]
+        if t < 0:
+            continue
+        for j in range(key_start[k], key_start[k + 1]):
+            i = ids[j] if 0 <= ids[j] < rows[t] else 0
+            want[j, :dim] = 0.0
+            want[j, :dims[t]] = ws[t][i].float().numpy()
+    assert np.array_equal(out.cpu().numpy(), want)
