@@ -281,10 +281,14 @@ def test_rows_gather_matches_indexing(dev, n_keys, per_key, dim):
         ids[rng.integers(0, n, size=max(1, n // 50))] = 10 ** 9  # out of range: row 0, as the pooled forward does
     stride = dim + 4
     out = torch.full((max(n, 1), stride), -7.0, dtype=torch.float32, device=dev)
-    rc = _lib.lib().tzr_rows_gather(_lib.ptr(_lib.upload_struct(tables, dev)), _lib.ptr(torch.from_numpy(key_table).to(dev)),
-                                    _lib.ptr(torch.from_numpy(key_start).to(dev)), n_keys, _lib.ptr(torch.from_numpy(ids).to(dev)), n,
+    # (named: a temporary's block would go back to the caching allocator -- and to the next upload -- before the launch)
+    d_tables, d_kt, d_ks, d_ids = (_lib.upload_struct(tables, dev), torch.from_numpy(key_table).to(dev), torch.from_numpy(key_start).to(dev),
+                                   torch.from_numpy(ids).to(dev))
+    rc = _lib.lib().tzr_rows_gather(_lib.ptr(d_tables), _lib.ptr(d_kt), _lib.ptr(d_ks), n_keys, _lib.ptr(d_ids), n,
                                     _lib.ptr(out), stride, dim, _lib.stream_ptr(dev))
     _lib.check(rc, "tzr_rows_gather")
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     want = np.full((max(n, 1), stride), -7.0, dtype=np.float32)
     for k in range(n_keys):
         t = key_table[k]
