@@ -223,3 +223,44 @@ def test_persistent_backward_walks_a_large_batch(F, D):
     rd, rs = torch.autograd.grad(ref, (d64, s64), go.double())
     torch.testing.assert_close(gd.double(), rd, rtol=1e-5, atol=1e-5 * float(rd.abs().max()))
     torch.testing.assert_close(gs.double(), rs, rtol=1e-5, atol=1e-5 * float(rs.abs().max()))
+
+
+def test_every_row_count_up_to_64_on_the_emulator(emu_path):
+    """n = 2 .. 64 x D in {4, 12, 24, 40} x (dense row / concatenation forms) x grid knob: every row-block count, every
+    partial 16-column block, the run-time S pitch of 33-48 rows, all three persistent-grid forms of the backward.  Emulator
+    only (1 008 cases in ~10 s on the host; on the chip the parametrised tests above cover the shape classes)."""
+    from torcheasyrec_amd import _lib
+
+    _lib.use_library(emu_path)  # (the `dev` fixture of the other tests selects its library itself)
+    try:
+        bad = []
+        for n in range(2, 65):
+            for D in (4, 12, 24, 40):
+                for hd, cd, cs, wgs in ((1, True, True, 0), (1, False, True, 1), (0, False, False, 2), (1, True, False, 1)):
+                    F, B = n - hd, 5
+                    g = torch.Generator().manual_seed(n * 100 + D)
+                    dense = torch.randn(B, D, generator=g) if hd else None
+                    sparse = torch.randn(B, F * D, generator=g)
+                    _lib.lib().tzr_tune(b"ia_gen_wgs", wgs)
+                    dd = dense.clone().requires_grad_(True) if hd else None
+                    sd = sparse.clone().requires_grad_(True)
+                    out = dot_interaction(dd, sd, D, cd, cs)
+                    dr = dense.clone().requires_grad_(True) if hd else None
+                    sr = sparse.clone().requires_grad_(True)
+                    rows = ([dr.unsqueeze(1)] if hd else []) + [sr.reshape(B, F, D)]
+                    parts = [orc.dot_interaction(torch.cat(rows, dim=1))]
+                    if cd and hd:
+                        parts.append(dr)
+                    if cs:
+                        parts.append(sr)
+                    ref = torch.cat(parts, dim=-1)
+                    go = torch.randn(ref.shape, generator=g)
+                    out.backward(go)
+                    ref.backward(go)
+                    ok = (torch.allclose(out.detach(), ref.detach(), rtol=1e-5, atol=1e-4) and torch.allclose(sd.grad, sr.grad, rtol=1e-5, atol=1e-4)
+                          and (not hd or torch.allclose(dd.grad, dr.grad, rtol=1e-5, atol=1e-4)))
+                    if not ok:
+                        bad.append((n, D, hd, cd, cs, wgs))
+        assert not bad, bad[:10]
+    finally:
+        _lib.lib().tzr_tune(b"ia_gen_wgs", 0)
