@@ -239,3 +239,13 @@ def test_top_kernels_with_row_strides_and_without_a_dense_row(dev, F, with_dense
     if with_dense:
         _close(gdb[:, :D], dense.grad, 1e-5)
         assert torch.isnan(gdb[:, D:]).all()
+
+
+def test_every_feature_count_on_the_emulator(emu_path):
+    """F = 1 .. 31 (every pair-block / row-block count the fused kernels dispatch on: the 48-block, 49-block and 64-block
+    forms of the backward, the 12 + 1 and the generic K split of the forward) x B in {1, 19, 33}: emulator only, ~10 s."""
+    _lib.use_library(emu_path)  # (the `dev` fixture of the other tests selects its library itself)
+    dev = torch.device("cpu")
+    for F in range(1, 32):
+        for B in (1, 19, 33):
+            test_top_fwd_bwd_match_torch(dev, B, F)
