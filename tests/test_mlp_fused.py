@@ -151,3 +151,17 @@ def test_mlp2_kernel_variants_agree(dev, knob, B, K0):
     out.backward(g)
     for w, p in zip(want, ps):
         _close(p.grad, w)
+
+
+def test_every_tail_of_the_16_sample_tiles_on_the_emulator(emu_path):
+    """The MFMA forms take 16 samples per wave and 4 waves per workgroup: B = 1 .. 35 and the sizes around 48, 64, 128
+    (every partial tile / partial workgroup), bottom-stack inputs 1 .. 16 wide, both label types.  Emulator only, ~3 s."""
+    from torcheasyrec_amd import _lib
+
+    _lib.use_library(emu_path)  # (the `dev` fixture of the other tests selects its library itself)
+    dev = torch.device("cpu")
+    for B in list(range(1, 36)) + [47, 48, 49, 63, 64, 65, 127, 129]:
+        for K0 in (1, 4, 13, 16):
+            test_mlp2_matches_torch(dev, B, K0, 64, 16)
+        for float_labels in (False, True):
+            test_top_loss_matches_torch(dev, B, 40, 64, 32, float_labels)
