@@ -311,9 +311,12 @@ class ShardedTrainStep:
         self._run_dense(seg, dense, label)
         pending = self._begin(next_kjt, t0) if (next_kjt is not None and self.prefetch) else None
         ebc.backward(st, [seg.grads[0]])
+        from .sharding import allreduce_flat_average, dense_grad_views, pack_dense_grads
+
         pg = list(seg.grads[1:])
-        model.allreduce_dense_grads(pg)
-        for p, g in zip(self.params, pg):
+        flat = pack_dense_grads(pg)  # DDP semantics: one flat all-reduce (AVG); the optimizer reads views of it
+        allreduce_flat_average(flat, model.pg)
+        for p, g in zip(self.params, dense_grad_views(flat, pg)):
             p.grad = g
         self.opt.step()
         if pending is not None:
@@ -355,11 +358,10 @@ class ShardedTrainStep:
         self.model.ebc.seg_apply_rw(st)
 
     def _seg2b(self, st: dict, sl: dict) -> None:
-        from .sharding import unpack_dense_grads
+        from .sharding import dense_grad_views
 
         self.model.ebc.seg_apply_dp(st)
-        unpack_dense_grads(sl["flat"], sl["grads"])
-        for p, g in zip(self.params, sl["grads"]):
+        for p, g in zip(self.params, dense_grad_views(sl["flat"], sl["grads"])):  # no unpack launch: views of the averaged buffer
             p.grad = g
         self.opt.step()
 
