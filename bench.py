@@ -98,7 +98,81 @@ def parse_args():
     ap.add_argument("--delta-tracker", action="store_true",
                     help="experiment: record every lookup in the delta-embedding tracker (tzr_delta_mark inside the step); off by default")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to tzr_tune")
+    ap.add_argument("--emulator", action="store_true",
+                    help="CPU plumbing check of the N-rank launch path: kernels through the lane emulator (tests/emu), gloo "
+                         "instead of RCCL, tables capped (--rows-cap, default 2000), no graphs / e2e / secondary readings.  "
+                         "Never a performance number: the line says so in `data`")
+    ap.add_argument("--n1-ms", type=float, default=0.0,
+                    help="sharded runs: ms per GLOBAL-batch step of the N = 1 line, for the `projection` object's scaling ratios")
+    ap.add_argument("--projection-world", type=int, default=0,
+                    help="sharded runs: world size the `projection` is made for (default: the job's, or 65536 / per-rank batch at N = 1)")
+    ap.add_argument("--no-sharded-proxy", action="store_true",
+                    help="N = 1 default line: skip the 1-rank RCCL proxy of the 8192-per-rank sharded step (a child process)")
+    ap.add_argument("--dp-max-rows", type=int, default=0,
+                    help="sharded runs: tables of at most this many rows are replicated (default 65536; 500 under --emulator, so "
+                         "that capped tables still take the row-wise exchange)")
+    ap.add_argument("--no-spawn", action="store_true",
+                    help="--gpus N > 1 outside torch.distributed.run: fail instead of re-launching under it")
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` (the driver's form) outside a launcher: start the N ranks ourselves --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` -- and hand its exit code back.  Rank 0 of that job prints the JSON line (its `ranks_seen` is an
+    all-reduce of ones over the process group: proof that N ranks took part)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TZR_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_ms_per_global_step=None, capacity_factor=1.25):
+    """The scaling arithmetic of the sharded step: what `step_ms` -- this run's time for ONE rank's
+    share of the step at `B_local` samples per rank -- means at `world_target` ranks, with the bytes SURVEY 8(d) counts
+    for the exchange priced at 153 GB/s per xGMI link (7 links per GPU, one per peer: a full-mesh all-to-all uses all
+    of them at once; the ring all-reduce is bound by ONE link's rate).  Wire time is reported both as hidden (overlap
+    perfect) and as exposed (no overlap at all): the truth on hardware lies between."""
+    W = world_target
+    link = 153e9
+    D = model.dim
+    e = model.ebc
+    F_rw = len(e._rw)
+    dp_rows = int(getattr(e, "_dp_rows", 0))
+    dense_bytes = sum(p.numel() for p in model.dense_parameters()) * 4
+    ids_msg = 8.0 * capacity_factor * F_rw * B_local / W          # bytes to ONE peer (capacity-bounded slices)
+    rows_msg = 4.0 * D * capacity_factor * F_rw * B_local / W      # rows back / gradient rows out, per peer
+    a2a_us = lambda b: b / link * 1e6                               # noqa: E731 -- all peers' links run concurrently
+    ring = lambda nbytes: 2.0 * (W - 1) / W * nbytes / link * 1e6  # noqa: E731 -- ring all-reduce, per-link bound
+    wire = {"ids_all_to_all_us": a2a_us(ids_msg), "rows_all_to_all_us": a2a_us(rows_msg), "grad_rows_all_to_all_us": a2a_us(rows_msg),
+            "replica_row_sums_all_reduce_us": ring(dp_rows * D * 4.0), "dense_grads_all_reduce_us": ring(dense_bytes)}
+    wire_total = sum(wire.values())
+    # the critical path cannot hide the rows all-to-all (nothing but the bottom MLP is independent of it) nor the gradient
+    # all-to-all's tail; the all-reduces fly under the owners' update (DESIGN.md 4)
+    exposed_min = wire["rows_all_to_all_us"] + wire["grad_rows_all_to_all_us"]
+    out = {"per_rank_batch": B_local, "world": W, "proxy_ms_per_step": step_ms,
+           "xgmi_link_GBps": link / 1e9, "wire_us": wire, "wire_total_us": wire_total,
+           "bytes_per_rank_per_step": {"ids_out": ids_msg * (W - 1), "rows_in": rows_msg * (W - 1), "grad_rows_out": rows_msg * (W - 1),
+                                       "replica_row_sums": dp_rows * D * 4.0, "dense_grads": float(dense_bytes)},
+           "samples_per_s_if_wire_hidden": W * B_local / (step_ms * 1e-3),
+           "samples_per_s_if_a2a_exposed": W * B_local / (step_ms * 1e-3 + exposed_min * 1e-6),
+           "samples_per_s_if_wire_exposed": W * B_local / (step_ms * 1e-3 + wire_total * 1e-6)}
+    if n1_ms_per_global_step:
+        n1 = W * B_local / (n1_ms_per_global_step * 1e-3)
+        out["n1_samples_per_s"] = n1
+        out["scaling_vs_n1"] = {"wire_hidden": out["samples_per_s_if_wire_hidden"] / n1,
+                                "a2a_exposed": out["samples_per_s_if_a2a_exposed"] / n1,
+                                "wire_exposed": out["samples_per_s_if_wire_exposed"] / n1}
+        out["step_ms_needed_for_6x"] = n1_ms_per_global_step / 6.0
+    return out
 
 
 class _Timers:
@@ -281,25 +355,56 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    # everything (warm-up, capture, replay, instrumented steps) runs on ONE non-default stream, so
-    # autograd's AccumulateGrad nodes and the captured graphs agree on it
-    work_stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(work_stream)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ and not args.no_spawn \
+                and not os.environ.get("TZR_BENCH_SPAWNED"):
+            raise SystemExit(spawn_ranks(args))  # `python bench.py --gpus N`: the N ranks are started here
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (or plainly as `python bench.py --gpus {args.gpus}`)")
+    emu = args.emulator
+    if emu:
+        args.rows_cap = args.rows_cap or 2000
+        args.no_graph = args.no_e2e = args.no_secondary = True
+        dev = torch.device("cpu")
+        work_stream = None
+    else:
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        # everything (warm-up, capture, replay, instrumented steps) runs on ONE non-default stream, so
+        # autograd's AccumulateGrad nodes and the captured graphs agree on it
+        work_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(work_stream)
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
+
     sharded = world > 1 or args.force_sharded
+    ranks_seen, coll_lib = 1, None
     if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the process group's flight recorder is what ShardedTrainStep asks whether the watchdog still lists a collective
+        # before it opens a hipGraph capture (sharded_step._quiesce_process_group)
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            coll_lib = "gloo (CPU plumbing run)"
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            try:
+                coll_lib = "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                coll_lib = "RCCL"
+        # proof that `world` ranks are in the job: every rank contributes a one
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f"process group saw {ranks_seen} ranks, expected {world}")
 
     from torcheasyrec_amd import _build, _lib
     from torcheasyrec_amd.criteo import (CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, algorithmic_bytes,
@@ -308,11 +413,19 @@ def main():
     if args.torch_bce:
         def bce_with_logits(logits, labels):  # noqa: F811 - A/B switch
             return torch.nn.functional.binary_cross_entropy_with_logits(logits, labels.float())
+    from torcheasyrec_amd.dense import root_loss
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
 
-    _lib.use_library(_build.build())
-    assert _lib.backend() == "hip-gfx950"
-    if not args.no_tunable_gemm:
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu.build_emu import build as build_emu
+
+        _lib.use_library(build_emu())
+        assert _lib.backend() == "emu"
+    else:
+        _lib.use_library(_build.build())
+        assert _lib.backend() == "hip-gfx950"
+    if not args.no_tunable_gemm and not emu:
         enable_tunable_gemm()
     for kv in args.tune:
         k, v = kv.split("=")
@@ -322,7 +435,7 @@ def main():
     B_global = args.global_batch if args.scaling == "strong" else args.global_batch * world
     B_local = B_global // world
     if args.exchange == "auto":
-        small = sharded and not args.no_pipeline and not args.no_graph and B_local <= 16384
+        small = sharded and not args.no_pipeline and (not args.no_graph or emu) and B_local <= 16384
         args.exchange = "capacity" if small else "exact"
         args.step_graph = args.step_graph or small
     if args.step_graph and args.exchange != "capacity":
@@ -338,14 +451,15 @@ def main():
 
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                             row_layout=args.row_layout, replicate_at_world1=args.replicate_small,
-                            exchange=args.exchange, capacity_factor=args.capacity_factor)
+                            exchange=args.exchange, capacity_factor=args.capacity_factor,
+                            dp_max_rows=args.dp_max_rows or (500 if emu else 65536))
         parallelism = model.describe() + (f"; exchange: {args.exchange}" + (f" x{args.capacity_factor}" if args.exchange == "capacity" else ""))
     delta_tracker = None
     if args.delta_tracker:  # what train_config.delta_embedding_dump_config adds to a step (never part of the default line)
         from torcheasyrec_amd.delta_embedding_dump import ModelDeltaTracker
 
         delta_tracker = ModelDeltaTracker(model)
-    use_graph = not sharded and not args.no_graph
+    use_graph = not sharded and not args.no_graph and not emu
     # capturable: the dense Adam step lives inside the captured hipGraph
     if args.torch_adam:
         dense_opt = torch.optim.Adam(list(model.dense_parameters()), lr=1e-3, fused=True, capturable=use_graph)
@@ -375,7 +489,7 @@ def main():
         return out, hv
 
     batches, host_vals = make_batches(B_global)
-    torch.cuda.synchronize()
+    sync()
 
     timers = _Timers()
     ebc = model.ebc if not sharded else None
@@ -400,7 +514,8 @@ def main():
         else:
             logits = model(dense, kjt)
             loss = bce_with_logits(logits, label)
-        loss.backward()
+        with root_loss():  # the unscaled loss is the root of the backward pass
+            loss.backward()
         if sharded:
             model.allreduce_dense_grads()
         dense_opt.step()
@@ -414,7 +529,7 @@ def main():
     # 3: the pipelined step captures on its 3rd call; 10: the two pipeline slots of --step-graph capture on their 3rd (step) and 4th (input dist) visits
     for i in range(max(args.warmup, (10 if args.step_graph else 3) if train_step is not None else (2 if use_graph else 0))):
         loss = step_body(*batches[i % nb])
-    torch.cuda.synchronize()
+    sync()
 
     graphs = None
     if use_graph:
@@ -429,7 +544,7 @@ def main():
                 losses.append(step_body(*batches[bi]))
             pool = g.pool()
             graphs.append(g)
-        torch.cuda.synchronize()
+        sync()
 
     def run_step(i):
         if graphs is not None:
@@ -439,14 +554,14 @@ def main():
 
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = run_step(args.warmup + i)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -461,21 +576,23 @@ def main():
     B2 = args.secondary_global_batch
     if B2 is None:  # strong headline -> weak at 8192 per rank; weak headline -> the strong reading
         B2 = (args.global_batch if args.scaling == "weak" else args.weak_per_rank_batch * world) if world > 1 else 0
+        if emu or args.no_secondary:
+            B2 = 0
     if B2 and train_step is not None and B2 != B_global and B2 % world == 0:
         b2, _ = make_batches(B2, seed0=1000)
         for i in range(max(args.warmup, 10 if args.step_graph else 4)):
             step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
         t1 = time.perf_counter()
         for i in range(args.steps):
             step_body(*b2[i % nb], next_kjt=b2[(i + 1) % nb][1])
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
         e2 = time.perf_counter() - t1
         if world > 1:
             t = torch.tensor([e2], dtype=torch.float64, device=dev)
@@ -535,20 +652,27 @@ def main():
         # TrainPipeline (one Python-launched kernel sequence per step): the launch-bound reading
         # (graph pipeline timed before and after the eager one: the first pipeline of a process also pays for the first
         # touches of the pinned batches)
-        e_graph = timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8) if not args.torch_adam else None
+        # (the first pipeline of a process also pays for the first touches of the pinned batches: one untimed pass first)
+        g_runs = []
+        if not args.torch_adam:
+            timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8)
+            g_runs.append(timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8))
         e_eager = timed(TrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 5)
-        if e_graph is not None:
-            e_graph = min(e_graph, timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8))
-        # the faster of the two is the e2e reading (both queue the next batch's H2D behind the step's launch)
-        use_graph_pipe = e_graph is not None and e_graph <= e_eager
-        e1 = e_graph if use_graph_pipe else e_eager
+        if not args.torch_adam:
+            for _ in range(2):
+                g_runs.append(timed(GraphTrainPipeline(_BatchModel(model), dense_opt, dev, loss_of), 8))
+        # the reading is the MEDIAN of the graph pipeline's three timed runs (the product's default pipeline); the eager
+        # pipeline is reported next to it
+        use_graph_pipe = bool(g_runs)
+        e1 = sorted(g_runs)[len(g_runs) // 2] if use_graph_pipe else e_eager
         e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
+               "statistic": "median of 3 timed runs" if use_graph_pipe else "one timed run",
                "h2d_bytes_per_step": h2d_graph if use_graph_pipe else h2d_eager,
                "launch": ("hipGraph replay per device slot, pinned host batches, H2D of the next batch on a copy stream "
                           "(GraphTrainPipeline.progress)" if use_graph_pipe else
                           "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"),
                "eager_ms_per_step": e_eager / n_e2e * 1e3,
-               "graph_ms_per_step": None if e_graph is None else e_graph / n_e2e * 1e3}
+               "graph_ms_per_step_runs": [g / n_e2e * 1e3 for g in g_runs]}
 
     # per-kernel HIP-event timing: instrumented eager steps on the same batches (events cannot sit
     def embedding_stages(ebc_, kjts, host_values, Bl, optimizer, iters=10):
@@ -644,8 +768,30 @@ def main():
         except Exception as e:
             secondary["interaction_first_layer_mfma"] = {"error": repr(e)[:200]}
 
+    # (e) the 8192-per-rank SHARDED step on a 1-rank RCCL group (every kernel and RCCL call of one rank of the 8-GPU job; the
+    # all-to-alls are self copies) + the scaling projection it implies -- in a child process, so that nothing of it (a
+    # second set of tables, the process group) can touch this process's line
+    if isinstance(secondary, dict) and "config2_batch8192" in secondary and not args.no_sharded_proxy:
+        import subprocess
+
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--replicate-small", "--global-batch", "8192",
+               "--steps", str(max(args.steps, 30)), "--warmup", "12", "--no-cpu-baseline", "--no-e2e",
+               "--n1-ms", repr(elapsed / args.steps * 1e3), "--projection-world", "8"]
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
+                                env=dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300)))
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1]
+            child = json.loads(line)
+            secondary["sharded_w1_proxy_b8192"] = {
+                "config": "row-wise sharded step of ONE rank at 8192 samples per rank on a 1-rank RCCL group (the per-rank work of "
+                          "the 8-GPU job at global batch 65536); collectives are self copies",
+                "ms_per_step": child["ms_per_step"], "launch": child["launch"], "parallelism": child["config"]["parallelism"],
+                "exchange": child.get("exchange"), "projection": child.get("projection"), "collectives": child.get("collectives")}
+        except Exception as e:
+            secondary["sharded_w1_proxy_b8192"] = {"error": repr(e)[:300]}
+
     # inside a captured graph); the kernels and inputs are the ones of the timed region
-    if ebc is not None:
+    if ebc is not None and not emu:
         # The three C-ABI calls of the embedding path (pooled forward, backward plan, backward
         # apply) are launched on the batches of the timed region with HIP events recorded right
         # before/after each call on the launching stream.  A GPU-side sleep first lets the host
@@ -670,7 +816,9 @@ def main():
                   + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not emu else "synthetic -- CPU LANE EMULATOR + gloo, tables capped: launch-path plumbing check, not a measurement",
+        "ranks_seen": ranks_seen, "collectives": coll_lib,
         "config": {"workload": "dlrm_criteo: 26 tables x dim 16 (204.2M rows, fp32), fused sparse "
                                f"{args.optimizer} + dense Adam, ids {args.dist}",
                    "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism,
@@ -679,13 +827,19 @@ def main():
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if graphs is not None else
-                   ((f"pipelined: input dist one batch ahead + {'five' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them" if args.step_graph else
+                   ((f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them (async, waited for on the stream)" if args.step_graph else
                      "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }
     if sharded:
         out["exchange"] = dict(model.ebc.exchange_stats, kind=args.exchange)
         if train_step is not None and args.step_graph:
             out["exchange"].update(graph_steps=train_step.graph_steps, eager_steps=train_step.eager_steps)
+        # the scaling arithmetic (what this step time means for the >= 6x target): at N = 1 the run is the proxy of one
+        # rank of a `65536 / B_local`-rank job, at N > 1 the measured job itself
+        Wp = args.projection_world or (world if world > 1 else max(2, 65536 // max(B_local, 1)))
+        out["projection"] = xgmi_projection(model, B_local, Wp, ms_per_step, args.n1_ms or None, args.capacity_factor)
+        out["projection"]["measured_on"] = (f"{world} rank(s); " + ("every collective is a self copy: wire time NOT in proxy_ms_per_step"
+                                                                    if world == 1 else "wire time included in proxy_ms_per_step"))
     if rank == 0 and world == 1:
         ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]
         fwd_b = float(np.mean([a["fwd"] for a in ab]))

@@ -9,6 +9,8 @@ tests compare against torch to 1e-6.
 """
 from __future__ import annotations
 
+import contextlib
+import threading
 from typing import Iterable, List, Optional
 
 import torch
@@ -100,6 +102,27 @@ def weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     if B >= 16384 and B % S == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(S, B // S, g.shape[1]).transpose(1, 2), x.view(S, B // S, x.shape[1])).sum(0)
     return g.t() @ x
+
+
+_ROOT_LOSS = threading.local()
+
+
+@contextlib.contextmanager
+def root_loss():
+    """`with root_loss(): loss.backward()` (or `autograd.grad(loss, ...)`): the caller differentiates the fused loss
+    ITSELF, so the gradient arriving at `_TopLossFn` / `_InteractionTopLossFn` is autograd's 1.0 and the multi-tensor
+    launch that scales the six parameter gradients by it (9 us per step) is skipped.  Not for a scaled loss (GradScaler,
+    gradient accumulation's 1/steps, a weighted sum of several losses): there the scale is real."""
+    prev = getattr(_ROOT_LOSS, "on", False)
+    _ROOT_LOSS.on = True
+    try:
+        yield
+    finally:
+        _ROOT_LOSS.on = prev
+
+
+def _loss_is_root() -> bool:
+    return getattr(_ROOT_LOSS, "on", False)
 
 
 class _Mlp2Fn(torch.autograd.Function):
@@ -199,6 +222,9 @@ class _TopLossFn(torch.autograd.Function):
         z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
         # the incoming gradient of the (scalar) loss scales everything; it is folded into the small operands so the
         # [B, *] tensors are touched by the two GEMMs only
+        if _loss_is_root():  # gl == 1.0 (root_loss): nothing to scale
+            dz = (g1 @ W1) if ctx.needs_input_grad[0] else None
+            return (dz, weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1], None)
         dz = (g1 @ (W1 * gl)) if ctx.needs_input_grad[0] else None
         # ... and one multi-tensor launch scales the six parameter gradients (six separate 5 us multiplies otherwise)
         outs = torch._foreach_mul([weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1]], gl)
@@ -253,7 +279,8 @@ class _InteractionTopLossFn(torch.autograd.Function):
         dense, sparse, z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
         F, D = ctx.cfg
         B = sparse.shape[0]
-        gl32 = gl.reshape(1).to(torch.float32)
+        root = _loss_is_root()  # gl == 1.0: no scale operand for the kernel, no multi-tensor scaling launch
+        gl32 = None if root else gl.reshape(1).to(torch.float32)
         gd = gs = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gs = torch.empty_like(sparse)
@@ -262,6 +289,8 @@ class _InteractionTopLossFn(torch.autograd.Function):
                 _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0),
                 g1.shape[1], _lib.ptr(W1), W1.stride(0), _lib.ptr(gl32), _lib.ptr(gd), gd.stride(0), _lib.ptr(gs),
                 gs.stride(0), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_bwd")
+        if root:
+            return (gd, gs, None, weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1], None)
         outs = torch._foreach_mul([weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1]], gl)
         return (gd, gs, None, *outs, None)
 

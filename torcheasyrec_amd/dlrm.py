@@ -168,10 +168,11 @@ class MLP(nn.Module):
         return self.mlp(x)
 
 
-def head_loss(model, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor):
+def head_loss(model, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor, d: Optional[torch.Tensor] = None):
     """(mean BCE-with-logits loss, logits [B]) of a DLRM head (`dense_mlp`, `final_mlp`, `output_mlp`, `dim`,
     `arch_with_sparse` of `model`) on the dense features and the pooled sparse block; shared by DLRM and ShardedDLRM."""
-    d = model.dense_mlp(dense)
+    if d is None:  # (`d`: the bottom MLP's output when the caller already ran it, e.g. under the rows all-to-all)
+        d = model.dense_mlp(dense)
     fused = _FUSED_TOP_LOSS and model.final_mlp._plain and (sparse.is_cuda or _on_emulator())
     if fused and _FUSED_IA_TOP and model.arch_with_sparse and sparse.shape[0] >= _FUSED_IA_TOP_MIN_B:
         from .dense import interaction_top_fits, interaction_top_loss, top_loss_fits

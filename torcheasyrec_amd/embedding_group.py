@@ -452,6 +452,17 @@ def _losses_and_predictions(model, loss_fn, batch):
     return loss_fn(predictions, batch), predictions
 
 
+def _backward_of_losses(losses) -> None:
+    """backward of the unweighted sum of the named losses (TrainWrapper.forward, tzrec/models/model.py:293): every loss
+    receives autograd's 1.0, which `dense.root_loss` lets the fused loss kernels skip multiplying by."""
+    from .dense import root_loss
+
+    vals = list(losses.values())
+    total = vals[0] if len(vals) == 1 else sum(vals[1:], vals[0])
+    with root_loss():
+        total.backward()
+
+
 class TrainPipeline:
     """Minimal ``pipeline.progress(iterator)`` (tzrec/utils/dist_util.py:221-303,336-377 ->
     torchrec TrainPipelineSparseDist [upstream]): the next batch is copied host->device on a memcpy
@@ -491,8 +502,7 @@ class TrainPipeline:
             self._next = self._fetch(dataloader_iter)  # overlaps with the step below
         self._opt.zero_grad(set_to_none=True)
         losses, predictions = _losses_and_predictions(self._model, self._loss_fn, batch)
-        total = sum(losses.values())
-        total.backward()
+        _backward_of_losses(losses)
         if hasattr(self._model, "allreduce_dense_grads"):
             self._model.allreduce_dense_grads()  # no-op unless the model was built over a process group
         self._opt.step()
@@ -588,7 +598,7 @@ class GraphTrainPipeline:
     def _step(self, batch: Batch):
         self._opt.zero_grad(set_to_none=True)
         losses, predictions = _losses_and_predictions(self._model, self._loss_fn, batch)
-        sum(losses.values()).backward()
+        _backward_of_losses(losses)
         self._opt.step()
         return losses, predictions
 

@@ -51,22 +51,62 @@ from .sparse import KeyedJaggedTensor
 _CAPTURE_MODE = "thread_local"
 
 
-def _quiesce_process_group(device) -> None:
+_FR_STATE = {"on": None}  # is the process group's flight recorder recording? (None: not probed yet)
+QUIESCE_FALLBACK_S = 0.35   # without the recorder: a few periods of the watchdog loop (kWatchdogThreadSleepMillis = 100)
+QUIESCE_TIMEOUT_S = 5.0
+
+
+def _active_collectives() -> Optional[int]:
+    """Number of collectives the process group's watchdog has NOT yet seen complete, from the flight recorder it feeds
+    (`FlightRecorder::retire_id` is called by the watchdog loop at the moment it finds a work finished and drops it from
+    its list).  None when the recorder is unavailable or off (TORCH_NCCL_TRACE_BUFFER_SIZE = 0)."""
+    import pickle
+
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace
+    except ImportError:
+        return None
+    try:
+        if _FR_STATE["on"] is None:  # collectives were issued before any capture (parameter broadcasts): the full dump has them
+            full = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False))
+            _FR_STATE["on"] = bool(full.get("entries"))
+        if not _FR_STATE["on"]:
+            return None
+        act = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+        return len(act.get("entries", ()))
+    except Exception:
+        return None
+
+
+def _quiesce_process_group(device) -> float:
     """Call right before opening a hipGraph capture next to an RCCL process group.  The group's watchdog thread polls the
     completion event of every collective it still lists (every ~100 ms, `hipEventQuery`); on this ROCm stack such a query
     fails with hipErrorCapturedEvent while a capture is open in the process -- the watchdog throws, the process aborts
-    (1 run in 4 - 6 of the step-graph tests in round 3, `profiles/r03bk`: always within the first capture).  After a device
-    synchronize every listed collective has completed; a few watchdog periods later the list is empty and there is
-    nothing left to poll during the capture.  Captures happen once per batch shape / pipeline slot: the wait is paid a
-    handful of times per run."""
+    (1 run in 4 - 6 of the step-graph tests in round 3, `profiles/r03bk`: always within the first capture).
+
+    So no capture opens while the watchdog has anything left to poll.  Mechanism, not timing (round 3 slept 0.35 s here):
+    device synchronize -- every collective issued so far HAS completed -- then a handshake with the watchdog itself:
+    wait until the flight recorder shows no active entry, i.e. the watchdog has seen every one of them complete and
+    dropped it (`_active_collectives`).  Nothing is issued between here and the capture, so its list stays empty.
+    Only when the recorder is off does this fall back to waiting a few watchdog periods.  Returns the seconds waited."""
     import time
 
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()):
-        return
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() == "gloo":
+        return 0.0
     torch.cuda.synchronize(device)
-    time.sleep(0.35)
+    t0 = time.monotonic()
+    n = _active_collectives()
+    if n is None:
+        time.sleep(QUIESCE_FALLBACK_S)
+        return time.monotonic() - t0
+    while n:
+        if time.monotonic() - t0 > QUIESCE_TIMEOUT_S:  # an entry that never retires (a work nobody enqueued): do not hang
+            break
+        time.sleep(0.002)
+        n = _active_collectives()
+    return time.monotonic() - t0
 
 
 class _Segment:
@@ -123,13 +163,21 @@ class ShardedTrainStep:
         # `ebc.input_dist_group` can name another communicator for it)
 
     # -- dense segment ---------------------------------------------------------------------------
-    def _dense_fwd_bwd(self, dense, sparse, label):
+    def _split_bottom(self) -> bool:
+        """can the bottom MLP run ahead of the rest of the dense segment (under the rows all-to-all)?"""
+        return self.loss_fn is bce_with_logits and hasattr(self.model, "dense_loss") and hasattr(self.model, "dense_bottom")
+
+    def _dense_fwd_bwd(self, dense, sparse, label, d=None):
         if self.loss_fn is bce_with_logits and hasattr(self.model, "dense_loss"):
-            loss, logits = self.model.dense_loss(dense, sparse, label)  # the top MLP's tail + loss + their backward: one launch
+            # the top MLP's tail + loss + their backward: one launch (`d`: the bottom MLP's output, already computed)
+            loss, logits = self.model.dense_loss(dense, sparse, label) if d is None else self.model.dense_loss(dense, sparse, label, d=d)
         else:
             logits = self.model.dense_forward(dense, sparse)
             loss = self.loss_fn(logits, label)
-        grads = torch.autograd.grad(loss, [sparse] + self.params)
+        from .dense import root_loss
+
+        with root_loss():  # the loss itself is differentiated: its incoming gradient is 1.0, nothing to scale
+            grads = torch.autograd.grad(loss, [sparse] + self.params)
         return loss.detach(), logits.detach(), grads
 
     def _segment(self, dense, label, width) -> _Segment:
@@ -253,14 +301,40 @@ class ShardedTrainStep:
     def _end(self, st: dict) -> dict:
         ebc = self.model.ebc
         if not self.cuda:
+            st.pop("_deferred", None)
             return ebc.input_dist_end(st)
         with torch.cuda.stream(self._side):
-            st = ebc.input_dist_end(st)
+            spec = st.pop("_deferred", False)
+            st2 = ebc.input_dist_end(st)
+            if spec and st2 is st:
+                return st  # the batch fitted: its plans and its `ready` event were queued a step ago (`_begin_ahead`)
+            st = st2
             if self.plan_ahead and not st.get("planned"):
                 st = ebc.plan_ahead(st)  # K6 of both backward halves needs ids only
             ev = torch.cuda.Event()
             ev.record(self._side)
         st["ready"] = ev
+        return st
+
+    def _begin_ahead(self, kjt: KeyedJaggedTensor, after) -> dict:
+        """Input dist of the NEXT batch, queued behind the start of the current step on the side stream.  Capacity-bounded
+        exchange: nothing of it needs the host -- the backward plans are queued right behind it (they depend on ids only)
+        and the overflow word is looked at when the batch's own step begins (`step` -> `_end`), a whole step after its
+        D2H copy was queued: no host wait inside a step (round 3 blocked here until the side stream had run the bucketize +
+        ids all-to-all + flag copy).  A batch that did overflow is redone through the exact exchange then, plans included.
+        Exact exchange: its all-to-all split sizes live on the host, the wait stays where it is."""
+        st = self._begin(kjt, after)
+        if "cap" not in st or "flag_host" not in st:
+            return self._end(st)
+        if self.cuda:
+            with torch.cuda.stream(self._side):
+                if self.plan_ahead and not st.get("planned"):
+                    st = self.model.ebc.plan_ahead(st)
+                    st["planned"] = True
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            st["ready"] = ev
+        st["_deferred"] = True
         return st
 
     def _consume(self, st: dict) -> None:
@@ -298,6 +372,8 @@ class ShardedTrainStep:
             t0.record(torch.cuda.current_stream(self.device))
         if self._ahead is not None and self._ahead[0] is kjt:
             st = self._ahead[1]
+            if st.get("_deferred"):
+                st = self._end(st)  # the overflow word of a batch whose input dist was queued a step ago
         else:
             st = self._end(self._begin(kjt))
         self._ahead = None
@@ -309,7 +385,7 @@ class ShardedTrainStep:
         seg = self._segment(dense, label, st["rm"]["widths"][0])
         ebc.lookup(st, [seg.sparse.detach()])
         self._run_dense(seg, dense, label)
-        pending = self._begin(next_kjt, t0) if (next_kjt is not None and self.prefetch) else None
+        pending = self._begin_ahead(next_kjt, t0) if (next_kjt is not None and self.prefetch) else None
         ebc.backward(st, [seg.grads[0]])
         from .sharding import allreduce_flat_average, dense_grad_views, pack_dense_grads
 
@@ -320,7 +396,7 @@ class ShardedTrainStep:
             p.grad = g
         self.opt.step()
         if pending is not None:
-            self._ahead = (next_kjt, self._end(pending))
+            self._ahead = (next_kjt, pending)
         return seg.loss
 
     # -- whole-step graphs ------------------------------------------------------------------------------
@@ -337,10 +413,19 @@ class ShardedTrainStep:
     def _seg0(self, st: dict, sl: dict) -> None:
         self.model.ebc.seg_owner_rows(st, [sl["sparse"].detach()])
 
+    # the overlapped order cuts G0 behind the owners' row gather: the rows all-to-all is issued there, and the work that does
+    # not depend on it -- the replicated tables' pooled lookup and the bottom MLP -- runs while it is in flight (G0b)
+    def _seg0_rw(self, st: dict, sl: dict) -> None:
+        self.model.ebc.seg_owner_rows(st, [sl["sparse"].detach()], dp=False)
+
+    def _seg0b(self, st: dict, sl: dict) -> None:
+        self.model.ebc.seg_dp_pool(st, [sl["sparse"].detach()])
+        sl["d"] = self.model.dense_bottom(sl["dense"]) if self._split_bottom() else None
+
     def _seg1a(self, st: dict, sl: dict) -> None:
         ebc = self.model.ebc
         ebc.seg_pool(st, [sl["sparse"].detach()])
-        sl["loss"], sl["logits"], grads = self._dense_fwd_bwd(sl["dense"], sl["sparse"], sl["label"])
+        sl["loss"], sl["logits"], grads = self._dense_fwd_bwd(sl["dense"], sl["sparse"], sl["label"], d=sl.pop("d", None))
         ebc.seg_grads_rw(st, [grads[0]])
         sl["grads"] = list(grads[1:])
 
@@ -371,6 +456,12 @@ class ShardedTrainStep:
 
     def _coll0(self, st: dict, sl: dict) -> None:
         self.model.ebc.coll_rows(st)
+
+    def _coll0_issue(self, st: dict, sl: dict) -> None:
+        sl["works"] = [self.model.ebc.coll_rows(st, async_op=self.cuda)]
+
+    def _coll0_wait(self, st: dict, sl: dict) -> None:
+        self._wait(sl.pop("works"))
 
     def _coll1(self, st: dict, sl: dict) -> None:
         from .sharding import allreduce_flat_average
@@ -408,8 +499,8 @@ class ShardedTrainStep:
         sl["dense"].copy_(dense, non_blocking=True)
         sl["label"].copy_(label, non_blocking=True)
         if self.overlap_collectives:
-            segs = (self._seg0, self._seg1a, self._seg1b, self._seg2a, self._seg2b)
-            colls = (self._coll0, self._coll1a, self._coll1b, self._coll2a, None)
+            segs = (self._seg0_rw, self._seg0b, self._seg1a, self._seg1b, self._seg2a, self._seg2b)
+            colls = (self._coll0_issue, self._coll0_wait, self._coll1a, self._coll1b, self._coll2a, None)
         else:
             segs, colls = (self._seg0, self._seg1, self._seg2), (self._coll0, self._coll1, None)
         capture = False
@@ -422,11 +513,15 @@ class ShardedTrainStep:
         if capture:
             sl["st"] = st  # the captured kernels read this state's buffers: keep them alive
             graphs = []
+            # one memory pool for the slot's graphs: they replay in capture order, never concurrently -- and the autograd
+            # graph of the bottom MLP is built in one capture (G0b) and walked backwards in the next (G1a), which is the
+            # arrangement of torch.cuda.make_graphed_callables (forward and backward graphs of one pool)
+            pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
         for i, (seg, coll) in enumerate(zip(segs, colls)):
             if capture:
                 g = torch.cuda.CUDAGraph()
                 _quiesce_process_group(self.device)
-                with torch.cuda.graph(g, stream=torch.cuda.current_stream(self.device), capture_error_mode=_CAPTURE_MODE):
+                with torch.cuda.graph(g, pool=pool, stream=torch.cuda.current_stream(self.device), capture_error_mode=_CAPTURE_MODE):
                     seg(st, sl)
                 graphs.append(g)
                 g.replay()
@@ -440,5 +535,5 @@ class ShardedTrainStep:
             sl["graph"] = graphs
         self.graph_steps += 1
         if next_kjt is not None and self.prefetch:
-            self._ahead = (next_kjt, self._end(self._begin(next_kjt, t0)))
+            self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
         return sl["loss"]

@@ -820,11 +820,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
             dsts[i].ptr, dsts[i].stride = _lib.ptr(o), o.stride(0)
         return dsts
 
-    def seg_owner_rows(self, st: dict, outs: List[torch.Tensor]) -> None:
-        """owner: one row per received id (-> `coll_rows`); replicated tables: pooled straight into `outs`"""
+    def seg_owner_rows(self, st: dict, outs: List[torch.Tensor], dp: bool = True) -> None:
+        """owner: one row per received id (-> `coll_rows`); `dp`: also the replicated tables, pooled straight into `outs`
+        (`seg_dp_pool`; a pipeline that issues the rows all-to-all async runs that half BEHIND the issue instead)"""
         L, dev, D = _lib.lib(), self._device, self.dim
         kjt, rm = st["kjt"], st["rm"]
-        B, stream = kjt.stride(), _lib.stream_ptr(dev)
+        stream = _lib.stream_ptr(dev)
         if "rw_n" in rm:
             om, n_recv = st["om"], st["n_recv"]
             st["owner_ids"] = st["recv_ids"]
@@ -834,6 +835,14 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_rows_gather(_lib.ptr(om["d_tables"]), _lib.ptr(om["d_key_table"]), _lib.ptr(st["key_start"]),
                                          om["K"], _lib.ptr(st["owner_ids"]), n_recv, _lib.ptr(st["rows_out"]), D, D, stream),
                        "tzr_rows_gather")
+        if dp:
+            self.seg_dp_pool(st, outs)
+
+    def seg_dp_pool(self, st: dict, outs: List[torch.Tensor]) -> None:
+        """replicated tables: purely local pooled lookup, straight into their columns of `outs`"""
+        L, dev = _lib.lib(), self._device
+        kjt, rm = st["kjt"], st["rm"]
+        B, stream = kjt.stride(), _lib.stream_ptr(dev)
         if "dp_n" in rm:
             if self._lookup_trackers:
                 if "dp_track_segs" not in rm:
@@ -847,10 +856,12 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                            None, B, self._dst_array(outs, B, rm["widths"]), len(outs), 1,
                                            _lib.FWD_MIXED_DTYPE if self.replica._has_fp16 else 0, stream), "tzr_pooled_fwd")
 
-    def coll_rows(self, st: dict) -> None:
+    def coll_rows(self, st: dict, async_op: bool = False):
+        """the rows all-to-all; `async_op`: returns the work handle (the caller's stream waits on `.wait()`)"""
         if "rw_n" in st["rm"]:
             rows_in, _ = self._recv_rows_buffer(st["N_pad"], st["rm"]["rw_n"])
-            dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg)
+            return dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg, async_op=async_op)
+        return None
 
     def seg_pool(self, st: dict, outs: List[torch.Tensor]) -> None:
         """requester: pooled gather over the rows that came back (ids = their positions in the message)"""
@@ -1028,13 +1039,18 @@ class ShardedDLRM(nn.Module):
         allf = dot_interaction(d, sparse, self.dim, cat_dense=True, cat_sparse=self.arch_with_sparse)
         return self.output_mlp(self.final_mlp(allf)).squeeze(1)
 
-    def dense_loss(self, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor):
+    def dense_loss(self, dense: torch.Tensor, sparse: torch.Tensor, labels: torch.Tensor, d: Optional[torch.Tensor] = None):
         """(mean BCE-with-logits loss over this rank's samples, logits [B]): `dense_forward` + the loss with everything
         behind the top MLP's first GEMM in one launch when the stack fits (torcheasyrec_amd.dense.top_loss; the
         unsharded DLRM.loss_from_embeddings does the same)."""
         from .dlrm import head_loss
 
-        return head_loss(self, dense, sparse, labels)
+        return head_loss(self, dense, sparse, labels, d=d)
+
+    def dense_bottom(self, dense: torch.Tensor) -> torch.Tensor:
+        """the bottom MLP alone: the one piece of the dense half that does not depend on the exchange -- a pipeline runs
+        it while the rows all-to-all is in flight and hands the result to `dense_loss(..., d=)`"""
+        return self.dense_mlp(dense)
 
     def forward(self, dense: torch.Tensor, sparse_features: KeyedJaggedTensor) -> torch.Tensor:
         if dense.is_cuda and self.overlap_dense:
