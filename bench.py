@@ -891,17 +891,12 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if sharded:
-        # No destroy_process_group(): tearing an RCCL group down next to captured step graphs aborted the interpreter now
-        # and then in round 3 (inside destroy, no message; profiles/r03at/abort_in_destroy_process_group.log) -- here that
-        # would be rank 0 dying in front of its JSON line.  The line is out and flushed; leave without any teardown.
-        # (Under rocprofv3 the tool writes its output from exit handlers: there the group is destroyed the regular way.)
+        # regular teardown.  (Round 3 left through os._exit here: the process used to abort now and then inside
+        # destroy_process_group next to captured step graphs -- the watchdog's exception of sharded_step._quiesce_process_group's
+        # docstring, gone since every collective runs on RCCL's own stream: profiles/r04c, 560 captures + a normal destroy.)
         sys.stdout.flush()
         sys.stderr.flush()
-        if os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("TZR_BENCH_TEARDOWN") == "destroy":
-            dist.destroy_process_group()
-        else:
-            os._exit(0)
-
+        dist.destroy_process_group()
 
 if __name__ == "__main__":
     main()

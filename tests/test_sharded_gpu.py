@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+# the process group's flight recorder: what sharded_step._quiesce_process_group asks before it opens a capture
+os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
 
 
 def _body_sharded_world1_matches_unsharded(kind, replicate):
@@ -198,9 +200,9 @@ def _body_sharded_zch_world1_matches_unsharded_zch():
 def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
     """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
     all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
-    pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed.  `overlap`: the five-graph
-    order (collectives issued async behind the graph that feeds them, waited for in front of the one that reads them),
-    which is the default."""
+    pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed.  `overlap`: the six-graph
+    order (collectives issued async behind the graph that feeds them, waited for in front of the one that reads them; the
+    replicas' lookup + the bottom MLP under the rows all-to-all), which is the default."""
     from torcheasyrec_amd import _lib
     from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.dense import FusedDenseAdam
@@ -234,7 +236,7 @@ def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
             assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
             assert ts.graph_steps == steps and ts.eager_steps == 0 and ts.overlap_collectives == overlap
             assert all(sl["graph"] is not None and (sl.get("in_graphs") is not None) == graph_input_dist for sl in ts._slots.values()) and len(ts._slots) == 2
-            assert all(len(sl["graph"]) == (5 if overlap else 3) for sl in ts._slots.values())
+            assert all(len(sl["graph"]) == (6 if overlap else 3) for sl in ts._slots.values())
             assert torch.equal(out["exact"][0], out["graph"][0])
             for a, b in zip(out["exact"][1], out["graph"][1]):
                 assert torch.equal(a, b)

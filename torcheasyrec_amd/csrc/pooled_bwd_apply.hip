@@ -22,216 +22,7 @@
 //     long): ONE launch for the whole apply.
 #include <tzr_gfx950.h>
 
-#include "pooled_bwd.h"
-
-struct BwdGrads {
-  TzrDst d[TZR_MAX_DST];
-};
-
-struct BwdOpt {
-  int kind, wd_mode, clip;
-  const float* lr;
-  float eps, wd, max_grad;
-  float beta1, beta2;
-  const float* adam;  // {step, 1 - beta1^step, 1 - beta2^step}
-};
-
-// Gradient sources of one lookup (key -> table), resolved once per workgroup when the table is
-// read by a single key (the common case).
-// (scalar fields, no arrays: a runtime-indexed array in this struct lands in scratch memory and
-// turned into 4x write amplification on the first version of this kernel -- profiles/r01b)
-struct BwdSrc {
-  const float *gp0, *gp1, *gp2, *gp3;  // group gradient buffer + first column
-  int64_t gs0, gs1, gs2, gs3;          // sample stride
-  int n_dst;
-  int mean;
-};
-
-// `sG` = the gradient-buffer descriptors copied to LDS once per workgroup: run-time selection
-// indexes LDS, never a private copy of the kernel arguments.
-__device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature* __restrict__ ft,
-                                              const TzrDst* sG) {
-  BwdSrc s;
-  const int n = ft->n_dst;
-  s.n_dst = n;
-  s.mean = ft->pooling == TZR_POOL_MEAN;
-  const int d0 = n > 0 ? ft->dst[0] : 0, d1 = n > 1 ? ft->dst[1] : 0;
-  const int d2 = n > 2 ? ft->dst[2] : 0, d3 = n > 3 ? ft->dst[3] : 0;
-  s.gp0 = reinterpret_cast<const float*>(sG[d0].ptr) + ft->col[0];
-  s.gp1 = reinterpret_cast<const float*>(sG[d1].ptr) + ft->col[1];
-  s.gp2 = reinterpret_cast<const float*>(sG[d2].ptr) + ft->col[2];
-  s.gp3 = reinterpret_cast<const float*>(sG[d3].ptr) + ft->col[3];
-  s.gs0 = sG[d0].stride;
-  s.gs1 = sG[d1].stride;
-  s.gs2 = sG[d2].stride;
-  s.gs3 = sG[d3].stride;
-  return s;
-}
-
-// dL/d(row contribution) of the lookup at original position i, float4 chunk c of its row.
-//   grad_mode 0: pooled-output gradients per feature group (bag (key,b) -> grad[g][b, col..])
-//   grad_mode 1: one gradient row per id: G.d[0][i, :]
-__device__ __forceinline__ float4 bwd_lookup_grad(
-    const TzrFeature* __restrict__ feats, const TzrTable& tb, const int32_t* __restrict__ feat_by_order,
-    const TzrDst* sG, const BwdSrc& one, bool single, int grad_mode,
-    const int64_t* __restrict__ offsets, const float* __restrict__ weights,
-    const uint32_t* __restrict__ bag_of, int64_t B, int uniform, uint32_t i, int c) {
-  if (grad_mode == 1)
-    return tzr_ld4(reinterpret_cast<const float*>(sG[0].ptr) + (int64_t)i * sG[0].stride + 4 * c);
-  const uint32_t bag = uniform ? i : bag_of[i];
-  const uint32_t key = bag / (uint32_t)B;
-  const int64_t b = bag - key * (uint32_t)B;
-  BwdSrc s = one;
-  if (!single) {  // the lookup of this table that reads `key` (a table is read once per key)
-    int o = tb.first_order;
-    while (o + 1 < tb.first_order + tb.n_feats && feats[feat_by_order[o]].key != (int32_t)key) ++o;
-    s = bwd_resolve(feats + feat_by_order[o], sG);
-  }
-  float4 g = tzr_ld4(s.gp0 + b * s.gs0 + 4 * c);
-  if (s.n_dst > 1) g = tzr_add4(g, tzr_ld4(s.gp1 + b * s.gs1 + 4 * c));
-  if (s.n_dst > 2) g = tzr_add4(g, tzr_ld4(s.gp2 + b * s.gs2 + 4 * c));
-  if (s.n_dst > 3) g = tzr_add4(g, tzr_ld4(s.gp3 + b * s.gs3 + 4 * c));
-  const bool mean = !uniform && s.mean;
-  if (weights || mean) {
-    float sc = weights ? weights[i] : 1.0f;
-    if (mean) {
-      const int64_t len = offsets[(int64_t)bag + 1] - offsets[bag];
-      if (len > 1) sc = sc / (float)len;
-    }
-    g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
-  }
-  return g;
-}
-
-// Sum of v over the `lg` lanes of a row group (all 64 lanes call it).
-__device__ __forceinline__ float bwd_group_sum(float v, int lg, int lane_in_group, int lane) {
-  if ((lg & (lg - 1)) == 0) {
-    for (int m = lg >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-  }
-  float s = 0.f;
-  const int g0 = lane - lane_in_group;
-  for (int l = 0; l < lg; ++l) s += __shfl(v, g0 + l, 64);
-  return s;
-}
-
-// Prefetch of the elementwise optimizer state of (row, chunk c): issued together with the weight
-// load, before the reduction, so the update itself waits on no memory.
-// (ADAM is a template parameter of everything below: with the Adam arithmetic as one more run-time
-// branch of the row update the reduce kernel needed 99 instead of 78 VGPRs, one wave per SIMD less,
-// and the DLRM-Criteo Adagrad step lost 17 us -- profiles/r01k.  The <false> instantiations are the
-// code that was there before.)
-template <bool ADAM>
-__device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOpt& opt, int64_t row,
-                                                 int c, bool active) {
-  if (active && (ADAM || opt.kind == TZR_OPT_ADAGRAD))  // Adam: exp_avg
-    return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
-  // row-wise Adagrad: the row's scalar, fetched by the group's first lane (c == lane in group at every call site)
-  // together with the weights -- not after the gradient reduction, where its latency was exposed once per run
-  if (!ADAM && active && c == 0 && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
-    return make_float4(reinterpret_cast<const float*>(tb.m)[row * (int64_t)tb.m_stride], 0.f, 0.f, 0.f);
-  return tzr_zero4();
-}
-
-// ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g, the row's current
-// weights w4 and (elementwise adagrad) state m4.  All 64 lanes of the wave must call (row-wise
-// adagrad reduces in the group).
-template <bool ADAM>
-__device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& opt, float lr,
-                                              int64_t row, int c, float4 g, float4 w4, float4 m4,
-                                              bool active, int lg, int lane_in_group, int lane) {
-  if (opt.clip) {
-    g.x = fminf(fmaxf(g.x, -opt.max_grad), opt.max_grad);
-    g.y = fminf(fmaxf(g.y, -opt.max_grad), opt.max_grad);
-    g.z = fminf(fmaxf(g.z, -opt.max_grad), opt.max_grad);
-    g.w = fminf(fmaxf(g.w, -opt.max_grad), opt.max_grad);
-  }
-  void* const wbase = reinterpret_cast<void*>(tb.w);
-  const int64_t woff = row * (int64_t)tb.w_stride + 4 * c;
-  if constexpr (ADAM) {
-    // fbgemm split Adam [upstream]: m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2,
-    // w -= lr * ((m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps) + wd * w); only touched rows move
-    if (active) {
-      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
-      float* vp = mp + tb.dim;
-      float4 v4 = tzr_ld4(vp);
-      const float b1 = opt.beta1, b2 = opt.beta2;
-      const float c1 = opt.adam[1], c2 = opt.adam[2];
-      m4.x = b1 * m4.x + (1.0f - b1) * g.x; m4.y = b1 * m4.y + (1.0f - b1) * g.y;
-      m4.z = b1 * m4.z + (1.0f - b1) * g.z; m4.w = b1 * m4.w + (1.0f - b1) * g.w;
-      v4.x = b2 * v4.x + (1.0f - b2) * g.x * g.x; v4.y = b2 * v4.y + (1.0f - b2) * g.y * g.y;
-      v4.z = b2 * v4.z + (1.0f - b2) * g.z * g.z; v4.w = b2 * v4.w + (1.0f - b2) * g.w * g.w;
-      tzr_st4(mp, m4);
-      tzr_st4(vp, v4);
-      w4.x -= lr * ((m4.x / c1) / (sqrtf(v4.x / c2) + opt.eps) + opt.wd * w4.x);
-      w4.y -= lr * ((m4.y / c1) / (sqrtf(v4.y / c2) + opt.eps) + opt.wd * w4.y);
-      w4.z -= lr * ((m4.z / c1) / (sqrtf(v4.z / c2) + opt.eps) + opt.wd * w4.z);
-      w4.w -= lr * ((m4.w / c1) / (sqrtf(v4.w / c2) + opt.eps) + opt.wd * w4.w);
-      tzr_stw4(wbase, tb.w_dtype, woff, w4);
-    }
-    return;
-  }
-  if (opt.kind == TZR_OPT_ADAGRAD) {
-    if (active) {
-      float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
-      m4.x += g.x * g.x; m4.y += g.y * g.y; m4.z += g.z * g.z; m4.w += g.w * g.w;
-      tzr_st4(mp, m4);
-      w4.x -= lr * g.x / (sqrtf(m4.x) + opt.eps);
-      w4.y -= lr * g.y / (sqrtf(m4.y) + opt.eps);
-      w4.z -= lr * g.z / (sqrtf(m4.z) + opt.eps);
-      w4.w -= lr * g.w / (sqrtf(m4.w) + opt.eps);
-      tzr_stw4(wbase, tb.w_dtype, woff, w4);
-    }
-  } else if (opt.kind == TZR_OPT_ROWWISE_ADAGRAD) {
-    float4 gl = g;
-    if (opt.wd_mode == TZR_WD_L2) gl = tzr_fma4(opt.wd, w4, g);
-    float ss = active ? (gl.x * gl.x + gl.y * gl.y + gl.z * gl.z + gl.w * gl.w) : 0.f;
-    ss = bwd_group_sum(ss, lg, lane_in_group, lane);
-    // the row's scalar state is read by the group's first lane only and broadcast, so no lane
-    // can observe the store below
-    float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride;
-    float mold = (active && lane_in_group == 0) ? m4.x : 0.f;  // loaded by bwd_load_state
-    mold = __shfl(mold, lane - lane_in_group, 64);
-    if (active) {
-      const float mnew = mold + ss / (float)tb.dim;
-      const float mult = lr / (sqrtf(mnew) + opt.eps);
-      float corr = 1.0f;
-      if (opt.wd_mode == TZR_WD_L2) corr = 1.0f - mult * opt.wd;
-      else if (opt.wd_mode == TZR_WD_DECOUPLE) corr = 1.0f - lr * opt.wd;
-      w4.x = corr * w4.x - mult * g.x;
-      w4.y = corr * w4.y - mult * g.y;
-      w4.z = corr * w4.z - mult * g.z;
-      w4.w = corr * w4.w - mult * g.w;
-      tzr_stw4(wbase, tb.w_dtype, woff, w4);
-      if (lane_in_group == 0) *mp = mnew;
-    }
-  } else if (opt.kind == TZR_OPT_ACCUMULATE) {
-    // replicated table: hand the summed row gradient to the all-reduce (tb.m = dense [rows, dim])
-    if (active) tzr_st4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, g);
-  } else {  // SGD
-    if (active) {
-      w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
-      tzr_stw4(wbase, tb.w_dtype, woff, w4);
-    }
-  }
-}
-
-__device__ __forceinline__ float4 bwd_shfl4(float4 v, int src) {
-  return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64),
-                     __shfl(v.w, src, 64));
-}
-
-// One row update done by a whole wave acting as a single group (lanes >= D/4 idle): used by the
-// stitching steps, where runs are few.
-template <bool ADAM>
-__device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const BwdOpt& opt, float lr,
-                                                   uint32_t key, float4 g, int lane) {
-  const bool on = lane < (tb.dim >> 2);
-  float4 w4 = tzr_zero4();
-  if (on) w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * lane);
-  const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, lane, on);
-  bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
-}
+#include "pooled_bwd_apply.h"
 
 // Boundary record of a unit: written by wave 0 of its workgroup, read by whichever workgroup
 // stitches the table (another CU, usually another XCD): agent-scope stores and loads (tzr_gfx950.h).

@@ -58,8 +58,10 @@ class RankModel(nn.Module):
         if self._pg is not None:
             import torch.distributed as dist
 
+            from .sharding import stream_collective
+
             for p in self.dense_parameters():
-                dist.broadcast(p.data, src=0, group=self._pg)
+                stream_collective(dist.broadcast, p.data, src=0, group=self._pg)
 
     def allreduce_dense_grads(self) -> None:
         """DDP semantics for the dense parameters: average their gradients over the ranks (one flat

@@ -51,15 +51,17 @@ from .sparse import KeyedJaggedTensor
 _CAPTURE_MODE = "thread_local"
 
 
-_FR_STATE = {"on": None}  # is the process group's flight recorder recording? (None: not probed yet)
+_FR_STATE = {"on": None, "stuck": set()}  # flight recorder recording? (None: not probed); entries given up on
 QUIESCE_FALLBACK_S = 0.35   # without the recorder: a few periods of the watchdog loop (kWatchdogThreadSleepMillis = 100)
-QUIESCE_TIMEOUT_S = 5.0
+QUIESCE_TIMEOUT_S = 3.0
 
 
-def _active_collectives() -> Optional[int]:
-    """Number of collectives the process group's watchdog has NOT yet seen complete, from the flight recorder it feeds
-    (`FlightRecorder::retire_id` is called by the watchdog loop at the moment it finds a work finished and drops it from
-    its list).  None when the recorder is unavailable or off (TORCH_NCCL_TRACE_BUFFER_SIZE = 0)."""
+def _unretired_collectives() -> Optional[set]:
+    """Ids of the collectives the process group's WATCHDOG still lists, read from the flight recorder it feeds: an entry's
+    `retired` flag is set by the watchdog loop (`FlightRecorder::retire_id`) at the moment it finds the work finished,
+    right before it drops the work from its list -- not by anything this thread does (`onlyActive` would not do: the dump
+    itself queries the events and marks finished entries completed).  None when the recorder is unavailable or off
+    (TORCH_FR_BUFFER_SIZE = 0)."""
     import pickle
 
     try:
@@ -67,28 +69,33 @@ def _active_collectives() -> Optional[int]:
     except ImportError:
         return None
     try:
-        if _FR_STATE["on"] is None:  # collectives were issued before any capture (parameter broadcasts): the full dump has them
-            full = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False))
-            _FR_STATE["on"] = bool(full.get("entries"))
-        if not _FR_STATE["on"]:
-            return None
-        act = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
-        return len(act.get("entries", ()))
+        ents = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries", ())
     except Exception:
         return None
+    if _FR_STATE["on"] is None:  # collectives were issued before any capture (parameter broadcasts): the dump has them
+        _FR_STATE["on"] = bool(ents) and all("retired" in e and "record_id" in e for e in ents[:1])
+    if not _FR_STATE["on"]:
+        return None
+    return {e["record_id"] for e in ents if not e["retired"]} - _FR_STATE["stuck"]
 
 
 def _quiesce_process_group(device) -> float:
-    """Call right before opening a hipGraph capture next to an RCCL process group.  The group's watchdog thread polls the
-    completion event of every collective it still lists (every ~100 ms, `hipEventQuery`); on this ROCm stack such a query
-    fails with hipErrorCapturedEvent while a capture is open in the process -- the watchdog throws, the process aborts
-    (1 run in 4 - 6 of the step-graph tests in round 3, `profiles/r03bk`: always within the first capture).
+    """Call right before opening a hipGraph capture next to an RCCL process group.
 
-    So no capture opens while the watchdog has anything left to poll.  Mechanism, not timing (round 3 slept 0.35 s here):
-    device synchronize -- every collective issued so far HAS completed -- then a handshake with the watchdog itself:
-    wait until the flight recorder shows no active entry, i.e. the watchdog has seen every one of them complete and
-    dropped it (`_active_collectives`).  Nothing is issued between here and the capture, so its list stays empty.
-    Only when the recorder is off does this fall back to waiting a few watchdog periods.  Returns the seconds waited."""
+    The failure this guards against (round 3: 1 run in 4 - 6 of the step-graph tests; round 4: reproduced at will by
+    scripts/capture_stress.py): torch runs a collective issued with async_op=False ON the current stream and records its
+    completion event there; the group's watchdog thread polls the events of every collective it still lists (every
+    ~100 ms, hipEventQuery); on this ROCm stack a query of an event whose stream is CAPTURING fails with
+    hipErrorCapturedEvent -- the watchdog throws, the process aborts (and the capture is invalidated on the way).
+
+    Two mechanisms, neither of them a timer:
+      1. every collective of this package is issued async (`sharding.stream_collective`): it runs on RCCL's own stream,
+         which nothing ever captures, so the watchdog may poll its event at any time;
+      2. for collectives issued by anybody else on the stream about to capture: device synchronize -- they HAVE
+         completed -- then a handshake with the watchdog itself: wait until the flight recorder shows every entry
+         retired, i.e. the watchdog has seen each of them complete and dropped it (`_unretired_collectives`).  Nothing is
+         issued between here and the capture, so its list stays empty.
+    Only when the recorder is off does (2) fall back to waiting a few watchdog periods.  Returns the seconds waited."""
     import time
 
     import torch.distributed as dist
@@ -97,15 +104,16 @@ def _quiesce_process_group(device) -> float:
         return 0.0
     torch.cuda.synchronize(device)
     t0 = time.monotonic()
-    n = _active_collectives()
-    if n is None:
+    left = _unretired_collectives()
+    if left is None:
         time.sleep(QUIESCE_FALLBACK_S)
         return time.monotonic() - t0
-    while n:
-        if time.monotonic() - t0 > QUIESCE_TIMEOUT_S:  # an entry that never retires (a work nobody enqueued): do not hang
+    while left:
+        if time.monotonic() - t0 > QUIESCE_TIMEOUT_S:  # entries that never retire (works nobody enqueued): do not hang, and
+            _FR_STATE["stuck"] |= left                # do not wait for them again
             break
-        time.sleep(0.002)
-        n = _active_collectives()
+        time.sleep(0.005)
+        left = _unretired_collectives()
     return time.monotonic() - t0
 
 

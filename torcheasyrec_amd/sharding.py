@@ -76,6 +76,23 @@ def row_wise_plan(rows: Sequence[int], world: int, whole: Optional[Sequence[bool
 SHARDING_TYPES = ("data_parallel", "table_wise", "row_wise")
 
 
+def stream_collective(fn, tensor: torch.Tensor, *args, **kw):
+    """A collective the caller needs complete IN STREAM ORDER (what `async_op=False` means), issued so that it is safe
+    next to hipGraph captures.  torch's process group runs a sync collective ON the current stream and records its
+    completion event there; its watchdog thread polls that event (hipEventQuery) until it has seen it complete, and on
+    this ROCm stack a query of an event whose stream is CAPTURING fails (hipErrorCapturedEvent) -- the watchdog throws,
+    the process aborts, and the capture is invalidated (round 3's intermittent abort; reproduced at will by
+    scripts/capture_stress.py in round 4).  Issued async the collective runs on RCCL's own stream -- which nothing ever
+    captures -- and `.wait()` makes the current stream wait for it: same ordering, no event of ours on a capturable
+    stream.  CPU tensors (gloo): the plain blocking call."""
+    if tensor.is_cuda:
+        w = fn(tensor, *args, async_op=True, **kw)
+        if w is not None:
+            w.wait()
+        return None
+    return fn(tensor, *args, **kw)
+
+
 def make_plan(tables: Sequence[EmbeddingBagConfig], world: int, dp_max_rows: int = 65536,
               replicate_at_world1: bool = False, constraints: Optional[Dict[str, str]] = None,
               tw_max_rows: int = 0) -> Dict[str, dict]:
@@ -210,10 +227,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
             row_layout=row_layout) if self._dp else None
         if self.replica is not None:
             for store in self.replica._storage:  # identical replicas: rank 0's values (and zero state)
-                dist.broadcast(store, src=0, group=self.pg)
+                stream_collective(dist.broadcast, store, src=0, group=self.pg)
             for st in self.replica._states.values():
                 if st.data_ptr() not in {s.data_ptr() for s in self.replica._storage}:
-                    dist.broadcast(st, src=0, group=self.pg) if st.is_contiguous() else None
+                    stream_collective(dist.broadcast, st, src=0, group=self.pg) if st.is_contiguous() else None
             rows = [c.num_embeddings for c in self._dp]
             self._dp_row_start = torch.tensor(np.concatenate([[0], np.cumsum(rows)]), dtype=torch.int64, device=self._device)
             self._dp_rows = int(sum(rows))
@@ -447,7 +464,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, async_op: bool = False):
         """async_op=True: the collective runs on RCCL's stream while the caller keeps queueing local
         kernels; `.wait()` makes the current stream wait for it (no host block on a GPU)."""
-        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg, async_op=async_op)
+        if async_op:
+            return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.pg, async_op=True)
+        return stream_collective(dist.all_to_all_single, out, inp, out_splits, in_splits, group=self.pg)
 
     def _optim_struct(self, kind: Optional[int] = None):
         return self.fused_optimizer.optim_struct(self._device, kind)
@@ -510,7 +529,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
 
     def cap_exchange(self, st: dict) -> None:
-        dist.all_to_all_single(st["msg"][1], st["msg"][0], group=self.input_dist_group or self.pg)
+        stream_collective(dist.all_to_all_single, st["msg"][1], st["msg"][0], group=self.input_dist_group or self.pg)
 
     def cap_segments(self, st: dict) -> None:
         seg = st["seg"]
@@ -860,7 +879,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         """the rows all-to-all; `async_op`: returns the work handle (the caller's stream waits on `.wait()`)"""
         if "rw_n" in st["rm"]:
             rows_in, _ = self._recv_rows_buffer(st["N_pad"], st["rm"]["rw_n"])
-            return dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg, async_op=async_op)
+            if async_op:
+                return dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg, async_op=True)
+            return stream_collective(dist.all_to_all_single, rows_in[:st["N_pad"]], st["rows_out"], group=self.pg)
         return None
 
     def seg_pool(self, st: dict, outs: List[torch.Tensor]) -> None:
@@ -924,13 +945,17 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if self.fused_optimizer is None or "rw_n" not in st["rm"]:
             return None
         st["grecv"] = self._slot(st["slot"], "grecv", (st["n_recv"], self.dim), torch.float32)
-        return dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg, async_op=async_op)
+        if async_op:
+            return dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg, async_op=True)
+        return stream_collective(dist.all_to_all_single, st["grecv"], st["grow"], group=self.pg)
 
     def coll_grads_dp(self, st: dict, async_op: bool = False):
         """the all-reduce of the replicated tables' row sums"""
         if self.fused_optimizer is None or "dp_n" not in st["rm"]:
             return None
-        return dist.all_reduce(self._dp_acc, group=self.pg, async_op=async_op)
+        if async_op:
+            return dist.all_reduce(self._dp_acc, group=self.pg, async_op=True)
+        return stream_collective(dist.all_reduce, self._dp_acc, group=self.pg)
 
     def seg_apply(self, st: dict) -> None:
         """owner: sort + fused optimizer over the received gradient rows; replicas: the dense row update"""
@@ -984,7 +1009,7 @@ def allreduce_average(grads: Sequence[torch.Tensor], process_group=None) -> None
     world = dist.get_world_size(process_group)
     flat = torch.cat([g.reshape(-1) for g in gs])
     if flat.is_cuda:
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group)
+        stream_collective(dist.all_reduce, flat, op=dist.ReduceOp.AVG, group=process_group)
     else:  # gloo has no AVG
         dist.all_reduce(flat, group=process_group)
         flat.div_(world)
@@ -1020,7 +1045,7 @@ class ShardedDLRM(nn.Module):
         self._side: Optional[torch.cuda.Stream] = None
         # same dense parameters on every rank (DDP broadcasts rank 0's at construction)
         for p in self.dense_parameters():
-            dist.broadcast(p.data, src=0, group=self.pg)
+            stream_collective(dist.broadcast, p.data, src=0, group=self.pg)
 
     def describe(self) -> str:
         e = self.ebc
@@ -1083,7 +1108,7 @@ class ShardedDLRM(nn.Module):
         world = dist.get_world_size(self.pg)
         flat = torch.cat([g.reshape(-1) for g in gs])
         if flat.is_cuda:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg)
+            stream_collective(dist.all_reduce, flat, op=dist.ReduceOp.AVG, group=self.pg)
         else:  # gloo has no AVG
             dist.all_reduce(flat, group=self.pg)
             flat.div_(world)
@@ -1096,7 +1121,9 @@ def pack_dense_grads(grads: Sequence[torch.Tensor]) -> torch.Tensor:
 
 def allreduce_flat_average(flat: torch.Tensor, process_group=None, async_op: bool = False):
     if flat.is_cuda:
-        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group, async_op=async_op)
+        if async_op:
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group, async_op=True)
+        return stream_collective(dist.all_reduce, flat, op=dist.ReduceOp.AVG, group=process_group)
     # gloo has no AVG (and nothing to overlap with on the CPU: always finished on return)
     dist.all_reduce(flat, group=process_group)
     flat.div_(dist.get_world_size(process_group))
