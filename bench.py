@@ -696,8 +696,9 @@ def main():
         ebc_._timers = None
         ab = [algorithmic_bytes(hv, Bl, rows, optimizer=optimizer) for hv in host_values]
         nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
-        f, p_, a_ = tm.mean_ms("fwd"), tm.mean_ms("plan"), tm.mean_ms("apply")
+        f, p_, a_ = tm.mean_ms("fwd"), tm.mean_ms("plan") or 0.0, tm.mean_ms("apply")  # (no plan launch: tzr_pooled_bwd_direct)
         return {"fwd_ms": f, "bwd_plan_ms": p_, "bwd_apply_ms": a_, "algorithmic_bytes": nbytes,
+                "backward": "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else "tzr_pooled_bwd_plan (4 launches) + tzr_pooled_bwd_apply",
                 "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
 
     # N = 1: the other readings BASELINE.json / the north star ask for, on the same box in the same process:
@@ -844,8 +845,8 @@ def main():
         ab = [algorithmic_bytes(hv, B_local, rows, optimizer=args.optimizer) for hv in host_vals]
         fwd_b = float(np.mean([a["fwd"] for a in ab]))
         bwd_b = float(np.mean([a["bwd"] for a in ab]))
-        t_fwd, t_plan, t_apply = timers.mean_ms("fwd"), timers.mean_ms("plan"), timers.mean_ms("apply")
-        if t_fwd and t_plan is not None and t_apply:
+        t_fwd, t_plan, t_apply = timers.mean_ms("fwd"), timers.mean_ms("plan") or 0.0, timers.mean_ms("apply")
+        if t_fwd and t_apply:
             # north star: "HBM-bandwidth roofline on the pooled embedding forward+backward".  Bytes are
             # SURVEY.md 8(d)'s algorithmic figures for THESE batches; the plan moves no algorithmic
             # bytes (its time counts against the aggregate in full).
@@ -857,17 +858,24 @@ def main():
                 return {"stage": name, "kernels": kernels, "launch_ms": ms, "algorithmic_bytes": nbytes,
                         "GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
 
+            direct = not t_plan  # no plan launch: the one-launch backward of small batches (tzr_pooled_bwd_direct)
+            fwd_k = "tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"
+            stages = [stage("forward", [fwd_k], fwd_b, t_fwd)]
+            if direct:
+                stages.append(stage("backward (index sort + fused optimizer, one launch)", ["tzr_bwd_direct_kernel"], bwd_b, t_apply))
+            else:
+                stages += [{"stage": "backward plan", "kernels": ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
+                                                                 "tzr_bwd_sort_kernel"], "launch_ms": t_plan, "algorithmic_bytes": 0.0,
+                            "GBps": 0.0, "frac": 0.0},
+                           stage("backward apply", ["tzr_bwd_reduce_w7_kernel"], bwd_b, t_apply)]
             out["roofline"] = {
-                "bound": "hbm", "kernel": "pooled embedding forward + backward (6 launches: tzr_pooled_fwd_u1_kernel / tzr_pooled_fwd_kernel; "
-                                          "tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_w7_kernel)",
+                "bound": "hbm", "kernel": ("pooled embedding forward + backward (" + ("2 launches: " + fwd_k + "; tzr_bwd_direct_kernel" if direct else
+                                           "6 launches: " + fwd_k + "; tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_w7_kernel") + ")"),
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "traffic": traffic, "launch_ms": t_fwd + t_plan + t_apply,
                 "algorithmic_bytes": fwd_b + bwd_b,
                 "unique_rows": float(np.mean([a["U"] for a in ab])),
-                "kernels": [stage("forward", ["tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"], fwd_b, t_fwd),
-                            stage("backward plan", ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
-                                                    "tzr_bwd_sort_kernel"], 0.0, t_plan),
-                            stage("backward apply", ["tzr_bwd_reduce_w7_kernel"], bwd_b, t_apply)],
+                "kernels": stages,
                 "practical_ceiling_GBps": 3970.0,  # random 64-B gather probe on this part, profiles/r01c
                 "frac_of_practical_ceiling": ach / 3.97e12,
                 "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command on this library "

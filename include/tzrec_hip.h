@@ -275,6 +275,30 @@ int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature
                         int64_t B,
                         int uniform_bag_len, void* ws, size_t ws_bytes, void* stream);
 
+/* K6 + K7 in ONE launch, no index plan: the small-batch form of the fused backward (csrc/pooled_bwd_direct.hip).
+ * Same semantics and argument meaning as tzr_pooled_bwd_plan followed by tzr_pooled_bwd_apply -- per distinct (table, row)
+ * of the batch ONE update with the sum of its lookups' gradients, summation order a function of the ids alone -- for
+ * batches whose per-table id lists are small enough to be read by every workgroup of the table (a rank's 8 192-sample
+ * share of examples/dlrm_criteo.config: 213 k lookups).  Workgroup (t, j) owns the j-th of k equal row ranges of table t,
+ * reads all ids of t, keeps its own in LDS, sorts, reduces, applies; the rows of a tiny table are split over several
+ * workgroups by position instead.  Cost grows with (lookups per table)^2 / 256: tzr_pooled_bwd_direct_supported says
+ * whether a batch should take this entry -- 0 for shapes it refuses (TZR_ERR_UNSUPPORTED: more than 256 lookups or tables,
+ * ragged pooled bags = grad_mode 0 with uniform_bag_len != 1) and for more than 16 384 lookups per table on average
+ * (tzr_tune "bwd_direct": 1 = any size, -1 = never); callers take the planned pair then.  Replaces the same fbgemm pieces
+ * as the pair (transpose_embedding_input + split_embedding_backward_codegen_*_exact, tzrec/modules/embedding.py:930,
+ * tzrec/main.py:774-781).
+ * `ws`: tzr_pooled_bwd_direct_workspace bytes, ZERO-FILLED by the caller before its first use (arrival counters of the
+ * workgroups that share a row of a tiny table; every launch leaves them zero, so the buffer can be kept and reused --
+ * one buffer per stream of launches). */
+int tzr_pooled_bwd_direct_supported(int64_t n_positions, int n_feats, int n_tables, int uniform_bag_len,
+                                    int grad_mode);
+size_t tzr_pooled_bwd_direct_workspace(int64_t n_positions, int n_tables, int max_dim);
+int tzr_pooled_bwd_direct(const TzrTable* d_tables, int n_tables, const TzrFeature* d_feats, int n_feats,
+                          int64_t max_rows, int max_dim, const int64_t* d_values, const int64_t* d_offsets,
+                          const float* d_weights, int64_t n_values, int64_t n_positions, int64_t B,
+                          int uniform_bag_len, int grad_mode, const TzrDst* h_grads, int n_dst,
+                          const TzrSparseOptim* h_optim, void* ws, size_t ws_bytes, void* stream);
+
 /* Inspection of a finished plan (tests / debugging): byte offsets into `ws` of out8[0] = the sorted
  * {row, lookup position} pairs (uint32 x 2 per table-major position) of every table with more than
  * 512 rows, out8[1] = the bucket-partitioned pairs (final for tables of <= 512 rows), out8[2] = the
@@ -308,6 +332,11 @@ int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats, in
 int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables, const int64_t* d_row_start,
                           int64_t total_rows, const float* d_acc, int dim,
                           const TzrSparseOptim* h_optim, void* stream);
+/* Same, and the rows of d_acc it applied are zero afterwards: the accumulation buffer is ready for the next step's
+ * TZR_OPT_ACCUMULATE pass (which writes only the rows it touches) without a memset launch in front of it. */
+int tzr_dense_rows_update_clear(const TzrTable* d_tables, int n_tables, const int64_t* d_row_start,
+                                int64_t total_rows, float* d_acc, int dim, const TzrSparseOptim* h_optim,
+                                void* stream);
 
 /* ---- row-wise sharded exchange (one process per GPU, RCCL all-to-all between the stages) ---- */
 

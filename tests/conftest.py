@@ -39,7 +39,7 @@ def _default_knobs():
     from torcheasyrec_amd import _lib
 
     if _lib._lib is not None:
-        for name in (b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_debug", b"bwd_ch", b"bwd_force_prep", b"bwd_one_wg_heavy", b"ia_bwd_plain", b"ia_bwd_wgs", b"ia_fwd_wgs", b"ia_gen_wgs", b"it_wgs", b"it_stagger", b"mlp_mfma"):
+        for name in (b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_debug", b"bwd_ch", b"bwd_direct_ch", b"bwd_direct", b"bwd_direct_debug", b"bwd_force_prep", b"bwd_one_wg_heavy", b"ia_bwd_plain", b"ia_bwd_wgs", b"ia_fwd_wgs", b"ia_gen_wgs", b"it_wgs", b"it_stagger", b"mlp_mfma"):
             _lib.lib().tzr_tune(name, 0)
         _lib.apply_env_tune()
 
@@ -63,3 +63,30 @@ def emu_heavy(dev=None):
     """Historical: marked test variants that were slow on the first lane emulator (one OS thread per lane).  The
     fiber emulator (tests/emu/hip/hip_runtime.h) runs the whole CPU suite in a few minutes: nothing is skipped."""
     return
+
+
+@pytest.fixture(params=["planned", "direct"])
+def bwd_path(request, dev):
+    """The fused backward in both of its forms on the same test body: "planned" = tzr_pooled_bwd_plan + _apply (the
+    large-batch path), "direct" = tzr_pooled_bwd_direct (one launch, small batches) wherever the library takes the shape
+    (ragged pooled bags still go through the plan).  By default the library picks by size; tests are small, so without
+    this fixture they would only ever see the direct kernel."""
+    from torcheasyrec_amd import _lib
+
+    L = _lib.lib()
+    assert L.tzr_tune(b"bwd_direct", -1 if request.param == "planned" else 1) == 0
+    calls = {"direct": 0}
+    orig = L.tzr_pooled_bwd_direct
+
+    def counted(*a):
+        calls["direct"] += 1
+        return orig(*a)
+
+    L.tzr_pooled_bwd_direct = counted
+    try:
+        yield calls
+    finally:
+        L.tzr_pooled_bwd_direct = orig
+        L.tzr_tune(b"bwd_direct", 0)
+    if request.param == "planned":
+        assert calls["direct"] == 0

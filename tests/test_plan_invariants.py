@@ -16,6 +16,17 @@ from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfi
 from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
 
 
+
+@pytest.fixture(autouse=True)
+def _planned_backward(dev):
+    """these tests inspect the index plan: batches this small would otherwise take the plan-less one-launch backward"""
+    from torcheasyrec_amd import _lib
+
+    assert _lib.lib().tzr_tune(b"bwd_direct", -1) == 0
+    yield
+    _lib.lib().tzr_tune(b"bwd_direct", 0)
+
+
 def _ids(rng, rows, n, kind):
     if kind == "uniform":
         return rng.integers(0, rows, size=n)

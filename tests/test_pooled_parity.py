@@ -18,6 +18,11 @@ from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
 RTOL = 1e-5
 
 
+def _direct_forced():
+    from torcheasyrec_amd import _lib
+    return bool(_lib.lib().tzr_pooled_bwd_direct_supported(1 << 30, 1, 1, 1, 0))  # only the forced knob takes a batch this size
+
+
 def _make_tables(spec, seed=0):
     """spec: list of (name, rows, dim, pooling, [features])"""
     cfgs, inits = [], {}
@@ -306,14 +311,15 @@ def _run_backward_case(dev, spec, keys, rows, B, mode, weighted, opt_cfg, groups
 
 
 @pytest.mark.parametrize("kind", ["adagrad", "rowwise_adagrad", "sgd"])
-def test_backward_uniform1(dev, kind):
+def test_backward_uniform1(dev, kind, bwd_path):
     opt = SparseOptimizerConfig(kind=kind, lr=0.05)
     _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 200,
                        "uniform1", False, opt)
+    assert (bwd_path["direct"] > 0) == (bwd_path is not None and _direct_forced())
 
 
 @pytest.mark.parametrize("mode,weighted,wd", [("uniform1", False, 0.0), ("jagged", True, 0.01)])
-def test_backward_sparse_adam(dev, mode, weighted, wd):
+def test_backward_sparse_adam(dev, mode, weighted, wd, bwd_path):
     """adam_optimizer (protos/optimizer.proto:89-96): state [exp_avg | exp_avg_sq], one step counter on
     the device advanced per backward, bias correction as fbgemm's split Adam; 3 steps so the
     correction terms move; clipping and weight decay in the second case"""
@@ -323,7 +329,7 @@ def test_backward_sparse_adam(dev, mode, weighted, wd):
                        steps=3, rtol=5e-5)
 
 
-def test_backward_long_runs(dev):
+def test_backward_long_runs(dev, bwd_path):
     """1- and 3-row tables with thousands of lookups: the long-run piece path.
 
     ~900 to 2,600 random-sign gradients are summed per row; the kernel reduces them with a fixed tree, the
@@ -383,7 +389,7 @@ PLAN_CASES = {
 @pytest.mark.parametrize("case,ch", [(c, 0) for c in sorted(PLAN_CASES)] +
                          [(c, ch) for c in ("light_units", "hot_multi_tile", "narrow_two_buckets", "wide_rows", "hot_many_tiles",
                                             "zipf_mid_table") for ch in (512, 1024)])
-def test_backward_plan_shapes(dev, case, ch):
+def test_backward_plan_shapes(dev, case, ch, bwd_path):
     """ch = positions per chunk of the plan (pooled_bwd.h: bwd_pick_ch); 0 = by problem size (256 here)"""
     from torcheasyrec_amd import _lib
     _lib.lib().tzr_tune(b"bwd_ch", ch)
@@ -420,7 +426,7 @@ def test_backward_plan_one_workgroup_heavy(dev, case):
         _lib.lib().tzr_tune(b"bwd_one_wg_heavy", 0)
 
 
-def test_backward_plan_shared_jagged_hot(dev):
+def test_backward_plan_shared_jagged_hot(dev, bwd_path):
     """two keys share a bucketed table, jagged bags, a hot row: table-major regrouping + bag_of + heavy"""
     opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.02)
     spec = [("u_emb", 50000, 8, "sum", ["user", "user_hist"]), ("i_emb", 3000, 16, "mean", ["item"])]
@@ -441,7 +447,7 @@ def test_backward_plan_prep_fallback(dev):
         _lib.lib().tzr_tune(b"bwd_force_prep", 0)
 
 
-def test_backward_plan_is_bit_reproducible(dev):
+def test_backward_plan_is_bit_reproducible(dev, bwd_path):
     """same ids, same gradients -> bit-identical weights, hot rows and heavy buckets included"""
     rng = np.random.default_rng(5)
     rows, B = 100000, (1500 if dev.type == "cuda" else 700)
@@ -458,14 +464,14 @@ def test_backward_plan_is_bit_reproducible(dev):
 
 
 @pytest.mark.parametrize("kind,weighted", [("adagrad", False), ("rowwise_adagrad", True)])
-def test_backward_jagged_shared_table(dev, kind, weighted):
+def test_backward_jagged_shared_table(dev, kind, weighted, bwd_path):
     opt = SparseOptimizerConfig(kind=kind, lr=0.02, gradient_clipping=True, max_gradient=0.7)
     keys = ["ctx", "item", "unused_key", "user", "user_hist", "wide_user"]
     rows = [40, 57, 10, 1000, 1000, 1000]
     _run_backward_case(dev, SPEC_MIXED, keys, rows, 45, "jagged", weighted, opt)
 
 
-def test_backward_grouped_sums_group_grads(dev):
+def test_backward_grouped_sums_group_grads(dev, bwd_path):
     spec = [
         ("a_emb", 100, 16, "sum", ["a"]),
         ("b_emb", 7, 16, "sum", ["b"]),
@@ -481,7 +487,7 @@ def test_backward_grouped_sums_group_grads(dev):
     _run_backward_case(dev, spec, ["a", "b"], [100, 7], 64, "uniform1", False, opt, groups=groups)
 
 
-def test_rowwise_weight_decay_modes(dev):
+def test_rowwise_weight_decay_modes(dev, bwd_path):
     for mode in ("l2", "decouple"):
         opt = SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.03, weight_decay=0.01, weight_decay_mode=mode)
         _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 100,
@@ -518,7 +524,7 @@ def test_frozen_table_is_left_out_of_the_fused_optimizer(dev):
 
 
 @pytest.mark.parametrize("kind", ["sgd", "adagrad", "rowwise_adagrad"])
-def test_fp16_tables(dev, kind):
+def test_fp16_tables(dev, kind, bwd_path):
     """`data_type: FP16` (tzrec/features/feature.py:346-356): half rows are widened exactly on read (so
     L=1 pooling is still a bit-exact copy), the optimizer computes in fp32 and rounds to nearest even on
     the way back; an fp32 table in the same collection is untouched by all of that."""

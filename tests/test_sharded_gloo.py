@@ -1076,9 +1076,28 @@ def _check_slots_run(exact, capacity, steps):
         assert torch.equal(a, b)
 
 
+@pytest.fixture
+def planned_backward(monkeypatch):
+    """the workers' fused backward through the index plan (tzr_pooled_bwd_plan + _apply) instead of the one-launch kernel
+    batches this small take by default: both halves of the sharded backward (replicas' ACCUMULATE pass, owners' per-id
+    gradients) keep their planned form covered at N > 1"""
+    monkeypatch.setenv("TZR_TUNE", "bwd_direct=-1")
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_whole_step_slots_equal_the_exact_pipeline(emu_path, world):
     """Six steps through the two pipeline slots of the whole-step path (capacity-bounded exchange, static buffers,
     one overflowing batch redone exactly) = the exact pipelined step, bit for bit: losses, table shards, dense weights."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_slots_worker, args=(world, os.path.join(d, "init"), emu_path), nprocs=world, join=True)
+
+
+def test_whole_step_slots_with_the_planned_backward(emu_path, planned_backward):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_slots_worker, args=(2, os.path.join(d, "init"), emu_path), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("mode,via_step", [("uniform1", True), ("jagged", False)])
+def test_sharded_dlrm_world2_with_the_planned_backward(emu_path, planned_backward, mode, via_step):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, os.path.join(d, "init"), emu_path, mode, d, via_step, False), nprocs=2, join=True)

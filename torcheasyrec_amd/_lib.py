@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 6  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 7  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -115,8 +115,13 @@ _SIGNATURES = {
     "tzr_pooled_bwd_plan_view": (_i32, [_i64, _i64, _i32, _i32, _i32, _vp]),
     "tzr_pooled_bwd_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _i32, _vp, _sz, _vp]),
+    "tzr_pooled_bwd_direct_supported": (_i32, [_i64, _i32, _i32, _i32, _i32]),
+    "tzr_pooled_bwd_direct_workspace": (_sz, [_i64, _i32, _i32]),
+    "tzr_pooled_bwd_direct": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                     C.POINTER(TzrDst), _i32, C.POINTER(TzrSparseOptim), _vp, _sz, _vp]),
     "tzr_sparse_adam_tick": (_i32, [_vp, C.c_float, C.c_float, _vp]),
     "tzr_dense_rows_update": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, C.POINTER(TzrSparseOptim), _vp]),
+    "tzr_dense_rows_update_clear": (_i32, [_vp, _i32, _vp, _i64, _vp, _i32, C.POINTER(TzrSparseOptim), _vp]),
     "tzr_rows_gather": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     "tzr_lookup_grads": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, C.POINTER(TzrDst), _i32, _vp,
                                 _i64, _i32, _vp]),
@@ -259,6 +264,13 @@ def upload_struct(arr: np.ndarray, device: torch.device) -> torch.Tensor:
     """Structured numpy array -> uint8 device tensor holding the same bytes."""
     raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()
     return torch.from_numpy(raw).to(device)
+
+
+def zeroed_workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """256-byte aligned, zero-filled, meant to be KEPT by the caller (tzr_pooled_bwd_direct's self-resetting counters)."""
+    t = torch.zeros(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:]
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:

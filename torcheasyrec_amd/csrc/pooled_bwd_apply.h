@@ -213,6 +213,20 @@ __device__ __forceinline__ void bwd_apply_row_wave(const TzrTable& tb, const Bwd
   bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, lane, g, w4, m4, on, TZR_WAVE, lane, lane);
 }
 
+// Boundary record of a unit: written by wave 0 of its workgroup, read by whichever workgroup
+// stitches the table (another CU, usually another XCD): agent-scope stores and loads (tzr_gfx950.h).
+__device__ __forceinline__ void bwd_publish4(float* p, float4 v) {
+  uint64_t* q = reinterpret_cast<uint64_t*>(p);
+  tzr_publish_u64(q, ((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x));
+  tzr_publish_u64(q + 1, ((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z));
+}
+__device__ __forceinline__ float4 bwd_consume4(const float* p) {
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+  const uint64_t a = tzr_consume_u64(q), b = tzr_consume_u64(q + 1);
+  return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)),
+                     __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32)));
+}
+
 // LDS of one unit's reduction: the sorted keys with one neighbour (or BWD_SENT) on either side, the lookup positions, and
 // the per-wave boundary records the workgroup's wave 0 stitches.
 struct BwdUnitLds {
@@ -220,23 +234,29 @@ struct BwdUnitLds {
   uint32_t sS[BWD_UMAX];
   uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
   float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
-  TzrDst sG[TZR_MAX_DST];
 };
 
-// The reduction of ONE unit held in LDS (U.sK[1 .. n], U.sS[0 .. n), neighbours in U.sK[0] / U.sK[n + 1], U.sG filled;
-// a barrier behind the fills): every wave reduces its quarter tile by tile and updates the rows whose runs end inside it,
-// wave 0 then stitches the runs that cross wave ranges and hands what stays open at the unit's two ends to
-// `tail(cf, okey, clead, osum)` (wave 0 only: cf = BWD_LEAD / BWD_LEAD_WHOLE / BWD_TRAIL, clead = the piece of the run
-// inherited from the unit before, okey / osum = the run that continues past the unit).  All threads of the workgroup call;
-// waves 1.. return behind the barrier in front of the stitch.  This is `bwd_reduce_body` of pooled_bwd_apply.hip between
-// its LDS fill and its boundary record, restated for the one-launch backward of small batches (pooled_bwd_direct.hip); the
-// planned apply keeps its own copy: that kernel is compiled for exactly 7 waves per SIMD (71 of 72 VGPRs) and any
-// re-arrangement of its source moved live ranges into scratch loads inside the tile loop.
-template <bool ADAM, class Tail>
+// The reduction of ONE unit held in LDS (U.sK[1 .. n], U.sS[0 .. n), neighbours in U.sK[0] / U.sK[n + 1]; sG = the
+// gradient-buffer descriptors, in LDS as well; a barrier behind the fills): every wave reduces its quarter and updates the
+// rows whose runs end inside it, wave 0 then stitches the runs that cross wave ranges and hands what stays open at the
+// unit's two ends to `tail(cf, okey, clead, osum)` (wave 0 only: cf = BWD_LEAD / BWD_LEAD_WHOLE / BWD_TRAIL, clead = the
+// piece of the run inherited from the unit before, okey / osum = the run that continues past the unit).  All threads of the
+// workgroup call; waves 1.. return behind the barrier in front of the stitch.
+//
+// Same arithmetic and the same summation order as `bwd_reduce_body` of pooled_bwd_apply.hip (segmented scan inside a
+// tile, carry across tiles, wave records), restated for the one-launch backward of small batches (pooled_bwd_direct.hip)
+// with the memory side turned around: that kernel runs grids of ~1 700 units at 7 waves per SIMD and walks its tiles one
+// round trip after the other (two tiles in flight cost it a wave of occupancy: 114 vs 85 us, NOTES.md); a small batch has
+// fewer workgroups than the chip has slots, so here NT tiles are in flight TOGETHER -- gradient rows, weights and state of
+// 64 lookups per wave in one round trip instead of four -- and the up to three runs wave 0 closes are loaded together too.
+// (The predicates of the loads are known up front: equal keys are adjacent, so "this lookup belongs to the run inherited
+// from the range before" is `key == leadkey` for the whole range.)  The planned apply keeps its own copy: it is compiled
+// for exactly 7 waves per SIMD (71 of 72 VGPRs) and any re-arrangement of its source moved live ranges into scratch.
+template <bool ADAM, int NT, class Tail>
 __device__ __forceinline__ void bwd_reduce_unit(
     const TzrTable& tb, const TzrFeature* __restrict__ feats, const int32_t* __restrict__ feat_by_order,
     const uint32_t* __restrict__ bag_of, const int64_t* __restrict__ offsets, const float* __restrict__ weights,
-    int64_t B, int uniform, int grad_mode, const BwdOpt& opt, BwdUnitLds& U, int n, Tail&& tail) {
+    int64_t B, int uniform, int grad_mode, const BwdOpt& opt, BwdUnitLds& U, const TzrDst* sG, int n, Tail&& tail) {
   uint32_t* const sK = U.sK;
   uint32_t* const sS = U.sS;
   uint32_t* const rflags = U.rflags;
@@ -244,7 +264,6 @@ __device__ __forceinline__ void bwd_reduce_unit(
   uint32_t* const rtkey = U.rtkey;
   float(*const rlead)[BWD_MAXDIM] = U.rlead;
   float(*const rtrail)[BWD_MAXDIM] = U.rtrail;
-  const TzrDst* const sG = U.sG;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   const int lg = tb.dim >> 2;    // lanes per row
@@ -261,51 +280,69 @@ __device__ __forceinline__ void bwd_reduce_unit(
   const int r1 = min(n, r0 + range);
   unsigned flags = 0;
   const uint32_t leadkey = r0 < r1 ? sK[r0 + 1] : BWD_SENT;
-  bool lead_open = r0 < r1 && sK[r0] == leadkey;  // first run started before this range
-  bool cvalid = false;                            // carry: run continuing from the previous tile
+  const bool lead0 = r0 < r1 && sK[r0] == leadkey;  // first run started before this range
+  bool lead_open = lead0;
+  bool cvalid = false;                              // carry: run continuing from the previous tile
   uint32_t ckey = BWD_SENT;
   float4 csum = tzr_zero4();
 
-  for (int t0 = r0; t0 < r1; t0 += gw) {
-    const int idx = t0 + gi;
-    const bool valid = lane_on && idx < r1;
-    const uint32_t key = valid ? sK[idx + 1] : BWD_SENT;
-    const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
-    const bool tail = valid && key != nxt;
-    float4 g = tzr_zero4();
-    if (valid)
-      g = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights,
-                          bag_of, B, uniform, sS[idx], c);
-    const bool in_lead = lead_open && key == leadkey;
-    const bool do_apply = tail && !in_lead;
-    float4 w4 = tzr_zero4();
-    if (do_apply)  // issued before the scan: overlaps the gradient gathers
-      w4 = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key * tb.w_stride + 4 * c);
-    const float4 m4 = bwd_load_state<ADAM>(tb, opt, (int64_t)key, c, do_apply);
-    // segmented inclusive scan over the lane groups of the tile (keys are sorted, so equality at
-    // distance d implies one run in between)
-    for (int d = 1; d < gw; d <<= 1) {
-      const uint32_t ok = __shfl_up(key, d * lg, 64);
-      const float4 ov = make_float4(__shfl_up(g.x, d * lg, 64), __shfl_up(g.y, d * lg, 64),
-                                    __shfl_up(g.z, d * lg, 64), __shfl_up(g.w, d * lg, 64));
-      if (gi >= d && ok == key) g = tzr_add4(ov, g);
+  for (int t0 = r0; t0 < r1; t0 += NT * gw) {
+    uint32_t key[NT];
+    float4 g[NT], w4[NT], m4[NT];
+    unsigned vmask = 0, tmask = 0, lmask = 0;  // per tile u: valid lookup / last of its run / in the inherited run
+    // every load of the NT tiles first
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int idx = t0 + u * gw + gi;
+      const bool valid = lane_on && idx < r1;
+      key[u] = valid ? sK[idx + 1] : BWD_SENT;
+      const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
+      const bool tl = valid && key[u] != nxt;
+      const bool inl = lead0 && key[u] == leadkey;
+      g[u] = tzr_zero4();
+      if (valid)
+        g[u] = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights, bag_of, B, uniform,
+                               sS[idx], c);
+      const bool dap = tl && !inl;
+      w4[u] = tzr_zero4();
+      if (dap) w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key[u] * tb.w_stride + 4 * c);
+      m4[u] = bwd_load_state<ADAM>(tb, opt, (int64_t)key[u], c, dap);
+      vmask |= valid ? 1u << u : 0u;
+      tmask |= tl ? 1u << u : 0u;
+      lmask |= inl ? 1u << u : 0u;
     }
-    if (cvalid && key == ckey) g = tzr_add4(csum, g);  // earlier lookups first
-    if (tail && in_lead) {  // the run inherited from the previous range ends here
-      rlead[wv][4 * c + 0] = g.x; rlead[wv][4 * c + 1] = g.y;
-      rlead[wv][4 * c + 2] = g.z; rlead[wv][4 * c + 3] = g.w;
+    // ... then the tiles in order: scan, carry, records, update
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (t0 + u * gw >= r1) break;  // wave-uniform
+      const bool valid = (vmask >> u) & 1u, tl = (tmask >> u) & 1u, in_lead = (lmask >> u) & 1u;
+      const bool do_apply = tl && !in_lead;
+      float4 gg = g[u];
+      // segmented inclusive scan over the lane groups of the tile (equal keys are adjacent, so equality at
+      // distance d implies one run in between)
+      for (int d = 1; d < gw; d <<= 1) {
+        const uint32_t ok = __shfl_up(key[u], d * lg, 64);
+        const float4 ov = make_float4(__shfl_up(gg.x, d * lg, 64), __shfl_up(gg.y, d * lg, 64),
+                                      __shfl_up(gg.z, d * lg, 64), __shfl_up(gg.w, d * lg, 64));
+        if (gi >= d && ok == key[u]) gg = tzr_add4(ov, gg);
+      }
+      if (cvalid && key[u] == ckey) gg = tzr_add4(csum, gg);  // earlier lookups first
+      if (tl && in_lead) {  // the run inherited from the previous range ends here
+        rlead[wv][4 * c + 0] = gg.x; rlead[wv][4 * c + 1] = gg.y;
+        rlead[wv][4 * c + 2] = gg.z; rlead[wv][4 * c + 3] = gg.w;
+      }
+      if (__any(tl && in_lead)) {
+        flags |= BWD_LEAD;
+        lead_open = false;
+      }
+      bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key[u], c, gg, w4[u], m4[u], do_apply, lg, c, lane);
+      // carry out of the tile: its last valid lookup, if that run goes on
+      const int nv = min(gw, r1 - (t0 + u * gw));
+      const int last = (nv - 1) * lg;
+      ckey = __shfl(key[u], last, 64);
+      cvalid = __shfl((int)(valid && !tl), last, 64) != 0;
+      csum = bwd_shfl4(gg, last + (lane_on ? c : 0));
     }
-    if (__any(tail && in_lead)) {
-      flags |= BWD_LEAD;
-      lead_open = false;
-    }
-    bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key, c, g, w4, m4, do_apply, lg, c, lane);
-    // carry out of the tile: its last valid lookup, if that run goes on
-    const int nv = min(gw, r1 - t0);
-    const int last = (nv - 1) * lg;
-    ckey = __shfl(key, last, 64);
-    cvalid = __shfl((int)(valid && !tail), last, 64) != 0;
-    csum = bwd_shfl4(g, last + (lane_on ? c : 0));
   }
   if (r0 < r1 && cvalid) {  // the last run continues past this range
     float* dst = lead_open ? rlead[wv] : rtrail[wv];
@@ -321,7 +358,9 @@ __device__ __forceinline__ void bwd_reduce_unit(
   }
   __syncthreads();
 
-  // stitch the 4 ranges of the chunk (wave 0; control flow is wave-uniform)
+  // stitch the 4 ranges of the chunk (wave 0; control flow is wave-uniform).  Pass 1 walks the records and notes the runs
+  // that close inside the unit (at most one per boundary between two ranges); pass 2 loads their rows TOGETHER and
+  // updates them.
   if (wv != 0) return;
   const bool on = lane < lg;
   bool open = false;
@@ -329,6 +368,10 @@ __device__ __forceinline__ void bwd_reduce_unit(
   float4 osum = tzr_zero4();
   unsigned cf = 0;
   float4 clead = tzr_zero4();
+  uint32_t ck[BWD_WAVES - 1];
+  float4 cs[BWD_WAVES - 1];
+  int nc = 0;
+#pragma unroll
   for (int r = 0; r < BWD_WAVES; ++r) {
     const unsigned f = rflags[r];
     if (f & BWD_LEAD) {
@@ -338,7 +381,13 @@ __device__ __forceinline__ void bwd_reduce_unit(
       if (open) {
         osum = tzr_add4(osum, lv);
         if (!(f & BWD_LEAD_WHOLE)) {
-          bwd_apply_row_wave<ADAM>(tb, opt, lr, okey, osum, lane);
+#pragma unroll
+          for (int q = 0; q < BWD_WAVES - 1; ++q)  // (static indices: the arrays stay in registers)
+            if (q == nc) {
+              ck[q] = okey;
+              cs[q] = osum;
+            }
+          ++nc;
           open = false;
         }
       } else {  // still inside the run inherited from the previous chunk
@@ -352,6 +401,21 @@ __device__ __forceinline__ void bwd_reduce_unit(
       osum = tzr_zero4();
       if (on) osum = make_float4(rtrail[r][4 * lane], rtrail[r][4 * lane + 1], rtrail[r][4 * lane + 2],
                                  rtrail[r][4 * lane + 3]);
+    }
+  }
+  {
+    float4 cw[BWD_WAVES - 1], cm[BWD_WAVES - 1];
+#pragma unroll
+    for (int q = 0; q < BWD_WAVES - 1; ++q) {
+      const bool act = on && q < nc;
+      cw[q] = tzr_zero4();
+      if (act) cw[q] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)ck[q] * tb.w_stride + 4 * lane);
+      cm[q] = bwd_load_state<ADAM>(tb, opt, (int64_t)(q < nc ? ck[q] : 0u), lane, act);
+    }
+#pragma unroll
+    for (int q = 0; q < BWD_WAVES - 1; ++q) {
+      if (q >= nc) break;  // wave-uniform
+      bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)ck[q], lane, cs[q], cw[q], cm[q], on, TZR_WAVE, lane, lane);
     }
   }
   if (open) cf |= BWD_TRAIL;

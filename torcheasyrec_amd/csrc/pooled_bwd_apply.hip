@@ -24,20 +24,6 @@
 
 #include "pooled_bwd_apply.h"
 
-// Boundary record of a unit: written by wave 0 of its workgroup, read by whichever workgroup
-// stitches the table (another CU, usually another XCD): agent-scope stores and loads (tzr_gfx950.h).
-__device__ __forceinline__ void bwd_publish4(float* p, float4 v) {
-  uint64_t* q = reinterpret_cast<uint64_t*>(p);
-  tzr_publish_u64(q, ((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x));
-  tzr_publish_u64(q + 1, ((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z));
-}
-__device__ __forceinline__ float4 bwd_consume4(const float* p) {
-  const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
-  const uint64_t a = tzr_consume_u64(q), b = tzr_consume_u64(q + 1);
-  return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)),
-                     __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32)));
-}
-
 // Runs crossing unit boundaries: the unit holding the run's first lookup adds the leading pieces
 // of the following units (in order) and updates the row.  One wave.
 template <bool ADAM>
@@ -364,7 +350,7 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
 template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
     const TzrTable* __restrict__ tables, int T, const int64_t* __restrict__ row_start,
-    int64_t total_rows, const float* __restrict__ acc, int dim, BwdOpt opt) {
+    int64_t total_rows, float* __restrict__ acc, int dim, BwdOpt opt, int clear) {
   const int lg = dim >> 2;
   const int gw = TZR_WAVE / lg;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
@@ -383,6 +369,9 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
     float nz = (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) ? 1.f : 0.f;
     nz = bwd_group_sum(nz, lg, c, lane);
     const bool active = valid && nz > 0.f;
+    // `clear`: leave the accumulation buffer zero behind the update -- the next step's ACCUMULATE pass writes only the rows
+    // it touches, and a whole-buffer memset in front of it was a launch of its own (4 us of a 0.4 ms sharded step)
+    if (clear && active) tzr_st4(acc + r * (int64_t)dim + 4 * c, tzr_zero4());
     int t = 0;
     int64_t row = 0;
     if (valid) {
@@ -397,10 +386,24 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_dense_rows_update_kernel(
   }
 }
 
+static int dense_rows_update(const TzrTable* d_tables, int n_tables, const int64_t* d_row_start, int64_t total_rows,
+                             float* d_acc, int dim, const TzrSparseOptim* h_optim, int clear, void* stream);
+
 extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
                                      const int64_t* d_row_start, int64_t total_rows,
                                      const float* d_acc, int dim, const TzrSparseOptim* h_optim,
                                      void* stream) {
+  return dense_rows_update(d_tables, n_tables, d_row_start, total_rows, const_cast<float*>(d_acc), dim, h_optim, 0, stream);
+}
+
+extern "C" int tzr_dense_rows_update_clear(const TzrTable* d_tables, int n_tables,
+                                           const int64_t* d_row_start, int64_t total_rows, float* d_acc,
+                                           int dim, const TzrSparseOptim* h_optim, void* stream) {
+  return dense_rows_update(d_tables, n_tables, d_row_start, total_rows, d_acc, dim, h_optim, 1, stream);
+}
+
+static int dense_rows_update(const TzrTable* d_tables, int n_tables, const int64_t* d_row_start, int64_t total_rows,
+                             float* d_acc, int dim, const TzrSparseOptim* h_optim, int clear, void* stream) {
   if (!d_tables || n_tables <= 0 || !d_row_start || total_rows < 0 || !h_optim || !h_optim->d_lr ||
       dim <= 0 || (dim & 3) || dim > BWD_MAXDIM)
     return TZR_ERR_INVALID;
@@ -426,11 +429,11 @@ extern "C" int tzr_dense_rows_update(const TzrTable* d_tables, int n_tables,
   if (opt.kind == TZR_OPT_ADAM) {
     hipLaunchKernelGGL((tzr_dense_rows_update_kernel<true>), dim3(grid), dim3(BWD_THREADS), 0,
                        static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
-                       d_acc, dim, opt);
+                       d_acc, dim, opt, clear);
   } else {
     hipLaunchKernelGGL((tzr_dense_rows_update_kernel<false>), dim3(grid), dim3(BWD_THREADS), 0,
                        static_cast<hipStream_t>(stream), d_tables, n_tables, d_row_start, total_rows,
-                       d_acc, dim, opt);
+                       d_acc, dim, opt, clear);
   }
   TZR_CHECK_LAUNCH();
   return TZR_OK;

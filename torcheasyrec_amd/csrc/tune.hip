@@ -10,6 +10,9 @@ extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
 extern int g_tzr_bwd_debug;
 extern int g_tzr_bwd_apply_waves;
+extern int g_tzr_bwd_direct_ch;
+extern int g_tzr_bwd_direct;
+extern int g_tzr_bwd_direct_debug;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_gen_wgs;
@@ -38,6 +41,18 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_apply_waves")) {
     g_tzr_bwd_apply_waves = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_direct")) {
+    g_tzr_bwd_direct = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_direct_debug")) {
+    g_tzr_bwd_direct_debug = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_direct_ch")) {
+    g_tzr_bwd_direct_ch = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_debug")) {

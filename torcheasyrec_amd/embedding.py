@@ -476,9 +476,30 @@ class EmbeddingBagCollection(nn.Module):
             mult[lk.key] = mult.get(lk.key, 0) + 1
         return kjt.values().numel() * max(mult.values())
 
-    def plan_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> torch.Tensor:
+    def _direct_workspace(self, n_positions: int) -> torch.Tensor:
+        """The persistent workspace of tzr_pooled_bwd_direct (zeroed once: its arrival counters reset themselves; the
+        launches of one collection run in stream order, so one buffer per size serves them all)."""
+        cache = self.__dict__.setdefault("_direct_ws", {})
+        ws = cache.get(n_positions)
+        if ws is None:
+            _, max_dim = self._bwd_dims()
+            # (never evicted: captured hipGraphs replay launches that hold these addresses)
+            ws = cache[n_positions] = _lib.zeroed_workspace(
+                _lib.lib().tzr_pooled_bwd_direct_workspace(n_positions, len(self._configs), max_dim), self._device)
+        return ws
+
+    def backward_is_direct(self, kjt: KeyedJaggedTensor) -> bool:
+        """Small batches skip the index plan: ONE launch sorts and applies (tzr_pooled_bwd_direct,
+        csrc/pooled_bwd_direct.hip) -- when the library takes the shape and the size (tzr_tune "bwd_direct")."""
+        return bool(_lib.lib().tzr_pooled_bwd_direct_supported(self._n_positions(kjt), len(self._lookups), len(self._configs),
+                                                               1 if kjt.uniform_length() == 1 else 0, 0))
+
+    def plan_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> Optional[torch.Tensor]:
         """K6: build the backward index plan for this batch (depends on ids only, so callers may run
-        it early on a side stream).  Returns the workspace holding the plan."""
+        it early on a side stream).  Returns the workspace holding the plan -- None for a batch whose
+        backward needs none (`backward_is_direct`)."""
+        if self.backward_is_direct(kjt):
+            return None
         layout = self._layout_for(dst_names)
         meta = self._meta(kjt.keys(), layout)
         L = _lib.lib()
@@ -506,7 +527,7 @@ class EmbeddingBagCollection(nn.Module):
         """Run K6 on a side HIP stream so it overlaps the forward and the dense MLPs (the reference's
         TrainPipelineSparseDist runs the input dist of the next batch on its own stream for the same
         reason, /root/reference/tzrec/utils/dist_util.py:221-303).  The backward waits on the event."""
-        if self._device.type != "cuda":
+        if self._device.type != "cuda" or self.backward_is_direct(kjt):
             self.plan_backward(kjt, dst_names)
             return
         if self._side_stream is None:
@@ -525,8 +546,11 @@ class EmbeddingBagCollection(nn.Module):
     def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
         if self.fused_optimizer is None:
             return  # frozen tables
+        direct = self.backward_is_direct(kjt)
         cached = getattr(kjt, "_tzr_plan", None)
-        if cached is not None and cached[0] == id(self) and cached[1] == dst_names:
+        if direct:
+            ws = None
+        elif cached is not None and cached[0] == id(self) and cached[1] == dst_names:
             ws = cached[2]
             if cached[3] is not None:
                 torch.cuda.current_stream(self._device).wait_event(cached[3])
@@ -537,7 +561,7 @@ class EmbeddingBagCollection(nn.Module):
         meta = self._meta(kjt.keys(), layout)
         B, N = kjt.stride(), kjt.values().numel()
         uniform, offsets = self._kjt_args(kjt)
-        _, max_dim = self._bwd_dims()
+        max_rows, max_dim = self._bwd_dims()
         widths = [sum(self._out_dim[k] for k in ks) for _, ks in layout]
         gl = []
         for g, w in zip(grads, widths):
@@ -554,15 +578,22 @@ class EmbeddingBagCollection(nn.Module):
         self.fused_optimizer.begin_step(self._device)
         opt = self.fused_optimizer.optim_struct(self._device)
         ev = self._timers.start("apply") if self._timers is not None else None
-        rc = _lib.lib().tzr_pooled_bwd_apply(
-            _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),
-            max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
-            1 if uniform else 0, 0,
-            gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
-        )
+        if direct:
+            dws = self._direct_workspace(self._n_positions(kjt))
+            rc = _lib.lib().tzr_pooled_bwd_direct(
+                _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), max_rows, max_dim,
+                _lib.ptr(kjt.values()), _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
+                1 if uniform else 0, 0, gd, len(gl), opt, _lib.ptr(dws), dws.numel(), _lib.stream_ptr(self._device))
+        else:
+            rc = _lib.lib().tzr_pooled_bwd_apply(
+                _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),
+                max_dim, _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
+                1 if uniform else 0, 0,
+                gd, len(gl), opt, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
+            )
         if ev is not None:
             ev.record()
-        _lib.check(rc, "tzr_pooled_bwd_apply")
+        _lib.check(rc, "tzr_pooled_bwd_direct" if direct else "tzr_pooled_bwd_apply")
         kjt._tzr_plan = None  # type: ignore[attr-defined]
 
     def register_post_lookup_tracker_fn(self, fn) -> None:

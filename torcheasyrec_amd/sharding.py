@@ -729,12 +729,84 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                          n_recv, 1, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_pooled_bwd_plan")
         return ws
 
+    # -- the fused backward of one half (replicas / owned shards): planned pair, or ONE launch for small batches ------
+    def _direct_ws(self, what: str, slot, n_positions: int, n_tables: int) -> torch.Tensor:
+        """persistent zero-initialised workspace of tzr_pooled_bwd_direct (its counters reset themselves); one per half,
+        pipeline slot and size -- never evicted: captured graphs hold the address"""
+        key = ("direct", what, slot, int(n_positions), int(n_tables))
+        hit = self._slot_bufs.get(key)
+        if hit is None:
+            hit = _lib.zeroed_workspace(_lib.lib().tzr_pooled_bwd_direct_workspace(n_positions, n_tables, self.dim), self._device)
+            self._slot_bufs[key] = hit
+        return hit
+
+    def _dp_direct(self, st: dict) -> bool:
+        kjt, rm = st["kjt"], st["rm"]
+        uniform = st["uniform"]
+        NP = rm["dp_n"] * kjt.stride() if uniform else kjt.values().numel()
+        return bool(_lib.lib().tzr_pooled_bwd_direct_supported(NP, rm["dp_n"], len(self._dp), 1 if uniform else 0, 0))
+
+    def _rw_direct(self, st: dict) -> bool:
+        om = st["om"]
+        return bool(_lib.lib().tzr_pooled_bwd_direct_supported(st["n_recv"], om["K"], om["T"], 0, 1))
+
+    def _bwd_dp(self, st: dict, gd, n_dst: int) -> None:
+        """replicated tables: exact per-row gradient sums of my samples into `_dp_acc` (ACCUMULATE)"""
+        L, dev, D = _lib.lib(), self._device, self.dim
+        kjt, rm, uniform = st["kjt"], st["rm"], st["uniform"]
+        B, N_all, n_dp, T_dp = kjt.stride(), kjt.values().numel(), rm["dp_n"], len(self._dp)
+        NP = n_dp * B if uniform else N_all
+        offsets = None if uniform else kjt.offsets()
+        stream = _lib.stream_ptr(dev)
+        if self._dp_direct(st):
+            ws = self._direct_ws("dp", st.get("slot") if "cap" in st else None, NP, T_dp)
+            _lib.check(L.tzr_pooled_bwd_direct(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_bwd_feats"]), n_dp,
+                                               rm["dp_max_rows"], D, _lib.ptr(kjt.values()), _lib.ptr(offsets),
+                                               _lib.ptr(kjt.weights_or_none()), N_all, NP, B, 1 if uniform else 0, 0, gd, n_dst,
+                                               self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
+                       "tzr_pooled_bwd_direct")
+            return
+        ws = st.get("ws_dp")
+        if ws is None:
+            ws = st["ws_dp"] = self._plan_dp(st)
+        _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_bwd_feats"]), n_dp, T_dp, D,
+                                          _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N_all, NP, B,
+                                          1 if uniform else 0, 0, gd, n_dst,
+                                          self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
+                   "tzr_pooled_bwd_apply")
+
+    def _bwd_rw(self, st: dict, grecv: torch.Tensor) -> None:
+        """owned shards: sort by (table, row) + fused optimizer over the received per-id gradient rows"""
+        L, dev, D = _lib.lib(), self._device, self.dim
+        om, n_recv = st["om"], st["n_recv"]
+        if n_recv <= 0:
+            return
+        K, T = om["K"], om["T"]
+        stream = _lib.stream_ptr(dev)
+        g1 = (_lib.TzrDst * 1)()
+        g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
+        ids = st.get("owner_ids", st["recv_ids"])
+        if self._rw_direct(st):
+            ws = self._direct_ws("rw", st.get("slot") if "cap" in st else None, n_recv, T)
+            _lib.check(L.tzr_pooled_bwd_direct(_lib.ptr(om["d_bwd_tables"]), T, _lib.ptr(om["d_bwd_feats"]), K, om["max_rows"], D,
+                                               _lib.ptr(ids), _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
+                                               self._optim_struct(), _lib.ptr(ws), ws.numel(), stream), "tzr_pooled_bwd_direct")
+            return
+        ws2 = st.get("ws_rw")
+        if ws2 is None:
+            ws2 = st["ws_rw"] = self._plan_rw(st)
+        _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), K, T, D,
+                                          _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
+                                          self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream), "tzr_pooled_bwd_apply")
+
     def plan_ahead(self, st: dict) -> dict:
+        """K6 of both halves, for a pipeline to run a batch ahead -- for the halves that have a plan at all (a small
+        batch's backward is one launch without one: `_dp_direct` / `_rw_direct`)"""
         if self.fused_optimizer is not None:
-            if "dp_n" in st["rm"]:
+            if "dp_n" in st["rm"] and not self._dp_direct(st):
                 st["ws_dp"] = self._plan_dp(st)
             # (hash-routed tables: the row ids only exist after the owner's remap in `lookup`)
-            if "rw_n" in st["rm"] and st.get("n_recv", 0) > 0 and self._owner_remap is None:
+            if "rw_n" in st["rm"] and st.get("n_recv", 0) > 0 and self._owner_remap is None and not self._rw_direct(st):
                 st["ws_rw"] = self._plan_rw(st)
         return st
 
@@ -788,38 +860,17 @@ class ShardedEmbeddingBagCollection(nn.Module):
             w_rows = self._a2a(grecv[:n_recv], grow[:n_out], st["recv_splits"], st["send_splits"], async_op=True)
         if "dp_n" in rm:
             # replicas: exact per-row gradient sums of my samples -> all-reduce -> same dense update
-            N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
-            offsets = None if uniform else kjt.offsets()
-            self._dp_acc.zero_()
-            NP = n_dp * B if uniform else N_all
-            ws = st.get("ws_dp")
-            if ws is None:
-                ws = self._plan_dp(st)
-            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_bwd_feats"]), n_dp, T_dp, D,
-                                              _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N_all, NP, B,
-                                              1 if uniform else 0, 0, gd, len(gl),
-                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
-                       "tzr_pooled_bwd_apply")
+            self._bwd_dp(st, gd, len(gl))  # (`_dp_acc` is zero: tzr_dense_rows_update_clear leaves it so)
             w_acc = dist.all_reduce(self._dp_acc, group=self.pg, async_op=True)
         if w_rows is not None:
             w_rows.wait()
             # owner: sort by (table,row) + fused optimizer, gradients addressed per id
-            if n_recv > 0:
-                K, T = om["K"], om["T"]
-                ws2 = st.get("ws_rw")
-                if ws2 is None:
-                    ws2 = self._plan_rw(st)
-                g1 = (_lib.TzrDst * 1)()
-                g1[0].ptr, g1[0].stride = _lib.ptr(grecv), grecv.stride(0)
-                _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), K, T, D,
-                                                  _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
-                                                  self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream),
-                           "tzr_pooled_bwd_apply")
+            self._bwd_rw(st, grecv)
         if w_acc is not None:
             w_acc.wait()
-            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
+            _lib.check(L.tzr_dense_rows_update_clear(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
-                       "tzr_dense_rows_update")
+                       "tzr_dense_rows_update_clear")
         self._after_backward(st)
 
     def _after_backward(self, st: dict) -> None:
@@ -926,15 +977,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if "dp_n" in rm:
             gl = st["_grads_alive"]
             gd = self._dst_array(gl, B, rm["widths"])
-            N_all, n_dp, T_dp = kjt.values().numel(), rm["dp_n"], len(self._dp)
-            self._dp_acc.zero_()
-            ws = st.get("ws_dp")
-            if ws is None:
-                ws = st["ws_dp"] = self._plan_dp(st)
-            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(rm["dp_d_acc_tables"]), _lib.ptr(rm["dp_d_bwd_feats"]), n_dp, T_dp, D,
-                                              None, None, N_all, n_dp * B, B, 1, 0, gd, len(gl),
-                                              self._optim_struct(_lib.OPT_ACCUMULATE), _lib.ptr(ws), ws.numel(), stream),
-                       "tzr_pooled_bwd_apply")
+            self._bwd_dp(st, gd, len(gl))  # (`_dp_acc` is zero: tzr_dense_rows_update_clear leaves it so)
 
     def coll_grads(self, st: dict) -> None:
         self.coll_grads_rw(st)
@@ -969,15 +1012,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         L, dev, D = _lib.lib(), self._device, self.dim
         rm, stream = st["rm"], _lib.stream_ptr(dev)
         if "rw_n" in rm:
-            om, n_recv = st["om"], st["n_recv"]
-            ws2 = st.get("ws_rw")
-            if ws2 is None:
-                ws2 = st["ws_rw"] = self._plan_rw(st)
-            g1 = (_lib.TzrDst * 1)()
-            g1[0].ptr, g1[0].stride = _lib.ptr(st["grecv"]), st["grecv"].stride(0)
-            _lib.check(L.tzr_pooled_bwd_apply(_lib.ptr(om["d_bwd_tables"]), _lib.ptr(om["d_bwd_feats"]), om["K"], om["T"], D,
-                                              _lib.ptr(st["key_start"]), None, n_recv, n_recv, 1, 0, 1, g1, 1,
-                                              self._optim_struct(), _lib.ptr(ws2), ws2.numel(), stream), "tzr_pooled_bwd_apply")
+            self._bwd_rw(st, st["grecv"])
 
     def seg_apply_dp(self, st: dict) -> None:
         """second half: needs the all-reduced row sums of the replicated tables"""
@@ -986,9 +1021,9 @@ class ShardedEmbeddingBagCollection(nn.Module):
         L, dev, D = _lib.lib(), self._device, self.dim
         rm, stream = st["rm"], _lib.stream_ptr(dev)
         if "dp_n" in rm:
-            _lib.check(L.tzr_dense_rows_update(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
+            _lib.check(L.tzr_dense_rows_update_clear(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
-                       "tzr_dense_rows_update")
+                       "tzr_dense_rows_update_clear")
         self._after_backward(st)
 
     # -- public API ------------------------------------------------------------------------------
