@@ -135,6 +135,29 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def sharded_proxy(args) -> dict:
+    """`python bench.py --force-sharded --replicate-small --global-batch 8192` as a child: the row-wise sharded step of ONE
+    rank at 8192 samples per rank (the per-rank work of the 8-GPU job at global batch 65536) on a 1-rank RCCL group --
+    every kernel and RCCL call of the step runs, the collectives are self copies -- and the scaling projection it
+    implies.  A process of its own, so that nothing of it (a second set of tables, the process group) can touch the
+    parent's line."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--replicate-small", "--global-batch", "8192",
+           "--steps", str(max(args.steps, 40)), "--warmup", "12", "--no-cpu-baseline", "--no-e2e", "--projection-world", "8"]
+    try:
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
+                            env=dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300)))
+        child = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"config": "row-wise sharded step of ONE rank at 8192 samples per rank on a 1-rank RCCL group (the per-rank work of "
+                          "the 8-GPU job at global batch 65536); collectives are self copies; measured in a child process before "
+                          "this process touched the GPU",
+                "ms_per_step": child["ms_per_step"], "launch": child["launch"], "parallelism": child["config"]["parallelism"],
+                "exchange": child.get("exchange"), "projection": child.get("projection"), "collectives": child.get("collectives")}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+
+
 def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_ms_per_global_step=None, capacity_factor=1.25):
     """The scaling arithmetic of the sharded step: what `step_ms` -- this run's time for ONE rank's
     share of the step at `B_local` samples per rank -- means at `world_target` ranks, with the bytes SURVEY 8(d) counts
@@ -361,6 +384,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus} (or plainly as `python bench.py --gpus {args.gpus}`)")
     emu = args.emulator
+    # N = 1 default line: the 8192-per-rank sharded step on a 1-rank RCCL group, in a child process that runs BEFORE this
+    # process touches the GPU (two processes on one GPU time-slice its queues: 0.50 ms measured next to an idle parent
+    # against 0.36 ms alone, profiles/r04l)
+    proxy_child = None
+    if (world == 1 and args.gpus == 1 and not emu and not args.force_sharded and not args.no_secondary and not args.no_sharded_proxy
+            and args.optimizer == "adagrad" and args.dist == "uniform" and not args.rows_cap and args.global_batch == 65536
+            and args.scaling == "strong"):
+        proxy_child = sharded_proxy(args)
     if emu:
         args.rows_cap = args.rows_cap or 2000
         args.no_graph = args.no_e2e = args.no_secondary = True
@@ -558,6 +589,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = run_step(args.warmup + i)
+    host_elapsed = time.perf_counter() - t0  # time the HOST needed to queue the steps (no wait for the GPU in it)
     sync()
     if world > 1:
         dist.barrier()
@@ -769,27 +801,18 @@ def main():
         except Exception as e:
             secondary["interaction_first_layer_mfma"] = {"error": repr(e)[:200]}
 
-    # (e) the 8192-per-rank SHARDED step on a 1-rank RCCL group (every kernel and RCCL call of one rank of the 8-GPU job; the
-    # all-to-alls are self copies) + the scaling projection it implies -- in a child process, so that nothing of it (a
-    # second set of tables, the process group) can touch this process's line
-    if isinstance(secondary, dict) and "config2_batch8192" in secondary and not args.no_sharded_proxy:
-        import subprocess
-
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--replicate-small", "--global-batch", "8192",
-               "--steps", str(max(args.steps, 30)), "--warmup", "12", "--no-cpu-baseline", "--no-e2e",
-               "--n1-ms", repr(elapsed / args.steps * 1e3), "--projection-world", "8"]
-        try:
-            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
-                                env=dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300)))
-            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1]
-            child = json.loads(line)
-            secondary["sharded_w1_proxy_b8192"] = {
-                "config": "row-wise sharded step of ONE rank at 8192 samples per rank on a 1-rank RCCL group (the per-rank work of "
-                          "the 8-GPU job at global batch 65536); collectives are self copies",
-                "ms_per_step": child["ms_per_step"], "launch": child["launch"], "parallelism": child["config"]["parallelism"],
-                "exchange": child.get("exchange"), "projection": child.get("projection"), "collectives": child.get("collectives")}
-        except Exception as e:
-            secondary["sharded_w1_proxy_b8192"] = {"error": repr(e)[:300]}
+    # (e) the sharded proxy measured at the start of this process (see sharded_proxy): ratios against THIS run's N = 1 step
+    if isinstance(secondary, dict) and proxy_child is not None:
+        if "projection" in proxy_child:
+            pj = proxy_child["projection"]
+            n1_ms = elapsed / args.steps * 1e3
+            n1 = B_global / (n1_ms * 1e-3)
+            pj["n1_samples_per_s"] = n1
+            pj["scaling_vs_n1"] = {k2: pj[k1] / n1 for k1, k2 in (("samples_per_s_if_wire_hidden", "wire_hidden"),
+                                                                   ("samples_per_s_if_a2a_exposed", "a2a_exposed"),
+                                                                   ("samples_per_s_if_wire_exposed", "wire_exposed"))}
+            pj["step_ms_needed_for_6x"] = n1_ms / 6.0
+        secondary["sharded_w1_proxy_b8192"] = proxy_child
 
     # inside a captured graph); the kernels and inputs are the ones of the timed region
     if ebc is not None and not emu:
@@ -816,7 +839,8 @@ def main():
         "metric": f"samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch {args.global_batch} "
                   + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+        "ms_per_step": ms_per_step, "host_queue_ms_per_step": host_elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" if not emu else "synthetic -- CPU LANE EMULATOR + gloo, tables capped: launch-path plumbing check, not a measurement",
         "ranks_seen": ranks_seen, "collectives": coll_lib,

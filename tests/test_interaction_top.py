@@ -104,6 +104,45 @@ def test_interaction_top_loss_matches_unfused(dev, B):
         _close(p.grad, w, 1e-5)
 
 
+@pytest.mark.parametrize("fused_interaction", [True, False])
+def test_root_loss_skips_the_unit_scaling_and_nothing_else(dev, fused_interaction, monkeypatch):
+    """`dense.root_loss()`: when the fused loss itself is differentiated its incoming gradient is 1.0; the multi-tensor
+    launch that multiplies the six parameter gradients by it is skipped -- on the autograd ENGINE's thread, where the
+    backward of device tensors runs -- and every gradient stays bit-identical."""
+    from torcheasyrec_amd import dense as dn
+    from torcheasyrec_amd.interaction import dot_interaction
+
+    D, F, B = 16, 26, 40
+    torch.manual_seed(9)
+    width = 27 * 26 // 2 + 27 * D
+    l1, l2, lo = torch.nn.Linear(width, 64).to(dev), torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 1).to(dev)
+    x_d, x_s = torch.randn(B, D, device=dev, requires_grad=True), torch.randn(B, F * D, device=dev, requires_grad=True)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+    ps = [x_d, x_s, l1.weight, l1.bias, l2.weight, l2.bias, lo.weight, lo.bias]
+
+    def loss_of():
+        if fused_interaction:
+            return dn.interaction_top_loss(x_d, x_s, D, l1, l2, lo, y)[0]
+        return dn.top_loss(dot_interaction(x_d, x_s, D, True, True), l1, l2, lo, y)[0]
+
+    calls = {"n": 0}
+    real = torch._foreach_mul
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(torch, "_foreach_mul", counted)
+    want = torch.autograd.grad(loss_of(), ps)
+    assert calls["n"] == 1
+    with dn.root_loss():
+        got = torch.autograd.grad(loss_of(), ps)
+    assert calls["n"] == 1  # not called again
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not dn._loss_is_root()
+
+
 def test_dlrm_predict_without_grad_uses_fused_first_layer(dev):
     """Inference (torch.no_grad) runs interaction + first top layer fused; logits equal the layer-wise path."""
     from torcheasyrec_amd.criteo import SPARSE_KEYS, criteo_tables, synthetic_batch

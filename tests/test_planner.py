@@ -248,3 +248,20 @@ def test_hierarchical_types_have_their_single_node_meaning():
     assert (p["c"]["sharding_type"], p["c"]["shard_dim"], len(p["c"]["ranks"])) == ("table_column_wise", 4, 4)
     with pytest.raises(PlannerError, match="across hosts"):
         plan_tables(tabs, Topology(8, local_world_size=4), 256, constraints={"g": ["grid_shard"]})
+
+
+def test_rowwise_adagrad_state_is_priced_as_allocated():
+    """under the default interleaved row layout a row-wise Adagrad table holds a second D-wide half per row
+    (its scalar state next to the weights): the storage estimate must count it, or plans that pass the HBM check OOM.
+    split layout and FP16 tables keep the [rows] state array."""
+    from torcheasyrec_amd.planner import EmbeddingEnumerator, TableSpec, Topology
+
+    en = EmbeddingEnumerator(Topology(2), 1024)
+    rows, D = 1_000_000, 16
+    inter = TableSpec("t", rows, D, ["f"], optimizer="rowwise_adagrad")
+    split = TableSpec("t", rows, D, ["f"], optimizer="rowwise_adagrad", row_layout="split")
+    half = TableSpec("t", rows, D, ["f"], optimizer="rowwise_adagrad", bytes_per_element=2)
+    assert en._state_bytes(inter, rows) == rows * D * 4
+    assert en._state_bytes(split, rows) == rows * 4 and en._state_bytes(half, rows) == rows * 4
+    tw = {o.sharding_type: o for o in en.enumerate([inter])}["table_wise"]
+    assert tw.shards[0].storage.hbm >= 2 * rows * D * 4  # weights + the padded state half

@@ -163,13 +163,22 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
   // memory latency per workgroup instead of one per element
   constexpr int kRounds = BWD_CH / BWD_THREADS;
   uint32_t kreg[kRounds];
+  if (tb.n_feats == 1) {  // (workgroup-uniform) one key reads the table: unconditional loads, see bwd_elem_one
+    const BwdOneSeg sg = bwd_one_seg(G, tb, A);
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int64_t p = cd.s + (int64_t)r * BWD_THREADS + threadIdx.x;
-    uint32_t sv;
-    int64_t kk;
-    kreg[r] = 0u;
-    if (p < cd.e) bwd_elem0(G, tb, A, p, &kreg[r], &sv, &kk);
+    for (int r = 0; r < kRounds; ++r) {
+      uint32_t sv;
+      bwd_elem_one(sg, tb, A, cd.s + (int64_t)r * BWD_THREADS + threadIdx.x, cd.e, &kreg[r], &sv);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int64_t p = cd.s + (int64_t)r * BWD_THREADS + threadIdx.x;
+      uint32_t sv;
+      int64_t kk;
+      kreg[r] = 0u;
+      if (p < cd.e) bwd_elem0(G, tb, A, p, &kreg[r], &sv, &kk);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -365,18 +374,31 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
   const int rounds = pw / TZR_WAVE;
   uint32_t kreg[kRounds], sreg[kRounds], dig[kRounds], dest[kRounds];
   uint32_t vmask = 0;
+  if (tb.n_feats == 1 && A.uniform) {  // (workgroup-uniform) one key, one id per bag: unconditional loads, see bwd_elem_one
+    const BwdOneSeg sg = bwd_one_seg(G, tb, A);
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int lp = wv * pw + r * TZR_WAVE + lane;
-    kreg[r] = sreg[r] = dig[r] = 0u;
-    if (r < rounds && lp < n) {
-      vmask |= 1u << r;
-      int64_t kk;
-      bwd_elem0(G, tb, A, cd.s + lp, &kreg[r], &sreg[r], &kk);
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      // (every round loads, also the ones past this chunk's `rounds`: a condition on a value read from memory is a
+      // divergent branch to the compiler, and a branch between two loads is a wait between them)
+      bwd_elem_one(sg, tb, A, cd.s + lp, cd.e, &kreg[r], &sreg[r]);
       dig[r] = bwd_bucket(kreg[r], cd.mult);
-      if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
-        const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[r]);
-        P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
+      vmask |= (r < rounds && lp < n) ? 1u << r : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int lp = wv * pw + r * TZR_WAVE + lane;
+      kreg[r] = sreg[r] = dig[r] = 0u;
+      if (r < rounds && lp < n) {
+        vmask |= 1u << r;
+        int64_t kk;
+        bwd_elem0(G, tb, A, cd.s + lp, &kreg[r], &sreg[r], &kk);
+        dig[r] = bwd_bucket(kreg[r], cd.mult);
+        if (!A.uniform) {  // bag of every lookup, once (same value from every table a key feeds)
+          const int64_t b = tzr_last_le(A.offsets + kk * A.B, A.B, (int64_t)sreg[r]);
+          P.bag_of[sreg[r]] = (uint32_t)(kk * A.B + b);
+        }
       }
     }
   }
@@ -440,11 +462,12 @@ __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ table
     kreg[r] = sreg[r] = bkt[r] = 0u;
     hbefore[r] = 0;
     const bool in = r < rounds && lp < n;
-    if (in) {
-      const uint2 v = src[lp];
-      kreg[r] = v.x;
-      sreg[r] = v.y;
-      bkt[r] = bwd_bucket(v.x, cd.mult);
+    {  // (the position is clamped, the load unconditional: `if (in) v = src[lp]` per round compiled to one dependent
+       // round trip per round -- see bwd_elem_one)
+      const uint2 v = src[lp < n ? lp : n - 1];
+      kreg[r] = in ? v.x : 0u;
+      sreg[r] = in ? v.y : 0u;
+      bkt[r] = in ? bwd_bucket(v.x, cd.mult) : 0u;
     }
     if (r < rounds) {
       const uint32_t hw = (uint32_t)__shfl((int)hword, (int)(bkt[r] >> 5), TZR_WAVE);

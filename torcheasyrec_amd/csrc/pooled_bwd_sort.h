@@ -103,6 +103,32 @@ __device__ __forceinline__ void bwd_elem0(const BwdGeo& G, const TzrTable& tb, c
   *kjt_key_out = key;
 }
 
+// The same for a table read by ONE key (nearly every table), BRANCH-FREE.  `if (p < end) bwd_elem0(...)` per element
+// compiles to branch / load / s_waitcnt vmcnt(0) per element (and, with the geometry in global memory, to a chain of
+// three dependent loads per element: key, bag offset, id): the "independent loads in flight" of the hist / scatter
+// kernels ran as 4 .. 12 dependent L2 round trips (found with the one-launch backward, profiles/r04i).  Here the key and
+// the segment base are resolved once per workgroup, the position is clamped below `end` (> the segment's start), the id
+// load is unconditional; the caller masks positions >= end.
+struct BwdOneSeg {
+  int64_t ts, fbase;
+};
+__device__ __forceinline__ BwdOneSeg bwd_one_seg(const BwdGeo& G, const TzrTable& tb, const BwdSrcArgs& A) {
+  BwdOneSeg g;
+  const int64_t key = G.fkey[tb.first_order];
+  g.ts = (int64_t)G.fstart[tb.first_order];
+  g.fbase = A.uniform ? key * A.B : A.offsets[key * A.B];
+  return g;
+}
+__device__ __forceinline__ void bwd_elem_one(const BwdOneSeg& g, const TzrTable& tb, const BwdSrcArgs& A, int64_t p,
+                                             int64_t end, uint32_t* key_out, uint32_t* src_out) {
+  const int64_t pc = p < end ? p : end - 1;
+  const int64_t i = g.fbase + (pc - g.ts);
+  int64_t id = A.values[i];
+  if ((uint64_t)id >= (uint64_t)tb.rows) id = 0;  // memory safety; K4 reports/clamps
+  *key_out = (uint32_t)id;
+  *src_out = (uint32_t)i;
+}
+
 // counts[d] += number of valid lanes with digit d, one LDS atomic per distinct digit of the wave
 // (a hot row id is every lane's digit: per-lane atomics on one address serialise)
 __device__ __forceinline__ void bwd_wave_count(unsigned* counts, uint32_t d, bool v, int wbits,

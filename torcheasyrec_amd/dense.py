@@ -10,7 +10,6 @@ tests compare against torch to 1e-6.
 from __future__ import annotations
 
 import contextlib
-import threading
 from typing import Iterable, List, Optional
 
 import torch
@@ -104,7 +103,9 @@ def weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return g.t() @ x
 
 
-_ROOT_LOSS = threading.local()
+# (a process-wide counter, not a thread-local: autograd runs the backward of device tensors on its own engine thread,
+# which would never see the caller's thread-local -- the first version of this switch did nothing, profiles/r04m)
+_ROOT_LOSS = {"on": 0}
 
 
 @contextlib.contextmanager
@@ -113,16 +114,15 @@ def root_loss():
     ITSELF, so the gradient arriving at `_TopLossFn` / `_InteractionTopLossFn` is autograd's 1.0 and the multi-tensor
     launch that scales the six parameter gradients by it (9 us per step) is skipped.  Not for a scaled loss (GradScaler,
     gradient accumulation's 1/steps, a weighted sum of several losses): there the scale is real."""
-    prev = getattr(_ROOT_LOSS, "on", False)
-    _ROOT_LOSS.on = True
+    _ROOT_LOSS["on"] += 1
     try:
         yield
     finally:
-        _ROOT_LOSS.on = prev
+        _ROOT_LOSS["on"] -= 1
 
 
 def _loss_is_root() -> bool:
-    return getattr(_ROOT_LOSS, "on", False)
+    return _ROOT_LOSS["on"] > 0
 
 
 class _Mlp2Fn(torch.autograd.Function):
@@ -372,6 +372,9 @@ class FusedDenseAdam:
         g = self.param_groups[0]
         if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             self.sync_lr()
+        elif g["lr"] != self._lr_host:  #  a capture would freeze the stale rate into the graph
+            raise RuntimeError("learning rate changed since the last sync and a hipGraph capture is open: call "
+                               "dense.sync_learning_rates(model, optimizer) before capturing / replaying (INTEGRATION.md)")
         rows = []
         for i, p in enumerate(self.params):
             gr = p.grad if grads is None else grads[i]
@@ -406,26 +409,48 @@ class FusedDenseAdam:
             self.param_groups[0][k] = v
 
 
-def sync_learning_rates(model, optimizer=None) -> None:
+def lr_sync_targets(model, optimizer=None) -> list:
+    """Every object with a `sync_lr()` reachable from the model's collections (their fused sparse optimizers) and from the
+    dense optimizer behind its wrappers (`_optimizer` chains, `_optims` / `optimizers` lists of combined optimizers) --
+    collected ONCE; a train step iterates the list (walking `model.modules()` every step was host time on the
+    hot path, and a combined optimizer's sub-optimizers were never reached)."""
+    out, seen = [], set()
+
+    def add(o):
+        if o is not None and id(o) not in seen and hasattr(o, "sync_lr"):
+            seen.add(id(o))
+            out.append(o)
+
+    for m in (list(model.modules()) if hasattr(model, "modules") else []):
+        try:
+            add(getattr(m, "fused_optimizer", None))
+        except Exception:
+            pass
+        for lane in ("local", "replica"):  # the two halves of a sharded collection hold their own
+            sub = getattr(m, lane, None)
+            if sub is not None:
+                add(getattr(sub, "fused_optimizer", None))
+    stack, hops = [optimizer], 0
+    while stack and hops < 64:
+        opt = stack.pop()
+        hops += 1
+        if opt is None:
+            continue
+        add(opt)
+        stack.append(getattr(opt, "_optimizer", None))
+        for name in ("_optims", "optimizers"):
+            subs = getattr(opt, name, None)
+            if isinstance(subs, (list, tuple)):
+                stack.extend(o[1] if isinstance(o, tuple) else o for o in subs)
+            elif isinstance(subs, dict):
+                stack.extend(subs.values())
+    return out
+
+
+def sync_learning_rates(model, optimizer=None, targets: Optional[list] = None) -> None:
     """Before replaying a hipGraph that contains update kernels: copy every learning rate a scheduler may have changed
     (fused sparse optimizers of the model's collections, the dense optimizer behind its wrappers) into the device
-    scalars the captured kernels read.  No-ops when nothing changed; never call it under capture."""
-    seen = set()
-    mods = list(model.modules()) if hasattr(model, "modules") else []
-    for m in mods:
-        for name in ("fused_optimizer",):
-            try:
-                fo = getattr(m, name, None)
-            except Exception:
-                fo = None
-            if fo is not None and id(fo) not in seen and hasattr(fo, "sync_lr"):
-                seen.add(id(fo))
-                fo.sync_lr()
-    opt = optimizer
-    hops = 0
-    while opt is not None and hops < 8:
-        if hasattr(opt, "sync_lr"):
-            opt.sync_lr()
-            break
-        opt = getattr(opt, "_optimizer", None)
-        hops += 1
+    scalars the captured kernels read.  No-ops when nothing changed; never call it under capture.  `targets`: the cached
+    result of `lr_sync_targets` (train steps collect it once)."""
+    for o in (targets if targets is not None else lr_sync_targets(model, optimizer)):
+        o.sync_lr()

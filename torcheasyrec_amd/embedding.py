@@ -122,12 +122,20 @@ class FusedSparseOptimizer:
         """The device scalar the update kernels read.  Outside a graph capture it is refreshed from
         ``param_groups[0]["lr"]`` here; UNDER capture nothing is written (a captured ``fill_`` would reset the
         learning rate on every replay): whoever replays graphs calls ``sync_lr`` before each replay."""
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if self._lr_dev is None or self._lr_dev.device != device:
+            if capturing:  # (ADVICE r3: the allocation + fill would be captured and replayed)
+                raise RuntimeError("the fused sparse optimizer's device learning rate does not exist yet: run one eager step "
+                                   "(or call fused_optimizer.sync_lr(device)) before capturing a graph with update kernels")
             lr = float(self.param_groups[0]["lr"])
             self._lr_dev = torch.full((1,), lr, dtype=torch.float32, device=device)
             self._lr_host = lr
-        elif not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        elif not capturing:
             self.sync_lr(device)
+        elif float(self.param_groups[0]["lr"]) != self._lr_host:
+            # a scheduler moved the rate and nobody mirrored it: the captured kernels would train with the stale one
+            raise RuntimeError("learning rate changed since the last sync and a hipGraph capture is open: call "
+                               "dense.sync_learning_rates(model, optimizer) before capturing / replaying (INTEGRATION.md)")
         return self._lr_dev
 
     def sync_lr(self, device: Optional[torch.device] = None) -> None:

@@ -203,7 +203,8 @@ class EmbeddingGroup(nn.Module):
 
             cons = {t: list(self._table_sharding_types.get(t) or self._global_sharding_types) for t in configs}
             kind = sparse_optimizer.kind if sparse_optimizer is not None else "sgd"
-            self._plan_in = plan_tables([TableSpec(c.name, c.num_embeddings, c.embedding_dim, list(c.feature_names), optimizer=kind)
+            self._plan_in = plan_tables([TableSpec(c.name, c.num_embeddings, c.embedding_dim, list(c.feature_names), optimizer=kind,
+                                                   bytes_per_element=2 if str(getattr(c, "data_type", "FP32")).upper() == "FP16" else 4)
                                          for c in configs.values()], Topology(dist.get_world_size(self._pg)), max(int(batch_size), 1),
                                         constraints={t: v for t, v in cons.items() if v})
         if self.has_sparse and self._pg is not None:
@@ -613,9 +614,11 @@ class GraphTrainPipeline:
         batch = self._slots[slot]
         if self._stage_first:
             self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
-        from .dense import sync_learning_rates
+        from .dense import lr_sync_targets, sync_learning_rates
 
-        sync_learning_rates(self._model, self._opt)  # outside capture: the graphs read the rates from device scalars
+        if getattr(self, "_lr_targets", None) is None:
+            self._lr_targets = lr_sync_targets(self._model, self._opt)
+        sync_learning_rates(self._model, self._opt, self._lr_targets)  # outside capture: the graphs read the rates from device scalars
         if self._graphs[slot] is None and self._seen[slot] >= self._warmup:
             g = torch.cuda.CUDAGraph()
             # capture on the caller's stream when it is a side stream (autograd's accumulation nodes and the

@@ -122,6 +122,10 @@ class TableSpec:
     pooling_factor: float = 1.0  # ids per bag
     optimizer: str = "adagrad"  # adagrad | rowwise_adagrad | sgd
     bytes_per_element: int = 4
+    # storage layout of the collection the plan is for (EmbeddingBagCollection(row_layout=...), default "interleaved"):
+    # interleaved fp32 rows are [w(D) | state] with a 2 D row stride -- ALSO for row-wise Adagrad, whose one scalar per
+    # row then occupies D floats of padding (embedding.py: the state sits in the sector next to its weights)
+    row_layout: str = "interleaved"
 
 
 class EmbeddingEnumerator:
@@ -132,12 +136,21 @@ class EmbeddingEnumerator:
     def __init__(self, topology: Topology, batch_size: int, constraints: Optional[Dict[str, Sequence[str]]] = None) -> None:
         self.topology, self.batch_size, self.constraints = topology, int(batch_size), constraints or {}
 
-    def _state_bytes(self, t: TableSpec, rows: int) -> int:
+    @staticmethod
+    def _state_bytes_dim(t: TableSpec, rows: int, dim: int) -> int:
+        """optimizer-state bytes of `rows` rows of `dim` columns AS ALLOCATED (the planner priced row-wise
+        Adagrad at 4 bytes per row while the default interleaved layout allocates a second D-wide half per row)"""
         if t.optimizer == "adagrad":
-            return rows * t.embedding_dim * 4
+            return rows * dim * 4
         if t.optimizer == "rowwise_adagrad":
-            return rows * 4
+            padded = t.row_layout == "interleaved" and t.bytes_per_element == 4  # (FP16 tables are never interleaved)
+            return rows * dim * 4 if padded else rows * 4
+        if t.optimizer == "adam":
+            return rows * dim * 8
         return 0
+
+    def _state_bytes(self, t: TableSpec, rows: int) -> int:
+        return self._state_bytes_dim(t, rows, t.embedding_dim)
 
     # torchrec's hierarchical types priced with their single-node meaning (sharding.MixedShardedEmbeddingBagCollection)
     _SINGLE_NODE_ALIAS = {"table_row_wise": "row_wise", "table_column_wise": "column_wise"}
@@ -208,8 +221,7 @@ class EmbeddingEnumerator:
             piece_rmw = 2 * piece_b + 2 * (d * 4 if t.optimizer == "adagrad" else 4 if t.optimizer == "rowwise_adagrad" else 0)
             wire = (n * (8 + 2 * piece_b) * (W - 1) / W) / top.a2a_bw
             perf = n * piece_b / top.hbm_gather_bw + n * piece_rmw / top.hbm_rmw_bw + wire + 3 * top.collective_latency
-            st = t.num_embeddings * piece_b + (t.num_embeddings * d * 4 if t.optimizer == "adagrad" else
-                                                t.num_embeddings * 4 if t.optimizer == "rowwise_adagrad" else 0)
+            st = t.num_embeddings * piece_b + self._state_bytes_dim(t, t.num_embeddings, d)
             shards = [Shard((t.num_embeddings, d), (0, j * d), Storage(st + int(n * (8 + 2 * piece_b))), perf) for j in range(k)]
         else:
             raise PlannerError(f"{t.name}: sharding type {kind!r} is not executable by this runtime")

@@ -146,6 +146,7 @@ class ShardedTrainStep:
         # (round 2 set tzr_tune("bwd_one_wg_heavy") here for its side-stream plans; round 3 could not reproduce that
         # failure -- round 2's own binary passes 200 / 200 on the round-3 boxes, the current one 3 000 iterations in
         # every stream arrangement, NOTES.md "Side-stream plan" -- and the knob is gone from the default path)
+        self._lr_targets = None  # objects whose learning rate is mirrored to the device before a replay (collected once)
         self._ahead: Optional[tuple] = None  # (kjt, state) of the batch whose input dist already ran
         # whole-step graphs: static inputs + one captured graph per pipeline slot
         self.step_graph = bool(step_graph)
@@ -367,13 +368,12 @@ class ShardedTrainStep:
         `next_kjt` lets the input dist of the following batch overlap this one."""
         model, ebc = self.model, self.model.ebc
         if self.cuda:  # the captured update kernels read learning rates from device scalars: refresh them outside capture
-            from .dense import sync_learning_rates
+            if self._lr_targets is None:
+                from .dense import lr_sync_targets
 
-            sync_learning_rates(model, self.opt)
-            for lane in (getattr(ebc, "local", None), getattr(ebc, "replica", None)):
-                fo = getattr(lane, "fused_optimizer", None) if lane is not None else None
-                if fo is not None:
-                    fo.sync_lr()
+                self._lr_targets = lr_sync_targets(model, self.opt)
+            for o in self._lr_targets:
+                o.sync_lr()
         t0 = None
         if self.cuda:
             t0 = torch.cuda.Event()
