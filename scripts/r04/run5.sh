@@ -4,8 +4,8 @@ set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 TAG=${1:-r04i}
 O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
-for B in 8192; do
- for cfg in "bwd_direct=1" "bwd_direct=1,bwd_direct_debug=4" "bwd_direct=1,bwd_direct_debug=5" "bwd_direct=1,bwd_direct_waves=41" "bwd_direct=1,bwd_direct_waves=5" "bwd_direct=1,bwd_direct_waves=5,bwd_direct_ch=192" "bwd_direct=1,bwd_direct_waves=5,bwd_direct_ch=128"; do
+for B in 8192 16384; do
+ for cfg in "bwd_direct=-1" "bwd_direct=1" "bwd_direct=1,bwd_direct_debug=3" "bwd_direct=1,bwd_direct_ch=192" "bwd_direct=1,bwd_direct_ch=128"; do
    TZR_TUNE=$cfg timeout 300 python bench.py --global-batch $B --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --no-secondary --no-graph 2> $O/err.txt | tail -1 > $O/out.json
    python - <<PY
 import json

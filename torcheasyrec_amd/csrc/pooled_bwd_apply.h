@@ -113,6 +113,19 @@ __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOp
   return tzr_zero4();
 }
 
+// The same with NO lane-dependent condition around the load (every lane of the wave loads; the caller passes a row that
+// exists for the lanes it will not use): a load inside `if (active)` is a branch to hipcc and a branch between two loads a
+// wait between them -- the gradient gather, the weights and the state of a tile ran as three dependent round trips
+// (pooled_bwd_direct.hip: "branch-free").  Row-wise Adagrad: all lanes of the group read the row's scalar (one address).
+template <bool ADAM>
+__device__ __forceinline__ float4 bwd_load_state_all(const TzrTable& tb, const BwdOpt& opt, int64_t row, int c) {
+  if (ADAM || opt.kind == TZR_OPT_ADAGRAD)  // (kernel-uniform)
+    return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
+  if (!ADAM && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
+    return make_float4(reinterpret_cast<const float*>(tb.m)[row * (int64_t)tb.m_stride], 0.f, 0.f, 0.f);
+  return tzr_zero4();
+}
+
 // ONE update of row `row`, chunk c; `active` lanes hold the summed gradient g, the row's current
 // weights w4 and (elementwise adagrad) state m4.  All 64 lanes of the wave must call (row-wise
 // adagrad reduces in the group).
@@ -290,27 +303,30 @@ __device__ __forceinline__ void bwd_reduce_unit(
     uint32_t key[NT];
     float4 g[NT], w4[NT], m4[NT];
     unsigned vmask = 0, tmask = 0, lmask = 0;  // per tile u: valid lookup / last of its run / in the inherited run
-    // every load of the NT tiles first
+    // every load of the NT tiles first -- UNCONDITIONALLY: lanes without a lookup (the range's tail, idle lane groups) read
+    // the range's last lookup and its row instead, lookups that are not the last of their run read their row all the
+    // same (an L2 hit next to the run's last lookup); what is used is decided by the masks below
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int idx = t0 + u * gw + gi;
       const bool valid = lane_on && idx < r1;
-      key[u] = valid ? sK[idx + 1] : BWD_SENT;
-      const uint32_t nxt = valid ? sK[idx + 2] : BWD_SENT;
-      const bool tl = valid && key[u] != nxt;
-      const bool inl = lead0 && key[u] == leadkey;
-      g[u] = tzr_zero4();
-      if (valid)
-        g[u] = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights, bag_of, B, uniform,
-                               sS[idx], c);
-      const bool dap = tl && !inl;
-      w4[u] = tzr_zero4();
-      if (dap) w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)key[u] * tb.w_stride + 4 * c);
-      m4[u] = bwd_load_state<ADAM>(tb, opt, (int64_t)key[u], c, dap);
+      const int idc = valid ? idx : r1 - 1;  // (r0 < r1 inside this loop)
+      const uint32_t kc = sK[idc + 1];
+      const uint32_t nxt = sK[idc + 2];
+      key[u] = valid ? kc : BWD_SENT;
+      const bool tl = valid && kc != nxt;
+      const bool inl = lead0 && kc == leadkey;
+      g[u] = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights, bag_of, B, uniform,
+                             sS[idc], c);
+      w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)kc * tb.w_stride + 4 * c);
+      m4[u] = bwd_load_state_all<ADAM>(tb, opt, (int64_t)kc, c);
       vmask |= valid ? 1u << u : 0u;
       tmask |= tl ? 1u << u : 0u;
       lmask |= inl ? 1u << u : 0u;
     }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+      if (!((vmask >> u) & 1u)) g[u] = tzr_zero4();
     // ... then the tiles in order: scan, carry, records, update
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
