@@ -106,6 +106,8 @@ def parse_args():
                     help="sharded runs: ms per GLOBAL-batch step of the N = 1 line, for the `projection` object's scaling ratios")
     ap.add_argument("--projection-world", type=int, default=0,
                     help="sharded runs: world size the `projection` is made for (default: the job's, or 65536 / per-rank batch at N = 1)")
+    ap.add_argument("--no-config-models", action="store_true",
+                    help="N = 1 default line: skip the DeepFM / multi_tower_din / MMoE + ZCH step readings")
     ap.add_argument("--no-sharded-proxy", action="store_true",
                     help="N = 1 default line: skip the 1-rank RCCL proxy of the 8192-per-rank sharded step (a child process)")
     ap.add_argument("--dp-max-rows", type=int, default=0,
@@ -133,6 +135,133 @@ def spawn_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def config_model_steps(dev, work_stream, steps: int = 20):
+    """Train-step timing of the other BASELINE.json model families at their config's batch size (8192), built from a
+    pipeline config TEXT through the same seam a tzrec user has (config.load_pipeline_spec -> rank_model.build_rank_model):
+    DeepFM-Criteo (configs[0]'s model on the GPU), multi_tower_din on the Taobao features with a 100-step click sequence
+    (configs[3]), MMoE with the user id behind a 200 M-row zero-collision hash, LFU (configs[4]).  One GPU, inputs resident,
+    fused sparse Adagrad + dense Adam, nothing skipped.  Eager launches (`ms_per_step`), and the same step replayed from a
+    hipGraph where the step is capturable (`graph_ms_per_step`; the ZCH step keeps host-side candidate lists: eager only)."""
+    from torcheasyrec_amd import example_configs as ec
+    from torcheasyrec_amd.config import load_pipeline_spec
+    from torcheasyrec_amd.dense import FusedDenseAdam
+    from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, _backward_of_losses, _losses_and_predictions
+    from torcheasyrec_amd.rank_model import build_rank_model
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor
+
+    def batches(spec, B, n, seed, raw_id_feature=None):
+        rng = np.random.default_rng(seed)
+        sparse = [f for f in spec.features if f.is_sparse]
+        dense = [f for f in spec.features if not f.is_sparse]
+        out = []
+        for _ in range(n):
+            vals, lens = [], []
+            seq_len = None
+            for f in sparse:
+                if f.is_sequence:  # the sub-features of one sequence share their lengths: histories of 10 .. sequence_length clicks
+                    if seq_len is None:
+                        seq_len = rng.integers(10, f.sequence_length + 1, size=B).astype(np.int32)
+                    ln = seq_len
+                else:
+                    ln = np.ones(B, np.int32)
+                lens.append(ln)
+                if f.name == raw_id_feature:  # raw 64-bit ids in front of the zero-collision hash: Zipf over 2^34 users
+                    u = np.minimum(rng.zipf(1.05, size=int(ln.sum())), 1 << 34).astype(np.int64)
+                    vals.append((u * 2654435761 + (1 << 40)) & ((1 << 62) - 1))
+                else:
+                    vals.append(rng.integers(0, f.num_embeddings, size=int(ln.sum())))
+            uni = all(not f.is_sequence for f in sparse)
+            kjt = KeyedJaggedTensor([f.name for f in sparse], torch.from_numpy(np.concatenate(vals).astype(np.int64)),
+                                    torch.from_numpy(np.concatenate(lens)), **({"uniform_length": 1} if uni else {}))
+            kt = KeyedTensor([f.name for f in dense], [f.value_dim for f in dense],
+                             torch.from_numpy(rng.random((B, max(1, sum(f.value_dim for f in dense))), dtype=np.float32)[:, :sum(f.value_dim for f in dense)]))
+            labels = {l: torch.from_numpy((rng.random(B) < 0.25).astype(np.int64)) for l in spec.label_fields}
+            out.append(Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt}, labels).to(dev))
+        return out
+
+    def run(name, text, config, raw_id_feature=None, capturable=True):
+        spec = load_pipeline_spec(text)
+        B = spec.batch_size
+        torch.manual_seed(7)
+        model = build_rank_model(spec, device=dev)
+        opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
+        bs = batches(spec, B, 4, 11, raw_id_feature)
+        n_ids = int(np.mean([b.sparse_features[BASE_DATA_GROUP].values().numel() for b in bs]))
+
+        def step(b):
+            opt.zero_grad(set_to_none=True)
+            losses, _ = _losses_and_predictions(model, model.loss, b)
+            _backward_of_losses(losses)
+            opt.step()
+            return losses
+
+        for i in range(4):
+            losses = step(bs[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            losses = step(bs[i % 4])
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        eager = time.perf_counter() - t0
+        out = {"config": config, "batch": B, "ids_per_step": n_ids, "ms_per_step": eager / steps * 1e3, "host_queue_ms_per_step": host / steps * 1e3,
+               "value": B * steps / eager, "unit": "samples/s", "launch": "eager",
+               "loss": {k: float(v.detach()) for k, v in losses.items()}}
+        if capturable:
+            try:
+                gs, pool = [], None
+                for b in bs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=work_stream):
+                        step(b)
+                    pool = g.pool()
+                    gs.append(g)
+                for i in range(4):
+                    gs[i].replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    gs[i % 4].replay()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                out.update(graph_ms_per_step=el / steps * 1e3, graph_value=B * steps / el)
+                del gs
+            except Exception as e:  # a step that is not capturable stays with its eager reading
+                out["graph_error"] = repr(e)[:160]
+                torch.cuda.synchronize()
+        mc = getattr(model.embedding_group, "mc", None)
+        if mc is not None:  # one admission / eviction round of the zero-collision hash, timed on its own
+            name_t = next(iter(mc.modules_by_table))
+            mod = mc.modules_by_table[name_t]
+            cand = mc.pending_candidates(name_t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            changed = mod.update_and_evict(cand, mc._iter)
+            torch.cuda.synchronize()
+            ev = (time.perf_counter() - t0) * 1e3
+            out["zch"] = {"table": name_t, "zch_size": mod.cfg.zch_size, "policy": mod.cfg.policy, "eviction_interval": mod.cfg.eviction_interval,
+                          "round_ms": ev, "candidates": int(cand.numel()), "rows_changed": int(changed.numel()),
+                          "amortised_ms_per_step": ev / max(mod.cfg.eviction_interval, 1)}
+        del model, opt, bs
+        torch.cuda.empty_cache()
+        return out
+
+    res = {}
+    for key, mk, config, kw in (
+            ("deepfm_criteo_b8192", ec.deepfm_criteo, "DeepFM on the Criteo features (examples/deepfm_criteo.config: 52 tables wide + deep, FM, "
+             "deep {512,256,128}, final {64}), batch 8192", {}),
+            ("din_taobao_b8192", ec.multi_tower_din_taobao, "multi_tower_din on the Taobao features (examples/multi_tower_din_taobao.config: 100-step "
+             "click sequence, DIN attention {256,64}), batch 8192, histories of 10..100 clicks", {}),
+            ("mmoe_zch_b8192", ec.mmoe_taobao_zch, "MMoE (3 experts, ctr + cvr towers) with user_id behind a 200M-row zero-collision hash, LFU "
+             "(BASELINE.json configs[4]), batch 8192, raw 64-bit Zipf user ids", {"raw_id_feature": "user_id", "capturable": False})):
+        try:
+            res[key] = run(key, mk(), config, **kw)
+        except Exception as e:
+            res[key] = {"config": config, "error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+    return res
 
 
 def sharded_proxy(args) -> dict:
@@ -562,7 +691,7 @@ def main():
         loss = step_body(*batches[i % nb])
     sync()
 
-    graphs = None
+    graphs, replayed_graphs = None, False
     if use_graph:
         # One hipGraph per distinct batch (inputs already in HBM, nothing is copied per step); all
         # graphs share one memory pool since they never run concurrently.  A step = one replay:
@@ -658,16 +787,18 @@ def main():
         host = []
         for s_ in range(nb):
             d_, k_, l_ = synthetic_batch(2000 + s_, B_local, rows, dist=args.dist)
+            # ids cross PCIe as int32 (Batch.narrow_ids: every Criteo table has fewer than 2^31 rows) and are widened on the
+            # device behind the copy: 10.7 instead of 17.5 MB per 65 536-sample step
             host.append(Batch({BASE_DATA_GROUP: KeyedTensor([f"int_{i}" for i in range(NUM_DENSE)], [1] * NUM_DENSE, d_)},
-                              {BASE_DATA_GROUP: k_}, {"label": l_}).pin_memory())
+                              {BASE_DATA_GROUP: k_}, {"label": l_}).narrow_ids().pin_memory())
         n_e2e = args.e2e_steps
         loss_of = lambda pred, b: {"bce": bce_with_logits(pred, b.labels["label"])}  # noqa: E731
         # (the lengths of one-id-per-bag keys are constant: GraphTrainPipeline keeps them in its device slots, the eager
         # pipeline moves the whole Batch)
-        h2d_graph = sum(t.numel() * t.element_size() for t in (host[0].dense_features[BASE_DATA_GROUP].values(),
-                                                               host[0].sparse_features[BASE_DATA_GROUP].values(),
-                                                               host[0].labels["label"]))
-        h2d_eager = h2d_graph + host[0].sparse_features[BASE_DATA_GROUP].lengths().numel() * host[0].sparse_features[BASE_DATA_GROUP].lengths().element_size()
+        from torcheasyrec_amd.embedding_group import _batch_tensors
+
+        h2d_graph = sum(t.numel() * t.element_size() for t in _batch_tensors(host[0], skip_constant=True))
+        h2d_eager = sum(t.numel() * t.element_size() for t in _batch_tensors(host[0], skip_constant=False))
 
         def timed(pipe, n_warm):
             it = iter([host[i % nb] for i in range(n_e2e + n_warm + 1)])
@@ -699,7 +830,7 @@ def main():
         e1 = sorted(g_runs)[len(g_runs) // 2] if use_graph_pipe else e_eager
         e2e = {"value": B_local * n_e2e / e1, "unit": "samples/s", "ms_per_step": e1 / n_e2e * 1e3, "steps": n_e2e,
                "statistic": "median of 3 timed runs" if use_graph_pipe else "one timed run",
-               "h2d_bytes_per_step": h2d_graph if use_graph_pipe else h2d_eager,
+               "h2d_bytes_per_step": h2d_graph if use_graph_pipe else h2d_eager, "id_wire_dtype": "int32 (widened on the device)",
                "launch": ("hipGraph replay per device slot, pinned host batches, H2D of the next batch on a copy stream "
                           "(GraphTrainPipeline.progress)" if use_graph_pipe else
                           "eager, TrainPipeline.progress, pinned host batches, H2D on a copy stream"),
@@ -801,6 +932,15 @@ def main():
         except Exception as e:
             secondary["interaction_first_layer_mfma"] = {"error": repr(e)[:200]}
 
+    # (f) the other model families of BASELINE.json, built from their configs: DeepFM-Criteo, multi_tower_din (configs[3]),
+    # MMoE + zero-collision hash (configs[4]) -- a train step each at batch 8192
+    if isinstance(secondary, dict) and "config2_batch8192" in secondary and not args.no_config_models:
+        replayed_graphs = graphs is not None
+        del graphs  # (their memory pool goes back to the allocator: the 200 M-row ZCH table needs room)
+        graphs = None
+        torch.cuda.empty_cache()
+        secondary.update(config_model_steps(dev, work_stream, steps=max(args.steps, 20)))
+
     # (e) the sharded proxy measured at the start of this process (see sharded_proxy): ratios against THIS run's N = 1 step
     if isinstance(secondary, dict) and proxy_child is not None:
         if "projection" in proxy_child:
@@ -851,7 +991,7 @@ def main():
         "final_loss": final_loss,
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
-        "launch": ("hipGraph replay" if graphs is not None else
+        "launch": ("hipGraph replay" if (graphs is not None or replayed_graphs) else
                    ((f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them (async, waited for on the stream)" if args.step_graph else
                      "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }

@@ -151,3 +151,32 @@ def test_kjt_normalises_dtypes_and_layout():
     assert k.lengths().dtype == torch.int32 and k.weights().dtype == torch.float32
     with pytest.raises(TypeError):
         KeyedJaggedTensor(["a"], torch.zeros(2), torch.ones(2, dtype=torch.int32))
+
+
+def test_int32_wire_form_of_a_batch_round_trips():
+    """Batch.narrow_ids (the int32 trip across PCIe, tzrec/datasets/utils.py:344-410 moves int64): `.to()` gives back a regular
+    KeyedJaggedTensor with the same int64 ids, lengths, weights and hints; ids that do not fit are refused."""
+    import torch
+
+    from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, _batch_tensors
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor
+
+    vals = torch.tensor([5, 0, (1 << 31) - 1, 7, 7, 2], dtype=torch.int64)
+    lens = torch.tensor([2, 0, 1, 3], dtype=torch.int32)
+    k = KeyedJaggedTensor(["a", "b"], vals, lens, torch.arange(6, dtype=torch.float32))
+    b = Batch({BASE_DATA_GROUP: KeyedTensor(["d"], [1], torch.rand(2, 1))}, {BASE_DATA_GROUP: k}, {"y": torch.tensor([0, 1])})
+    w = b.narrow_ids()
+    wire = [t for t in _batch_tensors(w) if t.dtype == torch.int32 and t.numel() == 6]
+    assert len(wire) == 1 and wire[0].tolist() == vals.tolist()
+    back = w.to("cpu").sparse_features[BASE_DATA_GROUP]
+    assert isinstance(back, KeyedJaggedTensor) and back.values().dtype == torch.int64
+    assert torch.equal(back.values(), vals) and torch.equal(back.lengths(), lens) and torch.equal(back.weights(), k.weights())
+    assert back.keys() == ["a", "b"] and back.stride() == 2
+    u = KeyedJaggedTensor(["a"], torch.tensor([3, 4]), torch.ones(2, dtype=torch.int32))
+    assert u.narrow_ids().to("cpu").uniform_length() == 1
+    import pytest
+
+    with pytest.raises(ValueError):
+        KeyedJaggedTensor(["a"], torch.tensor([1 << 31]), torch.ones(1, dtype=torch.int32)).narrow_ids()
+    with pytest.raises(ValueError):
+        KeyedJaggedTensor(["a"], torch.tensor([-1]), torch.ones(1, dtype=torch.int32)).narrow_ids()

@@ -43,11 +43,19 @@ def test_graph_pipeline_matches_eager_pipeline():
     res = []
     work = torch.cuda.Stream(dev)
     with torch.cuda.stream(work):
-        for cls, kw in ((TrainPipeline, {}), (GraphTrainPipeline, {}), (GraphTrainPipeline, {"stage_first": True}), (TrainPipeline, {"fetch_first": False})):
+        # "wire32": the same host batches with their ids narrowed to int32 for the trip across PCIe (Batch.narrow_ids),
+        # widened on the device behind the copy: the trajectory must not notice
+        narrow = [b_.narrow_ids().pin_memory() for b_ in (Batch({BASE_DATA_GROUP: hb.dense_features[BASE_DATA_GROUP]}, {BASE_DATA_GROUP: hb.sparse_features[BASE_DATA_GROUP]},
+                                                                  dict(hb.labels)) for hb in host)]
+        assert narrow[0].sparse_features[BASE_DATA_GROUP].wire_values().dtype == torch.int32
+        for cls, kw in ((TrainPipeline, {}), (GraphTrainPipeline, {}), (GraphTrainPipeline, {"stage_first": True}), (TrainPipeline, {"fetch_first": False}),
+                        (GraphTrainPipeline, {"wire32": True}), (TrainPipeline, {"wire32": True})):
+            kw = dict(kw)
+            batches_in = narrow if kw.pop("wire32", False) else host
             model = M()
             opt = FusedDenseAdam(list(model.m.dense_parameters()), lr=1e-2)
             pipe = cls(model, opt, dev, loss_of, **kw)
-            it = iter(host)
+            it = iter(batches_in)
             losses = []
             while True:
                 try:

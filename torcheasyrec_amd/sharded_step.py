@@ -352,6 +352,9 @@ class ShardedTrainStep:
             return
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(st["ready"])
+        if st.get("slot_key") is not None and "cap" in st:
+            return  # every buffer of a pipeline slot is persistent: nothing for the allocator to learn (15 record_stream calls
+            #         per step were ~40 us of a step whose HOST time is its duration: profiles/r04o)
         for v in st.values():
             if isinstance(v, torch.Tensor) and v.is_cuda:
                 v.record_stream(cur)

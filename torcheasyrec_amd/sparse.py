@@ -297,6 +297,10 @@ class KeyedJaggedTensor:
             if t is not None and t.is_cuda:
                 t.record_stream(stream)
 
+    def narrow_ids(self) -> "WireKeyedJaggedTensor":
+        """The same ids as int32 for the trip across PCIe (`Batch.narrow_ids`): 4 instead of 8 bytes per id."""
+        return WireKeyedJaggedTensor(self)
+
     # -- K1 --------------------------------------------------------------------------------
     def permute(self, indices: Sequence[int]) -> "KeyedJaggedTensor":
         """Output key t = input key indices[t] (torchrec KJT.permute -> fbgemm
@@ -379,3 +383,68 @@ def block_bucketize(
     keys = [f"{k}@{r}" for r in range(W) for k in kjt.keys()]
     out = KeyedJaggedTensor(keys, new_values, new_lengths, new_weights, new_offsets, B)
     return (out, unbucketize) if return_permute else out
+
+
+class WireKeyedJaggedTensor:
+    """A KeyedJaggedTensor on its way from the dataloader to the device with its ids narrowed to int32.
+
+    The kernels read ids as int64 (the KJT contract, /root/reference/tzrec/datasets/data_parser.py:576-585), but 13.6 of
+    the 17.5 MB a DLRM-Criteo batch of 65 536 samples moves host -> device are ids of tables that all hold fewer than 2^31
+    rows: on the slower hosts of the pool (25 GB/s) that copy, not the 0.58 ms step, bounded the end-to-end rate
+    (NOTES.md).  This is the WIRE form only -- host side of `Batch.to / pin_memory`, never handed to a lookup: `.to(device)`
+    moves the int32 ids and widens them on the device (one elementwise kernel behind the copy, on the copy's stream) into
+    a regular KeyedJaggedTensor.  Raw 64-bit ids (zero-collision-hash features) do not fit: `narrow_ids` refuses them."""
+
+    def __init__(self, kjt: "KeyedJaggedTensor", _values32: Optional[torch.Tensor] = None) -> None:
+        v = kjt.values()
+        if _values32 is None:
+            if v.numel() and (int(v.max()) >= (1 << 31) or int(v.min()) < 0):
+                raise ValueError("ids outside [0, 2^31) cannot travel as int32 (raw ids of a zero-collision-hash feature?)")
+            _values32 = v.to(torch.int32)
+        self._kjt, self._values32 = kjt, _values32
+
+    def keys(self):
+        return self._kjt.keys()
+
+    def stride(self) -> int:
+        return self._kjt.stride()
+
+    def uniform_length(self):
+        return self._kjt.uniform_length()
+
+    def wire_values(self) -> torch.Tensor:
+        return self._values32
+
+    def lengths_or_none(self):
+        return self._kjt.lengths_or_none()
+
+    def offsets_or_none(self):
+        return self._kjt.offsets_or_none()
+
+    def weights_or_none(self):
+        return self._kjt.weights_or_none()
+
+    def pin_memory(self) -> "WireKeyedJaggedTensor":
+        k = self._kjt
+        pin = lambda t: None if t is None else t.pin_memory()  # noqa: E731
+        meta = KeyedJaggedTensor(k._keys, torch.zeros(0, dtype=torch.int64), pin(k._lengths), pin(k._weights), pin(k._offsets), k._stride,
+                                 k._length_per_key, k._uniform_length)
+        meta._values = k._values  # (kept for `widen()` on the host; never copied)
+        return WireKeyedJaggedTensor(meta, self._values32.pin_memory())
+
+    def to(self, device, non_blocking: bool = False) -> "KeyedJaggedTensor":
+        k = self._kjt
+        if torch.device(device).type == "cpu":
+            return self.widen()
+        mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
+        vals = self._values32.to(device, non_blocking=non_blocking).to(torch.int64)  # widened on the device, behind the copy
+        return KeyedJaggedTensor(k._keys, vals, mv(k._lengths), mv(k._weights), mv(k._offsets), k._stride, k._length_per_key,
+                                 k._uniform_length)
+
+    def widen(self) -> "KeyedJaggedTensor":
+        k = self._kjt
+        return KeyedJaggedTensor(k._keys, self._values32.to(torch.int64), k._lengths, k._weights, k._offsets, k._stride, k._length_per_key,
+                                 k._uniform_length)
+
+    def record_stream(self, stream) -> None:
+        pass  # host tensors only
