@@ -11,7 +11,7 @@ R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 if [ -z "${SKIP_TESTS:-}" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
 fi
-timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/bench.json
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/bench.json
 if [ -z "${SKIP_EXTRA:-}" ]; then
 timeout 300 python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_b8192.json 2>> $O/bench.err; echo "bench b8192 rc=$?"
 timeout 300 python bench.py --optimizer rowwise_adagrad --no-cpu-baseline --no-e2e > $O/bench_rowwise_adagrad.json 2>> $O/bench.err; echo "bench rowwise rc=$?"
