@@ -330,6 +330,13 @@ def test_checkpoint_covers_pooled_and_sequence_tables(dev, tmp_path, tables_form
         pipe.progress(it)
     save_checkpoint(str(tmp_path), a, opt, tables_format=tables_format)
     assert set(read_plan(str(tmp_path))) == {"embedding_group.ebc", "embedding_group.ecs.16"}
+    if tables_format == "dcp":  # the containers name things by the reference's module paths (tzrec/modules/embedding.py:194-195,855,1193)
+        import torch.distributed.checkpoint as dcp
+
+        names = set(dcp.FileSystemReader(os.path.join(str(tmp_path), "model", "dcp")).read_metadata().state_dict_metadata)
+        assert "model.embedding_group.emb_impls.__BASE__.ebc.embedding_bags.user_id_emb.weight" in names, sorted(names)[:6]
+        assert "model.embedding_group.seq_emb_impls.__BASE__.ec_dict.16.embeddings.click_seq__adgroup_id_emb.weight" in names or any(
+            k.startswith("model.embedding_group.seq_emb_impls.__BASE__.ec_dict.16.embeddings.") for k in names), sorted(names)[:12]
     torch.manual_seed(9)
     b = build_rank_model(spec, device=dev)
     restore_checkpoint(str(tmp_path), b)

@@ -254,6 +254,13 @@ def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir, tables_format="file
     if tables_format == "dcp" and rank == 0:  # the bulk went through torch.distributed.checkpoint
         assert {".metadata", "__0_0.distcp", "__1_0.distcp"} <= set(os.listdir(os.path.join(ckpt_dir, "model", "dcp")))
         assert os.path.getsize(os.path.join(ckpt_dir, "model", "rank0.pt")) < 20000
+        import torch.distributed.checkpoint as dcp
+
+        names = set(dcp.FileSystemReader(os.path.join(ckpt_dir, "model", "dcp")).read_metadata().state_dict_metadata)
+        onames = set(dcp.FileSystemReader(os.path.join(ckpt_dir, "optimizer", "dcp")).read_metadata().state_dict_metadata)
+        # the reference's module paths (a model holding its collection directly: model.ebc...), torchrec's optimizer-state naming
+        assert "model.ebc.embedding_bags.cat_0_emb.weight" in names and "model.dense_mlp.mlp.0.weight" in names, sorted(names)[:8]
+        assert "state.model.ebc.embedding_bags.cat_0_emb.weight.cat_0_emb.momentum1" in onames, sorted(onames)[:4]
     assert read_plan(ckpt_dir)["ebc"]["cat_0_emb"] == {"sharding_type": "row_wise", "compute_kernel": "fused", "ranks": [0, 1]}
 
     # restore under a DIFFERENT placement: cat_0 table-wise, everything else row-wise (no replicas)
@@ -585,6 +592,94 @@ def _zch_worker(rank, world, init_file, emu_path):
     assert torch.equal(m2.forward_grouped(probe)["g"], m.forward_grouped(probe)["g"])
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _zch_reshard_worker(rank, world, init_file, emu_path, work_dir, phase):
+    """phase "save" (world 2): train a hash-routed ZCH table for a few steps, record what every probe id looks up, save
+    through torch.distributed.checkpoint.  phase "load" (any world size): a fresh model restores that checkpoint; every
+    probe id must look up the SAME embedding row as before -- its map entry, access statistics, row and optimizer state
+    followed it to whichever rank the hash now sends it to (VERDICT r3 #10 / ADVICE r2)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+    from torcheasyrec_amd.embedding import EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+    from torcheasyrec_amd.zch import EMPTY, ShardedManagedCollisionEmbeddingBagCollection, ZchConfig
+
+    _lib.use_library(emu_path)
+    dev = torch.device("cpu")
+    Z, D = 64, 8
+    keys = ["user", "item"]
+    tables = [EmbeddingBagConfig("user_emb", D, Z, ["user"], "sum"), EmbeddingBagConfig("item_emb", D, 300, ["item"], "sum")]
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.5, initial_accumulator_value=0.1)
+    torch.manual_seed(3 + (0 if phase == "save" else 50))
+    m = ShardedManagedCollisionEmbeddingBagCollection(tables, {"user_emb": ZchConfig(Z, 1, "lfu")}, device=dev, optimizer=opt,
+                                                      groups={"g": keys}, dp_max_rows=10)
+
+    class _Holder(torch.nn.Module):
+        def __init__(self, z):
+            super().__init__()
+            self._sharded_zch, self.ebc = z, z.sharded
+
+    rng = np.random.default_rng(11)
+    users = rng.integers(1 << 40, 1 << 50, size=24).astype(np.int64)  # few enough that every one gets a row, at any world size
+    Bg = 16
+
+    def lookup(uids, iids):  # my slice of a global batch -> pooled rows, gathered on every rank in global order
+        Bl = len(uids) // world
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        kjt = KeyedJaggedTensor(keys, torch.from_numpy(np.concatenate([uids[sl], iids[sl]])), torch.ones(2 * Bl, dtype=torch.int32), uniform_length=1)
+        out = m.forward_grouped(kjt)["g"]
+        parts = [None] * world
+        dist.all_gather_object(parts, out.detach().clone())
+        return torch.cat(parts), out
+
+    if phase == "save":
+        m.train()
+        for step in range(4):
+            u, it = users[(step * Bg + np.arange(Bg)) % len(users)], rng.integers(0, 300, size=Bg).astype(np.int64)  # every user shows up
+            _, out = lookup(u, it)
+            (out * torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))).sum().backward()
+        m.eval()
+        probe_u = np.concatenate([users, rng.integers(1 << 52, 1 << 53, size=8).astype(np.int64)])[:32]  # 24 admitted + 8 unknown ids
+        probe_i = rng.integers(0, 300, size=32).astype(np.int64)
+        ref, _ = lookup(probe_u, probe_i)
+        held = [None] * world
+        dist.all_gather_object(held, int((m.mc.modules_by_table["user_emb"].row_ids != EMPTY).sum()))
+        assert sum(held) == len(users), held  # every user id was admitted somewhere
+        save_checkpoint(os.path.join(work_dir, "ck"), _Holder(m), tables_format="dcp")
+        if rank == 0:
+            torch.save({"ref": ref, "probe_u": probe_u, "probe_i": probe_i, "iter": m.mc._iter}, os.path.join(work_dir, "ref.pt"))
+    else:
+        restore_checkpoint(os.path.join(work_dir, "ck"), _Holder(m))
+        want = torch.load(os.path.join(work_dir, "ref.pt"), weights_only=False)
+        m.eval()
+        got, _ = lookup(want["probe_u"], want["probe_i"])
+        # the 24 admitted users and every item: exactly the rows they had; the 8 unknown users are served from the shared
+        # row of whichever rank the hash sends them to -- one of the saved shared rows
+        known = np.isin(want["probe_u"], users)
+        assert torch.equal(got[known], want["ref"][known])
+        assert torch.equal(got[:, D:], want["ref"][:, D:])
+        assert m.mc._iter == want["iter"]
+        held = [None] * world
+        dist.all_gather_object(held, int((m.mc.modules_by_table["user_emb"].row_ids != EMPTY).sum()))
+        assert sum(held) == len(users)
+        # ... and the maps keep working: another training step admits nothing twice
+        m.train()
+        _, out = lookup(users[:Bg], rng.integers(0, 300, size=Bg).astype(np.int64))
+        out.sum().backward()
+        dist.all_gather_object(held, int((m.mc.modules_by_table["user_emb"].row_ids != EMPTY).sum()))
+        assert sum(held) == len(users)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("load_world", [4, 1, 2])
+def test_zch_checkpoint_restores_at_another_world_size(emu_path, load_world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_zch_reshard_worker, args=(2, os.path.join(d, "init_a"), emu_path, d, "save"), nprocs=2, join=True)
+        mp.spawn(_zch_reshard_worker, args=(load_world, os.path.join(d, "init_b"), emu_path, d, "load"), nprocs=load_world, join=True)
 
 
 def test_sharded_zch_world2(emu_path):
