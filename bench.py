@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--overlap-collectives", choices=["auto", "on", "off"], default="auto",
                     help="--step-graph runs: five graphs with the gradient all-to-all / all-reduces issued async between them "
                          "(auto = on; off: three graphs, every collective waited for where it is issued)")
+    ap.add_argument("--no-graph-input-dist", action="store_true",
+                    help="--step-graph runs: launch the input dist's kernels one by one instead of replaying its two kernel runs from "
+                         "hipGraphs (the step is host-bound: 2 replays instead of ~8 launches and their Python, profiles/r04r)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -662,6 +665,7 @@ def main():
 
         train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
                                       plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph,
+                                      graph_input_dist=args.step_graph and not args.no_graph_input_dist,
                                       overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives])
 
     def step_body(dense, kjt, label, next_kjt=None):

@@ -613,8 +613,9 @@ int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_stride, const fl
  * tzrec/models/dlrm.py:123-135: `final_mlp(cat(interaction, dense, sparse))`, first layer [P + D n -> H]).
  * Layout of the interaction row as tzr_dot_interaction_fwd writes it with cat_dense = (dense != 0), cat_sparse = 1:
  * [P pairs | dense row | sparse rows], width P + D n.  W1 is the nn.Linear weight [H, ldw >= width], row-major.
- * Supported: D = 16, H = 64, ceil(P / 16) + n <= 56, i.e. n <= 29 (tzr_dot_interaction_top_supported; otherwise
- * TZR_ERR_UNSUPPORTED and the caller runs the unfused ops).  fp32 MFMA, fixed summation order (deterministic).
+ * Supported: D = 16, H = 64, ceil(P / 16) + n <= 64 column blocks, i.e. n <= 32 (tzr_dot_interaction_top_supported;
+ * otherwise TZR_ERR_UNSUPPORTED and the caller runs the unfused ops).  Up to n = 29 the backward keeps two dz tiles in
+ * LDS (one barrier per tile); n = 30 .. 32 run the same kernel with one tile (two barriers), same results.  fp32 MFMA, fixed summation order (deterministic).
  *   _top_fwd: y1[b] = act(z[b] W1^T + bias) (relu != 0: ReLU), [B, H]; the interaction row z[b] itself is written
  *             only when d_z is non-null (training keeps it for the weight gradient; inference does not need it).
  *   _top_bwd: from g1 = d(loss)/d(z W1^T + bias) [B, H]: grad_dense / grad_sparse = the interaction backward of

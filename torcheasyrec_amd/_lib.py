@@ -255,9 +255,13 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def stream_ptr(device: torch.device) -> Optional[int]:
+    """raw handle of torch's current stream on `device` (one C call: `torch.cuda.current_stream(device).cuda_stream` builds
+    a Stream object through three layers of Python per kernel launch -- 35 us of a sharded step whose host time is its
+    duration, profiles/r04r)"""
     if device.type != "cuda":
         return None
-    return torch.cuda.current_stream(device).cuda_stream
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
 
 def upload_struct(arr: np.ndarray, device: torch.device) -> torch.Tensor:

@@ -296,7 +296,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
 
 
 def interaction_top_fits(dense: torch.Tensor, sparse: torch.Tensor, D: int, first_linear) -> bool:
-    """Whether the fused interaction + first-layer kernels take this shape (D = 16, H = 64, n <= 29, fp32)."""
+    """Whether the fused interaction + first-layer kernels take this shape (D = 16, H = 64, n <= 32, fp32)."""
     if dense is None or sparse.dim() != 2 or dense.dim() != 2 or dense.shape[1] != D or sparse.shape[1] % D:
         return False
     if sparse.dtype != torch.float32 or dense.dtype != torch.float32 or first_linear.weight.dtype != torch.float32:

@@ -278,6 +278,7 @@ class ShardedTrainStep:
         if ig is not None:
             ig[0].replay()
             ebc.cap_exchange(st)
+            ebc.cap_flag_arm(st)  # (the replayed D2H copy of the overflow word lands on this sentinel)
             ig[1].replay()
             for k in ("ws_dp", "ws_rw"):  # the plans live in the slot's workspaces
                 if k in sl["in_st"]:
@@ -528,7 +529,15 @@ class ShardedTrainStep:
             # graph of the bottom MLP is built in one capture (G0b) and walked backwards in the next (G1a), which is the
             # arrangement of torch.cuda.make_graphed_callables (forward and backward graphs of one pool)
             pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
+        ahead_done = False
         for i, (seg, coll) in enumerate(zip(segs, colls)):
+            if i == 2 and not capture and next_kjt is not None and self.prefetch:
+                # the NEXT batch's input dist is queued (on the side stream, behind the START of this step) as soon as this
+                # step's first graphs are out -- not at the end: its overflow word is read when the next step begins, and
+                # queued last it had the host wait there for the whole chain it had just queued (63 us per step, the largest
+                # single item of a step whose host time is its duration: profiles/r04r)
+                self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
+                ahead_done = True
             if capture:
                 g = torch.cuda.CUDAGraph()
                 _quiesce_process_group(self.device)
@@ -545,6 +554,6 @@ class ShardedTrainStep:
         if capture:
             sl["graph"] = graphs
         self.graph_steps += 1
-        if next_kjt is not None and self.prefetch:
+        if next_kjt is not None and self.prefetch and not ahead_done:
             self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
         return sl["loss"]

@@ -76,6 +76,26 @@ def row_wise_plan(rows: Sequence[int], world: int, whole: Optional[Sequence[bool
 SHARDING_TYPES = ("data_parallel", "table_wise", "row_wise")
 
 
+def _pg_of(group):
+    return group if group is not None else dist.group.WORLD
+
+
+def a2a_async(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """`dist.all_to_all_single(out, inp, async_op=True)` with equal splits, issued straight on the ProcessGroup object: the
+    functional wrapper's argument checks and logging decorator were 10 - 15 us of host time per collective, five of them
+    per sharded step (profiles/r04r)."""
+    opts = dist.AllToAllOptions()
+    opts.asyncOp = True
+    return _pg_of(group).alltoall_base(out, inp, [], [], opts)
+
+
+def allreduce_async(t: torch.Tensor, group=None, avg: bool = False):
+    opts = dist.AllreduceOptions()
+    opts.reduceOp = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    opts.asyncOp = True
+    return _pg_of(group).allreduce([t], opts)
+
+
 def stream_collective(fn, tensor: torch.Tensor, *args, **kw):
     """A collective the caller needs complete IN STREAM ORDER (what `async_op=False` means), issued so that it is safe
     next to hipGraph captures.  torch's process group runs a sync collective ON the current stream and records its
@@ -529,7 +549,10 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                                    _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "tzr_exchange_bucketize_capped")
 
     def cap_exchange(self, st: dict) -> None:
-        stream_collective(dist.all_to_all_single, st["msg"][1], st["msg"][0], group=self.input_dist_group or self.pg)
+        if st["msg"].is_cuda:
+            a2a_async(st["msg"][1], st["msg"][0], self.input_dist_group or self.pg).wait()
+        else:
+            dist.all_to_all_single(st["msg"][1], st["msg"][0], group=self.input_dist_group or self.pg)
 
     def cap_segments(self, st: dict) -> None:
         seg = st["seg"]
@@ -537,7 +560,18 @@ class ShardedEmbeddingBagCollection(nn.Module):
                                                           _lib.ptr(seg[-1:]), _lib.stream_ptr(self._device)),
                    "tzr_exchange_owner_segments")
         if self._device.type == "cuda":
+            self.cap_flag_arm(st)
             st["flag_host"].copy_(seg[-1:], non_blocking=True)
+
+    def cap_flag_arm(self, st: dict) -> None:
+        """Host side of the overflow word's trip: a sentinel in the pinned word BEFORE the D2H copy that will overwrite it is
+        queued (or replayed from a graph: call this in front of the replay).  `input_dist_end` then polls the word itself --
+        no event: hipEventSynchronize / hipEventQuery answered 60 - 150 us after the copy had landed (the event behind a
+        hipGraph launch completes when the runtime's handler thread gets to it), the largest single item of a sharded
+        step's host time (profiles/r04r, r04s)."""
+        if self._device.type == "cuda":
+            st["flag_host"].fill_(-1)
+            st["flag_armed"] = True
 
     def cap_flag_event(self, st: dict) -> None:
         if self._device.type == "cuda":
@@ -622,8 +656,16 @@ class ShardedEmbeddingBagCollection(nn.Module):
             # bucketize + ids all-to-all + flag copy.  Those were queued behind the START of the current step only
             # and run beside it, while the host has already queued the whole current step: the wait ends long
             # before the main stream drains -- but it is a wait, not "recorded a batch ago" (ADVICE round 2).
-            if "flag_event" in st:
-                st.pop("flag_event").synchronize()
+            ev = st.pop("flag_event", None)
+            if st.pop("flag_armed", False):  # the pinned word itself says when the copy has landed (`cap_flag_arm`)
+                host = st["flag_host"]
+                spins = 0
+                while int(host.item()) < 0:
+                    spins += 1
+                    if spins > 2_000_000 and ev is not None:  # (never seen; do not spin for ever on a lost copy)
+                        ev.synchronize()
+            elif ev is not None:
+                ev.synchronize()
             over = int(st.pop("flag_host").item())
             if over:
                 self.exchange_stats["overflow_retries"] += 1
@@ -931,7 +973,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if "rw_n" in st["rm"]:
             rows_in, _ = self._recv_rows_buffer(st["N_pad"], st["rm"]["rw_n"])
             if async_op:
-                return dist.all_to_all_single(rows_in[:st["N_pad"]], st["rows_out"], group=self.pg, async_op=True)
+                return a2a_async(rows_in[:st["N_pad"]], st["rows_out"], self.pg)
             return stream_collective(dist.all_to_all_single, rows_in[:st["N_pad"]], st["rows_out"], group=self.pg)
         return None
 
@@ -989,7 +1031,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             return None
         st["grecv"] = self._slot(st["slot"], "grecv", (st["n_recv"], self.dim), torch.float32)
         if async_op:
-            return dist.all_to_all_single(st["grecv"], st["grow"], group=self.pg, async_op=True)
+            return a2a_async(st["grecv"], st["grow"], self.pg)
         return stream_collective(dist.all_to_all_single, st["grecv"], st["grow"], group=self.pg)
 
     def coll_grads_dp(self, st: dict, async_op: bool = False):
@@ -997,7 +1039,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         if self.fused_optimizer is None or "dp_n" not in st["rm"]:
             return None
         if async_op:
-            return dist.all_reduce(self._dp_acc, group=self.pg, async_op=True)
+            return allreduce_async(self._dp_acc, self.pg)
         return stream_collective(dist.all_reduce, self._dp_acc, group=self.pg)
 
     def seg_apply(self, st: dict) -> None:
@@ -1157,7 +1199,7 @@ def pack_dense_grads(grads: Sequence[torch.Tensor]) -> torch.Tensor:
 def allreduce_flat_average(flat: torch.Tensor, process_group=None, async_op: bool = False):
     if flat.is_cuda:
         if async_op:
-            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=process_group, async_op=True)
+            return allreduce_async(flat, process_group, avg=True)
         return stream_collective(dist.all_reduce, flat, op=dist.ReduceOp.AVG, group=process_group)
     # gloo has no AVG (and nothing to overlap with on the CPU: always finished on return)
     dist.all_reduce(flat, group=process_group)
