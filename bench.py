@@ -66,6 +66,10 @@ def parse_args():
                     help="with --force-sharded: replicate small tables even at world 1 (exercise that path)")
     ap.add_argument("--layerwise-loss", action="store_true",
                     help="A/B: logits then tzr_bce_logits as separate autograd nodes instead of DLRM.forward_loss")
+    ap.add_argument("--owned-wgrad", action="store_true",
+                    help="weight gradient of the layer behind the interaction by tzr_dot_interaction_top_wgrad at every batch size (default: up to 16 384 samples)")
+    ap.add_argument("--gemm-wgrad", action="store_true",
+                    help="weight gradient of the layer behind the interaction by the GEMM library over a stored z (A/B against tzr_dot_interaction_top_wgrad)")
     ap.add_argument("--torch-bce", action="store_true", help="loss: torch BCE-with-logits instead of tzr_bce_logits")
     ap.add_argument("--torch-adam", action="store_true", help="dense optimizer: torch.optim.Adam(fused) instead of tzr_dense_adam")
     ap.add_argument("--secondary-global-batch", type=int, default=None,
@@ -371,8 +375,10 @@ def enable_tunable_gemm():
 
 
 def interaction_top_rooflines(dev, B):
-    """tzr_dot_interaction_top_fwd / _bwd at the DLRM-Criteo shape (27 rows of 16, first top layer 783 -> 64), alone:
-    median of 20 launches, HIP events on the launching stream."""
+    """tzr_dot_interaction_top_fwd / _bwd / _wgrad at the DLRM-Criteo shape (27 rows of 16, first top layer 783 -> 64), as the
+    step launches them (the forward keeps no z), alone: median of 20 launches, HIP events on the launching stream.  The
+    weight gradient's flops are the product's 2 x 783 x 64 per sample: its rebuilt pair blocks (2 x 3 x 16 x 16 x 16 more) and
+    its second launch (the sum over the batch slices) are overhead, inside `launch_ms`."""
     from torcheasyrec_amd import _lib
 
     L = _lib.lib()
@@ -383,20 +389,29 @@ def interaction_top_rooflines(dev, B):
     st = _lib.stream_ptr(dev)
     dense, sparse = torch.randn(B, D, device=dev), torch.randn(B, F * D, device=dev)
     W1, b1, g1 = torch.randn(H, width, device=dev) * 0.05, torch.randn(H, device=dev), torch.randn(B, H, device=dev)
-    z, y1 = torch.empty(B, width, device=dev), torch.empty(B, H, device=dev)
+    y1 = torch.empty(B, H, device=dev)
     gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
+    dW = torch.empty(H, width, device=dev)
+    ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, 1, H), dev)
 
     def fwd():
         _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1),
-                                                 H, 1, _lib.ptr(z), width, _lib.ptr(y1), H, st), "tzr_dot_interaction_top_fwd")
+                                                 H, 1, None, 0, _lib.ptr(y1), H, st), "tzr_dot_interaction_top_fwd")
+
+    def wgrad():
+        _lib.check(L.tzr_dot_interaction_top_wgrad(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, None,
+                                                   _lib.ptr(dW), width, _lib.ptr(ws), ws.numel(), st), "tzr_dot_interaction_top_wgrad")
 
     def bwd():
         _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, _lib.ptr(W1),
                                                  width, None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, st), "tzr_dot_interaction_top_bwd")
 
     out = {"peak": 157.3, "unit": "TFLOP/s", "bound": "mfma", "dtype": "f32 (v_mfma_f32_16x16x4_f32, exact)"}
+    kernels = {"forward": "tzr_ia_top_fwd_kernel", "backward": "tzr_ia_top_bwd_kernel",
+               "weight_gradient": "tzr_ia_wgrad_kernel + tzr_ia_wgrad_reduce_kernel"}
     for name, fn, flop in (("forward", fwd, B * (2.0 * width * H + 2.0 * P * D)),
-                           ("backward", bwd, B * (2.0 * width * H + 2.0 * n * n * D))):
+                           ("backward", bwd, B * (2.0 * width * H + 2.0 * n * n * D)),
+                           ("weight_gradient", wgrad, B * 2.0 * width * H)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -408,7 +423,7 @@ def interaction_top_rooflines(dev, B):
             b_.record()
         torch.cuda.synchronize()
         ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)[10]
-        out[name] = {"kernel": f"tzr_ia_top_{'fwd' if name == 'forward' else 'bwd'}_kernel", "launch_ms": ms, "algorithmic_flop": flop,
+        out[name] = {"kernel": kernels[name], "launch_ms": ms, "algorithmic_flop": flop,
                      "achieved": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 157.3e12}
     return out
 
@@ -516,6 +531,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus} (or plainly as `python bench.py --gpus {args.gpus}`)")
     emu = args.emulator
+    if args.gemm_wgrad or args.owned_wgrad:
+        import torcheasyrec_amd.dense as _dense
+
+        _dense.OWNED_WGRAD = bool(args.owned_wgrad)
     # N = 1 default line: the 8192-per-rank sharded step on a 1-rank RCCL group, in a child process that runs BEFORE this
     # process touches the GPU (two processes on one GPU time-slice its queues: 0.50 ms measured next to an idle parent
     # against 0.36 ms alone, profiles/r04l)

@@ -579,6 +579,7 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
  *   mlp_mfma            -1: tzr_mlp2_* / tzr_mlp_tail use their general LDS-tiled kernels for every shape (0: the MFMA
  *                       kernels of mlp_mfma.hip where the shape is DLRM-Criteo's)
+ *   wg_debug            phase-skipping bits of tzr_dot_interaction_top_wgrad for timing experiments (wrong results)
  *   it_wgs              persistent workgroups of the fused interaction + first-layer kernels (0 = 256, one per CU)
  *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per
  *                       1024-lookup tile.  Same plan, slower under heavy skew.  Set it when plans are built on a
@@ -630,6 +631,19 @@ int tzr_dot_interaction_top_bwd(const float* d_dense, int64_t dense_stride, cons
                                 int H, const float* d_W1, int64_t ldw, const float* d_scale, float* d_grad_dense,
                                 int64_t grad_dense_stride, float* d_grad_sparse, int64_t grad_sparse_stride,
                                 void* stream);
+
+/* K9c: the weight gradient of that first Linear, dW1 = scale * g1^T z [H, P + D n] (autograd of nn.Linear in
+ * tzrec/modules/mlp.py:58-83 behind tzrec/models/dlrm.py:123-135), with the interaction rows z REBUILT from the
+ * embeddings on the chip: training does not keep z (tzr_dot_interaction_top_fwd with d_z = null).  Same shapes as
+ * tzr_dot_interaction_top_supported; exact-fp32 MFMA; the batch is summed in a fixed order (run-to-run identical).
+ * d_ws: tzr_dot_interaction_top_wgrad_workspace(F, D, has_dense, H) bytes, 16-byte aligned (partial sums of the batch
+ * slices).  d_scale: device scalar or null (= 1).  d_dW1 row pitch ldw >= P + D n; columns behind the width are left alone.
+ * B = 0 writes zeros (the width still follows from F and whether d_dense is null). */
+int64_t tzr_dot_interaction_top_wgrad_workspace(int F, int D, int has_dense, int H);
+int tzr_dot_interaction_top_wgrad(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                  int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1, int64_t g1_stride,
+                                  int H, const float* d_scale, float* d_dW1, int64_t ldw, void* d_ws, int64_t ws_bytes,
+                                  void* stream);
 
 /* K10: FM second order.  Replaces tzrec FactorizationMachine.forward
  * (tzrec/modules/fm.py:27-42): out[b,:] = 0.5*((sum_f x_f)^2 - sum_f x_f^2), x:[B,F,D]. */

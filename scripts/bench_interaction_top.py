@@ -78,6 +78,23 @@ def main():
             print(f"B {B}: fused (it_wgs {wgs:4d})  top_fwd+z {timed(top_fwd(_lib.ptr(z))):6.1f}  top_fwd (no z) {timed(top_fwd(None)):6.1f}  "
                   f"top_bwd {timed(top_bwd):6.1f} us", flush=True)
         L.tzr_tune(b"it_wgs", 0)
+        ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, 1, H), dev)
+        dW = torch.empty(H, width, device=dev)
+
+        def top_wgrad():
+            L.tzr_dot_interaction_top_wgrad(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, None, _lib.ptr(dW),
+                                            width, _lib.ptr(ws), ws.numel(), st)
+
+        t_w = timed(top_wgrad)
+        L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1), H, 1,
+                                      _lib.ptr(z), width, _lib.ptr(y1), H, st)
+        ref = weight_grad(g1, z)
+        err = float((dW - ref).abs().max()) / float(ref.abs().max())
+        print(f"B {B}: top_wgrad (z rebuilt on the chip, kernel + reduce) {t_w:6.1f} us; max |dW - g1^T z| / max |.| = {err:.2e}", flush=True)
+        for dbg in [int(x) for x in os.environ.get("WG_DEBUG", "").split(",") if x]:
+            L.tzr_tune(b"wg_debug", dbg)
+            print(f"B {B}: wg_debug {dbg} (1 no product, 2 no tile build, 4 no loads): top_wgrad {timed(top_wgrad):6.1f} us", flush=True)
+        L.tzr_tune(b"wg_debug", 0)
         for sg in [int(x) for x in os.environ.get("IT_STAGGER", "").split(",") if x]:
             L.tzr_tune(b"it_stagger", sg)
             print(f"B {B}: it_stagger {sg}: top_bwd {timed(top_bwd):6.1f} us", flush=True)
@@ -110,21 +127,36 @@ def prof():
     gd, gs = torch.empty_like(dense), torch.empty_like(sparse)
     tab = torch.zeros(256 * 16 * 6, dtype=torch.int64, device=dev)
     L.tzr_it_prof_table(ctypes.c_void_p(tab.data_ptr()))
-    names = {"bwd": ["wait", "x-image", "product(first)", "contract", "pt+stores", "product(second)"],
+    ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, 1, H), dev)
+    dW = torch.empty(H, width, device=dev)
+    names = {"wgrad": ["load wait", "X stores + MFMAs", "load issue", "barrier (L)", "pair stores (L) / product (M)", "barrier (M)"],
+             "bwd": ["wait", "x-image", "product(first)", "contract", "pt+stores", "product(second)"],
              "fwd+z": ["wait1", "row(first)", "product", "row(second)", "wait2", "reduce"],
              "fwd": ["wait1", "row(first)", "product", "row(second)", "wait2", "reduce"]}
-    for kind in ("bwd", "fwd+z", "fwd"):
+    kinds = [k for k in os.environ.get("PROF_KINDS", "wgrad,bwd,fwd+z,fwd").split(",") if k]
+    L.tzr_tune(b"wg_debug", int(os.environ.get("PROF_WG_DEBUG", "0")))
+    for kind in kinds:
         for it in range(3):
             tab.zero_()
-            if kind == "bwd":
+            if kind == "wgrad":
+                L.tzr_dot_interaction_top_wgrad(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, None, _lib.ptr(dW),
+                                                width, _lib.ptr(ws), ws.numel(), st)
+            elif kind == "bwd":
                 L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H, _lib.ptr(W1), width,
                                               None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, st)
             else:
                 L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1), H, 1,
                                               _lib.ptr(z) if kind == "fwd+z" else None, width, _lib.ptr(y1), H, st)
             torch.cuda.synchronize()
-        t = tab.cpu().numpy().reshape(256, 16, 6).astype(np.float64) / 16.0  # clocks per tile (16 tiles per workgroup)
+        per_wg = 32.0 if kind == "wgrad" else 16.0  # tiles per workgroup
+        t = tab.cpu().numpy().reshape(256, 16, 6).astype(np.float64) / per_wg
         print(f"{kind}: shader clocks per tile, mean over workgroups; per wave (rows) x phase (cols) {names[kind]}")
+        if kind == "wgrad":  # by column group (workgroup b: group (b >> 3) & 3)
+            for gidx in range(4):
+                sel = [b for b in range(256) if ((b >> 3) & 3) == gidx]
+                mg = t[sel].mean(axis=0)
+                print(f"  group {gidx}: loaders (waves 0-7) " + " ".join(f"{v:8.0f}" for v in mg[:8].mean(axis=0)[:5])
+                      + "   multipliers (waves 8-15) " + " ".join(f"{v:8.0f}" for v in mg[8:].mean(axis=0)[4:]))
         m = t.mean(axis=0)
         for w in range(16):
             print(f"  wave {w:2d}: " + " ".join(f"{v:8.0f}" for v in m[w]) + f"   sum {m[w].sum():8.0f}")

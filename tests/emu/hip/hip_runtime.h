@@ -374,6 +374,30 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
   emu::wave_barrier();
   return d;
 }
+// v_mfma_f32_16x16x1_4b_f32: four independent 16 x 16 x 1 outer products.  Lane l supplies A[i=l&15] and B[j=l&15] of
+// block l>>4; C/D: register 4 b + e of lane l is D_b[row=(l>>4)*4+e][col=l&15] (scripts/r04/probe_mfma_4b.hip reads the
+// map off the device).
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+inline emu_f32x16 __builtin_amdgcn_mfma_f32_16x16x1f32(float a, float b, emu_f32x16 c, int, int, int) {
+  int l = emu::lane();
+  float ab[2] = {a, b};
+  memcpy(emu::wave().buf[l], ab, 8);
+  emu::wave_barrier();
+  emu::Wave& w = emu::wave();
+  emu_f32x16 d = c;
+  int col = l & 15;
+  for (int blk = 0; blk < 4; ++blk)
+    for (int e = 0; e < 4; ++e) {
+      int row = (l >> 4) * 4 + e;
+      float av, bv;
+      memcpy(&av, w.buf[blk * 16 + row], 4);
+      memcpy(&bv, w.buf[blk * 16 + col] + 4, 4);
+      d[4 * blk + e] = fmaf(av, bv, c[4 * blk + e]);
+    }
+  emu::wave_barrier();
+  return d;
+}
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu::exchange(v, 0); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

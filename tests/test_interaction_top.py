@@ -63,6 +63,58 @@ def test_top_fwd_bwd_match_torch(dev, B, F):
     _close(gs, sparse.grad, 1e-5)
 
 
+def _wgrad(dense, sparse, F, D, g1, scale, ldw=None):
+    L = _lib.lib()
+    B, H = sparse.shape[0], g1.shape[1]
+    hd = dense is not None
+    n = F + (1 if hd else 0)
+    width = n * (n - 1) // 2 + D * n
+    ldw = ldw or width
+    dW = torch.full((H, ldw), float("nan"), device=sparse.device)
+    ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, int(hd), H), sparse.device)
+    _lib.check(L.tzr_dot_interaction_top_wgrad(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), g1.stride(0), H,
+                                               _lib.ptr(scale), _lib.ptr(dW), ldw, _lib.ptr(ws), ws.numel(),
+                                               _lib.stream_ptr(sparse.device)), "wgrad")
+    return dW, width
+
+
+@pytest.mark.parametrize("B,F", [(1, 26), (16, 26), (37, 26), (600, 26), (2100, 26), (50, 3), (33, 1), (40, 28), (21, 15), (70, 16), (35, 31)])
+def test_top_wgrad_matches_torch(dev, B, F):
+    """dW1 = scale * g1^T z with z rebuilt on the chip (csrc/interaction_wgrad.hip) against autograd's weight gradient of the
+    Linear over the materialised z: to 1e-5 of the largest entry; twice the same bits; columns behind the width untouched."""
+    D, H = 16, 64
+    torch.manual_seed(B * 17 + F)
+    dense = torch.randn(B, D, device=dev)
+    sparse = torch.randn(B, F * D, device=dev)
+    g1 = torch.randn(B, H, device=dev)
+    scale = torch.tensor([0.5], device=dev)
+    z = _torch_z(dense, sparse, D).double()
+    ref = (0.5 * (g1.double().t() @ z)).float()
+    dW, width = _wgrad(dense, sparse, F, D, g1, scale, ldw=_torch_z(dense, sparse, D).shape[1] + 5)
+    assert torch.isnan(dW[:, width:]).all()
+    _close(dW[:, :width], ref, 1e-5)
+    dW2, _ = _wgrad(dense, sparse, F, D, g1, scale)
+    assert torch.equal(dW2, dW[:, :width])
+    dW3, _ = _wgrad(dense, sparse, F, D, g1, None)
+    _close(dW3, 2 * ref, 1e-5)
+
+
+def test_top_wgrad_without_dense_row_and_empty_batch(dev):
+    D, H, F, B = 16, 64, 20, 45
+    torch.manual_seed(3)
+    sparse = torch.randn(B, F * D, device=dev)
+    g1 = torch.randn(B, H, device=dev)
+    X = sparse.view(B, F, D).double()
+    iu = torch.triu_indices(F, F, offset=1)
+    z = torch.cat([torch.bmm(X, X.transpose(1, 2))[:, iu[0], iu[1]], sparse.double()], dim=1)
+    dW, width = _wgrad(None, sparse, F, D, g1, None)
+    assert width == z.shape[1]
+    _close(dW, (g1.double().t() @ z).float(), 1e-5)
+    e = sparse[:0]
+    dW0, _ = _wgrad(None, e, F, D, g1[:0], None)
+    assert torch.count_nonzero(dW0) == 0
+
+
 def test_top_unsupported_shapes(dev):
     L = _lib.lib()
     assert L.tzr_dot_interaction_top_supported(26, 16, 1, 64) == 1
@@ -102,6 +154,48 @@ def test_interaction_top_loss_matches_unfused(dev, B):
     (loss * 0.25).backward()
     for w, p in zip(want, ps):
         _close(p.grad, w, 1e-5)
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_interaction_top_loss_keeps_no_interaction_rows(dev, monkeypatch, scaled):
+    """The fused DLRM head with the weight gradient of its first layer from tzr_dot_interaction_top_wgrad: the forward is
+    called without a z buffer, and every gradient equals the variant that stores z for the GEMM library (`OWNED_WGRAD =
+    False`) to 1e-5 of its largest entry -- for autograd's unit gradient and for a scaled loss."""
+    from torcheasyrec_amd import dense as dn
+
+    D, F, B = 16, 26, 70
+    torch.manual_seed(21)
+    width = 27 * 26 // 2 + 27 * D
+    l1, l2, lo = torch.nn.Linear(width, 64).to(dev), torch.nn.Linear(64, 32).to(dev), torch.nn.Linear(32, 1).to(dev)
+    x_d, x_s = torch.randn(B, D, device=dev, requires_grad=True), torch.randn(B, F * D, device=dev, requires_grad=True)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+    ps = [x_d, x_s, l1.weight, l1.bias, l2.weight, l2.bias, lo.weight, lo.bias]
+    allocated = []
+    real_empty = torch.empty
+
+    def spy_empty(*size, **kw):
+        allocated.append(tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size))
+        return real_empty(*size, **kw)
+
+    grads, kept_z = {}, {}
+    for owned in (True, False):
+        monkeypatch.setattr(dn, "OWNED_WGRAD", owned)
+        for p_ in ps:
+            p_.grad = None
+        allocated.clear()
+        monkeypatch.setattr(torch, "empty", spy_empty)
+        loss, _ = dn.interaction_top_loss(x_d, x_s, D, l1, l2, lo, y)
+        monkeypatch.setattr(torch, "empty", real_empty)
+        kept_z[owned] = (B, width) in allocated
+        if scaled:
+            (loss * 0.125).backward()
+        else:
+            with dn.root_loss():
+                loss.backward()
+        grads[owned] = [p_.grad.clone() for p_ in ps]
+    assert kept_z == {True: False, False: True}
+    for a_, b_ in zip(grads[True], grads[False]):
+        _close(a_, b_, 1e-5)
 
 
 @pytest.mark.parametrize("fused_interaction", [True, False])

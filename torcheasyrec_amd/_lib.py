@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 7  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 8  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -137,6 +137,9 @@ _SIGNATURES = {
                                            _vp, _i64, _vp]),
     "tzr_dot_interaction_top_bwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp,
                                            _i64, _vp, _i64, _vp]),
+    "tzr_dot_interaction_top_wgrad_workspace": (_i64, [_i32, _i32, _i32, _i32]),
+    "tzr_dot_interaction_top_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp,
+                                             _i64, _vp]),
     "tzr_jagged_to_padded_dense": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, C.c_float, _vp, _vp]),
     "tzr_padded_dense_to_jagged": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "tzr_quantize_rows_q8f16": (_i32, [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),

@@ -1,0 +1,493 @@
+// K9c: the weight gradient of the Linear behind the DLRM dot interaction, dW1 = g1^T z, WITHOUT z in HBM (gfx950).
+//
+// DLRM.predict (/root/reference/tzrec/models/dlrm.py:123-135) feeds z[b] = [pairs of X_b X_b^T | dense row | sparse rows]
+// (P + 16 n floats) into `final_mlp` (/root/reference/tzrec/modules/mlp.py:58-83); autograd's weight gradient of its first
+// Linear is g1^T z, a [64 x B] . [B x (P + 16 n)] product over the stored z (205 MB at B = 65 536, written by the forward
+// only for this).  Here the z columns are rebuilt from X on the chip:
+//
+//   * the P + 16 n columns are cut into FOUR column groups, at most one block of the pair matrix each -- c00 = pairs (i < j <
+//     16), c01 = (i < 16 <= j), c11 = (16 <= i < j) -- plus a share of the X rows that evens out the MFMA work; a workgroup =
+//     (batch slice, column group).  With 256 workgroups that is 64 batch slices: 64 x 200 KB of partial sums instead of
+//     256 x 200 KB for workgroups that each own the full width (the partials are the only HBM writes of this kernel);
+//     the four groups of one slice sit on the same XCD (blockIdx -> XCD round-robin), so its L2 serves the X rows they share.
+//   * a tile is 32 samples, kept in LDS TRANSPOSED, zT[column][sample] and g1T[h][sample]: the samples are the contraction
+//     index of v_mfma_f32_16x16x4_f32, and one ds_read_b128 per operand then covers four k-steps.  The transposition costs
+//     no extra pass: a loader wave builds the pair blocks of FOUR consecutive samples (four MFMAs each), so a lane holds the
+//     same (i, j) of four samples -- one ds_write_b128 per (i, j); the X-row columns come out of the same operand registers.
+//   * eight waves multiply (wave = output block of the 64 layer outputs x column half: up to eight 16 x 16 accumulators,
+//     64 MFMAs per tile), eight load and build the next tile meanwhile; ONE barrier per tile (two tiles in LDS).
+//   * tzr_ia_wgrad_reduce_kernel sums the slices' partials in fixed order (deterministic), applies the loss scale and puts
+//     the columns back in z's order.
+// Exact fp32 MFMA throughout.  6.6 GFLOP + 1.6 for the pair blocks at B = 65 536.
+//
+// Measured (B = 65 536, profiles/r04x .. r04ak): 103 us + 6.5 us for the reduce kernel alone, the same as the library's split-K
+// GEMM plus the z store it needs inside the step (0.5693 vs 0.5668 ms per step; ahead of it at 8 192 and 32 768).  The
+// multipliers run at the MFMA pipe's pace (~4 500 clocks per tile against 4 096 of MFMA issue); what is left is the loaders'
+// chain per tile -- and the finding that cost the most time here: fp32 MFMAs and VALU instructions share ONE pipe on this
+// chip, so every v_mov / address instruction of a loader is taken from the product's time, and a loader's own 16 MFMAs queue
+// behind the multipliers'.  Versions on the way: all sixteen waves doing everything in turn 131 us (phases additive) ->
+// specialised waves 129 -> loads two tiles ahead 122 -> 1 KB-per-instruction operand loads 118 -> 32-bit sample offsets (700 ->
+// 250 instructions per tile and loader) 109 -> X rows out of the pair-operand registers 113 (fewer loads, more v_mov).
+// HBM traffic: X and g1 once (131 MB; the column groups' re-reads hit the L2, profiles/r04ad).
+#include "tzr_common.h"
+#include <tzr_gfx950.h>
+
+#define WG_THREADS 1024
+#define WG_WAVES (WG_THREADS / TZR_WAVE)
+#define WG_S 32            // samples per tile
+#define WG_ZP 40           // floats between two columns of a tile in LDS (32 + 8: the b128 operand reads of a 16-lane group hit 64 distinct banks)
+#define WG_MAXB 16         // column blocks (of 16) per group
+#define WG_H 64
+#define WG_D 16
+#define WG_NG 4
+#define WG_MAXSLICES 64
+
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+
+// -DIT_PROF (scripts/build_prof_lib.sh): per wave, the clocks spent in each phase of the tile loop, into the table of
+// tzr_it_prof_table (interaction_top.hip); not compiled into the product.
+#ifdef IT_PROF
+extern "C" uint64_t* g_tzr_it_prof;
+#define WG_PROF_DECL uint64_t wg_tl = __builtin_amdgcn_s_memtime(), wg_ts[6] = {0, 0, 0, 0, 0, 0}
+#define WG_PROF_MARK(i) do { const uint64_t wg_now = __builtin_amdgcn_s_memtime(); wg_ts[i] += wg_now - wg_tl; wg_tl = wg_now; } while (0)
+#define WG_PROF_DUMP(tab) do { if (tab && lane == 0) for (int i_ = 0; i_ < 6; ++i_) (tab)[((size_t)blockIdx.x * WG_WAVES + wv) * 6 + i_] = wg_ts[i_]; } while (0)
+#define WG_PROF_TOUCH(x) do { float wg_tmp = (x); TZR_OPAQUE(wg_tmp); } while (0)
+#else
+#define WG_PROF_DECL
+#define WG_PROF_MARK(i)
+#define WG_PROF_DUMP(tab)
+#define WG_PROF_TOUCH(x)
+#endif
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgGroup {
+  int src;    // block of the pair matrix this group produces: 0 none, 1 c00, 2 c01, 3 c11
+  int npb;    // its pair columns, in blocks of 16 (the last one padded)
+  int x0, xn; // X rows [x0, x0 + xn) behind them, one block each
+  int nb;     // npb + xn <= WG_MAXB
+  int vbase;  // first column of the group in a row of the partial sums
+};
+
+struct WgArgs {
+  const float *dense, *sparse, *g1;
+  float* part;  // [slices][64][vw]
+  int64_t dense_stride, sparse_stride, g1_stride, B;
+  int n, hd, slices, vw, debug;
+  uint64_t* prof;
+  WgGroup g[WG_NG];
+};
+
+// Column groups for n rows (n0 = min(n, 16) low rows, n1 = n - 16 high rows): the pair blocks go to groups 0 / 1 / 2, the X
+// rows to whichever group has the least MFMA work so far (a pair block costs 16 production MFMAs per 4 samples on top of
+// its columns).  Every group ends with at most 16 blocks: c00 / c11 have <= 8, c01 <= 16, and 64 blocks hold everything.
+// A loader reads whole 16-row blocks of X (the low rows, the high rows or both), which serve its pair block AND its X rows:
+// the row ranges go out in the order group 0 (c00: low rows), 3, 1, 2 (c11: high rows), so that the groups that need one
+// block for their pairs mostly find their X rows in it.
+static void wg_plan(int n, WgGroup g[WG_NG], int* vw) {
+  const int n0 = n < 16 ? n : 16, n1 = n > 16 ? n - 16 : 0;
+  const int np[WG_NG] = {n0 * (n0 - 1) / 2, n0 * n1, n1 * (n1 - 1) / 2, 0};
+  int cost[WG_NG];
+  for (int k = 0; k < WG_NG; ++k) {
+    g[k].src = np[k] > 0 ? k + 1 : 0;
+    g[k].npb = (np[k] + 15) / 16;
+    g[k].xn = 0;
+    cost[k] = (g[k].src ? 64 : 0) + 16 * g[k].npb;
+  }
+  for (int row = 0; row < n; ++row) {
+    int best = -1;
+    for (int k = 0; k < WG_NG; ++k)
+      if (g[k].npb + g[k].xn < WG_MAXB && (best < 0 || cost[k] < cost[best])) best = k;
+    g[best].xn += 1;
+    cost[best] += 16;
+  }
+  const int order[WG_NG] = {0, 3, 1, 2};
+  int x0 = 0;
+  for (int o = 0; o < WG_NG; ++o) {
+    const int k = order[o];
+    g[k].x0 = x0;
+    x0 += g[k].xn;
+  }
+  int vb = 0;
+  for (int k = 0; k < WG_NG; ++k) {
+    g[k].nb = g[k].npb + g[k].xn;
+    g[k].vbase = vb;
+    vb += 16 * g[k].nb;
+  }
+  *vw = vb;
+}
+
+// X row i of sample b (row 0 is the dense row when there is one)
+__device__ __forceinline__ const float* wg_row(const WgArgs& a, int64_t b, int i) {
+  return (a.hd && i == 0) ? a.dense + b * a.dense_stride : a.sparse + b * a.sparse_stride + (int64_t)(i - a.hd) * WG_D;
+}
+
+// The sixteen waves of a workgroup are SPECIALISED (first version: every wave loaded, built and multiplied in turn, the
+// three phases simply added up -- 27 + 48 + 57 us, profiles/r04x; a wave whose loads wait for a slot in the memory pipe
+// cannot issue its MFMAs either):
+//   waves 0 .. 7   load and build: loader l owns samples 4 l .. 4 l + 3 of every tile.  It reads 16-row blocks of X the way
+//                  the MFMA wants them -- lane (r, q): 16 bytes of row r at column 4 q, one instruction = 1 KB in one piece
+//                  -- builds the pair block of each sample (4 MFMAs) and stores, per entry, the four samples side by side;
+//                  the same registers are the group's X-row columns (a 4 x 4 transpose that costs nothing: component c of
+//                  the four samples' registers = one 16-byte store); one g1 item.  It runs two tiles ahead.
+//                  (X rows loaded one float per lane, four samples per item: 24 more load instructions per tile and loader,
+//                  and the CU's one memory pipe took ~2 000 clocks per tile to take them all, profiles/r04ae.)
+//   waves 8 .. 15  multiply: wave 8 + w = (output block hb = w & 3, column half ch = w >> 2), blocks ch, ch + 2, ... (<= 8
+//                  accumulators); two of them on every SIMD keep its MFMA pipe fed.
+// One barrier per tile hands tile t + 1 over.
+
+// LDS address (floats) of column block b of a tile: the pair blocks 16 columns x WG_ZP apart, the X-row blocks 8 floats more
+// (one lane per ROW stores into them: at 640 floats from row to row all eight lanes of a store group hit the same banks)
+#define WG_XBP (16 * WG_ZP + 8)
+#define WG_ZT (WG_MAXB * WG_XBP)  // floats per tile buffer
+__device__ __forceinline__ int wg_block_base(int b, int npb) { return b < npb ? b * (16 * WG_ZP) : npb * (16 * WG_ZP) + (b - npb) * WG_XBP; }
+
+// Registers a loader thread carries from the loads of a tile to its LDS stores.  Every load lands in the register it is
+// used from: nothing touches a loaded value (no select, no mask, no copy) before the stores -- that would be a wait right
+// behind the loads.  fetch() is branch-free (rows and samples clamped): hipcc then knows how many loads are younger than the
+// ones it waits for and leaves them in flight (s_waitcnt vmcnt(N), N > 0).
+template <bool LO, bool HI>
+struct WgRegs {
+  float4 lo[LO ? 4 : 1];  // (row r, columns 4 q .. 4 q + 3) of the wave's four samples
+  float4 hi[HI ? 4 : 1];  // (row 16 + r, ...)
+  float4 gv;              // g1 item: output h of 4 samples
+};
+
+// SRC = the group's block of the pair matrix (0: X rows only); LO / HI: which 16-row blocks of X the loaders read (what the
+// pair block needs and what the group's X rows lie in).
+template <int SRC, bool LO, bool HI>
+__device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float* __restrict__ zT, float* __restrict__ gT, int slice) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));
+  const int r = lane & 15, q = lane >> 4;
+  const int n = a.n;
+  const int n0 = n < 16 ? n : 16, n1 = n > 16 ? n - 16 : 0;
+  // (32-bit arithmetic throughout: the launcher checks that B * stride fits 32 bits for the three inputs -- with 64-bit
+  // sample offsets the loaders ran ~700 instructions per tile, most of them address arithmetic, profiles/r04ab)
+  const int B = (int)a.B;
+  const int ntiles = (B + WG_S - 1) / WG_S;
+  int t = slice;
+
+  const bool is_loader = wv < 8;
+  if (is_loader) {
+    // ================================================= loaders
+    const int lw = wv;  // the quad of samples of this wave
+    const unsigned dstride = (unsigned)a.dense_stride, sstride = (unsigned)a.sparse_stride, gstride = (unsigned)a.g1_stride;
+    typedef WgRegs<LO, HI> Regs;
+    // lane constants (a few registers, kept across the loop)
+    const bool lo_dense = a.hd && r == 0;  // this lane's low row is the dense row
+    const int rlo = r < n ? r : n - 1, rhi = 16 + r < n ? 16 + r : n - 1;
+    const unsigned lo_off = (unsigned)((rlo > a.hd ? rlo - a.hd : 0) * WG_D + 4 * q);
+    const unsigned hi_off = (unsigned)((rhi - a.hd) * WG_D + 4 * q);  // (a high row is never the dense row)
+    // loads of tile tt into registers (samples behind the batch read the last one; their g1 is zeroed at the store); the
+    // sample is wave-uniform: scalar row bases, 32-bit lane offsets
+    auto fetch = [&](Regs& R, int tt) {
+      const int s0 = tt * WG_S + 4 * lw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned se = (unsigned)(s0 + e < B ? s0 + e : B - 1);
+        const float* sp = a.sparse + se * sstride;  // (scalar)
+        if (LO) R.lo[e] = tzr_ld4(lo_dense ? a.dense + se * dstride + 4 * q : sp + lo_off);
+        if (HI) R.hi[e] = tzr_ld4(sp + hi_off);
+        const float gvv = (a.g1 + se * gstride)[lane];
+        if (e == 0) R.gv.x = gvv; else if (e == 1) R.gv.y = gvv; else if (e == 2) R.gv.z = gvv; else R.gv.w = gvv;
+      }
+    };
+    // component c of the four samples' registers = the four consecutive floats (samples 4 l ..) of one column: one 16-byte
+    // store.  (The four v_mov that line the registers up are VALU work, and the VALU shares its pipe with the multipliers'
+    // fp32 MFMAs; as dword stores straight from the registers -- ds_write2_b32, no VALU -- the stores of a row block hit 4
+    // banks with 32 lanes and the kernel got slower, 113 -> 119 us, profiles/r04aj.)
+    auto comp4 = [](const float4* v, int c) {
+      return c == 0 ? make_float4(v[0].x, v[1].x, v[2].x, v[3].x) : c == 1 ? make_float4(v[0].y, v[1].y, v[2].y, v[3].y)
+           : c == 2 ? make_float4(v[0].z, v[1].z, v[2].z, v[3].z) : make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+    };
+    WG_PROF_DECL;
+    // The registers (loaded from tile tt) into tile buffer `buf`, and the loads of tile tn into the same registers, in the
+    // order that keeps the chain short: the X-row / g1 stores first (they wait for nothing but the loads), then the pair
+    // MFMAs -- which queue behind the multipliers' -- then the NEW loads (the operand registers are free once the MFMAs have
+    // issued; the 1 KB-per-instruction loads take the CU's memory pipe ~16 clocks each), the pair stores last.
+    auto step = [&](int buf, Regs& R, int tt, int tn, bool build, bool load) {
+      float* zb = zT + buf * WG_ZT;
+      wg_f32x4 c[4];
+      if (build) {
+        // the group's X rows out of the registers: row -> block npb + (row - x0), column 4 q + c of it
+        float* xb = zb + G.npb * (16 * WG_ZP) + (4 * q) * WG_ZP + 4 * lw;
+        if (LO) {
+          const int xl = r - G.x0;
+          if (xl >= 0 && xl < G.xn) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) tzr_st4(xb + xl * WG_XBP + cc * WG_ZP, comp4(R.lo, cc));
+          }
+        }
+        if (HI) {
+          const int xl = 16 + r - G.x0;
+          if (xl >= 0 && xl < G.xn) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) tzr_st4(xb + xl * WG_XBP + cc * WG_ZP, comp4(R.hi, cc));
+          }
+        }
+        const int s = tt * WG_S + 4 * lw;
+        const float4 g = R.gv;
+        float* go = gT + buf * (WG_H * WG_ZP) + lane * WG_ZP + 4 * lw;
+        if (s + 3 < B) tzr_st4(go, g);  // (scalar branch: only the batch's last tile masks)
+        else tzr_st4(go, make_float4(s < B ? g.x : 0.f, s + 1 < B ? g.y : 0.f, s + 2 < B ? g.z : 0.f, s + 3 < B ? g.w : 0.f));
+        if (SRC != 0) {
+          // per sample a 16 x 16 block of X X^T by four v_mfma_f32_16x16x4_f32 (lane (r, q) supplies column 4 q + k-step of
+          // row r); result register e of lane (r, q) = entry (i = 4 q + e, j = r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float4 av = SRC == 3 ? R.hi[HI ? e : 0] : R.lo[LO ? e : 0], bv = SRC == 1 ? R.lo[LO ? e : 0] : R.hi[HI ? e : 0];
+            c[e] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+            c[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, c[e], 0, 0, 0);
+            c[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, c[e], 0, 0, 0);
+            c[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, c[e], 0, 0, 0);
+            c[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, c[e], 0, 0, 0);
+          }
+        }
+      }
+      WG_PROF_MARK(1);  // X / g1 stores, pair MFMAs issued
+      if (load) fetch(R, tn);
+      WG_PROF_MARK(2);  // load issue
+      if (build && SRC != 0) {
+        // entry (i, j) -> column of the group: c00 / c11 the strict upper triangle of their rows, row-major; c01 all of i x
+        // n1.  The four samples' results side by side are the four consecutive floats of one zT column: one 16-byte store.
+        const int nn = SRC == 1 ? n0 : n1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * q + e, j = r;
+          const bool ok = SRC == 2 ? j < n1 : (i < j && j < nn);
+          const int col = SRC == 2 ? i * n1 + j : (i * (2 * nn - i - 1)) / 2 + j - i - 1;
+          if (ok) tzr_st4(zb + col * WG_ZP + 4 * lw, make_float4(c[0][e], c[1][e], c[2][e], c[3][e]));
+        }
+      }
+    };
+    if (t >= ntiles) return;
+    const int S = a.slices;
+    int cur = 0;
+    // R0 / R1 alternate: the set stored in an iteration is refilled with the tile three ahead -- the loads run TWO tiles ahead
+    // of the stores (one tile of multiplying does not cover a load under this traffic)
+    Regs R0, R1;
+    fetch(R0, t);
+    fetch(R1, t + S);
+    step(0, R0, t, t + 2 * S, true, true);
+    tzr_lds_barrier();
+    for (;;) {
+      WG_PROF_TOUCH(R1.gv.w);
+      WG_PROF_MARK(0);  // loads of the tile about to be stored
+      step(1, R1, t + S, t + 3 * S, !(a.debug & 2), !(a.debug & 4));  // (cur == 0 here: buffer 1.  Behind the last tile: samples >= B with g1 = 0 into a buffer nobody multiplies)
+      WG_PROF_MARK(4);  // pair stores
+      tzr_lds_barrier();  // tile t + S complete, the multipliers done with tile t
+      WG_PROF_MARK(3);  // barrier
+      t += S; cur ^= 1;
+      if (t >= ntiles) break;
+      WG_PROF_TOUCH(R0.gv.w);
+      WG_PROF_MARK(0);
+      step(0, R0, t + S, t + 3 * S, !(a.debug & 2), !(a.debug & 4));
+      WG_PROF_MARK(4);
+      tzr_lds_barrier();
+      WG_PROF_MARK(3);
+      t += S; cur ^= 1;
+      if (t >= ntiles) break;
+    }
+    WG_PROF_DUMP(a.prof);
+    return;
+  }
+  // =================================================== multipliers
+  // dW[16 hb .., blocks of this wave] += g1T . zT over the 32 samples of a buffer.  Lane (r, q), read kk: the four samples
+  // 16 kk + 4 q .. + 3 of row r of either operand = four k-steps (k index q).  Blocks ch, ch + 2, .., ch + 10 always (a block
+  // behind the group's last reads columns nobody writes -- zeros -- and is not stored), ch + 12 / ch + 14 behind scalar
+  // branches: the operand reads of a half tile are in flight before its first MFMA.
+  const int hb = wv & 3, ch = (wv & 7) >> 2;
+  const int nbw = G.nb > ch ? (G.nb - ch + 1) >> 1 : 0;  // blocks ch, ch + 2, ... of this wave
+  wg_f32x4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  int bb[8];  // LDS offsets of this wave's blocks (scalar)
+#pragma unroll
+  for (int m = 0; m < 8; ++m) bb[m] = wg_block_base(ch + 2 * m < WG_MAXB ? ch + 2 * m : WG_MAXB - 1, G.npb);
+  auto mma = [&](wg_f32x4& c, const float4 av, const float4 bv) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, c, 0, 0, 0);
+  };
+  auto product = [&](int buf) {
+    const float* gp = gT + buf * (WG_H * WG_ZP) + (16 * hb + r) * WG_ZP + 4 * q;
+    const float* zp = zT + buf * WG_ZT + r * WG_ZP + 4 * q;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float4 av = tzr_ld4(gp + 16 * kk);
+      float4 bv[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) bv[m] = tzr_ld4(zp + bb[m] + 16 * kk);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) mma(acc[m], av, bv[m]);
+      if (nbw > 6) mma(acc[6], av, tzr_ld4(zp + bb[6] + 16 * kk));
+      if (nbw > 7) mma(acc[7], av, tzr_ld4(zp + bb[7] + 16 * kk));
+    }
+  };
+  if (t < ntiles) {
+    tzr_lds_barrier();  // tile t is in buffer 0
+    int cur = 0;
+    WG_PROF_DECL;
+    for (; t < ntiles; t += a.slices, cur ^= 1) {
+      if (!(a.debug & 1)) product(cur);
+      WG_PROF_MARK(4);  // product
+      tzr_lds_barrier();
+      WG_PROF_MARK(5);  // barrier
+    }
+    WG_PROF_DUMP(a.prof);
+  }
+  // ---- partial sums of this slice: accumulator register e of lane (r, q) = dW[h = 16 hb + 4 q + e][column r of the block]
+  int le = lane;
+  TZR_OPAQUE(le);  // (the store addresses are built here, not before the tile loop and carried through it)
+  float* po = a.part + ((int64_t)slice * WG_H + 16 * hb + 4 * (le >> 4)) * a.vw + G.vbase + (le & 15);
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (m < nbw) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) po[(int64_t)e * a.vw + 16 * (ch + 2 * m)] = acc[m][e];
+    }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void tzr_ia_wgrad_kernel(WgArgs a) {
+  __shared__ __attribute__((aligned(16))) float zT[2 * WG_ZT];  // [tile][column block][column][sample]
+  __shared__ __attribute__((aligned(16))) float gT[2 * WG_H * WG_ZP];          // [tile][h][sample]
+  // workgroup -> (slice, group): the four groups of a slice on one XCD
+  const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+  const int gi = kx & 3, slice = (kx >> 2) * 8 + xcd;
+  const WgGroup G = a.g[gi];
+  for (int k = threadIdx.x; k < 2 * WG_ZT; k += WG_THREADS) zT[k] = 0.f;  // pad columns of the last pair block stay zero
+  __syncthreads();
+  // which 16-row blocks of X the loaders of this group read: what its pair block needs, and where its X rows lie
+  const bool xlo = G.xn > 0 && G.x0 < 16, xhi = G.xn > 0 && G.x0 + G.xn > 16;
+  const bool lo = xlo || G.src == 1 || G.src == 2, hi = xhi || G.src == 2 || G.src == 3;
+  if (G.src == 0) {
+    if (lo && hi) wg_body<0, true, true>(a, G, zT, gT, slice);
+    else if (hi) wg_body<0, false, true>(a, G, zT, gT, slice);
+    else wg_body<0, true, false>(a, G, zT, gT, slice);
+  } else if (G.src == 1) {
+    if (hi) wg_body<1, true, true>(a, G, zT, gT, slice);
+    else wg_body<1, true, false>(a, G, zT, gT, slice);
+  } else if (G.src == 2) {
+    wg_body<2, true, true>(a, G, zT, gT, slice);
+  } else {
+    if (lo) wg_body<3, true, true>(a, G, zT, gT, slice);
+    else wg_body<3, false, true>(a, G, zT, gT, slice);
+  }
+}
+
+// dW1[h][c] = scale * sum over the slices of the partial column that holds z column c.  Four lanes per output, lane j sums the
+// slices j, j + 4, ... in order, then (s0 + s1) + (s2 + s3): one fixed order.  A wave = 16 outputs x 4 (j = lane >> 4).
+struct WgReduceArgs {
+  const float *part, *scale;
+  float* dW;
+  int64_t ldw;
+  int n, slices, vw;
+  WgGroup g[WG_NG];
+};
+
+__global__ __launch_bounds__(256) void tzr_ia_wgrad_reduce_kernel(WgReduceArgs a) {
+  const int n = a.n, P = n * (n - 1) / 2, width = P + WG_D * n;
+  const int lane = threadIdx.x & 63, j = lane >> 4;
+  int o = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  const bool live = o < WG_H * width;
+  o = live ? o : WG_H * width - 1;
+  const int h = o / width, c = o - h * width;
+  const int n0 = n < 16 ? n : 16, n1 = n > 16 ? n - 16 : 0;
+  int v;
+  if (c >= P) {
+    const int x = (c - P) >> 4, d = (c - P) & 15;
+    int k = 0;
+    while (k < WG_NG - 1 && !(x >= a.g[k].x0 && x < a.g[k].x0 + a.g[k].xn)) ++k;
+    v = a.g[k].vbase + 16 * (a.g[k].npb + x - a.g[k].x0) + d;
+  } else {
+    int i = 0, p = c;
+    while (p >= n - 1 - i) { p -= n - 1 - i; ++i; }
+    const int jj = i + 1 + p;
+    if (jj < 16) v = a.g[0].vbase + (i * (2 * n0 - i - 1)) / 2 + jj - i - 1;
+    else if (i < 16) v = a.g[1].vbase + i * n1 + (jj - 16);
+    else v = a.g[2].vbase + ((i - 16) * (2 * n1 - (i - 16) - 1)) / 2 + jj - i - 1;
+  }
+  const int64_t step = (int64_t)WG_H * a.vw;
+  const float* p = a.part + (int64_t)h * a.vw + v + j * step;
+  float sum = 0.f;
+  for (int s0 = 0; s0 < a.slices; s0 += 32) {  // (slices: a multiple of 8; 8 loads in flight per lane)
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int s = s0 + 4 * k;
+      x[k] = p[(int64_t)(s < a.slices ? s : 0) * step];
+      x[k] = s < a.slices ? x[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += x[k];
+  }
+  // (adding the zeros of slices beyond the count changes nothing: x + 0 = x, and -0 never arises from a sum started at +0)
+  const float s1 = __shfl_xor(sum, 16), t01 = j & 1 ? s1 + sum : sum + s1;   // lanes j = 0 / 1: s0 + s1; j = 2 / 3: s2 + s3
+  const float t23 = __shfl_xor(t01, 32);
+  const float tot = j < 2 ? t01 + t23 : t23 + t01;
+  const float sc = a.scale ? *a.scale : 1.f;
+  if (live && j == 0) a.dW[(int64_t)h * a.ldw + c] = sc * tot;
+}
+
+int g_tzr_wg_debug = 0;  // tzr_tune("wg_debug"): phase-skipping bits for timing experiments (1 no product, 2 no tile build, 4 no loads, 8 no main kernel, 16 no reduce kernel): wrong results
+
+static int wg_slices(int64_t B) {
+  const int64_t ntiles = (B + WG_S - 1) / WG_S;
+  int64_t s8 = (ntiles + 31) / 32;  // about four tiles per slice before a slice is added
+  s8 = s8 < 1 ? 1 : (s8 > WG_MAXSLICES / 8 ? WG_MAXSLICES / 8 : s8);
+  return (int)(8 * s8);
+}
+
+extern "C" int64_t tzr_dot_interaction_top_wgrad_workspace(int F, int D, int has_dense, int H) {
+  if (!tzr_dot_interaction_top_supported(F, D, has_dense, H)) return 0;
+  WgGroup g[WG_NG];
+  int vw;
+  wg_plan(F + (has_dense ? 1 : 0), g, &vw);
+  return (int64_t)WG_MAXSLICES * WG_H * vw * (int64_t)sizeof(float);
+}
+
+extern "C" int tzr_dot_interaction_top_wgrad(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                             int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1,
+                                             int64_t g1_stride, int H, const float* d_scale, float* d_dW1, int64_t ldw,
+                                             void* d_ws, int64_t ws_bytes, void* stream) {
+  const int hd = d_dense ? 1 : 0;
+  const int n = F + hd;
+  if (!d_dW1 || F <= 0 || B < 0 || (B > 0 && (!d_g1 || !d_sparse))) return TZR_ERR_INVALID;
+  if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
+  const int width = n * (n - 1) / 2 + WG_D * n;
+  if (ldw < width) return TZR_ERR_INVALID;
+  if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
+      ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_dense)) & 15) ||
+      ((reinterpret_cast<uintptr_t>(d_g1) | reinterpret_cast<uintptr_t>(d_dW1)) & 3))
+    return TZR_ERR_INVALID;
+  // (the kernel's sample offsets are 32-bit)
+  if (B >= (int64_t)1 << 31 || B * sparse_stride >= (int64_t)1 << 32 || B * g1_stride >= (int64_t)1 << 32 ||
+      (hd && B * dense_stride >= (int64_t)1 << 32) || sparse_stride < 0 || g1_stride < 0 || dense_stride < 0)
+    return TZR_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  WgReduceArgs ra;
+  int vw;
+  wg_plan(n, ra.g, &vw);
+  const int slices = B > 0 ? wg_slices(B) : 0;
+  if (B > 0) {
+    if (!d_ws || ws_bytes < (int64_t)slices * WG_H * vw * (int64_t)sizeof(float) || (reinterpret_cast<uintptr_t>(d_ws) & 15))
+      return TZR_ERR_INVALID;
+    WgArgs a;
+    a.dense = d_dense; a.sparse = d_sparse; a.g1 = d_g1; a.part = static_cast<float*>(d_ws);
+    a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.g1_stride = g1_stride; a.B = B;
+    a.n = n; a.hd = hd; a.slices = slices; a.vw = vw; a.debug = g_tzr_wg_debug;
+#ifdef IT_PROF
+    a.prof = g_tzr_it_prof;
+#else
+    a.prof = nullptr;
+#endif
+    for (int k = 0; k < WG_NG; ++k) a.g[k] = ra.g[k];
+    if (!(g_tzr_wg_debug & 8)) hipLaunchKernelGGL(tzr_ia_wgrad_kernel, dim3(WG_NG * slices), dim3(WG_THREADS), 0, st, a);
+    TZR_CHECK_LAUNCH();
+  }
+  ra.part = static_cast<const float*>(d_ws); ra.scale = d_scale; ra.dW = d_dW1; ra.ldw = ldw; ra.n = n; ra.slices = slices; ra.vw = vw;
+  if (!(g_tzr_wg_debug & 16)) hipLaunchKernelGGL(tzr_ia_wgrad_reduce_kernel, dim3((WG_H * width + 63) / 64), dim3(256), 0, st, ra);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}

@@ -19,6 +19,7 @@ extern int g_tzr_ia_gen_wgs;
 extern int g_tzr_ia_fwd_wgs;
 extern int g_tzr_it_wgs;
 extern int g_tzr_it_stagger;
+extern int g_tzr_wg_debug;
 extern int g_tzr_mlp_mfma;
 
 extern "C" int tzr_tune(const char* name, int value) {
@@ -73,6 +74,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "it_stagger")) {
     g_tzr_it_stagger = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "wg_debug")) {
+    g_tzr_wg_debug = value;
     return TZR_OK;
   }
   if (!strcmp(name, "it_wgs")) {

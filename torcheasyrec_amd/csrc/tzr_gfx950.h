@@ -50,3 +50,4 @@ __device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkm
 // arithmetic (an LDS offset): hipcc otherwise hoists it out of the loop, runs out of registers and SPILLS it -- and the
 // reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
 #define TZR_OPAQUE(x) asm volatile("" : "+v"(x))
+

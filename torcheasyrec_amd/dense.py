@@ -245,11 +245,23 @@ def top_loss(z, l1, l2, out_linear, labels):
     return _TopLossFn.apply(z, l1.weight, l1.bias, l2.weight, l2.bias, out_linear.weight, out_linear.bias, labels)
 
 
+# The weight gradient of the layer behind the interaction: tzr_dot_interaction_top_wgrad (z rebuilt on the chip, nothing kept
+# from the forward) or, when False, the GEMM library over a z the forward writes out for it (`weight_grad`; bench.py
+# --gemm-wgrad).  Inside the step the two take the same time to within the run-to-run spread at 8 192 .. 65 536 samples
+# (profiles/r04ak: 0.1618 / 0.2291 / 0.3536 / 0.5693 ms against 0.1646 / 0.2265 / 0.3564 / 0.5668); the own kernel keeps no
+# [B, P + D n] activation (205 MB at 65 536) and leaves no library GEMM in the step.
+OWNED_WGRAD = True
+
+
+def _owned_wgrad(batch: int) -> bool:
+    return bool(OWNED_WGRAD)
+
+
 class _InteractionTopLossFn(torch.autograd.Function):
     """DLRM from the embeddings to the loss: dot interaction + first top-MLP layer as one kernel per direction
     (tzr_dot_interaction_top_fwd / _bwd, csrc/interaction_top.hip), the rest of the top MLP + loss + their backward as
-    tzr_mlp_tail.  The interaction row z [B, P + 16 n] is written once (the weight gradient g1^T z reads it); its
-    gradient dz = g1 W1 never exists in HBM.  Same returns as _TopLossFn."""
+    tzr_mlp_tail.  Neither the interaction row z [B, P + 16 n] nor its gradient dz = g1 W1 ever exists in HBM: the weight
+    gradient g1^T z rebuilds z from the embeddings too (tzr_dot_interaction_top_wgrad).  Same returns as _TopLossFn."""
 
     @staticmethod
     def forward(ctx, dense, sparse, D, W1, b1, W2, b2, w3, b3, labels):
@@ -261,22 +273,23 @@ class _InteractionTopLossFn(torch.autograd.Function):
         width = n * (n - 1) // 2 + D * n
         H1 = W1.shape[0]
         dev = sparse.device
-        z = torch.empty(B, width, dtype=torch.float32, device=dev)
         y1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
+        z = None if _owned_wgrad(B) else torch.empty(B, width, dtype=torch.float32, device=dev)
         W1_, b1_ = _f32c(W1), _f32c(b1)
         _lib.check(_lib.lib().tzr_dot_interaction_top_fwd(
             _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(W1_), W1_.stride(0),
-            _lib.ptr(b1_), H1, 1, _lib.ptr(z), z.stride(0), _lib.ptr(y1), y1.stride(0), _lib.stream_ptr(dev)),
+            _lib.ptr(b1_), H1, 1, _lib.ptr(z), width, _lib.ptr(y1), y1.stride(0), _lib.stream_ptr(dev)),
             "tzr_dot_interaction_top_fwd")
         logits, g1, dW2, db2, dw3, scal, db1 = _mlp_tail(y1, labels, W2, b2, w3, b3)
-        ctx.save_for_backward(dense, sparse, z, W1_, g1, dW2, db2, dw3, scal, db1)
+        ctx.save_for_backward(dense, sparse, W1_, g1, dW2, db2, dw3, scal, db1)
+        ctx.z = z
         ctx.cfg = (F, D)
         ctx.mark_non_differentiable(logits)
         return scal[1], logits
 
     @staticmethod
     def backward(ctx, gl, _glogits):
-        dense, sparse, z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
+        dense, sparse, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
         F, D = ctx.cfg
         B = sparse.shape[0]
         root = _loss_is_root()  # gl == 1.0: no scale operand for the kernel, no multi-tensor scaling launch
@@ -289,10 +302,38 @@ class _InteractionTopLossFn(torch.autograd.Function):
                 _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0),
                 g1.shape[1], _lib.ptr(W1), W1.stride(0), _lib.ptr(gl32), _lib.ptr(gd), gd.stride(0), _lib.ptr(gs),
                 gs.stride(0), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_bwd")
+        if not ctx.needs_input_grad[3]:
+            dW1 = None
+        elif ctx.z is None:
+            dW1 = interaction_top_wgrad(dense, sparse, D, g1, gl32)
+        else:
+            dW1 = weight_grad(g1, ctx.z) if root else weight_grad(g1, ctx.z) * gl
         if root:
-            return (gd, gs, None, weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1], None)
-        outs = torch._foreach_mul([weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1]], gl)
-        return (gd, gs, None, *outs, None)
+            return (gd, gs, None, dW1, db1, dW2, db2, dw3, scal[0:1], None)
+        outs = torch._foreach_mul([db1, dW2, db2, dw3, scal[0:1]], gl)
+        return (gd, gs, None, dW1, *outs, None)
+
+
+def interaction_top_wgrad(dense: torch.Tensor, sparse: torch.Tensor, D: int, g1: torch.Tensor,
+                          scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW1 = scale * g1^T z [H, P + D n] of the Linear behind the dot interaction, z rebuilt from (dense, sparse) on the chip
+    (tzr_dot_interaction_top_wgrad, csrc/interaction_wgrad.hip): autograd's weight gradient of the first `final_mlp` layer
+    (/root/reference/tzrec/modules/mlp.py:58-83 behind models/dlrm.py:123-135) without the [B, P + D n] rows in HBM."""
+    B = sparse.shape[0]
+    F = sparse.shape[1] // D
+    n = F + 1
+    width = n * (n - 1) // 2 + D * n
+    H = g1.shape[1]
+    if B == 0:
+        return torch.zeros(H, width, dtype=torch.float32, device=sparse.device)
+    dW = torch.empty(H, width, dtype=torch.float32, device=sparse.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, 1, H), sparse.device)
+    _lib.check(L.tzr_dot_interaction_top_wgrad(
+        _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
+        _lib.ptr(scale), _lib.ptr(dW), dW.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(sparse.device)),
+        "tzr_dot_interaction_top_wgrad")
+    return dW
 
 
 def interaction_top_fits(dense: torch.Tensor, sparse: torch.Tensor, D: int, first_linear) -> bool:
