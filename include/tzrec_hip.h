@@ -579,6 +579,8 @@ int tzr_delta_collect(uint32_t* d_bitmap, int64_t rows, int64_t id_base, int cle
  *   ia_fwd_wgs          workgroups of the D = 16 dot-interaction forward (0 = by batch size)
  *   mlp_mfma            -1: tzr_mlp2_* / tzr_mlp_tail use their general LDS-tiled kernels for every shape (0: the MFMA
  *                       kernels of mlp_mfma.hip where the shape is DLRM-Criteo's)
+ *   it_fwd_stagger      fused interaction forward: 1 = half of the waves build the next tile's row before the product, half behind it;
+ *                       2 / 3 = all before / all behind; 0 = half and half when z is written, all behind when not
  *   wg_debug            phase-skipping bits of tzr_dot_interaction_top_wgrad for timing experiments (wrong results)
  *   it_wgs              persistent workgroups of the fused interaction + first-layer kernels (0 = 256, one per CU)
  *   bwd_one_wg_heavy    1: a heavy bucket of the backward plan is sorted by ONE workgroup instead of one per

@@ -99,6 +99,10 @@ def main():
             L.tzr_tune(b"it_stagger", sg)
             print(f"B {B}: it_stagger {sg}: top_bwd {timed(top_bwd):6.1f} us", flush=True)
         L.tzr_tune(b"it_stagger", 0)
+        for sg in [int(x) for x in os.environ.get("IT_FWD_STAGGER", "").split(",") if x]:  # 1 half / half, 2 all row-first, 3 all row-second
+            L.tzr_tune(b"it_fwd_stagger", sg)
+            print(f"B {B}: it_fwd_stagger {sg}: top_fwd+z {timed(top_fwd(_lib.ptr(z))):6.1f}  top_fwd (no z) {timed(top_fwd(None)):6.1f} us", flush=True)
+        L.tzr_tune(b"it_fwd_stagger", 0)
         for dbg in [int(x) for x in os.environ.get("IT_DEBUG", "").split(",") if x]:
             if L.tzr_tune(b"it_debug", dbg) != 0:
                 break  # (the phase-skipping knob existed in the first versions only: profiles/r03ae)

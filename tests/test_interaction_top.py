@@ -115,6 +115,34 @@ def test_top_wgrad_without_dense_row_and_empty_batch(dev):
     assert torch.count_nonzero(dW0) == 0
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_top_fwd_wave_orders_agree(dev, mode):
+    """`it_fwd_stagger`: half of the waves build the next tile's row before the product / all before / all behind -- the same
+    bits (the order only moves work between barriers), with and without the z store."""
+    D, H, F, B = 16, 64, 26, 1100
+    torch.manual_seed(5)
+    L = _lib.lib()
+    dense, sparse = torch.randn(B, D, device=dev), torch.randn(B, F * D, device=dev)
+    width = 27 * 26 // 2 + 27 * D
+    W1, b1 = torch.randn(H, width, device=dev) * 0.05, torch.randn(H, device=dev)
+
+    def run(with_z):
+        z = torch.empty(B, width, device=dev) if with_z else None
+        y1 = torch.empty(B, H, device=dev)
+        _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(W1), width, _lib.ptr(b1), H, 1,
+                                                 _lib.ptr(z), width, _lib.ptr(y1), H, _lib.stream_ptr(sparse.device)), "fwd")
+        return y1, z
+
+    y_ref, z_ref = run(True)
+    assert L.tzr_tune(b"it_fwd_stagger", mode) == 0
+    try:
+        y_a, z_a = run(True)
+        y_b, _ = run(False)
+    finally:
+        L.tzr_tune(b"it_fwd_stagger", 0)
+    assert torch.equal(y_a, y_ref) and torch.equal(z_a, z_ref) and torch.equal(y_b, y_ref)
+
+
 def test_top_unsupported_shapes(dev):
     L = _lib.lib()
     assert L.tzr_dot_interaction_top_supported(26, 16, 1, 64) == 1

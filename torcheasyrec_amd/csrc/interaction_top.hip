@@ -114,9 +114,11 @@ struct ItBwdArgs {
 // t + G goes into the other buffer while the samples of tile t are still being contracted.
 #define IT_ZPD 884  // pitch up to which two dz tiles fit beside the X images (n <= 29)
 
+#define IT_TP 34  // row pitch of the pair-offset table (uint16)
+
 template <int NB, bool XL>
 __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ Gs,
-                                            float* __restrict__ Wx, int lane, int wv, int P, int npb, int nblk) {
+                                            float* __restrict__ Wx, uint16_t* __restrict__ Tab, int lane, int wv, int P, int npb, int nblk) {
   const int r = lane & 15, q = lane >> 4;
   const int n = a.n;
   const int zp = 16 * nblk + 4;           // pitch of a sample's dz row
@@ -162,6 +164,17 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
     }
     __syncthreads();
   }
+  // ---- where pair (k, c) lies in a sample's dz row (byte offset), or the zero slot: the first pad float behind the row
+  {
+    const int e = threadIdx.x, k = e >> 5, c = e & 31;
+    const int i = k < c ? k : c, j = k < c ? c : k;
+    const bool ok = i != j && j < n;
+    Tab[k * IT_TP + c] = (uint16_t)(4 * (ok ? (i * (2 * n - 1 - i)) / 2 + j - i - 1 : 16 * nblk));
+    if (e < (dbl ? 2 : 1) * IT_TS) Z[(e >> 4) * zt + (e & 15) * zp + 16 * nblk] = 0.f;  // the zero slot of every sample of the tile(s) (the W1 slabs lay here)
+  }
+  __syncthreads();
+  const uint16_t* tabl = Tab + q * IT_TP + r;   // lane constants of the contraction (k = 4 ks + q, c = 16 h + r)
+  const int xoff = q * (IT_D + 1) + r;
   const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
   const int64_t G = gridDim.x;
   int64_t t = blockIdx.x;
@@ -246,37 +259,26 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
     if (dbl && more && product_first) product(cur ^ 1, cur ^ 1);
     IT_PROF_MARK(2);  // product (first half of the waves)
     // ---- dX = (G + G^T) X + pass-through of sample wv of the tile (transposed product, see interaction.hip): S[k][i] is
-    // the dz element of pair (min, max) of (k, i), zero on the diagonal and beyond n
-    const float* zs = Z + zcur * zt + wv * zp;
+    // the dz element of pair (min, max) of (k, i), zero on the diagonal and beyond n.  Where that element lies in the dz row
+    // comes from a table in LDS (byte offsets; the invalid pairs point at a pad float that stays zero): worked out per
+    // element it was ~15 VALU instructions x 16 elements per tile and wave -- and VALU instructions share the fp32 MFMAs'
+    // pipe (283 -> ~60 VALU instructions per tile and wave, profiles/r04al).
+    const char* zs = reinterpret_cast<const char*>(Z + zcur * zt + wv * zp);
     it_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-    const int b2n1 = 2 * n - 1;
-    int lo = lane;
-    TZR_OPAQUE(lo);  // (the pair indices below are redone per tile: hoisted out of the loop they are 14 registers, spilled)
-    const int rr = lo & 15, qq = lo >> 4;
-    // (all eight k-steps, no branch on n: one straight block lets the compiler batch the index arithmetic and the LDS
-    // reads; rows of the X image beyond n are zero and pairs beyond n read as zero)
+    // (all eight k-steps, no branch on n: rows of the X image beyond n are zero and pairs beyond n read the zero slot)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const int k = 4 * ks + qq;
-      const float xv = xs[k * (IT_D + 1) + rr];
-      float sv[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = 16 * h + rr;
-        const int i = k < c ? k : c, j = k < c ? c : k;
-        const bool ok = i != j && j < n;
-        const int idx = (int)(__umul24((unsigned)i, (unsigned)(b2n1 - i)) >> 1) + j - i - 1;
-        const float v = zs[ok ? idx : 0];
-        sv[h] = ok ? v : 0.f;
-      }
-      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, sv[0], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, sv[1], d1, 0, 0, 0);
+      const float xv = xs[(4 * ks) * (IT_D + 1) + xoff];
+      const unsigned o0 = tabl[(4 * ks) * IT_TP], o1 = tabl[(4 * ks) * IT_TP + 16];
+      const float s0 = *reinterpret_cast<const float*>(zs + o0), s1 = *reinterpret_cast<const float*>(zs + o1);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s0, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s1, d1, 0, 0, 0);
     }
     IT_PROF_MARK(3);  // contraction
     const int64_t b = t * IT_TS + wv;
     int rq = r * IT_D + 4 * q;
     TZR_OPAQUE(rq);  // (recomputed per tile, not hoisted and spilled)
-    const float* pt = zs + 16 * npb;
+    const float* pt = reinterpret_cast<const float*>(zs) + 16 * npb;
     if (b < a.B) {
       // (b is wave-uniform: scalar row bases, the lane part from rq)
       if (v0) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_bwd_kernel(ItBwdArgs a)
   __shared__ float Xs[IT_WAVES][IT_XS];     // per wave: the X image of its sample
   __shared__ __attribute__((aligned(16))) float Gs[2 * IT_TS * IT_GP];   // the g1 tile, double-buffered
   __shared__ float Wx[IT_KS * TZR_WAVE];    // W1 fragment of wave 0's extra block (it_bwd_loop<NB, true>)
+  __shared__ uint16_t Tab[32 * IT_TP];      // byte offset of pair (k, c) in a sample's dz row
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));  // (scalar: per-wave bases stay in SGPRs)
   const int n = a.n;
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_bwd_kernel(ItBwdArgs a)
   const int npb = (P + 15) >> 4, nblk = npb + n;
   // DLRM-Criteo: 49 blocks = 3 per wave and one more for wave 0 (fragment in LDS); up to 48: 3 per wave, zero-weighted;
   // more: 4 per wave in registers (spills, correct)
-  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
-  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
-  else it_bwd_loop<4, false>(a, Z, &Xs[wv][0], Gs, Wx, lane, wv, P, npb, nblk);
+  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
+  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
+  else it_bwd_loop<4, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
@@ -330,7 +333,7 @@ struct ItFwdArgs {
   const float *dense, *sparse, *W1, *bias;
   float *z, *y1;
   int64_t dense_stride, sparse_stride, ldw, z_stride, y1_stride, B;
-  int n, hd, relu;
+  int n, hd, relu, stagger;
   uint64_t* prof;
 };
 
@@ -467,7 +470,8 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
     // ---- partial y1[:, 16 hb ..] over the z columns of this wave's K-group
     // Half of the waves (two of the four on every SIMD) produce the next tile's row BEFORE the product, the other half
     // behind it: in lockstep all sixteen would be in their LDS / store phase at once and the MFMA pipe would idle.
-    const bool row_first = (wv >> 2) & 1;
+    const bool half = (wv >> 2) & 1;
+    const bool row_first = a.stagger == 0 ? half : a.stagger == 1;  // (1 = every wave builds its row first, 2 = every wave behind the product)
     auto next_row = [&]() {
     // ---- the row of sample wv of tile t + G into the other buffer (and out to HBM); then tile t + 2 G's X rows take off
       if (t + G < ntiles) {
@@ -524,7 +528,7 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
     // product only (thread -> sample, two outputs): hipcc waits for the prefetched X rows with s_waitcnt vmcnt(0), and a
     // y1 store issued here would be in flight when a row-first wave reaches that wait right behind the barrier (it stood
     // there 5 k clocks per tile, profiles/r03ak)
-    if (!row_first) {
+    if (!half) {
       const int t8 = ((wv >> 3) << 2) | (wv & 3);  // 0..7 among the row-second waves
       const int s = 2 * t8 + (lane >> 5), h = 2 * (lane & 31);
       float v0 = bias0, v1 = bias1;
@@ -566,6 +570,11 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a)
 }
 
 int g_tzr_it_stagger = 0;  // tzr_tune("it_stagger"): which half of the waves runs the next product first (0 / 1), 2 = none (experiments)
+// tzr_tune("it_fwd_stagger"): forward, order of row building and product: 1 = half of the waves each way, 2 / 3 = every wave
+// row-first / row-second, 0 = by whether z is written: with the z stores half and half hides them behind the other half's
+// product (111.6 vs 116-118 us); without them nothing is left to hide -- MFMA and VALU share the pipe, the phases add up
+// either way -- and every wave row-second is 2 % ahead (95.8 vs 97.7 us, profiles/r04ap)
+int g_tzr_it_fwd_stagger = 0;
 int g_tzr_it_wgs = 0;  // tzr_tune("it_wgs"): workgroups of the fused kernels (0 = one per CU)
 
 static unsigned it_grid(int64_t B) {
@@ -632,6 +641,7 @@ extern "C" int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_s
   a.dense = d_dense; a.sparse = d_sparse; a.W1 = d_W1; a.bias = d_bias; a.z = d_z; a.y1 = d_y1;
   a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.ldw = ldw; a.z_stride = z_stride; a.y1_stride = y1_stride;
   a.B = B; a.n = n; a.hd = hd; a.relu = relu;
+  a.stagger = g_tzr_it_fwd_stagger > 0 ? g_tzr_it_fwd_stagger - 1 : (d_z ? 0 : 2);
 #ifdef IT_PROF
   a.prof = g_tzr_it_prof;
 #else

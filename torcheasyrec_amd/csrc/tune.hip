@@ -20,6 +20,7 @@ extern int g_tzr_ia_fwd_wgs;
 extern int g_tzr_it_wgs;
 extern int g_tzr_it_stagger;
 extern int g_tzr_wg_debug;
+extern int g_tzr_it_fwd_stagger;
 extern int g_tzr_mlp_mfma;
 
 extern "C" int tzr_tune(const char* name, int value) {
@@ -74,6 +75,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "it_stagger")) {
     g_tzr_it_stagger = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "it_fwd_stagger")) {
+    g_tzr_it_fwd_stagger = value;
     return TZR_OK;
   }
   if (!strcmp(name, "wg_debug")) {
