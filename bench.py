@@ -217,6 +217,12 @@ def config_model_steps(dev, work_stream, steps: int = 20):
                "value": B * steps / eager, "unit": "samples/s", "launch": "eager",
                "loss": {k: float(v.detach()) for k, v in losses.items()}}
         if capturable:
+            eg = getattr(model, "embedding_group", None)
+            if eg is not None and getattr(eg, "_seq_info", None):
+                # sequence groups padded to the configured sequence_length instead of the batch's longest sequence (read back from
+                # the device, which a capture cannot do): same results, the padded positions are masked
+                eg.static_sequence_padding = True
+                out["graph_static_sequence_padding"] = True
             try:
                 gs, pool = [], None
                 for b in bs:

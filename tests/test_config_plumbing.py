@@ -256,6 +256,31 @@ def test_multi_tower_din_config_to_training(dev):
         assert not torch.equal(ec.table_weights()[name].detach(), w), name
 
 
+def test_static_sequence_padding_changes_shapes_not_results(dev):
+    """`EmbeddingGroup.static_sequence_padding`: the sequence group padded to its configured `sequence_length` (no read-back of
+    the batch's longest sequence: the step becomes capturable) -- the same logits and the same gradients as padded to the
+    batch maximum, because everything behind a sample's length is masked."""
+    emu_heavy(dev)
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "din_mini.config")).read())
+    # a batch whose longest history is shorter than the configured 12 steps
+    batch = next(b for sd in range(50) for b in _din_batches(spec, 3, 3, seed=sd)
+                 if 0 < int(b.sparse_features[BASE_DATA_GROUP].lengths().max()) < 9).to(dev)
+    outs = {}
+    for static in (False, True):
+        torch.manual_seed(0)
+        model = build_rank_model(spec, device=dev)  # (a fresh model per mode: the backward below trains the tables)
+        model.embedding_group.static_sequence_padding = static
+        L = model.embedding_group(batch)["seq.sequence"].shape[1]
+        pred = model(batch)
+        losses = model.loss(pred, batch)
+        sum(losses.values()).backward()
+        outs[static] = (L, pred["logits"].detach().clone(), [p_.grad.detach().clone() for p_ in model.dense_parameters()])
+    assert outs[True][0] == 12 and outs[False][0] < 9
+    torch.testing.assert_close(outs[True][1], outs[False][1], rtol=1e-6, atol=1e-6)
+    for a_, b_ in zip(outs[True][2], outs[False][2]):
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-6)
+
+
 def test_mmoe_with_zch_config_to_training(dev):
     """BASELINE config 5 at the config level: `mmoe {...}` over a group whose user id goes through a
     zero-collision hash (LFU eviction); two task towers, two labels, two losses."""

@@ -142,3 +142,70 @@ def test_graph_pipeline_honours_learning_rate_changes_after_capture():
         torch.testing.assert_close(wb[n], wa[n], rtol=1e-5, atol=1e-6, msg=n)
     # and the schedule did matter: a frozen rate ends somewhere else
     assert sparse_lr(n_steps - 1) != sparse_lr(0)
+
+
+@pytest.mark.gpu
+def test_sequence_model_step_is_capturable_with_static_padding():
+    """multi_tower_din (a SEQUENCE group with variable-length histories): with `static_sequence_padding` and the ids-per-key
+    counted while the batch is still in host memory, a whole train step captures into a hipGraph; one replay leaves the same
+    tables and dense weights as one eager step of an identically seeded model."""
+    import numpy as np
+
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.config import load_pipeline_spec
+    from torcheasyrec_amd.dense import FusedDenseAdam
+    from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, _backward_of_losses, _losses_and_predictions
+    from torcheasyrec_amd.rank_model import build_rank_model
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    spec = load_pipeline_spec(open(os.path.join(os.path.dirname(__file__), "golden", "din_mini.config")).read())
+    B = 64
+    rng = np.random.default_rng(4)
+    sparse = [f for f in spec.features if f.is_sparse]
+    dense = [f for f in spec.features if not f.is_sparse]
+
+    def batch():
+        lens = [rng.integers(0, f.sequence_length + 1, size=B).astype(np.int32) if f.is_sequence else np.ones(B, np.int32) for f in sparse]
+        seq = [i for i, f in enumerate(sparse) if f.is_sequence]
+        for i in seq[1:]:
+            lens[i] = lens[seq[0]]
+        vals = [rng.integers(0, f.num_embeddings, size=int(ln.sum())) for f, ln in zip(sparse, lens)]
+        kjt = KeyedJaggedTensor([f.name for f in sparse], torch.from_numpy(np.concatenate(vals).astype(np.int64)),
+                                torch.from_numpy(np.concatenate(lens)))
+        kt = KeyedTensor([f.name for f in dense], [f.value_dim for f in dense],
+                         torch.from_numpy(rng.random((B, sum(f.value_dim for f in dense)), dtype=np.float32)))
+        return Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt}, {"clk": torch.from_numpy((rng.random(B) < 0.3).astype(np.int64))}).to(dev)
+
+    warm, b = batch(), batch()
+    assert b.sparse_features[BASE_DATA_GROUP]._length_per_key is not None  # counted on the host side of .to()
+    stream = torch.cuda.Stream(device=dev)
+    states = []
+    with torch.cuda.stream(stream):
+        for captured in (False, True):
+            torch.manual_seed(3)
+            model = build_rank_model(spec, device=dev)
+            model.embedding_group.static_sequence_padding = True
+            opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
+
+            def step(bb):
+                opt.zero_grad(set_to_none=True)
+                losses, _ = _losses_and_predictions(model, model.loss, bb)
+                _backward_of_losses(losses)
+                opt.step()
+
+            step(warm)  # (allocations, permutation tensors, lazily built state: outside the capture)
+            if captured:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    step(b)
+                g.replay()
+            else:
+                step(b)
+            torch.cuda.synchronize()
+            eg = model.embedding_group
+            states.append([t.detach().clone() for t in list(eg.ebc.table_weights().values()) + list(eg.ecs["16"].table_weights().values())]
+                          + [p.detach().clone() for p in model.dense_parameters()])
+    for a_, b_ in zip(*states):
+        torch.testing.assert_close(a_, b_, rtol=1e-6, atol=1e-7)

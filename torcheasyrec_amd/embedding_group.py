@@ -275,6 +275,9 @@ class EmbeddingGroup(nn.Module):
         from .sequence import EmbeddingCollection, EmbeddingConfig
 
         self._seq_info: "OrderedDict[str, dict]" = OrderedDict()
+        # pad sequence groups to their configured `sequence_length` (no device read-back of the batch's longest sequence: see
+        # forward); off by default = the reference's shapes (tzrec/modules/embedding.py:1431-1446)
+        self.static_sequence_padding = False
         by_dim: Dict[int, "OrderedDict[str, EmbeddingConfig]"] = {}
         seq_constraints: Dict[str, str] = {}
         for g in self._seq_groups:
@@ -366,9 +369,19 @@ class EmbeddingGroup(nn.Module):
                 out[f"{g}.query"] = torch.cat(qs, dim=1)
             first = jts[info["sequence"][0].name]
             lens = first.lengths().to(torch.int64)
-            lmax = max(int(lens.max().item()) if lens.numel() else 0, 1)  # one host sync, as the reference's fx_int_item
-            if info["max_len"]:
-                lmax = min(lmax, info["max_len"])
+            if self.static_sequence_padding and info["max_len"]:
+                # pad to the configured sequence_length instead of the batch's longest sequence: no host sync (the step can be
+                # captured in a hipGraph) and one shape for every batch; the positions behind a sample's length are masked by
+                # the sequence encoders either way (`sequence_length` goes with the tensor)
+                lmax = info["max_len"]
+            else:
+                if lens.is_cuda and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("the padded length of a sequence group is the batch's longest sequence, read back from the "
+                                       "device: not capturable -- set EmbeddingGroup.static_sequence_padding = True (needs "
+                                       "`sequence_length` in the feature config)")
+                lmax = max(int(lens.max().item()) if lens.numel() else 0, 1)  # one host sync, as the reference's fx_int_item
+                if info["max_len"]:
+                    lmax = min(lmax, info["max_len"])
             out[f"{g}.sequence_length"] = lens
             out[f"{g}.sequence"] = torch.cat(
                 [jagged_to_padded_dense(jts[f.name].values(), jts[f.name].offsets(), lmax) for f in info["sequence"]], dim=-1)

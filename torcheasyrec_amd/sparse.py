@@ -110,6 +110,20 @@ class JaggedTensor:
         return JaggedTensor(values, lengths, off)
 
 
+# the key permutations of a model are a handful of fixed tuples: their device copies are made once (a host list -> device copy
+# is a synchronising transfer, and not allowed while a hipGraph is being captured)
+_PERM_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _perm_tensor(indices: tuple, dev: torch.device) -> torch.Tensor:
+    key = (indices, str(dev))
+    t = _PERM_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(list(indices), dtype=torch.int32, device=dev)
+        _PERM_CACHE[key] = t
+    return t
+
+
 class KeyedJaggedTensor:
     """Jagged ids for F keys x B samples, key-major (torchrec KJT field semantics)."""
 
@@ -201,6 +215,10 @@ class KeyedJaggedTensor:
 
     def length_per_key(self) -> List[int]:
         if self._length_per_key is None:
+            if self._lengths is not None and self._lengths.device.type == "cpu" and self._stride > 0:
+                # host bookkeeping on a batch still in host memory (dataloader side)
+                self._length_per_key = [int(v) for v in self._lengths.view(len(self._keys), self._stride).sum(dim=1).tolist()]
+                return self._length_per_key
             off = self.offsets()[:: self._stride].cpu().tolist() if self._stride > 0 else [0] * (len(self._keys) + 1)
             self._length_per_key = [int(off[i + 1] - off[i]) for i in range(len(self._keys))]
         return self._length_per_key
@@ -280,6 +298,11 @@ class KeyedJaggedTensor:
     # -- Pipelineable contract (tzrec Batch.to / record_stream, datasets/utils.py:344-408) ----
     def to(self, device, non_blocking: bool = False) -> "KeyedJaggedTensor":
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
+        # ids per key: free while the batch is still in host memory, a device read-back (and the end of any hipGraph capture)
+        # once it is not -- torchrec's KJT carries the same cache across `.to()`
+        if self._length_per_key is None and self._values.device.type == "cpu" and torch.device(device).type != "cpu" \
+                and self._lengths is not None:
+            self.length_per_key()
         return KeyedJaggedTensor(
             self._keys, mv(self._values), mv(self._lengths), mv(self._weights), mv(self._offsets),
             self._stride, self._length_per_key, self._uniform_length,
@@ -318,7 +341,7 @@ class KeyedJaggedTensor:
             n_out = self._values.numel()
         else:
             n_out = int(sum(self.length_per_key()[i] for i in indices))  # host sync, like torchrec
-        perm = torch.tensor(list(indices), dtype=torch.int32, device=dev)
+        perm = _perm_tensor(tuple(int(i) for i in indices), dev)
         out_lengths = torch.empty(T * B, dtype=lengths.dtype, device=dev)
         out_offsets = torch.empty(T * B + 1, dtype=torch.int64, device=dev)
         out_values = torch.empty(n_out, dtype=torch.int64, device=dev)
