@@ -601,7 +601,7 @@ def main():
     if args.torch_bce:
         def bce_with_logits(logits, labels):  # noqa: F811 - A/B switch
             return torch.nn.functional.binary_cross_entropy_with_logits(logits, labels.float())
-    from torcheasyrec_amd.dense import root_loss
+    from torcheasyrec_amd.dense import root_loss, unit_gradient
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
 
     if emu:
@@ -704,7 +704,7 @@ def main():
             logits = model(dense, kjt)
             loss = bce_with_logits(logits, label)
         with root_loss():  # the unscaled loss is the root of the backward pass
-            loss.backward()
+            loss.backward(gradient=unit_gradient(loss))
         if sharded:
             model.allreduce_dense_grads()
         dense_opt.step()

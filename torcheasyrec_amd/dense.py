@@ -121,6 +121,20 @@ def root_loss():
         _ROOT_LOSS["on"] -= 1
 
 
+_ONES: dict = {}
+
+
+def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """The 1.0 that autograd would create for the root of a backward pass (`ones_like`: a fill launch per step), made once
+    per device and dtype: `loss.backward(gradient=unit_gradient(loss))`."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    t = _ONES.get(key)
+    if t is None:
+        t = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+        _ONES[key] = t
+    return t
+
+
 def _loss_is_root() -> bool:
     return _ROOT_LOSS["on"] > 0
 
@@ -215,6 +229,7 @@ class _TopLossFn(torch.autograd.Function):
         logits, g1, dW2, db2, dw3, scal, db1 = _mlp_tail(y1, labels, W2, b2, w3, b3)
         ctx.save_for_backward(z, W1, g1, dW2, db2, dw3, scal, db1)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the gradient of `logits`: a [B] fill per step)
         return scal[1], logits
 
     @staticmethod
@@ -285,6 +300,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
         ctx.z = z
         ctx.cfg = (F, D)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the gradient of `logits`: a [B] fill per step)
         return scal[1], logits
 
     @staticmethod

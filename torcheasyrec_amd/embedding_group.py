@@ -477,12 +477,12 @@ def _losses_and_predictions(model, loss_fn, batch):
 def _backward_of_losses(losses) -> None:
     """backward of the unweighted sum of the named losses (TrainWrapper.forward, tzrec/models/model.py:293): every loss
     receives autograd's 1.0, which `dense.root_loss` lets the fused loss kernels skip multiplying by."""
-    from .dense import root_loss
+    from .dense import root_loss, unit_gradient
 
     vals = list(losses.values())
     total = vals[0] if len(vals) == 1 else sum(vals[1:], vals[0])
     with root_loss():
-        total.backward()
+        total.backward(gradient=unit_gradient(total))
 
 
 class TrainPipeline:

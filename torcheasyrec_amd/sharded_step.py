@@ -183,10 +183,10 @@ class ShardedTrainStep:
         else:
             logits = self.model.dense_forward(dense, sparse)
             loss = self.loss_fn(logits, label)
-        from .dense import root_loss
+        from .dense import root_loss, unit_gradient
 
         with root_loss():  # the loss itself is differentiated: its incoming gradient is 1.0, nothing to scale
-            grads = torch.autograd.grad(loss, [sparse] + self.params)
+            grads = torch.autograd.grad(loss, [sparse] + self.params, grad_outputs=unit_gradient(loss))
         return loss.detach(), logits.detach(), grads
 
     def _segment(self, dense, label, width) -> _Segment:
