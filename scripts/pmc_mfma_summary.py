@@ -25,7 +25,7 @@ def main(d, out):
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "interaction" not in k and "tzr_ia_top" not in k and "tzr_mlp" not in k:  # the MFMA kernels of the dense half
+        if "interaction" not in k and "tzr_ia_" not in k and "tzr_mlp" not in k:  # the MFMA kernels of the dense half
             continue
         name = k.split("(")[0].replace("void ", "").split("<")[0]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -22,6 +22,16 @@ from conftest import emu_heavy  # noqa: E402
 sys.path.insert(0, os.path.dirname(__file__))
 
 
+
+def _finish_worker():
+    """End of a spawned gloo worker: tear the group down, then leave without running the interpreter's exit handlers -- once in
+    a few dozen runs a worker died there with `terminate called without an active exception` (a joinable thread of the
+    checkpoint writer / gloo destroyed at exit), after every assertion had passed."""
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
+
 def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, planner=False, exchange="exact"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
@@ -173,7 +183,7 @@ def _worker(rank, world, init_file, emu_path, mode, result_dir, via_step=False, 
             # row-wise: every row has one owner; data_parallel: every rank holds (the same) all rows
             assert covered == cfg.num_embeddings * (world if kind == "data_parallel" else 1), (cfg.name, covered)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("mode,via_step,planner", [("uniform1", False, False), ("jagged", False, False),
@@ -300,7 +310,7 @@ def _ckpt_worker(rank, world, init_file, emu_path, ckpt_dir, tables_format="file
         assert torch.equal(c.ebc.table_weights()[n].detach(), fa_w[n]), n
         assert torch.equal(c.ebc.table_states()[n].detach(), fa_m[n]), n
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("tables_format", ["files", "dcp"])
@@ -363,7 +373,7 @@ def _fp16_worker(rank, world, init_file, emu_path, exchange="exact"):
         # same fp32 math up to summation order across ranks: at most one half ulp apart
         torch.testing.assert_close(got.float(), want.float(), rtol=1e-3, atol=1e-5, msg=name)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("exchange", ["exact", "capacity"])
@@ -423,7 +433,7 @@ def _adam_worker(rank, world, init_file, emu_path, exchange="exact"):
         torch.testing.assert_close(sh.table_weights()[name].detach()[:n], ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-6, msg=name)
         torch.testing.assert_close(sh.table_states()[name].detach()[:n], ref.table_states()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-7, msg=name)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("exchange", ["exact", "capacity"])
@@ -487,7 +497,7 @@ def _frozen_worker(rank, world, init_file, emu_path, exchange="exact"):
                 assert not torch.equal(got, before[name][:n]), name
             torch.testing.assert_close(got, ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=1e-6, msg=name)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("exchange", ["exact", "capacity"])
@@ -591,7 +601,7 @@ def _zch_worker(rank, world, init_file, emu_path):
     m.eval(), m2.eval()
     assert torch.equal(m2.forward_grouped(probe)["g"], m.forward_grouped(probe)["g"])
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 def _zch_reshard_worker(rank, world, init_file, emu_path, work_dir, phase):
@@ -672,7 +682,7 @@ def _zch_reshard_worker(rank, world, init_file, emu_path, work_dir, phase):
         dist.all_gather_object(held, int((m.mc.modules_by_table["user_emb"].row_ids != EMPTY).sum()))
         assert sum(held) == len(users)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("load_world", [4, 1, 2])
@@ -754,7 +764,7 @@ def _seq_worker(rank, world, init_file, emu_path):
             got = sh.table_weights()[name].detach()[:n]
             torch.testing.assert_close(got, ref.table_weights()[name].detach()[lo:lo + n], rtol=2e-5, atol=2e-4, msg=name)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 def test_sharded_sequence_lookup_world2(emu_path):
@@ -914,7 +924,7 @@ def _config_worker(rank, world, init_file, emu_path, cfg_name, label_names, cons
             if n:
                 torch.testing.assert_close(sec.table_weights()[name].detach()[:n], w.detach()[lo:lo + n], rtol=2e-4, atol=1e-4, msg=name)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("cfg,labels,in_config,exchange", [("deepfm_mini.config", ["label"], False, "exact"),
@@ -1087,7 +1097,7 @@ def _mixed_worker(rank, world, init_file, emu_path, jagged, planner=False, grid=
             for n in fa:
                 assert torch.equal(fa[n], fb[n]), (what, n)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 @pytest.mark.parametrize("jagged,planner,grid", [(False, False, False), (False, True, False), (True, False, True)])
@@ -1157,7 +1167,7 @@ def _slots_worker(rank, world, init_file, emu_path):
     for other in ("capacity", "capacity_overlap"):
         _check_slots_run(runs["exact"], runs[other], steps)
     dist.barrier()
-    dist.destroy_process_group()
+    _finish_worker()
 
 
 def _check_slots_run(exact, capacity, steps):

@@ -194,7 +194,7 @@ __device__ __forceinline__ void bwd_rank_tile(const uint32_t (&dig)[MAXR], uint3
   const int wv = tid / TZR_WAVE;
   for (int i = tid; i < BWD_WAVES * NB_; i += BWD_THREADS) (&L.wcnt[0][0])[i] = 0;
   __syncthreads();
-  volatile uint16_t* wrow = L.wcnt[wv];
+  volatile TZR_LDS_AS uint16_t* wrow = (volatile TZR_LDS_AS uint16_t*)L.wcnt[wv];  // (LDS address space kept: ds_read_u16 / ds_write_b16, not FLAT)
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t loc[MAXR];
 #pragma unroll

@@ -80,10 +80,11 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
     float4 acc[FWD_UNROLL];
 #pragma unroll
     for (int u = 0; u < FWD_UNROLL; ++u) {
-      const int k = k0 + u * FWD_THREADS;
+      int k = k0 + u * FWD_THREADS;
       const bool ok = k < total;
-      const int bl = ok ? k / ns : 0;
-      const int s = ok ? k - bl * ns : 0;
+      if (UNIFORM1) k = ok ? k : total - 1;  // (one id per bag: an element behind the tile repeats the last one and is not stored -- no condition around its loads)
+      const int bl = (ok || UNIFORM1) ? k / ns : 0;
+      const int s = (ok || UNIFORM1) ? k - bl * ns : 0;
       const FwdRSlot r = rs[s];
       const int64_t b = b0 + bl;
       const int64_t bag = (int64_t)r.feat * B + b;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
       dp[u] = r.dst + b * (int64_t)r.dst_stride;
       if (UNIFORM1) {
         st[u] = bag;
-        en[u] = ok ? bag + 1 : bag;
+        en[u] = bag + 1;
       } else {
         st[u] = ok ? offsets[bag] : 0;
         en[u] = ok ? offsets[bag + 1] : 0;
@@ -107,20 +108,21 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
       int64_t id[FWD_UNROLL];
       float sc[FWD_UNROLL];
 #pragma unroll
+      // (no lane-dependent condition around a load: to hipcc that is a branch, and a branch between two loads a wait)
       for (int u = 0; u < FWD_UNROLL; ++u) {
-        id[u] = (st[u] < en[u]) ? values[st[u]] : 0;
-        if ((uint64_t)id[u] >= (uint64_t)rows[u]) id[u] = 0;
-        sc[u] = (WEIGHTED && st[u] < en[u]) ? weights[st[u]] : 1.0f;
+        id[u] = values[st[u]];
+        sc[u] = WEIGHTED ? weights[st[u]] : 1.0f;
       }
 #pragma unroll
+      for (int u = 0; u < FWD_UNROLL; ++u)
+        if ((uint64_t)id[u] >= (uint64_t)rows[u]) id[u] = 0;
+#pragma unroll
       for (int u = 0; u < FWD_UNROLL; ++u) {
-        if (st[u] < en[u]) {
-          float4 v = tzr_ldw4(wp[u], wdt[u], id[u] * (int64_t)wstride[u]);
-          if (WEIGHTED) {
-            v.x *= sc[u]; v.y *= sc[u]; v.z *= sc[u]; v.w *= sc[u];
-          }
-          acc[u] = v;
+        float4 v = tzr_ldw4(wp[u], wdt[u], id[u] * (int64_t)wstride[u]);
+        if (WEIGHTED) {
+          v.x *= sc[u]; v.y *= sc[u]; v.z *= sc[u]; v.w *= sc[u];
         }
+        acc[u] = v;
       }
     } else {
       int64_t maxlen = 0;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
     }
 #pragma unroll
     for (int u = 0; u < FWD_UNROLL; ++u) {
-      if (k0 + u * FWD_THREADS < total) tzr_st4(dp[u], acc[u]);
+      if (k0 + u * FWD_THREADS < total) tzr_stg4(dp[u], acc[u]);
     }
   }
 }
@@ -262,24 +264,29 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
     __syncthreads();
     const int total = cnt * ns;
     for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * FWD1_UNROLL) {
+      // No lane-dependent condition around the LDS reads and the row loads (an element behind the tile's last repeats it
+      // and is not stored): `if (ok) acc = load(...)` is a branch per element to hipcc, and the slot / id reads inside it were
+      // waited for one element at a time -- eight "independent" gathers issued as a chain.
       float* dp[FWD1_UNROLL];
+      const float* wp[FWD1_UNROLL];
       float4 acc[FWD1_UNROLL];
 #pragma unroll
       for (int u = 0; u < FWD1_UNROLL; ++u) {
-        const int k = k0 + u * FWD_THREADS;
-        const bool ok = k < total;
-        int bl = ok ? (int)__umulhi((uint32_t)k, magic) : 0;
-        if (ok && (bl + 1) * ns <= k) ++bl;  // the magic quotient is at most one short
-        const int s = ok ? k - bl * ns : 0;
+        int k = k0 + u * FWD_THREADS;
+        k = k < total ? k : total - 1;
+        int bl = (int)__umulhi((uint32_t)k, magic);
+        if ((bl + 1) * ns <= k) ++bl;  // the magic quotient is at most one short
+        const int s = k - bl * ns;
         const Fwd1Slot r = rs[s];
         const int64_t id = sid[(int)gid[s] * sub + bl];
         dp[u] = r.dst + (b0 + sb + bl) * (int64_t)r.dst_stride;
-        acc[u] = tzr_zero4();
-        if (ok) acc[u] = tzr_ld4(r.w + id * (int64_t)r.w_stride);
+        wp[u] = r.w + id * (int64_t)r.w_stride;
       }
 #pragma unroll
+      for (int u = 0; u < FWD1_UNROLL; ++u) acc[u] = tzr_ldg4(wp[u]);
+#pragma unroll
       for (int u = 0; u < FWD1_UNROLL; ++u)
-        if (k0 + u * FWD_THREADS < total) tzr_st4(dp[u], acc[u]);
+        if (k0 + u * FWD_THREADS < total) tzr_stg4(dp[u], acc[u]);
     }
   }
 }

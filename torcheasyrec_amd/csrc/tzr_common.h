@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "../../include/tzrec_hip.h"
+#include <tzr_gfx950.h>
 
 #define TZR_WAVE 64
 
@@ -34,20 +35,21 @@ struct TzrCarver {
 __device__ __forceinline__ float4 tzr_ldw4(const void* w, int dtype, int64_t off) {
   if (dtype == TZR_DT_F16) {
     struct alignas(8) H4 { _Float16 a, b, c, d; };
-    const H4 h = *reinterpret_cast<const H4*>(static_cast<const char*>(w) + off * 2);
-    return make_float4((float)h.a, (float)h.b, (float)h.c, (float)h.d);
+    union { uint2 u; H4 h; } c;
+    c.u = tzr_ldg8(static_cast<const char*>(w) + off * 2);
+    return make_float4((float)c.h.a, (float)c.h.b, (float)c.h.c, (float)c.h.d);
   }
-  return *reinterpret_cast<const float4*>(static_cast<const float*>(w) + off);
+  return tzr_ldg4(static_cast<const float*>(w) + off);  // (table rows are device memory: global, not FLAT, instructions)
 }
 __device__ __forceinline__ void tzr_stw4(void* w, int dtype, int64_t off, float4 v) {
   if (dtype == TZR_DT_F16) {
     struct alignas(8) H4 { _Float16 a, b, c, d; };
-    H4 h;
-    h.a = (_Float16)v.x; h.b = (_Float16)v.y; h.c = (_Float16)v.z; h.d = (_Float16)v.w;
-    *reinterpret_cast<H4*>(static_cast<char*>(w) + off * 2) = h;
+    union { uint2 u; H4 h; } c;
+    c.h.a = (_Float16)v.x; c.h.b = (_Float16)v.y; c.h.c = (_Float16)v.z; c.h.d = (_Float16)v.w;
+    tzr_stg8(static_cast<char*>(w) + off * 2, c.u);
     return;
   }
-  *reinterpret_cast<float4*>(static_cast<float*>(w) + off) = v;
+  tzr_stg4(static_cast<float*>(w) + off, v);
 }
 
 __device__ __forceinline__ float4 tzr_ld4(const float* p) {

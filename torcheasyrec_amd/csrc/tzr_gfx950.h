@@ -51,3 +51,29 @@ __device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkm
 // reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
 #define TZR_OPAQUE(x) asm volatile("" : "+v"(x))
 
+
+// Loads / stores through a pointer that is KNOWN to be device memory.  hipcc only knows that of a kernel's own pointer
+// arguments; a pointer read out of a descriptor (TzrTable.w, a destination list, an LDS copy of either) is generic, and
+// its accesses become FLAT instructions -- which count in the LDS counter too: every `s_waitcnt lgkmcnt(0)` in front of an
+// LDS read then also waits for all the row gathers in flight.
+#define TZR_GLOBAL_AS __attribute__((address_space(1)))
+// (through builtin vector types: a HIP float4 is a struct whose copy operators take a generic `this` -- FLAT again)
+typedef float tzr_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tzr_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tzr_ldg(const float* p) { return *(const TZR_GLOBAL_AS float*)p; }
+__device__ __forceinline__ void tzr_stg(float* p, float v) { *(TZR_GLOBAL_AS float*)p = v; }
+__device__ __forceinline__ float4 tzr_ldg4(const float* p) {
+  const tzr_f32x4 v = *(const TZR_GLOBAL_AS tzr_f32x4*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void tzr_stg4(float* p, float4 v) { *(TZR_GLOBAL_AS tzr_f32x4*)p = tzr_f32x4{v.x, v.y, v.z, v.w}; }
+// 8 bytes (four fp16 of a half-precision table row, as two dwords)
+__device__ __forceinline__ uint2 tzr_ldg8(const void* p) {
+  const tzr_u32x2 v = *(const TZR_GLOBAL_AS tzr_u32x2*)p;
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void tzr_stg8(void* p, uint2 v) { *(TZR_GLOBAL_AS tzr_u32x2*)p = tzr_u32x2{v.x, v.y}; }
+
+// An LDS pointer that keeps its address space through `volatile` (a volatile generic pointer into LDS is accessed with FLAT
+// instructions: slower than ds_read / ds_write, and in the memory counter as well)
+#define TZR_LDS_AS __attribute__((address_space(3)))
