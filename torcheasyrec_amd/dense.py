@@ -268,8 +268,9 @@ def top_loss(z, l1, l2, out_linear, labels):
 OWNED_WGRAD = True
 
 
-def _owned_wgrad(batch: int) -> bool:
-    return bool(OWNED_WGRAD)
+def _owned_wgrad(batch: int, row_floats: int) -> bool:
+    # (the kernel's sample offsets are 32-bit: B * stride < 2^32 for the embeddings and for g1; a larger batch keeps z)
+    return bool(OWNED_WGRAD) and batch * max(row_floats, 64) < (1 << 32)
 
 
 class _InteractionTopLossFn(torch.autograd.Function):
@@ -289,7 +290,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
         H1 = W1.shape[0]
         dev = sparse.device
         y1 = torch.empty(B, H1, dtype=torch.float32, device=dev)
-        z = None if _owned_wgrad(B) else torch.empty(B, width, dtype=torch.float32, device=dev)
+        z = None if _owned_wgrad(B, sparse.shape[1]) else torch.empty(B, width, dtype=torch.float32, device=dev)
         W1_, b1_ = _f32c(W1), _f32c(b1)
         _lib.check(_lib.lib().tzr_dot_interaction_top_fwd(
             _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(W1_), W1_.stride(0),
