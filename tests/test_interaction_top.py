@@ -99,6 +99,23 @@ def test_top_wgrad_matches_torch(dev, B, F):
     _close(dW3, 2 * ref, 1e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [65536, 65521])
+def test_top_wgrad_full_batch_on_the_gpu(B):
+    """BASELINE's batch (and one that is no multiple of the 32-sample tile): 64 batch slices x 4 column groups, 32 tiles per
+    workgroup; against the fp64 product over the materialised z, and twice the same bits."""
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    D, H, F = 16, 64, 26
+    torch.manual_seed(B)
+    dense, sparse, g1 = torch.randn(B, D, device=dev), torch.randn(B, F * D, device=dev), torch.randn(B, H, device=dev) / B
+    ref = (g1.double().t() @ _torch_z(dense, sparse, D).double()).float()
+    dW, width = _wgrad(dense, sparse, F, D, g1, None)
+    _close(dW, ref, 1e-5)
+    dW2, _ = _wgrad(dense, sparse, F, D, g1, None)
+    assert torch.equal(dW, dW2)
+
+
 def test_top_wgrad_without_dense_row_and_empty_batch(dev):
     D, H, F, B = 16, 64, 20, 45
     torch.manual_seed(3)
