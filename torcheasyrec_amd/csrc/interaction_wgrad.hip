@@ -10,10 +10,9 @@
 //     (batch slice, column group).  With 256 workgroups that is 64 batch slices: 64 x 200 KB of partial sums instead of
 //     256 x 200 KB for workgroups that each own the full width (the partials are the only HBM writes of this kernel);
 //     the four groups of one slice sit on the same XCD (blockIdx -> XCD round-robin), so its L2 serves the X rows they share.
-//   * a tile is 32 samples, kept in LDS TRANSPOSED, zT[column][sample] and g1T[h][sample]: the samples are the contraction
-//     index of v_mfma_f32_16x16x4_f32, and one ds_read_b128 per operand then covers four k-steps.  The transposition costs
-//     no extra pass: a loader wave builds the pair blocks of FOUR consecutive samples (four MFMAs each), so a lane holds the
-//     same (i, j) of four samples -- one ds_write_b128 per (i, j); the X-row columns come out of the same operand registers.
+//   * a tile is 32 samples in LDS, z[sample][column] and g1[sample][h], exactly as the loaders hold them: an operand register
+//     (16 bytes of one X row of one sample) is stored as it is -- it IS the group's X-row columns -- and a pair block as dwords;
+//     the samples are the contraction index of v_mfma_f32_16x16x4_f32, the multipliers read one dword per k-step.
 //   * eight waves multiply (wave = output block of the 64 layer outputs x column half: up to eight 16 x 16 accumulators,
 //     64 MFMAs per tile), eight load and build the next tile meanwhile; ONE barrier per tile (two tiles in LDS).
 //   * tzr_ia_wgrad_reduce_kernel sums the slices' partials in fixed order (deterministic), applies the loss scale and puts
@@ -27,7 +26,8 @@
 // chip, so every v_mov / address instruction of a loader is taken from the product's time, and a loader's own 16 MFMAs queue
 // behind the multipliers'.  Versions on the way: all sixteen waves doing everything in turn 131 us (phases additive) ->
 // specialised waves 129 -> loads two tiles ahead 122 -> 1 KB-per-instruction operand loads 118 -> 32-bit sample offsets (700 ->
-// 250 instructions per tile and loader) 109 -> X rows out of the pair-operand registers 113 (fewer loads, more v_mov).
+// 250 instructions per tile and loader) 109 -> X rows out of the pair-operand registers 113 (fewer loads, more v_mov) -> tiles in
+// the loaders' own layout instead of transposed (no v_mov, dword operand reads) 109.
 // HBM traffic: X and g1 once (131 MB; the column groups' re-reads hit the L2, profiles/r04ad).
 #include "tzr_common.h"
 #include <tzr_gfx950.h>
@@ -35,7 +35,8 @@
 #define WG_THREADS 1024
 #define WG_WAVES (WG_THREADS / TZR_WAVE)
 #define WG_S 32            // samples per tile
-#define WG_ZP 40           // floats between two columns of a tile in LDS (32 + 8: the b128 operand reads of a 16-lane group hit 64 distinct banks)
+#define WG_P 336           // floats of a sample's row of a tile in LDS (>= 16 npb + 20 xn, = 16 mod 32: the dword operand reads of lanes (r, q) and (r, q + 1) fall on different bank halves)
+#define WG_PG 80           // ... of its g1 row (64 + 16)
 #define WG_MAXB 16         // column blocks (of 16) per group
 #define WG_H 64
 #define WG_D 16
@@ -135,11 +136,14 @@ __device__ __forceinline__ const float* wg_row(const WgArgs& a, int64_t b, int i
 //                  accumulators); two of them on every SIMD keep its MFMA pipe fed.
 // One barrier per tile hands tile t + 1 over.
 
-// LDS address (floats) of column block b of a tile: the pair blocks 16 columns x WG_ZP apart, the X-row blocks 8 floats more
-// (one lane per ROW stores into them: at 640 floats from row to row all eight lanes of a store group hit the same banks)
-#define WG_XBP (16 * WG_ZP + 8)
-#define WG_ZT (WG_MAXB * WG_XBP)  // floats per tile buffer
-__device__ __forceinline__ int wg_block_base(int b, int npb) { return b < npb ? b * (16 * WG_ZP) : npb * (16 * WG_ZP) + (b - npb) * WG_XBP; }
+// A tile in LDS is `z[sample][column]`, the way the loaders hold it: a loaded operand register (16 bytes of one X row of one
+// sample) is stored as it is, a pair-block result as four dwords -- no register shuffling on the VALU, which shares its pipe
+// with the multipliers' MFMAs (kept transposed, `zT[column][sample]`, every 16-byte store wanted four v_mov: 45 per tile).
+// The multipliers read their operands a dword per k-step instead of 16 bytes per four.  Column of block b in a sample's
+// row: the pair blocks 16 apart, the X-row blocks 20 apart (a lane per ROW stores 16 bytes into them: 16 floats apart the
+// eight lanes of a store group would share two bank quads).
+#define WG_ZT (WG_S * WG_P)  // floats per tile buffer
+__device__ __forceinline__ int wg_block_base(int b, int npb) { return b < npb ? 16 * b : 16 * npb + 20 * (b - npb); }
 
 // Registers a loader thread carries from the loads of a tile to its LDS stores.  Every load lands in the register it is
 // used from: nothing touches a loaded value (no select, no mask, no copy) before the stores -- that would be a wait right
@@ -192,44 +196,39 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
         if (e == 0) R.gv.x = gvv; else if (e == 1) R.gv.y = gvv; else if (e == 2) R.gv.z = gvv; else R.gv.w = gvv;
       }
     };
-    // component c of the four samples' registers = the four consecutive floats (samples 4 l ..) of one column: one 16-byte
-    // store.  (The four v_mov that line the registers up are VALU work, and the VALU shares its pipe with the multipliers'
-    // fp32 MFMAs; as dword stores straight from the registers -- ds_write2_b32, no VALU -- the stores of a row block hit 4
-    // banks with 32 lanes and the kernel got slower, 113 -> 119 us, profiles/r04aj.)
-    auto comp4 = [](const float4* v, int c) {
-      return c == 0 ? make_float4(v[0].x, v[1].x, v[2].x, v[3].x) : c == 1 ? make_float4(v[0].y, v[1].y, v[2].y, v[3].y)
-           : c == 2 ? make_float4(v[0].z, v[1].z, v[2].z, v[3].z) : make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
-    };
     WG_PROF_DECL;
     // The registers (loaded from tile tt) into tile buffer `buf`, and the loads of tile tn into the same registers, in the
     // order that keeps the chain short: the X-row / g1 stores first (they wait for nothing but the loads), then the pair
     // MFMAs -- which queue behind the multipliers' -- then the NEW loads (the operand registers are free once the MFMAs have
     // issued; the 1 KB-per-instruction loads take the CU's memory pipe ~16 clocks each), the pair stores last.
     auto step = [&](int buf, Regs& R, int tt, int tn, bool build, bool load) {
-      float* zb = zT + buf * WG_ZT;
+      float* zb = zT + buf * WG_ZT + (4 * lw) * WG_P;  // rows of this wave's four samples
       wg_f32x4 c[4];
       if (build) {
-        // the group's X rows out of the registers: row -> block npb + (row - x0), column 4 q + c of it
-        float* xb = zb + G.npb * (16 * WG_ZP) + (4 * q) * WG_ZP + 4 * lw;
+        // the group's X rows out of the registers: row -> block npb + (row - x0), this lane's 16 bytes of it, per sample
+        float* xb = zb + 16 * G.npb + 4 * q;
         if (LO) {
           const int xl = r - G.x0;
           if (xl >= 0 && xl < G.xn) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) tzr_st4(xb + xl * WG_XBP + cc * WG_ZP, comp4(R.lo, cc));
+            for (int e = 0; e < 4; ++e) tzr_st4(xb + 20 * xl + e * WG_P, R.lo[e]);
           }
         }
         if (HI) {
           const int xl = 16 + r - G.x0;
           if (xl >= 0 && xl < G.xn) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) tzr_st4(xb + xl * WG_XBP + cc * WG_ZP, comp4(R.hi, cc));
+            for (int e = 0; e < 4; ++e) tzr_st4(xb + 20 * xl + e * WG_P, R.hi[e]);
           }
         }
         const int s = tt * WG_S + 4 * lw;
         const float4 g = R.gv;
-        float* go = gT + buf * (WG_H * WG_ZP) + lane * WG_ZP + 4 * lw;
-        if (s + 3 < B) tzr_st4(go, g);  // (scalar branch: only the batch's last tile masks)
-        else tzr_st4(go, make_float4(s < B ? g.x : 0.f, s + 1 < B ? g.y : 0.f, s + 2 < B ? g.z : 0.f, s + 3 < B ? g.w : 0.f));
+        float* go = gT + buf * (WG_S * WG_PG) + (4 * lw) * WG_PG + lane;
+        if (s + 3 < B) {  // (scalar branch: only the batch's last tile masks)
+          go[0] = g.x; go[WG_PG] = g.y; go[2 * WG_PG] = g.z; go[3 * WG_PG] = g.w;
+        } else {
+          go[0] = s < B ? g.x : 0.f; go[WG_PG] = s + 1 < B ? g.y : 0.f; go[2 * WG_PG] = s + 2 < B ? g.z : 0.f; go[3 * WG_PG] = 0.f;
+        }
         if (SRC != 0) {
           // per sample a 16 x 16 block of X X^T by four v_mfma_f32_16x16x4_f32 (lane (r, q) supplies column 4 q + k-step of
           // row r); result register e of lane (r, q) = entry (i = 4 q + e, j = r)
@@ -249,14 +248,17 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
       WG_PROF_MARK(2);  // load issue
       if (build && SRC != 0) {
         // entry (i, j) -> column of the group: c00 / c11 the strict upper triangle of their rows, row-major; c01 all of i x
-        // n1.  The four samples' results side by side are the four consecutive floats of one zT column: one 16-byte store.
+        // n1; sample e's block into sample e's row
         const int nn = SRC == 1 ? n0 : n1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * q + e, j = r;
+        for (int k = 0; k < 4; ++k) {
+          const int i = 4 * q + k, j = r;
           const bool ok = SRC == 2 ? j < n1 : (i < j && j < nn);
           const int col = SRC == 2 ? i * n1 + j : (i * (2 * nn - i - 1)) / 2 + j - i - 1;
-          if (ok) tzr_st4(zb + col * WG_ZP + 4 * lw, make_float4(c[0][e], c[1][e], c[2][e], c[3][e]));
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zb[e * WG_P + col] = c[e][k];
+          }
         }
       }
     };
@@ -292,10 +294,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
     return;
   }
   // =================================================== multipliers
-  // dW[16 hb .., blocks of this wave] += g1T . zT over the 32 samples of a buffer.  Lane (r, q), read kk: the four samples
-  // 16 kk + 4 q .. + 3 of row r of either operand = four k-steps (k index q).  Blocks ch, ch + 2, .., ch + 10 always (a block
-  // behind the group's last reads columns nobody writes -- zeros -- and is not stored), ch + 12 / ch + 14 behind scalar
-  // branches: the operand reads of a half tile are in flight before its first MFMA.
+  // dW[16 hb .., blocks of this wave] += g1^T . z over the 32 samples of a buffer.  Blocks ch, ch + 2, .., ch + 10 always (a
+  // block behind the group's last reads columns nobody writes -- zeros -- and is not stored), ch + 12 / ch + 14 behind scalar
+  // branches.
   const int hb = wv & 3, ch = (wv & 7) >> 2;
   const int nbw = G.nb > ch ? (G.nb - ch + 1) >> 1 : 0;  // blocks ch, ch + 2, ... of this wave
   wg_f32x4 acc[8];
@@ -304,36 +305,52 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
   int bb[8];  // LDS offsets of this wave's blocks (scalar)
 #pragma unroll
   for (int m = 0; m < 8; ++m) bb[m] = wg_block_base(ch + 2 * m < WG_MAXB ? ch + 2 * m : WG_MAXB - 1, G.npb);
-  auto mma = [&](wg_f32x4& c, const float4 av, const float4 bv) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, c, 0, 0, 0);
-  };
+  // lane (r, q), k-step t of a tile: sample 4 t + q, one dword of either operand (k index q)
   auto product = [&](int buf) {
-    const float* gp = gT + buf * (WG_H * WG_ZP) + (16 * hb + r) * WG_ZP + 4 * q;
-    const float* zp = zT + buf * WG_ZT + r * WG_ZP + 4 * q;
+    const float* gp = gT + buf * (WG_S * WG_PG) + q * WG_PG + 16 * hb + r;
+    const float* zp = zT + buf * WG_ZT + q * WG_P + r;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const float4 av = tzr_ld4(gp + 16 * kk);
-      float4 bv[6];
+    for (int h2 = 0; h2 < 2; ++h2) {  // (half a tile's operand reads in flight before its first MFMA)
+      float av[4], bv[6][4];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) bv[m] = tzr_ld4(zp + bb[m] + 16 * kk);
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const int tt = 4 * h2 + t4;
+        av[t4] = gp[tt * 4 * WG_PG];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) mma(acc[m], av, bv[m]);
-      if (nbw > 6) mma(acc[6], av, tzr_ld4(zp + bb[6] + 16 * kk));
-      if (nbw > 7) mma(acc[7], av, tzr_ld4(zp + bb[7] + 16 * kk));
+        for (int m = 0; m < 6; ++m) bv[m][t4] = zp[tt * 4 * WG_P + bb[m]];
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv[m][t4], acc[m], 0, 0, 0);
+      if (nbw > 6) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+          acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], zp[(4 * h2 + t4) * 4 * WG_P + bb[6]], acc[6], 0, 0, 0);
+      }
+      if (nbw > 7) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+          acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], zp[(4 * h2 + t4) * 4 * WG_P + bb[7]], acc[7], 0, 0, 0);
+      }
     }
   };
   if (t < ntiles) {
     tzr_lds_barrier();  // tile t is in buffer 0
-    int cur = 0;
     WG_PROF_DECL;
-    for (; t < ntiles; t += a.slices, cur ^= 1) {
-      if (!(a.debug & 1)) product(cur);
+    for (;;) {  // (two tiles per trip: the buffer is a constant of each half)
+      if (!(a.debug & 1)) product(0);
       WG_PROF_MARK(4);  // product
       tzr_lds_barrier();
       WG_PROF_MARK(5);  // barrier
+      t += a.slices;
+      if (t >= ntiles) break;
+      if (!(a.debug & 1)) product(1);
+      WG_PROF_MARK(4);
+      tzr_lds_barrier();
+      WG_PROF_MARK(5);
+      t += a.slices;
+      if (t >= ntiles) break;
     }
     WG_PROF_DUMP(a.prof);
   }
@@ -350,8 +367,8 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
 }
 
 __global__ __launch_bounds__(WG_THREADS) void tzr_ia_wgrad_kernel(WgArgs a) {
-  __shared__ __attribute__((aligned(16))) float zT[2 * WG_ZT];  // [tile][column block][column][sample]
-  __shared__ __attribute__((aligned(16))) float gT[2 * WG_H * WG_ZP];          // [tile][h][sample]
+  __shared__ __attribute__((aligned(16))) float zT[2 * WG_ZT];  // [tile][sample][column]
+  __shared__ __attribute__((aligned(16))) float gT[2 * WG_S * WG_PG];  // [tile][sample][h]
   // workgroup -> (slice, group): the four groups of a slice on one XCD
   const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
   const int gi = kx & 3, slice = (kx >> 2) * 8 + xcd;
