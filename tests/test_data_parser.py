@@ -180,3 +180,22 @@ def test_int32_wire_form_of_a_batch_round_trips():
         KeyedJaggedTensor(["a"], torch.tensor([1 << 31]), torch.ones(1, dtype=torch.int32)).narrow_ids()
     with pytest.raises(ValueError):
         KeyedJaggedTensor(["a"], torch.tensor([-1]), torch.ones(1, dtype=torch.int32)).narrow_ids()
+
+
+def test_ids_per_key_are_counted_on_the_host_side_of_to():
+    """`KeyedJaggedTensor.length_per_key()` on a batch in host memory is host arithmetic (no device, no library call), and
+    `.to()` carries the cache: the device copy never has to read its offsets back (a synchronising copy, and the end of a
+    hipGraph capture)."""
+    import torch
+
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, _perm_tensor
+
+    lengths = torch.tensor([1, 0, 3, 2, 2, 2], dtype=torch.int32)  # 3 keys x 2 samples
+    kjt = KeyedJaggedTensor(["a", "b", "c"], torch.arange(10, dtype=torch.int64), lengths)
+    assert kjt._length_per_key is None
+    assert kjt.length_per_key() == [1, 5, 4]
+    moved = kjt.to(torch.device("cpu"))
+    assert moved._length_per_key == [1, 5, 4]
+    # the device copies of key permutations are made once per (permutation, device)
+    assert _perm_tensor((2, 0), torch.device("cpu")) is _perm_tensor((2, 0), torch.device("cpu"))
+    assert _perm_tensor((2, 0), torch.device("cpu")).tolist() == [2, 0]

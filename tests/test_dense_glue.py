@@ -171,3 +171,26 @@ def test_mlp_proto_fields_build_the_reference_perceptron():
         raise AssertionError("unknown activation accepted")
     except NotImplementedError:
         pass
+
+
+def test_unit_gradient_and_weight_gradient_policy():
+    """`dense.unit_gradient`: one cached 1.0 per (device, dtype, shape) for the root of the backward pass;
+    `dense._owned_wgrad`: the own weight-gradient kernel unless its 32-bit sample offsets would not fit."""
+    import torch
+
+    from torcheasyrec_amd import dense as dn
+
+    loss = torch.tensor(0.25)
+    one = dn.unit_gradient(loss)
+    assert one is dn.unit_gradient(torch.tensor(3.0)) and float(one) == 1.0 and one.shape == loss.shape
+    x = torch.tensor([2.0], requires_grad=True)
+    (x * x).sum().backward(gradient=dn.unit_gradient((x * x).sum()))
+    assert float(x.grad) == 4.0
+    assert dn._owned_wgrad(65536, 416) and dn._owned_wgrad(1 << 20, 416)
+    assert not dn._owned_wgrad(1 << 24, 416)  # 2^24 x 416 floats: offsets past 2^32
+    keep = dn.OWNED_WGRAD
+    try:
+        dn.OWNED_WGRAD = False
+        assert not dn._owned_wgrad(8192, 416)
+    finally:
+        dn.OWNED_WGRAD = keep
