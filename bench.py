@@ -144,7 +144,7 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def config_model_steps(dev, work_stream, steps: int = 20):
+def config_model_steps(dev, work_stream, steps: int = 20, only=None):
     """Train-step timing of the other BASELINE.json model families at their config's batch size (8192), built from a
     pipeline config TEXT through the same seam a tzrec user has (config.load_pipeline_spec -> rank_model.build_rank_model):
     DeepFM-Criteo (configs[0]'s model on the GPU), multi_tower_din on the Taobao features with a 100-step click sequence
@@ -269,6 +269,8 @@ def config_model_steps(dev, work_stream, steps: int = 20):
              "click sequence, DIN attention {256,64}), batch 8192, histories of 10..100 clicks", {}),
             ("mmoe_zch_b8192", ec.mmoe_taobao_zch, "MMoE (3 experts, ctr + cvr towers) with user_id behind a 200M-row zero-collision hash, LFU "
              "(BASELINE.json configs[4]), batch 8192, raw 64-bit Zipf user ids", {"raw_id_feature": "user_id", "capturable": False})):
+        if only is not None and key not in only:
+            continue
         try:
             res[key] = run(key, mk(), config, **kw)
         except Exception as e:

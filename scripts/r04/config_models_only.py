@@ -13,6 +13,7 @@ bench.enable_tunable_gemm()
 dev = torch.device("cuda", 0)
 ws = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(ws)  # (as bench.py's main does: the whole run on one side stream)
-res = bench.config_model_steps(dev, ws, steps=20)
+only = sys.argv[1].split(",") if len(sys.argv) > 1 else None  # e.g. din_taobao_b8192
+res = bench.config_model_steps(dev, ws, steps=20, only=only)
 for k, v in res.items():
     print(k, json.dumps({kk: v.get(kk) for kk in ("ms_per_step", "graph_ms_per_step", "host_queue_ms_per_step", "graph_error", "zch")}))

@@ -113,3 +113,29 @@ def test_segment_reduce_matches_torch(dev, pooling, D):
     # no segments at all
     e = segment_reduce(torch.zeros(0, D).to(dev), torch.zeros(0, dtype=torch.int64).to(dev), pooling)
     assert tuple(e.shape) == (0, D)
+
+
+def test_din_first_layer_split_equals_the_literal_input():
+    """DINEncoder: W [q, k, q - k, q * k] evaluated as (Wa + Wc) q + (Wb - Wc) k + Wd (q * k) -- the query part once per sample,
+    half the contraction per position, no [B, L, 4 D] tensor -- against the reference's literal concatenation
+    (/root/reference/tzrec/modules/sequence.py:100-128): output and every gradient to fp32 rounding."""
+    import torch
+
+    from torcheasyrec_amd.sequence import DINEncoder
+
+    torch.manual_seed(0)
+    for qd in (32, 16):
+        enc = DINEncoder(32, qd, "seq", {"hidden_units": [48, 8]})
+        B, L = 7, 11
+        emb = {"seq.query": torch.randn(B, qd, requires_grad=True), "seq.sequence": torch.randn(B, L, 32, requires_grad=True),
+               "seq.sequence_length": torch.tensor([0, 3, 11, 5, 1, 9, 11])}
+        outs = {}
+        for split in (True, False):
+            enc.split_first_layer = split
+            for t in list(enc.parameters()) + [emb["seq.query"], emb["seq.sequence"]]:
+                t.grad = None
+            o = enc(emb)
+            (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum().backward()
+            outs[split] = [o.detach().clone()] + [t.grad.clone() for t in list(enc.parameters()) + [emb["seq.query"], emb["seq.sequence"]]]
+        for a_, b_ in zip(outs[True], outs[False]):
+            torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
