@@ -606,6 +606,8 @@ def main():
     from torcheasyrec_amd.dense import root_loss, unit_gradient
     from torcheasyrec_amd.embedding import SparseOptimizerConfig
 
+    unit_gradient(torch.zeros((), dtype=torch.float32, device=dev))  # (the backward's root gradient exists before any capture)
+
     if emu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from emu.build_emu import build as build_emu

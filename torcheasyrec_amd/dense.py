@@ -126,7 +126,9 @@ _ONES: dict = {}
 
 def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
     """The 1.0 that autograd would create for the root of a backward pass (`ones_like`: a fill launch per step), made once
-    per device and dtype: `loss.backward(gradient=unit_gradient(loss))`."""
+    per device and dtype: `loss.backward(gradient=unit_gradient(loss))`.  Whoever captures a backward pass into a hipGraph calls
+    this once BEFORE the capture (the pipelines do, in their constructors): made inside a capture, the tensor would hold nothing
+    until that graph's first replay."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     t = _ONES.get(key)
     if t is None:

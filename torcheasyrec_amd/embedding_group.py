@@ -584,6 +584,8 @@ class GraphTrainPipeline:
         self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
         assert self._device.type == "cuda", "GraphTrainPipeline replays hipGraphs: CUDA/HIP device only"
         self._copy_stream = torch.cuda.Stream(device=self._device)
+        from .dense import unit_gradient
+        unit_gradient(torch.zeros((), dtype=torch.float32, device=self._device))  # (made before any capture, see dense.unit_gradient)
         self._slots = [None, None]     # device batches with static addresses
         self._graphs = [None, None]    # (CUDAGraph, losses, predictions) per slot
         self._seen = [0, 0]

@@ -140,6 +140,10 @@ class ShardedTrainStep:
         self.plan_ahead = plan_ahead
         self.warmup_iters = warmup_iters
         self.params = list(model.dense_parameters())
+        # the root gradient of the backward pass exists (and holds its 1.0) before any capture: created inside one it would
+        # be uninitialised until that graph's first replay
+        from .dense import unit_gradient
+        unit_gradient(torch.zeros((), dtype=torch.float32, device=self.device))
         self._seg: Dict[int, _Segment] = {}
         self._seen: Dict[int, int] = {}
         self._side = torch.cuda.Stream(self.device) if self.cuda else None
