@@ -236,7 +236,7 @@ def test_interaction_top_loss_keeps_no_interaction_rows(dev, monkeypatch, scaled
             (loss * 0.125).backward()
         else:
             with dn.root_loss():
-                loss.backward()
+                loss.backward(gradient=dn.unit_gradient(loss))
         grads[owned] = [p_.grad.clone() for p_ in ps]
     assert kept_z == {True: False, False: True}
     for a_, b_ in zip(grads[True], grads[False]):
@@ -275,11 +275,22 @@ def test_root_loss_skips_the_unit_scaling_and_nothing_else(dev, fused_interactio
     want = torch.autograd.grad(loss_of(), ps)
     assert calls["n"] == 1
     with dn.root_loss():
-        got = torch.autograd.grad(loss_of(), ps)
+        l_ = loss_of()
+        got = torch.autograd.grad(l_, ps, grad_outputs=dn.unit_gradient(l_))
     assert calls["n"] == 1  # not called again
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert not dn._loss_is_root()
+    # a caller that announces a root loss but hands in ANOTHER gradient (a scaled loss: task weights, GradScaler, 1 / accumulation
+    # steps) gets the scaled gradients: the unscaled path is taken only for the cached unit gradient itself
+    with dn.root_loss():
+        half = torch.autograd.grad(loss_of() * 0.5, ps)
+        l_ = loss_of()
+        other_one = torch.autograd.grad(l_, ps, grad_outputs=torch.ones_like(l_))
+    assert calls["n"] == 3
+    for a, b, c in zip(half, want, other_one):
+        torch.testing.assert_close(a, 0.5 * b, rtol=1e-6, atol=1e-9)
+        assert torch.equal(c, b)
 
 
 def test_dlrm_predict_without_grad_uses_fused_first_layer(dev):

@@ -144,6 +144,67 @@ def test_zch_state_survives_a_checkpoint(dev, tmp_path):
         assert torch.equal(getattr(a.mc.modules_by_table["t"], f), getattr(b.mc.modules_by_table["t"], f))
 
 
+def test_dcp_names_of_a_mixed_collection_and_refusal_of_other_naming_schemes(dev, tmp_path):
+    """A collection that holds a zero-collision-hash table NEXT TO a plain one (MMoE + ZCH): the reference keeps only the
+    managed-collision table under `mc_ebc._embedding_module`; the plain table stays under `...__BASE__.ebc.embedding_bags`
+    (tzrec/modules/embedding.py:855-864), and so does its optimizer state.  A DCP checkpoint whose entries were written
+    under another naming scheme is refused with a message that says so (not a KeyError from the template)."""
+    import json
+    import os
+
+    import torch.distributed.checkpoint as dcp
+
+    from torcheasyrec_amd.checkpoint import DCP_NAMES, restore_checkpoint, save_checkpoint
+
+    def build(seed):
+        torch.manual_seed(seed)
+        ebc = EmbeddingBagCollection([EmbeddingBagConfig("z", 4, 32, ["kz"]), EmbeddingBagConfig("plain", 4, 9, ["kp"])], device=dev,
+                                     optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+
+        class G(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.ebc = ebc
+                self.mc = ManagedCollisionEmbeddingBagCollection(ebc, {"z": ZchConfig(32, 2, "lfu")})
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.embedding_group = G()
+        return M()
+
+    a = build(0)
+    a.embedding_group.mc.train()
+    ids = torch.cat([torch.arange(6) * 7919 + (1 << 45), torch.arange(6) % 9])
+    out, _ = a.embedding_group.mc(KeyedJaggedTensor(["kz", "kp"], ids, torch.ones(12, dtype=torch.int32), uniform_length=1).to(dev))
+    out.values().sum().backward()
+    save_checkpoint(str(tmp_path), a, tables_format="dcp")
+    names = set(dcp.FileSystemReader(os.path.join(str(tmp_path), "model", "dcp")).read_metadata().state_dict_metadata)
+    onames = set(dcp.FileSystemReader(os.path.join(str(tmp_path), "optimizer", "dcp")).read_metadata().state_dict_metadata)
+    base = "model.embedding_group.emb_impls.__BASE__"
+    assert f"{base}.ebc.embedding_bags.plain.weight" in names
+    assert f"state.{base}.ebc.embedding_bags.plain.weight.plain.momentum1" in onames
+    assert not any(".mc_ebc._embedding_module.embedding_bags.plain." in n for n in names | onames)
+    assert any(n.startswith(f"{base}.mc_ebc._managed_collision_collection._managed_collision_modules.z.") for n in names)
+    b = build(1)
+    restore_checkpoint(str(tmp_path), b)
+    assert torch.equal(a.embedding_group.ebc.table_weights()["plain"].cpu(), b.embedding_group.ebc.table_weights()["plain"].cpu())
+    assert torch.equal(a.embedding_group.ebc.table_states()["plain"].cpu(), b.embedding_group.ebc.table_states()["plain"].cpu())
+    a.embedding_group.mc.eval(), b.embedding_group.mc.eval()
+    probe = KeyedJaggedTensor(["kz", "kp"], ids, torch.ones(12, dtype=torch.int32), uniform_length=1).to(dev)
+    with torch.no_grad():  # the ZCH table's rows travel by raw id: the same ids read the same vectors
+        assert torch.equal(a.embedding_group.mc(probe)[0].values(), b.embedding_group.mc(probe)[0].values())
+    assert json.load(open(os.path.join(str(tmp_path), "meta.json")))["dcp_names"] == DCP_NAMES
+    # the same directory relabelled as written by an earlier revision
+    meta = json.load(open(os.path.join(str(tmp_path), "meta.json")))
+    for legacy in ({"format": 1, "dcp_names": "reference"}, {"format": 1}, {"format": 2, "dcp_names": "reference"}):
+        m2 = {k: v for k, v in meta.items() if k != "dcp_names"}
+        m2.update(legacy)
+        json.dump(m2, open(os.path.join(str(tmp_path), "meta.json"), "w"))
+        with pytest.raises(ValueError, match="entry names"):
+            restore_checkpoint(str(tmp_path), build(2))
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_eviction_selection_equals_the_sorted_ranking(dev, seed):
     """`ManagedCollisionModule._select_kept` (radix selection of the entries that lose, csrc/zch_evict.hip) = the

@@ -56,7 +56,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-FORMAT_VERSION = 1
+FORMAT_VERSION = 2  # 2: DCP entries under the reference's module paths (DCP_NAMES); "files" checkpoints of format 1 still load
+DCP_NAMES = "reference-2"  # naming scheme of the DCP entries; a checkpoint written under another one is refused by name
 
 
 def _zch_empty() -> int:
@@ -222,8 +223,10 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
     zch_totals = {}
     for path, col in cols:
         weights, states = col.table_weights(), col.table_states()
-        has_mc = mc is not None and any(n_ in zch_names for n_ in weights)
         for name, (lo, n, total, kind) in _placement(col).items():
+            # the reference keeps a table under `mc_ebc._embedding_module` only when IT is managed-collision; the other tables
+            # of the same data group stay under `ebc` (tzrec/modules/embedding.py:855-864).  Decided per table.
+            has_mc = name in zch_names
             if use_dcp and name in zch_names:
                 # a zero-collision-hash table: its rows mean something only through the raw id -> row map, so they travel
                 # BY RAW ID (occupied rows only, all ranks concatenated): world-size independent
@@ -299,7 +302,7 @@ def save_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: Opti
             json.dump(plan_js, f)
         with open(os.path.join(checkpoint_dir, "meta.json"), "w") as f:
             json.dump({"format": FORMAT_VERSION, "world_size": world, "tables": dims, "tables_format": tables_format,
-                       "dcp_optimizer_state": bool(dcp_optim), "dcp_names": "reference", "zch_entries": zch_totals,
+                       "dcp_optimizer_state": bool(dcp_optim), "dcp_names": DCP_NAMES, "zch_entries": zch_totals,
                        "zch_shared_rows": (world if mc_sharded else 1) if zch_totals else 0}, f)
     if world > 1:
         dist.barrier()
@@ -320,8 +323,16 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
                        strict: bool = True) -> None:
     rank, world = _rank_world()
     meta = json.load(open(os.path.join(checkpoint_dir, "meta.json")))
-    if meta.get("format") != FORMAT_VERSION:
-        raise ValueError(f"checkpoint format {meta.get('format')} != {FORMAT_VERSION}")
+    fmt = meta.get("format")
+    is_dcp = meta.get("tables_format", "files") == "dcp"
+    if fmt not in (1, FORMAT_VERSION):
+        raise ValueError(f"checkpoint format {fmt}: this version reads formats 1 (tables_format 'files') and {FORMAT_VERSION}")
+    if is_dcp and (fmt != FORMAT_VERSION or meta.get("dcp_names") != DCP_NAMES):
+        # earlier revisions wrote the DCP entries under other names (`dense.*`, `<path>.embedding_bags.*`, later every table
+        # of a collection with a ZCH table under `mc_ebc`): the template below would not find them
+        raise ValueError(f"DCP checkpoint written with entry names {meta.get('dcp_names', 'legacy')!r} (format {fmt}); this version "
+                         f"reads {DCP_NAMES!r} (format {FORMAT_VERSION}).  Restore it with the revision that wrote it and save again, "
+                         "or save with tables_format='files', which is unchanged.")
     saved_world = int(meta["world_size"])
     cols = _collections(model)
     for path, col in cols:
@@ -426,8 +437,8 @@ def _restore_dcp(checkpoint_dir: str, model: nn.Module, cols, meta: dict, strict
     tm, to, back = {}, {}, []
     for path, col in cols:
         weights, states = col.table_weights(), col.table_states()
-        has_mc = mc is not None and any(n_ in zch_names for n_ in weights)
         for name, (lo, n, total, kind) in _placement(col).items():
+            has_mc = name in zch_names  # per table, as in save_checkpoint
             if f"{path}/{name}" not in meta["tables"]:
                 continue
             if name in zch_names and name in meta.get("zch_entries", {}):

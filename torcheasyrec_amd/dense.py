@@ -137,8 +137,16 @@ def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _loss_is_root() -> bool:
-    return _ROOT_LOSS["on"] > 0
+def _loss_is_root(gl: Optional[torch.Tensor] = None) -> bool:
+    """Inside `root_loss()` AND the gradient that arrived IS the cached unit gradient (same storage): a model that scales
+    the fused loss before summing (task / sample weights, a GradScaler, gradient accumulation's 1/steps) hands in another
+    tensor and takes the scaled path even when its caller announced a root loss."""
+    if _ROOT_LOSS["on"] <= 0:
+        return False
+    if gl is None:
+        return True
+    one = _ONES.get((gl.device, gl.dtype, tuple(gl.shape)))
+    return one is not None and gl.data_ptr() == one.data_ptr()
 
 
 class _Mlp2Fn(torch.autograd.Function):
@@ -239,7 +247,7 @@ class _TopLossFn(torch.autograd.Function):
         z, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
         # the incoming gradient of the (scalar) loss scales everything; it is folded into the small operands so the
         # [B, *] tensors are touched by the two GEMMs only
-        if _loss_is_root():  # gl == 1.0 (root_loss): nothing to scale
+        if _loss_is_root(gl):  # gl is the unit gradient (root_loss): nothing to scale
             dz = (g1 @ W1) if ctx.needs_input_grad[0] else None
             return (dz, weight_grad(g1, z), db1, dW2, db2, dw3, scal[0:1], None)
         dz = (g1 @ (W1 * gl)) if ctx.needs_input_grad[0] else None
@@ -311,7 +319,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
         dense, sparse, W1, g1, dW2, db2, dw3, scal, db1 = ctx.saved_tensors
         F, D = ctx.cfg
         B = sparse.shape[0]
-        root = _loss_is_root()  # gl == 1.0: no scale operand for the kernel, no multi-tensor scaling launch
+        root = _loss_is_root(gl)  # gl is the unit gradient: no scale operand for the kernel, no multi-tensor scaling launch
         gl32 = None if root else gl.reshape(1).to(torch.float32)
         gd = gs = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:

@@ -330,6 +330,20 @@ class ShardedTrainStep:
         st["ready"] = ev
         return st
 
+    def _drain_discarded_ahead(self) -> None:
+        """A prefetched input dist that is NOT the batch now stepped (the caller changed its mind about the next batch): its
+        overflow word's D2H copy may still be in flight towards the pinned word of a slot the new batch is about to re-arm --
+        landing after the sentinel it would be read as the new batch's word.  Wait for it before the slot is reused."""
+        if self._ahead is None:
+            return
+        st = self._ahead[1]
+        self._ahead = None
+        ev = st.get("flag_event") if isinstance(st, dict) else None
+        if ev is not None:
+            ev.synchronize()
+        elif self.cuda and isinstance(st, dict) and "flag_host" in st:
+            torch.cuda.synchronize(self.device)
+
     def _begin_ahead(self, kjt: KeyedJaggedTensor, after) -> dict:
         """Input dist of the NEXT batch, queued behind the start of the current step on the side stream.  Capacity-bounded
         exchange: nothing of it needs the host -- the backward plans are queued right behind it (they depend on ids only)
@@ -391,6 +405,7 @@ class ShardedTrainStep:
             if st.get("_deferred"):
                 st = self._end(st)  # the overflow word of a batch whose input dist was queued a step ago
         else:
+            self._drain_discarded_ahead()
             st = self._end(self._begin(kjt))
         self._ahead = None
         self._consume(st)

@@ -662,8 +662,15 @@ class ShardedEmbeddingBagCollection(nn.Module):
                 spins = 0
                 while int(host.item()) < 0:
                     spins += 1
-                    if spins > 2_000_000 and ev is not None:  # (never seen; do not spin for ever on a lost copy)
-                        ev.synchronize()
+                    if spins > 2_000_000:  # (never seen) not for ever on a lost copy: wait for the copy's event, read ONCE more
+                        if ev is not None:
+                            ev.synchronize()
+                        else:
+                            torch.cuda.current_stream(dev).synchronize()
+                        if int(host.item()) < 0:
+                            raise RuntimeError("capacity exchange: the overflow word's D2H copy completed without overwriting "
+                                               "the host sentinel (flag_host still < 0)")
+                        break
             elif ev is not None:
                 ev.synchronize()
             over = int(st.pop("flag_host").item())
@@ -800,6 +807,11 @@ class ShardedEmbeddingBagCollection(nn.Module):
         NP = n_dp * B if uniform else N_all
         offsets = None if uniform else kjt.offsets()
         stream = _lib.stream_ptr(dev)
+        # `_dp_acc` is zero on entry because the previous step's tzr_dense_rows_update_clear left it so.  A step that raised
+        # between this pass and that update left sums behind: cleared here (never inside a capture: a captured step ran whole)
+        if getattr(self, "_dp_acc_dirty", False) and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self._dp_acc.zero_()
+        self._dp_acc_dirty = True
         if self._dp_direct(st):
             ws = self._direct_ws("dp", st.get("slot") if "cap" in st else None, NP, T_dp)
             _lib.check(L.tzr_pooled_bwd_direct(_lib.ptr(rm["dp_d_acc_tables"]), T_dp, _lib.ptr(rm["dp_d_bwd_feats"]), n_dp,
@@ -913,6 +925,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_dense_rows_update_clear(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
                        "tzr_dense_rows_update_clear")
+            self._dp_acc_dirty = False
         self._after_backward(st)
 
     def _after_backward(self, st: dict) -> None:
@@ -1066,6 +1079,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             _lib.check(L.tzr_dense_rows_update_clear(_lib.ptr(rm["dp_d_tables"]), len(self._dp), _lib.ptr(self._dp_row_start),
                                                self._dp_rows, _lib.ptr(self._dp_acc), D, self._optim_struct(), stream),
                        "tzr_dense_rows_update_clear")
+            self._dp_acc_dirty = False
         self._after_backward(st)
 
     # -- public API ------------------------------------------------------------------------------
