@@ -18,7 +18,8 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = [b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
+KNOBS = {b"bwd_apply_waves": 0, b"fwd_tile_b": 0, b"fwd_variant": 0, b"bwd_ch": 0, b"bwd_one_wg_heavy": 0, b"bwd_force_prep": 0,
+         b"bwd_solo": 2}  # knob -> its default (restored in front of every set)
 
 
 class Timers:
@@ -60,8 +61,8 @@ def main():
             batches = [k.to(dev) for k in host]
             g = torch.randn(B, 416, device=dev) * 1e-3
             for spec in args.sets:
-                for k in KNOBS:
-                    L.tzr_tune(k, 0)
+                for k, v0 in KNOBS.items():
+                    L.tzr_tune(k, v0)
                 for kv in [x for x in spec.split(",") if x]:
                     name, v = kv.split("=")
                     assert L.tzr_tune(name.encode(), int(v)) == 0, kv
