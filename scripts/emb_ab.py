@@ -18,8 +18,7 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = {b"bwd_apply_waves": 0, b"fwd_tile_b": 0, b"fwd_variant": 0, b"bwd_ch": 0, b"bwd_one_wg_heavy": 0, b"bwd_force_prep": 0,
-         b"bwd_solo": 2}  # knob -> its default (restored in front of every set)
+KNOBS = [b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
 
 
 class Timers:
@@ -45,9 +44,10 @@ def main():
     ap.add_argument("--dist", default="uniform")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layout", default="interleaved")
+    ap.add_argument("--lib", default=None, help="another build of the library to time (same-box A/B against an older tree)")
     ap.add_argument("sets", nargs="*", default=[""])
     args = ap.parse_args()
-    _lib.use_library(_build.build())
+    _lib.use_library(args.lib or _build.build())
     L = _lib.lib()
     dev = torch.device("cuda", 0)
     ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev,
@@ -61,8 +61,8 @@ def main():
             batches = [k.to(dev) for k in host]
             g = torch.randn(B, 416, device=dev) * 1e-3
             for spec in args.sets:
-                for k, v0 in KNOBS.items():
-                    L.tzr_tune(k, v0)
+                for k in KNOBS:
+                    L.tzr_tune(k, 0)
                 for kv in [x for x in spec.split(",") if x]:
                     name, v = kv.split("=")
                     assert L.tzr_tune(name.encode(), int(v)) == 0, kv

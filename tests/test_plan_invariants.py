@@ -52,9 +52,7 @@ def _check_plan(ebc, kjt, dev):
     o8 = (ctypes.c_int64 * 8)()
     assert _lib.lib().tzr_pooled_bwd_plan_view(N, NP, F, T, max(c.embedding_dim for c in ebc._configs), o8) == 0
     host = ws.cpu()
-    sorted_pairs = host[o8[0]:o8[0] + 8 * NP].view(torch.int32).view(NP, 2).numpy().astype(np.int64) & 0xFFFFFFFF
-    solo_mark = (sorted_pairs[:, 1] >> 31) & 1  # BWD_SOLO_BIT: "alone in its row", set by the unit sort (csrc/pooled_bwd.h)
-    sorted_pairs[:, 1] &= 0x7FFFFFFF
+    sorted_pairs = host[o8[0]:o8[0] + 8 * NP].view(torch.int32).view(NP, 2).numpy().astype(np.int64)
     part_pairs = host[o8[1]:o8[1] + 8 * NP].view(torch.int32).view(NP, 2).numpy().astype(np.int64)
     fstart = host[o8[2]:o8[2] + 4 * (F + 1)].view(torch.int32).numpy().astype(np.int64)
     vals = kjt.values().cpu().numpy()
@@ -74,10 +72,6 @@ def _check_plan(ebc, kjt, dev):
         assert e - s == len(want_src), cfg.name
         pairs = (part_pairs if cfg.num_embeddings <= 512 else sorted_pairs)[s:e]
         k, sp = pairs[:, 0], pairs[:, 1]
-        if cfg.num_embeddings > 512:  # a marked lookup really is alone in its row (the position-order role updates it unsummed)
-            mk = k[solo_mark[s:e] == 1]
-            assert len(np.unique(mk)) == len(mk) and not np.isin(k[solo_mark[s:e] == 0], mk).any(), f"{cfg.name}: a marked lookup shares its row"
-
         assert np.array_equal(np.sort(sp), np.sort(want_src)), f"{cfg.name}: not a permutation of the table's lookups"
         assert np.array_equal(k, np.where((vals[sp] >= 0) & (vals[sp] < cfg.num_embeddings), vals[sp], 0)), f"{cfg.name}: row of a pair != its id"
         if len(k) > 1:

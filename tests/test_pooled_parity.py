@@ -463,54 +463,6 @@ def test_backward_plan_is_bit_reproducible(dev, bwd_path):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("kind", ["adagrad", "rowwise_adagrad", "sgd", "adam"])
-@pytest.mark.parametrize("mode,weighted", [("uniform1", False), ("jagged", True)])
-def test_position_order_role_equals_the_sorted_role(dev, kind, mode, weighted):
-    """Lookups that are alone in their row are updated by the position-order role of the apply (csrc/pooled_bwd.h "solo":
-    marked by the unit sort, skipped by the sorted role).  A row with one lookup has one gradient, so the tables -- weights
-    and optimizer state -- must come out BIT-identical with the role on (default) and off (`tzr_tune bwd_solo 0`: every
-    lookup through the sorted role), and identical from run to run.  Tables: one with many more rows than lookups (nearly
-    all alone), one of them with a hot row (a heavy bucket: units with heavy lookups mark nothing), one with as many rows
-    as lookups (not eligible), one tiny; two feature groups share a lookup (the gradient is a sum over groups)."""
-    from torcheasyrec_amd import _lib
-
-    L = _lib.lib()
-    B = 1500
-    spec = [("big", 3_000_000, 16, "sum", ["a"]), ("hot", 1 << 20, 8, "sum", ["b"]), ("mid", 2000, 16, "mean", ["c"]),
-            ("tiny", 5, 4, "sum", ["d"])]
-    keys, rows = ["a", "b", "c", "d"], [3_000_000, 1 << 20, 2000, 5]
-    groups = {"g0": ["a", "b", "c", "d"], "g1": ["a", "c"]}
-    hot = _hot(0.4, [777777])
-    rng = np.random.default_rng(11)
-    kjt = _make_kjt(keys, rows, B, rng, mode=mode, weighted=weighted,
-                    idgen=lambda r_, rw, n: hot(r_, rw, n) if rw == 1 << 20 else r_.integers(0, rw, size=n))
-    gens = {"g0": torch.randn(B, 44, generator=torch.Generator().manual_seed(1)), "g1": torch.randn(B, 32, generator=torch.Generator().manual_seed(2))}
-    opt = SparseOptimizerConfig(kind=kind, lr=0.05, weight_decay=0.01 if kind == "rowwise_adagrad" else 0.0,
-                                weight_decay_mode="l2" if kind == "rowwise_adagrad" else "none")
-    assert L.tzr_tune(b"bwd_direct", -1) == 0  # the planned pair, not the one-launch backward of small batches
-    results = []
-    try:
-        for solo in (2, 0, 2):
-            assert L.tzr_tune(b"bwd_solo", solo) == 0
-            cfgs, _ = _make_tables(spec)
-            ebc = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt, groups=groups)
-            for _ in range(2):
-                outs = ebc.forward_grouped(kjt.to(dev))
-                sum((outs[g] * gens[g].to(dev)).sum() for g in outs).backward()
-            results.append(({n: w.detach().cpu().clone() for n, w in ebc.table_weights().items()},
-                            {n: m.detach().cpu().clone() for n, m in ebc.table_states().items()}))
-    finally:
-        L.tzr_tune(b"bwd_solo", 2)
-        L.tzr_tune(b"bwd_direct", 0)
-    (w_on, m_on), (w_off, m_off), (w_again, m_again) = results
-    for n in w_on:
-        assert torch.equal(w_on[n], w_off[n]), f"weights of {n}: position-order role != sorted role"
-        assert torch.equal(w_on[n], w_again[n]), f"weights of {n}: not reproducible"
-    for n in m_on:
-        assert torch.equal(m_on[n], m_off[n]) and torch.equal(m_on[n], m_again[n]), f"state of {n}"
-    assert not torch.equal(w_on["big"], _make_tables(spec)[1]["big"])  # (the step did move the table)
-
-
 @pytest.mark.parametrize("kind,weighted", [("adagrad", False), ("rowwise_adagrad", True)])
 def test_backward_jagged_shared_table(dev, kind, weighted, bwd_path):
     opt = SparseOptimizerConfig(kind=kind, lr=0.02, gradient_clipping=True, max_gradient=0.7)

@@ -76,35 +76,10 @@ struct BwdPlan {  // pointers into the caller workspace
                            //     (in place) the slice's base = counts of the slices before it (only when nslices > 1)
   uint32_t* scnt;          // [T] slices of the table that have arrived (zeroed by the hist launch)
   int32_t nslices;         // workgroups per table of the scan launch
-  uint32_t* solo;          // [N] per table-major position of a table that takes the position-order role of the apply
-                           //     (bwd_solo_table): the lookup's row id when that row has no other lookup in this batch, else
-                           //     BWD_SENT; filled with BWD_SENT by the hist launch, set by the unit sort, which marks the same
-                           //     lookups in ks[0] (BWD_SOLO_BIT of the lookup position).  hcount[1] = the ratio the plan was
-                           //     built with (the apply reads it there: marks and roles cannot disagree)
-  uint32_t* usolo;         // [max_chunks] lookups of the unit the sort marked and moved to the unit's end (0 without marks)
-  int32_t solo_ratio;      // g_tzr_bwd_solo at the plan's launch (0: no marks)
   int64_t max_chunks;
   int64_t max_heavy;
   int32_t ch;  // positions per chunk (multiple of 256, <= BWD_CH)
 };
-
-// ---- lookups whose row nothing else touches ("solo") ------------------------------------------
-// The sorted order exists to bring the lookups of one row together.  In a table with many more rows than the batch has
-// lookups for it (the five 40 M-row tables of DLRM-Criteo at 65 536 samples: 99.9 % of the rows touched are touched once)
-// nearly every lookup is alone in its row -- and the sorted apply serves it the expensive way: keys staged through LDS, one
-// tile after the other per wave, the gradient row fetched from wherever the sort put it.  The unit sort sees every row's
-// neighbours anyway, so it MARKS the lookups that are alone (bit 31 of the lookup position in ks[0] + the row id in a
-// word per table-major position); the sorted role of the apply skips them, and a second role of the same launch walks the
-// table's positions in BATCH order -- row ids and gradient rows read as they lie in memory, nothing staged, several
-// rows in flight per lane -- and updates each marked row once.  A row is touched by exactly one of the two roles, and a
-// solo row has one gradient: no summation order to preserve.
-#define BWD_SOLO_BIT 0x80000000u
-extern int g_tzr_bwd_solo;  // tzr_tune("bwd_solo"): rows per lookup from which a table takes the solo role (0 = off; default 2)
-// (static in the table's shape, not in the batch's ids: every kernel of the plan and the apply derives the same answer)
-__host__ __device__ static inline bool bwd_solo_table(int solo_ratio, int64_t rows, int n_feats, int64_t n_positions_of_table) {
-  return solo_ratio > 0 && n_feats == 1 && rows > BWD_NB && n_positions_of_table > 0 &&
-         (uint64_t)rows >= (uint64_t)solo_ratio * (uint64_t)n_positions_of_table;
-}
 
 // Positions per chunk.  The plan / apply kernels are latency-bound: the time of a launch is the
 // time of ONE workgroup unless the chip is oversubscribed, so a small problem wants small chunks
@@ -164,9 +139,6 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.nslices = bwd_pick_slices(N, T, q.ch);
   q.stot = c.take<uint32_t>(q.nslices > 1 ? (size_t)T * q.nslices * BWD_NB : 1);
   q.scnt = c.take<uint32_t>(T > 0 ? T : 1);
-  q.solo = c.take<uint32_t>(N > 0 ? N : 1);
-  q.usolo = c.take<uint32_t>(q.max_chunks);
-  q.solo_ratio = NV < (1LL << 31) ? g_tzr_bwd_solo : 0;  // (the mark is bit 31 of a lookup position)
   if (p) *p = q;
   return c.off;
 }

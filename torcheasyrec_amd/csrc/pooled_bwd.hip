@@ -83,7 +83,6 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     }
     P.feat_start[F] = run;
     P.hcount[0] = 0;
-    P.hcount[1] = (uint32_t)P.solo_ratio;  // read back by the apply (pooled_bwd.h: "solo")
   }
   for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
   __syncthreads();
@@ -127,10 +126,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
       for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
       for (int t = threadIdx.x; t <= T; t += BWD_THREADS) P.tab_chunk[t] = (int32_t)GL.tchunk[t];
       for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
-      if (threadIdx.x == 0) {
-        P.hcount[0] = 0;
-        P.hcount[1] = (uint32_t)P.solo_ratio;  // read back by the apply (pooled_bwd.h: "solo")
-      }
+      if (threadIdx.x == 0) P.hcount[0] = 0;
     }
   } else {
     G.fstart = P.feat_start;
@@ -160,13 +156,8 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
     cd.s = cd.ts + (int64_t)(c - G.tchunk[lo]) * P.ch;
     cd.e = min(cd.te, cd.s + (int64_t)P.ch);
   }
-  if (threadIdx.x == 0) {
-    P.cdesc[c] = cd;
-    P.usolo[c] = 0;
-  }
+  if (threadIdx.x == 0) P.cdesc[c] = cd;
   if (cd.t < 0) return;
-  if (bwd_solo_table(P.solo_ratio, tb.rows, tb.n_feats, cd.te - cd.ts))  // (workgroup-uniform) "no solo lookup here" until the unit sort says otherwise
-    for (int64_t q = cd.s + threadIdx.x; q < cd.e; q += BWD_THREADS) P.solo[q] = BWD_SENT;
   for (int i = threadIdx.x; i < BWD_NB; i += BWD_THREADS) h[i] = 0;
   // all of the chunk's keys are loaded before any is counted: independent loads in flight, one
   // memory latency per workgroup instead of one per element
@@ -440,7 +431,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
 //     workgroup; a single workgroup walks the tiles in order, so the running per-digit offsets ARE
 //     the cross-tile prefix.
 
-__device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ tables, const BwdSrcArgs& A, const BwdPlan& P,
+__device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ tables, const BwdPlan& P,
                                               BwdSortLds& S, int c) {
   BwdChunkDesc cd;
   if (!bwd_chunk(P, c, &cd)) return;
@@ -521,49 +512,6 @@ __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ table
   if (kmin > kmax) return;  // nothing but heavy lookups (workgroup-uniform)
   bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), htot == 0,
                          S, dest);
-  // Lookups that are alone in their row (pooled_bwd.h: "solo").  The light lookups of the unit are whole buckets in an
-  // order that keeps equal rows adjacent, so a lookup is alone iff neither neighbour in that order has its row.  Such
-  // lookups are handed to the position-order role of the apply by row id (P.solo) and moved BEHIND the others inside the
-  // unit (marked: BWD_SOLO_BIT), P.usolo[c] counts them: the sorted role reduces the front part and never sees them.
-  // Only in a unit without heavy lookups (their places inside the unit are fixed by other workgroups), only for a table
-  // of bwd_solo_table.  (Both workgroup-uniform.)
-  const TzrTable tb = tables[cd.t];
-  if (htot == 0 && bwd_solo_table(P.solo_ratio, tb.rows, tb.n_feats, cd.te - cd.ts)) {
-    const int64_t key = P.feat_key[tb.first_order];
-    // solo word of lookup position i = swords[i] (a uniform base + a 32-bit lane offset: no 64-bit lane arithmetic per store)
-    uint32_t* const swords = P.solo + (cd.ts - (A.uniform ? key * A.B : A.offsets[key * A.B]));
-    __syncthreads();  // the core is done with S.pk / S.ps
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r)
-      if ((vmask >> r) & 1u) S.pk[dest[r]] = kreg[r];
-    __syncthreads();
-    uint32_t smask = 0;
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r)
-      if ((vmask >> r) & 1u) {
-        const uint32_t d = dest[r];
-        const uint32_t prev = d > 0 ? S.pk[d - 1] : BWD_SENT;
-        const uint32_t next = d + 1 < (uint32_t)n ? S.pk[d + 1] : BWD_SENT;
-        if (prev != kreg[r] && next != kreg[r]) smask |= 1u << r;
-        S.ps[d] = (prev != kreg[r] && next != kreg[r]) ? 0u : 1u;  // 1 = stays with the sorted role
-      }
-    __syncthreads();
-    bwd_block_scan(S.ps, n, S.wtot);  // -> lookups that stay, ahead of each sorted position; S.ps[n] = their number (n < BWD_UMAX)
-    const uint32_t stay = S.ps[n];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r)
-      if ((vmask >> r) & 1u) {
-        const uint32_t before = S.ps[dest[r]];
-        if ((smask >> r) & 1u) {
-          dst[stay + (dest[r] - before)] = make_uint2(kreg[r], sreg[r] | BWD_SOLO_BIT);
-          swords[sreg[r]] = kreg[r];
-        } else {
-          dst[before] = make_uint2(kreg[r], sreg[r]);
-        }
-      }
-    if (threadIdx.x == 0) P.usolo[c] = (uint32_t)n - stay;
-    return;
-  }
   // final position = unit start + rank among the unit's light lookups + heavy lookups ahead
 #pragma unroll
   for (int r = 0; r < kRounds; ++r)
@@ -990,11 +938,11 @@ __global__ void tzr_bwd_nop_kernel(uint32_t* p) {
 
 // first_block: offset added to blockIdx.x (the debug split launches the heavy workers on their own)
 __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_kernel(
-    const TzrTable* __restrict__ tables, BwdSrcArgs A, int n_units, unsigned first_block, unsigned total_blocks, BwdPlan P) {
+    const TzrTable* __restrict__ tables, int n_units, unsigned first_block, unsigned total_blocks, BwdPlan P) {
   __shared__ BwdSortLds S;
   const unsigned bid = blockIdx.x + first_block;
   if ((int)bid < n_units) {
-    bwd_sort_unit(tables, A, P, S, (int)bid);
+    bwd_sort_unit(tables, P, S, (int)bid);
     return;
   }
   const unsigned nh = P.hcount[0];
@@ -1014,7 +962,6 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_
 int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO geometry path
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
-int g_tzr_bwd_solo = 2;          // tzr_tune("bwd_solo"): see pooled_bwd.h ("solo"); 0 = every lookup through the sorted role
 int g_tzr_bwd_debug = 0;         // tzr_tune("bwd_debug"): bit 0/2 empty launch before/behind the sort, bit 1 sort split in two launches
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
@@ -1063,12 +1010,12 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   if (g_tzr_bwd_debug & 1)  // one more kernel boundary between the partition pass and the sort
     hipLaunchKernelGGL(tzr_bwd_nop_kernel, dim3(1), dim3(64), 0, s, P.hcount);
   if (g_tzr_bwd_debug & 2) {  // units and heavy workers as two launches
-    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, A, (int)chunks, 0u,
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, (int)chunks, 0u,
                        chunks + workers, P);
-    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(workers), dim3(BWD_THREADS), 0, s, d_tables, A, (int)chunks, chunks,
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(workers), dim3(BWD_THREADS), 0, s, d_tables, (int)chunks, chunks,
                        chunks + workers, P);
   } else {
-    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables, A,
+    hipLaunchKernelGGL(tzr_bwd_sort_kernel, dim3(chunks + workers), dim3(BWD_THREADS), 0, s, d_tables,
                        (int)chunks, 0u, chunks + workers, P);
   }
   if (g_tzr_bwd_debug & 4)  // ... and one behind the sort

@@ -48,48 +48,6 @@ __device__ __forceinline__ BwdSrc bwd_resolve(const TzrFeature* __restrict__ ft,
   return s;
 }
 
-// Pooled-output gradient of bag `bag` = (key, sample b) as the lookup at position i sees it, float4 chunk c: the feature
-// groups' gradients summed in destination order, times the per-id weight, over the bag length for mean pooling.
-__device__ __forceinline__ float4 bwd_bag_grad(const BwdSrc& s, const int64_t* __restrict__ offsets,
-                                               const float* __restrict__ weights, int uniform, int64_t i, int64_t bag,
-                                               int64_t b, int c) {
-  // (gradient buffers, optimizer state: device memory reached through descriptors -- global, not FLAT, instructions:
-  // tzr_gfx950.h; a FLAT access also counts in the LDS counter, and every wait for an LDS read then waits for it)
-  float4 g = tzr_ldg4(s.gp0 + b * s.gs0 + 4 * c);
-  if (s.n_dst > 1) g = tzr_add4(g, tzr_ldg4(s.gp1 + b * s.gs1 + 4 * c));
-  if (s.n_dst > 2) g = tzr_add4(g, tzr_ldg4(s.gp2 + b * s.gs2 + 4 * c));
-  if (s.n_dst > 3) g = tzr_add4(g, tzr_ldg4(s.gp3 + b * s.gs3 + 4 * c));
-  const bool mean = !uniform && s.mean;
-  if (weights || mean) {
-    float sc = weights ? weights[i] : 1.0f;
-    if (mean) {
-      const int64_t len = offsets[bag + 1] - offsets[bag];
-      if (len > 1) sc = sc / (float)len;
-    }
-    g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
-  }
-  return g;
-}
-
-__device__ __forceinline__ int64_t bwd_uni64(int64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ const float* bwd_uni_ptr(const float* p) {
-  return reinterpret_cast<const float*>(bwd_uni64(reinterpret_cast<int64_t>(p)));
-}
-
-// The gradient descriptors of a table's one lookup, read through LDS (run-time selection of the feature groups), are lane
-// values to the compiler: eight 64-bit registers per lane.  They are the same in every lane: scalar registers.
-__device__ __forceinline__ BwdSrc bwd_uni_src(BwdSrc one) {
-  one.gp0 = bwd_uni_ptr(one.gp0); one.gp1 = bwd_uni_ptr(one.gp1); one.gp2 = bwd_uni_ptr(one.gp2); one.gp3 = bwd_uni_ptr(one.gp3);
-  one.gs0 = bwd_uni64(one.gs0); one.gs1 = bwd_uni64(one.gs1); one.gs2 = bwd_uni64(one.gs2); one.gs3 = bwd_uni64(one.gs3);
-  one.n_dst = __builtin_amdgcn_readfirstlane(one.n_dst);
-  one.mean = __builtin_amdgcn_readfirstlane(one.mean);
-  return one;
-}
-
 // dL/d(row contribution) of the lookup at original position i, float4 chunk c of its row.
 //   grad_mode 0: pooled-output gradients per feature group (bag (key,b) -> grad[g][b, col..])
 //   grad_mode 1: one gradient row per id: G.d[0][i, :]
@@ -99,7 +57,7 @@ __device__ __forceinline__ float4 bwd_lookup_grad(
     const int64_t* __restrict__ offsets, const float* __restrict__ weights,
     const uint32_t* __restrict__ bag_of, int64_t B, int uniform, uint32_t i, int c) {
   if (grad_mode == 1)
-    return tzr_ldg4(reinterpret_cast<const float*>(sG[0].ptr) + (int64_t)i * sG[0].stride + 4 * c);
+    return tzr_ld4(reinterpret_cast<const float*>(sG[0].ptr) + (int64_t)i * sG[0].stride + 4 * c);
   const uint32_t bag = uniform ? i : bag_of[i];
   const uint32_t key = bag / (uint32_t)B;
   const int64_t b = bag - key * (uint32_t)B;
@@ -109,7 +67,20 @@ __device__ __forceinline__ float4 bwd_lookup_grad(
     while (o + 1 < tb.first_order + tb.n_feats && feats[feat_by_order[o]].key != (int32_t)key) ++o;
     s = bwd_resolve(feats + feat_by_order[o], sG);
   }
-  return bwd_bag_grad(s, offsets, weights, uniform, (int64_t)i, (int64_t)bag, b, c);
+  float4 g = tzr_ld4(s.gp0 + b * s.gs0 + 4 * c);
+  if (s.n_dst > 1) g = tzr_add4(g, tzr_ld4(s.gp1 + b * s.gs1 + 4 * c));
+  if (s.n_dst > 2) g = tzr_add4(g, tzr_ld4(s.gp2 + b * s.gs2 + 4 * c));
+  if (s.n_dst > 3) g = tzr_add4(g, tzr_ld4(s.gp3 + b * s.gs3 + 4 * c));
+  const bool mean = !uniform && s.mean;
+  if (weights || mean) {
+    float sc = weights ? weights[i] : 1.0f;
+    if (mean) {
+      const int64_t len = offsets[(int64_t)bag + 1] - offsets[bag];
+      if (len > 1) sc = sc / (float)len;
+    }
+    g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+  }
+  return g;
 }
 
 // Sum of v over the `lg` lanes of a row group (all 64 lanes call it).
@@ -134,11 +105,11 @@ template <bool ADAM>
 __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOpt& opt, int64_t row,
                                                  int c, bool active) {
   if (active && (ADAM || opt.kind == TZR_OPT_ADAGRAD))  // Adam: exp_avg
-    return tzr_ldg4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
+    return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
   // row-wise Adagrad: the row's scalar, fetched by the group's first lane (c == lane in group at every call site)
   // together with the weights -- not after the gradient reduction, where its latency was exposed once per run
   if (!ADAM && active && c == 0 && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
-    return make_float4(tzr_ldg(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride), 0.f, 0.f, 0.f);
+    return make_float4(reinterpret_cast<const float*>(tb.m)[row * (int64_t)tb.m_stride], 0.f, 0.f, 0.f);
   return tzr_zero4();
 }
 
@@ -149,9 +120,9 @@ __device__ __forceinline__ float4 bwd_load_state(const TzrTable& tb, const BwdOp
 template <bool ADAM>
 __device__ __forceinline__ float4 bwd_load_state_all(const TzrTable& tb, const BwdOpt& opt, int64_t row, int c) {
   if (ADAM || opt.kind == TZR_OPT_ADAGRAD)  // (kernel-uniform)
-    return tzr_ldg4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
+    return tzr_ld4(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c);
   if (!ADAM && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
-    return make_float4(tzr_ldg(reinterpret_cast<const float*>(tb.m) + row * (int64_t)tb.m_stride), 0.f, 0.f, 0.f);
+    return make_float4(reinterpret_cast<const float*>(tb.m)[row * (int64_t)tb.m_stride], 0.f, 0.f, 0.f);
   return tzr_zero4();
 }
 
@@ -176,15 +147,15 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
     if (active) {
       float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
       float* vp = mp + tb.dim;
-      float4 v4 = tzr_ldg4(vp);
+      float4 v4 = tzr_ld4(vp);
       const float b1 = opt.beta1, b2 = opt.beta2;
       const float c1 = opt.adam[1], c2 = opt.adam[2];
       m4.x = b1 * m4.x + (1.0f - b1) * g.x; m4.y = b1 * m4.y + (1.0f - b1) * g.y;
       m4.z = b1 * m4.z + (1.0f - b1) * g.z; m4.w = b1 * m4.w + (1.0f - b1) * g.w;
       v4.x = b2 * v4.x + (1.0f - b2) * g.x * g.x; v4.y = b2 * v4.y + (1.0f - b2) * g.y * g.y;
       v4.z = b2 * v4.z + (1.0f - b2) * g.z * g.z; v4.w = b2 * v4.w + (1.0f - b2) * g.w * g.w;
-      tzr_stg4(mp, m4);
-      tzr_stg4(vp, v4);
+      tzr_st4(mp, m4);
+      tzr_st4(vp, v4);
       w4.x -= lr * ((m4.x / c1) / (sqrtf(v4.x / c2) + opt.eps) + opt.wd * w4.x);
       w4.y -= lr * ((m4.y / c1) / (sqrtf(v4.y / c2) + opt.eps) + opt.wd * w4.y);
       w4.z -= lr * ((m4.z / c1) / (sqrtf(v4.z / c2) + opt.eps) + opt.wd * w4.z);
@@ -197,7 +168,7 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
     if (active) {
       float* mp = reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c;
       m4.x += g.x * g.x; m4.y += g.y * g.y; m4.z += g.z * g.z; m4.w += g.w * g.w;
-      tzr_stg4(mp, m4);
+      tzr_st4(mp, m4);
       w4.x -= lr * g.x / (sqrtf(m4.x) + opt.eps);
       w4.y -= lr * g.y / (sqrtf(m4.y) + opt.eps);
       w4.z -= lr * g.z / (sqrtf(m4.z) + opt.eps);
@@ -225,11 +196,11 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
       w4.z = corr * w4.z - mult * g.z;
       w4.w = corr * w4.w - mult * g.w;
       tzr_stw4(wbase, tb.w_dtype, woff, w4);
-      if (lane_in_group == 0) tzr_stg(mp, mnew);
+      if (lane_in_group == 0) *mp = mnew;
     }
   } else if (opt.kind == TZR_OPT_ACCUMULATE) {
     // replicated table: hand the summed row gradient to the all-reduce (tb.m = dense [rows, dim])
-    if (active) tzr_stg4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, g);
+    if (active) tzr_st4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, g);
   } else {  // SGD
     if (active) {
       w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
@@ -315,7 +286,7 @@ __device__ __forceinline__ void bwd_reduce_unit(
   const bool lane_on = gi < gw;
   const float lr = *opt.lr;
   const bool single = tb.n_feats == 1;
-  const BwdSrc one = bwd_uni_src(bwd_resolve(feats + feat_by_order[tb.first_order], sG));
+  const BwdSrc one = bwd_resolve(feats + feat_by_order[tb.first_order], sG);
 
   const int range = (n + BWD_WAVES - 1) / BWD_WAVES;  // sorted positions reduced by one wave
   const int r0 = min(n, wv * range);                  // range of this wave, unit-relative

@@ -106,9 +106,7 @@ __device__ __forceinline__ void bwd_reduce_body(
   // the unit: sorted positions [s, e) of the table (pooled_bwd.hip, scan kernel)
   const int64_t s = P.ucut[blockIdx.x];
   const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)P.ucut[blockIdx.x + 1] : te;
-  // (the unit sort moved the lookups that are alone in their row behind the others and counted them: they belong to the
-  // position-order role, bwd_solo_body -- pooled_bwd.h "solo")
-  const int n = (int)(e - s) - (int)P.usolo[blockIdx.x];
+  const int n = (int)(e - s);
   const TzrTable tb = tables[t];
   if (n <= 0 || n > BWD_UMAX) {  // an empty tail unit (n > BWD_UMAX cannot happen by construction)
     if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;  // overlaps no bucket: nobody waits for it
@@ -128,7 +126,7 @@ __device__ __forceinline__ void bwd_reduce_body(
     // the neighbours outside the unit are either in another bucket (another row id) or in the same
     // sorted bucket: comparing with them is always meaningful
     sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
-    sK[n + 1] = s + n < te ? KS[s + n].x : BWD_SENT;  // (the unit's own first solo lookup when it has any: no row of the unit)
+    sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
 #pragma unroll
     for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
   }
@@ -141,7 +139,7 @@ __device__ __forceinline__ void bwd_reduce_body(
   const bool lane_on = gi < gw;
   const float lr = *opt.lr;
   const bool single = tb.n_feats == 1;
-  const BwdSrc one = bwd_uni_src(bwd_resolve(feats + P.feat_by_order[tb.first_order], sG));
+  const BwdSrc one = bwd_resolve(feats + P.feat_by_order[tb.first_order], sG);
 
   const int range = (n + BWD_WAVES - 1) / BWD_WAVES;  // sorted positions reduced by one wave
   const int r0 = min(n, wv * range);                  // range of this wave, unit-relative
@@ -255,101 +253,12 @@ __device__ __forceinline__ void bwd_reduce_body(
                               bwd_bucket(sK[n], cd.mult), lane);
 }
 
-// ---- the position-order role of the apply: lookups alone in their row (pooled_bwd.h: "solo") -------------------------------
-// Workgroup <-> chunk of table-major positions (the same chunks the plan counted and scattered), tables of bwd_solo_table
-// only.  P.solo[p] = the row id when the lookup at position p is alone in its row, BWD_SENT otherwise (the unit sort wrote
-// it): a coalesced word per lookup is all this role reads of the plan.  U lookups per lane group in flight: their gradient
-// rows (batch order: consecutive samples), weights and optimizer state are fetched together, every load unconditional (a
-// lane without a solo lookup reads row 0 and writes nothing), then each row gets its ONE update -- the same arithmetic as
-// the sorted role on a run of length one.
-template <bool ADAM, int U>
-__device__ __forceinline__ void bwd_solo_body(
-    const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats, const int64_t* __restrict__ offsets,
-    const float* __restrict__ weights, int64_t B, int uniform, int grad_mode, const BwdGrads& G, const BwdOpt& opt,
-    const BwdPlan& P, int chunk) {
-  __shared__ TzrDst sG[TZR_MAX_DST];
-  BwdChunkDesc cd;
-  if (!bwd_chunk(P, chunk, &cd)) return;
-  const TzrTable tb = tables[cd.t];
-  if (!bwd_solo_table((int)P.hcount[1], tb.rows, tb.n_feats, cd.te - cd.ts)) return;  // (the ratio the PLAN was built with)
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & (TZR_WAVE - 1);
-  const int wv = threadIdx.x / TZR_WAVE;
-  const int lg = tb.dim >> 2;
-  const int gw = TZR_WAVE / lg;
-  const int gi = lane / lg;
-  const int c = lane - gi * lg;
-  const bool lane_on = gi < gw;
-  const float lr = *opt.lr;
-  const TzrFeature* const ft = feats + P.feat_by_order[tb.first_order];
-  const BwdSrc one = bwd_uni_src(bwd_resolve(ft, sG));
-  const int64_t key = P.feat_key[tb.first_order];
-  const int64_t fbase = uniform ? key * B : offsets[key * B];  // lookup position of the table's first position
-  const uint32_t* __restrict__ srow = P.solo + cd.s;
-  const int n = (int)(cd.e - cd.s);
-  const int64_t q0 = cd.s - cd.ts;  // index of the chunk's first position inside the table (uniform bags: its sample)
-  const int step = gw * BWD_WAVES;  // lookups of one pass of the workgroup
-  for (int t0 = wv * gw; t0 < n; t0 += U * step) {  // (wave-uniform: the row update is wave-collective)
-    uint32_t row[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = t0 + u * step + gi;
-      row[u] = srow[(lane_on && idx < n) ? idx : n - 1];
-      if (!(lane_on && idx < n)) row[u] = BWD_SENT;
-    }
-    unsigned omask = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) omask |= row[u] != BWD_SENT ? 1u << u : 0u;
-    if (!__any(omask != 0)) continue;  // (wave-uniform) nothing alone here: a stretch of duplicates / of a heavy bucket
-    float4 g[U], w4[U], m4[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = min(t0 + u * step + gi, n - 1);
-      const int64_t q = q0 + idx;        // position inside the table
-      const int64_t i = fbase + q;       // lookup position (index into the KJT's values)
-      const int64_t rw = (omask >> u) & 1u ? (int64_t)row[u] : 0;
-      if (grad_mode == 1) {
-        g[u] = tzr_ldg4(reinterpret_cast<const float*>(sG[0].ptr) + i * sG[0].stride + 4 * c);
-      } else {
-        const int64_t bag = uniform ? i : (int64_t)P.bag_of[i];
-        const int64_t b = bag - key * B;
-        g[u] = bwd_bag_grad(one, offsets, weights, uniform, i, bag, b, c);
-      }
-      w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, rw * tb.w_stride + 4 * c);
-      m4[u] = bwd_load_state_all<ADAM>(tb, opt, rw, c);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t0 + u * step >= n) break;  // wave-uniform
-      const bool on = (omask >> u) & 1u;
-      bwd_apply_row<ADAM>(tb, opt, lr, on ? (int64_t)row[u] : 0, c, g[u], w4[u], m4[u], on, lg, c, lane);
-    }
-  }
-}
-
-// blocks [0, max_chunks): the sorted role, one unit each; [max_chunks, 2 max_chunks): the position-order role, one chunk each
-template <bool ADAM, int U>
-__device__ __forceinline__ void bwd_apply_roles(
-    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
-    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
-    int grad_mode, const BwdGrads& G, const BwdOpt& opt, int max_dim, const BwdPlan& P) {
-  if ((int64_t)blockIdx.x < P.max_chunks) {
-    bwd_reduce_body<ADAM>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
-    return;
-  }
-  bwd_solo_body<ADAM, U>(tables, feats, offsets, weights, B, uniform, grad_mode, G, opt, P, (int)((int64_t)blockIdx.x - P.max_chunks));
-}
-
 template <bool ADAM>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_reduce_kernel(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  bwd_apply_roles<ADAM, 2>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+  bwd_reduce_body<ADAM>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
 }
 
 // the same body compiled for 7 / 8 waves per SIMD (72 / 64 VGPRs); tzr_tune("bwd_apply_waves") = 6 | 7 | 8, 0 = 7
@@ -357,13 +266,13 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(7) void tzr_bwd_reduc
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  bwd_apply_roles<false, 2>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+  bwd_reduce_body<false>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
 }
 __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_reduce_w8_kernel(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {
-  bwd_apply_roles<false, 2>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
+  bwd_reduce_body<false>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);
 }
 int g_tzr_bwd_apply_waves = 0;
 
@@ -415,7 +324,7 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned chunks = (unsigned)P.max_chunks;
 #define TZR_REDUCE_LAUNCH(K)                                                                       \
-  hipLaunchKernelGGL(K, dim3(2 * chunks), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats, d_offsets, \
+  hipLaunchKernelGGL(K, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats, d_offsets, \
                      d_weights, B, (int)uniform, grad_mode, G, opt, max_dim, P)
   if (opt.kind == TZR_OPT_ADAM) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<true>));  // Adam holds two state rows per lane: no registers for a second tile

@@ -305,7 +305,7 @@ __device__ __forceinline__ float4 bwd_direct_row_sum(const BwdGeo& G, const TzrT
   const int c = lane - gi * lg;
   const bool lane_on = gi < gw;
   const bool single = tb.n_feats == 1;
-  const BwdSrc one = bwd_uni_src(bwd_resolve(feats + L.fbo[tb.first_order], L.sG));
+  const BwdSrc one = bwd_resolve(feats + L.fbo[tb.first_order], L.sG);
   float4 acc = tzr_zero4();
   constexpr int SR = 4;  // 1 024 positions per block: at most 1 024 <= BWD_UMAX matches
   BWD_DIRECT_FOR_SEGMENTS(G, A, tb, s0, s1, seg, sa, sb)

@@ -9,7 +9,6 @@ extern int g_tzr_bwd_force_prep;
 extern int g_tzr_bwd_ch;
 extern int g_tzr_bwd_one_wg_heavy;
 extern int g_tzr_bwd_debug;
-extern int g_tzr_bwd_solo;
 extern int g_tzr_bwd_apply_waves;
 extern int g_tzr_bwd_direct_ch;
 extern int g_tzr_bwd_direct;
@@ -96,11 +95,6 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "ia_bwd_wgs")) {
     g_tzr_ia_bwd_wgs = value;
-    return TZR_OK;
-  }
-  if (!strcmp(name, "bwd_solo")) {
-    if (value < 0) return TZR_ERR_INVALID;
-    g_tzr_bwd_solo = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_force_prep")) {
