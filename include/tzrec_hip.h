@@ -518,6 +518,34 @@ int tzr_segment_reduce_bwd(const float* d_grad_out, int64_t grad_out_stride,
                            const int64_t* d_offsets, int64_t S, int dim, int mode,
                            float* d_grad_values, int64_t grad_values_stride, void* stream);
 
+/* DIN target attention over JAGGED positions: replaces DINEncoder.forward on padded [B, L, .] tensors
+ * (tzrec/modules/sequence.py:101-128; the padding is SequenceEmbeddingGroupImpl's to_padded_dense,
+ * tzrec/modules/embedding.py:1429-1480).  A position is a row of the unpooled lookup's output [N, D]; sample b owns rows
+ * [offsets[b], offsets[b+1]); rows at index >= max_len inside a sample do not exist for the encoder (the padded length /
+ * `max_seq_length`).  csrc/din_attention.hip states the masking semantics.  D, H multiples of 4, strides in floats
+ * (multiples of 4), max_len <= 2048.
+ *   tzr_jagged_segment_ids  d_seg[n] = sample of row n (B for rows at or behind offsets[B])
+ *   tzr_din_assemble_fwd    X[n] = [ k_n | q_b * k_n | q_b ]  ([N, 3 D]): the input of the attention MLP whose first layer
+ *                           W [q, k, q - k, q * k] the caller folds into [Wb - Wc | Wd | Wa + Wc]
+ *   tzr_din_assemble_bwd    d_dkv[n] (+)= dX_n[0:D] + q_b * dX_n[D:2D];  d_dq[b] = sum_n (k_n * dX_n[D:2D] + dX_n[2D:3D])
+ *   tzr_din_attn_fwd        s_n = h_n . w + bias[0]; p = softmax of s over a sample's rows; out[b] = sum_n p_n k_n
+ *   tzr_din_attn_bwd        d_ds[n] = p_n (g_b . k_n - sum_m p_m g_b . k_m);  d_dkv[n] = p_n g_b
+ * (the backward of s = h . w + bias is tzr_head_bwd on d_ds) */
+int tzr_jagged_segment_ids(const int64_t* d_offsets, int64_t B, int64_t N, int32_t* d_seg, void* stream);
+int tzr_din_assemble_fwd(const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride,
+                         const int32_t* d_seg, int64_t B, int64_t N, int D, float* d_X, int64_t x_stride,
+                         void* stream);
+int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride,
+                         const float* d_q, int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets,
+                         int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
+                         float* d_dq, int64_t dq_stride, void* stream);
+int tzr_din_attn_fwd(const float* d_h, int64_t h_stride, int H, const float* d_w, const float* d_bias,
+                     const float* d_kv, int64_t kv_stride, int D, const int64_t* d_offsets, int64_t B,
+                     int64_t max_len, float* d_out, int64_t out_stride, float* d_p, void* stream);
+int tzr_din_attn_bwd(const float* d_grad_out, int64_t grad_out_stride, const float* d_p, const float* d_kv,
+                     int64_t kv_stride, int D, const int64_t* d_offsets, int64_t B, int64_t max_len, float* d_ds,
+                     float* d_dkv, int64_t dkv_stride, void* stream);
+
 /* ---- export ------------------------------------------------------------------------------ */
 
 /* Row-wise INT8 export of a table: replaces _quantize_quint8_rowwise_f16

@@ -1,6 +1,6 @@
 // Identity of the CPU lane-emulator build of the kernels (tests only).
 extern "C" const char* tzr_backend(void) { return "emu"; }
-extern "C" int tzr_abi_version(void) { return 8; }
+extern "C" int tzr_abi_version(void) { return 9; }
 
 // Context switch of the lane fibers (tests/emu/hip/hip_runtime.h): saves the callee-saved registers of
 // the System V x86-64 ABI on the current stack, stores that stack pointer, loads the other one.

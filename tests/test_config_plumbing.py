@@ -270,6 +270,7 @@ def test_static_sequence_padding_changes_shapes_not_results(dev):
         torch.manual_seed(0)
         model = build_rank_model(spec, device=dev)  # (a fresh model per mode: the backward below trains the tables)
         model.embedding_group.static_sequence_padding = static
+        model.embedding_group.jagged_sequence_groups.clear()  # (this test is about the PADDED form of the group; the default is the next test)
         L = model.embedding_group(batch)["seq.sequence"].shape[1]
         pred = model(batch)
         losses = model.loss(pred, batch)
@@ -279,6 +280,36 @@ def test_static_sequence_padding_changes_shapes_not_results(dev):
     torch.testing.assert_close(outs[True][1], outs[False][1], rtol=1e-6, atol=1e-6)
     for a_, b_ in zip(outs[True][2], outs[False][2]):
         torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-6)
+
+
+def test_multi_tower_din_on_jagged_positions_equals_the_padded_model(dev):
+    """multi_tower_din built from its config: the DIN tower takes the sequence group as rows of the unpooled lookup
+    (`EmbeddingGroup.jagged_sequence_groups`, the default: csrc/din_attention.hip) -- the same logits, dense gradients and
+    table updates as the reference's padded evaluation of the same model."""
+    emu_heavy(dev)
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "din_mini.config")).read())
+    batch = next(iter(_din_batches(spec, 6, 6, seed=4))).to(dev)  # (lengths 0 .. sequence_length + 2: empty and truncated histories)
+    outs = {}
+    for jagged in (True, False):
+        torch.manual_seed(0)
+        model = build_rank_model(spec, device=dev)
+        assert model.embedding_group.jagged_sequence_groups == {"seq"}
+        if not jagged:
+            model.embedding_group.jagged_sequence_groups.clear()
+        g = model.embedding_group(batch)
+        assert ("seq.sequence_jagged" in g) == jagged and ("seq.sequence" in g) != jagged
+        pred = model(batch)
+        sum(model.loss(pred, batch).values()).backward()
+        tables = {}
+        for _, col in [("ebc", model.embedding_group.ebc)] + [(d, ec._store) for d, ec in model.embedding_group.ecs.items()]:
+            tables.update({n: w.detach().cpu().clone() for n, w in col.table_weights().items()})
+        outs[jagged] = (pred["logits"].detach().cpu(), [p_.grad.detach().cpu().clone() for p_ in model.dense_parameters()], tables)
+    torch.testing.assert_close(outs[True][0], outs[False][0], rtol=1e-5, atol=1e-6)
+    for a_, b_ in zip(outs[True][1], outs[False][1]):
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=2e-6)
+    for n in outs[True][2]:
+        # (the first Adagrad step moves a weight by ~lr * sign(g): where a gradient element nearly cancels, its rounding shows)
+        torch.testing.assert_close(outs[True][2][n], outs[False][2][n], rtol=1e-5, atol=5e-6, msg=lambda m, n=n: f"table {n}: {m}")
 
 
 def test_mmoe_with_zch_config_to_training(dev):

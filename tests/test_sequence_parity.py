@@ -139,3 +139,56 @@ def test_din_first_layer_split_equals_the_literal_input():
             outs[split] = [o.detach().clone()] + [t.grad.clone() for t in list(enc.parameters()) + [emb["seq.query"], emb["seq.sequence"]]]
         for a_, b_ in zip(outs[True], outs[False]):
             torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", ["plain", "narrow_query", "truncated", "max_seq_length", "wide_hidden"])
+def test_din_jagged_positions_equal_the_padded_form(dev, case):
+    """DINEncoder.forward_jagged (csrc/din_attention.hip: the attention MLP on the rows of the unpooled lookup, softmax and
+    weighted sum per sample's rows) against the reference's evaluation on the padded [B, L, D] tensor with the literal
+    [q, k, q - k, q * k] input (/root/reference/tzrec/modules/sequence.py:101-128): output and EVERY gradient -- query, sequence
+    rows, all attention-MLP parameters, the score layer -- elementwise to 1e-5.  Samples without any position, with one,
+    with more than the padded length (truncated: rows behind it get zero gradient), `max_seq_length` below the padded
+    length, a query narrower than the sequence rows, hidden widths that are no multiple of 16."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(7)
+    D, qd, hidden, L, msl = 16, 16, [24, 8], 9, 0
+    if case == "narrow_query":
+        qd = 12
+    if case == "max_seq_length":
+        msl = 5
+    if case == "wide_hidden":
+        D, qd, hidden = 48, 48, [256, 64]
+    B = 23
+    lens = rng.integers(0, L + 1, size=B)
+    lens[[0, 7]] = 0
+    lens[3] = 1
+    if case == "truncated":
+        lens[[2, 11]] = [L + 4, L + 1]  # longer than the padded length
+    lens = lens.astype(np.int64)
+    N = int(lens.sum())
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.from_numpy(np.cumsum(lens))
+    enc = DINEncoder(D, qd, "seq", {"hidden_units": hidden}, max_seq_length=msl).to(dev)
+    q0, v0 = torch.randn(B, qd), torch.randn(N, D)
+    gw = torch.randn(B, D)
+    res = {}
+    for form in ("padded", "jagged"):
+        for p_ in enc.parameters():
+            p_.grad = None
+        q, v = q0.clone().to(dev).requires_grad_(True), v0.clone().to(dev).requires_grad_(True)
+        if form == "padded":
+            enc.split_first_layer = False
+            out = enc({"seq.query": q, "seq.sequence": jagged_to_padded_dense(v, off.to(dev), L),
+                       "seq.sequence_length": torch.from_numpy(lens).to(dev)})
+        else:
+            assert enc.jagged_capable()
+            out = enc({"seq.query": q, "seq.sequence_jagged": v, "seq.sequence_offsets": off.to(dev), "seq.sequence_max_len": L,
+                       "seq.sequence_length": torch.from_numpy(lens).to(dev)})
+        (out * gw.to(dev)).sum().backward()
+        res[form] = [out.detach().cpu(), q.grad.cpu(), v.grad.cpu()] + [p_.grad.detach().cpu().clone() for p_ in enc.parameters()]
+    names = ["out", "d query", "d sequence rows"] + [n for n, _ in enc.named_parameters()]
+    for n, a_, b_ in zip(names, res["jagged"], res["padded"]):
+        # (the score layer's bias gradient is sum_n ds_n = 0 exactly -- a softmax does not see a shift of its scores: both
+        # forms return rounding noise of the order of 1e-6 there)
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-5 if n == "linear.bias" else 2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    assert bool((res["jagged"][0][[0, 7]] == 0).all())  # no position: zero output (the reference: uniform weights over zero padding rows)

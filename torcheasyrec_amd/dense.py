@@ -98,8 +98,10 @@ def weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     (fixed order: deterministic) it takes 77 instead of 120 us at B = 65536 (scripts/gemm_variants.py, profiles/r03z)."""
     B = g.shape[0]
     S = 16
-    if B >= 16384 and B % S == 0 and g.is_contiguous() and x.is_contiguous():
-        return torch.bmm(g.view(S, B // S, g.shape[1]).transpose(1, 2), x.view(S, B // S, x.shape[1])).sum(0)
+    if B >= 16384 and g.is_contiguous() and x.is_contiguous():
+        Bm = B // S * S  # (a row count that is no multiple of 16 -- the jagged positions of a sequence batch: the rest as one more product)
+        out = torch.bmm(g[:Bm].view(S, Bm // S, g.shape[1]).transpose(1, 2), x[:Bm].view(S, Bm // S, x.shape[1])).sum(0)
+        return out if Bm == B else out + g[Bm:].t() @ x[Bm:]
     return g.t() @ x
 
 

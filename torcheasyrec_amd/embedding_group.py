@@ -278,6 +278,10 @@ class EmbeddingGroup(nn.Module):
         # pad sequence groups to their configured `sequence_length` (no device read-back of the batch's longest sequence: see
         # forward); off by default = the reference's shapes (tzrec/modules/embedding.py:1431-1446)
         self.static_sequence_padding = False
+        # sequence groups handed to their encoders as ROWS -- `<g>.sequence_jagged` [N, sum D_s], `<g>.sequence_offsets`
+        # [B + 1], `<g>.sequence_max_len` -- instead of the padded `<g>.sequence` [B, L, sum D_s]: set by the models whose
+        # encoders evaluate the jagged form (sequence.DINEncoder.forward_jagged); no padding position is computed
+        self.jagged_sequence_groups: set = set()
         by_dim: Dict[int, "OrderedDict[str, EmbeddingConfig]"] = {}
         seq_constraints: Dict[str, str] = {}
         for g in self._seq_groups:
@@ -369,6 +373,12 @@ class EmbeddingGroup(nn.Module):
                 out[f"{g}.query"] = torch.cat(qs, dim=1)
             first = jts[info["sequence"][0].name]
             lens = first.lengths().to(torch.int64)
+            if g in self.jagged_sequence_groups:
+                out[f"{g}.sequence_length"] = lens
+                out[f"{g}.sequence_jagged"] = torch.cat([jts[f.name].values() for f in info["sequence"]], dim=1)
+                out[f"{g}.sequence_offsets"] = first.offsets()
+                out[f"{g}.sequence_max_len"] = info["max_len"] or 2048  # (the padded length the reference would have used, at most)
+                continue
             if self.static_sequence_padding and info["max_len"]:
                 # pad to the configured sequence_length instead of the batch's longest sequence: no host sync (the step can be
                 # captured in a hipGraph) and one shape for every batch; the positions behind a sample's length are masked by

@@ -162,6 +162,9 @@ class ConfigDeepFM(RankModel):
         return self._output_to_prediction(y)
 
 
+JAGGED_DIN = True  # multi_tower_din: DIN towers on the jagged positions (False: the reference's padded tensors)
+
+
 class ConfigMultiTowerDIN(RankModel):
     """`multi_tower_din {...}` (tzrec/models/multi_tower_din.py:36-111): one MLP tower per DEEP group,
     one DIN target-attention tower per SEQUENCE group, concatenated, optional final MLP, logits layer."""
@@ -185,6 +188,13 @@ class ConfigMultiTowerDIN(RankModel):
                              attn_mlp={"hidden_units": [int(x) for x in tower.one("attn_mlp").many("hidden_units")]})
             self.din_towers.append(din)
             total += din.output_dim()
+            # the tower takes the group's sequences as rows of the unpooled lookup (no padding) when its attention MLP is
+            # the plain Linear + ReLU stack and the group's sequence features come from ONE sequence_feature block (one
+            # set of lengths): csrc/din_attention.hip
+            info = eg._seq_info.get(g) if hasattr(eg, "_seq_info") else None
+            if JAGGED_DIN and info is not None and din.jagged_capable() and len({f.name.split("__")[0] for f in info["sequence"]}) == 1 \
+                    and not any(getattr(f, "value_dim", 1) not in (0, 1) for f in info["sequence"]):
+                eg.jagged_sequence_groups.add(g)
         self.final_mlp = None
         if m.has("final"):
             self.final_mlp = mlp_from_msg(total, m.one("final"))

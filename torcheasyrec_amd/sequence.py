@@ -315,9 +315,102 @@ class ShardedEmbeddingCollection(nn.Module):
         return out
 
 
+# ---- DIN target attention on the jagged positions (csrc/din_attention.hip) -------------------------------------------
+def jagged_segment_ids(offsets: torch.Tensor, n: int) -> torch.Tensor:
+    """sample of every row of a jagged [n, .] tensor (int32 [n]); rows at or behind offsets[-1] get B"""
+    seg = torch.empty(max(n, 1), dtype=torch.int32, device=offsets.device)
+    _lib.check(_lib.lib().tzr_jagged_segment_ids(_lib.ptr(offsets), offsets.numel() - 1, n, _lib.ptr(seg), _lib.stream_ptr(offsets.device)),
+               "tzr_jagged_segment_ids")
+    return seg[:n]
+
+
+class _DinAssembleFn(torch.autograd.Function):
+    """X[n] = [k_n | q_b * k_n | q_b] for every position n of sample b: the input of the attention MLP with its first layer
+    folded to three blocks (DINEncoder._folded_first_layer)."""
+
+    @staticmethod
+    def forward(ctx, kv, q, seg, offsets):
+        kv, q = kv.contiguous(), q.contiguous()
+        N, D = kv.shape
+        X = torch.empty(max(N, 1), 3 * D, dtype=torch.float32, device=kv.device)
+        _lib.check(_lib.lib().tzr_din_assemble_fwd(_lib.ptr(kv), kv.stride(0), _lib.ptr(q), q.stride(0), _lib.ptr(seg), q.shape[0], N, D,
+                                                   _lib.ptr(X), X.stride(0), _lib.stream_ptr(kv.device)), "tzr_din_assemble_fwd")
+        ctx.save_for_backward(kv, q, seg, offsets)
+        return X[:N]
+
+    @staticmethod
+    def backward(ctx, gX):
+        kv, q, seg, offsets = ctx.saved_tensors
+        N, D = kv.shape
+        B = q.shape[0]
+        gX = gX.contiguous()
+        dkv = torch.empty(max(N, 1), D, dtype=torch.float32, device=kv.device)
+        dq = torch.empty(max(B, 1), D, dtype=torch.float32, device=kv.device)
+        _lib.check(_lib.lib().tzr_din_assemble_bwd(_lib.ptr(gX), gX.stride(0) if N else 3 * D, _lib.ptr(kv), kv.stride(0), _lib.ptr(q), q.stride(0),
+                                                   _lib.ptr(seg), _lib.ptr(offsets), B, N, D, _lib.ptr(dkv), dkv.stride(0), 0,
+                                                   _lib.ptr(dq), dq.stride(0), _lib.stream_ptr(kv.device)), "tzr_din_assemble_bwd")
+        return dkv[:N], dq[:B], None, None
+
+
+class _DinAttnFn(torch.autograd.Function):
+    """scores s_n = h_n . w + b, softmax over every sample's positions, out_b = sum_n p_n k_n (tzr_din_attn_fwd / _bwd); the
+    backward of the one-unit score layer is tzr_head_bwd (dense.head_bwd), as for the logits layer of the rank models."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias, kv, offsets, max_len):
+        h, kv = h.contiguous(), kv.contiguous()
+        N, H = h.shape
+        D = kv.shape[1]
+        B = offsets.numel() - 1
+        w1 = w.reshape(-1).contiguous()
+        out = torch.empty(max(B, 1), D, dtype=torch.float32, device=h.device)
+        p = torch.empty(max(N, 1), dtype=torch.float32, device=h.device)
+        _lib.check(_lib.lib().tzr_din_attn_fwd(_lib.ptr(h), h.stride(0) if N else H, H, _lib.ptr(w1), _lib.ptr(bias), _lib.ptr(kv),
+                                               kv.stride(0) if N else D, D, _lib.ptr(offsets), B, max_len, _lib.ptr(out), out.stride(0),
+                                               _lib.ptr(p), _lib.stream_ptr(h.device)), "tzr_din_attn_fwd")
+        ctx.save_for_backward(h, w, kv, offsets, p)
+        ctx.max_len = max_len
+        ctx.has_bias = bias is not None
+        return out[:B]
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .dense import head_bwd
+
+        h, w, kv, offsets, p = ctx.saved_tensors
+        N, H = h.shape
+        D = kv.shape[1]
+        B = offsets.numel() - 1
+        gout = gout.contiguous()
+        ds = torch.empty(max(N, 1), dtype=torch.float32, device=h.device)
+        dkv = torch.empty(max(N, 1), D, dtype=torch.float32, device=h.device)
+        _lib.check(_lib.lib().tzr_din_attn_bwd(_lib.ptr(gout), gout.stride(0) if B else D, _lib.ptr(p), _lib.ptr(kv), kv.stride(0) if N else D, D,
+                                               _lib.ptr(offsets), B, ctx.max_len, _lib.ptr(ds), _lib.ptr(dkv), dkv.stride(0),
+                                               _lib.stream_ptr(h.device)), "tzr_din_attn_bwd")
+        if N and H % 4 == 0 and H <= 1024:
+            dh, dw, db = head_bwd(ds[:N], h, w, ctx.needs_input_grad[0])
+        else:
+            dsn = ds[:N]
+            dh = dsn.unsqueeze(1) * w.reshape(1, -1) if ctx.needs_input_grad[0] else None
+            dw, db = (h * dsn.unsqueeze(1)).sum(0, keepdim=True), dsn.sum().reshape(1)
+        return dh, dw.reshape(w.shape), (db if ctx.has_bias else None), dkv[:N], None, None
+
+
+def din_attention_jagged(h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], kv: torch.Tensor,
+                         offsets: torch.Tensor, max_len: int) -> torch.Tensor:
+    return _DinAttnFn.apply(h, weight, bias, kv, offsets, int(max_len))
+
+
+DIN_JAGGED_MAX_LEN = 2048  # (DA_MAXLEN of csrc/din_attention.hip: scores of one sample kept in LDS)
+
+
 class DINEncoder(nn.Module):
     """DIN target attention (same constructor/forward contract as the reference's DINEncoder,
-    tzrec/modules/sequence.py:65-128): scores = MLP([q, k, q-k, q*k]) -> masked softmax -> sum."""
+    tzrec/modules/sequence.py:65-128): scores = MLP([q, k, q-k, q*k]) -> masked softmax -> sum.
+
+    Two evaluations of the same function: on the PADDED `<input>.sequence` [B, L, D] (the reference's tensors), or -- when the
+    embedding group hands over `<input>.sequence_jagged` ([N, D] rows of the unpooled lookup) and `<input>.sequence_offsets`
+    -- on the jagged positions (`forward_jagged`): no padding position is ever computed (csrc/din_attention.hip)."""
 
     def __init__(self, sequence_dim: int, query_dim: int, input: str, attn_mlp: Dict[str, object], max_seq_length: int = 0) -> None:
         super().__init__()
@@ -334,7 +427,41 @@ class DINEncoder(nn.Module):
     def output_dim(self) -> int:
         return self._sequence_dim
 
+    def jagged_capable(self) -> bool:
+        """plain Linear + bias + ReLU layers (the reference's defaults): what `forward_jagged` evaluates"""
+        return bool(getattr(self.mlp, "_plain", False)) and self._sequence_dim % 4 == 0
+
+    def _folded_first_layer(self) -> torch.Tensor:
+        """W [q, k, q - k, q * k] = (Wb - Wc) k + Wd (q * k) + (Wa + Wc) q  ->  [Wb - Wc | Wd | Wa + Wc]  ([H, 3 D])"""
+        D = self._sequence_dim
+        W = self.mlp.mlp[0].weight
+        return torch.cat([W[:, D:2 * D] - W[:, 2 * D:3 * D], W[:, 3 * D:], W[:, :D] + W[:, 2 * D:3 * D]], dim=1)
+
+    def forward_jagged(self, query: torch.Tensor, values: torch.Tensor, offsets: torch.Tensor, max_len: int) -> torch.Tensor:
+        """query [B, query_dim]; values [N, D]: the rows of all samples' sequences, sample b = rows [offsets[b], offsets[b+1]);
+        max_len: positions at index >= max_len inside a sample do not take part (the padded length of the reference's
+        `sequence` tensor; `max_seq_length` is applied on top).  Same output and gradients as `forward` on the padded form."""
+        from .dlrm import _LinearReluFn
+
+        if self._max_seq_length > 0:
+            max_len = min(max_len, self._max_seq_length)
+        if self._query_dim < self._sequence_dim:
+            query = nn.functional.pad(query, (0, self._sequence_dim - self._query_dim))
+        N = values.shape[0]
+        seg = jagged_segment_ids(offsets, N)
+        x = _DinAssembleFn.apply(values, query, seg, offsets)
+        lin = self.mlp.linears()
+        fused = x.is_cuda
+        for i, m in enumerate(lin):
+            w = self._folded_first_layer() if i == 0 else m.weight
+            x = _LinearReluFn.apply(x, w, m.bias) if fused else torch.relu(nn.functional.linear(x, w, m.bias))
+        return din_attention_jagged(x, self.linear.weight, self.linear.bias, values, offsets, max_len)
+
     def forward(self, sequence_embedded: Dict[str, torch.Tensor]) -> torch.Tensor:
+        jag = sequence_embedded.get(self._sequence_name + "_jagged")
+        if jag is not None:
+            return self.forward_jagged(sequence_embedded[self._query_name], jag, sequence_embedded[self._sequence_name + "_offsets"],
+                                       int(sequence_embedded[self._sequence_name + "_max_len"]))
         query = sequence_embedded[self._query_name]
         sequence = sequence_embedded[self._sequence_name]
         sequence_length = sequence_embedded[self._sequence_length_name]
