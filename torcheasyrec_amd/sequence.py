@@ -324,81 +324,99 @@ def jagged_segment_ids(offsets: torch.Tensor, n: int) -> torch.Tensor:
     return seg[:n]
 
 
-class _DinAssembleFn(torch.autograd.Function):
-    """X[n] = [k_n | q_b * k_n | q_b] for every position n of sample b: the input of the attention MLP with its first layer
-    folded to three blocks (DINEncoder._folded_first_layer)."""
+class _DinTowerFn(torch.autograd.Function):
+    """The whole DIN tower on the jagged positions as ONE autograd node:
+
+        X = [k | q * k | q]  (tzr_din_assemble_fwd)  ->  relu(X W1'^T + b1) -> ... -> h  (one GEMM per layer, ReLU in its epilogue)
+        -> s = h . w + b, softmax over every sample's rows, out_b = sum_n p_n k_n  (tzr_din_attn_fwd)
+
+    and its backward spelled out: tzr_din_attn_bwd -> tzr_head_bwd (the one-unit score layer) -> per layer ReLU mask + bias
+    gradient in one pass (tzr_relu_bwd_colsum), weight gradient as 16 batched products + sum (dense.weight_grad), input
+    gradient -> tzr_din_assemble_bwd, which ADDS the attention's direct part of the rows' gradient.  One node instead of a
+    graph of them: no gradient-accumulation adds, no zero fills, no contiguous copies between the pieces; X is rebuilt in
+    the backward rather than kept (57 us against 260 MB at 450 k positions).  `wb` = (W1, b1, W2, b2, ...) with W1 the
+    reference's [H, 4 D] first layer: folded to three blocks here, its gradient unfolded."""
 
     @staticmethod
-    def forward(ctx, kv, q, seg, offsets):
-        kv, q = kv.contiguous(), q.contiguous()
-        N, D = kv.shape
-        X = torch.empty(max(N, 1), 3 * D, dtype=torch.float32, device=kv.device)
-        _lib.check(_lib.lib().tzr_din_assemble_fwd(_lib.ptr(kv), kv.stride(0), _lib.ptr(q), q.stride(0), _lib.ptr(seg), q.shape[0], N, D,
-                                                   _lib.ptr(X), X.stride(0), _lib.stream_ptr(kv.device)), "tzr_din_assemble_fwd")
-        ctx.save_for_backward(kv, q, seg, offsets)
-        return X[:N]
-
-    @staticmethod
-    def backward(ctx, gX):
-        kv, q, seg, offsets = ctx.saved_tensors
-        N, D = kv.shape
-        B = q.shape[0]
-        gX = gX.contiguous()
-        dkv = torch.empty(max(N, 1), D, dtype=torch.float32, device=kv.device)
-        dq = torch.empty(max(B, 1), D, dtype=torch.float32, device=kv.device)
-        _lib.check(_lib.lib().tzr_din_assemble_bwd(_lib.ptr(gX), gX.stride(0) if N else 3 * D, _lib.ptr(kv), kv.stride(0), _lib.ptr(q), q.stride(0),
-                                                   _lib.ptr(seg), _lib.ptr(offsets), B, N, D, _lib.ptr(dkv), dkv.stride(0), 0,
-                                                   _lib.ptr(dq), dq.stride(0), _lib.stream_ptr(kv.device)), "tzr_din_assemble_bwd")
-        return dkv[:N], dq[:B], None, None
-
-
-class _DinAttnFn(torch.autograd.Function):
-    """scores s_n = h_n . w + b, softmax over every sample's positions, out_b = sum_n p_n k_n (tzr_din_attn_fwd / _bwd); the
-    backward of the one-unit score layer is tzr_head_bwd (dense.head_bwd), as for the logits layer of the rank models."""
-
-    @staticmethod
-    def forward(ctx, h, w, bias, kv, offsets, max_len):
-        h, kv = h.contiguous(), kv.contiguous()
-        N, H = h.shape
-        D = kv.shape[1]
+    def forward(ctx, values, query, offsets, max_len, row_bucket, w3, b3, *wb):
+        values, query = values.contiguous(), query.contiguous()
+        N, D = values.shape
         B = offsets.numel() - 1
-        w1 = w.reshape(-1).contiguous()
-        out = torch.empty(max(B, 1), D, dtype=torch.float32, device=h.device)
-        p = torch.empty(max(N, 1), dtype=torch.float32, device=h.device)
-        _lib.check(_lib.lib().tzr_din_attn_fwd(_lib.ptr(h), h.stride(0) if N else H, H, _lib.ptr(w1), _lib.ptr(bias), _lib.ptr(kv),
-                                               kv.stride(0) if N else D, D, _lib.ptr(offsets), B, max_len, _lib.ptr(out), out.stride(0),
-                                               _lib.ptr(p), _lib.stream_ptr(h.device)), "tzr_din_attn_fwd")
-        ctx.save_for_backward(h, w, kv, offsets, p)
-        ctx.max_len = max_len
-        ctx.has_bias = bias is not None
+        dev = values.device
+        L = _lib.lib()
+        stream = _lib.stream_ptr(dev)
+        Np = (N + row_bucket - 1) // row_bucket * row_bucket
+        seg = jagged_segment_ids(offsets, Np)
+        X = torch.empty(max(Np, 1), 3 * D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_assemble_fwd(_lib.ptr(values), values.stride(0), _lib.ptr(query), query.stride(0), _lib.ptr(seg), B, Np, D,
+                                          _lib.ptr(X), X.stride(0), stream), "tzr_din_assemble_fwd")
+        Ws = [w.detach() for w in wb[0::2]]
+        bs = [b_.detach() for b_ in wb[1::2]]
+        W1 = Ws[0]
+        Ws[0] = torch.cat([W1[:, D:2 * D] - W1[:, 2 * D:3 * D], W1[:, 3 * D:], W1[:, :D] + W1[:, 2 * D:3 * D]], dim=1)
+        x, hs = X[:Np], []
+        for w, b_ in zip(Ws, bs):
+            x = torch._addmm_activation(b_, x, w.t(), use_gelu=False) if x.is_cuda else torch.relu(torch.nn.functional.linear(x, w, b_))
+            hs.append(x)
+        H = x.shape[1]
+        w3v = w3.detach().reshape(-1).contiguous()
+        out = torch.empty(max(B, 1), D, dtype=torch.float32, device=dev)
+        p = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_attn_fwd(_lib.ptr(x), x.stride(0) if Np else H, H, _lib.ptr(w3v), _lib.ptr(b3), _lib.ptr(values),
+                                      values.stride(0) if N else D, D, _lib.ptr(offsets), B, max_len, _lib.ptr(out), out.stride(0),
+                                      _lib.ptr(p), stream), "tzr_din_attn_fwd")
+        ctx.save_for_backward(values, query, offsets, seg, p, w3, *Ws, *hs)
+        ctx.cfg = (max_len, len(Ws), b3 is not None)
         return out[:B]
 
     @staticmethod
     def backward(ctx, gout):
-        from .dense import head_bwd
+        from .dense import head_bwd, relu_bwd_colsum, weight_grad
 
-        h, w, kv, offsets, p = ctx.saved_tensors
-        N, H = h.shape
-        D = kv.shape[1]
-        B = offsets.numel() - 1
+        max_len, nl, has_b3 = ctx.cfg
+        values, query, offsets, seg, p, w3 = ctx.saved_tensors[:6]
+        Ws, hs = ctx.saved_tensors[6:6 + nl], ctx.saved_tensors[6 + nl:]
+        N, D = values.shape
+        B, Np = offsets.numel() - 1, seg.numel()
+        dev = values.device
+        L = _lib.lib()
+        stream = _lib.stream_ptr(dev)
         gout = gout.contiguous()
-        ds = torch.empty(max(N, 1), dtype=torch.float32, device=h.device)
-        dkv = torch.empty(max(N, 1), D, dtype=torch.float32, device=h.device)
-        _lib.check(_lib.lib().tzr_din_attn_bwd(_lib.ptr(gout), gout.stride(0) if B else D, _lib.ptr(p), _lib.ptr(kv), kv.stride(0) if N else D, D,
-                                               _lib.ptr(offsets), B, ctx.max_len, _lib.ptr(ds), _lib.ptr(dkv), dkv.stride(0),
-                                               _lib.stream_ptr(h.device)), "tzr_din_attn_bwd")
-        if N and H % 4 == 0 and H <= 1024:
-            dh, dw, db = head_bwd(ds[:N], h, w, ctx.needs_input_grad[0])
+        ds = torch.empty(max(Np, 1), dtype=torch.float32, device=dev) if Np == N else torch.zeros(Np, dtype=torch.float32, device=dev)
+        dkv = torch.empty(max(Np, 1), D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_attn_bwd(_lib.ptr(gout), gout.stride(0) if B else D, _lib.ptr(p), _lib.ptr(values), values.stride(0) if N else D, D,
+                                      _lib.ptr(offsets), B, max_len, _lib.ptr(ds), _lib.ptr(dkv), dkv.stride(0), stream), "tzr_din_attn_bwd")
+        h = hs[-1]
+        H = h.shape[1]
+        if Np and H % 4 == 0 and H <= 1024:
+            dh, dw3, db3 = head_bwd(ds[:Np], h, w3, True)
         else:
-            dsn = ds[:N]
-            dh = dsn.unsqueeze(1) * w.reshape(1, -1) if ctx.needs_input_grad[0] else None
-            dw, db = (h * dsn.unsqueeze(1)).sum(0, keepdim=True), dsn.sum().reshape(1)
-        return dh, dw.reshape(w.shape), (db if ctx.has_bias else None), dkv[:N], None, None
-
-
-def din_attention_jagged(h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], kv: torch.Tensor,
-                         offsets: torch.Tensor, max_len: int) -> torch.Tensor:
-    return _DinAttnFn.apply(h, weight, bias, kv, offsets, int(max_len))
+            dsn = ds[:Np]
+            dh, dw3, db3 = dsn.unsqueeze(1) * w3.reshape(1, -1), (h * dsn.unsqueeze(1)).sum(0, keepdim=True), dsn.sum().reshape(1)
+        # X again (not kept from the forward)
+        X = torch.empty(max(Np, 1), 3 * D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_assemble_fwd(_lib.ptr(values), values.stride(0), _lib.ptr(query), query.stride(0), _lib.ptr(seg), B, Np, D,
+                                          _lib.ptr(X), X.stride(0), stream), "tzr_din_assemble_fwd")
+        grads_wb = [None] * (2 * nl)
+        for i in range(nl - 1, -1, -1):
+            y = hs[i]
+            if Np and y.shape[1] % 4 == 0 and y.shape[1] <= 1024:
+                g, gb = relu_bwd_colsum(dh, y)
+            else:
+                g = torch.ops.aten.threshold_backward(dh, y, 0.0)
+                gb = g.sum(0)
+            xin = hs[i - 1] if i > 0 else X[:Np]
+            grads_wb[2 * i] = weight_grad(g, xin) if Np else torch.zeros_like(Ws[i])
+            grads_wb[2 * i + 1] = gb
+            dh = g @ Ws[i]
+        dWf = grads_wb[0]  # [H1, 3 D] = [d(Wb - Wc) | dWd | d(Wa + Wc)]  ->  [dWa | dWb | dWc | dWd]
+        grads_wb[0] = torch.cat([dWf[:, 2 * D:], dWf[:, :D], dWf[:, 2 * D:] - dWf[:, :D], dWf[:, D:2 * D]], dim=1)
+        dX = dh.contiguous()
+        dq = torch.empty(max(B, 1), D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_assemble_bwd(_lib.ptr(dX), dX.stride(0) if Np else 3 * D, _lib.ptr(values), values.stride(0), _lib.ptr(query),
+                                          query.stride(0), _lib.ptr(seg), _lib.ptr(offsets), B, Np, D, _lib.ptr(dkv), dkv.stride(0), 1,
+                                          _lib.ptr(dq), dq.stride(0), stream), "tzr_din_assemble_bwd")
+        return (dkv[:N], dq[:B], None, None, None, dw3.reshape(w3.shape), (db3 if has_b3 else None), *grads_wb)
 
 
 DIN_JAGGED_MAX_LEN = 2048  # (DA_MAXLEN of csrc/din_attention.hip: scores of one sample kept in LDS)
@@ -423,6 +441,7 @@ class DINEncoder(nn.Module):
         self._sequence_name = f"{input}.sequence"
         self._sequence_length_name = f"{input}.sequence_length"
         self.split_first_layer = True  # see forward; False = the reference's literal [q, k, q - k, q * k] input
+        self.row_bucket = None  # forward_jagged: rows of the attention MLP's input = N rounded up to a multiple of this (None: 16384 on a GPU, 1 elsewhere)
 
     def output_dim(self) -> int:
         return self._sequence_dim
@@ -441,21 +460,19 @@ class DINEncoder(nn.Module):
         """query [B, query_dim]; values [N, D]: the rows of all samples' sequences, sample b = rows [offsets[b], offsets[b+1]);
         max_len: positions at index >= max_len inside a sample do not take part (the padded length of the reference's
         `sequence` tensor; `max_seq_length` is applied on top).  Same output and gradients as `forward` on the padded form."""
-        from .dlrm import _LinearReluFn
 
         if self._max_seq_length > 0:
             max_len = min(max_len, self._max_seq_length)
         if self._query_dim < self._sequence_dim:
             query = nn.functional.pad(query, (0, self._sequence_dim - self._query_dim))
-        N = values.shape[0]
-        seg = jagged_segment_ids(offsets, N)
-        x = _DinAssembleFn.apply(values, query, seg, offsets)
-        lin = self.mlp.linears()
-        fused = x.is_cuda
-        for i, m in enumerate(lin):
-            w = self._folded_first_layer() if i == 0 else m.weight
-            x = _LinearReluFn.apply(x, w, m.bias) if fused else torch.relu(nn.functional.linear(x, w, m.bias))
-        return din_attention_jagged(x, self.linear.weight, self.linear.bias, values, offsets, max_len)
+        # the attention MLP runs on Np >= N rows, N rounded up to `row_bucket`: a GEMM library tunes (and TunableOp keys) its
+        # kernels by exact shape, and every batch has its own N -- with buckets a handful of shapes serve them all; the
+        # rows behind N are zero inputs whose outputs nothing reads and whose gradients are zero
+        rb = max(int(self.row_bucket), 1) if self.row_bucket is not None else (16384 if values.is_cuda else 1)
+        wb = []
+        for m in self.mlp.linears():
+            wb += [m.weight, m.bias]
+        return _DinTowerFn.apply(values, query, offsets, int(max_len), rb, self.linear.weight, self.linear.bias, *wb)
 
     def forward(self, sequence_embedded: Dict[str, torch.Tensor]) -> torch.Tensor:
         jag = sequence_embedded.get(self._sequence_name + "_jagged")
