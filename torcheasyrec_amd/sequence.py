@@ -231,12 +231,13 @@ class EmbeddingCollection(nn.Module):
         B = features.stride()
         off, lens = features.offsets(), features.lengths()
         lpk = features.length_per_key()
-        out, start = {}, 0
+        # (one split, not a slice per key: the backward of a slice is a zero tensor of ALL rows plus an add into the sum of
+        # the others -- eight 90 MB fills and adds per multi_tower_din step; the backward of a split is one concatenation)
+        segs = torch.split(rows, [int(n) for n in lpk], dim=0)
+        out = {}
         for i, k in enumerate(features.keys()):
-            seg = rows[start:start + lpk[i]]
             o = off[i * B:(i + 1) * B + 1] - off[i * B]
-            out[k] = JaggedTensor(seg, lens[i * B:(i + 1) * B], o)
-            start += lpk[i]
+            out[k] = JaggedTensor(segs[i], lens[i * B:(i + 1) * B], o)
         return out
 
 
@@ -333,8 +334,7 @@ class _DinTowerFn(torch.autograd.Function):
     and its backward spelled out: tzr_din_attn_bwd -> tzr_head_bwd (the one-unit score layer) -> per layer ReLU mask + bias
     gradient in one pass (tzr_relu_bwd_colsum), weight gradient as 16 batched products + sum (dense.weight_grad), input
     gradient -> tzr_din_assemble_bwd, which ADDS the attention's direct part of the rows' gradient.  One node instead of a
-    graph of them: no gradient-accumulation adds, no zero fills, no contiguous copies between the pieces; X is rebuilt in
-    the backward rather than kept (57 us against 260 MB at 450 k positions).  `wb` = (W1, b1, W2, b2, ...) with W1 the
+    graph of them: no gradient-accumulation adds, no zero fills, no contiguous copies between the pieces.  `wb` = (W1, b1, W2, b2, ...) with W1 the
     reference's [H, 4 D] first layer: folded to three blocks here, its gradient unfolded."""
 
     @staticmethod
@@ -365,7 +365,7 @@ class _DinTowerFn(torch.autograd.Function):
         _lib.check(L.tzr_din_attn_fwd(_lib.ptr(x), x.stride(0) if Np else H, H, _lib.ptr(w3v), _lib.ptr(b3), _lib.ptr(values),
                                       values.stride(0) if N else D, D, _lib.ptr(offsets), B, max_len, _lib.ptr(out), out.stride(0),
                                       _lib.ptr(p), stream), "tzr_din_attn_fwd")
-        ctx.save_for_backward(values, query, offsets, seg, p, w3, *Ws, *hs)
+        ctx.save_for_backward(values, query, offsets, seg, p, w3, X, *Ws, *hs)
         ctx.cfg = (max_len, len(Ws), b3 is not None)
         return out[:B]
 
@@ -374,8 +374,8 @@ class _DinTowerFn(torch.autograd.Function):
         from .dense import head_bwd, relu_bwd_colsum, weight_grad
 
         max_len, nl, has_b3 = ctx.cfg
-        values, query, offsets, seg, p, w3 = ctx.saved_tensors[:6]
-        Ws, hs = ctx.saved_tensors[6:6 + nl], ctx.saved_tensors[6 + nl:]
+        values, query, offsets, seg, p, w3, X = ctx.saved_tensors[:7]
+        Ws, hs = ctx.saved_tensors[7:7 + nl], ctx.saved_tensors[7 + nl:]
         N, D = values.shape
         B, Np = offsets.numel() - 1, seg.numel()
         dev = values.device
@@ -393,10 +393,6 @@ class _DinTowerFn(torch.autograd.Function):
         else:
             dsn = ds[:Np]
             dh, dw3, db3 = dsn.unsqueeze(1) * w3.reshape(1, -1), (h * dsn.unsqueeze(1)).sum(0, keepdim=True), dsn.sum().reshape(1)
-        # X again (not kept from the forward)
-        X = torch.empty(max(Np, 1), 3 * D, dtype=torch.float32, device=dev)
-        _lib.check(L.tzr_din_assemble_fwd(_lib.ptr(values), values.stride(0), _lib.ptr(query), query.stride(0), _lib.ptr(seg), B, Np, D,
-                                          _lib.ptr(X), X.stride(0), stream), "tzr_din_assemble_fwd")
         grads_wb = [None] * (2 * nl)
         for i in range(nl - 1, -1, -1):
             y = hs[i]
