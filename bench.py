@@ -150,7 +150,7 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
     DeepFM-Criteo (configs[0]'s model on the GPU), multi_tower_din on the Taobao features with a 100-step click sequence
     (configs[3]), MMoE with the user id behind a 200 M-row zero-collision hash, LFU (configs[4]).  One GPU, inputs resident,
     fused sparse Adagrad + dense Adam, nothing skipped.  Eager launches (`ms_per_step`), and the same step replayed from a
-    hipGraph where the step is capturable (`graph_ms_per_step`; the ZCH step keeps host-side candidate lists: eager only)."""
+    hipGraph (`graph_ms_per_step`; the ZCH step in ring mode: device iteration counter + candidate ring, zch.py)."""
     from torcheasyrec_amd import example_configs as ec
     from torcheasyrec_amd.config import load_pipeline_spec
     from torcheasyrec_amd.dense import FusedDenseAdam
@@ -193,6 +193,9 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
         B = spec.batch_size
         torch.manual_seed(7)
         model = build_rank_model(spec, device=dev)
+        mc_ = getattr(model.embedding_group, "mc", None)
+        if mc_ is not None and capturable:  # ring mode: device iteration counter + candidate ring, the step can be captured (zch.py)
+            mc_.device_profile = True
         opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
         bs = batches(spec, B, 4, 11, raw_id_feature)
         n_ids = int(np.mean([b.sparse_features[BASE_DATA_GROUP].values().numel() for b in bs]))
@@ -231,12 +234,16 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
                         step(b)
                     pool = g.pool()
                     gs.append(g)
+                from torcheasyrec_amd.embedding_group import after_graph_replay
+
                 for i in range(4):
                     gs[i].replay()
+                    after_graph_replay(model)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(steps):
                     gs[i % 4].replay()
+                    after_graph_replay(model)  # (a zero-collision hash counts the step; its rounds run between replays when due)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
                 out.update(graph_ms_per_step=el / steps * 1e3, graph_value=B * steps / el)
@@ -268,7 +275,7 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
             ("din_taobao_b8192", ec.multi_tower_din_taobao, "multi_tower_din on the Taobao features (examples/multi_tower_din_taobao.config: 100-step "
              "click sequence, DIN attention {256,64}), batch 8192, histories of 10..100 clicks", {}),
             ("mmoe_zch_b8192", ec.mmoe_taobao_zch, "MMoE (3 experts, ctr + cvr towers) with user_id behind a 200M-row zero-collision hash, LFU "
-             "(BASELINE.json configs[4]), batch 8192, raw 64-bit Zipf user ids", {"raw_id_feature": "user_id", "capturable": False})):
+             "(BASELINE.json configs[4]), batch 8192, raw 64-bit Zipf user ids", {"raw_id_feature": "user_id"})):
         if only is not None and key not in only:
             continue
         try:

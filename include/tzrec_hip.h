@@ -432,6 +432,16 @@ int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key_module, in
                   int64_t n_values, int64_t iter, int profile, int64_t* d_out_values,
                   int64_t* d_candidates, void* stream);
 
+/* The same for a step that is replayed from a hipGraph: uniform bags only; the iteration number is read from DEVICE memory
+ * (*d_iter: the caller bumps it inside the graph), and with profile != 0 the candidates of the step go to slot
+ * `*d_iter % ring_slots` of d_cand_ring, int64 [ring_slots][n_cand_keys][B * uniform_bag_len]: one block per key that has
+ * a module (d_key_cand[key] = its index among those keys, -1 for the others), the raw id where it has no row yet,
+ * TZR_ZCH_EMPTY elsewhere.  Which step filled which slot is a function of the counter alone. */
+int tzr_zch_remap_ring(const TzrZchModule* d_modules, const int32_t* d_key_module, int n_keys,
+                       const int64_t* d_values, int64_t B, int uniform_bag_len, int64_t n_values,
+                       const int64_t* d_iter, int profile, int64_t* d_out_values, const int32_t* d_key_cand,
+                       int n_cand_keys, int64_t* d_cand_ring, int64_t ring_slots, void* stream);
+
 /* Rebuild a module's map from n distinct (raw id, row) pairs (after admission / eviction, or when
  * restoring a checkpoint).  h_module is a HOST struct holding device pointers. */
 int tzr_zch_build(const TzrZchModule* h_module, const int64_t* d_ids, const int32_t* d_rows,

@@ -209,3 +209,69 @@ def test_sequence_model_step_is_capturable_with_static_padding():
                           + [p.detach().clone() for p in model.dense_parameters()])
     for a_, b_ in zip(*states):
         torch.testing.assert_close(a_, b_, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_zero_collision_hash_step_replays_from_a_graph():
+    """MMoE with the user id behind a zero-collision hash (BASELINE configs[4] at test size, eviction every 2 steps): through
+    GraphTrainPipeline -- the ZCH wrapper in ring mode: device iteration counter, candidates in a device ring, admission /
+    eviction rounds run between replays -- the same losses, dense weights, tables and id -> row maps as the eager pipeline
+    with its per-step candidate lists."""
+    import numpy as np
+
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.config import load_pipeline_spec
+    from torcheasyrec_amd.dense import FusedDenseAdam
+    from torcheasyrec_amd.embedding_group import BASE_DATA_GROUP, Batch, GraphTrainPipeline, TrainPipeline
+    from torcheasyrec_amd.rank_model import build_rank_model
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor, KeyedTensor
+
+    _lib.use_native()
+    dev = torch.device("cuda", 0)
+    spec = load_pipeline_spec(open(os.path.join(os.path.dirname(__file__), "golden", "mmoe_mini.config")).read())
+    rng = np.random.default_rng(0)
+    users = rng.integers(1 << 40, 1 << 50, size=400).astype(np.int64)
+    b, n_steps = 64, 11
+    host = []
+    for _ in range(n_steps):
+        ids = np.concatenate([users[np.minimum(rng.zipf(1.3, size=b), 399)], rng.integers(0, 300, size=b), rng.integers(0, 20, size=b)])
+        kjt = KeyedJaggedTensor(["user_id", "adgroup_id", "pid"], torch.from_numpy(ids.astype(np.int64)), torch.ones(3 * b, dtype=torch.int32),
+                                uniform_length=1)
+        kt = KeyedTensor(["price"], [1], torch.from_numpy(rng.random((b, 1), dtype=np.float32)))
+        host.append(Batch({BASE_DATA_GROUP: kt}, {BASE_DATA_GROUP: kjt},
+                          {"clk": torch.from_numpy((rng.random(b) < 0.3).astype(np.int64)), "buy": torch.from_numpy((rng.random(b) < 0.1).astype(np.int64))}).pin_memory())
+    res = []
+    work = torch.cuda.Stream(dev)
+    with torch.cuda.stream(work):
+        for cls in (TrainPipeline, GraphTrainPipeline):
+            torch.manual_seed(0)
+            model = build_rank_model(spec, device=dev)
+            model.train()
+            opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
+            pipe = cls(model, opt, dev, model.loss)
+            it = iter(host)
+            losses = []
+            while True:
+                try:
+                    l, _, _ = pipe.progress(it)
+                except StopIteration:
+                    break
+                losses.append([float(v) for _, v in sorted(l.items())])
+            torch.cuda.synchronize()
+            mc = model.embedding_group.mc
+            m = mc.modules_by_table["user_id_emb"]
+            assert mc._iter == n_steps and (cls is TrainPipeline or (mc.device_profile and int(mc._d_iter.item()) == n_steps))
+            res.append((losses, [p.detach().clone() for p in model.dense_parameters()],
+                        {n: w.detach().clone() for n, w in model.embedding_group.ebc.table_weights().items()},
+                        (m.row_ids.clone(), m.counts.clone(), m.last_iter.clone())))
+            if cls is GraphTrainPipeline:
+                assert pipe._graphs[0] is not None and pipe._graphs[1] is not None
+    (la, pa, wa, za), (lb, pb, wb, zb) = res
+    torch.testing.assert_close(torch.tensor(lb), torch.tensor(la), rtol=1e-6, atol=1e-7)
+    for a, b_ in zip(pa, pb):
+        torch.testing.assert_close(b_, a, rtol=1e-5, atol=1e-6)
+    for n in wa:
+        torch.testing.assert_close(wb[n], wa[n], rtol=1e-5, atol=1e-6, msg=n)
+    for a, b_ in zip(za, zb):
+        assert torch.equal(a, b_)  # the maps: integer work
+    assert int((za[0] != (1 << 63) - 1).sum()) > 5  # users were admitted

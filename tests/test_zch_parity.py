@@ -144,6 +144,43 @@ def test_zch_state_survives_a_checkpoint(dev, tmp_path):
         assert torch.equal(getattr(a.mc.modules_by_table["t"], f), getattr(b.mc.modules_by_table["t"], f))
 
 
+def test_ring_mode_equals_the_positional_candidate_lists(dev):
+    """`ManagedCollisionEmbeddingBagCollection.device_profile` (what makes the step capturable: the iteration number read from
+    a device counter, a step's candidates written to slot `iter % slots` of a device ring -- tzr_zch_remap_ring) against the
+    default (host iteration number, one positional candidate tensor per step kept in a host list): the same remapped ids
+    at every step, and after rounds of two tables with DIFFERENT eviction intervals the same maps, counts and last-access
+    iterations."""
+    def build(ring):
+        torch.manual_seed(0)
+        ebc = EmbeddingBagCollection([EmbeddingBagConfig("a", 4, 16, ["ka", "ka2"]), EmbeddingBagConfig("b", 4, 9, ["kb"]),
+                                      EmbeddingBagConfig("plain", 4, 50, ["kp"])], device=dev,
+                                     optimizer=SparseOptimizerConfig(kind="sgd", lr=0.1))
+        mc = ManagedCollisionEmbeddingBagCollection(ebc, {"a": ZchConfig(16, 3, "lfu"), "b": ZchConfig(9, 2, "distance_lfu")})
+        mc.device_profile = ring
+        mc.train()
+        return mc
+
+    pos, ring = build(False), build(True)
+    rng = np.random.default_rng(1)
+    B = 12
+    for step in range(9):
+        ids = np.concatenate([rng.integers(0, 40, size=2 * B) * 7919 + (1 << 45), rng.integers(0, 25, size=B) * 104729 + (1 << 50),
+                              rng.integers(0, 50, size=B)]).astype(np.int64)
+        kjt = KeyedJaggedTensor(["ka", "ka2", "kb", "kp"], torch.from_numpy(ids), torch.ones(4 * B, dtype=torch.int32), uniform_length=1).to(dev)
+        outs = []
+        for mc in (pos, ring):
+            out, rm = mc(kjt)
+            out.values().sum().backward()
+            outs.append(rm.values().cpu())
+        assert torch.equal(outs[0], outs[1]), f"step {step}"
+        assert pos._iter == ring._iter == step + 1 and int(ring._d_iter.item()) == step + 1
+    for t in ("a", "b"):
+        for f in ("row_ids", "counts", "last_iter"):
+            assert torch.equal(getattr(pos.modules_by_table[t], f), getattr(ring.modules_by_table[t], f)), (t, f)
+        assert torch.equal(torch.sort(pos.pending_candidates(t)).values, torch.sort(ring.pending_candidates(t)).values)
+    assert int((ring.modules_by_table["a"].row_ids != EMPTY).sum()) > 0
+
+
 def test_dcp_names_of_a_mixed_collection_and_refusal_of_other_naming_schemes(dev, tmp_path):
     """A collection that holds a zero-collision-hash table NEXT TO a plain one (MMoE + ZCH): the reference keeps only the
     managed-collision table under `mc_ebc._embedding_module`; the plain table stays under `...__BASE__.ebc.embedding_bags`

@@ -165,6 +165,7 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _sz, _vp]),
     "tzr_dense_adam": (_i32, [_vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "tzr_zch_remap": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tzr_zch_remap_ring": (_i32, [_vp, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     "tzr_zch_build": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "tzr_zch_update": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "tzr_zch_select_hist": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, C.c_double, _i32, _i32, _i32, C.c_uint64, _i32,

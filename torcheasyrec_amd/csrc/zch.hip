@@ -26,14 +26,29 @@ __device__ __forceinline__ uint64_t zch_mix(int64_t id) {  // splitmix64 finalis
   return x ^ (x >> 31);
 }
 
+// Ring mode (tzr_zch_remap_ring: the step replayed from a hipGraph): the iteration number comes from DEVICE memory
+// (the graph's own counter, bumped by the caller inside the graph), and the candidates of a step go to slot
+// `iter % ring_slots` of a ring that holds a [n_cand_keys][per_key] block per slot -- only the keys that HAVE a module
+// (key_cand[f] = their index among those, -1 otherwise), per_key = B * uniform ids each.  Nothing on the host names a step.
 __global__ __launch_bounds__(ZCH_THREADS) void tzr_zch_remap_kernel(
     const TzrZchModule* __restrict__ mods, const int32_t* __restrict__ key_module, int n_keys,
     const int64_t* __restrict__ values, const int64_t* __restrict__ offsets, int64_t B, int uniform,
-    int64_t iter, int profile, int64_t* __restrict__ out, int64_t* __restrict__ candidates) {
+    int64_t iter, int profile, int64_t* __restrict__ out, int64_t* __restrict__ candidates,
+    const int64_t* __restrict__ d_iter, const int32_t* __restrict__ key_cand, int n_cand_keys, int64_t ring_slots) {
   const int f = blockIdx.y;
   const int m = key_module[f];
   const int64_t s = uniform ? (int64_t)f * B * uniform : offsets[(int64_t)f * B];
   const int64_t e = uniform ? (int64_t)(f + 1) * B * uniform : offsets[(int64_t)(f + 1) * B];
+  if (d_iter) {
+    iter = *d_iter;
+    if (profile) {
+      const int zk = key_cand[f];
+      const int64_t per_key = B * uniform;
+      // candidates[i] below = the ring cell of id i: base of (slot, key) - s
+      candidates = zk < 0 ? nullptr : candidates + ((iter % ring_slots) * n_cand_keys + zk) * per_key - s;
+      if (!candidates) profile = 0;
+    }
+  }
   if (m < 0) {  // key without a ZCH module: ids pass through
     for (int64_t i = s + (int64_t)blockIdx.x * ZCH_THREADS + threadIdx.x; i < e;
          i += (int64_t)gridDim.x * ZCH_THREADS) {
@@ -177,7 +192,28 @@ extern "C" int tzr_zch_remap(const TzrZchModule* d_modules, const int32_t* d_key
   const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (per_key + ZCH_THREADS - 1) / ZCH_THREADS));
   hipLaunchKernelGGL(tzr_zch_remap_kernel, dim3(gx, (unsigned)n_keys), dim3(ZCH_THREADS), 0,
                      static_cast<hipStream_t>(stream), d_modules, d_key_module, n_keys, d_values,
-                     d_offsets, B, uniform_bag_len, iter, profile, d_out_values, d_candidates);
+                     d_offsets, B, uniform_bag_len, iter, profile, d_out_values, d_candidates,
+                     static_cast<const int64_t*>(nullptr), static_cast<const int32_t*>(nullptr), 0, (int64_t)1);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+extern "C" int tzr_zch_remap_ring(const TzrZchModule* d_modules, const int32_t* d_key_module, int n_keys,
+                                  const int64_t* d_values, int64_t B, int uniform_bag_len, int64_t n_values,
+                                  const int64_t* d_iter, int profile, int64_t* d_out_values, const int32_t* d_key_cand,
+                                  int n_cand_keys, int64_t* d_cand_ring, int64_t ring_slots, void* stream) {
+  if (!d_modules || !d_key_module || n_keys <= 0 || B < 0 || n_values < 0 || uniform_bag_len <= 0 || !d_iter)
+    return TZR_ERR_INVALID;
+  if (n_values != (int64_t)n_keys * B * uniform_bag_len) return TZR_ERR_INVALID;  // (uniform bags: a step's ring block has one shape)
+  if (n_values == 0) return TZR_OK;
+  if (!d_values || !d_out_values) return TZR_ERR_INVALID;
+  if (profile && (!d_key_cand || n_cand_keys <= 0 || !d_cand_ring || ring_slots <= 0)) return TZR_ERR_INVALID;
+  const int64_t per_key = B * uniform_bag_len;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (per_key + ZCH_THREADS - 1) / ZCH_THREADS));
+  hipLaunchKernelGGL(tzr_zch_remap_kernel, dim3(gx, (unsigned)n_keys), dim3(ZCH_THREADS), 0,
+                     static_cast<hipStream_t>(stream), d_modules, d_key_module, n_keys, d_values,
+                     static_cast<const int64_t*>(nullptr), B, uniform_bag_len, (int64_t)0, profile, d_out_values, d_cand_ring,
+                     d_iter, d_key_cand, n_cand_keys, ring_slots);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

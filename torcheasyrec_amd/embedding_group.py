@@ -567,6 +567,22 @@ def _batch_tensors(b: Batch, skip_constant: bool = True):
     return out
 
 
+def zch_wrapper_of(model: nn.Module):
+    """the model's zero-collision-hash wrapper (`embedding_group.mc`), or None"""
+    eg = getattr(model, "embedding_group", None)
+    if eg is None and hasattr(model, "m"):  # (a thin wrapper around the model, as bench.py's)
+        eg = getattr(model.m, "embedding_group", None)
+    return getattr(eg, "mc", None) if eg is not None else None
+
+
+def after_graph_replay(model: nn.Module) -> None:
+    """Host bookkeeping behind one replay of a captured training step: a zero-collision hash in ring mode counts the step and
+    runs the admission / eviction round that falls due (zch.ManagedCollisionEmbeddingBagCollection.replayed)."""
+    mc = zch_wrapper_of(model)
+    if mc is not None and getattr(mc, "device_profile", False):
+        mc.replayed()
+
+
 class GraphTrainPipeline:
     """`pipeline.progress(iterator)` with the whole step replayed from a hipGraph while the NEXT batch
     crosses PCIe (tzrec/utils/dist_util.py:221-303: H2D of batch i+1 on the memcpy stream under the
@@ -593,6 +609,9 @@ class GraphTrainPipeline:
                                "(sharded models: sharded_step.ShardedTrainStep)")
         self._model, self._opt, self._device, self._loss_fn = model, optimizer, torch.device(device), loss_fn
         assert self._device.type == "cuda", "GraphTrainPipeline replays hipGraphs: CUDA/HIP device only"
+        mc = zch_wrapper_of(model)
+        if mc is not None:  # the step of a model with a zero-collision hash is capturable in ring mode (zch.py)
+            mc.device_profile = True
         self._copy_stream = torch.cuda.Stream(device=self._device)
         from .dense import unit_gradient
         unit_gradient(torch.zeros((), dtype=torch.float32, device=self._device))  # (made before any capture, see dense.unit_gradient)
@@ -672,6 +691,7 @@ class GraphTrainPipeline:
         if self._graphs[slot] is not None:
             g, losses, predictions = self._graphs[slot]
             g.replay()
+            after_graph_replay(self._model)
         else:
             losses, predictions = self._step(batch)
             self._seen[slot] += 1

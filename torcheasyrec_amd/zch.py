@@ -290,6 +290,15 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         self._cand: List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = []  # (candidates, module per key, ids per key)
         self._reset = reset_evicted_rows
         self.last_evicted: Dict[str, torch.Tensor] = {}
+        # Ring mode (`device_profile = True`, uniform bags): the step can be replayed from a hipGraph.  The iteration
+        # number the remap stamps rows with is a device counter bumped inside the step; a step's candidates go to slot
+        # `iter % slots` of a device ring (slots = the largest eviction interval), so nothing on the host names a step.
+        # The host's `_iter` follows: `remap_step` counts eager steps, `replayed()` counts graph replays (and runs the
+        # admission / eviction round when one is due -- eagerly, between replays).
+        self.device_profile = False
+        self._d_iter: Optional[torch.Tensor] = None
+        self._ring: Optional[torch.Tensor] = None
+        self._ring_meta: Optional[dict] = None
 
     @property
     def fused_optimizer(self):
@@ -311,6 +320,8 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         n = values.numel()
         uniform = kjt.uniform_length() or 0
         out = torch.empty_like(values)
+        if self.device_profile and profile:
+            return self._remap_ring(kjt, keys, km, out)
         cand = torch.empty_like(values) if profile else None
         _lib.check(_lib.lib().tzr_zch_remap(
             _lib.ptr(self._modules_device()), _lib.ptr(km), len(keys), _lib.ptr(values),
@@ -324,8 +335,85 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         return KeyedJaggedTensor(kjt.keys(), out, kjt.lengths(), kjt.weights_or_none(), kjt._offsets, kjt.stride(),
                                  uniform_length=kjt.uniform_length())
 
+    # -- ring mode -----------------------------------------------------------------------------------------------------
+    def _remap_ring(self, kjt: KeyedJaggedTensor, keys, km: torch.Tensor, out: torch.Tensor) -> KeyedJaggedTensor:
+        uniform = kjt.uniform_length() or 0
+        if not uniform:
+            raise ValueError("ManagedCollisionEmbeddingBagCollection.device_profile needs uniform bags (one shape per step)")
+        B = kjt.stride()
+        zk = [i for i, k in enumerate(keys) if self._key_module.get(k, -1) >= 0]
+        meta = self._ring_meta
+        capturing = self._device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing and (self._d_iter is None or meta is None or meta["keys"] != keys or meta["per_key"] != B * uniform):
+            # (the counter and the ring are made OUTSIDE any graph: a fill captured with the step would reset them at every replay)
+            raise RuntimeError("device_profile: run one eager training step of this shape before capturing it")
+        if meta is None or meta["keys"] != keys or meta["per_key"] != B * uniform:
+            if meta is not None and self._ring is not None and bool((self._ring != EMPTY).any()):
+                raise ValueError("device_profile: the shape of the step changed while candidates are pending")
+            slots = max(self.modules_by_table[n].cfg.eviction_interval for n in self._order)
+            key_cand = torch.full((len(keys),), -1, dtype=torch.int32)
+            for j, i in enumerate(zk):
+                key_cand[i] = j
+            self._ring = torch.full((slots, max(len(zk), 1), B * uniform), EMPTY, dtype=torch.int64, device=self._device)
+            self._ring_meta = meta = {"keys": keys, "per_key": B * uniform, "slots": slots, "zk": zk,
+                                      "key_cand": key_cand.to(self._device),
+                                      "zk_module": [self._key_module[keys[i]] for i in zk]}
+        if self._d_iter is None:  # (an eager step: `remap_step` has already counted it)
+            self._d_iter = torch.full((1,), self._iter - 1, dtype=torch.int64, device=self._device)
+        self._d_iter.add_(1)  # (inside the step: captured with it)
+        _lib.check(_lib.lib().tzr_zch_remap_ring(
+            _lib.ptr(self._modules_device()), _lib.ptr(km), len(keys), _lib.ptr(kjt.values()), B, uniform, kjt.values().numel(),
+            _lib.ptr(self._d_iter), 1, _lib.ptr(out), _lib.ptr(meta["key_cand"]), len(zk), _lib.ptr(self._ring), meta["slots"],
+            _lib.stream_ptr(self._device)), "tzr_zch_remap_ring")
+        return KeyedJaggedTensor(kjt.keys(), out, kjt.lengths(), kjt.weights_or_none(), kjt._offsets, kjt.stride(),
+                                 uniform_length=kjt.uniform_length())
+
+    def replayed(self) -> None:
+        """One replay of a captured training step has been queued: the host's iteration count follows the device's, and the
+        admission / eviction round runs when it is due (eagerly, on the current stream, behind the replay)."""
+        self._iter += 1
+        if any(self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order):
+            self._evict()
+
+    def _ring_candidates(self, j: int) -> torch.Tensor:
+        """raw ids recorded for module j in the ring (live cells only)"""
+        meta = self._ring_meta
+        cols = [c for c, m in enumerate(meta["zk_module"]) if m == j] if meta else []
+        if not cols:
+            return torch.zeros(0, dtype=torch.int64, device=self._device)
+        c = self._ring[:, cols, :].reshape(-1)
+        return c[c != EMPTY]
+
+    @torch.no_grad()
+    def _evict_ring(self) -> None:
+        meta = self._ring_meta
+        for j, name in enumerate(self._order):
+            mod = self.modules_by_table[name]
+            if self._iter % mod.cfg.eviction_interval != 0:
+                continue
+            changed = mod.update_and_evict(self._ring_candidates(j), self._iter)
+            self.last_evicted[name] = changed
+            self._reset_rows(name, mod, changed)
+            cols = [c for c, m in enumerate(meta["zk_module"]) if m == j] if meta else []
+            if cols:  # consumed: a module with a shorter interval than the ring must not meet them again
+                self._ring[:, cols, :] = EMPTY
+
+    def _reset_rows(self, name: str, mod: ManagedCollisionModule, changed: torch.Tensor) -> None:
+        if self._reset and changed.numel():
+            w = self.ebc.table_weights()[name]
+            a = (1.0 / mod.cfg.zch_size) ** 0.5
+            w.data[changed] = torch.empty(changed.numel(), w.shape[1], device=w.device).uniform_(-a, a)
+            st = self.ebc.table_states().get(name)
+            if st is not None:
+                st[changed] = 0
+
     @torch.no_grad()
     def _evict(self) -> None:
+        if self.device_profile and self._ring is not None:
+            self._evict_ring()
+            return
+        if not self._cand:
+            return
         ids = torch.cat([c for c, _, _ in self._cand])
         mods = torch.cat([torch.repeat_interleave(km, seg) for _, km, seg in self._cand])
         live = ids != EMPTY
@@ -337,13 +425,7 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
             mod = self.modules_by_table[name]
             changed = mod.update_and_evict(ids[mods == j], self._iter)
             self.last_evicted[name] = changed
-            if self._reset and changed.numel():
-                w = self.ebc.table_weights()[name]
-                a = (1.0 / mod.cfg.zch_size) ** 0.5
-                w.data[changed] = torch.empty(changed.numel(), w.shape[1], device=w.device).uniform_(-a, a)
-                st = self.ebc.table_states().get(name)
-                if st is not None:
-                    st[changed] = 0
+            self._reset_rows(name, mod, changed)
         if all(due):
             self._cand = []
         else:  # keep only the candidates of the modules that did not run
@@ -358,6 +440,8 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
     def pending_candidates(self, table: str) -> torch.Tensor:
         """Raw ids looked up without a row since `table`'s last admission round (not consumed)."""
         j = self._order.index(table)
+        if self.device_profile and self._ring is not None:
+            return self._ring_candidates(j)
         parts = []
         for c, km, seg in self._cand:
             mods = torch.repeat_interleave(km, seg)
@@ -368,9 +452,15 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         """First half of a step for callers that run the lookup themselves (EmbeddingGroup): remap, and
         in training count the iteration and profile."""
         training = self.training and torch.is_grad_enabled()
-        if training:
+        # (a step that is being CAPTURED is not a step yet: its replays are counted by `replayed()`, which also runs the
+        # rounds that fall due -- never inside the graph)
+        capturing = self._device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing and training and not self.device_profile:
+            raise RuntimeError("a training step with a zero-collision hash is capturable in ring mode only: set "
+                               "ManagedCollisionEmbeddingBagCollection.device_profile = True before the first step")
+        if training and not capturing:
             self._iter += 1
-        self._pending_evict = training and any(
+        self._pending_evict = training and not capturing and any(
             self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order)
         return self.remap(kjt, profile=training)
 
