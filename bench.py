@@ -96,6 +96,9 @@ def parse_args():
     ap.add_argument("--no-graph-input-dist", action="store_true",
                     help="--step-graph runs: launch the input dist's kernels one by one instead of replaying its two kernel runs from "
                          "hipGraphs (the step is host-bound: 2 replays instead of ~8 launches and their Python, profiles/r04r)")
+    ap.add_argument("--no-native-driver", action="store_true",
+                    help="--step-graph runs: issue the slot's graphs and collectives from Python through torch's ProcessGroup "
+                         "(the round-4 path) instead of one native call on the library's own RCCL communicator (native_step.py)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N=1 debugging: run the row-wise sharded module over a 1-rank RCCL group")
     ap.add_argument("--no-graph", action="store_true", help="N=1: launch every step eagerly instead of hipGraph replay")
@@ -303,7 +306,9 @@ def sharded_proxy(args) -> dict:
         return {"config": "row-wise sharded step of ONE rank at 8192 samples per rank on a 1-rank RCCL group (the per-rank work of "
                           "the 8-GPU job at global batch 65536); collectives are self copies; measured in a child process before "
                           "this process touched the GPU",
-                "ms_per_step": child["ms_per_step"], "launch": child["launch"], "parallelism": child["config"]["parallelism"],
+                "ms_per_step": child["ms_per_step"], "host_queue_ms_per_step": child.get("host_queue_ms_per_step"),
+                "host_flag_wait_ms_per_step": child.get("host_flag_wait_ms_per_step"), "host_busy_ms_per_step": child.get("host_busy_ms_per_step"),
+                "launch": child["launch"], "parallelism": child["config"]["parallelism"],
                 "exchange": child.get("exchange"), "projection": child.get("projection"), "collectives": child.get("collectives")}
     except Exception as e:
         return {"error": repr(e)[:300]}
@@ -702,7 +707,8 @@ def main():
         train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
                                       plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph,
                                       graph_input_dist=args.step_graph and not args.no_graph_input_dist,
-                                      overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives])
+                                      overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives],
+                                      native_driver=False if args.no_native_driver else None)
 
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:
@@ -755,10 +761,13 @@ def main():
     if world > 1:
         dist.barrier()
         sync()
+    fw0 = getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) if sharded else 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = run_step(args.warmup + i)
-    host_elapsed = time.perf_counter() - t0  # time the HOST needed to queue the steps (no wait for the GPU in it)
+    host_elapsed = time.perf_counter() - t0  # time until the HOST had queued the steps (sharded capacity exchange: includes its waits
+    #                                           for the batches' overflow words -- `host_flag_wait_ms_per_step`, the host AHEAD of the device)
+    host_flag_wait = (getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) - fw0) if sharded else 0.0
     sync()
     if world > 1:
         dist.barrier()
@@ -1020,6 +1029,8 @@ def main():
                   + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "host_queue_ms_per_step": host_elapsed / args.steps * 1e3,
+        **({"host_flag_wait_ms_per_step": host_flag_wait / args.steps * 1e3,
+            "host_busy_ms_per_step": (host_elapsed - host_flag_wait) / args.steps * 1e3} if sharded else {}),
         "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" if not emu else "synthetic -- CPU LANE EMULATOR + gloo, tables capped: launch-path plumbing check, not a measurement",
@@ -1032,13 +1043,17 @@ def main():
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
         "launch": ("hipGraph replay" if (graphs is not None or replayed_graphs) else
-                   ((f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them (async, waited for on the stream)" if args.step_graph else
+                   (("pipelined, native step driver: input dist one batch ahead as ONE hipGraph (ids all-to-all inside), the rest of the step ONE hipGraph "
+                     "(both all-to-alls and both all-reduces inside, on the library's own RCCL communicator), queued by tzr_step_run"
+                     if getattr(train_step, "native_steps", 0) else
+                     f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them (async, waited for on the stream)") if args.step_graph else
                      "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
     }
     if sharded:
         out["exchange"] = dict(model.ebc.exchange_stats, kind=args.exchange)
         if train_step is not None and args.step_graph:
-            out["exchange"].update(graph_steps=train_step.graph_steps, eager_steps=train_step.eager_steps)
+            out["exchange"].update(graph_steps=train_step.graph_steps, eager_steps=train_step.eager_steps,
+                                   native_driver_steps=train_step.native_steps)
         # the scaling arithmetic (what this step time means for the >= 6x target): at N = 1 the run is the proxy of one
         # rank of a `65536 / B_local`-rank job, at N > 1 the measured job itself
         Wp = args.projection_world or (world if world > 1 else max(2, 65536 // max(B_local, 1)))

@@ -556,6 +556,36 @@ int tzr_din_attn_bwd(const float* d_grad_out, int64_t grad_out_stride, const flo
                      int64_t kv_stride, int D, const int64_t* d_offsets, int64_t B, int64_t max_len, float* d_ds,
                      float* d_dkv, int64_t dkv_stride, void* stream);
 
+/* ---- native step driver (csrc/step_driver.hip) ------------------------------------------------------------------
+ * Replaces the host side of a steady-state train step of tzrec's pipeline (tzrec/utils/dist_util.py:221-303: Python +
+ * torch.distributed calls per collective) for a sharded step that was cut into captured hipGraphs: ONE call queues the
+ * graphs and the RCCL collectives between them.
+ *
+ * Communicator: RCCL reached through the librccl the process already holds (`librccl_path`: e.g. <torch>/lib/librccl.so;
+ * NULL = default search); rank 0 makes the 128-byte unique id, the launcher carries it to every rank (torch.distributed's
+ * store or one broadcast), every rank calls tzr_comm_create.  tzr_comm_all_to_all / _all_reduce are in stream order on
+ * `stream` (bytes_per_peer: what each rank sends to and receives from every rank; all-reduce: fp32 sum or average).
+ * Program: ops recorded once (tzr_step_add_*: each returns the op's index >= 0, or a negative TZR_ERR_*), replayed by
+ * tzr_step_run: a graph op is hipGraphLaunch on `stream`; a collective runs on the program's own communication stream
+ * behind everything queued on `stream` so far (sync != 0: `stream` waits for it on the spot; else a later wait op does);
+ * nothing allocates, nothing synchronises the host.  Buffers and graph handles must outlive the program. */
+int tzr_comm_available(const char* librccl_path); /* 1 / 0 */
+int tzr_comm_version(const char* librccl_path);   /* ncclGetVersion, -1 when RCCL is not reachable */
+int tzr_comm_unique_id(const char* librccl_path, void* out, size_t out_bytes); /* out_bytes >= 128 */
+int tzr_comm_create(const char* librccl_path, const void* unique_id, size_t id_bytes, int world, int rank,
+                    void** out_comm);
+int tzr_comm_destroy(void* comm);
+int tzr_comm_all_to_all(void* comm, const void* d_send, void* d_recv, int64_t bytes_per_peer, void* stream);
+int tzr_comm_all_reduce(void* comm, float* d_buf, int64_t count, int average, void* stream);
+int tzr_step_create(void** out_program);
+int tzr_step_destroy(void* program);
+int tzr_step_add_graph(void* program, void* graph_exec /* hipGraphExec_t */);
+int tzr_step_add_all_to_all(void* program, void* comm, const void* d_send, void* d_recv, int64_t bytes_per_peer, int sync);
+int tzr_step_add_all_reduce(void* program, void* comm, float* d_buf, int64_t count, int average, int sync);
+int tzr_step_add_wait(void* program, int collective_op);
+int tzr_step_num_ops(void* program);
+int tzr_step_run(void* program, void* stream);
+
 /* ---- export ------------------------------------------------------------------------------ */
 
 /* Row-wise INT8 export of a table: replaces _quantize_quint8_rowwise_f16

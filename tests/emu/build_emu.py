@@ -16,7 +16,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 def _sources():
     srcs = sorted(
-        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f != "abi.hip"
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("abi.hip", "step_driver.hip")  # (host-only: stubs in abi_emu.cpp)
     )
     return srcs + [os.path.join(HERE, "abi_emu.cpp")]
 

@@ -197,12 +197,14 @@ def _body_sharded_zch_world1_matches_unsharded_zch():
             pass  # (no destroy_process_group: the isolated process exits right behind the body, see _isolated)
 
 
-def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
+def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False, native=False):
     """Capacity-bounded exchange + ONE hipGraph per pipeline slot for everything after the input dist (RCCL
     all-to-alls, lookups, dense segment, sparse + dense optimizers): after the captures, the trajectory is the exact
     pipelined step's bit for bit -- losses, dense weights, table shards; no batch overflowed.  `overlap`: the six-graph
     order (collectives issued async behind the graph that feeds them, waited for in front of the one that reads them; the
-    replicas' lookup + the bottom MLP under the rows all-to-all), which is the default."""
+    replicas' lookup + the bottom MLP under the rows all-to-all), which is the default.  `native`: behind the captures the
+    slot's six graphs and the collectives between them are queued by ONE call of the native step driver on the library's own
+    RCCL communicator (native_step.StepProgram, csrc/step_driver.hip) -- no torch ProcessGroup call in those steps."""
     from torcheasyrec_amd import _lib
     from torcheasyrec_amd.criteo import CRITEO_ROWS, NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch
     from torcheasyrec_amd.dense import FusedDenseAdam
@@ -221,7 +223,7 @@ def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
             steps = 12
             batches = [tuple(t.to(dev) for t in synthetic_batch(s, B, rows)) for s in range(steps)]
             out = {}
-            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True, "graph_input_dist": graph_input_dist, "overlap_collectives": overlap})):
+            for name, kw, skw in (("exact", {}, {}), ("graph", {"exchange": "capacity"}, {"step_graph": True, "graph_input_dist": graph_input_dist, "overlap_collectives": overlap, "native_driver": native})):
                 torch.manual_seed(3)
                 m = ShardedDLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=opt,
                                 dp_max_rows=4096, replicate_at_world1=True, **kw)
@@ -236,7 +238,15 @@ def _body_whole_step_graph_world1(B, graph_input_dist, overlap=False):
             assert m.ebc.exchange_stats == {"capacity_batches": steps, "overflow_retries": 0}
             assert ts.graph_steps == steps and ts.eager_steps == 0 and ts.overlap_collectives == overlap
             assert all(sl["graph"] is not None and (sl.get("in_graphs") is not None) == graph_input_dist for sl in ts._slots.values()) and len(ts._slots) == 2
-            assert all(len(sl["graph"]) == (6 if overlap else 3) for sl in ts._slots.values())
+            if native:
+                # ONE graph per slot (all four collectives captured inside it, on the library's own communicator); the input
+                # dist is one graph too, its ids all-to-all inside; every step behind a slot's capture step went through tzr_step_run
+                assert all(len(sl["graph"]) == 1 and len(sl["program"]) == 1 for sl in ts._slots.values())
+                assert all(len(sl["in_graphs"]) == 1 for sl in ts._slots.values() if graph_input_dist)
+                assert ts.native_steps >= steps - 2 * (ts.warmup_iters + 2) and ts.native_steps > 0, ts.native_steps
+            else:
+                assert all(len(sl["graph"]) == (6 if overlap else 3) for sl in ts._slots.values())
+                assert ts.native_steps == 0
             assert torch.equal(out["exact"][0], out["graph"][0])
             for a, b in zip(out["exact"][1], out["graph"][1]):
                 assert torch.equal(a, b)
@@ -291,7 +301,8 @@ def test_sharded_zch_world1_matches_unsharded_zch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,graph_input_dist,overlap", [(2048, True, False), (8192, False, False), (8192, False, True)])
-def test_whole_step_graph_world1(B, graph_input_dist, overlap):
-    _isolated("whole_step_graph_world1", B, graph_input_dist, overlap)
+@pytest.mark.parametrize("B,graph_input_dist,overlap,native", [(2048, True, False, False), (8192, False, False, False), (8192, False, True, False),
+                                                                (8192, False, True, True), (2048, True, True, True)])
+def test_whole_step_graph_world1(B, graph_input_dist, overlap, native):
+    _isolated("whole_step_graph_world1", B, graph_input_dist, overlap, native)
 

@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 9  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 10  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -151,6 +151,21 @@ _SIGNATURES = {
     "tzr_din_assemble_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     "tzr_din_attn_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tzr_din_attn_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "tzr_comm_available": (_i32, [C.c_char_p]),
+    "tzr_comm_version": (_i32, [C.c_char_p]),
+    "tzr_comm_unique_id": (_i32, [C.c_char_p, _vp, _sz]),
+    "tzr_comm_create": (_i32, [C.c_char_p, _vp, _sz, _i32, _i32, C.POINTER(C.c_void_p)]),
+    "tzr_comm_destroy": (_i32, [_vp]),
+    "tzr_comm_all_to_all": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "tzr_comm_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "tzr_step_create": (_i32, [C.POINTER(C.c_void_p)]),
+    "tzr_step_destroy": (_i32, [_vp]),
+    "tzr_step_add_graph": (_i32, [_vp, _vp]),
+    "tzr_step_add_all_to_all": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32]),
+    "tzr_step_add_all_reduce": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
+    "tzr_step_add_wait": (_i32, [_vp, _i32]),
+    "tzr_step_num_ops": (_i32, [_vp]),
+    "tzr_step_run": (_i32, [_vp, _vp]),
     "tzr_bce_logits_workspace": (_sz, [_i64]),
     "tzr_bce_logits": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tzr_relu_bwd_colsum_workspace": (_sz, [_i64, _i32]),

@@ -39,6 +39,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
+from . import _lib
 from .dlrm import bce_with_logits
 from .sharding import ShardedDLRM
 from .sparse import KeyedJaggedTensor
@@ -131,7 +132,7 @@ class ShardedTrainStep:
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
                  use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2,
                  plan_ahead: bool = True, step_graph: bool = False, graph_input_dist: bool = False,
-                 overlap_collectives: Optional[bool] = None) -> None:
+                 overlap_collectives: Optional[bool] = None, native_driver: Optional[bool] = None) -> None:
         self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
         self.device = model.ebc._device
         self.cuda = self.device.type == "cuda"
@@ -171,6 +172,13 @@ class ShardedTrainStep:
         if overlap_collectives is None:
             overlap_collectives = True
         self.overlap_collectives = bool(overlap_collectives)
+        # Whole-step path, steady state: the slot's six graphs and the collectives between them queued by ONE native call
+        # (native_step.StepProgram over csrc/step_driver.hip) on a communicator of the library's own -- no torch ProcessGroup
+        # call, no Python between the graphs.  None = whenever the library can reach RCCL (a GPU build next to torch's
+        # librccl); the warm-up and capture steps run the Python sequence, which is also what the gloo tests run.
+        self.native_driver = native_driver
+        self._comm = None
+        self.native_steps = 0
         # (the ids all-to-all of batch i+1 is issued from the side stream on the collection's own process group, like the
         # exact exchange's: every RCCL call of the step is eager, torch orders them on the group's stream in issue order --
         # `ebc.input_dist_group` can name another communicator for it)
@@ -279,7 +287,14 @@ class ShardedTrainStep:
               "dst_names": ("sparse",), "slot": key[0], "slot_key": key}
         ebc.cap_state(st, key[0])
         ig = sl.get("in_graphs")
-        if ig is not None:
+        if ig is not None and len(ig) == 1:  # native driver: ONE graph, the ids all-to-all inside (`_capture_native`)
+            ebc.cap_flag_arm(st)
+            ig[0].replay()
+            for k in ("ws_dp", "ws_rw"):
+                if k in sl["in_st"]:
+                    st[k] = sl["in_st"][k]
+            st["planned"] = True
+        elif ig is not None:
             ig[0].replay()
             ebc.cap_exchange(st)
             ebc.cap_flag_arm(st)  # (the replayed D2H copy of the overflow word lands on this sentinel)
@@ -294,6 +309,23 @@ class ShardedTrainStep:
                 ebc.cap_bucketize(st)
                 ebc.cap_exchange(st)
                 ebc.cap_segments(st)
+            elif self._use_native_driver():
+                # bucketize | ids all-to-all (the library's own communicator, on the capturing stream) | owner segments,
+                # overflow word to the host, both backward plans: one graph, one launch per batch
+                comm = self._native_comm_in()
+                g01 = torch.cuda.CUDAGraph()
+                _quiesce_process_group(self.device)
+                ebc.cap_flag_arm(st)
+                with torch.cuda.graph(g01, stream=self._side, capture_error_mode=_CAPTURE_MODE):
+                    ebc.cap_bucketize(st)
+                    comm.all_to_all(st["msg"][0], st["msg"][1], stream=self._side.cuda_stream)
+                    ebc.cap_segments(st)
+                    if self.plan_ahead:
+                        ebc.plan_ahead(st)
+                ebc.cap_flag_arm(st)
+                g01.replay()
+                sl["in_graphs"], sl["in_st"] = (g01,), st
+                st["planned"] = True
             else:
                 g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 _quiesce_process_group(self.device)
@@ -541,6 +573,13 @@ class ShardedTrainStep:
             if capture and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
                 raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
                                    "non-default stream (torch.cuda.set_stream)")
+        if capture and self._use_native_driver():
+            sl["st"] = st
+            self._capture_native(st, sl)
+            self.graph_steps += 1
+            if next_kjt is not None and self.prefetch:
+                self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
+            return sl["loss"]
         if capture:
             sl["st"] = st  # the captured kernels read this state's buffers: keep them alive
             graphs = []
@@ -548,6 +587,17 @@ class ShardedTrainStep:
             # graph of the bottom MLP is built in one capture (G0b) and walked backwards in the next (G1a), which is the
             # arrangement of torch.cuda.make_graphed_callables (forward and backward graphs of one pool)
             pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
+        prog = sl.get("program") if not capture else None
+        if prog is not None:
+            # steady state: the NEXT batch's input dist first (one graph on the side stream, behind the start of this step:
+            # its overflow word is what the host needs first when the next step begins), then one native call queues this
+            # step's graphs and the all-reduces between them
+            if next_kjt is not None and self.prefetch:
+                self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
+            prog.run(torch.cuda.current_stream(self.device).cuda_stream)
+            self.graph_steps += 1
+            self.native_steps += 1
+            return sl["loss"]
         ahead_done = False
         for i, (seg, coll) in enumerate(zip(segs, colls)):
             if i == 2 and not capture and next_kjt is not None and self.prefetch:
@@ -576,3 +626,76 @@ class ShardedTrainStep:
         if next_kjt is not None and self.prefetch and not ahead_done:
             self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
         return sl["loss"]
+
+    # -- native step driver -------------------------------------------------------------------------------
+    def _use_native_driver(self) -> bool:
+        if not (self.cuda and self.overlap_collectives):
+            return False
+        if self.native_driver is None:
+            from . import native_step
+
+            self.native_driver = native_step.available()
+        return bool(self.native_driver)
+
+    def _native_comm(self):
+        if self._comm is None:
+            from .native_step import NativeComm
+
+            self._comm = NativeComm(self.model.pg, self.device)
+        return self._comm
+
+    def _native_comm_in(self):
+        """a second communicator for the input dist: it runs on the side stream, one batch ahead of the step's collectives"""
+        if getattr(self, "_comm_in", None) is None:
+            from .native_step import NativeComm
+
+            self._comm_in = NativeComm(self.model.ebc.input_dist_group or self.model.pg, self.device)
+        return self._comm_in
+
+    def _capture_native(self, st: dict, sl: dict) -> None:
+        """The step of a slot for the native driver.  RCCL calls on the library's own communicator CAN be captured into a
+        hipGraph when they sit on the capturing stream itself (scripts/r05/rccl_own_capture_probe.py: `inline` replays; the
+        fork / join form and child graphs crash in hipStreamEndCapture on this stack) -- so all four collectives live INSIDE
+        the graph, and the step is ONE graph, one launch:
+
+            owners' row gather | rows all-to-all | replicas' lookup + bottom MLP | pooled gather, dense forward + backward,
+            per-id gradient rows | gradient all-to-all | replicas' row sums, dense gradients packed | owners' sort + fused
+            optimizer | all-reduce of the replicas' row sums | all-reduce of the dense gradients | replicas' dense row
+            update, Adam
+
+        In stream order the collectives hide behind nothing -- but every boundary between two graphs of the six-graph order
+        is ~20 us of launch latency on this part (profiles/r05q/timeline.txt), four of them per step, and what they bought
+        was at most the replicas' 25 us of row sums under the gradient all-to-all and the owners' 26 us update under the
+        all-reduces.  This call is the slot's capture step AND a training step: the graph is replayed behind its capture."""
+        from .native_step import StepProgram
+
+        ebc, comm = self.model.ebc, self._native_comm()
+        rm = st["rm"]
+        cur = torch.cuda.current_stream(self.device)
+        sp = cur.cuda_stream
+        pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
+        has_rw = "rw_n" in rm
+        train_rw = ebc.fused_optimizer is not None and has_rw
+        train_dp = ebc.fused_optimizer is not None and "dp_n" in rm
+        g = torch.cuda.CUDAGraph()
+        _quiesce_process_group(self.device)
+        with torch.cuda.graph(g, pool=pool, stream=cur, capture_error_mode=_CAPTURE_MODE):
+            self._seg0_rw(st, sl)
+            if has_rw:
+                rows_in, _ = ebc._recv_rows_buffer(st["N_pad"], rm["rw_n"])
+                comm.all_to_all(st["rows_out"], rows_in[:st["N_pad"]], stream=sp)
+            self._seg0b(st, sl)
+            self._seg1a(st, sl)
+            if train_rw:
+                st["grecv"] = ebc._slot(st["slot"], "grecv", (st["n_recv"], ebc.dim), torch.float32)
+                comm.all_to_all(st["grow"], st["grecv"], stream=sp)
+            self._seg1b(st, sl)
+            self._seg2a(st, sl)
+            if train_dp:
+                comm.all_reduce(ebc._dp_acc, stream=sp)
+            comm.all_reduce(sl["flat"], average=True, stream=sp)
+            self._seg2b(st, sl)
+        g.replay()
+        P = StepProgram()
+        P.add_graph(g)
+        sl["graph"], sl["program"] = [g], P

@@ -36,6 +36,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -280,6 +282,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
         # count -- they are sized for this many ids per bag on average (None: such batches take the exact exchange)
         self.capacity_bag_len: Optional[float] = None
         self.exchange_stats = {"capacity_batches": 0, "overflow_retries": 0}
+        self.flag_wait_s = 0.0  # host time spent waiting for a batch's overflow word (the host ahead of the device, not busy)
         self.input_dist_group = None  # process group of the ids all-to-all (default: `process_group`); a step captured
         #                               in a hipGraph replays its collectives while the next batch's input dist runs
         self._slot_bufs: Dict[Tuple, dict] = {}
@@ -660,6 +663,7 @@ class ShardedEmbeddingBagCollection(nn.Module):
             if st.pop("flag_armed", False):  # the pinned word itself says when the copy has landed (`cap_flag_arm`)
                 host = st["flag_host"]
                 spins = 0
+                t_w = time.perf_counter() if int(host.item()) < 0 else None  # (the host is AHEAD of the device here: waiting, not working)
                 while int(host.item()) < 0:
                     spins += 1
                     if spins > 2_000_000:  # (never seen) not for ever on a lost copy: wait for the copy's event, read ONCE more
@@ -671,6 +675,8 @@ class ShardedEmbeddingBagCollection(nn.Module):
                             raise RuntimeError("capacity exchange: the overflow word's D2H copy completed without overwriting "
                                                "the host sentinel (flag_host still < 0)")
                         break
+                if t_w is not None:
+                    self.flag_wait_s += time.perf_counter() - t_w
             elif ev is not None:
                 ev.synchronize()
             over = int(st.pop("flag_host").item())
