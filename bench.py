@@ -121,8 +121,9 @@ def parse_args():
     ap.add_argument("--no-sharded-proxy", action="store_true",
                     help="N = 1 default line: skip the 1-rank RCCL proxy of the 8192-per-rank sharded step (a child process)")
     ap.add_argument("--dp-max-rows", type=int, default=0,
-                    help="sharded runs: tables of at most this many rows are replicated (default 65536; 500 under --emulator, so "
-                         "that capped tables still take the row-wise exchange)")
+                    help="sharded runs: tables of at most this many rows are replicated (default: planner.pick_dp_max_rows -- the "
+                         "threshold with the least modelled wire + kernel time at the run's (or the projection's) world size; 500 under "
+                         "--emulator, so that capped tables still take the row-wise exchange; 65536 = the round-4 constant)")
     ap.add_argument("--no-spawn", action="store_true",
                     help="--gpus N > 1 outside torch.distributed.run: fail instead of re-launching under it")
     return ap.parse_args()
@@ -653,10 +654,19 @@ def main():
     else:
         from torcheasyrec_amd.sharding import ShardedDLRM
 
+        # which tables are replicated: the planner's wire + kernel arithmetic for the world the run stands for (its own, or the
+        # one a 1-rank proxy projects to) -- planner.pick_dp_max_rows; `--dp-max-rows N` pins it (65536: the round-4 constant)
+        from torcheasyrec_amd.planner import pick_dp_max_rows
+
+        W_plan = world if world > 1 else (args.projection_world or max(2, 65536 // max(B_local, 1)))
+        dp_pick, dp_costs = pick_dp_max_rows(rows, 16, W_plan, B_local, capacity_factor=args.capacity_factor)
+        dp_max_rows = args.dp_max_rows or (500 if emu else dp_pick)
+        dp_choice = {"world": W_plan, "picked": dp_pick, "used": dp_max_rows,
+                     "candidates": [c for c in dp_costs if c["dp_max_rows"] in (dp_pick, dp_max_rows, 0, 39060) or c["dp_max_rows"] == max(r for r in rows if r <= 65536)]}
         model = ShardedDLRM(criteo_tables(rows), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=sopt,
                             row_layout=args.row_layout, replicate_at_world1=args.replicate_small,
                             exchange=args.exchange, capacity_factor=args.capacity_factor,
-                            dp_max_rows=args.dp_max_rows or (500 if emu else 65536))
+                            dp_max_rows=dp_max_rows)
         parallelism = model.describe() + (f"; exchange: {args.exchange}" + (f" x{args.capacity_factor}" if args.exchange == "capacity" else ""))
     delta_tracker = None
     if args.delta_tracker:  # what train_config.delta_embedding_dump_config adds to a step (never part of the default line)
@@ -1024,6 +1034,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = B_global * args.steps / elapsed
 
+    if graphs is not None or replayed_graphs:
+        launch_desc = "hipGraph replay"
+    elif train_step is None:
+        launch_desc = "eager"
+    elif not args.step_graph:
+        launch_desc = "pipelined: input dist one batch ahead + hipGraph dense segment"
+    elif getattr(train_step, "native_steps", 0):
+        launch_desc = ("pipelined, native step driver: input dist one batch ahead as ONE hipGraph (ids all-to-all inside), the rest of the step ONE "
+                       "hipGraph (both all-to-alls and both all-reduces inside, on the library's own RCCL communicator), queued by tzr_step_run")
+    else:
+        launch_desc = (f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs "
+                       "for the rest of the step, RCCL calls between them (async, waited for on the stream)")
     out = {
         "metric": f"samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch {args.global_batch} "
                   + ("per GPU" if args.scaling == "weak" else "global"),
@@ -1042,12 +1064,7 @@ def main():
         "final_loss": final_loss,
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
-        "launch": ("hipGraph replay" if (graphs is not None or replayed_graphs) else
-                   (("pipelined, native step driver: input dist one batch ahead as ONE hipGraph (ids all-to-all inside), the rest of the step ONE hipGraph "
-                     "(both all-to-alls and both all-reduces inside, on the library's own RCCL communicator), queued by tzr_step_run"
-                     if getattr(train_step, "native_steps", 0) else
-                     f"pipelined: input dist one batch ahead + {'six' if getattr(train_step, 'overlap_collectives', False) else 'three'} hipGraphs for the rest of the step, RCCL calls between them (async, waited for on the stream)") if args.step_graph else
-                     "pipelined: input dist one batch ahead + hipGraph dense segment") if train_step is not None else "eager")),
+        "launch": launch_desc,
     }
     if sharded:
         out["exchange"] = dict(model.ebc.exchange_stats, kind=args.exchange)
@@ -1058,6 +1075,7 @@ def main():
         # rank of a `65536 / B_local`-rank job, at N > 1 the measured job itself
         Wp = args.projection_world or (world if world > 1 else max(2, 65536 // max(B_local, 1)))
         out["projection"] = xgmi_projection(model, B_local, Wp, ms_per_step, args.n1_ms or None, args.capacity_factor)
+        out["projection"]["dp_max_rows_choice"] = dp_choice
         out["projection"]["measured_on"] = (f"{world} rank(s); " + ("every collective is a self copy: wire time NOT in proxy_ms_per_step"
                                                                     if world == 1 else "wire time included in proxy_ms_per_step"))
     if rank == 0 and world == 1:

@@ -451,6 +451,59 @@ def plan_tables(tables: Sequence[TableSpec], topology: Topology, batch_size: int
     return {t.name: plan[t.name] for t in tables}
 
 
+# ---- replicate or exchange: the row count up to which a table is data_parallel ------------------------------------------------
+# A replicated table costs wire in proportion to its ROWS (its dense row-sum all-reduce: 2 (W-1)/W x rows x D x 4 bytes over
+# one xGMI link, whatever the batch), a row-wise one in proportion to its LOOKUPS (one id out, one row back, one gradient row
+# out per lookup, spread over all W-1 links) plus the exchange path's kernels per id.  sharding.make_plan takes the threshold
+# as `dp_max_rows`; round 4 passed the constant 65 536 (18 of DLRM-Criteo's 26 tables replicated: a 7.75 MB all-reduce, 89 of
+# the step's 100 us of wire at 8 ranks).  This is the arithmetic that picks it.
+#
+# Constants: 153 GB/s per xGMI link (MI355X_MICROARCH.md).  Kernel time of the two paths per 1 000 lookups: their AVERAGE
+# cost on the 8 192-per-rank step is 1.07 (exchange: bucketize 15 + rows gather 10 + pooled gather 6 + gradient rows 7 +
+# owners' update 33 us for 65 k ids) against 0.28 us (replicas: lookup 6 + row sums 26 + dense update 9 us for 147 k
+# lookups, profiles/r05q/timeline.txt) -- but these kernels are latency-bound at that size, and what the threshold moves is
+# the MARGINAL cost: the step measured 0.2636 / 0.2620 / 0.2647 ms with 8 / 13 / 15 exchanged features (profiles/r05s), i.e.
+# +0.02 us per 1 000 ids moved from the replicas to the exchange.  The marginal figures are what the model uses.
+XGMI_LINK_BYTES_PER_S = 153e9
+EXCHANGE_US_PER_1K_IDS = 0.30
+REPLICA_US_PER_1K_IDS = 0.28
+
+
+def dp_threshold_costs(rows: Sequence[int], dim: int, world: int, batch_per_rank: int, ids_per_sample: float = 1.0,
+                       capacity_factor: float = 1.25) -> List[dict]:
+    """For every candidate threshold (0 and each distinct row count): the modelled per-step microseconds of wire and of the
+    two lookup paths' kernels at `world` ranks.  [{dp_max_rows, replicated_tables, replicated_rows, wire_us, kernels_us, total_us}]"""
+    W = max(int(world), 1)
+    link = XGMI_LINK_BYTES_PER_S
+    out = []
+    for cand in [0] + sorted(set(int(r) for r in rows)):
+        rep = [r for r in rows if r <= cand]
+        exch = [r for r in rows if r > cand]
+        n_rep_ids = len(rep) * batch_per_rank * ids_per_sample
+        n_ex_ids = len(exch) * batch_per_rank * ids_per_sample
+        if W > 1:
+            ar = 2.0 * (W - 1) / W * sum(rep) * dim * 4.0 / link * 1e6
+            per_peer = capacity_factor * n_ex_ids / W
+            a2a = (8.0 * per_peer + 2 * 4.0 * dim * per_peer) / link * 1e6  # ids out, rows back, gradient rows out: every link at once
+        else:
+            ar = a2a = 0.0
+        kern = EXCHANGE_US_PER_1K_IDS * n_ex_ids / 1e3 + REPLICA_US_PER_1K_IDS * n_rep_ids / 1e3
+        out.append({"dp_max_rows": cand, "replicated_tables": len(rep), "replicated_rows": int(sum(rep)), "wire_us": ar + a2a,
+                    "replica_all_reduce_us": ar, "all_to_all_us": a2a, "kernels_us": kern, "total_us": ar + a2a + kern})
+    return out
+
+
+def pick_dp_max_rows(rows: Sequence[int], dim: int, world: int, batch_per_rank: int, ids_per_sample: float = 1.0,
+                     capacity_factor: float = 1.25) -> Tuple[int, List[dict]]:
+    """(threshold with the smallest modelled wire + kernel time, the table of all candidates).  One rank: everything that can
+    be replicated is local anyway -- the largest candidate below 2^16 rows, as before."""
+    costs = dp_threshold_costs(rows, dim, world, batch_per_rank, ids_per_sample, capacity_factor)
+    if world <= 1:
+        return 65536, costs
+    best = min(costs, key=lambda c: (c["total_us"], c["dp_max_rows"]))
+    return int(best["dp_max_rows"]), costs
+
+
 def plan_to_json(plan: Dict[str, dict]) -> str:
     """The `plan` file the reference writes next to a checkpoint (checkpoint_util.py:1152-1167):
     {table: {sharding_type, compute_kernel, ranks}}."""
