@@ -148,6 +148,9 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+SECONDARY_REPLAYS = 200  # secondary readings are timed over at least this many graph replays / kernel iterations
+
+
 def config_model_steps(dev, work_stream, steps: int = 20, only=None):
     """Train-step timing of the other BASELINE.json model families at their config's batch size (8192), built from a
     pipeline config TEXT through the same seam a tzrec user has (config.load_pipeline_spec -> rank_model.build_rank_model):
@@ -245,12 +248,13 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
                     after_graph_replay(model)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for i in range(steps):
+                n_rep = max(steps, SECONDARY_REPLAYS)
+                for i in range(n_rep):
                     gs[i % 4].replay()
                     after_graph_replay(model)  # (a zero-collision hash counts the step; its rounds run between replays when due)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t0
-                out.update(graph_ms_per_step=el / steps * 1e3, graph_value=B * steps / el)
+                out.update(graph_ms_per_step=el / n_rep * 1e3, graph_value=B * n_rep / el, graph_replays=n_rep)
                 del gs
             except Exception as e:  # a step that is not capturable stays with its eager reading
                 out["graph_error"] = repr(e)[:160]
@@ -299,7 +303,7 @@ def sharded_proxy(args) -> dict:
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--replicate-small", "--global-batch", "8192",
-           "--steps", str(max(args.steps, 40)), "--warmup", "12", "--no-cpu-baseline", "--no-e2e", "--projection-world", "8"]
+           "--steps", str(max(args.steps, SECONDARY_REPLAYS)), "--warmup", "12", "--no-cpu-baseline", "--no-e2e", "--projection-world", "8"]
     try:
         pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                             env=dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300)))
@@ -372,6 +376,10 @@ class _Timers:
         ps = self.pairs.get(name, [])
         return float(np.mean([a.elapsed_time(b) for a, b in ps])) if ps else None
 
+    def median_ms(self, name):
+        ps = self.pairs.get(name, [])
+        return float(np.median([a.elapsed_time(b) for a, b in ps])) if ps else None
+
 
 def enable_tunable_gemm():
     """The MLPs stay on PyTorch.  Its default hipBLASLt heuristic picks poor
@@ -397,7 +405,7 @@ def enable_tunable_gemm():
 
 def interaction_top_rooflines(dev, B):
     """tzr_dot_interaction_top_fwd / _bwd / _wgrad at the DLRM-Criteo shape (27 rows of 16, first top layer 783 -> 64), as the
-    step launches them (the forward keeps no z), alone: median of 20 launches, HIP events on the launching stream.  The
+    step launches them (the forward keeps no z), alone: median of 200 launches, HIP events on the launching stream.  The
     weight gradient's flops are the product's 2 x 783 x 64 per sample: its rebuilt pair blocks (2 x 3 x 16 x 16 x 16 more) and
     its second launch (the sum over the batch slices) are overhead, inside `launch_ms`."""
     from torcheasyrec_amd import _lib
@@ -437,13 +445,13 @@ def interaction_top_rooflines(dev, B):
             fn()
         torch.cuda.synchronize()
         torch.cuda._sleep(int(1e7))
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(SECONDARY_REPLAYS)]
         for a_, b_ in ev:
             a_.record()
             fn()
             b_.record()
         torch.cuda.synchronize()
-        ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)[10]
+        ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)[len(ev) // 2]
         out[name] = {"kernel": kernels[name], "launch_ms": ms, "algorithmic_flop": flop,
                      "achieved": flop / (ms * 1e-3) / 1e12, "frac": flop / (ms * 1e-3) / 157.3e12}
     return out
@@ -918,10 +926,11 @@ def main():
         ebc_._timers = None
         ab = [algorithmic_bytes(hv, Bl, rows, optimizer=optimizer) for hv in host_values]
         nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
-        f, p_, a_ = tm.mean_ms("fwd"), tm.mean_ms("plan") or 0.0, tm.mean_ms("apply")  # (no plan launch: tzr_pooled_bwd_direct)
+        stat = tm.mean_ms if iters <= 10 else tm.median_ms  # (long secondary runs: the median, so that a host gap late in the queue does not enter)
+        f, p_, a_ = stat("fwd"), stat("plan") or 0.0, stat("apply")  # (no plan launch: tzr_pooled_bwd_direct)
         return {"fwd_ms": f, "bwd_plan_ms": p_, "bwd_apply_ms": a_, "algorithmic_bytes": nbytes,
                 "backward": "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else "tzr_pooled_bwd_plan (4 launches) + tzr_pooled_bwd_apply",
-                "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
+                "iterations": iters, "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
 
     # N = 1: the other readings BASELINE.json / the north star ask for, on the same box in the same process:
     # config 2 (examples/dlrm_criteo.config at its own batch_size 8192: whole step + embedding stages), the
@@ -952,14 +961,14 @@ def main():
             g2[i % 4].replay()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        n2 = max(args.steps, 30)
+        n2 = max(args.steps, SECONDARY_REPLAYS)
         for i in range(n2):
             g2[i % 4].replay()
         torch.cuda.synchronize()
         e2_ = time.perf_counter() - t1
         secondary["config2_batch8192"] = {"config": "examples/dlrm_criteo.config, 1 GPU, batch 8192 (BASELINE.json configs[1])",
-                                          "value": B2 * n2 / e2_, "unit": "samples/s", "ms_per_step": e2_ / n2 * 1e3,
-                                          "embedding": embedding_stages(ebc, [b[1] for b in b2], h2, B2, "adagrad")}
+                                          "value": B2 * n2 / e2_, "unit": "samples/s", "ms_per_step": e2_ / n2 * 1e3, "replays": n2,
+                                          "embedding": embedding_stages(ebc, [b[1] for b in b2], h2, B2, "adagrad", iters=SECONDARY_REPLAYS)}
         del g2
         # (b) Zipf(1.05) ids at the headline batch: embedding stages
         bz, hz = [], []
@@ -968,7 +977,7 @@ def main():
             hz.append(k_.values().numpy())
             bz.append(k_.to(dev))
         secondary["zipf_ids_batch65536"] = {"config": "ids Zipf(1.05) clipped to the table (SURVEY 8d secondary distribution)",
-                                            "embedding": embedding_stages(ebc, bz, hz, B_global, "adagrad")}
+                                            "embedding": embedding_stages(ebc, bz, hz, B_global, "adagrad", iters=SECONDARY_REPLAYS)}
         del bz
         # (c) row-wise Adagrad, the optimizer the north star names: its own collection (weights [rows, 16] + [rows] state)
         try:
@@ -978,7 +987,7 @@ def main():
                                             groups={"sparse": SPARSE_KEYS})
             secondary["rowwise_adagrad_batch65536"] = {
                 "config": "fused row-wise Adagrad (protos/optimizer.proto:133-139), uniform ids",
-                "embedding": embedding_stages(ebc_rw, [b[1] for b in batches[:4]], host_vals[:4], B_global, "rowwise_adagrad")}
+                "embedding": embedding_stages(ebc_rw, [b[1] for b in batches[:4]], host_vals[:4], B_global, "rowwise_adagrad", iters=SECONDARY_REPLAYS)}
             del ebc_rw
         except Exception as e:  # e.g. not enough free HBM next to the main model
             secondary["rowwise_adagrad_batch65536"] = {"error": repr(e)[:200]}
