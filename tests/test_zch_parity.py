@@ -325,3 +325,17 @@ def test_zch_map_stays_consistent_under_churn(dev):
         hit = rng.choice(list(resident.values()), size=min(20, len(resident)), replace=False)
         m.last_iter[torch.from_numpy(hit).to(dev)] = it
     assert seen_rebuilds >= 1 and seen_inplace >= 10  # both the in-place update and the rebuild ran
+
+
+def test_first_zero_rows_equals_the_listing_of_all():
+    """the windowed search for the first n rows without a keeper (zch._first_zero_rows) = nonzero(flags == 0)[:n]"""
+    from torcheasyrec_amd.zch import _first_zero_rows
+
+    g = torch.Generator().manual_seed(5)
+    for Z, p_zero in ((1, 1.0), (37, 0.0), (500, 0.02), (500, 0.5), (4096, 0.9), (4096, 0.001)):
+        flags = (torch.rand(Z, generator=g) >= p_zero).to(torch.uint8)
+        for n in (0, 1, 3, 50, Z, Z + 7):
+            want = torch.nonzero(flags == 0).squeeze(1)[:n]
+            for mw in (1, 8, 1 << 20):
+                got = _first_zero_rows(flags, n, min_window=mw)
+                assert torch.equal(got, want), (Z, p_zero, n, mw)

@@ -546,9 +546,10 @@ class EmbeddingBagCollection(nn.Module):
             ws = self.plan_backward(kjt, dst_names)
             ev = torch.cuda.Event()
             ev.record()
-        for t in (kjt.values(), kjt.offsets_or_none()):
-            if t is not None:
-                t.record_stream(self._side_stream)
+        if not torch.cuda.is_current_stream_capturing():  # (a captured step owns its buffers for the graph's life)
+            for t in (kjt.values(), kjt.offsets_or_none()):
+                if t is not None:
+                    t.record_stream(self._side_stream)
         kjt._tzr_plan = (id(self), dst_names, ws, ev)  # type: ignore[attr-defined]
 
     def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
@@ -562,7 +563,8 @@ class EmbeddingBagCollection(nn.Module):
             ws = cached[2]
             if cached[3] is not None:
                 torch.cuda.current_stream(self._device).wait_event(cached[3])
-                ws.record_stream(torch.cuda.current_stream(self._device))
+                if not torch.cuda.is_current_stream_capturing():
+                    ws.record_stream(torch.cuda.current_stream(self._device))
         else:
             ws = self.plan_backward(kjt, dst_names)
         layout = self._layout_for(dst_names)

@@ -60,6 +60,28 @@ def probabilistic_threshold_filter(id_counts: torch.Tensor, per_id_probability: 
     return score > threshold, threshold
 
 
+def _first_zero_rows(flags: torch.Tensor, n: int, min_window: int = 1 << 20) -> torch.Tensor:
+    """`torch.nonzero(flags == 0).squeeze(1)[:n]` without materialising every zero position first: a 200 M-row table that is
+    mostly EMPTY has ~200 M rows without a keeper, and listing them all (1.6 GB of int64 + the allocation) was 90 of the
+    97-128 ms of an admission round at BASELINE config 5's scale (profiles/r05u), to keep the first few hundred thousand.
+    Windows of growing size until n rows are found: one window on a sparse table, log2 windows = one pass on a full one."""
+    Z = flags.numel()
+    if n <= 0 or Z == 0:
+        return torch.zeros(0, dtype=torch.int64, device=flags.device)
+    out, got, a, step = [], 0, 0, max(4 * n, min_window)
+    while a < Z and got < n:
+        b = min(Z, a + step)
+        f = torch.nonzero(flags[a:b] == 0).squeeze(1)
+        if f.numel():
+            f = f[:n - got]
+            out.append(f + a if a else f)
+            got += f.numel()
+        a, step = b, step * 2
+    if not out:
+        return torch.zeros(0, dtype=torch.int64, device=flags.device)
+    return torch.cat(out) if len(out) > 1 else out[0]
+
+
 def zch_config_from_msg(z) -> "ZchConfig":
     """`zch {...}` block of a feature config (protos/feature.proto:31-47) -> ZchConfig.  The
     admission filter is a lambda STRING evaluated with the documented helpers in scope, exactly as
@@ -234,7 +256,7 @@ class ManagedCollisionModule:
         # ... into admission order: score descending (a candidate's age is 1: its score is its count, or 1 for lru)
         if cfg.policy != "lru" and kept_new.numel() > 1:
             kept_new = kept_new[torch.sort(new_cnt[kept_new], descending=True, stable=True).indices]
-        free = torch.nonzero(row_kept == 0).squeeze(1)[:kept_new.numel()]  # ascending rows
+        free = _first_zero_rows(row_kept, kept_new.numel())  # ascending rows
         old = self.row_ids[free]
         admitted = new_ids[kept_new].contiguous()
         if self._event_trackers:
