@@ -387,6 +387,27 @@ int tzr_head_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x,
                  const float* d_w, int64_t B, int N, float* d_grad_x, int64_t grad_x_stride,
                  float* d_grad_wb, void* ws, size_t ws_bytes, void* stream);
 
+/* tzr_head_bwd when x is the output of a ReLU (the last hidden layer of the attention MLP in front of DIN's one-unit score
+ * layer, tzrec/modules/sequence.py:101-128): d_grad[b,:] = gy[b] * w * (x[b,:] > 0) -- the gradient at the hidden layer's
+ * pre-activation --, d_sums = [sum_b gy[b] x[b,:] (N) | sum_b gy[b], 0, 0, 0 | sum_b d_grad[b,:] (N)]: the score layer's weight
+ * and bias gradient and the hidden layer's bias gradient from one pass over x.  Replaces tzr_head_bwd + tzr_relu_bwd_colsum. */
+size_t tzr_head_bwd_relu_workspace(int64_t B, int N);
+int tzr_head_bwd_relu(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                      const float* d_w, int64_t B, int N, float* d_grad, int64_t grad_stride,
+                      float* d_sums, void* ws, size_t ws_bytes, void* stream);
+
+/* Input gradient of a Linear layer chained with the ReLU mask and bias gradient of the layer below it (autograd of
+ * Linear -> ReLU -> Linear, tzrec/modules/mlp.py:58-83), one launch on the matrix cores (exact fp32):
+ *   d_grad_out[n,h] = (sum_k d_grad_in[n,k] * d_w[k,h]) * (d_y[n,h] > 0),  d_colsum[h] = sum_n d_grad_out[n,h].
+ * d_w = the upper layer's weight [K, H] row-major (nn.Linear's own layout: out_features x in_features), d_y = the lower
+ * layer's ReLU output.  d(loss)/d(y) is never written.  Shapes: tzr_linear_bwd_relu_supported(K, H) (K in {16, 32, 64},
+ * H in {64, 128, 256}); strides in floats, multiples of 4; 16-byte aligned pointers.  Deterministic. */
+int tzr_linear_bwd_relu_supported(int K, int H);
+size_t tzr_linear_bwd_relu_workspace(int64_t N, int H);
+int tzr_linear_bwd_relu(const float* d_grad_in, int64_t grad_in_stride, const float* d_w, int64_t w_stride,
+                        const float* d_y, int64_t y_stride, int64_t N, int K, int H, float* d_grad_out,
+                        int64_t grad_out_stride, float* d_colsum, void* ws, size_t ws_bytes, void* stream);
+
 #define TZR_ADAM_MAX_TENSORS 32
 typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, float32 */
   uint64_t param, grad, exp_avg, exp_avg_sq;

@@ -1,6 +1,6 @@
 // Identity of the CPU lane-emulator build of the kernels (tests only).
 extern "C" const char* tzr_backend(void) { return "emu"; }
-extern "C" int tzr_abi_version(void) { return 10; }
+extern "C" int tzr_abi_version(void) { return 11; }
 
 // The native step driver (csrc/step_driver.hip: hipGraphLaunch + RCCL, host-only code) has nothing to emulate: the
 // emulator library exports its entry points so that the binding table loads, and refuses them.

@@ -135,6 +135,54 @@ def test_head_bwd_matches_torch(dev, B, N):
     assert gx2 is None
 
 
+@pytest.mark.parametrize("B,N", [(1, 4), (999, 32), (3000, 64), (70000, 8)])
+def test_head_bwd_relu_matches_torch(dev, B, N):
+    """the score layer's backward chained with the mask + bias gradient of the ReLU layer below it (tzr_head_bwd_relu)"""
+    from torcheasyrec_amd.dense import head_bwd_relu
+
+    g = torch.Generator().manual_seed(B * 5 + N)
+    x = torch.relu(torch.randn(B, N, generator=g))
+    w = torch.randn(1, N, generator=g)
+    gy = torch.randn(B, 1, generator=g) / B
+    got, gw, gb, col = head_bwd_relu(gy.to(dev), x.to(dev), w.to(dev))
+    ref = (gy @ w) * (x > 0)
+    assert got.shape == (B, N) and gw.shape == (1, N) and gb.shape == (1,) and col.shape == (N,)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(gw.cpu().double(), gy.double().t() @ x.double(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(gb.cpu().double(), gy.double().sum(0), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(col.cpu().double(), ref.double().sum(0), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,K,H,cap", [(1, 64, 256, 0), (16, 16, 64, 0), (37, 32, 128, 0), (1000, 64, 256, 0), (1000, 64, 256, 3),
+                                        (515, 64, 64, 2), (2049, 16, 256, 5), (300, 32, 64, 1), (70000, 64, 128, 0)])
+def test_linear_bwd_relu_matches_torch(dev, N, K, H, cap):
+    """(g_in W) masked by the ReLU below + its column sums in one launch (tzr_linear_bwd_relu, exact-fp32 MFMA) against the three
+    torch ops it replaces; `cap` workgroups: many tiles per workgroup (the double-buffered tile loop) on small inputs"""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.dense import linear_bwd_relu, linear_bwd_relu_supported
+
+    g = torch.Generator().manual_seed(N + K + H)
+    y = torch.relu(torch.randn(N, H, generator=g))
+    W = torch.randn(K, H, generator=g) / K ** 0.5
+    gi_full = torch.randn(N, K + 8, generator=g)
+    gi = gi_full[:, 4:K + 4] if N % 2 else gi_full[:, :K]  # row-strided input
+    assert linear_bwd_relu_supported(gi.to(dev), W.to(dev))
+    assert not linear_bwd_relu_supported(gi.to(dev), torch.randn(K, 96).to(dev))
+    _lib.check(_lib.lib().tzr_tune(b"linear_bwd_wg", cap), "tzr_tune")
+    try:
+        got, col = linear_bwd_relu(gi.to(dev), W.to(dev), y.to(dev))
+        again, col2 = linear_bwd_relu(gi.to(dev), W.to(dev), y.to(dev))
+    finally:
+        _lib.check(_lib.lib().tzr_tune(b"linear_bwd_wg", 0), "tzr_tune")
+    ref = (gi.double() @ W.double()) * (y > 0)
+    scale = float(ref.abs().max()) + 1e-30
+    assert float((got.cpu().double() - ref).abs().max()) <= 2e-6 * scale  # fp32 products, 64-term sums
+    assert torch.equal((got != 0).cpu() | (ref == 0), torch.ones(N, H, dtype=torch.bool))  # the mask itself is exact
+    assert torch.equal(got.cpu()[y == 0], torch.zeros(int((y == 0).sum())))
+    torch.testing.assert_close(col.cpu().double(), ref.sum(0), rtol=1e-4, atol=2e-6 * scale * N ** 0.5)
+    assert torch.equal(got, again) and torch.equal(col, col2)  # fixed summation order
+
+
 def test_mlp_proto_fields_build_the_reference_perceptron():
     """use_bn / use_ln / dropout_ratio / activation / bias of the MLP proto (tzrec/protos/module.proto:4-17)
     reach the module (config-built towers used to read hidden_units only): same layer sequence as

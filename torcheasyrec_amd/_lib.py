@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 10  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 11  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -172,6 +172,11 @@ _SIGNATURES = {
     "tzr_relu_bwd_colsum": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_head_bwd_workspace": (_sz, [_i64, _i32]),
     "tzr_head_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_head_bwd_relu_workspace": (_sz, [_i64, _i32]),
+    "tzr_head_bwd_relu": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_linear_bwd_relu_supported": (_i32, [_i32, _i32]),
+    "tzr_linear_bwd_relu_workspace": (_sz, [_i64, _i32]),
+    "tzr_linear_bwd_relu": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_mlp_workspace": (_sz, []),
     "tzr_mlp2_fwd": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp]),
     "tzr_mlp2_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,

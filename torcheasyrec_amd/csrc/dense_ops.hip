@@ -318,6 +318,104 @@ extern "C" int tzr_head_bwd(const float* d_grad_y, int64_t grad_y_stride, const 
   return TZR_OK;
 }
 
+// The same layer when x is the OUTPUT OF A RELU (the last hidden layer of an MLP in front of a one-unit score layer, e.g.
+// DIN's attention MLP, /root/reference/tzrec/modules/sequence.py:101-128): the input gradient is masked on the way out,
+// g[b, n] = gy[b] * w[n] * (x[b, n] > 0), and its column sums -- the bias gradient of the layer that produced x -- come
+// from the same pass.  Saves writing gx unmasked and tzr_relu_bwd_colsum's re-read of gx and x.
+// parts row: [gw (N) | gb, 0, 0, 0 | colsum g (N)]
+__global__ __launch_bounds__(RB_THREADS) void tzr_head_bwd_relu_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ x, int64_t x_stride,
+    const float* __restrict__ w, int64_t B, int N, int64_t rows_per_wg, float* __restrict__ g,
+    int64_t g_stride, float* __restrict__ parts /*[n_wg][2 N + 4]*/) {
+  __shared__ float4 red[RB_THREADS];
+  __shared__ float4 redc[RB_THREADS];
+  __shared__ float redb[RB_THREADS];
+  const int N4 = N >> 2;
+  const int rl = RB_THREADS / N4;
+  const int c = threadIdx.x % N4;
+  const int r = threadIdx.x / N4;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = min(B, lo + rows_per_wg);
+  float4 acc = tzr_zero4(), accc = tzr_zero4();
+  float accb = 0.f;
+  if (r < rl) {
+    const float4 w4 = tzr_ld4(w + 4 * c);
+    for (int64_t b0 = lo + r; b0 < hi; b0 += (int64_t)rl * RB_UNROLL) {
+      float4 v[RB_UNROLL];
+      float gs[RB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        v[u] = b < hi ? tzr_ld4(x + b * x_stride + 4 * c) : tzr_zero4();
+        gs[u] = b < hi ? gy[b * gy_stride] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        if (b >= hi) continue;
+        float4 o;
+        o.x = v[u].x > 0.f ? gs[u] * w4.x : 0.f;
+        o.y = v[u].y > 0.f ? gs[u] * w4.y : 0.f;
+        o.z = v[u].z > 0.f ? gs[u] * w4.z : 0.f;
+        o.w = v[u].w > 0.f ? gs[u] * w4.w : 0.f;
+        tzr_st4(g + b * g_stride + 4 * c, o);
+        accc = tzr_add4(accc, o);
+        acc = tzr_fma4(gs[u], v[u], acc);
+        if (c == 0) accb += gs[u];
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  redc[threadIdx.x] = accc;
+  redb[threadIdx.x] = accb;
+  __syncthreads();
+  if (r == 0 && c < N4) {
+    float4 t = red[c], tc = redc[c];
+    for (int k = 1; k < rl; ++k) {
+      t = tzr_add4(t, red[k * N4 + c]);
+      tc = tzr_add4(tc, redc[k * N4 + c]);
+    }
+    float* const row = parts + (size_t)blockIdx.x * (2 * N + 4);
+    tzr_st4(row + 4 * c, t);
+    tzr_st4(row + N + 4 + 4 * c, tc);
+    if (c == 0) {
+      float tb = 0.f;
+      for (int k = 0; k < rl; ++k) tb += redb[k * N4];
+      row[N] = tb;
+      row[N + 1] = row[N + 2] = row[N + 3] = 0.f;
+    }
+  }
+}
+
+extern "C" size_t tzr_head_bwd_relu_workspace(int64_t B, int N) {
+  (void)B;
+  return (size_t)RB_MAX_WG * (size_t)(2 * N + 4) * sizeof(float) + 256;
+}
+
+extern "C" int tzr_head_bwd_relu(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                 const float* d_w, int64_t B, int N, float* d_grad, int64_t grad_stride,
+                                 float* d_sums /*[2 N + 4]: gw | gb, 0, 0, 0 | colsum*/, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_grad_y || !d_x || !d_w || !d_grad || !d_sums || B <= 0 || N <= 0) return TZR_ERR_INVALID;
+  if ((N & 3) || N > 4 * RB_THREADS || (x_stride & 3) || (grad_stride & 3)) return TZR_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_head_bwd_relu_workspace(B, N) - 256)
+    return TZR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rl = RB_THREADS / (N >> 2);
+  int64_t rows_per_wg = (int64_t)rl * RB_UNROLL;
+  int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  if (n_wg > RB_MAX_WG) {
+    rows_per_wg = ((B + RB_MAX_WG - 1) / RB_MAX_WG + rl * RB_UNROLL - 1) / (rl * RB_UNROLL) * (rl * RB_UNROLL);
+    n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  }
+  float* parts = static_cast<float*>(ws);
+  hipLaunchKernelGGL(tzr_head_bwd_relu_kernel, dim3((unsigned)n_wg), dim3(RB_THREADS), 0, s, d_grad_y, grad_y_stride,
+                     d_x, x_stride, d_w, B, N, rows_per_wg, d_grad, grad_stride, parts);
+  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((2 * N + 4 + 63) / 64)), dim3(RB_FIN_THREADS), 0, s,
+                     parts, (int)n_wg, 2 * N + 4, d_sums);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------
 
 struct AdamTable {

@@ -22,6 +22,7 @@ extern int g_tzr_it_stagger;
 extern int g_tzr_wg_debug;
 extern int g_tzr_it_fwd_stagger;
 extern int g_tzr_mlp_mfma;
+extern int g_tzr_linear_bwd_wg;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
@@ -71,6 +72,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "mlp_mfma")) {
     g_tzr_mlp_mfma = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "linear_bwd_wg")) {
+    g_tzr_linear_bwd_wg = value;
     return TZR_OK;
   }
   if (!strcmp(name, "it_stagger")) {

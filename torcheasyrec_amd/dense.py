@@ -83,6 +83,43 @@ def head_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_g
     return gx, wb[:N].unsqueeze(0), wb[N:N + 1]
 
 
+def head_bwd_relu(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor):
+    """Backward of Linear(in, 1) on the output x of a ReLU layer, chained with that layer's mask and bias gradient
+    (tzr_head_bwd_relu): (g = grad_y * w * (x > 0) [B, in], grad_weight [1, in], grad_bias [1], column sums of g [in])."""
+    B, N = x.shape
+    gy = grad_y.reshape(B)
+    xs = _rows16(x)
+    g = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    sums = torch.empty(2 * N + 4, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_head_bwd_relu_workspace(B, N), x.device)
+    _lib.check(L.tzr_head_bwd_relu(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight.reshape(-1)), B, N,
+                                   _lib.ptr(g), g.stride(0), _lib.ptr(sums), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device)),
+               "tzr_head_bwd_relu")
+    return g, sums[:N].unsqueeze(0), sums[N:N + 1], sums[N + 4:]
+
+
+def linear_bwd_relu_supported(g_in: torch.Tensor, weight: torch.Tensor) -> bool:
+    K, H = weight.shape
+    return bool(g_in.shape[0] > 0 and weight.stride(1) == 1 and _lib.lib().tzr_linear_bwd_relu_supported(K, H))
+
+
+def linear_bwd_relu(g_in: torch.Tensor, weight: torch.Tensor, y: torch.Tensor):
+    """((g_in @ weight) * (y > 0), its column sums) in one launch (tzr_linear_bwd_relu): the input gradient of the Linear layer
+    with `weight` [K, H] chained with the ReLU mask and bias gradient of the layer that produced y [N, H]."""
+    N, K = g_in.shape
+    H = weight.shape[1]
+    gi, ys = _rows16(g_in), _rows16(y)
+    g = torch.empty(N, H, dtype=torch.float32, device=y.device)
+    col = torch.empty(H, dtype=torch.float32, device=y.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_linear_bwd_relu_workspace(N, H), y.device)
+    _lib.check(L.tzr_linear_bwd_relu(_lib.ptr(gi), gi.stride(0), _lib.ptr(weight), weight.stride(0), _lib.ptr(ys), ys.stride(0), N, K, H,
+                                     _lib.ptr(g), g.stride(0), _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)),
+               "tzr_linear_bwd_relu")
+    return g, col
+
+
 # ---- small layer stacks as whole-stack kernels (csrc/mlp_ops.hip) -------------------------------------------------
 MLP2_MAX = (32, 64, 32)  # input, hidden, output widths tzr_mlp2_* take
 TAIL_MAX = (64, 32)      # input, hidden widths tzr_mlp_tail takes

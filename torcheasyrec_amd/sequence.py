@@ -371,7 +371,7 @@ class _DinTowerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        from .dense import head_bwd, relu_bwd_colsum, weight_grad
+        from .dense import head_bwd_relu, linear_bwd_relu, linear_bwd_relu_supported, relu_bwd_colsum, weight_grad
 
         max_len, nl, has_b3 = ctx.cfg
         values, query, offsets, seg, p, w3, X = ctx.saved_tensors[:7]
@@ -388,23 +388,29 @@ class _DinTowerFn(torch.autograd.Function):
                                       _lib.ptr(offsets), B, max_len, _lib.ptr(ds), _lib.ptr(dkv), dkv.stride(0), stream), "tzr_din_attn_bwd")
         h = hs[-1]
         H = h.shape[1]
-        if Np and H % 4 == 0 and H <= 1024:
-            dh, dw3, db3 = head_bwd(ds[:Np], h, w3, True)
+        kernels = bool(Np) and all(y.shape[1] % 4 == 0 and y.shape[1] <= 1024 for y in hs)
+        # the score layer's backward chained with the last hidden layer's mask + bias gradient (tzr_head_bwd_relu)
+        if kernels:
+            g, dw3, db3, gb = head_bwd_relu(ds[:Np], h, w3)
         else:
             dsn = ds[:Np]
             dh, dw3, db3 = dsn.unsqueeze(1) * w3.reshape(1, -1), (h * dsn.unsqueeze(1)).sum(0, keepdim=True), dsn.sum().reshape(1)
+            g = torch.ops.aten.threshold_backward(dh, h, 0.0)
+            gb = g.sum(0)
         grads_wb = [None] * (2 * nl)
-        for i in range(nl - 1, -1, -1):
-            y = hs[i]
-            if Np and y.shape[1] % 4 == 0 and y.shape[1] <= 1024:
-                g, gb = relu_bwd_colsum(dh, y)
-            else:
-                g = torch.ops.aten.threshold_backward(dh, y, 0.0)
-                gb = g.sum(0)
+        for i in range(nl - 1, -1, -1):  # g = the gradient at layer i's pre-activation, gb = its column sums
             xin = hs[i - 1] if i > 0 else X[:Np]
             grads_wb[2 * i] = weight_grad(g, xin) if Np else torch.zeros_like(Ws[i])
             grads_wb[2 * i + 1] = gb
-            dh = g @ Ws[i]
+            if i == 0:
+                dh = g @ Ws[0]
+            elif kernels and linear_bwd_relu_supported(g, Ws[i]):
+                g, gb = linear_bwd_relu(g, Ws[i], hs[i - 1])  # (g W_i) masked by layer i - 1's ReLU + its column sums: d(loss)/d(h) never written
+            elif kernels:
+                g, gb = relu_bwd_colsum(g @ Ws[i], hs[i - 1])
+            else:
+                g = torch.ops.aten.threshold_backward(g @ Ws[i], hs[i - 1], 0.0)
+                gb = g.sum(0)
         dWf = grads_wb[0]  # [H1, 3 D] = [d(Wb - Wc) | dWd | d(Wa + Wc)]  ->  [dWa | dWb | dWc | dWd]
         grads_wb[0] = torch.cat([dWf[:, 2 * D:], dWf[:, :D], dWf[:, 2 * D:] - dWf[:, :D], dWf[:, D:2 * D]], dim=1)
         dX = dh.contiguous()
