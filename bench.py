@@ -84,12 +84,13 @@ def parse_args():
     ap.add_argument("--exchange", choices=["auto", "exact", "capacity"], default="auto",
                     help="sharded runs: 'capacity' = fixed-size message slices (one ids all-to-all, no counts through the "
                          "host); a batch that overflows is redone through the exact exchange.  'auto': capacity + "
-                         "--step-graph when the per-rank batch is <= 16384 (the launch-bound regime: 0.47 vs 0.65 ms at 8192 "
-                         "on the 1-rank proxy, but 1.13 vs 1.09 ms at 65536 -- profiles/r02q), else exact")
+                         "--step-graph when the per-rank batch is <= 65536 (1-rank proxy with the native step driver: 0.26-0.28 vs "
+                         "0.47 ms at 8192, 0.77 vs 0.86 ms at 65536 -- profiles/r05s, r05v), else exact")
     ap.add_argument("--capacity-factor", type=float, default=1.25)
     ap.add_argument("--step-graph", action="store_true",
                     help="sharded runs with --exchange capacity: everything after the input dist (lookups, dense segment, "
-                         "sparse + dense optimizers) replayed from three hipGraphs per pipeline slot, RCCL calls between them")
+                         "sparse + dense optimizers) replayed from ONE hipGraph per pipeline slot with the RCCL calls captured inside (native step driver; "
+                         "--no-native-driver: six graphs, RCCL calls between them)")
     ap.add_argument("--overlap-collectives", choices=["auto", "on", "off"], default="auto",
                     help="--step-graph runs: five graphs with the gradient all-to-all / all-reduces issued async between them "
                          "(auto = on; off: three graphs, every collective waited for where it is issued)")
@@ -264,6 +265,16 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
             name_t = next(iter(mc.modules_by_table))
             mod = mc.modules_by_table[name_t]
             cand = mc.pending_candidates(name_t)
+            # a throwaway module (half as many rows as there are candidates: it admits AND evicts) runs two rounds first: the FIRST use of torch.sort / unique / nonzero and of the selection
+            # kernels in a process loads their code objects -- 40-90 ms each, 300 of the 302 ms of a first round and nothing of
+            # the second (profiles/r05z/zch_round_profile.txt) -- a cost of the process, not of a round every 1 000 steps
+            from torcheasyrec_amd.zch import ManagedCollisionModule, ZchConfig
+
+            n_c = max(int(cand.numel()), 6000)  # (same candidate count: torch picks its sort / select kernels by size)
+            toy = ManagedCollisionModule(ZchConfig(max(4096, n_c // 2), 1, mod.cfg.policy, mod.cfg.decay_exponent), dev)
+            for it in (1, 2):
+                toy.update_and_evict(torch.randint(0, 1 << 40, (n_c,), device=dev), it)
+            del toy
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             changed = mod.update_and_evict(cand, mc._iter)
@@ -648,7 +659,7 @@ def main():
     B_global = args.global_batch if args.scaling == "strong" else args.global_batch * world
     B_local = B_global // world
     if args.exchange == "auto":
-        small = sharded and not args.no_pipeline and (not args.no_graph or emu) and B_local <= 16384
+        small = sharded and not args.no_pipeline and (not args.no_graph or emu) and B_local <= 65536  # (profiles/r05v: 0.77 vs 0.86 ms at 65 536 per rank)
         args.exchange = "capacity" if small else "exact"
         args.step_graph = args.step_graph or small
     if args.step_graph and args.exchange != "capacity":

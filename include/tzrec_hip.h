@@ -287,9 +287,15 @@ int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables, const TzrFeature
  * (tzr_tune "bwd_direct": 1 = any size, -1 = never); callers take the planned pair then.  Replaces the same fbgemm pieces
  * as the pair (transpose_embedding_input + split_embedding_backward_codegen_*_exact, tzrec/modules/embedding.py:930,
  * tzrec/main.py:774-781).
+ * grad_mode | TZR_GRAD_HOT_ROWS: the caller expects a row with more lookups than fit a workgroup's LDS (1 280) -- the shared
+ * row of a zero-collision hash's unseen ids (tzrec/features/feature.py:693-736: row zch_size - 1), a default id: such a row,
+ * when it is the mode of the table's first 16 ids, is summed by ALL of the table's workgroups (a slice of the positions each,
+ * partial sums added in slice order) instead of by its range's workgroup alone (140 -> 45 us at 8 192 lookups, 95 % on one
+ * row).  Without the flag, or when the sample misses, the row is still handled correctly, only slower.
  * `ws`: tzr_pooled_bwd_direct_workspace bytes, ZERO-FILLED by the caller before its first use (arrival counters of the
  * workgroups that share a row of a tiny table; every launch leaves them zero, so the buffer can be kept and reused --
  * one buffer per stream of launches). */
+#define TZR_GRAD_HOT_ROWS 0x100
 int tzr_pooled_bwd_direct_supported(int64_t n_positions, int n_feats, int n_tables, int uniform_bag_len,
                                     int grad_mode);
 size_t tzr_pooled_bwd_direct_workspace(int64_t n_positions, int n_tables, int max_dim);
@@ -395,6 +401,47 @@ size_t tzr_head_bwd_relu_workspace(int64_t B, int N);
 int tzr_head_bwd_relu(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
                       const float* d_w, int64_t B, int N, float* d_grad, int64_t grad_stride,
                       float* d_sums, void* ws, size_t ws_bytes, void* stream);
+
+/* The mixing step of a multi-gate mixture of experts (tzrec/modules/mmoe.py:63-76) for ALL tasks in one launch:
+ *   out_t[b,:] = sum_e softmax(logits_t[b,:])_e * expert_e[b,:]
+ * forward: reads logits / expert, writes out and probs (the softmax, [B, n_experts] contiguous per task, kept for the backward);
+ * backward: reads grad_out / expert / probs, writes d_expert_e[b,:] = sum_t probs_t[b,e] * grad_out_t[b,:] (the sum over the
+ * tasks included) and d_logits_t (softmax backward of <grad_out_t[b,:], expert_e[b,:]>).  Nothing is stacked: every expert is its
+ * own [B, H] buffer.  H multiple of 4; float pointers 16-byte aligned, row strides multiples of 4 (logits / d_logits: any). */
+#define TZR_MOE_MAX_EXPERTS 8
+#define TZR_MOE_MAX_TASKS 4
+typedef struct TzrMoeMix {
+  int64_t B;
+  int32_t H, n_experts, n_tasks, reserved;
+  uint64_t expert[TZR_MOE_MAX_EXPERTS];          /* const float* [B, H]                       */
+  int64_t expert_stride[TZR_MOE_MAX_EXPERTS];
+  uint64_t d_expert[TZR_MOE_MAX_EXPERTS];        /* float* [B, H]            (backward)       */
+  int64_t d_expert_stride[TZR_MOE_MAX_EXPERTS];
+  uint64_t logits[TZR_MOE_MAX_TASKS];            /* const float* [B, n_experts]   (forward)   */
+  int64_t logits_stride[TZR_MOE_MAX_TASKS];
+  uint64_t probs[TZR_MOE_MAX_TASKS];             /* float* [B, n_experts] contiguous          */
+  uint64_t out[TZR_MOE_MAX_TASKS];               /* float* [B, H]                 (forward)   */
+  int64_t out_stride[TZR_MOE_MAX_TASKS];
+  uint64_t grad_out[TZR_MOE_MAX_TASKS];          /* const float* [B, H]           (backward)  */
+  int64_t grad_out_stride[TZR_MOE_MAX_TASKS];
+  uint64_t d_logits[TZR_MOE_MAX_TASKS];          /* float* [B, n_experts]         (backward)  */
+  int64_t d_logits_stride[TZR_MOE_MAX_TASKS];
+} TzrMoeMix;
+int tzr_moe_mix_fwd(const TzrMoeMix* h_mix, void* stream);
+int tzr_moe_mix_bwd(const TzrMoeMix* h_mix, void* stream);
+
+/* Linear layers with a handful of output units, n_out <= 8: the logits layer of the rank models
+ * (tzrec/models/rank_model.py:190-191) and the gates of MMoE (tzrec/modules/mmoe.py: Linear(in, num_expert)).
+ * forward: d_y[b, j] = sum_k d_x[b, k] * d_w[j, k] + d_bias[j] (d_bias nullable); one pass over x.
+ * backward: d_grad_x[b, :] = sum_j gy[b, j] * w[j, :] (nullable), d_grad_wb = [gy^T x (n_out x K row-major) | sum_b gy[b, :]
+ * (n_out, padded to a multiple of 4)]; one pass over x + a fixed-order sum of the workgroups' rows.  K multiple of 4, <= 1024;
+ * x / w / grad_x strides multiples of 4 floats.  Replace torch's addmm + three backward products (one output tile wide). */
+int tzr_skinny_linear_fwd(const float* d_x, int64_t x_stride, const float* d_w, int64_t w_stride, const float* d_bias,
+                          int64_t B, int K, int n_out, float* d_y, int64_t y_stride, void* stream);
+size_t tzr_skinny_linear_bwd_workspace(int64_t B, int K, int n_out);
+int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                          const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                          int64_t grad_x_stride, float* d_grad_wb, void* ws, size_t ws_bytes, void* stream);
 
 /* Input gradient of a Linear layer chained with the ReLU mask and bias gradient of the layer below it (autograd of
  * Linear -> ReLU -> Linear, tzrec/modules/mlp.py:58-83), one launch on the matrix cores (exact fp32):

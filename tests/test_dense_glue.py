@@ -183,6 +183,71 @@ def test_linear_bwd_relu_matches_torch(dev, N, K, H, cap):
     assert torch.equal(got, again) and torch.equal(col, col2)  # fixed summation order
 
 
+@pytest.mark.parametrize("B,K,n", [(1, 4, 1), (37, 64, 1), (1000, 64, 3), (999, 200, 2), (513, 256, 5), (300, 512, 8), (70, 1024, 3),
+                                   (20000, 16, 4), (8192, 128, 3)])
+def test_skinny_linear_matches_torch(dev, B, K, n):
+    """Linear layers with <= 8 output units (logits, MMoE gates): tzr_skinny_linear_fwd / _bwd against nn.functional.linear and its
+    autograd, through the module that the rank models use (dlrm.OutputLinear)"""
+    from torcheasyrec_amd import dlrm
+    from torcheasyrec_amd.dense import skinny_linear_bwd, skinny_linear_fwd, skinny_linear_ok
+
+    g = torch.Generator().manual_seed(B + K + n)
+    x_full = torch.randn(B, K + 8, generator=g)
+    x = (x_full[:, 4:K + 4] if B % 2 else x_full[:, :K]).to(dev)  # row-strided input
+    lin = dlrm.OutputLinear(K, n).to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(n, K, generator=g) / K ** 0.5)
+        lin.bias.copy_(torch.randn(n, generator=g))
+    assert skinny_linear_ok(x, lin.weight)
+    gy = torch.randn(B, n, generator=g).to(dev) / B
+    xr = x.detach().cpu().double().requires_grad_(True)
+    wr, br = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double().requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, wr, br)
+    ref.backward(gy.cpu().double())
+    xd = x.detach().clone().requires_grad_(True)
+    y = lin(xd)
+    assert y.shape == (B, n) and y.grad_fn is not None and "Skinny" in type(y.grad_fn).__name__
+    y.backward(gy)
+    scale = float(ref.detach().abs().max())
+    assert float((y.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-6 * scale + 1e-7
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(lin.weight.grad.cpu().double(), wr.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(lin.bias.grad.cpu().double(), br.grad, rtol=1e-4, atol=1e-7)
+    # the entry points themselves: no bias, no input gradient
+    y2 = skinny_linear_fwd(x, lin.weight.detach(), None)
+    torch.testing.assert_close(y2.cpu().double(), (ref - br).detach(), rtol=1e-5, atol=2e-6 * scale + 1e-7)
+    gx2, gw2, gb2 = skinny_linear_bwd(gy, x, lin.weight.detach(), need_grad_x=False)
+    assert gx2 is None and torch.equal(gw2, lin.weight.grad) and torch.equal(gb2, lin.bias.grad)  # deterministic
+
+
+@pytest.mark.parametrize("B,H,E,T", [(1, 4, 1, 1), (37, 8, 3, 2), (1000, 128, 3, 2), (513, 264, 8, 4), (70, 1024, 2, 1), (4099, 64, 5, 3)])
+def test_moe_mix_matches_the_stacked_form(dev, B, H, E, T):
+    """softmax + mixing of all tasks of an MMoE in one launch per direction (tzr_moe_mix_fwd / _bwd) against the reference's
+    literal form: stack, softmax, batched matmul (tzrec/modules/mmoe.py:63-76) and its autograd"""
+    from torcheasyrec_amd.dense import moe_mix, moe_mix_ok
+
+    g = torch.Generator().manual_seed(B + H + E + T)
+    xs = [torch.randn(B, H, generator=g) for _ in range(E)]
+    ls = [torch.randn(B, E, generator=g) * 2 for _ in range(T)]
+    gos = [torch.randn(B, H, generator=g) for _ in range(T)]
+    xr = [x.double().requires_grad_(True) for x in xs]
+    lr = [l.double().requires_grad_(True) for l in ls]
+    st = torch.stack(xr, dim=1)
+    refs = [torch.matmul(torch.softmax(l, dim=1).unsqueeze(1), st).squeeze(1) for l in lr]
+    torch.autograd.backward(refs, [go.double() for go in gos])
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    ld = [l.to(dev).requires_grad_(True) for l in ls]
+    assert moe_mix_ok(ld, xd)
+    outs = moe_mix(ld, xd)
+    torch.autograd.backward(outs, [go.to(dev) for go in gos])
+    for t in range(T):
+        torch.testing.assert_close(outs[t].detach().cpu().double(), refs[t].detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ld[t].grad.cpu().double(), lr[t].grad, rtol=1e-4, atol=1e-5 * H ** 0.5)
+    for e in range(E):
+        torch.testing.assert_close(xd[e].grad.cpu().double(), xr[e].grad, rtol=1e-5, atol=1e-6)
+    assert not moe_mix_ok(ld, [x[:, :H - 1] for x in xd]) if H > 4 else True
+
+
 def test_mlp_proto_fields_build_the_reference_perceptron():
     """use_bn / use_ln / dropout_ratio / activation / bias of the MLP proto (tzrec/protos/module.proto:4-17)
     reach the module (config-built towers used to read hidden_units only): same layer sequence as

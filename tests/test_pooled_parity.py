@@ -435,6 +435,41 @@ def test_backward_plan_shared_jagged_hot(dev, bwd_path):
                        steps=1, rtol=5e-4, idgen=gen)
 
 
+@pytest.mark.parametrize("case", ["last_row_95", "two_hot_rows", "candidate_not_hot", "shared_table", "rowwise", "sgd_small_ch"])
+def test_direct_backward_hot_row_is_shared_by_the_tables_workgroups(dev, case):
+    """tzr_pooled_bwd_direct: a row with more lookups than an LDS unit (the shared row of a zero-collision hash's unseen ids: the
+    LAST row of the table) is summed by ALL of the table's workgroups, a slice of the positions each, and applied by the last to
+    arrive; a second hot row that is not the sample's mode still goes the streaming way; a frequent row below a unit is left
+    to its range"""
+    from torcheasyrec_amd import _lib
+    rows = 1 << 20
+    kind, frac, hot_ids, B, ch, keys, spec = "adagrad", 0.95, [rows - 1], 3000, 0, ["c0", "c1"], None
+    if case == "two_hot_rows":
+        frac, hot_ids, B = 0.9, [rows - 1, 4321], 4000
+    elif case == "candidate_not_hot":
+        frac, B = 0.25, 2400
+    elif case == "shared_table":  # two keys read the table: the slices cross the boundary between the keys' segments
+        spec = [("t_a", rows, 16, "sum", ["c0", "c2"]), ("t_small", 40, 16, "sum", ["c1"])]
+        keys, B = ["c0", "c1", "c2"], 1700
+    elif case == "rowwise":
+        kind = "rowwise_adagrad"
+    elif case == "sgd_small_ch":
+        kind, ch = "sgd", 64
+    spec = spec or [("t_a", rows, 16, "sum", ["c0"]), ("t_small", 40, 16, "sum", ["c1"])]
+    gen = _hot(frac, hot_ids)
+    opt = SparseOptimizerConfig(kind=kind, lr=0.05, **({"initial_accumulator_value": 0.1} if kind == "adagrad" else {}))
+    L = _lib.lib()
+    # (bwd_direct_hot 2 = look for a hot row whether or not the caller said so: the collection of _run_backward_case does not)
+    assert L.tzr_tune(b"bwd_direct", 1) == 0 and L.tzr_tune(b"bwd_direct_ch", ch) == 0 and L.tzr_tune(b"bwd_direct_hot", 2) == 0
+    try:
+        _run_backward_case(dev, spec, keys, [rows if k != "c1" else 40 for k in keys], B, "uniform1", False, opt, steps=2, rtol=5e-4,
+                           idgen=(lambda rng, r, n: gen(rng, r, n) if r == rows else rng.integers(0, r, size=n)))
+    finally:
+        L.tzr_tune(b"bwd_direct", 0)
+        L.tzr_tune(b"bwd_direct_ch", 0)
+        L.tzr_tune(b"bwd_direct_hot", 1)
+
+
 def test_backward_plan_prep_fallback(dev):
     """more than BWD_GEO lookups/tables take the single-workgroup geometry kernel: forced here"""
     from torcheasyrec_amd import _lib

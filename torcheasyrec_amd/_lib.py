@@ -48,6 +48,23 @@ class TzrDst(C.Structure):
     _fields_ = [("ptr", C.c_uint64), ("stride", C.c_int64)]
 
 
+GRAD_HOT_ROWS = 0x100  # TZR_GRAD_HOT_ROWS: flag in tzr_pooled_bwd_direct's grad_mode
+MOE_MAX_EXPERTS, MOE_MAX_TASKS = 8, 4
+
+
+class TzrMoeMix(C.Structure):
+    _fields_ = [
+        ("B", C.c_int64), ("H", C.c_int32), ("n_experts", C.c_int32), ("n_tasks", C.c_int32), ("reserved", C.c_int32),
+        ("expert", C.c_uint64 * MOE_MAX_EXPERTS), ("expert_stride", C.c_int64 * MOE_MAX_EXPERTS),
+        ("d_expert", C.c_uint64 * MOE_MAX_EXPERTS), ("d_expert_stride", C.c_int64 * MOE_MAX_EXPERTS),
+        ("logits", C.c_uint64 * MOE_MAX_TASKS), ("logits_stride", C.c_int64 * MOE_MAX_TASKS),
+        ("probs", C.c_uint64 * MOE_MAX_TASKS),
+        ("out", C.c_uint64 * MOE_MAX_TASKS), ("out_stride", C.c_int64 * MOE_MAX_TASKS),
+        ("grad_out", C.c_uint64 * MOE_MAX_TASKS), ("grad_out_stride", C.c_int64 * MOE_MAX_TASKS),
+        ("d_logits", C.c_uint64 * MOE_MAX_TASKS), ("d_logits_stride", C.c_int64 * MOE_MAX_TASKS),
+    ]
+
+
 class TzrSparseOptim(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -174,6 +191,11 @@ _SIGNATURES = {
     "tzr_head_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_head_bwd_relu_workspace": (_sz, [_i64, _i32]),
     "tzr_head_bwd_relu": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_moe_mix_fwd": (_i32, [_vp, _vp]),
+    "tzr_moe_mix_bwd": (_i32, [_vp, _vp]),
+    "tzr_skinny_linear_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "tzr_skinny_linear_bwd_workspace": (_sz, [_i64, _i32, _i32]),
+    "tzr_skinny_linear_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_linear_bwd_relu_supported": (_i32, [_i32, _i32]),
     "tzr_linear_bwd_relu_workspace": (_sz, [_i64, _i32]),
     "tzr_linear_bwd_relu": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),

@@ -416,6 +416,207 @@ extern "C" int tzr_head_bwd_relu(const float* d_grad_y, int64_t grad_y_stride, c
   return TZR_OK;
 }
 
+// ---- Linear layers with a handful of output units (logits, MMoE gates) -----------------------------------------------
+// y = x W^T + b with n_out <= 8 (the output layer of every rank model, /root/reference/tzrec/models/rank_model.py:190-191; the
+// gates of MMoE, /root/reference/tzrec/modules/mmoe.py: Linear(in, num_expert) + softmax).  As GEMMs these are one output tile
+// wide: hipBLASLt takes 31 us for [8192, 64] x [64, 1] and 26 us for the [3, 8192] x [8192, 256] weight gradient (profiles/r05j)
+// -- 2 MB of input each.  Forward: one pass over x, a row per lane group, weights in registers, shuffle reduction, no LDS.
+// Backward: tzr_head_bwd's scheme with NO accumulators per thread (gx = sum_j gy_j w_j, gw_j += gy_j x, gb_j += gy_j).
+#define SK_MAX_OUT 8
+
+template <int NO>
+__global__ __launch_bounds__(RB_THREADS) void tzr_skinny_linear_fwd_kernel(
+    const float* __restrict__ x, int64_t x_stride, const float* __restrict__ w, int64_t w_stride,
+    const float* __restrict__ bias, int64_t B, int K, int n_out, int lgp, float* __restrict__ y, int64_t y_stride) {
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int N4 = K >> 2;
+  const int rpw = TZR_WAVE / lgp;  // rows of a wave's sweep
+  const int gi = lane / lgp, c = lane - gi * lgp;
+  const int64_t wave = (int64_t)blockIdx.x * (RB_THREADS / TZR_WAVE) + threadIdx.x / TZR_WAVE;
+  const int64_t n_waves = (int64_t)gridDim.x * (RB_THREADS / TZR_WAVE);
+  const bool one_col = N4 <= lgp;
+  float4 wr[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) wr[j] = (one_col && c < N4 && j < n_out) ? tzr_ld4(w + (int64_t)j * w_stride + 4 * c) : tzr_zero4();
+  for (int64_t row0 = wave * rpw * RB_UNROLL; row0 < B; row0 += n_waves * rpw * RB_UNROLL) {
+    float acc[RB_UNROLL][NO];
+    if (one_col) {
+      float4 v[RB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = row0 + (int64_t)u * rpw + gi;
+        v[u] = (b < B && c < N4) ? tzr_ld4(x + b * x_stride + 4 * c) : tzr_zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u)
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[u][j] = v[u].x * wr[j].x + v[u].y * wr[j].y + v[u].z * wr[j].z + v[u].w * wr[j].w;
+    } else {  // K > 256: a lane walks its columns, the weights come from the cache
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = row0 + (int64_t)u * rpw + gi;
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[u][j] = 0.f;
+        if (b < B)
+          for (int cc = c; cc < N4; cc += lgp) {
+            const float4 v = tzr_ld4(x + b * x_stride + 4 * cc);
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+              if (j >= n_out) break;
+              const float4 ww = tzr_ld4(w + (int64_t)j * w_stride + 4 * cc);
+              acc[u][j] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB_UNROLL; ++u) {
+      const int64_t b = row0 + (int64_t)u * rpw + gi;
+#pragma unroll
+      for (int j = 0; j < NO; ++j) {
+        float t = acc[u][j];
+        for (int m = lgp >> 1; m > 0; m >>= 1) t += __shfl_xor(t, m, TZR_WAVE);
+        if (c == 0 && b < B && j < n_out) y[b * y_stride + j] = t + (bias ? bias[j] : 0.f);
+      }
+    }
+  }
+}
+
+extern "C" int tzr_skinny_linear_fwd(const float* d_x, int64_t x_stride, const float* d_w, int64_t w_stride, const float* d_bias,
+                                     int64_t B, int K, int n_out, float* d_y, int64_t y_stride, void* stream) {
+  if (!d_x || !d_w || !d_y || B <= 0 || K <= 0 || n_out <= 0) return TZR_ERR_INVALID;
+  if ((K & 3) || K > 4 * RB_THREADS || n_out > SK_MAX_OUT || (x_stride & 3) || (w_stride & 3) || y_stride < n_out ||
+      ((uintptr_t)d_x & 15) || ((uintptr_t)d_w & 15))
+    return TZR_ERR_UNSUPPORTED;
+  int lgp = 1;
+  while (lgp < (K >> 2) && lgp < TZR_WAVE) lgp <<= 1;
+  const int rpw = TZR_WAVE / lgp;
+  const int64_t rows_per_wg = (int64_t)rpw * RB_UNROLL * (RB_THREADS / TZR_WAVE);
+  const unsigned grid = (unsigned)std::min<int64_t>((B + rows_per_wg - 1) / rows_per_wg, 2048);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define SK_FWD(NO_)                                                                                                      \
+  hipLaunchKernelGGL((tzr_skinny_linear_fwd_kernel<NO_>), dim3(grid), dim3(RB_THREADS), 0, s, d_x, x_stride, d_w, w_stride, d_bias, B, K, \
+                     n_out, lgp, d_y, y_stride)
+  if (n_out == 1) SK_FWD(1);
+  else if (n_out == 2) SK_FWD(2);
+  else if (n_out <= 4) SK_FWD(4);
+  else SK_FWD(8);
+#undef SK_FWD
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// parts row of a workgroup: [gw (n_out x K, row-major) | gb (n_out, padded to a multiple of 4)]
+template <int NO>
+__global__ __launch_bounds__(RB_THREADS) void tzr_skinny_linear_bwd_kernel(
+    const float* __restrict__ gy, int64_t gy_stride, const float* __restrict__ x, int64_t x_stride,
+    const float* __restrict__ w, int64_t w_stride, int64_t B, int K, int n_out, int64_t rows_per_wg, float* __restrict__ gx,
+    int64_t gx_stride, float* __restrict__ parts, int row_len) {
+  __shared__ float4 red[RB_THREADS];
+  __shared__ float redb[RB_THREADS];
+  const int N4 = K >> 2;
+  const int rl = RB_THREADS / N4;
+  const int c = threadIdx.x % N4;
+  const int r = threadIdx.x / N4;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = min(B, lo + rows_per_wg);
+  float4 acc[NO], w4[NO];
+  float accb[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    acc[j] = tzr_zero4();
+    accb[j] = 0.f;
+    w4[j] = (r < rl && j < n_out) ? tzr_ld4(w + (int64_t)j * w_stride + 4 * c) : tzr_zero4();
+  }
+  if (r < rl) {
+    for (int64_t b0 = lo + r; b0 < hi; b0 += (int64_t)rl * RB_UNROLL) {
+      float4 v[RB_UNROLL];
+      float gs[RB_UNROLL][NO];
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        v[u] = b < hi ? tzr_ld4(x + b * x_stride + 4 * c) : tzr_zero4();
+#pragma unroll
+        for (int j = 0; j < NO; ++j) gs[u][j] = (b < hi && j < n_out) ? gy[b * gy_stride + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < RB_UNROLL; ++u) {
+        const int64_t b = b0 + (int64_t)u * rl;
+        if (b >= hi) continue;
+        float4 o = tzr_zero4();
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+          o = tzr_fma4(gs[u][j], w4[j], o);
+          acc[j] = tzr_fma4(gs[u][j], v[u], acc[j]);
+          if (c == 0) accb[j] += gs[u][j];
+        }
+        if (gx) tzr_st4(gx + b * gx_stride + 4 * c, o);
+      }
+    }
+  }
+  float* const row = parts + (size_t)blockIdx.x * row_len;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    if (j >= n_out) break;  // uniform
+    __syncthreads();
+    red[threadIdx.x] = acc[j];
+    redb[threadIdx.x] = accb[j];
+    __syncthreads();
+    if (r == 0 && c < N4) {
+      float4 t = red[c];
+      for (int k = 1; k < rl; ++k) t = tzr_add4(t, red[k * N4 + c]);
+      tzr_st4(row + (size_t)j * K + 4 * c, t);
+      if (c == 0) {
+        float tb = 0.f;
+        for (int k = 0; k < rl; ++k) tb += redb[k * N4];
+        row[(size_t)n_out * K + j] = tb;
+      }
+    }
+  }
+  if (threadIdx.x < (unsigned)(row_len - n_out * K - n_out)) row[(size_t)n_out * K + n_out + threadIdx.x] = 0.f;  // padding of gb
+}
+
+static inline int sk_row_len(int K, int n_out) { return n_out * K + (n_out + 3) / 4 * 4; }
+
+extern "C" size_t tzr_skinny_linear_bwd_workspace(int64_t B, int K, int n_out) {
+  (void)B;
+  return (size_t)RB_MAX_WG * (size_t)sk_row_len(K, std::max(n_out, 1)) * sizeof(float) + 256;
+}
+
+extern "C" int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                     const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                                     int64_t grad_x_stride, float* d_grad_wb /*[n_out K + n_out padded to 4]*/, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (!d_grad_y || !d_x || !d_w || !d_grad_wb || B <= 0 || K <= 0 || n_out <= 0) return TZR_ERR_INVALID;
+  if ((K & 3) || K > 4 * RB_THREADS || n_out > SK_MAX_OUT || (x_stride & 3) || (w_stride & 3) || grad_y_stride < n_out ||
+      (d_grad_x && (grad_x_stride & 3)))
+    return TZR_ERR_UNSUPPORTED;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_skinny_linear_bwd_workspace(B, K, n_out) - 256)
+    return TZR_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rl = RB_THREADS / (K >> 2);
+  int64_t rows_per_wg = (int64_t)rl * RB_UNROLL;
+  int64_t n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  if (n_wg > RB_MAX_WG) {
+    rows_per_wg = ((B + RB_MAX_WG - 1) / RB_MAX_WG + rl * RB_UNROLL - 1) / (rl * RB_UNROLL) * (rl * RB_UNROLL);
+    n_wg = (B + rows_per_wg - 1) / rows_per_wg;
+  }
+  const int row_len = sk_row_len(K, n_out);
+  float* parts = static_cast<float*>(ws);
+#define SK_BWD(NO_)                                                                                                          \
+  hipLaunchKernelGGL((tzr_skinny_linear_bwd_kernel<NO_>), dim3((unsigned)n_wg), dim3(RB_THREADS), 0, s, d_grad_y, grad_y_stride, d_x, \
+                     x_stride, d_w, w_stride, B, K, n_out, rows_per_wg, d_grad_x, grad_x_stride, parts, row_len)
+  if (n_out == 1) SK_BWD(1);
+  else if (n_out == 2) SK_BWD(2);
+  else if (n_out <= 4) SK_BWD(4);
+  else SK_BWD(8);
+#undef SK_BWD
+  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((row_len + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts, (int)n_wg,
+                     row_len, d_grad_wb);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
 // ---- Adam ---------------------------------------------------------------------------------------
 
 struct AdamTable {

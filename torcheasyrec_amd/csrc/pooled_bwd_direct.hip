@@ -79,6 +79,7 @@ struct BwdDirectLds {
   TzrDst sG[TZR_MAX_DST];
   uint32_t wcnt[BWD_WAVES];
   uint32_t red[BWD_WAVES];
+  uint32_t hcnt[BWD_WAVES];  // lookups of the table's hot-row candidate a wave met on its walk
   union {
     BwdSortLds S;  // gather target (S.pk / S.ps, position order), histogram (S.gstart), the sort
     BwdUnitLds U;  // the sorted unit and its reduction
@@ -159,12 +160,12 @@ __device__ __forceinline__ uint32_t bwd_direct_block(const BwdSrcArgs& A, int64_
 // how many there are.
 __device__ __forceinline__ uint32_t bwd_direct_gather(const BwdGeo& G, const TzrTable& tb, const BwdSrcArgs& A,
                                                       int64_t ts, int64_t te, uint32_t lo, uint32_t hi,
-                                                      BwdDirectLds& L) {
+                                                      BwdDirectLds& L, bool has_x = false, uint32_t xrow = 0u) {
   uint32_t total = 0;
   BWD_DIRECT_FOR_SEGMENTS(G, A, tb, ts, te, seg, a, b)
     for (int64_t base = a; base < b; base += BWD_DR * BWD_THREADS)
       total += bwd_direct_block<BWD_DR>(
-          A, tb.rows, seg, base, b, L.wcnt, total, [&](uint32_t key) { return key >= lo && key < hi; },
+          A, tb.rows, seg, base, b, L.wcnt, total, [&](uint32_t key) { return key >= lo && key < hi && !(has_x && key == xrow); },
           [&](uint32_t at, uint32_t key, uint32_t src) {
             if (at < (uint32_t)BWD_UMAX) {
               L.S.pk[at] = key;
@@ -178,10 +179,15 @@ __device__ __forceinline__ uint32_t bwd_direct_gather(const BwdGeo& G, const Tzr
 // lookups of rows [lo, hi) it finds there in its own region of S.pk / S.ps (BWD_WCAP entries), sixteen id loads in flight
 // per lane.  Position order = (wave, index in the region), which is all the sort needs.  Returns the number of lookups
 // found; *fits = every wave's share fitted its region (else the caller takes the ordered gather above, piece by piece).
+// `detect`: the table's hot-row CANDIDATE (see the body) is determined on the way -- the mode of the table's first 16 ids, loaded
+// together with the walk's first ids, so no round trip of its own -- and its lookups ANYWHERE in the table are counted
+// (*has_c, *crow, *n_c).  `has_x`: row `xrow` is left out of the gather.
 #define BWD_DGR 16  // id loads in flight per lane (64-bit each: 32 registers)
 __device__ __forceinline__ uint32_t bwd_direct_gather_waves(const BwdGeo& G, const TzrTable& tb, const BwdSrcArgs& A,
                                                             int64_t ts, int64_t te, uint32_t lo, uint32_t hi,
-                                                            BwdDirectLds& L, bool* fits) {
+                                                            BwdDirectLds& L, bool* fits, bool detect = false, bool* has_c_out = nullptr,
+                                                            uint32_t* crow_out = nullptr, uint32_t* n_c = nullptr, bool has_x = false,
+                                                            uint32_t xrow = 0u) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = (int)tzr_uni(threadIdx.x / TZR_WAVE);
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -190,16 +196,41 @@ __device__ __forceinline__ uint32_t bwd_direct_gather_waves(const BwdGeo& G, con
   const int64_t w0 = min(te, ts + (int64_t)wv * per), w1 = min(te, w0 + per);
   uint32_t* const rk = L.S.pk + wv * BWD_WCAP;
   uint32_t* const rs = L.S.ps + wv * BWD_WCAP;
-  uint32_t cnt = 0;
+  uint32_t cnt = 0, hc = 0;
+  bool has_c = false, pending = false;
+  uint32_t crow = 0u, sv = 0u;
+  int slen = 0;
+  if (detect) {  // (workgroup-uniform) the sample: issued here, looked at behind the first batch of id loads below
+    const BwdDSeg s0 = bwd_direct_seg(G, A, tb.first_order);
+    slen = (int)min((int64_t)16, s0.e - s0.s);
+    if (slen > 0) {
+      sv = bwd_direct_id(A, tb.rows, s0, s0.s + (lane & 15), s0.e);
+      pending = true;
+    }
+  }
   BWD_DIRECT_FOR_SEGMENTS(G, A, tb, w0, w1, seg, sa, sb)
     for (int64_t base = sa; base < sb; base += (int64_t)BWD_DGR * TZR_WAVE) {
       uint32_t k[BWD_DGR];
 #pragma unroll
       for (int r = 0; r < BWD_DGR; ++r) k[r] = bwd_direct_id(A, tb.rows, seg, base + (int64_t)r * TZR_WAVE + lane, sb);
+      if (pending) {  // every wave of every workgroup of the table looks at the same 16 ids: the same candidate everywhere
+        pending = false;
+        uint32_t same = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) same += (i < slen && (uint32_t)__shfl((int)sv, i, TZR_WAVE) == sv) ? 1u : 0u;
+        uint32_t best = (lane < slen) ? ((same << 8) | (uint32_t)(15 - lane)) : 0u;  // most frequent, then the earliest
+        for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m, TZR_WAVE));
+        best = tzr_uni(best);
+        if ((best >> 8) >= 3u) {
+          has_c = true;
+          crow = tzr_uni((uint32_t)__shfl((int)sv, 15 - (int)(best & 255u), TZR_WAVE));
+        }
+      }
 #pragma unroll
       for (int r = 0; r < BWD_DGR; ++r) {
         const int64_t p = base + (int64_t)r * TZR_WAVE + lane;
-        const bool m = p < sb && k[r] >= lo && k[r] < hi;
+        if (has_c) hc += (uint32_t)__popcll(__ballot(p < sb && k[r] == crow));  // (workgroup-uniform branch)
+        const bool m = p < sb && k[r] >= lo && k[r] < hi && !(has_x && k[r] == xrow);
         const unsigned long long bal = __ballot(m);
         if (bal == 0ull) continue;  // wave-uniform: most rounds of a wave hold none of this range's lookups
         const uint32_t at = cnt + (uint32_t)__popcll(bal & lt);
@@ -210,17 +241,30 @@ __device__ __forceinline__ uint32_t bwd_direct_gather_waves(const BwdGeo& G, con
         cnt += (uint32_t)__popcll(bal);
       }
     }
-  if (lane == 0) L.wcnt[wv] = cnt;
+  if (lane == 0) {
+    L.wcnt[wv] = cnt;
+    L.hcnt[wv] = hc;
+    if (detect && wv == 0) {  // (a wave whose quarter of the positions is empty never looked: the candidate is wave 0's)
+      L.red[0] = has_c ? 1u : 0u;
+      L.red[1] = crow;
+    }
+  }
   __syncthreads();
-  uint32_t total = 0;
+  uint32_t total = 0, htot = 0;
   bool ok = true;
 #pragma unroll
   for (int w = 0; w < BWD_WAVES; ++w) {
     const uint32_t c = tzr_uni(L.wcnt[w]);
     total += c;
+    htot += tzr_uni(L.hcnt[w]);
     ok = ok && c <= (uint32_t)BWD_WCAP;
   }
   *fits = ok;
+  if (detect) {
+    *has_c_out = tzr_uni(L.red[0]) != 0u;
+    *crow_out = tzr_uni(L.red[1]);
+    *n_c = htot;
+  }
   return total;
 }
 
@@ -377,7 +421,8 @@ __device__ __forceinline__ void bwd_direct_body(
     const float* __restrict__ weights, int grad_mode, const BwdGrads& Gr, const BwdOpt& opt, int ch,
     uint32_t* __restrict__ wcount, float* __restrict__ wpart, int max_dim) {
   __shared__ BwdDirectLds L;
-  const int dbg = ch >> 16;  // tzr_tune("bwd_direct_debug"): stop behind 1 = geometry, 2 = id walk, 3 = sort (timing experiments)
+  const int dbg = (ch >> 16) & 0xFF;  // tzr_tune("bwd_direct_debug"): stop behind 1 = geometry, 2 = id walk, 3 = sort (timing experiments)
+  const bool no_hot = (ch >> 24) & 1;  // no hot-row candidate: every hot row is streamed by its range's workgroup (the launcher: TZR_GRAD_HOT_ROWS / tzr_tune "bwd_direct_hot")
   ch &= 0xFFFF;
   // geometry (bwd_geometry of pooled_bwd_sort.h, with every global load of it -- lookups, their key lengths, table
   // descriptors -- issued before the first barrier: one memory round trip instead of two + the table fetch behind them)
@@ -475,72 +520,114 @@ __device__ __forceinline__ void bwd_direct_body(
   const uint32_t hi = (uint32_t)hi64;
   if (lo >= hi) return;
 
-  bool fits;
-  const uint32_t total = bwd_direct_gather_waves(G, tb, A, ts, te, lo, hi, L, &fits);
-  if (total == 0 || dbg == 2) return;
-  if (fits) {
-    bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)total, true, dbg == 3);
-    return;
-  }
-  __syncthreads();  // (S is reused by the walk below)
-  // ---- more lookups than one LDS unit: piece by piece ----
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = (int)tzr_uni(threadIdx.x / TZR_WAVE);
-  uint32_t cur = lo;
-  while (cur < hi) {
-    uint32_t lim = hi;
-    for (;;) {
-      const uint32_t span = lim - cur;
-      const uint64_t m2 = span <= (uint32_t)BWD_NB ? (1ull << 32) : (((uint64_t)BWD_NB << 32) / span);
-      const int sbits = bwd_bits(min(span, (uint32_t)BWD_NB) - 1u);
-      for (int i = threadIdx.x; i <= BWD_NB; i += BWD_THREADS) L.S.gstart[i] = 0;
-      __syncthreads();
-      BWD_DIRECT_FOR_SEGMENTS(G, A, tb, ts, te, seg, sa, sb)
-        for (int64_t base = sa; base < sb; base += 4 * BWD_THREADS) {
-          uint32_t kk[4];
+  // ---- hot row.  One row that holds more lookups than an LDS unit -- the shared row of a zero-collision hash's unseen ids
+  // (/root/reference/tzrec/features/feature.py:693-736: every id without a slot reads row zch_size - 1), a default id, a Zipf
+  // head -- used to be summed by its range's workgroup alone, streaming: 140 us of a 45 us kernel at 8 192 lookups of which
+  // 95 % read one row (profiles/r05j).  Every workgroup of the table reads all of the table's ids anyway, so all of them can
+  // agree on it without talking: the CANDIDATE is the mode of the table's first 16 ids (a function of the ids alone, the same
+  // in every workgroup; three of the sixteen must agree), its lookups are counted on the walk below, and when they exceed a unit
+  // every workgroup sums the candidate's gradient rows over ITS slice of the table's positions; the last to arrive adds
+  // the partial sums in slice order and applies the row (the tiny tables' mechanism: same counter, same records).  The
+  // candidate's range workgroup leaves the row out of its own range.  A miss (no candidate, or a hot row that is not the
+  // mode of the sample) costs nothing but the old path.  Looking costs ~2 us of a 43 us launch on ids without a hot row
+  // (profiles/r05ac), so it is the CALLER's statement (grad_mode | TZR_GRAD_HOT_ROWS) that such rows are expected.
+  bool fits, has_c = false;
+  uint32_t n_c = 0, crow = 0u;
+  const bool detect = te - ts > (int64_t)BWD_UMAX && !no_hot;  // (workgroup-uniform; fewer lookups always fit)
+  uint32_t total = bwd_direct_gather_waves(G, tb, A, ts, te, lo, hi, L, &fits, detect, &has_c, &crow, &n_c);
+  if (dbg == 2) return;
+  const bool hot = has_c && n_c > (uint32_t)BWD_UMAX;  // the same in every workgroup of the table
+  const bool has_x = hot && crow >= lo && crow < hi;   // this workgroup's range holds the hot row: gathered again without it
+  if (has_x) {
+    __syncthreads();
+    total = bwd_direct_gather_waves(G, tb, A, ts, te, lo, hi, L, &fits, false, nullptr, nullptr, nullptr, true, crow);
+  }
+  if (total != 0 && fits) {
+    bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)total, true, dbg == 3);
+  } else if (total != 0) {
+    __syncthreads();  // (S is reused by the walk below)
+    // ---- more lookups than one LDS unit: piece by piece ----
+    uint32_t cur = lo;
+    while (cur < hi) {
+      uint32_t lim = hi;
+      for (;;) {
+        const uint32_t span = lim - cur;
+        const uint64_t m2 = span <= (uint32_t)BWD_NB ? (1ull << 32) : (((uint64_t)BWD_NB << 32) / span);
+        const int sbits = bwd_bits(min(span, (uint32_t)BWD_NB) - 1u);
+        for (int i = threadIdx.x; i <= BWD_NB; i += BWD_THREADS) L.S.gstart[i] = 0;
+        __syncthreads();
+        BWD_DIRECT_FOR_SEGMENTS(G, A, tb, ts, te, seg, sa, sb)
+          for (int64_t base = sa; base < sb; base += 4 * BWD_THREADS) {
+            uint32_t kk[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) kk[r] = bwd_direct_id(A, tb.rows, seg, base + r * BWD_THREADS + threadIdx.x, sb);
+            for (int r = 0; r < 4; ++r) kk[r] = bwd_direct_id(A, tb.rows, seg, base + r * BWD_THREADS + threadIdx.x, sb);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (base + r * BWD_THREADS >= sb) break;  // wave-uniform
-            const bool v = base + r * BWD_THREADS + (int64_t)threadIdx.x < sb && kk[r] >= cur && kk[r] < lim;
-            const uint32_t sub = v ? (uint32_t)(((uint64_t)(kk[r] - cur) * m2) >> 32) : 0u;
-            bwd_wave_count(L.S.gstart, sub, v, max(sbits, 1), lane);
+            for (int r = 0; r < 4; ++r) {
+              if (base + r * BWD_THREADS >= sb) break;  // wave-uniform
+              const bool v = base + r * BWD_THREADS + (int64_t)threadIdx.x < sb && kk[r] >= cur && kk[r] < lim &&
+                             !(has_x && kk[r] == crow);
+              const uint32_t sub = v ? (uint32_t)(((uint64_t)(kk[r] - cur) * m2) >> 32) : 0u;
+              bwd_wave_count(L.S.gstart, sub, v, max(sbits, 1), lane);
+            }
           }
-        }
-      __syncthreads();
-      bwd_block_scan(L.S.gstart, BWD_NB, L.S.wtot);  // exclusive starts; gstart[BWD_NB] = lookups in [cur, lim)
-      const uint32_t in_range = tzr_uni(L.S.gstart[BWD_NB]);
-      // p = the number of leading sub-ranges that fit one unit together: gstart is monotone, so p = #{i in 1..NB: gstart[i] <= UMAX}
-      uint32_t fit = 0;
-      for (int i = 1 + (int)threadIdx.x; i <= BWD_NB; i += BWD_THREADS) fit += L.S.gstart[i] <= (uint32_t)BWD_UMAX ? 1u : 0u;
-      for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) fit += (uint32_t)__shfl_xor((int)fit, m, TZR_WAVE);
-      if (lane == 0) L.red[wv] = fit;
-      __syncthreads();
-      uint32_t p = 0;
+        __syncthreads();
+        bwd_block_scan(L.S.gstart, BWD_NB, L.S.wtot);  // exclusive starts; gstart[BWD_NB] = lookups in [cur, lim)
+        const uint32_t in_range = tzr_uni(L.S.gstart[BWD_NB]);
+        // p = the number of leading sub-ranges that fit one unit together: gstart is monotone, so p = #{i in 1..NB: gstart[i] <= UMAX}
+        uint32_t fit = 0;
+        for (int i = 1 + (int)threadIdx.x; i <= BWD_NB; i += BWD_THREADS) fit += L.S.gstart[i] <= (uint32_t)BWD_UMAX ? 1u : 0u;
+        for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) fit += (uint32_t)__shfl_xor((int)fit, m, TZR_WAVE);
+        if (lane == 0) L.red[wv] = fit;
+        __syncthreads();
+        uint32_t p = 0;
 #pragma unroll
-      for (int w = 0; w < BWD_WAVES; ++w) p += tzr_uni(L.red[w]);
-      __syncthreads();  // gstart / red are rewritten below
-      if (in_range == 0) {
-        cur = lim;
-        break;
+        for (int w = 0; w < BWD_WAVES; ++w) p += tzr_uni(L.red[w]);
+        __syncthreads();  // gstart / red are rewritten below
+        if (in_range == 0) {
+          cur = lim;
+          break;
+        }
+        if (p >= 1) {
+          const uint32_t end = p >= (uint32_t)BWD_NB ? lim : min(lim, bwd_direct_sub_start(cur, m2, p));
+          const uint32_t n = bwd_direct_gather(G, tb, A, ts, te, cur, end, L, has_x, crow);
+          bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)min(n, (uint32_t)BWD_UMAX));
+          cur = end;
+          break;
+        }
+        // the first sub-range alone does not fit
+        const uint32_t end0 = min(lim, bwd_direct_sub_start(cur, m2, 1));
+        if (end0 - cur <= 1u) {
+          bwd_direct_stream_row<ADAM>(G, tb, feats, A, weights, grad_mode, opt, ts, te, cur, L);
+          cur += 1;
+          break;
+        }
+        lim = end0;  // narrow
       }
-      if (p >= 1) {
-        const uint32_t end = p >= (uint32_t)BWD_NB ? lim : min(lim, bwd_direct_sub_start(cur, m2, p));
-        const uint32_t n = bwd_direct_gather(G, tb, A, ts, te, cur, end, L);
-        bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)min(n, (uint32_t)BWD_UMAX));
-        cur = end;
-        break;
-      }
-      // the first sub-range alone does not fit
-      const uint32_t end0 = min(lim, bwd_direct_sub_start(cur, m2, 1));
-      if (end0 - cur <= 1u) {
-        bwd_direct_stream_row<ADAM>(G, tb, feats, A, weights, grad_mode, opt, ts, te, cur, L);
-        cur += 1;
-        break;
-      }
-      lim = end0;  // narrow
     }
+  }
+  if (!hot || dbg == 3) return;
+  // ---- the hot row: this workgroup's slice of the table's positions, the last of the k arrivals applies ----
+  {
+    __syncthreads();
+    const int64_t n_t = te - ts;
+    const int64_t s0 = ts + n_t * (int64_t)j / (int64_t)k, s1 = ts + n_t * (int64_t)(j + 1) / (int64_t)k;
+    const float4 sum = bwd_direct_row_sum(G, tb, feats, A, weights, grad_mode, s0, s1, crow, L);
+    if (threadIdx.x >= TZR_WAVE) return;
+    const int lg = tb.dim >> 2;
+    const uint32_t c0 = tzr_uni(L.G.tchunk[t]);
+    if (lane < lg) bwd_publish4(wpart + (size_t)cidx * max_dim + 4 * lane, sum);
+    tzr_drain_stores();
+    int last = 0;
+    if (lane == 0) last = tzr_arrive(wcount + c0) == k - 1 ? 1 : 0;
+    last = __shfl(last, 0, TZR_WAVE);
+    if (!last) return;
+    if (lane == 0) tzr_publish_u32(wcount + c0, 0u);  // the counter is zero again when the launch ends
+    float4 tot = tzr_zero4();
+    for (uint32_t q = 0; q < k; ++q)
+      if (lane < lg) tot = tzr_add4(tot, bwd_consume4(wpart + (size_t)(c0 + q) * max_dim + 4 * lane));
+    bwd_apply_row_wave<ADAM>(tb, opt, *opt.lr, crow, tot, lane);
   }
 }
 
@@ -557,6 +644,7 @@ __device__ __forceinline__ void bwd_direct_body(
 BWD_DIRECT_KERNEL(tzr_bwd_direct_kernel, false, 4, 2)
 BWD_DIRECT_KERNEL(tzr_bwd_direct_adam_kernel, true, 3, 2)
 int g_tzr_bwd_direct_debug = 0;  // tzr_tune("bwd_direct_debug"): timing experiments, see bwd_direct_body
+int g_tzr_bwd_direct_hot = 1;    // tzr_tune("bwd_direct_hot"): hot rows shared among a table's workgroups 1 = when the caller sets TZR_GRAD_HOT_ROWS, 0 = never, 2 = always
 
 int g_tzr_bwd_direct_ch = 0;  // tzr_tune("bwd_direct_ch"): lookups per workgroup (0 = by problem size)
 int g_tzr_bwd_direct = 0;     // tzr_tune("bwd_direct"): 0 = up to BWD_DIRECT_MAX lookups per table on average, 1 = whenever the
@@ -578,7 +666,7 @@ static inline int bwd_direct_shape_ok(int64_t n_positions, int n_feats, int n_ta
 // shape the kernel takes AND size the policy wants it for
 extern "C" int tzr_pooled_bwd_direct_supported(int64_t n_positions, int n_feats, int n_tables,
                                                int uniform_bag_len, int grad_mode) {
-  if (!bwd_direct_shape_ok(n_positions, n_feats, n_tables, uniform_bag_len, grad_mode)) return 0;
+  if (!bwd_direct_shape_ok(n_positions, n_feats, n_tables, uniform_bag_len, grad_mode & ~TZR_GRAD_HOT_ROWS)) return 0;
   if (g_tzr_bwd_direct < 0) return 0;
   if (g_tzr_bwd_direct == 0 && n_positions > (int64_t)BWD_DIRECT_MAX * n_tables) return 0;  // quadratic id reads beyond this
   return 1;
@@ -609,8 +697,11 @@ extern "C" int tzr_pooled_bwd_direct(const TzrTable* d_tables, int n_tables, con
                                      void* ws, size_t ws_bytes, void* stream) {
   if (!d_tables || !d_feats || !h_grads || !h_optim || n_tables <= 0 || n_feats <= 0 || n_values < 0 || B < 0 ||
       n_dst <= 0 || n_dst > TZR_MAX_DST || max_dim <= 0 || max_dim > BWD_MAXDIM || (max_dim & 3) ||
-      (grad_mode != 0 && grad_mode != 1) || max_rows < 0)
+      max_rows < 0)
     return TZR_ERR_INVALID;
+  const int hot_rows = (grad_mode & TZR_GRAD_HOT_ROWS) ? 1 : 0;  // the caller expects rows hotter than an LDS unit (see the body)
+  grad_mode &= ~TZR_GRAD_HOT_ROWS;
+  if (grad_mode != 0 && grad_mode != 1) return TZR_ERR_INVALID;
   const bool uniform = uniform_bag_len == 1;
   if (!uniform && !d_offsets) return TZR_ERR_INVALID;
   if (!bwd_direct_shape_ok(n_positions, n_feats, n_tables, uniform_bag_len, grad_mode)) return TZR_ERR_UNSUPPORTED;
@@ -654,7 +745,9 @@ extern "C" int tzr_pooled_bwd_direct(const TzrTable* d_tables, int n_tables, con
   A.uniform = (int)uniform;
   const int ch0 = bwd_direct_pick_ch(n_positions);
   const unsigned grid = (unsigned)bwd_max_chunks(n_positions, n_tables, ch0);
-  const int ch = ch0 | (g_tzr_bwd_direct_debug << 16);
+  // tzr_tune("bwd_direct_hot"): 1 = the caller's flag decides, 0 = never, 2 = always
+  const bool look = g_tzr_bwd_direct_hot == 2 || (g_tzr_bwd_direct_hot == 1 && hot_rows);
+  const int ch = ch0 | ((g_tzr_bwd_direct_debug & 0xFF) << 16) | (look ? 0 : 1 << 24);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (opt.kind == TZR_OPT_ADAM)
     hipLaunchKernelGGL(tzr_bwd_direct_adam_kernel, dim3(grid), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats,

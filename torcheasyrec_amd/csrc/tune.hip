@@ -13,6 +13,7 @@ extern int g_tzr_bwd_apply_waves;
 extern int g_tzr_bwd_direct_ch;
 extern int g_tzr_bwd_direct;
 extern int g_tzr_bwd_direct_debug;
+extern int g_tzr_bwd_direct_hot;
 extern int g_tzr_ia_bwd_plain;
 extern int g_tzr_ia_bwd_wgs;
 extern int g_tzr_ia_gen_wgs;
@@ -68,6 +69,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "ia_fwd_wgs")) {
     g_tzr_ia_fwd_wgs = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_direct_hot")) {
+    g_tzr_bwd_direct_hot = value;
     return TZR_OK;
   }
   if (!strcmp(name, "mlp_mfma")) {

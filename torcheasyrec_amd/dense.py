@@ -99,6 +99,101 @@ def head_bwd_relu(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor):
     return g, sums[:N].unsqueeze(0), sums[N:N + 1], sums[N + 4:]
 
 
+class _MoeMixFn(torch.autograd.Function):
+    """out_t = softmax(logits_t) . experts for every task of a multi-gate mixture of experts in one launch per direction
+    (tzr_moe_mix_fwd / _bwd, csrc/moe_ops.hip); inputs: T gate-logit tensors [B, E], then E expert outputs [B, H]."""
+
+    @staticmethod
+    def forward(ctx, n_tasks, *tensors):
+        logits = [t.contiguous() for t in tensors[:n_tasks]]
+        experts = [_rows16(t) for t in tensors[n_tasks:]]
+        B, H = experts[0].shape
+        E, dev = len(experts), experts[0].device
+        m = _lib.TzrMoeMix()
+        m.B, m.H, m.n_experts, m.n_tasks = B, H, E, n_tasks
+        outs = [torch.empty(B, H, dtype=torch.float32, device=dev) for _ in range(n_tasks)]
+        probs = [torch.empty(B, E, dtype=torch.float32, device=dev) for _ in range(n_tasks)]
+        for e, x in enumerate(experts):
+            m.expert[e], m.expert_stride[e] = _lib.ptr(x), x.stride(0)
+        for t in range(n_tasks):
+            m.logits[t], m.logits_stride[t] = _lib.ptr(logits[t]), logits[t].stride(0)
+            m.probs[t] = _lib.ptr(probs[t])
+            m.out[t], m.out_stride[t] = _lib.ptr(outs[t]), outs[t].stride(0)
+        _lib.check(_lib.lib().tzr_moe_mix_fwd(_lib.C.byref(m), _lib.stream_ptr(dev)), "tzr_moe_mix_fwd")
+        ctx.save_for_backward(*probs, *experts)
+        ctx.n_tasks = n_tasks
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        T = ctx.n_tasks
+        probs, experts = ctx.saved_tensors[:T], ctx.saved_tensors[T:]
+        B, H = experts[0].shape
+        E, dev = len(experts), experts[0].device
+        gs = [torch.zeros(B, H, dtype=torch.float32, device=dev) if g is None else _rows16(g.float()) for g in gouts]
+        m = _lib.TzrMoeMix()
+        m.B, m.H, m.n_experts, m.n_tasks = B, H, E, T
+        dx = [torch.empty(B, H, dtype=torch.float32, device=dev) for _ in range(E)]
+        dl = [torch.empty(B, E, dtype=torch.float32, device=dev) for _ in range(T)]
+        for e, x in enumerate(experts):
+            m.expert[e], m.expert_stride[e] = _lib.ptr(x), x.stride(0)
+            m.d_expert[e], m.d_expert_stride[e] = _lib.ptr(dx[e]), dx[e].stride(0)
+        for t in range(T):
+            m.probs[t] = _lib.ptr(probs[t])
+            m.grad_out[t], m.grad_out_stride[t] = _lib.ptr(gs[t]), gs[t].stride(0)
+            m.d_logits[t], m.d_logits_stride[t] = _lib.ptr(dl[t]), dl[t].stride(0)
+        _lib.check(_lib.lib().tzr_moe_mix_bwd(_lib.C.byref(m), _lib.stream_ptr(dev)), "tzr_moe_mix_bwd")
+        return (None, *dl, *dx)
+
+
+def moe_mix_ok(logits, experts) -> bool:
+    x = experts[0]
+    return bool(0 < len(experts) <= _lib.MOE_MAX_EXPERTS and 0 < len(logits) <= _lib.MOE_MAX_TASKS and x.dim() == 2 and x.shape[0] > 0
+                and x.shape[1] % 4 == 0 and x.shape[1] <= 4096 and all(t.dtype == torch.float32 and t.shape == x.shape for t in experts)
+                and all(t.dtype == torch.float32 and t.shape == (x.shape[0], len(experts)) for t in logits))
+
+
+def moe_mix(logits, experts):
+    """[softmax(logits_t) . experts for t] -- the mixing step of MMoE (tzrec/modules/mmoe.py:63-76) -- one launch for all tasks."""
+    return list(_MoeMixFn.apply(len(logits), *logits, *experts))
+
+
+SKINNY_MAX_OUT = 8  # output units up to which a Linear layer takes tzr_skinny_linear_* (csrc/dense_ops.hip)
+
+
+def skinny_linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    n, K = weight.shape
+    return bool(x.dim() == 2 and x.shape[0] > 0 and x.dtype == torch.float32 and weight.dtype == torch.float32 and n <= SKINNY_MAX_OUT
+                and K % 4 == 0 and K <= 1024 and weight.stride(1) == 1 and weight.stride(0) % 4 == 0)
+
+
+def skinny_linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x W^T + b for a Linear layer with <= 8 output units in one pass over x (tzr_skinny_linear_fwd)."""
+    B, K = x.shape
+    n = weight.shape[0]
+    xs = _rows16(x)
+    y = torch.empty(B, n, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tzr_skinny_linear_fwd(_lib.ptr(xs), xs.stride(0), _lib.ptr(weight), weight.stride(0), _lib.ptr(bias), B, K, n,
+                                                _lib.ptr(y), y.stride(0), _lib.stream_ptr(x.device)), "tzr_skinny_linear_fwd")
+    return y
+
+
+def skinny_linear_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_grad_x: bool = True):
+    """(grad_x [B, K] | None, grad_weight [n, K], grad_bias [n]) of a Linear layer with <= 8 output units (tzr_skinny_linear_bwd)."""
+    B, K = x.shape
+    n = weight.shape[0]
+    gy = grad_y if grad_y.stride(1) == 1 or n == 1 else grad_y.contiguous()
+    xs = _rows16(x)
+    gx = torch.empty(B, K, dtype=torch.float32, device=x.device) if need_grad_x else None
+    wb = torch.empty(n * K + (n + 3) // 4 * 4, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.tzr_skinny_linear_bwd_workspace(B, K, n), x.device)
+    _lib.check(L.tzr_skinny_linear_bwd(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight), weight.stride(0), B, K, n,
+                                       _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(wb), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(x.device)), "tzr_skinny_linear_bwd")
+    return gx, wb[:n * K].view(n, K), wb[n * K:n * K + n]
+
+
 def linear_bwd_relu_supported(g_in: torch.Tensor, weight: torch.Tensor) -> bool:
     K, H = weight.shape
     return bool(g_in.shape[0] > 0 and weight.stride(1) == 1 and _lib.lib().tzr_linear_bwd_relu_supported(K, H))

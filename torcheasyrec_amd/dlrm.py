@@ -87,10 +87,40 @@ class _Linear1Fn(torch.autograd.Function):
         return gx, (x * gy).sum(0, keepdim=True), gy.sum(0)
 
 
+class _SkinnyLinearFn(torch.autograd.Function):
+    """Linear with <= 8 output units (logits, MMoE gates) as two one-pass kernels instead of GEMMs that are one output tile
+    wide (tzr_skinny_linear_fwd / _bwd, csrc/dense_ops.hip: 31 us per forward GEMM at [8192, 64] x [64, 1], profiles/r05j)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .dense import skinny_linear_fwd
+
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return skinny_linear_fwd(x, weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .dense import skinny_linear_bwd
+
+        x, weight = ctx.saved_tensors
+        gx, gw, gb = skinny_linear_bwd(gy.float(), x, weight, ctx.needs_input_grad[0])
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+_SKINNY_LINEAR = os.environ.get("TZR_SKINNY_LINEAR", "1") == "1"  # A/B switch
+
+
 class OutputLinear(nn.Linear):
-    """The logits layer (same parameters / state_dict keys as nn.Linear)."""
+    """A Linear layer with a handful of output units -- the logits layer, an MMoE gate -- (same parameters / state_dict keys
+    as nn.Linear)."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _SKINNY_LINEAR and (x.is_cuda or _on_emulator()) and x.dim() == 2:
+            from .dense import skinny_linear_ok
+
+            if skinny_linear_ok(x, self.weight):
+                return _SkinnyLinearFn.apply(x, self.weight, self.bias)
         if _GEMV_OUTPUT and self.out_features == 1 and x.is_cuda and x.dim() == 2 and self.bias is not None:
             return _Linear1Fn.apply(x, self.weight, self.bias)
         return super().forward(x)

@@ -301,6 +301,10 @@ class EmbeddingBagCollection(nn.Module):
         # whenever other kernels of the main stream ran next to it, while the same kernels in ONE stream
         # were right in 220 of 220 (NOTES.md "side-stream plan"); and the plan is ~60 us of a step now.
         self.async_plan = False
+        # a row with more lookups than a workgroup's LDS holds is expected (the shared row of a zero-collision hash's unseen ids, a
+        # default id): the one-launch backward then lets all of a table's workgroups sum such a row (TZR_GRAD_HOT_ROWS,
+        # include/tzrec_hip.h); zch.ManagedCollisionEmbeddingBagCollection sets it
+        self.expect_hot_rows = False
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
@@ -593,7 +597,8 @@ class EmbeddingBagCollection(nn.Module):
             rc = _lib.lib().tzr_pooled_bwd_direct(
                 _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), max_rows, max_dim,
                 _lib.ptr(kjt.values()), _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
-                1 if uniform else 0, 0, gd, len(gl), opt, _lib.ptr(dws), dws.numel(), _lib.stream_ptr(self._device))
+                1 if uniform else 0, _lib.GRAD_HOT_ROWS if self.expect_hot_rows else 0, gd, len(gl), opt, _lib.ptr(dws), dws.numel(),
+                _lib.stream_ptr(self._device))
         else:
             rc = _lib.lib().tzr_pooled_bwd_apply(
                 _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),

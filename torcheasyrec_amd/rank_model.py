@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .config import PipelineSpec
-from .dlrm import MLP, OutputLinear
+from .dlrm import MLP, OutputLinear, _on_emulator
 from .embedding import SparseOptimizerConfig
 from .embedding_group import Batch, EmbeddingGroup
 from .interaction import FactorizationMachine, dot_interaction
@@ -215,6 +215,9 @@ class ConfigMultiTowerDIN(RankModel):
         return self._output_to_prediction(self.output_mlp(y))
 
 
+FUSED_MOE_MIX = True  # A/B switch: False = the reference's stack / softmax / batched-matmul form
+
+
 class MMoE(nn.Module):
     """Multi-gate mixture of experts, the reference module's constructor and forward
     (tzrec/modules/mmoe.py:20-76): `num_expert` expert MLPs over the input, per task an optional
@@ -230,19 +233,21 @@ class MMoE(nn.Module):
         if self.has_gate_mlp:
             self.gate_mlps = nn.ModuleList([MLP(in_features, **gate_mlp) for _ in range(num_task)])
             gate_in = self.gate_mlps[0].hidden_units[-1]
-        self.gate_finals = nn.ModuleList([nn.Linear(gate_in, num_expert) for _ in range(num_task)])
+        self.gate_finals = nn.ModuleList([OutputLinear(gate_in, num_expert) for _ in range(num_task)])  # (nn.Linear's parameters; <= 8 units: one-pass kernels)
 
     def output_dim(self) -> int:
         return self.expert_mlps[0].hidden_units[-1]
 
     def forward(self, input: torch.Tensor):
-        experts = torch.stack([e(input) for e in self.expert_mlps], dim=1)  # [B, E, H]
-        result = []
-        for i in range(self.num_task):
-            g = self.gate_mlps[i](input) if self.has_gate_mlp else input
-            gate = torch.softmax(self.gate_finals[i](g), dim=1).unsqueeze(1)
-            result.append(torch.matmul(gate, experts).squeeze(1))
-        return result
+        outs = [e(input) for e in self.expert_mlps]
+        logits = [self.gate_finals[i](self.gate_mlps[i](input) if self.has_gate_mlp else input) for i in range(self.num_task)]
+        if FUSED_MOE_MIX and input.dim() == 2 and (input.is_cuda or _on_emulator()):
+            from .dense import moe_mix, moe_mix_ok
+
+            if moe_mix_ok(logits, outs):  # softmax + mixing of every task in one launch per direction, nothing stacked (csrc/moe_ops.hip)
+                return moe_mix(logits, outs)
+        experts = torch.stack(outs, dim=1)  # [B, E, H]: the reference's literal form
+        return [torch.matmul(torch.softmax(lg, dim=1).unsqueeze(1), experts).squeeze(1) for lg in logits]
 
 
 class ConfigMMoE(RankModel):

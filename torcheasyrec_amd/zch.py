@@ -292,6 +292,7 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
     def __init__(self, ebc: EmbeddingBagCollection, zch: Dict[str, ZchConfig], reset_evicted_rows: bool = False) -> None:
         super().__init__()
         self.ebc = ebc
+        ebc.expect_hot_rows = True  # every id without a slot reads the table's LAST row: thousands of lookups of one row per step
         self._device = ebc.device
         cfgs = {c.name: c for c in ebc.embedding_bag_configs()}
         self.modules_by_table: Dict[str, ManagedCollisionModule] = {}
