@@ -35,6 +35,8 @@ earlier), so a batch that does not fit simply takes the eager exact path; nothin
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Optional
 
 import torch
@@ -634,7 +636,9 @@ class ShardedTrainStep:
         if self.native_driver is None:
             from . import native_step
 
-            self.native_driver = native_step.available()
+            # TZR_NATIVE_DRIVER=0: the six-graph form with torch.distributed's collectives between the graphs (the escape hatch
+            # should RCCL kernels inside a hipGraph misbehave on some stack; measured here on ROCm 7.2 / RCCL 2.26.6)
+            self.native_driver = os.environ.get("TZR_NATIVE_DRIVER", "1") != "0" and native_step.available()
         return bool(self.native_driver)
 
     def _native_comm(self):
