@@ -18,7 +18,7 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = [b"bwd_apply_waves", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
+KNOBS = [b"bwd_apply_waves", b"bwd_apply_fast", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
 
 
 class Timers:
@@ -45,18 +45,32 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--layout", default="interleaved")
     ap.add_argument("--lib", default=None, help="another build of the library to time (same-box A/B against an older tree)")
+    ap.add_argument("--grad-stride0", action="store_true",
+                    help="experiment: the apply reads every lookup's gradient from ONE row (sample stride 0): what the apply costs without "
+                         "its 1.7 M random gradient-row requests (results are meaningless)")
+    ap.add_argument("--rows-cap", type=int, default=0, help="experiment: every table capped at this many rows (address-translation reach)")
     ap.add_argument("sets", nargs="*", default=[""])
     args = ap.parse_args()
     _lib.use_library(args.lib or _build.build())
     L = _lib.lib()
+    if args.grad_stride0:
+        orig_apply = L.tzr_pooled_bwd_apply
+
+        def apply0(*a):
+            for i in range(a[13]):
+                a[12][i].stride = 16  # (rows overlap: the whole gradient "buffer" is 4 MB, cache-resident, spread over every channel)
+            return orig_apply(*a)
+
+        L.tzr_pooled_bwd_apply = apply0
     dev = torch.device("cuda", 0)
-    ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev,
+    ROWS = [min(r, args.rows_cap) for r in CRITEO_ROWS] if args.rows_cap else list(CRITEO_ROWS)
+    ebc = EmbeddingBagCollection(criteo_tables(ROWS), device=dev,
                                  optimizer=SparseOptimizerConfig(kind=args.opt, lr=1e-3), groups={"sparse": SPARSE_KEYS},
                                  row_layout=args.layout)
     for B in [int(x) for x in args.B.split(",")]:
         for dist in args.dist.split(","):
-            host = [synthetic_batch(s, B, CRITEO_ROWS, dist=dist)[1] for s in range(4)]
-            ab = [algorithmic_bytes(k.values().numpy(), B, CRITEO_ROWS, optimizer=args.opt) for k in host]
+            host = [synthetic_batch(s, B, ROWS, dist=dist)[1] for s in range(4)]
+            ab = [algorithmic_bytes(k.values().numpy(), B, ROWS, optimizer=args.opt) for k in host]
             nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
             batches = [k.to(dev) for k in host]
             g = torch.randn(B, 416, device=dev) * 1e-3

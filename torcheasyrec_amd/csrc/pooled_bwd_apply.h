@@ -209,6 +209,59 @@ __device__ __forceinline__ void bwd_apply_row(const TzrTable& tb, const BwdOpt& 
   }
 }
 
+// The FAST form of the tile loop's memory side (bwd_reduce_unit<.., FK != 0>): fp32 tables read by ONE key whose gradient comes
+// from ONE buffer, bags of exactly one id, no per-sample weights, the optimizer kind FK known at compile time.  Every access is
+// a GLOBAL instruction through a pointer that is known to be device memory (the general forms go through descriptor pointers:
+// FLAT instructions, which count in the LDS counter as well -- every `s_waitcnt lgkmcnt(0)` in front of an LDS read then waits
+// for the gradient gather and the row stores in flight) and nothing is loaded conditionally (a load inside `if` is a branch, a
+// branch between two loads a wait): the ISA of the general loop ran the gradient gather, the weights, the state and the stores
+// of a tile as FOUR dependent round trips (profiles/r05ai), this one as one.
+template <int FK>
+__device__ __forceinline__ void bwd_apply_row_fast(const TzrTable& tb, const BwdOpt& opt, float lr, int64_t row, int c, float4 g,
+                                                   float4 w4, float4 m4, bool active, int lg, int lane_in_group, int lane) {
+  if (opt.clip) {
+    g.x = fminf(fmaxf(g.x, -opt.max_grad), opt.max_grad);
+    g.y = fminf(fmaxf(g.y, -opt.max_grad), opt.max_grad);
+    g.z = fminf(fmaxf(g.z, -opt.max_grad), opt.max_grad);
+    g.w = fminf(fmaxf(g.w, -opt.max_grad), opt.max_grad);
+  }
+  float* const wp = reinterpret_cast<float*>(tb.w) + row * (int64_t)tb.w_stride + 4 * c;
+  if constexpr (FK == TZR_OPT_ADAGRAD) {
+    if (active) {
+      m4.x += g.x * g.x; m4.y += g.y * g.y; m4.z += g.z * g.z; m4.w += g.w * g.w;
+      tzr_stg4(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride + 4 * c, m4);
+      w4.x -= lr * g.x / (sqrtf(m4.x) + opt.eps);
+      w4.y -= lr * g.y / (sqrtf(m4.y) + opt.eps);
+      w4.z -= lr * g.z / (sqrtf(m4.z) + opt.eps);
+      w4.w -= lr * g.w / (sqrtf(m4.w) + opt.eps);
+      tzr_stg4(wp, w4);
+    }
+  } else if constexpr (FK == TZR_OPT_ROWWISE_ADAGRAD) {
+    float4 gl = g;
+    if (opt.wd_mode == TZR_WD_L2) gl = tzr_fma4(opt.wd, w4, g);
+    float ss = active ? (gl.x * gl.x + gl.y * gl.y + gl.z * gl.z + gl.w * gl.w) : 0.f;
+    ss = bwd_group_sum(ss, lg, lane_in_group, lane);
+    if (active) {  // (every lane of the group loaded the row's scalar itself: m4.x)
+      const float mnew = m4.x + ss / (float)tb.dim;
+      const float mult = lr / (sqrtf(mnew) + opt.eps);
+      float corr = 1.0f;
+      if (opt.wd_mode == TZR_WD_L2) corr = 1.0f - mult * opt.wd;
+      else if (opt.wd_mode == TZR_WD_DECOUPLE) corr = 1.0f - lr * opt.wd;
+      w4.x = corr * w4.x - mult * g.x;
+      w4.y = corr * w4.y - mult * g.y;
+      w4.z = corr * w4.z - mult * g.z;
+      w4.w = corr * w4.w - mult * g.w;
+      tzr_stg4(wp, w4);
+      if (lane_in_group == 0) tzr_stg(reinterpret_cast<float*>(tb.m) + row * (int64_t)tb.m_stride, mnew);
+    }
+  } else {  // SGD
+    if (active) {
+      w4.x -= lr * g.x; w4.y -= lr * g.y; w4.z -= lr * g.z; w4.w -= lr * g.w;
+      tzr_stg4(wp, w4);
+    }
+  }
+}
+
 __device__ __forceinline__ float4 bwd_shfl4(float4 v, int src) {
   return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64),
                      __shfl(v.w, src, 64));
@@ -265,7 +318,7 @@ struct BwdUnitLds {
 // (The predicates of the loads are known up front: equal keys are adjacent, so "this lookup belongs to the run inherited
 // from the range before" is `key == leadkey` for the whole range.)  The planned apply keeps its own copy: it is compiled
 // for exactly 7 waves per SIMD (71 of 72 VGPRs) and any re-arrangement of its source moved live ranges into scratch.
-template <bool ADAM, int NT, class Tail>
+template <bool ADAM, int NT, int FK = 0, class Tail>
 __device__ __forceinline__ void bwd_reduce_unit(
     const TzrTable& tb, const TzrFeature* __restrict__ feats, const int32_t* __restrict__ feat_by_order,
     const uint32_t* __restrict__ bag_of, const int64_t* __restrict__ offsets, const float* __restrict__ weights,
@@ -287,6 +340,12 @@ __device__ __forceinline__ void bwd_reduce_unit(
   const float lr = *opt.lr;
   const bool single = tb.n_feats == 1;
   const BwdSrc one = bwd_resolve(feats + feat_by_order[tb.first_order], sG);
+  // FK != 0 (see bwd_apply_row_fast): lookup position i of the table's one key is bag (key, b = i - key B) with ONE gradient row
+  const float* const fgp = one.gp0;
+  const int64_t fgs = one.gs0;
+  const uint32_t fkb = FK != 0 ? (uint32_t)feats[feat_by_order[tb.first_order]].key * (uint32_t)B : 0u;
+  const float* const fwp = reinterpret_cast<const float*>(tb.w);
+  const float* const fmp = reinterpret_cast<const float*>(tb.m);
 
   const int range = (n + BWD_WAVES - 1) / BWD_WAVES;  // sorted positions reduced by one wave
   const int r0 = min(n, wv * range);                  // range of this wave, unit-relative
@@ -316,10 +375,18 @@ __device__ __forceinline__ void bwd_reduce_unit(
       key[u] = valid ? kc : BWD_SENT;
       const bool tl = valid && kc != nxt;
       const bool inl = lead0 && kc == leadkey;
-      g[u] = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights, bag_of, B, uniform,
-                             sS[idc], c);
-      w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)kc * tb.w_stride + 4 * c);
-      m4[u] = bwd_load_state_all<ADAM>(tb, opt, (int64_t)kc, c);
+      if constexpr (FK != 0) {
+        g[u] = tzr_ldg4(fgp + (int64_t)(sS[idc] - fkb) * fgs + 4 * c);
+        w4[u] = tzr_ldg4(fwp + (int64_t)kc * tb.w_stride + 4 * c);
+        if constexpr (FK == TZR_OPT_ADAGRAD) m4[u] = tzr_ldg4(fmp + (int64_t)kc * tb.m_stride + 4 * c);
+        else if constexpr (FK == TZR_OPT_ROWWISE_ADAGRAD) m4[u] = make_float4(tzr_ldg(fmp + (int64_t)kc * tb.m_stride), 0.f, 0.f, 0.f);
+        else m4[u] = tzr_zero4();
+      } else {
+        g[u] = bwd_lookup_grad(feats, tb, feat_by_order, sG, one, single, grad_mode, offsets, weights, bag_of, B, uniform,
+                               sS[idc], c);
+        w4[u] = tzr_ldw4(reinterpret_cast<const void*>(tb.w), tb.w_dtype, (int64_t)kc * tb.w_stride + 4 * c);
+        m4[u] = bwd_load_state_all<ADAM>(tb, opt, (int64_t)kc, c);
+      }
       vmask |= valid ? 1u << u : 0u;
       tmask |= tl ? 1u << u : 0u;
       lmask |= inl ? 1u << u : 0u;
@@ -351,7 +418,8 @@ __device__ __forceinline__ void bwd_reduce_unit(
         flags |= BWD_LEAD;
         lead_open = false;
       }
-      bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key[u], c, gg, w4[u], m4[u], do_apply, lg, c, lane);
+      if constexpr (FK != 0) bwd_apply_row_fast<FK>(tb, opt, lr, (int64_t)key[u], c, gg, w4[u], m4[u], do_apply, lg, c, lane);
+      else bwd_apply_row<ADAM>(tb, opt, lr, (int64_t)key[u], c, gg, w4[u], m4[u], do_apply, lg, c, lane);
       // carry out of the tile: its last valid lookup, if that run goes on
       const int nv = min(gw, r1 - (t0 + u * gw));
       const int last = (nv - 1) * lg;
@@ -372,6 +440,9 @@ __device__ __forceinline__ void bwd_reduce_unit(
     rlkey[wv] = leadkey;
     rtkey[wv] = ckey;
   }
+#ifdef BWD_PROF_MARK
+  BWD_PROF_MARK(2);  // this wave's tiles done
+#endif
   __syncthreads();
 
   // stitch the 4 ranges of the chunk (wave 0; control flow is wave-uniform).  Pass 1 walks the records and notes the runs

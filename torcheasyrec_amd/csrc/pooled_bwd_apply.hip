@@ -22,6 +22,19 @@
 //     long): ONE launch for the whole apply.
 #include <tzr_gfx950.h>
 
+#ifdef IT_PROF  // scripts/build_prof_lib.sh: wall-clock stamps (100 MHz) of every workgroup's phases, read back by tzr_bwd_prof_dump
+#define BWD_PROF_WGS 4096
+__device__ uint64_t g_bwd_prof[BWD_PROF_WGS * 8];
+#define BWD_PROF_MARK(i) do { if (blockIdx.x < BWD_PROF_WGS && (threadIdx.x & (TZR_WAVE - 1)) == 0) { \
+    const int w_ = threadIdx.x / TZR_WAVE; if ((i) < 2 ? w_ == 0 : true) g_bwd_prof[blockIdx.x * 8 + ((i) < 2 ? (i) : (i) == 2 ? 2 + w_ : 6 + ((i) - 3))] = wall_clock64(); } } while (0)
+extern "C" int tzr_bwd_prof_dump(uint64_t* h_out, int n_wg) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_bwd_prof), (size_t)std::min(n_wg, BWD_PROF_WGS) * 8 * sizeof(uint64_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define BWD_PROF_MARK(i)
+#endif
+
 #include "pooled_bwd_apply.h"
 
 // Runs crossing unit boundaries: the unit holding the run's first lookup adds the leading pieces
@@ -30,15 +43,42 @@ template <bool ADAM>
 __device__ __forceinline__ void bwd_stitch_unit(const TzrTable& tb, const BwdOpt& opt, float lr,
                                                 int max_dim, const BwdPlan& P, int chunk,
                                                 int last_chunk, int lane) {
-  const bool on = lane < (tb.dim >> 2);
+  // The run that is open at the end of unit `chunk` continues through the LEADING pieces of the units behind it.  Their
+  // records are fetched a wave's worth at a time -- 64 / (D / 4) units per round trip, flag and piece together -- and added in
+  // unit order by shuffles.  (One unit after the other, flag then piece, this walk was two dependent cache-bypassing loads
+  // per unit: 21 units x ~1.5 us for a row of the 3-row Criteo table at B = 65 536, and the workgroup doing it was the LAST
+  // of the launch to finish -- 34 of the kernel's 78 us, profiles/r05ai/apply_phase_profile_fast1.txt.)
+  const int lg = tb.dim >> 2;    // lanes per record
+  const int gw = TZR_WAVE / lg;  // records per round trip
+  const int gi = lane / lg, c = lane - gi * lg;
+  const bool lane_on = gi < gw;
   const uint32_t key = tzr_consume_u32(P.ctkey + chunk);
   float4 sum = tzr_zero4();
-  if (on) sum = bwd_consume4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
-  for (int c2 = chunk + 1; c2 < last_chunk; ++c2) {
-    const unsigned f = tzr_consume_u32(P.cflags + c2);
-    if (!(f & BWD_LEAD)) break;
-    if (on) sum = tzr_add4(sum, bwd_consume4(P.clead + (size_t)c2 * max_dim + 4 * lane));
-    if (!(f & BWD_LEAD_WHOLE)) break;
+  if (lane < lg) sum = bwd_consume4(P.ctrail + (size_t)chunk * max_dim + 4 * lane);
+  bool done = false;
+  for (int c0 = chunk + 1; c0 < last_chunk && !done; c0 += gw) {
+    const int c2 = c0 + gi;
+    const bool in = lane_on && c2 < last_chunk;
+    unsigned f = 0;
+    float4 v = tzr_zero4();
+    if (in) {
+      f = tzr_consume_u32(P.cflags + c2);
+      v = bwd_consume4(P.clead + (size_t)c2 * max_dim + 4 * c);
+    }
+    const unsigned long long lead = __ballot(in && c == 0 && (f & BWD_LEAD));
+    const unsigned long long whole = __ballot(in && c == 0 && (f & BWD_LEAD) && (f & BWD_LEAD_WHOLE));
+    for (int g = 0; g < gw; ++g) {  // (wave-uniform)
+      if (!((lead >> (g * lg)) & 1ull)) {
+        done = true;
+        break;
+      }
+      const float4 piece = bwd_shfl4(v, g * lg + (lane < lg ? lane : 0));
+      if (lane < lg) sum = tzr_add4(sum, piece);
+      if (!((whole >> (g * lg)) & 1ull)) {
+        done = true;
+        break;
+      }
+    }
   }
   bwd_apply_row_wave<ADAM>(tb, opt, lr, key, sum, lane);
 }
@@ -276,6 +316,95 @@ __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_reduc
 }
 int g_tzr_bwd_apply_waves = 0;
 
+// ---- the same unit through bwd_reduce_unit's FAST memory side (pooled_bwd_apply.h: bwd_apply_row_fast) ----------------------
+// Round 5.  The ISA of the loop above (profiles/r05ai/apply_w7_loop.s) runs a tile as a CHAIN: LDS keys -> FLAT gradient gather
+// -> `s_waitcnt lgkmcnt(0)` (an LDS wait: it also waits for the FLAT gather) -> weights (a dtype branch around the load: wait)
+// -> FLAT state load -> wait -> scan -> FLAT stores, whose acknowledgement the next tile's LDS reads wait for: four dependent
+// round trips per 16 lookups, 16 tiles per wave -- ~4.5 us per tile whatever the data's home (tables capped at 100 k rows, i.e.
+// cache resident: 78 vs 80 us; gradients cache resident: 77 vs 80, profiles/r05ah).  Units whose table is fp32, read by one key
+// with one gradient buffer take bwd_reduce_unit<.., FK>: global instructions only, nothing loaded conditionally, ONE round trip
+// per NT tiles; every other unit takes the general form of the same function.  Same arithmetic, same summation order.
+template <int FK, int NT>
+__device__ __forceinline__ void bwd_reduce_body_fast(
+    const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
+    const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
+    int grad_mode, const BwdGrads& G, const BwdOpt& opt, int max_dim, const BwdPlan& P) {
+  __shared__ BwdUnitLds U;
+  __shared__ TzrDst sG[TZR_MAX_DST];
+  BWD_PROF_MARK(0);  // workgroup started
+  // (the unit's cuts are fetched WITH its descriptor, not behind it: the staging below is a chain of dependent round trips --
+  // descriptor -> cuts -> keys -> LDS, 4.9 us per workgroup in profiles/r05ai/apply_phase_profile.txt; the grid is max_chunks
+  // workgroups and ucut holds max_chunks + 1 entries)
+  const uint32_t u0 = P.ucut[blockIdx.x], u1 = P.ucut[blockIdx.x + 1];
+  BwdChunkDesc cd;
+  if (!bwd_chunk(P, blockIdx.x, &cd)) return;
+  const int t = cd.t;
+  const int64_t ts = cd.ts, te = cd.te;
+  const int64_t s = u0;
+  const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)u1 : te;
+  const int n = (int)(e - s);
+  const TzrTable tb = tables[t];
+  if (n <= 0 || n > BWD_UMAX) {
+    if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;
+    return;
+  }
+  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const TzrFeature* const ft = feats + P.feat_by_order[tb.first_order];
+  const int ft_dst = ft->n_dst;  // (issued with the unit's keys: no round trip of its own)
+  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+    const uint2 v = KS[s + i];
+    U.sK[i + 1] = v.x;
+    U.sS[i] = v.y;
+  }
+  if (threadIdx.x == 0) {
+    U.sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
+    U.sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
+#pragma unroll
+    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];
+  }
+  __syncthreads();
+  BWD_PROF_MARK(1);  // unit staged in LDS
+  const float lr = *opt.lr;
+  const int lg = tb.dim >> 2;
+  auto tail = [&](unsigned cf, uint32_t okey, const float4& clead, const float4& osum) {  // wave 0: the unit's open ends
+    BWD_PROF_MARK(3);  // tiles + stitch of the wave ranges done
+    if (lane < lg && cf) {
+      bwd_publish4(P.clead + (size_t)blockIdx.x * max_dim + 4 * lane, clead);
+      bwd_publish4(P.ctrail + (size_t)blockIdx.x * max_dim + 4 * lane, osum);
+    }
+    if (lane == 0) {
+      tzr_publish_u32(P.cflags + blockIdx.x, cf);
+      tzr_publish_u32(P.clkey + blockIdx.x, U.sK[1]);
+      tzr_publish_u32(P.ctkey + blockIdx.x, okey);
+    }
+    bwd_arrive_and_stitch<false>(tb, opt, lr, max_dim, P, cd, bwd_bucket(U.sK[1], cd.mult), bwd_bucket(U.sK[n], cd.mult), lane);
+    BWD_PROF_MARK(4);  // unit boundaries done: the workgroup ends
+  };
+  const bool fast = tb.n_feats == 1 && tb.w_dtype == TZR_DT_F32 && ft_dst == 1;  // (workgroup-uniform)
+  if (fast)
+    bwd_reduce_unit<false, NT, FK>(tb, feats, P.feat_by_order, P.bag_of, offsets, weights, B, uniform, grad_mode, opt, U, sG, n, tail);
+  else
+    bwd_reduce_unit<false, 1, 0>(tb, feats, P.feat_by_order, P.bag_of, offsets, weights, B, uniform, grad_mode, opt, U, sG, n, tail);
+}
+
+#define TZR_REDUCE_FAST_KERNEL(NAME, FK_, NT_, ATTR)                                                                  \
+  __global__ __launch_bounds__(BWD_THREADS) ATTR void NAME(                                                          \
+      const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,                              \
+      const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform, int grad_mode, \
+      BwdGrads G, BwdOpt opt, int max_dim, BwdPlan P) {                                                               \
+    bwd_reduce_body_fast<FK_, NT_>(tables, T, feats, offsets, weights, B, uniform, grad_mode, G, opt, max_dim, P);    \
+  }
+// one tile per round trip at 7 waves per SIMD (the whole unit grid of a 65 536-sample Criteo step resident at once) ...
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast_adagrad_kernel, TZR_OPT_ADAGRAD, 1, TZR_WAVES_PER_EU(7))
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast_rowwise_kernel, TZR_OPT_ROWWISE_ADAGRAD, 1, TZR_WAVES_PER_EU(7))
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast_sgd_kernel, TZR_OPT_SGD, 1, TZR_WAVES_PER_EU(7))
+// ... or two tiles per round trip, also at 7 (tzr_tune "bwd_apply_fast" = 2)
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast2_adagrad_kernel, TZR_OPT_ADAGRAD, 2, TZR_WAVES_PER_EU(7))
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast2_rowwise_kernel, TZR_OPT_ROWWISE_ADAGRAD, 2, TZR_WAVES_PER_EU(7))
+TZR_REDUCE_FAST_KERNEL(tzr_bwd_reduce_fast2_sgd_kernel, TZR_OPT_SGD, 2, TZR_WAVES_PER_EU(7))
+int g_tzr_bwd_apply_fast = 0;  // tzr_tune("bwd_apply_fast"): 0 = one tile per round trip, 2 = two, -1 = the general loop only
+
 extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats,
                                     int n_feats, int n_tables, int max_dim,
                                     const int64_t* d_offsets, const float* d_weights,
@@ -326,7 +455,19 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
 #define TZR_REDUCE_LAUNCH(K)                                                                       \
   hipLaunchKernelGGL(K, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats, d_offsets, \
                      d_weights, B, (int)uniform, grad_mode, G, opt, max_dim, P)
-  if (opt.kind == TZR_OPT_ADAM) {
+  // bags of one id, pooled gradients, no per-sample weights: the shape the fast memory side of the tile loop is written for
+  const bool fast_shape = grad_mode == 0 && uniform && !d_weights && g_tzr_bwd_apply_fast >= 0 && g_tzr_bwd_apply_waves == 0 &&
+                          (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ROWWISE_ADAGRAD || opt.kind == TZR_OPT_SGD);
+  if (fast_shape) {
+    const bool two = g_tzr_bwd_apply_fast == 2;
+    if (opt.kind == TZR_OPT_ADAGRAD) {
+      if (two) TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast2_adagrad_kernel); else TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast_adagrad_kernel);
+    } else if (opt.kind == TZR_OPT_ROWWISE_ADAGRAD) {
+      if (two) TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast2_rowwise_kernel); else TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast_rowwise_kernel);
+    } else {
+      if (two) TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast2_sgd_kernel); else TZR_REDUCE_LAUNCH(tzr_bwd_reduce_fast_sgd_kernel);
+    }
+  } else if (opt.kind == TZR_OPT_ADAM) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<true>));  // Adam holds two state rows per lane: no registers for a second tile
   } else if (g_tzr_bwd_apply_waves == 6) {
     TZR_REDUCE_LAUNCH((tzr_bwd_reduce_kernel<false>));
