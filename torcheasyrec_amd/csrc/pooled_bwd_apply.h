@@ -341,9 +341,10 @@ __device__ __forceinline__ void bwd_reduce_unit(
   const bool single = tb.n_feats == 1;
   const BwdSrc one = bwd_resolve(feats + feat_by_order[tb.first_order], sG);
   // FK != 0 (see bwd_apply_row_fast): lookup position i of the table's one key is bag (key, b = i - key B) with ONE gradient row
-  const float* const fgp = one.gp0;
-  const int64_t fgs = one.gs0;
-  const uint32_t fkb = FK != 0 ? (uint32_t)feats[feat_by_order[tb.first_order]].key * (uint32_t)B : 0u;
+  // (grad_mode 1: one gradient row per lookup position, whatever the table's keys)
+  const float* const fgp = grad_mode == 1 ? reinterpret_cast<const float*>(sG[0].ptr) : one.gp0;
+  const int64_t fgs = grad_mode == 1 ? sG[0].stride : one.gs0;
+  const uint32_t fkb = (FK != 0 && grad_mode == 0) ? (uint32_t)feats[feat_by_order[tb.first_order]].key * (uint32_t)B : 0u;
   const float* const fwp = reinterpret_cast<const float*>(tb.w);
   const float* const fmp = reinterpret_cast<const float*>(tb.m);
 

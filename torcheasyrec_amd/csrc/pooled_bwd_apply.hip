@@ -381,7 +381,7 @@ __device__ __forceinline__ void bwd_reduce_body_fast(
     bwd_arrive_and_stitch<false>(tb, opt, lr, max_dim, P, cd, bwd_bucket(U.sK[1], cd.mult), bwd_bucket(U.sK[n], cd.mult), lane);
     BWD_PROF_MARK(4);  // unit boundaries done: the workgroup ends
   };
-  const bool fast = tb.n_feats == 1 && tb.w_dtype == TZR_DT_F32 && ft_dst == 1;  // (workgroup-uniform)
+  const bool fast = tb.w_dtype == TZR_DT_F32 && (grad_mode == 1 || (tb.n_feats == 1 && ft_dst == 1));  // (workgroup-uniform)
   if (fast)
     bwd_reduce_unit<false, NT, FK>(tb, feats, P.feat_by_order, P.bag_of, offsets, weights, B, uniform, grad_mode, opt, U, sG, n, tail);
   else
@@ -455,8 +455,10 @@ extern "C" int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* 
 #define TZR_REDUCE_LAUNCH(K)                                                                       \
   hipLaunchKernelGGL(K, dim3(chunks), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats, d_offsets, \
                      d_weights, B, (int)uniform, grad_mode, G, opt, max_dim, P)
-  // bags of one id, pooled gradients, no per-sample weights: the shape the fast memory side of the tile loop is written for
-  const bool fast_shape = grad_mode == 0 && uniform && !d_weights && g_tzr_bwd_apply_fast >= 0 && g_tzr_bwd_apply_waves == 0 &&
+  // bags of one id with pooled gradients, or one gradient row per id (the sharded owners' and the sequence lookup's backward), no
+  // per-sample weights: the shapes the fast memory side of the tile loop is written for
+  const bool fast_shape = ((grad_mode == 0 && uniform) || grad_mode == 1) && !d_weights && g_tzr_bwd_apply_fast >= 0 &&
+                          g_tzr_bwd_apply_waves == 0 &&
                           (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ROWWISE_ADAGRAD || opt.kind == TZR_OPT_SGD);
   if (fast_shape) {
     const bool two = g_tzr_bwd_apply_fast == 2;
