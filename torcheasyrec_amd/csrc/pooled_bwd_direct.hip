@@ -270,7 +270,7 @@ __device__ __forceinline__ uint32_t bwd_direct_gather_waves(const BwdGeo& G, con
 
 // The unit's lookups in LDS in position order -> sorted by row id -> reduced and applied.  `regions`: they lie in the four
 // wave regions of bwd_direct_gather_waves (L.wcnt[w] entries each); else in S.pk / S.ps[0 .. n), n <= BWD_UMAX.
-template <bool ADAM, int NT>
+template <bool ADAM, int NT, int FK = 0>
 __device__ __forceinline__ void bwd_direct_unit(const TzrTable& tb, const TzrFeature* __restrict__ feats,
                                                 const BwdSrcArgs& A, const float* __restrict__ weights, int grad_mode,
                                                 const BwdOpt& opt, BwdDirectLds& L, int n, bool regions = false,
@@ -328,8 +328,18 @@ __device__ __forceinline__ void bwd_direct_unit(const TzrTable& tb, const TzrFea
     L.U.sK[n + 1] = BWD_SENT;
   }
   __syncthreads();
-  bwd_reduce_unit<ADAM, NT>(tb, feats, L.fbo, nullptr, A.offsets, weights, A.B, A.uniform, grad_mode, opt, L.U, L.sG, n,
-                                 [](unsigned, uint32_t, const float4&, const float4&) {});
+  auto none = [](unsigned, uint32_t, const float4&, const float4&) {};
+  if constexpr (FK != 0) {
+    // fp32 table read by one key with one gradient buffer, pooled gradients, no per-sample weights: the fast memory side of
+    // the tile loop (pooled_bwd_apply.h: bwd_apply_row_fast); every other unit of the launch the general one
+    const TzrFeature* const ft = feats + L.fbo[tb.first_order];
+    if (tb.w_dtype == TZR_DT_F32 && !weights && (grad_mode == 1 || (tb.n_feats == 1 && ft->n_dst == 1)))
+      bwd_reduce_unit<ADAM, NT, FK>(tb, feats, L.fbo, nullptr, A.offsets, weights, A.B, A.uniform, grad_mode, opt, L.U, L.sG, n, none);
+    else
+      bwd_reduce_unit<ADAM, NT>(tb, feats, L.fbo, nullptr, A.offsets, weights, A.B, A.uniform, grad_mode, opt, L.U, L.sG, n, none);
+  } else {
+    bwd_reduce_unit<ADAM, NT>(tb, feats, L.fbo, nullptr, A.offsets, weights, A.B, A.uniform, grad_mode, opt, L.U, L.sG, n, none);
+  }
   __syncthreads();  // wave 0's stitch reads U while the others would already refill S
 }
 
@@ -415,7 +425,7 @@ __device__ __forceinline__ uint32_t bwd_direct_sub_start(uint32_t cur, uint64_t 
   return cur + (uint32_t)((((uint64_t)p << 32) + m2 - 1) / m2);
 }
 
-template <bool ADAM, int NT>
+template <bool ADAM, int NT, int FK = 0>
 __device__ __forceinline__ void bwd_direct_body(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats, int F, const BwdSrcArgs& A,
     const float* __restrict__ weights, int grad_mode, const BwdGrads& Gr, const BwdOpt& opt, int ch,
@@ -545,7 +555,7 @@ __device__ __forceinline__ void bwd_direct_body(
     total = bwd_direct_gather_waves(G, tb, A, ts, te, lo, hi, L, &fits, false, nullptr, nullptr, nullptr, true, crow);
   }
   if (total != 0 && fits) {
-    bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)total, true, dbg == 3);
+    bwd_direct_unit<ADAM, NT, FK>(tb, feats, A, weights, grad_mode, opt, L, (int)total, true, dbg == 3);
   } else if (total != 0) {
     __syncthreads();  // (S is reused by the walk below)
     // ---- more lookups than one LDS unit: piece by piece ----
@@ -592,7 +602,7 @@ __device__ __forceinline__ void bwd_direct_body(
         if (p >= 1) {
           const uint32_t end = p >= (uint32_t)BWD_NB ? lim : min(lim, bwd_direct_sub_start(cur, m2, p));
           const uint32_t n = bwd_direct_gather(G, tb, A, ts, te, cur, end, L, has_x, crow);
-          bwd_direct_unit<ADAM, NT>(tb, feats, A, weights, grad_mode, opt, L, (int)min(n, (uint32_t)BWD_UMAX));
+          bwd_direct_unit<ADAM, NT, FK>(tb, feats, A, weights, grad_mode, opt, L, (int)min(n, (uint32_t)BWD_UMAX));
           cur = end;
           break;
         }
@@ -631,18 +641,23 @@ __device__ __forceinline__ void bwd_direct_body(
   }
 }
 
-#define BWD_DIRECT_KERNEL(NAME, ADAM_, WAVES, NT_)                                                                        \
+#define BWD_DIRECT_KERNEL(NAME, ADAM_, WAVES, NT_, FK_)                                                                      \
   __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(WAVES) void NAME(                                        \
       const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats, int F, BwdSrcArgs A,         \
       const float* __restrict__ weights, int grad_mode, BwdGrads Gr, BwdOpt opt, int ch,                             \
       uint32_t* __restrict__ wcount, float* __restrict__ wpart, int max_dim) {                                       \
-    bwd_direct_body<ADAM_, NT_>(tables, T, feats, F, A, weights, grad_mode, Gr, opt, ch, wcount, wpart, max_dim);         \
+    bwd_direct_body<ADAM_, NT_, FK_>(tables, T, feats, F, A, weights, grad_mode, Gr, opt, ch, wcount, wpart, max_dim);    \
   }
 // 4 waves per SIMD (128 VGPRs): 1 024 workgroups resident = the whole grid of an 8 192-per-rank step at once (at 3 waves,
 // 768 slots for ~860 workgroups: 66 vs 39 us).  Two tiles of the reduction in flight per wave; four (at 3 waves) or one
 // measured the same or worse: the kernel is not bound by the reduction's round trips (profiles/r04j, r04k).
-BWD_DIRECT_KERNEL(tzr_bwd_direct_kernel, false, 4, 2)
-BWD_DIRECT_KERNEL(tzr_bwd_direct_adam_kernel, true, 3, 2)
+BWD_DIRECT_KERNEL(tzr_bwd_direct_kernel, false, 4, 2, 0)
+BWD_DIRECT_KERNEL(tzr_bwd_direct_adam_kernel, true, 3, 2, 0)
+// the optimizer kind at compile time: units of fp32 single-key tables take the fast tile loop (tzr_tune "bwd_apply_fast" >= 0)
+BWD_DIRECT_KERNEL(tzr_bwd_direct_adagrad_kernel, false, 4, 2, TZR_OPT_ADAGRAD)
+BWD_DIRECT_KERNEL(tzr_bwd_direct_rowwise_kernel, false, 4, 2, TZR_OPT_ROWWISE_ADAGRAD)
+BWD_DIRECT_KERNEL(tzr_bwd_direct_sgd_kernel, false, 4, 2, TZR_OPT_SGD)
+extern int g_tzr_bwd_apply_fast;  // pooled_bwd_apply.hip
 int g_tzr_bwd_direct_debug = 0;  // tzr_tune("bwd_direct_debug"): timing experiments, see bwd_direct_body
 int g_tzr_bwd_direct_hot = 1;    // tzr_tune("bwd_direct_hot"): hot rows shared among a table's workgroups 1 = when the caller sets TZR_GRAD_HOT_ROWS, 0 = never, 2 = always
 
@@ -749,9 +764,18 @@ extern "C" int tzr_pooled_bwd_direct(const TzrTable* d_tables, int n_tables, con
   const bool look = g_tzr_bwd_direct_hot == 2 || (g_tzr_bwd_direct_hot == 1 && hot_rows);
   const int ch = ch0 | ((g_tzr_bwd_direct_debug & 0xFF) << 16) | (look ? 0 : 1 << 24);
   hipStream_t s = static_cast<hipStream_t>(stream);
+#define BWD_DIRECT_LAUNCH(K)                                                                                              \
+  hipLaunchKernelGGL(K, dim3(grid), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats, n_feats, A, d_weights, grad_mode, G, opt, ch, \
+                     wcount, wpart, max_dim)
   if (opt.kind == TZR_OPT_ADAM)
     hipLaunchKernelGGL(tzr_bwd_direct_adam_kernel, dim3(grid), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats,
                        n_feats, A, d_weights, grad_mode, G, opt, ch, wcount, wpart, max_dim);
+  else if (g_tzr_bwd_apply_fast >= 0 && !d_weights && opt.kind == TZR_OPT_ADAGRAD)
+    BWD_DIRECT_LAUNCH(tzr_bwd_direct_adagrad_kernel);
+  else if (g_tzr_bwd_apply_fast >= 0 && !d_weights && opt.kind == TZR_OPT_ROWWISE_ADAGRAD)
+    BWD_DIRECT_LAUNCH(tzr_bwd_direct_rowwise_kernel);
+  else if (g_tzr_bwd_apply_fast >= 0 && !d_weights && opt.kind == TZR_OPT_SGD)
+    BWD_DIRECT_LAUNCH(tzr_bwd_direct_sgd_kernel);
   else
     hipLaunchKernelGGL(tzr_bwd_direct_kernel, dim3(grid), dim3(BWD_THREADS), 0, s, d_tables, n_tables, d_feats,
                        n_feats, A, d_weights, grad_mode, G, opt, ch, wcount, wpart, max_dim);
