@@ -184,6 +184,18 @@ struct Fwd1Slot {  // 24 bytes
   int32_t w_stride;
 };
 
+#ifdef IT_PROF  // scripts/build_prof_lib.sh: wall-clock stamps (100 MHz) of every workgroup's phases, read back by tzr_fwd_prof_dump
+#define FWD_PROF_WGS 4096
+__device__ uint64_t g_fwd_prof[FWD_PROF_WGS * 4];
+#define FWD_PROF_MARK(i) do { if (blockIdx.y == 0 && blockIdx.x < FWD_PROF_WGS && threadIdx.x == 0) g_fwd_prof[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+extern "C" int tzr_fwd_prof_dump(uint64_t* h_out, int n_wg) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_fwd_prof), (size_t)std::min(n_wg, FWD_PROF_WGS) * 4 * sizeof(uint64_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define FWD_PROF_MARK(i)
+#endif
+
 __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
   const int ns = min(FWD1_SLOTS, n_slots - s0);
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
+  FWD_PROF_MARK(0);
   {
     const int s = threadIdx.x;
     if (s < ns) {
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
     ngroups = (int)tot;
   }
   __syncthreads();
+  FWD_PROF_MARK(1);  // slots resolved, id groups formed
   const int64_t b0 = (int64_t)blockIdx.x * tile_b;
   const int nb = (int)min((int64_t)tile_b, B - b0);
   const int sub = min(nb, FWD1_MAX_IDS / ngroups);  // samples per LDS pass (ngroups <= FWD1_SLOTS: >= 8)
@@ -262,6 +276,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
       sid[i] = id;
     }
     __syncthreads();
+    FWD_PROF_MARK(2);  // the tile's ids in LDS
     const int total = cnt * ns;
     for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * FWD1_UNROLL) {
       // No lane-dependent condition around the LDS reads and the row loads (an element behind the tile's last repeats it
@@ -289,6 +304,7 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
         if (k0 + u * FWD_THREADS < total) tzr_stg4(dp[u], acc[u]);
     }
   }
+  FWD_PROF_MARK(3);  // (thread 0's last store issued)
 }
 
 // flags: TZR_FWD_MIXED_DTYPE = some table holds fp16 rows (TzrTable.w_dtype is honoured); without it
