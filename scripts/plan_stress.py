@@ -124,6 +124,7 @@ def main():
         mode, *knobs = case.split(":")
         for name in (b"bwd_one_wg_heavy", b"bwd_ch"):
             L.tzr_tune(name, 0)
+        L.tzr_tune(b"bwd_no_fuse_sort", 1)  # the plan is verified from ks[0]: every unit sorted by the sort launch
         for kv in knobs:
             name, v = kv.split("=")
             assert L.tzr_tune(name.encode(), int(v)) == 0, kv

@@ -25,6 +25,7 @@ def run(iters, dbg, B=65536, seed=0, variant=0):
                                  device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=lr))
     rng = np.random.default_rng(seed)
     _lib.lib().tzr_tune(b"bwd_one_wg_heavy", int(os.environ.get("TZR_ONE_WG_HEAVY", "0")))
+    _lib.lib().tzr_tune(b"bwd_no_fuse_sort", 1)  # the plan is verified from ks[0]: every unit sorted by the sort launch
     bad = 0
     import time
     t0 = time.time()

@@ -19,12 +19,14 @@ from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
 
 @pytest.fixture(autouse=True)
 def _planned_backward(dev):
-    """these tests inspect the index plan: batches this small would otherwise take the plan-less one-launch backward"""
+    """these tests inspect the index plan: batches this small would otherwise take the plan-less one-launch backward, and a fused
+    plan leaves the units without heavy lookups to the apply's own LDS sort (ks[0] would be incomplete: bwd_no_fuse_sort)"""
     from torcheasyrec_amd import _lib
 
-    assert _lib.lib().tzr_tune(b"bwd_direct", -1) == 0
+    assert _lib.lib().tzr_tune(b"bwd_direct", -1) == 0 and _lib.lib().tzr_tune(b"bwd_no_fuse_sort", 1) == 0
     yield
     _lib.lib().tzr_tune(b"bwd_direct", 0)
+    _lib.lib().tzr_tune(b"bwd_no_fuse_sort", 0)
 
 
 def _ids(rng, rows, n, kind):

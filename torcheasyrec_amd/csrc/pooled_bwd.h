@@ -75,6 +75,10 @@ struct BwdPlan {  // pointers into the caller workspace
   uint32_t* stot;          // [T * nslices * BWD_NB] scan slices: bucket counts of a slice of a table's chunks, then
                            //     (in place) the slice's base = counts of the slices before it (only when nslices > 1)
   uint32_t* scnt;          // [T] slices of the table that have arrived (zeroed by the hist launch)
+  uint32_t* umix;          // [max_chunks] 1 = the unit's table holds heavy buckets (scan launch): its light lookups are sorted by the
+                           //     sort launch; the units of every other bucketed table are sorted by the APPLY itself in LDS when
+                           //     the plan was built fused (hcount[1]; pooled_bwd_apply.hip: bwd_stage_unit)
+  int32_t fuse;            // host side of hcount[1] (plan launch only)
   int32_t nslices;         // workgroups per table of the scan launch
   int64_t max_chunks;
   int64_t max_heavy;
@@ -139,6 +143,8 @@ static inline size_t bwd_layout(BwdPlan* p, void* ws, int64_t NV, int64_t N, int
   q.nslices = bwd_pick_slices(N, T, q.ch);
   q.stot = c.take<uint32_t>(q.nslices > 1 ? (size_t)T * q.nslices * BWD_NB : 1);
   q.scnt = c.take<uint32_t>(T > 0 ? T : 1);
+  q.umix = c.take<uint32_t>(q.max_chunks);
+  q.fuse = 0;
   if (p) *p = q;
   return c.off;
 }

@@ -25,6 +25,27 @@
 
 #include "pooled_bwd_sort.h"
 
+#ifdef IT_PROF  // scripts/build_prof_lib.sh: wall-clock (100 MHz) start / end of every workgroup of the plan's four launches
+#define PLAN_PROF_WGS 4096
+__device__ uint64_t g_plan_prof[4 * PLAN_PROF_WGS * 2];
+struct PlanProf {
+  int k;
+  __device__ PlanProf(int k_) : k(k_) {
+    if (threadIdx.x == 0 && blockIdx.x < PLAN_PROF_WGS) g_plan_prof[((size_t)k * PLAN_PROF_WGS + blockIdx.x) * 2] = wall_clock64();
+  }
+  __device__ ~PlanProf() {
+    if (threadIdx.x == 0 && blockIdx.x < PLAN_PROF_WGS) g_plan_prof[((size_t)k * PLAN_PROF_WGS + blockIdx.x) * 2 + 1] = wall_clock64();
+  }
+};
+#define PLAN_PROF(k) PlanProf plan_prof_(k)
+extern "C" int tzr_plan_prof_dump(uint64_t* h_out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_plan_prof), sizeof(uint64_t) * 4 * PLAN_PROF_WGS * 2) == hipSuccess ? 0 : -1;
+}
+#else
+#define PLAN_PROF(k)
+#endif
+
 extern "C" size_t tzr_pooled_bwd_workspace(int64_t n_values, int64_t n_positions, int n_feats,
                                            int n_tables, int64_t B, int max_dim) {
   (void)B;
@@ -83,6 +104,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
     }
     P.feat_start[F] = run;
     P.hcount[0] = 0;
+    P.hcount[1] = (uint32_t)P.fuse;
   }
   for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
   __syncthreads();
@@ -110,6 +132,7 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_prep_kernel(
 template <bool FUSED>
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
     const TzrTable* __restrict__ tables, int T, int F, BwdSrcArgs A, BwdPlan P) {
+  PLAN_PROF(0);
   __shared__ unsigned h[BWD_NB];
   __shared__ BwdGeoLds GL;
   BwdGeo G;
@@ -126,7 +149,10 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
       for (int f = threadIdx.x; f < F; f += BWD_THREADS) P.feat_by_order[A.feats[f].order] = f;
       for (int t = threadIdx.x; t <= T; t += BWD_THREADS) P.tab_chunk[t] = (int32_t)GL.tchunk[t];
       for (int t = threadIdx.x; t < T; t += BWD_THREADS) P.tab_stitch[t] = 0;
-      if (threadIdx.x == 0) P.hcount[0] = 0;
+      if (threadIdx.x == 0) {
+        P.hcount[0] = 0;
+        P.hcount[1] = (uint32_t)P.fuse;  // the apply sorts the units without heavy lookups itself (read by the sort launch and the apply)
+      }
     }
   } else {
     G.fstart = P.feat_start;
@@ -206,8 +232,9 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_hist_kernel(
 #define BWD_SCAN_BATCH 64
 __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __restrict__ tables,
                                                               int T, int one_wg_heavy, BwdPlan P) {
+  PLAN_PROF(1);
   __shared__ unsigned tot[BWD_NB];
-  __shared__ int s_last;
+  __shared__ int s_last, s_heavy;
   const int nsl = P.nslices;
   const int t = nsl > 1 ? (int)blockIdx.x / nsl : (int)blockIdx.x;
   const int sl = nsl > 1 ? (int)blockIdx.x % nsl : 0;
@@ -252,6 +279,15 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
     }
     if (C <= 0) return;
   }
+  // A table WITH heavy buckets keeps the sort launch for all of its units (the launch is long anyway -- its heavy buckets -- and
+  // the light units sort under them for free: fusing them into the apply measured +6 us on Zipf ids, profiles/r05ao); a table
+  // without any leaves every unit to the apply.
+  if (bin == 0) s_heavy = 0;  // (a variable of its own: other waves may still be reading s_last above)
+  __syncthreads();
+  if (!exact && run > BWD_TH) s_heavy = 1;
+  __syncthreads();
+  const int any_heavy = s_heavy;
+  for (int i = bin; i < C; i += BWD_NB) P.umix[c0 + i] = any_heavy ? 1u : 0u;
   tot[bin] = run;
   __syncthreads();
   // Hillis-Steele inclusive scan over the buckets
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(BWD_NB) void tzr_bwd_scan_kernel(const TzrTable* __
 // 2 x 4 bytes to unrelated lines, ~3x write amplification measured).
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
     const TzrTable* __restrict__ tables, int T, BwdSrcArgs A, BwdPlan P) {
+  PLAN_PROF(2);
   __shared__ BwdRankLds<BWD_NB> L;
   __shared__ unsigned base0[BWD_NB];  // global position of the chunk's first element of each bucket
   __shared__ uint2 stage[BWD_CH];
@@ -434,8 +471,10 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_scatter_kernel(
 __device__ __forceinline__ void bwd_sort_unit(const TzrTable* __restrict__ tables, const BwdPlan& P,
                                               BwdSortLds& S, int c) {
   BwdChunkDesc cd;
+  const uint32_t uf = P.uflag[c], um = P.umix[c], fz = P.hcount[1];  // (fetched with the descriptor)
   if (!bwd_chunk(P, c, &cd)) return;
-  if (P.uflag[c]) return;
+  if (uf) return;
+  if (fz && !um) return;  // fused plan: a unit without heavy lookups is sorted by the apply, in its LDS (bwd_stage_unit)
   const int64_t s = P.ucut[c];
   const int64_t e = c + 1 < cd.last_chunk ? (int64_t)P.ucut[c + 1] : cd.te;
   const int n = (int)(e - s);
@@ -939,6 +978,7 @@ __global__ void tzr_bwd_nop_kernel(uint32_t* p) {
 // first_block: offset added to blockIdx.x (the debug split launches the heavy workers on their own)
 __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(8) void tzr_bwd_sort_kernel(
     const TzrTable* __restrict__ tables, int n_units, unsigned first_block, unsigned total_blocks, BwdPlan P) {
+  PLAN_PROF(3);
   __shared__ BwdSortLds S;
   const unsigned bid = blockIdx.x + first_block;
   if ((int)bid < n_units) {
@@ -963,6 +1003,7 @@ int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
 int g_tzr_bwd_debug = 0;         // tzr_tune("bwd_debug"): bit 0/2 empty launch before/behind the sort, bit 1 sort split in two launches
+int g_tzr_bwd_no_fuse_sort = 0;  // tzr_tune("bwd_no_fuse_sort"): 1 = every unit is sorted by the sort launch (ks[0] complete: tzr_pooled_bwd_plan_view)
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
                                    const TzrFeature* d_feats, int n_feats, int n_keys,
@@ -987,6 +1028,7 @@ extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,
   if (!d_values) return TZR_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned chunks = (unsigned)P.max_chunks;
+  P.fuse = g_tzr_bwd_no_fuse_sort ? 0 : 1;
   BwdSrcArgs A;
   A.feats = d_feats;
   A.values = d_values;

@@ -36,6 +36,97 @@ extern "C" int tzr_bwd_prof_dump(uint64_t* h_out, int n_wg) {
 #endif
 
 #include "pooled_bwd_apply.h"
+#include "pooled_bwd_sort.h"
+
+// LDS of an apply workgroup: the unit's reduction (U), and -- before it, in the same bytes -- the unit's sort when the plan
+// left it to the apply (S).
+union BwdApplyLds {
+  BwdSortLds S;
+  BwdUnitLds U;
+};
+
+// The unit's lookups into U.sK[1 .. n] / U.sS[0 .. n) with a neighbour (or BWD_SENT) on either side, SORTED: from ks[0] (the
+// sort launch's output; ks[1] for an exact table, final after the partition pass) -- or, for a unit of a bucketed table whose
+// position range holds no heavy lookup when the plan was built fused (P.hcount[1]; pooled_bwd.hip: the sort launch skips those
+// units), from ks[1] through the sort launch's own LDS sort (bwd_sort_core: one LDS atomic per lookup into 512 groups by the
+// low bits of the row id, in-group ranking by (row id, position)), here.  That takes the unit sort's dependent chain --
+// descriptor -> cuts -> lookups -> LDS -> 8-byte scattered stores -> the apply's re-read -- off the step: with uniform ids the
+// sort launch was 15 us behind a 2.7 us launch gap, each of its workgroups 12.7 us (profiles/r05an/plan_phase_profile.txt).
+// A unit made of whole light buckets has no run that continues outside it: sentinels on both sides.  All threads call; ends
+// with a barrier.
+__device__ __forceinline__ void bwd_stage_unit(const BwdPlan& P, const BwdChunkDesc& cd, int64_t s, int64_t e, int n, bool fused,
+                                               BwdApplyLds& L, TzrDst* sG, const BwdGrads& G) {
+  const int64_t ts = cd.ts, te = cd.te;
+  if (!fused) {
+    const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
+    for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+      const uint2 v = KS[s + i];
+      L.U.sK[i + 1] = v.x;
+      L.U.sS[i] = v.y;
+    }
+    if (threadIdx.x == 0) {
+      // the neighbours outside the unit are either in another bucket (another row id) or in the same
+      // sorted bucket: comparing with them is always meaningful
+      L.U.sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
+      L.U.sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
+#pragma unroll
+      for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
+    }
+    __syncthreads();
+    return;
+  }
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const uint2* __restrict__ src = P.ks[1] + s;
+  constexpr int kRounds = BWD_UMAX / BWD_THREADS;
+  const int pw = bwd_wave_span(n);
+  const int rounds = pw / TZR_WAVE;
+  uint32_t kreg[kRounds], sreg[kRounds], dest[kRounds];
+  uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    const bool in = r < rounds && lp < n;
+    const uint2 v = src[lp < n ? lp : n - 1];  // (clamped, unconditional: see bwd_elem_one)
+    kreg[r] = in ? v.x : 0u;
+    sreg[r] = in ? v.y : 0u;
+    if (in) {
+      vmask |= 1u << r;
+      kmin = min(kmin, v.x);
+      kmax = max(kmax, v.x);
+    }
+  }
+  for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, TZR_WAVE));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m, TZR_WAVE));
+  }
+  if (lane == 0) {
+    L.S.smm[wv] = kmin;
+    L.S.smm[BWD_WAVES + wv] = kmax;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < BWD_WAVES; ++w) {
+    kmin = min(kmin, L.S.smm[w]);
+    kmax = max(kmax, L.S.smm[BWD_WAVES + w]);
+  }
+  __syncthreads();  // smm is reused by the core
+  bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), true, L.S, dest);
+  __syncthreads();  // the sort's LDS is dead: the unit's arrays take its place
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r)
+    if ((vmask >> r) & 1u) {
+      L.U.sK[dest[r] + 1] = kreg[r];
+      L.U.sS[dest[r]] = sreg[r];
+    }
+  if (threadIdx.x == 0) {
+    L.U.sK[0] = BWD_SENT;
+    L.U.sK[n + 1] = BWD_SENT;
+#pragma unroll
+    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];
+  }
+  __syncthreads();
+}
 
 // Runs crossing unit boundaries: the unit holding the run's first lookup adds the leading pieces
 // of the following units (in order) and updates the row.  One wave.
@@ -134,15 +225,21 @@ __device__ __forceinline__ void bwd_reduce_body(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, const BwdGrads& G, const BwdOpt& opt, int max_dim, const BwdPlan& P) {
-  __shared__ uint32_t sK[BWD_UMAX + 2];  // K[s-1], K[s..e), K[e] (sentinels at table ends)
-  __shared__ uint32_t sS[BWD_UMAX];
-  __shared__ uint32_t rflags[BWD_WAVES], rlkey[BWD_WAVES], rtkey[BWD_WAVES];
-  __shared__ float rlead[BWD_WAVES][BWD_MAXDIM], rtrail[BWD_WAVES][BWD_MAXDIM];
+  __shared__ BwdApplyLds L;
   __shared__ TzrDst sG[TZR_MAX_DST];
+  uint32_t* const sK = L.U.sK;  // K[s-1], K[s..e), K[e] (sentinels at table ends)
+  uint32_t* const sS = L.U.sS;
+  uint32_t* const rflags = L.U.rflags;
+  uint32_t* const rlkey = L.U.rlkey;
+  uint32_t* const rtkey = L.U.rtkey;
+  float(*const rlead)[BWD_MAXDIM] = L.U.rlead;
+  float(*const rtrail)[BWD_MAXDIM] = L.U.rtrail;
+  const uint32_t uf = P.uflag[blockIdx.x], um = P.umix[blockIdx.x], fz = P.hcount[1];
   BwdChunkDesc cd;
   if (!bwd_chunk(P, blockIdx.x, &cd)) return;
   const int t = cd.t;
   const int64_t ts = cd.ts, te = cd.te;
+  (void)ts;
   // the unit: sorted positions [s, e) of the table (pooled_bwd.hip, scan kernel)
   const int64_t s = P.ucut[blockIdx.x];
   const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)P.ucut[blockIdx.x + 1] : te;
@@ -152,25 +249,9 @@ __device__ __forceinline__ void bwd_reduce_body(
     if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;  // overlaps no bucket: nobody waits for it
     return;
   }
-  // exact tables are final after the partition pass (ks[1]); everything else was finished by the
-  // sort kernel (ks[0])
-  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
-  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-    const uint2 v = KS[s + i];
-    sK[i + 1] = v.x;
-    sS[i] = v.y;
-  }
-  if (threadIdx.x == 0) {
-    // the neighbours outside the unit are either in another bucket (another row id) or in the same
-    // sorted bucket: comparing with them is always meaningful
-    sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
-    sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
-#pragma unroll
-    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
-  }
-  __syncthreads();
+  bwd_stage_unit(P, cd, s, e, n, fz && !cd.exact && !uf && !um, L, sG, G);
 
   const int lg = tb.dim >> 2;    // lanes per row
   const int gw = TZR_WAVE / lg;  // lookups per tile
@@ -329,17 +410,19 @@ __device__ __forceinline__ void bwd_reduce_body_fast(
     const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats,
     const int64_t* __restrict__ offsets, const float* __restrict__ weights, int64_t B, int uniform,
     int grad_mode, const BwdGrads& G, const BwdOpt& opt, int max_dim, const BwdPlan& P) {
-  __shared__ BwdUnitLds U;
+  __shared__ BwdApplyLds L;
   __shared__ TzrDst sG[TZR_MAX_DST];
+  BwdUnitLds& U = L.U;
   BWD_PROF_MARK(0);  // workgroup started
-  // (the unit's cuts are fetched WITH its descriptor, not behind it: the staging below is a chain of dependent round trips --
-  // descriptor -> cuts -> keys -> LDS, 4.9 us per workgroup in profiles/r05ai/apply_phase_profile.txt; the grid is max_chunks
-  // workgroups and ucut holds max_chunks + 1 entries)
+  // (the unit's cuts and flags are fetched WITH its descriptor, not behind it: the staging below is a chain of dependent round
+  // trips -- descriptor -> cuts -> keys -> LDS, 4.9 us per workgroup in profiles/r05ai/apply_phase_profile.txt; the grid is
+  // max_chunks workgroups and ucut holds max_chunks + 1 entries)
   const uint32_t u0 = P.ucut[blockIdx.x], u1 = P.ucut[blockIdx.x + 1];
+  const uint32_t uf = P.uflag[blockIdx.x], um = P.umix[blockIdx.x], fz = P.hcount[1];
   BwdChunkDesc cd;
   if (!bwd_chunk(P, blockIdx.x, &cd)) return;
   const int t = cd.t;
-  const int64_t ts = cd.ts, te = cd.te;
+  const int64_t te = cd.te;
   const int64_t s = u0;
   const int64_t e = (int)blockIdx.x + 1 < cd.last_chunk ? (int64_t)u1 : te;
   const int n = (int)(e - s);
@@ -348,22 +431,10 @@ __device__ __forceinline__ void bwd_reduce_body_fast(
     if (threadIdx.x == 0) P.cflags[blockIdx.x] = 0;
     return;
   }
-  const uint2* __restrict__ KS = cd.exact ? P.ks[1] : P.ks[0];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const TzrFeature* const ft = feats + P.feat_by_order[tb.first_order];
   const int ft_dst = ft->n_dst;  // (issued with the unit's keys: no round trip of its own)
-  for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-    const uint2 v = KS[s + i];
-    U.sK[i + 1] = v.x;
-    U.sS[i] = v.y;
-  }
-  if (threadIdx.x == 0) {
-    U.sK[0] = s > ts ? KS[s - 1].x : BWD_SENT;
-    U.sK[n + 1] = e < te ? KS[e].x : BWD_SENT;
-#pragma unroll
-    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];
-  }
-  __syncthreads();
+  bwd_stage_unit(P, cd, s, e, n, fz && !cd.exact && !uf && !um, L, sG, G);
   BWD_PROF_MARK(1);  // unit staged in LDS
   const float lr = *opt.lr;
   const int lg = tb.dim >> 2;
