@@ -1116,18 +1116,21 @@ def main():
                         "GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
 
             direct = not t_plan  # no plan launch: the one-launch backward of small batches (tzr_pooled_bwd_direct)
+            kind_k = {"adagrad": "adagrad", "rowwise_adagrad": "rowwise", "sgd": "sgd"}.get(args.optimizer)
+            apply_k = f"tzr_bwd_reduce_fast_{kind_k}_kernel" if kind_k else "tzr_bwd_reduce_kernel"   # (the optimizer kind is a template parameter)
+            direct_k = f"tzr_bwd_direct_{kind_k}_kernel" if kind_k else "tzr_bwd_direct_adam_kernel"
             fwd_k = "tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"
             stages = [stage("forward", [fwd_k], fwd_b, t_fwd)]
             if direct:
-                stages.append(stage("backward (index sort + fused optimizer, one launch)", ["tzr_bwd_direct_kernel"], bwd_b, t_apply))
+                stages.append(stage("backward (index sort + fused optimizer, one launch)", [direct_k], bwd_b, t_apply))
             else:
                 stages += [{"stage": "backward plan", "kernels": ["tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
                                                                  "tzr_bwd_sort_kernel"], "launch_ms": t_plan, "algorithmic_bytes": 0.0,
                             "GBps": 0.0, "frac": 0.0},
-                           stage("backward apply", ["tzr_bwd_reduce_w7_kernel"], bwd_b, t_apply)]
+                           stage("backward apply (+ the LDS sort of every unit of a table without heavy buckets)", [apply_k], bwd_b, t_apply)]
             out["roofline"] = {
-                "bound": "hbm", "kernel": ("pooled embedding forward + backward (" + ("2 launches: " + fwd_k + "; tzr_bwd_direct_kernel" if direct else
-                                           "6 launches: " + fwd_k + "; tzr_bwd_hist/scan/scatter/sort_kernel; tzr_bwd_reduce_w7_kernel") + ")"),
+                "bound": "hbm", "kernel": ("pooled embedding forward + backward (" + ("2 launches: " + fwd_k + "; " + direct_k if direct else
+                                           "6 launches: " + fwd_k + "; tzr_bwd_hist/scan/scatter/sort_kernel; " + apply_k) + ")"),
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "traffic": traffic, "launch_ms": t_fwd + t_plan + t_apply,
                 "algorithmic_bytes": fwd_b + bwd_b,

@@ -37,8 +37,9 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
         e = ks[fwd_name]
         e["traffic_corrected"] = e["FETCH_SIZE"] + 0.5 * 8 * int(n_lookups) + e["WRITE_SIZE"]
     # the north-star aggregate: the six launches of the pooled embedding forward + backward
-    red_name = next((k for k in ("tzr_bwd_reduce_w7_kernel", "tzr_bwd_reduce_w8_kernel", "tzr_bwd_reduce_kernel") if k in ks),
-                    "tzr_bwd_reduce_kernel")  # the apply's default instantiation: 7 waves per SIMD
+    red_name = next((k for k in ("tzr_bwd_reduce_fast_adagrad_kernel", "tzr_bwd_reduce_fast_rowwise_kernel", "tzr_bwd_reduce_fast_sgd_kernel",
+                                 "tzr_bwd_reduce_w7_kernel", "tzr_bwd_reduce_w8_kernel", "tzr_bwd_reduce_kernel") if k in ks),
+                    "tzr_bwd_reduce_kernel")  # the apply's instantiation for the run's optimizer (round 5: the fast tile loop)
     six = [fwd_name, "tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
            "tzr_bwd_sort_kernel", red_name]
     if all(k in ks for k in six):
