@@ -57,6 +57,18 @@ class NativeComm:
         _lib.check(L.tzr_comm_create(path, C.cast(uid, C.c_void_p), 128, self.world, self.rank, C.byref(h)), "tzr_comm_create")
         self._h = h
         self.version = int(L.tzr_comm_version(path))
+        # RCCL sets its peer connections up lazily, on the first call of a kind -- a host-side handshake between the ranks.  One
+        # eager call of each collective this class offers, here, so that none of that happens while a stream is being captured
+        # (the step's first native call IS a capture: sharded_step._capture_native).
+        dev = torch.device(device) if device is not None else None
+        if dev is not None and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            a = torch.zeros(self.world * 64, dtype=torch.int64, device=dev)
+            b = torch.empty_like(a)
+            r = torch.zeros(1024, dtype=torch.float32, device=dev)
+            self.all_to_all(a, b)
+            self.all_reduce(r, average=False)
+            self.all_reduce(r, average=True)
+            torch.cuda.current_stream(dev).synchronize()
 
     @property
     def handle(self) -> C.c_void_p:
