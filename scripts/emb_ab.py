@@ -18,7 +18,7 @@ from torcheasyrec_amd import _build, _lib  # noqa: E402
 from torcheasyrec_amd.criteo import CRITEO_ROWS, SPARSE_KEYS, algorithmic_bytes, criteo_tables, synthetic_batch  # noqa: E402
 from torcheasyrec_amd.embedding import EmbeddingBagCollection, SparseOptimizerConfig  # noqa: E402
 
-KNOBS = [b"bwd_apply_waves", b"bwd_apply_fast", b"bwd_no_fuse_sort", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
+KNOBS = [b"bwd_apply_waves", b"bwd_apply_fast", b"bwd_no_fuse_sort", b"bwd_scan_slices", b"fwd_tile_b", b"fwd_variant", b"bwd_ch", b"bwd_one_wg_heavy", b"bwd_force_prep"]
 
 
 class Timers:

@@ -39,7 +39,7 @@ def _default_knobs():
     from torcheasyrec_amd import _lib
 
     if _lib._lib is not None:
-        for name in (b"bwd_apply_waves", b"bwd_apply_fast", b"bwd_no_fuse_sort", b"fwd_tile_b", b"fwd_variant", b"bwd_debug", b"bwd_ch", b"bwd_direct_ch", b"bwd_direct", b"bwd_direct_debug", b"bwd_force_prep", b"linear_bwd_wg", b"bwd_one_wg_heavy", b"ia_bwd_plain", b"ia_bwd_wgs", b"ia_fwd_wgs", b"ia_gen_wgs", b"it_wgs", b"it_stagger", b"mlp_mfma", b"wg_debug", b"it_fwd_stagger"):
+        for name in (b"bwd_apply_waves", b"bwd_apply_fast", b"bwd_no_fuse_sort", b"bwd_scan_slices", b"fwd_tile_b", b"fwd_variant", b"bwd_debug", b"bwd_ch", b"bwd_direct_ch", b"bwd_direct", b"bwd_direct_debug", b"bwd_force_prep", b"linear_bwd_wg", b"bwd_one_wg_heavy", b"ia_bwd_plain", b"ia_bwd_wgs", b"ia_fwd_wgs", b"ia_gen_wgs", b"it_wgs", b"it_stagger", b"mlp_mfma", b"wg_debug", b"it_fwd_stagger"):
             _lib.lib().tzr_tune(name, 0)
         _lib.apply_env_tune()
 

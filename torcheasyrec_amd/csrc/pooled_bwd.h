@@ -102,7 +102,9 @@ static inline int64_t bwd_max_chunks(int64_t N, int T, int ch) { return N / ch +
 // sequence path, 417 k ids -- made that launch 128 us (profiles/r03bp).  When the average table has more than 128 chunks
 // the walk is cut into slices of ~128 chunks, a workgroup each; the last to arrive finishes the table.
 #define BWD_MAXSL 16
+extern int g_tzr_bwd_scan_slices;  // tzr_tune("bwd_scan_slices"): > 0 forces the workgroups per table of the scan launch (<= BWD_MAXSL)
 static inline int bwd_pick_slices(int64_t N, int T, int ch) {
+  if (g_tzr_bwd_scan_slices > 0) return g_tzr_bwd_scan_slices > BWD_MAXSL ? BWD_MAXSL : g_tzr_bwd_scan_slices;
   const int64_t avg = N / ((int64_t)(T > 0 ? T : 1) * ch);
   if (avg <= 128) return 1;
   const int64_t s = (avg + 127) / 128;

@@ -1003,6 +1003,7 @@ int g_tzr_bwd_force_prep = 0;  // tzr_tune("bwd_force_prep"): take the > BWD_GEO
 int g_tzr_bwd_ch = 0;          // tzr_tune("bwd_ch"): positions per chunk (0 = by problem size)
 int g_tzr_bwd_one_wg_heavy = 0;  // tzr_tune("bwd_one_wg_heavy"): no tile-parallel heavy buckets
 int g_tzr_bwd_debug = 0;         // tzr_tune("bwd_debug"): bit 0/2 empty launch before/behind the sort, bit 1 sort split in two launches
+int g_tzr_bwd_scan_slices = 0;   // tzr_tune("bwd_scan_slices"), see bwd_pick_slices
 int g_tzr_bwd_no_fuse_sort = 0;  // tzr_tune("bwd_no_fuse_sort"): 1 = every unit is sorted by the sort launch (ks[0] complete: tzr_pooled_bwd_plan_view)
 
 extern "C" int tzr_pooled_bwd_plan(const TzrTable* d_tables, int n_tables,

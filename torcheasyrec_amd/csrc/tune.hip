@@ -12,6 +12,7 @@ extern int g_tzr_bwd_debug;
 extern int g_tzr_bwd_apply_waves;
 extern int g_tzr_bwd_apply_fast;
 extern int g_tzr_bwd_no_fuse_sort;
+extern int g_tzr_bwd_scan_slices;
 extern int g_tzr_bwd_direct_ch;
 extern int g_tzr_bwd_direct;
 extern int g_tzr_bwd_direct_debug;
@@ -71,6 +72,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "ia_fwd_wgs")) {
     g_tzr_ia_fwd_wgs = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "bwd_scan_slices")) {
+    g_tzr_bwd_scan_slices = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_no_fuse_sort")) {
