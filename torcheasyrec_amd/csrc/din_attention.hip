@@ -116,7 +116,8 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_q_kernel(
     const int64_t b = k / lg;
     const int64_t s = offsets[b], e = offsets[b + 1];
     float4 a = tzr_zero4();
-    for (int64_t n = s; n < e; ++n) {
+    for (int64_t n = s; n < e; ++n) {  // (four positions' loads in flight at a time measured no better: 80.8 vs 76.8 us, profiles/r05au --
+      //                                   the lanes of a wave walk samples of different lengths, that is the cost)
       const float* xp = dX + n * xs + 4 * c;
       const float4 g1 = tzr_ld4(xp + 4 * lg), g2 = tzr_ld4(xp + 8 * lg), kk = tzr_ld4(kv + n * kvs + 4 * c);
       a.x += fmaf(kk.x, g1.x, g2.x); a.y += fmaf(kk.y, g1.y, g2.y); a.z += fmaf(kk.z, g1.z, g2.z); a.w += fmaf(kk.w, g1.w, g2.w);
@@ -177,16 +178,27 @@ __device__ __forceinline__ float da_wave_sum(float v) {
 __device__ __forceinline__ void da_row_dots(const float* __restrict__ rows, int64_t stride, int64_t s, int len, int cols4,
                                             const float* __restrict__ w, float bias, float* sc, int lane) {
   const int g = lane >> 4, j = lane & 15;
-  for (int i0 = 0; i0 < len; i0 += 4) {
-    const int i = i0 + g;
-    float a = 0.f;
-    if (i < len)
+  // sixteen positions per pass: four per 16-lane group, their row loads in flight TOGETHER (a position behind the sample's last
+  // re-reads the last: no load sits inside a branch).  One position per pass was one dependent round trip per four positions,
+  // 14 in a row for a 55-click history (72 us for the forward kernel, profiles/r05x).  Same arithmetic per position.
+  for (int i0 = 0; i0 < len; i0 += 16) {
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u + g;
+      const int ic = i < len ? i : len - 1;
+      a[u] = 0.f;
       for (int c = j; c < cols4; c += 16) {
-        const float4 x = tzr_ld4(rows + (s + i) * stride + 4 * c), ww = tzr_ld4(w + 4 * c);
-        a = fmaf(x.x, ww.x, a); a = fmaf(x.y, ww.y, a); a = fmaf(x.z, ww.z, a); a = fmaf(x.w, ww.w, a);
+        const float4 x = tzr_ld4(rows + (s + ic) * stride + 4 * c), ww = tzr_ld4(w + 4 * c);
+        a[u] = fmaf(x.x, ww.x, a[u]); a[u] = fmaf(x.y, ww.y, a[u]); a[u] = fmaf(x.z, ww.z, a[u]); a[u] = fmaf(x.w, ww.w, a[u]);
       }
-    a = da_group16_sum(a);
-    if (i < len && j == 0) sc[i] = a + bias;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u + g;
+      const float t = da_group16_sum(a[u]);
+      if (i < len && j == 0) sc[i] = t + bias;
+    }
   }
 }
 
@@ -227,7 +239,17 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_attn_fwd_kernel(
     const int g = lane >> 4, j = lane & 15;
     for (int c = j; c < (D >> 2); c += 16) {
       float4 a = tzr_zero4();
-      for (int i = g; i < len; i += 4) a = tzr_fma4(sc[i], tzr_ld4(kv + (s + i) * kvs + 4 * c), a);
+      for (int i0 = g; i0 < len; i0 += 16) {  // four of the group's positions per pass, loads together, added in position order
+        float4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 4 * u;
+          r[u] = tzr_ld4(kv + (s + (i < len ? i : len - 1)) * kvs + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 4 * u < len) a = tzr_fma4(sc[i0 + 4 * u], r[u], a);
+      }
       a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
       a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
       if (g == 0) tzr_st4(out + b * outs + 4 * c, a);
