@@ -106,23 +106,33 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_k_kernel(
   }
 }
 
-// dq: thread = (sample, chunk), its positions in order
+// dq: one WAVE per sample (a thread per (sample, chunk) walking the sample's positions made the lanes of a wave wait for the
+// longest of their five samples: 77 us, profiles/r05x).  Lane (g, c): position group g = lane / lg of 64 / lg, chunk c; the
+// groups take positions g, g + G, ... and are added in group order at the end (fixed order: a function of the lengths alone).
 __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_q_kernel(
     const float* __restrict__ dX, int64_t xs, const float* __restrict__ kv, int64_t kvs, const int64_t* __restrict__ offsets,
     int64_t B, int lg, float* __restrict__ dq, int64_t dqs) {
-  const int64_t total = B * lg;
-  for (int64_t k = (int64_t)blockIdx.x * DA_THREADS + threadIdx.x; k < total; k += (int64_t)gridDim.x * DA_THREADS) {
-    const int c = (int)(k % lg);
-    const int64_t b = k / lg;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int G = TZR_WAVE / lg;  // position groups of a wave (lg <= 64)
+  const int g = lane / lg, c = lane - g * lg;
+  const bool on = g < G;
+  for (int64_t b = (int64_t)blockIdx.x * DA_WAVES + wv; b < B; b += (int64_t)gridDim.x * DA_WAVES) {
     const int64_t s = offsets[b], e = offsets[b + 1];
     float4 a = tzr_zero4();
-    for (int64_t n = s; n < e; ++n) {  // (four positions' loads in flight at a time measured no better: 80.8 vs 76.8 us, profiles/r05au --
-      //                                   the lanes of a wave walk samples of different lengths, that is the cost)
-      const float* xp = dX + n * xs + 4 * c;
-      const float4 g1 = tzr_ld4(xp + 4 * lg), g2 = tzr_ld4(xp + 8 * lg), kk = tzr_ld4(kv + n * kvs + 4 * c);
-      a.x += fmaf(kk.x, g1.x, g2.x); a.y += fmaf(kk.y, g1.y, g2.y); a.z += fmaf(kk.z, g1.z, g2.z); a.w += fmaf(kk.w, g1.w, g2.w);
+    if (on)
+      for (int64_t n = s + g; n < e; n += G) {
+        const float* xp = dX + n * xs + 4 * c;
+        const float4 g1 = tzr_ld4(xp + 4 * lg), g2 = tzr_ld4(xp + 8 * lg), kk = tzr_ld4(kv + n * kvs + 4 * c);
+        a.x += fmaf(kk.x, g1.x, g2.x); a.y += fmaf(kk.y, g1.y, g2.y); a.z += fmaf(kk.z, g1.z, g2.z); a.w += fmaf(kk.w, g1.w, g2.w);
+      }
+    float4 t = a;  // group 0's lanes collect the groups in order
+    for (int q = 1; q < G; ++q) {
+      const int src = q * lg + (lane < lg ? lane : 0);
+      const float4 o = make_float4(__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src), __shfl(a.w, src));
+      if (lane < lg) t = tzr_add4(t, o);
     }
-    tzr_st4(dq + b * dqs + 4 * c, a);
+    if (lane < lg) tzr_st4(dq + b * dqs + 4 * lane, t);
   }
 }
 
@@ -131,9 +141,9 @@ extern "C" int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const f
                                     int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
                                     float* d_dq, int64_t dq_stride, void* stream) {
   if (B < 0 || N < 0 || D <= 0) return TZR_ERR_INVALID;
-  if ((D & 3) || ((kv_stride | q_stride | x_stride | dkv_stride | dq_stride) & 3) || kv_stride < D || q_stride < D ||
+  if ((D & 3) || D > 4 * TZR_WAVE || ((kv_stride | q_stride | x_stride | dkv_stride | dq_stride) & 3) || kv_stride < D || q_stride < D ||
       x_stride < 3 * D || dkv_stride < D || dq_stride < D)
-    return TZR_ERR_UNSUPPORTED;
+    return TZR_ERR_UNSUPPORTED;  // (D <= 256: a wave holds a row of the query gradient)
   if (B > 0 && (!d_offsets || !d_dq || (reinterpret_cast<uintptr_t>(d_dq) & 15))) return TZR_ERR_INVALID;
   if (N > 0 && (!d_dX || !d_kv || !d_q || !d_seg || !d_dkv ||
                 ((reinterpret_cast<uintptr_t>(d_dX) | reinterpret_cast<uintptr_t>(d_kv) | reinterpret_cast<uintptr_t>(d_q) |
@@ -147,7 +157,7 @@ extern "C" int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const f
                        lg, d_dkv, dkv_stride, accumulate_dkv);
   }
   if (B > 0) {
-    const unsigned grid = (unsigned)std::min<int64_t>(16384, (B * lg + DA_THREADS - 1) / DA_THREADS);
+    const unsigned grid = (unsigned)std::min<int64_t>(16384, (B + DA_WAVES - 1) / DA_WAVES);
     hipLaunchKernelGGL(tzr_din_assemble_bwd_q_kernel, dim3(grid), dim3(DA_THREADS), 0, s, d_dX, x_stride, d_kv, kv_stride, d_offsets,
                        B, lg, d_dq, dq_stride);
   }
