@@ -623,6 +623,7 @@ class GraphTrainPipeline:
         self._warmup, self._pool = warmup, None
         self._pending = None           # (slot, host batch) of the batch copied ahead
         self._wire = {}                # (slot, tensor index) -> int32 staging buffer of ids that cross PCIe narrowed
+        self._widen = [[], []]         # per slot: (int64 ids of the slot, their int32 staging buffer) still to be widened
         self._exhausted, self._i = False, 0
 
     def _stage(self, it):
@@ -644,13 +645,18 @@ class GraphTrainPipeline:
                 narrow = lambda a, b: a.dtype == torch.int32 and b.dtype == torch.int64  # noqa: E731 -- ids on the int32 wire
                 if len(src) != len(dst) or any(a.shape != b.shape or (a.dtype != b.dtype and not narrow(a, b)) for a, b in zip(src, dst)):
                     raise ValueError("GraphTrainPipeline needs fixed-shape batches (shapes changed between batches)")
+                widen = []
                 for j, (a, b) in enumerate(zip(src, dst)):
                     if a.dtype == b.dtype:
                         b.copy_(a, non_blocking=True)
-                    else:  # int32 over PCIe into a staging buffer of the slot, widened into the slot's int64 ids behind the copy
+                    else:  # int32 over PCIe into a staging buffer of the slot; widened into the slot's int64 ids on the STEP's
+                        # stream, in front of the step (progress): as a kernel of the copy stream it ran NEXT TO the previous
+                        # step's kernels -- 11-56 us of a second queue's kernel per step, and two queues share the chip badly
+                        # here (profiles/r05as: e2e 0.595 ms against 0.536 resident)
                         stg = self._wire.setdefault((slot, j), torch.empty(a.shape, dtype=torch.int32, device=self._device))
                         stg.copy_(a, non_blocking=True)
-                        b.copy_(stg)
+                        widen.append((b, stg))
+                self._widen[slot] = widen
             ev = torch.cuda.Event()
             ev.record()
             self._ready[slot] = ev
@@ -672,6 +678,9 @@ class GraphTrainPipeline:
         cur = torch.cuda.current_stream(self._device)
         cur.wait_event(self._ready[slot])
         batch = self._slots[slot]
+        for dst_ids, stg in self._widen[slot]:  # (see _stage)
+            dst_ids.copy_(stg)
+        self._widen[slot] = []
         if self._stage_first:
             self._pending = self._stage(dataloader_iter)  # batch i+1 crosses PCIe under the step below
         from .dense import lr_sync_targets, sync_learning_rates
