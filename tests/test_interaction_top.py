@@ -310,7 +310,7 @@ def test_dlrm_predict_without_grad_uses_fused_first_layer(dev):
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,wgs", [(600, 3), (97, 2), (256, 1), (33, 2)])
+@pytest.mark.parametrize("B,wgs", [(600, 3), (97, 2), (256, 1), (33, 2), (16, 1), (40, 3), (70, 2)])
 def test_top_persistent_loop_over_many_tiles(dev, B, wgs):
     """Few workgroups, many tiles each: the software pipeline (rows of tile t + G produced beside the product of tile t,
     double-buffered z tile, g1 / X fetched a tile ahead), a partial last tile, odd and even trip counts."""
@@ -333,6 +333,15 @@ def test_top_persistent_loop_over_many_tiles(dev, B, wgs):
                                              _lib.ptr(lin.bias), H, 0, _lib.ptr(z), width, _lib.ptr(y1), H, stream), "fwd")
     _close(y1, pre.detach(), 2e-6)
     _close(z, z_ref.detach(), 1e-6)
+    # ... and the kernel that does not write z (the training step's: one barrier per tile, the sum of a tile's partials taken
+    # a tile later out of the second set): the same sums in the same order, so the same bits
+    for relu in (0, 1):
+        y1z, y1n = torch.full((B, H), float("nan"), device=dev), torch.full((B, H), float("nan"), device=dev)
+        for zz, out in ((z, y1z), (None, y1n)):
+            _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight), width,
+                                                     _lib.ptr(lin.bias), H, relu, _lib.ptr(zz), width, _lib.ptr(out), H, stream), "fwd")
+        assert torch.equal(y1z, y1n)
+        _close(y1n, (torch.relu(pre) if relu else pre).detach(), 2e-6)
     gd, gs = torch.full_like(dense, float("nan")), torch.full_like(sparse, float("nan"))
     _lib.check(L.tzr_dot_interaction_top_bwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(g1), H, H,
                                              _lib.ptr(lin.weight), width, None, _lib.ptr(gd), D, _lib.ptr(gs), F * D, stream), "bwd")

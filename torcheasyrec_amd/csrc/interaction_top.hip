@@ -19,6 +19,7 @@
 // by the MFMAs of the other three (an 8-wave version with twice the work per wave ran at half the MFMA rate, and
 // interleaving the instruction streams by hand inside a wave did not help).
 #include "tzr_common.h"
+#include <type_traits>
 #include <tzr_gfx950.h>
 
 #define IT_THREADS 1024
@@ -30,6 +31,7 @@
 #define IT_MAXBLK 64                 // virtual column blocks: ceil(P / 16) + n <= 64, i.e. n <= 32
 #define IT_BPW (IT_MAXBLK / IT_WAVES)  // backward: column blocks per wave (4)
 #define IT_KB (IT_MAXBLK / 4)        // forward: blocks per K-group (16)
+#define IT_N_CRITEO 27               // DLRM-Criteo: 26 tables + the dense vector (351 pairs: 22 + 27 = 49 column blocks)
 #define IT_SROW 33                   // row pitch of one S matrix (odd: conflict-free column reads)
 #define IT_SS (32 * IT_SROW + 4)     // floats per sample in S (1060: the four sample groups of an accumulator scatter land 16 banks apart)
 #define IT_PS (32 * IT_D)            // floats per sample of pass-through gradients
@@ -118,9 +120,12 @@ struct ItBwdArgs {
 
 template <int NB, bool XL>
 __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restrict__ Z, float* __restrict__ xs, float* __restrict__ Gs,
-                                            float* __restrict__ Wx, uint16_t* __restrict__ Tab, int lane, int wv, int P, int npb, int nblk) {
+                                            float* __restrict__ Wx, uint16_t* __restrict__ Tab, int lane, int wv) {
   const int r = lane & 15, q = lane >> 4;
-  const int n = a.n;
+  // (XL is DLRM-Criteo's 49 blocks, i.e. 27 vectors: the row pitch, the block bounds and the lane masks are constants there)
+  const int n = XL ? IT_N_CRITEO : a.n;
+  const int P = n * (n - 1) / 2;
+  const int npb = (P + 15) >> 4, nblk = npb + n;
   const int zp = 16 * nblk + 4;           // pitch of a sample's dz row
   const bool dbl = zp <= IT_ZPD;          // two dz tiles fit
   const int zt = IT_TS * zp;              // floats per tile
@@ -316,9 +321,9 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_bwd_kernel(ItBwdArgs a)
   const int npb = (P + 15) >> 4, nblk = npb + n;
   // DLRM-Criteo: 49 blocks = 3 per wave and one more for wave 0 (fragment in LDS); up to 48: 3 per wave, zero-weighted;
   // more: 4 per wave in registers (spills, correct)
-  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
-  else if (nblk == 3 * IT_WAVES + 1) it_bwd_loop<3, true>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
-  else it_bwd_loop<4, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv, P, npb, nblk);
+  if (nblk <= 3 * IT_WAVES) it_bwd_loop<3, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv);
+  else if (n == IT_N_CRITEO) it_bwd_loop<3, true>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv);  // (the one n with 3 x 16 + 1 blocks)
+  else it_bwd_loop<4, false>(a, Z, &Xs[wv][0], Gs, Wx, Tab, lane, wv);
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
@@ -394,57 +399,71 @@ __device__ __forceinline__ void it_fwd_row_pairs_out(const float* __restrict__ z
   }
 }
 
-// NB whole blocks [vfirst, vfirst + base) per wave (`base` of them real, the rest zero weights) and one k-step of each of
-// the REM left-over blocks 4 base + j (k-step kg of it): every wave runs the same 4 NB + REM MFMAs per tile.
-template <int NB, int REM>
-__device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restrict__ Zs, float* __restrict__ Ys,
-                                            float* __restrict__ trash, int lane, int wv, int P, int npb, int base, int rem) {
-  const int r = lane & 15, q = lane >> 4;
-  const int kg = wv >> 2, hb = wv & 3;
-  const int n = a.n;
-  const int pt0 = 16 * npb;  // virtual column of X row 0
-  const int vfirst = kg * base, vlast = vfirst + base;
-  // W1 fragments [block of the group][kk] for this wave's 16 outputs; pad columns and blocks behind the group are zero.
-  // Staged through LDS (the z tile's space) in two halves of 32 rows so the global loads are coalesced runs.
-  float Wf[NB][4];
-  float Wx[REM > 0 ? REM : 1];  // ... and for k-step kg of the left-over blocks
-  {
-    const int nblk = npb + n;
-    float* Wl = Zs;  // [32 rows][IT_ZP]
-    const int c = threadIdx.x;  // thread -> virtual column (16 nblk <= 1024 of them)
-    const int col = c < 16 * nblk ? it_real_col(c, P, npb, nblk) : -1;
+// W1 fragments [block of the group][kk] for a wave's 16 outputs (pad columns and blocks behind the group are zero) and for
+// k-step kg of the left-over blocks.  Staged through LDS (the z tiles' space, [32 rows][ZP]) in two halves of 32 rows so
+// the global loads are coalesced runs; leaves both z tiles zeroed (the pad slots behind the last pair stay zero).
+template <int NB, int REM, int ZP>
+__device__ __forceinline__ void it_fwd_stage_w(const ItFwdArgs& a, float* __restrict__ Zs, float (&Wf)[NB][4], float (&Wx)[REM > 0 ? REM : 1],
+                                               int n, int P, int npb, int base, int rem, int vfirst, int vlast, int r, int q,
+                                               int kg, int hb) {
+  const int nblk = npb + n;
+  float* Wl = Zs;
+  const int c = threadIdx.x;  // thread -> virtual column (16 nblk <= 1024 of them)
+  const int col = c < 16 * nblk ? it_real_col(c, P, npb, nblk) : -1;
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      float w[2][16];
+  for (int half = 0; half < 2; ++half) {
+    float w[2][16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[g][i] = a.W1[(int64_t)(32 * half + 16 * g + i) * a.ldw + (col >= 0 ? col : 0)];
+    __syncthreads();  // the previous half has been read
+    if (c < ZP) {
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[g][i] = a.W1[(int64_t)(32 * half + 16 * g + i) * a.ldw + (col >= 0 ? col : 0)];
-      __syncthreads();  // the previous half has been read
-      if (c < IT_ZP) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) Wl[(16 * g + i) * IT_ZP + c] = col >= 0 ? w[g][i] : 0.f;
-      }
-      __syncthreads();
-      if ((hb >> 1) == half) {
-#pragma unroll
-        for (int m = 0; m < NB; ++m) {
-          const int v = vfirst + m;
-          const float4 w = tzr_ld4(Wl + (16 * (hb & 1) + r) * IT_ZP + 16 * (v < vlast ? v : vfirst) + 4 * q);
-          const float keep = v < vlast ? 1.f : 0.f;
-          Wf[m][0] = keep * w.x; Wf[m][1] = keep * w.y; Wf[m][2] = keep * w.z; Wf[m][3] = keep * w.w;
-        }
-#pragma unroll
-        for (int j = 0; j < REM; ++j)
-          Wx[j] = j < rem ? Wl[(16 * (hb & 1) + r) * IT_ZP + 16 * (4 * base + j) + 4 * q + kg] : 0.f;
-      }
+        for (int i = 0; i < 16; ++i) Wl[(16 * g + i) * ZP + c] = col >= 0 ? w[g][i] : 0.f;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * IT_TS * IT_ZP; k += IT_THREADS) Zs[k] = 0.f;  // the pad slots behind the last pair stay zero
-    __syncthreads();
+    if ((hb >> 1) == half) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        const int v = vfirst + m;
+        const float4 w = tzr_ld4(Wl + (16 * (hb & 1) + r) * ZP + 16 * (v < vlast ? v : vfirst) + 4 * q);
+        const float keep = v < vlast ? 1.f : 0.f;
+        Wf[m][0] = keep * w.x; Wf[m][1] = keep * w.y; Wf[m][2] = keep * w.z; Wf[m][3] = keep * w.w;
+      }
+#pragma unroll
+      for (int j = 0; j < REM; ++j)
+        Wx[j] = j < rem ? Wl[(16 * (hb & 1) + r) * ZP + 16 * (4 * base + j) + 4 * q + kg] : 0.f;
+    }
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * IT_TS * ZP; k += IT_THREADS) Zs[k] = 0.f;
+  __syncthreads();
+}
+
+// NB whole blocks [vfirst, vfirst + base) per wave (`base` of them real, the rest zero weights) and one k-step of each of
+// the REM left-over blocks 4 base + j (k-step kg of it): every wave runs the same 4 NB + REM MFMAs per tile.
+// NFIX > 0: the number of vectors is this constant (the pair offsets of the scatter, the clamps of the row loads and the
+// block counts fold into immediates: registers and VALU work of the row builder)
+template <int NB, int REM, bool ZOUT, int NFIX>
+__device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restrict__ Zs, float* __restrict__ Ys,
+                                            float* __restrict__ trash, int lane, int wv) {
+  // pitch of a sample's row in the z tile: the blocks of THIS n when it is a constant (LDS left for a second Ys)
+  constexpr int ZP = NFIX > 0 ? 16 * ((NFIX * (NFIX - 1) / 2 + 15) / 16 + NFIX) + 4 : IT_ZP;
+  const int r = lane & 15, q = lane >> 4;
+  const int kg = wv >> 2, hb = wv & 3;
+  const int n = NFIX > 0 ? NFIX : a.n;
+  const int P = n * (n - 1) / 2;
+  const int npb = (P + 15) >> 4;
+  // K-group kg: whole blocks [kg base, kg base + base), base = nblk / 4, and one k-step of each of the nblk % 4 blocks left
+  const int base = (npb + n) >> 2, rem = (npb + n) & 3;
+  const int pt0 = 16 * npb;  // virtual column of X row 0
+  const int vfirst = kg * base, vlast = vfirst + base;
+  float Wf[NB][4];
+  float Wx[REM > 0 ? REM : 1];  // ... and for k-step kg of the left-over blocks
+  it_fwd_stage_w<NB, REM, ZP>(a, Zs, Wf, Wx, n, P, npb, base, rem, vfirst, vlast, r, q, kg, hb);
   const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
   const int64_t G = gridDim.x;
   int64_t t = blockIdx.x;
@@ -452,9 +471,9 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
   {
     const int64_t b = t * IT_TS + wv;
     const ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, b, a.B, n, a.hd, r, q);
-    float* o = (a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
-    it_fwd_row(X, Zs + wv * IT_ZP, trash, o, n, P, pt0, lane);
-    it_fwd_row_pairs_out(Zs + wv * IT_ZP, o, P, lane);
+    float* o = (ZOUT && a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
+    it_fwd_row(X, Zs + wv * ZP, trash, o, n, P, pt0, lane);
+    it_fwd_row_pairs_out(Zs + wv * ZP, o, P, lane);
   }
   ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + G < ntiles ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
   int cur = 0;
@@ -464,19 +483,28 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
   TZR_OPAQUE(bias1);
   IT_PROF_DECL;
   for (; t < ntiles; t += G, cur ^= 1) {
-    const float* zb = Zs + cur * (IT_TS * IT_ZP);
+    const float* zb = Zs + cur * (IT_TS * ZP);
     tzr_lds_barrier();  // tile t complete in zb; the other buffer and Ys free
     IT_PROF_MARK(0);  // wait 1
     // ---- partial y1[:, 16 hb ..] over the z columns of this wave's K-group
     // Half of the waves (two of the four on every SIMD) produce the next tile's row BEFORE the product, the other half
     // behind it: in lockstep all sixteen would be in their LDS / store phase at once and the MFMA pipe would idle.
     const bool half = (wv >> 2) & 1;
-    const bool row_first = a.stagger == 0 ? half : a.stagger == 1;  // (1 = every wave builds its row first, 2 = every wave behind the product)
+    // (1 = every wave builds its row first, 2 = every wave behind the product; z not written: always behind it)
+    const bool row_first = ZOUT && (a.stagger == 0 ? half : a.stagger == 1);
     auto next_row = [&]() {
     // ---- the row of sample wv of tile t + G into the other buffer (and out to HBM); then tile t + 2 G's X rows take off
       if (t + G < ntiles) {
         const int64_t b = (t + G) * IT_TS + wv;
-        float* zs = Zs + (cur ^ 1) * (IT_TS * IT_ZP) + wv * IT_ZP;
+        float* zs = Zs + (cur ^ 1) * (IT_TS * ZP) + wv * ZP;
+        if (!ZOUT) {
+          // every wave is behind the product here: the rows fetched now are used a product and two barriers later, so
+          // they take off BEHIND the row and need no second set of registers (which spilled W1 fragments)
+          it_fwd_row(X, zs, trash, nullptr, n, P, pt0, lane);
+          X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (t + 2 * G < ntiles ? t + 2 * G : t) * IT_TS + wv,
+                         a.B, n, a.hd, r, q);
+          return;
+        }
         float* o = (a.z && b < a.B) ? a.z + b * a.z_stride : nullptr;
         // the X rows of the tile after that take off FIRST (into a second set of registers): a row-first wave is back
         // here ~3 k clocks after its last row, less than an HBM round trip under this load -- it stood 5 k clocks per tile
@@ -494,18 +522,19 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
     {
       // A operand of block m, k-steps 0..3 = columns 4 q + kk: one ds_read_b128, issued two blocks ahead of its MFMAs and
       // pinned there (left alone, hipcc hoists all NB reads to the top: 52 registers, and spills W1 fragments)
-      const float* zr = zb + r * IT_ZP + 4 * q;
+      const float* zr = zb + r * ZP + 4 * q;
       auto rd = [&](int m) {
         const int v = vfirst + m;
         return tzr_ld4(zr + 16 * (v < vlast ? v : vfirst));  // (a block behind the group: zero weights on valid data)
       };
-      float4 av[3];
+      constexpr int RING = ZOUT ? 3 : 2;  // (z not written: one block ahead; the second costs W1 fragments their registers)
+      float4 av[RING];
       av[0] = rd(0);
-      av[1] = rd(1 < NB ? 1 : 0);
+      if (RING > 2) av[1] = rd(1 < NB ? 1 : 0);
 #pragma unroll
       for (int m = 0; m < NB; ++m) {
-        if (m + 2 < NB) av[(m + 2) % 3] = rd(m + 2);
-        const float4 c = av[m % 3];
+        if (m + RING - 1 < NB) av[(m + RING - 1) % RING] = rd(m + RING - 1);
+        const float4 c = av[m % RING];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, Wf[m][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, Wf[m][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, Wf[m][2], acc, 0, 0, 0);
@@ -552,22 +581,186 @@ __device__ __forceinline__ void it_fwd_loop(const ItFwdArgs& a, float* __restric
   IT_PROF_DUMP(a.prof);
 }
 
-__global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a) {
-  __shared__ float Zs[2 * IT_TS * IT_ZP];
-  __shared__ float Ys[4 * IT_TS * IT_YP];
+// ---- DLRM-Criteo's forward of the training step: 27 vectors, z not written -------------------------------------------
+// Same tiles, same MFMAs, same order of every sum as it_fwd_loop<12, 1, ., 27>; what differs is what the tile loop does NOT
+// do -- VALU instructions share the fp32 MFMAs' pipe (NOTES.md), and the general loop spends ~140 of them per tile and
+// wave on values that never change:
+//   * every LDS address is a lane constant worked out once (the kernel has ~30 registers to spare on this path): the twelve
+//     scatter targets of the pair products, the two X-row stores, the A-operand reads, the partial sums.  The tile loop is
+//     unrolled by two so that the buffer in turn is an immediate offset of those addresses;
+//   * a lane without a valid scatter target writes to a slot of its own BEHIND its wave's row (the row pitch carries 64
+//     floats for that), so that the target is an address like any other -- no compare, no select;
+//   * the operands of the pair products are the X rows as loaded: a row beyond n (a repeat of row n - 1) only reaches
+//     entries that land in those slots;
+//   * ONE barrier per tile: the partial sums are double-buffered and the sum of tile t - G is taken at the top of tile t's
+//     turn by all sixteen waves, one output per thread (before: behind a second barrier, by eight waves, two outputs each).
+#define IT_C_P (IT_N_CRITEO * (IT_N_CRITEO - 1) / 2)         // 351 pairs
+#define IT_C_NPB ((IT_C_P + 15) / 16)                         // 22 blocks of them
+#define IT_C_NBLK (IT_C_NPB + IT_N_CRITEO)                    // 49 column blocks
+#define IT_C_ZP (16 * IT_C_NBLK + 4 + TZR_WAVE)               // row pitch: the columns, the bank pad, a slot per lane (852)
+#define IT_C_ZT (IT_TS * IT_C_ZP)                             // floats per z tile
+#define IT_C_YT (4 * IT_TS * IT_YP)                           // floats per set of partial sums
+static_assert(IT_C_NBLK == 4 * 12 + 1, "twelve whole blocks per K-group and one k-step of the 49th");
+static_assert(2 * IT_C_ZT + 2 * IT_C_YT <= 2 * IT_TS * IT_ZP + IT_C_YT, "fits the forward's LDS");
+static_assert(IT_C_ZT * 4 < 65536 && IT_C_YT * 4 < 65536, "the other buffer is an immediate offset of a DS instruction");
+
+__device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restrict__ Zs, float* __restrict__ Ys, int lane, int wv) {
+  constexpr int n = IT_N_CRITEO, P = IT_C_P, npb = IT_C_NPB, NB = 12;
+  const int r = lane & 15, q = lane >> 4;
+  const int kg = wv >> 2, hb = wv & 3;
+  const int vfirst = kg * NB;
+  float Wf[NB][4];
+  float Wx[1];
+  it_fwd_stage_w<NB, 1, IT_C_ZP>(a, Zs, Wf, Wx, n, P, npb, NB, 1, vfirst, vfirst + NB, r, q, kg, hb);
+  const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
+  const int64_t G = gridDim.x;
+  int64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  // ---- lane constants (addresses in buffer 0)
+  float* const zrow = Zs + wv * IT_C_ZP;  // this wave's row of a tile: sample wv
+  float* tg[12];                          // where the pair products go: [reg][c00, c01, c11]
+  {
+    float* const slot = zrow + 16 * IT_C_NBLK + 4 + lane;
+    // strict upper triangle, row-major (i < j): idx(i, j) = i (2 n - i - 1) / 2 + j - i - 1
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i0 = 4 * q + reg, i1 = 16 + i0, j0 = r, j1 = 16 + r;
+      const int b0 = i0 * (2 * n - i0 - 1) / 2 - i0 - 1, b1 = i1 * (2 * n - i1 - 1) / 2 - i1 - 1;
+      tg[3 * reg + 0] = (i0 < j0) ? zrow + b0 + j0 : slot;
+      tg[3 * reg + 1] = (j1 < n) ? zrow + b0 + j1 : slot;
+      tg[3 * reg + 2] = (i1 < j1 && j1 < n) ? zrow + b1 + j1 : slot;
+    }
+  }
+  const int rr1 = 16 + r < n ? 16 + r : n - 1;
+  float* const xs0 = zrow + 16 * npb + IT_D * r + 4 * q;    // X row r behind the pairs (r < n always)
+  float* const xs1 = zrow + 16 * npb + IT_D * rr1 + 4 * q;  // (lanes of a row >= n repeat row n - 1: same address, same value)
+  const float* const zr = Zs + r * IT_C_ZP + 4 * q + 16 * vfirst;          // A operand: sample r, this K-group's blocks
+  const float* const zx = Zs + r * IT_C_ZP + 4 * q + 16 * (4 * NB) + kg;   // ... and k-step kg of the 49th block
+  float* const yw = Ys + kg * (IT_TS * IT_YP) + (4 * q) * IT_YP + 16 * hb + r;  // accumulator reg j = partial y1[sample 4 q + j][16 hb + r]
+  const float* const yr = Ys + wv * IT_YP + lane;                            // the sum: sample wv, output h = lane
+  // X rows r and min(16 + r, n - 1), columns 4 q .. 4 q + 3 of a sample: 32-bit lane offsets from the sample's rows (the
+  // sample is wave-uniform: scalar bases)
+  const bool lo_dense = a.hd && r == 0;
+  const unsigned lo_off = (unsigned)((r > a.hd ? r - a.hd : 0) * IT_D + 4 * q), hi_off = (unsigned)((rr1 - a.hd) * IT_D + 4 * q);
+  auto fetch = [&](int64_t tt) {
+    int64_t b = tt * IT_TS + wv;
+    b = b < a.B ? b : a.B - 1;
+    const float* sp = a.sparse + b * a.sparse_stride;
+    ItX x;
+    x.lo = tzr_ld4(lo_dense ? a.dense + b * a.dense_stride + 4 * q : sp + lo_off);
+    x.hi = tzr_ld4(sp + hi_off);
+    return x;
+  };
+  // one sample's row of a z tile (buffer offset `zo`): pairwise products by MFMA to their targets, X rows behind them
+  auto row = [&](const ItX& X, const int zo) {
+    it_f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c11 = c00;
+    const float x0[4] = {X.lo.x, X.lo.y, X.lo.z, X.lo.w};
+    const float x1[4] = {X.hi.x, X.hi.y, X.hi.z, X.hi.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x0[e], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], x1[e], c01, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], x1[e], c11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      tg[3 * reg + 0][zo] = c00[reg];
+      tg[3 * reg + 1][zo] = c01[reg];
+      tg[3 * reg + 2][zo] = c11[reg];
+    }
+    tzr_st4(xs0 + zo, X.lo);
+    tzr_st4(xs1 + zo, X.hi);
+  };
+  row(fetch(t), 0);
+  ItX X = fetch(t + G < ntiles ? t + G : t);
+  float bias = a.bias ? a.bias[lane] : 0.f;
+  TZR_OPAQUE(bias);  // (forces the wait for this load HERE, not -- as vmcnt(0) -- at its first use inside the loop)
+  // y1[sample wv of tile tt][h = lane] = the four partials in K-group order + bias, activation
+  auto sum_out = [&](int64_t tt, const int yo) {
+    float v = bias;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v += yr[yo + g * (IT_TS * IT_YP)];
+    if (a.relu) v = v > 0.f ? v : 0.f;
+    const int64_t b = tt * IT_TS + wv;
+    if (b < a.B) a.y1[b * a.y1_stride + lane] = v;
+  };
+  IT_PROF_DECL;
+  // tile t out of buffer CUR; `prev`: tile t - G was this workgroup's too (its partials are in the other set)
+  auto tile = [&](auto CUR, bool prev) {
+    constexpr int cur = decltype(CUR)::value;
+    constexpr int zo = cur * IT_C_ZT, zn = (cur ^ 1) * IT_C_ZT, yo = cur * IT_C_YT, yp = (cur ^ 1) * IT_C_YT;
+    tzr_lds_barrier();  // tile t complete in buffer cur; the other buffer and the partials of tile t - 2 G free
+    IT_PROF_MARK(0);  // wait
+    if (prev) sum_out(t - G, yp);
+    IT_PROF_MARK(5);  // sum of the previous tile's partials
+    it_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      // A operand of block m, k-steps 0..3 = columns 4 q + kk: one ds_read_b128, issued a block ahead of its MFMAs and pinned
+      // there (left alone, hipcc hoists all twelve reads to the top: 48 registers)
+      float4 av[2];
+      av[0] = tzr_ld4(zr + zo);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        if (m + 1 < NB) av[(m + 1) & 1] = tzr_ld4(zr + zo + 16 * (m + 1));
+        const float4 c = av[m & 1];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, Wf[m][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, Wf[m][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, Wf[m][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, Wf[m][3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zx[zo], Wx[0], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yw[yo + j * IT_YP] = acc[j];
+    IT_PROF_MARK(2);  // product
+    // ---- the row of sample wv of tile t + G into the other buffer; then tile t + 2 G's X rows take off (used a product and a
+    // barrier later)
+    if (t + G < ntiles) row(X, zn);
+    X = fetch(t + 2 * G < ntiles ? t + 2 * G : t);  // (unconditional: the loads land in X's registers, no copy -- and no wait -- at the top of the next turn)
+    IT_PROF_MARK(3);  // row
+  };
+  bool prev = false;
+  int last;
+  for (;;) {
+    tile(std::integral_constant<int, 0>(), prev);
+    t += G;
+    last = 0;
+    if (t >= ntiles) break;
+    tile(std::integral_constant<int, 1>(), true);
+    t += G;
+    last = 1;
+    if (t >= ntiles) break;
+    prev = true;
+  }
+  tzr_lds_barrier();  // the last tile's partials
+  sum_out(t - G, last * IT_C_YT);
+  IT_PROF_DUMP(a.prof);
+}
+
+template <bool ZOUT>
+__device__ __forceinline__ void it_fwd_body(const ItFwdArgs& a) {
+  // two z tiles at the pitch of the body + the partial sums (it_fwd_criteo: two sets of them behind its smaller tiles)
+  constexpr int kZCriteo = 2 * IT_TS * (16 * 49 + 4), kYs = 4 * IT_TS * IT_YP;
+  __shared__ __attribute__((aligned(16))) float Sm[2 * IT_TS * IT_ZP + kYs];
   __shared__ float trash[IT_THREADS];
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / TZR_WAVE));  // (scalar: per-wave bases stay in SGPRs)
-  const int n = a.n;
-  const int P = n * (n - 1) / 2;
-  const int npb = (P + 15) >> 4, nblk = npb + n;
-  // K-group kg: whole blocks [kg base, kg base + base), base = nblk / 4, and one k-step of each of the nblk % 4 blocks left
-  const int base = nblk >> 2, rem = nblk & 3;
   float* tr = trash + threadIdx.x;
-  // Criteo: 12 blocks + 1 k-step per wave (49 MFMAs, 49 registers of W1); other shapes run the longest body, zero-weighted
-  if (base == 12 && rem == 1) it_fwd_loop<12, 1>(a, Zs, Ys, tr, lane, wv, P, npb, base, rem);
-  else it_fwd_loop<IT_KB, 3>(a, Zs, Ys, tr, lane, wv, P, npb, base, rem);
+  // Criteo (27 vectors: 22 pair blocks + 27 = 49): 12 blocks + 1 k-step per wave (49 MFMAs, 49 registers of W1); other
+  // shapes run the longest body, zero-weighted
+  if (a.n == IT_N_CRITEO) {
+    if (ZOUT) it_fwd_loop<12, 1, ZOUT, IT_N_CRITEO>(a, Sm, Sm + kZCriteo, tr, lane, wv);
+    else it_fwd_criteo(a, Sm, Sm + 2 * IT_C_ZT, lane, wv);
+  } else {
+    it_fwd_loop<IT_KB, 3, ZOUT, 0>(a, Sm, Sm + 2 * IT_TS * IT_ZP, tr, lane, wv);
+  }
 }
+
+// two kernels, not one branch: the registers of the z-writing body (store addresses, a second set of X rows) would be the
+// budget of the other one too, and W1 fragments of the training step's forward (z = null) would be spilled
+__global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a) { it_fwd_body<false>(a); }
+__global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_z_kernel(ItFwdArgs a) { it_fwd_body<true>(a); }
 
 int g_tzr_it_stagger = 0;  // tzr_tune("it_stagger"): which half of the waves runs the next product first (0 / 1), 2 = none (experiments)
 // tzr_tune("it_fwd_stagger"): forward, order of row building and product: 1 = half of the waves each way, 2 / 3 = every wave
@@ -647,7 +840,8 @@ extern "C" int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_s
 #else
   a.prof = nullptr;
 #endif
-  hipLaunchKernelGGL(tzr_ia_top_fwd_kernel, dim3(it_grid(B)), dim3(IT_THREADS), 0, st, a);
+  if (d_z) hipLaunchKernelGGL(tzr_ia_top_fwd_z_kernel, dim3(it_grid(B)), dim3(IT_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(tzr_ia_top_fwd_kernel, dim3(it_grid(B)), dim3(IT_THREADS), 0, st, a);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
