@@ -70,6 +70,14 @@ def main():
                 o = out[tag]
                 print(f"B {B} round {rnd} {tag}: top_fwd (no z) {timed(o['fwd']):6.1f}  top_fwd+z {timed(o['fwdz']):6.1f}  top_bwd {timed(o['bwd']):6.1f} us",
                       flush=True)
+        for sg in [int(x) for x in os.environ.get("IT_FWD_STAGGER", "").split(",") if x]:  # 1 half / half, 2 all row-first, 3 all row-second
+            new.tzr_tune(b"it_fwd_stagger", sg)
+            print(f"B {B} new, it_fwd_stagger {sg}: top_fwd (no z) {timed(out['new']['fwd']):6.1f}  top_fwd+z {timed(out['new']['fwdz']):6.1f} us", flush=True)
+            torch.cuda.synchronize()
+            print(f"    y1 equal to the old build's: {bool(torch.equal(out['old']['t'][1], out['new']['t'][1]))}", flush=True)
+        new.tzr_tune(b"it_fwd_stagger", 0)
+        out["new"]["fwd"]()
+        torch.cuda.synchronize()
         same = [bool(torch.equal(a, b)) for a, b in zip(out["old"]["t"], out["new"]["t"])]
         print(f"B {B}: outputs equal bit for bit (z, y1, y1 with z, grad dense, grad sparse): {same}", flush=True)
 

@@ -335,11 +335,15 @@ def test_top_persistent_loop_over_many_tiles(dev, B, wgs):
     _close(z, z_ref.detach(), 1e-6)
     # ... and the kernel that does not write z (the training step's: one barrier per tile, the sum of a tile's partials taken
     # a tile later out of the second set): the same sums in the same order, so the same bits
-    for relu in (0, 1):
+    for relu, order in ((0, 0), (1, 0), (1, 1), (0, 2), (1, 3)):  # (order of a wave's turn: it_fwd_stagger)
         y1z, y1n = torch.full((B, H), float("nan"), device=dev), torch.full((B, H), float("nan"), device=dev)
-        for zz, out in ((z, y1z), (None, y1n)):
-            _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight), width,
-                                                     _lib.ptr(lin.bias), H, relu, _lib.ptr(zz), width, _lib.ptr(out), H, stream), "fwd")
+        assert L.tzr_tune(b"it_fwd_stagger", order) == 0
+        try:
+            for zz, out in ((z, y1z), (None, y1n)):
+                _lib.check(L.tzr_dot_interaction_top_fwd(_lib.ptr(dense), D, _lib.ptr(sparse), F * D, F, D, B, _lib.ptr(lin.weight), width,
+                                                         _lib.ptr(lin.bias), H, relu, _lib.ptr(zz), width, _lib.ptr(out), H, stream), "fwd")
+        finally:
+            L.tzr_tune(b"it_fwd_stagger", 0)
         assert torch.equal(y1z, y1n)
         _close(y1n, (torch.relu(pre) if relu else pre).detach(), 2e-6)
     gd, gs = torch.full_like(dense, float("nan")), torch.full_like(sparse, float("nan"))

@@ -116,6 +116,9 @@ struct ItBwdArgs {
 // t + G goes into the other buffer while the samples of tile t are still being contracted.
 #define IT_ZPD 884  // pitch up to which two dz tiles fit beside the X images (n <= 29)
 
+#ifndef IT_BWD_PK
+#define IT_BWD_PK 0
+#endif
 #define IT_TP 34  // row pitch of the pair-offset table (uint16)
 
 template <int NB, bool XL>
@@ -232,25 +235,68 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
   };
   Gs[gs * IT_GP + gh] = g1_elem(t);
   Gs[IT_TS * IT_GP + gs * IT_GP + gh] = g1_elem(t + G);
-  ItX X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, t * IT_TS + wv, a.B, n, a.hd, r, q);
+  // ---- the wave's sample of a tile.  General shapes: X rows in the layout of the loads (16 bytes of a row per lane), turned
+  // into the contraction's operand layout through an image in LDS.  XL (27 vectors): loaded in the operand layout in the
+  // first place -- lane (r, q), k-step ks: X[row 4 ks + q][column r] = element 64 ks + lane of the sample's rows, seven
+  // coalesced dword loads -- and rows 28 .. 31 (k-step 7) are not multiplied at all.  No image, no LDS round trip.
+  ItX X;
+  float xv[XL ? 7 : 1];
+  const unsigned l6 = q == 3 ? lane - IT_D : lane;  // (k-step 6 of q = 3 is row 27: it repeats row 26 and is zeroed at its use)
+  // XL: the operand of k-step ks of the wave's sample of tile tt
+  auto fetch_k = [&](int64_t tt, int ks) {
+    int64_t b = tt * IT_TS + wv;
+    b = b < a.B ? b : a.B - 1;
+    const float* sp = a.sparse + b * a.sparse_stride - IT_D * a.hd;  // row k >= hd of X at sp + 16 k
+    if (ks == 0) return *((a.hd && q == 0) ? a.dense + b * a.dense_stride + r : sp + lane);
+    return sp[64 * ks + (ks == 6 ? l6 : (unsigned)lane)];
+  };
+  auto fetch = [&](int64_t tt) {
+    if (XL) {
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) xv[XL ? ks : 0] = fetch_k(tt, ks);
+    } else {
+      X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, tt * IT_TS + wv, a.B, n, a.hd, r, q);
+    }
+  };
+  // XL: where S[4 ks + q][r] and S[4 ks + q][16 + r] lie -- byte offsets from Z of this wave's row of dz buffer 0 (< 2^16),
+  // two per register.  The other buffer, and Z itself, are constants of the read.
+  unsigned pk[XL ? 7 : 1];
+  if (XL && IT_BWD_PK) {
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+      unsigned o[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 4 * ks + q, c = 16 * h + r;
+        const int i = k < c ? k : c, jj = k < c ? c : k;
+        const bool ok = i != jj && jj < n;
+        o[h] = 4u * (unsigned)(wv * zp + (ok ? (i * (2 * n - 1 - i)) / 2 + jj - i - 1 : 16 * nblk));
+      }
+      pk[ks] = o[0] | (o[1] << 16);
+    }
+  }
+  fetch(t);
   __syncthreads();
   product(0, 0);
   // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
   // of this one, the other half behind it: in lockstep all sixteen would sit in the LDS-latency-bound contraction at
   // once with the MFMA pipe mostly idle, then all in the product.
-  const bool product_first = a.stagger == 2 ? false : (((wv >> 2) & 1) != (a.stagger == 1));
+  const bool product_first_wave = a.stagger == 2 ? false : (((wv >> 2) & 1) != (a.stagger == 1));
   const bool v0 = r < n, v1 = 16 + r < n;
   IT_PROF_DECL;
-  int cur = 0;
-  for (; t < ntiles; t += G, cur ^= 1) {
+  // tile t, its dz and g1 tiles in buffer CUR (a constant of the code: the loop is unrolled by two, and there is one loop per
+  // order of a wave's turn -- the buffers are immediate offsets, and nothing changes registers between turns)
+  auto tile = [&](auto CUR, auto PF) {
+    constexpr int cur = decltype(CUR)::value;
+    constexpr bool product_first = decltype(PF)::value;
     tzr_lds_barrier();  // the dz tile of t is complete; every wave is done with tile t - G (its dz tile, its g1 tile)
     IT_PROF_MARK(0);  // wait
     const bool more = t + G < ntiles;
     const int zcur = dbl ? cur : 0;
-    // ---- the X image of this wave's sample; then the loads of the tiles ahead take off (X rows of t + G into the registers
-    // just copied, the g1 element of t + 2 G).  Order matters: hipcc waits for a loop-carried load with s_waitcnt vmcnt(0),
-    // i.e. for EVERYTHING in flight -- nothing may be issued shortly before such a wait (profiles/r03ak).
-    {
+    // ---- general shapes: the X image of this wave's sample; then the loads of the tiles ahead take off (the sample of t + G
+    // into the registers just read, the g1 element of t + 2 G).  Order matters: hipcc waits for a loop-carried load with
+    // s_waitcnt vmcnt(0), i.e. for EVERYTHING in flight -- nothing may be issued shortly before such a wait (profiles/r03ak).
+    if (!XL) {
       const float4 x0 = v0 ? X.lo : tzr_zero4(), x1 = v1 ? X.hi : tzr_zero4();
       float* p0 = xs + r * (IT_D + 1) + 4 * q;
       float* p1 = xs + (16 + r) * (IT_D + 1) + 4 * q;
@@ -258,26 +304,48 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
       p1[0] = x1.x; p1[1] = x1.y; p1[2] = x1.z; p1[3] = x1.w;
     }
     const float gnext = g1_elem(t + 2 * G);
-    X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (more ? t + G : t) * IT_TS + wv, a.B, n, a.hd, r, q);
+    if (!XL) fetch(more ? t + G : t);  // (XL: every operand register is refilled right behind the MFMAs that read it)
     __builtin_amdgcn_wave_barrier();  // the X image is private to this wave
     IT_PROF_MARK(1);  // X image, prefetch issue
-    if (dbl && more && product_first) product(cur ^ 1, cur ^ 1);
+    if (product_first && dbl && more) product(cur ^ 1, cur ^ 1);
     IT_PROF_MARK(2);  // product (first half of the waves)
     // ---- dX = (G + G^T) X + pass-through of sample wv of the tile (transposed product, see interaction.hip): S[k][i] is
     // the dz element of pair (min, max) of (k, i), zero on the diagonal and beyond n.  Where that element lies in the dz row
-    // comes from a table in LDS (byte offsets; the invalid pairs point at a pad float that stays zero): worked out per
-    // element it was ~15 VALU instructions x 16 elements per tile and wave -- and VALU instructions share the fp32 MFMAs'
-    // pipe (283 -> ~60 VALU instructions per tile and wave, profiles/r04al).
+    // comes from a table (byte offsets; the invalid pairs point at a pad float that stays zero): worked out per element it
+    // was ~15 VALU instructions x 16 elements per tile and wave -- and VALU instructions share the fp32 MFMAs' pipe
+    // (283 -> ~60 VALU instructions per tile and wave, profiles/r04al).  The table is in LDS, XL's in registers.
     const char* zs = reinterpret_cast<const char*>(Z + zcur * zt + wv * zp);
     it_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-    // (all eight k-steps, no branch on n: rows of the X image beyond n are zero and pairs beyond n read the zero slot)
+#if IT_X_BWD_PHASE
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    if (XL) {
+      const char* zb = reinterpret_cast<const char*>(Z + cur * zt);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const float xv = xs[(4 * ks) * (IT_D + 1) + xoff];
-      const unsigned o0 = tabl[(4 * ks) * IT_TP], o1 = tabl[(4 * ks) * IT_TP + 16];
-      const float s0 = *reinterpret_cast<const float*>(zs + o0), s1 = *reinterpret_cast<const float*>(zs + o1);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s0, d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, s1, d1, 0, 0, 0);
+      for (int ks = 0; ks < 7; ++ks) {
+        float x = xv[XL ? ks : 0];
+        if (ks == 6) x = q == 3 ? 0.f : x;
+#if IT_BWD_PK
+        const unsigned pp = pk[XL ? ks : 0];
+        const float s0 = *reinterpret_cast<const float*>(zb + (pp & 0xffffu)), s1 = *reinterpret_cast<const float*>(zb + (pp >> 16));
+#else
+        const unsigned o0 = tabl[(4 * ks) * IT_TP], o1 = tabl[(4 * ks) * IT_TP + 16];
+        const float s0 = *reinterpret_cast<const float*>(zs + o0), s1 = *reinterpret_cast<const float*>(zs + o1);
+#endif
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s0, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s1, d1, 0, 0, 0);
+        xv[XL ? ks : 0] = fetch_k(more ? t + G : t, ks);
+      }
+    } else {
+      // (all eight k-steps, no branch on n: rows of the X image beyond n are zero and pairs beyond n read the zero slot)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float x = xs[(4 * ks) * (IT_D + 1) + xoff];
+        const unsigned o0 = tabl[(4 * ks) * IT_TP], o1 = tabl[(4 * ks) * IT_TP + 16];
+        const float s0 = *reinterpret_cast<const float*>(zs + o0), s1 = *reinterpret_cast<const float*>(zs + o1);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s0, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s1, d1, 0, 0, 0);
+      }
     }
     IT_PROF_MARK(3);  // contraction
     const int64_t b = t * IT_TS + wv;
@@ -299,12 +367,27 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
       }
     }
     IT_PROF_MARK(4);  // pass-through + stores
+#if IT_X_BWD_PHASE
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!dbl) tzr_lds_barrier();  // one dz tile only: every wave must be done with it before the next product lands
     if (more && !(dbl && product_first)) product(cur ^ 1, dbl ? cur ^ 1 : 0);
     // the g1 tile of t + 2 G takes the buffer the product of tile t read (a tile ago: every wave is past it)
     Gs[cur * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
     IT_PROF_MARK(5);  // product (second half), g1 hand-over
-  }
+  };
+  auto run = [&](auto PF) {
+    for (;;) {
+      tile(std::integral_constant<int, 0>(), PF);
+      t += G;
+      if (t >= ntiles) break;
+      tile(std::integral_constant<int, 1>(), PF);
+      t += G;
+      if (t >= ntiles) break;
+    }
+  };
+  if (product_first_wave) run(std::true_type());
+  else run(std::false_type());
   IT_PROF_DUMP(a.prof);
 }
 
@@ -675,26 +758,40 @@ __device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restr
   ItX X = fetch(t + G < ntiles ? t + G : t);
   float bias = a.bias ? a.bias[lane] : 0.f;
   TZR_OPAQUE(bias);  // (forces the wait for this load HERE, not -- as vmcnt(0) -- at its first use inside the loop)
-  // y1[sample wv of tile tt][h = lane] = the four partials in K-group order + bias, activation
-  auto sum_out = [&](int64_t tt, const int yo) {
+  // y1[sample wv of tile tt][h = lane] = the four partials in K-group order + bias, activation; in two steps so that the LDS
+  // reads can take off a product ahead of the sum
+  struct Part { float p[4]; };
+  auto sum_load = [&](const int yo) {
+    Part s;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s.p[g] = yr[yo + g * (IT_TS * IT_YP)];
+    return s;
+  };
+  auto sum_store = [&](int64_t tt, const Part& s) {
     float v = bias;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) v += yr[yo + g * (IT_TS * IT_YP)];
+    for (int g = 0; g < 4; ++g) v += s.p[g];
     if (a.relu) v = v > 0.f ? v : 0.f;
     const int64_t b = tt * IT_TS + wv;
     if (b < a.B) a.y1[b * a.y1_stride + lane] = v;
   };
+  // Order of a wave's turn (a.stagger: 0 half of the waves -- two of the four on every SIMD -- each way, 1 / 2 every wave the
+  // first / the second way):
+  //   row first:  row of tile t + G, fetch, sum of tile t - G, product of tile t -- starts on X out of registers, so the MFMA
+  //               pipe has work right behind the barrier while the others wait for their first LDS reads;
+  //   row second: product of tile t (the partials of tile t - G read ahead of it, summed behind it), row, fetch.
+  // (A y1 store must not be in flight right before a wait for X -- hipcc waits with vmcnt(0) -- hence the places of the sum.)
+  // (one loop per order, chosen once: with both orders in one loop body X ends a turn in different registers and is copied
+  // -- and waited for -- at the top of the next)
+  const bool row_first_wave = a.stagger == 0 ? ((wv >> 2) & 1) != 0 : a.stagger == 1;
   IT_PROF_DECL;
   // tile t out of buffer CUR; `prev`: tile t - G was this workgroup's too (its partials are in the other set)
-  auto tile = [&](auto CUR, bool prev) {
+  auto tile = [&](auto CUR, auto RF, bool prev) {
     constexpr int cur = decltype(CUR)::value;
+    constexpr bool row_first = decltype(RF)::value;
     constexpr int zo = cur * IT_C_ZT, zn = (cur ^ 1) * IT_C_ZT, yo = cur * IT_C_YT, yp = (cur ^ 1) * IT_C_YT;
-    tzr_lds_barrier();  // tile t complete in buffer cur; the other buffer and the partials of tile t - 2 G free
-    IT_PROF_MARK(0);  // wait
-    if (prev) sum_out(t - G, yp);
-    IT_PROF_MARK(5);  // sum of the previous tile's partials
-    it_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    {
+    auto product = [&]() {
+      it_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       // A operand of block m, k-steps 0..3 = columns 4 q + kk: one ds_read_b128, issued a block ahead of its MFMAs and pinned
       // there (left alone, hipcc hoists all twelve reads to the top: 48 registers)
       float4 av[2];
@@ -710,31 +807,55 @@ __device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zx[zo], Wx[0], acc, 0, 0, 0);
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) yw[yo + j * IT_YP] = acc[j];
-    IT_PROF_MARK(2);  // product
-    // ---- the row of sample wv of tile t + G into the other buffer; then tile t + 2 G's X rows take off (used a product and a
-    // barrier later)
-    if (t + G < ntiles) row(X, zn);
-    X = fetch(t + 2 * G < ntiles ? t + 2 * G : t);  // (unconditional: the loads land in X's registers, no copy -- and no wait -- at the top of the next turn)
-    IT_PROF_MARK(3);  // row
+      for (int j = 0; j < 4; ++j) yw[yo + j * IT_YP] = acc[j];
+    };
+    // the row of sample wv of tile t + G into the other buffer; then tile t + 2 G's X rows take off (unconditionally: the
+    // loads land in X's registers -- no copy, and no wait, at the top of the next turn)
+    auto next_row = [&]() {
+      if (t + G < ntiles) row(X, zn);
+      X = fetch(t + 2 * G < ntiles ? t + 2 * G : t);
+    };
+    tzr_lds_barrier();  // tile t complete in buffer cur; the other buffer and the partials of tile t - 2 G free
+    IT_PROF_MARK(0);  // wait
+    if (row_first) {
+      next_row();
+      IT_PROF_MARK(1);  // row (first)
+      if (prev) sum_store(t - G, sum_load(yp));
+      IT_PROF_MARK(5);  // sum of the previous tile's partials
+      product();
+      IT_PROF_MARK(2);  // product
+    } else {
+      Part s;
+      if (prev) s = sum_load(yp);
+      __builtin_amdgcn_sched_barrier(0);
+      product();
+      IT_PROF_MARK(2);  // product
+      if (prev) sum_store(t - G, s);
+      IT_PROF_MARK(5);
+      next_row();
+      IT_PROF_MARK(3);  // row (second)
+    }
   };
-  bool prev = false;
-  int last;
-  for (;;) {
-    tile(std::integral_constant<int, 0>(), prev);
-    t += G;
-    last = 0;
-    if (t >= ntiles) break;
-    tile(std::integral_constant<int, 1>(), true);
-    t += G;
-    last = 1;
-    if (t >= ntiles) break;
-    prev = true;
-  }
+  int last = 0;
+  auto run = [&](auto RF) {
+    bool prev = false;
+    for (;;) {
+      tile(std::integral_constant<int, 0>(), RF, prev);
+      t += G;
+      last = 0;
+      if (t >= ntiles) break;
+      tile(std::integral_constant<int, 1>(), RF, true);
+      t += G;
+      last = 1;
+      if (t >= ntiles) break;
+      prev = true;
+    }
+  };
+  if (row_first_wave) run(std::true_type());
+  else run(std::false_type());
   tzr_lds_barrier();  // the last tile's partials
-  sum_out(t - G, last * IT_C_YT);
+  sum_store(t - G, sum_load(last * IT_C_YT));
   IT_PROF_DUMP(a.prof);
 }
 
@@ -763,10 +884,10 @@ __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_kernel(ItFwdArgs a)
 __global__ __launch_bounds__(IT_THREADS) void tzr_ia_top_fwd_z_kernel(ItFwdArgs a) { it_fwd_body<true>(a); }
 
 int g_tzr_it_stagger = 0;  // tzr_tune("it_stagger"): which half of the waves runs the next product first (0 / 1), 2 = none (experiments)
-// tzr_tune("it_fwd_stagger"): forward, order of row building and product: 1 = half of the waves each way, 2 / 3 = every wave
-// row-first / row-second, 0 = by whether z is written: with the z stores half and half hides them behind the other half's
-// product (111.6 vs 116-118 us); without them nothing is left to hide -- MFMA and VALU share the pipe, the phases add up
-// either way -- and every wave row-second is 2 % ahead (95.8 vs 97.7 us, profiles/r04ap)
+// tzr_tune("it_fwd_stagger"): forward, order of row building and product in a wave's turn: 0 / 1 = half of the waves each way
+// (two of the four on every SIMD), 2 / 3 = every wave row-first / row-second.  Half and half is the default for both
+// kernels: with the z stores it hides them behind the other half's product (111.6 vs 116-118 us, profiles/r04ap); without
+// them (it_fwd_criteo) the row-first waves give the MFMA pipe work right behind the barrier (84.5 vs 85.9 us, profiles/r05ba)
 int g_tzr_it_fwd_stagger = 0;
 int g_tzr_it_wgs = 0;  // tzr_tune("it_wgs"): workgroups of the fused kernels (0 = one per CU)
 
@@ -834,7 +955,7 @@ extern "C" int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_s
   a.dense = d_dense; a.sparse = d_sparse; a.W1 = d_W1; a.bias = d_bias; a.z = d_z; a.y1 = d_y1;
   a.dense_stride = dense_stride; a.sparse_stride = sparse_stride; a.ldw = ldw; a.z_stride = z_stride; a.y1_stride = y1_stride;
   a.B = B; a.n = n; a.hd = hd; a.relu = relu;
-  a.stagger = g_tzr_it_fwd_stagger > 0 ? g_tzr_it_fwd_stagger - 1 : (d_z ? 0 : 2);
+  a.stagger = g_tzr_it_fwd_stagger > 0 ? g_tzr_it_fwd_stagger - 1 : 0;
 #ifdef IT_PROF
   a.prof = g_tzr_it_prof;
 #else

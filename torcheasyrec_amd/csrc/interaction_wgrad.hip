@@ -172,6 +172,10 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
   int t = slice;
 
   const bool is_loader = wv < 8;
+  // The multipliers are the younger half of the workgroup and lose every arbitration by age against the loaders' VALU and
+  // memory instructions; their MFMA stream is what the tile time is made of.  Static priority, set once: 107.0 -> 104.2 us
+  // (profiles/r05be; the loaders at the higher priority instead: no change).
+  if (!is_loader) __builtin_amdgcn_s_setprio(1);
   if (is_loader) {
     // ================================================= loaders
     const int lw = wv;  // the quad of samples of this wave
