@@ -31,6 +31,7 @@
 #define IT_MAXBLK 64                 // virtual column blocks: ceil(P / 16) + n <= 64, i.e. n <= 32
 #define IT_BPW (IT_MAXBLK / IT_WAVES)  // backward: column blocks per wave (4)
 #define IT_KB (IT_MAXBLK / 4)        // forward: blocks per K-group (16)
+#define IT_MAX_BATCH (int64_t(1) << 30)  // samples per call: the kernels count tiles and samples in 32 bits
 #define IT_N_CRITEO 27               // DLRM-Criteo: 26 tables + the dense vector (351 pairs: 22 + 27 = 49 column blocks)
 #define IT_SROW 33                   // row pitch of one S matrix (odd: conflict-free column reads)
 #define IT_SS (32 * IT_SROW + 4)     // floats per sample in S (1060: the four sample groups of an accumulator scatter land 16 banks apart)
@@ -116,9 +117,6 @@ struct ItBwdArgs {
 // t + G goes into the other buffer while the samples of tile t are still being contracted.
 #define IT_ZPD 884  // pitch up to which two dz tiles fit beside the X images (n <= 29)
 
-#ifndef IT_BWD_PK
-#define IT_BWD_PK 0
-#endif
 #define IT_TP 34  // row pitch of the pair-offset table (uint16)
 
 template <int NB, bool XL>
@@ -183,17 +181,21 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
   __syncthreads();
   const uint16_t* tabl = Tab + q * IT_TP + r;   // lane constants of the contraction (k = 4 ks + q, c = 16 h + r)
   const int xoff = q * (IT_D + 1) + r;
-  const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
-  const int64_t G = gridDim.x;
-  int64_t t = blockIdx.x;
+  // (tile and sample counters in 32 bits -- the launcher checks B: their compares are scalar instructions then, 64-bit
+  // ones are VALU work; the sample offsets are widened where they are multiplied with a stride)
+  const int Bn = (int)a.B;
+  const int ntiles = (Bn + IT_TS - 1) / IT_TS;
+  const int G = gridDim.x;
+  int t = blockIdx.x;
   if (t >= ntiles) return;
   // the g1 tile goes through LDS (one element per thread, double-buffered): every wave needs all of it as its A operand,
   // and sixteen copies from L2 would cost more than the HBM traffic of the whole kernel
-  const int gs = threadIdx.x >> 6, gh = threadIdx.x & 63;
-  const unsigned goff = (unsigned)gs * (unsigned)a.g1_stride + (unsigned)gh;  // (< 2^32: checked by the launcher)
-  auto g1_elem = [&](int64_t tt) {
-    const float* base = a.g1 + tt * IT_TS * a.g1_stride;  // scalar
-    return (tt < ntiles && tt * IT_TS + gs < a.B) ? base[goff] : 0.f;
+  const int gs = wv, gh = lane;  // (the sample is the wave's: a scalar row base, the lane is the column)
+  auto g1_elem = [&](int tt) {
+    const int row = tt * IT_TS + gs;
+    const bool ok = tt < ntiles && row < Bn;
+    const float v = (a.g1 + (int64_t)(ok ? row : 0) * a.g1_stride)[gh];
+    return ok ? v : 0.f;
   };
   // dz[:, blocks of this wave] of the g1 tile in Gs[gbuf] -> dz tile zbuf.  A operand: lane (i = r, q) reads g1[i][16 q ..
   // 16 q + 15], k-step ks uses element 16 q + ks (the contraction order is free as long as the W1 fragment agrees);
@@ -228,6 +230,7 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
         accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, Wx[(4 * k4 + 1) * TZR_WAVE + lane], accx, 0, 0, 0);
         accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, Wx[(4 * k4 + 2) * TZR_WAVE + lane], accx, 0, 0, 0);
         accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, Wx[(4 * k4 + 3) * TZR_WAVE + lane], accx, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // (four fragment reads at a time: sixteen at once are sixteen registers)
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) zo[j * zp + 16 * (IT_WAVES * NB)] = accx[j];
@@ -243,39 +246,44 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
   float xv[XL ? 7 : 1];
   const unsigned l6 = q == 3 ? lane - IT_D : lane;  // (k-step 6 of q = 3 is row 27: it repeats row 26 and is zeroed at its use)
   // XL: the operand of k-step ks of the wave's sample of tile tt
-  auto fetch_k = [&](int64_t tt, int ks) {
-    int64_t b = tt * IT_TS + wv;
-    b = b < a.B ? b : a.B - 1;
+  auto fetch_k = [&](int tt, int ks) {
+    const int bi = tt * IT_TS + wv;
+    const int64_t b = bi < Bn ? bi : Bn - 1;
     const float* sp = a.sparse + b * a.sparse_stride - IT_D * a.hd;  // row k >= hd of X at sp + 16 k
-    if (ks == 0) return *((a.hd && q == 0) ? a.dense + b * a.dense_stride + r : sp + lane);
-    return sp[64 * ks + (ks == 6 ? l6 : (unsigned)lane)];
+    if (ks == 0) {  // (two masked loads off scalar bases, not one load through a selected 64-bit pointer: no VALU)
+      float x;
+      if (a.hd && q == 0) x = (a.dense + b * a.dense_stride)[(unsigned)lane];
+      else x = sp[(unsigned)lane];
+      return x;
+    }
+    return (sp + 64 * ks)[ks == 6 ? l6 : (unsigned)lane];  // (base + constant, then the lane: an immediate offset of the load)
   };
-  auto fetch = [&](int64_t tt) {
+  auto fetch = [&](int tt) {
     if (XL) {
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) xv[XL ? ks : 0] = fetch_k(tt, ks);
     } else {
-      X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, tt * IT_TS + wv, a.B, n, a.hd, r, q);
+      X = it_fetch_x(a.dense, a.dense_stride, a.sparse, a.sparse_stride, (int64_t)tt * IT_TS + wv, a.B, n, a.hd, r, q);
     }
   };
-  // XL: where S[4 ks + q][r] and S[4 ks + q][16 + r] lie -- byte offsets from Z of this wave's row of dz buffer 0 (< 2^16),
-  // two per register.  The other buffer, and Z itself, are constants of the read.
-  unsigned pk[XL ? 7 : 1];
-  if (XL && IT_BWD_PK) {
+  // XL: where S[4 ks + q][r] and S[4 ks + q][16 + r] lie -- a table of this WAVE's own (in the space of the X image it does
+  // not write): byte offsets from Z of ITS row of dz buffer 0 (< 2^16), so that an entry is the address of the read as it
+  // stands -- the other buffer, and Z itself, are constants of the instruction; the shared table's row offsets want an add
+  // per element (14 VALU instructions per tile and wave)
+  uint16_t* const tw = reinterpret_cast<uint16_t*>(xs) + lane;  // [2 ks + h][64 lanes]
+  if (XL) {
 #pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-      unsigned o[2];
+    for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 4 * ks + q, c = 16 * h + r;
         const int i = k < c ? k : c, jj = k < c ? c : k;
         const bool ok = i != jj && jj < n;
-        o[h] = 4u * (unsigned)(wv * zp + (ok ? (i * (2 * n - 1 - i)) / 2 + jj - i - 1 : 16 * nblk));
+        tw[(2 * ks + h) * TZR_WAVE] = (uint16_t)(4 * (wv * zp + (ok ? (i * (2 * n - 1 - i)) / 2 + jj - i - 1 : 16 * nblk)));
       }
-      pk[ks] = o[0] | (o[1] << 16);
-    }
   }
   fetch(t);
+  float gnext = g1_elem(t + 2 * G);
   __syncthreads();
   product(0, 0);
   // Half of the waves (two of the four on every SIMD) run the product of the NEXT tile before they contract their sample
@@ -284,11 +292,11 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
   const bool product_first_wave = a.stagger == 2 ? false : (((wv >> 2) & 1) != (a.stagger == 1));
   const bool v0 = r < n, v1 = 16 + r < n;
   IT_PROF_DECL;
-  // tile t, its dz and g1 tiles in buffer CUR (a constant of the code: the loop is unrolled by two, and there is one loop per
-  // order of a wave's turn -- the buffers are immediate offsets, and nothing changes registers between turns)
+  // tile t, its dz and g1 tiles in buffer CUR (XL: a constant of the code -- the loop is unrolled by two, and there is one loop
+  // per order of a wave's turn: the buffers are immediate offsets, and nothing changes registers between turns)
   auto tile = [&](auto CUR, auto PF) {
-    constexpr int cur = decltype(CUR)::value;
-    constexpr bool product_first = decltype(PF)::value;
+    const int cur = CUR;
+    const bool product_first = PF;
     tzr_lds_barrier();  // the dz tile of t is complete; every wave is done with tile t - G (its dz tile, its g1 tile)
     IT_PROF_MARK(0);  // wait
     const bool more = t + G < ntiles;
@@ -303,7 +311,6 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
       p0[0] = x0.x; p0[1] = x0.y; p0[2] = x0.z; p0[3] = x0.w;
       p1[0] = x1.x; p1[1] = x1.y; p1[2] = x1.z; p1[3] = x1.w;
     }
-    const float gnext = g1_elem(t + 2 * G);
     if (!XL) fetch(more ? t + G : t);  // (XL: every operand register is refilled right behind the MFMAs that read it)
     __builtin_amdgcn_wave_barrier();  // the X image is private to this wave
     IT_PROF_MARK(1);  // X image, prefetch issue
@@ -316,22 +323,14 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
     // (283 -> ~60 VALU instructions per tile and wave, profiles/r04al).  The table is in LDS, XL's in registers.
     const char* zs = reinterpret_cast<const char*>(Z + zcur * zt + wv * zp);
     it_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-#if IT_X_BWD_PHASE
-    __builtin_amdgcn_s_setprio(1);
-#endif
     if (XL) {
       const char* zb = reinterpret_cast<const char*>(Z + cur * zt);
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) {
         float x = xv[XL ? ks : 0];
         if (ks == 6) x = q == 3 ? 0.f : x;
-#if IT_BWD_PK
-        const unsigned pp = pk[XL ? ks : 0];
-        const float s0 = *reinterpret_cast<const float*>(zb + (pp & 0xffffu)), s1 = *reinterpret_cast<const float*>(zb + (pp >> 16));
-#else
-        const unsigned o0 = tabl[(4 * ks) * IT_TP], o1 = tabl[(4 * ks) * IT_TP + 16];
-        const float s0 = *reinterpret_cast<const float*>(zs + o0), s1 = *reinterpret_cast<const float*>(zs + o1);
-#endif
+        const unsigned o0 = tw[(2 * ks) * TZR_WAVE], o1 = tw[(2 * ks + 1) * TZR_WAVE];
+        const float s0 = *reinterpret_cast<const float*>(zb + o0), s1 = *reinterpret_cast<const float*>(zb + o1);
         d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s0, d0, 0, 0, 0);
         d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, s1, d1, 0, 0, 0);
         xv[XL ? ks : 0] = fetch_k(more ? t + G : t, ks);
@@ -348,32 +347,34 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
       }
     }
     IT_PROF_MARK(3);  // contraction
-    const int64_t b = t * IT_TS + wv;
+    const int bi = t * IT_TS + wv;
+    const int64_t b = bi;
     int rq = r * IT_D + 4 * q;
     TZR_OPAQUE(rq);  // (recomputed per tile, not hoisted and spilled)
     const float* pt = reinterpret_cast<const float*>(zs) + 16 * npb;
-    if (b < a.B) {
-      // (b is wave-uniform: scalar row bases, the lane part from rq)
+    if (bi < Bn) {
+      // (b is wave-uniform: scalar row bases, 32-bit lane offsets)
+      float* const gsrow = a.gsparse + b * a.gsparse_stride - IT_D * a.hd;  // row k >= hd of the gradient at gsrow + 16 k
       if (v0) {
         const float4 p = tzr_ld4(pt + rq);
         const float4 v = make_float4(d0[0] + p.x, d0[1] + p.y, d0[2] + p.z, d0[3] + p.w);
-        if (a.hd && r == 0) tzr_st4(a.gdense + b * a.gdense_stride + rq, v);
-        else tzr_st4(a.gsparse + b * a.gsparse_stride + (rq - IT_D * a.hd), v);
+        if (a.hd && r == 0) tzr_st4(a.gdense + b * a.gdense_stride + (unsigned)rq, v);
+        else tzr_st4(gsrow + (unsigned)rq, v);
       }
       if (v1) {
         const float4 p = tzr_ld4(pt + 16 * IT_D + rq);
         const float4 v = make_float4(d1[0] + p.x, d1[1] + p.y, d1[2] + p.z, d1[3] + p.w);
-        tzr_st4(a.gsparse + b * a.gsparse_stride + (rq + IT_D * (16 - a.hd)), v);
+        tzr_st4(gsrow + IT_D * 16 + (unsigned)rq, v);
       }
     }
     IT_PROF_MARK(4);  // pass-through + stores
-#if IT_X_BWD_PHASE
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (!dbl) tzr_lds_barrier();  // one dz tile only: every wave must be done with it before the next product lands
     if (more && !(dbl && product_first)) product(cur ^ 1, dbl ? cur ^ 1 : 0);
-    // the g1 tile of t + 2 G takes the buffer the product of tile t read (a tile ago: every wave is past it)
+    // the g1 tile of t + 2 G takes the buffer the product of tile t read (a tile ago: every wave is past it); its element
+    // was loaded a whole turn ago, the one of t + 3 G takes off now -- loaded at the top of the turn it was waited for in the
+    // middle of the contraction (hipcc's counts leave only the newest loads in flight: profiles/r05bi)
     Gs[cur * (IT_TS * IT_GP) + gs * IT_GP + gh] = gnext;
+    gnext = g1_elem(t + 3 * G);
     IT_PROF_MARK(5);  // product (second half), g1 hand-over
   };
   auto run = [&](auto PF) {
@@ -386,8 +387,12 @@ __device__ __forceinline__ void it_bwd_loop(const ItBwdArgs& a, float* __restric
       if (t >= ntiles) break;
     }
   };
-  if (product_first_wave) run(std::true_type());
-  else run(std::false_type());
+  if (XL) {
+    if (product_first_wave) run(std::true_type());
+    else run(std::false_type());
+  } else {  // (the general shapes keep one loop: twice unrolled, and once per order, they spill)
+    for (int cur = 0; t < ntiles; t += G, cur ^= 1) tile(cur, product_first_wave);
+  }
   IT_PROF_DUMP(a.prof);
 }
 
@@ -695,9 +700,10 @@ __device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restr
   float Wf[NB][4];
   float Wx[1];
   it_fwd_stage_w<NB, 1, IT_C_ZP>(a, Zs, Wf, Wx, n, P, npb, NB, 1, vfirst, vfirst + NB, r, q, kg, hb);
-  const int64_t ntiles = (a.B + IT_TS - 1) / IT_TS;
-  const int64_t G = gridDim.x;
-  int64_t t = blockIdx.x;
+  const int Bn = (int)a.B;  // (32-bit tile and sample counters, checked by the launcher: scalar compares)
+  const int ntiles = (Bn + IT_TS - 1) / IT_TS;
+  const int G = gridDim.x;
+  int t = blockIdx.x;
   if (t >= ntiles) return;
   // ---- lane constants (addresses in buffer 0)
   float* const zrow = Zs + wv * IT_C_ZP;  // this wave's row of a tile: sample wv
@@ -725,9 +731,9 @@ __device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restr
   // sample is wave-uniform: scalar bases)
   const bool lo_dense = a.hd && r == 0;
   const unsigned lo_off = (unsigned)((r > a.hd ? r - a.hd : 0) * IT_D + 4 * q), hi_off = (unsigned)((rr1 - a.hd) * IT_D + 4 * q);
-  auto fetch = [&](int64_t tt) {
-    int64_t b = tt * IT_TS + wv;
-    b = b < a.B ? b : a.B - 1;
+  auto fetch = [&](int tt) {
+    const int bi = tt * IT_TS + wv;
+    const int64_t b = bi < Bn ? bi : Bn - 1;
     const float* sp = a.sparse + b * a.sparse_stride;
     ItX x;
     x.lo = tzr_ld4(lo_dense ? a.dense + b * a.dense_stride + 4 * q : sp + lo_off);
@@ -767,13 +773,13 @@ __device__ __forceinline__ void it_fwd_criteo(const ItFwdArgs& a, float* __restr
     for (int g = 0; g < 4; ++g) s.p[g] = yr[yo + g * (IT_TS * IT_YP)];
     return s;
   };
-  auto sum_store = [&](int64_t tt, const Part& s) {
+  auto sum_store = [&](int tt, const Part& s) {
     float v = bias;
 #pragma unroll
     for (int g = 0; g < 4; ++g) v += s.p[g];
     if (a.relu) v = v > 0.f ? v : 0.f;
-    const int64_t b = tt * IT_TS + wv;
-    if (b < a.B) a.y1[b * a.y1_stride + lane] = v;
+    const int b = tt * IT_TS + wv;
+    if (b < Bn) a.y1[(int64_t)b * a.y1_stride + lane] = v;
   };
   // Order of a wave's turn (a.stagger: 0 half of the waves -- two of the four on every SIMD -- each way, 1 / 2 every wave the
   // first / the second way):
@@ -911,6 +917,7 @@ extern "C" int tzr_dot_interaction_top_bwd(const float* d_dense, int64_t dense_s
   const int hd = d_dense ? 1 : 0;
   const int n = F + hd;
   if (!d_sparse || !d_g1 || !d_W1 || !d_grad_sparse || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (B > IT_MAX_BATCH) return TZR_ERR_UNSUPPORTED;
   if (hd && !d_grad_dense) return TZR_ERR_INVALID;
   if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
   if (ldw < n * (n - 1) / 2 + IT_D * n) return TZR_ERR_INVALID;
@@ -942,6 +949,7 @@ extern "C" int tzr_dot_interaction_top_fwd(const float* d_dense, int64_t dense_s
   const int hd = d_dense ? 1 : 0;
   const int n = F + hd;
   if (!d_sparse || !d_W1 || !d_y1 || F <= 0 || B < 0) return TZR_ERR_INVALID;
+  if (B > IT_MAX_BATCH) return TZR_ERR_UNSUPPORTED;
   if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
   const int width = n * (n - 1) / 2 + IT_D * n;
   if (ldw < width || (d_z && z_stride < width)) return TZR_ERR_INVALID;

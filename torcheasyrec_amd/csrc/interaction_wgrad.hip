@@ -53,11 +53,19 @@ extern "C" uint64_t* g_tzr_it_prof;
 #define WG_PROF_MARK(i) do { const uint64_t wg_now = __builtin_amdgcn_s_memtime(); wg_ts[i] += wg_now - wg_tl; wg_tl = wg_now; } while (0)
 #define WG_PROF_DUMP(tab) do { if (tab && lane == 0) for (int i_ = 0; i_ < 6; ++i_) (tab)[((size_t)blockIdx.x * WG_WAVES + wv) * 6 + i_] = wg_ts[i_]; } while (0)
 #define WG_PROF_TOUCH(x) do { float wg_tmp = (x); TZR_OPAQUE(wg_tmp); } while (0)
+#define WG_BUILD !(a.debug & 2)
+#define WG_LOAD !(a.debug & 4)
 #else
 #define WG_PROF_DECL
 #define WG_PROF_MARK(i)
 #define WG_PROF_DUMP(tab)
 #define WG_PROF_TOUCH(x)
+// (the phase-skipping bits 2 and 4 of tzr_tune("wg_debug") exist in the IT_PROF build only: as run-time conditions around the
+// loaders' stores and loads they cost the product its prefetch depth -- with a path on which a set of loads is never
+// consumed hipcc waits for EVERY load in flight before it refills the set (s_waitcnt vmcnt(0) once per tile instead of
+// vmcnt(12): profiles/r05bl))
+#define WG_BUILD true
+#define WG_LOAD true
 #endif
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -268,7 +276,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
     };
     if (t >= ntiles) return;
     const int S = a.slices;
-    int cur = 0;
     // R0 / R1 alternate: the set stored in an iteration is refilled with the tile three ahead -- the loads run TWO tiles ahead
     // of the stores (one tile of multiplying does not cover a load under this traffic)
     Regs R0, R1;
@@ -276,24 +283,35 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
     fetch(R1, t + S);
     step(0, R0, t, t + 2 * S, true, true);
     tzr_lds_barrier();
-    for (;;) {
+    // One turn per tile of this slice, the two register sets in turn.  Counted, with the odd turn behind the loop -- NOT
+    // `for (;;) { A; if (done) break; B; if (done) break; }`: hipcc routes both exits through the loop's latch, its wait
+    // counts then allow for the path "A, latch, A" on which A's own loads are the youngest in flight, and every A waits for
+    // everything (s_waitcnt vmcnt(0): the loads B issued a moment ago).  This way both turns leave the other set's twelve
+    // loads in flight (vmcnt(12)): profiles/r05bm.
+    auto turn_a = [&]() {
       WG_PROF_TOUCH(R1.gv.w);
       WG_PROF_MARK(0);  // loads of the tile about to be stored
-      step(1, R1, t + S, t + 3 * S, !(a.debug & 2), !(a.debug & 4));  // (cur == 0 here: buffer 1.  Behind the last tile: samples >= B with g1 = 0 into a buffer nobody multiplies)
+      step(1, R1, t + S, t + 3 * S, WG_BUILD, WG_LOAD);  // (buffer 1.  Behind the last tile: samples >= B with g1 = 0 into a buffer nobody multiplies)
       WG_PROF_MARK(4);  // pair stores
       tzr_lds_barrier();  // tile t + S complete, the multipliers done with tile t
       WG_PROF_MARK(3);  // barrier
-      t += S; cur ^= 1;
-      if (t >= ntiles) break;
+      t += S;
+    };
+    auto turn_b = [&]() {
       WG_PROF_TOUCH(R0.gv.w);
       WG_PROF_MARK(0);
-      step(0, R0, t + S, t + 3 * S, !(a.debug & 2), !(a.debug & 4));
+      step(0, R0, t + S, t + 3 * S, WG_BUILD, WG_LOAD);
       WG_PROF_MARK(4);
       tzr_lds_barrier();
       WG_PROF_MARK(3);
-      t += S; cur ^= 1;
-      if (t >= ntiles) break;
+      t += S;
+    };
+    const int turns = (ntiles - t + S - 1) / S;
+    for (int k = 0; k < (turns >> 1); ++k) {
+      turn_a();
+      turn_b();
     }
+    if (turns & 1) turn_a();
     WG_PROF_DUMP(a.prof);
     return;
   }
