@@ -43,7 +43,7 @@ __device__ __forceinline__ float mm_sum_q(float v) {  // over the 4 lanes that s
 #define MT_ROW (MT_H2 * MT_H1 + 2 * MT_H2 + 2 + MT_H1)
 
 template <typename LabelT>
-__global__ __launch_bounds__(MM_THREADS) void tzr_mlp_tail64_kernel(
+__global__ __launch_bounds__(MM_THREADS) TZR_WAVES_PER_EU(2) void tzr_mlp_tail64_kernel(
     const float* __restrict__ y1, int64_t y1s, const LabelT* __restrict__ labels, int64_t B, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, float* __restrict__ logits,
     float* __restrict__ g1, int64_t g1s, float* __restrict__ parts) {
@@ -85,15 +85,29 @@ __global__ __launch_bounds__(MM_THREADS) void tzr_mlp_tail64_kernel(
 
   const int64_t tiles = (B + MM_TS - 1) / MM_TS;
   const int64_t nw = (int64_t)gridDim.x * MM_WAVES;
-  for (int64_t t = (int64_t)blockIdx.x * MM_WAVES + wv; t < tiles; t += nw) {
-    const int64_t b0 = t * MM_TS;
-    // ---- y1 tile -> LDS (4 KB contiguous when y1 is dense: four 16-byte pieces per lane)
+  // a wave's y1 tile (4 KB contiguous when y1 is dense: four 16-byte pieces per lane), fetched a turn ahead: a wave has two
+  // or more turns at the step's batch, and each was a chain that began with an HBM round trip (rows behind the batch read
+  // row B - 1 and are zeroed when the tile is stored)
+  auto fetch = [&](float4 (&v)[4], int64_t tt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + TZR_WAVE * i, row = e >> 4, c4 = e & 15;
-      const float4 v = b0 + row < B ? tzr_ld4(y1 + (b0 + row) * y1s + 4 * c4) : tzr_zero4();
-      tzr_st4(T1 + row * MT_P1 + 4 * c4, v);
+      const int64_t b = tt * MM_TS + row;
+      v[i] = tzr_ld4(y1 + (b < B ? b : B - 1) * y1s + 4 * c4);
     }
+  };
+  int64_t t = (int64_t)blockIdx.x * MM_WAVES + wv;
+  float4 yt[4];
+  if (t < tiles) fetch(yt, t);
+  for (; t < tiles; t += nw) {
+    const int64_t b0 = t * MM_TS;
+    // ---- y1 tile -> LDS; the next turn's takes off
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + TZR_WAVE * i, row = e >> 4, c4 = e & 15;
+      tzr_st4(T1 + row * MT_P1 + 4 * c4, b0 + row < B ? yt[i] : tzr_zero4());
+    }
+    fetch(yt, t + nw < tiles ? t + nw : t);
     __builtin_amdgcn_wave_barrier();
     // ---- y2 = relu(y1 W2^T + b2): A = y1[sample r][16 q + ks]
     mm_f32x4 y2a[2] = {mm_f32x4{0.f, 0.f, 0.f, 0.f}, mm_f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -364,30 +378,55 @@ __global__ __launch_bounds__(MM_THREADS) void tzr_mlp2_bwd16_kernel(
   const int trow = lane >> 2, tc4 = lane & 3;  // this lane's 16-byte piece of a [16 x 16] tile
   const int64_t tiles = (B + MM_TS - 1) / MM_TS;
   const int64_t nw = (int64_t)gridDim.x * MM_WAVES;
-  for (int64_t t = (int64_t)blockIdx.x * MM_WAVES + wv; t < tiles; t += nw) {
-    const int64_t b0 = t * MM_TS;
-    // ---- tiles -> LDS: ha (four pieces per lane), gb = dhb masked by hb > 0 and x (one piece per lane each)
+  // a wave's tiles, fetched a turn ahead (two or more turns per wave at the step's batch, each a chain that began with an HBM
+  // round trip): ha (four pieces per lane), dhb, hb and x (one piece per lane each).  Rows behind the batch and inputs
+  // behind K0 read a clamped address and are zeroed at the LDS stores.
+  struct In {
+    float4 ha[4], d, h;
+    float x[4];
+  };
+  auto fetch = [&](In& v, int64_t tt) {
+    const int64_t b0 = tt * MM_TS;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + TZR_WAVE * i, row = e >> 4, c4 = e & 15;
-      tzr_st4(Tha + row * MT_P1 + 4 * c4, b0 + row < B ? tzr_ld4(ha + (b0 + row) * has + 4 * c4) : tzr_zero4());
+      const int64_t b = b0 + row < B ? b0 + row : B - 1;
+      v.ha[i] = tzr_ld4(ha + b * has + 4 * c4);
+    }
+    const int64_t b = b0 + trow < B ? b0 + trow : B - 1;
+    v.d = tzr_ld4(dhb + b * dhbs + 4 * tc4);
+    v.h = tzr_ld4(hb + b * hbs + 4 * tc4);
+    const float* xp = x + b * xs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.x[j] = xp[4 * tc4 + j < K0 ? 4 * tc4 + j : 0];
+  };
+  int64_t t = (int64_t)blockIdx.x * MM_WAVES + wv;
+  In in;
+  if (t < tiles) fetch(in, t);
+  for (; t < tiles; t += nw) {
+    const int64_t b0 = t * MM_TS;
+    // ---- tiles -> LDS: ha, gb = dhb masked by hb > 0, x; the next turn's take off
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + TZR_WAVE * i, row = e >> 4, c4 = e & 15;
+      tzr_st4(Tha + row * MT_P1 + 4 * c4, b0 + row < B ? in.ha[i] : tzr_zero4());
     }
     {
       float4 g = tzr_zero4(), xv = tzr_zero4();
       if (b0 + trow < B) {
-        const float4 d = tzr_ld4(dhb + (b0 + trow) * dhbs + 4 * tc4), h = tzr_ld4(hb + (b0 + trow) * hbs + 4 * tc4);
+        const float4 d = in.d, h = in.h;
         g = make_float4(h.x > 0.f ? d.x : 0.f, h.y > 0.f ? d.y : 0.f, h.z > 0.f ? d.z : 0.f, h.w > 0.f ? d.w : 0.f);
-        const float* xp = x + (b0 + trow) * xs;
         const int k = 4 * tc4;
-        xv.x = k < K0 ? xp[k] : 0.f;
-        xv.y = k + 1 < K0 ? xp[k + 1] : 0.f;
-        xv.z = k + 2 < K0 ? xp[k + 2] : 0.f;
-        xv.w = k + 3 < K0 ? xp[k + 3] : 0.f;
+        xv.x = k < K0 ? in.x[0] : 0.f;
+        xv.y = k + 1 < K0 ? in.x[1] : 0.f;
+        xv.z = k + 2 < K0 ? in.x[2] : 0.f;
+        xv.w = k + 3 < K0 ? in.x[3] : 0.f;
       }
       dbba[0] += g.x; dbba[1] += g.y; dbba[2] += g.z; dbba[3] += g.w;  // columns 4 tc4 .. of dbb, rows trow + 16 n
       tzr_st4(Tgb + trow * MB_PX + 4 * tc4, g);
       tzr_st4(Tx + trow * MB_PX + 4 * tc4, xv);
     }
+    fetch(in, t + nw < tiles ? t + nw : t);
     __builtin_amdgcn_wave_barrier();
     // ---- ga = (gb Wb) masked by ha > 0: A = gb[sample r][4 q + ks]
     mm_f32x4 acc[4];
