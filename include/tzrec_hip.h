@@ -755,6 +755,7 @@ int tzr_dot_interaction_bwd(const float* d_dense, int64_t dense_stride, const fl
  * Supported: D = 16, H = 64, ceil(P / 16) + n <= 64 column blocks, i.e. n <= 32 (tzr_dot_interaction_top_supported;
  * otherwise TZR_ERR_UNSUPPORTED and the caller runs the unfused ops).  Up to n = 29 the backward keeps two dz tiles in
  * LDS (one barrier per tile); n = 30 .. 32 run the same kernel with one tile (two barriers), same results.  fp32 MFMA, fixed summation order (deterministic).
+ * B <= 2^30 samples per call (the kernels count tiles and samples in 32 bits; more: TZR_ERR_UNSUPPORTED).
  *   _top_fwd: y1[b] = act(z[b] W1^T + bias) (relu != 0: ReLU), [B, H]; the interaction row z[b] itself is written
  *             only when d_z is non-null (training keeps it for the weight gradient; inference does not need it).
  *   _top_bwd: from g1 = d(loss)/d(z W1^T + bias) [B, H]: grad_dense / grad_sparse = the interaction backward of

@@ -171,6 +171,14 @@ def test_top_unsupported_shapes(dev):
     rc = L.tzr_dot_interaction_top_fwd(None, 0, _lib.ptr(x), 64, 8, 8, 4, _lib.ptr(x), 64, None, 64, 1, None, 0, _lib.ptr(x), 64,
                                        _lib.stream_ptr(x.device))
     assert rc == -4  # TZR_ERR_UNSUPPORTED
+    # more than 2^30 samples in one call: refused before anything is read (the kernels count samples in 32 bits)
+    y = torch.zeros(4, 27 * 16, device=dev)
+    rc = L.tzr_dot_interaction_top_fwd(_lib.ptr(y), 16, _lib.ptr(y), 26 * 16, 26, 16, (1 << 30) + 1, _lib.ptr(y), 783, None, 64, 1, None, 0,
+                                       _lib.ptr(y), 64, _lib.stream_ptr(y.device))
+    assert rc == -4
+    rc = L.tzr_dot_interaction_top_bwd(_lib.ptr(y), 16, _lib.ptr(y), 26 * 16, 26, 16, (1 << 30) + 1, _lib.ptr(y), 64, 64, _lib.ptr(y), 783,
+                                       None, _lib.ptr(y), 16, _lib.ptr(y), 26 * 16, _lib.stream_ptr(y.device))
+    assert rc == -4
 
 
 @pytest.mark.parametrize("B", [5, 100])

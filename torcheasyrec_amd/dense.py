@@ -505,7 +505,7 @@ def interaction_top_fits(dense: torch.Tensor, sparse: torch.Tensor, D: int, firs
         return False
     F = sparse.shape[1] // D
     n = F + 1
-    if first_linear.in_features != n * (n - 1) // 2 + D * n:
+    if first_linear.in_features != n * (n - 1) // 2 + D * n or sparse.shape[0] > (1 << 30):  # (samples per call: 32-bit counters)
         return False
     return bool(_lib.lib().tzr_dot_interaction_top_supported(F, D, 1, first_linear.out_features))
 
