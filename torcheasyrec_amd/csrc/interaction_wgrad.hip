@@ -69,6 +69,14 @@ extern "C" uint64_t* g_tzr_it_prof;
 #endif
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
+struct __attribute__((packed, aligned(4))) wg_f4u {
+  float x, y, z, w;
+};
+__device__ __forceinline__ float4 wg_ld4_a4(const float* p) {  // 16-byte load from a 4-byte aligned address
+  const wg_f4u u = *reinterpret_cast<const wg_f4u*>(p);
+  return make_float4(u.x, u.y, u.z, u.w);
+}
+
 struct WgGroup {
   int src;    // block of the pair matrix this group produces: 0 none, 1 c00, 2 c01, 3 c11
   int npb;    // its pair columns, in blocks of 16 (the last one padded)
@@ -161,7 +169,7 @@ template <bool LO, bool HI>
 struct WgRegs {
   float4 lo[LO ? 4 : 1];  // (row r, columns 4 q .. 4 q + 3) of the wave's four samples
   float4 hi[HI ? 4 : 1];  // (row 16 + r, ...)
-  float4 gv;              // g1 item: output h of 4 samples
+  float4 gv;              // g1 item: outputs 4 (lane & 15) .. + 3 of sample lane >> 4
 };
 
 // SRC = the group's block of the pair matrix (0: X rows only); LO / HI: which 16-row blocks of X the loaders read (what the
@@ -196,6 +204,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
     const unsigned hi_off = (unsigned)((rhi - a.hd) * WG_D + 4 * q);  // (a high row is never the dense row)
     // loads of tile tt into registers (samples behind the batch read the last one; their g1 is zeroed at the store); the
     // sample is wave-uniform: scalar row bases, 32-bit lane offsets
+    const unsigned g_off = (unsigned)(lane >> 4) * gstride + 4 * (lane & 15);
     auto fetch = [&](Regs& R, int tt) {
       const int s0 = tt * WG_S + 4 * lw;
 #pragma unroll
@@ -204,8 +213,14 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
         const float* sp = a.sparse + se * sstride;  // (scalar)
         if (LO) R.lo[e] = tzr_ld4(lo_dense ? a.dense + se * dstride + 4 * q : sp + lo_off);
         if (HI) R.hi[e] = tzr_ld4(sp + hi_off);
-        const float gvv = (a.g1 + se * gstride)[lane];
-        if (e == 0) R.gv.x = gvv; else if (e == 1) R.gv.y = gvv; else if (e == 2) R.gv.z = gvv; else R.gv.w = gvv;
+      }
+      // g1 of the four samples as ONE instruction: lane -> (sample lane >> 4, outputs 4 (lane & 15) ..), 1 KB in one piece
+      // like the X rows (it was a dword per lane and sample: four instructions and four LDS stores per tile and loader)
+      if (s0 + 3 < B) {  // (scalar branch: a scalar row base and a lane constant; only the batch's last tile clamps per lane)
+        R.gv = wg_ld4_a4(a.g1 + (unsigned)s0 * gstride + g_off);
+      } else {
+        const unsigned sg = (unsigned)(s0 + (lane >> 4) < B ? s0 + (lane >> 4) : B - 1);
+        R.gv = wg_ld4_a4(a.g1 + sg * gstride + 4 * (lane & 15));
       }
     };
     WG_PROF_DECL;
@@ -235,12 +250,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& a, const WgGroup& G, float
         }
         const int s = tt * WG_S + 4 * lw;
         const float4 g = R.gv;
-        float* go = gT + buf * (WG_S * WG_PG) + (4 * lw) * WG_PG + lane;
-        if (s + 3 < B) {  // (scalar branch: only the batch's last tile masks)
-          go[0] = g.x; go[WG_PG] = g.y; go[2 * WG_PG] = g.z; go[3 * WG_PG] = g.w;
-        } else {
-          go[0] = s < B ? g.x : 0.f; go[WG_PG] = s + 1 < B ? g.y : 0.f; go[2 * WG_PG] = s + 2 < B ? g.z : 0.f; go[3 * WG_PG] = 0.f;
-        }
+        float* go = gT + buf * (WG_S * WG_PG) + (4 * lw + (lane >> 4)) * WG_PG + 4 * (lane & 15);
+        if (s + 3 < B) tzr_st4(go, g);  // (scalar branch: only the batch's last tile masks)
+        else tzr_st4(go, s + (lane >> 4) < B ? g : tzr_zero4());
         if (SRC != 0) {
           // per sample a 16 x 16 block of X X^T by four v_mfma_f32_16x16x4_f32 (lane (r, q) supplies column 4 q + k-step of
           // row r); result register e of lane (r, q) = entry (i = 4 q + e, j = r)
@@ -450,16 +462,17 @@ __global__ __launch_bounds__(256) void tzr_ia_wgrad_reduce_kernel(WgReduceArgs a
   const int64_t step = (int64_t)WG_H * a.vw;
   const float* p = a.part + (int64_t)h * a.vw + v + j * step;
   float sum = 0.f;
-  for (int s0 = 0; s0 < a.slices; s0 += 32) {  // (slices: a multiple of 8; 8 loads in flight per lane)
-    float x[8];
+  static_assert(WG_MAXSLICES <= 64, "sixteen slices per lane");
+  {  // (slices: a multiple of 8, at most 64: all of a lane's loads in flight at once -- it was two dependent rounds of eight)
+    float x[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int s = s0 + 4 * k;
+    for (int k = 0; k < 16; ++k) {
+      const int s = 4 * k;
       x[k] = p[(int64_t)(s < a.slices ? s : 0) * step];
       x[k] = s < a.slices ? x[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sum += x[k];
+    for (int k = 0; k < 16; ++k) sum += x[k];
   }
   // (adding the zeros of slices beyond the count changes nothing: x + 0 = x, and -0 never arises from a sum started at +0)
   const float s1 = __shfl_xor(sum, 16), t01 = j & 1 ? s1 + sum : sum + s1;   // lanes j = 0 / 1: s0 + s1; j = 2 / 3: s2 + s3
