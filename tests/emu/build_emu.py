@@ -34,21 +34,49 @@ def _digest():
     return h.hexdigest()
 
 
+def _object_digest(src):
+    h = hashlib.sha256()
+    deps = [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "tzrec_hip.h"),
+        os.path.join(HERE, "hip", "hip_runtime.h"),
+        os.path.join(HERE, "tzr_gfx950.h"),
+    ]
+    for p in deps:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(OUT_DIR, exist_ok=True)
     stamp = os.path.join(OUT_DIR, "stamp")
     dig = _digest()
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
         return OUT
     cc = CLANG if os.path.exists(CLANG) else "clang++"
-    objs = []
+    objs, todo = [], []
     for src in _sources():
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        od = _object_digest(src)
+        st = obj + ".stamp"
+        if force or not (os.path.exists(obj) and os.path.exists(st) and open(st).read() == od):
+            todo.append((src, obj, st, od))
+
+    def one(job):
+        src, obj, st, od = job
         cmd = [cc, "-x", "c++", "-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unused-value",
                "-I", HERE, "-I", CSRC, "-c", src, "-o", obj]
         subprocess.check_call(cmd)
-        objs.append(obj)
-    subprocess.check_call([cc, "-shared", "-pthread", "-o", OUT] + objs)
+        with open(st, "w") as f:
+            f.write(od)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(one, todo))
+    subprocess.check_call([cc, "-shared", "-pthread", "-o", OUT + ".tmp"] + objs)
+    os.replace(OUT + ".tmp", OUT)
     with open(stamp, "w") as f:
         f.write(dig)
     return OUT

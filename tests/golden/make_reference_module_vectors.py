@@ -84,6 +84,14 @@ def _mlp_params(out, prefix, mlp):
         out[f"{prefix}/b{i}"] = _np(lin.bias)
 
 
+def _din_param_grads(out, tag, din):
+    """gradients of the attention MLP's layers and of the score layer (tzrec/modules/sequence.py:92-99)"""
+    for i, layer in enumerate(din.mlp.mlp):
+        lin = layer.perceptron[0]
+        out[f"{tag}/gW{i}"], out[f"{tag}/gb{i}"] = _np(lin.weight.grad), _np(lin.bias.grad)
+    out[f"{tag}/glinW"], out[f"{tag}/glinb"] = _np(din.linear.weight.grad), _np(din.linear.bias.grad)
+
+
 def main():
     install_reference_imports()
     fm_mod = importlib.import_module("tzrec.modules.fm")
@@ -134,6 +142,7 @@ def main():
     out["din/linW"], out["din/linb"] = _np(din.linear.weight), _np(din.linear.bias)
     out["din/query"], out["din/sequence"], out["din/length"] = _np(q), _np(s), _np(L)
     out["din/y"], out["din/gy"], out["din/gquery"], out["din/gsequence"] = _np(y), _np(gy), _np(q.grad), _np(s.grad)
+    _din_param_grads(out, "din", din)
 
     # MMoE with and without gate MLPs
     for tag, gate in (("mmoe_gate", {"hidden_units": [6]}), ("mmoe_plain", None)):
@@ -171,6 +180,25 @@ def main():
     out["dlrm/logits"], out["dlrm/loss"], out["dlrm/gsparse"] = _np(logits), _np(loss), _np(sparse.grad)
     out["dlrm/g_final_W0"] = _np(final_mlp.mlp[0].perceptron[0].weight.grad)
     out["dlrm/g_outW"] = _np(output.weight.grad)
+
+    # (added in round 6, BEHIND everything above so that the earlier arrays keep their random draws)
+    # DINEncoder at the shapes of examples/multi_tower_din_taobao.config: three 16-wide sequence features = 48-wide rows, query of
+    # the same width, attn_mlp [256, 64], sequence_length 50 here (100 there); lengths incl. 0, 1 and the full length
+    din = seq_mod.DINEncoder(sequence_dim=48, query_dim=48, input="g", attn_mlp={"hidden_units": [256, 64]})
+    q = torch.randn(12, 48, requires_grad=True)
+    L = torch.tensor([0, 1, 50, 50, 17, 33, 2, 49, 16, 31, 5, 40], dtype=torch.int64)
+    # (zero rows behind a sample's length, as to_padded_dense leaves them -- tzrec/modules/embedding.py:1480: the sample without
+    # any position then has output 0, which is also what an evaluation on the jagged rows gives)
+    s = (torch.randn(12, 50, 48) * (torch.arange(50).unsqueeze(0) < L.unsqueeze(1)).unsqueeze(2)).requires_grad_(True)
+    y = din({"g.query": q, "g.sequence": s, "g.sequence_length": L})
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _mlp_params(out, "din_taobao/mlp", din.mlp)
+    out["din_taobao/linW"], out["din_taobao/linb"] = _np(din.linear.weight), _np(din.linear.bias)
+    out["din_taobao/query"], out["din_taobao/sequence"], out["din_taobao/length"] = _np(q), _np(s), _np(L)
+    out["din_taobao/y"], out["din_taobao/gy"] = _np(y), _np(gy)
+    out["din_taobao/gquery"], out["din_taobao/gsequence"] = _np(q.grad), _np(s.grad)
+    _din_param_grads(out, "din_taobao", din)
 
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_module_vectors.npz")
     np.savez_compressed(path, **out)

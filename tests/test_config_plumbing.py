@@ -256,6 +256,69 @@ def test_multi_tower_din_config_to_training(dev):
         assert not torch.equal(ec.table_weights()[name].detach(), w), name
 
 
+def test_multi_tower_din_jagged_step_against_the_oracle(dev):
+    """The default config-4 model (DIN tower on the jagged rows: csrc/din_attention.hip, linear_bwd.hip) differentiated END TO END
+    against the oracle's autograd on the padded restatement (oracle/tzrec_oracle.din_encoder = tzrec/modules/sequence.py:101-128,
+    pinned to the reference module's outputs AND parameter gradients by tests/test_reference_module_vectors.py): loss, the gradient
+    of EVERY dense parameter (deep tower, attention MLP, score layer, final MLP, output layer) elementwise 1e-5, and every
+    table of both collections after the step's fused Adagrad update (pooled deep-group tables and the sequence group's own)."""
+    emu_heavy(dev)
+    spec = load_pipeline_spec(open(os.path.join(HERE, "golden", "din_mini.config")).read())
+    torch.manual_seed(0)
+    model = build_rank_model(spec, device=dev)
+    eg = model.embedding_group
+    assert eg.jagged_sequence_groups == {"seq"}
+    ec = eg.ecs["16"]
+    first = next(_din_batches(spec, 48, 48, seed=9))
+    kjt = first.sparse_features[BASE_DATA_GROUP]
+    B = kjt.stride()
+    off = orc.lengths_to_offsets(kjt.lengths().numpy())
+    key = {k: i for i, k in enumerate(kjt.keys())}
+    ids = lambda k: kjt.values()[off[key[k] * B]:off[(key[k] + 1) * B]]  # noqa: E731
+    lens = lambda k: kjt.lengths()[key[k] * B:(key[k] + 1) * B].to(torch.int64)  # noqa: E731
+    assert int(lens("click_seq__adgroup_id").min()) == 0 and int(lens("click_seq__adgroup_id").max()) > 12  # empty and truncated histories
+    # ---- the oracle, on leaf copies of every parameter and table
+    wb = {n: t.detach().cpu().clone().requires_grad_(True) for n, t in eg.ebc.table_weights().items()}
+    wc = {n: t.detach().cpu().clone().requires_grad_(True) for n, t in ec.table_weights().items()}
+    dense_named = [(n, p_) for n, p_ in model.named_parameters() if any(p_ is q for q in model.dense_parameters())]
+    leaf = {n: p_.detach().cpu().clone().requires_grad_(True) for n, p_ in dense_named}
+    by_obj = {id(p_): leaf[n] for n, p_ in dense_named}
+    lin = lambda seqm: [(by_obj[id(m.weight)], by_obj[id(m.bias)]) for m in seqm if hasattr(m, "weight")]  # noqa: E731
+    dense = first.dense_features[BASE_DATA_GROUP].values()
+    deep = torch.cat([wb["user_id_emb"][ids("user_id")], wb["adgroup_id_emb"][ids("adgroup_id")], wb["cate_id_emb"][ids("cate_id")],
+                      wb["price_emb"][ids("price")], dense], dim=1)
+    query = torch.cat([wc["adgroup_id_emb"][ids("adgroup_id")], wc["cate_id_emb"][ids("cate_id")]], dim=1)
+    sl = lens("click_seq__adgroup_id")
+    seq = torch.cat([orc.jagged_to_padded_dense(wc[f"{k}_emb"][ids(k)], lens(k), 12) for k in ("click_seq__adgroup_id", "click_seq__cate_id")], dim=-1)
+    din = model.din_towers[0]
+    y = torch.cat([orc.mlp(deep, lin(model.towers["deep"].mlp)),
+                   orc.din_encoder(query, seq, sl, lin(din.mlp.mlp), (by_obj[id(din.linear.weight)], by_obj[id(din.linear.bias)]))], dim=-1)
+    y = orc.mlp(y, lin(model.final_mlp.mlp))
+    ref_logits = torch.nn.functional.linear(y, by_obj[id(model.output_mlp.weight)], by_obj[id(model.output_mlp.bias)]).squeeze(1)
+    ref_loss = orc.bce_with_logits(ref_logits, first.labels["clk"])
+    ref_loss.backward()
+    # ---- the product: one training step's forward + backward (the tables update inside it)
+    batch = first.to(dev)
+    pred = model(batch)
+    loss = sum(model.loss(pred, batch).values())
+    loss.backward()
+    torch.testing.assert_close(pred["logits"].detach().cpu(), ref_logits.detach(), rtol=1e-5, atol=1e-5)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach()))
+    for n, p_ in dense_named:
+        assert leaf[n].grad is not None and p_.grad is not None, n
+        torch.testing.assert_close(p_.grad.detach().cpu(), leaf[n].grad, rtol=1e-5, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
+    lr, eps = spec.sparse_optimizer.lr, 1e-8
+    assert spec.sparse_optimizer.kind == "adagrad" and lr == 0.05
+    for col, ws in ((eg.ebc, wb), (ec, wc)):
+        for n, w in ws.items():
+            g = w.grad if w.grad is not None else torch.zeros_like(w)
+            touched = (g != 0).any(dim=1, keepdim=True)
+            # Adagrad from a zero state: state = g^2, w -= lr g / (|g| + eps) on the rows looked up (optim/optimizer_builder.py:53-59)
+            exp = torch.where(touched, w.detach() - lr * g / (g.abs() + eps), w.detach())
+            # (the first Adagrad step moves a weight by ~lr * sign(g): where a gradient element nearly cancels, its rounding shows)
+            torch.testing.assert_close(col.table_weights()[n].detach().cpu(), exp, rtol=1e-5, atol=5e-6, msg=lambda m, n=n: f"table {n}: {m}")
+
+
 def test_static_sequence_padding_changes_shapes_not_results(dev):
     """`EmbeddingGroup.static_sequence_padding`: the sequence group padded to its configured `sequence_length` (no read-back of
     the batch's longest sequence: the step becomes capturable) -- the same logits and the same gradients as padded to the

@@ -470,6 +470,26 @@ def test_direct_backward_hot_row_is_shared_by_the_tables_workgroups(dev, case):
         L.tzr_tune(b"bwd_direct_hot", 1)
 
 
+@pytest.mark.parametrize("rows,B", [(20, 8192), (24, 8000), (32, 8192), (100, 8192)])
+def test_direct_backward_hot_row_with_more_workgroups_than_rows(dev, rows, B):
+    """a table with rows <= k < 2 rows workgroups (k = ceil(lookups / 256): 20 or 24 rows at 8 192 lookups)
+    has workgroups without a row of their own; they used to leave before the hot row's arrival count, which waits for all k:
+    the hot row was never applied and the counter stayed non-zero in the reused workspace.  They now walk the ids with an
+    empty range and take their slice.  Two steps: the second would read a stale counter."""
+    from torcheasyrec_amd import _lib
+    spec = [("t_a", rows, 16, "sum", ["c0"]), ("t_b", 5000, 16, "sum", ["c1"])]
+    gen = _hot(0.6, [rows // 3])
+    opt = SparseOptimizerConfig(kind="adagrad", lr=0.05, initial_accumulator_value=0.1)
+    L = _lib.lib()
+    assert L.tzr_tune(b"bwd_direct", 1) == 0 and L.tzr_tune(b"bwd_direct_hot", 2) == 0
+    try:
+        _run_backward_case(dev, spec, ["c0", "c1"], [rows, 5000], B, "uniform1", False, opt, steps=2, rtol=5e-4,
+                           idgen=(lambda rng, r, n: gen(rng, r, n) if r == rows else rng.integers(0, r, size=n)))
+    finally:
+        L.tzr_tune(b"bwd_direct", 0)
+        L.tzr_tune(b"bwd_direct_hot", 1)
+
+
 def test_backward_plan_prep_fallback(dev):
     """more than BWD_GEO lookups/tables take the single-workgroup geometry kernel: forced here"""
     from torcheasyrec_amd import _lib

@@ -145,6 +145,72 @@ def test_din_encoder_module(dev):
     close(s.grad, T("din/gsequence"))
 
 
+@pytest.mark.parametrize("tag,cfg", [("din", dict(sequence_dim=16, query_dim=12, hidden=[20, 8], max_seq_length=6)),
+                                     ("din_taobao", dict(sequence_dim=48, query_dim=48, hidden=[256, 64], max_seq_length=0))])
+def test_din_encoder_jagged_path(dev, tag, cfg):
+    """The DEFAULT config-4 evaluation -- DINEncoder.forward_jagged: csrc/din_attention.hip + linear_bwd.hip on the rows of the
+    unpooled lookup, no padded tensor -- directly against outputs of the reference's DINEncoder (tzrec/modules/sequence.py:65-128)
+    run on the padded tensor: output, query gradient, the gradient of every valid sequence row, and the gradient of every
+    attention-MLP layer and of the score layer, elementwise 1e-5.  The jagged rows are the padded vectors' valid positions
+    (what to_padded_dense was given: tzrec/modules/embedding.py:1480).  `din` pads with random rows: a sample WITHOUT positions
+    averages them in the reference (uniform softmax over masked scores) -- a property of that fixture's padding, not of the path
+    (the lookup pads with zeros), so that one sample's output is compared against zero and its padding rows are left out."""
+    from torcheasyrec_amd.sequence import DINEncoder
+
+    din = DINEncoder(sequence_dim=cfg["sequence_dim"], query_dim=cfg["query_dim"], input="g", attn_mlp={"hidden_units": cfg["hidden"]},
+                     max_seq_length=cfg["max_seq_length"])
+    load_mlp(din.mlp, f"{tag}/mlp", dev)
+    with torch.no_grad():
+        din.linear.weight.copy_(T(f"{tag}/linW"))
+        din.linear.bias.copy_(T(f"{tag}/linb"))
+    din.to(dev)
+    assert din.jagged_capable()
+    din.row_bucket = 16  # (rows of the MLP input rounded up: zero rows behind the last position)
+    seq, lens = T(f"{tag}/sequence"), T(f"{tag}/length")
+    B, L, D = seq.shape
+    valid = torch.arange(L).unsqueeze(0) < lens.unsqueeze(1)  # [B, L]
+    rows = seq[valid]                                          # sample-major, position order: the unpooled lookup's rows
+    off = torch.zeros(B + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    q = T(f"{tag}/query").to(dev).requires_grad_(True)
+    v = rows.to(dev).requires_grad_(True)
+    y = din({"g.query": q, "g.sequence_jagged": v, "g.sequence_offsets": off.to(dev), "g.sequence_max_len": L,
+             "g.sequence_length": lens.to(dev)})
+    y_ref = T(f"{tag}/y").clone()
+    y_ref[lens == 0] = 0.0
+    close(y, y_ref)
+    y.backward(T(f"{tag}/gy").to(dev))
+    close(q.grad, T(f"{tag}/gquery"))
+    eff = valid if not cfg["max_seq_length"] else valid & (torch.arange(L).unsqueeze(0) < cfg["max_seq_length"])
+    g_ref = T(f"{tag}/gsequence")
+    close(v.grad, (g_ref * eff.unsqueeze(2))[valid])  # (a row behind max_seq_length takes no part: zero gradient, as in the reference)
+    lins = [m for m in din.mlp.mlp if isinstance(m, torch.nn.Linear)]
+    for i, lin in enumerate(lins):
+        close(lin.weight.grad, T(f"{tag}/gW{i}"))
+        close(lin.bias.grad, T(f"{tag}/gb{i}"))
+    close(din.linear.weight.grad, T(f"{tag}/glinW"))
+    close(din.linear.bias.grad, T(f"{tag}/glinb"))
+
+
+def test_oracle_din_param_gradients():
+    """oracle/tzrec_oracle.din_encoder differentiated by autograd against the reference module's parameter gradients (pins the
+    oracle's backward, which the config-level DIN tests compare the HIP path with)"""
+    for tag, msl in (("din", 6), ("din_taobao", 0)):
+        ls = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in layers(f"{tag}/mlp")]
+        lw, lb = T(f"{tag}/linW").requires_grad_(True), T(f"{tag}/linb").requires_grad_(True)
+        q, s = T(f"{tag}/query").requires_grad_(True), T(f"{tag}/sequence").requires_grad_(True)
+        y = orc.din_encoder(q, s, T(f"{tag}/length"), ls, (lw, lb), max_seq_length=msl)
+        close(y, T(f"{tag}/y"))
+        y.backward(T(f"{tag}/gy"))
+        close(q.grad, T(f"{tag}/gquery"))
+        close(s.grad, T(f"{tag}/gsequence"))
+        for i, (w, b) in enumerate(ls):
+            close(w.grad, T(f"{tag}/gW{i}"))
+            close(b.grad, T(f"{tag}/gb{i}"))
+        close(lw.grad, T(f"{tag}/glinW"))
+        close(lb.grad, T(f"{tag}/glinb"))
+
+
 def test_dlrm_dense_half(dev):
     """dense MLP -> fused dot interaction + concatenation -> final MLP -> logits -> BCE, against the
     reference modules wired as tzrec/models/dlrm.py:101-135 wires them (DLRM-Criteo shapes)."""

@@ -181,6 +181,92 @@ def test_ring_mode_equals_the_positional_candidate_lists(dev):
     assert int((ring.modules_by_table["a"].row_ids != EMPTY).sum()) > 0
 
 
+def test_restore_in_ring_mode_resets_the_device_counter_and_the_ring(dev, tmp_path):
+    """restore_checkpoint into a collection that has ALREADY run ring-mode steps (resume in-process, warm-up before a
+    restore): the device iteration counter the captured step stamps `last_iter` with restarts at the checkpoint's count, and
+    candidates recorded before the restore are not admitted afterwards.  Continuing from the restore equals continuing the
+    run that saved: same remapped ids, maps, counts and last-access iterations, step by step."""
+    from torcheasyrec_amd.checkpoint import restore_checkpoint, save_checkpoint
+
+    def build(seed):
+        torch.manual_seed(seed)
+        ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, 24, ["k"])], device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=0.1))
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.ebc = ebc
+                self.mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(24, 3, "distance_lfu")})
+                self.mc.device_profile = True
+        m = M()
+        m.mc.train()
+        return m
+
+    def batch(rng, lo, hi):
+        ids = torch.from_numpy(rng.integers(lo, hi, size=16) * 7919 + (1 << 45))
+        return KeyedJaggedTensor(["k"], ids, torch.ones(16, dtype=torch.int32), uniform_length=1).to(dev)
+
+    def step(m, kjt):
+        out, rm = m.mc(kjt)
+        out.values().sum().backward()
+        return rm.values().cpu()
+
+    a, rng = build(0), np.random.default_rng(3)
+    for _ in range(4):  # (4 = one round at 3 + one step of candidates pending in the ring)
+        step(a, batch(rng, 0, 40))
+    save_checkpoint(str(tmp_path), a)
+    b, rng_b = build(1), np.random.default_rng(11)
+    for _ in range(7):  # another history: other ids, another iteration count, its own pending candidates
+        step(b, batch(rng_b, 100, 160))
+    assert int(b.mc._d_iter.item()) == 7 and bool((b.mc._ring != EMPTY).any())
+    restore_checkpoint(str(tmp_path), b)
+    assert b.mc._iter == 4 and int(b.mc._d_iter.item()) == 4 and not bool((b.mc._ring != EMPTY).any())
+    a.mc._ring.fill_(EMPTY)  # (pending candidates are not part of a checkpoint: the saving run drops its own to compare)
+    cont = np.random.default_rng(5)
+    for i in range(5):
+        kjt = batch(cont, 0, 60)
+        assert torch.equal(step(a, kjt), step(b, kjt)), f"step {i} after the restore"
+        assert int(b.mc._d_iter.item()) == b.mc._iter == a.mc._iter == 5 + i
+    for f in ("row_ids", "counts", "last_iter"):
+        assert torch.equal(getattr(a.mc.modules_by_table["t"], f), getattr(b.mc.modules_by_table["t"], f)), f
+
+
+def test_device_profile_keeps_jagged_bags_working_and_their_candidates(dev):
+    """`device_profile` (set by GraphTrainPipeline for every model with a zero-collision hash) used to raise on a
+    batch with jagged bags -- also in eager warm-up steps -- and to drop the positional candidates of earlier steps once the
+    ring existed.  Jagged batches take the positional record outside a capture; a round admits the candidates of BOTH
+    records.  Mixed run (jagged, uniform, jagged ...) == the same run without device_profile."""
+    def build(ring):
+        torch.manual_seed(0)
+        ebc = EmbeddingBagCollection([EmbeddingBagConfig("t", 4, 20, ["k"])], device=dev, optimizer=SparseOptimizerConfig(kind="sgd", lr=0.1))
+        mc = ManagedCollisionEmbeddingBagCollection(ebc, {"t": ZchConfig(20, 4, "lfu")})
+        mc.device_profile = ring
+        mc.train()
+        return mc
+
+    pos, ring = build(False), build(True)
+    rng = np.random.default_rng(2)
+    B = 10
+    for stepno in range(9):
+        if stepno % 2 == 0:
+            lens = rng.integers(0, 4, size=B).astype(np.int32)
+            uni = None
+        else:
+            lens, uni = np.ones(B, dtype=np.int32), 1
+        ids = torch.from_numpy(rng.integers(0, 50, size=int(lens.sum())) * 7919 + (1 << 45))
+        kjt = KeyedJaggedTensor(["k"], ids, torch.from_numpy(lens), **({"uniform_length": uni} if uni else {})).to(dev)
+        got = []
+        for mc in (pos, ring):
+            out, rm = mc(kjt)
+            out.values().sum().backward()
+            got.append(rm.values().cpu())
+        assert torch.equal(got[0], got[1]), f"step {stepno}"
+        assert torch.equal(torch.sort(pos.pending_candidates("t")).values, torch.sort(ring.pending_candidates("t")).values), stepno
+    for f in ("row_ids", "counts", "last_iter"):
+        assert torch.equal(getattr(pos.modules_by_table["t"], f), getattr(ring.modules_by_table["t"], f)), f
+    assert ring._ring is not None and int((ring.modules_by_table["t"].row_ids != EMPTY).sum()) > 0
+
+
 def test_dcp_names_of_a_mixed_collection_and_refusal_of_other_naming_schemes(dev, tmp_path):
     """A collection that holds a zero-collision-hash table NEXT TO a plain one (MMoE + ZCH): the reference keeps only the
     managed-collision table under `mc_ebc._embedding_module`; the plain table stays under `...__BASE__.ebc.embedding_bags`

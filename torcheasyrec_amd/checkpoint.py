@@ -379,8 +379,7 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
     mc, mc_sharded = _mc_of(model)
     zch = None
     if mc is not None and use_dcp and (m_files[0].get("zch") or {}).get("by_raw_id"):
-        mc._iter = int(m_files[0]["zch"]["iter"])
-        mc._cand = []
+        mc.load_iter(int(m_files[0]["zch"]["iter"]))
         mc = None  # the maps came in through _restore_dcp, by raw id
     if mc is not None:
         if mc_sharded:
@@ -397,8 +396,7 @@ def restore_checkpoint(checkpoint_dir: str, model: nn.Module, dense_optimizer: O
         if zch is None and strict:
             raise KeyError("checkpoint has no zch state for this rank")
     if mc is not None and zch is not None:
-        mc._iter = int(zch["iter"])
-        mc._cand = []
+        mc.load_iter(int(zch["iter"]))
         for n, m in mc.modules_by_table.items():
             if n in zch["tables"]:
                 z = zch["tables"][n]

@@ -523,12 +523,17 @@ __device__ __forceinline__ void bwd_direct_body(
   // range j of k: rows [(j << 32) / mult, ((j + 1) << 32) / mult), bucket(row) = (row * mult) >> 32 (bwd_bucket_params)
   const bool row_per_wg = rows <= (uint64_t)k;
   const uint64_t mult = row_per_wg ? (1ull << 32) : (((uint64_t)k << 32) / rows);
-  if (row_per_wg && (uint64_t)j >= rows) return;
-  const uint32_t lo = (uint32_t)((((uint64_t)j << 32) + mult - 1) / mult);
+  // (a workgroup without rows of its own -- more workgroups than rows, or nothing left by rounding -- still walks the ids
+  // when a hot row is looked for: ALL k workgroups of the table take a slice of the hot row's positions and arrive below)
+  const bool detect = te - ts > (int64_t)BWD_UMAX && !no_hot;  // (workgroup-uniform; fewer lookups always fit)
+  uint64_t lo64 = (((uint64_t)j << 32) + mult - 1) / mult;
   uint64_t hi64 = (((uint64_t)(j + 1) << 32) + mult - 1) / mult;
   if (hi64 > rows || j + 1 == k) hi64 = rows;  // the last range takes what rounding left
-  const uint32_t hi = (uint32_t)hi64;
-  if (lo >= hi) return;
+  if ((row_per_wg && (uint64_t)j >= rows) || lo64 >= hi64) {
+    if (!detect) return;
+    lo64 = hi64 = 0;  // an empty range: gathers nothing, counts the candidate's lookups like everyone else
+  }
+  const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)hi64;
 
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = (int)tzr_uni(threadIdx.x / TZR_WAVE);
@@ -545,7 +550,6 @@ __device__ __forceinline__ void bwd_direct_body(
   // (profiles/r05ac), so it is the CALLER's statement (grad_mode | TZR_GRAD_HOT_ROWS) that such rows are expected.
   bool fits, has_c = false;
   uint32_t n_c = 0, crow = 0u;
-  const bool detect = te - ts > (int64_t)BWD_UMAX && !no_hot;  // (workgroup-uniform; fewer lookups always fit)
   uint32_t total = bwd_direct_gather_waves(G, tb, A, ts, te, lo, hi, L, &fits, detect, &has_c, &crow, &n_c);
   if (dbg == 2) return;
   const bool hot = has_c && n_c > (uint32_t)BWD_UMAX;  // the same in every workgroup of the table

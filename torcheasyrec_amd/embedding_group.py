@@ -377,7 +377,7 @@ class EmbeddingGroup(nn.Module):
                 out[f"{g}.sequence_length"] = lens
                 out[f"{g}.sequence_jagged"] = torch.cat([jts[f.name].values() for f in info["sequence"]], dim=1)
                 out[f"{g}.sequence_offsets"] = first.offsets()
-                out[f"{g}.sequence_max_len"] = info["max_len"] or 2048  # (the padded length the reference would have used, at most)
+                out[f"{g}.sequence_max_len"] = info["max_len"]  # (the padded length the reference uses; rank_model adds a group here only when it is configured)
                 continue
             if self.static_sequence_padding and info["max_len"]:
                 # pad to the configured sequence_length instead of the batch's longest sequence: no host sync (the step can be
@@ -626,6 +626,13 @@ class GraphTrainPipeline:
         self._widen = [[], []]         # per slot: (int64 ids of the slot, their int32 staging buffer) still to be widened
         self._exhausted, self._i = False, 0
 
+    def _capturable(self, batch) -> bool:
+        """a model with a zero-collision hash replays from a graph in ring mode, which needs uniform bags (zch.py): slots that
+        hold jagged id lists keep stepping eagerly instead of failing inside a capture"""
+        if zch_wrapper_of(self._model) is None:
+            return True
+        return all(k.uniform_length() for k in getattr(batch, "sparse_features", {}).values())
+
     def _stage(self, it):
         """next host batch -> the idle slot, on the copy stream"""
         try:
@@ -688,7 +695,7 @@ class GraphTrainPipeline:
         if getattr(self, "_lr_targets", None) is None:
             self._lr_targets = lr_sync_targets(self._model, self._opt)
         sync_learning_rates(self._model, self._opt, self._lr_targets)  # outside capture: the graphs read the rates from device scalars
-        if self._graphs[slot] is None and self._seen[slot] >= self._warmup:
+        if self._graphs[slot] is None and self._seen[slot] >= self._warmup and self._capturable(batch):
             g = torch.cuda.CUDAGraph()
             # capture on the caller's stream when it is a side stream (autograd's accumulation nodes and the
             # captured kernels then agree on it); torch picks one when the caller sits on the default stream

@@ -171,7 +171,7 @@ class ConfigMultiTowerDIN(RankModel):
 
     def __init__(self, spec: PipelineSpec, device=None, sparse_optimizer=None) -> None:
         super().__init__(spec, device, sparse_optimizer)
-        from .sequence import DINEncoder
+        from .sequence import DIN_JAGGED_MAX_LEN, DINEncoder
 
         eg, m = self.embedding_group, spec.model
         self.towers = nn.ModuleDict()
@@ -193,7 +193,11 @@ class ConfigMultiTowerDIN(RankModel):
             # set of lengths): csrc/din_attention.hip
             info = eg._seq_info.get(g) if hasattr(eg, "_seq_info") else None
             if JAGGED_DIN and info is not None and din.jagged_capable() and len({f.name.split("__")[0] for f in info["sequence"]}) == 1 \
-                    and not any(getattr(f, "value_dim", 1) not in (0, 1) for f in info["sequence"]):
+                    and not any(getattr(f, "value_dim", 1) not in (0, 1) for f in info["sequence"]) \
+                    and info.get("max_len") and int(info["max_len"]) <= DIN_JAGGED_MAX_LEN:
+                # (a group without a configured sequence_length pads to the batch's longest sequence in the reference: nothing
+                # is truncated there, and the jagged kernels keep at most DIN_JAGGED_MAX_LEN positions of a sample -- such
+                # groups stay on the padded form)
                 eg.jagged_sequence_groups.add(g)
         self.final_mlp = None
         if m.has("final"):

@@ -120,6 +120,12 @@ def _quiesce_process_group(device) -> float:
     return time.monotonic() - t0
 
 
+def _consumes_rng(model) -> bool:
+    """does a training step of `model` draw random numbers?  (the stochastic layers this package builds: nn.Dropout of dlrm.MLP)"""
+    mods = model.modules() if hasattr(model, "modules") else []
+    return any(isinstance(m, (torch.nn.Dropout, torch.nn.Dropout1d, torch.nn.Dropout2d, torch.nn.AlphaDropout)) and m.p > 0 for m in mods)
+
+
 class _Segment:
     """Static buffers + captured graph of the dense segment for one batch size."""
 
@@ -639,6 +645,14 @@ class ShardedTrainStep:
             # TZR_NATIVE_DRIVER=0: the six-graph form with torch.distributed's collectives between the graphs (the escape hatch
             # should RCCL kernels inside a hipGraph misbehave on some stack; measured here on ROCm 7.2 / RCCL 2.26.6)
             self.native_driver = os.environ.get("TZR_NATIVE_DRIVER", "1") != "0" and native_step.available()
+            if self.native_driver and _consumes_rng(self.model):
+                # the driver launches torch's captured graphs with a raw hipGraphLaunch: `CUDAGraph.replay()`'s prologue, which
+                # advances the philox offset the graph's random kernels read, does not run -- a dropout mask would repeat every
+                # step.  Such models keep the six-graph form (replayed through torch).
+                self.native_driver = False
+        elif self.native_driver and _consumes_rng(self.model):
+            raise ValueError("native_driver=True: the model holds an active Dropout; graphs launched by the native driver do not "
+                             "advance torch's random state (use native_driver=None / False)")
         return bool(self.native_driver)
 
     def _native_comm(self):

@@ -344,12 +344,19 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         uniform = kjt.uniform_length() or 0
         out = torch.empty_like(values)
         if self.device_profile and profile:
-            return self._remap_ring(kjt, keys, km, out)
+            if uniform:
+                return self._remap_ring(kjt, keys, km, out)
+            if self._device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("not capturable: a training step with a zero-collision hash replays from a hipGraph in ring mode, "
+                                   "which needs uniform bags (one id list shape per step); this batch has jagged bags")
+            # (jagged bags outside a capture: the ordinary record below; `_evict` reads both)
         cand = torch.empty_like(values) if profile else None
         _lib.check(_lib.lib().tzr_zch_remap(
             _lib.ptr(self._modules_device()), _lib.ptr(km), len(keys), _lib.ptr(values),
             _lib.ptr(None if uniform else kjt.offsets()), kjt.stride(), uniform, n, self._iter, 1 if profile else 0,
             _lib.ptr(out), _lib.ptr(cand), _lib.stream_ptr(self._device)), "tzr_zch_remap")
+        if profile and self._d_iter is not None:
+            self._d_iter.fill_(self._iter)  # (this step was counted by the host: ring mode's device counter follows)
         if profile:  # positional candidates of this step + where each key's segment ends
             B = kjt.stride()
             seg = (torch.full((len(keys),), B * uniform, dtype=torch.int64, device=self._device) if uniform
@@ -383,6 +390,8 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
                                       "zk_module": [self._key_module[keys[i]] for i in zk]}
         if self._d_iter is None:  # (an eager step: `remap_step` has already counted it)
             self._d_iter = torch.full((1,), self._iter - 1, dtype=torch.int64, device=self._device)
+        elif not capturing:  # (eager steps of the other record -- jagged bags -- may have been counted by the host alone)
+            self._d_iter.fill_(self._iter - 1)
         self._d_iter.add_(1)  # (inside the step: captured with it)
         _lib.check(_lib.lib().tzr_zch_remap_ring(
             _lib.ptr(self._modules_device()), _lib.ptr(km), len(keys), _lib.ptr(kjt.values()), B, uniform, kjt.values().numel(),
@@ -390,6 +399,18 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
             _lib.stream_ptr(self._device)), "tzr_zch_remap_ring")
         return KeyedJaggedTensor(kjt.keys(), out, kjt.lengths(), kjt.weights_or_none(), kjt._offsets, kjt.stride(),
                                  uniform_length=kjt.uniform_length())
+
+    def load_iter(self, n: int) -> None:
+        """The iteration count of restored maps (checkpoint.restore_checkpoint): the host's count, the device counter of ring mode
+        (the captured step bumps and stamps `last_iter` with it: it has to restart where the maps were saved, not where this
+        process happened to be) -- and no candidate of the steps before the restore is left pending in either form."""
+        self._iter = int(n)
+        self._cand = []
+        self._pending_evict = False
+        if self._d_iter is not None:
+            self._d_iter.fill_(int(n))  # (== the host's count between steps: the step itself adds the one)
+        if self._ring is not None:
+            self._ring.fill_(EMPTY)
 
     def replayed(self) -> None:
         """One replay of a captured training step has been queued: the host's iteration count follows the device's, and the
@@ -407,20 +428,6 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
         c = self._ring[:, cols, :].reshape(-1)
         return c[c != EMPTY]
 
-    @torch.no_grad()
-    def _evict_ring(self) -> None:
-        meta = self._ring_meta
-        for j, name in enumerate(self._order):
-            mod = self.modules_by_table[name]
-            if self._iter % mod.cfg.eviction_interval != 0:
-                continue
-            changed = mod.update_and_evict(self._ring_candidates(j), self._iter)
-            self.last_evicted[name] = changed
-            self._reset_rows(name, mod, changed)
-            cols = [c for c, m in enumerate(meta["zk_module"]) if m == j] if meta else []
-            if cols:  # consumed: a module with a shorter interval than the ring must not meet them again
-                self._ring[:, cols, :] = EMPTY
-
     def _reset_rows(self, name: str, mod: ManagedCollisionModule, changed: torch.Tensor) -> None:
         if self._reset and changed.numel():
             w = self.ebc.table_weights()[name]
@@ -432,23 +439,37 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
 
     @torch.no_grad()
     def _evict(self) -> None:
-        if self.device_profile and self._ring is not None:
-            self._evict_ring()
+        """The admission / eviction round of every module that is due.  Candidates come from both records: the device ring
+        (ring-mode steps) and the positional lists of ordinary eager steps -- a model can see both (warm-up steps with jagged
+        bags before a capturable shape), and neither may be dropped."""
+        ids = mods = None
+        if self._cand:
+            ids = torch.cat([c for c, _, _ in self._cand])
+            mods = torch.cat([torch.repeat_interleave(km, seg) for _, km, seg in self._cand])
+            live = ids != EMPTY
+            ids, mods = ids[live], mods[live]
+        meta = self._ring_meta if self._ring is not None else None
+        if ids is None and meta is None:
             return
-        if not self._cand:
-            return
-        ids = torch.cat([c for c, _, _ in self._cand])
-        mods = torch.cat([torch.repeat_interleave(km, seg) for _, km, seg in self._cand])
-        live = ids != EMPTY
-        ids, mods = ids[live], mods[live]
         due = [self._iter % self.modules_by_table[n].cfg.eviction_interval == 0 for n in self._order]
         for j, name in enumerate(self._order):
             if not due[j]:
                 continue
             mod = self.modules_by_table[name]
-            changed = mod.update_and_evict(ids[mods == j], self._iter)
+            parts = []
+            if meta is not None:
+                parts.append(self._ring_candidates(j))
+            if ids is not None:
+                parts.append(ids[mods == j])
+            changed = mod.update_and_evict(parts[0] if len(parts) == 1 else torch.cat(parts), self._iter)
             self.last_evicted[name] = changed
             self._reset_rows(name, mod, changed)
+            if meta is not None:
+                cols = [c for c, m in enumerate(meta["zk_module"]) if m == j]
+                if cols:  # consumed: a module with a shorter interval than the ring must not meet them again
+                    self._ring[:, cols, :] = EMPTY
+        if ids is None:
+            return
         if all(due):
             self._cand = []
         else:  # keep only the candidates of the modules that did not run
@@ -463,9 +484,7 @@ class ManagedCollisionEmbeddingBagCollection(nn.Module):
     def pending_candidates(self, table: str) -> torch.Tensor:
         """Raw ids looked up without a row since `table`'s last admission round (not consumed)."""
         j = self._order.index(table)
-        if self.device_profile and self._ring is not None:
-            return self._ring_candidates(j)
-        parts = []
+        parts = [self._ring_candidates(j)] if self._ring is not None else []
         for c, km, seg in self._cand:
             mods = torch.repeat_interleave(km, seg)
             parts.append(c[(mods == j) & (c != EMPTY)])
