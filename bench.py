@@ -125,6 +125,15 @@ def parse_args():
                     help="sharded runs: tables of at most this many rows are replicated (default: planner.pick_dp_max_rows -- the "
                          "threshold with the least modelled wire + kernel time at the run's (or the projection's) world size; 500 under "
                          "--emulator, so that capped tables still take the row-wise exchange; 65536 = the round-4 constant)")
+    ap.add_argument("--forms", choices=["auto", "ab", "one_graph", "overlapped"], default="auto",
+                    help="sharded --step-graph runs: which form of the step is timed.  one_graph = the native driver (the step ONE "
+                         "hipGraph with its RCCL collectives inline), overlapped = six hipGraphs with torch.distributed's collectives "
+                         "between them.  ab = both are warmed up and timed (>= 50 steps each, reported as `sharded_forms`), the faster "
+                         "one gives `value`; a one-graph form that raises or does not come back within --form-timeout falls back to "
+                         "the overlapped form and the line says so.  auto = ab on more than one rank, else whatever the library picks")
+    ap.add_argument("--form-timeout", type=float, default=240.0,
+                    help="--forms ab: seconds the one-graph form gets for its warm-up + trial + timed steps before the run gives it up")
+    ap.add_argument("--form-trial-steps", type=int, default=50, help="--forms ab: steps of each form's trial (at least --steps)")
     ap.add_argument("--no-spawn", action="store_true",
                     help="--gpus N > 1 outside torch.distributed.run: fail instead of re-launching under it")
     return ap.parse_args()
@@ -330,7 +339,8 @@ def sharded_proxy(args) -> dict:
         return {"error": repr(e)[:300]}
 
 
-def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_ms_per_global_step=None, capacity_factor=1.25):
+def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_ms_per_global_step=None, capacity_factor=1.25,
+                    collective_latency_us=None, in_step_collectives=4, input_dist_on_main=True):
     """The scaling arithmetic of the sharded step: what `step_ms` -- this run's time for ONE rank's
     share of the step at `B_local` samples per rank -- means at `world_target` ranks, with the bytes SURVEY 8(d) counts
     for the exchange priced at 153 GB/s per xGMI link (7 links per GPU, one per peer: a full-mesh all-to-all uses all
@@ -350,6 +360,17 @@ def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_m
     wire = {"ids_all_to_all_us": a2a_us(ids_msg), "rows_all_to_all_us": a2a_us(rows_msg), "grad_rows_all_to_all_us": a2a_us(rows_msg),
             "replica_row_sums_all_reduce_us": ring(dp_rows * D * 4.0), "dense_grads_all_reduce_us": ring(dense_bytes)}
     wire_total = sum(wire.values())
+    # Bytes are not the whole price of a collective: each one is a launch + a rendezvous of W ranks' kernels.  Until a multi-rank
+    # run measures it, the planner's own constant (planner.Topology.collective_latency, 20 us) per collective: the step has
+    # `in_step_collectives` of them in stream order (rows and gradient all-to-all, the two all-reduces: nothing hides them in
+    # the one-graph form) plus the input dist's ids all-to-all when that runs on the step's stream (the ordering edge of
+    # ShardedTrainStep._input_dist_on_main) -- the 1-rank proxy's step_ms holds their self-copy kernels, not this.
+    if collective_latency_us is None:
+        from torcheasyrec_amd.planner import Topology
+
+        collective_latency_us = Topology(W).collective_latency * 1e6
+    n_coll = in_step_collectives + (1 if input_dist_on_main else 0)
+    latency_total = n_coll * collective_latency_us
     # the critical path cannot hide the rows all-to-all (nothing but the bottom MLP is independent of it) nor the gradient
     # all-to-all's tail; the all-reduces fly under the owners' update
     exposed_min = wire["rows_all_to_all_us"] + wire["grad_rows_all_to_all_us"]
@@ -359,13 +380,20 @@ def xgmi_projection(model, B_local: int, world_target: int, step_ms: float, n1_m
                                        "replica_row_sums": dp_rows * D * 4.0, "dense_grads": float(dense_bytes)},
            "samples_per_s_if_wire_hidden": W * B_local / (step_ms * 1e-3),
            "samples_per_s_if_a2a_exposed": W * B_local / (step_ms * 1e-3 + exposed_min * 1e-6),
-           "samples_per_s_if_wire_exposed": W * B_local / (step_ms * 1e-3 + wire_total * 1e-6)}
+           "samples_per_s_if_wire_exposed": W * B_local / (step_ms * 1e-3 + wire_total * 1e-6),
+           "collective_latency_us": collective_latency_us, "collectives_in_stream_order": n_coll, "latency_total_us": latency_total,
+           "latency_source": "planner.Topology.collective_latency (assumed, not measured: no multi-rank run from this side)",
+           "samples_per_s_with_latency": {
+               "wire_hidden": W * B_local / (step_ms * 1e-3 + latency_total * 1e-6),
+               "a2a_exposed": W * B_local / (step_ms * 1e-3 + (exposed_min + latency_total) * 1e-6),
+               "wire_exposed": W * B_local / (step_ms * 1e-3 + (wire_total + latency_total) * 1e-6)}}
     if n1_ms_per_global_step:
         n1 = W * B_local / (n1_ms_per_global_step * 1e-3)
         out["n1_samples_per_s"] = n1
         out["scaling_vs_n1"] = {"wire_hidden": out["samples_per_s_if_wire_hidden"] / n1,
                                 "a2a_exposed": out["samples_per_s_if_a2a_exposed"] / n1,
                                 "wire_exposed": out["samples_per_s_if_wire_exposed"] / n1}
+        out["scaling_vs_n1_with_latency"] = {k: v / n1 for k, v in out["samples_per_s_with_latency"].items()}
         out["step_ms_needed_for_6x"] = n1_ms_per_global_step / 6.0
     return out
 
@@ -730,14 +758,32 @@ def main():
         ebc.async_plan = args.async_plan
 
     train_step = None
-    if sharded and not args.no_pipeline:
+    graph_factory = None
+    if emu and sharded and args.step_graph:
+        # plumbing runs on the CPU suite: the native driver over the emulator's recorded host functions and the shared-memory RCCL
+        # stand-in (tests/emu), so that --forms ab and its fall-back are exercised without a GPU
+        from emu.build_emu import RCCL_STUB
+        from emu.graphs import EmuGraph
+
+        if os.path.exists(RCCL_STUB):
+            os.environ.setdefault("TZR_RCCL_PATH", RCCL_STUB)
+            graph_factory = EmuGraph
+
+    def make_train_step(native):
         from torcheasyrec_amd.sharded_step import ShardedTrainStep
 
-        train_step = ShardedTrainStep(model, dense_opt, use_graph=not args.no_graph, prefetch=not args.no_prefetch,
-                                      plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph,
-                                      graph_input_dist=args.step_graph and not args.no_graph_input_dist,
-                                      overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives],
-                                      native_driver=False if args.no_native_driver else None)
+        return ShardedTrainStep(model, dense_opt, use_graph=(not args.no_graph) or graph_factory is not None, prefetch=not args.no_prefetch,
+                                plan_ahead=not args.no_plan_ahead, step_graph=args.step_graph,
+                                graph_input_dist=args.step_graph and not args.no_graph_input_dist,
+                                overlap_collectives={"auto": None, "on": True, "off": False}[args.overlap_collectives],
+                                native_driver=native, graph_factory=graph_factory,
+                                **({"warmup_iters": 0} if graph_factory is not None else {}))
+
+    # (--forms ab: the run starts on the six-graph form; the one-graph form is built later, under its deadline)
+    forms_ab = (sharded and not args.no_pipeline and args.step_graph and not args.no_native_driver
+                and (args.forms == "ab" or (args.forms == "auto" and world > 1)))
+    if sharded and not args.no_pipeline:
+        train_step = make_train_step(False if (args.no_native_driver or args.forms == "overlapped" or forms_ab) else None)
 
     def step_body(dense, kjt, label, next_kjt=None):
         if train_step is not None:
@@ -781,31 +827,124 @@ def main():
             graphs.append(g)
         sync()
 
-    def run_step(i):
+    def run_step(i, last=False):
         if graphs is not None:
             graphs[i % nb].replay()
             return losses[i % nb]
-        return step_body(*batches[i % nb], next_kjt=batches[(i + 1) % nb][1])
+        return step_body(*batches[i % nb], next_kjt=None if last else batches[(i + 1) % nb][1])
 
-    if world > 1:
-        dist.barrier()
+    def timed_block(n_steps, first=0):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; the MAX over ranks.  -> (elapsed, host seconds
+        until the steps were queued, of which waiting for overflow words, last loss)"""
+        if world > 1:
+            dist.barrier()
+            sync()
+        fw0 = getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) if sharded else 0.0
+        t0 = time.perf_counter()
+        loss_ = None
+        for i in range(n_steps):
+            loss_ = run_step(first + i)
+        host_el = time.perf_counter() - t0  # time until the HOST had queued the steps (sharded capacity exchange: includes its waits
+        #                                      for the batches' overflow words -- `host_flag_wait_ms_per_step`, the host AHEAD of the device)
+        host_fw = (getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) - fw0) if sharded else 0.0
         sync()
-    fw0 = getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) if sharded else 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = run_step(args.warmup + i)
-    host_elapsed = time.perf_counter() - t0  # time until the HOST had queued the steps (sharded capacity exchange: includes its waits
-    #                                           for the batches' overflow words -- `host_flag_wait_ms_per_step`, the host AHEAD of the device)
-    host_flag_wait = (getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) - fw0) if sharded else 0.0
-    sync()
-    if world > 1:
-        dist.barrier()
-        sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if world > 1:
+            dist.barrier()
+            sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, host_el, host_fw, loss_
+
+    # ---- N > 1: which form of the sharded step?  (VERDICT r5 #1c)  The one-graph form -- the native driver, RCCL collectives captured
+    # inline -- is the faster one on the 1-rank proxy and has never run on more than one rank from this side; the six-graph form
+    # overlaps its collectives with the neighbouring graphs and uses torch.distributed only.  Both are warmed up and timed here,
+    # the faster gives `value`; the one-graph form runs under a deadline and inside try / except: an RCCL or capture error, or a
+    # step that does not come back, falls back to the six-graph measurement (already taken) and the line says which and why.
+    sharded_forms = None
+    official = None
+    if forms_ab:
+        import threading
+
+        n_trial = max(args.form_trial_steps, args.steps)
+        n_warm = max(args.warmup, 10)
+
+        def measure(ts_):
+            nonlocal train_step
+            train_step = ts_
+            for i in range(n_warm):
+                run_step(i, last=i == n_warm - 1)
+            sync()
+            trial = timed_block(n_trial)
+            return trial[0] / n_trial * 1e3, timed_block(args.steps, first=args.warmup)
+
+        ts_six = train_step if train_step.native_driver is False else make_train_step(False)
+        six_ms, six_official = measure(ts_six)
+        sharded_forms = {"overlapped_ms": six_ms, "one_graph_ms": None, "picked": "overlapped", "trial_steps": n_trial,
+                         "overlapped": "six hipGraphs per step, torch.distributed (RCCL) collectives issued async between them",
+                         "one_graph": "ONE hipGraph per step with both all-to-alls and both all-reduces captured inline on the library's "
+                                      "own communicator, queued by tzr_step_run; input dist on the step's stream at N > 1"}
+
+        def fallback_line(reason):
+            el = six_official[0]
+            return {"metric": f"samples/sec DLRM-Criteo (examples/dlrm_criteo.config) training, batch {args.global_batch} "
+                              + ("per GPU" if args.scaling == "weak" else "global"),
+                    "value": B_global * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "collectives": coll_lib,
+                    "config": {"workload": f"dlrm_criteo: 26 tables x dim 16 (204.2M rows, fp32), fused sparse {args.optimizer} + dense Adam, "
+                                           f"ids {args.dist}", "global_batch": B_global, "per_rank_batch": B_local, "parallelism": parallelism},
+                    "sharded_forms": dict(sharded_forms, one_graph_error=reason),
+                    "launch": "pipelined: input dist one batch ahead + six hipGraphs, RCCL calls between them (the one-graph form did not "
+                              "come back: this line was written by the deadline, from the six-graph measurement taken before it)"}
+
+        def deadline():
+            # a collective that never completes cannot be cancelled: every rank's own timer ends its process; rank 0 leaves the line
+            if rank == 0:
+                print(json.dumps(fallback_line(f"no answer within {args.form_timeout:.0f} s (--form-timeout)")), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+        ts_one, err = None, None
+        timer = threading.Timer(args.form_timeout, deadline)
+        timer.daemon = True
+        timer.start()
+        try:
+            if os.environ.get("TZR_BENCH_SIMULATE") == "hang":
+                time.sleep(10 * args.form_timeout)
+            if os.environ.get("TZR_BENCH_SIMULATE") == "raise":
+                raise RuntimeError("simulated RCCL failure (TZR_BENCH_SIMULATE=raise)")
+            ts_one = make_train_step(True if graph_factory is not None else None)
+            if not ts_one._use_native_driver():
+                err = "the library cannot reach RCCL (native_step.available() is false)"
+            else:
+                one_ms, one_official = measure(ts_one)
+                if ts_one.native_error is not None or not ts_one.native_steps:
+                    err = ts_one.native_error or "no step went through the native driver"
+        except Exception as e:  # noqa: BLE001 -- any failure of this form is an answer, not the end of the run
+            err = f"{type(e).__name__}: {e}"
+        # every rank takes the same decision: one failure anywhere gives the form up everywhere (still under the deadline: a rank
+        # whose peers are stuck inside a collective never gets this answer)
+        okf = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        timer.cancel()
+        if float(okf.item()) == 0.0:
+            sharded_forms["one_graph_error"] = err or "failed on another rank"
+            train_step, official = ts_six, six_official
+            if err and not emu:
+                sync()
+        else:
+            sharded_forms["one_graph_ms"] = one_ms
+            sharded_forms["input_dist_stream"] = "main" if ts_one._input_dist_on_main() else "side"
+            if one_ms <= six_ms:
+                sharded_forms["picked"], train_step, official = "one_graph", ts_one, one_official
+            else:
+                train_step, official = ts_six, six_official
+
+    elapsed, host_elapsed, host_flag_wait, loss = official if official is not None else timed_block(args.steps, first=args.warmup)
     final_loss = float(loss.item())
 
     # Secondary reading for N > 1: the OTHER scaling regime on the same model (BASELINE.md quotes the
@@ -1087,6 +1226,7 @@ def main():
         "final_loss": final_loss,
         "secondary": secondary,
         **({"delta_tracker": True} if delta_tracker is not None else {}),
+        **({"sharded_forms": sharded_forms} if sharded_forms is not None else {}),
         "launch": launch_desc,
     }
     if sharded:
@@ -1097,7 +1237,9 @@ def main():
         # the scaling arithmetic (what this step time means for the >= 6x target): at N = 1 the run is the proxy of one
         # rank of a `65536 / B_local`-rank job, at N > 1 the measured job itself
         Wp = args.projection_world or (world if world > 1 else max(2, 65536 // max(B_local, 1)))
-        out["projection"] = xgmi_projection(model, B_local, Wp, ms_per_step, args.n1_ms or None, args.capacity_factor)
+        out["projection"] = xgmi_projection(model, B_local, Wp, ms_per_step, args.n1_ms or None, args.capacity_factor,
+                                            input_dist_on_main=(train_step._input_dist_on_main() if world > 1 else True)
+                                            if train_step is not None and args.step_graph else False)
         out["projection"]["dp_max_rows_choice"] = dp_choice
         out["projection"]["measured_on"] = (f"{world} rank(s); " + ("every collective is a self copy: wire time NOT in proxy_ms_per_step"
                                                                     if world == 1 else "wire time included in proxy_ms_per_step"))

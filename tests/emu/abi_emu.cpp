@@ -2,26 +2,20 @@
 extern "C" const char* tzr_backend(void) { return "emu"; }
 extern "C" int tzr_abi_version(void) { return 11; }
 
-// The native step driver (csrc/step_driver.hip: hipGraphLaunch + RCCL, host-only code) has nothing to emulate: the
-// emulator library exports its entry points so that the binding table loads, and refuses them.
-#include <cstddef>
-#include <cstdint>
-#define TZR_EMU_UNSUPPORTED (-4)
-extern "C" int tzr_comm_available(const char*) { return 0; }
-extern "C" int tzr_comm_version(const char*) { return -1; }
-extern "C" int tzr_comm_unique_id(const char*, void*, size_t) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_comm_create(const char*, const void*, size_t, int, int, void**) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_comm_destroy(void*) { return 0; }
-extern "C" int tzr_comm_all_to_all(void*, const void*, void*, int64_t, void*) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_comm_all_reduce(void*, float*, int64_t, int, void*) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_create(void**) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_destroy(void*) { return 0; }
-extern "C" int tzr_step_add_graph(void*, void*) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_add_all_to_all(void*, void*, const void*, void*, int64_t, int) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_add_all_reduce(void*, void*, float*, int64_t, int, int) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_add_wait(void*, int) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_num_ops(void*) { return TZR_EMU_UNSUPPORTED; }
-extern "C" int tzr_step_run(void*, void*) { return TZR_EMU_UNSUPPORTED; }
+// The native step driver (csrc/step_driver.hip: host-only code) is compiled into the emulator UNCHANGED: hipGraphLaunch / events /
+// streams are the synchronous shims of tests/emu/hip/hip_runtime.h, RCCL is whatever library `tzr_comm_create` is pointed at
+// (the CPU suite: tests/emu/rccl_stub.cpp, shared memory between the ranks' processes).  A "captured graph" on this side is a
+// host function recorded by the test harness:
+#include <hip/hip_runtime.h>
+extern "C" int tzr_emu_graph_create(void (*fn)(void*), void* arg, void** out_graph_exec) {
+  if (!fn || !out_graph_exec) return -1;
+  *out_graph_exec = new hipGraphExecEmu{fn, arg};
+  return 0;
+}
+extern "C" int tzr_emu_graph_destroy(void* graph_exec) {
+  delete static_cast<hipGraphExecEmu*>(graph_exec);
+  return 0;
+}
 
 // Context switch of the lane fibers (tests/emu/hip/hip_runtime.h): saves the callee-saved registers of
 // the System V x86-64 ABI on the current stack, stores that stack pointer, loads the other one.

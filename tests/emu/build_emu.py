@@ -11,12 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "torcheasyrec_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUT_DIR, "libtzrec_emu.so")
+RCCL_STUB = os.path.join(OUT_DIR, "librccl_stub.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def _sources():
     srcs = sorted(
-        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("abi.hip", "step_driver.hip")  # (host-only: stubs in abi_emu.cpp)
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and f != "abi.hip"  # (the version symbol: abi_emu.cpp's own)
     )
     return srcs + [os.path.join(HERE, "abi_emu.cpp")]
 
@@ -27,6 +28,8 @@ def _digest():
         os.path.join(ROOT, "include", "tzrec_hip.h"),
         os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.join(HERE, "tzr_gfx950.h"),
+        os.path.join(HERE, "rccl", "rccl.h"),
+        os.path.join(HERE, "rccl_stub.cpp"),
     ]
     for p in deps:
         with open(p, "rb") as f:
@@ -40,6 +43,7 @@ def _object_digest(src):
         os.path.join(ROOT, "include", "tzrec_hip.h"),
         os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.join(HERE, "tzr_gfx950.h"),
+        os.path.join(HERE, "rccl", "rccl.h"),
     ]
     for p in deps:
         with open(p, "rb") as f:
@@ -75,8 +79,12 @@ def build(force: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(one, todo))
-    subprocess.check_call([cc, "-shared", "-pthread", "-o", OUT + ".tmp"] + objs)
+    subprocess.check_call([cc, "-shared", "-pthread", "-o", OUT + ".tmp"] + objs + ["-ldl"])
     os.replace(OUT + ".tmp", OUT)
+    # the RCCL stand-in of the CPU suite (shared memory between the ranks' processes): a library of its own, reached by path
+    subprocess.check_call([cc, "-x", "c++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-I", HERE,
+                           os.path.join(HERE, "rccl_stub.cpp"), "-o", RCCL_STUB + ".tmp", "-lrt"])
+    os.replace(RCCL_STUB + ".tmp", RCCL_STUB)
     with open(stamp, "w") as f:
         f.write(dig)
     return OUT

@@ -248,6 +248,28 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 
+// ---- host API of csrc/step_driver.hip (graphs, events, streams).  The emulator runs everything synchronously on the calling
+// thread, so streams and events carry nothing; a "graph" is a recorded host function (tzr_emu_graph_create, abi_emu.cpp) that a
+// launch calls.
+typedef void* hipEvent_t;
+struct hipGraphExecEmu {
+  void (*fn)(void*);
+  void* arg;
+};
+typedef hipGraphExecEmu* hipGraphExec_t;
+static constexpr unsigned hipStreamNonBlocking = 1u, hipEventDisableTiming = 2u;
+inline hipError_t hipGraphLaunch(hipGraphExec_t g, hipStream_t) {
+  if (!g || !g->fn) return 1;
+  g->fn(g->arg);
+  return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(1); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+
 inline void __syncthreads() { emu::block_barrier(); }
 // lanes are OS threads here: a wave-level barrier has to be a real one
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }

@@ -1153,8 +1153,17 @@ def _slots_worker(rank, world, init_file, emu_path):
                         label[sl].contiguous()))
     runs = {}
     cap = {"exchange": "capacity", "capacity_factor": 1.3}
+    # "native": the DEFAULT N > 1 form of a GPU job -- csrc/step_driver.hip compiled unchanged into the emulator, its two
+    # communicators made over the RCCL stand-in (tests/emu/rccl_stub.cpp: shared memory between these processes), the step of a
+    # slot recorded as ONE graph with the four collectives inline, the input dist as one graph with its all-to-all inline, both
+    # replayed (`tzr_step_run` / `replay`) from the slots' second visit on
+    from emu.graphs import EmuGraph
+    os.environ["TZR_RCCL_PATH"] = os.path.join(os.path.dirname(emu_path), "librccl_stub.so")
+    native = {"step_graph": True, "graph_input_dist": True, "native_driver": True, "use_graph": True, "graph_factory": EmuGraph,
+              "warmup_iters": 0}
     for name, kw, skw in (("exact", {}, {}), ("capacity", cap, {"step_graph": True, "overlap_collectives": False}),
-                          ("capacity_overlap", cap, {"step_graph": True})):  # the default: the five-segment order
+                          ("capacity_overlap", cap, {"step_graph": True}),  # the six-segment order
+                          ("native", cap, native), ("native_side", cap, dict(native, input_dist_stream="side"))):
         torch.manual_seed(7)
         model = ShardedDLRM(criteo_tables(rows, init="seeded"), keys, NUM_DENSE, device=dev, dp_max_rows=100,
                             sparse_optimizer=SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05), **kw)
@@ -1163,22 +1172,118 @@ def _slots_worker(rank, world, init_file, emu_path):
         losses = [float(ts.step(*batches[i], next_kjt=batches[i + 1][1] if i + 1 < steps else None)) for i in range(steps)]
         runs[name] = (losses, {n: w.detach().clone() for n, w in model.ebc.table_weights().items()},
                       [p.detach().clone() for p in model.dense_parameters()], dict(model.ebc.exchange_stats), ts.graph_steps, ts.eager_steps)
+        if name.startswith("native"):
+            # the driver really ran: both slots hold a one-graph program and a one-graph input dist, every steady-state step
+            # went through tzr_step_run, both communicators exist, nothing fell back
+            assert ts.native_error is None and ts.native_driver is True
+            assert ts._comm is not None and ts._comm_in is not None and ts._comm.world == world
+            assert len(ts._slots) == 2 and all(len(sl["graph"]) == 1 and len(sl["in_graphs"]) == 1 and len(sl["program"]) == 1
+                                               for sl in ts._slots.values())
+            assert ts.native_steps == steps - 1 - 2, ts.native_steps  # (two capture steps, one overflowing batch stepped exactly)
+            assert ts._input_dist_on_main() == (name == "native" and world > 1)
     assert ts.overlap_collectives
-    for other in ("capacity", "capacity_overlap"):
-        _check_slots_run(runs["exact"], runs[other], steps)
+    for other in ("capacity", "capacity_overlap", "native", "native_side"):
+        # (world 2: a + b in any order -- bit for bit against gloo's all-reduce too; larger worlds: the stand-in adds in rank
+        # order, gloo in ring order: the dense weights agree to rounding there, everything else still bit for bit)
+        _check_slots_run(runs["exact"], runs[other], steps, exact_dense=not (other.startswith("native") and world > 2))
+    assert runs["native"][0] == runs["native_side"][0]  # the two stream orders of the input dist: the same run, bit for bit
+    for a, b in zip(runs["native"][2], runs["native_side"][2]):
+        assert torch.equal(a, b)
     dist.barrier()
     _finish_worker()
 
 
-def _check_slots_run(exact, capacity, steps):
+def _check_slots_run(exact, capacity, steps, exact_dense=True):
     (la, wa, da, _, _, _), (lb, wb, db, stats, n_graph, n_eager) = exact, capacity
     assert stats["overflow_retries"] == 1 and stats["capacity_batches"] == steps - 1, stats
     assert (n_graph, n_eager) == (steps - 1, 1)
-    assert la == lb  # same kernels on the same rows in the same order: bit for bit
+    if exact_dense:
+        assert la == lb  # same kernels on the same rows in the same order: bit for bit
+        for n in wa:
+            assert torch.equal(wa[n], wb[n]), n
+        for a, b in zip(da, db):
+            assert torch.equal(a, b)
+        return
+    # another summation order inside the all-reduces (replicated tables' row sums, dense gradients): rounding-level differences
+    # that feed back through the weights
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
     for n in wa:
-        assert torch.equal(wa[n], wb[n]), n
+        torch.testing.assert_close(wa[n], wb[n], rtol=1e-5, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
     for a, b in zip(da, db):
-        assert torch.equal(a, b)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def _native_comm_worker(rank, world, init_file, emu_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from emu.graphs import EmuGraph
+    from torcheasyrec_amd import _lib, native_step
+
+    _lib.use_library(emu_path)
+    assert not native_step.available()  # (the emulator never reaches an RCCL by itself)
+    os.environ["TZR_RCCL_PATH"] = os.path.join(os.path.dirname(emu_path), "librccl_stub.so")
+    assert native_step.available()
+    comm, comm2 = native_step.NativeComm(None, torch.device("cpu")), native_step.NativeComm(None, torch.device("cpu"))
+    assert (comm.world, comm.rank, comm.version) == (world, rank, 22606)
+    g = torch.Generator().manual_seed(100 + rank)
+    # all-to-all: rank r's slice j goes to rank j's slice r (equal splits, bytes)
+    send = torch.randint(0, 1 << 40, (world * 5,), generator=g)
+    recv, ref = torch.empty_like(send), torch.empty_like(send)
+    comm.all_to_all(send, recv)
+    dist.all_to_all_single(ref, send)
+    assert torch.equal(recv, ref)
+    # all-reduce: the ranks' buffers added in rank order (every rank the same bits), AVG = that sum times 1 / world
+    x = torch.randn(1000, generator=g)
+    parts = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(parts, x)
+    acc = parts[0].clone()
+    for p_ in parts[1:]:
+        acc += p_
+    a, b = x.clone(), x.clone()
+    comm.all_reduce(a)
+    comm2.all_reduce(b, average=True)  # (a second communicator: its own control segment and sequence numbers)
+    assert torch.equal(a, acc) and torch.equal(b, acc * (1.0 / world))
+    # a program in the six-graph style: graph | all-to-all issued async | graph | waited for | all-reduce in stream order | graph
+    log = []
+    s2, r2 = torch.zeros(world * 3, dtype=torch.int64), torch.zeros(world * 3, dtype=torch.int64)
+    red = torch.zeros(8)
+    g0 = EmuGraph(lambda: (log.append("g0"), s2.copy_(torch.arange(world * 3) + 1000 * rank + len(log))))
+    g1 = EmuGraph(lambda: log.append("g1"))
+    g2 = EmuGraph(lambda: (log.append("g2"), red.fill_(float(r2.sum()))))
+    g3 = EmuGraph(lambda: log.append(("g3", red.clone())))
+    P = native_step.StepProgram()
+    P.add_graph(g0)
+    a2a = P.add_all_to_all(comm, s2, r2, sync=False)
+    P.add_graph(g1)
+    P.add_wait(a2a)
+    P.add_graph(g2)
+    P.add_all_reduce(comm2, red, average=False, sync=True)
+    P.add_graph(g3)
+    assert len(P) == 7
+    for it in range(3):
+        log.clear()
+        P.run(None)
+        exp_r2 = torch.cat([torch.arange(3) + 3 * rank + 1000 * j + 1 for j in range(world)])
+        assert torch.equal(r2, exp_r2), (r2, exp_r2)
+        tot = sum(float(torch.cat([torch.arange(3) + 3 * q + 1000 * j + 1 for j in range(world)]).sum()) for q in range(world))
+        assert [e if isinstance(e, str) else e[0] for e in log] == ["g0", "g1", "g2", "g3"] and float(log[-1][1][0]) == tot
+    # a graph whose host function raises: the error crosses the driver and comes out of `run`
+    bad = native_step.StepProgram()
+    bad.add_graph(EmuGraph(lambda: (_ for _ in ()).throw(ValueError("from inside a graph"))))
+    with pytest.raises(ValueError, match="from inside a graph"):
+        bad.run(None)
+    dist.barrier()
+    _finish_worker()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_communicator_and_step_program_over_the_rccl_stand_in(emu_path, world):
+    """csrc/step_driver.hip (compiled UNCHANGED into the emulator) end to end between processes: communicators made from a
+    unique id carried by the process group, all-to-all and all-reduce against gloo's results, two communicators side by side,
+    and a recorded program of graphs, asynchronous collectives and waits replayed three times.  RCCL itself is stood in for
+    by tests/emu/rccl_stub.cpp (shared memory; reached through the same dlsym table as the real library)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_native_comm_worker, args=(world, os.path.join(d, "init"), emu_path), nprocs=world, join=True)
 
 
 @pytest.fixture

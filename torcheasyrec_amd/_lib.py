@@ -312,7 +312,39 @@ def stream_ptr(device: torch.device) -> Optional[int]:
     if device.type != "cuda":
         return None
     idx = device.index
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _probe_raw_stream():
+    """`torch._C._cuda_getCurrentRawStream` is a private binding (what torch's own inductor / triton glue calls per launch).
+    Used only when it exists AND agrees with the public path on this build; otherwise the public path, slower, is taken."""
+    fn = getattr(getattr(torch, "_C", None), "_cuda_getCurrentRawStream", None)
+    if fn is None or not torch.cuda.is_available():
+        return None
+    try:
+        d = torch.cuda.current_device()
+        return fn if int(fn(d)) == int(torch.cuda.current_stream(d).cuda_stream) else None
+    except Exception:
+        return None
+
+
+class _LazyRawStream:
+    """probed at the first call on a process that has a GPU (importing this module must not initialise HIP)"""
+
+    def __init__(self):
+        self._fn, self._probed = None, False
+
+    def __call__(self, idx):
+        if not self._probed:
+            self._fn, self._probed = _probe_raw_stream(), True
+        if self._fn is None:
+            return torch.cuda.current_stream(idx).cuda_stream
+        return self._fn(idx)
+
+
+_RAW_STREAM = _LazyRawStream()
 
 
 def upload_struct(arr: np.ndarray, device: torch.device) -> torch.Tensor:

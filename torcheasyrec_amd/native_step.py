@@ -17,13 +17,21 @@ from . import _lib
 
 
 def librccl_path() -> bytes:
-    """the RCCL library this process already holds (torch's own copy): the driver looks its symbols up there"""
+    """the RCCL library this process already holds (torch's own copy): the driver looks its symbols up there.
+    `TZR_RCCL_PATH` names another one (a site's own RCCL build; the CPU suite's shared-memory stand-in, tests/emu/rccl_stub.cpp)."""
+    env = os.environ.get("TZR_RCCL_PATH", "")
+    if env:
+        return env.encode()
     p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     return p.encode() if os.path.exists(p) else b""
 
 
 def available() -> bool:
-    return _lib.backend() == "hip-gfx950" and bool(_lib.lib().tzr_comm_available(librccl_path()))
+    """can this process make a communicator of the library's own?  On the GPU: whenever RCCL is reachable.  Under the lane
+    emulator (tests): only when a library was named explicitly."""
+    if _lib.backend() != "hip-gfx950" and not os.environ.get("TZR_RCCL_PATH"):
+        return False
+    return bool(_lib.lib().tzr_comm_available(librccl_path()))
 
 
 class NativeComm:
@@ -107,6 +115,7 @@ class StepProgram:
         _lib.check(_lib.lib().tzr_step_create(C.byref(h)), "tzr_step_create")
         self._h = h
         self._keep: list = []
+        self._graphs: list = []
 
     def _op(self, rc: int, what: str) -> int:
         if rc < 0:
@@ -115,6 +124,8 @@ class StepProgram:
 
     def add_graph(self, graph: "torch.cuda.CUDAGraph") -> int:
         self._keep.append(graph)
+        if hasattr(graph, "check"):
+            self._graphs.append(graph)
         return self._op(_lib.lib().tzr_step_add_graph(self._h, C.c_void_p(graph.raw_cuda_graph_exec())), "tzr_step_add_graph")
 
     def add_all_to_all(self, comm: NativeComm, send: torch.Tensor, recv: torch.Tensor, sync: bool = False) -> int:
@@ -136,8 +147,10 @@ class StepProgram:
     def __len__(self) -> int:
         return int(_lib.lib().tzr_step_num_ops(self._h))
 
-    def run(self, stream: int) -> None:
+    def run(self, stream: Optional[int]) -> None:
         _lib.check(_lib.lib().tzr_step_run(self._h, stream), "tzr_step_run")
+        for g in self._graphs:  # (stand-ins for graphs that run host code -- the CPU suite's -- hand their exceptions over here)
+            g.check()
 
     def close(self) -> None:
         if getattr(self, "_h", None):

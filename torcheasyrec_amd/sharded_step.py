@@ -140,11 +140,23 @@ class ShardedTrainStep:
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = bce_with_logits,
                  use_graph: Optional[bool] = None, prefetch: bool = True, warmup_iters: int = 2,
                  plan_ahead: bool = True, step_graph: bool = False, graph_input_dist: bool = False,
-                 overlap_collectives: Optional[bool] = None, native_driver: Optional[bool] = None) -> None:
+                 overlap_collectives: Optional[bool] = None, native_driver: Optional[bool] = None,
+                 input_dist_stream: Optional[str] = None, graph_factory: Optional[Callable] = None) -> None:
+        """`input_dist_stream`: "side" -- the next batch's input dist replays on a second stream next to the current step -- or
+        "main" -- on the step's own stream, in front of the step.  None: "main" when the native driver runs on more than one
+        rank (see `_input_dist_on_main`), else "side".
+        `graph_factory(body) -> graph` (an object with `replay()` and `raw_cuda_graph_exec()`): what stands in for a hipGraph
+        capture of `body`'s launches on a device without graphs -- the CPU suite hands in tests/emu's recorded host functions
+        so that the native driver's program order runs at world size 2 / 4 on gloo; never set on a GPU."""
         self.model, self.opt, self.loss_fn = model, dense_optimizer, loss_fn
         self.device = model.ebc._device
         self.cuda = self.device.type == "cuda"
-        self.use_graph = self.cuda if use_graph is None else (use_graph and self.cuda)
+        self._graph_factory = graph_factory
+        can_graph = self.cuda or graph_factory is not None
+        self.use_graph = can_graph if use_graph is None else (use_graph and can_graph)
+        if input_dist_stream not in (None, "side", "main"):
+            raise ValueError("input_dist_stream: 'side', 'main' or None")
+        self.input_dist_stream = input_dist_stream
         self.prefetch = prefetch
         self.plan_ahead = plan_ahead
         self.warmup_iters = warmup_iters
@@ -185,11 +197,57 @@ class ShardedTrainStep:
         # call, no Python between the graphs.  None = whenever the library can reach RCCL (a GPU build next to torch's
         # librccl); the warm-up and capture steps run the Python sequence, which is also what the gloo tests run.
         self.native_driver = native_driver
+        self.native_error: Optional[str] = None  # why the native driver was given up at run time (`_native_failed`)
         self._comm = None
         self.native_steps = 0
         # (the ids all-to-all of batch i+1 is issued from the side stream on the collection's own process group, like the
         # exact exchange's: every RCCL call of the step is eager, torch orders them on the group's stream in issue order --
         # `ebc.input_dist_group` can name another communicator for it)
+
+    # -- graphs and streams ----------------------------------------------------------------------
+    def _can_graph(self) -> bool:
+        return self.cuda or self._graph_factory is not None
+
+    def _capture(self, body: Callable[[], None], stream=None, pool=None):
+        """`body`'s launches as one hipGraph (not run).  A capture that fails leaves no open capture behind (torch ends it)."""
+        if self._graph_factory is not None:
+            return self._graph_factory(body)
+        g = torch.cuda.CUDAGraph()
+        _quiesce_process_group(self.device)
+        kw = {} if pool is None else {"pool": pool}
+        with torch.cuda.graph(g, stream=stream if stream is not None else torch.cuda.current_stream(self.device),
+                              capture_error_mode=_CAPTURE_MODE, **kw):
+            body()
+        return g
+
+    def _raw_stream(self, stream=None):
+        if not self.cuda:
+            return None
+        return (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+
+    def _input_dist_on_main(self) -> bool:
+        """The native driver's two communicators -- the step's, and the input dist's, which works a batch ahead -- must not have
+        collectives in flight at the same time in an order that differs between ranks (the documented hazard of concurrent
+        NCCL communicators: each rank's kernels of one communicator wait for their peers while the other communicator's
+        cannot start).  On two streams nothing orders them.  The ordering edge: with more than one rank the input dist of batch
+        i + 1 is queued on the STEP's stream, in front of step i -- every rank then runs `in(i+1), step(i), in(i+2), ...` in one
+        stream order, and the two communicators are never concurrent.  What it gives up is the overlap of the ~30 us input dist
+        with the step; what it gains besides safety: the batch's overflow word reaches the host a whole step earlier."""
+        if self.input_dist_stream is not None:
+            return self.input_dist_stream == "main"
+        env = os.environ.get("TZR_INPUT_DIST_STREAM", "")
+        if env in ("main", "side"):
+            return env == "main"
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.model.pg) if dist.is_available() and dist.is_initialized() else 1
+        return world > 1 and self._use_native_driver()
+
+    def _in_stream(self):
+        """the stream the input dist is queued on (None off the GPU)"""
+        if not self.cuda:
+            return None
+        return torch.cuda.current_stream(self.device) if self._input_dist_on_main() else self._side
 
     # -- dense segment ---------------------------------------------------------------------------
     def _split_bottom(self) -> bool:
@@ -233,16 +291,15 @@ class ShardedTrainStep:
             if n < self.warmup_iters:  # eager: TunableOp / lazy inits must not happen under capture
                 seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
                 return
-            cur = torch.cuda.current_stream(self.device)
-            if cur == torch.cuda.default_stream(self.device):
+            if self.cuda and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
                 raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
                                    "non-default stream (torch.cuda.set_stream)")
             seg.loss = seg.logits = seg.grads = None
-            g = torch.cuda.CUDAGraph()
-            _quiesce_process_group(self.device)
-            with torch.cuda.graph(g, stream=cur, capture_error_mode=_CAPTURE_MODE):
+
+            def body():
                 seg.loss, seg.logits, seg.grads = self._dense_fwd_bwd(seg.dense, seg.sparse, seg.label)
-            seg.graph = g
+
+            seg.graph = self._capture(body)
         seg.graph.replay()
 
     # -- input dist, possibly one batch ahead ------------------------------------------------------
@@ -274,11 +331,13 @@ class ShardedTrainStep:
         # the ids must exist before the side stream reads them: either everything queued on the main
         # stream so far, or (prefetch) just the point where this step started -- NOT the step's own
         # work, or the prefetch would queue behind the dense segment it is meant to overlap
-        if after is not None:
-            self._side.wait_event(after)
-        else:
-            self._side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self._side):
+        ins = self._in_stream()
+        if ins is self._side:
+            if after is not None:
+                self._side.wait_event(after)
+            else:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(ins):
             key, skjt = self._static_kjt(kjt)
             if key is not None and ebc.cap_eligible(skjt, ("sparse",)):
                 return self._begin_graphed(self._slots[key], key, skjt)
@@ -313,39 +372,45 @@ class ShardedTrainStep:
             st["planned"] = True
         else:
             sl["seen_in"] = sl.get("seen_in", 0) + 1
-            if sl["seen_in"] <= self.warmup_iters + 1 or not (self.graph_input_dist and self.use_graph and self.cuda):
+            ins = self._in_stream()
+            g01 = None
+            if sl["seen_in"] <= self.warmup_iters + 1 or not (self.graph_input_dist and self.use_graph and self._can_graph()):
                 ebc.cap_bucketize(st)
                 ebc.cap_exchange(st)
                 ebc.cap_segments(st)
             elif self._use_native_driver():
                 # bucketize | ids all-to-all (the library's own communicator, on the capturing stream) | owner segments,
                 # overflow word to the host, both backward plans: one graph, one launch per batch
-                comm = self._native_comm_in()
-                g01 = torch.cuda.CUDAGraph()
-                _quiesce_process_group(self.device)
-                ebc.cap_flag_arm(st)
-                with torch.cuda.graph(g01, stream=self._side, capture_error_mode=_CAPTURE_MODE):
+                def body01():
                     ebc.cap_bucketize(st)
-                    comm.all_to_all(st["msg"][0], st["msg"][1], stream=self._side.cuda_stream)
+                    comm.all_to_all(st["msg"][0], st["msg"][1], stream=self._raw_stream(ins))
                     ebc.cap_segments(st)
                     if self.plan_ahead:
                         ebc.plan_ahead(st)
+
+                try:
+                    comm = self._native_comm_in()
+                    ebc.cap_flag_arm(st)
+                    g01 = self._capture(body01, stream=ins)
+                except Exception as e:  # RCCL not capturable on this stack: the two-graph form with torch's all-to-all between
+                    self._native_failed("input dist capture", e)
+                    g01 = None
+            if g01 is not None:
                 ebc.cap_flag_arm(st)
                 g01.replay()
                 sl["in_graphs"], sl["in_st"] = (g01,), st
                 st["planned"] = True
-            else:
-                g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                _quiesce_process_group(self.device)
-                with torch.cuda.graph(g0, stream=self._side, capture_error_mode=_CAPTURE_MODE):
-                    ebc.cap_bucketize(st)
+            elif not (sl["seen_in"] <= self.warmup_iters + 1 or not (self.graph_input_dist and self.use_graph and self._can_graph())):
+                g0 = self._capture(lambda: ebc.cap_bucketize(st), stream=ins)
                 g0.replay()
                 ebc.cap_exchange(st)
-                _quiesce_process_group(self.device)
-                with torch.cuda.graph(g1, stream=self._side, capture_error_mode=_CAPTURE_MODE):
+
+                def body1():
                     ebc.cap_segments(st)
                     if self.plan_ahead:
                         ebc.plan_ahead(st)
+
+                g1 = self._capture(body1, stream=ins)
                 g1.replay()
                 sl["in_graphs"], sl["in_st"] = (g0, g1), st
                 st["planned"] = True
@@ -357,7 +422,8 @@ class ShardedTrainStep:
         if not self.cuda:
             st.pop("_deferred", None)
             return ebc.input_dist_end(st)
-        with torch.cuda.stream(self._side):
+        ins = self._in_stream()
+        with torch.cuda.stream(ins):
             spec = st.pop("_deferred", False)
             st2 = ebc.input_dist_end(st)
             if spec and st2 is st:
@@ -366,7 +432,7 @@ class ShardedTrainStep:
             if self.plan_ahead and not st.get("planned"):
                 st = ebc.plan_ahead(st)  # K6 of both backward halves needs ids only
             ev = torch.cuda.Event()
-            ev.record(self._side)
+            ev.record(ins)
         st["ready"] = ev
         return st
 
@@ -395,12 +461,13 @@ class ShardedTrainStep:
         if "cap" not in st or "flag_host" not in st:
             return self._end(st)
         if self.cuda:
-            with torch.cuda.stream(self._side):
+            ins = self._in_stream()
+            with torch.cuda.stream(ins):
                 if self.plan_ahead and not st.get("planned"):
                     st = self.model.ebc.plan_ahead(st)
                     st["planned"] = True
                 ev = torch.cuda.Event()
-                ev.record(self._side)
+                ev.record(ins)
             st["ready"] = ev
         st["_deferred"] = True
         return st
@@ -575,26 +642,26 @@ class ShardedTrainStep:
         else:
             segs, colls = (self._seg0, self._seg1, self._seg2), (self._coll0, self._coll1, None)
         capture = False
-        if self.use_graph and self.cuda and sl["graph"] is None:
+        if self.use_graph and self._can_graph() and sl["graph"] is None:
             sl["seen"] += 1
             capture = sl["seen"] > self.warmup_iters  # before: eager (lazy inits, GEMM tuning, RCCL channel setup)
-            if capture and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
+            if capture and self.cuda and torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device):
                 raise RuntimeError("ShardedTrainStep captures on the current stream: run the training loop under a "
                                    "non-default stream (torch.cuda.set_stream)")
         if capture and self._use_native_driver():
             sl["st"] = st
-            self._capture_native(st, sl)
-            self.graph_steps += 1
-            if next_kjt is not None and self.prefetch:
-                self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
-            return sl["loss"]
+            if self._capture_native(st, sl):
+                self.graph_steps += 1
+                if next_kjt is not None and self.prefetch:
+                    self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
+                return sl["loss"]
         if capture:
             sl["st"] = st  # the captured kernels read this state's buffers: keep them alive
             graphs = []
             # one memory pool for the slot's graphs: they replay in capture order, never concurrently -- and the autograd
             # graph of the bottom MLP is built in one capture (G0b) and walked backwards in the next (G1a), which is the
             # arrangement of torch.cuda.make_graphed_callables (forward and backward graphs of one pool)
-            pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
+            pool = sl.setdefault("pool", torch.cuda.graph_pool_handle()) if self.cuda else None
         prog = sl.get("program") if not capture else None
         if prog is not None:
             # steady state: the NEXT batch's input dist first (one graph on the side stream, behind the start of this step:
@@ -602,7 +669,7 @@ class ShardedTrainStep:
             # step's graphs and the all-reduces between them
             if next_kjt is not None and self.prefetch:
                 self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
-            prog.run(torch.cuda.current_stream(self.device).cuda_stream)
+            prog.run(self._raw_stream())
             self.graph_steps += 1
             self.native_steps += 1
             return sl["loss"]
@@ -616,10 +683,7 @@ class ShardedTrainStep:
                 self._ahead = (next_kjt, self._begin_ahead(next_kjt, t0))
                 ahead_done = True
             if capture:
-                g = torch.cuda.CUDAGraph()
-                _quiesce_process_group(self.device)
-                with torch.cuda.graph(g, pool=pool, stream=torch.cuda.current_stream(self.device), capture_error_mode=_CAPTURE_MODE):
-                    seg(st, sl)
+                g = self._capture(lambda seg=seg: seg(st, sl), pool=pool)
                 graphs.append(g)
                 g.replay()
             elif sl["graph"] is not None:
@@ -637,7 +701,7 @@ class ShardedTrainStep:
 
     # -- native step driver -------------------------------------------------------------------------------
     def _use_native_driver(self) -> bool:
-        if not (self.cuda and self.overlap_collectives):
+        if not (self._can_graph() and self.overlap_collectives):
             return False
         if self.native_driver is None:
             from . import native_step
@@ -670,7 +734,7 @@ class ShardedTrainStep:
             self._comm_in = NativeComm(self.model.ebc.input_dist_group or self.model.pg, self.device)
         return self._comm_in
 
-    def _capture_native(self, st: dict, sl: dict) -> None:
+    def _capture_native(self, st: dict, sl: dict) -> bool:
         """The step of a slot for the native driver.  RCCL calls on the library's own communicator CAN be captured into a
         hipGraph when they sit on the capturing stream itself (scripts/r05/rccl_own_capture_probe.py: `inline` replays; the
         fork / join form and child graphs crash in hipStreamEndCapture on this stack) -- so all four collectives live INSIDE
@@ -687,17 +751,14 @@ class ShardedTrainStep:
         all-reduces.  This call is the slot's capture step AND a training step: the graph is replayed behind its capture."""
         from .native_step import StepProgram
 
-        ebc, comm = self.model.ebc, self._native_comm()
+        ebc = self.model.ebc
         rm = st["rm"]
-        cur = torch.cuda.current_stream(self.device)
-        sp = cur.cuda_stream
-        pool = sl.setdefault("pool", torch.cuda.graph_pool_handle())
         has_rw = "rw_n" in rm
         train_rw = ebc.fused_optimizer is not None and has_rw
         train_dp = ebc.fused_optimizer is not None and "dp_n" in rm
-        g = torch.cuda.CUDAGraph()
-        _quiesce_process_group(self.device)
-        with torch.cuda.graph(g, pool=pool, stream=cur, capture_error_mode=_CAPTURE_MODE):
+        sp = self._raw_stream()
+
+        def body():
             self._seg0_rw(st, sl)
             if has_rw:
                 rows_in, _ = ebc._recv_rows_buffer(st["N_pad"], rm["rw_n"])
@@ -713,7 +774,28 @@ class ShardedTrainStep:
                 comm.all_reduce(ebc._dp_acc, stream=sp)
             comm.all_reduce(sl["flat"], average=True, stream=sp)
             self._seg2b(st, sl)
+
+        try:
+            comm = self._native_comm()
+            pool = sl.setdefault("pool", torch.cuda.graph_pool_handle()) if self.cuda else None
+            g = self._capture(body, pool=pool)
+        except Exception as e:
+            # RCCL calls that do not capture on this stack (or a communicator that cannot be made): the step keeps working in
+            # the six-graph form with torch.distributed's collectives between the graphs -- said once, loudly, not silently
+            self._native_failed("step capture", e)
+            return False
         g.replay()
         P = StepProgram()
         P.add_graph(g)
         sl["graph"], sl["program"] = [g], P
+        return True
+
+    def _native_failed(self, where: str, err: Exception) -> None:
+        import warnings
+
+        self.native_driver = False
+        self.native_error = f"{where}: {type(err).__name__}: {err}"
+        warnings.warn(f"ShardedTrainStep: native step driver given up ({self.native_error}); continuing with the six-graph form "
+                      "(torch.distributed collectives between the graphs)", RuntimeWarning)
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
