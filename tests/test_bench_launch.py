@@ -43,9 +43,10 @@ def test_bench_gpus2_times_both_forms_of_the_sharded_step(emu_path):
     d = _run("--gpus", "2", "--emulator", "--global-batch", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--form-trial-steps", "6")
     sf = d["sharded_forms"]
     assert sf["overlapped_ms"] > 0 and sf["one_graph_ms"] and sf["one_graph_ms"] > 0 and "one_graph_error" not in sf, sf
-    assert sf["picked"] == ("one_graph" if sf["one_graph_ms"] <= sf["overlapped_ms"] else "overlapped") and sf["trial_steps"] == 6
-    assert sf["input_dist_stream"] == "main"  # the ordering edge between the two communicators at N > 1
-    assert (d["exchange"]["native_driver_steps"] > 0) == (sf["picked"] == "one_graph")
+    assert sf["one_graph_side_ms"] and sf["one_graph_side_ms"] > 0 and "one_graph_side_error" not in sf, sf
+    times = {"overlapped": sf["overlapped_ms"], "one_graph": sf["one_graph_ms"], "one_graph_side": sf["one_graph_side_ms"]}
+    assert times[sf["picked"]] == min(times.values()) and sf["trial_steps"] == 6
+    assert (d["exchange"]["native_driver_steps"] > 0) == (sf["picked"] != "overlapped")
     pr = d["projection"]
     n_coll = 4 + (sf["picked"] == "one_graph")  # (the one-graph form's input dist runs on the step's stream: its all-to-all counts too)
     assert pr["collective_latency_us"] == 20.0 and pr["collectives_in_stream_order"] == n_coll and pr["latency_total_us"] == 20.0 * n_coll
@@ -74,6 +75,15 @@ def test_bench_falls_back_when_the_one_graph_form_fails_or_hangs(emu_path):
     sf = d["sharded_forms"]
     assert sf["picked"] == "overlapped" and "no answer within 5 s" in sf["one_graph_error"]
     assert d["value"] > 0 and d["n_gpus"] == 2 and d["steps"] == 2 and d["ms_per_step"] > 0
+    # only the side-stream variant hangs: the line is the best of the two forms measured before it
+    os.environ["TZR_BENCH_SIMULATE"] = "hang:one_graph_side"
+    try:
+        d = _run(*base, "--form-timeout", "20")
+    finally:
+        del os.environ["TZR_BENCH_SIMULATE"]
+    sf = d["sharded_forms"]
+    assert sf["picked"] in ("overlapped", "one_graph") and sf["one_graph_ms"] > 0 and "no answer within 20 s" in sf["one_graph_side_error"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
 def test_bench_refuses_a_world_it_was_not_launched_with(emu_path):

@@ -1,0 +1,89 @@
+// The "cells" form of the backward index plan (K6) for batches of one id per bag: ONE launch instead of four.
+//
+// The four-launch plan (pooled_bwd.hip) orders a table's lookups globally: a histogram per chunk, a scan over the chunks and
+// buckets, a partition pass to global offsets -- 40 us at B = 65 536 for no algorithmic byte, most of it launch boundaries and a
+// scan that 26 workgroups run on a 256-CU chip (profiles/r05ao).  The global order is not needed since the apply sorts its
+// unit itself (round 5): a unit only has to be able to FIND its lookups.  So:
+//
+//   partition  (one launch, a workgroup per chunk of <= 1024 table-major positions, no communication between workgroups):
+//              the chunk's lookups ordered by bucket IN PLACE -- `slab` positions [s, e) hold chunk c's {row id, lookup
+//              position} sorted by (bucket, position) -- and the chunk's bucket starts, `lstart[c][0 .. nb]`.  Cell (c, b) =
+//              slab[s + lstart[c][b] .. s + lstart[c][b + 1]).
+//   apply      a unit = the cells of a bucket range x a chunk range, known at launch time (the geometry below is a function
+//              of the tables and the batch size alone, built on the host once and kept on the device by the caller): it
+//              reads its cells' bounds (one round trip), gathers them into LDS (one more), sorts by (row id, position) and
+//              reduces as before.  Units own DISJOINT row ranges: no run crosses a unit, no stitching -- except the rows of
+//              a table with fewer rows than units, which are split over chunk ranges: their units leave a partial sum and the
+//              last of a row's units to arrive adds them in unit order and updates the row (the tiny tables' mechanism of
+//              pooled_bwd_direct.hip).
+//
+// Unit sizes are EXPECTATIONS (uniformly drawn ids fill the buckets evenly: ~1024 +- 32 lookups against a capacity of
+// BWD_UMAX = 1280).  A unit that holds more -- skewed ids -- is still updated correctly, row by row in ascending order without
+// the LDS sort (bwd_cells_slow_unit: as many passes over the unit as it has distinct rows), and counted in the geometry
+// buffer's overflow word, which is how the caller learns that this batch distribution belongs on the exact plan.
+#pragma once
+#include "pooled_bwd.h"
+
+#define BWD_CELLS_MAXC 256   // chunks of one table (cells a unit may gather from): 262 144 lookups per table at 1024 per chunk
+#define BWD_CELLS_LROW 520   // uint16 entries per lstart row (BWD_NB + 1 used; rows 16-byte aligned)
+
+struct BwdCellChunk {  // 64 bytes: everything a partition workgroup needs, in ONE load
+  int32_t t;           // table, -1: surplus
+  int32_t nb;          // buckets of the table's map
+  int64_t s, e;        // table-major positions [s, e) of the chunk
+  int64_t ts;          // first position of the table
+  uint64_t mult;       // bucket of row id k = (k * mult) >> 32
+  int64_t rows;        // (ids are clamped against it)
+  int64_t fbase;       // single-key table: index of position ts in the KJT's values (key * B); -1: several keys read the table
+  int64_t pad;
+};
+static_assert(sizeof(BwdCellChunk) == 64, "one 64-byte load");
+
+struct BwdCellUnit {  // 96 bytes: the unit's table (a copy: no dependent load) + its cells
+  TzrTable tb;
+  int32_t t;
+  int32_t c0, c1;      // chunks [c0, c1) (absolute chunk indices)
+  int32_t b0, b1;      // buckets [b0, b1)
+  int32_t split;       // > 0: one of `split` units of a single row (row id = b0: exact table), partial sums
+  int32_t rec;         // split: index of this unit's partial-sum record
+  int32_t rec0;        // split: record of the row's first unit (the row's records are consecutive)
+  int32_t counter;     // split: index of the row's arrival counter
+  int32_t feat;        // index (in the TzrFeature array) of the table's first key
+  int64_t ts;          // first table-major position of the table
+};
+static_assert(sizeof(BwdCellUnit) == 96, "two 48-byte halves");
+
+// Geometry buffer (caller-owned device memory, built by tzr_bwd_cells_geometry into a host image the caller uploads once per
+// (tables, batch size); the kernels only write its tail: records, counters, the overflow word).
+struct BwdCellsGeo {
+  int64_t n_chunks, n_units, n_recs, n_counters, n_feats, max_dim, ch, n_positions;
+  // byte offsets from the start of the buffer
+  int64_t off_chunks, off_units, off_fstart, off_fkey, off_fbo, off_recs, off_rcount, off_counters, off_overflow, bytes;
+};
+
+struct BwdCellsView {  // device pointers into the geometry buffer
+  const BwdCellChunk* chunks;
+  const BwdCellUnit* units;
+  const uint32_t* fstart;     // [F + 1]
+  const int32_t* fkey;        // [F]
+  const int32_t* feat_by_order;  // [F]
+  float* recs;                // [n_recs * max_dim] partial sums of split units
+  uint32_t* rcount;           // [n_recs] lookups behind each partial sum
+  uint32_t* counters;         // [n_counters] arrivals per split row (zero between launches)
+  uint32_t* overflow;         // [4]: [0] units that took the slow path since the buffer was made (never reset by the kernels)
+};
+
+static inline BwdCellsView bwd_cells_view(void* base, const BwdCellsGeo& g) {
+  char* b = static_cast<char*>(base);
+  BwdCellsView v;
+  v.chunks = reinterpret_cast<const BwdCellChunk*>(b + g.off_chunks);
+  v.units = reinterpret_cast<const BwdCellUnit*>(b + g.off_units);
+  v.fstart = reinterpret_cast<const uint32_t*>(b + g.off_fstart);
+  v.fkey = reinterpret_cast<const int32_t*>(b + g.off_fkey);
+  v.feat_by_order = reinterpret_cast<const int32_t*>(b + g.off_fbo);
+  v.recs = reinterpret_cast<float*>(b + g.off_recs);
+  v.rcount = reinterpret_cast<uint32_t*>(b + g.off_rcount);
+  v.counters = reinterpret_cast<uint32_t*>(b + g.off_counters);
+  v.overflow = reinterpret_cast<uint32_t*>(b + g.off_overflow);
+  return v;
+}
