@@ -331,6 +331,35 @@ int tzr_pooled_bwd_apply(const TzrTable* d_tables, const TzrFeature* d_feats, in
                          int uniform_bag_len, int grad_mode, const TzrDst* h_grads, int n_dst,
                          const TzrSparseOptim* h_optim, void* ws, size_t ws_bytes, void* stream);
 
+/* K6 / K7 in the "cells" form (csrc/pooled_bwd_cells.hip): the index plan as ONE launch for batches of exactly one id per
+ * bag -- the shape of examples/dlrm_criteo.config -- and the apply that reads it.  Same reference pieces replaced as
+ * tzr_pooled_bwd_plan / _apply (fbgemm transpose_embedding_input + split_embedding_backward_codegen_*_exact behind
+ * tzrec/modules/embedding.py:930, tzrec/main.py:774-781), same semantics: per distinct (table, row) the gradient rows of
+ * its lookups added in lookup-position order, one update (the grouping of the partial sums follows each plan's own unit
+ * boundaries: the two plans agree to fp32 rounding, each is bit-reproducible).  The plan only orders every chunk of <= 1024 lookups by
+ * bucket in place and notes the chunk's bucket starts (no histogram, no scan, no communication between workgroups); a unit of
+ * the apply gathers the cells of its bucket range from the chunks and sorts them in LDS.  Which unit reads which cells is a
+ * function of the tables and B alone: tzr_bwd_cells_geometry builds that description ON THE HOST, once; the caller keeps a
+ * device copy (256-byte aligned; the kernels write its tail: partial-sum records, arrival counters, the overflow word) and
+ * hands both to the two calls.
+ *   tzr_bwd_cells_geometry: h_tables / h_feats = HOST copies of the arrays the device calls get.  h_out == NULL: sizes only.
+ *     out_info8: [0] bytes of the image, [1] chunks, [2] units, [3] table-major positions, [4] positions per chunk,
+ *     [5] partial-sum records, [6] byte offset of the overflow word (uint32) inside the image.  TZR_ERR_UNSUPPORTED: not a
+ *     case for this plan (a table with more than 256 chunks of lookups, an empty batch): take tzr_pooled_bwd_plan.
+ *   Unit sizes are expectations for evenly drawn ids (~1024 of a capacity of 1 280).  A unit that holds more is still updated
+ *     correctly -- row by row, without the LDS sort, slowly -- and counted in the overflow word, never reset by the library: a
+ *     caller that sees it move sends this id distribution to tzr_pooled_bwd_plan, whose heavy-bucket machinery is made for it.
+ *   `ws`: tzr_pooled_bwd_workspace bytes (one size serves either plan).  d_weights: per-id weights or NULL. */
+int tzr_bwd_cells_geometry(const TzrTable* h_tables, int n_tables, const TzrFeature* h_feats, int n_feats, int64_t B,
+                           int max_dim, void* h_out, size_t out_bytes, int64_t* out_info8);
+int tzr_pooled_bwd_cells_plan(const TzrTable* d_tables, int n_tables, const TzrFeature* d_feats, int n_feats, int max_dim,
+                              const int64_t* d_values, int64_t n_values, int64_t B, const void* h_geo, void* d_geo, void* ws,
+                              size_t ws_bytes, void* stream);
+int tzr_pooled_bwd_cells_apply(const TzrTable* d_tables, const TzrFeature* d_feats, int n_feats, int n_tables, int max_dim,
+                               const float* d_weights, int64_t n_values, int64_t B, int grad_mode, const TzrDst* h_grads,
+                               int n_dst, const TzrSparseOptim* h_optim, const void* h_geo, void* d_geo, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* Dense update of replicated (data_parallel) tables after their accumulated row gradients were
  * all-reduced: for every row r of every table t with a non-zero gradient
  * g = d_acc[(d_row_start[t] + r) * dim ...], apply h_optim exactly like K7 does for one row.  Rows

@@ -49,6 +49,7 @@ def main():
                     help="experiment: the apply reads every lookup's gradient from ONE row (sample stride 0): what the apply costs without "
                          "its 1.7 M random gradient-row requests (results are meaningless)")
     ap.add_argument("--rows-cap", type=int, default=0, help="experiment: every table capped at this many rows (address-translation reach)")
+    ap.add_argument("--plan", default="auto", help="EmbeddingBagCollection.plan_mode: auto | cells | exact (comma list: each is timed)")
     ap.add_argument("sets", nargs="*", default=[""])
     args = ap.parse_args()
     _lib.use_library(args.lib or _build.build())
@@ -74,7 +75,8 @@ def main():
             nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
             batches = [k.to(dev) for k in host]
             g = torch.randn(B, 416, device=dev) * 1e-3
-            for spec in args.sets:
+            for spec in [(sp, pm) for pm in args.plan.split(",") for sp in args.sets]:
+                spec, ebc.plan_mode = spec
                 for k in KNOBS:
                     L.tzr_tune(k, 0)
                 for kv in [x for x in spec.split(",") if x]:
@@ -98,7 +100,7 @@ def main():
                 ebc._timers = None
                 f, p, a = tm.us("fwd"), tm.us("plan"), tm.us("apply")
                 tot = f[0] + p[0] + a[0]
-                print(f"B {B:6d} {dist:8s} {args.opt + '/' + args.layout[:5]:22s} [{spec or 'defaults':40s}] fwd {f[0]:6.1f} (med {f[1]:6.1f} min {f[2]:6.1f})  "
+                print(f"B {B:6d} {dist:8s} {args.opt + '/' + args.layout[:5]:22s} [{(spec or 'defaults') + ' plan=' + ebc.plan_mode:40s}] fwd {f[0]:6.1f} (med {f[1]:6.1f} min {f[2]:6.1f})  "
                       f"plan {p[0]:6.1f} ({p[1]:6.1f} {p[2]:6.1f})  apply {a[0]:6.1f} ({a[1]:6.1f} {a[2]:6.1f})  "
                       f"sum {tot:6.1f} us  frac {nbytes / (tot * 1e-6) / 8e12:.3f}", flush=True)
 

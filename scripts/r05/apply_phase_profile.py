@@ -20,6 +20,7 @@ dev = torch.device("cuda", 0)
 B = 65536
 ebc = EmbeddingBagCollection(criteo_tables(CRITEO_ROWS), device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=1e-3),
                              groups={"sparse": SPARSE_KEYS})
+ebc.plan_mode = "exact"  # (the four-launch plan's apply is what this script clocks; round 6's one-launch plan: scripts/r06/cells_phase_profile.py)
 batches = [synthetic_batch(s, B, CRITEO_ROWS)[1].to(dev) for s in range(3)]
 g = torch.randn(B, 416, device=dev) * 1e-3
 for i in range(4):

@@ -65,28 +65,37 @@ def emu_heavy(dev=None):
     return
 
 
-@pytest.fixture(params=["planned", "direct"])
-def bwd_path(request, dev):
-    """The fused backward in both of its forms on the same test body: "planned" = tzr_pooled_bwd_plan + _apply (the
-    large-batch path), "direct" = tzr_pooled_bwd_direct (one launch, small batches) wherever the library takes the shape
-    (ragged pooled bags still go through the plan).  By default the library picks by size; tests are small, so without
-    this fixture they would only ever see the direct kernel."""
+@pytest.fixture(params=["planned", "cells", "direct"])
+def bwd_path(request, dev, monkeypatch):
+    """The fused backward in each of its forms on the same test body: "planned" = tzr_pooled_bwd_plan + _apply (four-launch
+    index plan, any ids), "cells" = tzr_pooled_bwd_cells_plan + _apply (one-launch plan; batches of one id per bag -- others
+    still take the exact plan), "direct" = tzr_pooled_bwd_direct (one launch, small batches) wherever the library takes the
+    shape (ragged pooled bags still go through the plan).  By default the library picks by size and the collection by id
+    statistics; tests are small, so without this fixture they would only ever see the direct kernel."""
     from torcheasyrec_amd import _lib
 
     L = _lib.lib()
-    assert L.tzr_tune(b"bwd_direct", -1 if request.param == "planned" else 1) == 0
-    calls = {"direct": 0}
-    orig = L.tzr_pooled_bwd_direct
+    assert L.tzr_tune(b"bwd_direct", 1 if request.param == "direct" else -1) == 0
+    monkeypatch.setenv("TZR_BWD_PLAN", "cells" if request.param == "cells" else "exact")  # (read by EmbeddingBagCollection.__init__)
+    calls = {"direct": 0, "cells": 0, "exact": 0, "path": request.param}
+    orig = {n: getattr(L, n) for n in ("tzr_pooled_bwd_direct", "tzr_pooled_bwd_cells_apply", "tzr_pooled_bwd_apply")}
 
-    def counted(*a):
-        calls["direct"] += 1
-        return orig(*a)
+    def counted(name, key):
+        def f(*a):
+            calls[key] += 1
+            return orig[name](*a)
+        return f
 
-    L.tzr_pooled_bwd_direct = counted
+    L.tzr_pooled_bwd_direct = counted("tzr_pooled_bwd_direct", "direct")
+    L.tzr_pooled_bwd_cells_apply = counted("tzr_pooled_bwd_cells_apply", "cells")
+    L.tzr_pooled_bwd_apply = counted("tzr_pooled_bwd_apply", "exact")
     try:
         yield calls
     finally:
-        L.tzr_pooled_bwd_direct = orig
+        for n, f in orig.items():
+            setattr(L, n, f)
         L.tzr_tune(b"bwd_direct", 0)
     if request.param == "planned":
+        assert calls["direct"] == 0 and calls["cells"] == 0
+    if request.param == "cells":
         assert calls["direct"] == 0

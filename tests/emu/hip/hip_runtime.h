@@ -274,6 +274,7 @@ inline void __syncthreads() { emu::block_barrier(); }
 // lanes are OS threads here: a wave-level barrier has to be a real one
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}  // a compiler scheduling fence: nothing to emulate
+inline void __builtin_amdgcn_s_sleep(int) {}        // (workgroups run one after the other here: nobody to wait for)
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 

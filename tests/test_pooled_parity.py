@@ -316,6 +316,7 @@ def test_backward_uniform1(dev, kind, bwd_path):
     _run_backward_case(dev, SPEC_CRITEO_SMALL, ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4], 200,
                        "uniform1", False, opt)
     assert (bwd_path["direct"] > 0) == (bwd_path is not None and _direct_forced())
+    assert (bwd_path["cells"] > 0, bwd_path["exact"] > 0) == (bwd_path["path"] == "cells", bwd_path["path"] == "planned")
 
 
 @pytest.mark.parametrize("mode,weighted,wd", [("uniform1", False, 0.0), ("jagged", True, 0.01)])
@@ -341,6 +342,8 @@ def test_backward_long_runs(dev, bwd_path):
     # whole-chunk piece, trailing piece), the 3-row table's runs cross chunk and wave-range boundaries
     spec = [("t_one", 1, 16, "sum", ["c0"]), ("t_tiny", 3, 16, "sum", ["c1"])]
     _run_backward_case(dev, spec, ["c0", "c1"], [1, 3], 2600, "uniform1", False, opt, steps=1, rtol=5e-4)
+    # (cells plan: both tables' rows are SPLIT over chunk ranges -- partial-sum records, the last unit to arrive combines)
+    assert (bwd_path["cells"] > 0) == (bwd_path["path"] == "cells")
 
 
 def _hot(frac, hot_ids):

@@ -18,14 +18,26 @@
 //              pooled_bwd_direct.hip).
 //
 // Unit sizes are EXPECTATIONS (uniformly drawn ids fill the buckets evenly: ~1024 +- 32 lookups against a capacity of
-// BWD_UMAX = 1280).  A unit that holds more -- skewed ids -- is still updated correctly, row by row in ascending order without
-// the LDS sort (bwd_cells_slow_unit: as many passes over the unit as it has distinct rows), and counted in the geometry
-// buffer's overflow word, which is how the caller learns that this batch distribution belongs on the exact plan.
+// BWD_UMAX = 1280).  A unit that holds more -- skewed ids -- leaves itself on a list; BWD_CELLS_WORKERS workgroups at the END of
+// the same launch's grid wait until every unit has looked at its size, then take the listed units piece by piece
+// (pooled_bwd_cells.hip: bwd_cells_worker).  Still one launch, still correct for any ids, and the ordinary units' code holds
+// nothing of it.  The geometry buffer's overflow word counts such units: how the caller learns that this id distribution belongs
+// on the exact plan, whose heavy-bucket machinery is made for it.
 #pragma once
 #include "pooled_bwd.h"
 
 #define BWD_CELLS_MAXC 256   // chunks of one table (cells a unit may gather from): 262 144 lookups per table at 1024 per chunk
 #define BWD_CELLS_LROW 520   // uint16 entries per lstart row (BWD_NB + 1 used; rows 16-byte aligned)
+#define BWD_CELLS_TARGET 1076  // largest EXPECTED size of a unit: BWD_UMAX - 6 sqrt(BWD_UMAX)
+#define BWD_CELLS_WORKERS 32   // workgroups behind the units of the apply launch that take the units that did not fit
+// words of the overflow area (BwdCellsView::overflow)
+#define BWD_CELLS_OVF_TOTAL 0    // units that did not fit since the buffer was made (never reset by the kernels: the caller's signal)
+#define BWD_CELLS_OVF_LEN 1      // ... of this launch (reset by the last worker)
+#define BWD_CELLS_OVF_EPOCH 2    // launches finished on this buffer: a unit that has looked at its size says so by writing EPOCH + 1
+                                 // into its flag word (a plain store -- a shared arrival counter cost every unit a contended atomic)
+#define BWD_CELLS_OVF_CURSOR 3   // next list entry to hand out
+#define BWD_CELLS_OVF_DONE 4     // workers that have finished
+#define BWD_CELLS_OVF_LIST 8     // first of the n_units list words; the n_units flag words follow them
 
 struct BwdCellChunk {  // 64 bytes: everything a partition workgroup needs, in ONE load
   int32_t t;           // table, -1: surplus
@@ -70,7 +82,7 @@ struct BwdCellsView {  // device pointers into the geometry buffer
   float* recs;                // [n_recs * max_dim] partial sums of split units
   uint32_t* rcount;           // [n_recs] lookups behind each partial sum
   uint32_t* counters;         // [n_counters] arrivals per split row (zero between launches)
-  uint32_t* overflow;         // [4]: [0] units that took the slow path since the buffer was made (never reset by the kernels)
+  uint32_t* overflow;         // [BWD_CELLS_OVF_LIST + n_units]: counters + the list of this launch's units that did not fit
 };
 
 static inline BwdCellsView bwd_cells_view(void* base, const BwdCellsGeo& g) {

@@ -3,13 +3,31 @@
 // Replaces, like pooled_bwd.hip / pooled_bwd_apply.hip, fbgemm's transpose_embedding_input + split_embedding_backward_codegen_*
 // behind autograd of self.ebc(kjt) (/root/reference/tzrec/modules/embedding.py:930) with the optimizer fused by
 // apply_optimizer_in_backward (/root/reference/tzrec/main.py:774-781; optim/optimizer_builder.py:30-97): per distinct (table, row)
-// the gradient rows of its lookups are added in LOOKUP-POSITION order and the row is updated once -- the same sums in the
-// same order as the four-launch plan's apply, bit for bit (tests/test_pooled_parity.py: bwd_path "cells").
+// the gradient rows of its lookups are added in LOOKUP-POSITION order and the row is updated once.  The order of the additions
+// is the four-launch plan's; the GROUPING of the partial sums follows each plan's own unit / tile boundaries, so the two agree to
+// fp32 rounding, and each is bit-reproducible: a function of the ids alone (tests/test_pooled_parity.py: bwd_path "cells").
 #include <tzr_gfx950.h>
 
 #include <algorithm>
 #include <cstring>
 #include <vector>
+
+#ifdef IT_PROF  // scripts/build_prof_lib.sh: wall-clock stamps (100 MHz) of every workgroup of the cells apply, read back by tzr_cells_prof_dump
+#define CELLS_PROF_WGS 4096
+__device__ uint64_t g_cells_prof[CELLS_PROF_WGS * 16];
+// slots: 0 start | 1 bounds known | 2 lookups in registers | 3 sorted, in LDS | 4 .. 7 a wave's tiles done | 8 end | 9 n | 10 split
+#define CELLS_MARK(i) do { if (blockIdx.x < CELLS_PROF_WGS && threadIdx.x == 0) g_cells_prof[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define CELLS_NOTE(i, v) do { if (blockIdx.x < CELLS_PROF_WGS && threadIdx.x == 0) g_cells_prof[blockIdx.x * 16 + (i)] = (uint64_t)(v); } while (0)
+#define BWD_PROF_MARK(i) do { if ((i) == 2 && blockIdx.x < CELLS_PROF_WGS && (threadIdx.x & (TZR_WAVE - 1)) == 0) \
+    g_cells_prof[blockIdx.x * 16 + 4 + threadIdx.x / TZR_WAVE] = wall_clock64(); } while (0)
+extern "C" int tzr_cells_prof_dump(uint64_t* h_out, int n_wg) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_cells_prof), (size_t)std::min(n_wg, CELLS_PROF_WGS) * 16 * sizeof(uint64_t)) == hipSuccess ? 0 : -1;
+}
+#else
+#define CELLS_MARK(i)
+#define CELLS_NOTE(i, v)
+#endif
 
 #include "pooled_bwd_apply.h"
 #include "pooled_bwd_cells.h"
@@ -107,6 +125,11 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
       cd.fbase = fbase;
       H.chunks.push_back(cd);
     }
+    // Expected lookups of a unit of an exact table (rows grouped / a row split): at most BWD_CELLS_TARGET -- 6 standard deviations
+    // (sqrt(n p)) below the LDS capacity, so that evenly drawn ids practically never overflow a unit -- and as close to it as whole
+    // rows allow: every unit is a workgroup, and the apply wants its whole grid resident (1 792 slots at 7 waves per SIMD;
+    // DLRM-Criteo at 65 536: 1 737 units)
+    const int64_t target = BWD_CELLS_TARGET;
     BwdCellUnit u;
     std::memset(&u, 0, sizeof(u));
     u.tb = tb;
@@ -126,9 +149,9 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
         u.split = 0;
         if (u.b1 > u.b0) H.units.push_back(u);
       }
-    } else if (n <= (int64_t)ch * tb.rows) {
-      // a bucket is a row; expected lookups per row <= one chunk: whole rows grouped up to ~ch lookups, over all chunks
-      const int64_t rpu = std::max<int64_t>(1, ((int64_t)ch * tb.rows) / n);
+    } else if (n <= target * tb.rows) {
+      // a bucket is a row; expected lookups per row <= the target: whole rows grouped up to it, over all chunks
+      const int64_t rpu = std::max<int64_t>(1, (target * tb.rows) / n);
       for (int64_t r = 0; r < tb.rows; r += rpu) {
         u.c0 = c_lo;
         u.c1 = c_hi;
@@ -139,7 +162,10 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
       }
     } else {
       // fewer rows than chunks' worth of lookups: a row is SPLIT over K chunk ranges, partial sums combined by the last to arrive
-      const int64_t K = std::min<int64_t>(C, (n + (int64_t)ch * tb.rows - 1) / ((int64_t)ch * tb.rows));
+      // (whole chunks: m = the most chunks whose expected share of one row stays within the target, K = ceil(C / m) slices of
+      // floor / ceil(C / K) <= m chunks)
+      const int64_t m = std::max<int64_t>(1, (target * tb.rows * C) / n);
+      const int64_t K = std::min<int64_t>(C, (C + m - 1) / m);
       for (int64_t r = 0; r < tb.rows; ++r) {
         for (int64_t k = 0; k < K; ++k) {
           u.c0 = c_lo + (int32_t)(k * C / K);
@@ -190,7 +216,7 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
   g.off_counters = off;
   off = align256(off + std::max<int64_t>(1, n_counters) * 4);
   g.off_overflow = off;
-  off = align256(off + 16);
+  off = align256(off + 4 * (BWD_CELLS_OVF_LIST + 2 * g.n_units));
   g.bytes = off;
   return TZR_OK;
 }
@@ -323,25 +349,39 @@ __device__ __forceinline__ void bwd_cells_combine(const BwdCellUnit& u, const Bw
   last = __shfl(last, 0, TZR_WAVE);
   if (!last) return;
   if (lane == 0) tzr_publish_u32(V.counters + u.counter, 0u);  // the counter is zero again when the launch ends
+  // the row's records a wave's worth at a time -- 64 / (D / 4) records per round trip -- and added in unit order by shuffles (one
+  // record after the other this walk was a chain of cache-bypassing loads: ~1.5 us each, 21 of them for a row of the 3-row
+  // Criteo table at B = 65 536, in the workgroup that is the last of its row to arrive: the lesson of bwd_stitch_unit)
+  const int gw = TZR_WAVE / lg;
+  const int gi = lane / lg, c = lane - gi * lg;
   float4 tot = tzr_zero4();
   uint32_t cnt = 0;
-  for (int k = 0; k < u.split; ++k) {
-    if (lane < lg) tot = tzr_add4(tot, bwd_consume4(V.recs + (size_t)(u.rec0 + k) * max_dim + 4 * lane));
-    cnt += tzr_consume_u32(V.rcount + u.rec0 + k);
+  for (int k0 = 0; k0 < u.split; k0 += gw) {
+    const int k = k0 + gi;
+    const bool in = gi < gw && k < u.split;
+    float4 v = tzr_zero4();
+    uint32_t cn = 0;
+    if (in) {
+      v = bwd_consume4(V.recs + (size_t)(u.rec0 + k) * max_dim + 4 * c);
+      cn = tzr_consume_u32(V.rcount + u.rec0 + k);
+    }
+    const int nk = min(gw, u.split - k0);
+    for (int g = 0; g < nk; ++g) {  // (wave-uniform)
+      const float4 piece = bwd_shfl4(v, g * lg + (lane < lg ? lane : 0));
+      if (lane < lg) tot = tzr_add4(tot, piece);
+      cnt += (uint32_t)__shfl((int)cn, g * lg, TZR_WAVE);
+    }
   }
   if (cnt) bwd_apply_row_wave<ADAM>(u.tb, opt, lr, (uint32_t)u.b0, tot, lane);  // (a row nobody looked up is not touched)
 }
 
-// A unit with more lookups than the LDS unit holds (skewed ids: this geometry expects evenly filled buckets): its rows one
-// after the other in ascending order, as many passes over the unit as it has distinct rows.  Pass 1 finds the smallest row id
-// not done yet; pass 2 adds that row's gradient rows -- lane group q takes lookups q, q + G, q + 2 G, ... in order, the groups'
-// sums are added in group order: a function of the ids alone.  Correct for any ids; slow on purpose-built ones -- the caller
-// sees the overflow word move and sends this distribution to the exact plan.
-template <bool ADAM>
-__device__ __forceinline__ void bwd_cells_slow_unit(
+// Sum of the gradient rows of the unit's lookups of ONE row, in lookup order: lane group q takes lookups q, q + G, q + 2 G, ...
+// in order, the groups' sums are added in group order -- a function of the ids alone.  All threads call; the result (and the
+// number of lookups) in wave 0, lanes < dim / 4.  `red`: 4 KB of LDS, `sm`: 2 * BWD_WAVES + 64 words.
+__device__ __forceinline__ float4 bwd_cells_row_sum(
     const BwdCellUnit& u, const BwdCellsView& V, const uint2* __restrict__ slab, const uint32_t* cpre, const uint32_t* cbase,
-    int ncell, int n, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B, int grad_mode,
-    const BwdOpt& opt, int max_dim, const TzrDst* sG, float* red, uint32_t* sm) {
+    int ncell, int n, uint32_t row, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
+    int grad_mode, const TzrDst* sG, float* red, uint32_t* sm, uint32_t* count_out) {
   const TzrTable& tb = u.tb;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
@@ -349,133 +389,170 @@ __device__ __forceinline__ void bwd_cells_slow_unit(
   const int gi = lane / lg, c = lane - gi * lg;
   const bool lane_on = gi < gw;
   const int groups = gw * BWD_WAVES, q = wv * gw + gi;
-  const float lr = *opt.lr;
   const bool single = tb.n_feats == 1;
   const BwdSrc one = bwd_resolve(feats + V.feat_by_order[tb.first_order], sG);
-  uint32_t cur = 0;
-  float4 rowsum = tzr_zero4();  // split unit: its one row
-  uint32_t rowcnt = 0;
-  for (;;) {
-    uint32_t m = BWD_SENT;
-    for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
-      const uint32_t k = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)i).x;
-      if (k >= cur) m = min(m, k);
+  float4 acc = tzr_zero4();
+  uint32_t cnt = 0;
+  const int trips = (n + groups - 1) / groups;
+  for (int j = 0; j < trips; ++j) {
+    const int i = j * groups + q;
+    const bool valid = lane_on && i < n;
+    const uint2 e = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));
+    if (valid && e.x == row) {
+      acc = tzr_add4(acc, bwd_lookup_grad(feats, tb, V.feat_by_order, sG, one, single, grad_mode, nullptr, weights, nullptr, B, 1,
+                                          e.y, c));
+      cnt += 1;
     }
-    for (int d = TZR_WAVE >> 1; d > 0; d >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d, TZR_WAVE));
-    __syncthreads();  // (sm / red of the previous row are read)
-    if (lane == 0) sm[wv] = m;
-    __syncthreads();
-    m = sm[0];
-#pragma unroll
-    for (int w = 1; w < BWD_WAVES; ++w) m = min(m, sm[w]);
-    if (m == BWD_SENT) break;  // workgroup-uniform
-    float4 acc = tzr_zero4();
-    uint32_t cnt = 0;
-    const int trips = (n + groups - 1) / groups;
-    for (int j = 0; j < trips; ++j) {
-      const int i = j * groups + q;
-      const bool valid = lane_on && i < n;
-      const uint2 e = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));
-      if (valid && e.x == m) {
-        acc = tzr_add4(acc, bwd_lookup_grad(feats, tb, V.feat_by_order, sG, one, single, grad_mode, nullptr, weights, nullptr, B, 1,
-                                            e.y, c));
-        cnt += 1;
-      }
-    }
-    if (lane_on) {
-      float* r = red + (size_t)(q * lg + c) * 4;
-      r[0] = acc.x; r[1] = acc.y; r[2] = acc.z; r[3] = acc.w;
-    }
-    if (lane_on && c == 0) sm[BWD_WAVES + q] = cnt;
-    __syncthreads();
-    if (wv == 0) {
-      float4 tot = tzr_zero4();
-      uint32_t ct = 0;
-      for (int g = 0; g < groups; ++g) {
-        if (lane < lg) {
-          const float* r = red + (size_t)(g * lg + lane) * 4;
-          tot = tzr_add4(tot, make_float4(r[0], r[1], r[2], r[3]));
-        }
-        ct += sm[BWD_WAVES + g];
-      }
-      if (u.split > 0) {
-        rowsum = tot;
-        rowcnt = ct;
-      } else {
-        bwd_apply_row_wave<ADAM>(tb, opt, lr, m, tot, lane);
-      }
-    }
-    if (m == 0xFFFFFFFEu) break;
-    cur = m + 1u;
   }
-  if (u.split > 0 && wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, rowsum, rowcnt, lane);
+  __syncthreads();  // (red / sm may still be read from an earlier call)
+  if (lane_on) {
+    float* r = red + (size_t)(q * lg + c) * 4;
+    r[0] = acc.x; r[1] = acc.y; r[2] = acc.z; r[3] = acc.w;
+    if (c == 0) sm[2 * BWD_WAVES + q] = cnt;
+  }
+  __syncthreads();
+  float4 tot = tzr_zero4();
+  uint32_t ct = 0;
+  if (wv == 0) {
+    for (int g = 0; g < groups; ++g) {
+      if (lane < lg) {
+        const float* r = red + (size_t)(g * lg + lane) * 4;
+        tot = tzr_add4(tot, make_float4(r[0], r[1], r[2], r[3]));
+      }
+      ct += sm[2 * BWD_WAVES + g];
+    }
+  }
+  *count_out = ct;
+  return tot;
 }
 
-template <bool ADAM, int FK, int NT>
-__device__ __forceinline__ void bwd_cells_apply_body(
-    BwdCellsView V, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B, int grad_mode,
-    const BwdGrads& G, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ lstart, int ch) {
-  __shared__ BwdCellsLds L;
-  __shared__ TzrDst sG[TZR_MAX_DST];
-  const BwdCellUnit u = V.units[blockIdx.x];
+// A unit with more lookups than the LDS unit holds (skewed ids: the geometry expects evenly filled buckets) is done piece by
+// piece, the way the one-launch backward walks a row range that does not fit (pooled_bwd_direct.hip): a histogram of the unit's
+// lookups over 256 sub-ranges of the rows still to do gives the longest prefix of sub-ranges that fits one LDS unit; those
+// lookups are compacted into the exchange buffer in arrival order and take the ordinary sort + reduction (the SAME call sites as
+// an ordinary unit's, in a workgroup of its own role: bwd_cells_worker); a single row with more lookups than a unit is summed in a streaming
+// pass.  Every pass reads the unit's cells again (L2).  Correct for any ids, slower than the exact plan's tile-parallel heavy
+// buckets -- the caller sees the overflow word move and sends this id distribution there.
+//
+// bwd_cells_next_piece: advances `cur` over the unit's rows [cur, khi) until a piece is staged -- L.S.pk / ps[0 .. np) hold its
+// lookups in arrival order, returns np > 0 -- or the rows are exhausted (0).  Rows streamed on the way are updated here.
+template <bool ADAM>
+__device__ __forceinline__ int bwd_cells_next_piece(
+    const BwdCellUnit& u, const BwdCellsView& V, const uint2* __restrict__ slab, const uint32_t* cpre, const uint32_t* cbase,
+    int ncell, int n, uint32_t& cur, uint32_t khi, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
+    int grad_mode, const BwdOpt& opt, float lr, BwdCellsLds& L, const TzrDst* sG) {
+  const TzrTable& tb = u.tb;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
+  float* const red = reinterpret_cast<float*>(&L.S.L);  // 4 KB (the ranking rows: free outside the sort)
+  uint32_t* const hist = L.S.gstart;
+  uint32_t* const sm = L.S.gstart + 264;                // (behind the 257 histogram words)
+  constexpr int SB = BWD_THREADS;  // sub-ranges per pass: one per thread
+  while (cur < khi) {
+    uint32_t lim = khi;
+    for (;;) {
+      const uint32_t span = lim - cur;
+      const uint64_t m2 = span <= (uint32_t)SB ? (1ull << 32) : (((uint64_t)SB << 32) / span);
+      __syncthreads();
+      hist[threadIdx.x] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += BWD_THREADS) {
+        const uint32_t k = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)i).x;
+        if (k >= cur && k < lim) atomicAdd(&hist[(uint32_t)(((uint64_t)(k - cur) * m2) >> 32)], 1u);
+      }
+      __syncthreads();
+      bwd_block_scan(hist, SB, L.S.wtot);  // exclusive starts; hist[SB] = lookups in [cur, lim)
+      const uint32_t in_range = hist[SB];
+      // p = leading sub-ranges that fit one unit together: hist is monotone, p = #{ j in 1 .. SB : hist[j] <= UMAX }
+      uint32_t fit = hist[threadIdx.x + 1] <= (uint32_t)BWD_UMAX ? 1u : 0u;
+      for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) fit += (uint32_t)__shfl_xor((int)fit, m, TZR_WAVE);
+      if (lane == 0) sm[wv] = fit;
+      __syncthreads();
+      uint32_t p = 0;
+#pragma unroll
+      for (int w = 0; w < BWD_WAVES; ++w) p += sm[w];
+      if (in_range == 0) {
+        cur = lim;
+        break;
+      }
+      if (p >= 1) {
+        const uint32_t end = p >= (uint32_t)SB ? lim : min(lim, cur + (uint32_t)((((uint64_t)p << 32) + m2 - 1) / m2));
+        // the piece's lookups compacted in arrival order into the exchange buffer
+        __syncthreads();  // (hist / sm are read above)
+        uint32_t total = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int base = 0; base < n; base += BWD_THREADS) {
+          const int i = base + (int)threadIdx.x;
+          const uint2 e = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));
+          const bool m = i < n && e.x >= cur && e.x < end;
+          const unsigned long long bal = __ballot(m);
+          if (lane == 0) sm[BWD_WAVES + wv] = (uint32_t)__popcll(bal);
+          __syncthreads();
+          uint32_t pre = total, all = 0;
+#pragma unroll
+          for (int w = 0; w < BWD_WAVES; ++w) {
+            const uint32_t cw = sm[BWD_WAVES + w];
+            if (w < wv) pre += cw;
+            all += cw;
+          }
+          const uint32_t at = pre + (uint32_t)__popcll(bal & lt);
+          if (m && at < (uint32_t)BWD_UMAX) {
+            L.S.pk[at] = e.x;
+            L.S.ps[at] = e.y;
+          }
+          total += all;
+          __syncthreads();
+        }
+        cur = end;
+        if (total == 0) break;  // (leading sub-ranges without a lookup in front of one that does not fit: nothing to reduce)
+        return (int)min(total, (uint32_t)BWD_UMAX);
+      }
+      // the first sub-range alone does not fit
+      const uint32_t end0 = min(lim, cur + (uint32_t)((((uint64_t)1 << 32) + m2 - 1) / m2));
+      if (end0 - cur <= 1u) {  // one row with more lookups than a unit: streamed
+        uint32_t cnt;
+        const float4 sum = bwd_cells_row_sum(u, V, slab, cpre, cbase, ncell, n, cur, feats, weights, B, grad_mode, sG, red, sm, &cnt);
+        if (wv == 0 && cnt) bwd_apply_row_wave<ADAM>(tb, opt, lr, cur, sum, lane);
+        cur += 1;
+        break;
+      }
+      lim = end0;  // narrow
+    }
+  }
+  return 0;
+}
+
+// The bounds of unit u's cells into LDS (cpre: exclusive counts, cpre[ncell] = the unit's lookups; cbase: slab position of a
+// cell's first lookup): two 2-byte loads + the chunk's start per cell, all independent.  All threads call; ends with a barrier.
+__device__ __forceinline__ int bwd_cells_bounds(const BwdCellUnit& u, const BwdCellsView& V, const uint16_t* __restrict__ lstart,
+                                                uint32_t* cpre, uint32_t* cbase, uint32_t* wtot) {
   const int ncell = u.c1 - u.c0;
-  // the table's first key: read together with the cells' bounds (no round trip of its own)
-  const int ft_dst = feats[u.feat].n_dst;
-  const int cfirst_rel = 0;
-  (void)cfirst_rel;
-  // ---- the cells' bounds: two 2-byte loads per cell, all independent ----
-  uint32_t* const cpre = L.S.pk;          // [ncell + 1] exclusive counts (dead before the sort's exchange buffer is written)
-  uint32_t* const cbase = L.S.ps;         // [ncell] slab position of the cell's first lookup
   if ((int)threadIdx.x < ncell) {
     const int cc = u.c0 + (int)threadIdx.x;
     const uint16_t* lrow = lstart + (size_t)cc * BWD_CELLS_LROW;
     const uint32_t a = lrow[u.b0], b = lrow[u.b1];
-    const BwdCellChunk* cdp = V.chunks + cc;
-    const int64_t cs = cdp->s;  // (independent of the two loads above)
+    const int64_t cs = V.chunks[cc].s;  // (independent of the two loads above)
     cpre[threadIdx.x] = b - a;
     cbase[threadIdx.x] = (uint32_t)cs + a;
   }
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
-  }
   __syncthreads();
-  bwd_block_scan(cpre, ncell, L.S.wtot);
-  const int n = (int)cpre[ncell];
-  const float lr = *opt.lr;
+  bwd_block_scan(cpre, ncell, wtot);
+  return (int)cpre[ncell];
+}
+
+// The ordinary unit from its lookups in registers: sort by (row id, arrival) in LDS, reduction, the split rows' records.  `np`
+// lookups, element r of a lane = arrival position wv * pw + r * 64 + lane (bwd_stage_unit's fused form).
+template <bool ADAM, int FK, int NT, int MAXR>
+__device__ __forceinline__ void bwd_cells_sort_reduce(
+    const BwdCellUnit& u, const BwdCellsView& V, uint32_t (&kreg)[MAXR], uint32_t (&sreg)[MAXR], uint32_t vmask, uint32_t kmin,
+    uint32_t kmax, int np, int ft_dst, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
+    int grad_mode, const BwdOpt& opt, float lr, int max_dim, BwdCellsLds& L, const TzrDst* sG) {
   const TzrTable& tb = u.tb;
-  const int lg = tb.dim >> 2;
-  if (n == 0) {
-    if (u.split > 0 && wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, tzr_zero4(), 0u, lane);
-    return;
-  }
-  if (n > BWD_UMAX) {  // skewed ids
-    if (threadIdx.x == 0) atomicAdd(V.overflow, 1u);
-    bwd_cells_slow_unit<ADAM>(u, V, slab, cpre, cbase, ncell, n, feats, weights, B, grad_mode, opt, max_dim, sG,
-                              reinterpret_cast<float*>(&L.S.L), L.S.smm - 0 + 0 == nullptr ? nullptr : L.S.gstart);
-    return;
-  }
-  // ---- gather + sort by (row id, position) in LDS: bwd_stage_unit's fused form with the cells as the source ----
-  constexpr int kRounds = BWD_UMAX / BWD_THREADS;
-  const int pw = bwd_wave_span(n);
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int pw = bwd_wave_span(np);
   const int rounds = pw / TZR_WAVE;
-  uint32_t kreg[kRounds], sreg[kRounds], dest[kRounds];
-  uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-  for (int r = 0; r < kRounds; ++r) {
-    const int lp = wv * pw + r * TZR_WAVE + lane;
-    const bool in = r < rounds && lp < n;
-    const uint2 v = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(lp < n ? lp : n - 1));  // (clamped, unconditional)
-    kreg[r] = in ? v.x : 0u;
-    sreg[r] = in ? v.y : 0u;
-    if (in) {
-      vmask |= 1u << r;
-      kmin = min(kmin, v.x);
-      kmax = max(kmax, v.x);
-    }
-  }
+  uint32_t dest[MAXR];
   for (int m = TZR_WAVE >> 1; m > 0; m >>= 1) {
     kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, TZR_WAVE));
     kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m, TZR_WAVE));
@@ -491,47 +568,208 @@ __device__ __forceinline__ void bwd_cells_apply_body(
     kmax = max(kmax, L.S.smm[BWD_WAVES + w]);
   }
   __syncthreads();  // smm is reused by the core
-  bwd_sort_core<kRounds>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), true, L.S, dest);
+  if (kmin == kmax) {  // (workgroup-uniform) ONE row -- a slice of a split row, a hot row alone in its unit: arrival order is the order
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) dest[r] = (uint32_t)(wv * pw + r * TZR_WAVE + lane);
+  } else {
+    // grouping by the low bits of the row id wants many distinct rows: a unit of an exact table (a handful of rows, hundreds of
+    // lookups each) would send every lookup to one of a few LDS counters; it takes the counting pass(es) over its few bits
+    bwd_sort_core<MAXR>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), tb.rows > BWD_NB, L.S, dest);
+  }
   __syncthreads();  // the sort's LDS is dead: the unit's arrays take its place
 #pragma unroll
-  for (int r = 0; r < kRounds; ++r)
+  for (int r = 0; r < MAXR; ++r)
     if ((vmask >> r) & 1u) {
       L.U.sK[dest[r] + 1] = kreg[r];
       L.U.sS[dest[r]] = sreg[r];
     }
   if (threadIdx.x == 0) {
-    // a unit owns its rows -- no run continues outside it -- except one slice of a split row: open on both sides, so that
-    // the reduction leaves the slice's whole sum as its leading piece and updates nothing
+    // a unit (a piece) owns its rows -- no run continues outside it -- except one slice of a split row: open on both sides,
+    // so that the reduction leaves the slice's whole sum as its leading piece and updates nothing
     const uint32_t edge = u.split > 0 ? (uint32_t)u.b0 : BWD_SENT;
     L.U.sK[0] = edge;
-    L.U.sK[n + 1] = edge;
+    L.U.sK[np + 1] = edge;
   }
   __syncthreads();
+  CELLS_MARK(3);
   auto tail = [&](unsigned cf, uint32_t okey, const float4& clead, const float4& osum) {  // wave 0
     (void)cf;
     (void)okey;
     (void)osum;
-    if (u.split > 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, clead, (uint32_t)n, lane);
+    if (u.split > 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, clead, (uint32_t)np, lane);
   };
   if constexpr (FK != 0) {
     const bool fast = tb.w_dtype == TZR_DT_F32 && (grad_mode == 1 || (tb.n_feats == 1 && ft_dst == 1));  // (workgroup-uniform)
     if (fast)
-      bwd_reduce_unit<false, NT, FK>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, n, tail);
+      bwd_reduce_unit<false, NT, FK>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, np, tail);
     else
-      bwd_reduce_unit<false, 1, 0>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, n, tail);
+      bwd_reduce_unit<false, 1, 0>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, np, tail);
   } else {
-    bwd_reduce_unit<ADAM, 1, 0>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, n, tail);
+    bwd_reduce_unit<ADAM, 1, 0>(tb, feats, V.feat_by_order, nullptr, nullptr, weights, B, 1, grad_mode, opt, L.U, sG, np, tail);
   }
-  (void)ch;
-  (void)lg;
+}
+
+// Worker workgroups (the last BWD_CELLS_WORKERS of the apply launch's grid): wait until every unit has looked at its size, then
+// take the units that did not fit off the list, piece by piece.  The last worker to finish resets the launch's counters.
+template <bool ADAM>
+__device__ __forceinline__ void bwd_cells_worker(
+    const BwdCellsView& V, int n_units, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
+    int grad_mode, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ lstart,
+    BwdCellsLds& L, const TzrDst* sG, uint32_t* xcell) {
+  __shared__ uint32_t s_item;
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  uint32_t* const ov = V.overflow;
+  {
+    const uint32_t want = tzr_consume_u32(ov + BWD_CELLS_OVF_EPOCH) + 1u;  // (moved only by the last worker of a launch, at its end)
+    const uint32_t* flags = ov + BWD_CELLS_OVF_LIST + n_units;
+    for (int i = threadIdx.x; i < n_units; i += BWD_THREADS)
+      while (tzr_consume_u32(flags + i) != want) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+  const uint32_t len = tzr_consume_u32(ov + BWD_CELLS_OVF_LEN);
+  const float lr = *opt.lr;
+  uint32_t* const cpre = xcell;
+  uint32_t* const cbase = xcell + BWD_CELLS_MAXC + 8;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = len ? atomicAdd(ov + BWD_CELLS_OVF_CURSOR, 1u) : 0u;
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= len) break;
+    const BwdCellUnit u = V.units[tzr_consume_u32(ov + BWD_CELLS_OVF_LIST + item)];
+    const TzrTable& tb = u.tb;
+    const int ncell = u.c1 - u.c0;
+    const int n = bwd_cells_bounds(u, V, lstart, cpre, cbase, L.S.wtot);
+    const int ft_dst = feats[u.feat].n_dst;
+    if (u.split > 0) {  // one slice of ONE row: its sum is the record
+      uint32_t cnt;
+      const float4 sum = bwd_cells_row_sum(u, V, slab, cpre, cbase, ncell, n, (uint32_t)u.b0, feats, weights, B, grad_mode, sG,
+                                           reinterpret_cast<float*>(&L.S.L), L.S.gstart + 264, &cnt);
+      if (wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, sum, cnt, lane);
+      continue;
+    }
+    const uint64_t mult = V.chunks[u.c0].mult;  // (the table's bucket map: the same in all of its chunks)
+    uint32_t cur = (uint32_t)((((uint64_t)u.b0 << 32) + mult - 1) / mult);  // rows of the unit's buckets: [cur, khi)
+    uint64_t khi64 = (((uint64_t)u.b1 << 32) + mult - 1) / mult;
+    if (khi64 > (uint64_t)tb.rows) khi64 = (uint64_t)tb.rows;
+    const uint32_t khi = (uint32_t)khi64;
+    for (;;) {
+      const int np = bwd_cells_next_piece<ADAM>(u, V, slab, cpre, cbase, ncell, n, cur, khi, feats, weights, B, grad_mode, opt, lr, L, sG);
+      if (np == 0) break;
+      constexpr int kRounds = BWD_UMAX / BWD_THREADS;
+      const int pw = bwd_wave_span(np);
+      const int rounds = pw / TZR_WAVE;
+      uint32_t kreg[kRounds], sreg[kRounds];
+      uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+        const int lp = wv * pw + r * TZR_WAVE + lane;
+        const bool in = r < rounds && lp < np;
+        kreg[r] = in ? L.S.pk[lp] : 0u;
+        sreg[r] = in ? L.S.ps[lp] : 0u;
+        if (in) {
+          vmask |= 1u << r;
+          kmin = min(kmin, kreg[r]);
+          kmax = max(kmax, kreg[r]);
+        }
+      }
+      __syncthreads();
+      bwd_cells_sort_reduce<ADAM, 0, 1, kRounds>(u, V, kreg, sreg, vmask, kmin, kmax, np, ft_dst, feats, weights, B, grad_mode, opt, lr,
+                                                 max_dim, L, sG);
+      __syncthreads();  // (waves 1.. left the reduction before wave 0's stitch: everyone is here before the next piece's passes)
+    }
+  }
+  // the launch's counters back to zero by the last worker out (every worker has read `len` and its last cursor value by then)
+  if (threadIdx.x == 0 && tzr_arrive(ov + BWD_CELLS_OVF_DONE) == (uint32_t)BWD_CELLS_WORKERS - 1u) {
+    if (len) atomicAdd(ov + BWD_CELLS_OVF_TOTAL, len);
+    tzr_publish_u32(ov + BWD_CELLS_OVF_LEN, 0u);
+    tzr_publish_u32(ov + BWD_CELLS_OVF_CURSOR, 0u);
+    tzr_publish_u32(ov + BWD_CELLS_OVF_DONE, 0u);
+    tzr_publish_u32(ov + BWD_CELLS_OVF_EPOCH, tzr_consume_u32(ov + BWD_CELLS_OVF_EPOCH) + 1u);  // the next launch's flag value
+  }
+}
+
+template <bool ADAM, int FK, int NT>
+__device__ __forceinline__ void bwd_cells_apply_body(
+    BwdCellsView V, int n_units, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B, int grad_mode,
+    const BwdGrads& G, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ lstart) {
+  __shared__ BwdCellsLds L;
+  __shared__ TzrDst sG[TZR_MAX_DST];
+  __shared__ uint32_t xcell[2 * BWD_CELLS_MAXC + 8];  // the unit's cells: exclusive counts [ncell + 1], slab starts [ncell]
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < TZR_MAX_DST; ++i) sG[i] = G.d[i];  // static indices: straight from kernarg
+  }
+  if ((int)blockIdx.x >= n_units) {  // (workgroup-uniform; nothing of the unit path below is live here)
+    __syncthreads();
+#ifndef CELLS_NO_WORKER  // (timing experiment: the units' code alone; units that do not fit are then simply dropped)
+    bwd_cells_worker<ADAM>(V, n_units, feats, weights, B, grad_mode, opt, max_dim, slab, lstart, L, sG, xcell);
+#endif
+    return;
+  }
+  CELLS_MARK(0);
+  const BwdCellUnit u = V.units[blockIdx.x];
+  const uint32_t epoch = V.overflow[BWD_CELLS_OVF_EPOCH];  // (constant during a launch; loaded with the unit)
+  const int lane = threadIdx.x & (TZR_WAVE - 1);
+  const int wv = threadIdx.x / TZR_WAVE;
+  const int ncell = u.c1 - u.c0;
+  const int ft_dst = feats[u.feat].n_dst;  // the table's first key: read together with the cells' bounds (no round trip of its own)
+  uint32_t* const cpre = xcell;
+  uint32_t* const cbase = xcell + BWD_CELLS_MAXC + 8;
+  const int n = bwd_cells_bounds(u, V, lstart, cpre, cbase, L.S.wtot);
+  const float lr = *opt.lr;
+  CELLS_MARK(1);
+  CELLS_NOTE(9, n);
+  CELLS_NOTE(10, u.split);
+  if (threadIdx.x == 0) {  // "I have looked at my size" (+ my index on the list when it does not fit): what the workers wait for
+    if (n > BWD_UMAX) {
+      const uint32_t at = atomicAdd(V.overflow + BWD_CELLS_OVF_LEN, 1u);
+      tzr_publish_u32(V.overflow + BWD_CELLS_OVF_LIST + at, (uint32_t)blockIdx.x);
+      tzr_drain_stores();
+    }
+    tzr_publish_u32(V.overflow + BWD_CELLS_OVF_LIST + n_units + blockIdx.x, epoch + 1u);  // (a store: nothing waits for it)
+  }
+  if (n > BWD_UMAX) return;  // skewed ids: a worker takes this unit
+  if (n == 0) {
+    if (u.split > 0 && wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, tzr_zero4(), 0u, lane);
+    return;
+  }
+  // ---- gather the cells' lookups into registers (arrival order = chunk-major = lookup-position order inside a row) ----
+  constexpr int kRounds = BWD_UMAX / BWD_THREADS;
+  const int pw = bwd_wave_span(n);
+  const int rounds = pw / TZR_WAVE;
+  uint32_t kreg[kRounds], sreg[kRounds];
+  uint32_t vmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const int lp = wv * pw + r * TZR_WAVE + lane;
+    const bool in = r < rounds && lp < n;
+#ifdef CELLS_EXP_CONTIG  // (timing experiment: the same number of lookups of the same table from ONE contiguous run -- wrong sums)
+    const uint2 v = slab[cbase[0] + (uint32_t)(lp < n ? lp : n - 1)];
+#else
+    const uint2 v = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(lp < n ? lp : n - 1));  // (clamped, unconditional)
+#endif
+    kreg[r] = in ? v.x : 0u;
+    sreg[r] = in ? v.y : 0u;
+    if (in) {
+      vmask |= 1u << r;
+      kmin = min(kmin, v.x);
+      kmax = max(kmax, v.x);
+    }
+  }
+  CELLS_MARK(2);
+  bwd_cells_sort_reduce<ADAM, FK, NT, kRounds>(u, V, kreg, sreg, vmask, kmin, kmax, n, ft_dst, feats, weights, B, grad_mode, opt, lr,
+                                               max_dim, L, sG);
+  CELLS_MARK(8);
 }
 
 #define TZR_CELLS_APPLY_KERNEL(NAME, ADAM_, FK_, ATTR)                                                                         \
-  __global__ __launch_bounds__(BWD_THREADS) ATTR void NAME(BwdCellsView V, const TzrFeature* __restrict__ feats,               \
+  __global__ __launch_bounds__(BWD_THREADS) ATTR void NAME(BwdCellsView V, int n_units, const TzrFeature* __restrict__ feats,  \
                                                           const float* __restrict__ weights, int64_t B, int grad_mode,         \
                                                           BwdGrads G, BwdOpt opt, int max_dim, const uint2* __restrict__ slab, \
-                                                          const uint16_t* __restrict__ lstart, int ch) {                       \
-    bwd_cells_apply_body<ADAM_, FK_, 1>(V, feats, weights, B, grad_mode, G, opt, max_dim, slab, lstart, ch);                   \
+                                                          const uint16_t* __restrict__ lstart) {                               \
+    bwd_cells_apply_body<ADAM_, FK_, 1>(V, n_units, feats, weights, B, grad_mode, G, opt, max_dim, slab, lstart);              \
   }
 TZR_CELLS_APPLY_KERNEL(tzr_bwd_cells_apply_adagrad_kernel, false, TZR_OPT_ADAGRAD, TZR_WAVES_PER_EU(7))
 TZR_CELLS_APPLY_KERNEL(tzr_bwd_cells_apply_rowwise_kernel, false, TZR_OPT_ROWWISE_ADAGRAD, TZR_WAVES_PER_EU(7))
@@ -621,8 +859,8 @@ extern "C" int tzr_pooled_bwd_cells_apply(const TzrTable* d_tables, const TzrFea
   opt.adam = reinterpret_cast<const float*>(h_optim->d_adam);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define TZR_CELLS_LAUNCH(K)                                                                                               \
-  hipLaunchKernelGGL(K, dim3((unsigned)g.n_units), dim3(BWD_THREADS), 0, s, V, d_feats, d_weights, B, grad_mode, G, opt, max_dim, \
-                     (const uint2*)P.ks[1], (const uint16_t*)reinterpret_cast<uint16_t*>(P.hist), (int)g.ch)
+  hipLaunchKernelGGL(K, dim3((unsigned)g.n_units + BWD_CELLS_WORKERS), dim3(BWD_THREADS), 0, s, V, (int)g.n_units, d_feats, d_weights, \
+                     B, grad_mode, G, opt, max_dim, (const uint2*)P.ks[1], (const uint16_t*)reinterpret_cast<uint16_t*>(P.hist))
   const bool fast_shape = !d_weights && (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ROWWISE_ADAGRAD || opt.kind == TZR_OPT_SGD);
   if (opt.kind == TZR_OPT_ADAM) {
     TZR_CELLS_LAUNCH(tzr_bwd_cells_apply_adam_kernel);

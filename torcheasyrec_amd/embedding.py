@@ -17,7 +17,9 @@ KeyedTensor`` with keys in table-then-feature order).  Differences by design:
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -199,7 +201,29 @@ class _Meta:
         self.tables_np = self.feats_np = self.slots_np = None
         self.d_tables = self.d_feats = self.d_slots = None
         self.d_bwd_tables = self.d_bwd_feats = None
+        self.bwd_tables_np = self.bwd_feats_np = None  # host copies of the backward descriptors (cells geometry)
         self.n_keys = 0
+        self.cells: Dict[int, Optional["_CellsGeo"]] = {}  # batch size -> geometry of the one-launch plan (None: not a case for it)
+
+
+class _CellsGeo:
+    """The geometry buffer of the cells plan for one (descriptor set, batch size): host image + device copy (the kernels write
+    its tail), and the host's view of its overflow word (include/tzrec_hip.h: tzr_bwd_cells_geometry)."""
+
+    def __init__(self, image: np.ndarray, info, device: torch.device) -> None:
+        self.h_img = image                       # uint8, kept: the launchers read the header from it
+        self.h_ptr = image.ctypes.data
+        self.n_chunks, self.n_units = int(info[1]), int(info[2])
+        self.d_img = _lib.workspace(image.nbytes, device)[:image.nbytes]
+        self.d_img.copy_(torch.from_numpy(image))
+        off = int(info[6])
+        self.d_overflow = self.d_img[off:off + 4].view(torch.int32)
+        pin = device.type == "cuda"
+        self.h_overflow = torch.zeros(1, dtype=torch.int32, pin_memory=pin)
+        self.seen = 0          # overflow count already acted on
+        self.copied = None     # event behind the last queued copy of the word
+        self.launches = 0
+        self.demoted = False
 
 
 def mask_frozen_descriptors(tables: np.ndarray, feats: np.ndarray, frozen: Sequence[bool]):
@@ -305,6 +329,54 @@ class EmbeddingBagCollection(nn.Module):
         # default id): the one-launch backward then lets all of a table's workgroups sum such a row (TZR_GRAD_HOT_ROWS,
         # include/tzrec_hip.h); zch.ManagedCollisionEmbeddingBagCollection sets it
         self.expect_hot_rows = False
+        # Which index plan a batch of one id per bag takes (batches with jagged bags always take the exact one):
+        #   "exact"  tzr_pooled_bwd_plan: four launches, any id distribution at full speed (heavy buckets, hot rows);
+        #   "cells"  tzr_pooled_bwd_cells_plan: ONE launch; unit sizes are expectations for evenly drawn ids, a unit that holds
+        #            more is still right but slow, and counted;
+        #   "auto"   cells until that count moves -- the library's overflow word, copied to the host behind every apply and
+        #            looked at before the next plan (the first CELLS_PROBATION batches wait for it: a skewed id distribution
+        #            is found out before anything is captured into a hipGraph) -- then exact for good.
+        self.plan_mode = os.environ.get("TZR_BWD_PLAN", "auto")
+        if self.plan_mode not in ("auto", "cells", "exact"):
+            raise ValueError("TZR_BWD_PLAN: auto | cells | exact")
+
+    CELLS_PROBATION = 4
+
+    def _cells_geometry(self, meta: _Meta, B: int) -> Optional[_CellsGeo]:
+        if B in meta.cells:
+            return meta.cells[B]
+        L = _lib.lib()
+        _, max_dim = self._bwd_dims()
+        info = (C.c_int64 * 8)()
+        tp, fp = meta.bwd_tables_np.ctypes.data, meta.bwd_feats_np.ctypes.data
+        rc = L.tzr_bwd_cells_geometry(tp, len(self._configs), fp, len(self._lookups), B, max_dim, None, 0, info)
+        geo = None
+        if rc == _lib.TZR_OK:
+            img = np.zeros(int(info[0]), dtype=np.uint8)
+            _lib.check(L.tzr_bwd_cells_geometry(tp, len(self._configs), fp, len(self._lookups), B, max_dim, img.ctypes.data, img.nbytes,
+                                                info), "tzr_bwd_cells_geometry")
+            geo = _CellsGeo(img, info, self._device)
+        elif rc != -4:  # (TZR_ERR_UNSUPPORTED: simply not a case for the cells plan)
+            _lib.check(rc, "tzr_bwd_cells_geometry")
+        meta.cells[B] = geo
+        return geo
+
+    def _cells_for(self, kjt: KeyedJaggedTensor, meta: _Meta) -> Optional[_CellsGeo]:
+        """the geometry of the one-launch plan when this batch takes it, else None"""
+        if self.plan_mode == "exact" or kjt.uniform_length() != 1 or kjt.weights_or_none() is not None:
+            return None
+        geo = self._cells_geometry(meta, kjt.stride())
+        if geo is None or self.plan_mode == "cells":
+            return geo
+        if geo.demoted:
+            return None
+        capturing = self._device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if geo.copied is not None and geo.launches <= self.CELLS_PROBATION and not capturing:
+            geo.copied.synchronize()  # (the first batches: know before deciding; later the word is read as it lies)
+        if int(geo.h_overflow[0]) != geo.seen:
+            geo.demoted = True  # units overflowed: ids this skewed belong on the exact plan (heavy buckets, hot rows)
+            return None
+        return geo
 
     # -- storage ---------------------------------------------------------------------------
     def _allocate(self) -> None:
@@ -431,8 +503,10 @@ class EmbeddingBagCollection(nn.Module):
         # last), so the plan sorts nothing for them and the optimizer never touches their rows
         frozen = [not cfg.trainable for cfg in self._configs]
         meta.d_bwd_tables, meta.d_bwd_feats = meta.d_tables, meta.d_feats
+        meta.bwd_tables_np, meta.bwd_feats_np = tables, feats
         if any(frozen):
             bt, bf = mask_frozen_descriptors(tables, feats, frozen)
+            meta.bwd_tables_np, meta.bwd_feats_np = bt, bf
             meta.d_bwd_tables = _lib.upload_struct(bt, self._device)
             meta.d_bwd_feats = _lib.upload_struct(bf, self._device)
         meta.d_slots = _lib.upload_struct(meta.slots_np, self._device)
@@ -521,18 +595,24 @@ class EmbeddingBagCollection(nn.Module):
         NP = self._n_positions(kjt)
         nbytes = L.tzr_pooled_bwd_workspace(N, NP, len(self._lookups), len(self._configs), B, max_dim)
         ws = _lib.workspace(nbytes, self._device)
+        geo = self._cells_for(kjt, meta)
         ev = self._timers.start("plan") if self._timers is not None else None
-        rc = L.tzr_pooled_bwd_plan(
-            _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups),
-            meta.n_keys, max_rows, max_dim, _lib.ptr(kjt.values()), _lib.ptr(offsets), N, NP, B,
-            1 if uniform else 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
-        )
+        if geo is not None:
+            rc = L.tzr_pooled_bwd_cells_plan(
+                _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), max_dim,
+                _lib.ptr(kjt.values()), N, B, geo.h_ptr, _lib.ptr(geo.d_img), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device))
+        else:
+            rc = L.tzr_pooled_bwd_plan(
+                _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups),
+                meta.n_keys, max_rows, max_dim, _lib.ptr(kjt.values()), _lib.ptr(offsets), N, NP, B,
+                1 if uniform else 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device),
+            )
         if ev is not None:
             ev.record()
-        _lib.check(rc, "tzr_pooled_bwd_plan")
+        _lib.check(rc, "tzr_pooled_bwd_cells_plan" if geo is not None else "tzr_pooled_bwd_plan")
         if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
             ws.record_stream(torch.cuda.current_stream(self._device))
-        kjt._tzr_plan = (id(self), dst_names, ws, None)  # type: ignore[attr-defined]
+        kjt._tzr_plan = (id(self), dst_names, ws, None, geo)  # type: ignore[attr-defined]
         return ws
 
     def plan_backward_async(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> None:
@@ -554,23 +634,25 @@ class EmbeddingBagCollection(nn.Module):
             for t in (kjt.values(), kjt.offsets_or_none()):
                 if t is not None:
                     t.record_stream(self._side_stream)
-        kjt._tzr_plan = (id(self), dst_names, ws, ev)  # type: ignore[attr-defined]
+        kjt._tzr_plan = (id(self), dst_names, ws, ev, kjt._tzr_plan[4])  # type: ignore[attr-defined]
 
     def _launch_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], grads) -> None:
         if self.fused_optimizer is None:
             return  # frozen tables
         direct = self.backward_is_direct(kjt)
         cached = getattr(kjt, "_tzr_plan", None)
+        geo = None
         if direct:
             ws = None
         elif cached is not None and cached[0] == id(self) and cached[1] == dst_names:
-            ws = cached[2]
+            ws, geo = cached[2], cached[4]
             if cached[3] is not None:
                 torch.cuda.current_stream(self._device).wait_event(cached[3])
                 if not torch.cuda.is_current_stream_capturing():
                     ws.record_stream(torch.cuda.current_stream(self._device))
         else:
             ws = self.plan_backward(kjt, dst_names)
+            geo = kjt._tzr_plan[4]  # type: ignore[attr-defined]
         layout = self._layout_for(dst_names)
         meta = self._meta(kjt.keys(), layout)
         B, N = kjt.stride(), kjt.values().numel()
@@ -599,6 +681,10 @@ class EmbeddingBagCollection(nn.Module):
                 _lib.ptr(kjt.values()), _lib.ptr(offsets), _lib.ptr(kjt.weights_or_none()), N, self._n_positions(kjt), B,
                 1 if uniform else 0, _lib.GRAD_HOT_ROWS if self.expect_hot_rows else 0, gd, len(gl), opt, _lib.ptr(dws), dws.numel(),
                 _lib.stream_ptr(self._device))
+        elif geo is not None:
+            rc = _lib.lib().tzr_pooled_bwd_cells_apply(
+                _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs), max_dim, None, N, B, 0,
+                gd, len(gl), opt, geo.h_ptr, _lib.ptr(geo.d_img), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device))
         else:
             rc = _lib.lib().tzr_pooled_bwd_apply(
                 _lib.ptr(meta.d_bwd_tables), _lib.ptr(meta.d_bwd_feats), len(self._lookups), len(self._configs),
@@ -608,7 +694,14 @@ class EmbeddingBagCollection(nn.Module):
             )
         if ev is not None:
             ev.record()
-        _lib.check(rc, "tzr_pooled_bwd_direct" if direct else "tzr_pooled_bwd_apply")
+        _lib.check(rc, "tzr_pooled_bwd_direct" if direct else ("tzr_pooled_bwd_cells_apply" if geo is not None else "tzr_pooled_bwd_apply"))
+        if geo is not None and self.plan_mode == "auto":
+            # the overflow word follows the apply to the host (8 bytes, no wait): `_cells_for` looks at it before the next plan
+            geo.launches += 1
+            geo.h_overflow.copy_(geo.d_overflow, non_blocking=True)
+            if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                geo.copied = torch.cuda.Event()
+                geo.copied.record(torch.cuda.current_stream(self._device))
         kjt._tzr_plan = None  # type: ignore[attr-defined]
 
     def register_post_lookup_tracker_fn(self, fn) -> None:
