@@ -19,6 +19,7 @@ modes
 """
 import os
 import sys
+os.environ.setdefault("TZR_BWD_PLAN", "exact")  # (these scripts inspect the four-launch plan)
 import time
 
 import numpy as np

@@ -42,13 +42,17 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
                     "tzr_bwd_reduce_kernel")  # the apply's instantiation for the run's optimizer (round 5: the fast tile loop)
     six = [fwd_name, "tzr_bwd_hist_kernel", "tzr_bwd_scan_kernel", "tzr_bwd_scatter_kernel",
            "tzr_bwd_sort_kernel", red_name]
+    # round 6: batches of one id per bag take the one-launch index plan (csrc/pooled_bwd_cells.hip): THREE launches in all
+    cells_apply = next((k for k in ks if k.startswith("tzr_bwd_cells_apply_")), None)
+    if "tzr_bwd_cells_partition_kernel" in ks and cells_apply:
+        six = [fwd_name, "tzr_bwd_cells_partition_kernel", cells_apply]
     if all(k in ks for k in six):
         agg = 0.0
         for k in six:
             e = ks[k]
             agg += e.get("traffic_corrected") or ((e["FETCH_SIZE"] or 0.0) + (e["WRITE_SIZE"] or 0.0))
         ks["__embedding_fwd_bwd__"] = {"traffic_corrected": agg, "kernels": six,
-                                       "note": "forward corrected as above; the other five at FETCH_SIZE + WRITE_SIZE as counted "
+                                       "note": "forward corrected as above; the others at FETCH_SIZE + WRITE_SIZE as counted "
                                                "(64-B row gathers are exact; the 8-B key/source streams of the plan are uncalibrated)"}
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from torcheasyrec_amd import _build  # the digest of the kernel sources these counters were measured on

@@ -6,6 +6,7 @@ closed form; every iteration is checked on the device against index_add in fp64.
     python scripts/zipf_debug.py [iterations] [bwd_debug ...]"""
 import os
 import sys
+os.environ.setdefault("TZR_BWD_PLAN", "exact")  # (these scripts inspect the four-launch plan)
 
 import numpy as np
 import torch

@@ -18,12 +18,13 @@ from torcheasyrec_amd.sparse import KeyedJaggedTensor  # noqa: E402
 
 
 @pytest.fixture(autouse=True)
-def _planned_backward(dev):
+def _planned_backward(dev, monkeypatch):
     """these tests inspect the index plan: batches this small would otherwise take the plan-less one-launch backward, and a fused
     plan leaves the units without heavy lookups to the apply's own LDS sort (ks[0] would be incomplete: bwd_no_fuse_sort)"""
     from torcheasyrec_amd import _lib
 
     assert _lib.lib().tzr_tune(b"bwd_direct", -1) == 0 and _lib.lib().tzr_tune(b"bwd_no_fuse_sort", 1) == 0
+    monkeypatch.setenv("TZR_BWD_PLAN", "exact")  # (the four-launch plan is the object inspected here; the one-launch plan: tests/test_cells_plan.py)
     yield
     _lib.lib().tzr_tune(b"bwd_direct", 0)
     _lib.lib().tzr_tune(b"bwd_no_fuse_sort", 0)

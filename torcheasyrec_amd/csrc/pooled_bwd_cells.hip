@@ -36,6 +36,10 @@ extern "C" int tzr_cells_prof_dump(uint64_t* h_out, int n_wg) {
 // ------------------------------------------------------------------------------------------------------------------------
 // geometry (host)
 // ------------------------------------------------------------------------------------------------------------------------
+// (Measured and dropped in round 6 -- profiles/r06g, r06h: rows of small tables summed in streaming passes instead of gathered and
+// sorted, and units sized by expected traffic under a budget of resident workgroups (more, smaller units for the 40 M-row tables):
+// 92.6 - 100.9 us against 88 -- the tile loops run at the memory system's rate for the launch's TOTAL traffic whatever the
+// partition, smaller units only add staging, and the streaming code cost the gathered units' path registers.)
 namespace {
 
 struct HostGeo {
@@ -44,6 +48,7 @@ struct HostGeo {
   std::vector<BwdCellUnit> units;
   std::vector<uint32_t> fstart;
   std::vector<int32_t> fkey, fbo;
+  std::vector<uint16_t> bnd;  // boundary list: bucket numbers, table after table
 };
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
@@ -88,30 +93,103 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
   if (N == 0) return TZR_ERR_UNSUPPORTED;
   const int ch = bwd_pick_ch(N);
   int64_t n_chunks = 0;
-  std::vector<int64_t> cfirst(T + 1, 0);
+  std::vector<int64_t> cfirst(T + 1, 0), nt(T, 0);
   for (int t = 0; t < T; ++t) {
     const TzrTable& tb = tabs[t];
     if (tb.n_feats < 0 || (tb.n_feats > 0 && (tb.first_order < 0 || tb.first_order + tb.n_feats > F))) return TZR_ERR_INVALID;
     const int64_t n = tb.n_feats > 0 ? (int64_t)H.fstart[tb.first_order + tb.n_feats] - (int64_t)H.fstart[tb.first_order] : 0;
     const int64_t C = (n + ch - 1) / ch;
     if (C > BWD_CELLS_MAXC) return TZR_ERR_UNSUPPORTED;
+    if (n > 0 && (tb.rows <= 0 || tb.rows > (1LL << 32))) return TZR_ERR_UNSUPPORTED;
+    nt[t] = n;
     cfirst[t] = n_chunks;
     n_chunks += C;
   }
   cfirst[T] = n_chunks;
   if (n_chunks > bwd_max_chunks(N, T, ch)) return TZR_ERR_UNSUPPORTED;
+
+  // ---- units of a bucketed table: ranges of whole buckets, ceil(512 / U) of them at most -- the smallest U whose largest range
+  // still expects <= target lookups (evenly drawn ids: 6 standard deviations under the LDS capacity) ----
+  const int64_t target = BWD_CELLS_TARGET;
+  std::vector<int64_t> U(T, 0);
+  for (int t = 0; t < T; ++t) {
+    if (nt[t] == 0 || tabs[t].rows <= BWD_NB) continue;
+    const int64_t per = (target * BWD_NB) / nt[t];  // buckets a unit may hold
+    if (per < 1) return TZR_ERR_UNSUPPORTED;        // (one bucket already expects more than a unit: the table is too big for this batch size)
+    U[t] = (BWD_NB + per - 1) / per;
+  }
+
   int64_t n_recs = 0, n_counters = 0;
   for (int t = 0; t < T; ++t) {
     const TzrTable& tb = tabs[t];
     const int64_t C = cfirst[t + 1] - cfirst[t];
     if (C == 0) continue;
-    if (tb.rows <= 0 || tb.rows > (1LL << 32)) return TZR_ERR_UNSUPPORTED;
     const int64_t ts = H.fstart[tb.first_order], te = H.fstart[tb.first_order + tb.n_feats];
     const int64_t n = te - ts;
     int nb;
     uint64_t mult;
     bucket_params_host(tb.rows, &nb, &mult);
     const int64_t fbase = tb.n_feats == 1 ? (int64_t)H.fkey[tb.first_order] * B : -1;
+    const int32_t bnd0 = (int32_t)H.bnd.size();
+    BwdCellUnit u;
+    std::memset(&u, 0, sizeof(u));
+    u.tb = tb;
+    u.feat = H.fbo[tb.first_order];
+    u.ts = (uint32_t)ts;
+    u.rec = u.rec0 = u.counter = -1;
+    u.crel0 = 0;
+    u.ncell = (int32_t)C;
+    if (tb.rows > BWD_NB) {
+      // bucketed table: U units, each a range of the 512 buckets over all chunks
+      const int64_t Ut = U[t];
+      for (int64_t j = 0; j <= Ut; ++j) H.bnd.push_back((uint16_t)(j * nb / Ut));
+      for (int64_t j = 0; j < Ut; ++j) {
+        u.b0 = (int32_t)(j * nb / Ut);
+        u.i0 = bnd0 + (int32_t)j;
+        u.i1 = u.i0 + 1;
+        H.units.push_back(u);
+      }
+    } else {
+      const int64_t e = (n + tb.rows - 1) / tb.rows;
+      if (e > target) {
+        // gathered units of ONE row each, the row split over K chunk ranges: every row is a boundary
+        for (int64_t r = 0; r <= tb.rows; ++r) H.bnd.push_back((uint16_t)r);
+        const int64_t m = std::max<int64_t>(1, (target * tb.rows * C) / n);
+        const int64_t K = std::min<int64_t>(C, (C + m - 1) / m);
+        for (int64_t r = 0; r < tb.rows; ++r) {
+          for (int64_t k = 0; k < K; ++k) {
+            u.crel0 = (int32_t)(k * C / K);
+            u.ncell = (int32_t)((k + 1) * C / K) - u.crel0;
+            u.b0 = (int32_t)r;
+            u.nrows = 0;
+            u.i0 = bnd0 + (int32_t)r;
+            u.i1 = u.i0 + 1;
+            u.split = K > 1 ? (int32_t)K : 0;
+            u.rec = K > 1 ? (int32_t)(n_recs + k) : -1;
+            u.rec0 = K > 1 ? (int32_t)n_recs : -1;
+            u.counter = K > 1 ? (int32_t)n_counters : -1;
+            H.units.push_back(u);
+          }
+          if (K > 1) {
+            n_recs += K;
+            n_counters += 1;
+          }
+        }
+      } else {
+        // few lookups per row: whole rows grouped up to the target, gathered and sorted like a bucket range
+        const int64_t rpu = std::max<int64_t>(1, (target * tb.rows) / n);
+        int32_t g = 0;
+        for (int64_t r = 0; r < tb.rows; r += rpu, ++g) {
+          H.bnd.push_back((uint16_t)r);
+          u.b0 = (int32_t)r;
+          u.i0 = bnd0 + g;
+          u.i1 = u.i0 + 1;
+          H.units.push_back(u);
+        }
+        H.bnd.push_back((uint16_t)tb.rows);
+      }
+    }
+    const int32_t nbnd = (int32_t)H.bnd.size() - bnd0;
     for (int64_t c = 0; c < C; ++c) {
       BwdCellChunk cd;
       std::memset(&cd, 0, sizeof(cd));
@@ -123,69 +201,9 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
       cd.mult = mult;
       cd.rows = tb.rows;
       cd.fbase = fbase;
+      cd.bnd0 = bnd0;
+      cd.nbnd = nbnd;
       H.chunks.push_back(cd);
-    }
-    // Expected lookups of a unit of an exact table (rows grouped / a row split): at most BWD_CELLS_TARGET -- 6 standard deviations
-    // (sqrt(n p)) below the LDS capacity, so that evenly drawn ids practically never overflow a unit -- and as close to it as whole
-    // rows allow: every unit is a workgroup, and the apply wants its whole grid resident (1 792 slots at 7 waves per SIMD;
-    // DLRM-Criteo at 65 536: 1 737 units)
-    const int64_t target = BWD_CELLS_TARGET;
-    BwdCellUnit u;
-    std::memset(&u, 0, sizeof(u));
-    u.tb = tb;
-    u.t = t;
-    u.feat = H.fbo[tb.first_order];
-    u.ts = ts;
-    u.rec = u.rec0 = u.counter = -1;
-    const int c_lo = (int)cfirst[t], c_hi = (int)cfirst[t + 1];
-    if (tb.rows > BWD_NB) {
-      // bucketed table: C units, each a range of the 512 buckets over all chunks (C <= BWD_CELLS_MAXC <= BWD_NB)
-      const int64_t U = C;
-      for (int64_t j = 0; j < U; ++j) {
-        u.c0 = c_lo;
-        u.c1 = c_hi;
-        u.b0 = (int32_t)(j * nb / U);
-        u.b1 = (int32_t)((j + 1) * nb / U);
-        u.split = 0;
-        if (u.b1 > u.b0) H.units.push_back(u);
-      }
-    } else if (n <= target * tb.rows) {
-      // a bucket is a row; expected lookups per row <= the target: whole rows grouped up to it, over all chunks
-      const int64_t rpu = std::max<int64_t>(1, (target * tb.rows) / n);
-      for (int64_t r = 0; r < tb.rows; r += rpu) {
-        u.c0 = c_lo;
-        u.c1 = c_hi;
-        u.b0 = (int32_t)r;
-        u.b1 = (int32_t)std::min<int64_t>(tb.rows, r + rpu);
-        u.split = 0;
-        H.units.push_back(u);
-      }
-    } else {
-      // fewer rows than chunks' worth of lookups: a row is SPLIT over K chunk ranges, partial sums combined by the last to arrive
-      // (whole chunks: m = the most chunks whose expected share of one row stays within the target, K = ceil(C / m) slices of
-      // floor / ceil(C / K) <= m chunks)
-      const int64_t m = std::max<int64_t>(1, (target * tb.rows * C) / n);
-      const int64_t K = std::min<int64_t>(C, (C + m - 1) / m);
-      for (int64_t r = 0; r < tb.rows; ++r) {
-        for (int64_t k = 0; k < K; ++k) {
-          u.c0 = c_lo + (int32_t)(k * C / K);
-          u.c1 = c_lo + (int32_t)((k + 1) * C / K);
-          u.b0 = (int32_t)r;
-          u.b1 = (int32_t)r + 1;
-          u.split = K > 1 ? (int32_t)K : 0;
-          if (K > 1) {
-            u.rec = (int32_t)(n_recs + k);
-            u.rec0 = (int32_t)n_recs;
-            u.counter = (int32_t)n_counters;
-          }
-          H.units.push_back(u);
-        }
-        if (K > 1) {
-          n_recs += K;
-          n_counters += 1;
-        }
-        u.rec = u.rec0 = u.counter = -1;
-      }
     }
   }
   BwdCellsGeo& g = H.g;
@@ -198,6 +216,9 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
   g.max_dim = max_dim;
   g.ch = ch;
   g.n_positions = N;
+  g.n_bnd = (int64_t)H.bnd.size();
+  // (the boundary table lives in the plan's histogram area: max_chunks rows of BWD_NB uint32)
+  if (g.n_bnd * BWD_CELLS_MAXC * 2 > bwd_max_chunks(N, T, ch) * (int64_t)BWD_NB * 4) return TZR_ERR_UNSUPPORTED;
   int64_t off = align256(sizeof(BwdCellsGeo));
   g.off_chunks = off;
   off = align256(off + n_chunks * (int64_t)sizeof(BwdCellChunk));
@@ -209,6 +230,8 @@ int build_geometry(const TzrTable* tabs, int T, const TzrFeature* feats, int F, 
   off = align256(off + F * 4);
   g.off_fbo = off;
   off = align256(off + F * 4);
+  g.off_bnd = off;
+  off = align256(off + g.n_bnd * 2);
   g.off_recs = off;
   off = align256(off + std::max<int64_t>(1, n_recs) * max_dim * 4);
   g.off_rcount = off;
@@ -252,6 +275,7 @@ extern "C" int tzr_bwd_cells_geometry(const TzrTable* h_tables, int n_tables, co
   std::memcpy(b + g.off_fstart, H.fstart.data(), H.fstart.size() * 4);
   std::memcpy(b + g.off_fkey, H.fkey.data(), H.fkey.size() * 4);
   std::memcpy(b + g.off_fbo, H.fbo.data(), H.fbo.size() * 4);
+  std::memcpy(b + g.off_bnd, H.bnd.data(), H.bnd.size() * 2);
   return TZR_OK;
 }
 
@@ -259,7 +283,7 @@ extern "C" int tzr_bwd_cells_geometry(const TzrTable* h_tables, int n_tables, co
 // partition: every chunk ordered by bucket in place + its bucket starts.  No workgroup talks to another.
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
-    BwdCellsView V, const TzrTable* __restrict__ tables, BwdSrcArgs A, uint2* __restrict__ slab, uint16_t* __restrict__ lstart) {
+    BwdCellsView V, const TzrTable* __restrict__ tables, BwdSrcArgs A, uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch) {
   __shared__ BwdRankLds<BWD_NB> L;
   __shared__ uint2 stage[BWD_CH];
   const BwdCellChunk cd = V.chunks[blockIdx.x];
@@ -307,9 +331,13 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
 #pragma unroll
   for (int r = 0; r < kRounds; ++r)
     if ((vmask >> r) & 1u) stage[dest[r]] = make_uint2(kreg[r], sreg[r]);
-  // the chunk's bucket starts (digits at or above nb hold nothing: their start is n)
-  uint16_t* lrow = lstart + (size_t)blockIdx.x * BWD_CELLS_LROW;
-  for (int d = threadIdx.x; d <= BWD_NB; d += BWD_THREADS) lrow[d] = L.lstart[d];
+  // this chunk's column of the boundary table: where each unit boundary of the table (a bucket number) starts inside the chunk
+  // (buckets at or above nb hold nothing: their start is n)
+  {
+    const int col = (int)((cd.s - cd.ts) / (cd.e > cd.s ? (int64_t)ch : 1));
+    for (int i = threadIdx.x; i < cd.nbnd; i += BWD_THREADS)
+      bnd[(size_t)(cd.bnd0 + i) * BWD_CELLS_MAXC + col] = L.lstart[V.bnd_bucket[cd.bnd0 + i]];
+  }
   __syncthreads();
   uint2* out = slab + cd.s;
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) out[i] = stage[i];  // one coalesced 8-byte store per lookup
@@ -375,13 +403,19 @@ __device__ __forceinline__ void bwd_cells_combine(const BwdCellUnit& u, const Bw
   if (cnt) bwd_apply_row_wave<ADAM>(u.tb, opt, lr, (uint32_t)u.b0, tot, lane);  // (a row nobody looked up is not touched)
 }
 
-// Sum of the gradient rows of the unit's lookups of ONE row, in lookup order: lane group q takes lookups q, q + G, q + 2 G, ...
-// in order, the groups' sums are added in group order -- a function of the ids alone.  All threads call; the result (and the
-// number of lookups) in wave 0, lanes < dim / 4.  `red`: 4 KB of LDS, `sm`: 2 * BWD_WAVES + 64 words.
-__device__ __forceinline__ float4 bwd_cells_row_sum(
+// Sum of the gradient rows of the lookups of ONE row held by the cells in LDS (cpre / cbase, n lookups; `row`: only lookups of
+// that row count -- pass BWD_SENT when the cells hold nothing else), in lookup order: lane group q takes lookups q, q + G,
+// q + 2 G, ... in order (UF of them in flight together: their {row, position} pairs first, then their gradient rows), the groups'
+// sums are added in group order -- a function of the ids alone.  All threads call; the result (and the number of lookups) in
+// wave 0, lanes < dim / 4.  `red`: 4 KB of LDS, `sm`: 2 * BWD_WAVES + 64 words.
+// FAST (compile time): the table is fp32-gradient "one key, one buffer" (bwd_reduce_unit's FK != 0 case): the gradient row of
+// lookup position i is fgp + (i - fkb) * fgs -- no descriptor walk, no branch around a load.
+template <bool FAST>
+__device__ __forceinline__ float4 bwd_cells_stream_row(
     const BwdCellUnit& u, const BwdCellsView& V, const uint2* __restrict__ slab, const uint32_t* cpre, const uint32_t* cbase,
     int ncell, int n, uint32_t row, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
     int grad_mode, const TzrDst* sG, float* red, uint32_t* sm, uint32_t* count_out) {
+  constexpr int UF = 4;
   const TzrTable& tb = u.tb;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
@@ -391,17 +425,40 @@ __device__ __forceinline__ float4 bwd_cells_row_sum(
   const int groups = gw * BWD_WAVES, q = wv * gw + gi;
   const bool single = tb.n_feats == 1;
   const BwdSrc one = bwd_resolve(feats + V.feat_by_order[tb.first_order], sG);
+  const float* const fgp = grad_mode == 1 ? reinterpret_cast<const float*>(sG[0].ptr) : one.gp0;
+  const int64_t fgs = grad_mode == 1 ? sG[0].stride : one.gs0;
+  const uint32_t fkb = grad_mode == 0 ? (uint32_t)feats[V.feat_by_order[tb.first_order]].key * (uint32_t)B : 0u;
   float4 acc = tzr_zero4();
   uint32_t cnt = 0;
-  const int trips = (n + groups - 1) / groups;
+  const int trips = (n + groups * UF - 1) / (groups * UF);
+  // the {row, position} pairs of a trip are fetched a trip AHEAD of their gradient rows: one round trip per trip, not two
+  uint2 e[UF];
+#pragma unroll
+  for (int k = 0; k < UF; ++k) {
+    const int i = k * groups + q;
+    e[k] = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));  // (clamped, unconditional)
+  }
   for (int j = 0; j < trips; ++j) {
-    const int i = j * groups + q;
-    const bool valid = lane_on && i < n;
-    const uint2 e = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));
-    if (valid && e.x == row) {
-      acc = tzr_add4(acc, bwd_lookup_grad(feats, tb, V.feat_by_order, sG, one, single, grad_mode, nullptr, weights, nullptr, B, 1,
-                                          e.y, c));
-      cnt += 1;
+    float4 g[UF];
+#pragma unroll
+    for (int k = 0; k < UF; ++k) {
+      if constexpr (FAST) g[k] = tzr_ldg4(fgp + (int64_t)(e[k].y - fkb) * fgs + 4 * c);
+      else g[k] = bwd_lookup_grad(feats, tb, V.feat_by_order, sG, one, single, grad_mode, nullptr, weights, nullptr, B, 1, e[k].y, c);
+    }
+    uint2 en[UF];
+#pragma unroll
+    for (int k = 0; k < UF; ++k) {
+      const int i = ((j + 1) * UF + k) * groups + q;
+      en[k] = bwd_cells_elem(slab, cpre, cbase, ncell, (uint32_t)(i < n ? i : n - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < UF; ++k) {
+      const int i = (j * UF + k) * groups + q;
+      if (lane_on && i < n && (row == BWD_SENT || e[k].x == row)) {
+        acc = tzr_add4(acc, g[k]);
+        cnt += 1;
+      }
+      e[k] = en[k];
     }
   }
   __syncthreads();  // (red / sm may still be read from an earlier call)
@@ -414,12 +471,12 @@ __device__ __forceinline__ float4 bwd_cells_row_sum(
   float4 tot = tzr_zero4();
   uint32_t ct = 0;
   if (wv == 0) {
-    for (int g = 0; g < groups; ++g) {
+    for (int g2 = 0; g2 < groups; ++g2) {
       if (lane < lg) {
-        const float* r = red + (size_t)(g * lg + lane) * 4;
+        const float* r = red + (size_t)(g2 * lg + lane) * 4;
         tot = tzr_add4(tot, make_float4(r[0], r[1], r[2], r[3]));
       }
-      ct += sm[2 * BWD_WAVES + g];
+      ct += sm[2 * BWD_WAVES + g2];
     }
   }
   *count_out = ct;
@@ -511,7 +568,7 @@ __device__ __forceinline__ int bwd_cells_next_piece(
       const uint32_t end0 = min(lim, cur + (uint32_t)((((uint64_t)1 << 32) + m2 - 1) / m2));
       if (end0 - cur <= 1u) {  // one row with more lookups than a unit: streamed
         uint32_t cnt;
-        const float4 sum = bwd_cells_row_sum(u, V, slab, cpre, cbase, ncell, n, cur, feats, weights, B, grad_mode, sG, red, sm, &cnt);
+        const float4 sum = bwd_cells_stream_row<false>(u, V, slab, cpre, cbase, ncell, n, cur, feats, weights, B, grad_mode, sG, red, sm, &cnt);
         if (wv == 0 && cnt) bwd_apply_row_wave<ADAM>(tb, opt, lr, cur, sum, lane);
         cur += 1;
         break;
@@ -522,18 +579,17 @@ __device__ __forceinline__ int bwd_cells_next_piece(
   return 0;
 }
 
-// The bounds of unit u's cells into LDS (cpre: exclusive counts, cpre[ncell] = the unit's lookups; cbase: slab position of a
-// cell's first lookup): two 2-byte loads + the chunk's start per cell, all independent.  All threads call; ends with a barrier.
-__device__ __forceinline__ int bwd_cells_bounds(const BwdCellUnit& u, const BwdCellsView& V, const uint16_t* __restrict__ lstart,
+// The bounds of the cells of boundary rows [i0, i1) x the unit's chunks into LDS (cpre: exclusive counts, cpre[ncell] = the
+// lookups; cbase: slab position of a cell's first lookup): two CONTIGUOUS 2-byte-per-chunk reads of the boundary table.  All
+// threads call; ends with a barrier.
+__device__ __forceinline__ int bwd_cells_bounds(const BwdCellUnit& u, int i0, int i1, const uint16_t* __restrict__ bnd, int ch,
                                                 uint32_t* cpre, uint32_t* cbase, uint32_t* wtot) {
-  const int ncell = u.c1 - u.c0;
+  const int ncell = u.ncell;
   if ((int)threadIdx.x < ncell) {
-    const int cc = u.c0 + (int)threadIdx.x;
-    const uint16_t* lrow = lstart + (size_t)cc * BWD_CELLS_LROW;
-    const uint32_t a = lrow[u.b0], b = lrow[u.b1];
-    const int64_t cs = V.chunks[cc].s;  // (independent of the two loads above)
+    const int col = u.crel0 + (int)threadIdx.x;
+    const uint32_t a = bnd[(size_t)i0 * BWD_CELLS_MAXC + col], b = bnd[(size_t)i1 * BWD_CELLS_MAXC + col];
     cpre[threadIdx.x] = b - a;
-    cbase[threadIdx.x] = (uint32_t)cs + a;
+    cbase[threadIdx.x] = u.ts + (uint32_t)col * (uint32_t)ch + a;
   }
   __syncthreads();
   bwd_block_scan(cpre, ncell, wtot);
@@ -568,13 +624,19 @@ __device__ __forceinline__ void bwd_cells_sort_reduce(
     kmax = max(kmax, L.S.smm[BWD_WAVES + w]);
   }
   __syncthreads();  // smm is reused by the core
-  if (kmin == kmax) {  // (workgroup-uniform) ONE row -- a slice of a split row, a hot row alone in its unit: arrival order is the order
+#ifdef CELLS_ALWAYS_GROUPED  // (timing experiment: the sort as bwd_stage_unit runs it)
+  const bool one_row = false, grouped = true;
+#else
+  // ONE row -- a slice of a split row, a hot row alone in its unit: arrival order is the order.  Grouping by the low bits of the
+  // row id wants many distinct rows: a unit of an exact table (a handful of rows, hundreds of lookups each) would send every
+  // lookup to one of a few LDS counters; it takes the counting pass(es) over its few bits
+  const bool one_row = kmin == kmax, grouped = tb.rows > BWD_NB;  // (workgroup-uniform)
+#endif
+  if (one_row) {
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) dest[r] = (uint32_t)(wv * pw + r * TZR_WAVE + lane);
   } else {
-    // grouping by the low bits of the row id wants many distinct rows: a unit of an exact table (a handful of rows, hundreds of
-    // lookups each) would send every lookup to one of a few LDS counters; it takes the counting pass(es) over its few bits
-    bwd_sort_core<MAXR>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), tb.rows > BWD_NB, L.S, dest);
+    bwd_sort_core<MAXR>(kreg, sreg, vmask, pw, rounds, kmin, max(1, bwd_bits(kmax - kmin)), grouped, L.S, dest);
   }
   __syncthreads();  // the sort's LDS is dead: the unit's arrays take its place
 #pragma unroll
@@ -614,7 +676,7 @@ __device__ __forceinline__ void bwd_cells_sort_reduce(
 template <bool ADAM>
 __device__ __forceinline__ void bwd_cells_worker(
     const BwdCellsView& V, int n_units, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B,
-    int grad_mode, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ lstart,
+    int grad_mode, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ bnd, int ch,
     BwdCellsLds& L, const TzrDst* sG, uint32_t* xcell) {
   __shared__ uint32_t s_item;
   const int lane = threadIdx.x & (TZR_WAVE - 1);
@@ -639,19 +701,22 @@ __device__ __forceinline__ void bwd_cells_worker(
     if (item >= len) break;
     const BwdCellUnit u = V.units[tzr_consume_u32(ov + BWD_CELLS_OVF_LIST + item)];
     const TzrTable& tb = u.tb;
-    const int ncell = u.c1 - u.c0;
-    const int n = bwd_cells_bounds(u, V, lstart, cpre, cbase, L.S.wtot);
+    const int ncell = u.ncell;
+    const int n = bwd_cells_bounds(u, u.i0, u.i1, bnd, ch, cpre, cbase, L.S.wtot);
     const int ft_dst = feats[u.feat].n_dst;
     if (u.split > 0) {  // one slice of ONE row: its sum is the record
       uint32_t cnt;
-      const float4 sum = bwd_cells_row_sum(u, V, slab, cpre, cbase, ncell, n, (uint32_t)u.b0, feats, weights, B, grad_mode, sG,
-                                           reinterpret_cast<float*>(&L.S.L), L.S.gstart + 264, &cnt);
+      const float4 sum = bwd_cells_stream_row<false>(u, V, slab, cpre, cbase, ncell, n, BWD_SENT, feats, weights, B, grad_mode, sG,
+                                                     reinterpret_cast<float*>(&L.S.L), L.S.gstart + 264, &cnt);
       if (wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, sum, cnt, lane);
       continue;
     }
-    const uint64_t mult = V.chunks[u.c0].mult;  // (the table's bucket map: the same in all of its chunks)
+    int nb;
+    uint64_t mult;
+    bwd_bucket_params(tb.rows, &nb, &mult);
+    const uint32_t bend = V.bnd_bucket[u.i1];  // the bucket behind the unit's last
     uint32_t cur = (uint32_t)((((uint64_t)u.b0 << 32) + mult - 1) / mult);  // rows of the unit's buckets: [cur, khi)
-    uint64_t khi64 = (((uint64_t)u.b1 << 32) + mult - 1) / mult;
+    uint64_t khi64 = (((uint64_t)bend << 32) + mult - 1) / mult;
     if (khi64 > (uint64_t)tb.rows) khi64 = (uint64_t)tb.rows;
     const uint32_t khi = (uint32_t)khi64;
     for (;;) {
@@ -693,7 +758,7 @@ __device__ __forceinline__ void bwd_cells_worker(
 template <bool ADAM, int FK, int NT>
 __device__ __forceinline__ void bwd_cells_apply_body(
     BwdCellsView V, int n_units, const TzrFeature* __restrict__ feats, const float* __restrict__ weights, int64_t B, int grad_mode,
-    const BwdGrads& G, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ lstart) {
+    const BwdGrads& G, const BwdOpt& opt, int max_dim, const uint2* __restrict__ slab, const uint16_t* __restrict__ bnd, int ch) {
   __shared__ BwdCellsLds L;
   __shared__ TzrDst sG[TZR_MAX_DST];
   __shared__ uint32_t xcell[2 * BWD_CELLS_MAXC + 8];  // the unit's cells: exclusive counts [ncell + 1], slab starts [ncell]
@@ -704,7 +769,7 @@ __device__ __forceinline__ void bwd_cells_apply_body(
   if ((int)blockIdx.x >= n_units) {  // (workgroup-uniform; nothing of the unit path below is live here)
     __syncthreads();
 #ifndef CELLS_NO_WORKER  // (timing experiment: the units' code alone; units that do not fit are then simply dropped)
-    bwd_cells_worker<ADAM>(V, n_units, feats, weights, B, grad_mode, opt, max_dim, slab, lstart, L, sG, xcell);
+    bwd_cells_worker<ADAM>(V, n_units, feats, weights, B, grad_mode, opt, max_dim, slab, bnd, ch, L, sG, xcell);
 #endif
     return;
   }
@@ -713,15 +778,14 @@ __device__ __forceinline__ void bwd_cells_apply_body(
   const uint32_t epoch = V.overflow[BWD_CELLS_OVF_EPOCH];  // (constant during a launch; loaded with the unit)
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
-  const int ncell = u.c1 - u.c0;
+  const int ncell = u.ncell;
   const int ft_dst = feats[u.feat].n_dst;  // the table's first key: read together with the cells' bounds (no round trip of its own)
   uint32_t* const cpre = xcell;
   uint32_t* const cbase = xcell + BWD_CELLS_MAXC + 8;
-  const int n = bwd_cells_bounds(u, V, lstart, cpre, cbase, L.S.wtot);
   const float lr = *opt.lr;
+  const int n = bwd_cells_bounds(u, u.i0, u.i1, bnd, ch, cpre, cbase, L.S.wtot);
   CELLS_MARK(1);
   CELLS_NOTE(9, n);
-  CELLS_NOTE(10, u.split);
   if (threadIdx.x == 0) {  // "I have looked at my size" (+ my index on the list when it does not fit): what the workers wait for
     if (n > BWD_UMAX) {
       const uint32_t at = atomicAdd(V.overflow + BWD_CELLS_OVF_LEN, 1u);
@@ -730,11 +794,7 @@ __device__ __forceinline__ void bwd_cells_apply_body(
     }
     tzr_publish_u32(V.overflow + BWD_CELLS_OVF_LIST + n_units + blockIdx.x, epoch + 1u);  // (a store: nothing waits for it)
   }
-  if (n > BWD_UMAX) return;  // skewed ids: a worker takes this unit
-  if (n == 0) {
-    if (u.split > 0 && wv == 0) bwd_cells_combine<ADAM>(u, V, opt, lr, max_dim, tzr_zero4(), 0u, lane);
-    return;
-  }
+  if (n > BWD_UMAX || n == 0) return;  // skewed ids: a worker takes this unit
   // ---- gather the cells' lookups into registers (arrival order = chunk-major = lookup-position order inside a row) ----
   constexpr int kRounds = BWD_UMAX / BWD_THREADS;
   const int pw = bwd_wave_span(n);
@@ -768,8 +828,8 @@ __device__ __forceinline__ void bwd_cells_apply_body(
   __global__ __launch_bounds__(BWD_THREADS) ATTR void NAME(BwdCellsView V, int n_units, const TzrFeature* __restrict__ feats,  \
                                                           const float* __restrict__ weights, int64_t B, int grad_mode,         \
                                                           BwdGrads G, BwdOpt opt, int max_dim, const uint2* __restrict__ slab, \
-                                                          const uint16_t* __restrict__ lstart) {                               \
-    bwd_cells_apply_body<ADAM_, FK_, 1>(V, n_units, feats, weights, B, grad_mode, G, opt, max_dim, slab, lstart);              \
+                                                          const uint16_t* __restrict__ bnd, int ch) {                          \
+    bwd_cells_apply_body<ADAM_, FK_, 1>(V, n_units, feats, weights, B, grad_mode, G, opt, max_dim, slab, bnd, ch);             \
   }
 TZR_CELLS_APPLY_KERNEL(tzr_bwd_cells_apply_adagrad_kernel, false, TZR_OPT_ADAGRAD, TZR_WAVES_PER_EU(7))
 TZR_CELLS_APPLY_KERNEL(tzr_bwd_cells_apply_rowwise_kernel, false, TZR_OPT_ROWWISE_ADAGRAD, TZR_WAVES_PER_EU(7))
@@ -788,7 +848,6 @@ static int cells_common(const void* h_geo, void* d_geo, void* ws, size_t ws_byte
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return TZR_ERR_WORKSPACE;
   if (bwd_layout(P, ws, n_values, g->n_positions, n_feats, n_tables, max_dim) > ws_bytes) return TZR_ERR_WORKSPACE;
   if (P->ch != (int)g->ch || g->n_chunks > P->max_chunks) return TZR_ERR_INVALID;  // (a geometry built for another batch size)
-  static_assert(BWD_CELLS_LROW * 2 <= BWD_NB * 4, "the lstart rows live in the plan's histogram area");
   *V = bwd_cells_view(d_geo, *g);
   return TZR_OK;
 }
@@ -814,7 +873,7 @@ extern "C" int tzr_pooled_bwd_cells_plan(const TzrTable* d_tables, int n_tables,
   A.B = B;
   A.uniform = 1;
   hipLaunchKernelGGL(tzr_bwd_cells_partition_kernel, dim3((unsigned)g.n_chunks), dim3(BWD_THREADS), 0, static_cast<hipStream_t>(stream), V,
-                     d_tables, A, P.ks[1], reinterpret_cast<uint16_t*>(P.hist));
+                     d_tables, A, P.ks[1], reinterpret_cast<uint16_t*>(P.hist), (int)g.ch);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }
@@ -860,7 +919,7 @@ extern "C" int tzr_pooled_bwd_cells_apply(const TzrTable* d_tables, const TzrFea
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define TZR_CELLS_LAUNCH(K)                                                                                               \
   hipLaunchKernelGGL(K, dim3((unsigned)g.n_units + BWD_CELLS_WORKERS), dim3(BWD_THREADS), 0, s, V, (int)g.n_units, d_feats, d_weights, \
-                     B, grad_mode, G, opt, max_dim, (const uint2*)P.ks[1], (const uint16_t*)reinterpret_cast<uint16_t*>(P.hist))
+                     B, grad_mode, G, opt, max_dim, (const uint2*)P.ks[1], (const uint16_t*)reinterpret_cast<uint16_t*>(P.hist), (int)g.ch)
   const bool fast_shape = !d_weights && (opt.kind == TZR_OPT_ADAGRAD || opt.kind == TZR_OPT_ROWWISE_ADAGRAD || opt.kind == TZR_OPT_SGD);
   if (opt.kind == TZR_OPT_ADAM) {
     TZR_CELLS_LAUNCH(tzr_bwd_cells_apply_adam_kernel);

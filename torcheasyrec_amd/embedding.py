@@ -580,6 +580,14 @@ class EmbeddingBagCollection(nn.Module):
         return bool(_lib.lib().tzr_pooled_bwd_direct_supported(self._n_positions(kjt), len(self._lookups), len(self._configs),
                                                                1 if kjt.uniform_length() == 1 else 0, 0))
 
+    def backward_form(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> str:
+        """which form the fused backward of this batch takes right now: "direct" (one launch, no plan), "cells" (one-launch plan +
+        apply) or "exact" (four-launch plan + apply)"""
+        if self.backward_is_direct(kjt):
+            return "direct"
+        meta = self._meta(kjt.keys(), self._layout_for(dst_names))
+        return "cells" if self._cells_for(kjt, meta) is not None else "exact"
+
     def plan_backward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...] = ("__all__",)) -> Optional[torch.Tensor]:
         """K6: build the backward index plan for this batch (depends on ids only, so callers may run
         it early on a side stream).  Returns the workspace holding the plan -- None for a batch whose
