@@ -1095,7 +1095,9 @@ def main():
         stat = tm.mean_ms if iters <= 10 else tm.median_ms  # (long secondary runs: the median, so that a host gap late in the queue does not enter)
         f, p_, a_ = stat("fwd"), stat("plan") or 0.0, stat("apply")  # (no plan launch: tzr_pooled_bwd_direct)
         return {"fwd_ms": f, "bwd_plan_ms": p_, "bwd_apply_ms": a_, "algorithmic_bytes": nbytes,
-                "backward": "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else "tzr_pooled_bwd_plan (4 launches) + tzr_pooled_bwd_apply",
+                "backward": "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else
+                            ("tzr_pooled_bwd_cells_plan (1 launch) + tzr_pooled_bwd_cells_apply" if ebc_.backward_form(kjts[0], ("sparse",)) == "cells"
+                             else "tzr_pooled_bwd_plan (4 launches) + tzr_pooled_bwd_apply"),
                 "iterations": iters, "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
 
     # N = 1: the other readings BASELINE.json / the north star ask for, on the same box in the same process:
@@ -1144,6 +1146,7 @@ def main():
             bz.append(k_.to(dev))
         secondary["zipf_ids_batch65536"] = {"config": "ids Zipf(1.05) clipped to the table (SURVEY 8d secondary distribution)",
                                             "embedding": embedding_stages(ebc, bz, hz, B_global, "adagrad", iters=SECONDARY_REPLAYS)}
+        ebc.reset_plan_mode()  # (Zipf ids sent the collection to the exact index plan for good; the headline's ids are evenly drawn)
         del bz
         # (c) row-wise Adagrad, the optimizer the north star names: its own collection (weights [rows, 16] + [rows] state)
         try:

@@ -28,7 +28,9 @@
 
 #define BWD_CELLS_MAXC 256   // chunks of one table (cells a unit may gather from): 262 144 lookups per table at 1024 per chunk
 #define BWD_CELLS_TARGET 1076  // largest EXPECTED size of a unit: BWD_UMAX - 6 sqrt(BWD_UMAX)
+#ifndef BWD_CELLS_WORKERS
 #define BWD_CELLS_WORKERS 32   // workgroups behind the units of the apply launch that take the units that did not fit
+#endif
 // words of the overflow area (BwdCellsView::overflow)
 #define BWD_CELLS_OVF_TOTAL 0    // units that did not fit since the buffer was made (never reset by the kernels: the caller's signal)
 #define BWD_CELLS_OVF_LEN 1      // ... of this launch (reset by the last worker)

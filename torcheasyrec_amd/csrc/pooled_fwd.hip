@@ -171,7 +171,9 @@ __global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_kernel(
 // the ids of its tile -- one coalesced pass, one round trip -- into LDS, so every row gather of the
 // tile is an independent load: FWD1_UNROLL of them in flight per thread, and tiles of 32 samples make
 // 2048 workgroups at B = 65536 (~13 KB of LDS each: the register file, not LDS, bounds residency).
+#ifndef FWD1_UNROLL
 #define FWD1_UNROLL 8
+#endif
 #define FWD1_SLOTS 128    // slots per workgroup row (blockIdx.y); DLRM-Criteo: 104
 #define FWD1_MAX_IDS 2048 // ids of a (sub-)tile held in LDS: groups x samples
 
@@ -196,7 +198,12 @@ extern "C" int tzr_fwd_prof_dump(uint64_t* h_out, int n_wg) {
 #define FWD_PROF_MARK(i)
 #endif
 
-__global__ __launch_bounds__(FWD_THREADS) void tzr_pooled_fwd_u1_kernel(
+#ifndef FWD1_WAVES  // (timing experiments: -DFWD1_WAVES=n compiles the kernel for n waves per SIMD, -DFWD1_UNROLL=m gathers in flight per thread)
+#define FWD1_WAVES_ATTR
+#else
+#define FWD1_WAVES_ATTR TZR_WAVES_PER_EU(FWD1_WAVES)
+#endif
+__global__ __launch_bounds__(FWD_THREADS) FWD1_WAVES_ATTR void tzr_pooled_fwd_u1_kernel(
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
     int tile_b, FwdDsts dsts) {

@@ -361,6 +361,17 @@ class EmbeddingBagCollection(nn.Module):
         meta.cells[B] = geo
         return geo
 
+    def reset_plan_mode(self) -> None:
+        """Forget what "auto" has learnt about the id distribution (a collection that met skewed ids stays on the exact plan for
+        good): for callers that know the distribution has changed -- bench.py times Zipf ids and evenly drawn ones on one
+        collection."""
+        for meta in self._meta_cache.values():
+            for geo in meta.cells.values():
+                if geo is not None:
+                    if geo.copied is not None:
+                        geo.copied.synchronize()
+                    geo.seen, geo.demoted, geo.launches = int(geo.h_overflow[0]), False, 0
+
     def _cells_for(self, kjt: KeyedJaggedTensor, meta: _Meta) -> Optional[_CellsGeo]:
         """the geometry of the one-launch plan when this batch takes it, else None"""
         if self.plan_mode == "exact" or kjt.uniform_length() != 1 or kjt.weights_or_none() is not None:
