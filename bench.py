@@ -125,6 +125,9 @@ def parse_args():
                     help="sharded runs: tables of at most this many rows are replicated (default: planner.pick_dp_max_rows -- the "
                          "threshold with the least modelled wire + kernel time at the run's (or the projection's) world size; 500 under "
                          "--emulator, so that capped tables still take the row-wise exchange; 65536 = the round-4 constant)")
+    ap.add_argument("--no-fuse-finish", action="store_true",
+                    help="dense optimizer: the gradients of the bottom MLP and of the first top-MLP layer as finished tensors (their own "
+                         "finishing launches) instead of partial sums added up inside the optimizer's launch")
     ap.add_argument("--forms", choices=["auto", "ab", "one_graph", "overlapped"], default="auto",
                     help="sharded --step-graph runs: which form of the step is timed.  one_graph = the native driver (the step ONE "
                          "hipGraph with its RCCL collectives inline), overlapped = six hipGraphs with torch.distributed's collectives "
@@ -727,7 +730,9 @@ def main():
     else:  # same update, two launches for all ten tensors (torcheasyrec_amd/dense.py)
         from torcheasyrec_amd.dense import FusedDenseAdam
 
-        dense_opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-3)
+        # (one GPU: the bottom MLP's and the first top-MLP layer's gradients stay partial sums until the optimizer's own launch adds
+        # them up -- dense.FUSE_FINISH; the sharded step packs its dense gradients for the all-reduce: finished tensors there)
+        dense_opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-3, fuse_finish=not sharded and not args.no_fuse_finish)
 
     # synthetic batches, resident in HBM before the timed region
     from torcheasyrec_amd.sparse import KeyedJaggedTensor

@@ -501,6 +501,40 @@ typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, 
 int tzr_dense_adam(const TzrAdamTensor* h_tensors, int n_tensors, const float* d_lr, float lr,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* The same Adam step in ONE launch, with gradients taken as they lie (csrc/adam_fused.hip): a finished tensor
+ * (TZR_ADAM_SRC_TENSOR: TzrAdamTensor.grad), rows of per-workgroup partial sums left by tzr_mlp2_bwd_parts (TZR_ADAM_SRC_ROWS:
+ * element i of the tensor = sum over the G rows of parts[g * P + col + i], added in tzr_mlp2_bwd's own finish order), or the
+ * batch slices of tzr_dot_interaction_top_wgrad_parts (TZR_ADAM_SRC_WGRAD, at most one per call: *h_wgrad).  The column-sum
+ * finish launches and the slice reduction of the DLRM step (tzrec/models/dlrm.py:101-135 behind tzrec/optim/optimizer.py:56-68)
+ * disappear into the optimizer's launch; sums and updates are bit-identical to the separate launches.
+ * TzrAdamTensor.state here: float[TZR_ADAM_FUSED_STATE]: [0] step count, [1 ..] arrival counters (ZERO between launches: the
+ * tensor's workgroups arrive in groups of 32, the last one moves the step on and clears them) -- not interchangeable with
+ * tzr_dense_adam's float[3] on the same tensor.
+ * A tensor with param == 0 only gets its finished gradient stored into `grad` (for a caller that needs the tensor after all).
+ * h_sources NULL: every gradient is a finished tensor. */
+#define TZR_ADAM_FUSED_STATE 40 /* 1 step + 1 + 32 counters (<= 1024 workgroups per tensor), padded */
+#define TZR_ADAM_SRC_TENSOR 0
+#define TZR_ADAM_SRC_ROWS 1
+#define TZR_ADAM_SRC_WGRAD 2
+typedef struct TzrAdamSource {
+  int32_t kind, G, P, col;
+  uint64_t parts; /* const float* device address of the partial-sum rows (TZR_ADAM_SRC_ROWS) */
+  uint64_t reserved;
+} TzrAdamSource; /* 32 bytes */
+typedef struct TzrWgradParts { uint64_t opaque[24]; } TzrWgradParts; /* filled by tzr_dot_interaction_top_wgrad_parts */
+int tzr_dense_adam_fused(const TzrAdamTensor* h_tensors, const TzrAdamSource* h_sources, int n_tensors,
+                         const TzrWgradParts* h_wgrad, const float* d_lr, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, void* stream);
+/* tzr_mlp2_bwd / tzr_dot_interaction_top_wgrad without their finishing launch (same arguments, same workspace, which stays the
+ * caller's until tzr_dense_adam_fused has consumed it): *out_G rows of *out_P floats, columns [dWb: H2 x H1 | dbb: H2 |
+ * dWa: H1 x K0 | dba: H1]; *h_out for TZR_ADAM_SRC_WGRAD (B > 0). */
+int tzr_mlp2_bwd_parts(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride, const float* d_ha,
+                       int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0, int H1, int H2,
+                       const float* d_Wb, void* ws, size_t ws_bytes, int* out_G, int* out_P, void* stream);
+int tzr_dot_interaction_top_wgrad_parts(const float* d_dense, int64_t dense_stride, const float* d_sparse, int64_t sparse_stride,
+                                        int F, int D, int64_t B, const float* d_g1, int64_t g1_stride, int H, const float* d_scale,
+                                        void* d_ws, int64_t ws_bytes, TzrWgradParts* h_out, void* stream);
+
 /* ---- zero-collision hash ---------------------------------------- */
 
 #define TZR_ZCH_EMPTY INT64_MAX /* unoccupied cell / row (tzrec/utils/zch_util.py:29 ZCH_EMPTY_SLOT) */

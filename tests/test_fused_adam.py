@@ -1,0 +1,114 @@
+"""tzr_dense_adam_fused (csrc/adam_fused.hip): the dense optimizer that takes gradients as they lie -- finished tensors, rows of
+partial sums (tzr_mlp2_bwd_parts), the slices of the first top-MLP layer's weight gradient (tzr_dot_interaction_top_wgrad_parts).
+The additions are the finishing launches' own, so a training run with `FusedDenseAdam(fuse_finish=True)` must equal the run
+with separate finishing launches BIT FOR BIT; gradients that nobody steps are written out as tensors all the same."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from torcheasyrec_amd import dense  # noqa: E402
+from torcheasyrec_amd.criteo import NUM_DENSE, SPARSE_KEYS, criteo_tables, synthetic_batch  # noqa: E402
+from torcheasyrec_amd.dense import FusedDenseAdam  # noqa: E402
+from torcheasyrec_amd.dlrm import DLRM  # noqa: E402
+from torcheasyrec_amd.embedding import SparseOptimizerConfig  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _reset_flag():
+    dense.FUSE_FINISH = False
+    dense._PENDING.clear()
+    yield
+    dense.FUSE_FINISH = False
+    dense._PENDING.clear()
+
+
+def _train(dev, fuse, steps, B=96, read_grads_at=None):
+    torch.manual_seed(0)
+    rows = [min(r, 300) for r in [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938, 155, 4, 976, 14,
+                                  40000000, 40000000, 40000000, 590152, 12973, 108, 36]]
+    model = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=SparseOptimizerConfig(kind="sgd", lr=0.01))
+    params = list(model.dense_parameters())
+    dense.FUSE_FINISH = False
+    opt = FusedDenseAdam(params, lr=1e-2, weight_decay=1e-3, fuse_finish=fuse)
+    assert dense.FUSE_FINISH == fuse
+    grads = None
+    for s in range(steps):
+        d, kjt, y = synthetic_batch(s, B, rows)
+        loss, _ = model.forward_loss(d.to(dev), kjt.to(dev), y.to(dev))
+        with dense.root_loss():
+            loss.backward(gradient=dense.unit_gradient(loss))
+        if read_grads_at == s:
+            dense.materialize_pending()  # (a reader of finished gradients in front of the optimizer)
+            assert not dense._PENDING
+            grads = [p.grad.detach().cpu().clone() for p in params]
+        opt.step()
+        assert not dense._PENDING
+        opt.zero_grad(set_to_none=True)
+    return [p.detach().cpu().clone() for p in params], opt._state.cpu().clone(), grads, float(loss.detach())
+
+
+def test_training_with_gradients_left_as_partial_sums_is_bit_identical(dev):
+    pa, sa, _, la = _train(dev, False, 3)
+    pb, sb, _, lb = _train(dev, True, 3)
+    assert la == lb
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert torch.equal(sa, sb) and bool((sa[:, 0] == 3).all()) and bool((sa[:, 1] == 0).all())  # steps counted, arrival counters back at zero
+
+
+def test_pending_gradients_can_be_written_out_before_the_step(dev):
+    _, _, ga, _ = _train(dev, False, 2, read_grads_at=1)
+    pb, _, gb, _ = _train(dev, True, 2, read_grads_at=1)
+    pa, _, _, _ = _train(dev, False, 2)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+    for a, b in zip(pa, pb):  # ... and the step behind it takes the written-out tensors: the same parameters again
+        assert torch.equal(a, b)
+
+
+def test_more_tensors_than_one_launch_takes_and_tensors_without_a_gradient(dev):
+    """40 tensors (two launches of <= 32), every third without a gradient: its step count does not move (torch counts steps per
+    parameter), the others follow torch.optim.Adam"""
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(int(n), device=dev)) for n in np.random.default_rng(0).integers(1, 3000, size=40)]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FusedDenseAdam(ps, lr=3e-3)
+    topt = torch.optim.Adam(ref, lr=3e-3)
+    for step in range(3):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i % 3 == step % 3:
+                p.grad = r.grad = None
+                continue
+            g = torch.randn(p.shape, generator=torch.Generator().manual_seed(100 * step + i))
+            p.grad, r.grad = g.to(dev), g.clone()
+        opt.step()
+        topt.step()
+    for i, (p, r) in enumerate(zip(ps, ref)):
+        torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=2e-6, atol=2e-7)
+    assert opt._state[:, 0].cpu().tolist() == [2.0] * 40 and bool((opt._state[:, 1] == 0).all())
+
+
+def test_a_gradient_that_would_be_accumulated_is_finished_as_a_tensor(dev):
+    """parameters that still hold a gradient when the backward runs (no zero_grad: autograd ADDS the new gradient to the old one)
+    do not get theirs as partial sums: two backward passes + one step == the same with the finishing launches"""
+    def run(fuse):
+        torch.manual_seed(0)
+        rows = [200] * 26
+        model = DLRM(criteo_tables(rows, init="seeded"), SPARSE_KEYS, NUM_DENSE, device=dev, sparse_optimizer=SparseOptimizerConfig(kind="sgd", lr=0.01))
+        dense.FUSE_FINISH = False
+        opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-2, fuse_finish=fuse)
+        for s in range(2):
+            d, kjt, y = synthetic_batch(s, 64, rows)
+            loss, _ = model.forward_loss(d.to(dev), kjt.to(dev), y.to(dev))
+            with dense.root_loss():
+                loss.backward(gradient=dense.unit_gradient(loss))  # (no zero_grad between the two)
+        opt.step()
+        assert not dense._PENDING
+        return [p.detach().cpu().clone() for p in model.dense_parameters()]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)

@@ -85,6 +85,17 @@ class TzrAdamTensor(C.Structure):
                 ("state", C.c_uint64), ("numel", C.c_int64)]
 
 
+class TzrAdamSource(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("G", C.c_int32), ("P", C.c_int32), ("col", C.c_int32), ("parts", C.c_uint64), ("reserved", C.c_uint64)]
+
+
+class TzrWgradParts(C.Structure):
+    _fields_ = [("opaque", C.c_uint64 * 24)]
+
+
+ADAM_SRC_TENSOR, ADAM_SRC_ROWS, ADAM_SRC_WGRAD = 0, 1, 2
+
+
 class TzrZchModule(C.Structure):
     _fields_ = [("keys", C.c_uint64), ("rows", C.c_uint64), ("counts", C.c_uint64), ("last_iter", C.c_uint64),
                 ("capacity", C.c_int64), ("zch_size", C.c_int64), ("reserved", C.c_int64 * 2)]
@@ -149,6 +160,12 @@ _SIGNATURES = {
     "tzr_pooled_bwd_cells_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tzr_pooled_bwd_cells_apply": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _i32, C.POINTER(TzrDst), _i32,
                                           C.POINTER(TzrSparseOptim), _vp, _vp, _vp, _sz, _vp]),
+    "tzr_dense_adam_fused": (_i32, [C.POINTER(TzrAdamTensor), C.POINTER(TzrAdamSource), _i32, C.POINTER(TzrWgradParts), _vp, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    "tzr_mlp2_bwd_parts": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _sz, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), _vp]),
+    "tzr_dot_interaction_top_wgrad_parts": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _i64,
+                                                   C.POINTER(TzrWgradParts), _vp]),
     "tzr_dot_interaction_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,
                                        _i32, _vp]),
     "tzr_dot_interaction_bwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _i32,

@@ -29,8 +29,12 @@
 // 250 instructions per tile and loader) 109 -> X rows out of the pair-operand registers 113 (fewer loads, more v_mov) -> tiles in
 // the loaders' own layout instead of transposed (no v_mov, dword operand reads) 109.
 // HBM traffic: X and g1 once (131 MB; the column groups' re-reads hit the L2, profiles/r04ad).
+#include <cstring>
+
 #include "tzr_common.h"
 #include <tzr_gfx950.h>
+
+#include "wgrad_reduce.h"
 
 #define WG_THREADS 1024
 #define WG_WAVES (WG_THREADS / TZR_WAVE)
@@ -38,10 +42,6 @@
 #define WG_P 336           // floats of a sample's row of a tile in LDS (>= 16 npb + 20 xn, = 16 mod 32: the dword operand reads of lanes (r, q) and (r, q + 1) fall on different bank halves)
 #define WG_PG 80           // ... of its g1 row (64 + 16)
 #define WG_MAXB 16         // column blocks (of 16) per group
-#define WG_H 64
-#define WG_D 16
-#define WG_NG 4
-#define WG_MAXSLICES 64
 
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -77,13 +77,6 @@ __device__ __forceinline__ float4 wg_ld4_a4(const float* p) {  // 16-byte load f
   return make_float4(u.x, u.y, u.z, u.w);
 }
 
-struct WgGroup {
-  int src;    // block of the pair matrix this group produces: 0 none, 1 c00, 2 c01, 3 c11
-  int npb;    // its pair columns, in blocks of 16 (the last one padded)
-  int x0, xn; // X rows [x0, x0 + xn) behind them, one block each
-  int nb;     // npb + xn <= WG_MAXB
-  int vbase;  // first column of the group in a row of the partial sums
-};
 
 struct WgArgs {
   const float *dense, *sparse, *g1;
@@ -427,59 +420,13 @@ __global__ __launch_bounds__(WG_THREADS) void tzr_ia_wgrad_kernel(WgArgs a) {
   }
 }
 
-// dW1[h][c] = scale * sum over the slices of the partial column that holds z column c.  Four lanes per output, lane j sums the
-// slices j, j + 4, ... in order, then (s0 + s1) + (s2 + s3): one fixed order.  A wave = 16 outputs x 4 (j = lane >> 4).
-struct WgReduceArgs {
-  const float *part, *scale;
-  float* dW;
-  int64_t ldw;
-  int n, slices, vw;
-  WgGroup g[WG_NG];
-};
-
 __global__ __launch_bounds__(256) void tzr_ia_wgrad_reduce_kernel(WgReduceArgs a) {
-  const int n = a.n, P = n * (n - 1) / 2, width = P + WG_D * n;
-  const int lane = threadIdx.x & 63, j = lane >> 4;
-  int o = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
-  const bool live = o < WG_H * width;
-  o = live ? o : WG_H * width - 1;
-  const int h = o / width, c = o - h * width;
-  const int n0 = n < 16 ? n : 16, n1 = n > 16 ? n - 16 : 0;
-  int v;
-  if (c >= P) {
-    const int x = (c - P) >> 4, d = (c - P) & 15;
-    int k = 0;
-    while (k < WG_NG - 1 && !(x >= a.g[k].x0 && x < a.g[k].x0 + a.g[k].xn)) ++k;
-    v = a.g[k].vbase + 16 * (a.g[k].npb + x - a.g[k].x0) + d;
-  } else {
-    int i = 0, p = c;
-    while (p >= n - 1 - i) { p -= n - 1 - i; ++i; }
-    const int jj = i + 1 + p;
-    if (jj < 16) v = a.g[0].vbase + (i * (2 * n0 - i - 1)) / 2 + jj - i - 1;
-    else if (i < 16) v = a.g[1].vbase + i * n1 + (jj - 16);
-    else v = a.g[2].vbase + ((i - 16) * (2 * n1 - (i - 16) - 1)) / 2 + jj - i - 1;
-  }
-  const int64_t step = (int64_t)WG_H * a.vw;
-  const float* p = a.part + (int64_t)h * a.vw + v + j * step;
-  float sum = 0.f;
-  static_assert(WG_MAXSLICES <= 64, "sixteen slices per lane");
-  {  // (slices: a multiple of 8, at most 64: all of a lane's loads in flight at once -- it was two dependent rounds of eight)
-    float x[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int s = 4 * k;
-      x[k] = p[(int64_t)(s < a.slices ? s : 0) * step];
-      x[k] = s < a.slices ? x[k] : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sum += x[k];
-  }
-  // (adding the zeros of slices beyond the count changes nothing: x + 0 = x, and -0 never arises from a sum started at +0)
-  const float s1 = __shfl_xor(sum, 16), t01 = j & 1 ? s1 + sum : sum + s1;   // lanes j = 0 / 1: s0 + s1; j = 2 / 3: s2 + s3
-  const float t23 = __shfl_xor(t01, 32);
-  const float tot = j < 2 ? t01 + t23 : t23 + t01;
-  const float sc = a.scale ? *a.scale : 1.f;
-  if (live && j == 0) a.dW[(int64_t)h * a.ldw + c] = sc * tot;
+  const int lane = threadIdx.x & 63;
+  const int o = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  int h, c;
+  bool live;
+  const float v = wg_reduce_output(a, o, lane, &h, &c, &live);
+  if (live && (lane >> 4) == 0) a.dW[(int64_t)h * a.ldw + c] = v;
 }
 
 int g_tzr_wg_debug = 0;  // tzr_tune("wg_debug"): phase-skipping bits for timing experiments (1 no product, 2 no tile build, 4 no loads, 8 no main kernel, 16 no reduce kernel): wrong results
@@ -499,28 +446,26 @@ extern "C" int64_t tzr_dot_interaction_top_wgrad_workspace(int F, int D, int has
   return (int64_t)WG_MAXSLICES * WG_H * vw * (int64_t)sizeof(float);
 }
 
-extern "C" int tzr_dot_interaction_top_wgrad(const float* d_dense, int64_t dense_stride, const float* d_sparse,
-                                             int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1,
-                                             int64_t g1_stride, int H, const float* d_scale, float* d_dW1, int64_t ldw,
-                                             void* d_ws, int64_t ws_bytes, void* stream) {
+// The weight-gradient kernel alone: the batch slices' partial sums stay in d_ws and `ra` says how to add them up
+// (wg_reduce_output) -- for tzr_dot_interaction_top_wgrad's own reduce launch, or for a consumer that takes them as they are
+// (tzr_dense_adam_fused).
+static int wgrad_partials(const float* d_dense, int64_t dense_stride, const float* d_sparse, int64_t sparse_stride, int F, int D,
+                          int64_t B, const float* d_g1, int64_t g1_stride, int H, const float* d_scale, void* d_ws, int64_t ws_bytes,
+                          WgReduceArgs* ra, void* stream) {
   const int hd = d_dense ? 1 : 0;
   const int n = F + hd;
-  if (!d_dW1 || F <= 0 || B < 0 || (B > 0 && (!d_g1 || !d_sparse))) return TZR_ERR_INVALID;
+  if (F <= 0 || B < 0 || (B > 0 && (!d_g1 || !d_sparse))) return TZR_ERR_INVALID;
   if (!tzr_dot_interaction_top_supported(F, D, hd, H)) return TZR_ERR_UNSUPPORTED;
-  const int width = n * (n - 1) / 2 + WG_D * n;
-  if (ldw < width) return TZR_ERR_INVALID;
   if ((sparse_stride & 3) || (hd && (dense_stride & 3)) ||
-      ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_dense)) & 15) ||
-      ((reinterpret_cast<uintptr_t>(d_g1) | reinterpret_cast<uintptr_t>(d_dW1)) & 3))
+      ((reinterpret_cast<uintptr_t>(d_sparse) | reinterpret_cast<uintptr_t>(d_dense)) & 15) || (reinterpret_cast<uintptr_t>(d_g1) & 3))
     return TZR_ERR_INVALID;
   // (the kernel's sample offsets are 32-bit)
   if (B >= (int64_t)1 << 31 || B * sparse_stride >= (int64_t)1 << 32 || B * g1_stride >= (int64_t)1 << 32 ||
       (hd && B * dense_stride >= (int64_t)1 << 32) || sparse_stride < 0 || g1_stride < 0 || dense_stride < 0)
     return TZR_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  WgReduceArgs ra;
   int vw;
-  wg_plan(n, ra.g, &vw);
+  wg_plan(n, ra->g, &vw);
   const int slices = B > 0 ? wg_slices(B) : 0;
   if (B > 0) {
     if (!d_ws || ws_bytes < (int64_t)slices * WG_H * vw * (int64_t)sizeof(float) || (reinterpret_cast<uintptr_t>(d_ws) & 15))
@@ -534,12 +479,46 @@ extern "C" int tzr_dot_interaction_top_wgrad(const float* d_dense, int64_t dense
 #else
     a.prof = nullptr;
 #endif
-    for (int k = 0; k < WG_NG; ++k) a.g[k] = ra.g[k];
+    for (int k = 0; k < WG_NG; ++k) a.g[k] = ra->g[k];
     if (!(g_tzr_wg_debug & 8)) hipLaunchKernelGGL(tzr_ia_wgrad_kernel, dim3(WG_NG * slices), dim3(WG_THREADS), 0, st, a);
     TZR_CHECK_LAUNCH();
   }
-  ra.part = static_cast<const float*>(d_ws); ra.scale = d_scale; ra.dW = d_dW1; ra.ldw = ldw; ra.n = n; ra.slices = slices; ra.vw = vw;
-  if (!(g_tzr_wg_debug & 16)) hipLaunchKernelGGL(tzr_ia_wgrad_reduce_kernel, dim3((WG_H * width + 63) / 64), dim3(256), 0, st, ra);
+  ra->part = static_cast<const float*>(d_ws); ra->scale = d_scale; ra->dW = nullptr; ra->ldw = 0; ra->n = n; ra->slices = slices; ra->vw = vw;
+  return TZR_OK;
+}
+
+extern "C" int tzr_dot_interaction_top_wgrad(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                             int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1,
+                                             int64_t g1_stride, int H, const float* d_scale, float* d_dW1, int64_t ldw,
+                                             void* d_ws, int64_t ws_bytes, void* stream) {
+  const int n = F + (d_dense ? 1 : 0);
+  const int width = n * (n - 1) / 2 + WG_D * n;
+  if (!d_dW1 || ldw < width || (reinterpret_cast<uintptr_t>(d_dW1) & 3)) return TZR_ERR_INVALID;
+  WgReduceArgs ra;
+  const int rc = wgrad_partials(d_dense, dense_stride, d_sparse, sparse_stride, F, D, B, d_g1, g1_stride, H, d_scale, d_ws, ws_bytes, &ra,
+                                stream);
+  if (rc != TZR_OK) return rc;
+  ra.dW = d_dW1;
+  ra.ldw = ldw;
+  if (!(g_tzr_wg_debug & 16))
+    hipLaunchKernelGGL(tzr_ia_wgrad_reduce_kernel, dim3((WG_H * width + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), ra);
   TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// ... without the reduce launch: h_out (TzrWgradParts, include/tzrec_hip.h) describes the partial sums for tzr_dense_adam_fused,
+// which adds them up on its way to the Adam update of W1 (B > 0; d_ws stays the caller's until that call has run).
+extern "C" int tzr_dot_interaction_top_wgrad_parts(const float* d_dense, int64_t dense_stride, const float* d_sparse,
+                                                   int64_t sparse_stride, int F, int D, int64_t B, const float* d_g1,
+                                                   int64_t g1_stride, int H, const float* d_scale, void* d_ws, int64_t ws_bytes,
+                                                   TzrWgradParts* h_out, void* stream) {
+  static_assert(sizeof(WgReduceArgs) <= sizeof(TzrWgradParts), "the opaque blob of the C ABI holds the reduce arguments");
+  if (!h_out || B <= 0) return TZR_ERR_INVALID;
+  WgReduceArgs ra;
+  const int rc = wgrad_partials(d_dense, dense_stride, d_sparse, sparse_stride, F, D, B, d_g1, g1_stride, H, d_scale, d_ws, ws_bytes, &ra,
+                                stream);
+  if (rc != TZR_OK) return rc;
+  std::memset(h_out, 0, sizeof(*h_out));
+  std::memcpy(h_out, &ra, sizeof(ra));
   return TZR_OK;
 }

@@ -333,12 +333,11 @@ __global__ __launch_bounds__(ML_THREADS) void tzr_mlp2_bwd_kernel(
 
 extern "C" size_t tzr_mlp_workspace(void) { return (size_t)ML_MAX_WG * (ML_H2 * ML_H1 + ML_H1 * ML_K0 + 4 * ML_H1) * sizeof(float) + 256; }
 
-extern "C" int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride,
-                            const float* d_ha, int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0,
-                            int H1, int H2, const float* d_Wb, float* d_dWa, float* d_dba, float* d_dWb, float* d_dbb,
-                            void* ws, size_t ws_bytes, void* stream) {
-  if (!d_dhb || !d_hb || !d_ha || !d_x || !d_Wb || !d_dWa || !d_dWb || B <= 0 || K0 <= 0 || H1 <= 0 || H2 <= 0)
-    return TZR_ERR_INVALID;
+// the producing launch of tzr_mlp2_bwd: one partial-sum row per workgroup, [dWb: H2 x H1 | dbb: H2 | dWa: H1 x K0 | dba: H1]
+static int mlp2_bwd_partials(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride, const float* d_ha,
+                             int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0, int H1, int H2,
+                             const float* d_Wb, void* ws, size_t ws_bytes, int* G_out, int* P_out, void* stream) {
+  if (!d_dhb || !d_hb || !d_ha || !d_x || !d_Wb || B <= 0 || K0 <= 0 || H1 <= 0 || H2 <= 0) return TZR_ERR_INVALID;
   if (K0 > ML_K0 || H1 > ML_H1 || H2 > ML_H2) return TZR_ERR_UNSUPPORTED;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_mlp_workspace() - 256) return TZR_ERR_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -352,6 +351,21 @@ extern "C" int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float*
   else
     hipLaunchKernelGGL(tzr_mlp2_bwd_kernel, dim3(G), dim3(ML_THREADS), 0, s, d_dhb, dhb_stride, d_hb, hb_stride, d_ha,
                        ha_stride, d_x, x_stride, B, K0, H1, H2, d_Wb, parts, P);
+  TZR_CHECK_LAUNCH();
+  *G_out = G;
+  *P_out = P;
+  return TZR_OK;
+}
+
+extern "C" int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride,
+                            const float* d_ha, int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0,
+                            int H1, int H2, const float* d_Wb, float* d_dWa, float* d_dba, float* d_dWb, float* d_dbb,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!d_dWa || !d_dWb) return TZR_ERR_INVALID;
+  int G, P;
+  const int rc = mlp2_bwd_partials(d_dhb, dhb_stride, d_hb, hb_stride, d_ha, ha_stride, d_x, x_stride, B, K0, H1, H2, d_Wb, ws, ws_bytes,
+                                   &G, &P, stream);
+  if (rc != TZR_OK) return rc;
   MlParts out;
   for (int i = 0; i < 6; ++i) {
     out.dst[i] = nullptr;
@@ -361,10 +375,21 @@ extern "C" int tzr_mlp2_bwd(const float* d_dhb, int64_t dhb_stride, const float*
   out.dst[1] = d_dbb; out.n[1] = H2;
   out.dst[2] = d_dWa; out.n[2] = H1 * K0;
   out.dst[3] = d_dba; out.n[3] = H1;
-  hipLaunchKernelGGL(tzr_mlp_finish_kernel, dim3((P + 15) / 16), dim3(ML_THREADS), 0, s, parts, G, P,
-                     out);
+  hipLaunchKernelGGL(tzr_mlp_finish_kernel, dim3((P + 15) / 16), dim3(ML_THREADS), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(ws), G, P, out);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+// ... without the finish launch: the partial-sum rows stay in `ws` (G rows of P floats: *out_G, *out_P; columns
+// [dWb | dbb | dWa | dba]) for tzr_dense_adam_fused, which adds them up on its way to the four tensors' Adam updates.
+extern "C" int tzr_mlp2_bwd_parts(const float* d_dhb, int64_t dhb_stride, const float* d_hb, int64_t hb_stride,
+                                  const float* d_ha, int64_t ha_stride, const float* d_x, int64_t x_stride, int64_t B, int K0,
+                                  int H1, int H2, const float* d_Wb, void* ws, size_t ws_bytes, int* out_G, int* out_P,
+                                  void* stream) {
+  if (!out_G || !out_P) return TZR_ERR_INVALID;
+  return mlp2_bwd_partials(d_dhb, dhb_stride, d_hb, hb_stride, d_ha, ha_stride, d_x, x_stride, B, K0, H1, H2, d_Wb, ws, ws_bytes, out_G,
+                           out_P, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -10,7 +10,10 @@ tests compare against torch to 1e-6.
 from __future__ import annotations
 
 import contextlib
+import weakref
 from typing import Iterable, List, Optional
+
+import ctypes as C
 
 import torch
 
@@ -283,6 +286,96 @@ def _loss_is_root(gl: Optional[torch.Tensor] = None) -> bool:
     return one is not None and gl.data_ptr() == one.data_ptr()
 
 
+# ---- gradients left as partial sums for the optimizer's own launch (tzr_dense_adam_fused) ------------------------------------
+# With FusedDenseAdam(fuse_finish=True) as the dense optimizer the bottom MLP's backward and the first top-MLP layer's weight
+# gradient do not run their finishing launches: the tensors they return to autograd are UNWRITTEN, and what they stand for is
+# noted here under the tensor's address; `FusedDenseAdam.step` adds the partial sums up on its way to the parameter update
+# (same order of additions: bit-identical) and anything left over is written out by `materialize_pending`.  Who else reads such a
+# gradient before the optimizer has run -- clipping, a collective, gradient accumulation -- calls `materialize_pending()` first;
+# the flag is the caller's statement that nothing does.
+FUSE_FINISH = False
+# data_ptr of the returned gradient tensor -> (kind, keep-alive tensors, source fields, generation).  (NO reference to the tensor
+# itself: autograd hands a gradient over to `.grad` without a copy only when nobody else holds it -- a copy would be a copy of
+# unwritten memory under another address.  Claimed by address: `FusedDenseAdam.step` / `materialize_pending` look their tensors up.)
+_PENDING: dict = {}
+
+
+def _defer_finish(dev: torch.device, params=()) -> bool:
+    """leave this backward's parameter gradients as partial sums?  Only when the flag is up AND none of the parameters holds a
+    gradient already: autograd would ADD the new gradient to the old one -- an addition that reads the unwritten tensor."""
+    if not FUSE_FINISH or dev.type == "meta":
+        return False
+    held = [p.grad for p in params if getattr(p, "grad", None) is not None]
+    if held:
+        materialize_pending(held)  # (an earlier backward's gradient, still partial sums: written out before autograd adds to it)
+        return False
+    return True
+
+
+def _adam_tables(rows):
+    """rows: (param | None, grad, exp_avg | None, exp_avg_sq | None, state | None) -> the C arrays of tzr_dense_adam_fused"""
+    n = len(rows)
+    tab = (_lib.TzrAdamTensor * n)()
+    src = (_lib.TzrAdamSource * n)()
+    wg = None
+    keep = []
+    for i, (p, gr, m, v, st) in enumerate(rows):
+        tab[i].param = _lib.ptr(p) if p is not None else 0
+        tab[i].grad = _lib.ptr(gr)
+        tab[i].exp_avg = _lib.ptr(m) if m is not None else 0
+        tab[i].exp_avg_sq = _lib.ptr(v) if v is not None else 0
+        tab[i].state = _lib.ptr(st) if st is not None else 0
+        tab[i].numel = gr.numel()
+        pend = _PENDING.pop(gr.data_ptr(), None)
+        if pend is None:
+            src[i].kind = _lib.ADAM_SRC_TENSOR
+        elif pend[0] == "rows":
+            _, alive, (G, P, col), _gen = pend
+            if col + gr.numel() > P:  # an entry left behind by a tensor that is gone, its address reused: this gradient is a finished tensor
+                src[i].kind = _lib.ADAM_SRC_TENSOR
+                continue
+            src[i].kind, src[i].G, src[i].P, src[i].col, src[i].parts = _lib.ADAM_SRC_ROWS, G, P, col, _lib.ptr(alive[0])
+            keep.append(alive)
+        else:
+            _, alive, blob, _gen = pend
+            if wg is not None:  # (one slice set per launch: the first stays, this one is written out on its own below)
+                _PENDING[gr.data_ptr()] = pend
+                src[i].kind = -1
+                continue
+            src[i].kind, wg = _lib.ADAM_SRC_WGRAD, blob
+            keep.append(alive)
+    return tab, src, wg, keep
+
+
+_OPTIMIZERS: "weakref.WeakSet" = weakref.WeakSet()  # live FusedDenseAdam objects (materialize_pending's default reach)
+_GENERATION = [0]  # optimizer steps seen: an entry nobody has claimed two steps later belongs to a tensor that is gone
+
+
+def materialize_pending(tensors: Optional[Iterable[torch.Tensor]] = None) -> None:
+    """Write the gradients among `tensors` (default: the `.grad` of every parameter of every live FusedDenseAdam) that are
+    still sets of partial sums out as finished tensors (one launch per 32): for whoever needs them before -- or without --
+    `FusedDenseAdam.step`."""
+    if not _PENDING:
+        return
+    if tensors is None:
+        tensors = [p.grad for o in list(_OPTIMIZERS) for p in o.params if p.grad is not None]
+    todo = [t for t in tensors if t is not None and t.data_ptr() in _PENDING]
+    while todo:
+        rows, rest, has_wg = [], [], False
+        for t in todo:
+            is_wg = _PENDING[t.data_ptr()][0] == "wgrad"
+            if len(rows) == 32 or (is_wg and has_wg):  # (one slice set per launch)
+                rest.append(t)
+                continue
+            has_wg = has_wg or is_wg
+            rows.append((None, t, None, None, None))
+        tab, src, wg, keep = _adam_tables(rows)
+        _lib.check(_lib.lib().tzr_dense_adam_fused(tab, src, len(rows), C.byref(wg) if wg is not None else None, None, 0.0, 0.9, 0.999,
+                                                   1e-8, 0.0, _lib.stream_ptr(rows[0][1].device)), "tzr_dense_adam_fused")
+        del keep
+        todo = rest
+
+
 class _Mlp2Fn(torch.autograd.Function):
     """relu(relu(x Wa^T + ba) Wb^T + bb): forward in one launch, the four parameter gradients in one launch + a finish
     (tzr_mlp2_fwd / tzr_mlp2_bwd).  `x` is data (no input gradient): the bottom MLP of DLRM on the dense features."""
@@ -300,6 +393,7 @@ class _Mlp2Fn(torch.autograd.Function):
                                            _lib.stream_ptr(x.device)), "tzr_mlp2_fwd")
         ctx.save_for_backward(xs, ha, hb, Wb_)
         ctx.dims = (K0, H1, H2)
+        ctx.param_refs = (Wa, ba, Wb, bb)  # (backward looks at their `.grad`: see FUSE_FINISH)
         return hb
 
     @staticmethod
@@ -314,6 +408,18 @@ class _Mlp2Fn(torch.autograd.Function):
         dbb = torch.empty(H2, dtype=torch.float32, device=xs.device)
         L = _lib.lib()
         ws = _lib.workspace(L.tzr_mlp_workspace(), xs.device)
+        if _defer_finish(xs.device, ctx.param_refs):
+            # no finish launch: the four tensors stay unwritten, the optimizer's launch adds the partial rows up (row layout:
+            # [dWb | dbb | dWa | dba], include/tzrec_hip.h)
+            G, P = C.c_int(0), C.c_int(0)
+            _lib.check(L.tzr_mlp2_bwd_parts(_lib.ptr(g), g.stride(0), _lib.ptr(hb), hb.stride(0), _lib.ptr(ha), ha.stride(0), _lib.ptr(xs),
+                                            xs.stride(0), B, K0, H1, H2, _lib.ptr(Wb_), _lib.ptr(ws), ws.numel(), C.byref(G), C.byref(P),
+                                            _lib.stream_ptr(xs.device)), "tzr_mlp2_bwd_parts")
+            col = 0
+            for t in (dWb, dbb, dWa, dba):
+                _PENDING[t.data_ptr()] = ("rows", (ws,), (G.value, P.value, col), _GENERATION[0])
+                col += t.numel()
+            return None, dWa, dba, dWb, dbb
         _lib.check(L.tzr_mlp2_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(hb), hb.stride(0), _lib.ptr(ha), ha.stride(0), _lib.ptr(xs),
                                   xs.stride(0), B, K0, H1, H2, _lib.ptr(Wb_), _lib.ptr(dWa), _lib.ptr(dba), _lib.ptr(dWb),
                                   _lib.ptr(dbb), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(xs.device)), "tzr_mlp2_bwd")
@@ -444,6 +550,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
         ctx.save_for_backward(dense, sparse, W1_, g1, dW2, db2, dw3, scal, db1)
         ctx.z = z
         ctx.cfg = (F, D)
+        ctx.w1_ref = W1
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)  # (no zero tensor for the gradient of `logits`: a [B] fill per step)
         return scal[1], logits
@@ -466,7 +573,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
         if not ctx.needs_input_grad[3]:
             dW1 = None
         elif ctx.z is None:
-            dW1 = interaction_top_wgrad(dense, sparse, D, g1, gl32)
+            dW1 = interaction_top_wgrad(dense, sparse, D, g1, gl32, defer_for=(ctx.w1_ref,))
         else:
             dW1 = weight_grad(g1, ctx.z) if root else weight_grad(g1, ctx.z) * gl
         if root:
@@ -476,7 +583,7 @@ class _InteractionTopLossFn(torch.autograd.Function):
 
 
 def interaction_top_wgrad(dense: torch.Tensor, sparse: torch.Tensor, D: int, g1: torch.Tensor,
-                          scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          scale: Optional[torch.Tensor] = None, defer_for=None) -> torch.Tensor:
     """dW1 = scale * g1^T z [H, P + D n] of the Linear behind the dot interaction, z rebuilt from (dense, sparse) on the chip
     (tzr_dot_interaction_top_wgrad, csrc/interaction_wgrad.hip): autograd's weight gradient of the first `final_mlp` layer
     (/root/reference/tzrec/modules/mlp.py:58-83 behind models/dlrm.py:123-135) without the [B, P + D n] rows in HBM."""
@@ -490,6 +597,13 @@ def interaction_top_wgrad(dense: torch.Tensor, sparse: torch.Tensor, D: int, g1:
     dW = torch.empty(H, width, dtype=torch.float32, device=sparse.device)
     L = _lib.lib()
     ws = _lib.workspace(L.tzr_dot_interaction_top_wgrad_workspace(F, D, 1, H), sparse.device)
+    if defer_for is not None and _defer_finish(sparse.device, defer_for):  # no slice reduction launch: the optimizer's launch adds the slices up (see FUSE_FINISH)
+        blob = _lib.TzrWgradParts()
+        _lib.check(L.tzr_dot_interaction_top_wgrad_parts(
+            _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
+            _lib.ptr(scale), _lib.ptr(ws), ws.numel(), C.byref(blob), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_wgrad_parts")
+        _PENDING[dW.data_ptr()] = ("wgrad", (ws, scale), blob, _GENERATION[0])
+        return dW
     _lib.check(L.tzr_dot_interaction_top_wgrad(
         _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
         _lib.ptr(scale), _lib.ptr(dW), dW.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(sparse.device)),
@@ -533,15 +647,23 @@ def interaction_top_loss(dense, sparse, D, l1, l2, out_linear, labels):
 
 
 class FusedDenseAdam:
-    """torch.optim.Adam (amsgrad off) for the dense parameters, two launches per step regardless of the
-    number of tensors.  `param_groups[0]["lr"]` may be changed between steps (it is mirrored into a
+    """torch.optim.Adam (amsgrad off) for the dense parameters, ONE launch per step regardless of the
+    number of tensors (tzr_dense_adam_fused: a tensor's step count is moved on by the last of its workgroups).  `param_groups[0]["lr"]` may be changed between steps (it is mirrored into a
     device scalar, so a captured hipGraph sees the new value)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0) -> None:
+                 weight_decay: float = 0.0, fuse_finish: bool = False) -> None:
+        """`fuse_finish`: the backward passes that feed this optimizer leave their gradients as partial sums and `step` adds
+        them up inside its own launch (dense.FUSE_FINISH: three launches of the DLRM step fewer).  The caller's statement that
+        nothing reads a dense gradient between `loss.backward()` and `step()` (or calls `dense.materialize_pending()` first) and
+        that gradients are not accumulated over several backward passes."""
+        if fuse_finish:
+            global FUSE_FINISH
+            FUSE_FINISH = True
         self.params: List[torch.nn.Parameter] = [p for p in params]
         if not self.params:
             raise ValueError("no parameters")
+        _OPTIMIZERS.add(self)
         dev = self.params[0].device
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
@@ -551,7 +673,8 @@ class FusedDenseAdam:
         self.device = dev
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self._state = torch.zeros(len(self.params), 3, dtype=torch.float32, device=dev)  # per tensor: step, 1-b1^t, 1-b2^t
+        # per tensor: [0] step count, [1 ..] arrival counters of tzr_dense_adam_fused (TZR_ADAM_FUSED_STATE floats, zero between launches)
+        self._state = torch.zeros(len(self.params), 40, dtype=torch.float32, device=dev)
         self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self._lr_host = float(lr)
 
@@ -587,13 +710,20 @@ class FusedDenseAdam:
             rows.append((p, gr, self.exp_avg[i], self.exp_avg_sq[i], self._state[i]))
         if not rows:
             return
-        tab = (_lib.TzrAdamTensor * len(rows))()
-        for i, (p, gr, m, v, st) in enumerate(rows):
-            tab[i].param, tab[i].grad, tab[i].exp_avg, tab[i].exp_avg_sq = _lib.ptr(p.data), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v)
-            tab[i].state, tab[i].numel = _lib.ptr(st), p.numel()
         b1, b2 = g["betas"]
-        _lib.check(_lib.lib().tzr_dense_adam(tab, len(rows), _lib.ptr(self._lr_dev), g["lr"], b1, b2,
-                                             g["eps"], g["weight_decay"], _lib.stream_ptr(self.device)), "tzr_dense_adam")
+        for base in range(0, len(rows), 32):
+            tab, src, wg, keep = _adam_tables([(p.data, gr, m, v, st) for p, gr, m, v, st in rows[base:base + 32]])
+            if any(src[i].kind < 0 for i in range(len(tab))):  # (a second slice set in one launch: written out first)
+                materialize_pending([gr for _, gr, _, _, _ in rows[base:base + 32]])
+                tab, src, wg, keep = _adam_tables([(p.data, gr, m, v, st) for p, gr, m, v, st in rows[base:base + 32]])
+            _lib.check(_lib.lib().tzr_dense_adam_fused(tab, src, len(tab), C.byref(wg) if wg is not None else None, _lib.ptr(self._lr_dev),
+                                                       g["lr"], b1, b2, g["eps"], g["weight_decay"], _lib.stream_ptr(self.device)),
+                       "tzr_dense_adam_fused")
+            del keep
+        if _PENDING:  # (entries of tensors that are gone -- a gradient autograd dropped: unclaimed two steps later)
+            _GENERATION[0] += 1
+            for ptr in [q for q, e in _PENDING.items() if e[3] < _GENERATION[0] - 2]:
+                del _PENDING[ptr]
 
     def state_dict(self) -> dict:
         return {"state": {i: {"step": self._state[i, 0].clone(), "exp_avg": m, "exp_avg_sq": v}
@@ -601,12 +731,11 @@ class FusedDenseAdam:
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd: dict) -> None:
-        b1, b2 = self.param_groups[0]["betas"]
+        self._state[:, 1:].zero_()  # (tzr_dense_adam_fused's arrival counters: zero between launches)
         for i, st in sd["state"].items():
             self.exp_avg[int(i)].copy_(st["exp_avg"])
             self.exp_avg_sq[int(i)].copy_(st["exp_avg_sq"])
-            t = float(st["step"])
-            self._state[int(i)] = torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t])
+            self._state[int(i), 0] = float(st["step"])  # (the bias corrections are computed from it inside the launch)
         for k, v in sd["param_groups"][0].items():
             self.param_groups[0][k] = v
 

@@ -60,6 +60,9 @@ class GradientClippingOptimizer(OptimizerWrapper):
         self._global = bool(enable_global_grad_clip)
 
     def step(self, closure: Any = None) -> None:
+        from .dense import materialize_pending
+
+        materialize_pending([p.grad for p in _params_of(self._optimizer) if p.grad is not None])  # (clipping reads finished gradients)
         params = [p for p in _params_of(self._optimizer) if p.grad is not None]
         if params and self._clipping == "norm":
             torch.nn.utils.clip_grad_norm_(params, self._max_gradient, norm_type=self._norm_type)

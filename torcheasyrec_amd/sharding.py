@@ -1213,6 +1213,9 @@ class ShardedDLRM(nn.Module):
 
 
 def pack_dense_grads(grads: Sequence[torch.Tensor]) -> torch.Tensor:
+    from .dense import materialize_pending
+
+    materialize_pending(grads)  # (gradients a FusedDenseAdam(fuse_finish=True) would have taken as partial sums: the collective wants tensors)
     return torch.cat([g.reshape(-1) for g in grads])
 
 
