@@ -484,6 +484,28 @@ int tzr_linear_bwd_relu(const float* d_grad_in, int64_t grad_in_stride, const fl
                         const float* d_y, int64_t y_stride, int64_t N, int K, int H, float* d_grad_out,
                         int64_t grad_out_stride, float* d_colsum, void* ws, size_t ws_bytes, void* stream);
 
+/* Linear layers over a TALL input (every position of a sequence batch: the attention MLP of DIN on the jagged positions,
+ * tzrec/modules/sequence.py:101-128 over tzrec/modules/mlp.py:58-83) with the small weight matrix resident in registers, exact
+ * fp32 on the matrix cores (csrc/gemm_rows.hip).
+ *   tzr_linear_rows:  d_out[n, h] = act(sum_k d_in[n, k] * W(k, h) + d_bias[h] + d_rowvec[d_row_index[n], h])
+ *     w_out_major != 0: W(k, h) = d_w[h * w_stride + k]  (nn.Linear's weight [H, K]: the layer's forward, torch's addmm + ReLU);
+ *     w_out_major == 0: W(k, h) = d_w[k * w_stride + h]  (the input gradient g @ weight of a layer whose weight is [K, H]).
+ *     d_bias / d_rowvec may be NULL; d_rowvec [R, H] is a per-row addend gathered through d_row_index (int32 [N]) -- the part of a
+ *     layer over positions that depends on the SAMPLE only (DIN's query terms).  relu != 0: max(., 0).
+ *   tzr_linear_rows_wgrad:  d_dw[h, k] (+)= sum_n d_g[n, h] * d_x[n, k]  (autograd's weight gradient g^T x), partial sums of
+ *     <= 512 workgroups added in workgroup order by a second launch (deterministic; workspace from _wgrad_workspace).
+ * Shapes: *_supported (K, H multiples of 16 out of a fixed list up to 256; tzr_linear_rows_supported returns 3 where d_rowvec is
+ * taken too, 1 where only the plain form is built); strides in floats, multiples of 4; 16-byte aligned
+ * pointers.  TZR_ERR_UNSUPPORTED otherwise: the caller keeps its GEMM library call. */
+int tzr_linear_rows_supported(int K, int H);
+int tzr_linear_rows(const float* d_in, int64_t in_stride, const float* d_w, int64_t w_stride, int w_out_major,
+                    const float* d_bias, const float* d_rowvec, int64_t rowvec_stride, const int32_t* d_row_index, int relu,
+                    int64_t N, int K, int H, float* d_out, int64_t out_stride, void* stream);
+int tzr_linear_rows_wgrad_supported(int H, int K);
+size_t tzr_linear_rows_wgrad_workspace(int64_t N, int H, int K);
+int tzr_linear_rows_wgrad(const float* d_g, int64_t g_stride, const float* d_x, int64_t x_stride, int64_t N, int H, int K,
+                          float* d_dw, int64_t dw_stride, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 #define TZR_ADAM_MAX_TENSORS 32
 typedef struct TzrAdamTensor { /* one dense parameter tensor, device addresses, float32 */
   uint64_t param, grad, exp_avg, exp_avg_sq;
@@ -680,6 +702,17 @@ int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const float* d_kv,
                          const float* d_q, int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets,
                          int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
                          float* d_dq, int64_t dq_stride, void* stream);
+/* The same pair with the query's own block left out of the rows: X[n] = [k_n | q_b * k_n] (2 D wide).  The first attention
+ * layer W [q, k, q - k, q * k] = (Wb - Wc) k + Wd (q * k) + (Wa + Wc) q: its last term is one product per SAMPLE, added to the
+ * per-position product as tzr_linear_rows' gathered row vector -- a third less contraction length than the 3 D form above.
+ * Backward: dk_n (+)= dX_n[0:D] + q_b * dX_n[D:2D];  dq_b = sum_n k_n * dX_n[D:2D] + d_dq_add[b] (d_dq_add [B, D] or NULL: the
+ * query's gradient through that per-sample term). */
+int tzr_din_assemble2_fwd(const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride, const int32_t* d_seg, int64_t B,
+                          int64_t N, int D, float* d_X, int64_t x_stride, void* stream);
+int tzr_din_assemble2_bwd(const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride, const float* d_q,
+                          int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets, int64_t B, int64_t N, int D,
+                          float* d_dkv, int64_t dkv_stride, int accumulate_dkv, const float* d_dq_add, int64_t dq_add_stride,
+                          float* d_dq, int64_t dq_stride, void* stream);
 int tzr_din_attn_fwd(const float* d_h, int64_t h_stride, int H, const float* d_w, const float* d_bias,
                      const float* d_kv, int64_t kv_stride, int D, const int64_t* d_offsets, int64_t B,
                      int64_t max_len, float* d_out, int64_t out_stride, float* d_p, void* stream);

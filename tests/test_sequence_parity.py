@@ -141,8 +141,9 @@ def test_din_first_layer_split_equals_the_literal_input():
             torch.testing.assert_close(a_, b_, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("case", ["plain", "narrow_query", "truncated", "max_seq_length", "wide_hidden"])
-def test_din_jagged_positions_equal_the_padded_form(dev, case):
+@pytest.mark.parametrize("case", ["plain", "narrow_query", "truncated", "max_seq_length", "wide_hidden", "wide_hidden_library", "own_narrow_query",
+                                  "own_truncated"])
+def test_din_jagged_positions_equal_the_padded_form(dev, case, monkeypatch):
     """DINEncoder.forward_jagged (csrc/din_attention.hip: the attention MLP on the rows of the unpooled lookup, softmax and
     weighted sum per sample's rows) against the reference's evaluation on the padded [B, L, D] tensor with the literal
     [q, k, q - k, q * k] input (/root/reference/tzrec/modules/sequence.py:101-128): output and EVERY gradient -- query, sequence
@@ -156,13 +157,24 @@ def test_din_jagged_positions_equal_the_padded_form(dev, case):
         qd = 12
     if case == "max_seq_length":
         msl = 5
-    if case == "wide_hidden":
+    from torcheasyrec_amd import dense
+    from torcheasyrec_amd.sequence import _DinTowerFn
+
+    # "wide_hidden" / "own_*": widths the library's own tall-input products take (csrc/gemm_rows.hip: the query's block of the first
+    # layer once per sample) -- however few rows; "wide_hidden_library": the same widths through the GEMM library path
+    own = case in ("wide_hidden", "own_narrow_query", "own_truncated")
+    if case.startswith("wide_hidden") or own:
         D, qd, hidden = 48, 48, [256, 64]
+    if case == "own_narrow_query":
+        D, qd, hidden = 32, 20, [128, 64]
+    monkeypatch.setattr(dense, "ROWS_GEMM_MIN_ROWS", 0)
+    monkeypatch.setattr(dense, "OWN_ROWS_GEMM", case != "wide_hidden_library")
+    calls0 = _DinTowerFn.own_calls
     B = 23
     lens = rng.integers(0, L + 1, size=B)
     lens[[0, 7]] = 0
     lens[3] = 1
-    if case == "truncated":
+    if case in ("truncated", "own_truncated"):
         lens[[2, 11]] = [L + 4, L + 1]  # longer than the padded length
     lens = lens.astype(np.int64)
     N = int(lens.sum())
@@ -192,4 +204,5 @@ def test_din_jagged_positions_equal_the_padded_form(dev, case):
         # (the score layer's bias gradient is sum_n ds_n = 0 exactly -- a softmax does not see a shift of its scores: both
         # forms return rounding noise of the order of 1e-6 there)
         torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-5 if n == "linear.bias" else 2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    assert (_DinTowerFn.own_calls > calls0) == own
     assert bool((res["jagged"][0][[0, 7]] == 0).all())  # no position: zero output (the reference: uniform weights over zero padding rows)

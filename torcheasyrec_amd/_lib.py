@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 12  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 13  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -187,6 +187,8 @@ _SIGNATURES = {
     "tzr_jagged_segment_ids": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "tzr_din_assemble_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "tzr_din_assemble_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "tzr_din_assemble2_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
+    "tzr_din_assemble2_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
     "tzr_din_attn_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tzr_din_attn_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "tzr_comm_available": (_i32, [C.c_char_p]),
@@ -217,6 +219,11 @@ _SIGNATURES = {
     "tzr_skinny_linear_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "tzr_skinny_linear_bwd_workspace": (_sz, [_i64, _i32, _i32]),
     "tzr_skinny_linear_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_linear_rows_supported": (_i32, [_i32, _i32]),
+    "tzr_linear_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "tzr_linear_rows_wgrad_supported": (_i32, [_i32, _i32]),
+    "tzr_linear_rows_wgrad_workspace": (_sz, [_i64, _i32, _i32]),
+    "tzr_linear_rows_wgrad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _sz, _vp]),
     "tzr_linear_bwd_relu_supported": (_i32, [_i32, _i32]),
     "tzr_linear_bwd_relu_workspace": (_sz, [_i64, _i32]),
     "tzr_linear_bwd_relu": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),

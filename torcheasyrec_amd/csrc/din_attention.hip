@@ -48,6 +48,7 @@ extern "C" int tzr_jagged_segment_ids(const int64_t* d_offsets, int64_t B, int64
 }
 
 // thread = (position n, float4 chunk c of D)
+template <bool Q3 /* the query as a third block of the row */>
 __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_fwd_kernel(
     const float* __restrict__ kv, int64_t kvs, const float* __restrict__ q, int64_t qs, const int32_t* __restrict__ seg,
     int64_t B, int64_t N, int lg, float* __restrict__ X, int64_t xs) {
@@ -64,15 +65,14 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_fwd_kernel(
     float* xp = X + n * xs + 4 * c;
     tzr_st4(xp, kk);
     tzr_st4(xp + 4 * lg, make_float4(qq.x * kk.x, qq.y * kk.y, qq.z * kk.z, qq.w * kk.w));
-    tzr_st4(xp + 8 * lg, qq);
+    if (Q3) tzr_st4(xp + 8 * lg, qq);
   }
 }
 
-extern "C" int tzr_din_assemble_fwd(const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride,
-                                    const int32_t* d_seg, int64_t B, int64_t N, int D, float* d_X, int64_t x_stride,
-                                    void* stream) {
+static int din_assemble_fwd(bool q3, const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride, const int32_t* d_seg,
+                            int64_t B, int64_t N, int D, float* d_X, int64_t x_stride, void* stream) {
   if (B < 0 || N < 0 || D <= 0) return TZR_ERR_INVALID;
-  if ((D & 3) || (kv_stride & 3) || (q_stride & 3) || (x_stride & 3) || kv_stride < D || q_stride < D || x_stride < 3 * D)
+  if ((D & 3) || (kv_stride & 3) || (q_stride & 3) || (x_stride & 3) || kv_stride < D || q_stride < D || x_stride < (q3 ? 3 : 2) * D)
     return TZR_ERR_UNSUPPORTED;
   if (N == 0) return TZR_OK;
   if (!d_kv || !d_q || !d_seg || !d_X ||
@@ -80,10 +80,27 @@ extern "C" int tzr_din_assemble_fwd(const float* d_kv, int64_t kv_stride, const 
     return TZR_ERR_INVALID;
   const int64_t total = N * (D >> 2);
   const unsigned grid = (unsigned)std::min<int64_t>(16384, (total + DA_THREADS - 1) / DA_THREADS);
-  hipLaunchKernelGGL(tzr_din_assemble_fwd_kernel, dim3(grid), dim3(DA_THREADS), 0, static_cast<hipStream_t>(stream), d_kv, kv_stride,
-                     d_q, q_stride, d_seg, B, N, D >> 2, d_X, x_stride);
+  if (q3)
+    hipLaunchKernelGGL(tzr_din_assemble_fwd_kernel<true>, dim3(grid), dim3(DA_THREADS), 0, static_cast<hipStream_t>(stream), d_kv, kv_stride,
+                       d_q, q_stride, d_seg, B, N, D >> 2, d_X, x_stride);
+  else
+    hipLaunchKernelGGL(tzr_din_assemble_fwd_kernel<false>, dim3(grid), dim3(DA_THREADS), 0, static_cast<hipStream_t>(stream), d_kv,
+                       kv_stride, d_q, q_stride, d_seg, B, N, D >> 2, d_X, x_stride);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+extern "C" int tzr_din_assemble_fwd(const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride,
+                                    const int32_t* d_seg, int64_t B, int64_t N, int D, float* d_X, int64_t x_stride,
+                                    void* stream) {
+  return din_assemble_fwd(true, d_kv, kv_stride, d_q, q_stride, d_seg, B, N, D, d_X, x_stride, stream);
+}
+
+// X[n] = [ k_n | q_b * k_n ] only: the query's own block of the first layer is one product per SAMPLE (tzr_linear_rows' row vector)
+extern "C" int tzr_din_assemble2_fwd(const float* d_kv, int64_t kv_stride, const float* d_q, int64_t q_stride,
+                                     const int32_t* d_seg, int64_t B, int64_t N, int D, float* d_X, int64_t x_stride,
+                                     void* stream) {
+  return din_assemble_fwd(false, d_kv, kv_stride, d_q, q_stride, d_seg, B, N, D, d_X, x_stride, stream);
 }
 
 // dk: thread = (position, chunk).  `acc` != 0: dk is added to what d_dkv holds (the attention's direct part).
@@ -109,9 +126,10 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_k_kernel(
 // dq: one WAVE per sample (a thread per (sample, chunk) walking the sample's positions made the lanes of a wave wait for the
 // longest of their five samples: 77 us, profiles/r05x).  Lane (g, c): position group g = lane / lg of 64 / lg, chunk c; the
 // groups take positions g, g + G, ... and are added in group order at the end (fixed order: a function of the lengths alone).
+template <bool Q3>
 __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_q_kernel(
     const float* __restrict__ dX, int64_t xs, const float* __restrict__ kv, int64_t kvs, const int64_t* __restrict__ offsets,
-    int64_t B, int lg, float* __restrict__ dq, int64_t dqs) {
+    int64_t B, int lg, const float* __restrict__ add, int64_t adds, float* __restrict__ dq, int64_t dqs) {
   const int lane = threadIdx.x & (TZR_WAVE - 1);
   const int wv = threadIdx.x / TZR_WAVE;
   const int G = TZR_WAVE / lg;  // position groups of a wave (lg <= 64)
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_q_kernel(
     if (on)
       for (int64_t n = s + g; n < e; n += G) {
         const float* xp = dX + n * xs + 4 * c;
-        const float4 g1 = tzr_ld4(xp + 4 * lg), g2 = tzr_ld4(xp + 8 * lg), kk = tzr_ld4(kv + n * kvs + 4 * c);
+        const float4 g1 = tzr_ld4(xp + 4 * lg), g2 = Q3 ? tzr_ld4(xp + 8 * lg) : tzr_zero4(), kk = tzr_ld4(kv + n * kvs + 4 * c);
         a.x += fmaf(kk.x, g1.x, g2.x); a.y += fmaf(kk.y, g1.y, g2.y); a.z += fmaf(kk.z, g1.z, g2.z); a.w += fmaf(kk.w, g1.w, g2.w);
       }
     float4 t = a;  // group 0's lanes collect the groups in order
@@ -132,18 +150,22 @@ __global__ __launch_bounds__(DA_THREADS) void tzr_din_assemble_bwd_q_kernel(
       const float4 o = make_float4(__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src), __shfl(a.w, src));
       if (lane < lg) t = tzr_add4(t, o);
     }
-    if (lane < lg) tzr_st4(dq + b * dqs + 4 * lane, t);
+    if (lane < lg) {
+      if (add) t = tzr_add4(t, tzr_ld4(add + b * adds + 4 * lane));
+      tzr_st4(dq + b * dqs + 4 * lane, t);
+    }
   }
 }
 
-extern "C" int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride,
-                                    const float* d_q, int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets,
-                                    int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
-                                    float* d_dq, int64_t dq_stride, void* stream) {
+static int din_assemble_bwd(bool q3, const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride, const float* d_q,
+                            int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets, int64_t B, int64_t N, int D, float* d_dkv,
+                            int64_t dkv_stride, int accumulate_dkv, const float* d_dq_add, int64_t dq_add_stride, float* d_dq,
+                            int64_t dq_stride, void* stream) {
   if (B < 0 || N < 0 || D <= 0) return TZR_ERR_INVALID;
-  if ((D & 3) || D > 4 * TZR_WAVE || ((kv_stride | q_stride | x_stride | dkv_stride | dq_stride) & 3) || kv_stride < D || q_stride < D ||
-      x_stride < 3 * D || dkv_stride < D || dq_stride < D)
+  if ((D & 3) || D > 4 * TZR_WAVE || ((kv_stride | q_stride | x_stride | dkv_stride | dq_stride | dq_add_stride) & 3) || kv_stride < D ||
+      q_stride < D || x_stride < (q3 ? 3 : 2) * D || dkv_stride < D || dq_stride < D || (d_dq_add && dq_add_stride < D))
     return TZR_ERR_UNSUPPORTED;  // (D <= 256: a wave holds a row of the query gradient)
+  if (d_dq_add && (reinterpret_cast<uintptr_t>(d_dq_add) & 15)) return TZR_ERR_INVALID;
   if (B > 0 && (!d_offsets || !d_dq || (reinterpret_cast<uintptr_t>(d_dq) & 15))) return TZR_ERR_INVALID;
   if (N > 0 && (!d_dX || !d_kv || !d_q || !d_seg || !d_dkv ||
                 ((reinterpret_cast<uintptr_t>(d_dX) | reinterpret_cast<uintptr_t>(d_kv) | reinterpret_cast<uintptr_t>(d_q) |
@@ -158,11 +180,33 @@ extern "C" int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const f
   }
   if (B > 0) {
     const unsigned grid = (unsigned)std::min<int64_t>(16384, (B + DA_WAVES - 1) / DA_WAVES);
-    hipLaunchKernelGGL(tzr_din_assemble_bwd_q_kernel, dim3(grid), dim3(DA_THREADS), 0, s, d_dX, x_stride, d_kv, kv_stride, d_offsets,
-                       B, lg, d_dq, dq_stride);
+    if (q3)
+      hipLaunchKernelGGL(tzr_din_assemble_bwd_q_kernel<true>, dim3(grid), dim3(DA_THREADS), 0, s, d_dX, x_stride, d_kv, kv_stride,
+                         d_offsets, B, lg, d_dq_add, dq_add_stride, d_dq, dq_stride);
+    else
+      hipLaunchKernelGGL(tzr_din_assemble_bwd_q_kernel<false>, dim3(grid), dim3(DA_THREADS), 0, s, d_dX, x_stride, d_kv, kv_stride,
+                         d_offsets, B, lg, d_dq_add, dq_add_stride, d_dq, dq_stride);
   }
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+extern "C" int tzr_din_assemble_bwd(const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride,
+                                    const float* d_q, int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets,
+                                    int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
+                                    float* d_dq, int64_t dq_stride, void* stream) {
+  return din_assemble_bwd(true, d_dX, x_stride, d_kv, kv_stride, d_q, q_stride, d_seg, d_offsets, B, N, D, d_dkv, dkv_stride,
+                          accumulate_dkv, nullptr, 0, d_dq, dq_stride, stream);
+}
+
+// backward of tzr_din_assemble2_fwd: dk_n (+)= dX_n[0:D] + q_b * dX_n[D:2D];  dq_b = sum_n k_n * dX_n[D:2D] + d_dq_add[b]
+// (d_dq_add: the query's gradient through its own per-sample block of the first layer, or NULL)
+extern "C" int tzr_din_assemble2_bwd(const float* d_dX, int64_t x_stride, const float* d_kv, int64_t kv_stride,
+                                     const float* d_q, int64_t q_stride, const int32_t* d_seg, const int64_t* d_offsets,
+                                     int64_t B, int64_t N, int D, float* d_dkv, int64_t dkv_stride, int accumulate_dkv,
+                                     const float* d_dq_add, int64_t dq_add_stride, float* d_dq, int64_t dq_stride, void* stream) {
+  return din_assemble_bwd(false, d_dX, x_stride, d_kv, kv_stride, d_q, q_stride, d_seg, d_offsets, B, N, D, d_dkv, dkv_stride,
+                          accumulate_dkv, d_dq_add, dq_add_stride, d_dq, dq_stride, stream);
 }
 
 // ---- scores, softmax over a sample's positions, weighted sum of its rows: one wave per sample ------------------------

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(LB_THREADS) TZR_WAVES_PER_EU(3) void tzr_linear_bwd
 #pragma unroll
         for (int jb = 0; jb < HB; ++jb) acc[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wa[jb][4 * e + c], a4[c], acc[jb], 0, 0, 0);
     }
+    // (staged BEFORE this tile's stores are issued: behind stores under a row test the wait for nx would count short and become a
+    // wait for the stores themselves -- gemm_rows.hip)
+    if (tn < ntiles && stager) tzr_st4(&TA[buf ^ 1][trow * P + 4 * tc4], nx);
 #pragma unroll
     for (int jb = 0; jb < HB; ++jb) {
       float4 o;
@@ -100,7 +103,6 @@ __global__ __launch_bounds__(LB_THREADS) TZR_WAVES_PER_EU(3) void tzr_linear_bwd
       cs[jb] = tzr_add4(cs[jb], o);  // (rows beyond N: y read as 0 -> o = 0)
       if (ok) tzr_stg4(gout + row * gout_stride + cb + 16 * jb + 4 * q, o);
     }
-    if (tn < ntiles && stager) tzr_st4(&TA[buf ^ 1][trow * P + 4 * tc4], nx);
     tzr_lds_barrier();  // every wave is done with TA[buf]; TA[buf ^ 1] is complete (global loads / stores stay in flight)
     buf ^= 1;
   }

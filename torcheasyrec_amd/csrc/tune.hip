@@ -27,6 +27,7 @@ extern int g_tzr_wg_debug;
 extern int g_tzr_it_fwd_stagger;
 extern int g_tzr_mlp_mfma;
 extern int g_tzr_linear_bwd_wg;
+extern int g_tzr_gemm_rows_wg;
 
 extern "C" int tzr_tune(const char* name, int value) {
   if (!name) return TZR_ERR_INVALID;
@@ -96,6 +97,10 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "linear_bwd_wg")) {
     g_tzr_linear_bwd_wg = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "gemm_rows_wg")) {
+    g_tzr_gemm_rows_wg = value;
     return TZR_OK;
   }
   if (!strcmp(name, "it_stagger")) {

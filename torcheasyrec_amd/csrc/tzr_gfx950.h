@@ -51,6 +51,15 @@ __device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkm
 // reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
 #define TZR_OPAQUE(x) asm volatile("" : "+v"(x))
 
+// Keep four lane values in their registers up to this point.  gfx950 reads a vector store's data registers late: whatever
+// overwrites them first has to wait for the store to COMPLETE (hipcc puts `s_waitcnt vmcnt` there).  In a persistent loop
+// "store this turn's result, start the next turn" that wait lands on the next turn's first instruction that reuses one of those
+// registers -- a full memory round trip per turn with the matrix pipe idle (gemm_rows.hip: 20-30 % of the kernel).  Carrying the
+// stored values to a keep-alive a turn later makes the allocator give the next turn other registers.
+__device__ __forceinline__ void tzr_keep_alive4(float4 v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+// (the same for the store's address registers)
+__device__ __forceinline__ void tzr_keep_alive_ptr(const void* p) { asm volatile("" ::"v"(p)); }
+
 
 // Loads / stores through a pointer that is KNOWN to be device memory.  hipcc only knows that of a kernel's own pointer
 // arguments; a pointer read out of a descriptor (TzrTable.w, a destination list, an LDS copy of either) is generic, and
@@ -67,6 +76,8 @@ __device__ __forceinline__ float4 tzr_ldg4(const float* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void tzr_stg4(float* p, float4 v) { *(TZR_GLOBAL_AS tzr_f32x4*)p = tzr_f32x4{v.x, v.y, v.z, v.w}; }
+// streaming form: output that nobody on the chip reads again soon (nontemporal: no L2 allocation kept for it)
+__device__ __forceinline__ void tzr_stg4_nt(float* p, float4 v) { __builtin_nontemporal_store(tzr_f32x4{v.x, v.y, v.z, v.w}, (TZR_GLOBAL_AS tzr_f32x4*)p); }
 // 8 bytes (four fp16 of a half-precision table row, as two dwords)
 __device__ __forceinline__ uint2 tzr_ldg8(const void* p) {
   const tzr_u32x2 v = *(const TZR_GLOBAL_AS tzr_u32x2*)p;

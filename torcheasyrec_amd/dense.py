@@ -10,6 +10,7 @@ tests compare against torch to 1e-6.
 from __future__ import annotations
 
 import contextlib
+import os
 import weakref
 from typing import Iterable, List, Optional
 
@@ -216,6 +217,60 @@ def linear_bwd_relu(g_in: torch.Tensor, weight: torch.Tensor, y: torch.Tensor):
                                      _lib.ptr(g), g.stride(0), _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)),
                "tzr_linear_bwd_relu")
     return g, col
+
+
+# ---- Linear layers over a tall input with the weight resident in registers (csrc/gemm_rows.hip) --------------------------
+OWN_ROWS_GEMM = os.environ.get("TZR_OWN_ROWS_GEMM", "1") != "0"  # False: the GEMM library (A/B switch of the bench)
+ROWS_GEMM_MIN_ROWS = 4096  # below this many rows a launch of the library's small-tile kernels is as good
+
+
+def _al16(t: torch.Tensor) -> bool:
+    return t.data_ptr() % 16 == 0
+
+
+def linear_rows_supported(x: torch.Tensor, K: int, H: int) -> bool:
+    """x [N, >= K] fp32 with rows 16-byte aligned, (K, H) one of the shapes `tzr_linear_rows` is built for"""
+    return bool(OWN_ROWS_GEMM and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and _al16(x) and _lib.lib().tzr_linear_rows_supported(K, H))
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False, out_major: bool = True,
+                rowvec: Optional[torch.Tensor] = None, row_index: Optional[torch.Tensor] = None, K: Optional[int] = None) -> torch.Tensor:
+    """act(x[:, :K] @ W + bias + rowvec[row_index]) in one launch (tzr_linear_rows).  out_major: `weight` is nn.Linear's [H, K]
+    (the layer's forward); else `weight` is [K, H] (an input gradient g @ weight).  `K` < x.shape[1] reads the leading columns of
+    wider rows."""
+    N = x.shape[0]
+    if out_major:
+        H, Kw = weight.shape
+    else:
+        Kw, H = weight.shape
+    K = Kw if K is None else K
+    assert K == Kw and weight.stride(1) == 1
+    out = torch.empty(N, H, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tzr_linear_rows(_lib.ptr(x), x.stride(0), _lib.ptr(weight), weight.stride(0), 1 if out_major else 0,
+                                          _lib.ptr(bias) if bias is not None else None, _lib.ptr(rowvec) if rowvec is not None else None,
+                                          rowvec.stride(0) if rowvec is not None else 0, _lib.ptr(row_index) if row_index is not None else None,
+                                          1 if relu else 0, N, K, H, _lib.ptr(out), out.stride(0), _lib.stream_ptr(x.device)), "tzr_linear_rows")
+    return out
+
+
+def linear_rows_wgrad_supported(g: torch.Tensor, x: torch.Tensor, K: Optional[int] = None) -> bool:
+    K = x.shape[1] if K is None else K
+    ok = lambda t: t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and _al16(t)
+    return bool(OWN_ROWS_GEMM and g.shape[0] > 0 and ok(g) and ok(x) and _lib.lib().tzr_linear_rows_wgrad_supported(g.shape[1], K))
+
+
+def linear_rows_wgrad(g: torch.Tensor, x: torch.Tensor, K: Optional[int] = None) -> torch.Tensor:
+    """g^T x[:, :K] ([H, N] x [N, K]): the weight gradient of a Linear layer over a tall input (tzr_linear_rows_wgrad: partial sums
+    per workgroup, added in workgroup order -- deterministic)"""
+    N, H = g.shape
+    K = x.shape[1] if K is None else K
+    L = _lib.lib()
+    dw = torch.empty(H, K, dtype=torch.float32, device=g.device)
+    ws = _lib.workspace(L.tzr_linear_rows_wgrad_workspace(N, H, K), g.device)
+    _lib.check(L.tzr_linear_rows_wgrad(_lib.ptr(g), g.stride(0), _lib.ptr(x), x.stride(0), N, H, K, _lib.ptr(dw), dw.stride(0), 0, _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_ptr(g.device)), "tzr_linear_rows_wgrad")
+    return dw
 
 
 # ---- small layer stacks as whole-stack kernels (csrc/mlp_ops.hip) -------------------------------------------------

@@ -345,6 +345,9 @@ class _DinTowerFn(torch.autograd.Function):
         dev = values.device
         L = _lib.lib()
         stream = _lib.stream_ptr(dev)
+        if _DinTowerFn._own_products(values, query, wb):
+            return _DinTowerFn._forward_own(ctx, values, query, offsets, max_len, w3, b3, wb)
+        ctx.own = False
         Np = (N + row_bucket - 1) // row_bucket * row_bucket
         seg = jagged_segment_ids(offsets, Np)
         X = torch.empty(max(Np, 1), 3 * D, dtype=torch.float32, device=dev)
@@ -369,10 +372,117 @@ class _DinTowerFn(torch.autograd.Function):
         ctx.cfg = (max_len, len(Ws), b3 is not None)
         return out[:B]
 
+    # ---- the same tower with its products on the library's own tall-input kernels (csrc/gemm_rows.hip) and the query's block of
+    # the first layer taken once per SAMPLE: W1 [q, k, q - k, q * k] = (Wb - Wc) k + Wd (q * k) + [(Wa + Wc) q + b1], the bracket a
+    # [B, H1] product whose rows the per-position kernel gathers.  No row bucket (no library to key by shape), no GEMM library call.
+    @staticmethod
+    def _own_products(values, query, wb) -> bool:
+        from . import dense
+        from .dense import linear_rows_supported, linear_rows_wgrad_supported
+
+        N, D = values.shape
+        if N < dense.ROWS_GEMM_MIN_ROWS and values.is_cuda or N == 0 or query.shape[0] == 0 or len(wb) < 4:
+            return False
+        L = _lib.lib()
+        Hs = [w.shape[0] for w in wb[0::2]]
+        Ks = [2 * D] + Hs[:-1]
+        if wb[0].shape[1] != 4 * D or not L.tzr_linear_rows_supported(D, Hs[0]) or not L.tzr_linear_rows_supported(Hs[0], D) \
+                or not L.tzr_linear_rows_wgrad_supported(Hs[0], D):
+            return False
+        for i, (K, H) in enumerate(zip(Ks, Hs)):
+            if not (L.tzr_linear_rows_supported(K, H) and L.tzr_linear_rows_wgrad_supported(H, K)):
+                return False
+            if i == 0 and not (L.tzr_linear_rows_supported(K, H) & 2 and L.tzr_linear_rows_supported(H, K)):  # row-vector form; its input gradient
+                return False
+            if i > 0 and not L.tzr_linear_bwd_relu_supported(H, K):
+                return False
+        return linear_rows_supported(values, D, Hs[0]) and values.dtype == torch.float32 and all(w.dtype == torch.float32 for w in wb)
+
+    own_calls = 0  # forwards that took the library's own products (tests)
+
+    @staticmethod
+    def _forward_own(ctx, values, query, offsets, max_len, w3, b3, wb):
+        from .dense import linear_rows
+
+        _DinTowerFn.own_calls += 1
+
+        N, D = values.shape
+        B = offsets.numel() - 1
+        dev = values.device
+        L = _lib.lib()
+        stream = _lib.stream_ptr(dev)
+        seg = jagged_segment_ids(offsets, N)
+        X = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_assemble2_fwd(_lib.ptr(values), values.stride(0), _lib.ptr(query), query.stride(0), _lib.ptr(seg), B, N, D,
+                                           _lib.ptr(X), X.stride(0), stream), "tzr_din_assemble2_fwd")
+        Ws = [w.detach() for w in wb[0::2]]
+        bs = [b_.detach() for b_ in wb[1::2]]
+        W1 = Ws[0]
+        Wq = (W1[:, :D] + W1[:, 2 * D:3 * D]).contiguous()                                  # [H1, D]
+        Ws[0] = torch.cat([W1[:, D:2 * D] - W1[:, 2 * D:3 * D], W1[:, 3 * D:]], dim=1)      # [H1, 2 D]
+        hq = linear_rows(query, Wq, bs[0])                                                   # [B, H1]: (Wa + Wc) q + b1
+        x, hs = X, []
+        for i, (w, b_) in enumerate(zip(Ws, bs)):
+            x = linear_rows(x, w, None, relu=True, rowvec=hq, row_index=seg) if i == 0 else linear_rows(x, w, b_, relu=True)
+            hs.append(x)
+        H = x.shape[1]
+        w3v = w3.detach().reshape(-1).contiguous()
+        out = torch.empty(max(B, 1), D, dtype=torch.float32, device=dev)
+        p = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_attn_fwd(_lib.ptr(x), x.stride(0), H, _lib.ptr(w3v), _lib.ptr(b3), _lib.ptr(values), values.stride(0), D,
+                                      _lib.ptr(offsets), B, max_len, _lib.ptr(out), out.stride(0), _lib.ptr(p), stream), "tzr_din_attn_fwd")
+        ctx.save_for_backward(values, query, offsets, seg, p, w3, X, Wq, *Ws, *hs)
+        ctx.cfg = (max_len, len(Ws), b3 is not None)
+        ctx.own = True
+        return out[:B]
+
+    @staticmethod
+    def _backward_own(ctx, gout):
+        from .dense import head_bwd_relu, linear_bwd_relu, linear_rows, linear_rows_wgrad
+
+        max_len, nl, has_b3 = ctx.cfg
+        values, query, offsets, seg, p, w3, X, Wq = ctx.saved_tensors[:8]
+        Ws, hs = ctx.saved_tensors[8:8 + nl], ctx.saved_tensors[8 + nl:]
+        N, D = values.shape
+        B = offsets.numel() - 1
+        dev = values.device
+        L = _lib.lib()
+        stream = _lib.stream_ptr(dev)
+        gout = gout.contiguous()
+        ds = torch.empty(N, dtype=torch.float32, device=dev)
+        dkv = torch.empty(N, D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_attn_bwd(_lib.ptr(gout), gout.stride(0), _lib.ptr(p), _lib.ptr(values), values.stride(0), D, _lib.ptr(offsets), B,
+                                      max_len, _lib.ptr(ds), _lib.ptr(dkv), dkv.stride(0), stream), "tzr_din_attn_bwd")
+        g, dw3, db3, gb = head_bwd_relu(ds, hs[-1], w3)
+        grads_wb = [None] * (2 * nl)
+        for i in range(nl - 1, 0, -1):  # g = the gradient at layer i's pre-activation, gb = its column sums
+            grads_wb[2 * i] = linear_rows_wgrad(g, hs[i - 1])
+            grads_wb[2 * i + 1] = gb
+            g, gb = linear_bwd_relu(g, Ws[i], hs[i - 1])
+        # first layer: its per-position block [Wb - Wc | Wd] and, through the per-sample sums of g, the query's block Wa + Wc
+        dWk = linear_rows_wgrad(g, X)                                   # [H1, 2 D]
+        dX = linear_rows(g, Ws[0], out_major=False)                     # [N, 2 D]
+        H1 = g.shape[1]
+        dhq = torch.empty(max(B, 1), H1, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_segment_reduce_fwd(_lib.ptr(g), g.stride(0), _lib.ptr(offsets), B, H1, 0, _lib.ptr(dhq), dhq.stride(0), stream),
+                   "tzr_segment_reduce_fwd")
+        dhq = dhq[:B]
+        dWq = linear_rows_wgrad(dhq, query)                             # [H1, D]
+        dq_add = linear_rows(dhq, Wq, out_major=False)                  # [B, D]
+        grads_wb[0] = torch.cat([dWq, dWk[:, :D], dWq - dWk[:, :D], dWk[:, D:]], dim=1)  # [dWa | dWb | dWc | dWd]
+        grads_wb[1] = gb
+        dq = torch.empty(max(B, 1), D, dtype=torch.float32, device=dev)
+        _lib.check(L.tzr_din_assemble2_bwd(_lib.ptr(dX), dX.stride(0), _lib.ptr(values), values.stride(0), _lib.ptr(query), query.stride(0),
+                                           _lib.ptr(seg), _lib.ptr(offsets), B, N, D, _lib.ptr(dkv), dkv.stride(0), 1, _lib.ptr(dq_add),
+                                           dq_add.stride(0), _lib.ptr(dq), dq.stride(0), stream), "tzr_din_assemble2_bwd")
+        return (dkv, dq[:B], None, None, None, dw3.reshape(w3.shape), (db3 if has_b3 else None), *grads_wb)
+
     @staticmethod
     def backward(ctx, gout):
         from .dense import head_bwd_relu, linear_bwd_relu, linear_bwd_relu_supported, relu_bwd_colsum, weight_grad
 
+        if ctx.own:
+            return _DinTowerFn._backward_own(ctx, gout)
         max_len, nl, has_b3 = ctx.cfg
         values, query, offsets, seg, p, w3, X = ctx.saved_tensors[:7]
         Ws, hs = ctx.saved_tensors[7:7 + nl], ctx.saved_tensors[7 + nl:]
