@@ -4,7 +4,7 @@
 tag=${1:-r06r}; out=gpurun_out/$tag; mkdir -p $out
 timeout 900 python -m pytest tests/test_gemm_rows.py tests/test_sequence_parity.py tests/test_reference_module_vectors.py tests/test_dense_glue.py -x -q -m gpu > $out/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $out/gpu_tests.log
 PYTORCH_TUNABLEOP_ENABLED=0 timeout 600 python scripts/r06/rows_gemm_bench.py > $out/rows_gemm_bench.txt 2>&1; echo "bench rc=$?"
-for v in ${VARIANTS:-ntstore}; do
+for v in ${VARIANTS:-}; do
   PYTORCH_TUNABLEOP_ENABLED=0 ROWS_LIB=libtzrec_hip_$v.so ROWS_NO_CHECK=1 timeout 600 python scripts/r06/rows_gemm_bench.py > $out/rows_gemm_bench_$v.txt 2>&1; echo "$v rc=$?"
 done
 for f in $out/rows_gemm_bench*.txt; do echo "== $f"; grep -v amdgpu.ids $f | cut -c1-100; done

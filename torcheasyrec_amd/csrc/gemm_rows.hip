@@ -82,28 +82,34 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
   }
   const int64_t nturns = (N + ROWS - 1) / ROWS;
   const int64_t last = N - 1;
-  // rows beyond N are read as row N - 1 (an output row depends on its own input row only, and theirs are not stored)
+  // Addresses = a UNIFORM base of the turn (scalar registers, scalar arithmetic) + a lane offset that never changes (one
+  // register per piece): no vector instruction per load -- the fp32 matrix pipe and the vector ALU are one pipe, every VALU
+  // instruction of the turn is time taken from the products (variants without any memory access ran no faster: profiles/r06w).
+  // Rows beyond N (the last turn only) are read as row N - 1: an output row depends on its own input row only, and theirs go
+  // to row N - 1's address with row N - 1's bits.
+  const int rows_last = (int)(N - (nturns - 1) * ROWS);  // rows of the last turn, 1 .. ROWS
+  uint32_t poff[NST], poff_tail[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    poff[i] = (uint32_t)(srow[i] * (int)in_stride + 4 * sc4[i]);
+    poff_tail[i] = (uint32_t)((srow[i] < rows_last ? srow[i] : rows_last - 1) * (int)in_stride + 4 * sc4[i]);
+  }
   auto fetch = [&](int64_t turn, int i) -> float4 {
-    const int64_t row = std::min<int64_t>(turn * ROWS + srow[i], last);
-    return tzr_ldg4(in + row * in_stride + 4 * sc4[i]);
+#ifdef GR_NO_LOAD  // (experiment)
+    return make_float4((float)turn, 1.f, 2.f, (float)i);
+#endif
+    const float* const base = in + turn * ROWS * in_stride;  // uniform
+    return tzr_ldg4(base + (turn == nturns - 1 ? poff_tail[i] : poff[i]));
   };
   int64_t t = blockIdx.x;
   const int irow = (int)threadIdx.x % ROWS;  // the row whose index this thread stages (threads >= ROWS repeat: same value, no branch)
   if (t < nturns) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) tzr_st4(&TA[0][srow[i] * P + 4 * sc4[i]], fetch(t, i));
-    if (RV) TI[0][irow] = row_index[std::min<int64_t>(t * ROWS + irow, last)];
+    if (RV) TI[0][irow] = row_index[t * ROWS + (t == nturns - 1 ? (irow < rows_last ? irow : rows_last - 1) : irow)];
   }
   __syncthreads();
   int buf = 0;
-  float4 kept[TT][HB];  // last turn's stored values and their addresses (tzr_keep_alive4)
-  float* keptp[TT];
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) keptp[tt] = out;
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-    for (int jb = 0; jb < HB; ++jb) kept[tt][jb] = tzr_zero4();
   for (; t < nturns; t += gridDim.x) {
     const int64_t tn = std::min<int64_t>(t + gridDim.x, nturns - 1);  // (the last turn's prefetch repeats a turn: never staged twice into a buffer in use)
     float4 nx[NST];
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
     float4 rv[TT][HB];
     int32_t nxi = 0;
     if (RV) {
-      nxi = row_index[std::min<int64_t>(tn * ROWS + irow, last)];
+      nxi = row_index[tn * ROWS + (tn == nturns - 1 ? (irow < rows_last ? irow : rows_last - 1) : irow)];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         const float* const rp = rowvec + (int64_t)TI[buf][tt * GR_TS + r] * rowvec_stride + cb + 4 * q;
@@ -132,8 +138,12 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
     float4 pa[TT][2];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
+#ifdef GR_NO_LDS  // (experiment: operands from registers)
+      pa[tt][0] = pa[tt][1] = make_float4((float)lane, 1.f, (float)t, 3.f);
+#else
       pa[tt][0] = tzr_ld4(A + tt * GR_TS * P);
       pa[tt][1] = tzr_ld4(A + tt * GR_TS * P + (E > 1 ? 16 : 0));
+#endif
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -142,7 +152,9 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
       for (int tt = 0; tt < TT; ++tt) {
         const float4 av = pa[tt][e & 1];
         a4[tt][0] = av.x, a4[tt][1] = av.y, a4[tt][2] = av.z, a4[tt][3] = av.w;
+#ifndef GR_NO_LDS
         if (e + 2 < E) pa[tt][e & 1] = tzr_ld4(A + tt * GR_TS * P + 16 * (e + 2));
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -154,13 +166,6 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
             acc[tt][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wa[jb][4 * e + c], a4[tt][c], acc[tt][jb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // last turn's store data stayed in its registers until here: its stores completed long ago
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-      for (int jb = 0; jb < HB; ++jb) tzr_keep_alive4(kept[tt][jb]);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) tzr_keep_alive_ptr(keptp[tt]);
     // the next turn's rows into the other buffer BEFORE this turn's stores are issued: the wait for those loads must not become
     // a wait for the stores (stores behind a row test: at the join the compiler has to assume none was issued and counts short)
 #pragma unroll
@@ -171,18 +176,13 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
     // been issued: the row-index prefetch below would wait for this turn's stores.)
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
-      const int64_t row = std::min<int64_t>(t * ROWS + tt * GR_TS + r, last);
-      float* op = out + row * out_stride + cb + 4 * q;
-      TZR_OPAQUE(op);  // (the registers the stores read ARE the ones kept: see tzr_keep_alive4)
+      const int rl = t == nturns - 1 ? (tt * GR_TS + r < rows_last ? tt * GR_TS + r : rows_last - 1) : tt * GR_TS + r;
+      float* op = out + t * ROWS * out_stride + (uint32_t)(rl * (int)out_stride + cb + 4 * q);
 #pragma unroll
       for (int jb = 0; jb < HB; ++jb) {
         float4 o = make_float4(acc[tt][jb][0], acc[tt][jb][1], acc[tt][jb][2], acc[tt][jb][3]);
         if (RV) o = tzr_add4(o, rv[tt][jb]);
-        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        TZR_OPAQUE(o.x);
-        TZR_OPAQUE(o.y);
-        TZR_OPAQUE(o.z);
-        TZR_OPAQUE(o.w);
+        if (relu) o = make_float4(tzr_relu(o.x), tzr_relu(o.y), tzr_relu(o.z), tzr_relu(o.w));
 #ifdef GR_NO_STORE  // (experiment: what the stores cost -- none is issued, the compiler cannot know)
         if (o.x == 12345.678f)
 #endif
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(WAVES* TZR_WAVE) TZR_WAVES_PER_EU(WPE) void tzr_gem
 #else
         tzr_stg4(op + 16 * jb, o);
 #endif
-        kept[tt][jb] = o;
       }
-      keptp[tt] = op;
     }
+#ifndef GR_NO_BARRIER  // (experiment: wrong results, the turn without its synchronisation)
     tzr_lds_barrier();  // every wave is done with TA[buf]; TA[buf ^ 1] is complete (global loads / stores stay in flight)
+#endif
     buf ^= 1;
   }
 }
@@ -344,12 +344,12 @@ struct RowsCfg { int K, H, HB, WAVES, TT, WPE, RV; };
   X(32, 64, 1, 4, 2, 3, 1) \
   X(32, 128, 2, 4, 1, 3, 1) \
   X(32, 256, 4, 4, 1, 3, 1) \
-  X(64, 16, 1, 1, 1, 3, 1) \
-  X(128, 16, 1, 1, 1, 3, 1) \
-  X(256, 16, 1, 1, 1, 1, 1) \
-  X(64, 32, 1, 2, 1, 3, 1) \
-  X(128, 32, 1, 2, 1, 3, 1) \
-  X(256, 32, 1, 2, 1, 2, 1) \
+  X(64, 16, 1, 1, 1, 3, 0) \
+  X(128, 16, 1, 1, 1, 3, 0) \
+  X(256, 16, 1, 1, 1, 1, 0) \
+  X(64, 32, 1, 2, 1, 3, 0) \
+  X(128, 32, 1, 2, 1, 3, 0) \
+  X(256, 32, 1, 2, 1, 2, 0) \
   X(48, 64, 1, 4, 2, 3, 1) \
   X(48, 128, 2, 4, 1, 3, 1) \
   X(48, 256, 4, 4, 1, 3, 1) \
@@ -371,18 +371,18 @@ struct RowsCfg { int K, H, HB, WAVES, TT, WPE, RV; };
   X(256, 64, 1, 4, 2, 2, 1) \
   X(256, 128, 2, 4, 1, 2, 1) \
   X(256, 256, 2, 8, 1, 2, 1) \
-  X(64, 48, 1, 3, 2, 3, 1) \
-  X(64, 96, 1, 6, 1, 3, 1) \
-  X(64, 144, 3, 3, 1, 3, 1) \
-  X(64, 192, 3, 4, 1, 3, 1) \
-  X(128, 48, 1, 3, 2, 3, 1) \
-  X(128, 96, 1, 6, 1, 3, 1) \
-  X(128, 144, 3, 3, 1, 2, 1) \
-  X(128, 192, 3, 4, 1, 2, 1) \
-  X(256, 48, 1, 3, 2, 2, 1) \
-  X(256, 96, 1, 6, 1, 3, 1) \
-  X(256, 144, 1, 9, 1, 3, 1) \
-  X(256, 192, 2, 6, 1, 2, 1)
+  X(64, 48, 1, 3, 2, 3, 0) \
+  X(64, 96, 1, 6, 1, 3, 0) \
+  X(64, 144, 3, 3, 1, 3, 0) \
+  X(64, 192, 3, 4, 1, 3, 0) \
+  X(128, 48, 1, 3, 2, 3, 0) \
+  X(128, 96, 1, 6, 1, 3, 0) \
+  X(128, 144, 3, 3, 1, 2, 0) \
+  X(128, 192, 3, 4, 1, 2, 0) \
+  X(256, 48, 1, 3, 2, 2, 0) \
+  X(256, 96, 1, 6, 1, 3, 0) \
+  X(256, 144, 1, 9, 1, 3, 0) \
+  X(256, 192, 2, 6, 1, 2, 0)
 constexpr RowsCfg kRows[] = {
 #define GR_ROW(K_, H_, HB_, W_, TT_, WPE_, RV_) {K_, H_, HB_, W_, TT_, WPE_, RV_},
     GR_ROWS_CONFIGS(GR_ROW)

@@ -51,14 +51,12 @@ __device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkm
 // reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
 #define TZR_OPAQUE(x) asm volatile("" : "+v"(x))
 
-// Keep four lane values in their registers up to this point.  gfx950 reads a vector store's data registers late: whatever
-// overwrites them first has to wait for the store to COMPLETE (hipcc puts `s_waitcnt vmcnt` there).  In a persistent loop
-// "store this turn's result, start the next turn" that wait lands on the next turn's first instruction that reuses one of those
-// registers -- a full memory round trip per turn with the matrix pipe idle (gemm_rows.hip: 20-30 % of the kernel).  Carrying the
-// stored values to a keep-alive a turn later makes the allocator give the next turn other registers.
-__device__ __forceinline__ void tzr_keep_alive4(float4 v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-// (the same for the store's address registers)
-__device__ __forceinline__ void tzr_keep_alive_ptr(const void* p) { asm volatile("" ::"v"(p)); }
+// max(x, 0) as ONE instruction (fmaxf is two: it quiets a signalling NaN first; a NaN comes out as 0 here)
+__device__ __forceinline__ float tzr_relu(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
 
 
 // Loads / stores through a pointer that is KNOWN to be device memory.  hipcc only knows that of a kernel's own pointer
