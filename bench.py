@@ -732,7 +732,7 @@ def main():
 
         # (one GPU: the bottom MLP's and the first top-MLP layer's gradients stay partial sums until the optimizer's own launch adds
         # them up -- dense.FUSE_FINISH; the sharded step packs its dense gradients for the all-reduce: finished tensors there)
-        dense_opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-3, fuse_finish=not sharded and not args.no_fuse_finish)
+        dense_opt = FusedDenseAdam(list(model.dense_parameters()), lr=1e-3, fuse_finish=not args.no_fuse_finish)
 
     # synthetic batches, resident in HBM before the timed region
     from torcheasyrec_amd.sparse import KeyedJaggedTensor

@@ -533,6 +533,8 @@ int tzr_dense_adam(const TzrAdamTensor* h_tensors, int n_tensors, const float* d
  * tensor's workgroups arrive in groups of 32, the last one moves the step on and clears them) -- not interchangeable with
  * tzr_dense_adam's float[3] on the same tensor.
  * A tensor with param == 0 only gets its finished gradient stored into `grad` (for a caller that needs the tensor after all).
+ * TZR_ADAM_SRC_TENSOR with `parts` != 0: the finished gradient is read from `parts` instead of `grad` -- with param == 0 a copy,
+ * which makes ONE store-only call the packing of a model's gradients (finished or not) into a flat buffer for a collective.
  * h_sources NULL: every gradient is a finished tensor. */
 #define TZR_ADAM_FUSED_STATE 40 /* 1 step + 1 + 32 counters (<= 1024 workgroups per tensor), padded */
 #define TZR_ADAM_SRC_TENSOR 0

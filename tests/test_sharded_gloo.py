@@ -1161,15 +1161,23 @@ def _slots_worker(rank, world, init_file, emu_path):
     os.environ["TZR_RCCL_PATH"] = os.path.join(os.path.dirname(emu_path), "librccl_stub.so")
     native = {"step_graph": True, "graph_input_dist": True, "native_driver": True, "use_graph": True, "graph_factory": EmuGraph,
               "warmup_iters": 0}
+    # "*_fused": FusedDenseAdam(fuse_finish=True) -- the dense backward leaves partial sums, `pack_dense_grads` adds them up on
+    # their way into the all-reduce's flat buffer in ONE launch (dense.pack_gradients): the same run, bit for bit
     for name, kw, skw in (("exact", {}, {}), ("capacity", cap, {"step_graph": True, "overlap_collectives": False}),
                           ("capacity_overlap", cap, {"step_graph": True}),  # the six-segment order
-                          ("native", cap, native), ("native_side", cap, dict(native, input_dist_stream="side"))):
+                          ("native", cap, native), ("native_side", cap, dict(native, input_dist_stream="side")),
+                          ("exact_fused", {}, {}), ("native_fused", cap, native)):
         torch.manual_seed(7)
         model = ShardedDLRM(criteo_tables(rows, init="seeded"), keys, NUM_DENSE, device=dev, dp_max_rows=100,
                             sparse_optimizer=SparseOptimizerConfig(kind="rowwise_adagrad", lr=0.05), **kw)
         model.ebc.capacity_slack = 8
-        ts = ShardedTrainStep(model, FusedDenseAdam(list(model.dense_parameters()), lr=1e-2), **skw)
+        from torcheasyrec_amd import dense as _dense
+        packs0, parts0 = _dense.PACKED_LAUNCHES[0], _dense.PACKED_PARTIALS[0]
+        ts = ShardedTrainStep(model, FusedDenseAdam(list(model.dense_parameters()), lr=1e-2, fuse_finish=name.endswith("_fused")), **skw)
         losses = [float(ts.step(*batches[i], next_kjt=batches[i + 1][1] if i + 1 < steps else None)) for i in range(steps)]
+        assert _dense.PACKED_LAUNCHES[0] > packs0  # (every form packs through the one launch; the fused ones with partial sums in it)
+        if name.endswith("_fused"):  # every eager step and every capture packed partial sums (replays run no Python)
+            assert _dense.PACKED_PARTIALS[0] - parts0 >= (steps if name == "exact_fused" else 3), (name, _dense.PACKED_PARTIALS[0] - parts0)
         runs[name] = (losses, {n: w.detach().clone() for n, w in model.ebc.table_weights().items()},
                       [p.detach().clone() for p in model.dense_parameters()], dict(model.ebc.exchange_stats), ts.graph_steps, ts.eager_steps)
         if name.startswith("native"):
@@ -1180,12 +1188,18 @@ def _slots_worker(rank, world, init_file, emu_path):
             assert len(ts._slots) == 2 and all(len(sl["graph"]) == 1 and len(sl["in_graphs"]) == 1 and len(sl["program"]) == 1
                                                for sl in ts._slots.values())
             assert ts.native_steps == steps - 1 - 2, ts.native_steps  # (two capture steps, one overflowing batch stepped exactly)
-            assert ts._input_dist_on_main() == (name == "native" and world > 1)
+            assert ts._input_dist_on_main() == (name != "native_side" and world > 1)
     assert ts.overlap_collectives
     for other in ("capacity", "capacity_overlap", "native", "native_side"):
         # (world 2: a + b in any order -- bit for bit against gloo's all-reduce too; larger worlds: the stand-in adds in rank
         # order, gloo in ring order: the dense weights agree to rounding there, everything else still bit for bit)
         _check_slots_run(runs["exact"], runs[other], steps, exact_dense=not (other.startswith("native") and world > 2))
+    for plain, fused in (("exact", "exact_fused"), ("native", "native_fused")):
+        assert runs[plain][0] == runs[fused][0], (plain, runs[plain][0], runs[fused][0])
+        for a, b in zip(runs[plain][2], runs[fused][2]):
+            assert torch.equal(a, b)
+        for n in runs[plain][1]:
+            assert torch.equal(runs[plain][1][n], runs[fused][1][n]), n
     assert runs["native"][0] == runs["native_side"][0]  # the two stream orders of the input dist: the same run, bit for bit
     for a, b in zip(runs["native"][2], runs["native_side"][2]):
         assert torch.equal(a, b)

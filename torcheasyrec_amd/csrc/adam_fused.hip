@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void tzr_adam_fused_kernel(FusedTable T, const
     k.bc2_sqrt = sqrtf(1.0f - powf(b2, step));
   }
   if (src.kind == 0) {
-    const float* __restrict__ g = reinterpret_cast<const float*>(a.grad);
+    // (src.parts != 0 with a finished tensor: the gradient is read from THERE -- a store-only call then copies it to `grad`, which is
+    // how a set of gradients is packed into one flat buffer for a collective, partial sums and finished tensors in one launch)
+    const float* __restrict__ g = src.parts ? src.parts : reinterpret_cast<const float*>(a.grad);
     for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < a.numel; i += (int64_t)nblk * 256) adam_element(a, k, i, g[i]);
   } else if (src.kind == 1) {
     // tzr_mlp_finish_kernel's sum: 16 outputs per workgroup x 16 slices of the partial rows, a thread adds its slice's partials
@@ -168,6 +170,7 @@ extern "C" int tzr_dense_adam_fused(const TzrAdamTensor* h_tensors, const TzrAda
         fs.kind = 2;
         nb = (WG_H * width + 63) / 64;
       } else {
+        if (h_sources && h_sources[base + i].parts) fs.parts = reinterpret_cast<const float*>(h_sources[base + i].parts);
         nb = (int)std::min<int64_t>(1024, (a.numel + 255) / 256);
       }
       blocks += std::max(nb, a.numel > 0 ? 1 : 0);

@@ -374,27 +374,35 @@ def _adam_tables(rows):
     src = (_lib.TzrAdamSource * n)()
     wg = None
     keep = []
-    for i, (p, gr, m, v, st) in enumerate(rows):
+    for i, row in enumerate(rows):
+        p, gr, m, v, st = row[:5]
+        key = row[5] if len(row) > 5 else gr  # the tensor autograd returned (what _PENDING knows); `gr` = where the gradient goes / lies
         tab[i].param = _lib.ptr(p) if p is not None else 0
         tab[i].grad = _lib.ptr(gr)
         tab[i].exp_avg = _lib.ptr(m) if m is not None else 0
         tab[i].exp_avg_sq = _lib.ptr(v) if v is not None else 0
         tab[i].state = _lib.ptr(st) if st is not None else 0
         tab[i].numel = gr.numel()
-        pend = _PENDING.pop(gr.data_ptr(), None)
+        pend = _PENDING.pop(key.data_ptr(), None)
         if pend is None:
             src[i].kind = _lib.ADAM_SRC_TENSOR
+            if key is not gr:
+                src[i].parts = _lib.ptr(key)  # a finished tensor elsewhere: copied
+                keep.append((key,))
         elif pend[0] == "rows":
             _, alive, (G, P, col), _gen = pend
             if col + gr.numel() > P:  # an entry left behind by a tensor that is gone, its address reused: this gradient is a finished tensor
                 src[i].kind = _lib.ADAM_SRC_TENSOR
+                if key is not gr:
+                    src[i].parts = _lib.ptr(key)
+                    keep.append((key,))
                 continue
             src[i].kind, src[i].G, src[i].P, src[i].col, src[i].parts = _lib.ADAM_SRC_ROWS, G, P, col, _lib.ptr(alive[0])
             keep.append(alive)
         else:
             _, alive, blob, _gen = pend
             if wg is not None:  # (one slice set per launch: the first stays, this one is written out on its own below)
-                _PENDING[gr.data_ptr()] = pend
+                _PENDING[key.data_ptr()] = pend
                 src[i].kind = -1
                 continue
             src[i].kind, wg = _lib.ADAM_SRC_WGRAD, blob
@@ -429,6 +437,39 @@ def materialize_pending(tensors: Optional[Iterable[torch.Tensor]] = None) -> Non
                                                    1e-8, 0.0, _lib.stream_ptr(rows[0][1].device)), "tzr_dense_adam_fused")
         del keep
         todo = rest
+
+
+PACKED_LAUNCHES = [0]  # pack_gradients calls that launched / of them: with partial sums among the sources (tests)
+PACKED_PARTIALS = [0]
+
+
+def pack_gradients(grads) -> Optional[torch.Tensor]:
+    """torch.cat([g.reshape(-1) for g in grads]) in ONE launch that takes each gradient as it lies -- a finished tensor (copied) or
+    the partial sums a backward left for the optimizer (added up on the way, same order as their finishing launch: bit-identical)
+    -- the flat buffer of the sharded step's dense all-reduce.  None: not a case for it (the caller concatenates)."""
+    grads = list(grads)
+    if not grads or len(grads) > 32 or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    if sum(1 for g in grads if _PENDING.get(g.data_ptr(), ("",))[0] == "wgrad") > 1:
+        return None
+    total = sum(g.numel() for g in grads)
+    flat = torch.empty(total, dtype=torch.float32, device=grads[0].device)
+    rows, o = [], 0
+    for g in grads:
+        rows.append((None, flat[o:o + g.numel()], None, None, None, g))
+        o += g.numel()
+    tab, src, wg, keep = _adam_tables(rows)
+    if any(e[3] == _GENERATION[0] for e in _PENDING.values()):
+        # a backward of THIS step left partial sums that none of `grads` claims: autograd handed its tensor on as a copy (another
+        # address) -- the copy is unwritten memory.  Never silently.
+        raise RuntimeError("pack_gradients: a gradient left as partial sums (FusedDenseAdam(fuse_finish=True)) is not among the tensors "
+                           "to pack -- it reached the caller as a copy; construct the optimizer with fuse_finish=False for this model")
+    _lib.check(_lib.lib().tzr_dense_adam_fused(tab, src, len(rows), C.byref(wg) if wg is not None else None, None, 0.0, 0.9, 0.999, 1e-8,
+                                               0.0, _lib.stream_ptr(flat.device)), "tzr_dense_adam_fused")
+    del keep
+    PACKED_LAUNCHES[0] += 1
+    PACKED_PARTIALS[0] += int(any(src[i].kind != _lib.ADAM_SRC_TENSOR for i in range(len(rows))))
+    return flat
 
 
 class _Mlp2Fn(torch.autograd.Function):

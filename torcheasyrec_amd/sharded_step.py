@@ -267,6 +267,16 @@ class ShardedTrainStep:
             grads = torch.autograd.grad(loss, [sparse] + self.params, grad_outputs=unit_gradient(loss))
         return loss.detach(), logits.detach(), grads
 
+    def _drop_grads(self) -> None:
+        """With FusedDenseAdam(fuse_finish=True) the parameters do not keep their `.grad` (views of the all-reduced buffer) past the
+        optimizer's step: a backward leaves its gradients as partial sums only for parameters that hold none (dense._defer_finish --
+        autograd's accumulation would read the unwritten tensor), and this step takes its gradients by `autograd.grad` anyway."""
+        from . import dense
+
+        if dense.FUSE_FINISH:
+            for p in self.params:
+                p.grad = None
+
     def _segment(self, dense, label, width) -> _Segment:
         B = dense.shape[0]
         seg = self._seg.get(B)
@@ -533,6 +543,7 @@ class ShardedTrainStep:
         for p, g in zip(self.params, dense_grad_views(flat, pg)):
             p.grad = g
         self.opt.step()
+        self._drop_grads()
         if pending is not None:
             self._ahead = (next_kjt, pending)
         return seg.loss
@@ -587,6 +598,7 @@ class ShardedTrainStep:
         for p, g in zip(self.params, dense_grad_views(sl["flat"], sl["grads"])):  # no unpack launch: views of the averaged buffer
             p.grad = g
         self.opt.step()
+        self._drop_grads()
 
     def _seg2(self, st: dict, sl: dict) -> None:
         self._seg2a(st, sl)
