@@ -112,3 +112,43 @@ def test_a_gradient_that_would_be_accumulated_is_finished_as_a_tensor(dev):
 
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+def test_only_parameters_of_a_live_fusing_optimizer_are_deferred(dev):
+    """dense.FUSE_FINISH is process-wide and stays up; the promise behind it is ONE optimizer's.  A model stepped by another
+    optimizer (here: torch's Adam) in the same process must get finished gradients -- its backward must not leave partial sums
+    nobody will add up."""
+    import gc
+
+    from torcheasyrec_amd import dense
+    from torcheasyrec_amd.dense import mlp2
+
+    torch.manual_seed(0)
+    keep = FusedDenseAdam([torch.nn.Parameter(torch.zeros(4, device=dev))], lr=1e-2, fuse_finish=True)  # raises the flag
+    assert dense.FUSE_FINISH
+    Wa, ba = torch.nn.Parameter(torch.randn(64, 13, device=dev) * 0.1), torch.nn.Parameter(torch.zeros(64, device=dev))
+    Wb, bb = torch.nn.Parameter(torch.randn(16, 64, device=dev) * 0.1), torch.nn.Parameter(torch.zeros(16, device=dev))
+    x = torch.randn(96, 13, device=dev)
+    n0 = len(dense._PENDING)
+    mlp2(x, Wa, ba, Wb, bb).sum().backward()
+    assert len(dense._PENDING) == n0  # nothing deferred: these parameters belong to no fusing optimizer
+    ref = torch.relu(torch.relu(x.cpu() @ Wa.detach().cpu().t()) @ Wb.detach().cpu().t())
+    gWb = torch.autograd.grad  # (finished tensors: compare one of them with torch)
+    xr, War, Wbr = x.cpu(), Wa.detach().cpu().requires_grad_(True), Wb.detach().cpu().requires_grad_(True)
+    torch.relu(torch.relu(xr @ War.t()) @ Wbr.t()).sum().backward()
+    torch.testing.assert_close(Wb.grad.cpu(), Wbr.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(Wa.grad.cpu(), War.grad, rtol=1e-5, atol=1e-6)
+    # ... and once the fusing optimizer is gone its parameters are not deferred either
+    own = [torch.nn.Parameter(t.detach().clone()) for t in (Wa, ba, Wb, bb)]
+    o = FusedDenseAdam(own, lr=1e-2, fuse_finish=True)
+    mlp2(x, *own).sum().backward()
+    assert len(dense._PENDING) > n0
+    o.step()
+    for q in own:
+        q.grad = None
+    del o
+    gc.collect()
+    n1 = len(dense._PENDING)
+    mlp2(x, *own).sum().backward()
+    assert len(dense._PENDING) == n1
+    del keep

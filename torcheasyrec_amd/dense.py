@@ -360,6 +360,11 @@ def _defer_finish(dev: torch.device, params=()) -> bool:
     gradient already: autograd would ADD the new gradient to the old one -- an addition that reads the unwritten tensor."""
     if not FUSE_FINISH or dev.type == "meta":
         return False
+    # (the flag is process-wide; the promise is an optimizer's: only for parameters a LIVE FusedDenseAdam(fuse_finish=True) steps)
+    for p in params:
+        ent = _FUSED_OWNER.get(id(p))
+        if ent is None or ent[0]() is not p or ent[1]() is None:
+            return False
     held = [p.grad for p in params if getattr(p, "grad", None) is not None]
     if held:
         materialize_pending(held)  # (an earlier backward's gradient, still partial sums: written out before autograd adds to it)
@@ -411,6 +416,7 @@ def _adam_tables(rows):
 
 
 _OPTIMIZERS: "weakref.WeakSet" = weakref.WeakSet()  # live FusedDenseAdam objects (materialize_pending's default reach)
+_FUSED_OWNER: dict = {}  # id(parameter) -> (weakref of the parameter, weakref of the fuse_finish optimizer that steps it)  (by id: tensors compare elementwise)
 _GENERATION = [0]  # optimizer steps seen: an entry nobody has claimed two steps later belongs to a tensor that is gone
 
 
@@ -760,6 +766,12 @@ class FusedDenseAdam:
         if not self.params:
             raise ValueError("no parameters")
         _OPTIMIZERS.add(self)
+        if fuse_finish:
+            me = weakref.ref(self)
+            for k in [k for k, e in _FUSED_OWNER.items() if e[0]() is None or e[1]() is None]:
+                del _FUSED_OWNER[k]
+            for p in self.params:
+                _FUSED_OWNER[id(p)] = (weakref.ref(p), me)
         dev = self.params[0].device
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
