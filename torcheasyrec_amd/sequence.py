@@ -381,8 +381,8 @@ class _DinTowerFn(torch.autograd.Function):
         from .dense import linear_rows_supported, linear_rows_wgrad_supported
 
         N, D = values.shape
-        if N < dense.ROWS_GEMM_MIN_ROWS and values.is_cuda or N == 0 or query.shape[0] == 0 or len(wb) < 4:
-            return False
+        if N < dense.ROWS_GEMM_MIN_ROWS and values.is_cuda or N == 0 or query.shape[0] == 0 or len(wb) < 4 or any(t is None for t in wb):
+            return False  # (few rows: the library's small tiles do as well; a layer without bias: the library path)
         L = _lib.lib()
         Hs = [w.shape[0] for w in wb[0::2]]
         Ks = [2 * D] + Hs[:-1]
