@@ -41,6 +41,9 @@ HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md); 6.29e12 measured co
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed graph replays between the capture and the --warmup / --steps the line reports (one GPU, graph replay): "
+                         "the device's clocks after the idle seconds of a capture")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", "--batch", dest="global_batch", type=int, default=65536,
@@ -831,6 +834,18 @@ def main():
             pool = g.pool()
             graphs.append(g)
         sync()
+        # a hipGraph's FIRST launch uploads it to the device (~75 us each here: with the clock started on never-launched graphs the
+        # timed region carried 8 uploads -- 0.6 ms, 6 % of a 20-step reading, profiles/r06ah); every graph is launched once, untimed,
+        # like the warm-up steps before it (nb more training steps on the same batches)
+        for g in graphs:
+            g.replay()
+        sync()
+        # ... and the device is brought to its running state: capture leaves it idle for seconds, and its clocks come back over the next
+        # ~10 ms of work -- the first 24 replays after an idle period ran 0.526, 0.510, ... 0.478 ms (profiles/r06ah), so a 20-step
+        # reading right behind the capture measured the ramp, not the step.  --settle-steps more untimed replays (reported as `settle_steps`)
+        for i in range(args.settle_steps):
+            graphs[i % nb].replay()
+        sync()
 
     def run_step(i, last=False):
         if graphs is not None:
@@ -845,10 +860,19 @@ def main():
             dist.barrier()
             sync()
         fw0 = getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) if sharded else 0.0
+        evs = [] if os.environ.get("TZR_BENCH_STEP_TIMES") and not emu else None  # (diagnostic: where inside the region the time goes)
         t0 = time.perf_counter()
         loss_ = None
+        if evs is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
         for i in range(n_steps):
             loss_ = run_step(first + i)
+            if evs is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
         host_el = time.perf_counter() - t0  # time until the HOST had queued the steps (sharded capacity exchange: includes its waits
         #                                      for the batches' overflow words -- `host_flag_wait_ms_per_step`, the host AHEAD of the device)
         host_fw = (getattr(getattr(model, "ebc", None), "flag_wait_s", 0.0) - fw0) if sharded else 0.0
@@ -857,6 +881,10 @@ def main():
             dist.barrier()
             sync()
         el = time.perf_counter() - t0
+        if evs is not None:
+            d = [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
+            print("[step times, ms] host queued in %.3f, wall %.3f, device span %.3f: %s" % (
+                host_el * 1e3, el * 1e3, evs[0].elapsed_time(evs[-1]), " ".join("%.3f" % x for x in d)), file=sys.stderr, flush=True)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1234,6 +1262,10 @@ def main():
                   + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "host_queue_ms_per_step": host_elapsed / args.steps * 1e3,
+        **({"settle_steps": (len(graphs) if replayed_graphs or graphs is not None else 0) + args.settle_steps,
+            "settle_note": "untimed replays between the capture and the timed steps: every hipGraph launched once (its first launch "
+                           "uploads it) + --settle-steps more (the device's clocks after the idle seconds of a capture)"}
+           if (graphs is not None or replayed_graphs) else {}),
         **({"host_flag_wait_ms_per_step": host_flag_wait / args.steps * 1e3,
             "host_busy_ms_per_step": (host_elapsed - host_flag_wait) / args.steps * 1e3} if sharded else {}),
         "higher_is_better": True, "scaling": args.scaling,
