@@ -820,7 +820,7 @@ def main():
         loss = step_body(*batches[i % nb])
     sync()
 
-    graphs, replayed_graphs = None, False
+    graphs, replayed_graphs, settle_done = None, False, 0
     if use_graph:
         # One hipGraph per distinct batch (inputs already in HBM, nothing is copied per step); all
         # graphs share one memory pool since they never run concurrently.  A step = one replay:
@@ -846,6 +846,7 @@ def main():
         for i in range(args.settle_steps):
             graphs[i % nb].replay()
         sync()
+        settle_done = len(graphs) + args.settle_steps
 
     def run_step(i, last=False):
         if graphs is not None:
@@ -1262,10 +1263,10 @@ def main():
                   + ("per GPU" if args.scaling == "weak" else "global"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "host_queue_ms_per_step": host_elapsed / args.steps * 1e3,
-        **({"settle_steps": (len(graphs) if replayed_graphs or graphs is not None else 0) + args.settle_steps,
+        **({"settle_steps": settle_done,
             "settle_note": "untimed replays between the capture and the timed steps: every hipGraph launched once (its first launch "
                            "uploads it) + --settle-steps more (the device's clocks after the idle seconds of a capture)"}
-           if (graphs is not None or replayed_graphs) else {}),
+           if settle_done else {}),
         **({"host_flag_wait_ms_per_step": host_flag_wait / args.steps * 1e3,
             "host_busy_ms_per_step": (host_elapsed - host_flag_wait) / args.steps * 1e3} if sharded else {}),
         "higher_is_better": True, "scaling": args.scaling,
