@@ -259,8 +259,8 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
                     gs.append(g)
                 from torcheasyrec_amd.embedding_group import after_graph_replay
 
-                for i in range(4):
-                    gs[i].replay()
+                for i in range(4 + 40):  # (every graph launched once + ~20-100 ms of replays: the device's clocks after the idle capture)
+                    gs[i % 4].replay()
                     after_graph_replay(model)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -1159,7 +1159,7 @@ def main():
             pool2 = g_.pool()
             g2.append(g_)
         torch.cuda.synchronize()
-        for i in range(5):
+        for i in range(4 + 150):  # (every graph launched once + ~20 ms of replays: the device's clocks after the idle capture)
             g2[i % 4].replay()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
