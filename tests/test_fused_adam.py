@@ -152,3 +152,38 @@ def test_only_parameters_of_a_live_fusing_optimizer_are_deferred(dev):
     mlp2(x, *own).sum().backward()
     assert len(dense._PENDING) == n1
     del keep
+
+
+def test_pack_gradients_equals_concatenation_and_fails_loudly_on_a_lost_partial(dev):
+    """dense.pack_gradients: finished tensors and partial sums into one flat buffer in one launch == torch.cat of the finished
+    gradients, bit for bit; a gradient that was left as partial sums but is not among the tensors handed in (autograd passed it on
+    as a copy) is an error, never a silently unwritten slice."""
+    from torcheasyrec_amd.dense import mlp2, pack_gradients
+
+    torch.manual_seed(0)
+    x = torch.randn(96, 13, device=dev)
+
+    def grads(fuse):
+        own = [torch.nn.Parameter(t) for t in (torch.randn(64, 13, device=dev) * 0.1, torch.zeros(64, device=dev),
+                                               torch.randn(16, 64, device=dev) * 0.1, torch.zeros(16, device=dev))]
+        extra = torch.nn.Parameter(torch.randn(7, 5, device=dev))
+        o = FusedDenseAdam(own + [extra], lr=1e-2, fuse_finish=fuse)
+        loss = mlp2(x, *own).sum() + (extra * extra).sum()
+        gs = torch.autograd.grad(loss, own + [extra])
+        return o, gs
+
+    torch.manual_seed(1)
+    o1, g_plain = grads(False)
+    want = torch.cat([g.reshape(-1) for g in g_plain])
+    torch.manual_seed(1)
+    o2, g_fused = grads(True)
+    assert len(dense._PENDING) >= 4
+    flat = pack_gradients(list(g_fused))
+    assert flat is not None and torch.equal(flat.cpu(), want.cpu())
+    assert not any(e[3] == dense._GENERATION[0] for e in dense._PENDING.values())
+    torch.manual_seed(1)
+    o3, g_lost = grads(True)
+    with pytest.raises(RuntimeError, match="partial sums"):
+        pack_gradients([g.clone() if i == 2 else g for i, g in enumerate(g_lost)])  # (tensor 2 arrives as a copy)
+    dense._PENDING.clear()
+    del o1, o2, o3
