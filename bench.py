@@ -219,7 +219,9 @@ def config_model_steps(dev, work_stream, steps: int = 20, only=None):
         mc_ = getattr(model.embedding_group, "mc", None)
         if mc_ is not None and capturable:  # ring mode: device iteration counter + candidate ring, the step can be captured (zch.py)
             mc_.device_profile = True
-        opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr)
+        # (fuse_finish: the Linear + ReLU layers' bias gradients go into the optimizer's launch as the mask kernels' partial rows --
+        # no finishing launch per layer; TZR_MODELS_FUSE_FINISH=0: the A/B switch)
+        opt = FusedDenseAdam(list(model.dense_parameters()), lr=spec.dense_lr, fuse_finish=os.environ.get("TZR_MODELS_FUSE_FINISH", "1") != "0")
         bs = batches(spec, B, 4, 11, raw_id_feature)
         n_ids = int(np.mean([b.sparse_features[BASE_DATA_GROUP].values().numel() for b in bs]))
 

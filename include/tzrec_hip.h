@@ -413,6 +413,11 @@ size_t tzr_relu_bwd_colsum_workspace(int64_t B, int N);
 int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const float* d_y,
                         int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
                         float* d_colsum, void* ws, size_t ws_bytes, void* stream);
+/* The same without its finishing launch: the column sums stay *out_G rows of N partial sums at the head of `ws` (which remains the
+ * caller's until they are consumed) -- a source of kind TZR_ADAM_SRC_ROWS (G = *out_G, P = N, col = 0) for tzr_dense_adam_fused:
+ * the bias gradient of a Linear + ReLU layer goes into the optimizer's launch without ever being a tensor. */
+int tzr_relu_bwd_colsum_parts(const float* d_grad_y, int64_t grad_y_stride, const float* d_y, int64_t y_stride, int64_t B, int N,
+                              float* d_grad, int64_t grad_stride, void* ws, size_t ws_bytes, int* out_G, void* stream);
 
 /* Backward of the one-unit logits layer y = x w^T + b (tzrec/models/rank_model.py output layer
  * with num_class 1): d_grad_x[b,:] = gy[b] * w (nullable), d_grad_wb[0:N] = sum_b gy[b] * x[b,:],

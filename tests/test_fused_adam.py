@@ -187,3 +187,35 @@ def test_pack_gradients_equals_concatenation_and_fails_loudly_on_a_lost_partial(
         pack_gradients([g.clone() if i == 2 else g for i, g in enumerate(g_lost)])  # (tensor 2 arrives as a copy)
     dense._PENDING.clear()
     del o1, o2, o3
+
+
+def test_linear_relu_bias_gradients_go_into_the_optimizers_launch(dev):
+    """dlrm.MLP (Linear + bias + ReLU layers) under FusedDenseAdam(fuse_finish=True): the bias gradients stay the mask kernel's
+    partial rows (tzr_relu_bwd_colsum_parts) and are added up inside tzr_dense_adam_fused -- the same training run as with the
+    finishing launches, to the rounding of a different summation order (<= 1e-6 relative on the parameters after 5 steps)."""
+    from torcheasyrec_amd import dlrm
+    from torcheasyrec_amd.dlrm import MLP
+
+    if dev.type == "cpu":
+        pytest.skip("the Linear + ReLU autograd function is the GPU path of dlrm.MLP")
+
+    def run(fuse):
+        torch.manual_seed(0)
+        mlp = MLP(96, [256, 128, 64]).to(dev)
+        dense.FUSE_FINISH = False
+        opt = FusedDenseAdam(list(mlp.parameters()), lr=1e-2, fuse_finish=fuse)
+        deferred = 0
+        for s in range(5):
+            x = torch.randn(4096, 96, generator=torch.Generator().manual_seed(s)).to(dev)
+            n0 = len(dense._PENDING)
+            mlp(x).square().mean().backward()
+            deferred += len(dense._PENDING) - n0
+            opt.step()
+            opt.zero_grad()
+        assert not dense._PENDING
+        return [p.detach().cpu().clone() for p in mlp.parameters()], deferred
+
+    (pa, da), (pb, db) = run(False), run(True)
+    assert da == 0 and db == 5 * 3  # three layers' bias gradients per step
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)

@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 13  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 14  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -210,6 +210,7 @@ _SIGNATURES = {
     "tzr_bce_logits": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tzr_relu_bwd_colsum_workspace": (_sz, [_i64, _i32]),
     "tzr_relu_bwd_colsum": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_relu_bwd_colsum_parts": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp, _vp]),
     "tzr_head_bwd_workspace": (_sz, [_i64, _i32]),
     "tzr_head_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "tzr_head_bwd_relu_workspace": (_sz, [_i64, _i32]),

@@ -208,10 +208,12 @@ extern "C" size_t tzr_relu_bwd_colsum_workspace(int64_t B, int N) {
   return (size_t)RB_MAX_WG * (size_t)std::max(N, 4) * sizeof(float) + 256;
 }
 
-extern "C" int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const float* d_y,
-                                   int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
-                                   float* d_colsum, void* ws, size_t ws_bytes, void* stream) {
-  if (!d_grad_y || !d_y || !d_grad || !d_colsum || B <= 0 || N <= 0) return TZR_ERR_INVALID;
+// d_colsum == NULL with out_G != NULL: no finishing launch -- the column sums stay *out_G rows of N partial sums at the head of
+// `ws` (tzr_relu_bwd_colsum_parts: for tzr_dense_adam_fused's TZR_ADAM_SRC_ROWS)
+static int relu_bwd_colsum_impl(const float* d_grad_y, int64_t grad_y_stride, const float* d_y, int64_t y_stride, int64_t B, int N,
+                                float* d_grad, int64_t grad_stride, float* d_colsum, int* out_G, void* ws, size_t ws_bytes,
+                                void* stream) {
+  if (!d_grad_y || !d_y || !d_grad || (!d_colsum && !out_G) || B <= 0 || N <= 0) return TZR_ERR_INVALID;
   if ((N & 3) || N > 4 * RB_THREADS || (grad_y_stride & 3) || (y_stride & 3) || (grad_stride & 3))
     return TZR_ERR_UNSUPPORTED;
   if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) || ws_bytes < tzr_relu_bwd_colsum_workspace(B, N) - 256)
@@ -228,10 +230,26 @@ extern "C" int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride,
   float* parts = static_cast<float*>(ws);
   hipLaunchKernelGGL(tzr_relu_bwd_colsum_kernel, dim3((unsigned)n_wg), dim3(RB_THREADS), 0, s, d_grad_y,
                      grad_y_stride, d_y, y_stride, B, N, rows_per_wg, d_grad, grad_stride, parts);
-  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts,
-                     (int)n_wg, N, d_colsum);
+  if (d_colsum)
+    hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts,
+                       (int)n_wg, N, d_colsum);
+  if (out_G) *out_G = (int)n_wg;
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+extern "C" int tzr_relu_bwd_colsum(const float* d_grad_y, int64_t grad_y_stride, const float* d_y,
+                                   int64_t y_stride, int64_t B, int N, float* d_grad, int64_t grad_stride,
+                                   float* d_colsum, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_colsum) return TZR_ERR_INVALID;
+  return relu_bwd_colsum_impl(d_grad_y, grad_y_stride, d_y, y_stride, B, N, d_grad, grad_stride, d_colsum, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int tzr_relu_bwd_colsum_parts(const float* d_grad_y, int64_t grad_y_stride, const float* d_y, int64_t y_stride,
+                                         int64_t B, int N, float* d_grad, int64_t grad_stride, void* ws, size_t ws_bytes,
+                                         int* out_G, void* stream) {
+  if (!out_G) return TZR_ERR_INVALID;
+  return relu_bwd_colsum_impl(d_grad_y, grad_y_stride, d_y, y_stride, B, N, d_grad, grad_stride, nullptr, out_G, ws, ws_bytes, stream);
 }
 
 // ---- backward of the one-unit logits layer ---------------------------------------------------------

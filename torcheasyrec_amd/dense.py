@@ -59,14 +59,22 @@ def _rows16(t: torch.Tensor) -> torch.Tensor:
     return t.clone(memory_format=torch.contiguous_format)  # .contiguous() keeps odd strides of 1-row tensors
 
 
-def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor):
-    """(grad_y * (y > 0), its column sums): ReLU backward + bias gradient of a Linear+ReLU layer."""
+def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor, defer_for=None):
+    """(grad_y * (y > 0), its column sums): ReLU backward + bias gradient of a Linear+ReLU layer.  `defer_for` = (the bias
+    parameter,): with a live FusedDenseAdam(fuse_finish=True) stepping it the column sums are left as the kernel's per-workgroup
+    partial rows for the optimizer's own launch (no finishing launch; the returned tensor is unwritten: see FUSE_FINISH)."""
     B, N = y.shape
     gy, y = _rows16(grad_y), _rows16(y)
     g = torch.empty(B, N, dtype=torch.float32, device=y.device)
     col = torch.empty(N, dtype=torch.float32, device=y.device)
     L = _lib.lib()
     ws = _lib.workspace(L.tzr_relu_bwd_colsum_workspace(B, N), y.device)
+    if defer_for is not None and _defer_finish(y.device, defer_for):
+        G = C.c_int(0)
+        _lib.check(L.tzr_relu_bwd_colsum_parts(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
+                                               _lib.ptr(ws), ws.numel(), C.byref(G), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum_parts")
+        _PENDING[col.data_ptr()] = ("rows", (ws,), (G.value, N, 0), _GENERATION[0])
+        return g, col
     _lib.check(L.tzr_relu_bwd_colsum(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                      _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum")
     return g, col

@@ -47,6 +47,7 @@ class _LinearReluFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
         ctx.save_for_backward(x, weight, y)
+        ctx.bias_ref = bias  # (the Parameter: dense._defer_finish looks at who steps it)
         return y
 
     @staticmethod
@@ -55,7 +56,7 @@ class _LinearReluFn(torch.autograd.Function):
         if _FUSED_RELU_BWD and y.shape[1] % 4 == 0 and y.shape[1] <= 1024 and gy.dtype == torch.float32:
             from .dense import relu_bwd_colsum
 
-            g, gb = relu_bwd_colsum(gy, y)  # mask + bias gradient in one pass (tzr_relu_bwd_colsum)
+            g, gb = relu_bwd_colsum(gy, y, defer_for=(ctx.bias_ref,))  # mask + bias gradient in one pass (tzr_relu_bwd_colsum)
         else:
             g = torch.ops.aten.threshold_backward(gy, y, 0.0)
             gb = g.sum(0)
