@@ -476,6 +476,11 @@ size_t tzr_skinny_linear_bwd_workspace(int64_t B, int K, int n_out);
 int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
                           const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
                           int64_t grad_x_stride, float* d_grad_wb, void* ws, size_t ws_bytes, void* stream);
+/* ... without its finishing launch: [weight gradient n_out x K | bias gradient n_out, padded to 4] stay *out_G rows of *out_P
+ * partial sums at the head of `ws`: two sources of kind TZR_ADAM_SRC_ROWS (col 0 and col n_out K) for tzr_dense_adam_fused. */
+int tzr_skinny_linear_bwd_parts(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                                int64_t grad_x_stride, void* ws, size_t ws_bytes, int* out_G, int* out_P, void* stream);
 
 /* Input gradient of a Linear layer chained with the ReLU mask and bias gradient of the layer below it (autograd of
  * Linear -> ReLU -> Linear, tzrec/modules/mlp.py:58-83), one launch on the matrix cores (exact fp32):

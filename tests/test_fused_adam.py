@@ -219,3 +219,20 @@ def test_linear_relu_bias_gradients_go_into_the_optimizers_launch(dev):
     assert da == 0 and db == 5 * 3  # three layers' bias gradients per step
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_a_shared_layer_under_fuse_finish_fails_loudly(dev):
+    """the same parameters twice in one backward pass: autograd would add two gradients of which the first is unwritten partial
+    sums -- refused with an error naming the remedy, not trained on garbage"""
+    from torcheasyrec_amd.dense import mlp2
+
+    torch.manual_seed(0)
+    own = [torch.nn.Parameter(t) for t in (torch.randn(64, 13, device=dev) * 0.1, torch.zeros(64, device=dev),
+                                           torch.randn(16, 64, device=dev) * 0.1, torch.zeros(16, device=dev))]
+    o = FusedDenseAdam(own, lr=1e-2, fuse_finish=True)
+    x1, x2 = torch.randn(96, 13, device=dev), torch.randn(96, 13, device=dev)
+    with pytest.raises(RuntimeError, match="shared layer"):
+        (mlp2(x1, *own).sum() + mlp2(x2, *own).sum()).backward()
+    dense._PENDING.clear()
+    dense._DEFERRED.clear()
+    del o

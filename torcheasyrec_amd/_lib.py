@@ -220,6 +220,7 @@ _SIGNATURES = {
     "tzr_skinny_linear_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "tzr_skinny_linear_bwd_workspace": (_sz, [_i64, _i32, _i32]),
     "tzr_skinny_linear_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "tzr_skinny_linear_bwd_parts": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
     "tzr_linear_rows_supported": (_i32, [_i32, _i32]),
     "tzr_linear_rows": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _i64, _vp]),
     "tzr_linear_rows_wgrad_supported": (_i32, [_i32, _i32]),

@@ -601,11 +601,12 @@ extern "C" size_t tzr_skinny_linear_bwd_workspace(int64_t B, int K, int n_out) {
   return (size_t)RB_MAX_WG * (size_t)sk_row_len(K, std::max(n_out, 1)) * sizeof(float) + 256;
 }
 
-extern "C" int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
-                                     const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
-                                     int64_t grad_x_stride, float* d_grad_wb /*[n_out K + n_out padded to 4]*/, void* ws,
-                                     size_t ws_bytes, void* stream) {
-  if (!d_grad_y || !d_x || !d_w || !d_grad_wb || B <= 0 || K <= 0 || n_out <= 0) return TZR_ERR_INVALID;
+// d_grad_wb == NULL with out_G / out_P: no finishing launch, the sums stay *out_G rows of *out_P partial sums at the head of `ws`
+static int skinny_linear_bwd_impl(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                  const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                                  int64_t grad_x_stride, float* d_grad_wb /*[n_out K + n_out padded to 4]*/, int* out_G, int* out_P,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (!d_grad_y || !d_x || !d_w || (!d_grad_wb && !(out_G && out_P)) || B <= 0 || K <= 0 || n_out <= 0) return TZR_ERR_INVALID;
   if ((K & 3) || K > 4 * RB_THREADS || n_out > SK_MAX_OUT || (x_stride & 3) || (w_stride & 3) || grad_y_stride < n_out ||
       (d_grad_x && (grad_x_stride & 3)))
     return TZR_ERR_UNSUPPORTED;
@@ -629,10 +630,30 @@ extern "C" int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_strid
   else if (n_out <= 4) SK_BWD(4);
   else SK_BWD(8);
 #undef SK_BWD
-  hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((row_len + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts, (int)n_wg,
-                     row_len, d_grad_wb);
+  if (d_grad_wb)
+    hipLaunchKernelGGL(tzr_colsum_finish_kernel, dim3((unsigned)((row_len + 63) / 64)), dim3(RB_FIN_THREADS), 0, s, parts, (int)n_wg,
+                       row_len, d_grad_wb);
+  if (out_G) *out_G = (int)n_wg;
+  if (out_P) *out_P = row_len;
   TZR_CHECK_LAUNCH();
   return TZR_OK;
+}
+
+extern "C" int tzr_skinny_linear_bwd(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                     const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                                     int64_t grad_x_stride, float* d_grad_wb /*[n_out K + n_out padded to 4]*/, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (!d_grad_wb) return TZR_ERR_INVALID;
+  return skinny_linear_bwd_impl(d_grad_y, grad_y_stride, d_x, x_stride, d_w, w_stride, B, K, n_out, d_grad_x, grad_x_stride, d_grad_wb,
+                                nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int tzr_skinny_linear_bwd_parts(const float* d_grad_y, int64_t grad_y_stride, const float* d_x, int64_t x_stride,
+                                           const float* d_w, int64_t w_stride, int64_t B, int K, int n_out, float* d_grad_x,
+                                           int64_t grad_x_stride, void* ws, size_t ws_bytes, int* out_G, int* out_P, void* stream) {
+  if (!out_G || !out_P) return TZR_ERR_INVALID;
+  return skinny_linear_bwd_impl(d_grad_y, grad_y_stride, d_x, x_stride, d_w, w_stride, B, K, n_out, d_grad_x, grad_x_stride, nullptr,
+                                out_G, out_P, ws, ws_bytes, stream);
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------

@@ -73,7 +73,7 @@ def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor, defer_for=None):
         G = C.c_int(0)
         _lib.check(L.tzr_relu_bwd_colsum_parts(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                                _lib.ptr(ws), ws.numel(), C.byref(G), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum_parts")
-        _PENDING[col.data_ptr()] = ("rows", (ws,), (G.value, N, 0), _GENERATION[0])
+        _PENDING[col.data_ptr()] = ("rows", (ws,), (G.value, N, 0), _GENERATION[0], _owner_id(defer_for))
         return g, col
     _lib.check(L.tzr_relu_bwd_colsum(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                      _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum")
@@ -190,8 +190,10 @@ def skinny_linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     return y
 
 
-def skinny_linear_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_grad_x: bool = True):
-    """(grad_x [B, K] | None, grad_weight [n, K], grad_bias [n]) of a Linear layer with <= 8 output units (tzr_skinny_linear_bwd)."""
+def skinny_linear_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, need_grad_x: bool = True, defer_for=None):
+    """(grad_x [B, K] | None, grad_weight [n, K], grad_bias [n]) of a Linear layer with <= 8 output units (tzr_skinny_linear_bwd).
+    `defer_for` = the layer's parameters: stepped by a live FusedDenseAdam(fuse_finish=True), their gradients stay the kernel's
+    partial rows for the optimizer's launch (the returned tensors are unwritten: see FUSE_FINISH)."""
     B, K = x.shape
     n = weight.shape[0]
     gy = grad_y if grad_y.stride(1) == 1 or n == 1 else grad_y.contiguous()
@@ -200,6 +202,15 @@ def skinny_linear_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tenso
     wb = torch.empty(n * K + (n + 3) // 4 * 4, dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = _lib.workspace(L.tzr_skinny_linear_bwd_workspace(B, K, n), x.device)
+    if defer_for is not None and _defer_finish(x.device, defer_for):
+        G, P = C.c_int(0), C.c_int(0)
+        _lib.check(L.tzr_skinny_linear_bwd_parts(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight), weight.stride(0), B, K,
+                                                 n, _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(ws), ws.numel(), C.byref(G),
+                                                 C.byref(P), _lib.stream_ptr(x.device)), "tzr_skinny_linear_bwd_parts")
+        gw, gb = wb[:n * K].view(n, K), wb[n * K:n * K + n]
+        _PENDING[gw.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, 0), _GENERATION[0], _owner_id(defer_for))
+        _PENDING[gb.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, n * K), _GENERATION[0], _owner_id(defer_for))
+        return gx, gw, gb
     _lib.check(L.tzr_skinny_linear_bwd(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight), weight.stride(0), B, K, n,
                                        _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(wb), _lib.ptr(ws), ws.numel(),
                                        _lib.stream_ptr(x.device)), "tzr_skinny_linear_bwd")
@@ -361,6 +372,14 @@ FUSE_FINISH = False
 # itself: autograd hands a gradient over to `.grad` without a copy only when nobody else holds it -- a copy would be a copy of
 # unwritten memory under another address.  Claimed by address: `FusedDenseAdam.step` / `materialize_pending` look their tensors up.)
 _PENDING: dict = {}
+_DEFERRED: set = set()  # ids of the parameters whose gradient of the current backward pass was left as partial sums (cleared by the optimizer's step)
+
+
+def _owner_id(params) -> int:
+    """id of the fusing optimizer that steps `params` (what _defer_finish just checked): a pending entry remembers whose it is"""
+    ent = _FUSED_OWNER.get(id(params[0])) if params else None
+    o = ent[1]() if ent is not None else None
+    return id(o) if o is not None else 0
 
 
 def _defer_finish(dev: torch.device, params=()) -> bool:
@@ -377,6 +396,12 @@ def _defer_finish(dev: torch.device, params=()) -> bool:
     if held:
         materialize_pending(held)  # (an earlier backward's gradient, still partial sums: written out before autograd adds to it)
         return False
+    if any(id(p) in _DEFERRED for p in params):
+        # a parameter used twice in one backward pass (a shared layer): autograd will ADD the two gradients, and the first one --
+        # left as partial sums -- may not have reached `.grad` yet: nothing here can write it out in time.  Never silently.
+        raise RuntimeError("FusedDenseAdam(fuse_finish=True): a parameter takes part in the model twice (a shared layer): its two "
+                           "gradients would be added before the first is written; construct the optimizer with fuse_finish=False")
+    _DEFERRED.update(id(p) for p in params)
     return True
 
 
@@ -403,7 +428,7 @@ def _adam_tables(rows):
                 src[i].parts = _lib.ptr(key)  # a finished tensor elsewhere: copied
                 keep.append((key,))
         elif pend[0] == "rows":
-            _, alive, (G, P, col), _gen = pend
+            _, alive, (G, P, col) = pend[:3]
             if col + gr.numel() > P:  # an entry left behind by a tensor that is gone, its address reused: this gradient is a finished tensor
                 src[i].kind = _lib.ADAM_SRC_TENSOR
                 if key is not gr:
@@ -413,7 +438,7 @@ def _adam_tables(rows):
             src[i].kind, src[i].G, src[i].P, src[i].col, src[i].parts = _lib.ADAM_SRC_ROWS, G, P, col, _lib.ptr(alive[0])
             keep.append(alive)
         else:
-            _, alive, blob, _gen = pend
+            _, alive, blob = pend[:3]
             if wg is not None:  # (one slice set per launch: the first stays, this one is written out on its own below)
                 _PENDING[key.data_ptr()] = pend
                 src[i].kind = -1
@@ -527,7 +552,7 @@ class _Mlp2Fn(torch.autograd.Function):
                                             _lib.stream_ptr(xs.device)), "tzr_mlp2_bwd_parts")
             col = 0
             for t in (dWb, dbb, dWa, dba):
-                _PENDING[t.data_ptr()] = ("rows", (ws,), (G.value, P.value, col), _GENERATION[0])
+                _PENDING[t.data_ptr()] = ("rows", (ws,), (G.value, P.value, col), _GENERATION[0], _owner_id(ctx.param_refs))
                 col += t.numel()
             return None, dWa, dba, dWb, dbb
         _lib.check(L.tzr_mlp2_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(hb), hb.stride(0), _lib.ptr(ha), ha.stride(0), _lib.ptr(xs),
@@ -712,7 +737,7 @@ def interaction_top_wgrad(dense: torch.Tensor, sparse: torch.Tensor, D: int, g1:
         _lib.check(L.tzr_dot_interaction_top_wgrad_parts(
             _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
             _lib.ptr(scale), _lib.ptr(ws), ws.numel(), C.byref(blob), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_wgrad_parts")
-        _PENDING[dW.data_ptr()] = ("wgrad", (ws, scale), blob, _GENERATION[0])
+        _PENDING[dW.data_ptr()] = ("wgrad", (ws, scale), blob, _GENERATION[0], _owner_id(defer_for))
         return dW
     _lib.check(L.tzr_dot_interaction_top_wgrad(
         _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
@@ -795,6 +820,7 @@ class FusedDenseAdam:
         self._lr_host = float(lr)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
+        _DEFERRED.difference_update(id(p) for p in self.params)
         for p in self.params:
             if set_to_none:
                 p.grad = None
@@ -836,6 +862,13 @@ class FusedDenseAdam:
                                                        g["lr"], b1, b2, g["eps"], g["weight_decay"], _lib.stream_ptr(self.device)),
                        "tzr_dense_adam_fused")
             del keep
+        _DEFERRED.difference_update(id(p) for p in self.params)
+        if any(len(e) > 4 and e[4] == id(self) and e[3] == _GENERATION[0] for e in _PENDING.values()):
+            # a backward left a gradient of one of THIS optimizer's parameters as partial sums and the tensor that reached `.grad` is
+            # another one (autograd copied it): its parameter was just stepped with unwritten memory.  Never silently.
+            raise RuntimeError("FusedDenseAdam(fuse_finish=True): a gradient left as partial sums did not reach its parameter's .grad "
+                               "as the tensor the backward returned (it was copied on the way); construct the optimizer with "
+                               "fuse_finish=False for this model")
         if _PENDING:  # (entries of tensors that are gone -- a gradient autograd dropped: unclaimed two steps later)
             _GENERATION[0] += 1
             for ptr in [q for q, e in _PENDING.items() if e[3] < _GENERATION[0] - 2]:

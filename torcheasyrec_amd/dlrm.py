@@ -98,6 +98,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
 
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.param_refs = (weight, bias) if bias is not None else None  # (dense._defer_finish looks at who steps them)
         return skinny_linear_fwd(x, weight.detach(), None if bias is None else bias.detach())
 
     @staticmethod
@@ -105,7 +106,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
         from .dense import skinny_linear_bwd
 
         x, weight = ctx.saved_tensors
-        gx, gw, gb = skinny_linear_bwd(gy.float(), x, weight, ctx.needs_input_grad[0])
+        gx, gw, gb = skinny_linear_bwd(gy.float(), x, weight, ctx.needs_input_grad[0], defer_for=ctx.param_refs)
         return gx, gw, (gb if ctx.has_bias else None)
 
 
