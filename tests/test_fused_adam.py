@@ -236,3 +236,25 @@ def test_a_shared_layer_under_fuse_finish_fails_loudly(dev):
     dense._PENDING.clear()
     dense._DEFERRED.clear()
     del o
+
+
+def test_an_abandoned_backward_pass_does_not_look_like_a_shared_layer(dev):
+    """gradients dropped by hand (`p.grad = None`, no step, no zero_grad) and a new backward pass: the parameters' entries belong
+    to another pass -- deferred again, trained normally, no 'shared layer' error"""
+    from torcheasyrec_amd.dense import mlp2
+
+    torch.manual_seed(0)
+    own = [torch.nn.Parameter(t) for t in (torch.randn(64, 13, device=dev) * 0.1, torch.zeros(64, device=dev),
+                                           torch.randn(16, 64, device=dev) * 0.1, torch.zeros(16, device=dev))]
+    o = FusedDenseAdam(own, lr=1e-2, fuse_finish=True)
+    x = torch.randn(96, 13, device=dev)
+    mlp2(x, *own).sum().backward()
+    for p in own:
+        p.grad = None  # the pass is abandoned
+    before = [p.detach().clone() for p in own]
+    mlp2(x, *own).sum().backward()
+    o.step()
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, own))
+    assert bool(all(torch.isfinite(p).all() for p in own))
+    dense._PENDING.clear()
+    del o

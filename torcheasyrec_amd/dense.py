@@ -73,7 +73,7 @@ def relu_bwd_colsum(grad_y: torch.Tensor, y: torch.Tensor, defer_for=None):
         G = C.c_int(0)
         _lib.check(L.tzr_relu_bwd_colsum_parts(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                                _lib.ptr(ws), ws.numel(), C.byref(G), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum_parts")
-        _PENDING[col.data_ptr()] = ("rows", (ws,), (G.value, N, 0), _GENERATION[0], _owner_id(defer_for))
+        _PENDING[col.data_ptr()] = ("rows", (ws,), (G.value, N, 0), _GENERATION[0], _owner_id(defer_for), tuple(id(q) for q in defer_for))
         return g, col
     _lib.check(L.tzr_relu_bwd_colsum(_lib.ptr(gy), gy.stride(0), _lib.ptr(y), y.stride(0), B, N, _lib.ptr(g), g.stride(0),
                                      _lib.ptr(col), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(y.device)), "tzr_relu_bwd_colsum")
@@ -208,8 +208,8 @@ def skinny_linear_bwd(grad_y: torch.Tensor, x: torch.Tensor, weight: torch.Tenso
                                                  n, _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(ws), ws.numel(), C.byref(G),
                                                  C.byref(P), _lib.stream_ptr(x.device)), "tzr_skinny_linear_bwd_parts")
         gw, gb = wb[:n * K].view(n, K), wb[n * K:n * K + n]
-        _PENDING[gw.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, 0), _GENERATION[0], _owner_id(defer_for))
-        _PENDING[gb.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, n * K), _GENERATION[0], _owner_id(defer_for))
+        _PENDING[gw.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, 0), _GENERATION[0], _owner_id(defer_for), tuple(id(q) for q in defer_for))
+        _PENDING[gb.data_ptr()] = ("rows", (ws, wb), (G.value, P.value, n * K), _GENERATION[0], _owner_id(defer_for), tuple(id(q) for q in defer_for))
         return gx, gw, gb
     _lib.check(L.tzr_skinny_linear_bwd(_lib.ptr(gy), gy.stride(0), _lib.ptr(xs), xs.stride(0), _lib.ptr(weight), weight.stride(0), B, K, n,
                                        _lib.ptr(gx), 0 if gx is None else gx.stride(0), _lib.ptr(wb), _lib.ptr(ws), ws.numel(),
@@ -372,7 +372,14 @@ FUSE_FINISH = False
 # itself: autograd hands a gradient over to `.grad` without a copy only when nobody else holds it -- a copy would be a copy of
 # unwritten memory under another address.  Claimed by address: `FusedDenseAdam.step` / `materialize_pending` look their tensors up.)
 _PENDING: dict = {}
-_DEFERRED: set = set()  # ids of the parameters whose gradient of the current backward pass was left as partial sums (cleared by the optimizer's step)
+# id of a parameter whose gradient was left as partial sums -> the backward pass that did it (autograd's graph-task id; cleared by
+# the optimizer's step / zero_grad)
+_DEFERRED: dict = {}
+
+
+def _backward_pass_id() -> int:
+    f = getattr(torch._C, "_current_graph_task_id", None)  # (guarded: a private hook; without it every pass looks like the same one)
+    return int(f()) if f is not None else -1
 
 
 def _owner_id(params) -> int:
@@ -396,12 +403,17 @@ def _defer_finish(dev: torch.device, params=()) -> bool:
     if held:
         materialize_pending(held)  # (an earlier backward's gradient, still partial sums: written out before autograd adds to it)
         return False
-    if any(id(p) in _DEFERRED for p in params):
+    task = _backward_pass_id()
+    if any(_DEFERRED.get(id(p), None) == task for p in params):  # (an entry of ANOTHER pass: its gradient was dropped unstepped -- overwritten below)
         # a parameter used twice in one backward pass (a shared layer): autograd will ADD the two gradients, and the first one --
         # left as partial sums -- may not have reached `.grad` yet: nothing here can write it out in time.  Never silently.
         raise RuntimeError("FusedDenseAdam(fuse_finish=True): a parameter takes part in the model twice (a shared layer): its two "
                            "gradients would be added before the first is written; construct the optimizer with fuse_finish=False")
-    _DEFERRED.update(id(p) for p in params)
+    stale = {id(p) for p in params if id(p) in _DEFERRED}
+    if stale:  # their earlier pass was abandoned (gradients dropped by hand): what it left behind goes with it
+        for ptr in [q for q, e in _PENDING.items() if len(e) > 5 and stale.intersection(e[5])]:
+            del _PENDING[ptr]
+    _DEFERRED.update((id(p), task) for p in params)
     return True
 
 
@@ -552,7 +564,7 @@ class _Mlp2Fn(torch.autograd.Function):
                                             _lib.stream_ptr(xs.device)), "tzr_mlp2_bwd_parts")
             col = 0
             for t in (dWb, dbb, dWa, dba):
-                _PENDING[t.data_ptr()] = ("rows", (ws,), (G.value, P.value, col), _GENERATION[0], _owner_id(ctx.param_refs))
+                _PENDING[t.data_ptr()] = ("rows", (ws,), (G.value, P.value, col), _GENERATION[0], _owner_id(ctx.param_refs), tuple(id(q) for q in ctx.param_refs))
                 col += t.numel()
             return None, dWa, dba, dWb, dbb
         _lib.check(L.tzr_mlp2_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(hb), hb.stride(0), _lib.ptr(ha), ha.stride(0), _lib.ptr(xs),
@@ -737,7 +749,7 @@ def interaction_top_wgrad(dense: torch.Tensor, sparse: torch.Tensor, D: int, g1:
         _lib.check(L.tzr_dot_interaction_top_wgrad_parts(
             _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
             _lib.ptr(scale), _lib.ptr(ws), ws.numel(), C.byref(blob), _lib.stream_ptr(sparse.device)), "tzr_dot_interaction_top_wgrad_parts")
-        _PENDING[dW.data_ptr()] = ("wgrad", (ws, scale), blob, _GENERATION[0], _owner_id(defer_for))
+        _PENDING[dW.data_ptr()] = ("wgrad", (ws, scale), blob, _GENERATION[0], _owner_id(defer_for), tuple(id(q) for q in defer_for))
         return dW
     _lib.check(L.tzr_dot_interaction_top_wgrad(
         _lib.ptr(dense), dense.stride(0), _lib.ptr(sparse), sparse.stride(0), F, D, B, _lib.ptr(g1), g1.stride(0), H,
@@ -820,7 +832,8 @@ class FusedDenseAdam:
         self._lr_host = float(lr)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        _DEFERRED.difference_update(id(p) for p in self.params)
+        for p in self.params:
+            _DEFERRED.pop(id(p), None)
         for p in self.params:
             if set_to_none:
                 p.grad = None
@@ -862,7 +875,8 @@ class FusedDenseAdam:
                                                        g["lr"], b1, b2, g["eps"], g["weight_decay"], _lib.stream_ptr(self.device)),
                        "tzr_dense_adam_fused")
             del keep
-        _DEFERRED.difference_update(id(p) for p in self.params)
+        for p in self.params:
+            _DEFERRED.pop(id(p), None)
         if any(len(e) > 4 and e[4] == id(self) and e[3] == _GENERATION[0] for e in _PENDING.values()):
             # a backward left a gradient of one of THIS optimizer's parameters as partial sums and the tensor that reached `.grad` is
             # another one (autograd copied it): its parameter was just stepped with unwritten memory.  Never silently.
