@@ -199,3 +199,33 @@ def test_ids_per_key_are_counted_on_the_host_side_of_to():
     # the device copies of key permutations are made once per (permutation, device)
     assert _perm_tensor((2, 0), torch.device("cpu")) is _perm_tensor((2, 0), torch.device("cpu"))
     assert _perm_tensor((2, 0), torch.device("cpu")).tolist() == [2, 0]
+
+
+def test_per_key_uniform_hint_survives_permute_and_moves(dev):
+    """A batch's ONE KeyedJaggedTensor holds sequence keys next to one-id-per-sample keys (tzrec/datasets/data_parser.py:576-585).
+    Built on the host, the keys with exactly one id per bag are noted; `permute` to a subset of them is a uniform
+    KeyedJaggedTensor again (the pooled collection then takes the kernels' one-id-per-bag forms: no host sync for the id count
+    either), a subset with a sequence key is not, and the hint survives `.to()`, `pin_memory`-style copies, `split` and `concat`."""
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    B = 5
+    lens = torch.tensor([1] * B + [2, 0, 3, 1, 4] + [1] * B + [1, 1, 0, 1, 1], dtype=torch.int32)
+    vals = torch.arange(int(lens.sum()), dtype=torch.int64) * 7 + 3
+    k = KeyedJaggedTensor(["a", "seq", "b", "c"], vals, lens)
+    assert k.uniform_length() is None and k._uniform_keys == frozenset({"a", "b"})
+    kd = k.to(dev)
+    assert kd._uniform_keys == frozenset({"a", "b"})
+    p = kd.permute([2, 0])
+    assert p.uniform_length() == 1 and p.keys() == ["b", "a"]
+    assert p.values().cpu().tolist() == vals[B + 10:2 * B + 10].tolist() + vals[:B].tolist()
+    assert p.lengths().cpu().tolist() == [1] * (2 * B)
+    q = kd.permute([0, 1])
+    assert q.uniform_length() is None and q._uniform_keys == frozenset({"a"})
+    r = kd.permute([3, 2])  # "c" has an empty bag: not uniform
+    assert r.uniform_length() is None
+    s0, s1 = k.split([2, 2])
+    assert s0._uniform_keys == frozenset({"a"}) and s1._uniform_keys == frozenset({"b"})
+    cc = KeyedJaggedTensor.concat([s0, s1])
+    assert cc.uniform_length() is None and cc._uniform_keys == frozenset({"a", "b"})
+    allone = KeyedJaggedTensor(["x", "y"], torch.arange(2 * B), torch.ones(2 * B, dtype=torch.int32))
+    assert allone.uniform_length() == 1  # (the global hint as before)

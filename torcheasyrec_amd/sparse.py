@@ -170,11 +170,27 @@ class KeyedJaggedTensor:
         self._length_per_key = list(length_per_key) if length_per_key is not None else None
         # Host-side hint: every bag has exactly this many ids (1 for Criteo).  Known for free when
         # the batch is assembled on CPU (dataloader workers); lets the kernels skip the offsets.
+        # ... and PER KEY (a batch whose one KeyedJaggedTensor holds sequence keys next to one-id-per-sample keys, as tzrec builds
+        # it: data_parser.py:576-585): the keys known to hold exactly one id per bag.  `permute` to a subset of them gives a
+        # uniform KeyedJaggedTensor again -- the pooled collection of such a model then takes the kernels' one-id-per-bag forms.
+        self._uniform_keys: frozenset = frozenset()
         if uniform_length is None and lengths is not None and lengths.device.type == "cpu":
             n = lengths.numel()
             if n > 0 and values.numel() == n and bool((lengths == 1).all()):
                 uniform_length = 1
+            elif n > 0 and self._stride > 0 and n == len(self._keys) * self._stride:
+                ones = (lengths.view(len(self._keys), self._stride) == 1).all(dim=1).tolist()
+                self._uniform_keys = frozenset(k for k, u in zip(self._keys, ones) if u)
         self._uniform_length = uniform_length
+
+    def _carry(self, new: "KeyedJaggedTensor", *others: "KeyedJaggedTensor") -> "KeyedJaggedTensor":
+        """the per-key hint of `self` (and `others`) on a KeyedJaggedTensor derived from them (restricted to its keys)"""
+        hint = set(self._uniform_keys)
+        for o in others:
+            hint |= o._uniform_keys
+        if hint and new._uniform_length is None:
+            new._uniform_keys = frozenset(k for k in new._keys if k in hint)
+        return new
 
     # -- torchrec accessors ----------------------------------------------------------------
     def keys(self) -> List[str]:
@@ -254,10 +270,10 @@ class KeyedJaggedTensor:
         B, opk = self._stride, self.offset_per_key()
         lo, hi = opk[lo_key], opk[hi_key]
         off = None if self._offsets is None else self._offsets[lo_key * B:hi_key * B + 1] - lo
-        return KeyedJaggedTensor(
+        return self._carry(KeyedJaggedTensor(
             self._keys[lo_key:hi_key], self._values[lo:hi], self.lengths()[lo_key * B:hi_key * B],
             None if self._weights is None else self._weights[lo:hi], off, B, self.length_per_key()[lo_key:hi_key],
-            self._uniform_length)
+            self._uniform_length))
 
     def __getitem__(self, key: str) -> JaggedTensor:
         i = self._keys.index(key)
@@ -290,10 +306,16 @@ class KeyedJaggedTensor:
             raise ValueError("concat: either every KeyedJaggedTensor carries weights or none does")
         keys = [x for k in kjt_list for x in k.keys()]
         uni = {k.uniform_length() for k in kjt_list}
-        return KeyedJaggedTensor(
+        out = KeyedJaggedTensor(
             keys, torch.cat([k.values() for k in kjt_list]), torch.cat([k.lengths() for k in kjt_list]),
             torch.cat([k.weights() for k in kjt_list]) if any_w else None, None,
             strides.pop() if strides else 0, None, uni.pop() if len(uni) == 1 else None)
+        if out._uniform_length is None:  # (inputs that are uniform as a whole count key by key)
+            hint = set()
+            for k in kjt_list:
+                hint |= set(k._keys) if k._uniform_length == 1 else set(k._uniform_keys)
+            out._uniform_keys = frozenset(hint)
+        return out
 
     # -- Pipelineable contract (tzrec Batch.to / record_stream, datasets/utils.py:344-408) ----
     def to(self, device, non_blocking: bool = False) -> "KeyedJaggedTensor":
@@ -303,17 +325,17 @@ class KeyedJaggedTensor:
         if self._length_per_key is None and self._values.device.type == "cpu" and torch.device(device).type != "cpu" \
                 and self._lengths is not None:
             self.length_per_key()
-        return KeyedJaggedTensor(
+        return self._carry(KeyedJaggedTensor(
             self._keys, mv(self._values), mv(self._lengths), mv(self._weights), mv(self._offsets),
             self._stride, self._length_per_key, self._uniform_length,
-        )
+        ))
 
     def pin_memory(self) -> "KeyedJaggedTensor":
         pin = lambda t: None if t is None else t.pin_memory()  # noqa: E731
-        return KeyedJaggedTensor(
+        return self._carry(KeyedJaggedTensor(
             self._keys, pin(self._values), pin(self._lengths), pin(self._weights), pin(self._offsets),
             self._stride, self._length_per_key, self._uniform_length,
-        )
+        ))
 
     def record_stream(self, stream) -> None:
         for t in (self._values, self._lengths, self._weights, self._offsets):
@@ -333,7 +355,12 @@ class KeyedJaggedTensor:
         lengths = self.lengths()
         in_off = self.offsets()
         lpk = self._length_per_key
-        if lpk is not None:
+        uni_out = self._uniform_length
+        if uni_out is None and T > 0 and self._uniform_keys and all(self._keys[i] in self._uniform_keys for i in indices):
+            uni_out = 1  # every selected key holds one id per bag (the per-key hint)
+        if uni_out is not None and self._uniform_length is None:
+            n_out = T * B * uni_out
+        elif lpk is not None:
             n_out = int(sum(lpk[i] for i in indices))
         elif self._uniform_length is not None:
             n_out = T * B * self._uniform_length
@@ -356,10 +383,10 @@ class KeyedJaggedTensor:
             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev),
         )
         _lib.check(rc, "tzr_kjt_permute")
-        return KeyedJaggedTensor(
+        return self._carry(KeyedJaggedTensor(
             [self._keys[i] for i in indices], out_values, out_lengths, out_weights, out_offsets, B,
-            None if lpk is None else [lpk[i] for i in indices], self._uniform_length,
-        )
+            None if lpk is None else [lpk[i] for i in indices], uni_out,
+        ))
 
 
 def lengths_to_offsets(lengths: torch.Tensor) -> torch.Tensor:
@@ -450,8 +477,8 @@ class WireKeyedJaggedTensor:
     def pin_memory(self) -> "WireKeyedJaggedTensor":
         k = self._kjt
         pin = lambda t: None if t is None else t.pin_memory()  # noqa: E731
-        meta = KeyedJaggedTensor(k._keys, torch.zeros(0, dtype=torch.int64), pin(k._lengths), pin(k._weights), pin(k._offsets), k._stride,
-                                 k._length_per_key, k._uniform_length)
+        meta = k._carry(KeyedJaggedTensor(k._keys, torch.zeros(0, dtype=torch.int64), pin(k._lengths), pin(k._weights), pin(k._offsets), k._stride,
+                                          k._length_per_key, k._uniform_length))
         meta._values = k._values  # (kept for `widen()` on the host; never copied)
         return WireKeyedJaggedTensor(meta, self._values32.pin_memory())
 
@@ -461,13 +488,13 @@ class WireKeyedJaggedTensor:
             return self.widen()
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)  # noqa: E731
         vals = self._values32.to(device, non_blocking=non_blocking).to(torch.int64)  # widened on the device, behind the copy
-        return KeyedJaggedTensor(k._keys, vals, mv(k._lengths), mv(k._weights), mv(k._offsets), k._stride, k._length_per_key,
-                                 k._uniform_length)
+        return k._carry(KeyedJaggedTensor(k._keys, vals, mv(k._lengths), mv(k._weights), mv(k._offsets), k._stride, k._length_per_key,
+                                          k._uniform_length))
 
     def widen(self) -> "KeyedJaggedTensor":
         k = self._kjt
-        return KeyedJaggedTensor(k._keys, self._values32.to(torch.int64), k._lengths, k._weights, k._offsets, k._stride, k._length_per_key,
-                                 k._uniform_length)
+        return k._carry(KeyedJaggedTensor(k._keys, self._values32.to(torch.int64), k._lengths, k._weights, k._offsets, k._stride,
+                                          k._length_per_key, k._uniform_length))
 
     def record_stream(self, stream) -> None:
         pass  # host tensors only
