@@ -202,6 +202,8 @@ def test_ids_per_key_are_counted_on_the_host_side_of_to():
 
 
 def test_per_key_uniform_hint_survives_permute_and_moves(dev):
+    import torch
+
     """A batch's ONE KeyedJaggedTensor holds sequence keys next to one-id-per-sample keys (tzrec/datasets/data_parser.py:576-585).
     Built on the host, the keys with exactly one id per bag are noted; `permute` to a subset of them is a uniform
     KeyedJaggedTensor again (the pooled collection then takes the kernels' one-id-per-bag forms: no host sync for the id count
@@ -229,3 +231,43 @@ def test_per_key_uniform_hint_survives_permute_and_moves(dev):
     assert cc.uniform_length() is None and cc._uniform_keys == frozenset({"a", "b"})
     allone = KeyedJaggedTensor(["x", "y"], torch.arange(2 * B), torch.ones(2 * B, dtype=torch.int32))
     assert allone.uniform_length() == 1  # (the global hint as before)
+
+
+def test_pooled_collection_takes_the_uniform_prefix_of_a_mixed_batch(dev):
+    """EmbeddingBagCollection on a KeyedJaggedTensor that holds a sequence key BEHIND its own one-id-per-bag keys: it runs on the
+    uniform view of the keys in front (sparse.uniform_prefix: shared storage) -- same pooled rows and the same fused update as on
+    the KeyedJaggedTensor of its keys alone, and the one-id forms are the ones taken (`uniform_length() == 1` reaches the kernels)."""
+    import torch
+
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    B = 64
+    rng = np.random.default_rng(0)
+
+    def build():
+        torch.manual_seed(0)
+        return EmbeddingBagCollection([EmbeddingBagConfig("ta", 16, 500, ["a"]), EmbeddingBagConfig("tb", 16, 40, ["b"])], device=dev,
+                                      optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+
+    ia, ib = rng.integers(0, 500, B), rng.integers(0, 40, B)
+    seq_len = rng.integers(0, 5, B).astype(np.int32)
+    seq = rng.integers(0, 100, int(seq_len.sum()))
+    mixed = KeyedJaggedTensor(["a", "b", "seq"], torch.from_numpy(np.concatenate([ia, ib, seq])),
+                              torch.from_numpy(np.concatenate([np.ones(2 * B, np.int32), seq_len]))).to(dev)
+    own = KeyedJaggedTensor(["a", "b"], torch.from_numpy(np.concatenate([ia, ib])), torch.ones(2 * B, dtype=torch.int32)).to(dev)
+    assert mixed.uniform_length() is None and own.uniform_length() == 1
+    view = mixed.uniform_prefix(["b", "a"])
+    assert view is not None and view.uniform_length() == 1 and view.keys() == ["a", "b"]
+    assert view.values().data_ptr() == mixed.values().data_ptr()
+    assert mixed.uniform_prefix(["a", "seq"]) is None
+    g = torch.randn(B, 32, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = []
+    for kjt in (own, mixed):
+        ebc = build()
+        out = ebc(kjt).values()
+        (out * g).sum().backward()
+        res.append((out.detach().cpu(), {n: w.detach().cpu().clone() for n, w in ebc.table_weights().items()}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n

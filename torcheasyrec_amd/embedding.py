@@ -743,6 +743,12 @@ class EmbeddingBagCollection(nn.Module):
             fn(self, segs, kjt.values(), offsets, kjt.stride(), 1 if uniform else 0)
 
     def _run(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
+        # a batch whose KeyedJaggedTensor holds sequence keys behind this collection's one-id-per-bag keys: the uniform view of
+        # the keys in front (sparse.uniform_prefix) -- the forward's one-id form, the one-launch / cells backward
+        if kjt.uniform_length() is None and getattr(kjt, "_uniform_keys", None):
+            view = kjt.uniform_prefix([lk.key for lk in self._lookups])
+            if view is not None:
+                kjt = view
         if self._lookup_trackers:
             self._notify_trackers(kjt)
         if torch.is_grad_enabled() and self.fused_optimizer is not None and self.training:

@@ -342,6 +342,26 @@ class KeyedJaggedTensor:
             if t is not None and t.is_cuda:
                 t.record_stream(stream)
 
+    def uniform_prefix(self, keys: Sequence[str]) -> Optional["KeyedJaggedTensor"]:
+        """A uniform (one id per bag) VIEW that holds `keys`, or None: when `keys` and every key in front of the last of them are
+        known to hold one id per bag (the per-key hint), the first `last + 1` keys ARE a uniform KeyedJaggedTensor -- key k's ids
+        are values[k B : (k + 1) B] -- sharing this one's storage: no kernel, no copy, no read-back."""
+        if self._uniform_length is not None or not self._uniform_keys or not keys:
+            return None
+        idx = {k: i for i, k in enumerate(self._keys)}
+        if any(k not in idx for k in keys):
+            return None
+        last = max(idx[k] for k in keys)
+        if any(self._keys[i] not in self._uniform_keys for i in range(last + 1)):
+            return None
+        B, n = self._stride, last + 1
+        if self._values.numel() < n * B:
+            return None
+        lengths = None if self._lengths is None else self._lengths[:n * B]
+        offsets = None if self._offsets is None else self._offsets[:n * B + 1]
+        weights = None if self._weights is None else self._weights[:n * B]
+        return KeyedJaggedTensor(self._keys[:n], self._values[:n * B], lengths, weights, offsets, B, [B] * n, 1)
+
     def narrow_ids(self) -> "WireKeyedJaggedTensor":
         """The same ids as int32 for the trip across PCIe (`Batch.narrow_ids`): 4 instead of 8 bytes per id."""
         return WireKeyedJaggedTensor(self)
