@@ -504,6 +504,15 @@ def interaction_top_rooflines(dev, B):
     return out
 
 
+def _emb_calls(ebc, kjt, gbuf):
+    """The C-ABI calls of the embedding path as the training step makes them: the forward (its launch carries the backward's
+    index plan when the batch takes the cells plan: tzr_pooled_fwd_cells_plan), the plan if it did not, the apply."""
+    ebc._launch_forward(kjt, ("sparse",), with_plan=True)
+    if getattr(kjt, "_tzr_plan", None) is None:
+        ebc.plan_backward(kjt, ("sparse",))
+    ebc._launch_backward(kjt, ("sparse",), [gbuf])
+
+
 def pmc_traffic(args, B_local):
     """HBM bytes per step of the six embedding launches from the rocprofv3 PMC passes kept under profiles/
     (FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, scripts/pmc_summary.py).  Counters cannot be read
@@ -1114,25 +1123,25 @@ def main():
         tm = _Timers()
         gbuf = torch.randn(Bl, 26 * 16, device=dev) * 1e-3
         for i in range(max(2, int(24e-3 / (2.5e-9 * max(Bl, 1)))) if not emu else 2):  # (~25 ms of the same work first: the device's clocks)
-            ebc_._launch_forward(kjts[i % len(kjts)], ("sparse",))
-            ebc_.plan_backward(kjts[i % len(kjts)], ("sparse",))
-            ebc_._launch_backward(kjts[i % len(kjts)], ("sparse",), [gbuf])
+            _emb_calls(ebc_, kjts[i % len(kjts)], gbuf)
         torch.cuda.synchronize()
         torch.cuda._sleep(int(2.0e6))
         ebc_._timers = tm
         for i in range(iters):
             k = kjts[i % len(kjts)]
-            ebc_._launch_forward(k, ("sparse",))
-            ebc_.plan_backward(k, ("sparse",))
-            ebc_._launch_backward(k, ("sparse",), [gbuf])
+            _emb_calls(ebc_, k, gbuf)
         torch.cuda.synchronize()
         ebc_._timers = None
         ab = [algorithmic_bytes(hv, Bl, rows, optimizer=optimizer) for hv in host_values]
         nbytes = float(np.mean([a["fwd"] + a["bwd"] for a in ab]))
         stat = tm.mean_ms if iters <= 10 else tm.median_ms  # (long secondary runs: the median, so that a host gap late in the queue does not enter)
         f, p_, a_ = stat("fwd"), stat("plan") or 0.0, stat("apply")  # (no plan launch: tzr_pooled_bwd_direct)
+        fp_ = stat("fwd+plan")  # the forward's launch carried the plan
+        if fp_:
+            f, p_ = fp_, 0.0
         return {"fwd_ms": f, "bwd_plan_ms": p_, "bwd_apply_ms": a_, "algorithmic_bytes": nbytes,
-                "backward": "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else
+                "forward": "tzr_pooled_fwd_cells_plan (the backward's index plan in the forward's launch)" if fp_ else "tzr_pooled_fwd",
+                "backward": "tzr_pooled_bwd_cells_apply (plan: see forward)" if fp_ else "tzr_pooled_bwd_direct (one launch: no index plan)" if not p_ else
                             ("tzr_pooled_bwd_cells_plan (1 launch) + tzr_pooled_bwd_cells_apply" if ebc_.backward_form(kjts[0], ("sparse",)) == "cells"
                              else "tzr_pooled_bwd_plan (4 launches) + tzr_pooled_bwd_apply"),
                 "iterations": iters, "fwd_bwd_GBps": nbytes / ((f + p_ + a_) * 1e-3) / 1e9, "frac_of_8TBps": nbytes / ((f + p_ + a_) * 1e-3) / HBM_PEAK}
@@ -1240,17 +1249,13 @@ def main():
         # clocks come back over ~10 ms of work -- ten timed iterations right away read 5 % long, profiles/r06ah)
         for i in range(150):
             kjt_i = batches[i % nb][1]
-            ebc._launch_forward(kjt_i, ("sparse",))
-            ebc.plan_backward(kjt_i, ("sparse",))
-            ebc._launch_backward(kjt_i, ("sparse",), [gbuf])
+            _emb_calls(ebc, kjt_i, gbuf)
         torch.cuda.synchronize()
         torch.cuda._sleep(int(2.0e6))
         ebc._timers = timers
         for i in range(max(min(args.steps, 40), 20)):
             kjt_i = batches[i % nb][1]
-            ebc._launch_forward(kjt_i, ("sparse",))
-            ebc.plan_backward(kjt_i, ("sparse",))
-            ebc._launch_backward(kjt_i, ("sparse",), [gbuf])
+            _emb_calls(ebc, kjt_i, gbuf)
         torch.cuda.synchronize()
         ebc._timers = None
     ms_per_step = elapsed / args.steps * 1e3
@@ -1312,6 +1317,9 @@ def main():
         fwd_b = float(np.mean([a["fwd"] for a in ab]))
         bwd_b = float(np.mean([a["bwd"] for a in ab]))
         t_fwd, t_plan, t_apply = timers.mean_ms("fwd"), timers.mean_ms("plan") or 0.0, timers.mean_ms("apply")
+        t_fp = timers.mean_ms("fwd+plan")  # the forward's launch carried the backward's index plan (tzr_pooled_fwd_cells_plan)
+        if t_fp:
+            t_fwd, t_plan = t_fp, 0.0
         if t_fwd and t_apply:
             # north star: "HBM-bandwidth roofline on the pooled embedding forward+backward".  Bytes are
             # SURVEY.md 8(d)'s algorithmic figures for THESE batches; the plan moves no algorithmic
@@ -1324,15 +1332,22 @@ def main():
                 return {"stage": name, "kernels": kernels, "launch_ms": ms, "algorithmic_bytes": nbytes,
                         "GBps": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / HBM_PEAK}
 
-            direct = not t_plan  # no plan launch: the one-launch backward of small batches (tzr_pooled_bwd_direct)
+            direct = not t_plan and not t_fp  # no plan launch: the one-launch backward of small batches (tzr_pooled_bwd_direct)
             cells = (not direct) and model.ebc.backward_form(batches[0][1], ("sparse",)) == "cells"  # the one-launch index plan (round 6)
             kind_k = {"adagrad": "adagrad", "rowwise_adagrad": "rowwise", "sgd": "sgd"}.get(args.optimizer)
             apply_k = f"tzr_bwd_reduce_fast_{kind_k}_kernel" if kind_k else "tzr_bwd_reduce_kernel"   # (the optimizer kind is a template parameter)
             cells_k = f"tzr_bwd_cells_apply_{kind_k}_kernel" if kind_k else "tzr_bwd_cells_apply_adam_kernel"
             direct_k = f"tzr_bwd_direct_{kind_k}_kernel" if kind_k else "tzr_bwd_direct_adam_kernel"
             fwd_k = "tzr_pooled_fwd_u1_kernel" if B_local >= 32768 else "tzr_pooled_fwd_kernel"
-            stages = [stage("forward", [fwd_k], fwd_b, t_fwd)]
+            if t_fp:
+                fwd_k = "tzr_pooled_fwd_u1_cells_plan_kernel"
+            stages = [stage("forward" + (" + backward plan (one launch: the plan's workgroups -- every chunk of lookups ordered by bucket in "
+                                         "place -- between the forward's)" if t_fp else ""), [fwd_k], fwd_b, t_fwd)]
             if direct:
+                stages.append(stage("backward (index sort + fused optimizer, one launch)", [direct_k], bwd_b, t_apply))
+            elif t_fp:
+                stages.append(stage("backward apply (units gather their cells, sort them in LDS, reduce, update)", [cells_k], bwd_b, t_apply))
+            elif False:
                 stages.append(stage("backward (index sort + fused optimizer, one launch)", [direct_k], bwd_b, t_apply))
             elif cells:
                 stages += [{"stage": "backward plan (one launch: every chunk of lookups ordered by bucket in place)",
@@ -1345,6 +1360,7 @@ def main():
                            stage("backward apply (+ the LDS sort of every unit of a table without heavy buckets)", [apply_k], bwd_b, t_apply)]
             out["roofline"] = {
                 "bound": "hbm", "kernel": ("pooled embedding forward + backward (" + ("2 launches: " + fwd_k + "; " + direct_k if direct else
+                                           "2 launches: " + fwd_k + "; " + cells_k if t_fp else
                                            ("3 launches: " + fwd_k + "; tzr_bwd_cells_partition_kernel; " + cells_k if cells else
                                             "6 launches: " + fwd_k + "; tzr_bwd_hist/scan/scatter/sort_kernel; " + apply_k)) + ")"),
                 "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,

@@ -33,6 +33,10 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
         ks[k] = {"FETCH_SIZE": fe.get(k), "WRITE_SIZE": wr.get(k)}
     # the forward runs as tzr_pooled_fwd_u1_kernel (ids staged in LDS) at B >= 32768 one-id bags, else tzr_pooled_fwd_kernel
     fwd_name = "tzr_pooled_fwd_u1_kernel" if "tzr_pooled_fwd_u1_kernel" in ks else "tzr_pooled_fwd_kernel"
+    # ... and, in a training step whose backward takes the cells plan, as the launch that carries the plan's workgroups behind its own
+    fused = "tzr_pooled_fwd_u1_cells_plan_kernel"
+    if fused in ks:
+        fwd_name = fused
     if fwd_name in ks:
         e = ks[fwd_name]
         e["traffic_corrected"] = e["FETCH_SIZE"] + 0.5 * 8 * int(n_lookups) + e["WRITE_SIZE"]
@@ -44,7 +48,9 @@ def main(fetch_dir, write_dir, out, n_lookups=26 * 65536):
            "tzr_bwd_sort_kernel", red_name]
     # round 6: batches of one id per bag take the one-launch index plan (csrc/pooled_bwd_cells.hip): THREE launches in all
     cells_apply = next((k for k in ks if k.startswith("tzr_bwd_cells_apply_")), None)
-    if "tzr_bwd_cells_partition_kernel" in ks and cells_apply:
+    if fwd_name == fused and cells_apply:
+        six = [fused, cells_apply]  # TWO launches
+    elif "tzr_bwd_cells_partition_kernel" in ks and cells_apply:
         six = [fwd_name, "tzr_bwd_cells_partition_kernel", cells_apply]
     if all(k in ks for k in six):
         agg = 0.0

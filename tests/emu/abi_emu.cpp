@@ -1,6 +1,6 @@
 // Identity of the CPU lane-emulator build of the kernels (tests only).
 extern "C" const char* tzr_backend(void) { return "emu"; }
-extern "C" int tzr_abi_version(void) { return 14; }
+extern "C" int tzr_abi_version(void) { return 15; }
 
 // The native step driver (csrc/step_driver.hip: host-only code) is compiled into the emulator UNCHANGED: hipGraphLaunch / events /
 // streams are the synchronous shims of tests/emu/hip/hip_runtime.h, RCCL is whatever library `tzr_comm_create` is pointed at

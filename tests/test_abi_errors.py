@@ -59,6 +59,32 @@ def test_pooled_forward_rejects_bad_destinations(dev):
     assert L.tzr_pooled_fwd(p(tables), p(feats), 1, p(slots), 1, None, None, None, 0, d, 1, 1, None) == OK  # empty batch
 
 
+def test_forward_that_carries_the_plan_argument_checks(dev):
+    L = _lib.lib()
+    tables, feats, slots = _buf(dev, 48, torch.uint8), _buf(dev, 64, torch.uint8), _buf(dev, 16, torch.uint8)
+    vals, out = _buf(dev, 4, torch.int64), _buf(dev, 64)
+    d = (_lib.TzrDst * 1)()
+    d[0].ptr, d[0].stride = _lib.ptr(out), 16
+    p = _lib.ptr
+    assert L.tzr_pooled_fwd_cells_plan_supported(104, 65536) == 1 and L.tzr_pooled_fwd_cells_plan_supported(104, 8192) == 0
+    assert L.tzr_pooled_fwd_cells_plan_supported(129, 65536) == 0 and L.tzr_pooled_fwd_cells_plan_supported(0, 65536) == 0
+    args = [p(tables), p(feats), 1, p(slots), 1, d, 1, p(tables), 1, p(feats), 1, 16, p(vals), 4, 4, None, None, None, 0, None]
+    assert L.tzr_pooled_fwd_cells_plan(*args) == UNSUPPORTED  # a batch this small: the two calls
+    bad = list(args)
+    bad[0] = None
+    assert L.tzr_pooled_fwd_cells_plan(*bad) == INVALID
+    assert L.tzr_tune(b"fwd_plan", 0) == OK
+    try:
+        assert L.tzr_pooled_fwd_cells_plan_supported(104, 65536) == 0
+    finally:
+        L.tzr_tune(b"fwd_plan", 1)
+    assert L.tzr_tune(b"fwd_plan", 2) == OK
+    try:
+        assert L.tzr_pooled_fwd_cells_plan(*args) in (INVALID, WORKSPACE)  # supported at any size now: no geometry, no workspace
+    finally:
+        L.tzr_tune(b"fwd_plan", 1)
+
+
 def test_backward_plan_limits(dev):
     L = _lib.lib()
     tables, feats = _buf(dev, 48, torch.uint8), _buf(dev, 64, torch.uint8)

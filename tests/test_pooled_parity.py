@@ -622,3 +622,59 @@ def test_fp16_tables(dev, kind, bwd_path):
             np.testing.assert_allclose(got.numpy(), w, rtol=2e-5, atol=2e-3 * lr)
         if m is not None:
             np.testing.assert_allclose(ebc.table_states()[name].detach().cpu().numpy(), m, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind,B", [("adagrad", 200), ("rowwise_adagrad", 1500), ("sgd", 33)])
+def test_forward_launch_that_carries_the_plan(dev, kind, B, monkeypatch):
+    """tzr_pooled_fwd_cells_plan: the one-id forward and the cells plan of the same batch as ONE launch (forward and partition
+    workgroups alternate in the grid) -- against the oracle like every other form, and bit for bit against the two launches."""
+    from torcheasyrec_amd import _lib
+
+    L = _lib.lib()
+    monkeypatch.setenv("TZR_BWD_PLAN", "cells")
+    assert L.tzr_tune(b"bwd_direct", -1) == 0 and L.tzr_tune(b"fwd_plan", 2) == 0  # (at test sizes: no one-launch backward, any batch size)
+    try:
+        opt = SparseOptimizerConfig(kind=kind, lr=0.05)
+        keys, rows = ["c0", "c1", "c2", "c3"], [5000, 300, 3, 4]
+        made = []
+        real = EmbeddingBagCollection.__init__
+
+        def spy(self, *a, **k):
+            real(self, *a, **k)
+            made.append(self)
+
+        monkeypatch.setattr(EmbeddingBagCollection, "__init__", spy)
+        _run_backward_case(dev, SPEC_CRITEO_SMALL, keys, rows, B, "uniform1", False, opt)
+        assert made and made[0].forward_plans == 2  # both steps
+        monkeypatch.setattr(EmbeddingBagCollection, "__init__", real)
+        # the same two steps with and without: same bits everywhere
+        res = []
+        for carry in (True, False):
+            cfgs, _ = _make_tables(SPEC_CRITEO_SMALL)
+            ebc = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt)
+            ebc.forward_plan = carry
+            rng = np.random.default_rng(11)
+            outs = []
+            for _ in range(2):
+                kd = _make_kjt(keys, rows, B, rng).to(dev)
+                out = ebc(kd).values()
+                g = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).to(dev)
+                (out * g).sum().backward()
+                outs.append(out.detach().cpu())
+            assert ebc.forward_plans == (2 if carry else 0)
+            res.append((outs, {n: w.detach().cpu() for n, w in ebc.table_weights().items()},
+                        {n: (s.detach().cpu() if s is not None else None) for n, s in ebc.table_states().items()}))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a, b)
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), n
+            if res[0][2].get(n) is not None:
+                assert torch.equal(res[0][2][n], res[1][2][n]), n
+        # an evaluation forward (no backward follows) stays the plain launch
+        ebc.forward_plan = True
+        with torch.no_grad():
+            ebc(kd)
+        assert ebc.forward_plans == 0
+    finally:
+        L.tzr_tune(b"bwd_direct", 0)
+        L.tzr_tune(b"fwd_plan", 1)

@@ -24,7 +24,7 @@ POOL_SUM, POOL_MEAN = 0, 1
 DT_F32, DT_F16 = 0, 1
 FWD_MIXED_DTYPE = 1
 OPT_SGD, OPT_ADAGRAD, OPT_ROWWISE_ADAGRAD, OPT_ACCUMULATE, OPT_ADAM = 0, 1, 2, 3, 4
-ABI_VERSION = 14  # struct layouts below match include/tzrec_hip.h of this version
+ABI_VERSION = 15  # struct layouts below match include/tzrec_hip.h of this version
 WD_NONE, WD_L2, WD_DECOUPLE = 0, 1, 2
 BOUNDS_FATAL, BOUNDS_WARNING, BOUNDS_IGNORE = 0, 1, 2
 
@@ -158,6 +158,8 @@ _SIGNATURES = {
                                     _vp]),
     "tzr_bwd_cells_geometry": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _sz, C.POINTER(C.c_int64)]),
     "tzr_pooled_bwd_cells_plan": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "tzr_pooled_fwd_cells_plan_supported": (_i32, [_i32, _i64]),
+    "tzr_pooled_fwd_cells_plan": (_i32, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "tzr_pooled_bwd_cells_apply": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _i32, C.POINTER(TzrDst), _i32,
                                           C.POINTER(TzrSparseOptim), _vp, _vp, _vp, _sz, _vp]),
     "tzr_dense_adam_fused": (_i32, [C.POINTER(TzrAdamTensor), C.POINTER(TzrAdamSource), _i32, C.POINTER(TzrWgradParts), _vp, C.c_float,

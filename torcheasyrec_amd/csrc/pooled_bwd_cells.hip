@@ -8,6 +8,8 @@
 // fp32 rounding, and each is bit-reproducible: a function of the ids alone (tests/test_pooled_parity.py: bwd_path "cells").
 #include <tzr_gfx950.h>
 
+#include "pooled_fwd_u1.h"
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -282,11 +284,11 @@ extern "C" int tzr_bwd_cells_geometry(const TzrTable* h_tables, int n_tables, co
 // ------------------------------------------------------------------------------------------------------------------------
 // partition: every chunk ordered by bucket in place + its bucket starts.  No workgroup talks to another.
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
-    BwdCellsView V, const TzrTable* __restrict__ tables, BwdSrcArgs A, uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch) {
+__device__ __forceinline__ void bwd_cells_partition_body(const BwdCellsView& V, const TzrTable* __restrict__ tables, const BwdSrcArgs& A,
+                                                         uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch, unsigned chunk) {
   __shared__ BwdRankLds<BWD_NB> L;
   __shared__ uint2 stage[BWD_CH];
-  const BwdCellChunk cd = V.chunks[blockIdx.x];
+  const BwdCellChunk cd = V.chunks[chunk];
   if (cd.t < 0) return;
   const int n = (int)(cd.e - cd.s);
   const int lane = threadIdx.x & (TZR_WAVE - 1);
@@ -341,6 +343,58 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
   __syncthreads();
   uint2* out = slab + cd.s;
   for (int i = threadIdx.x; i < n; i += BWD_THREADS) out[i] = stage[i];  // one coalesced 8-byte store per lookup
+}
+
+__global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
+    BwdCellsView V, const TzrTable* __restrict__ tables, BwdSrcArgs A, uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch) {
+  bwd_cells_partition_body(V, tables, A, slab, bnd, ch, blockIdx.x);
+}
+
+// The plan in the FORWARD's launch.  The partition needs the ids and nothing else, and what it does with them is LDS and ALU work
+// (rank 1 024 lookups by bucket, 16 bytes of HBM traffic per lookup) while the one-id forward next to it is bound by the rate of its
+// 64-byte row requests: as a launch of its own the plan is 12 us of the step in which HBM idles; as a second stream inside the step's
+// graph it costs more than it hides (fork + join: +10 us, scripts/r06/gpu_async_plan.sh).  Here the two kinds of workgroup share
+// one grid, chosen by the workgroup index alone.  Measured at B = 65 536 (step, driver flags, profiles/r06au): the plan's
+// workgroups BEHIND the forward's -3.5 us (they fill the slots the forward's last workgroups leave), in front of them -2,
+// alternating with them +13 -- the forward is bound by its resident waves (98 registers: four workgroups per CU), and every slot a
+// partition workgroup holds is one fewer gather stream in flight.
+static_assert(FWD_THREADS == BWD_THREADS, "one workgroup size for both kinds");
+struct FwdPlanArgs {
+  const TzrTable* ftables;
+  const TzrFeature* ffeats;
+  const TzrSlot* slots;
+  const int64_t* values;
+  int64_t B;
+  int32_t n_slots, tile_b;
+  uint32_t n_fwd, n_part;
+  const TzrTable* btables;
+  uint2* slab;
+  uint16_t* bnd;
+  int32_t ch, order;
+};
+
+__global__ __launch_bounds__(BWD_THREADS) void tzr_pooled_fwd_u1_cells_plan_kernel(FwdPlanArgs a, FwdDsts dsts, BwdCellsView V, BwdSrcArgs A) {
+  const uint32_t i = blockIdx.x;
+  const uint32_t both = 2u * min(a.n_fwd, a.n_part);
+  bool part;
+  uint32_t idx;
+  if (a.order == 1) {  // the plan's workgroups first
+    part = i < a.n_part;
+    idx = part ? i : i - a.n_part;
+  } else if (a.order == 2) {  // ... last
+    part = i >= a.n_fwd;
+    idx = part ? i - a.n_fwd : i;
+  } else if (i < both) {
+    part = (i & 1u) != 0u;
+    idx = i >> 1;
+  } else {
+    part = a.n_part > a.n_fwd;
+    idx = i - (both >> 1);
+  }
+  if (part)  // (workgroup-uniform)
+    bwd_cells_partition_body(V, a.btables, A, a.slab, a.bnd, a.ch, idx);
+  else
+    fwd_u1_body(a.ftables, a.ffeats, a.slots, a.n_slots, a.values, a.B, a.tile_b, dsts, idx, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -874,6 +928,69 @@ extern "C" int tzr_pooled_bwd_cells_plan(const TzrTable* d_tables, int n_tables,
   A.uniform = 1;
   hipLaunchKernelGGL(tzr_bwd_cells_partition_kernel, dim3((unsigned)g.n_chunks), dim3(BWD_THREADS), 0, static_cast<hipStream_t>(stream), V,
                      d_tables, A, P.ks[1], reinterpret_cast<uint16_t*>(P.hist), (int)g.ch);
+  TZR_CHECK_LAUNCH();
+  return TZR_OK;
+}
+
+// tzr_pooled_fwd (one id per bag, fp32 tables, unweighted: what tzr_pooled_fwd_ex sends to its LDS-ids kernel) and
+// tzr_pooled_bwd_cells_plan of the same batch as ONE launch.  TZR_ERR_UNSUPPORTED: not that case (the caller makes the two calls).
+extern int g_tzr_fwd_tile_b;
+int g_tzr_fwd_plan_order = 2;  // tzr_tune("fwd_plan_order"): 0 = alternating, 1 = the plan's workgroups first, 2 = last (measured: see the kernel)
+int g_tzr_fwd_plan = 1;  // tzr_tune("fwd_plan"): 0 = never (tzr_pooled_fwd_cells_plan_supported says no), 2 = at any batch size (tests)
+
+extern "C" int tzr_pooled_fwd_cells_plan_supported(int n_slots, int64_t B) {
+  // (batch sizes at which tzr_pooled_fwd_ex takes its LDS-ids kernel: smaller ones run the general kernel, and mostly the one-launch backward)
+  return (g_tzr_fwd_plan != 0 && n_slots > 0 && n_slots <= FWD1_SLOTS && B > 0 && (B >= 32768 || g_tzr_fwd_plan == 2)) ? 1 : 0;
+}
+
+extern "C" int tzr_pooled_fwd_cells_plan(const TzrTable* d_ftables, const TzrFeature* d_ffeats, int n_ffeats, const TzrSlot* d_slots,
+                                         int n_slots, const TzrDst* h_dsts, int n_dst, const TzrTable* d_tables, int n_tables,
+                                         const TzrFeature* d_feats, int n_feats, int max_dim, const int64_t* d_values, int64_t n_values,
+                                         int64_t B, const void* h_geo, void* d_geo, void* ws, size_t ws_bytes, void* stream) {
+  if (!d_ftables || !d_ffeats || !d_slots || !h_dsts || n_ffeats <= 0 || n_slots <= 0 || n_dst <= 0 || n_dst > TZR_MAX_DST ||
+      !d_tables || !d_feats || n_tables <= 0 || n_feats <= 0 || n_values < 0 || B <= 0)
+    return TZR_ERR_INVALID;
+  if (!tzr_pooled_fwd_cells_plan_supported(n_slots, B)) return TZR_ERR_UNSUPPORTED;
+  BwdCellsGeo g;
+  BwdCellsView V;
+  BwdPlan P;
+  const int rc = cells_common(h_geo, d_geo, ws, ws_bytes, n_values, n_feats, n_tables, max_dim, &g, &V, &P);
+  if (rc != TZR_OK) return rc;
+  if (!d_values) return TZR_ERR_INVALID;
+  if (n_values >= (1LL << 32)) return TZR_ERR_UNSUPPORTED;
+  FwdDsts dsts;
+  for (int i = 0; i < TZR_MAX_DST; ++i) {
+    dsts.d[i].ptr = 0;
+    dsts.d[i].stride = 0;
+  }
+  for (int i = 0; i < n_dst; ++i) {
+    if (!h_dsts[i].ptr || (h_dsts[i].stride & 3) || (h_dsts[i].ptr & 15)) return TZR_ERR_INVALID;
+    if (h_dsts[i].stride > 0x7fffffffLL) return TZR_ERR_UNSUPPORTED;
+    dsts.d[i] = h_dsts[i];
+  }
+  BwdSrcArgs A;
+  A.feats = d_feats;
+  A.values = d_values;
+  A.offsets = nullptr;
+  A.B = B;
+  A.uniform = 1;
+  FwdPlanArgs a;
+  a.ftables = d_ftables;
+  a.ffeats = d_ffeats;
+  a.slots = d_slots;
+  a.values = d_values;
+  a.B = B;
+  a.n_slots = n_slots;
+  a.tile_b = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 32 : (B >= 8192 ? 16 : 8));
+  a.n_fwd = (uint32_t)((B + a.tile_b - 1) / a.tile_b);
+  a.n_part = (uint32_t)g.n_chunks;
+  a.btables = d_tables;
+  a.slab = P.ks[1];
+  a.bnd = reinterpret_cast<uint16_t*>(P.hist);
+  a.ch = (int)g.ch;
+  a.order = g_tzr_fwd_plan_order;
+  hipLaunchKernelGGL(tzr_pooled_fwd_u1_cells_plan_kernel, dim3(a.n_fwd + a.n_part), dim3(BWD_THREADS), 0, static_cast<hipStream_t>(stream),
+                     a, dsts, V, A);
   TZR_CHECK_LAUNCH();
   return TZR_OK;
 }

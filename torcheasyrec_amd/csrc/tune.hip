@@ -15,6 +15,8 @@ extern int g_tzr_bwd_no_fuse_sort;
 extern int g_tzr_bwd_scan_slices;
 extern int g_tzr_bwd_direct_ch;
 extern int g_tzr_bwd_direct;
+extern int g_tzr_fwd_plan;
+extern int g_tzr_fwd_plan_order;
 extern int g_tzr_bwd_direct_debug;
 extern int g_tzr_bwd_direct_hot;
 extern int g_tzr_ia_bwd_plain;
@@ -49,6 +51,14 @@ extern "C" int tzr_tune(const char* name, int value) {
   }
   if (!strcmp(name, "bwd_apply_waves")) {
     g_tzr_bwd_apply_waves = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "fwd_plan_order")) {
+    g_tzr_fwd_plan_order = value;
+    return TZR_OK;
+  }
+  if (!strcmp(name, "fwd_plan")) {
+    g_tzr_fwd_plan = value;
     return TZR_OK;
   }
   if (!strcmp(name, "bwd_direct")) {

@@ -249,7 +249,7 @@ def mask_frozen_descriptors(tables: np.ndarray, feats: np.ndarray, frozen: Seque
 class _PooledLookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ebc, kjt, dst_names, hook):  # hook: zero-size tensor that requires grad
-        outs = ebc._launch_forward(kjt, dst_names)
+        outs = ebc._launch_forward(kjt, dst_names, with_plan=True)
         ctx.ebc, ctx.kjt, ctx.dst_names = ebc, kjt, dst_names
         return tuple(outs)
 
@@ -325,6 +325,10 @@ class EmbeddingBagCollection(nn.Module):
         # whenever other kernels of the main stream ran next to it, while the same kernels in ONE stream
         # were right in 220 of 220 (NOTES.md "side-stream plan"); and the plan is ~60 us of a step now.
         self.async_plan = False
+        # ... what does pay: the plan's workgroups INSIDE the forward's launch (tzr_pooled_fwd_cells_plan; batches of one id per bag
+        # that take the cells plan).  TZR_FWD_PLAN=0: the two launches.
+        self.forward_plan = os.environ.get("TZR_FWD_PLAN", "1") != "0"
+        self.forward_plans = 0  # launches that carried a plan
         # a row with more lookups than a workgroup's LDS holds is expected (the shared row of a zero-collision hash's unseen ids, a
         # default id): the one-launch backward then lets all of a table's workgroups sum such a row (TZR_GRAD_HOT_ROWS,
         # include/tzrec_hip.h); zch.ManagedCollisionEmbeddingBagCollection sets it
@@ -537,7 +541,19 @@ class EmbeddingBagCollection(nn.Module):
         offsets = None if uniform else kjt.offsets()
         return uniform, offsets
 
-    def _launch_forward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...]) -> List[torch.Tensor]:
+    def _forward_carries_plan(self, kjt: KeyedJaggedTensor, meta: _Meta) -> Optional["_CellsGeo"]:
+        """The cells geometry when this batch's forward can carry the backward's index plan in its launch
+        (tzr_pooled_fwd_cells_plan: one id per bag, fp32 tables, no per-sample weights, a batch the cells plan takes)."""
+        if not self.forward_plan or self._has_fp16 or kjt.uniform_length() != 1 or kjt.weights_or_none() is not None:
+            return None
+        if getattr(kjt, "_tzr_plan", None) is not None or self.backward_is_direct(kjt):
+            return None
+        if not _lib.lib().tzr_pooled_fwd_cells_plan_supported(len(meta.slots_np), kjt.stride()):
+            return None
+        return self._cells_for(kjt, meta)
+
+    def _launch_forward(self, kjt: KeyedJaggedTensor, dst_names: Tuple[str, ...], with_plan: bool = False) -> List[torch.Tensor]:
+        """`with_plan`: a backward of this batch follows (the autograd node's forward): the launch may carry its index plan."""
         layout = self._layout_for(dst_names)
         meta = self._meta(kjt.keys(), layout)
         B = kjt.stride()
@@ -548,6 +564,26 @@ class EmbeddingBagCollection(nn.Module):
         for i, o in enumerate(outs):
             dsts[i].ptr = _lib.ptr(o)
             dsts[i].stride = o.stride(0)
+        geo = self._forward_carries_plan(kjt, meta) if with_plan else None
+        if geo is not None:
+            L = _lib.lib()
+            N = kjt.values().numel()
+            max_dim = self._bwd_dims()[1]
+            ws = _lib.workspace(L.tzr_pooled_bwd_workspace(N, self._n_positions(kjt), len(self._lookups), len(self._configs), B, max_dim),
+                                self._device)
+            ev = self._timers.start("fwd+plan") if self._timers is not None else None
+            rc = L.tzr_pooled_fwd_cells_plan(
+                _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), _lib.ptr(meta.d_slots), len(meta.slots_np), dsts,
+                len(outs), _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), max_dim,
+                _lib.ptr(kjt.values()), N, B, geo.h_ptr, _lib.ptr(geo.d_img), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device))
+            if ev is not None:
+                ev.record()
+            _lib.check(rc, "tzr_pooled_fwd_cells_plan")
+            if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                ws.record_stream(torch.cuda.current_stream(self._device))
+            kjt._tzr_plan = (id(self), dst_names, ws, None, geo)  # type: ignore[attr-defined]
+            self.forward_plans += 1
+            return outs
         ev = self._timers.start("fwd") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_fwd_ex(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
