@@ -31,7 +31,8 @@ def main():
     import bench
 
     bench.enable_tunable_gemm()  # the unfused GEMMs as the step runs them
-    _lib.use_library(_build.build())
+    # IT_LIB: a variant build (scripts/r06/build_variant.py) instead of the product library
+    _lib.use_library(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), os.environ["IT_LIB"]) if os.environ.get("IT_LIB") else _build.build())
     L = _lib.lib()
     dev = torch.device("cuda", 0)
     D, F, H = 16, 26, 64

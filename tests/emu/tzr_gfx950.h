@@ -14,6 +14,7 @@ inline uint32_t tzr_arrive(uint32_t* counter) { return __atomic_fetch_add(counte
 #define TZR_WAVES_PER_EU(n)
 inline void tzr_lds_barrier() { __syncthreads(); }
 #define TZR_OPAQUE(x) ((void)(x))
+inline void tzr_prio_by_slot(unsigned) {}  // (scheduling only)
 inline float tzr_relu(float x) { return x > 0.f ? x : 0.f; }  // (a register-allocation hint: nothing to emulate)
 inline float tzr_ldg(const float* p) { return *p; }
 inline void tzr_stg(float* p, float v) { *p = v; }

@@ -828,6 +828,13 @@ __device__ __forceinline__ void bwd_cells_apply_body(
     return;
   }
   CELLS_MARK(0);
+#ifndef CELLS_NO_PRIO
+  // The seven units a CU holds start together and would stay in lock step (their lookups, their LDS sorts, their gathers all at the
+  // same moments: profiles/r06g); wave priorities by residency slot -- workgroup i shares its CU with i +- 256 k -- let them drift
+  // apart, so that one unit's gathers are in flight while another sorts (apply 90.9 -> 86.8 us, same box: profiles/r06av; letting
+  // the slots 4 .. 6, which repeat the priorities 0 .. 2, sleep 1.7 us first: 86.0, 3.4 us: 87.8 -- not kept).
+  tzr_prio_by_slot(blockIdx.x);
+#endif
   const BwdCellUnit u = V.units[blockIdx.x];
   const uint32_t epoch = V.overflow[BWD_CELLS_OVF_EPOCH];  // (constant during a launch; loaded with the unit)
   const int lane = threadIdx.x & (TZR_WAVE - 1);

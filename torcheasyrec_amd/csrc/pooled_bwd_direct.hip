@@ -645,11 +645,14 @@ __device__ __forceinline__ void bwd_direct_body(
   }
 }
 
+// (wave priorities by residency slot, tzr_gfx950.h: the four workgroups of a CU out of lock step: 36.0 -> 34.5 us at B = 8 192,
+// profiles/r06av; the same in the exact plan's apply: 76.5 -> 79.2 us, in the cells partition: 14.9 -> 15.9 -- not there)
 #define BWD_DIRECT_KERNEL(NAME, ADAM_, WAVES, NT_, FK_)                                                                      \
   __global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(WAVES) void NAME(                                        \
       const TzrTable* __restrict__ tables, int T, const TzrFeature* __restrict__ feats, int F, BwdSrcArgs A,         \
       const float* __restrict__ weights, int grad_mode, BwdGrads Gr, BwdOpt opt, int ch,                             \
       uint32_t* __restrict__ wcount, float* __restrict__ wpart, int max_dim) {                                       \
+    tzr_prio_by_slot(blockIdx.x);                                                                                    \
     bwd_direct_body<ADAM_, NT_, FK_>(tables, T, feats, F, A, weights, grad_mode, Gr, opt, ch, wcount, wpart, max_dim);    \
   }
 // 4 waves per SIMD (128 VGPRs): 1 024 workgroups resident = the whole grid of an 8 192-per-rank step at once (at 3 waves,

@@ -51,6 +51,19 @@ __device__ __forceinline__ void tzr_lds_barrier() { asm volatile("s_waitcnt lgkm
 // reload inside the loop comes with s_waitcnt vmcnt(0), which also waits for every prefetch in flight.
 #define TZR_OPAQUE(x) asm volatile("" : "+v"(x))
 
+// Wave priority of a workgroup by the residency slot it will take: with a grid of `per_round` workgroups resident at once per
+// round-robin pass of the dispatcher (256 CUs), workgroup i shares its CU with i +- 256 k.  Co-resident workgroups that start
+// together and run the same phases otherwise stay in lock step -- every one of them waiting on memory, then every one sorting in
+// LDS; different priorities let them drift apart (measured on the cells apply: pooled_bwd_cells.hip).
+__device__ __forceinline__ void tzr_prio_by_slot(unsigned block) {
+  switch ((block >> 8) & 3u) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+}
+
 // max(x, 0) as ONE instruction (fmaxf is two: it quiets a signalling NaN first; a NaN comes out as 0 here)
 __device__ __forceinline__ float tzr_relu(float x) {
   float y;
