@@ -11,7 +11,7 @@ R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 if [ -z "${SKIP_TESTS:-}" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
 fi
-timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/bench.json
+: > $O/bench.err
 if [ -z "${SKIP_EXTRA:-}" ]; then
 timeout 300 python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_b8192.json 2>> $O/bench.err; echo "bench b8192 rc=$?"
 timeout 300 python bench.py --optimizer rowwise_adagrad --no-cpu-baseline --no-e2e > $O/bench_rowwise_adagrad.json 2>> $O/bench.err; echo "bench rowwise rc=$?"
@@ -43,6 +43,9 @@ if [ -z "${SKIP_PMC:-}" ]; then
 python scripts/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json
 [ -z "${SKIP_MFMA:-}" ] && { python scripts/pmc_mfma_summary.py $O/pmc_mfma $O/pmc_mfma.json || tail -5 $O/pmc_mfma.log; }
 fi
+# the default line LAST: `roofline.traffic` is read from profiles/r*/pmc_traffic.json of this library digest -- the file just made
+if [ -z "${SKIP_PMC:-}" ] && [ -f $O/pmc_traffic.json ]; then mkdir -p profiles/$TAG; cp $O/pmc_traffic.json profiles/$TAG/; fi
+timeout 1200 python bench.py > $O/bench.json 2>> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/bench.json
 S=$(find $O/trace -name '*kernel_stats.csv' | head -1); cp "$S" $O/kernel_stats.csv
 grep tzr_ $O/kernel_stats.csv | cut -c1-60,200-400 | head -24
 rm -rf $O/trace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
