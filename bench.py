@@ -112,6 +112,7 @@ def parse_args():
     ap.add_argument("--delta-tracker", action="store_true",
                     help="experiment: record every lookup in the delta-embedding tracker (tzr_delta_mark inside the step); off by default")
     ap.add_argument("--tune", action="append", default=[], help="name=value passed to tzr_tune")
+    ap.add_argument("--lib", default=None, help="experiments: file name of a variant build under torcheasyrec_amd/ instead of the product library")
     ap.add_argument("--emulator", action="store_true",
                     help="CPU plumbing check of the N-rank launch path: kernels through the lane emulator (tests/emu), gloo "
                          "instead of RCCL, tables capped (--rows-cap, default 2000), no graphs / e2e / secondary readings.  "
@@ -692,7 +693,8 @@ def main():
         _lib.use_library(build_emu())
         assert _lib.backend() == "emu"
     else:
-        _lib.use_library(_build.build())
+        # (--lib: a variant build for same-box A/B, scripts/r06/build_variant.py; its numbers are experiments, never the contract line)
+        _lib.use_library(os.path.join(ROOT, "torcheasyrec_amd", args.lib) if args.lib else _build.build())
         assert _lib.backend() == "hip-gfx950"
     if not args.no_tunable_gemm and not emu:
         enable_tunable_gemm()

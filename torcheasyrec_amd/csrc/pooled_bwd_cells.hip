@@ -284,10 +284,16 @@ extern "C" int tzr_bwd_cells_geometry(const TzrTable* h_tables, int n_tables, co
 // ------------------------------------------------------------------------------------------------------------------------
 // partition: every chunk ordered by bucket in place + its bucket starts.  No workgroup talks to another.
 // ------------------------------------------------------------------------------------------------------------------------
+struct BwdPartLds {  // 13.3 KB
+  BwdRankLds<BWD_NB> L;
+  uint2 stage[BWD_CH];
+};
+
 __device__ __forceinline__ void bwd_cells_partition_body(const BwdCellsView& V, const TzrTable* __restrict__ tables, const BwdSrcArgs& A,
-                                                         uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch, unsigned chunk) {
-  __shared__ BwdRankLds<BWD_NB> L;
-  __shared__ uint2 stage[BWD_CH];
+                                                         uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch, unsigned chunk,
+                                                         BwdPartLds& PL) {
+  auto& L = PL.L;
+  auto& stage = PL.stage;
   const BwdCellChunk cd = V.chunks[chunk];
   if (cd.t < 0) return;
   const int n = (int)(cd.e - cd.s);
@@ -347,7 +353,8 @@ __device__ __forceinline__ void bwd_cells_partition_body(const BwdCellsView& V, 
 
 __global__ __launch_bounds__(BWD_THREADS) void tzr_bwd_cells_partition_kernel(
     BwdCellsView V, const TzrTable* __restrict__ tables, BwdSrcArgs A, uint2* __restrict__ slab, uint16_t* __restrict__ bnd, int ch) {
-  bwd_cells_partition_body(V, tables, A, slab, bnd, ch, blockIdx.x);
+  __shared__ BwdPartLds PL;
+  bwd_cells_partition_body(V, tables, A, slab, bnd, ch, blockIdx.x, PL);
 }
 
 // The plan in the FORWARD's launch.  The partition needs the ids and nothing else, and what it does with them is LDS and ALU work
@@ -373,7 +380,25 @@ struct FwdPlanArgs {
   int32_t ch, order;
 };
 
-__global__ __launch_bounds__(BWD_THREADS) void tzr_pooled_fwd_u1_cells_plan_kernel(FwdPlanArgs a, FwdDsts dsts, BwdCellsView V, BwdSrcArgs A) {
+// Residency: the two kinds of workgroup share ONE LDS area (the larger: 22.8 KB) and the forward keeps 4 gathers in flight per
+// thread instead of 8 (52 registers), so that SEVEN workgroups fit a CU instead of four.  The forward alone does not care (49.6-54.9
+// us at every residency, profiles/r06j); the pair does: forward + plan 58.4-59.4 us at 4 workgroups / 8 gathers, 56.0-56.5 at 5 / 8,
+// 54.3-55.3 at 6 or 7 / 4 (profiles/r06aw).  Tiles of 64 samples (1 024 forward workgroups: all resident at once, the plan's
+// workgroups start in the slots beside them): 52.0-53.1 against 55.2 at 32; 72 / 78 / 96 / 128: 56-60.
+#ifndef FWD_PLAN_WAVES
+#define FWD_PLAN_WAVES 7
+#endif
+#ifndef FWD_PLAN_UNROLL
+#define FWD_PLAN_UNROLL 4
+#endif
+union FwdPlanLds {  // (one kind of workgroup or the other: the larger of the two, so that LDS does not bound residency)
+  Fwd1Lds f;
+  BwdPartLds p;
+};
+
+__global__ __launch_bounds__(BWD_THREADS) TZR_WAVES_PER_EU(FWD_PLAN_WAVES) void tzr_pooled_fwd_u1_cells_plan_kernel(FwdPlanArgs a, FwdDsts dsts,
+                                                                                                          BwdCellsView V, BwdSrcArgs A) {
+  __shared__ FwdPlanLds S;
   const uint32_t i = blockIdx.x;
   const uint32_t both = 2u * min(a.n_fwd, a.n_part);
   bool part;
@@ -392,9 +417,9 @@ __global__ __launch_bounds__(BWD_THREADS) void tzr_pooled_fwd_u1_cells_plan_kern
     idx = i - (both >> 1);
   }
   if (part)  // (workgroup-uniform)
-    bwd_cells_partition_body(V, a.btables, A, a.slab, a.bnd, a.ch, idx);
+    bwd_cells_partition_body(V, a.btables, A, a.slab, a.bnd, a.ch, idx, S.p);
   else
-    fwd_u1_body(a.ftables, a.ffeats, a.slots, a.n_slots, a.values, a.B, a.tile_b, dsts, idx, 0u);
+    fwd_u1_body<FWD_PLAN_UNROLL>(a.ftables, a.ffeats, a.slots, a.n_slots, a.values, a.B, a.tile_b, dsts, idx, 0u, S.f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -831,9 +856,11 @@ __device__ __forceinline__ void bwd_cells_apply_body(
 #ifndef CELLS_NO_PRIO
   // The seven units a CU holds start together and would stay in lock step (their lookups, their LDS sorts, their gathers all at the
   // same moments: profiles/r06g); wave priorities by residency slot -- workgroup i shares its CU with i +- 256 k -- let them drift
-  // apart, so that one unit's gathers are in flight while another sorts (apply 90.9 -> 86.8 us, same box: profiles/r06av; letting
-  // the slots 4 .. 6, which repeat the priorities 0 .. 2, sleep 1.7 us first: 86.0, 3.4 us: 87.8 -- not kept).
+  // apart, so that one unit's gathers are in flight while another sorts (apply 90.9 -> 86.8 us, same box: profiles/r06av)
   tzr_prio_by_slot(blockIdx.x);
+  // ... and the slots 4 .. 6, which repeat the priorities 0 .. 2, start 64 x 64 clocks (~1.7 us) late: 87.2 -> 86.2 us (five same-box
+  // pairs, profiles/r06av); 0.85 us: nothing; every slot k x 0.4 / 0.2 us late: 88.9 / 90.3.
+  if ((blockIdx.x >> 8) >= 4u) __builtin_amdgcn_s_sleep(64);
 #endif
   const BwdCellUnit u = V.units[blockIdx.x];
   const uint32_t epoch = V.overflow[BWD_CELLS_OVF_EPOCH];  // (constant during a launch; loaded with the unit)
@@ -988,7 +1015,7 @@ extern "C" int tzr_pooled_fwd_cells_plan(const TzrTable* d_ftables, const TzrFea
   a.values = d_values;
   a.B = B;
   a.n_slots = n_slots;
-  a.tile_b = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 32 : (B >= 8192 ? 16 : 8));
+  a.tile_b = g_tzr_fwd_tile_b > 0 ? g_tzr_fwd_tile_b : (B >= 32768 ? 64 : (B >= 8192 ? 16 : 8));  // (64: see the kernel)
   a.n_fwd = (uint32_t)((B + a.tile_b - 1) / a.tile_b);
   a.n_part = (uint32_t)g.n_chunks;
   a.btables = d_tables;

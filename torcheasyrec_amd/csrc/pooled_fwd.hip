@@ -182,7 +182,8 @@ __global__ __launch_bounds__(FWD_THREADS) FWD1_WAVES_ATTR void tzr_pooled_fwd_u1
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
     int tile_b, FwdDsts dsts) {
-  fwd_u1_body(tables, feats, slots, n_slots, values, B, tile_b, dsts, blockIdx.x, blockIdx.y);
+  __shared__ Fwd1Lds S;
+  fwd_u1_body<FWD1_UNROLL>(tables, feats, slots, n_slots, values, B, tile_b, dsts, blockIdx.x, blockIdx.y, S);
 }
 
 // flags: TZR_FWD_MIXED_DTYPE = some table holds fp16 rows (TzrTable.w_dtype is honoured); without it

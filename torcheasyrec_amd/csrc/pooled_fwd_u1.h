@@ -36,19 +36,31 @@ struct Fwd1Slot {  // 24 bytes
 #define FWD_PROF_MARK(i)
 #endif
 
-// workgroup (bx, by) of the grid (tiles of `tile_b` samples, rows of FWD1_SLOTS slots)
+struct Fwd1Lds {  // 22.8 KB
+  Fwd1Slot rs[FWD1_SLOTS];
+  int64_t srows[FWD1_SLOTS];   // per slot, then compacted per id group
+  int32_t sfeat[FWD1_SLOTS];   // KJT key index, same
+  int64_t grows[FWD1_SLOTS];
+  int32_t gfeat[FWD1_SLOTS];
+  uint16_t gid[FWD1_SLOTS];    // id group of a slot (consecutive slots of one key share it)
+  int64_t sid[FWD1_MAX_IDS];
+  uint32_t wsum[FWD_THREADS / TZR_WAVE];
+};
+
+// workgroup (bx, by) of the grid (tiles of `tile_b` samples, rows of FWD1_SLOTS slots); UNR gathers in flight per thread
+template <int UNR>
 __device__ __forceinline__ void fwd_u1_body(
     const TzrTable* __restrict__ tables, const TzrFeature* __restrict__ feats,
     const TzrSlot* __restrict__ slots, int n_slots, const int64_t* __restrict__ values, int64_t B,
-    int tile_b, FwdDsts dsts, unsigned bx, unsigned by) {
-  __shared__ Fwd1Slot rs[FWD1_SLOTS];
-  __shared__ int64_t srows[FWD1_SLOTS];   // per slot, then compacted per id group
-  __shared__ int32_t sfeat[FWD1_SLOTS];   // KJT key index, same
-  __shared__ int64_t grows[FWD1_SLOTS];
-  __shared__ int32_t gfeat[FWD1_SLOTS];
-  __shared__ uint16_t gid[FWD1_SLOTS];    // id group of a slot (consecutive slots of one key share it)
-  __shared__ int64_t sid[FWD1_MAX_IDS];
-  __shared__ uint32_t wsum[FWD_THREADS / TZR_WAVE];
+    int tile_b, const FwdDsts& dsts, unsigned bx, unsigned by, Fwd1Lds& S) {
+  auto& rs = S.rs;
+  auto& srows = S.srows;
+  auto& sfeat = S.sfeat;
+  auto& grows = S.grows;
+  auto& gfeat = S.gfeat;
+  auto& gid = S.gid;
+  auto& sid = S.sid;
+  auto& wsum = S.wsum;
   static_assert(FWD1_SLOTS <= FWD_THREADS, "one slot per thread in the prologue");
   const int s0 = by * FWD1_SLOTS;
   const int ns = min(FWD1_SLOTS, n_slots - s0);
@@ -119,15 +131,15 @@ __device__ __forceinline__ void fwd_u1_body(
     __syncthreads();
     FWD_PROF_MARK(2);  // the tile's ids in LDS
     const int total = cnt * ns;
-    for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * FWD1_UNROLL) {
+    for (int k0 = threadIdx.x; k0 < total; k0 += FWD_THREADS * UNR) {
       // No lane-dependent condition around the LDS reads and the row loads (an element behind the tile's last repeats it
       // and is not stored): `if (ok) acc = load(...)` is a branch per element to hipcc, and the slot / id reads inside it were
       // waited for one element at a time -- eight "independent" gathers issued as a chain.
-      float* dp[FWD1_UNROLL];
-      const float* wp[FWD1_UNROLL];
-      float4 acc[FWD1_UNROLL];
+      float* dp[UNR];
+      const float* wp[UNR];
+      float4 acc[UNR];
 #pragma unroll
-      for (int u = 0; u < FWD1_UNROLL; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         int k = k0 + u * FWD_THREADS;
         k = k < total ? k : total - 1;
         int bl = (int)__umulhi((uint32_t)k, magic);
@@ -139,9 +151,9 @@ __device__ __forceinline__ void fwd_u1_body(
         wp[u] = r.w + id * (int64_t)r.w_stride;
       }
 #pragma unroll
-      for (int u = 0; u < FWD1_UNROLL; ++u) acc[u] = tzr_ldg4(wp[u]);
+      for (int u = 0; u < UNR; ++u) acc[u] = tzr_ldg4(wp[u]);
 #pragma unroll
-      for (int u = 0; u < FWD1_UNROLL; ++u)
+      for (int u = 0; u < UNR; ++u)
         if (k0 + u * FWD_THREADS < total) tzr_stg4(dp[u], acc[u]);
     }
   }
