@@ -670,6 +670,23 @@ def test_forward_launch_that_carries_the_plan(dev, kind, B, monkeypatch):
             assert torch.equal(res[0][1][n], res[1][1][n]), n
             if res[0][2].get(n) is not None:
                 assert torch.equal(res[0][2][n], res[1][2][n]), n
+        # a forward whose backward never ran leaves a plan behind; the ids are then refreshed IN PLACE (a static input buffer): the
+        # next forward of the same object plans again instead of handing the stale plan to its backward
+        cfgs, _ = _make_tables(SPEC_CRITEO_SMALL)
+        e1 = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt)
+        e2 = EmbeddingBagCollection(cfgs, device=dev, optimizer=opt)
+        rng = np.random.default_rng(5)
+        k1 = _make_kjt(keys, rows, B, rng).to(dev)
+        fresh = _make_kjt(keys, rows, B, rng).to(dev)
+        e1(k1)  # (plan made, never consumed)
+        assert k1._tzr_plan is not None
+        k1.values().copy_(fresh.values())
+        g = torch.from_numpy(rng.standard_normal((B, 64)).astype(np.float32)).to(dev)
+        (e1(k1).values() * g).sum().backward()
+        (e2(fresh).values() * g).sum().backward()
+        assert e1.forward_plans == 2
+        for n in e1.table_weights():
+            assert torch.equal(e1.table_weights()[n].cpu(), e2.table_weights()[n].cpu()), n
         # an evaluation forward (no backward follows) stays the plain launch
         ebc.forward_plan = True
         with torch.no_grad():

@@ -546,7 +546,11 @@ class EmbeddingBagCollection(nn.Module):
         (tzr_pooled_fwd_cells_plan: one id per bag, fp32 tables, no per-sample weights, a batch the cells plan takes)."""
         if not self.forward_plan or self._has_fp16 or kjt.uniform_length() != 1 or kjt.weights_or_none() is not None:
             return None
-        if getattr(kjt, "_tzr_plan", None) is not None or self.backward_is_direct(kjt):
+        cached = getattr(kjt, "_tzr_plan", None)
+        if cached is not None and not (len(cached) > 5 and cached[5] == "forward"):
+            return None  # planned ahead by the caller (plan_backward / plan_backward_async): that plan is the batch's
+        # (a plan left by an earlier forward of this object whose backward never ran is dropped: the ids may have been refreshed in place)
+        if self.backward_is_direct(kjt):
             return None
         if not _lib.lib().tzr_pooled_fwd_cells_plan_supported(len(meta.slots_np), kjt.stride()):
             return None
@@ -581,7 +585,7 @@ class EmbeddingBagCollection(nn.Module):
             _lib.check(rc, "tzr_pooled_fwd_cells_plan")
             if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
                 ws.record_stream(torch.cuda.current_stream(self._device))
-            kjt._tzr_plan = (id(self), dst_names, ws, None, geo)  # type: ignore[attr-defined]
+            kjt._tzr_plan = (id(self), dst_names, ws, None, geo, "forward")  # type: ignore[attr-defined]
             self.forward_plans += 1
             return outs
         ev = self._timers.start("fwd") if self._timers is not None else None
