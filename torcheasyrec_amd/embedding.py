@@ -580,14 +580,17 @@ class EmbeddingBagCollection(nn.Module):
                 _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups), _lib.ptr(meta.d_slots), len(meta.slots_np), dsts,
                 len(outs), _lib.ptr(meta.d_bwd_tables), len(self._configs), _lib.ptr(meta.d_bwd_feats), len(self._lookups), max_dim,
                 _lib.ptr(kjt.values()), N, B, geo.h_ptr, _lib.ptr(geo.d_img), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(self._device))
-            if ev is not None:
-                ev.record()
-            _lib.check(rc, "tzr_pooled_fwd_cells_plan")
-            if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-                ws.record_stream(torch.cuda.current_stream(self._device))
-            kjt._tzr_plan = (id(self), dst_names, ws, None, geo, "forward")  # type: ignore[attr-defined]
-            self.forward_plans += 1
-            return outs
+            if rc != -4:  # (TZR_ERR_UNSUPPORTED: nothing was launched -- the two calls, as below)
+                if ev is not None:
+                    ev.record()
+                _lib.check(rc, "tzr_pooled_fwd_cells_plan")
+                if self._device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                    ws.record_stream(torch.cuda.current_stream(self._device))
+                kjt._tzr_plan = (id(self), dst_names, ws, None, geo, "forward")  # type: ignore[attr-defined]
+                self.forward_plans += 1
+                return outs
+            if self._timers is not None:
+                self._timers.pairs["fwd+plan"].pop()
         ev = self._timers.start("fwd") if self._timers is not None else None
         rc = _lib.lib().tzr_pooled_fwd_ex(
             _lib.ptr(meta.d_tables), _lib.ptr(meta.d_feats), len(self._lookups),
