@@ -357,9 +357,10 @@ int tzr_pooled_bwd_cells_plan(const TzrTable* d_tables, int n_tables, const TzrF
                               size_t ws_bytes, void* stream);
 /* The forward and the cells plan of the SAME batch as one launch: tzr_pooled_fwd (one id per bag, fp32 tables, no per-sample
  * weights; d_ftables / d_ffeats / d_slots / h_dsts as there) + tzr_pooled_bwd_cells_plan (the other arguments as there).  The
- * plan needs only the ids, and its work is LDS / ALU work next to a forward bound by the rate of its 64-byte row requests, so
- * the two kinds of workgroup alternate in one grid; results are those of the two calls, bit for bit (each workgroup runs the
- * same code on the same data).  tzr_pooled_fwd_cells_plan_supported == 0 / TZR_ERR_UNSUPPORTED: not a case for it (more than
+ * plan needs only the ids, and its work is LDS / ALU work while the forward is bound by its 64-byte row requests: the plan's
+ * workgroups follow the forward's in ONE grid and run in the slots those leave (seven workgroups of either kind per CU), which
+ * hides all but ~2 us of the plan's 15; results are those of the two calls, bit for bit (each workgroup runs the same code on
+ * the same data).  tzr_pooled_fwd_cells_plan_supported == 0 / TZR_ERR_UNSUPPORTED: not a case for it (more than
  * 128 slots, B < 32 768, tzr_tune "fwd_plan" 0) -- make the two calls.  In the reference both halves sit behind self.ebc(kjt)
  * and its autograd (tzrec/modules/embedding.py:930; fbgemm's transpose_embedding_input runs at backward time). */
 int tzr_pooled_fwd_cells_plan_supported(int n_slots, int64_t B);
