@@ -188,3 +188,28 @@ def test_adagrad_values_at_full_size(kind, dist):
             assert bool((m_err <= m_bound).all()), f"step {step} {n}: state err {float((m_err - m_bound).max())} over the bound"
             # and nothing else moved: a sample of untouched rows is bit-identical (small tables: all of them)
         del out
+
+
+def test_forward_that_carries_the_plan_at_full_size():
+    """tzr_pooled_fwd_cells_plan at BASELINE's size (1 024 forward workgroups + 1 757 partition workgroups in one grid, seven per
+    CU): outputs, table rows and Adagrad state after two steps equal the two launches' bit for bit."""
+    res = []
+    for carry in (True, False):
+        ebc, kjt, B, dev = _setup("adagrad", 0.05)
+        ebc.forward_plan = carry
+        outs = []
+        for s in range(2):
+            out = ebc.forward_grouped(kjt)["sparse"]
+            g = torch.randn(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + s))
+            (out * g).sum().backward()
+            outs.append(out.detach().clone())
+        assert ebc.forward_plans == (2 if carry else 0)
+        assert ebc.backward_form(kjt, ("sparse",)) == "cells"
+        res.append((outs, ebc))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    wa, wb = res[0][1].table_weights(), res[1][1].table_weights()
+    sa, sb = res[0][1].table_states(), res[1][1].table_states()
+    for n in wa:
+        assert torch.equal(wa[n].detach(), wb[n].detach()), n
+        assert torch.equal(sa[n].detach(), sb[n].detach()), n
