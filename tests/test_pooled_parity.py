@@ -695,3 +695,55 @@ def test_forward_launch_that_carries_the_plan(dev, kind, B, monkeypatch):
     finally:
         L.tzr_tune(b"bwd_direct", 0)
         L.tzr_tune(b"fwd_plan", 1)
+
+
+def test_forward_that_carries_the_plan_with_a_frozen_table_and_what_it_declines(dev, monkeypatch):
+    """A frozen table: the forward reads it (forward descriptors), the plan in the same launch leaves it out (backward descriptors) --
+    same bits as the two launches.  Per-sample weights, half-precision tables, jagged bags: the forward goes out on its own."""
+    from torcheasyrec_amd import _lib
+    from torcheasyrec_amd.embedding import EmbeddingBagCollection, EmbeddingBagConfig, SparseOptimizerConfig
+    from torcheasyrec_amd.sparse import KeyedJaggedTensor
+
+    L = _lib.lib()
+    monkeypatch.setenv("TZR_BWD_PLAN", "cells")
+    assert L.tzr_tune(b"bwd_direct", -1) == 0 and L.tzr_tune(b"fwd_plan", 2) == 0
+    try:
+        rng = np.random.default_rng(3)
+        B, rows = 300, [40, 7, 3000]
+        ids = np.stack([rng.integers(0, r, size=B) for r in rows]).astype(np.int64)
+        kjt = KeyedJaggedTensor(["a", "b", "c"], torch.from_numpy(ids.reshape(-1)), torch.ones(3 * B, dtype=torch.int32)).to(dev)
+        g = torch.randn(B, 24, generator=torch.Generator().manual_seed(1)).to(dev)
+        res = []
+        for carry in (True, False):
+            torch.manual_seed(0)
+            ebc = EmbeddingBagCollection(
+                [EmbeddingBagConfig("ta", 8, rows[0], ["a"]), EmbeddingBagConfig("tb", 8, rows[1], ["b"], trainable=False),
+                 EmbeddingBagConfig("tc", 8, rows[2], ["c"])], device=dev, optimizer=SparseOptimizerConfig(kind="adagrad", lr=0.1))
+            ebc.forward_plan = carry
+            before_tb = ebc.table_weights()["tb"].detach().clone()
+            out = ebc(kjt).values()
+            (out * g).sum().backward()
+            assert ebc.forward_plans == (1 if carry else 0)
+            assert torch.equal(ebc.table_weights()["tb"].detach(), before_tb)  # frozen: never written
+            res.append((out.detach().cpu(), {n: w.detach().cpu().clone() for n, w in ebc.table_weights().items()}))
+        assert torch.equal(res[0][0], res[1][0])
+        for n in res[0][1]:
+            assert torch.equal(res[0][1][n], res[1][1][n]), n
+        # what the launch does not take
+        opt = SparseOptimizerConfig(kind="adagrad", lr=0.1)
+        half = EmbeddingBagCollection([EmbeddingBagConfig("h", 8, 40, ["a"], data_type="FP16")], device=dev, optimizer=opt)
+        ka = KeyedJaggedTensor(["a"], torch.from_numpy(ids[0]), torch.ones(B, dtype=torch.int32)).to(dev)
+        half(ka).values().sum().backward()
+        assert half.forward_plans == 0
+        plain = EmbeddingBagCollection([EmbeddingBagConfig("p", 8, 40, ["a"])], device=dev, optimizer=opt)
+        kw = KeyedJaggedTensor(["a"], torch.from_numpy(ids[0]), torch.ones(B, dtype=torch.int32), weights=torch.rand(B)).to(dev)
+        plain(kw).values().sum().backward()
+        lens = rng.integers(0, 3, size=B).astype(np.int32)
+        kj = KeyedJaggedTensor(["a"], torch.from_numpy(rng.integers(0, 40, size=int(lens.sum())).astype(np.int64)), torch.from_numpy(lens)).to(dev)
+        plain(kj).values().sum().backward()
+        assert plain.forward_plans == 0
+        plain(ka).values().sum().backward()
+        assert plain.forward_plans == 1
+    finally:
+        L.tzr_tune(b"bwd_direct", 0)
+        L.tzr_tune(b"fwd_plan", 1)
